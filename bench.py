@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: overfit iters/sec on synthetic F-frame H×W video.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = what ModelWrapperOverfit.training_step + backward do per optimisation
+iteration (model_wrapper_overfit.py:51-62): explicit-depth backbone ->
+regressed intrinsics -> unproject -> Procrustes extrinsics -> flow loss -> backward to
+(depth, weight logits, focal length).  No optimiser step, exactly like the CPU baseline
+in BASELINE.md.  Workload at N=1: BASELINE.json configs[1] (150 frames @ 720x1280, flow
+loss only, Procrustes P=1000), inputs resident in HBM.  For N>1 every rank owns its own
+150-frame shard of a longer video (weak scaling; frame pairs shard with a one-frame
+halo), with one packed all-reduce of the shared-intrinsics gradient + loss and a halo
+exchange of the boundary frame's depth gradient over RCCL.
+
+Prints ONE JSON line (rank 0) carrying `roofline` for the fused flow kernel (HIP-event
+timed on its launch stream inside the timed region) and `cpu_baseline` (the oracle — a
+PyTorch-CPU port of the reference path — timed on a bounded sample of the same workload).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=150)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--points", type=int, default=1000, help="Procrustes points (config/model/extrinsics/procrustes.yaml:3)")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--items-per-thread", type=int, default=0)
+    return ap.parse_args()
+
+
+def make_inputs(f, h, w, device, seed):
+    """i.i.d. synthetic inputs of BASELINE.md §2, generated directly in HBM."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    depth = 1.10 + 0.05 * torch.rand((f, h, w), device=device, generator=g)
+    wlogit = 0.01 * torch.randn((f - 1, h, w), device=device, generator=g)
+    from flowmap_amd import Flows
+
+    flows = Flows(
+        0.01 * torch.randn((1, f - 1, h, w, 2), device=device, generator=g),
+        0.01 * torch.randn((1, f - 1, h, w, 2), device=device, generator=g),
+        torch.rand((1, f - 1, h, w), device=device, generator=g),
+        torch.rand((1, f - 1, h, w), device=device, generator=g),
+    )
+    return depth, wlogit, flows
+
+
+def cpu_baseline(frames, h, w, points, iters):
+    """The oracle (PyTorch CPU port of the reference path) on a bounded sample: same
+    frame size, fewer frames; forward + backward, all host cores."""
+    from oracle import flowmap_oracle as orc
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    depth, wlogit, flows = orc.synth_iid(frames, h, w, seed=0)
+    depth.requires_grad_(True)
+    wlogit.requires_grad_(True)
+    focal = torch.tensor(0.85, requires_grad=True)
+
+    def step():
+        for p in (depth, wlogit, focal):
+            p.grad = None
+        total, _, _ = orc.explicit_depth_step(depth, wlogit, focal, flows, (h, w), num_points=points)
+        total.backward()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return dt, cores
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import flowmap_amd
+    from flowmap_amd import Batch, _ops
+    from flowmap_amd.loss import LossFlow, LossFlowCfg
+    from flowmap_amd.loss.mapping import MappingHuberCfg
+    from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
+    from flowmap_amd.sharding import FrameShard
+
+    f, h, w = args.frames, args.height, args.width
+    flowmap_amd.set_lazy_surfaces(True)
+    depth, wlogit, flows = make_inputs(f, h, w, device, seed=1 + rank)
+    cfg = ModelCfg(
+        BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
+        IntrinsicsRegressedCfg("regressed", 0.85),
+        ExtrinsicsProcrustesCfg("procrustes", args.points, False),
+    )
+    model = Model(cfg, num_frames=f, image_shape=(h, w)).to(device)
+    model.backbone.depth.data = depth
+    model.backbone.weights.data = wlogit
+    batch = Batch(torch.zeros((1, f, 3, 1, 1), device=device).expand(1, f, 3, h, w))
+    loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
+    if args.items_per_thread:
+        loss_fn.items_per_thread = args.items_per_thread
+    shard = FrameShard(rank, world, dist)
+    shard.prepare_flow_loss(loss_fn, flows)  # global valid-sum (one-time all-reduce)
+
+    kernel_events = []
+    _ops.flow_kernel_events = kernel_events  # (start, end) per fused-kernel launch
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = model(batch, flows, 0)
+        loss = loss_fn(batch, flows, None, out, 0)
+        loss.backward()
+        shard.sync(loss, model.intrinsics.focal_length, model.backbone.depth)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    kernel_events.clear()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms = sum(s.elapsed_time(e) for s, e in kernel_events) / max(len(kernel_events), 1)
+    n = h * w
+    algo_bytes = n * (8 * f + 24 * (f - 1))  # B_flow per launch
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        result = {
+            "metric": "overfit iters/sec (150 frames @ 720p) at 1/2/4/8 MI355X; final ATE vs ref",
+            "value": world * args.steps / elapsed,
+            "unit": "iters/sec (one iter = fwd+bwd over one 150-frame shard; aggregate over GPUs)",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE.json configs[1]: {f} frames @ {h}x{w}, flow loss only (huber 0.01, weight 1000), "
+                f"explicit-depth backbone, regressed intrinsics, Procrustes P={args.points}; fwd+bwd, no optimiser",
+                "frames_per_gpu": f,
+                "height": h,
+                "width": w,
+                "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU",
+                "loss": float(loss.item()),
+            },
+            "roofline": {
+                "kernel": "fm::flow_fused_kernel<4,true>",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel_ms": kernel_ms,
+                "launches_timed": len(kernel_events),
+            },
+        }
+        if world == 1 and args.cpu_frames >= 2:
+            dt, cores = cpu_baseline(args.cpu_frames, h, w, args.points, args.cpu_iters)
+            scaled = dt * (f - 1) / (args.cpu_frames - 1)  # per-pair cost is constant (optimistic for the CPU)
+            result["cpu_baseline"] = {
+                "value": 1.0 / scaled,
+                "unit": "iters/sec",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"oracle (PyTorch-CPU port of the reference path), {args.cpu_frames} frames @ {h}x{w}, fwd+bwd, "
+                f"{args.cpu_iters} timed iters after 1 warm-up: {dt:.3f} s/iter, scaled by pairs ({f - 1}/{args.cpu_frames - 1}) "
+                f"to {f} frames",
+                "sample_seconds_per_iter": dt,
+            }
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

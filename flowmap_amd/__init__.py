@@ -1,0 +1,22 @@
+"""flowmap_amd — MI355X-native (gfx950) implementation of FlowMap's per-iteration
+reprojection / flow-consistency inner loop behind the reference's Python call surface.
+
+    flowmap_amd.model.projection   <-> flowmap/model/projection.py
+    flowmap_amd.model.procrustes   <-> flowmap/model/procrustes.py
+    flowmap_amd.loss               <-> flowmap/loss/**
+    flowmap_amd.install()          rebinds an importable reference ``flowmap`` package
+                                   to these implementations
+
+All arithmetic runs in hand-written HIP kernels (flowmap_amd/csrc) loaded from
+libflowmap_hip.so through ctypes; there is no CPU or eager fallback.
+"""
+
+from . import loss, model  # noqa: F401
+from .install import install, uninstall  # noqa: F401
+from .model.projection import set_lazy_surfaces  # noqa: F401
+from .types import BackboneOutput, Batch, Flows, ModelOutput, Tracks  # noqa: F401
+
+__all__ = [
+    "loss", "model", "install", "uninstall", "set_lazy_surfaces",
+    "Batch", "BackboneOutput", "Flows", "ModelOutput", "Tracks",
+]

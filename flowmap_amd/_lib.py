@@ -1,0 +1,143 @@
+"""ctypes binding of libflowmap_hip.so (the C ABI declared in include/flowmap_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``flowmap_amd.build``.
+There is NO fallback: if the shared object is missing or a call reports a non-zero
+status, a RuntimeError is raised.  ``set_library_for_testing`` exists so the CPU test
+suite can inject tests/host_sim's serial build of the same math; the product never
+selects it on its own.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+from typing import Optional
+
+import torch  # noqa: F401  (imported first so our .so binds to torch's libamdhip64)
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libflowmap_hip.so"
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+L = ctypes.c_long
+F = ctypes.c_float
+
+# name -> argtypes, in the order of include/flowmap_hip.h
+SIGNATURES = {
+    "fm_flow_loss_fused": [P] * 10 + [I, I, I, I, I, F, F, F, P, P, I, P],
+    "fm_flow_loss_finalize": [P] * 5 + [I, I] + [P] * 4 + [P],
+    "fm_flow_valid_norm": [P, P, L, F, P, P, P],
+    "fm_scale_if_needed": [P, L, P, P],
+    "fm_procrustes_stats": [P] * 6 + [L, I, I, I, I, P, P],
+    "fm_pose_solve": [P, I, P, P, P, P],
+    "fm_pose_solve_bwd": [P, P, P, P, I, P, P],
+    "fm_procrustes_scatter": [P] * 6 + [L, I, I, I, I] + [P] * 6 + [P],
+    "fm_pose_chain_fwd": [P, I, I, P, P],
+    "fm_pose_chain_bwd": [P, P, P, I, I, P, P],
+    "fm_relative_pose_fwd": [P, I, I, P, P, P],
+    "fm_relative_pose_bwd": [P, P, P, I, I, P, P],
+    "fm_allpairs_pose_fwd": [P, I, I, P, P],
+    "fm_allpairs_pose_bwd": [P, P, I, I, P, P],
+    "fm_intrinsics_inverse": [P, I, P, P],
+    "fm_intrinsics_inverse_bwd": [P, P, I, P, I, P],
+    "fm_unproject_fwd": [P, L, P, P, I, L, P, P],
+    "fm_unproject_bwd": [P, L, P, P, P, I, L, P, P, P],
+    "fm_reproject_fwd": [P, P, P, I, L, P, P],
+    "fm_reproject_bwd": [P, P, P, P, I, L, P, P, P, P, P],
+    "fm_bilinear_sample_fwd": [P, P, I, I, I, I, L, P, P],
+    "fm_bilinear_sample_bwd": [P, P, I, I, I, I, L, P, P],
+    "fm_mapping_fwd": [P, P, L, I, F, F, F, P, P],
+    "fm_mapping_bwd": [P, P, P, L, I, F, F, F, P, P, P],
+    "fm_align_rigid_stats": [P, P, P, I, L, P, P],
+    "fm_align_rigid_bwd": [P, P, P, I, L, P, P, P, P, P, P],
+}
+
+_lib: Optional[ctypes.CDLL] = None
+_lib_is_test_double = False
+
+
+def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue  # checked by tests/test_abi.py; calling a missing symbol raises below
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    return lib
+
+
+def library() -> ctypes.CDLL:
+    """Return the loaded native library, loading libflowmap_hip.so on first use."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  flowmap_amd has no CPU or eager fallback."
+            )
+        _lib = _bind(ctypes.CDLL(str(LIB_PATH)))
+    return _lib
+
+
+def set_library_for_testing(path: Optional[os.PathLike]) -> None:
+    """Inject a different build of the same C ABI (tests only), or reset with None."""
+    global _lib, _lib_is_test_double
+    if path is None:
+        _lib, _lib_is_test_double = None, False
+    else:
+        _lib, _lib_is_test_double = _bind(ctypes.CDLL(str(path))), True
+
+
+def using_test_double() -> bool:
+    return _lib_is_test_double
+
+
+def ptr(t) -> Optional[int]:
+    """Device (or host, for the test double) address of a tensor; None -> NULL."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_for(t: torch.Tensor) -> Optional[int]:
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return None
+
+
+def check_device(*tensors) -> torch.device:
+    """All tensors must live on one device; CUDA(HIP) unless the test double is active."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"flowmap_amd: tensors on different devices ({dev} vs {t.device})")
+    if dev is None:
+        raise RuntimeError("flowmap_amd: no tensor arguments")
+    if dev.type != "cuda" and not _lib_is_test_double:
+        raise RuntimeError(
+            f"flowmap_amd: tensors are on {dev}; the HIP path needs a GPU (device 'cuda' on ROCm). "
+            "There is no CPU fallback."
+        )
+    if dev.type == "cuda" and _lib_is_test_double:
+        raise RuntimeError("flowmap_amd: the host test double cannot take GPU tensors")
+    return dev
+
+
+_STATUS = {1: "invalid argument", 2: "HIP launch/runtime failure"}
+
+
+def call(name: str, *args) -> None:
+    lib = library()
+    fn = getattr(lib, name, None)
+    if fn is None:
+        raise RuntimeError(f"flowmap_amd: native symbol {name} is not exported by the loaded library")
+    status = fn(*args)
+    if status != 0:
+        raise RuntimeError(f"flowmap_amd: {name} failed: {_STATUS.get(status, status)}")

@@ -1,0 +1,532 @@
+"""torch.autograd.Function wrappers around the C ABI (include/flowmap_hip.h).
+
+These are the differentiable building blocks the reference-shaped call surface
+(flowmap_amd.model.projection, flowmap_amd.loss) is assembled from.  Every Function
+launches hand-written HIP kernels on the current stream through ctypes; none of them
+synchronises the device or falls back to eager PyTorch math.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import call, check_device, ptr, stream_for
+
+MAPPING_KINDS = {"huber": 0, "l1": 1, "l2": 2}
+
+FLOW_ACC_STRIDE = 20
+STAT_STRIDE = 16
+AUX_STRIDE = 32
+PAIR_GRAD_STRIDE = 20
+
+
+def _f32c(t: Tensor, what: str) -> Tensor:
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"flowmap_amd: {what} must be float32 (got {t.dtype})")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _guard:
+    """Select the tensor's GPU for the launches inside (no-op for the host test double)."""
+
+    def __init__(self, dev: torch.device):
+        self.ctx = torch.cuda.device(dev) if dev.type == "cuda" else None
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
+def intrinsics_inverse(k: Tensor) -> Tensor:
+    """K⁻¹ for a (..., 3, 3) stack (no autograd; callers chain the backward)."""
+    k = _f32c(k, "intrinsics")
+    out = torch.empty_like(k)
+    with _guard(k.device):
+        call("fm_intrinsics_inverse", ptr(k), k.numel() // 9, ptr(out), stream_for(k))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Pose plumbing
+# --------------------------------------------------------------------------------------
+
+
+class PoseChain(torch.autograd.Function):
+    """get_extrinsics (flowmap/model/projection.py:187-210)."""
+
+    @staticmethod
+    def forward(ctx, rel: Tensor) -> Tensor:
+        check_device(rel)
+        rel = _f32c(rel, "relative transformations")
+        *batch, steps, _, _ = rel.shape
+        nb = 1
+        for d in batch:
+            nb *= d
+        ext = torch.empty((*batch, steps + 1, 4, 4), dtype=torch.float32, device=rel.device)
+        with _guard(rel.device):
+            call("fm_pose_chain_fwd", ptr(rel), nb, steps, ptr(ext), stream_for(rel))
+        ctx.save_for_backward(rel, ext)
+        ctx.nb, ctx.steps = nb, steps
+        return ext
+
+    @staticmethod
+    def backward(ctx, g_ext: Tensor):
+        rel, ext = ctx.saved_tensors
+        g_ext = _f32c(g_ext, "grad")
+        g_rel = torch.empty_like(rel)
+        with _guard(rel.device):
+            call("fm_pose_chain_bwd", ptr(rel), ptr(ext), ptr(g_ext), ctx.nb, ctx.steps, ptr(g_rel), stream_for(rel))
+        return g_rel
+
+
+class RelativePoses(torch.autograd.Function):
+    """later(E).inverse() @ earlier(E) and earlier(E).inverse() @ later(E)
+    (flowmap/model/projection.py:154,176).  extrinsics (B,F,4,4) -> two (B,F-1,4,4)."""
+
+    @staticmethod
+    def forward(ctx, ext: Tensor):
+        check_device(ext)
+        ext = _f32c(ext, "extrinsics")
+        b, f = ext.shape[:2]
+        fwd = torch.empty((b, f - 1, 4, 4), dtype=torch.float32, device=ext.device)
+        bwd = torch.empty_like(fwd)
+        with _guard(ext.device):
+            call("fm_relative_pose_fwd", ptr(ext), b, f, ptr(fwd), ptr(bwd), stream_for(ext))
+        ctx.save_for_backward(ext)
+        return fwd, bwd
+
+    @staticmethod
+    def backward(ctx, g_fwd: Optional[Tensor], g_bwd: Optional[Tensor]):
+        (ext,) = ctx.saved_tensors
+        b, f = ext.shape[:2]
+        g_fwd = None if g_fwd is None else _f32c(g_fwd, "grad")
+        g_bwd = None if g_bwd is None else _f32c(g_bwd, "grad")
+        g_ext = torch.empty_like(ext)
+        with _guard(ext.device):
+            call("fm_relative_pose_bwd", ptr(ext), ptr(g_fwd), ptr(g_bwd), b, f, ptr(g_ext), stream_for(ext))
+        return g_ext
+
+
+class AllPairsPoses(torch.autograd.Function):
+    """extrinsics_target.inverse() @ extrinsics_source for all (source, target) pairs
+    (flowmap/model/projection.py:288).  (B,f,4,4) -> (B,f,f,4,4) indexed [b, src, tgt]."""
+
+    @staticmethod
+    def forward(ctx, ext: Tensor):
+        check_device(ext)
+        ext = _f32c(ext, "extrinsics")
+        b, f = ext.shape[:2]
+        rel = torch.empty((b, f, f, 4, 4), dtype=torch.float32, device=ext.device)
+        with _guard(ext.device):
+            call("fm_allpairs_pose_fwd", ptr(ext), b, f, ptr(rel), stream_for(ext))
+        ctx.save_for_backward(ext)
+        return rel
+
+    @staticmethod
+    def backward(ctx, g_rel: Tensor):
+        (ext,) = ctx.saved_tensors
+        b, f = ext.shape[:2]
+        g_rel = _f32c(g_rel, "grad")
+        g_ext = torch.empty_like(ext)
+        with _guard(ext.device):
+            call("fm_allpairs_pose_bwd", ptr(ext), ptr(g_rel), b, f, ptr(g_ext), stream_for(ext))
+        return g_ext
+
+
+# --------------------------------------------------------------------------------------
+# Procrustes fit of adjacent frames
+# --------------------------------------------------------------------------------------
+
+
+def _find_fit_node(t: Tensor, depth_key, max_depth: int = 4):
+    """Walk up the autograd graph from a pose tensor looking for the ProcrustesFit node
+    that produced it from the SAME depth tensor (see "carried depth gradient" below)."""
+    start = t.grad_fn
+    if start is None:
+        return None
+    frontier = [start]
+    for _ in range(max_depth):
+        nxt = []
+        for node in frontier:
+            if getattr(node, "_fm_fit_depth_key", None) == depth_key:
+                return node
+            nxt.extend(fn for fn, _ in getattr(node, "next_functions", ()) if fn is not None)
+        frontier = nxt
+        if not frontier:
+            break
+    return None
+
+
+class ProcrustesFit(torch.autograd.Function):
+    """align_surfaces up to (not including) the pose chain (projection.py:213-249) with
+    align_rigid (procrustes.py:7-51) inside.  Source of xyz is either
+
+      depth (B,F,H,W) + intrinsics (B,F,3,3)   [surfaces never materialised], or
+      surfaces (B,F,H,W,3).
+
+    Returns the "inverse relative transformations" (B,F-1,4,4): later -> earlier camera.
+    """
+
+    @staticmethod
+    def forward(ctx, depth, k, surfaces, weights, bwd_flow, indices):
+        from_depth = surfaces is None
+        check_device(depth if from_depth else surfaces, weights, bwd_flow, indices)
+        weights = _f32c(weights, "weights")
+        bwd_flow = _f32c(bwd_flow, "backward flow")
+        if bwd_flow.requires_grad:
+            raise RuntimeError("flowmap_amd: gradients w.r.t. optical flow are not supported (flows are constants)")
+        if from_depth:
+            depth = _f32c(depth, "depth")
+            k = _f32c(k, "intrinsics")
+            b, f, h, w = depth.shape
+            kinv = intrinsics_inverse(k)
+            dev = depth.device
+        else:
+            surfaces = _f32c(surfaces, "surfaces")
+            b, f, h, w, _ = surfaces.shape
+            kinv = None
+            dev = surfaces.device
+        if tuple(weights.shape) != (b, f - 1, h, w) or tuple(bwd_flow.shape) != (b, f - 1, h, w, 2):
+            raise RuntimeError("flowmap_amd: weights/backward-flow shapes do not match the surfaces")
+        if indices is not None:
+            if indices.dtype != torch.int64:
+                raise RuntimeError("flowmap_amd: indices must be int64")
+            indices = indices.contiguous()
+            points = indices.numel()
+        else:
+            points = h * w
+        pairs = b * (f - 1)
+        stats = torch.empty((pairs, STAT_STRIDE), dtype=torch.float64, device=dev)
+        t_bwd = torch.empty((b, f - 1, 4, 4), dtype=torch.float32, device=dev)
+        aux = torch.empty((pairs, AUX_STRIDE), dtype=torch.float64, device=dev)
+        with _guard(dev):
+            st = stream_for(weights)
+            call("fm_procrustes_stats", ptr(depth) if from_depth else None, ptr(kinv), ptr(surfaces), ptr(bwd_flow),
+                 ptr(weights), ptr(indices), points, b, f, h, w, ptr(stats), st)
+            call("fm_pose_solve", ptr(stats), pairs, ptr(t_bwd), None, ptr(aux), st)
+        ctx.save_for_backward(depth if from_depth else surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux)
+        ctx.from_depth, ctx.dims, ctx.points = from_depth, (b, f, h, w), points
+        # Carried depth gradient: when the fused flow loss consumes poses fitted from the very
+        # same depth tensor, it parks its dense dL/ddepth here instead of returning it, and
+        # this node (which autograd always runs later) scatters its sparse part into that
+        # buffer and returns the sum once — no second dense tensor, no dense add.
+        ctx._fm_fit_depth_key = (depth.data_ptr(), depth._version, tuple(depth.shape)) if from_depth else None
+        ctx._fm_carried = None
+        return t_bwd
+
+    @staticmethod
+    def backward(ctx, g_t):
+        src, kinv, weights, bwd_flow, indices, t_bwd, aux = ctx.saved_tensors
+        b, f, h, w = ctx.dims
+        pairs = b * (f - 1)
+        dev = weights.device
+        g_t = _f32c(g_t, "grad")
+        need_src = ctx.needs_input_grad[0] if ctx.from_depth else ctx.needs_input_grad[2]
+        need_k = ctx.from_depth and ctx.needs_input_grad[1]
+        need_w = ctx.needs_input_grad[3]
+        pair_grad = torch.empty((pairs, PAIR_GRAD_STRIDE), dtype=torch.float64, device=dev)
+        g_src = g_k = g_w = None
+        carried = ctx._fm_carried
+        ctx._fm_carried = None
+        if need_src:
+            g_src = carried if carried is not None else torch.zeros_like(src)
+        if need_w:
+            g_w = torch.zeros_like(weights)
+        kinv_acc = torch.zeros((b * f, 9), dtype=torch.float64, device=dev) if need_k else None
+        with _guard(dev):
+            st = stream_for(weights)
+            call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t_bwd), ptr(aux), pairs, ptr(pair_grad), st)
+            call("fm_procrustes_scatter", ptr(src) if ctx.from_depth else None, ptr(kinv), None if ctx.from_depth else ptr(src),
+                 ptr(bwd_flow), ptr(weights), ptr(indices), ctx.points, b, f, h, w, ptr(aux), ptr(pair_grad),
+                 ptr(g_src) if ctx.from_depth else None, None if ctx.from_depth else ptr(g_src), ptr(g_w), ptr(kinv_acc), st)
+            if need_k:
+                g_k = torch.empty_like(kinv)
+                call("fm_intrinsics_inverse_bwd", ptr(kinv_acc), ptr(kinv), b * f, ptr(g_k), 0, st)
+        if ctx.from_depth:
+            return g_src, g_k, None, g_w, None, None
+        return None, None, g_src, g_w, None, None
+
+
+# --------------------------------------------------------------------------------------
+# Fused flow loss
+# --------------------------------------------------------------------------------------
+
+_norm_cache: dict = {}
+
+# bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs around every
+# launch of the fused flow kernel (same stream as the launch).
+flow_kernel_events = None
+
+
+def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=None) -> Tensor:
+    """Device tensor [weight/(V or 1), (V or 1)] with V = Σmask_fwd + Σmask_bwd
+    (loss_flow.py:56,66,70).  Masks are constants of the optimisation, so the result is
+    cached per (storage, version, weight) and costs nothing after the first step.
+    ``reducer`` (frame sharding) maps the local fp64 sum to the global one."""
+    key = (mask_fwd.data_ptr(), mask_bwd.data_ptr(), mask_fwd._version, mask_bwd._version, tuple(mask_fwd.shape),
+           float(weight), str(mask_fwd.device), id(reducer))
+    hit = _norm_cache.get(key)
+    if hit is not None:
+        return hit
+    vsum = torch.empty((1,), dtype=torch.float64, device=mask_fwd.device)
+    norm = torch.empty((2,), dtype=torch.float32, device=mask_fwd.device)
+    with _guard(mask_fwd.device):
+        call("fm_flow_valid_norm", ptr(mask_fwd), ptr(mask_bwd), mask_fwd.numel(), float(weight), ptr(vsum), ptr(norm),
+             stream_for(mask_fwd))
+    if reducer is not None:
+        vsum = reducer(vsum)
+        veff = torch.where(vsum == 0, torch.ones_like(vsum), vsum)
+        norm = torch.cat([float(weight) / veff, veff]).to(torch.float32)
+    if len(_norm_cache) > 8:
+        _norm_cache.clear()
+    _norm_cache[key] = norm
+    return norm
+
+
+class FlowLossFused(torch.autograd.Function):
+    """weight · LossFlow.compute_unweighted_loss (flowmap/loss/loss_flow.py:31-70,
+    flowmap/loss/loss.py:47) evaluated from depth + intrinsics + relative poses, with the
+    analytic gradient of every input produced in the same HBM pass."""
+
+    @staticmethod
+    def forward(ctx, depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, kind, delta, carry, items):
+        dev = check_device(depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm)
+        depth = _f32c(depth, "depth")
+        k = _f32c(k, "intrinsics")
+        t_fwd = _f32c(t_fwd, "forward poses")
+        t_bwd = _f32c(t_bwd, "backward poses")
+        flow_fwd, flow_bwd = _f32c(flow_fwd, "forward flow"), _f32c(flow_bwd, "backward flow")
+        mask_fwd, mask_bwd = _f32c(mask_fwd, "forward mask"), _f32c(mask_bwd, "backward mask")
+        b, f, h, w = depth.shape
+        if tuple(flow_fwd.shape) != (b, f - 1, h, w, 2) or tuple(flow_bwd.shape) != (b, f - 1, h, w, 2):
+            raise RuntimeError("flowmap_amd: flow shape does not match depth")
+        if tuple(mask_fwd.shape) != (b, f - 1, h, w) or tuple(mask_bwd.shape) != (b, f - 1, h, w):
+            raise RuntimeError("flowmap_amd: mask shape does not match depth")
+        if tuple(k.shape) != (b, f, 3, 3) or tuple(t_fwd.shape) != (b, f - 1, 4, 4) or tuple(t_bwd.shape) != (b, f - 1, 4, 4):
+            raise RuntimeError("flowmap_amd: intrinsics / pose shapes do not match depth")
+        need = any(ctx.needs_input_grad[:4])
+        kinv = intrinsics_inverse(k)
+        acc = torch.empty((b * f * 2 * FLOW_ACC_STRIDE,), dtype=torch.float64, device=dev)
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        g_depth = torch.empty_like(depth) if (need and ctx.needs_input_grad[0]) else None
+        g_tf = torch.empty_like(t_fwd)
+        g_tb = torch.empty_like(t_bwd)
+        g_k = torch.empty_like(k)
+        scale = (h * w) ** 0.5
+        events = None
+        if flow_kernel_events is not None and depth.is_cuda:
+            events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        with _guard(dev):
+            st = stream_for(depth)
+            if events:
+                events[0].record()
+            call("fm_flow_loss_fused", ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd),
+                 ptr(mask_fwd), ptr(mask_bwd), ptr(norm) if need else None, b, f, h, w, kind, float(delta), w / scale, h / scale,
+                 ptr(g_depth), ptr(acc), int(items), st)
+            if events:
+                events[1].record()
+                flow_kernel_events.append(events)
+            call("fm_flow_loss_finalize", ptr(acc), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(norm), b, f, ptr(loss), ptr(g_tf),
+                 ptr(g_tb), ptr(g_k), st)
+        ctx.grads = (g_depth, g_k, g_tf, g_tb) if need else None
+        ctx.fit_node = None
+        if carry and g_depth is not None:
+            key = (depth.data_ptr(), depth._version, tuple(depth.shape))
+            node = _find_fit_node(t_bwd, key)
+            if node is not None and node.needs_input_grad[0] and _find_fit_node(t_fwd, key) is node:
+                ctx.fit_node = node
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.grads is None:
+            raise RuntimeError("flowmap_amd: FlowLossFused gradients are single-use; run the forward again")
+        g_depth, g_k, g_tf, g_tb = ctx.grads
+        ctx.grads = None
+        g = g.reshape(1).to(torch.float32).contiguous()
+        with _guard(g.device):
+            st = stream_for(g)
+            for buf in (g_depth, g_k, g_tf, g_tb):
+                if buf is not None:
+                    call("fm_scale_if_needed", ptr(buf), buf.numel(), ptr(g), st)
+        node = ctx.fit_node
+        ctx.fit_node = None
+        if node is not None and g_depth is not None and node._fm_carried is None:
+            node._fm_carried = g_depth  # returned (summed) by ProcrustesFit.backward
+            g_depth = None
+        need = ctx.needs_input_grad
+        return (g_depth if (need[0] and g_depth is not None) else None, g_k if need[1] else None, g_tf if need[2] else None,
+                g_tb if need[3] else None, None, None, None, None, None, None, None, None, None)
+
+
+# --------------------------------------------------------------------------------------
+# Function-level building blocks on explicit point sets
+# --------------------------------------------------------------------------------------
+
+
+class Unproject(torch.autograd.Function):
+    """unproject (flowmap/model/projection.py:76-90) for G groups of N points:
+    xy (N,2) shared or (G,N,2); z (G,N); k (G,3,3) -> (G,N,3)."""
+
+    @staticmethod
+    def forward(ctx, xy, z, k):
+        dev = check_device(xy, z, k)
+        xy, z, k = _f32c(xy, "coordinates"), _f32c(z, "z"), _f32c(k, "intrinsics")
+        if xy.requires_grad:
+            raise RuntimeError("flowmap_amd: gradients w.r.t. image coordinates are not supported")
+        g, n = z.shape
+        shared = xy.dim() == 2
+        kinv = intrinsics_inverse(k)
+        out = torch.empty((g, n, 3), dtype=torch.float32, device=dev)
+        with _guard(dev):
+            call("fm_unproject_fwd", ptr(xy), 0 if shared else n * 2, ptr(z), ptr(kinv), g, n, ptr(out), stream_for(z))
+        ctx.save_for_backward(xy, z, kinv)
+        ctx.shared = shared
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        xy, z, kinv = ctx.saved_tensors
+        g, n = z.shape
+        g_out = _f32c(g_out, "grad")
+        g_z = torch.empty_like(z) if ctx.needs_input_grad[1] else None
+        need_k = ctx.needs_input_grad[2]
+        acc = torch.empty((g, 9), dtype=torch.float64, device=z.device) if need_k else None
+        g_k = None
+        with _guard(z.device):
+            st = stream_for(z)
+            call("fm_unproject_bwd", ptr(xy), 0 if ctx.shared else n * 2, ptr(z), ptr(kinv), ptr(g_out), g, n, ptr(g_z), ptr(acc), st)
+            if need_k:
+                g_k = torch.empty_like(kinv)
+                call("fm_intrinsics_inverse_bwd", ptr(acc), ptr(kinv), g, ptr(g_k), 0, st)
+        return None, g_z, g_k
+
+
+class Reproject(torch.autograd.Function):
+    """reproject_points (flowmap/model/projection.py:116-134): xyz (G,N,3), T (G,4,4),
+    K (G,3,3) -> xy (G,N,2)."""
+
+    @staticmethod
+    def forward(ctx, xyz, t, k):
+        dev = check_device(xyz, t, k)
+        xyz, t, k = _f32c(xyz, "points"), _f32c(t, "transformations"), _f32c(k, "intrinsics")
+        g, n, _ = xyz.shape
+        out = torch.empty((g, n, 2), dtype=torch.float32, device=dev)
+        with _guard(dev):
+            call("fm_reproject_fwd", ptr(xyz), ptr(t), ptr(k), g, n, ptr(out), stream_for(xyz))
+        ctx.save_for_backward(xyz, t, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_xy):
+        xyz, t, k = ctx.saved_tensors
+        g, n, _ = xyz.shape
+        g_xy = _f32c(g_xy, "grad")
+        g_xyz = torch.empty_like(xyz) if ctx.needs_input_grad[0] else None
+        g_t = torch.empty_like(t)
+        g_k = torch.empty_like(k)
+        acc = torch.empty((g, 18), dtype=torch.float64, device=xyz.device)
+        with _guard(xyz.device):
+            call("fm_reproject_bwd", ptr(xyz), ptr(t), ptr(k), ptr(g_xy), g, n, ptr(g_xyz), ptr(g_t), ptr(g_k), ptr(acc),
+                 stream_for(xyz))
+        return g_xyz, g_t if ctx.needs_input_grad[1] else None, g_k if ctx.needs_input_grad[2] else None
+
+
+class BilinearSample(torch.autograd.Function):
+    """F.grid_sample(bilinear, border, align_corners=False) of a channels-last image
+    (G,H,W,C) at normalised coordinates (G,P,2) in (0,1) -> (G,P,C)
+    (flowmap/model/projection.py:235-241,266-272)."""
+
+    @staticmethod
+    def forward(ctx, img, xy):
+        dev = check_device(img, xy)
+        img, xy = _f32c(img, "image"), _f32c(xy, "coordinates")
+        if xy.requires_grad:
+            raise RuntimeError("flowmap_amd: gradients w.r.t. sampling coordinates are not supported")
+        g, h, w, c = img.shape
+        p = xy.shape[1]
+        out = torch.empty((g, p, c), dtype=torch.float32, device=dev)
+        with _guard(dev):
+            call("fm_bilinear_sample_fwd", ptr(img), ptr(xy), g, h, w, c, p, ptr(out), stream_for(img))
+        ctx.save_for_backward(xy)
+        ctx.dims = (g, h, w, c, p)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (xy,) = ctx.saved_tensors
+        g, h, w, c, p = ctx.dims
+        g_out = _f32c(g_out, "grad")
+        g_img = torch.zeros((g, h, w, c), dtype=torch.float32, device=xy.device)
+        with _guard(xy.device):
+            call("fm_bilinear_sample_bwd", ptr(g_out), ptr(xy), g, h, w, c, p, ptr(g_img), stream_for(xy))
+        return g_img, None
+
+
+class RobustMapping(torch.autograd.Function):
+    """Mapping.forward (flowmap/loss/mapping/mapping.py:35-43) on (n,2) pairs."""
+
+    @staticmethod
+    def forward(ctx, a, b, kind, delta, ax, ay):
+        dev = check_device(a, b)
+        a, b = _f32c(a, "a"), _f32c(b, "b")
+        n = a.shape[0]
+        out = torch.empty((n,), dtype=torch.float32, device=dev)
+        with _guard(dev):
+            call("fm_mapping_fwd", ptr(a), ptr(b), n, kind, float(delta), float(ax), float(ay), ptr(out), stream_for(a))
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (kind, float(delta), float(ax), float(ay))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        a, b = ctx.saved_tensors
+        kind, delta, ax, ay = ctx.cfg
+        g_out = _f32c(g_out, "grad")
+        g_a = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        g_b = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        with _guard(a.device):
+            call("fm_mapping_bwd", ptr(a), ptr(b), ptr(g_out), a.shape[0], kind, delta, ax, ay, ptr(g_a), ptr(g_b), stream_for(a))
+        return g_a, g_b, None, None, None, None
+
+
+class AlignRigid(torch.autograd.Function):
+    """align_rigid (flowmap/model/procrustes.py:7-51): p, q (G,P,3), w (G,P) -> (G,4,4)."""
+
+    @staticmethod
+    def forward(ctx, p, q, w):
+        dev = check_device(p, q, w)
+        p, q, w = _f32c(p, "p"), _f32c(q, "q"), _f32c(w, "weights")
+        g, n, _ = p.shape
+        stats = torch.empty((g, STAT_STRIDE), dtype=torch.float64, device=dev)
+        t = torch.empty((g, 4, 4), dtype=torch.float32, device=dev)
+        aux = torch.empty((g, AUX_STRIDE), dtype=torch.float64, device=dev)
+        with _guard(dev):
+            st = stream_for(p)
+            call("fm_align_rigid_stats", ptr(p), ptr(q), ptr(w), g, n, ptr(stats), st)
+            call("fm_pose_solve", ptr(stats), g, ptr(t), None, ptr(aux), st)
+        ctx.save_for_backward(p, q, w, t, aux)
+        return t
+
+    @staticmethod
+    def backward(ctx, g_t):
+        p, q, w, t, aux = ctx.saved_tensors
+        g, n, _ = p.shape
+        g_t = _f32c(g_t, "grad")
+        pair_grad = torch.empty((g, PAIR_GRAD_STRIDE), dtype=torch.float64, device=p.device)
+        g_p = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        g_q = torch.empty_like(q) if ctx.needs_input_grad[1] else None
+        g_w = torch.empty_like(w) if ctx.needs_input_grad[2] else None
+        with _guard(p.device):
+            st = stream_for(p)
+            call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t), ptr(aux), g, ptr(pair_grad), st)
+            call("fm_align_rigid_bwd", ptr(p), ptr(q), ptr(w), g, n, ptr(aux), ptr(pair_grad), ptr(g_p), ptr(g_q), ptr(g_w), st)
+        return g_p, g_q, g_w

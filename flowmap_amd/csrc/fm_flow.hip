@@ -1,0 +1,293 @@
+// Fused flow-consistency loss + analytic gradients (the roofline kernel).
+//
+// Replaces, in ONE pass over HBM, the reference chain
+//   unproject (projection.py:76-90) -> compute_forward_flow / compute_backward_flow
+//   (projection.py:143-184) -> reproject_points / project_camera_space (:116-134,:49-58)
+//   -> Mapping.forward (loss/mapping/mapping.py:35-43, mapping_huber.py:19-34)
+//   -> masked sums (loss/loss_flow.py:55-70)
+// and everything autograd would replay for it.
+//
+// Work decomposition: the grid is organised per SOURCE frame.
+// Frame f is the source of the forward term of pair f (into camera f+1) and of the
+// backward term of pair f-1 (into camera f-1), so one thread per (frame, pixel) reads
+// depth[f] once, reads flow/mask of both directions once, and writes dL/ddepth[f] once
+// with no atomics on the big tensor.  Algorithmic traffic: N·(8F + 24(F−1)) bytes.
+//
+// Pose / intrinsics gradients are linear in per-pixel quantities and are reduced
+// per (frame, direction) into 19 numbers:
+//   [0]      Σ ρ·m                       (loss numerator, unscaled)
+//   [1..3]   Σ g_X'                      (= dL/dt of the direction's relative pose)
+//   [4..12]  S = Σ g_X' ⊗ (z·[u,v,1])    (dL/dR = S·Kinvᵀ ; dL/dKinv_src = Rᵀ·S)
+//   [13..18] Σ (g_u, g_v) ⊗ p            (rows 0,1 of dL/dK_dst)
+// wave shuffle -> LDS -> one fp64 atomic per value per block.
+#include "fm_device.h"
+#include "fm_pose.h"
+
+namespace fm {
+
+struct FlowParams {
+  const float* depth;     // (B,F,H,W)
+  const float* k;         // (B,F,3,3)
+  const float* kinv;      // (B,F,3,3)
+  const float* t_fwd;     // (B,F-1,4,4) camera f -> camera f+1
+  const float* t_bwd;     // (B,F-1,4,4) camera f+1 -> camera f
+  const float* flow_fwd;  // (B,F-1,H,W,2)
+  const float* flow_bwd;  // (B,F-1,H,W,2)
+  const float* mask_fwd;  // (B,F-1,H,W)
+  const float* mask_bwd;  // (B,F-1,H,W)
+  const float* scale;     // device scalar multiplied into every per-residual gradient
+  float* grad_depth;      // (B,F,H,W) or null
+  double* acc;            // (B*F, 2, kFlowAccStride)
+  int frames, height, width;
+  int kind;
+  float delta, ax, ay;
+  int iters;              // items per thread
+};
+
+template <int VEC, bool GRAD>
+__global__ void __launch_bounds__(256) flow_fused_kernel(FlowParams p) {
+  extern __shared__ float lds[];  // [width] u-table, then reduction scratch
+  float* u_tab = lds;
+  float* red = lds + p.width;
+
+  const int bf = blockIdx.y;  // batch*frames + frame
+  const int f = bf % p.frames;
+  const int b = bf / p.frames;
+  const bool has_fwd = f < p.frames - 1;
+  const bool has_bwd = f > 0;
+  const int n = p.height * p.width;
+  const int items = n / VEC;
+  const int items_per_row = p.width / VEC;
+
+  for (int c = threadIdx.x; c < p.width; c += blockDim.x) u_tab[c] = pixel_center(c, p.width);
+  __syncthreads();
+
+  Mat3 kinv, k_f, k_b;
+  Pose t_f, t_b;
+  load_mat3(p.kinv + (size_t)bf * 9, kinv);
+  const size_t pair_f = (size_t)b * (p.frames - 1) + f;  // pair whose earlier frame is f
+  const size_t pair_b = pair_f - 1;                       // pair whose later frame is f
+  if (has_fwd) {
+    load_mat3(p.k + (size_t)(bf + 1) * 9, k_f);
+    load_pose44(p.t_fwd + pair_f * 16, t_f);
+  }
+  if (has_bwd) {
+    load_mat3(p.k + (size_t)(bf - 1) * 9, k_b);
+    load_pose44(p.t_bwd + pair_b * 16, t_b);
+  }
+  const float scale = GRAD ? p.scale[0] : 0.f;
+
+  const float* depth = p.depth + (size_t)bf * n;
+  const float* ff = p.flow_fwd + pair_f * (size_t)n * 2;
+  const float* mf = p.mask_fwd + pair_f * (size_t)n;
+  const float* fb = p.flow_bwd + pair_b * (size_t)n * 2;
+  const float* mb = p.mask_bwd + pair_b * (size_t)n;
+  float* gd = GRAD && p.grad_depth ? p.grad_depth + (size_t)bf * n : nullptr;
+
+  float acc_f[kFlowAcc], acc_b[kFlowAcc];
+#pragma unroll
+  for (int i = 0; i < kFlowAcc; ++i) acc_f[i] = acc_b[i] = 0.f;
+
+  const int base = blockIdx.x * (blockDim.x * p.iters);
+  for (int it = 0; it < p.iters; ++it) {
+    const int item = base + it * blockDim.x + threadIdx.x;
+    if (item >= items) break;
+    float z[VEC], gz[VEC], fxf[VEC], fyf[VEC], mmf[VEC], fxb[VEC], fyb[VEC], mmb[VEC];
+    if (VEC == 4) {
+      const float4 zq = reinterpret_cast<const float4*>(depth)[item];
+      z[0] = zq.x; z[1] = zq.y; z[2] = zq.z; z[3] = zq.w;
+      if (has_fwd) {
+        const float4 a = reinterpret_cast<const float4*>(ff)[item * 2];
+        const float4 c = reinterpret_cast<const float4*>(ff)[item * 2 + 1];
+        const float4 mq = reinterpret_cast<const float4*>(mf)[item];
+        fxf[0] = a.x; fyf[0] = a.y; fxf[1] = a.z; fyf[1] = a.w;
+        fxf[2] = c.x; fyf[2] = c.y; fxf[3] = c.z; fyf[3] = c.w;
+        mmf[0] = mq.x; mmf[1] = mq.y; mmf[2] = mq.z; mmf[3] = mq.w;
+      }
+      if (has_bwd) {
+        const float4 a = reinterpret_cast<const float4*>(fb)[item * 2];
+        const float4 c = reinterpret_cast<const float4*>(fb)[item * 2 + 1];
+        const float4 mq = reinterpret_cast<const float4*>(mb)[item];
+        fxb[0] = a.x; fyb[0] = a.y; fxb[1] = a.z; fyb[1] = a.w;
+        fxb[2] = c.x; fyb[2] = c.y; fxb[3] = c.z; fyb[3] = c.w;
+        mmb[0] = mq.x; mmb[1] = mq.y; mmb[2] = mq.z; mmb[3] = mq.w;
+      }
+    } else {
+      z[0] = depth[item];
+      if (has_fwd) {
+        const float2 a = reinterpret_cast<const float2*>(ff)[item];
+        fxf[0] = a.x; fyf[0] = a.y; mmf[0] = mf[item];
+      }
+      if (has_bwd) {
+        const float2 a = reinterpret_cast<const float2*>(fb)[item];
+        fxb[0] = a.x; fyb[0] = a.y; mmb[0] = mb[item];
+      }
+    }
+    const int row = item / items_per_row;
+    const int col0 = (item - row * items_per_row) * VEC;
+    const float v = pixel_center(row, p.height);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float u = u_tab[col0 + e];
+      float ray[3];
+      ray_dir(kinv, u, v, ray);
+      gz[e] = 0.f;
+      if (has_fwd) flow_term<GRAD>(t_f, k_f, ray, z[e], u, v, fxf[e], fyf[e], mmf[e], scale, p.kind, p.delta, p.ax, p.ay, acc_f, gz[e]);
+      if (has_bwd) flow_term<GRAD>(t_b, k_b, ray, z[e], u, v, fxb[e], fyb[e], mmb[e], scale, p.kind, p.delta, p.ax, p.ay, acc_b, gz[e]);
+    }
+    if (GRAD && gd) {
+      if (VEC == 4) {
+        reinterpret_cast<float4*>(gd)[item] = make_float4(gz[0], gz[1], gz[2], gz[3]);
+      } else {
+        gd[item] = gz[0];
+      }
+    }
+  }
+
+  double* dst = p.acc + (size_t)bf * 2 * kFlowAccStride;
+  if (has_fwd) block_accumulate<kFlowAcc>(acc_f, red, dst);
+  if (has_bwd) block_accumulate<kFlowAcc>(acc_b, red, dst + kFlowAccStride);
+}
+
+// ---------------------------------------------------------------------------------
+// Finalize: turn the per-(frame, direction) sums into the loss and the small gradients.
+//   loss[0]      = weight · Σρm / V_eff                     (loss.py:47, loss_flow.py:70)
+//   g_t_fwd/bwd  = dL/dT of the relative poses (B,F-1,4,4), bottom row 0
+//   g_k          = dL/dK (B,F,3,3) through the destination role (rows 0,1) AND through
+//                  K⁻¹ of the source role:  dK = −K⁻ᵀ · dKinv · K⁻ᵀ
+// One thread per frame; loss summed by thread 0 of block 0 (B·F ≤ a few thousand).
+// ---------------------------------------------------------------------------------
+struct FlowFinalizeParams {
+  const double* acc;
+  const float* kinv;
+  const float* t_fwd;
+  const float* t_bwd;
+  const float* norm;  // device: [0] = weight / V_eff (loss normaliser)
+  float* loss;        // (1)
+  float* g_t_fwd;     // (B,F-1,4,4)
+  float* g_t_bwd;     // (B,F-1,4,4)
+  float* g_k;         // (B,F,3,3)
+  int batch, frames;
+};
+
+__global__ void flow_finalize_kernel(FlowFinalizeParams p) {
+  const int bf = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = p.batch * p.frames;
+  if (bf < total) flow_finalize_frame(p.acc, p.kinv, p.t_fwd, p.t_bwd, p.batch, p.frames, bf, p.g_t_fwd, p.g_t_bwd, p.g_k);
+  if (blockIdx.x == 0) {
+    // loss numerator: sum over all (frame, direction) in fp64 by one wave
+    double s = 0.0;
+    if (threadIdx.x < kWave)
+      for (int i = threadIdx.x; i < total * 2; i += kWave) s += p.acc[(size_t)i * kFlowAccStride];
+    if (threadIdx.x < kWave) s = wave_sum(s);
+    if (threadIdx.x == 0) p.loss[0] = (float)(s * (double)p.norm[0]);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Σ mask (loss_flow.py:56,66).  Masks never change during an optimisation, so the host
+// caches the result per Flows object; this runs once.
+// out[0] += Σ a + Σ b  (fp64)
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sum2_kernel(const float* a, const float* b, long n, double* out) {
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float t = a[i];
+    if (b) t += b[i];
+    s += (double)t;
+  }
+  s = wave_sum(s);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// norm[0] = weight / (V or 1) (loss normaliser);  norm[1] = V_eff
+__global__ void flow_norm_kernel(const double* vsum, float weight, float* norm) {
+  const double v = vsum[0];
+  const double veff = v != 0.0 ? v : 1.0;  // `valid_sum or 1` (loss_flow.py:70)
+  norm[0] = (float)((double)weight / veff);
+  norm[1] = (float)veff;
+}
+
+// In-place scale of gradient buffers by a device scalar, skipped entirely when the
+// scalar is exactly 1 (the autograd root case): every block exits after one load.
+__global__ void __launch_bounds__(256) scale_if_needed_kernel(float* x, long n, const float* s) {
+  const float sv = s[0];
+  if (sv == 1.0f) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= sv;
+}
+
+}  // namespace fm
+
+using namespace fm;
+
+extern "C" {
+
+int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                       const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
+                       const float* scale, int batch, int frames, int height, int width, int mapping_kind, float delta,
+                       float aspect_x, float aspect_y, float* grad_depth, double* acc, int items_per_thread, void* stream) {
+  FM_CHECK_ARG(depth && k && kinv && flow_fwd && flow_bwd && mask_fwd && mask_bwd && acc);
+  FM_CHECK_ARG(batch >= 1 && frames >= 2 && height >= 1 && width >= 1);
+  FM_CHECK_ARG(mapping_kind >= 0 && mapping_kind <= 2);
+  FM_CHECK_ARG((long)height * width < (1L << 30));
+  FM_CHECK_ARG((long)batch * frames <= 65535);
+  hipStream_t st = (hipStream_t)stream;
+  const bool grad = scale != nullptr;
+  FlowParams p{depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, scale, grad_depth, acc,
+               frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 8};
+  if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride, st) != hipSuccess) return FM_ERR_LAUNCH;
+  auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool vec4 = (width % 4 == 0) && aligned(depth) && aligned(flow_fwd) && aligned(flow_bwd) && aligned(mask_fwd) &&
+                    aligned(mask_bwd) && (!grad_depth || aligned(grad_depth));
+  const int vec = vec4 ? 4 : 1;
+  const long items = (long)height * width / vec;
+  const int threads = 256;
+  const long per_block = (long)threads * p.iters;
+  dim3 grid((unsigned)((items + per_block - 1) / per_block), (unsigned)(batch * frames));
+  const size_t lds = sizeof(float) * ((size_t)width + (threads / 64) * kFlowAcc);
+  if (vec4) {
+    if (grad) hipLaunchKernelGGL((flow_fused_kernel<4, true>), grid, dim3(threads), lds, st, p);
+    else hipLaunchKernelGGL((flow_fused_kernel<4, false>), grid, dim3(threads), lds, st, p);
+  } else {
+    if (grad) hipLaunchKernelGGL((flow_fused_kernel<1, true>), grid, dim3(threads), lds, st, p);
+    else hipLaunchKernelGGL((flow_fused_kernel<1, false>), grid, dim3(threads), lds, st, p);
+  }
+  FM_LAUNCH_STATUS();
+}
+
+int fm_flow_loss_finalize(const double* acc, const float* kinv, const float* t_fwd, const float* t_bwd, const float* norm,
+                          int batch, int frames, float* loss, float* g_t_fwd, float* g_t_bwd, float* g_k, void* stream) {
+  FM_CHECK_ARG(acc && kinv && t_fwd && t_bwd && norm && loss && g_t_fwd && g_t_bwd && g_k);
+  FlowFinalizeParams p{acc, kinv, t_fwd, t_bwd, norm, loss, g_t_fwd, g_t_bwd, g_k, batch, frames};
+  const int total = batch * frames;
+  hipLaunchKernelGGL(flow_finalize_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, p);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_flow_valid_norm(const float* mask_fwd, const float* mask_bwd, long count, float weight, double* vsum, float* norm,
+                       void* stream) {
+  FM_CHECK_ARG(mask_fwd && vsum && norm && count >= 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(vsum, 0, sizeof(double), st) != hipSuccess) return FM_ERR_LAUNCH;
+  if (count > 0) {
+    long blocks = (count + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sum2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mask_fwd, mask_bwd, count, vsum);
+  }
+  hipLaunchKernelGGL(flow_norm_kernel, dim3(1), dim3(1), 0, st, vsum, weight, norm);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_scale_if_needed(float* x, long count, const float* scalar, void* stream) {
+  FM_CHECK_ARG(x && scalar && count >= 0);
+  if (count == 0) return FM_OK;
+  long blocks = (count + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(scale_if_needed_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, count, scalar);
+  FM_LAUNCH_STATUS();
+}
+
+}  // extern "C"

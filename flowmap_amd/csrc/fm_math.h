@@ -1,0 +1,552 @@
+// Per-element math of FlowMap's reprojection / flow-consistency hot path.
+//
+// Everything here is a plain inline function usable from HIP device code (hipcc) and
+// from a host C++ compiler (g++, used only by tests/host_sim to check the analytic
+// gradients on the CPU before spending GPU minutes).  No memory traffic, no launch
+// logic: kernels in *.hip own indexing, coalescing and reductions.
+//
+// Reference semantics restated (file:line are relative to dcharatan/flowmap):
+//   unproject              flowmap/model/projection.py:76-90
+//   reproject_points       flowmap/model/projection.py:116-134
+//   project_camera_space   flowmap/model/projection.py:49-58   (eps=1e-5, inf=1e8)
+//   grid_sample(bilinear, border, align_corners=False)  projection.py:235-241,266-272
+//   Mapping / Huber / L1 / L2   flowmap/loss/mapping/*.py
+//   align_rigid            flowmap/model/procrustes.py:7-51
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FM_HD __host__ __device__ __forceinline__
+#else
+#define FM_HD inline
+#endif
+
+namespace fm {
+
+constexpr float kProjEps = 1e-5f;  // projection.py:52
+constexpr float kProjInf = 1e8f;   // projection.py:53
+
+enum MappingKind : int { kHuber = 0, kL1 = 1, kL2 = 2 };
+
+struct Mat3 {  // row-major 3x3
+  float m[9];
+};
+
+struct Pose {  // top three rows of a 4x4 [R | t]
+  float r[9];
+  float t[3];
+};
+
+FM_HD void load_mat3(const float* p, Mat3& o) {
+  for (int i = 0; i < 9; ++i) o.m[i] = p[i];
+}
+
+// Top 3 rows of a row-major 4x4.
+FM_HD void load_pose44(const float* p, Pose& o) {
+  for (int r = 0; r < 3; ++r) {
+    o.r[r * 3 + 0] = p[r * 4 + 0];
+    o.r[r * 3 + 1] = p[r * 4 + 1];
+    o.r[r * 3 + 2] = p[r * 4 + 2];
+    o.t[r] = p[r * 4 + 3];
+  }
+}
+
+// Pixel-centre coordinate, evaluated like sample_image_grid (projection.py:109):
+// (int + 0.5) / length in fp32 with a true division.
+FM_HD float pixel_center(int i, int n) { return ((float)i + 0.5f) / (float)n; }
+
+// ray = Kinv · [u, v, 1]   (projection.py:84-87)
+FM_HD void ray_dir(const Mat3& kinv, float u, float v, float ray[3]) {
+  ray[0] = kinv.m[0] * u + kinv.m[1] * v + kinv.m[2];
+  ray[1] = kinv.m[3] * u + kinv.m[4] * v + kinv.m[5];
+  ray[2] = kinv.m[6] * u + kinv.m[7] * v + kinv.m[8];
+}
+
+// nan_to_num(posinf=1e8, neginf=-1e8) with its autograd mask (projection.py:56).
+FM_HD float nan_to_num(float x, float& pass) {
+  if (x != x) {
+    pass = 0.f;
+    return 0.f;
+  }
+  if (x > 3.0e38f) {
+    pass = 0.f;
+    return kProjInf;
+  }
+  if (x < -3.0e38f) {
+    pass = 0.f;
+    return -kProjInf;
+  }
+  pass = 1.f;
+  return x;
+}
+
+// Result of projecting one camera-space point X' with destination intrinsics K.
+struct Projected {
+  float u, v;        // image position
+  float p[3];        // X'/(Z'+eps) after nan_to_num
+  float inv_s;       // 1/(Z'+eps)
+  float pass[3];     // nan_to_num gradient masks
+};
+
+FM_HD Projected project_point(const float xc[3], const Mat3& k) {
+  Projected o;
+  const float s = xc[2] + kProjEps;
+  o.inv_s = 1.0f / s;
+  // The reference divides each component by s; x * (1/s) differs by <=1 ulp.
+  for (int a = 0; a < 3; ++a) o.p[a] = nan_to_num(xc[a] * o.inv_s, o.pass[a]);
+  o.u = k.m[0] * o.p[0] + k.m[1] * o.p[1] + k.m[2] * o.p[2];
+  o.v = k.m[3] * o.p[0] + k.m[4] * o.p[1] + k.m[5] * o.p[2];
+  return o;
+}
+
+// Back-propagate (gu, gv) = dL/d(u,v) through project_point.
+//   gk[6] += outer((gu,gv), p)       (rows 0,1 of K)
+//   gxc    = dL/dX'
+// At the exact singularity Z' = -eps the reference's gradient is NaN (inf·0); we
+// define it as 0 (SURVEY.md §7 "hard parts").
+FM_HD void project_point_bwd(const Projected& f, const Mat3& k, float gu, float gv, float gk[6], float gxc[3]) {
+  gk[0] += gu * f.p[0];
+  gk[1] += gu * f.p[1];
+  gk[2] += gu * f.p[2];
+  gk[3] += gv * f.p[0];
+  gk[4] += gv * f.p[1];
+  gk[5] += gv * f.p[2];
+  float gp[3];
+  gp[0] = (k.m[0] * gu + k.m[3] * gv) * f.pass[0];
+  gp[1] = (k.m[1] * gu + k.m[4] * gv) * f.pass[1];
+  gp[2] = (k.m[2] * gu + k.m[5] * gv) * f.pass[2];
+  const bool finite = (f.pass[0] + f.pass[1] + f.pass[2]) == 3.f;
+  const float is = finite ? f.inv_s : 0.f;
+  const float dot = gp[0] * f.p[0] + gp[1] * f.p[1] + gp[2] * f.p[2];
+  gxc[0] = gp[0] * is;
+  gxc[1] = gp[1] * is;
+  gxc[2] = (gp[2] - dot) * is;
+}
+
+FM_HD void apply_pose(const Pose& t, const float x[3], float o[3]) {
+  // einsum over the homogeneous point: r0·x0 + r1·x1 + r2·x2 + t·1 (projection.py:127-131)
+  o[0] = t.r[0] * x[0] + t.r[1] * x[1] + t.r[2] * x[2] + t.t[0];
+  o[1] = t.r[3] * x[0] + t.r[4] * x[1] + t.r[5] * x[2] + t.t[1];
+  o[2] = t.r[6] * x[0] + t.r[7] * x[1] + t.r[8] * x[2] + t.t[2];
+}
+
+FM_HD void apply_rot_t(const Pose& t, const float g[3], float o[3]) {  // Rᵀ g
+  o[0] = t.r[0] * g[0] + t.r[3] * g[1] + t.r[6] * g[2];
+  o[1] = t.r[1] * g[0] + t.r[4] * g[1] + t.r[7] * g[2];
+  o[2] = t.r[2] * g[0] + t.r[5] * g[1] + t.r[8] * g[2];
+}
+
+// Robust mapping of an aspect-corrected residual (rx, ry): value and d(value)/d(rx,ry).
+//   huber: F.huber_loss(n, 0, delta)/delta  (mapping_huber.py:23-34)
+//   l1:    n                                 (mapping_l1.py:20)
+//   l2:    0.5 (rx² + ry²)                   (mapping_l2.py:21)
+// ‖·‖ has sub-gradient 0 at 0 (torch's norm backward masks n == 0).
+FM_HD float robust_map(int kind, float delta, float rx, float ry, float& drx, float& dry) {
+  const float ss = rx * rx + ry * ry;
+  if (kind == kL2) {
+    drx = rx;
+    dry = ry;
+    return 0.5f * ss;
+  }
+  const float n = sqrtf(ss);
+  const float inv_n = n > 0.f ? 1.0f / n : 0.f;
+  if (kind == kL1 || !(n < delta)) {
+    drx = rx * inv_n;
+    dry = ry * inv_n;
+    return kind == kL1 ? n : (delta * (n - 0.5f * delta)) / delta;
+  }
+  const float inv_d = 1.0f / delta;
+  drx = rx * inv_d;
+  dry = ry * inv_d;
+  return (0.5f * n * n) * inv_d;
+}
+
+// ---------------------------------------------------------------------------------
+// Bilinear sampling with border padding, align_corners=False (ATen grid_sampler_2d).
+// ---------------------------------------------------------------------------------
+struct Taps {
+  int x0, y0;          // north-west tap
+  float w[4];          // nw, ne, sw, se
+  bool in[4];          // tap inside the image
+};
+
+// coordinate in normalised (0,1) units -> taps; the reference feeds grid_sample with
+// xy*2-1 (projection.py:237,268) and ATen un-normalises with ((g+1)*size-1)/2.
+FM_HD Taps bilinear_taps(float x01, float y01, int h, int w) {
+  Taps t;
+  float gx = x01 * 2.f - 1.f;
+  float gy = y01 * 2.f - 1.f;
+  float ix = ((gx + 1.f) * (float)w - 1.f) / 2.f;
+  float iy = ((gy + 1.f) * (float)h - 1.f) / 2.f;
+  ix = fminf((float)(w - 1), fmaxf(ix, 0.f));
+  iy = fminf((float)(h - 1), fmaxf(iy, 0.f));
+  const float fx = floorf(ix), fy = floorf(iy);
+  t.x0 = (int)fx;
+  t.y0 = (int)fy;
+  const float ex = fx + 1.f, ey = fy + 1.f;
+  t.w[0] = (ex - ix) * (ey - iy);
+  t.w[1] = (ix - fx) * (ey - iy);
+  t.w[2] = (ex - ix) * (iy - fy);
+  t.w[3] = (ix - fx) * (iy - fy);
+  const bool xin0 = t.x0 >= 0 && t.x0 < w, xin1 = t.x0 + 1 >= 0 && t.x0 + 1 < w;
+  const bool yin0 = t.y0 >= 0 && t.y0 < h, yin1 = t.y0 + 1 >= 0 && t.y0 + 1 < h;
+  t.in[0] = xin0 && yin0;
+  t.in[1] = xin1 && yin0;
+  t.in[2] = xin0 && yin1;
+  t.in[3] = xin1 && yin1;
+  return t;
+}
+
+FM_HD int tap_col(const Taps& t, int k) { return t.x0 + (k & 1); }
+FM_HD int tap_row(const Taps& t, int k) { return t.y0 + (k >> 1); }
+
+// ---------------------------------------------------------------------------------
+// One flow residual (used by the fused flow kernel): source pixel with ray/depth ->
+// destination image -> robust loss, and its analytic gradients.
+//   acc[0]      += ρ·m                      (loss numerator, unscaled)
+//   acc[1..3]   += g_X'                     (dL/dt of the relative pose)
+//   acc[4..12]  += g_X' ⊗ (z·[u,v,1])       (S; dL/dR = S·Kinvᵀ, dL/dKinv_src = Rᵀ·S)
+//   acc[13..18] += (g_u, g_v) ⊗ p           (rows 0,1 of dL/dK_dst)
+//   gz          += dL/dz of the source pixel
+// ---------------------------------------------------------------------------------
+constexpr int kFlowAcc = 19;
+
+template <bool GRAD>
+FM_HD void flow_term(const Pose& tr, const Mat3& kd, const float ray[3], float z, float u, float v, float flow_x,
+                     float flow_y, float m, float scale, int kind, float delta, float ax, float ay, float (&acc)[kFlowAcc],
+                     float& gz) {
+  float x[3] = {ray[0] * z, ray[1] * z, ray[2] * z};
+  float xc[3];
+  apply_pose(tr, x, xc);
+  const Projected pr = project_point(xc, kd);
+  // Mapping.forward: fix_aspect_ratio(a) - fix_aspect_ratio(b) (mapping.py:41-43)
+  const float rx = (pr.u - u) * ax - flow_x * ax;
+  const float ry = (pr.v - v) * ay - flow_y * ay;
+  float drx, dry;
+  const float rho = robust_map(kind, delta, rx, ry, drx, dry);
+  acc[0] += rho * m;
+  if (GRAD) {
+    const float g = scale * m;
+    const float gu = g * drx * ax;
+    const float gv = g * dry * ay;
+    float gk[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gxc[3];
+    project_point_bwd(pr, kd, gu, gv, gk, gxc);
+    for (int i = 0; i < 6; ++i) acc[13 + i] += gk[i];
+    const float zh[3] = {z * u, z * v, z};
+    for (int a = 0; a < 3; ++a) {
+      acc[1 + a] += gxc[a];
+      acc[4 + a * 3 + 0] += gxc[a] * zh[0];
+      acc[4 + a * 3 + 1] += gxc[a] * zh[1];
+      acc[4 + a * 3 + 2] += gxc[a] * zh[2];
+    }
+    float gx[3];
+    apply_rot_t(tr, gxc, gx);
+    gz += gx[0] * ray[0] + gx[1] * ray[1] + gx[2] * ray[2];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// One Procrustes correspondence of frame pair (earlier e, later l), evaluated
+// identically in the statistics passes and in the backward scatter.
+//   p = xyz_l[idx]                                   (projection.py:226-227)
+//   q = bilinear(xyz_e, xy[idx] + bwd_flow[idx])     (projection.py:231-242)
+//   w = weights[idx]                                  (projection.py:245-249)
+// xyz is read from an explicit surfaces image (surf_* != null) or recomputed from
+// depth and K⁻¹.  All image pointers address ONE frame (H·W pixels).
+// ---------------------------------------------------------------------------------
+struct CorrSrc {
+  const float* depth_e;   // (H,W)   earlier frame depth       [depth-sourced]
+  const float* depth_l;   // (H,W)   later frame depth         [depth-sourced]
+  const float* surf_e;    // (H,W,3) earlier frame surfaces    [surface-sourced]
+  const float* surf_l;    // (H,W,3)
+  const float* bwd_flow;  // (H,W,2)
+  const float* weights;   // (H,W)
+  int height, width;
+};
+
+struct Corr {
+  float p[3], q[3], w;
+  int idx;
+  Taps taps;
+  float ray_p[3];  // later-frame ray at idx   [depth-sourced]
+  float z_p;
+};
+
+FM_HD Corr corr_load(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, int idx) {
+  Corr c;
+  c.idx = idx;
+  const int row = idx / s.width, col = idx - row * s.width;
+  const float u = pixel_center(col, s.width), v = pixel_center(row, s.height);
+  const float fx = s.bwd_flow[2 * (size_t)idx], fy = s.bwd_flow[2 * (size_t)idx + 1];
+  c.w = s.weights[idx];
+  c.taps = bilinear_taps(u + fx, v + fy, s.height, s.width);
+  c.q[0] = c.q[1] = c.q[2] = 0.f;
+  c.z_p = 0.f;
+  c.ray_p[0] = c.ray_p[1] = c.ray_p[2] = 0.f;
+  if (s.surf_l == nullptr) {
+    c.z_p = s.depth_l[idx];
+    ray_dir(kinv_l, u, v, c.ray_p);
+    c.p[0] = c.ray_p[0] * c.z_p;
+    c.p[1] = c.ray_p[1] * c.z_p;
+    c.p[2] = c.ray_p[2] * c.z_p;
+    for (int k = 0; k < 4; ++k) {
+      if (!c.taps.in[k]) continue;
+      const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
+      const float z = s.depth_e[tr * s.width + tc];
+      float ray[3];
+      ray_dir(kinv_e, pixel_center(tc, s.width), pixel_center(tr, s.height), ray);
+      c.q[0] += (ray[0] * z) * c.taps.w[k];
+      c.q[1] += (ray[1] * z) * c.taps.w[k];
+      c.q[2] += (ray[2] * z) * c.taps.w[k];
+    }
+  } else {
+    const float* sl = s.surf_l + (size_t)idx * 3;
+    c.p[0] = sl[0];
+    c.p[1] = sl[1];
+    c.p[2] = sl[2];
+    for (int k = 0; k < 4; ++k) {
+      if (!c.taps.in[k]) continue;
+      const float* se = s.surf_e + ((size_t)tap_row(c.taps, k) * s.width + tap_col(c.taps, k)) * 3;
+      c.q[0] += se[0] * c.taps.w[k];
+      c.q[1] += se[1] * c.taps.w[k];
+      c.q[2] += se[2] * c.taps.w[k];
+    }
+  }
+  return c;
+}
+
+// Per-pair constants of the Procrustes backward (produced by the pose-solve backward).
+struct PairGrad {
+  float gM[9];      // dL/dM
+  float gqbar[3];   // total dL/dq̄ (through t and through the centred vectors)
+  float gpbar[3];   // total dL/dp̄
+  float pbar[3], qbar[3];
+  float dbar;       // gq̄·q̄ + gp̄·p̄
+  float inv_wsum;   // 1/(Σw + 1e-8)
+};
+
+// dL/dq_j, dL/dp_j, dL/dw_j of one correspondence (derived in DESIGN.md).
+FM_HD void corr_backward(const Corr& c, const PairGrad& g, float gq[3], float gp[3], float& gw) {
+  float pc[3], qc[3];
+  for (int a = 0; a < 3; ++a) {
+    pc[a] = c.p[a] - g.pbar[a];
+    qc[a] = c.q[a] - g.qbar[a];
+  }
+  const float wn = c.w * g.inv_wsum;
+  float dj = 0.f;
+  gw = 0.f;
+  for (int a = 0; a < 3; ++a) {
+    const float mp = g.gM[a * 3 + 0] * pc[0] + g.gM[a * 3 + 1] * pc[1] + g.gM[a * 3 + 2] * pc[2];  // (gM·pc)_a
+    const float mq = g.gM[0 * 3 + a] * qc[0] + g.gM[1 * 3 + a] * qc[1] + g.gM[2 * 3 + a] * qc[2];  // (gMᵀ·qc)_a
+    gq[a] = c.w * mp + wn * g.gqbar[a];
+    gp[a] = c.w * mq + wn * g.gpbar[a];
+    gw += qc[a] * mp;
+    dj += g.gqbar[a] * c.q[a] + g.gpbar[a] * c.p[a];
+  }
+  gw += (dj - g.dbar) * g.inv_wsum;
+}
+
+// ---------------------------------------------------------------------------------
+// 3x3 helpers in double (pose solve runs one thread per frame pair; cost is nil).
+// ---------------------------------------------------------------------------------
+FM_HD void mat3_mul(const double* a, const double* b, double* o) {  // o = a b
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
+}
+FM_HD void mat3_mul_tn(const double* a, const double* b, double* o) {  // o = aᵀ b
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[0 * 3 + i] * b[0 * 3 + j] + a[1 * 3 + i] * b[1 * 3 + j] + a[2 * 3 + i] * b[2 * 3 + j];
+}
+FM_HD void mat3_mul_nt(const double* a, const double* b, double* o) {  // o = a bᵀ
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[i * 3 + 0] * b[j * 3 + 0] + a[i * 3 + 1] * b[j * 3 + 1] + a[i * 3 + 2] * b[j * 3 + 2];
+}
+FM_HD void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// Polar/SVD factorisation used by align_rigid (procrustes.py:35-39):
+//   M = Ũ diag(σ̃) Ṽᵀ with Ũ, Ṽ ∈ SO(3), σ̃ = (σ1, σ2, ±σ3); R = Ũ Ṽᵀ equals the
+//   reference's U·diag(1,1,sign(det U · det Vᵀ))·Vᵀ.  Computed from the Jacobi
+//   eigen-decomposition of MᵀM; the third directions come from cross products so the
+//   reflection fix is built in and R only depends on the two dominant singular pairs.
+// Outputs are column-major-free: U[i*3+c] is row i, column c.
+FM_HD void polar_svd3(const double* m, double* U, double* V, double* sig) {
+  double a[9];
+  mat3_mul_tn(m, m, a);  // a = MᵀM (symmetric)
+  double v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = fabs(a[1]) + fabs(a[2]) + fabs(a[5]);
+    const double diag = fabs(a[0]) + fabs(a[4]) + fabs(a[8]);
+    if (off <= 1e-300 || off <= 1e-17 * diag) break;
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0;
+      const int q = pq == 0 ? 1 : 2;
+      const double apq = a[p * 3 + q];
+      if (apq == 0.0) continue;
+      const double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      for (int k = 0; k < 3; ++k) {  // a <- a J
+        const double akp = a[k * 3 + p], akq = a[k * 3 + q];
+        a[k * 3 + p] = c * akp - s * akq;
+        a[k * 3 + q] = s * akp + c * akq;
+      }
+      for (int k = 0; k < 3; ++k) {  // a <- Jᵀ a
+        const double apk = a[p * 3 + k], aqk = a[q * 3 + k];
+        a[p * 3 + k] = c * apk - s * aqk;
+        a[q * 3 + k] = s * apk + c * aqk;
+      }
+      for (int k = 0; k < 3; ++k) {  // v <- v J
+        const double vkp = v[k * 3 + p], vkq = v[k * 3 + q];
+        v[k * 3 + p] = c * vkp - s * vkq;
+        v[k * 3 + q] = s * vkp + c * vkq;
+      }
+    }
+  }
+  // order eigenvalues descending
+  int o0 = 0, o1 = 1, o2 = 2;
+  double l0 = a[0], l1 = a[4], l2 = a[8];
+  if (l0 < l1) { double tl = l0; l0 = l1; l1 = tl; int ti = o0; o0 = o1; o1 = ti; }
+  if (l0 < l2) { double tl = l0; l0 = l2; l2 = tl; int ti = o0; o0 = o2; o2 = ti; }
+  if (l1 < l2) { double tl = l1; l1 = l2; l2 = tl; int ti = o1; o1 = o2; o2 = ti; }
+  double v1[3] = {v[0 * 3 + o0], v[1 * 3 + o0], v[2 * 3 + o0]};
+  double v2[3] = {v[0 * 3 + o1], v[1 * 3 + o1], v[2 * 3 + o1]};
+  double v3[3];
+  cross3(v1, v2, v3);
+  const double s1 = sqrt(l0 > 0 ? l0 : 0), s2 = sqrt(l1 > 0 ? l1 : 0);
+  double u1[3], u2[3], u3[3];
+  if (!(s1 > 1e-150)) {  // M == 0: the reference's svd(0) yields U = V = I  ->  R = I
+    for (int i = 0; i < 9; ++i) U[i] = V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    sig[0] = sig[1] = sig[2] = 0.0;
+    return;
+  }
+  for (int i = 0; i < 3; ++i) u1[i] = (m[i * 3 + 0] * v1[0] + m[i * 3 + 1] * v1[1] + m[i * 3 + 2] * v1[2]) / s1;
+  double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+  for (int i = 0; i < 3; ++i) u1[i] /= n1;
+  for (int i = 0; i < 3; ++i) u2[i] = m[i * 3 + 0] * v2[0] + m[i * 3 + 1] * v2[1] + m[i * 3 + 2] * v2[2];
+  double d12 = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+  for (int i = 0; i < 3; ++i) u2[i] -= d12 * u1[i];
+  double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+  if (n2 > 1e-12 * s1) {
+    for (int i = 0; i < 3; ++i) u2[i] /= n2;
+  } else {  // rank-1 cloud: any unit vector orthogonal to u1 (rotation is not unique)
+    int k = fabs(u1[0]) < fabs(u1[1]) ? (fabs(u1[0]) < fabs(u1[2]) ? 0 : 2) : (fabs(u1[1]) < fabs(u1[2]) ? 1 : 2);
+    double e[3] = {0, 0, 0};
+    e[k] = 1.0;
+    cross3(u1, e, u2);
+    n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    for (int i = 0; i < 3; ++i) u2[i] /= n2;
+  }
+  cross3(u1, u2, u3);
+  for (int i = 0; i < 3; ++i) {
+    U[i * 3 + 0] = u1[i];
+    U[i * 3 + 1] = u2[i];
+    U[i * 3 + 2] = u3[i];
+    V[i * 3 + 0] = v1[i];
+    V[i * 3 + 1] = v2[i];
+    V[i * 3 + 2] = v3[i];
+  }
+  double mv3[3];
+  for (int i = 0; i < 3; ++i) mv3[i] = m[i * 3 + 0] * v3[0] + m[i * 3 + 1] * v3[1] + m[i * 3 + 2] * v3[2];
+  sig[0] = s1;
+  sig[1] = s2;
+  sig[2] = u3[0] * mv3[0] + u3[1] * mv3[1] + u3[2] * mv3[2];  // signed: ±σ3
+}
+
+// dL/dM from dL/dR for R = Ũ Ṽᵀ (polar-decomposition differential):
+//   C = Ũᵀ G_R Ṽ ;  X_ab = (C_ab − C_ba)/(σ̃_a + σ̃_b), X_aa = 0 ;  G_M = Ũ X Ṽᵀ.
+FM_HD void polar_svd3_bwd(const double* U, const double* V, const double* sig, const double* gR, double* gM) {
+  double tmp[9], c[9], x[9];
+  mat3_mul_tn(U, gR, tmp);
+  mat3_mul(tmp, V, c);
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      const double den = sig[a] + sig[b];
+      x[a * 3 + b] = (a == b || fabs(den) < 1e-300) ? 0.0 : (c[a * 3 + b] - c[b * 3 + a]) / den;
+    }
+  mat3_mul(U, x, tmp);
+  mat3_mul_nt(tmp, V, gM);
+}
+
+// General 3x3 inverse via the adjugate (Tensor.inverse() on K, projection.py:86).
+FM_HD void inv3(const float* k, float* o) {
+  const double a = k[0], b = k[1], c = k[2], d = k[3], e = k[4], f = k[5], g = k[6], h = k[7], i = k[8];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const double inv_det = 1.0 / (a * A + b * B + c * C);
+  o[0] = (float)(A * inv_det);
+  o[1] = (float)(-(b * i - c * h) * inv_det);
+  o[2] = (float)((b * f - c * e) * inv_det);
+  o[3] = (float)(B * inv_det);
+  o[4] = (float)((a * i - c * g) * inv_det);
+  o[5] = (float)(-(a * f - c * d) * inv_det);
+  o[6] = (float)(C * inv_det);
+  o[7] = (float)(-(a * h - b * g) * inv_det);
+  o[8] = (float)((a * e - b * d) * inv_det);
+}
+
+// General 4x4 inverse in double (Tensor.inverse() on poses, projection.py:46,154,176,288).
+// Returns false when singular.
+FM_HD bool inv4(const double* m, double* o) {
+  double a[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      a[r][c] = m[r * 4 + c];
+      a[r][4 + c] = r == c ? 1.0 : 0.0;
+    }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r)
+      if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+    if (a[piv][col] == 0.0) return false;
+    if (piv != col)
+      for (int c = 0; c < 8; ++c) {
+        const double tv = a[col][c];
+        a[col][c] = a[piv][c];
+        a[piv][c] = tv;
+      }
+    const double ip = 1.0 / a[col][col];
+    for (int c = 0; c < 8; ++c) a[col][c] *= ip;
+    for (int r = 0; r < 4; ++r)
+      if (r != col) {
+        const double fct = a[r][col];
+        if (fct != 0.0)
+          for (int c = 0; c < 8; ++c) a[r][c] -= fct * a[col][c];
+      }
+  }
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) o[r * 4 + c] = a[r][4 + c];
+  return true;
+}
+
+FM_HD void mat4_mul(const double* a, const double* b, double* o) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
+      o[i * 4 + j] = s;
+    }
+}
+FM_HD void mat4_mul_tn(const double* a, const double* b, double* o) {  // aᵀ b
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += a[k * 4 + i] * b[k * 4 + j];
+      o[i * 4 + j] = s;
+    }
+}
+FM_HD void mat4_mul_nt(const double* a, const double* b, double* o) {  // a bᵀ
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[j * 4 + k];
+      o[i * 4 + j] = s;
+    }
+}
+
+}  // namespace fm

@@ -1,0 +1,293 @@
+// Per-frame / per-pair small-matrix steps of the hot path (pose solve, pose chain,
+// relative poses, finalisation of the flow kernel's reductions).  Each runs in ONE
+// thread in fp64; kernels are thin wrappers (fm_procrustes.hip, fm_flow.hip) and
+// tests/host_sim calls the very same functions on the CPU.
+#pragma once
+
+#include "fm_math.h"
+
+namespace fm {
+
+constexpr int kFlowAccStride = 20;   // kFlowAcc (19) padded
+constexpr int kStatStride = 16;      // [0]=Σw [1..3]=Σw·p [4..6]=Σw·q [7..15]=M
+constexpr int kAuxStride = 32;       // U(9) V(9) sig(3) pbar(3) qbar(3) wsum(1)
+constexpr int kPairGradStride = 20;  // gM(9) gqbar(3) gpbar(3) dbar(1) inv_wsum(1)
+
+// ---- align_rigid, steps 1,4,5 (procrustes.py:23-25,35-51) -----------------------------
+//   t_bwd = [R | t]: later-camera -> earlier-camera ("inverse relative transformation",
+//   projection.py:190-197);  t_fwd = its rigid inverse [Rᵀ | −Rᵀt].
+FM_HD void pose_solve_one(const double* st, float* tb, float* tf, double* ax) {
+  const double inv = 1.0 / (st[0] + 1e-8);
+  double pbar[3], qbar[3];
+  for (int a = 0; a < 3; ++a) {
+    pbar[a] = st[1 + a] * inv;
+    qbar[a] = st[4 + a] * inv;
+  }
+  double U[9], V[9], sig[3], R[9];
+  polar_svd3(st + 7, U, V, sig);
+  mat3_mul_nt(U, V, R);
+  double t[3];
+  for (int a = 0; a < 3; ++a) t[a] = qbar[a] - (R[a * 3 + 0] * pbar[0] + R[a * 3 + 1] * pbar[1] + R[a * 3 + 2] * pbar[2]);
+  for (int a = 0; a < 3; ++a) {
+    for (int c = 0; c < 3; ++c) tb[a * 4 + c] = (float)R[a * 3 + c];
+    tb[a * 4 + 3] = (float)t[a];
+  }
+  tb[12] = tb[13] = tb[14] = 0.f;
+  tb[15] = 1.f;
+  if (tf) {
+    for (int a = 0; a < 3; ++a) {
+      for (int c = 0; c < 3; ++c) tf[a * 4 + c] = (float)R[c * 3 + a];
+      tf[a * 4 + 3] = (float)(-(R[0 * 3 + a] * t[0] + R[1 * 3 + a] * t[1] + R[2 * 3 + a] * t[2]));
+    }
+    tf[12] = tf[13] = tf[14] = 0.f;
+    tf[15] = 1.f;
+  }
+  for (int k = 0; k < 9; ++k) {
+    ax[k] = U[k];
+    ax[9 + k] = V[k];
+  }
+  for (int a = 0; a < 3; ++a) {
+    ax[18 + a] = sig[a];
+    ax[21 + a] = pbar[a];
+    ax[24 + a] = qbar[a];
+  }
+  ax[27] = st[0];
+}
+
+// Backward of pose_solve_one.  g_tb / g_tf: dL/dT_bwd, dL/dT_fwd (4x4 row-major, bottom
+// rows ignored; either may be null).  Writes gM, total centroid gradients and scalars.
+FM_HD void pose_solve_bwd_one(const float* g_tb, const float* g_tf, const float* tb, const double* ax, double* out) {
+  double R[9], t[3], gR[9], gt[3];
+  for (int a = 0; a < 3; ++a) {
+    for (int c = 0; c < 3; ++c) {
+      R[a * 3 + c] = tb[a * 4 + c];
+      gR[a * 3 + c] = g_tb ? (double)g_tb[a * 4 + c] : 0.0;
+    }
+    t[a] = tb[a * 4 + 3];
+    gt[a] = g_tb ? (double)g_tb[a * 4 + 3] : 0.0;
+  }
+  if (g_tf) {
+    // T_fwd = [Rᵀ | −Rᵀ t]:  gR += G_Rfᵀ − t·G_tfᵀ ;  gt += −R·G_tf
+    const double gtf[3] = {g_tf[3], g_tf[7], g_tf[11]};
+    for (int a = 0; a < 3; ++a) {
+      for (int c = 0; c < 3; ++c) gR[a * 3 + c] += (double)g_tf[c * 4 + a] - t[a] * gtf[c];
+      gt[a] -= R[a * 3 + 0] * gtf[0] + R[a * 3 + 1] * gtf[1] + R[a * 3 + 2] * gtf[2];
+    }
+  }
+  const double* pbar = ax + 21;
+  const double* qbar = ax + 24;
+  const double wsum = ax[27];
+  // t = q̄ − R p̄
+  double gq[3], gp[3];
+  for (int a = 0; a < 3; ++a) {
+    gq[a] = gt[a];
+    gp[a] = -(R[0 * 3 + a] * gt[0] + R[1 * 3 + a] * gt[1] + R[2 * 3 + a] * gt[2]);
+    for (int c = 0; c < 3; ++c) gR[a * 3 + c] -= gt[a] * pbar[c];
+  }
+  double gM[9];
+  polar_svd3_bwd(ax, ax + 9, ax + 18, gR, gM);
+  // centred vectors also depend on the centroids: Σ_j w_j (p_j − p̄) = 1e-8·p̄ exactly
+  const double eps = 1e-8;
+  for (int a = 0; a < 3; ++a) {
+    gq[a] -= eps * (gM[a * 3 + 0] * pbar[0] + gM[a * 3 + 1] * pbar[1] + gM[a * 3 + 2] * pbar[2]);
+    gp[a] -= eps * (gM[0 * 3 + a] * qbar[0] + gM[1 * 3 + a] * qbar[1] + gM[2 * 3 + a] * qbar[2]);
+  }
+  for (int k = 0; k < 9; ++k) out[k] = gM[k];
+  double dbar = 0;
+  for (int a = 0; a < 3; ++a) {
+    out[9 + a] = gq[a];
+    out[12 + a] = gp[a];
+    dbar += gq[a] * qbar[a] + gp[a] * pbar[a];
+  }
+  out[15] = dbar;
+  out[16] = 1.0 / (wsum + 1e-8);
+}
+
+// ---- get_extrinsics (projection.py:187-210): E_0 = I, E_k = E_{k-1}·T_{k-1} ------------
+FM_HD void pose_chain_fwd_one(const float* rel, int steps, float* e) {
+  double cur[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int k = 0; k < 16; ++k) e[k] = (float)cur[k];
+  for (int s = 0; s < steps; ++s) {
+    double t[16], nxt[16];
+    for (int k = 0; k < 16; ++k) t[k] = rel[(size_t)s * 16 + k];
+    mat4_mul(cur, t, nxt);
+    for (int k = 0; k < 16; ++k) {
+      cur[k] = nxt[k];
+      e[(size_t)(s + 1) * 16 + k] = (float)nxt[k];
+    }
+  }
+}
+
+FM_HD void pose_chain_bwd_one(const float* rel, const float* e, const float* ge, int steps, float* g_rel) {
+  double carry[16];
+  for (int k = 0; k < 16; ++k) carry[k] = ge[(size_t)steps * 16 + k];
+  for (int s = steps - 1; s >= 0; --s) {
+    double prev[16], t[16], gt[16], back[16];
+    for (int k = 0; k < 16; ++k) {
+      prev[k] = e[(size_t)s * 16 + k];
+      t[k] = rel[(size_t)s * 16 + k];
+    }
+    mat4_mul_tn(prev, carry, gt);  // dL/dT_s = E_sᵀ · G_{s+1}
+    mat4_mul_nt(carry, t, back);   // dL/dE_s += G_{s+1} · T_sᵀ
+    for (int k = 0; k < 16; ++k) {
+      g_rel[(size_t)s * 16 + k] = (float)gt[k];
+      carry[k] = back[k] + (double)ge[(size_t)s * 16 + k];
+    }
+  }
+}
+
+// ---- relative poses with a GENERAL 4x4 inverse (projection.py:154,176) -----------------
+//   fwd = inv(E1)·E0    bwd = inv(E0)·E1     (e01 points at E0; E1 follows)
+FM_HD void relative_pose_fwd_one(const float* e01, float* fwd, float* bwd) {
+  double e0[16], e1[16], inv0[16], inv1[16], o[16];
+  for (int k = 0; k < 16; ++k) {
+    e0[k] = e01[k];
+    e1[k] = e01[16 + k];
+  }
+  inv4(e0, inv0);
+  inv4(e1, inv1);
+  mat4_mul(inv1, e0, o);
+  for (int k = 0; k < 16; ++k) fwd[k] = (float)o[k];
+  mat4_mul(inv0, e1, o);
+  for (int k = 0; k < 16; ++k) bwd[k] = (float)o[k];
+}
+
+FM_HD void relative_pose_bwd_one(const float* e01, const float* g_fwd, const float* g_bwd, double* ge0, double* ge1) {
+  double e0[16], e1[16], inv0[16], inv1[16];
+  for (int k = 0; k < 16; ++k) {
+    e0[k] = e01[k];
+    e1[k] = e01[16 + k];
+    ge0[k] = ge1[k] = 0.0;
+  }
+  inv4(e0, inv0);
+  inv4(e1, inv1);
+  double g[16], tmp[16], tmp2[16];
+  if (g_fwd) {  // C = inv(E1)·E0 : dE0 += inv1ᵀ G ; dinv1 = G E0ᵀ ; dE1 += −inv1ᵀ dinv1 inv1ᵀ
+    for (int k = 0; k < 16; ++k) g[k] = g_fwd[k];
+    mat4_mul_tn(inv1, g, tmp);
+    for (int k = 0; k < 16; ++k) ge0[k] += tmp[k];
+    mat4_mul_nt(g, e0, tmp);
+    mat4_mul_tn(inv1, tmp, tmp2);
+    mat4_mul_nt(tmp2, inv1, tmp);
+    for (int k = 0; k < 16; ++k) ge1[k] -= tmp[k];
+  }
+  if (g_bwd) {  // C = inv(E0)·E1
+    for (int k = 0; k < 16; ++k) g[k] = g_bwd[k];
+    mat4_mul_tn(inv0, g, tmp);
+    for (int k = 0; k < 16; ++k) ge1[k] += tmp[k];
+    mat4_mul_nt(g, e1, tmp);
+    mat4_mul_tn(inv0, tmp, tmp2);
+    mat4_mul_nt(tmp2, inv0, tmp);
+    for (int k = 0; k < 16; ++k) ge0[k] -= tmp[k];
+  }
+}
+
+// ---- all-pairs relative poses of a track segment (projection.py:288) ---------------------
+//   rel[fs, ft] = inv(E_ft) · E_fs   for one batch element with f frames (ext: (f,4,4)).
+FM_HD void allpairs_pose_fwd_one(const float* ext, int fs, int ft, float* out) {
+  double es[16], et[16], inv[16], o[16];
+  for (int k = 0; k < 16; ++k) {
+    es[k] = ext[(size_t)fs * 16 + k];
+    et[k] = ext[(size_t)ft * 16 + k];
+  }
+  inv4(et, inv);
+  mat4_mul(inv, es, o);
+  for (int k = 0; k < 16; ++k) out[k] = (float)o[k];
+}
+
+// dL/dE_frame from dL/drel (f,f,4,4):  as source  Σ_ft inv(E_ft)ᵀ·G[frame,ft]
+//                                      as target  −inv(E_fr)ᵀ·(Σ_fs G[fs,frame]·E_fsᵀ)·inv(E_fr)ᵀ
+FM_HD void allpairs_pose_bwd_one(const float* ext, const float* g_rel, int f, int frame, float* g_ext) {
+  double acc[16], sum_t[16], e[16], inv[16], g[16], tmp[16], tmp2[16];
+  for (int k = 0; k < 16; ++k) acc[k] = sum_t[k] = 0.0;
+  for (int other = 0; other < f; ++other) {
+    for (int k = 0; k < 16; ++k) e[k] = ext[(size_t)other * 16 + k];
+    // source role: rel[frame, other] = inv(E_other)·E_frame
+    inv4(e, inv);
+    for (int k = 0; k < 16; ++k) g[k] = g_rel[((size_t)frame * f + other) * 16 + k];
+    mat4_mul_tn(inv, g, tmp);
+    for (int k = 0; k < 16; ++k) acc[k] += tmp[k];
+    // target role: rel[other, frame] = inv(E_frame)·E_other
+    for (int k = 0; k < 16; ++k) g[k] = g_rel[((size_t)other * f + frame) * 16 + k];
+    mat4_mul_nt(g, e, tmp);
+    for (int k = 0; k < 16; ++k) sum_t[k] += tmp[k];
+  }
+  for (int k = 0; k < 16; ++k) e[k] = ext[(size_t)frame * 16 + k];
+  inv4(e, inv);
+  mat4_mul_tn(inv, sum_t, tmp);
+  mat4_mul_nt(tmp, inv, tmp2);
+  for (int k = 0; k < 16; ++k) g_ext[k] = (float)(acc[k] - tmp2[k]);
+}
+
+// dK = −K⁻ᵀ · dKinv · K⁻ᵀ   (backward of Tensor.inverse(), projection.py:86)
+FM_HD void kinv_grad_to_k(const double* g, const float* ki, double* gk) {
+  double tmp[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+      for (int j = 0; j < 3; ++j) s += (double)ki[j * 3 + r] * g[j * 3 + c];
+      tmp[r * 3 + c] = s;
+    }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+      for (int j = 0; j < 3; ++j) s += tmp[r * 3 + j] * (double)ki[c * 3 + j];
+      gk[r * 3 + c] = -s;
+    }
+}
+
+// ---- flow kernel finalisation for one frame (see fm_flow.hip) ---------------------------
+// acc: (B*F, 2, kFlowAccStride) sums indexed by SOURCE frame and direction.
+FM_HD void pose_grad_from_sums(const double* a, const float* kinv, float* g_t44) {
+  // dL/dR = S · Kinvᵀ ; dL/dt = Σ g_X'
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+      for (int j = 0; j < 3; ++j) s += a[4 + r * 3 + j] * (double)kinv[c * 3 + j];
+      g_t44[r * 4 + c] = (float)s;
+    }
+    g_t44[r * 4 + 3] = (float)a[1 + r];
+  }
+  for (int c = 0; c < 4; ++c) g_t44[12 + c] = 0.f;
+}
+
+FM_HD void flow_finalize_frame(const double* acc, const float* kinv_all, const float* t_fwd, const float* t_bwd, int batch,
+                               int frames, int bf, float* g_t_fwd, float* g_t_bwd, float* g_k) {
+  (void)batch;
+  const int f = bf % frames;
+  const int b = bf / frames;
+  const double* af = acc + (size_t)bf * 2 * kFlowAccStride;
+  const double* ab = af + kFlowAccStride;
+  const float* kinv = kinv_all + (size_t)bf * 9;
+  const size_t pair_f = (size_t)b * (frames - 1) + f;
+  double gkinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (f < frames - 1) {
+    pose_grad_from_sums(af, kinv, g_t_fwd + pair_f * 16);
+    const float* t = t_fwd + pair_f * 16;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        for (int j = 0; j < 3; ++j) gkinv[r * 3 + c] += (double)t[j * 4 + r] * af[4 + j * 3 + c];  // Rᵀ·S
+  }
+  if (f > 0) {
+    pose_grad_from_sums(ab, kinv, g_t_bwd + (pair_f - 1) * 16);
+    const float* t = t_bwd + (pair_f - 1) * 16;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        for (int j = 0; j < 3; ++j) gkinv[r * 3 + c] += (double)t[j * 4 + r] * ab[4 + j * 3 + c];
+  }
+  double gk[9];
+  kinv_grad_to_k(gkinv, kinv, gk);
+  // destination role: frame f is the destination of the forward term sourced at f-1 and
+  // of the backward term sourced at f+1.
+  if (f > 0) {
+    const double* s = acc + (size_t)(bf - 1) * 2 * kFlowAccStride;
+    for (int i = 0; i < 6; ++i) gk[i] += s[13 + i];
+  }
+  if (f < frames - 1) {
+    const double* s = acc + (size_t)(bf + 1) * 2 * kFlowAccStride + kFlowAccStride;
+    for (int i = 0; i < 6; ++i) gk[i] += s[13 + i];
+  }
+  for (int i = 0; i < 9; ++i) g_k[(size_t)bf * 9 + i] = (float)gk[i];
+}
+
+}  // namespace fm

@@ -1,0 +1,441 @@
+// Weighted Procrustes pose fit between adjacent frames, pose chain, and their backward.
+//
+// Replaces align_surfaces (flowmap/model/projection.py:213-252), align_rigid
+// (flowmap/model/procrustes.py:7-51) and get_extrinsics (projection.py:187-210) plus
+// what autograd replays for them (index / grid_sampler_2d_backward / svd_backward /
+// a Python loop of F-1 matmuls).
+//
+// Forward, per frame pair i (later = i+1, earlier = i), point j with flat pixel idx_j:
+//   p_j = xyz_{i+1}[idx_j]                                   (projection.py:226-227)
+//   q_j = bilinear(xyz_i, xy[idx_j] + bwd_flow_i[idx_j])     (:231-242, border padding)
+//   w_j = weights_i[idx_j]                                    (:245-249)
+//   pass 1: Σw, Σw·p, Σw·q  -> centroids with weights/(Σw+1e-8)   (procrustes.py:23-25)
+//   pass 2: M = Σ w (q−q̄)(p−p̄)ᵀ with RAW weights                 (procrustes.py:28-32)
+//   solve : R = Ũ Ṽᵀ (in-register Jacobi, fp64), t = q̄ − R p̄     (procrustes.py:35-42)
+// xyz comes either from an explicit surfaces tensor (function-level API) or is
+// recomputed on the fly from depth and K⁻¹ (fused path: surfaces never exist in HBM).
+//
+// Backward: dL/dT -> (polar differential) dL/dM, dL/dp̄, dL/dq̄ -> per-point gradients,
+// scattered with fp32 atomics into dL/ddepth (or dL/dsurfaces) and dL/dweights; the
+// K⁻¹ gradient is block-reduced into per-frame fp64 accumulators.
+#include "fm_device.h"
+#include "fm_pose.h"
+
+namespace fm {
+
+
+struct ProcParams {
+  const float* depth;      // (B,F,H,W)            [SRC_DEPTH]
+  const float* kinv;       // (B,F,3,3)            [SRC_DEPTH]
+  const float* surfaces;   // (B,F,H,W,3)          [SRC_SURF]
+  const float* bwd_flow;   // (B,F-1,H,W,2)
+  const float* weights;    // (B,F-1,H,W)
+  const int64_t* indices;  // (P) flat pixel indices, or null for arange(H*W)
+  double* stats;           // (B*(F-1), kStatStride)
+  const double* pair_grad; // (B*(F-1), kPairGradStride)       [scatter]
+  float* grad_depth;       // (B,F,H,W)    atomically accumulated [scatter, SRC_DEPTH]
+  float* grad_surfaces;    // (B,F,H,W,3)  atomically accumulated [scatter, SRC_SURF]
+  float* grad_weights;     // (B,F-1,H,W)  atomically accumulated [scatter]
+  double* kinv_acc;        // (B*F, 9) fp64 accumulators          [scatter, SRC_DEPTH]
+  int frames, height, width;
+  long points;
+};
+
+enum { SRC_DEPTH = 0, SRC_SURF = 1 };
+
+// Per-pair view of the inputs for corr_load (fm_math.h).
+template <int SRC>
+__device__ __forceinline__ CorrSrc pair_source(const ProcParams& p, size_t pair, int b, int i) {
+  const size_t n = (size_t)p.height * p.width;
+  const size_t fe = (size_t)b * p.frames + i, fl = fe + 1;
+  CorrSrc s;
+  s.depth_e = SRC == SRC_DEPTH ? p.depth + fe * n : nullptr;
+  s.depth_l = SRC == SRC_DEPTH ? p.depth + fl * n : nullptr;
+  s.surf_e = SRC == SRC_SURF ? p.surfaces + fe * n * 3 : nullptr;
+  s.surf_l = SRC == SRC_SURF ? p.surfaces + fl * n * 3 : nullptr;
+  s.bwd_flow = p.bwd_flow + pair * n * 2;
+  s.weights = p.weights + pair * n;
+  s.height = p.height;
+  s.width = p.width;
+  return s;
+}
+
+// grid: (chunks, B*(F-1)); PASS 1 accumulates stats[0..6], PASS 2 stats[7..15].
+template <int SRC, int PASS>
+__global__ void __launch_bounds__(256) procrustes_stats_kernel(ProcParams p, int iters) {
+  __shared__ float red[4 * 9];
+  const size_t pair = blockIdx.y;
+  const int b = (int)(pair / (p.frames - 1));
+  const int i = (int)(pair % (p.frames - 1));
+  Mat3 kinv_e, kinv_l;
+  if (SRC == SRC_DEPTH) {
+    load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
+    load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
+  }
+  const CorrSrc src = pair_source<SRC>(p, pair, b, i);
+  double* st = p.stats + pair * kStatStride;
+  float pbar[3] = {0, 0, 0}, qbar[3] = {0, 0, 0};
+  if (PASS == 2) {
+    const double inv = 1.0 / (st[0] + 1e-8);
+    for (int a = 0; a < 3; ++a) {
+      pbar[a] = (float)(st[1 + a] * inv);
+      qbar[a] = (float)(st[4 + a] * inv);
+    }
+  }
+  constexpr int NV = PASS == 1 ? 7 : 9;
+  float acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+  const long base = (long)blockIdx.x * blockDim.x * iters;
+  for (int it = 0; it < iters; ++it) {
+    const long j = base + (long)it * blockDim.x + threadIdx.x;
+    if (j >= p.points) break;
+    const Corr c = corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j);
+    if (PASS == 1) {
+      acc[0] += c.w;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        acc[1 + a] += c.w * c.p[a];
+        acc[4 + a] += c.w * c.q[a];
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float wq = c.w * (c.q[a] - qbar[a]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[a * 3 + d] += wq * (c.p[d] - pbar[d]);
+      }
+    }
+  }
+  block_accumulate<NV>(acc, red, st + (PASS == 1 ? 0 : 7));
+}
+
+// ---------------------------------------------------------------------------------
+// Pose solve: one thread per pair.
+//   t_bwd[pair] = [R | t]  maps later-camera -> earlier-camera ("inverse relative
+//                 transformation", projection.py:190-197)
+//   t_fwd[pair] = its rigid inverse [Rᵀ | −Rᵀt]
+// ---------------------------------------------------------------------------------
+__global__ void pose_solve_kernel(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux) {
+  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pr >= pairs) return;
+  pose_solve_one(stats + (size_t)pr * kStatStride, t_bwd + (size_t)pr * 16, t_fwd ? t_fwd + (size_t)pr * 16 : nullptr,
+                 aux + (size_t)pr * kAuxStride);
+}
+
+// Backward of the solve.  Inputs: dL/dT_bwd and (optionally) dL/dT_fwd, 4x4 row-major,
+// bottom rows ignored.  Output per pair: gM, total centroid gradients, and the scalars
+// the per-point pass needs.
+__global__ void pose_solve_bwd_kernel(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux,
+                                      int pairs, double* pair_grad) {
+  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pr >= pairs) return;
+  pose_solve_bwd_one(g_t_bwd ? g_t_bwd + (size_t)pr * 16 : nullptr, g_t_fwd ? g_t_fwd + (size_t)pr * 16 : nullptr,
+                     t_bwd + (size_t)pr * 16, aux + (size_t)pr * kAuxStride, pair_grad + (size_t)pr * kPairGradStride);
+}
+
+// Per-point backward + scatter.  grid: (chunks, B*(F-1)).
+template <int SRC>
+__global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, const double* aux, int iters) {
+  __shared__ float red[4 * 18];
+  const size_t pair = blockIdx.y;
+  const int b = (int)(pair / (p.frames - 1));
+  const int i = (int)(pair % (p.frames - 1));
+  const int n = p.height * p.width;
+  Mat3 kinv_e, kinv_l;
+  if (SRC == SRC_DEPTH) {
+    load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
+    load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
+  }
+  const CorrSrc src = pair_source<SRC>(p, pair, b, i);
+  const double* pg = p.pair_grad + pair * kPairGradStride;
+  const double* ax = aux + pair * kAuxStride;
+  PairGrad g;
+  for (int k = 0; k < 9; ++k) g.gM[k] = (float)pg[k];
+  for (int a = 0; a < 3; ++a) {
+    g.gqbar[a] = (float)pg[9 + a];
+    g.gpbar[a] = (float)pg[12 + a];
+    g.pbar[a] = (float)ax[21 + a];
+    g.qbar[a] = (float)ax[24 + a];
+  }
+  g.dbar = (float)pg[15];
+  g.inv_wsum = (float)pg[16];
+  const size_t fe = (size_t)b * p.frames + i, fl = fe + 1;
+
+  float acc[18];  // [0..8] dKinv later frame, [9..17] dKinv earlier frame
+#pragma unroll
+  for (int k = 0; k < 18; ++k) acc[k] = 0.f;
+
+  const long base = (long)blockIdx.x * blockDim.x * iters;
+  for (int it = 0; it < iters; ++it) {
+    const long j = base + (long)it * blockDim.x + threadIdx.x;
+    if (j >= p.points) break;
+    const Corr c = corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j);
+    float gq[3], gp[3], gw;
+    corr_backward(c, g, gq, gp, gw);
+    if (p.grad_weights) atomicAdd(p.grad_weights + pair * (size_t)n + c.idx, gw);
+    if (SRC == SRC_DEPTH) {
+      const int row = c.idx / p.width, col = c.idx - row * p.width;
+      const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
+      if (p.grad_depth) atomicAdd(p.grad_depth + fl * n + c.idx, gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2]);
+      const float zh[3] = {c.z_p * u, c.z_p * v, c.z_p};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[a * 3 + d] += gp[a] * zh[d];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!c.taps.in[k]) continue;
+        const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
+        const float ut = pixel_center(tc, p.width), vt = pixel_center(tr, p.height);
+        const float z = p.depth[fe * n + tr * p.width + tc];
+        float ray[3];
+        ray_dir(kinv_e, ut, vt, ray);
+        const float wt = c.taps.w[k];
+        if (p.grad_depth) atomicAdd(p.grad_depth + fe * n + tr * p.width + tc, wt * (gq[0] * ray[0] + gq[1] * ray[1] + gq[2] * ray[2]));
+        const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) acc[9 + a * 3 + d] += gq[a] * zt[d];
+      }
+    } else {
+      if (p.grad_surfaces) {
+        float* gl = p.grad_surfaces + (fl * n + c.idx) * 3;
+        atomicAdd(gl + 0, gp[0]);
+        atomicAdd(gl + 1, gp[1]);
+        atomicAdd(gl + 2, gp[2]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!c.taps.in[k]) continue;
+          float* ge = p.grad_surfaces + (fe * n + tap_row(c.taps, k) * p.width + tap_col(c.taps, k)) * 3;
+          atomicAdd(ge + 0, gq[0] * c.taps.w[k]);
+          atomicAdd(ge + 1, gq[1] * c.taps.w[k]);
+          atomicAdd(ge + 2, gq[2] * c.taps.w[k]);
+        }
+      }
+    }
+  }
+  if (SRC == SRC_DEPTH && p.kinv_acc) {
+    // later-frame and earlier-frame accumulators are adjacent rows of kinv_acc:
+    // (fe)*9 = earlier, (fl)*9 = later  ->  reorder so one call covers 18 contiguous values
+    float ordered[18];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      ordered[k] = acc[9 + k];
+      ordered[9 + k] = acc[k];
+    }
+    block_accumulate<18>(ordered, red, p.kinv_acc + fe * 9);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Pose chain (get_extrinsics): E_0 = I, E_k = E_{k-1} · T_{k-1}.  One thread per batch
+// element walks the chain in fp64 (F ≤ a few thousand; latency ≈ tens of µs, replacing
+// F-1 dependent matmul launches).  Backward is the reverse scan.
+// ---------------------------------------------------------------------------------
+__global__ void pose_chain_fwd_kernel(const float* rel, int batch, int steps, float* ext) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  pose_chain_fwd_one(rel + (size_t)b * steps * 16, steps, ext + (size_t)b * (steps + 1) * 16);
+}
+
+__global__ void pose_chain_bwd_kernel(const float* rel, const float* ext, const float* g_ext, int batch, int steps,
+                                      float* g_rel) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  pose_chain_bwd_one(rel + (size_t)b * steps * 16, ext + (size_t)b * (steps + 1) * 16, g_ext + (size_t)b * (steps + 1) * 16,
+                     steps, g_rel + (size_t)b * steps * 16);
+}
+
+// ---------------------------------------------------------------------------------
+// Relative poses from camera-to-world extrinsics with a GENERAL 4x4 inverse, exactly
+// as the reference writes them (projection.py:154,176):
+//   fwd[i] = inv(E_{i+1}) · E_i       bwd[i] = inv(E_i) · E_{i+1}
+// and their backward  dE = −A⁻ᵀ·G·A⁻ᵀ  /  Aᵀ-products.  One thread per pair.
+// ---------------------------------------------------------------------------------
+__global__ void relative_pose_fwd_kernel(const float* ext, int batch, int frames, float* fwd, float* bwd) {
+  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pairs = batch * (frames - 1);
+  if (pr >= pairs) return;
+  const int b = pr / (frames - 1), i = pr % (frames - 1);
+  relative_pose_fwd_one(ext + ((size_t)b * frames + i) * 16, fwd + (size_t)pr * 16, bwd + (size_t)pr * 16);
+}
+
+// g_ext must be zero-initialised; adjacent pairs touch the same frame -> atomics.
+__global__ void relative_pose_bwd_kernel(const float* ext, const float* g_fwd, const float* g_bwd, int batch, int frames,
+                                         float* g_ext) {
+  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pairs = batch * (frames - 1);
+  if (pr >= pairs) return;
+  const int b = pr / (frames - 1), i = pr % (frames - 1);
+  double ge0[16], ge1[16];
+  relative_pose_bwd_one(ext + ((size_t)b * frames + i) * 16, g_fwd ? g_fwd + (size_t)pr * 16 : nullptr,
+                        g_bwd ? g_bwd + (size_t)pr * 16 : nullptr, ge0, ge1);
+  float* o0 = g_ext + ((size_t)b * frames + i) * 16;
+  for (int k = 0; k < 16; ++k) {
+    atomicAdd(o0 + k, (float)ge0[k]);
+    atomicAdd(o0 + 16 + k, (float)ge1[k]);
+  }
+}
+
+// All-pairs relative poses inside a track segment: rel (B,f,f,4,4), one thread each.
+__global__ void allpairs_pose_fwd_kernel(const float* ext, int batch, int f, float* rel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * f * f) return;
+  const int b = i / (f * f), r = i % (f * f);
+  allpairs_pose_fwd_one(ext + (size_t)b * f * 16, r / f, r % f, rel + (size_t)i * 16);
+}
+
+__global__ void allpairs_pose_bwd_kernel(const float* ext, const float* g_rel, int batch, int f, float* g_ext) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * f) return;
+  const int b = i / f;
+  allpairs_pose_bwd_one(ext + (size_t)b * f * 16, g_rel + (size_t)b * f * f * 16, f, i % f, g_ext + (size_t)i * 16);
+}
+
+// K⁻¹ for every frame, and the map of a K⁻¹ gradient (fp64 accumulators) back to K:
+//   dK += −K⁻ᵀ · dKinv · K⁻ᵀ
+__global__ void inv3_kernel(const float* k, int count, float* kinv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) inv3(k + (size_t)i * 9, kinv + (size_t)i * 9);
+}
+
+__global__ void kinv_grad_to_k_kernel(const double* kinv_acc, const float* kinv, int count, float* g_k, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double gk[9];
+  kinv_grad_to_k(kinv_acc + (size_t)i * 9, kinv + (size_t)i * 9, gk);
+  for (int e = 0; e < 9; ++e) {
+    float* o = g_k + (size_t)i * 9 + e;
+    *o = (accumulate ? *o : 0.f) + (float)gk[e];
+  }
+}
+
+}  // namespace fm
+
+using namespace fm;
+
+static inline int choose_iters(long points) {
+  // enough blocks to fill the chip when P = H*W, a single block when P is ~1000
+  if (points <= 256 * 4) return (int)((points + 255) / 256);
+  return 8;
+}
+
+extern "C" {
+
+int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                        const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
+                        int width, double* stats, void* stream) {
+  FM_CHECK_ARG((depth && kinv) || surfaces);
+  FM_CHECK_ARG(bwd_flow && weights && stats && points >= 1 && batch >= 1 && frames >= 2);
+  FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
+  hipStream_t st = (hipStream_t)stream;
+  const int pairs = batch * (frames - 1);
+  if (hipMemsetAsync(stats, 0, sizeof(double) * (size_t)pairs * kStatStride, st) != hipSuccess) return FM_ERR_LAUNCH;
+  ProcParams p{};
+  p.depth = depth; p.kinv = kinv; p.surfaces = surfaces; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
+  p.stats = stats; p.frames = frames; p.height = height; p.width = width; p.points = points;
+  const int iters = choose_iters(points);
+  dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
+  if (surfaces) {
+    hipLaunchKernelGGL((procrustes_stats_kernel<SRC_SURF, 1>), grid, dim3(256), 0, st, p, iters);
+    hipLaunchKernelGGL((procrustes_stats_kernel<SRC_SURF, 2>), grid, dim3(256), 0, st, p, iters);
+  } else {
+    hipLaunchKernelGGL((procrustes_stats_kernel<SRC_DEPTH, 1>), grid, dim3(256), 0, st, p, iters);
+    hipLaunchKernelGGL((procrustes_stats_kernel<SRC_DEPTH, 2>), grid, dim3(256), 0, st, p, iters);
+  }
+  FM_LAUNCH_STATUS();
+}
+
+int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux, void* stream) {
+  FM_CHECK_ARG(stats && t_bwd && aux && pairs >= 1);
+  hipLaunchKernelGGL(pose_solve_kernel, dim3((pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, pairs, t_bwd, t_fwd, aux);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux, int pairs,
+                      double* pair_grad, void* stream) {
+  FM_CHECK_ARG(t_bwd && aux && pair_grad && pairs >= 1);
+  hipLaunchKernelGGL(pose_solve_bwd_kernel, dim3((pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, g_t_bwd, g_t_fwd, t_bwd,
+                     aux, pairs, pair_grad);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                          const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
+                          int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
+                          float* grad_weights, double* kinv_acc, void* stream) {
+  FM_CHECK_ARG((depth && kinv) || surfaces);
+  FM_CHECK_ARG(bwd_flow && weights && aux && pair_grad && points >= 1);
+  hipStream_t st = (hipStream_t)stream;
+  const int pairs = batch * (frames - 1);
+  ProcParams p{};
+  p.depth = depth; p.kinv = kinv; p.surfaces = surfaces; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
+  p.pair_grad = pair_grad; p.grad_depth = grad_depth; p.grad_surfaces = grad_surfaces; p.grad_weights = grad_weights;
+  p.kinv_acc = kinv_acc; p.frames = frames; p.height = height; p.width = width; p.points = points;
+  const int iters = choose_iters(points);
+  dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
+  if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);
+  else hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, aux, iters);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_pose_chain_fwd(const float* rel, int batch, int steps, float* ext, void* stream) {
+  FM_CHECK_ARG(rel && ext && batch >= 1 && steps >= 0);
+  hipLaunchKernelGGL(pose_chain_fwd_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, rel, batch, steps, ext);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_pose_chain_bwd(const float* rel, const float* ext, const float* g_ext, int batch, int steps, float* g_rel, void* stream) {
+  FM_CHECK_ARG(rel && ext && g_ext && g_rel && batch >= 1 && steps >= 0);
+  hipLaunchKernelGGL(pose_chain_bwd_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, rel, ext, g_ext, batch,
+                     steps, g_rel);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_relative_pose_fwd(const float* ext, int batch, int frames, float* fwd, float* bwd, void* stream) {
+  FM_CHECK_ARG(ext && fwd && bwd && batch >= 1 && frames >= 2);
+  const int pairs = batch * (frames - 1);
+  hipLaunchKernelGGL(relative_pose_fwd_kernel, dim3((pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, ext, batch, frames, fwd, bwd);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_relative_pose_bwd(const float* ext, const float* g_fwd, const float* g_bwd, int batch, int frames, float* g_ext,
+                         void* stream) {
+  FM_CHECK_ARG(ext && g_ext && batch >= 1 && frames >= 2);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(g_ext, 0, sizeof(float) * (size_t)batch * frames * 16, st) != hipSuccess) return FM_ERR_LAUNCH;
+  const int pairs = batch * (frames - 1);
+  hipLaunchKernelGGL(relative_pose_bwd_kernel, dim3((pairs + 63) / 64), dim3(64), 0, st, ext, g_fwd, g_bwd, batch, frames, g_ext);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_allpairs_pose_fwd(const float* ext, int batch, int frames, float* rel, void* stream) {
+  FM_CHECK_ARG(ext && rel && batch >= 1 && frames >= 1);
+  const int n = batch * frames * frames;
+  hipLaunchKernelGGL(allpairs_pose_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, ext, batch, frames, rel);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_allpairs_pose_bwd(const float* ext, const float* g_rel, int batch, int frames, float* g_ext, void* stream) {
+  FM_CHECK_ARG(ext && g_rel && g_ext && batch >= 1 && frames >= 1);
+  const int n = batch * frames;
+  hipLaunchKernelGGL(allpairs_pose_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, ext, g_rel, batch, frames, g_ext);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_intrinsics_inverse(const float* k, int count, float* kinv, void* stream) {
+  FM_CHECK_ARG(k && kinv && count >= 1);
+  hipLaunchKernelGGL(inv3_kernel, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, k, count, kinv);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_intrinsics_inverse_bwd(const double* kinv_acc, const float* kinv, int count, float* g_k, int accumulate, void* stream) {
+  FM_CHECK_ARG(kinv_acc && kinv && g_k && count >= 1);
+  hipLaunchKernelGGL(kinv_grad_to_k_kernel, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, kinv_acc, kinv, count, g_k,
+                     accumulate);
+  FM_LAUNCH_STATUS();
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+"""Rebind an importable reference ``flowmap`` package to the HIP implementations.
+
+The reference dispatches by registry (``LOSSES[cfg.name]``, ``EXTRINSICS[cfg.name]``)
+and by names bound at import time (``from ..model.projection import unproject``), so
+both have to be patched.  After ``install()``, an unmodified
+``python -m flowmap.overfit`` runs its hot path on the kernels of this package.
+"""
+
+from __future__ import annotations
+
+import importlib
+from typing import Dict, List, Tuple
+
+_saved: List[Tuple[object, str, object]] = []
+
+# module -> names it bound with ``from ..model.projection import ...`` (file:line)
+_IMPORT_SITES: Dict[str, Tuple[str, ...]] = {
+    "flowmap.model.model": ("sample_image_grid", "unproject"),  # model/model.py:13
+    "flowmap.model.extrinsics.extrinsics_procrustes": ("align_surfaces",),  # extrinsics_procrustes.py:11
+    "flowmap.model.extrinsics.extrinsics_regressed": ("get_extrinsics",),  # extrinsics_regressed.py:12
+    "flowmap.model.intrinsics.intrinsics_softmin": (  # intrinsics_softmin.py:13-18
+        "align_surfaces", "compute_backward_flow", "sample_image_grid", "unproject",
+    ),
+    "flowmap.loss.loss_flow": ("compute_backward_flow", "compute_forward_flow", "sample_image_grid"),  # loss_flow.py:10-14
+    "flowmap.loss.loss_tracking": ("compute_track_flow",),  # loss_tracking.py:11
+    "flowmap.visualization.visualizer_summary": ("compute_backward_flow", "compute_forward_flow"),  # visualizer_summary.py:13
+    "flowmap.model.projection": ("align_rigid",),  # projection.py:8
+}
+
+
+def _set(obj, name, value):
+    _saved.append((obj, name, getattr(obj, name, None)))
+    setattr(obj, name, value)
+
+
+def install(lazy_surfaces: bool = True) -> None:
+    """Patch the reference in place.  ``lazy_surfaces=True`` additionally lets
+    ``Model.forward``'s ``unproject`` hand a LazySurfaces to the fused consumers."""
+    from . import loss as our_loss
+    from .loss import mapping as our_mapping
+    from .model import procrustes as our_procrustes
+    from .model import projection as our_projection
+    from .model.extrinsics_procrustes import ExtrinsicsProcrustes
+
+    if _saved:
+        uninstall()
+
+    ref_projection = importlib.import_module("flowmap.model.projection")
+    ref_procrustes = importlib.import_module("flowmap.model.procrustes")
+    public = [n for n in dir(our_projection) if not n.startswith("_") and hasattr(ref_projection, n) and callable(getattr(our_projection, n))]
+    for name in public:
+        _set(ref_projection, name, getattr(our_projection, name))
+    _set(ref_procrustes, "align_rigid", our_procrustes.align_rigid)
+
+    for mod_name, names in _IMPORT_SITES.items():
+        try:
+            mod = importlib.import_module(mod_name)
+        except Exception:  # optional dependency of that module is absent (e.g. flow_vis_torch)
+            continue
+        for name in names:
+            src = our_procrustes if name == "align_rigid" else our_projection
+            _set(mod, name, getattr(src, name))
+
+    ref_loss = importlib.import_module("flowmap.loss")
+    _set(ref_loss, "LOSSES", {**ref_loss.LOSSES, "flow": our_loss.LossFlow, "tracking": our_loss.LossTracking})
+    ref_mapping = importlib.import_module("flowmap.loss.mapping")
+    _set(ref_mapping, "MAPPINGS", {**ref_mapping.MAPPINGS, **our_mapping.MAPPINGS})
+    ref_extr = importlib.import_module("flowmap.model.extrinsics")
+    _set(ref_extr, "EXTRINSICS", {**ref_extr.EXTRINSICS, "procrustes": ExtrinsicsProcrustes})
+
+    our_projection.set_lazy_surfaces(lazy_surfaces)
+
+
+def uninstall() -> None:
+    from .model import projection as our_projection
+
+    while _saved:
+        obj, name, old = _saved.pop()
+        setattr(obj, name, old)
+    our_projection.set_lazy_surfaces(False)

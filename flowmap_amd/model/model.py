@@ -1,0 +1,122 @@
+"""Caller glue of the hot path: a mirror of flowmap/model/model.py:41-90 with the two
+parameter-only front ends the benchmarks use (BackboneExplicitDepth,
+IntrinsicsRegressed).  These modules are NOT part of the accelerated path — they are
+the thinnest possible PyTorch producers of its inputs, kept so that bench.py, the tests
+and `smoke()` drive the kernels exactly the way ``ModelWrapperOverfit.training_step``
+(model_wrapper_overfit.py:51-62) drives the reference.  An unmodified reference
+``Model`` works too after ``flowmap_amd.install()``.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Literal, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from ..types import BackboneOutput, ModelOutput
+from .extrinsics_procrustes import ExtrinsicsProcrustes, ExtrinsicsProcrustesCfg
+from .projection import sample_image_grid, unproject
+
+
+def focal_lengths_to_intrinsics(focal_lengths: Tensor, image_shape: Tuple[int, int]) -> Tensor:
+    """flowmap/model/intrinsics/common.py:6-20"""
+    device = focal_lengths.device
+    h, w = image_shape
+    focal_lengths = focal_lengths * (h * w) ** 0.5
+    intrinsics = torch.eye(3, dtype=torch.float32, device=device)
+    intrinsics[:2, 2] = 0.5
+    intrinsics = intrinsics.broadcast_to((*focal_lengths.shape, 3, 3)).contiguous()
+    intrinsics[..., 0, 0] = focal_lengths / w  # fx
+    intrinsics[..., 1, 1] = focal_lengths / h  # fy
+    return intrinsics
+
+
+@dataclass
+class BackboneExplicitDepthCfg:
+    """flowmap/model/backbone/backbone_explicit_depth.py:12-16"""
+
+    name: Literal["explicit_depth"]
+    initial_depth: float
+    weight_sensitivity: float
+
+
+class BackboneExplicitDepth(nn.Module):
+    """flowmap/model/backbone/backbone_explicit_depth.py:19-41: depth and correspondence-
+    weight logits as free parameters."""
+
+    def __init__(self, cfg: BackboneExplicitDepthCfg, num_frames: int, image_shape: Tuple[int, int]) -> None:
+        super().__init__()
+        self.cfg = cfg
+        self.depth = nn.Parameter(torch.full((num_frames, *image_shape), cfg.initial_depth, dtype=torch.float32))
+        self.weights = nn.Parameter(torch.full((num_frames - 1, *image_shape), 0, dtype=torch.float32))
+
+    def forward(self, batch, flows) -> BackboneOutput:
+        b = batch.videos.shape[0]
+        assert b == 1
+        return BackboneOutput(self.depth[None], (self.cfg.weight_sensitivity * self.weights).sigmoid()[None])
+
+
+@dataclass
+class IntrinsicsRegressedCfg:
+    """flowmap/model/intrinsics/intrinsics_regressed.py:16-19"""
+
+    name: Literal["regressed"]
+    initial_focal_length: float
+
+
+class IntrinsicsRegressed(nn.Module):
+    """flowmap/model/intrinsics/intrinsics_regressed.py:22-41"""
+
+    def __init__(self, cfg: IntrinsicsRegressedCfg) -> None:
+        super().__init__()
+        self.cfg = cfg
+        self.focal_length = nn.Parameter(torch.full(tuple(), cfg.initial_focal_length, dtype=torch.float32))
+
+    def forward(self, batch, flows, backbone_output, global_step: int) -> Tensor:
+        b, f, _, h, w = batch.videos.shape
+        intrinsics = focal_lengths_to_intrinsics(self.focal_length, (h, w))
+        return intrinsics.expand(b, f, 3, 3)
+
+
+@dataclass
+class ModelCfg:
+    """flowmap/model/model.py:16-21"""
+
+    backbone: BackboneExplicitDepthCfg
+    intrinsics: IntrinsicsRegressedCfg
+    extrinsics: ExtrinsicsProcrustesCfg
+    use_correspondence_weights: bool = True
+
+
+class Model(nn.Module):
+    """flowmap/model/model.py:41-90"""
+
+    def __init__(self, cfg: ModelCfg, num_frames: Optional[int] = None, image_shape: Optional[Tuple[int, int]] = None) -> None:
+        super().__init__()
+        self.cfg = cfg
+        self.backbone = BackboneExplicitDepth(cfg.backbone, num_frames, image_shape)
+        self.intrinsics = IntrinsicsRegressed(cfg.intrinsics)
+        self.extrinsics = ExtrinsicsProcrustes(cfg.extrinsics, num_frames)
+
+    def forward(self, batch, flows, global_step: int) -> ModelOutput:
+        device = batch.videos.device
+        _, _, _, h, w = batch.videos.shape
+
+        # Run the backbone, which provides depths and correspondence weights.
+        backbone_out = self.backbone.forward(batch, flows)
+        if not self.cfg.use_correspondence_weights:
+            backbone_out.weights = torch.ones_like(backbone_out.weights)
+
+        # Compute the intrinsics.
+        intrinsics = self.intrinsics.forward(batch, flows, backbone_out, global_step)
+
+        # Use the intrinsics to calculate camera-space surfaces (lazy when enabled).
+        xy, _ = sample_image_grid((h, w), device=device)
+        surfaces = unproject(xy, backbone_out.depths, intrinsics[:, :, None, None])
+
+        # Finally, compute the extrinsics.
+        extrinsics = self.extrinsics.forward(batch, flows, backbone_out, surfaces)
+
+        return ModelOutput(backbone_out.depths, surfaces, intrinsics, extrinsics, backbone_out.weights)

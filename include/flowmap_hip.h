@@ -1,0 +1,177 @@
+/* flowmap_hip.h — C ABI of libflowmap_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for FlowMap's per-iteration reprojection / flow-consistency
+ * inner loop.  The reference (dcharatan/flowmap) has NO native layer: the path is a
+ * Python call surface (flowmap/model/projection.py, flowmap/model/procrustes.py,
+ * flowmap/loss/**) executed as chains of ATen ops.  Each entry point below replaces
+ * one such chain; the citation names the reference code it stands in for.  The
+ * Python host mirror (flowmap_amd/) binds these through ctypes and re-exposes the
+ * reference's function / class names; INTEGRATION.md shows the binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major fp32 data unless
+ *     stated otherwise (double = fp64 workspace, int64_t = index tensors);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call
+ *     is asynchronous on that stream, never synchronises, never allocates;
+ *   - return value: 0 ok, 1 invalid argument, 2 launch/runtime failure.  Nothing
+ *     throws across the boundary;
+ *   - B batch, F frames, H×W pixels, N = H·W, P Procrustes points, pair i = frames
+ *     (i, i+1); poses are 4×4 row-major, intrinsics 3×3 row-major, normalised image
+ *     coordinates (x right, y down, both in (0,1)).
+ */
+#ifndef FLOWMAP_HIP_H
+#define FLOWMAP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FM_MAPPING_HUBER 0 /* flowmap/loss/mapping/mapping_huber.py:18-34 */
+#define FM_MAPPING_L1 1    /* flowmap/loss/mapping/mapping_l1.py:15-20 */
+#define FM_MAPPING_L2 2    /* flowmap/loss/mapping/mapping_l2.py:15-21 */
+
+#define FM_FLOW_ACC_STRIDE 20  /* doubles per (frame, direction) in `acc` */
+#define FM_STAT_STRIDE 16      /* doubles per pair in `stats` */
+#define FM_AUX_STRIDE 32       /* doubles per pair in `aux` */
+#define FM_PAIR_GRAD_STRIDE 20 /* doubles per pair in `pair_grad` */
+
+/* ---------------------------------------------------------------------------------
+ * Fused flow loss (the roofline kernel).
+ * Replaces LossFlow.compute_unweighted_loss (flowmap/loss/loss_flow.py:31-70) with
+ * everything under it — unproject (projection.py:76-90), compute_forward_flow /
+ * compute_backward_flow (projection.py:143-184), reproject_points (:116-134),
+ * project_camera_space (:49-58), Mapping.forward (loss/mapping/mapping.py:35-43) —
+ * AND the autograd backward of that chain, in one pass over HBM.
+ *
+ *   depth (B,F,H,W); k, kinv (B,F,3,3); t_fwd (B,F-1,4,4) camera i -> camera i+1;
+ *   t_bwd (B,F-1,4,4) camera i+1 -> camera i; flow_* (B,F-1,H,W,2); mask_* (B,F-1,H,W).
+ *   scale: device scalar multiplied into every residual's gradient (weight/valid_sum
+ *          from fm_flow_valid_norm); NULL = loss only, no gradients.
+ *   grad_depth (B,F,H,W) out: dL/ddepth with poses held fixed (may be NULL).
+ *   acc (B*F, 2, FM_FLOW_ACC_STRIDE) fp64 out: per (source frame, direction) sums,
+ *          zeroed by this call, consumed by fm_flow_loss_finalize.
+ *   items_per_thread: tuning knob (<=0 -> default).
+ */
+int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                       const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
+                       const float* scale, int batch, int frames, int height, int width, int mapping_kind, float delta,
+                       float aspect_x, float aspect_y, float* grad_depth, double* acc, int items_per_thread, void* stream);
+
+/* Turns `acc` into: loss[0] = norm[0]·Σρm (loss.py:47 weight and loss_flow.py:70
+ * normalisation folded into norm[0]); g_t_fwd / g_t_bwd (B,F-1,4,4) = dL/dT (bottom
+ * rows 0); g_k (B,F,3,3) = dL/dK through both the projection (rows 0,1) and K⁻¹. */
+int fm_flow_loss_finalize(const double* acc, const float* kinv, const float* t_fwd, const float* t_bwd, const float* norm,
+                          int batch, int frames, float* loss, float* g_t_fwd, float* g_t_bwd, float* g_k, void* stream);
+
+/* valid_sum of loss_flow.py:56,66,70: vsum[0] = Σmask_fwd + Σmask_bwd (fp64);
+ * norm[0] = weight / (vsum or 1), norm[1] = (vsum or 1).  `count` = elements per mask. */
+int fm_flow_valid_norm(const float* mask_fwd, const float* mask_bwd, long count, float weight, double* vsum, float* norm,
+                       void* stream);
+
+/* x[i] *= scalar[0] unless scalar[0] == 1 (autograd's grad_output at the root). */
+int fm_scale_if_needed(float* x, long count, const float* scalar, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Procrustes pose fit.  Replaces align_surfaces (projection.py:213-252) +
+ * align_rigid (flowmap/model/procrustes.py:7-51) and their backward.
+ * Exactly one source must be given: (depth, kinv) — xyz recomputed on the fly — or
+ * `surfaces` (B,F,H,W,3).  indices (P) int64 flat pixel indices, NULL = arange(N).
+ * stats (B*(F-1), FM_STAT_STRIDE) fp64 out: Σw, Σw·p, Σw·q, covariance.
+ */
+int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                        const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
+                        int width, double* stats, void* stream);
+
+/* procrustes.py:35-51: R = U·diag(1,1,±1)·Vᵀ by in-register 3×3 SVD, t = q̄ − R·p̄.
+ * t_bwd (pairs,4,4) = [R|t] ("inverse relative transformation", later -> earlier
+ * camera); t_fwd (pairs,4,4) = its inverse (may be NULL); aux (pairs, FM_AUX_STRIDE). */
+int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux, void* stream);
+
+/* Backward of fm_pose_solve (replaces linalg_svd_backward et al.).  g_t_bwd / g_t_fwd
+ * (pairs,4,4) may be NULL.  pair_grad (pairs, FM_PAIR_GRAD_STRIDE) fp64 out. */
+int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux, int pairs,
+                      double* pair_grad, void* stream);
+
+/* Per-point backward (replaces grid_sampler_2d_backward + index_put of
+ * projection.py:226-249).  ATOMICALLY ADDS into grad_depth (B,F,H,W) or grad_surfaces
+ * (B,F,H,W,3) and grad_weights (B,F-1,H,W): callers zero them (or pass a buffer that
+ * already holds another gradient to fuse the accumulation).  kinv_acc (B*F,9) fp64:
+ * dL/dK⁻¹ accumulators (caller zeroes), depth source only.  Any output may be NULL. */
+int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                          const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
+                          int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
+                          float* grad_weights, double* kinv_acc, void* stream);
+
+/* get_extrinsics (projection.py:187-210): ext (B,steps+1,4,4), ext[0]=I,
+ * ext[k] = ext[k-1]·rel[k-1]; and its backward (replaces the Python loop of matmuls). */
+int fm_pose_chain_fwd(const float* rel, int batch, int steps, float* ext, void* stream);
+int fm_pose_chain_bwd(const float* rel, const float* ext, const float* g_ext, int batch, int steps, float* g_rel, void* stream);
+
+/* later(E).inverse() @ earlier(E) and earlier(E).inverse() @ later(E)
+ * (projection.py:154,176) with a general 4×4 inverse, and the backward (g_ext is
+ * overwritten; g_fwd / g_bwd may be NULL). */
+int fm_relative_pose_fwd(const float* ext, int batch, int frames, float* fwd, float* bwd, void* stream);
+int fm_relative_pose_bwd(const float* ext, const float* g_fwd, const float* g_bwd, int batch, int frames, float* g_ext,
+                         void* stream);
+
+/* extrinsics_target.inverse() @ extrinsics_source for every (source, target) pair of a
+ * track segment (projection.py:288): ext (B,f,4,4) -> rel (B,f,f,4,4) indexed
+ * [b, source, target]; backward g_rel -> g_ext (overwritten). */
+int fm_allpairs_pose_fwd(const float* ext, int batch, int frames, float* rel, void* stream);
+int fm_allpairs_pose_bwd(const float* ext, const float* g_rel, int batch, int frames, float* g_ext, void* stream);
+
+/* intrinsics.inverse() of unproject (projection.py:86) for `count` 3×3 matrices, and
+ * g_k (+)= −K⁻ᵀ·kinv_acc·K⁻ᵀ. */
+int fm_intrinsics_inverse(const float* k, int count, float* kinv, void* stream);
+int fm_intrinsics_inverse_bwd(const double* kinv_acc, const float* kinv, int count, float* g_k, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Function-level building blocks on explicit point sets (the standalone call surface
+ * used by the visualiser, IntrinsicsSoftmin and the exporters).  G = number of groups
+ * (one small matrix per group), `points` = points per group.
+ */
+
+/* unproject (projection.py:76-90): out (G,points,3) = (kinv_g·[x,y,1])·z.
+ * xy is (G,points,2) with xy_group_stride = points*2, or one shared (points,2) grid
+ * with xy_group_stride = 0.  bwd: g_z (G,points), kinv_acc (G,9) fp64 (zeroed here). */
+int fm_unproject_fwd(const float* xy, long xy_group_stride, const float* z, const float* kinv, int groups, long points,
+                     float* out, void* stream);
+int fm_unproject_bwd(const float* xy, long xy_group_stride, const float* z, const float* kinv, const float* g_out, int groups,
+                     long points, float* g_z, double* kinv_acc, void* stream);
+
+/* reproject_points (projection.py:116-134) with project_camera_space (:49-58):
+ * xyz (G,points,3), t (G,4,4), k (G,3,3) -> xy (G,points,2).  bwd: g_xyz (nullable),
+ * g_t (G,4,4) bottom row 0, g_k (G,3,3) bottom row 0; acc (G,18) fp64 workspace. */
+int fm_reproject_fwd(const float* xyz, const float* t, const float* k, int groups, long points, float* xy, void* stream);
+int fm_reproject_bwd(const float* xyz, const float* t, const float* k, const float* g_xy, int groups, long points, float* g_xyz,
+                     float* g_t, float* g_k, double* acc, void* stream);
+
+/* F.grid_sample(mode="bilinear", padding_mode="border", align_corners=False) as used
+ * at projection.py:235-241,266-272: img (G,H,W,C) channels-last, xy (G,points,2) in
+ * (0,1) -> out (G,points,C).  bwd ATOMICALLY ADDS into g_img (caller zeroes). */
+int fm_bilinear_sample_fwd(const float* img, const float* xy, int groups, int height, int width, int channels, long points,
+                           float* out, void* stream);
+int fm_bilinear_sample_bwd(const float* g_out, const float* xy, int groups, int height, int width, int channels, long points,
+                           float* g_img, void* stream);
+
+/* Mapping.forward (loss/mapping/mapping.py:35-43) with huber / l1 / l2:
+ * a, b (count,2) -> out (count);  bwd: g_a, g_b (count,2), either nullable. */
+int fm_mapping_fwd(const float* a, const float* b, long count, int kind, float delta, float aspect_x, float aspect_y, float* out,
+                   void* stream);
+int fm_mapping_bwd(const float* a, const float* b, const float* g_out, long count, int kind, float delta, float aspect_x,
+                   float aspect_y, float* g_a, float* g_b, void* stream);
+
+/* align_rigid (procrustes.py:7-51) on explicit p, q (G,points,3), w (G,points):
+ * statistics for fm_pose_solve, and the per-point backward given fm_pose_solve_bwd's
+ * pair_grad. */
+int fm_align_rigid_stats(const float* p, const float* q, const float* w, int groups, long points, double* stats, void* stream);
+int fm_align_rigid_bwd(const float* p, const float* q, const float* w, int groups, long points, const double* aux,
+                       const double* pair_grad, float* g_p, float* g_q, float* g_w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWMAP_HIP_H */

@@ -32,7 +32,8 @@ def load_golden(name):
 
 
 def t(a, dtype=None, device="cpu"):
-    x = torch.from_numpy(np.ascontiguousarray(a))
+    a = np.asarray(a)
+    x = torch.from_numpy(np.ascontiguousarray(a)).reshape(a.shape)
     if dtype is not None and x.is_floating_point():
         x = x.to(dtype)
     return x.to(device)

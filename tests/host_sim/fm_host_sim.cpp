@@ -1,0 +1,527 @@
+// TEST INFRASTRUCTURE ONLY — never shipped, never loaded by the product path.
+//
+// A serial CPU build of the SAME per-element math the HIP kernels run
+// (flowmap_amd/csrc/fm_math.h, fm_pose.h), exported under the same C ABI
+// (include/flowmap_hip.h).  tests/ inject it with
+// `flowmap_amd._lib.set_library_for_testing()` so the Python host layer and the
+// analytic gradients can be checked against the oracle in the GPU-less build
+// container before GPU minutes are spent.  Launch geometry, coalescing, wave
+// reductions and atomics are what it does NOT cover — the `-m gpu` tests do.
+#include <cstring>
+#include <vector>
+
+#include "../../flowmap_amd/csrc/fm_math.h"
+#include "../../flowmap_amd/csrc/fm_pose.h"
+#include "../../include/flowmap_hip.h"
+
+using namespace fm;
+
+extern "C" {
+
+int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                       const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
+                       const float* scale, int batch, int frames, int height, int width, int mapping_kind, float delta,
+                       float ax, float ay, float* grad_depth, double* acc, int, void*) {
+  const size_t n = (size_t)height * width;
+  std::memset(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride);
+  const float sc = scale ? scale[0] : 0.f;
+  for (int bf = 0; bf < batch * frames; ++bf) {
+    const int f = bf % frames, b = bf / frames;
+    const bool has_fwd = f < frames - 1, has_bwd = f > 0;
+    Mat3 ki, k_f, k_b;
+    Pose t_f, t_b;
+    load_mat3(kinv + (size_t)bf * 9, ki);
+    const size_t pair_f = (size_t)b * (frames - 1) + f, pair_b = pair_f - 1;
+    if (has_fwd) {
+      load_mat3(k + (size_t)(bf + 1) * 9, k_f);
+      load_pose44(t_fwd + pair_f * 16, t_f);
+    }
+    if (has_bwd) {
+      load_mat3(k + (size_t)(bf - 1) * 9, k_b);
+      load_pose44(t_bwd + pair_b * 16, t_b);
+    }
+    double* dst = acc + (size_t)bf * 2 * kFlowAccStride;
+    for (int row = 0; row < height; ++row)
+      for (int col = 0; col < width; ++col) {
+        const size_t px = (size_t)row * width + col;
+        const float u = pixel_center(col, width), v = pixel_center(row, height);
+        float ray[3];
+        ray_dir(ki, u, v, ray);
+        const float z = depth[(size_t)bf * n + px];
+        float gz = 0.f;
+        float a_f[kFlowAcc] = {0}, a_b[kFlowAcc] = {0};
+        if (has_fwd) {
+          const float* fl = flow_fwd + (pair_f * n + px) * 2;
+          if (scale) flow_term<true>(t_f, k_f, ray, z, u, v, fl[0], fl[1], mask_fwd[pair_f * n + px], sc, mapping_kind, delta, ax, ay, a_f, gz);
+          else flow_term<false>(t_f, k_f, ray, z, u, v, fl[0], fl[1], mask_fwd[pair_f * n + px], sc, mapping_kind, delta, ax, ay, a_f, gz);
+        }
+        if (has_bwd) {
+          const float* fl = flow_bwd + (pair_b * n + px) * 2;
+          if (scale) flow_term<true>(t_b, k_b, ray, z, u, v, fl[0], fl[1], mask_bwd[pair_b * n + px], sc, mapping_kind, delta, ax, ay, a_b, gz);
+          else flow_term<false>(t_b, k_b, ray, z, u, v, fl[0], fl[1], mask_bwd[pair_b * n + px], sc, mapping_kind, delta, ax, ay, a_b, gz);
+        }
+        for (int i = 0; i < kFlowAcc; ++i) {
+          dst[i] += a_f[i];
+          dst[kFlowAccStride + i] += a_b[i];
+        }
+        if (scale && grad_depth) grad_depth[(size_t)bf * n + px] = gz;
+      }
+  }
+  return 0;
+}
+
+int fm_flow_loss_finalize(const double* acc, const float* kinv, const float* t_fwd, const float* t_bwd, const float* norm,
+                          int batch, int frames, float* loss, float* g_t_fwd, float* g_t_bwd, float* g_k, void*) {
+  double s = 0;
+  for (int bf = 0; bf < batch * frames; ++bf) {
+    flow_finalize_frame(acc, kinv, t_fwd, t_bwd, batch, frames, bf, g_t_fwd, g_t_bwd, g_k);
+    s += acc[(size_t)bf * 2 * kFlowAccStride] + acc[(size_t)bf * 2 * kFlowAccStride + kFlowAccStride];
+  }
+  loss[0] = (float)(s * (double)norm[0]);
+  return 0;
+}
+
+int fm_flow_valid_norm(const float* mask_fwd, const float* mask_bwd, long count, float weight, double* vsum, float* norm, void*) {
+  double s = 0;
+  for (long i = 0; i < count; ++i) s += (double)mask_fwd[i] + (mask_bwd ? (double)mask_bwd[i] : 0.0);
+  vsum[0] = s;
+  const double veff = s != 0.0 ? s : 1.0;
+  norm[0] = (float)((double)weight / veff);
+  norm[1] = (float)veff;
+  return 0;
+}
+
+int fm_scale_if_needed(float* x, long count, const float* scalar, void*) {
+  if (scalar[0] == 1.0f) return 0;
+  for (long i = 0; i < count; ++i) x[i] *= scalar[0];
+  return 0;
+}
+
+static CorrSrc make_src(const float* depth, const float* surfaces, const float* bwd_flow, const float* weights, size_t pair,
+                        int b, int i, int frames, int height, int width) {
+  const size_t n = (size_t)height * width;
+  const size_t fe = (size_t)b * frames + i, fl = fe + 1;
+  CorrSrc s;
+  s.depth_e = surfaces ? nullptr : depth + fe * n;
+  s.depth_l = surfaces ? nullptr : depth + fl * n;
+  s.surf_e = surfaces ? surfaces + fe * n * 3 : nullptr;
+  s.surf_l = surfaces ? surfaces + fl * n * 3 : nullptr;
+  s.bwd_flow = bwd_flow + pair * n * 2;
+  s.weights = weights + pair * n;
+  s.height = height;
+  s.width = width;
+  return s;
+}
+
+int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                        const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
+                        int width, double* stats, void*) {
+  const int pairs = batch * (frames - 1);
+  std::memset(stats, 0, sizeof(double) * (size_t)pairs * kStatStride);
+  for (int pr = 0; pr < pairs; ++pr) {
+    const int b = pr / (frames - 1), i = pr % (frames - 1);
+    Mat3 ke{}, kl{};
+    if (!surfaces) {
+      load_mat3(kinv + ((size_t)b * frames + i) * 9, ke);
+      load_mat3(kinv + ((size_t)b * frames + i + 1) * 9, kl);
+    }
+    const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, pr, b, i, frames, height, width);
+    double* st = stats + (size_t)pr * kStatStride;
+    for (long j = 0; j < points; ++j) {
+      const Corr c = corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j);
+      st[0] += c.w;
+      for (int a = 0; a < 3; ++a) {
+        st[1 + a] += c.w * c.p[a];
+        st[4 + a] += c.w * c.q[a];
+      }
+    }
+    const double inv = 1.0 / (st[0] + 1e-8);
+    float pbar[3], qbar[3];
+    for (int a = 0; a < 3; ++a) {
+      pbar[a] = (float)(st[1 + a] * inv);
+      qbar[a] = (float)(st[4 + a] * inv);
+    }
+    for (long j = 0; j < points; ++j) {
+      const Corr c = corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j);
+      for (int a = 0; a < 3; ++a) {
+        const float wq = c.w * (c.q[a] - qbar[a]);
+        for (int d = 0; d < 3; ++d) st[7 + a * 3 + d] += wq * (c.p[d] - pbar[d]);
+      }
+    }
+  }
+  return 0;
+}
+
+int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux, void*) {
+  for (int pr = 0; pr < pairs; ++pr)
+    pose_solve_one(stats + (size_t)pr * kStatStride, t_bwd + (size_t)pr * 16, t_fwd ? t_fwd + (size_t)pr * 16 : nullptr,
+                   aux + (size_t)pr * kAuxStride);
+  return 0;
+}
+
+int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux, int pairs,
+                      double* pair_grad, void*) {
+  for (int pr = 0; pr < pairs; ++pr)
+    pose_solve_bwd_one(g_t_bwd ? g_t_bwd + (size_t)pr * 16 : nullptr, g_t_fwd ? g_t_fwd + (size_t)pr * 16 : nullptr,
+                       t_bwd + (size_t)pr * 16, aux + (size_t)pr * kAuxStride, pair_grad + (size_t)pr * kPairGradStride);
+  return 0;
+}
+
+int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                          const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
+                          int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
+                          float* grad_weights, double* kinv_acc, void*) {
+  const int pairs = batch * (frames - 1);
+  const size_t n = (size_t)height * width;
+  for (int pr = 0; pr < pairs; ++pr) {
+    const int b = pr / (frames - 1), i = pr % (frames - 1);
+    Mat3 ke{}, kl{};
+    if (!surfaces) {
+      load_mat3(kinv + ((size_t)b * frames + i) * 9, ke);
+      load_mat3(kinv + ((size_t)b * frames + i + 1) * 9, kl);
+    }
+    const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, pr, b, i, frames, height, width);
+    const double* pg = pair_grad + (size_t)pr * kPairGradStride;
+    const double* ax = aux + (size_t)pr * kAuxStride;
+    PairGrad g;
+    for (int k = 0; k < 9; ++k) g.gM[k] = (float)pg[k];
+    for (int a = 0; a < 3; ++a) {
+      g.gqbar[a] = (float)pg[9 + a];
+      g.gpbar[a] = (float)pg[12 + a];
+      g.pbar[a] = (float)ax[21 + a];
+      g.qbar[a] = (float)ax[24 + a];
+    }
+    g.dbar = (float)pg[15];
+    g.inv_wsum = (float)pg[16];
+    const size_t fe = (size_t)b * frames + i, fl = fe + 1;
+    for (long j = 0; j < points; ++j) {
+      const Corr c = corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j);
+      float gq[3], gp[3], gw;
+      corr_backward(c, g, gq, gp, gw);
+      if (grad_weights) grad_weights[(size_t)pr * n + c.idx] += gw;
+      if (!surfaces) {
+        const int row = c.idx / width, col = c.idx - row * width;
+        const float u = pixel_center(col, width), v = pixel_center(row, height);
+        if (grad_depth) grad_depth[fl * n + c.idx] += gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2];
+        const float zh[3] = {c.z_p * u, c.z_p * v, c.z_p};
+        if (kinv_acc)
+          for (int a = 0; a < 3; ++a)
+            for (int d = 0; d < 3; ++d) kinv_acc[fl * 9 + a * 3 + d] += gp[a] * zh[d];
+        for (int k = 0; k < 4; ++k) {
+          if (!c.taps.in[k]) continue;
+          const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
+          const float ut = pixel_center(tc, width), vt = pixel_center(tr, height);
+          const float z = depth[fe * n + (size_t)tr * width + tc];
+          float ray[3];
+          ray_dir(ke, ut, vt, ray);
+          const float wt = c.taps.w[k];
+          if (grad_depth) grad_depth[fe * n + (size_t)tr * width + tc] += wt * (gq[0] * ray[0] + gq[1] * ray[1] + gq[2] * ray[2]);
+          const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
+          if (kinv_acc)
+            for (int a = 0; a < 3; ++a)
+              for (int d = 0; d < 3; ++d) kinv_acc[fe * 9 + a * 3 + d] += gq[a] * zt[d];
+        }
+      } else if (grad_surfaces) {
+        float* gl = grad_surfaces + (fl * n + c.idx) * 3;
+        for (int a = 0; a < 3; ++a) gl[a] += gp[a];
+        for (int k = 0; k < 4; ++k) {
+          if (!c.taps.in[k]) continue;
+          float* ge = grad_surfaces + (fe * n + (size_t)tap_row(c.taps, k) * width + tap_col(c.taps, k)) * 3;
+          for (int a = 0; a < 3; ++a) ge[a] += gq[a] * c.taps.w[k];
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+int fm_pose_chain_fwd(const float* rel, int batch, int steps, float* ext, void*) {
+  for (int b = 0; b < batch; ++b) pose_chain_fwd_one(rel + (size_t)b * steps * 16, steps, ext + (size_t)b * (steps + 1) * 16);
+  return 0;
+}
+
+int fm_pose_chain_bwd(const float* rel, const float* ext, const float* g_ext, int batch, int steps, float* g_rel, void*) {
+  for (int b = 0; b < batch; ++b)
+    pose_chain_bwd_one(rel + (size_t)b * steps * 16, ext + (size_t)b * (steps + 1) * 16, g_ext + (size_t)b * (steps + 1) * 16, steps,
+                       g_rel + (size_t)b * steps * 16);
+  return 0;
+}
+
+int fm_relative_pose_fwd(const float* ext, int batch, int frames, float* fwd, float* bwd, void*) {
+  for (int pr = 0; pr < batch * (frames - 1); ++pr) {
+    const int b = pr / (frames - 1), i = pr % (frames - 1);
+    relative_pose_fwd_one(ext + ((size_t)b * frames + i) * 16, fwd + (size_t)pr * 16, bwd + (size_t)pr * 16);
+  }
+  return 0;
+}
+
+int fm_relative_pose_bwd(const float* ext, const float* g_fwd, const float* g_bwd, int batch, int frames, float* g_ext, void*) {
+  std::memset(g_ext, 0, sizeof(float) * (size_t)batch * frames * 16);
+  for (int pr = 0; pr < batch * (frames - 1); ++pr) {
+    const int b = pr / (frames - 1), i = pr % (frames - 1);
+    double ge0[16], ge1[16];
+    relative_pose_bwd_one(ext + ((size_t)b * frames + i) * 16, g_fwd ? g_fwd + (size_t)pr * 16 : nullptr,
+                          g_bwd ? g_bwd + (size_t)pr * 16 : nullptr, ge0, ge1);
+    float* o0 = g_ext + ((size_t)b * frames + i) * 16;
+    for (int k = 0; k < 16; ++k) {
+      o0[k] += (float)ge0[k];
+      o0[16 + k] += (float)ge1[k];
+    }
+  }
+  return 0;
+}
+
+int fm_allpairs_pose_fwd(const float* ext, int batch, int f, float* rel, void*) {
+  for (int i = 0; i < batch * f * f; ++i) {
+    const int b = i / (f * f), r = i % (f * f);
+    allpairs_pose_fwd_one(ext + (size_t)b * f * 16, r / f, r % f, rel + (size_t)i * 16);
+  }
+  return 0;
+}
+
+int fm_allpairs_pose_bwd(const float* ext, const float* g_rel, int batch, int f, float* g_ext, void*) {
+  for (int i = 0; i < batch * f; ++i) {
+    const int b = i / f;
+    allpairs_pose_bwd_one(ext + (size_t)b * f * 16, g_rel + (size_t)b * f * f * 16, f, i % f, g_ext + (size_t)i * 16);
+  }
+  return 0;
+}
+
+int fm_intrinsics_inverse(const float* k, int count, float* kinv, void*) {
+  for (int i = 0; i < count; ++i) inv3(k + (size_t)i * 9, kinv + (size_t)i * 9);
+  return 0;
+}
+
+int fm_intrinsics_inverse_bwd(const double* kinv_acc, const float* kinv, int count, float* g_k, int accumulate, void*) {
+  for (int i = 0; i < count; ++i) {
+    double gk[9];
+    kinv_grad_to_k(kinv_acc + (size_t)i * 9, kinv + (size_t)i * 9, gk);
+    for (int e = 0; e < 9; ++e) g_k[(size_t)i * 9 + e] = (accumulate ? g_k[(size_t)i * 9 + e] : 0.f) + (float)gk[e];
+  }
+  return 0;
+}
+
+
+int fm_unproject_fwd(const float* xy, long xy_group_stride, const float* z, const float* kinv, int groups, long points,
+                     float* out, void*) {
+  for (int g = 0; g < groups; ++g) {
+    Mat3 ki;
+    load_mat3(kinv + (size_t)g * 9, ki);
+    for (long i = 0; i < points; ++i) {
+      const float* c = xy + (size_t)g * xy_group_stride + i * 2;
+      float ray[3];
+      ray_dir(ki, c[0], c[1], ray);
+      const float zz = z[(size_t)g * points + i];
+      for (int a = 0; a < 3; ++a) out[((size_t)g * points + i) * 3 + a] = ray[a] * zz;
+    }
+  }
+  return 0;
+}
+
+int fm_unproject_bwd(const float* xy, long xy_group_stride, const float* z, const float* kinv, const float* g_out, int groups,
+                     long points, float* g_z, double* kinv_acc, void*) {
+  if (kinv_acc) std::memset(kinv_acc, 0, sizeof(double) * (size_t)groups * 9);
+  for (int g = 0; g < groups; ++g) {
+    Mat3 ki;
+    load_mat3(kinv + (size_t)g * 9, ki);
+    for (long i = 0; i < points; ++i) {
+      const float* c = xy + (size_t)g * xy_group_stride + i * 2;
+      float ray[3];
+      ray_dir(ki, c[0], c[1], ray);
+      const float zz = z[(size_t)g * points + i];
+      const float* go = g_out + ((size_t)g * points + i) * 3;
+      if (g_z) g_z[(size_t)g * points + i] = go[0] * ray[0] + go[1] * ray[1] + go[2] * ray[2];
+      const float zh[3] = {zz * c[0], zz * c[1], zz};
+      if (kinv_acc)
+        for (int a = 0; a < 3; ++a)
+          for (int d = 0; d < 3; ++d) kinv_acc[(size_t)g * 9 + a * 3 + d] += go[a] * zh[d];
+    }
+  }
+  return 0;
+}
+
+int fm_reproject_fwd(const float* xyz, const float* t, const float* k, int groups, long points, float* xy, void*) {
+  for (int g = 0; g < groups; ++g) {
+    Pose tr;
+    Mat3 kk;
+    load_pose44(t + (size_t)g * 16, tr);
+    load_mat3(k + (size_t)g * 9, kk);
+    for (long i = 0; i < points; ++i) {
+      const float* p = xyz + ((size_t)g * points + i) * 3;
+      float xc[3];
+      apply_pose(tr, p, xc);
+      const Projected pr = project_point(xc, kk);
+      xy[((size_t)g * points + i) * 2] = pr.u;
+      xy[((size_t)g * points + i) * 2 + 1] = pr.v;
+    }
+  }
+  return 0;
+}
+
+int fm_reproject_bwd(const float* xyz, const float* t, const float* k, const float* g_xy, int groups, long points, float* g_xyz,
+                     float* g_t, float* g_k, double* acc, void*) {
+  std::memset(acc, 0, sizeof(double) * (size_t)groups * 18);
+  for (int g = 0; g < groups; ++g) {
+    Pose tr;
+    Mat3 kk;
+    load_pose44(t + (size_t)g * 16, tr);
+    load_mat3(k + (size_t)g * 9, kk);
+    double* a = acc + (size_t)g * 18;
+    for (long i = 0; i < points; ++i) {
+      const float* p = xyz + ((size_t)g * points + i) * 3;
+      float xc[3];
+      apply_pose(tr, p, xc);
+      const Projected pr = project_point(xc, kk);
+      const float* go = g_xy + ((size_t)g * points + i) * 2;
+      float gk[6] = {0, 0, 0, 0, 0, 0}, gxc[3];
+      project_point_bwd(pr, kk, go[0], go[1], gk, gxc);
+      for (int r = 0; r < 3; ++r) {
+        a[r] += gxc[r];
+        for (int d = 0; d < 3; ++d) a[3 + r * 3 + d] += gxc[r] * p[d];
+      }
+      for (int r = 0; r < 6; ++r) a[12 + r] += gk[r];
+      if (g_xyz) {
+        float gx[3];
+        apply_rot_t(tr, gxc, gx);
+        for (int r = 0; r < 3; ++r) g_xyz[((size_t)g * points + i) * 3 + r] = gx[r];
+      }
+    }
+    if (g_t) {
+      float* o = g_t + (size_t)g * 16;
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) o[r * 4 + c] = (float)a[3 + r * 3 + c];
+        o[r * 4 + 3] = (float)a[r];
+      }
+      o[12] = o[13] = o[14] = o[15] = 0.f;
+    }
+    if (g_k) {
+      float* o = g_k + (size_t)g * 9;
+      for (int i = 0; i < 6; ++i) o[i] = (float)a[12 + i];
+      o[6] = o[7] = o[8] = 0.f;
+    }
+  }
+  return 0;
+}
+
+int fm_bilinear_sample_fwd(const float* img, const float* xy, int groups, int h, int w, int c, long points, float* out, void*) {
+  for (int g = 0; g < groups; ++g) {
+    const float* im = img + (size_t)g * h * w * c;
+    for (long i = 0; i < points; ++i) {
+      const float* q = xy + ((size_t)g * points + i) * 2;
+      const Taps t = bilinear_taps(q[0], q[1], h, w);
+      for (int ch = 0; ch < c; ++ch) {
+        float s = 0.f;
+        for (int k = 0; k < 4; ++k)
+          if (t.in[k]) s += im[((size_t)tap_row(t, k) * w + tap_col(t, k)) * c + ch] * t.w[k];
+        out[((size_t)g * points + i) * c + ch] = s;
+      }
+    }
+  }
+  return 0;
+}
+
+int fm_bilinear_sample_bwd(const float* g_out, const float* xy, int groups, int h, int w, int c, long points, float* g_img, void*) {
+  for (int g = 0; g < groups; ++g) {
+    float* gi = g_img + (size_t)g * h * w * c;
+    for (long i = 0; i < points; ++i) {
+      const float* q = xy + ((size_t)g * points + i) * 2;
+      const Taps t = bilinear_taps(q[0], q[1], h, w);
+      for (int ch = 0; ch < c; ++ch)
+        for (int k = 0; k < 4; ++k)
+          if (t.in[k]) gi[((size_t)tap_row(t, k) * w + tap_col(t, k)) * c + ch] += g_out[((size_t)g * points + i) * c + ch] * t.w[k];
+    }
+  }
+  return 0;
+}
+
+int fm_mapping_fwd(const float* a, const float* b, long count, int kind, float delta, float ax, float ay, float* out, void*) {
+  for (long i = 0; i < count; ++i) {
+    float dx, dy;
+    out[i] = robust_map(kind, delta, a[2 * i] * ax - b[2 * i] * ax, a[2 * i + 1] * ay - b[2 * i + 1] * ay, dx, dy);
+  }
+  return 0;
+}
+
+int fm_mapping_bwd(const float* a, const float* b, const float* g_out, long count, int kind, float delta, float ax, float ay,
+                   float* g_a, float* g_b, void*) {
+  for (long i = 0; i < count; ++i) {
+    float dx, dy;
+    robust_map(kind, delta, a[2 * i] * ax - b[2 * i] * ax, a[2 * i + 1] * ay - b[2 * i + 1] * ay, dx, dy);
+    const float gx = g_out[i] * dx * ax, gy = g_out[i] * dy * ay;
+    if (g_a) {
+      g_a[2 * i] = gx;
+      g_a[2 * i + 1] = gy;
+    }
+    if (g_b) {
+      g_b[2 * i] = -gx;
+      g_b[2 * i + 1] = -gy;
+    }
+  }
+  return 0;
+}
+
+int fm_align_rigid_stats(const float* p, const float* q, const float* w, int groups, long points, double* stats, void*) {
+  std::memset(stats, 0, sizeof(double) * (size_t)groups * kStatStride);
+  for (int g = 0; g < groups; ++g) {
+    double* st = stats + (size_t)g * kStatStride;
+    for (long j = 0; j < points; ++j) {
+      const size_t o = (size_t)g * points + j;
+      st[0] += w[o];
+      for (int a = 0; a < 3; ++a) {
+        st[1 + a] += w[o] * p[o * 3 + a];
+        st[4 + a] += w[o] * q[o * 3 + a];
+      }
+    }
+    const double inv = 1.0 / (st[0] + 1e-8);
+    float pbar[3], qbar[3];
+    for (int a = 0; a < 3; ++a) {
+      pbar[a] = (float)(st[1 + a] * inv);
+      qbar[a] = (float)(st[4 + a] * inv);
+    }
+    for (long j = 0; j < points; ++j) {
+      const size_t o = (size_t)g * points + j;
+      for (int a = 0; a < 3; ++a) {
+        const float wq = w[o] * (q[o * 3 + a] - qbar[a]);
+        for (int d = 0; d < 3; ++d) st[7 + a * 3 + d] += wq * (p[o * 3 + d] - pbar[d]);
+      }
+    }
+  }
+  return 0;
+}
+
+int fm_align_rigid_bwd(const float* p, const float* q, const float* w, int groups, long points, const double* aux,
+                       const double* pair_grad, float* g_p, float* g_q, float* g_w, void*) {
+  for (int g = 0; g < groups; ++g) {
+    const double* pg = pair_grad + (size_t)g * kPairGradStride;
+    const double* ax = aux + (size_t)g * kAuxStride;
+    PairGrad gr;
+    for (int k = 0; k < 9; ++k) gr.gM[k] = (float)pg[k];
+    for (int a = 0; a < 3; ++a) {
+      gr.gqbar[a] = (float)pg[9 + a];
+      gr.gpbar[a] = (float)pg[12 + a];
+      gr.pbar[a] = (float)ax[21 + a];
+      gr.qbar[a] = (float)ax[24 + a];
+    }
+    gr.dbar = (float)pg[15];
+    gr.inv_wsum = (float)pg[16];
+    for (long j = 0; j < points; ++j) {
+      const size_t o = (size_t)g * points + j;
+      Corr c;
+      for (int a = 0; a < 3; ++a) {
+        c.p[a] = p[o * 3 + a];
+        c.q[a] = q[o * 3 + a];
+      }
+      c.w = w[o];
+      float gq[3], gp[3], gw;
+      corr_backward(c, gr, gq, gp, gw);
+      for (int a = 0; a < 3; ++a) {
+        if (g_p) g_p[o * 3 + a] = gp[a];
+        if (g_q) g_q[o * 3 + a] = gq[a];
+      }
+      if (g_w) g_w[o] = gw;
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+"""CPU parity of the flowmap_amd host layer + the kernels' per-element math (through the
+tests/host_sim double of the C ABI) against the oracle and the reference's golden
+vectors.  What this cannot see (launch geometry, atomics, wave reductions) is covered
+by the `-m gpu` twins in test_gpu_parity.py."""
+
+import numpy as np
+import pytest
+import torch
+
+import flowmap_amd
+from flowmap_amd import _lib
+from conftest import assert_close, load_golden, t
+from helpers import build_host_sim, run_oracle, run_ours
+from oracle import flowmap_oracle as orc
+from test_oracle_golden import _flows, _tracks
+
+
+@pytest.fixture(autouse=True, scope="module")
+def host_double():
+    _lib.set_library_for_testing(build_host_sim())
+    yield
+    _lib.set_library_for_testing(None)
+
+
+def compare(ours, ref, tol=1e-4, focal_tol=1e-3):
+    assert_close(ours["total"], ref["total"], tol, what="total")
+    assert_close(ours["loss_flow"], ref["loss_flow"], tol, what="loss_flow")
+    assert_close(ours["loss_tracking"], ref["loss_tracking"], tol, what="loss_tracking")
+    assert_close(ours["extrinsics"], ref["extrinsics"], tol, what="extrinsics")
+    assert_close(ours["g_depth"], ref["g_depth"], tol, what="g_depth")
+    assert_close(ours["g_wlogit"], ref["g_wlogit"], 3 * tol, what="g_wlogit")
+    assert_close(ours["g_focal"], ref["g_focal"], focal_tol, abs_=1e-4 * abs(float(ref["total"])), what="g_focal")
+
+
+@pytest.mark.parametrize("lazy", [True, False])
+@pytest.mark.parametrize(
+    "name,kind",
+    [("step_iid_flow", "huber"), ("step_scene_flow_tracking", "huber"), ("step_iid_l1_odd", "l1"), ("step_iid_l2_odd", "l2")],
+)
+def test_step_vs_reference_golden(name, kind, lazy):
+    g = load_golden(name)
+    depth, wlogit = t(g["depth"]), t(g["wlogit"])
+    npts = int(g["num_points"])
+    ours = run_ours(depth, wlogit, float(g["focal"]), _flows(g), depth.shape[1:], None if npts < 0 else npts, _tracks(g), kind, lazy=lazy)
+    ref = {k: t(g[k]) for k in ("total", "loss_flow", "loss_tracking", "extrinsics", "g_depth", "g_wlogit", "g_focal")}
+    compare(ours, ref)
+
+
+@pytest.mark.parametrize("f,h,w,p", [(4, 16, 24, 64), (3, 9, 13, None), (6, 32, 20, 200)])
+def test_step_vs_oracle_fp64(f, h, w, p):
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=f * 7 + h)
+    ours = run_ours(depth, wlogit, 0.85, flows, (h, w), p)
+    ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), p, dtype=torch.float64)
+    compare(ours, ref)
+
+
+def test_loss_scale_and_carry():
+    """grad_output != 1 exercises fm_scale_if_needed; results must scale linearly and the
+    carried-gradient path must equal the plain dense path."""
+    f, h, w = 4, 12, 16
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=3)
+    a = run_ours(depth, wlogit, 0.85, flows, (h, w), 40)
+    b = run_ours(depth, wlogit, 0.85, flows, (h, w), 40, loss_scale=0.5)
+    assert_close(b["g_depth"], 0.5 * a["g_depth"], 1e-6)
+    assert_close(b["g_wlogit"], 0.5 * a["g_wlogit"], 1e-6)
+    from flowmap_amd.loss import LossFlow
+
+    LossFlow.carry_depth_grad = False
+    try:
+        c = run_ours(depth, wlogit, 0.85, flows, (h, w), 40)
+    finally:
+        LossFlow.carry_depth_grad = True
+    assert_close(c["g_depth"], a["g_depth"], 1e-6)
+
+
+def test_zero_masks_give_zero_loss():
+    f, h, w = 3, 8, 12
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=1)
+    flows.forward_mask.zero_()
+    flows.backward_mask.zero_()
+    ours = run_ours(depth, wlogit, 0.85, flows, (h, w), 30)
+    assert float(ours["total"]) == 0.0
+    assert float(ours["g_depth"].abs().max()) == 0.0
