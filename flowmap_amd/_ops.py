@@ -220,6 +220,7 @@ class ProcrustesFit(torch.autograd.Function):
         # buffer and returns the sum once — no second dense tensor, no dense add.
         ctx._fm_fit_depth_key = (depth.data_ptr(), depth._version, tuple(depth.shape)) if from_depth else None
         ctx._fm_carried = None
+        ctx._fm_pending = []  # deferred scatters of other losses into the final dL/ddepth buffer
         return t_bwd
 
     @staticmethod
@@ -236,8 +237,11 @@ class ProcrustesFit(torch.autograd.Function):
         g_src = g_k = g_w = None
         carried = ctx._fm_carried
         ctx._fm_carried = None
+        pending, ctx._fm_pending = ctx._fm_pending, []
         if need_src:
             g_src = carried if carried is not None else torch.zeros_like(src)
+            for scatter in pending:
+                scatter(g_src)
         if need_w:
             g_w = torch.zeros_like(weights)
         kinv_acc = torch.zeros((b * f, 9), dtype=torch.float64, device=dev) if need_k else None
@@ -530,3 +534,121 @@ class AlignRigid(torch.autograd.Function):
             call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t), ptr(aux), g, ptr(pair_grad), st)
             call("fm_align_rigid_bwd", ptr(p), ptr(q), ptr(w), g, n, ptr(aux), ptr(pair_grad), ptr(g_p), ptr(g_q), ptr(g_w), st)
         return g_p, g_q, g_w
+
+
+# --------------------------------------------------------------------------------------
+# Fused tracking loss
+# --------------------------------------------------------------------------------------
+
+
+class PackedTracks:
+    """All track segments (flowmap/tracking/track_predictor.py:13-20) packed into the flat
+    arrays fm_track_* expects.  Tracks are constants of the optimisation: packed once."""
+
+    def __init__(self, tracks, device):
+        xy, vis, seg, blocks = [], [], [], []
+        offset = 0
+        for s_idx, t in enumerate(tracks):
+            b, f, p, _ = t.xy.shape
+            if b != 1:
+                raise RuntimeError("flowmap_amd: the fused tracking loss supports batch size 1 (as the reference asserts)")
+            xy.append(t.xy[0].reshape(f * p, 2).to(device=device, dtype=torch.float32))
+            vis.append(t.visibility[0].reshape(f * p).to(device=device, dtype=torch.uint8))
+            seg.append([int(t.start_frame), f, p, offset])
+            blocks.extend([s_idx, fr] for fr in range(f))
+            offset += f * p
+        self.total = offset
+        self.xy = torch.cat(xy).contiguous()
+        self.vis = torch.cat(vis).contiguous()
+        self.seg = torch.tensor(seg, dtype=torch.int32).to(device)
+        self.blocks = torch.tensor(blocks, dtype=torch.int32).to(device)
+        self.nblocks = len(blocks)
+        self.pmax = max(s_[2] for s_ in seg)
+        self.fmax = max(s_[1] for s_ in seg)
+        self.last_frame = max(s_[0] + s_[1] for s_ in seg)
+
+
+_packed_cache: dict = {}
+
+
+def pack_tracks(tracks, device) -> PackedTracks:
+    key = tuple((t.xy.data_ptr(), t.xy._version, t.visibility.data_ptr(), int(t.start_frame), tuple(t.xy.shape)) for t in tracks) + (str(device),)
+    hit = _packed_cache.get(key)
+    if hit is None:
+        if len(_packed_cache) > 4:
+            _packed_cache.clear()
+        hit = _packed_cache[key] = PackedTracks(tracks, device)
+    return hit
+
+
+class TrackLossFused(torch.autograd.Function):
+    """weight · LossTracking.compute_unweighted_loss (flowmap/loss/loss_tracking.py:28-61,
+    flowmap/loss/loss.py:47) over all segments, from depth + intrinsics + extrinsics."""
+
+    @staticmethod
+    def forward(ctx, depth, k, ext, packed: PackedTracks, weight, kind, delta, defer):
+        dev = check_device(depth, k, ext, packed.xy)
+        depth, k, ext = _f32c(depth, "depth"), _f32c(k, "intrinsics"), _f32c(ext, "extrinsics")
+        b, f, h, w = depth.shape
+        if b != 1:
+            raise RuntimeError("flowmap_amd: the fused tracking loss supports batch size 1")
+        if packed.last_frame > f:
+            raise RuntimeError("flowmap_amd: a track segment extends past the last frame")
+        kinv = intrinsics_inverse(k)
+        ext_inv = torch.empty_like(ext)
+        ws = torch.empty((packed.total, 6), dtype=torch.float32, device=dev)
+        flag = torch.empty((packed.total,), dtype=torch.uint8, device=dev)
+        acc = torch.empty((f * 20 + 2,), dtype=torch.float64, device=dev)
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        scale = torch.empty((2,), dtype=torch.float32, device=dev)
+        sc = (h * w) ** 0.5
+        with _guard(dev):
+            st = stream_for(depth)
+            call("fm_extrinsics_inverse", ptr(ext), f, ptr(ext_inv), st)
+            call("fm_track_points", ptr(depth), ptr(kinv), ptr(ext), ptr(packed.xy), ptr(packed.vis), ptr(packed.seg),
+                 ptr(packed.blocks), packed.nblocks, packed.pmax, h, w, ptr(ws), ptr(flag), st)
+            call("fm_track_loss_fwd", ptr(ws), ptr(flag), ptr(packed.xy), ptr(packed.vis), ptr(packed.seg), ptr(packed.blocks),
+                 packed.nblocks, packed.pmax, ptr(ext_inv), ptr(k), f, h, w, kind, float(delta), w / sc, h / sc, float(weight),
+                 ptr(acc), ptr(loss), ptr(scale), st)
+        ctx.save_for_backward(depth, k, ext, kinv, ext_inv, ws, flag, acc, scale)
+        ctx.packed, ctx.cfg, ctx.dims = packed, (kind, float(delta), w / sc, h / sc), (f, h, w)
+        ctx.fit_node = None
+        if defer and ctx.needs_input_grad[0]:
+            node = _find_fit_node(ext, (depth.data_ptr(), depth._version, tuple(depth.shape)))
+            if node is not None and node.needs_input_grad[0]:
+                ctx.fit_node = node
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        depth, k, ext, kinv, ext_inv, ws, flag, acc, scale = ctx.saved_tensors
+        pk: PackedTracks = ctx.packed
+        kind, delta, ax, ay = ctx.cfg
+        f, h, w = ctx.dims
+        dev = depth.device
+        g = g.reshape(1).to(torch.float32).contiguous()
+        gws = torch.empty((pk.total, 3), dtype=torch.float32, device=dev)
+        acc2 = torch.empty((f * 24,), dtype=torch.float64, device=dev)
+        g_ext = torch.empty_like(ext)
+        g_k = torch.empty_like(k)
+        with _guard(dev):
+            call("fm_track_loss_bwd", ptr(ws), ptr(flag), ptr(pk.xy), ptr(pk.vis), ptr(pk.seg), ptr(pk.blocks), pk.nblocks, pk.pmax,
+                 pk.fmax, ptr(depth), ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), f, h, w, kind, delta, ax, ay, ptr(acc), ptr(scale),
+                 ptr(g), ptr(gws), ptr(acc2), ptr(g_ext), ptr(g_k), stream_for(depth))
+
+        def scatter(buffer: Tensor) -> None:
+            with _guard(dev):
+                call("fm_track_scatter", ptr(gws), ptr(flag), ptr(pk.xy), ptr(pk.vis), ptr(pk.seg), ptr(pk.blocks), pk.nblocks,
+                     pk.pmax, ptr(kinv), h, w, ptr(buffer), stream_for(buffer))
+
+        g_depth = None
+        if ctx.needs_input_grad[0]:
+            node = ctx.fit_node
+            ctx.fit_node = None
+            if node is not None:
+                node._fm_pending.append(scatter)  # lands in the buffer ProcrustesFit.backward returns
+            else:
+                g_depth = torch.zeros_like(depth)
+                scatter(g_depth)
+        need = ctx.needs_input_grad
+        return g_depth, g_k if need[1] else None, g_ext if need[2] else None, None, None, None, None, None

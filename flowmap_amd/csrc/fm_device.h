@@ -24,23 +24,24 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // Block-wide reduction of NV per-thread fp32 partials followed by ONE fp64 atomic per
-// value per block (guide §6 G12).  `lds` must hold (blockDim.x/64) * NV floats.
-// Partials are summed in fp32 inside a wave (64 values), in fp64 across waves and
-// across blocks, so the grand totals over ~1e6 pixels keep ~1e-7 relative accuracy.
+// value per block (guide §6 G12).  `lds` must hold (blockDim.x/64) * NV doubles.
+// Per-thread partials are fp32; everything above a thread (wave butterfly, cross-wave,
+// cross-block) is fp64, so the heavily cancelling pose/intrinsics gradient sums over
+// ~1e6 pixels keep ~1e-7 relative accuracy and are reproducible to fp32 rounding.
 template <int NV>
-__device__ __forceinline__ void block_accumulate(const float (&v)[NV], float* lds, double* dst) {
+__device__ __forceinline__ void block_accumulate(const float (&v)[NV], double* lds, double* dst) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int nwaves = blockDim.x >> 6;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const float s = wave_sum(v[i]);
+    const double s = wave_sum((double)v[i]);
     if (lane == 0) lds[wave * NV + i] = s;
   }
   __syncthreads();
   if (threadIdx.x < NV) {
     double tot = 0.0;
-    for (int w = 0; w < nwaves; ++w) tot += (double)lds[w * NV + threadIdx.x];
+    for (int w = 0; w < nwaves; ++w) tot += lds[w * NV + threadIdx.x];
     if (tot != 0.0) atomicAdd(dst + threadIdx.x, tot);
   }
   __syncthreads();

@@ -46,9 +46,9 @@ struct FlowParams {
 
 template <int VEC, bool GRAD>
 __global__ void __launch_bounds__(256) flow_fused_kernel(FlowParams p) {
-  extern __shared__ float lds[];  // [width] u-table, then reduction scratch
-  float* u_tab = lds;
-  float* red = lds + p.width;
+  extern __shared__ double lds[];  // reduction scratch (fp64), then the [width] u-table
+  double* red = lds;
+  float* u_tab = reinterpret_cast<float*>(lds + (256 / 64) * kFlowAcc);
 
   const int bf = blockIdx.y;  // batch*frames + frame
   const int f = bf % p.frames;
@@ -247,7 +247,7 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   const int threads = 256;
   const long per_block = (long)threads * p.iters;
   dim3 grid((unsigned)((items + per_block - 1) / per_block), (unsigned)(batch * frames));
-  const size_t lds = sizeof(float) * ((size_t)width + (threads / 64) * kFlowAcc);
+  const size_t lds = sizeof(float) * (size_t)width + sizeof(double) * (threads / 64) * kFlowAcc;
   if (vec4) {
     if (grad) hipLaunchKernelGGL((flow_fused_kernel<4, true>), grid, dim3(threads), lds, st, p);
     else hipLaunchKernelGGL((flow_fused_kernel<4, false>), grid, dim3(threads), lds, st, p);

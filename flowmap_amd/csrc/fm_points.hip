@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) unproject_fwd_kernel(const float* xy, lon
 __global__ void __launch_bounds__(256) unproject_bwd_kernel(const float* xy, long xy_group_stride, const float* z,
                                                             const float* kinv, const float* g_out, long n, float* g_z,
                                                             double* kinv_acc) {
-  __shared__ float red[4 * 9];
+  __shared__ double red[4 * 9];
   const int g = blockIdx.y;
   Mat3 ki;
   load_mat3(kinv + (size_t)g * 9, ki);
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) reproject_fwd_kernel(const float* xyz, co
 // acc per group: [0..2] dL/dt, [3..11] dL/dR, [12..17] dL/dK rows 0,1
 __global__ void __launch_bounds__(256) reproject_bwd_kernel(const float* xyz, const float* t, const float* k, const float* g_xy,
                                                             long n, float* g_xyz, double* acc_out) {
-  __shared__ float red[4 * 18];
+  __shared__ double red[4 * 18];
   const int g = blockIdx.y;
   Pose tr;
   Mat3 kk;
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) mapping_bwd_kernel(const float* a, const 
 template <int PASS>
 __global__ void __launch_bounds__(256) rigid_stats_kernel(const float* p, const float* q, const float* w, long points,
                                                           double* stats) {
-  __shared__ float red[4 * 9];
+  __shared__ double red[4 * 9];
   const int g = blockIdx.y;
   double* st = stats + (size_t)g * kStatStride;
   float pbar[3] = {0, 0, 0}, qbar[3] = {0, 0, 0};

@@ -63,7 +63,7 @@ __device__ __forceinline__ CorrSrc pair_source(const ProcParams& p, size_t pair,
 // grid: (chunks, B*(F-1)); PASS 1 accumulates stats[0..6], PASS 2 stats[7..15].
 template <int SRC, int PASS>
 __global__ void __launch_bounds__(256) procrustes_stats_kernel(ProcParams p, int iters) {
-  __shared__ float red[4 * 9];
+  __shared__ double red[4 * 9];
   const size_t pair = blockIdx.y;
   const int b = (int)(pair / (p.frames - 1));
   const int i = (int)(pair % (p.frames - 1));
@@ -137,7 +137,7 @@ __global__ void pose_solve_bwd_kernel(const float* g_t_bwd, const float* g_t_fwd
 // Per-point backward + scatter.  grid: (chunks, B*(F-1)).
 template <int SRC>
 __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, const double* aux, int iters) {
-  __shared__ float red[4 * 18];
+  __shared__ double red[4 * 18];
   const size_t pair = blockIdx.y;
   const int b = (int)(pair / (p.frames - 1));
   const int i = (int)(pair % (p.frames - 1));

@@ -7,7 +7,10 @@ from typing import Literal, Optional
 
 from torch import Tensor
 
-from ..model.projection import compute_track_flow
+import torch
+
+from .. import _ops
+from ..model.projection import LazySurfaces, compute_track_flow
 from .loss import Loss, LossCfgCommon, or_one
 from .mapping import MappingCfg, get_mapping
 
@@ -20,15 +23,50 @@ class LossTrackingCfg(LossCfgCommon):
 
 class LossTracking(Loss[LossTrackingCfg]):
     """flowmap/loss/loss_tracking.py:23-61: all-pairs track reprojection error over every
-    segment, one global masked mean."""
+    segment, one global masked mean.
+
+    Fast path (LazySurfaces of the model's own depths/intrinsics, batch 1): all segments
+    in a handful of HIP launches straight from depth (fm_track_*); the (f,f,P,2) all-pairs
+    tensors are never materialised.  General path: the reference's per-segment
+    composition of compute_track_flow -> mapping -> masked sums.
+    """
+
+    # let ProcrustesFit.backward apply our sparse depth scatter to its final buffer
+    defer_depth_scatter: bool = True
 
     def __init__(self, cfg: LossTrackingCfg) -> None:
         super().__init__(cfg)
         self.mapping = get_mapping(cfg.mapping)
 
+    @staticmethod
+    def _fusable(model_output, tracks) -> bool:
+        s = model_output.surfaces
+        return (
+            isinstance(s, LazySurfaces) and s.depths is model_output.depths and s.depths.shape[0] == 1 and tracks is not None
+            and len(tracks) > 0
+        )
+
+    def _fused(self, tracks, model_output, weight: float) -> Tensor:
+        s: LazySurfaces = model_output.surfaces
+        packed = _ops.pack_tracks(tracks, s.depths.device)
+        return _ops.TrackLossFused.apply(
+            s.depths, model_output.intrinsics, model_output.extrinsics, packed, weight, _ops.MAPPING_KINDS[self.mapping.kind],
+            self.mapping.delta, self.defer_depth_scatter,
+        )
+
+    def compute_weighted_loss(self, batch, flows, tracks, model_output, global_step: int, weight: float) -> Tensor:
+        assert tracks is not None
+        if self._fusable(model_output, tracks):
+            return self._fused(tracks, model_output, weight)
+        return weight * self.compute_unweighted_loss(batch, flows, tracks, model_output, global_step)
+
     def compute_unweighted_loss(self, batch, flows, tracks: Optional[list], model_output, global_step: int) -> Tensor:
         # Tracks must be available for the tracking loss (loss_tracking.py:37).
         assert tracks is not None
+        if self._fusable(model_output, tracks):
+            return self._fused(tracks, model_output, 1.0)
+        if len(tracks) == 0:
+            return torch.zeros((), dtype=torch.float32, device=batch.videos.device)
 
         _, _, _, h, w = batch.videos.shape
 

@@ -36,7 +36,9 @@ def procrustes_indices(h: int, w: int, num_points: Optional[int], randomize: boo
     if key not in _index_cache:
         if len(_index_cache) > 16:
             _index_cache.clear()
-        _index_cache[key] = torch.linspace(0, h * w - 1, num_points, dtype=torch.int64, device=device)
+        # Built on the host so the selection is identical on every device (torch.linspace with
+        # an integer dtype rounds differently on CPU and GPU); it is a constant, copied once.
+        _index_cache[key] = torch.linspace(0, h * w - 1, num_points, dtype=torch.int64).to(device)
     return _index_cache[key]
 
 

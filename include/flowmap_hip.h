@@ -3,7 +3,7 @@
  * The drop-in boundary for FlowMap's per-iteration reprojection / flow-consistency
  * inner loop.  The reference (dcharatan/flowmap) has NO native layer: the path is a
  * Python call surface (flowmap/model/projection.py, flowmap/model/procrustes.py,
- * flowmap/loss/**) executed as chains of ATen ops.  Each entry point below replaces
+ * flowmap/loss/) executed as chains of ATen ops.  Each entry point below replaces
  * one such chain; the citation names the reference code it stands in for.  The
  * Python host mirror (flowmap_amd/) binds these through ctypes and re-exposes the
  * reference's function / class names; INTEGRATION.md shows the binding a maintainer
@@ -170,6 +170,46 @@ int fm_mapping_bwd(const float* a, const float* b, const float* g_out, long coun
 int fm_align_rigid_stats(const float* p, const float* q, const float* w, int groups, long points, double* stats, void* stream);
 int fm_align_rigid_bwd(const float* p, const float* q, const float* w, int groups, long points, const double* aux,
                        const double* pair_grad, float* g_p, float* g_q, float* g_w, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused point-tracking loss.  Replaces LossTracking.compute_unweighted_loss
+ * (flowmap/loss/loss_tracking.py:28-61) + compute_track_flow (projection.py:255-298)
+ * for ALL segments at once, batch 1 (the reference asserts b == 1,
+ * tracking/__init__.py:89-90).  Tracks are packed once by the host:
+ *   xy (total,2) fp32, vis (total) uint8, total = Σ_s f_s·P_s, point (s, frame, p) at
+ *   seg[s].offset + frame·P_s + p;  seg (S,4) int32 = {start_frame, f, P, offset};
+ *   blocks (nblocks,2) int32 = every (segment, local frame);  pmax = max P, fmax = max f.
+ * depth (F,H,W); k, kinv (F,3,3); ext, ext_inv (F,4,4).
+ */
+int fm_extrinsics_inverse(const float* ext, int count, float* inv, void* stream); /* general 4x4 inverse, projection.py:288 */
+
+/* ws (total,6): camera-space xyz of every track point (bilinear sample of the surfaces,
+ * projection.py:266-273) and its world position E_fs·xyz; flag (total): visibility ∧
+ * source-in-frame (projection.py:290-294). */
+int fm_track_points(const float* depth, const float* kinv, const float* ext, const float* xy, const uint8_t* vis,
+                    const int32_t* seg, const int32_t* blocks, int nblocks, int pmax, int height, int width, float* ws,
+                    uint8_t* flag, void* stream);
+
+/* acc (frames*20 + 2) fp64 workspace (zeroed here).  loss[0] = weight·Σρ·vis/max(Σvis,1);
+ * scale[0] = weight/max(Σvis,1), scale[1] = Σvis. */
+int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
+                      const int32_t* blocks, int nblocks, int pmax, const float* ext_inv, const float* k, int frames, int height,
+                      int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, double* acc,
+                      float* loss, float* scale, void* stream);
+
+/* Gradients, all multiplied by scale[0]·upstream[0] (upstream NULL = 1): g_ext (F,4,4),
+ * g_k (F,3,3) and gws (total,3) = dL/dxyz of every track point; acc2 (frames*24) fp64
+ * workspace (zeroed here); acc from fm_track_loss_fwd. */
+int fm_track_loss_bwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
+                      const int32_t* blocks, int nblocks, int pmax, int fmax, const float* depth, const float* kinv, const float* ext,
+                      const float* ext_inv, const float* k, int frames, int height, int width, int mapping_kind, float delta,
+                      float aspect_x, float aspect_y, const double* acc, const float* scale, const float* upstream,
+                      float* gws, double* acc2, float* g_ext, float* g_k, void* stream);
+
+/* Scatter gws through the bilinear taps: ATOMICALLY ADDS into grad_depth (F,H,W). */
+int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
+                     const int32_t* blocks, int nblocks, int pmax, const float* kinv, int height, int width, float* grad_depth,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,138 @@
+"""Parity cases shared by the CPU (host test double) and GPU (HIP) test modules: each
+takes the device to run flowmap_amd on and compares against the reference's golden
+vectors (tests/golden, made by oracle/make_golden.py) and/or the oracle."""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from conftest import assert_close, load_golden, t
+from flowmap_amd import Tracks
+from flowmap_amd.loss.mapping import get_mapping
+from flowmap_amd.model import procrustes as fp
+from flowmap_amd.model import projection as fm
+from helpers import mapping_cfg
+from oracle import flowmap_oracle as orc
+
+TOL = 1e-4
+
+
+def _leaf(a, dev):
+    return t(a).to(dev).requires_grad_(True)
+
+
+def case_grid_and_unproject(dev):
+    g = load_golden("fn_unproject")
+    h, w = g["xy"].shape[:2]
+    xy, ij = fm.sample_image_grid((h, w), dev)
+    assert np.array_equal(xy.cpu().numpy(), g["xy"]) and np.array_equal(ij.cpu().numpy(), g["ij"])
+    z, k = _leaf(g["z"], dev), _leaf(g["k"], dev)
+    s = fm.unproject(xy, z, k[:, :, None, None])
+    assert isinstance(s, torch.Tensor)
+    (s * t(g["cot"]).to(dev)).sum().backward()
+    assert_close(s, g["surfaces"], 1e-6, what="surfaces")
+    assert_close(z.grad, g["g_z"], 1e-5, what="g_z")
+    assert_close(k.grad, g["g_k"], 1e-5, what="g_k")
+
+
+def case_flow_positions(dev):
+    g = load_golden("fn_flow_positions")
+    s, e, k = _leaf(g["surfaces"], dev), _leaf(g["extrinsics"], dev), _leaf(g["intrinsics"], dev)
+    f_ = fm.compute_forward_flow(s, e, k)
+    b_ = fm.compute_backward_flow(s, e, k)
+    ((f_ * t(g["cot_f"]).to(dev)).sum() + (b_ * t(g["cot_b"]).to(dev)).sum()).backward()
+    assert_close(f_, g["xy_fwd"], 1e-5, what="xy_fwd")
+    assert_close(b_, g["xy_bwd"], 1e-5, what="xy_bwd")
+    assert_close(s.grad, g["g_surfaces"], TOL, what="g_surfaces")
+    assert_close(e.grad, g["g_extrinsics"], TOL, what="g_extrinsics")
+    assert_close(k.grad, g["g_intrinsics"], TOL, what="g_intrinsics")
+    g1 = load_golden("fn_flow_positions_1d")  # 1-D grid, as IntrinsicsSoftmin calls it
+    b1 = fm.compute_backward_flow(t(g1["surfaces"]).to(dev), t(g1["extrinsics"]).to(dev), t(g1["intrinsics"]).to(dev))
+    assert_close(b1, g1["xy_bwd"], 1e-5, what="xy_bwd 1d")
+
+
+def case_projection_edges(dev):
+    g = load_golden("fn_project_edge")  # z = -eps (inf/nan clamps), behind camera, z ~ 0
+    out = fm.project_camera_space(t(g["points"]).to(dev), t(g["k"]).to(dev))
+    assert torch.isfinite(out).all()
+    assert_close(out, g["xy"], 1e-6, what="edge projection")
+    g = load_golden("fn_reproject")  # broadcasting (4,7,3) x (4,1,4,4) x (3,3)
+    assert_close(fm.reproject_points(t(g["xyz"]).to(dev), t(g["rel"]).to(dev), t(g["k"]).to(dev)), g["xy"], 1e-5, what="reproject")
+    g = load_golden("fn_project")
+    xy, front = fm.project(t(g["xyz"]).to(dev), t(g["extrinsics"]).to(dev), t(g["k"]).to(dev))
+    assert_close(xy, g["xy"], 1e-5, what="project")
+    assert np.array_equal(front.cpu().numpy(), g["in_front"])
+
+
+def case_pose_chain(dev):
+    g = load_golden("fn_get_extrinsics")
+    rel = _leaf(g["rel"], dev)
+    e = fm.get_extrinsics(rel)
+    (e * t(g["cot"]).to(dev)).sum().backward()
+    assert_close(e, g["extrinsics"], 1e-6, what="extrinsics")
+    assert_close(rel.grad, g["g_rel"], 1e-5, what="g_rel")
+
+
+def case_align_rigid(dev, case):
+    g = load_golden("fn_align_rigid")
+    p, q, w = _leaf(g[f"{case}_p"], dev), _leaf(g[f"{case}_q"], dev), _leaf(g[f"{case}_w"], dev)
+    T = fp.align_rigid(p, q, w)
+    (T * t(g[f"{case}_cot"]).to(dev)).sum().backward()
+    assert_close(T, g[f"{case}_T"], 1e-5, what="T")
+    # the reference's own fp32 svd_backward is only good to ~1e-4 on these small clouds
+    assert_close(p.grad, g[f"{case}_g_p"], 3e-4, what="g_p")
+    assert_close(q.grad, g[f"{case}_g_q"], 3e-4, what="g_q")
+    assert_close(w.grad, g[f"{case}_g_w"], 3e-4, what="g_w")
+    # ... so also check against the fp64 oracle, where the bar is the usual 1e-4
+    p64 = t(g[f"{case}_p"]).double().requires_grad_(True)
+    q64 = t(g[f"{case}_q"]).double().requires_grad_(True)
+    w64 = t(g[f"{case}_w"]).double().requires_grad_(True)
+    (orc.rigid_fit(p64, q64, w64) * t(g[f"{case}_cot"]).double()).sum().backward()
+    assert_close(p.grad, p64.grad, TOL, what="g_p vs fp64")
+    assert_close(q.grad, q64.grad, TOL, what="g_q vs fp64")
+    assert_close(w.grad, w64.grad, TOL, what="g_w vs fp64")
+
+
+def case_align_surfaces(dev, lazy):
+    g = load_golden("fn_align_surfaces")  # b=2, repeated indices, samples pushed off-image
+    z, k, w = _leaf(g["z"], dev), _leaf(g["k"], dev), _leaf(g["weights"], dev)
+    h, wd = z.shape[2:]
+    xy, _ = fm.sample_image_grid((h, wd), dev)
+    fm.set_lazy_surfaces(lazy)
+    try:
+        surfaces = fm.unproject(xy, z, k[:, :, None, None])
+        assert isinstance(surfaces, fm.LazySurfaces) == lazy
+        e = fm.align_surfaces(surfaces, t(g["bwd_flow"]).to(dev), w, t(g["indices"]).to(dev))
+    finally:
+        fm.set_lazy_surfaces(False)
+    (e * t(g["cot"]).to(dev)).sum().backward()
+    assert_close(e, g["extrinsics"], 1e-5, what="extrinsics")
+    assert_close(z.grad, g["g_z"], 3e-4, what="g_z")
+    assert_close(k.grad, g["g_k"], 3e-4, what="g_k")
+    assert_close(w.grad, g["g_weights"], 3e-4, what="g_weights")
+
+
+def case_track_flow(dev):
+    g = load_golden("fn_track_flow")
+    z, k, e = _leaf(g["z"], dev), _leaf(g["k"], dev), _leaf(g["extrinsics"], dev)
+    h, w = z.shape[2:]
+    xy, _ = fm.sample_image_grid((h, w), dev)
+    surfaces = fm.unproject(xy, z, k[:, :, None, None])
+    tgt, vis = fm.compute_track_flow(surfaces, e, k, Tracks(t(g["track_xy"]).to(dev), t(g["track_vis"]).to(dev), 0))
+    (tgt * t(g["cot"]).to(dev)).sum().backward()
+    assert_close(tgt, g["xy_target"], 1e-5, what="xy_target")
+    assert np.array_equal(vis.cpu().numpy(), g["visibility"])
+    assert_close(z.grad, g["g_z"], TOL, what="g_z")
+    assert_close(k.grad, g["g_k"], TOL, what="g_k")
+    assert_close(e.grad, g["g_extrinsics"], TOL, what="g_extrinsics")
+
+
+def case_mappings(dev, kind):
+    g = load_golden("fn_mapping")  # includes a zero residual and one on the huber knee
+    a = _leaf(g["a"], dev)
+    val = get_mapping(mapping_cfg(kind)).forward(a, t(g["b"]).to(dev), tuple(int(x) for x in g["image_shape"]))
+    val.sum().backward()
+    assert_close(val, g[f"{kind}_val"], 1e-6, what="value")
+    assert_close(a.grad, g[f"{kind}_g_a"], 1e-6, what="grad")
+    assert torch.isfinite(a.grad).all()

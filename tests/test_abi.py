@@ -1,0 +1,53 @@
+"""The C-ABI library loads and exports every entry point include/flowmap_hip.h declares;
+the ctypes table matches the header; the product path refuses to run without a GPU."""
+
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+from flowmap_amd import _lib
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "flowmap_hip.h").read_text()
+DECLS = re.findall(r"^int\s+(fm_\w+)\s*\(([^;]*?)\)\s*;", HEADER, flags=re.M | re.S)
+
+
+def test_header_declares_entry_points():
+    assert len(DECLS) >= 30
+    assert {n for n, _ in DECLS} == set(_lib.SIGNATURES), "ctypes table and header disagree on the symbol set"
+
+
+@pytest.mark.parametrize("name,args", DECLS)
+def test_signature_arity_matches_header(name, args):
+    n_args = len([a for a in args.split(",") if a.strip()])
+    assert n_args == len(_lib.SIGNATURES[name]), f"{name}: header has {n_args} parameters"
+
+
+def test_library_exports_every_symbol():
+    if not _lib.LIB_PATH.exists():
+        from flowmap_amd.build import build_library
+
+        build_library()
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    missing = [n for n, _ in DECLS if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_host_double_exports_every_symbol():
+    from helpers import build_host_sim
+
+    lib = ctypes.CDLL(str(build_host_sim()))
+    missing = [n for n, _ in DECLS if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must be refused loudly by the product path (no eager fallback)."""
+    from flowmap_amd.model import projection as fm
+
+    _lib.set_library_for_testing(None)
+    with pytest.raises(RuntimeError, match="no CPU fallback|needs a GPU"):
+        fm.get_extrinsics(torch.eye(4).repeat(1, 3, 1, 1))

@@ -131,3 +131,54 @@ def test_full_size_properties_c1():
     assert_close(ga[:, :75], g_whole[:, :75], 1e-4, what="shard A grads")
     assert_close(gb[:, 1:], g_whole[:, 76:], 1e-4, what="shard B grads")
     assert_close(ga[:, 75] + gb[:, 0], g_whole[:, 75], 1e-4, what="halo grad")
+
+
+# ---- function-level call surface on the GPU (same cases as test_hostsim_functions.py) ----
+import cases  # noqa: E402
+
+
+def test_fn_grid_and_unproject():
+    cases.case_grid_and_unproject(DEV)
+
+
+def test_fn_flow_positions():
+    cases.case_flow_positions(DEV)
+
+
+def test_fn_projection_edges():
+    cases.case_projection_edges(DEV)
+
+
+def test_fn_pose_chain():
+    cases.case_pose_chain(DEV)
+
+
+@pytest.mark.parametrize("case", ["generic", "noisy_planar", "few"])
+def test_fn_align_rigid(case):
+    cases.case_align_rigid(DEV, case)
+
+
+@pytest.mark.parametrize("lazy", [True, False])
+def test_fn_align_surfaces(lazy):
+    cases.case_align_surfaces(DEV, lazy)
+
+
+def test_fn_track_flow():
+    cases.case_track_flow(DEV)
+
+
+@pytest.mark.parametrize("kind", ["huber", "l1", "l2"])
+def test_fn_mappings(kind):
+    cases.case_mappings(DEV, kind)
+
+
+def test_tracking_scene_vs_oracle_fp64():
+    """Flow + tracking on a consistent scene with several overlapping segments (fused
+    tracking kernels, deferred depth scatter) against the fp64 oracle."""
+    f, h, w = 12, 40, 56
+    sc = orc.synth_scene(f, h, w, seed=4)
+    tr = orc.synth_tracks(f, h, w, scene=sc, seed=4, interval=3, radius=4, grid=9)
+    wl = 0.01 * torch.randn((f - 1, h, w), generator=torch.Generator().manual_seed(0))
+    ours = run_ours(sc["depth_init"], wl, 0.8, sc["flows"], (h, w), 300, tr, device=DEV)
+    ref = run_oracle(sc["depth_init"], wl, 0.8, sc["flows"], (h, w), 300, tr, dtype=torch.float64)
+    compare(ours, ref)

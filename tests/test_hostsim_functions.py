@@ -1,0 +1,50 @@
+"""Function-level call surface (flowmap_amd.model.projection / procrustes / loss.mapping)
+against the reference's golden vectors — CPU, through the host test double."""
+
+import pytest
+
+import cases
+from flowmap_amd import _lib
+from helpers import build_host_sim
+
+
+@pytest.fixture(autouse=True, scope="module")
+def host_double():
+    _lib.set_library_for_testing(build_host_sim())
+    yield
+    _lib.set_library_for_testing(None)
+
+
+def test_grid_and_unproject():
+    cases.case_grid_and_unproject("cpu")
+
+
+def test_flow_positions():
+    cases.case_flow_positions("cpu")
+
+
+def test_projection_edges():
+    cases.case_projection_edges("cpu")
+
+
+def test_pose_chain():
+    cases.case_pose_chain("cpu")
+
+
+@pytest.mark.parametrize("case", ["generic", "noisy_planar", "few"])
+def test_align_rigid(case):
+    cases.case_align_rigid("cpu", case)
+
+
+@pytest.mark.parametrize("lazy", [True, False])
+def test_align_surfaces(lazy):
+    cases.case_align_surfaces("cpu", lazy)
+
+
+def test_track_flow():
+    cases.case_track_flow("cpu")
+
+
+@pytest.mark.parametrize("kind", ["huber", "l1", "l2"])
+def test_mappings(kind):
+    cases.case_mappings("cpu", kind)

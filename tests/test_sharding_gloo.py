@@ -1,0 +1,109 @@
+"""Frame-pair sharding (flowmap_amd/sharding.py) with world_size 2 over gloo on CPU:
+the product host layer (through the host test double) on each shard + FrameShard.sync
+must reproduce the unsharded oracle: loss, dL/dfocal, dL/ddepth incl. the halo frame."""
+
+import os
+import socket
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+from flowmap_amd.sharding import shard_frames, shard_pairs  # noqa: E402
+
+
+def test_shard_pairs_cover_everything():
+    for pairs in (1, 5, 149, 1199):
+        for world in (1, 2, 4, 8):
+            ranges = shard_pairs(pairs, world)
+            assert ranges[0][0] == 0 and ranges[-1][1] == pairs
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+            for r in ranges:
+                first, last = shard_frames(r)
+                assert last - first == r[1] - r[0]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, f, h, w, points, out_path):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import flowmap_amd
+    from flowmap_amd import Batch, Flows, _lib
+    from flowmap_amd.loss import LossFlow, LossFlowCfg
+    from flowmap_amd.loss.mapping import MappingHuberCfg
+    from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
+    from flowmap_amd.sharding import FrameShard
+    from helpers import build_host_sim
+    from oracle import flowmap_oracle as orc
+
+    _lib.set_library_for_testing(build_host_sim())
+    flowmap_amd.set_lazy_surfaces(True)
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
+    a, b = shard_pairs(f - 1, world)[rank]
+    lo, hi = shard_frames((a, b))
+    nf = hi - lo + 1
+    cfg = ModelCfg(
+        BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
+        IntrinsicsRegressedCfg("regressed", 0.85),
+        ExtrinsicsProcrustesCfg("procrustes", points, False),
+    )
+    model = Model(cfg, num_frames=nf, image_shape=(h, w))
+    model.backbone.depth.data = depth[lo : hi + 1].clone()
+    model.backbone.weights.data = wlogit[a:b].clone()
+    local = Flows(flows.forward[:, a:b].contiguous(), flows.backward[:, a:b].contiguous(),
+                  flows.forward_mask[:, a:b].contiguous(), flows.backward_mask[:, a:b].contiguous())
+    batch = Batch(torch.zeros((1, nf, 3, h, w)))
+    loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
+    shard = FrameShard(rank, world, dist)
+    shard.prepare_flow_loss(loss_fn, local)
+    out = model(batch, local, 0)
+    loss = loss_fn(batch, local, None, out, 0)
+    loss.backward()
+    total = shard.sync(loss, model.intrinsics.focal_length, model.backbone.depth)
+    torch.save(
+        {"loss": total.clone(), "g_focal": model.intrinsics.focal_length.grad.clone(), "g_depth": model.backbone.depth.grad.clone(),
+         "g_w": model.backbone.weights.grad.clone(), "frames": (lo, hi), "pairs": (a, b)},
+        f"{out_path}.{rank}",
+    )
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_shards_match_unsharded_oracle(tmp_path):
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import assert_close
+    from helpers import run_oracle
+    from oracle import flowmap_oracle as orc
+
+    f, h, w, points = 7, 12, 16, 40
+    world = 2
+    out = str(tmp_path / "shard")
+    mp.spawn(_worker, args=(world, _free_port(), f, h, w, points, out), nprocs=world, join=True)
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
+    ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, dtype=torch.float64)
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    for r in res:
+        assert_close(r["loss"], ref["total"], 1e-5, what="global loss")
+        assert_close(r["g_focal"], ref["g_focal"], 1e-3, abs_=1e-4 * abs(float(ref["total"])), what="g_focal")
+        lo, hi = r["frames"]
+        a, b = r["pairs"]
+        assert_close(r["g_depth"], ref["g_depth"][lo : hi + 1], 1e-4, what="g_depth shard (halo summed)")
+        assert_close(r["g_w"], ref["g_wlogit"][a:b], 3e-4, what="g_wlogit shard")
