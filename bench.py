@@ -47,8 +47,11 @@ def parse():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--points", type=int, default=1000, help="Procrustes points (config/model/extrinsics/procrustes.yaml:3)")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="torch threads for the CPU baseline (16 measured fastest on the 256-thread EPYC 9575F host: "
+                    "8 -> 0.42, 16 -> 0.25, 32 -> 0.35, 64 -> 0.45, 256 -> 5.2 s/iter at 4 frames @720p)")
     ap.add_argument("--items-per-thread", type=int, default=0)
     return ap.parse_args()
 
@@ -69,12 +72,12 @@ def make_inputs(f, h, w, device, seed):
     return depth, wlogit, flows
 
 
-def cpu_baseline(frames, h, w, points, iters):
+def cpu_baseline(frames, h, w, points, iters, threads):
     """The oracle (PyTorch CPU port of the reference path) on a bounded sample: same
     frame size, fewer frames; forward + backward, all host cores."""
     from oracle import flowmap_oracle as orc
 
-    cores = os.cpu_count() or 1
+    cores = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(cores)
     depth, wlogit, flows = orc.synth_iid(frames, h, w, seed=0)
     depth.requires_grad_(True)
@@ -210,14 +213,15 @@ def main():
             },
         }
         if world == 1 and args.cpu_frames >= 2:
-            dt, cores = cpu_baseline(args.cpu_frames, h, w, args.points, args.cpu_iters)
+            dt, cores = cpu_baseline(args.cpu_frames, h, w, args.points, args.cpu_iters, args.cpu_threads)
             scaled = dt * (f - 1) / (args.cpu_frames - 1)  # per-pair cost is constant (optimistic for the CPU)
             result["cpu_baseline"] = {
                 "value": 1.0 / scaled,
                 "unit": "iters/sec",
                 "cores": cores,
                 "kind": "port",
-                "sample": f"oracle (PyTorch-CPU port of the reference path), {args.cpu_frames} frames @ {h}x{w}, fwd+bwd, "
+                "host_logical_cpus": os.cpu_count(),
+                "sample": f"oracle (PyTorch-CPU port of the reference path), {cores} torch threads, {args.cpu_frames} frames @ {h}x{w}, fwd+bwd, "
                 f"{args.cpu_iters} timed iters after 1 warm-up: {dt:.3f} s/iter, scaled by pairs ({f - 1}/{args.cpu_frames - 1}) "
                 f"to {f} frames",
                 "sample_seconds_per_iter": dt,

@@ -23,11 +23,29 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Wave64 sum with DPP lane moves only (no LDS traffic, unlike ds_bpermute shuffles):
+// quad butterflies, the two row mirrors, then the cross-row broadcasts.  The total is
+// valid in lane 63 (and every lane of the last 16-lane row).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v += dpp_mov<0xB1, 0xf>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_mov<0x4E, 0xf>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_mov<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_mov<0x140, 0xf>(v);  // row_mirror        -> every lane holds its row's sum
+  v += dpp_mov<0x142, 0xa>(v);  // row_bcast:15      -> rows 1,3 += rows 0,2
+  v += dpp_mov<0x143, 0xc>(v);  // row_bcast:31      -> rows 2,3 += rows 0+1
+  return v;
+}
+
 // Block-wide reduction of NV per-thread fp32 partials followed by ONE fp64 atomic per
 // value per block (guide §6 G12).  `lds` must hold (blockDim.x/64) * NV doubles.
-// Per-thread partials are fp32; everything above a thread (wave butterfly, cross-wave,
+// Per-thread partials and the in-wave tree are fp32 (a 6-level tree adds less rounding
+// than the ≥32-term per-thread sums below it); everything above a wave (cross-wave,
 // cross-block) is fp64, so the heavily cancelling pose/intrinsics gradient sums over
-// ~1e6 pixels keep ~1e-7 relative accuracy and are reproducible to fp32 rounding.
+// ~1e6 pixels do not lose accuracy as the image grows.
 template <int NV>
 __device__ __forceinline__ void block_accumulate(const float (&v)[NV], double* lds, double* dst) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -35,8 +53,8 @@ __device__ __forceinline__ void block_accumulate(const float (&v)[NV], double* l
   const int nwaves = blockDim.x >> 6;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const double s = wave_sum((double)v[i]);
-    if (lane == 0) lds[wave * NV + i] = s;
+    const float s = wave_sum_lane63(v[i]);
+    if (lane == kWave - 1) lds[wave * NV + i] = (double)s;
   }
   __syncthreads();
   if (threadIdx.x < NV) {

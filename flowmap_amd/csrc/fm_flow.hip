@@ -44,8 +44,105 @@ struct FlowParams {
   int iters;              // items per thread
 };
 
-template <int VEC, bool GRAD>
-__global__ void __launch_bounds__(256) flow_fused_kernel(FlowParams p) {
+// Per-(frame, direction) constants, wave-uniform (SGPRs).
+//   m    = R·K⁻¹_src (3x3): X' = z·(m·[u,v,1]) + t, so neither the ray nor the camera-space
+//          point of the source pixel is formed per direction, and dL/dz = g_X'·(m·[u,v,1]).
+//   kd   = rows 0,1 of the destination intrinsics.
+struct DirConst {
+  float m[9];
+  float t[3];
+  float kd[6];
+};
+
+__device__ __forceinline__ void make_dir(const Pose& pose, const Mat3& kinv, const Mat3& kd, DirConst& d) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      d.m[r * 3 + c] = pose.r[r * 3 + 0] * kinv.m[0 * 3 + c] + pose.r[r * 3 + 1] * kinv.m[1 * 3 + c] + pose.r[r * 3 + 2] * kinv.m[2 * 3 + c];
+    d.t[r] = pose.t[r];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) d.kd[i] = kd.m[i];
+}
+
+// Residual + gradient of one (pixel, direction): branch-free, ~95 VALU ops.
+//  * hardware reciprocal / reciprocal-square-root (1 ulp) instead of IEEE divide + sqrt:
+//    the loss moves by < 1e-7 relative;
+//  * the singular case Z' + 1e-5 == 0 (1/s not finite): the reference clamps the
+//    projection to ±1e8 and its GRADIENT IS NaN there (inf·0).  A pixel in
+//    that measure-zero set is dropped here (zero loss, zero gradient) by zeroing its
+//    mask; the function-level reproject kernels keep the exact clamp semantics.
+template <int KIND, bool GRAD>
+__device__ __forceinline__ void flow_term_fast(const DirConst& d, float z, float u, float v, float zu, float zv, float flow_x,
+                                               float flow_y, float m, float scale, float delta, float inv_delta, float ax,
+                                               float ay, float (&acc)[kFlowAcc], float& gz) {
+  const float mh0 = fmaf(d.m[0], u, fmaf(d.m[1], v, d.m[2]));
+  const float mh1 = fmaf(d.m[3], u, fmaf(d.m[4], v, d.m[5]));
+  const float mh2 = fmaf(d.m[6], u, fmaf(d.m[7], v, d.m[8]));
+  const float x0 = fmaf(z, mh0, d.t[0]);
+  const float x1 = fmaf(z, mh1, d.t[1]);
+  const float x2 = fmaf(z, mh2, d.t[2]);
+  float inv_s = __builtin_amdgcn_rcpf(x2 + kProjEps);
+  const bool ok = __builtin_fabsf(inv_s) <= 3.0e38f;
+  inv_s = ok ? inv_s : 0.f;
+  m = ok ? m : 0.f;
+  const float p0 = x0 * inv_s, p1 = x1 * inv_s, p2 = x2 * inv_s;
+  const float pu = fmaf(d.kd[0], p0, fmaf(d.kd[1], p1, d.kd[2] * p2));
+  const float pv = fmaf(d.kd[3], p0, fmaf(d.kd[4], p1, d.kd[5] * p2));
+  const float rx = ((pu - u) - flow_x) * ax;
+  const float ry = ((pv - v) - flow_y) * ay;
+  const float ss = fmaf(rx, rx, ry * ry);
+  float rho, coef;  // ρ and dρ/dr = coef·r
+  if (KIND == kL2) {
+    rho = 0.5f * ss;
+    coef = 1.f;
+  } else {
+    const float inv_n = ss > 0.f ? __builtin_amdgcn_rsqf(ss) : 0.f;
+    const float n = ss * inv_n;
+    if (KIND == kL1) {
+      rho = n;
+      coef = inv_n;
+    } else {
+      const bool quad = n < delta;
+      rho = quad ? 0.5f * ss * inv_delta : n - 0.5f * delta;
+      coef = quad ? inv_delta : inv_n;
+    }
+  }
+  acc[0] = fmaf(rho, m, acc[0]);
+  if (GRAD) {
+    const float gc = scale * m * coef;
+    const float gu = gc * rx * ax;
+    const float gv = gc * ry * ay;
+    acc[13] = fmaf(gu, p0, acc[13]);
+    acc[14] = fmaf(gu, p1, acc[14]);
+    acc[15] = fmaf(gu, p2, acc[15]);
+    acc[16] = fmaf(gv, p0, acc[16]);
+    acc[17] = fmaf(gv, p1, acc[17]);
+    acc[18] = fmaf(gv, p2, acc[18]);
+    const float gp0 = fmaf(d.kd[0], gu, d.kd[3] * gv);
+    const float gp1 = fmaf(d.kd[1], gu, d.kd[4] * gv);
+    const float gp2 = fmaf(d.kd[2], gu, d.kd[5] * gv);
+    const float dot = fmaf(gp0, p0, fmaf(gp1, p1, gp2 * p2));
+    const float g0 = gp0 * inv_s, g1 = gp1 * inv_s, g2 = (gp2 - dot) * inv_s;  // dL/dX'
+    acc[1] += g0;
+    acc[2] += g1;
+    acc[3] += g2;
+    acc[4] = fmaf(g0, zu, acc[4]);
+    acc[5] = fmaf(g0, zv, acc[5]);
+    acc[6] = fmaf(g0, z, acc[6]);
+    acc[7] = fmaf(g1, zu, acc[7]);
+    acc[8] = fmaf(g1, zv, acc[8]);
+    acc[9] = fmaf(g1, z, acc[9]);
+    acc[10] = fmaf(g2, zu, acc[10]);
+    acc[11] = fmaf(g2, zv, acc[11]);
+    acc[12] = fmaf(g2, z, acc[12]);
+    gz = fmaf(g0, mh0, fmaf(g1, mh1, fmaf(g2, mh2, gz)));
+  }
+}
+
+template <int VEC, int KIND, bool GRAD>
+__global__ void __launch_bounds__(256, 4) flow_fused_kernel(FlowParams p) {
   extern __shared__ double lds[];  // reduction scratch (fp64), then the [width] u-table
   double* red = lds;
   float* u_tab = reinterpret_cast<float*>(lds + (256 / 64) * kFlowAcc);
@@ -62,20 +159,26 @@ __global__ void __launch_bounds__(256) flow_fused_kernel(FlowParams p) {
   for (int c = threadIdx.x; c < p.width; c += blockDim.x) u_tab[c] = pixel_center(c, p.width);
   __syncthreads();
 
-  Mat3 kinv, k_f, k_b;
-  Pose t_f, t_b;
-  load_mat3(p.kinv + (size_t)bf * 9, kinv);
+  DirConst df, db;
   const size_t pair_f = (size_t)b * (p.frames - 1) + f;  // pair whose earlier frame is f
   const size_t pair_b = pair_f - 1;                       // pair whose later frame is f
-  if (has_fwd) {
-    load_mat3(p.k + (size_t)(bf + 1) * 9, k_f);
-    load_pose44(p.t_fwd + pair_f * 16, t_f);
-  }
-  if (has_bwd) {
-    load_mat3(p.k + (size_t)(bf - 1) * 9, k_b);
-    load_pose44(p.t_bwd + pair_b * 16, t_b);
+  {
+    Mat3 kinv, kd;
+    Pose t;
+    load_mat3(p.kinv + (size_t)bf * 9, kinv);
+    if (has_fwd) {
+      load_mat3(p.k + (size_t)(bf + 1) * 9, kd);
+      load_pose44(p.t_fwd + pair_f * 16, t);
+      make_dir(t, kinv, kd, df);
+    }
+    if (has_bwd) {
+      load_mat3(p.k + (size_t)(bf - 1) * 9, kd);
+      load_pose44(p.t_bwd + pair_b * 16, t);
+      make_dir(t, kinv, kd, db);
+    }
   }
   const float scale = GRAD ? p.scale[0] : 0.f;
+  const float inv_delta = KIND == kHuber ? 1.0f / p.delta : 0.f;
 
   const float* depth = p.depth + (size_t)bf * n;
   const float* ff = p.flow_fwd + pair_f * (size_t)n * 2;
@@ -88,6 +191,10 @@ __global__ void __launch_bounds__(256) flow_fused_kernel(FlowParams p) {
 #pragma unroll
   for (int i = 0; i < kFlowAcc; ++i) acc_f[i] = acc_b[i] = 0.f;
 
+  // The direction tests below are wave-uniform run-time branches ON PURPOSE: they keep each
+  // residual's loads and ~95 ops together.  With compile-time direction flags the
+  // scheduler hoists all seven 16-byte loads and interleaves the eight residuals of a
+  // quad, and the kernel spills (measured: 336 B/lane scratch, +40 % instructions).
   const int base = blockIdx.x * (blockDim.x * p.iters);
   for (int it = 0; it < p.iters; ++it) {
     const int item = base + it * blockDim.x + threadIdx.x;
@@ -129,11 +236,10 @@ __global__ void __launch_bounds__(256) flow_fused_kernel(FlowParams p) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float u = u_tab[col0 + e];
-      float ray[3];
-      ray_dir(kinv, u, v, ray);
+      const float zu = z[e] * u, zv = z[e] * v;
       gz[e] = 0.f;
-      if (has_fwd) flow_term<GRAD>(t_f, k_f, ray, z[e], u, v, fxf[e], fyf[e], mmf[e], scale, p.kind, p.delta, p.ax, p.ay, acc_f, gz[e]);
-      if (has_bwd) flow_term<GRAD>(t_b, k_b, ray, z[e], u, v, fxb[e], fyb[e], mmb[e], scale, p.kind, p.delta, p.ax, p.ay, acc_b, gz[e]);
+      if (has_fwd) flow_term_fast<KIND, GRAD>(df, z[e], u, v, zu, zv, fxf[e], fyf[e], mmf[e], scale, p.delta, inv_delta, p.ax, p.ay, acc_f, gz[e]);
+      if (has_bwd) flow_term_fast<KIND, GRAD>(db, z[e], u, v, zu, zv, fxb[e], fyb[e], mmb[e], scale, p.delta, inv_delta, p.ax, p.ay, acc_b, gz[e]);
     }
     if (GRAD && gd) {
       if (VEC == 4) {
@@ -237,7 +343,7 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   hipStream_t st = (hipStream_t)stream;
   const bool grad = scale != nullptr;
   FlowParams p{depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, scale, grad_depth, acc,
-               frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 8};
+               frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 16};
   if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride, st) != hipSuccess) return FM_ERR_LAUNCH;
   auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool vec4 = (width % 4 == 0) && aligned(depth) && aligned(flow_fwd) && aligned(flow_bwd) && aligned(mask_fwd) &&
@@ -248,13 +354,21 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   const long per_block = (long)threads * p.iters;
   dim3 grid((unsigned)((items + per_block - 1) / per_block), (unsigned)(batch * frames));
   const size_t lds = sizeof(float) * (size_t)width + sizeof(double) * (threads / 64) * kFlowAcc;
-  if (vec4) {
-    if (grad) hipLaunchKernelGGL((flow_fused_kernel<4, true>), grid, dim3(threads), lds, st, p);
-    else hipLaunchKernelGGL((flow_fused_kernel<4, false>), grid, dim3(threads), lds, st, p);
-  } else {
-    if (grad) hipLaunchKernelGGL((flow_fused_kernel<1, true>), grid, dim3(threads), lds, st, p);
-    else hipLaunchKernelGGL((flow_fused_kernel<1, false>), grid, dim3(threads), lds, st, p);
-  }
+#define FM_FLOW_LAUNCH(V, K)                                                                              \
+  do {                                                                                                    \
+    if (grad) hipLaunchKernelGGL((flow_fused_kernel<V, K, true>), grid, dim3(threads), lds, st, p);       \
+    else hipLaunchKernelGGL((flow_fused_kernel<V, K, false>), grid, dim3(threads), lds, st, p);          \
+  } while (0)
+#define FM_FLOW_KIND(V)                                          \
+  do {                                                           \
+    if (mapping_kind == kHuber) FM_FLOW_LAUNCH(V, kHuber);       \
+    else if (mapping_kind == kL1) FM_FLOW_LAUNCH(V, kL1);        \
+    else FM_FLOW_LAUNCH(V, kL2);                                 \
+  } while (0)
+  if (vec4) FM_FLOW_KIND(4);
+  else FM_FLOW_KIND(1);
+#undef FM_FLOW_KIND
+#undef FM_FLOW_LAUNCH
   FM_LAUNCH_STATUS();
 }
 

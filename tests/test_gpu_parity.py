@@ -53,7 +53,7 @@ def test_step_vs_reference_golden(name, kind, lazy):
         (16, 256, 256, 1000),  # C0 (BASELINE.json configs[0])
         (4, 720, 1280, 1000),  # C1's frame size, few frames (oracle finishes in seconds)
         (5, 90, 122, None),  # width not a multiple of 4 -> scalar kernel path, dense Procrustes
-        (3, 64, 96, 64),
+        (3, 64, 96, 600),
     ],
 )
 def test_step_vs_oracle(f, h, w, p):
