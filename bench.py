@@ -170,6 +170,13 @@ def main():
         elapsed = float(tmax.item())
 
     kernel_ms = sum(s.elapsed_time(e) for s, e in kernel_events) / max(len(kernel_events), 1)
+    traffic, traffic_src = None, None
+    try:  # HBM bytes per launch from the PMC passes committed under profiles/ (same workload only)
+        rec = json.loads((ROOT / "profiles" / "r01_flow_kernel_traffic.json").read_text())
+        if rec["workload"] == {"frames": args.frames, "height": args.height, "width": args.width}:
+            traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_flow_kernel_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"
+    except Exception:
+        pass
     n = h * w
     algo_bytes = n * (8 * f + 24 * (f - 1))  # B_flow per launch
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -206,7 +213,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": kernel_ms,
                 "launches_timed": len(kernel_events),

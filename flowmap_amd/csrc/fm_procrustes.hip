@@ -234,18 +234,135 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
 // element walks the chain in fp64 (F ≤ a few thousand; latency ≈ tens of µs, replacing
 // F-1 dependent matmul launches).  Backward is the reverse scan.
 // ---------------------------------------------------------------------------------
-__global__ void pose_chain_fwd_kernel(const float* rel, int batch, int steps, float* ext) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
-  pose_chain_fwd_one(rel + (size_t)b * steps * 16, steps, ext + (size_t)b * (steps + 1) * 16);
+// Forward: one block per batch element.  Each thread multiplies a chunk of consecutive
+// relative poses, the chunk products are prefix-multiplied with a Hillis-Steele scan in
+// LDS (8 dependent 4x4 products instead of F-1), then every thread re-walks its chunk
+// from its exclusive prefix and writes the extrinsics.
+constexpr int kChainThreads = 256;
+
+__device__ __forceinline__ void load16(const float* p, double* o) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) o[k] = p[k];
 }
 
-__global__ void pose_chain_bwd_kernel(const float* rel, const float* ext, const float* g_ext, int batch, int steps,
-                                      float* g_rel) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
-  pose_chain_bwd_one(rel + (size_t)b * steps * 16, ext + (size_t)b * (steps + 1) * 16, g_ext + (size_t)b * (steps + 1) * 16,
-                     steps, g_rel + (size_t)b * steps * 16);
+__global__ void __launch_bounds__(kChainThreads) pose_chain_fwd_kernel(const float* rel, int batch, int steps, float* ext) {
+  __shared__ double buf[2][kChainThreads][16];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* r = rel + (size_t)b * steps * 16;
+  float* e = ext + (size_t)b * (steps + 1) * 16;
+  const int chunk = (steps + kChainThreads - 1) / kChainThreads;
+  const int lo = t * chunk, hi = min(steps, lo + chunk);
+  double prod[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int s = lo; s < hi; ++s) {
+    double m[16], nxt[16];
+    load16(r + (size_t)s * 16, m);
+    mat4_mul(prod, m, nxt);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) prod[k] = nxt[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) buf[0][t][k] = prod[k];
+  __syncthreads();
+  int cur = 0;
+  for (int off = 1; off < kChainThreads; off <<= 1) {  // inclusive scan: buf[t] = C_0 · … · C_t
+    double mine[16], out[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mine[k] = buf[cur][t][k];
+    if (t >= off) {
+      double left[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) left[k] = buf[cur][t - off][k];
+      mat4_mul(left, mine, out);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) out[k] = mine[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) buf[cur ^ 1][t][k] = out[k];
+    __syncthreads();
+    cur ^= 1;
+  }
+  double run[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  if (t > 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) run[k] = buf[cur][t - 1][k];  // exclusive prefix
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = (float)run[k];  // E_0 = I
+  }
+  for (int s = lo; s < hi; ++s) {
+    double m[16], nxt[16];
+    load16(r + (size_t)s * 16, m);
+    mat4_mul(run, m, nxt);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      run[k] = nxt[k];
+      e[(size_t)(s + 1) * 16 + k] = (float)nxt[k];
+    }
+  }
+}
+
+// Backward.  The reverse recurrence  carry_s = G_s + carry_{s+1}·T_sᵀ  unrolls, with
+// T_s·…·T_{j-1} = E_s⁻¹·E_j, to  carry_s = (Σ_{j≥s} G_j·E_jᵀ)·E_s⁻ᵀ : an ADDITIVE suffix
+// sum of A_j = G_j·E_jᵀ (parallel scan in LDS) followed by independent 4x4 products;
+// dL/dT_s = E_sᵀ·carry_{s+1}.
+__global__ void __launch_bounds__(kChainThreads) pose_chain_bwd_kernel(const float* rel, const float* ext, const float* g_ext,
+                                                                     int batch, int steps, float* g_rel) {
+  __shared__ double buf[2][kChainThreads][16];
+  (void)rel;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* e = ext + (size_t)b * (steps + 1) * 16;
+  const float* ge = g_ext + (size_t)b * (steps + 1) * 16;
+  float* o = g_rel + (size_t)b * steps * 16;
+  const int frames = steps + 1;
+  const int chunk = (frames + kChainThreads - 1) / kChainThreads;
+  const int lo = t * chunk, hi = min(frames, lo + chunk);
+  // chunk sums of A_j
+  double sum[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sum[k] = 0.0;
+  for (int j = lo; j < hi; ++j) {
+    double g[16], ej[16], a[16];
+    load16(ge + (size_t)j * 16, g);
+    load16(e + (size_t)j * 16, ej);
+    mat4_mul_nt(g, ej, a);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum[k] += a[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) buf[0][t][k] = sum[k];
+  __syncthreads();
+  int cur = 0;
+  for (int off = 1; off < kChainThreads; off <<= 1) {  // inclusive SUFFIX sum over chunks
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = buf[cur][t][k] + (t + off < kChainThreads ? buf[cur][t + off][k] : 0.0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) buf[cur ^ 1][t][k] = v[k];
+    __syncthreads();
+    cur ^= 1;
+  }
+  // suffix[j] for j in this chunk, walking from the chunk's end: start with the sum of all later chunks
+  double suf[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) suf[k] = (t + 1 < kChainThreads) ? buf[cur][t + 1][k] : 0.0;
+  for (int j = hi - 1; j >= lo; --j) {
+    double g[16], ej[16], a[16];
+    load16(ge + (size_t)j * 16, g);
+    load16(e + (size_t)j * 16, ej);
+    mat4_mul_nt(g, ej, a);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) suf[k] += a[k];  // = Σ_{i≥j} A_i
+    if (j >= 1) {                                  // dL/dT_{j-1} = E_{j-1}ᵀ · (suf_j · E_j⁻ᵀ)
+      double inv[16], carry[16], prev[16], gt[16];
+      inv4(ej, inv);
+      mat4_mul_nt(suf, inv, carry);
+      load16(e + (size_t)(j - 1) * 16, prev);
+      mat4_mul_tn(prev, carry, gt);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) o[(size_t)(j - 1) * 16 + k] = (float)gt[k];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -383,13 +500,13 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
 
 int fm_pose_chain_fwd(const float* rel, int batch, int steps, float* ext, void* stream) {
   FM_CHECK_ARG(rel && ext && batch >= 1 && steps >= 0);
-  hipLaunchKernelGGL(pose_chain_fwd_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, rel, batch, steps, ext);
+  hipLaunchKernelGGL(pose_chain_fwd_kernel, dim3(batch), dim3(kChainThreads), 0, (hipStream_t)stream, rel, batch, steps, ext);
   FM_LAUNCH_STATUS();
 }
 
 int fm_pose_chain_bwd(const float* rel, const float* ext, const float* g_ext, int batch, int steps, float* g_rel, void* stream) {
   FM_CHECK_ARG(rel && ext && g_ext && g_rel && batch >= 1 && steps >= 0);
-  hipLaunchKernelGGL(pose_chain_bwd_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, rel, ext, g_ext, batch,
+  hipLaunchKernelGGL(pose_chain_bwd_kernel, dim3(batch), dim3(kChainThreads), 0, (hipStream_t)stream, rel, ext, g_ext, batch,
                      steps, g_rel);
   FM_LAUNCH_STATUS();
 }

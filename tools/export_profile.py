@@ -1,0 +1,60 @@
+"""Turn rocprofv3 SQLite outputs into small text/CSV summaries (for profiles/).
+
+    python tools/export_profile.py <stats_dir> [<pmc_dir> ...]
+Prints a kernel table (calls, total, average µs, %) for the first directory and, for
+every further directory, the per-kernel average of each collected PMC counter.
+"""
+import glob
+import sqlite3
+import sys
+
+
+def db_in(d):
+    hits = glob.glob(f"{d}/**/*.db", recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name, n=90):
+    name = name.replace("void ", "")
+    return name if len(name) <= n else name[: n - 3] + "..."
+
+
+def kernel_table(path):
+    con = sqlite3.connect(path)
+    rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    print("kernel,calls,total_us,avg_us,percent")
+    for name, calls, total, avg, pct in rows:
+        print(f"\"{short(name)}\",{calls},{total:.1f},{avg:.2f},{pct:.2f}")
+
+
+def pmc_table(path):
+    con = sqlite3.connect(path)
+    cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
+    print("# columns:", cols)
+    name_col = "kernel_name" if "kernel_name" in cols else ("name" if "name" in cols else None)
+    cnt_col = "counter_name" if "counter_name" in cols else None
+    val_col = "value" if "value" in cols else ("counter_value" if "counter_value" in cols else None)
+    if not (name_col and cnt_col and val_col):
+        for r in con.execute("select * from counters_collection limit 5"):
+            print(r)
+        return
+    q = f"select {name_col}, {cnt_col}, count(*), avg({val_col}), sum({val_col}) from counters_collection group by {name_col}, {cnt_col} order by sum({val_col}) desc limit 25"
+    print("kernel,counter,dispatches,avg_value,sum_value")
+    for name, cnt, n, avg, tot in con.execute(q):
+        print(f"\"{short(name)}\",{cnt},{n},{avg:.1f},{tot:.1f}")
+
+
+if __name__ == "__main__":
+    dirs = sys.argv[1:]
+    for i, d in enumerate(dirs):
+        path = db_in(d)
+        print(f"## {d}: {path}")
+        if not path:
+            continue
+        try:
+            if i == 0:
+                kernel_table(path)
+            else:
+                pmc_table(path)
+        except Exception as exc:  # keep going: the raw db is merged back anyway
+            print("error:", exc)
