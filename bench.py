@@ -53,6 +53,8 @@ def parse():
                     help="torch threads for the CPU baseline (16 measured fastest on the 256-thread EPYC 9575F host: "
                     "8 -> 0.42, 16 -> 0.25, 32 -> 0.35, 64 -> 0.45, 256 -> 5.2 s/iter at 4 frames @720p)")
     ap.add_argument("--items-per-thread", type=int, default=0)
+    ap.add_argument("--tracking", action="store_true",
+                    help="BASELINE.json configs[2]: add the tracking loss (segments every 5 frames, +-20 frames, 35x35 tracks)")
     return ap.parse_args()
 
 
@@ -137,6 +139,14 @@ def main():
     loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
     if args.items_per_thread:
         loss_fn.items_per_thread = args.items_per_thread
+    tracks, track_fn = None, None
+    if args.tracking:
+        from flowmap_amd import Tracks
+        from flowmap_amd.loss import LossTracking, LossTrackingCfg
+        from oracle import flowmap_oracle as orc  # input generator only (i.i.d. track layout of tracking/__init__.py:49-70)
+
+        tracks = [Tracks(t.xy.to(device), t.visibility.to(device), t.start_frame) for t in orc.synth_tracks(f, h, w, scene=None, seed=rank)]
+        track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
     shard = FrameShard(rank, world, dist)
     shard.prepare_flow_loss(loss_fn, flows)  # global valid-sum (one-time all-reduce)
 
@@ -147,6 +157,8 @@ def main():
         model.zero_grad(set_to_none=True)
         out = model(batch, flows, 0)
         loss = loss_fn(batch, flows, None, out, 0)
+        if track_fn is not None:
+            loss = loss + track_fn(batch, flows, tracks, out, 0)
         loss.backward()
         shard.sync(loss, model.intrinsics.focal_length, model.backbone.depth)
         return loss
@@ -199,7 +211,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE.json configs[1]: {f} frames @ {h}x{w}, flow loss only (huber 0.01, weight 1000), "
-                f"explicit-depth backbone, regressed intrinsics, Procrustes P={args.points}; fwd+bwd, no optimiser",
+                f"explicit-depth backbone, regressed intrinsics, Procrustes P={args.points}; fwd+bwd, no optimiser"
+                + (f"; + tracking loss (configs[2]): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else ""),
                 "frames_per_gpu": f,
                 "height": h,
                 "width": w,

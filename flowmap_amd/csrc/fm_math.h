@@ -138,6 +138,19 @@ FM_HD void apply_rot_t(const Pose& t, const float g[3], float o[3]) {  // Rᵀ g
   o[2] = t.r[2] * g[0] + t.r[5] * g[1] + t.r[8] * g[2];
 }
 
+// fix_aspect_ratio(a) − fix_aspect_ratio(b) (mapping.py:41-43): two ROUNDED products, then
+// the difference.  Must not be contracted into an FMA: with a == b the reference gets an
+// exact 0 (and ‖·‖'s sub-gradient 0 there), a fused multiply-add leaves the rounding
+// residue of one product and turns that into a unit-length L1 gradient.
+FM_HD float aspect_diff(float a, float b, float s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __fsub_rn(__fmul_rn(a, s), __fmul_rn(b, s));
+#else
+  volatile float pa = a * s, pb = b * s;
+  return pa - pb;
+#endif
+}
+
 // Robust mapping of an aspect-corrected residual (rx, ry): value and d(value)/d(rx,ry).
 //   huber: F.huber_loss(n, 0, delta)/delta  (mapping_huber.py:23-34)
 //   l1:    n                                 (mapping_l1.py:20)
@@ -222,8 +235,8 @@ FM_HD void flow_term(const Pose& tr, const Mat3& kd, const float ray[3], float z
   apply_pose(tr, x, xc);
   const Projected pr = project_point(xc, kd);
   // Mapping.forward: fix_aspect_ratio(a) - fix_aspect_ratio(b) (mapping.py:41-43)
-  const float rx = (pr.u - u) * ax - flow_x * ax;
-  const float ry = (pr.v - v) * ay - flow_y * ay;
+  const float rx = aspect_diff(pr.u - u, flow_x, ax);
+  const float ry = aspect_diff(pr.v - v, flow_y, ay);
   float drx, dry;
   const float rho = robust_map(kind, delta, rx, ry, drx, dry);
   acc[0] += rho * m;

@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) mapping_fwd_kernel(const float* a, const 
     const float2 pa = reinterpret_cast<const float2*>(a)[i];
     const float2 pb = reinterpret_cast<const float2*>(b)[i];
     float dx, dy;
-    out[i] = robust_map(kind, delta, pa.x * ax - pb.x * ax, pa.y * ay - pb.y * ay, dx, dy);
+    out[i] = robust_map(kind, delta, aspect_diff(pa.x, pb.x, ax), aspect_diff(pa.y, pb.y, ay), dx, dy);
   }
 }
 
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) mapping_bwd_kernel(const float* a, const 
     const float2 pa = reinterpret_cast<const float2*>(a)[i];
     const float2 pb = reinterpret_cast<const float2*>(b)[i];
     float dx, dy;
-    robust_map(kind, delta, pa.x * ax - pb.x * ax, pa.y * ay - pb.y * ay, dx, dy);
+    robust_map(kind, delta, aspect_diff(pa.x, pb.x, ax), aspect_diff(pa.y, pb.y, ay), dx, dy);
     const float go = g_out[i];
     const float gx = go * dx * ax, gy = go * dy * ay;
     if (g_a) reinterpret_cast<float2*>(g_a)[i] = make_float2(gx, gy);

@@ -91,7 +91,7 @@ __device__ __forceinline__ bool track_eval(const Pose& einv_t, const Mat3& k_t, 
   apply_pose(einv_t, xw, xc);
   o.pr = project_point(xc, k_t);
   if (!(o.pr.u >= 0.f && o.pr.v >= 0.f && o.pr.u < 1.f && o.pr.v < 1.f)) return false;
-  o.rho = robust_map(kind, delta, o.pr.u * ax - gt_x * ax, o.pr.v * ay - gt_y * ay, o.drx, o.dry);
+  o.rho = robust_map(kind, delta, aspect_diff(o.pr.u, gt_x, ax), aspect_diff(o.pr.v, gt_y, ay), o.drx, o.dry);
   return true;
 }
 

@@ -59,11 +59,14 @@ def sample_image_grid(shape: Tuple[int, ...], device: torch.device = torch.devic
     hit = _grid_cache.get(key)
     if hit is not None:
         return hit
-    indices = [torch.arange(length, device=device) for length in shape]
-    stacked = torch.stack(torch.meshgrid(*indices, indexing="ij"), dim=-1)
+    # Built on the host and copied once: torch's GPU division differs from the CPU's by an
+    # ulp on some pixel centres, and the kernels (which derive coordinates from the thread
+    # index with an IEEE divide) follow the CPU values the oracle and golden vectors use.
+    indices = [torch.arange(length) for length in shape]
+    stacked = torch.stack(torch.meshgrid(*indices, indexing="ij"), dim=-1).to(device)
     coords = [(idx + 0.5) / length for idx, length in zip(indices, shape)]
     coords = list(reversed(coords))
-    xy = torch.stack(torch.meshgrid(*coords, indexing="xy"), dim=-1)
+    xy = torch.stack(torch.meshgrid(*coords, indexing="xy"), dim=-1).to(device)
     if len(_grid_cache) > 16:
         _grid_cache.clear()
     _grid_cache[key] = (xy, stacked)

@@ -437,7 +437,7 @@ int fm_bilinear_sample_bwd(const float* g_out, const float* xy, int groups, int 
 int fm_mapping_fwd(const float* a, const float* b, long count, int kind, float delta, float ax, float ay, float* out, void*) {
   for (long i = 0; i < count; ++i) {
     float dx, dy;
-    out[i] = robust_map(kind, delta, a[2 * i] * ax - b[2 * i] * ax, a[2 * i + 1] * ay - b[2 * i + 1] * ay, dx, dy);
+    out[i] = robust_map(kind, delta, aspect_diff(a[2 * i], b[2 * i], ax), aspect_diff(a[2 * i + 1], b[2 * i + 1], ay), dx, dy);
   }
   return 0;
 }
@@ -446,7 +446,7 @@ int fm_mapping_bwd(const float* a, const float* b, const float* g_out, long coun
                    float* g_a, float* g_b, void*) {
   for (long i = 0; i < count; ++i) {
     float dx, dy;
-    robust_map(kind, delta, a[2 * i] * ax - b[2 * i] * ax, a[2 * i + 1] * ay - b[2 * i + 1] * ay, dx, dy);
+    robust_map(kind, delta, aspect_diff(a[2 * i], b[2 * i], ax), aspect_diff(a[2 * i + 1], b[2 * i + 1], ay), dx, dy);
     const float gx = g_out[i] * dx * ax, gy = g_out[i] * dy * ay;
     if (g_a) {
       g_a[2 * i] = gx;
@@ -584,7 +584,7 @@ static bool sim_track_eval(const Pose& einv, const Mat3& kt, const float* xw, fl
   apply_pose(einv, xw, xc);
   o.pr = project_point(xc, kt);
   if (!(o.pr.u >= 0.f && o.pr.v >= 0.f && o.pr.u < 1.f && o.pr.v < 1.f)) return false;
-  o.rho = robust_map(kind, delta, o.pr.u * ax - gx * ax, o.pr.v * ay - gy * ay, o.drx, o.dry);
+  o.rho = robust_map(kind, delta, aspect_diff(o.pr.u, gx, ax), aspect_diff(o.pr.v, gy, ay), o.drx, o.dry);
   return true;
 }
 

@@ -208,3 +208,14 @@ def test_pose_chain_scan_matches_serial_oracle(steps):
     (e * cot.float().to(DEV)).sum().backward()
     assert_close(e, orc.chain_poses(rel), 1e-6, what="extrinsics")
     assert_close(r32.grad, r64.grad, 1e-5, what="g_rel")
+
+
+def test_tracking_long_windows_vs_oracle_fp64():
+    """41-frame track windows (the reference's radius 20) straddling a 45-frame clip."""
+    f, h, w = 45, 48, 64
+    sc = orc.synth_scene(f, h, w, seed=6)
+    tr = orc.synth_tracks(f, h, w, scene=sc, seed=6, interval=15, radius=20, grid=10)
+    wl = 0.01 * torch.randn((f - 1, h, w), generator=torch.Generator().manual_seed(1))
+    ours = run_ours(sc["depth_init"], wl, 0.8, sc["flows"], (h, w), 400, tr, device=DEV)
+    ref = run_oracle(sc["depth_init"], wl, 0.8, sc["flows"], (h, w), 400, tr, dtype=torch.float64)
+    compare(ours, ref)

@@ -1,0 +1,90 @@
+"""flowmap_amd.install() against the REAL reference package (importable only in the build
+container, /root/reference; skipped elsewhere): the reference's own Model, registries and
+Loss classes, unmodified, must run their hot path on our kernels (host double here) and
+reproduce the golden step results the unpatched reference produced."""
+
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path(os.environ.get("FLOWMAP_REFERENCE", "/root/reference"))
+
+pytestmark = pytest.mark.skipif(not (REF / "flowmap" / "model" / "projection.py").exists(), reason="reference not mounted")
+
+
+@pytest.fixture()
+def patched_reference():
+    sys.dont_write_bytecode = True
+    added = [str(ROOT / "oracle" / "refstubs"), str(REF)]
+    sys.path[:0] = added
+    import flowmap_amd
+    from flowmap_amd import _lib
+    from helpers import build_host_sim
+
+    _lib.set_library_for_testing(build_host_sim())
+    flowmap_amd.install()
+    yield
+    flowmap_amd.uninstall()
+    _lib.set_library_for_testing(None)
+    for p in added:
+        sys.path.remove(p)
+
+
+@pytest.mark.parametrize("name,with_tracks", [("step_iid_flow", False), ("step_scene_flow_tracking", True)])
+def test_unmodified_reference_model_runs_on_our_kernels(patched_reference, name, with_tracks):
+    from conftest import assert_close, load_golden, t
+
+    import flowmap.loss as ref_loss
+    import flowmap.model.extrinsics as ref_extr
+    from flowmap.dataset.types import Batch
+    from flowmap.flow.flow_predictor import Flows
+    from flowmap.loss.loss_flow import LossFlowCfg
+    from flowmap.loss.loss_tracking import LossTrackingCfg
+    from flowmap.loss.mapping.mapping_huber import MappingHuberCfg
+    from flowmap.model.backbone.backbone_explicit_depth import BackboneExplicitDepthCfg
+    from flowmap.model.extrinsics.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap.model.intrinsics.intrinsics_regressed import IntrinsicsRegressedCfg
+    from flowmap.model.model import Model, ModelCfg
+    from flowmap.tracking.track_predictor import Tracks
+
+    import flowmap_amd
+    from flowmap_amd.model.projection import LazySurfaces
+
+    # the registries now hand out our classes
+    assert ref_loss.LOSSES["flow"] is flowmap_amd.loss.LossFlow
+    assert ref_extr.EXTRINSICS["procrustes"].__module__.startswith("flowmap_amd")
+
+    g = load_golden(name)
+    depth, wlogit = t(g["depth"]), t(g["wlogit"])
+    f, h, w = depth.shape
+    npts = int(g["num_points"])
+    cfg = ModelCfg(
+        BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
+        IntrinsicsRegressedCfg("regressed", float(g["focal"])),
+        ExtrinsicsProcrustesCfg("procrustes", None if npts < 0 else npts, False),
+        True,
+    )
+    model = Model(cfg, num_frames=f, image_shape=(h, w))  # the reference's Model, unmodified
+    model.backbone.depth.data = depth.clone()
+    model.backbone.weights.data = wlogit.clone()
+    batch = Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["s"], ["d"])
+    flows = Flows(t(g["fwd"]), t(g["bwd"]), t(g["fwd_mask"]), t(g["bwd_mask"]))
+    cfgs = [LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01))]
+    tracks = None
+    if with_tracks:
+        cfgs.append(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
+        tracks = [Tracks(t(g[f"trk{i}_xy"]), t(g[f"trk{i}_vis"]), int(g[f"trk{i}_start"])) for i in range(int(g["n_segments"]))]
+    losses = ref_loss.get_losses(cfgs)  # the reference's factory -> our Loss classes
+    out = model(batch, flows, 0)
+    assert isinstance(out.surfaces, LazySurfaces)  # Model.forward's unproject went lazy
+    total = sum(fn(batch, flows, tracks, out, 0) for fn in losses)
+    total.backward()
+    assert_close(total, g["total"], 1e-4, what="total")
+    assert_close(out.extrinsics, g["extrinsics"], 1e-4, what="extrinsics")
+    assert_close(model.backbone.depth.grad, g["g_depth"], 1e-4, what="g_depth")
+    assert_close(model.backbone.weights.grad, g["g_wlogit"], 3e-4, what="g_wlogit")
+    assert_close(model.intrinsics.focal_length.grad, g["g_focal"], 1e-3, abs_=1e-4 * abs(float(g["total"])), what="g_focal")
