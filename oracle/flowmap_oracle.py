@@ -495,3 +495,16 @@ def synth_tracks(
         vis = inside & (torch.rand(inside.shape, generator=g) < p_visible)
         out.append(OTracks(xyt[None].contiguous(), vis[None].contiguous(), s))
     return out
+
+
+# --------------------------------------------------------------------------------------
+# ATE (flowmap/misc/ate.py:7-25): RMS over all coordinates after scipy's Procrustes
+# alignment (translation, uniform scale, rotation/reflection; both sets normalised).
+# --------------------------------------------------------------------------------------
+
+
+def ate(gt_positions: Tensor, predicted_positions: Tensor) -> float:
+    from scipy import spatial
+
+    a, b, _ = spatial.procrustes(gt_positions.detach().cpu().double().numpy(), predicted_positions.detach().cpu().double().numpy())
+    return float(((torch.tensor(a, dtype=torch.float32) - torch.tensor(b, dtype=torch.float32)) ** 2).mean() ** 0.5)

@@ -136,3 +136,81 @@ def case_mappings(dev, kind):
     assert_close(val, g[f"{kind}_val"], 1e-6, what="value")
     assert_close(a.grad, g[f"{kind}_g_a"], 1e-6, what="grad")
     assert torch.isfinite(a.grad).all()
+
+
+def case_flow_loss_batched(dev, lazy):
+    """LossFlow with batch size 2 (the pretraining shape, model_wrapper_pretrain.py:60-82):
+    poses fitted per batch element, one global masked mean."""
+    from flowmap_amd import Batch, Flows, ModelOutput
+    from flowmap_amd.loss import LossFlow, LossFlowCfg
+
+    b, f, h, w, p = 2, 4, 12, 16, 60
+    g = torch.Generator().manual_seed(5)
+    depth = (1.1 + 0.1 * torch.rand((b, f, h, w), generator=g))
+    weights = torch.rand((b, f - 1, h, w), generator=g)
+    focal = torch.tensor([0.8, 0.9])
+    k = orc.focal_to_k(focal, (h, w))[:, None].expand(b, f, 3, 3).contiguous()
+    fl = orc.OFlows(
+        0.01 * torch.randn((b, f - 1, h, w, 2), generator=g), 0.01 * torch.randn((b, f - 1, h, w, 2), generator=g),
+        torch.rand((b, f - 1, h, w), generator=g), torch.rand((b, f - 1, h, w), generator=g),
+    )
+    idx = torch.linspace(0, h * w - 1, p, dtype=torch.int64)
+
+    # oracle (fp64)
+    d64 = depth.double().requires_grad_(True)
+    w64 = weights.double().requires_grad_(True)
+    k64 = k.double().requires_grad_(True)
+    fl64 = orc.OFlows(*(x.double() for x in (fl.forward, fl.backward, fl.forward_mask, fl.backward_mask)))
+    o = orc.model_forward(d64, w64, k64, fl64, idx)
+    ref = 1000.0 * orc.flow_loss(o.surfaces, o.extrinsics, k64, fl64, (h, w))
+    ref.backward()
+
+    # ours
+    d, wt, kk = depth.to(dev).requires_grad_(True), weights.to(dev).requires_grad_(True), k.to(dev).requires_grad_(True)
+    flows = Flows(fl.forward.to(dev), fl.backward.to(dev), fl.forward_mask.to(dev), fl.backward_mask.to(dev))
+    fm.set_lazy_surfaces(lazy)
+    try:
+        xy, _ = fm.sample_image_grid((h, w), dev)
+        surfaces = fm.unproject(xy, d, kk[:, :, None, None])
+        ext = fm.align_surfaces(surfaces, flows.backward, wt, idx.to(dev))
+        out = ModelOutput(d, surfaces, kk, ext, wt)
+        loss = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))(Batch(torch.zeros((b, f, 3, h, w), device=dev)), flows, None, out, 0)
+    finally:
+        fm.set_lazy_surfaces(False)
+    loss.backward()
+    assert_close(loss, ref, TOL, what="loss")
+    assert_close(ext, o.extrinsics, TOL, what="extrinsics")
+    assert_close(d.grad, d64.grad, TOL, what="g_depth")
+    assert_close(wt.grad, w64.grad, 3 * TOL, what="g_weights")
+    assert_close(kk.grad, k64.grad, 1e-3, abs_=1e-4 * abs(float(ref.detach())), what="g_k")
+
+
+def case_loss_gating_and_empty_tracks(dev):
+    """Loss.forward's enable_after gate (loss.py:39-41) and the degenerate inputs: no track
+    segments, all-invisible tracks (valid_sum or 1)."""
+    from flowmap_amd import Batch, Flows, ModelOutput, Tracks
+    from flowmap_amd.loss import LossTracking, LossTrackingCfg
+
+    f, h, w = 3, 8, 10
+    depth, wlogit, fl = orc.synth_iid(f, h, w, seed=2)
+    d = depth[None].to(dev).requires_grad_(True)
+    k = orc.focal_to_k(torch.tensor(0.85), (h, w)).expand(1, f, 3, 3).contiguous().to(dev)
+    flows = Flows(*(x.to(dev) for x in (fl.forward, fl.backward, fl.forward_mask, fl.backward_mask)))
+    batch = Batch(torch.zeros((1, f, 3, h, w), device=dev))
+    for lazy in (True, False):
+        fm.set_lazy_surfaces(lazy)
+        try:
+            xy, _ = fm.sample_image_grid((h, w), dev)
+            surfaces = fm.unproject(xy, d, k[:, :, None, None])
+            ext = fm.align_surfaces(surfaces, flows.backward, torch.full((1, f - 1, h, w), 0.5, device=dev), None)
+            out = ModelOutput(d, surfaces, k, ext, None)
+            fn = LossTracking(LossTrackingCfg(50, 100.0, "tracking", mapping_cfg("huber")))
+            gated = fn(batch, flows, None, out, 10)  # before enable_after: tracks may even be None
+            assert float(gated) == 0.0 and gated.dtype == torch.float32
+            invisible = [Tracks(torch.rand((1, f, 7, 2), device=dev), torch.zeros((1, f, 7), dtype=torch.bool, device=dev), 0)]
+            val = fn(batch, flows, invisible, out, 60)
+            assert float(val) == 0.0
+            val.backward()
+            assert float(fn(batch, flows, [], out, 60)) == 0.0
+        finally:
+            fm.set_lazy_surfaces(False)

@@ -219,3 +219,12 @@ def test_tracking_long_windows_vs_oracle_fp64():
     ours = run_ours(sc["depth_init"], wl, 0.8, sc["flows"], (h, w), 400, tr, device=DEV)
     ref = run_oracle(sc["depth_init"], wl, 0.8, sc["flows"], (h, w), 400, tr, dtype=torch.float64)
     compare(ours, ref)
+
+
+@pytest.mark.parametrize("lazy", [True, False])
+def test_fn_flow_loss_batched(lazy):
+    cases.case_flow_loss_batched(DEV, lazy)
+
+
+def test_fn_loss_gating_and_empty_tracks():
+    cases.case_loss_gating_and_empty_tracks(DEV)

@@ -48,3 +48,12 @@ def test_track_flow():
 @pytest.mark.parametrize("kind", ["huber", "l1", "l2"])
 def test_mappings(kind):
     cases.case_mappings("cpu", kind)
+
+
+@pytest.mark.parametrize("lazy", [True, False])
+def test_flow_loss_batched(lazy):
+    cases.case_flow_loss_batched("cpu", lazy)
+
+
+def test_loss_gating_and_empty_tracks():
+    cases.case_loss_gating_and_empty_tracks("cpu")
