@@ -172,11 +172,15 @@ class ProcrustesFit(torch.autograd.Function):
       depth (B,F,H,W) + intrinsics (B,F,3,3)   [surfaces never materialised], or
       surfaces (B,F,H,W,3).
 
+    ``weight_sens != 0``: ``weights`` holds LOGITS and w = sigmoid(weight_sens·logit) is
+    evaluated at the gathered points only (BackboneExplicitDepth fused into the gather);
+    the returned gradient is then w.r.t. the logits.
+
     Returns the "inverse relative transformations" (B,F-1,4,4): later -> earlier camera.
     """
 
     @staticmethod
-    def forward(ctx, depth, k, surfaces, weights, bwd_flow, indices):
+    def forward(ctx, depth, k, surfaces, weights, bwd_flow, indices, weight_sens=0.0):
         from_depth = surfaces is None
         check_device(depth if from_depth else surfaces, weights, bwd_flow, indices)
         weights = _f32c(weights, "weights")
@@ -210,10 +214,10 @@ class ProcrustesFit(torch.autograd.Function):
         with _guard(dev):
             st = stream_for(weights)
             call("fm_procrustes_stats", ptr(depth) if from_depth else None, ptr(kinv), ptr(surfaces), ptr(bwd_flow),
-                 ptr(weights), ptr(indices), points, b, f, h, w, ptr(stats), st)
+                 ptr(weights), float(weight_sens), ptr(indices), points, b, f, h, w, ptr(stats), st)
             call("fm_pose_solve", ptr(stats), pairs, ptr(t_bwd), None, ptr(aux), st)
         ctx.save_for_backward(depth if from_depth else surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux)
-        ctx.from_depth, ctx.dims, ctx.points = from_depth, (b, f, h, w), points
+        ctx.from_depth, ctx.dims, ctx.points, ctx.weight_sens = from_depth, (b, f, h, w), points, float(weight_sens)
         # Carried depth gradient: when the fused flow loss consumes poses fitted from the very
         # same depth tensor, it parks its dense dL/ddepth here instead of returning it, and
         # this node (which autograd always runs later) scatters its sparse part into that
@@ -249,14 +253,14 @@ class ProcrustesFit(torch.autograd.Function):
             st = stream_for(weights)
             call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t_bwd), ptr(aux), pairs, ptr(pair_grad), st)
             call("fm_procrustes_scatter", ptr(src) if ctx.from_depth else None, ptr(kinv), None if ctx.from_depth else ptr(src),
-                 ptr(bwd_flow), ptr(weights), ptr(indices), ctx.points, b, f, h, w, ptr(aux), ptr(pair_grad),
+                 ptr(bwd_flow), ptr(weights), ctx.weight_sens, ptr(indices), ctx.points, b, f, h, w, ptr(aux), ptr(pair_grad),
                  ptr(g_src) if ctx.from_depth else None, None if ctx.from_depth else ptr(g_src), ptr(g_w), ptr(kinv_acc), st)
             if need_k:
                 g_k = torch.empty_like(kinv)
                 call("fm_intrinsics_inverse_bwd", ptr(kinv_acc), ptr(kinv), b * f, ptr(g_k), 0, st)
         if ctx.from_depth:
-            return g_src, g_k, None, g_w, None, None
-        return None, None, g_src, g_w, None, None
+            return g_src, g_k, None, g_w, None, None, None
+        return None, None, g_src, g_w, None, None, None
 
 
 # --------------------------------------------------------------------------------------

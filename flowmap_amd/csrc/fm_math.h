@@ -276,8 +276,9 @@ struct CorrSrc {
   const float* surf_e;    // (H,W,3) earlier frame surfaces    [surface-sourced]
   const float* surf_l;    // (H,W,3)
   const float* bwd_flow;  // (H,W,2)
-  const float* weights;   // (H,W)
-  int height, width;
+  const float* weights;   // (H,W)  correspondence weights, or their logits when weight_sens != 0
+  float weight_sens;      // 0: plain weights;  s != 0: w = sigmoid(s · weights[idx])
+  int height, width;      //    (backbone_explicit_depth.py:38-41 fused into the gather)
 };
 
 struct Corr {
@@ -295,6 +296,7 @@ FM_HD Corr corr_load(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, i
   const float u = pixel_center(col, s.width), v = pixel_center(row, s.height);
   const float fx = s.bwd_flow[2 * (size_t)idx], fy = s.bwd_flow[2 * (size_t)idx + 1];
   c.w = s.weights[idx];
+  if (s.weight_sens != 0.f) c.w = 1.0f / (1.0f + expf(-s.weight_sens * c.w));
   c.taps = bilinear_taps(u + fx, v + fy, s.height, s.width);
   c.q[0] = c.q[1] = c.q[2] = 0.f;
   c.z_p = 0.f;

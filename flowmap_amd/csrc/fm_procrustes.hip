@@ -39,6 +39,7 @@ struct ProcParams {
   double* kinv_acc;        // (B*F, 9) fp64 accumulators          [scatter, SRC_DEPTH]
   int frames, height, width;
   long points;
+  float weight_sens;       // != 0: `weights` holds logits, w = sigmoid(weight_sens·logit)
 };
 
 enum { SRC_DEPTH = 0, SRC_SURF = 1 };
@@ -55,6 +56,7 @@ __device__ __forceinline__ CorrSrc pair_source(const ProcParams& p, size_t pair,
   s.surf_l = SRC == SRC_SURF ? p.surfaces + fl * n * 3 : nullptr;
   s.bwd_flow = p.bwd_flow + pair * n * 2;
   s.weights = p.weights + pair * n;
+  s.weight_sens = p.weight_sens;
   s.height = p.height;
   s.width = p.width;
   return s;
@@ -173,6 +175,7 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
     const Corr c = corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j);
     float gq[3], gp[3], gw;
     corr_backward(c, g, gq, gp, gw);
+    if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
     if (p.grad_weights) atomicAdd(p.grad_weights + pair * (size_t)n + c.idx, gw);
     if (SRC == SRC_DEPTH) {
       const int row = c.idx / p.width, col = c.idx - row * p.width;
@@ -442,8 +445,8 @@ static inline int choose_iters(long points) {
 extern "C" {
 
 int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
-                        const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
-                        int width, double* stats, void* stream) {
+                        const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
+                        int frames, int height, int width, double* stats, void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
   FM_CHECK_ARG(bwd_flow && weights && stats && points >= 1 && batch >= 1 && frames >= 2);
   FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
@@ -453,6 +456,7 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
   ProcParams p{};
   p.depth = depth; p.kinv = kinv; p.surfaces = surfaces; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
   p.stats = stats; p.frames = frames; p.height = height; p.width = width; p.points = points;
+  p.weight_sens = weight_sensitivity;
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
   if (surfaces) {
@@ -480,9 +484,9 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
 }
 
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
-                          const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
-                          int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
-                          float* grad_weights, double* kinv_acc, void* stream) {
+                          const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
+                          int frames, int height, int width, const double* aux, const double* pair_grad, float* grad_depth,
+                          float* grad_surfaces, float* grad_weights, double* kinv_acc, void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
   FM_CHECK_ARG(bwd_flow && weights && aux && pair_grad && points >= 1);
   hipStream_t st = (hipStream_t)stream;
@@ -491,6 +495,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
   p.depth = depth; p.kinv = kinv; p.surfaces = surfaces; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
   p.pair_grad = pair_grad; p.grad_depth = grad_depth; p.grad_surfaces = grad_surfaces; p.grad_weights = grad_weights;
   p.kinv_acc = kinv_acc; p.frames = frames; p.height = height; p.width = width; p.points = points;
+  p.weight_sens = weight_sensitivity;
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
   if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);

@@ -17,7 +17,7 @@ from torch import Tensor, nn
 
 from ..types import BackboneOutput, ModelOutput
 from .extrinsics_procrustes import ExtrinsicsProcrustes, ExtrinsicsProcrustesCfg
-from .projection import sample_image_grid, unproject
+from .projection import LazyWeights, lazy_surfaces_enabled, sample_image_grid, unproject
 
 
 def focal_lengths_to_intrinsics(focal_lengths: Tensor, image_shape: Tuple[int, int]) -> Tensor:
@@ -55,6 +55,9 @@ class BackboneExplicitDepth(nn.Module):
     def forward(self, batch, flows) -> BackboneOutput:
         b = batch.videos.shape[0]
         assert b == 1
+        if lazy_surfaces_enabled():
+            # same values, not stored: align_surfaces applies the sigmoid at the points it gathers
+            return BackboneOutput(self.depth[None], LazyWeights(self.weights[None], self.cfg.weight_sensitivity))
         return BackboneOutput(self.depth[None], (self.cfg.weight_sensitivity * self.weights).sigmoid()[None])
 
 
@@ -107,7 +110,7 @@ class Model(nn.Module):
         # Run the backbone, which provides depths and correspondence weights.
         backbone_out = self.backbone.forward(batch, flows)
         if not self.cfg.use_correspondence_weights:
-            backbone_out.weights = torch.ones_like(backbone_out.weights)
+            backbone_out.weights = torch.ones(backbone_out.weights.shape, dtype=torch.float32, device=device)
 
         # Compute the intrinsics.
         intrinsics = self.intrinsics.forward(batch, flows, backbone_out, global_step)

@@ -163,6 +163,53 @@ def _dense(surfaces) -> Tensor:
     return surfaces.materialize() if isinstance(surfaces, LazySurfaces) else surfaces
 
 
+class LazyWeights:
+    """Correspondence weights sigmoid(sensitivity · logits) (BackboneExplicitDepth,
+    flowmap/model/backbone/backbone_explicit_depth.py:38-41) that are not stored: only
+    the P sampled pixels per pair are ever read (0.1 % at 720p with P = 1000), so
+    ``align_surfaces`` applies the sigmoid inside its gather and writes the logit gradient
+    directly.  Any other use materialises the real (b, f-1, h, w) tensor."""
+
+    def __init__(self, logits: Tensor, sensitivity: float):
+        self.logits = logits  # (b, f-1, h, w)
+        self.sensitivity = float(sensitivity)
+        self._dense: Optional[Tensor] = None
+
+    @property
+    def shape(self):
+        return self.logits.shape
+
+    @property
+    def device(self):
+        return self.logits.device
+
+    @property
+    def dtype(self):
+        return self.logits.dtype
+
+    def materialize(self) -> Tensor:
+        if self._dense is None:
+            self._dense = (self.sensitivity * self.logits).sigmoid()
+        return self._dense
+
+    def __getitem__(self, item):
+        return self.materialize()[item]
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        conv = lambda a: a.materialize() if isinstance(a, (LazyWeights, LazySurfaces)) else a  # noqa: E731
+        return func(*tuple(conv(a) for a in args), **{k: conv(v) for k, v in kwargs.items()})
+
+    def __repr__(self):
+        return f"LazyWeights(shape={tuple(self.shape)}, sensitivity={self.sensitivity})"
+
+
 # --------------------------------------------------------------------------------------
 # unproject
 # --------------------------------------------------------------------------------------
@@ -349,10 +396,16 @@ def align_surfaces(surfaces, backward_flows: Tensor, backward_weights: Tensor, i
         h, w = surfaces.shape[2:4]
     if idx is not None and idx.numel() == h * w and getattr(idx, "_fm_is_arange", False):
         idx = None  # dense: the kernel derives the index from the thread id
+    sens = 0.0
+    if isinstance(backward_weights, LazyWeights):
+        if backward_weights.sensitivity != 0.0:
+            backward_weights, sens = backward_weights.logits, backward_weights.sensitivity
+        else:
+            backward_weights = backward_weights.materialize()
     if isinstance(surfaces, LazySurfaces):
-        rel = _ops.ProcrustesFit.apply(surfaces.depths, surfaces.intrinsics, None, backward_weights, backward_flows, idx)
+        rel = _ops.ProcrustesFit.apply(surfaces.depths, surfaces.intrinsics, None, backward_weights, backward_flows, idx, sens)
     else:
-        rel = _ops.ProcrustesFit.apply(None, None, surfaces, backward_weights, backward_flows, idx)
+        rel = _ops.ProcrustesFit.apply(None, None, surfaces, backward_weights, backward_flows, idx, sens)
     return _ops.PoseChain.apply(rel)
 
 

@@ -80,10 +80,14 @@ int fm_scale_if_needed(float* x, long count, const float* scalar, void* stream);
  * Exactly one source must be given: (depth, kinv) — xyz recomputed on the fly — or
  * `surfaces` (B,F,H,W,3).  indices (P) int64 flat pixel indices, NULL = arange(N).
  * stats (B*(F-1), FM_STAT_STRIDE) fp64 out: Σw, Σw·p, Σw·q, covariance.
+ * weight_sensitivity: 0 = `weights` are the correspondence weights; s != 0 = `weights`
+ * are LOGITS and w = sigmoid(s·logit) is applied at the gathered points only
+ * (BackboneExplicitDepth, backbone_explicit_depth.py:38-41), grad_weights then being
+ * the gradient w.r.t. the logits.
  */
 int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
-                        const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
-                        int width, double* stats, void* stream);
+                        const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
+                        int frames, int height, int width, double* stats, void* stream);
 
 /* procrustes.py:35-51: R = U·diag(1,1,±1)·Vᵀ by in-register 3×3 SVD, t = q̄ − R·p̄.
  * t_bwd (pairs,4,4) = [R|t] ("inverse relative transformation", later -> earlier
@@ -101,9 +105,9 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
  * already holds another gradient to fuse the accumulation).  kinv_acc (B*F,9) fp64:
  * dL/dK⁻¹ accumulators (caller zeroes), depth source only.  Any output may be NULL. */
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
-                          const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
-                          int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
-                          float* grad_weights, double* kinv_acc, void* stream);
+                          const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
+                          int frames, int height, int width, const double* aux, const double* pair_grad, float* grad_depth,
+                          float* grad_surfaces, float* grad_weights, double* kinv_acc, void* stream);
 
 /* get_extrinsics (projection.py:187-210): ext (B,steps+1,4,4), ext[0]=I,
  * ext[k] = ext[k-1]·rel[k-1]; and its backward (replaces the Python loop of matmuls). */

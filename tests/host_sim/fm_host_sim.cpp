@@ -97,8 +97,8 @@ int fm_scale_if_needed(float* x, long count, const float* scalar, void*) {
   return 0;
 }
 
-static CorrSrc make_src(const float* depth, const float* surfaces, const float* bwd_flow, const float* weights, size_t pair,
-                        int b, int i, int frames, int height, int width) {
+static CorrSrc make_src(const float* depth, const float* surfaces, const float* bwd_flow, const float* weights, float sens,
+                        size_t pair, int b, int i, int frames, int height, int width) {
   const size_t n = (size_t)height * width;
   const size_t fe = (size_t)b * frames + i, fl = fe + 1;
   CorrSrc s;
@@ -108,13 +108,14 @@ static CorrSrc make_src(const float* depth, const float* surfaces, const float* 
   s.surf_l = surfaces ? surfaces + fl * n * 3 : nullptr;
   s.bwd_flow = bwd_flow + pair * n * 2;
   s.weights = weights + pair * n;
+  s.weight_sens = sens;
   s.height = height;
   s.width = width;
   return s;
 }
 
 int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
-                        const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
+                        const float* weights, float sens, const int64_t* indices, long points, int batch, int frames, int height,
                         int width, double* stats, void*) {
   const int pairs = batch * (frames - 1);
   std::memset(stats, 0, sizeof(double) * (size_t)pairs * kStatStride);
@@ -125,7 +126,7 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
       load_mat3(kinv + ((size_t)b * frames + i) * 9, ke);
       load_mat3(kinv + ((size_t)b * frames + i + 1) * 9, kl);
     }
-    const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, pr, b, i, frames, height, width);
+    const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, sens, pr, b, i, frames, height, width);
     double* st = stats + (size_t)pr * kStatStride;
     for (long j = 0; j < points; ++j) {
       const Corr c = corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j);
@@ -168,7 +169,7 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
 }
 
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
-                          const float* weights, const int64_t* indices, long points, int batch, int frames, int height,
+                          const float* weights, float sens, const int64_t* indices, long points, int batch, int frames, int height,
                           int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
                           float* grad_weights, double* kinv_acc, void*) {
   const int pairs = batch * (frames - 1);
@@ -180,7 +181,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
       load_mat3(kinv + ((size_t)b * frames + i) * 9, ke);
       load_mat3(kinv + ((size_t)b * frames + i + 1) * 9, kl);
     }
-    const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, pr, b, i, frames, height, width);
+    const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, sens, pr, b, i, frames, height, width);
     const double* pg = pair_grad + (size_t)pr * kPairGradStride;
     const double* ax = aux + (size_t)pr * kAuxStride;
     PairGrad g;
@@ -198,6 +199,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
       const Corr c = corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j);
       float gq[3], gp[3], gw;
       corr_backward(c, g, gq, gp, gw);
+      if (sens != 0.f) gw *= sens * c.w * (1.f - c.w);
       if (grad_weights) grad_weights[(size_t)pr * n + c.idx] += gw;
       if (!surfaces) {
         const int row = c.idx / width, col = c.idx - row * width;
