@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=150)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--points", type=int, default=1000, help="Procrustes points (config/model/extrinsics/procrustes.yaml:3)")
+    ap.add_argument("--points", type=int, default=1000,
+                    help="Procrustes points (config/model/extrinsics/procrustes.yaml:3); 0 = all pixels (ablation_explicit_depth.yaml:11-12)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=16,
@@ -130,7 +131,7 @@ def main():
     cfg = ModelCfg(
         BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
         IntrinsicsRegressedCfg("regressed", 0.85),
-        ExtrinsicsProcrustesCfg("procrustes", args.points, False),
+        ExtrinsicsProcrustesCfg("procrustes", args.points if args.points > 0 else None, False),
     )
     model = Model(cfg, num_frames=f, image_shape=(h, w)).to(device)
     model.backbone.depth.data = depth

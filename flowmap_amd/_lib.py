@@ -27,7 +27,7 @@ F = ctypes.c_float
 # name -> argtypes, in the order of include/flowmap_hip.h
 SIGNATURES = {
     "fm_flow_loss_fused": [P] * 10 + [I, I, I, I, I, F, F, F, P, P, I, P],
-    "fm_flow_loss_finalize": [P] * 5 + [I, I] + [P] * 4 + [P],
+    "fm_flow_loss_finalize": [P] * 6 + [I, I, F, F] + [P] * 4 + [P],
     "fm_flow_valid_norm": [P, P, L, F, P, P, P],
     "fm_scale_if_needed": [P, L, P, P],
     "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, P, P],

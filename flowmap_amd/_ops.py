@@ -342,8 +342,8 @@ class FlowLossFused(torch.autograd.Function):
             if events:
                 events[1].record()
                 flow_kernel_events.append(events)
-            call("fm_flow_loss_finalize", ptr(acc), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(norm), b, f, ptr(loss), ptr(g_tf),
-                 ptr(g_tb), ptr(g_k), st)
+            call("fm_flow_loss_finalize", ptr(acc), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(norm), b, f, w / scale, h / scale,
+                 ptr(loss), ptr(g_tf), ptr(g_tb), ptr(g_k), st)
         ctx.grads = (g_depth, g_k, g_tf, g_tb) if need else None
         ctx.fit_node = None
         if carry and g_depth is not None:

@@ -16,7 +16,8 @@ CSRC = HERE / "csrc"
 OUT = HERE / "libflowmap_hip.so"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
-
+# Per-file extras (none at the moment; see DESIGN.md §3.1 for the variants that were measured).
+FILE_FLAGS: dict = {}
 
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -44,7 +45,7 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
     build_dir.mkdir(exist_ok=True)
     for src in sources():
         obj = build_dir / (src.stem + ".o")
-        cmd = [hipcc(), f"--offload-arch={ARCH}", *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc(), f"--offload-arch={ARCH}", *FLAGS, *FILE_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

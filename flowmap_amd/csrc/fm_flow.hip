@@ -14,12 +14,12 @@
 // with no atomics on the big tensor.  Algorithmic traffic: N·(8F + 24(F−1)) bytes.
 //
 // Pose / intrinsics gradients are linear in per-pixel quantities and are reduced
-// per (frame, direction) into 19 numbers:
-//   [0]      Σ ρ·m                       (loss numerator, unscaled)
-//   [1..3]   Σ g_X'                      (= dL/dt of the direction's relative pose)
-//   [4..12]  S = Σ g_X' ⊗ (z·[u,v,1])    (dL/dR = S·Kinvᵀ ; dL/dKinv_src = Rᵀ·S)
-//   [13..18] Σ (g_u, g_v) ⊗ p            (rows 0,1 of dL/dK_dst)
-// wave shuffle -> LDS -> one fp64 atomic per value per block.
+// per (frame, direction) into 13 numbers (fm_math.h "One flow residual"):
+//   [0]      Σ ρ·m                        (loss numerator, unscaled)
+//   [1..3]   σ = Σ ω                      ω = (q·w_u, q·w_v, q·(w·kd p)),  q = 1/(Z'+eps)
+//   [4..12]  Ω = Σ ω ⊗ (z·[u,v,1])
+// from which flow_finalize_frame derives dL/dR, dL/dt, dL/dK⁻¹_src and dL/dK_dst.
+// DPP wave reduction -> LDS (fp64) -> one fp64 atomic per value per block.
 #include "fm_device.h"
 #include "fm_pose.h"
 
@@ -44,105 +44,35 @@ struct FlowParams {
   int iters;              // items per thread
 };
 
-// Per-(frame, direction) constants, wave-uniform (SGPRs).
-//   m    = R·K⁻¹_src (3x3): X' = z·(m·[u,v,1]) + t, so neither the ray nor the camera-space
-//          point of the source pixel is formed per direction, and dL/dz = g_X'·(m·[u,v,1]).
-//   kd   = rows 0,1 of the destination intrinsics.
-struct DirConst {
-  float m[9];
-  float t[3];
-  float kd[6];
-};
+// 16-byte streaming accesses.  Every input element is read exactly once and the gradient is
+// written exactly once, so the accesses carry the non-temporal hint (measured on C1:
+// 0.90 -> 0.83 ms; loads-only 0.86, stores-only 0.85).  -DFM_FLOW_NO_NT turns it off.
+#if !defined(FM_FLOW_NO_NT) && !defined(FM_FLOW_NT_LOAD) && !defined(FM_FLOW_NT_STORE)
+#define FM_FLOW_NT 1
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+#if defined(FM_FLOW_NT) || defined(FM_FLOW_NT_LOAD)
+#define FM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define FM_LOAD(p) (*(p))
+#endif
+#if defined(FM_FLOW_NT) || defined(FM_FLOW_NT_STORE)
+#define FM_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define FM_STORE(v, p) (*(p) = (v))
+#endif
+__device__ __forceinline__ v4f ld4(const float* base, int i) { return FM_LOAD(reinterpret_cast<const v4f*>(base) + i); }
+__device__ __forceinline__ v2f ld2(const float* base, int i) { return FM_LOAD(reinterpret_cast<const v2f*>(base) + i); }
 
-__device__ __forceinline__ void make_dir(const Pose& pose, const Mat3& kinv, const Mat3& kd, DirConst& d) {
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      d.m[r * 3 + c] = pose.r[r * 3 + 0] * kinv.m[0 * 3 + c] + pose.r[r * 3 + 1] * kinv.m[1 * 3 + c] + pose.r[r * 3 + 2] * kinv.m[2 * 3 + c];
-    d.t[r] = pose.t[r];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) d.kd[i] = kd.m[i];
-}
-
-// Residual + gradient of one (pixel, direction): branch-free, ~95 VALU ops.
-//  * hardware reciprocal / reciprocal-square-root (1 ulp) instead of IEEE divide + sqrt:
-//    the loss moves by < 1e-7 relative;
-//  * the singular case Z' + 1e-5 == 0 (1/s not finite): the reference clamps the
-//    projection to ±1e8 and its GRADIENT IS NaN there (inf·0).  A pixel in
-//    that measure-zero set is dropped here (zero loss, zero gradient) by zeroing its
-//    mask; the function-level reproject kernels keep the exact clamp semantics.
-template <int KIND, bool GRAD>
-__device__ __forceinline__ void flow_term_fast(const DirConst& d, float z, float u, float v, float zu, float zv, float flow_x,
-                                               float flow_y, float m, float scale, float delta, float inv_delta, float ax,
-                                               float ay, float (&acc)[kFlowAcc], float& gz) {
-  const float mh0 = fmaf(d.m[0], u, fmaf(d.m[1], v, d.m[2]));
-  const float mh1 = fmaf(d.m[3], u, fmaf(d.m[4], v, d.m[5]));
-  const float mh2 = fmaf(d.m[6], u, fmaf(d.m[7], v, d.m[8]));
-  const float x0 = fmaf(z, mh0, d.t[0]);
-  const float x1 = fmaf(z, mh1, d.t[1]);
-  const float x2 = fmaf(z, mh2, d.t[2]);
-  float inv_s = __builtin_amdgcn_rcpf(x2 + kProjEps);
-  const bool ok = __builtin_fabsf(inv_s) <= 3.0e38f;
-  inv_s = ok ? inv_s : 0.f;
-  m = ok ? m : 0.f;
-  const float p0 = x0 * inv_s, p1 = x1 * inv_s, p2 = x2 * inv_s;
-  const float pu = fmaf(d.kd[0], p0, fmaf(d.kd[1], p1, d.kd[2] * p2));
-  const float pv = fmaf(d.kd[3], p0, fmaf(d.kd[4], p1, d.kd[5] * p2));
-  const float rx = ((pu - u) - flow_x) * ax;
-  const float ry = ((pv - v) - flow_y) * ay;
-  const float ss = fmaf(rx, rx, ry * ry);
-  float rho, coef;  // ρ and dρ/dr = coef·r
-  if (KIND == kL2) {
-    rho = 0.5f * ss;
-    coef = 1.f;
-  } else {
-    const float inv_n = ss > 0.f ? __builtin_amdgcn_rsqf(ss) : 0.f;
-    const float n = ss * inv_n;
-    if (KIND == kL1) {
-      rho = n;
-      coef = inv_n;
-    } else {
-      const bool quad = n < delta;
-      rho = quad ? 0.5f * ss * inv_delta : n - 0.5f * delta;
-      coef = quad ? inv_delta : inv_n;
-    }
-  }
-  acc[0] = fmaf(rho, m, acc[0]);
-  if (GRAD) {
-    const float gc = scale * m * coef;
-    const float gu = gc * rx * ax;
-    const float gv = gc * ry * ay;
-    acc[13] = fmaf(gu, p0, acc[13]);
-    acc[14] = fmaf(gu, p1, acc[14]);
-    acc[15] = fmaf(gu, p2, acc[15]);
-    acc[16] = fmaf(gv, p0, acc[16]);
-    acc[17] = fmaf(gv, p1, acc[17]);
-    acc[18] = fmaf(gv, p2, acc[18]);
-    const float gp0 = fmaf(d.kd[0], gu, d.kd[3] * gv);
-    const float gp1 = fmaf(d.kd[1], gu, d.kd[4] * gv);
-    const float gp2 = fmaf(d.kd[2], gu, d.kd[5] * gv);
-    const float dot = fmaf(gp0, p0, fmaf(gp1, p1, gp2 * p2));
-    const float g0 = gp0 * inv_s, g1 = gp1 * inv_s, g2 = (gp2 - dot) * inv_s;  // dL/dX'
-    acc[1] += g0;
-    acc[2] += g1;
-    acc[3] += g2;
-    acc[4] = fmaf(g0, zu, acc[4]);
-    acc[5] = fmaf(g0, zv, acc[5]);
-    acc[6] = fmaf(g0, z, acc[6]);
-    acc[7] = fmaf(g1, zu, acc[7]);
-    acc[8] = fmaf(g1, zv, acc[8]);
-    acc[9] = fmaf(g1, z, acc[9]);
-    acc[10] = fmaf(g2, zu, acc[10]);
-    acc[11] = fmaf(g2, zv, acc[11]);
-    acc[12] = fmaf(g2, z, acc[12]);
-    gz = fmaf(g0, mh0, fmaf(g1, mh1, fmaf(g2, mh2, gz)));
-  }
-}
+#ifndef FM_FLOW_WAVES
+// Waves per SIMD the register allocator must leave room for.  3 (<=168 VGPRs, 133 used, no
+// scratch) beat 4 (128 VGPRs) by 3-5 % and 2 by 4 % in interleaved A/B runs; 5 spills.
+#define FM_FLOW_WAVES 3
+#endif
 
 template <int VEC, int KIND, bool GRAD>
-__global__ void __launch_bounds__(256, 4) flow_fused_kernel(FlowParams p) {
+__global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowParams p) {
   extern __shared__ double lds[];  // reduction scratch (fp64), then the [width] u-table
   double* red = lds;
   float* u_tab = reinterpret_cast<float*>(lds + (256 / 64) * kFlowAcc);
@@ -159,7 +89,7 @@ __global__ void __launch_bounds__(256, 4) flow_fused_kernel(FlowParams p) {
   for (int c = threadIdx.x; c < p.width; c += blockDim.x) u_tab[c] = pixel_center(c, p.width);
   __syncthreads();
 
-  DirConst df, db;
+  DirConst df = {}, db = {};
   const size_t pair_f = (size_t)b * (p.frames - 1) + f;  // pair whose earlier frame is f
   const size_t pair_b = pair_f - 1;                       // pair whose later frame is f
   {
@@ -169,12 +99,12 @@ __global__ void __launch_bounds__(256, 4) flow_fused_kernel(FlowParams p) {
     if (has_fwd) {
       load_mat3(p.k + (size_t)(bf + 1) * 9, kd);
       load_pose44(p.t_fwd + pair_f * 16, t);
-      make_dir(t, kinv, kd, df);
+      make_dir(t, kinv, kd, p.ax, p.ay, df);
     }
     if (has_bwd) {
       load_mat3(p.k + (size_t)(bf - 1) * 9, kd);
       load_pose44(p.t_bwd + pair_b * 16, t);
-      make_dir(t, kinv, kd, db);
+      make_dir(t, kinv, kd, p.ax, p.ay, db);
     }
   }
   const float scale = GRAD ? p.scale[0] : 0.f;
@@ -201,23 +131,38 @@ __global__ void __launch_bounds__(256, 4) flow_fused_kernel(FlowParams p) {
     if (item >= items) break;
     float z[VEC], gz[VEC], fxf[VEC], fyf[VEC], mmf[VEC], fxb[VEC], fyb[VEC], mmb[VEC];
     if (VEC == 4) {
-      const float4 zq = reinterpret_cast<const float4*>(depth)[item];
+      const v4f zq = ld4(depth, item);
       z[0] = zq.x; z[1] = zq.y; z[2] = zq.z; z[3] = zq.w;
       if (has_fwd) {
-        const float4 a = reinterpret_cast<const float4*>(ff)[item * 2];
-        const float4 c = reinterpret_cast<const float4*>(ff)[item * 2 + 1];
-        const float4 mq = reinterpret_cast<const float4*>(mf)[item];
+        const v4f a = ld4(ff, item * 2);
+        const v4f c = ld4(ff, item * 2 + 1);
+        const v4f mq = ld4(mf, item);
         fxf[0] = a.x; fyf[0] = a.y; fxf[1] = a.z; fyf[1] = a.w;
         fxf[2] = c.x; fyf[2] = c.y; fxf[3] = c.z; fyf[3] = c.w;
         mmf[0] = mq.x; mmf[1] = mq.y; mmf[2] = mq.z; mmf[3] = mq.w;
       }
       if (has_bwd) {
-        const float4 a = reinterpret_cast<const float4*>(fb)[item * 2];
-        const float4 c = reinterpret_cast<const float4*>(fb)[item * 2 + 1];
-        const float4 mq = reinterpret_cast<const float4*>(mb)[item];
+        const v4f a = ld4(fb, item * 2);
+        const v4f c = ld4(fb, item * 2 + 1);
+        const v4f mq = ld4(mb, item);
         fxb[0] = a.x; fyb[0] = a.y; fxb[1] = a.z; fyb[1] = a.w;
         fxb[2] = c.x; fyb[2] = c.y; fxb[3] = c.z; fyb[3] = c.w;
         mmb[0] = mq.x; mmb[1] = mq.y; mmb[2] = mq.z; mmb[3] = mq.w;
+      }
+    } else if (VEC == 2) {
+      const v2f zq = ld2(depth, item);
+      z[0] = zq.x; z[VEC - 1] = zq.y;
+      if (has_fwd) {
+        const v4f a = ld4(ff, item);
+        const v2f mq = ld2(mf, item);
+        fxf[0] = a.x; fyf[0] = a.y; fxf[VEC - 1] = a.z; fyf[VEC - 1] = a.w;
+        mmf[0] = mq.x; mmf[VEC - 1] = mq.y;
+      }
+      if (has_bwd) {
+        const v4f a = ld4(fb, item);
+        const v2f mq = ld2(mb, item);
+        fxb[0] = a.x; fyb[0] = a.y; fxb[VEC - 1] = a.z; fyb[VEC - 1] = a.w;
+        mmb[0] = mq.x; mmb[VEC - 1] = mq.y;
       }
     } else {
       z[0] = depth[item];
@@ -233,17 +178,31 @@ __global__ void __launch_bounds__(256, 4) flow_fused_kernel(FlowParams p) {
     const int row = item / items_per_row;
     const int col0 = (item - row * items_per_row) * VEC;
     const float v = pixel_center(row, p.height);
+    const float v_ay = v * p.ay;
+    // m[:,1]·v + m[:,2] is constant along the image row the quad lies in
+    const float rf0 = fmaf(df.m[1], v, df.m[2]), rf1 = fmaf(df.m[4], v, df.m[5]), rf2 = fmaf(df.m[7], v, df.m[8]);
+    const float rb0 = fmaf(db.m[1], v, db.m[2]), rb1 = fmaf(db.m[4], v, db.m[5]), rb2 = fmaf(db.m[7], v, db.m[8]);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float u = u_tab[col0 + e];
-      const float zu = z[e] * u, zv = z[e] * v;
+      const float zu = z[e] * u, zv = z[e] * v, u_ax = u * p.ax;
       gz[e] = 0.f;
-      if (has_fwd) flow_term_fast<KIND, GRAD>(df, z[e], u, v, zu, zv, fxf[e], fyf[e], mmf[e], scale, p.delta, inv_delta, p.ax, p.ay, acc_f, gz[e]);
-      if (has_bwd) flow_term_fast<KIND, GRAD>(db, z[e], u, v, zu, zv, fxb[e], fyb[e], mmb[e], scale, p.delta, inv_delta, p.ax, p.ay, acc_b, gz[e]);
+      if (has_fwd)
+        flow_term_fast<KIND, GRAD>(df, rf0, rf1, rf2, z[e], u, zu, zv, u_ax, v_ay, fxf[e], fyf[e], mmf[e], scale, p.delta, inv_delta, p.ax,
+                                   p.ay, acc_f, gz[e]);
+      if (has_bwd)
+        flow_term_fast<KIND, GRAD>(db, rb0, rb1, rb2, z[e], u, zu, zv, u_ax, v_ay, fxb[e], fyb[e], mmb[e], scale, p.delta, inv_delta, p.ax,
+                                   p.ay, acc_b, gz[e]);
     }
     if (GRAD && gd) {
       if (VEC == 4) {
-        reinterpret_cast<float4*>(gd)[item] = make_float4(gz[0], gz[1], gz[2], gz[3]);
+        v4f o;
+        o.x = gz[0]; o.y = gz[1]; o.z = gz[2]; o.w = gz[3];
+        FM_STORE(o, reinterpret_cast<v4f*>(gd) + item);
+      } else if (VEC == 2) {
+        v2f o;
+        o.x = gz[0]; o.y = gz[VEC - 1];
+        FM_STORE(o, reinterpret_cast<v2f*>(gd) + item);
       } else {
         gd[item] = gz[0];
       }
@@ -265,6 +224,7 @@ __global__ void __launch_bounds__(256, 4) flow_fused_kernel(FlowParams p) {
 // ---------------------------------------------------------------------------------
 struct FlowFinalizeParams {
   const double* acc;
+  const float* k;
   const float* kinv;
   const float* t_fwd;
   const float* t_bwd;
@@ -274,12 +234,13 @@ struct FlowFinalizeParams {
   float* g_t_bwd;     // (B,F-1,4,4)
   float* g_k;         // (B,F,3,3)
   int batch, frames;
+  float ax, ay;
 };
 
 __global__ void flow_finalize_kernel(FlowFinalizeParams p) {
   const int bf = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = p.batch * p.frames;
-  if (bf < total) flow_finalize_frame(p.acc, p.kinv, p.t_fwd, p.t_bwd, p.batch, p.frames, bf, p.g_t_fwd, p.g_t_bwd, p.g_k);
+  if (bf < total) flow_finalize_frame(p.acc, p.k, p.kinv, p.t_fwd, p.t_bwd, p.batch, p.frames, bf, p.ax, p.ay, p.g_t_fwd, p.g_t_bwd, p.g_k);
   if (blockIdx.x == 0) {
     // loss numerator: sum over all (frame, direction) in fp64 by one wave
     double s = 0.0;
@@ -348,7 +309,11 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool vec4 = (width % 4 == 0) && aligned(depth) && aligned(flow_fwd) && aligned(flow_bwd) && aligned(mask_fwd) &&
                     aligned(mask_bwd) && (!grad_depth || aligned(grad_depth));
+#ifdef FM_FLOW_FORCE_VEC2
+  const int vec = vec4 ? 2 : 1;
+#else
   const int vec = vec4 ? 4 : 1;
+#endif
   const long items = (long)height * width / vec;
   const int threads = 256;
   const long per_block = (long)threads * p.iters;
@@ -365,17 +330,19 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
     else if (mapping_kind == kL1) FM_FLOW_LAUNCH(V, kL1);        \
     else FM_FLOW_LAUNCH(V, kL2);                                 \
   } while (0)
-  if (vec4) FM_FLOW_KIND(4);
+  if (vec == 4) FM_FLOW_KIND(4);
+  else if (vec == 2) FM_FLOW_KIND(2);
   else FM_FLOW_KIND(1);
 #undef FM_FLOW_KIND
 #undef FM_FLOW_LAUNCH
   FM_LAUNCH_STATUS();
 }
 
-int fm_flow_loss_finalize(const double* acc, const float* kinv, const float* t_fwd, const float* t_bwd, const float* norm,
-                          int batch, int frames, float* loss, float* g_t_fwd, float* g_t_bwd, float* g_k, void* stream) {
-  FM_CHECK_ARG(acc && kinv && t_fwd && t_bwd && norm && loss && g_t_fwd && g_t_bwd && g_k);
-  FlowFinalizeParams p{acc, kinv, t_fwd, t_bwd, norm, loss, g_t_fwd, g_t_bwd, g_k, batch, frames};
+int fm_flow_loss_finalize(const double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                          const float* norm, int batch, int frames, float aspect_x, float aspect_y, float* loss, float* g_t_fwd,
+                          float* g_t_bwd, float* g_k, void* stream) {
+  FM_CHECK_ARG(acc && k && kinv && t_fwd && t_bwd && norm && loss && g_t_fwd && g_t_bwd && g_k);
+  FlowFinalizeParams p{acc, k, kinv, t_fwd, t_bwd, norm, loss, g_t_fwd, g_t_bwd, g_k, batch, frames, aspect_x, aspect_y};
   const int total = batch * frames;
   hipLaunchKernelGGL(flow_finalize_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, p);
   FM_LAUNCH_STATUS();

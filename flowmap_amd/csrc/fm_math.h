@@ -143,8 +143,11 @@ FM_HD void apply_rot_t(const Pose& t, const float g[3], float o[3]) {  // Rᵀ g
 // exact 0 (and ‖·‖'s sub-gradient 0 there), a fused multiply-add leaves the rounding
 // residue of one product and turns that into a unit-length L1 gradient.
 FM_HD float aspect_diff(float a, float b, float s) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __fsub_rn(__fmul_rn(a, s), __fmul_rn(b, s));
+#if defined(__clang__)
+#pragma clang fp contract(off)
+  const float pa = a * s;
+  const float pb = b * s;
+  return pa - pb;
 #else
   volatile float pa = a * s, pb = b * s;
   return pa - pb;
@@ -216,48 +219,119 @@ FM_HD int tap_col(const Taps& t, int k) { return t.x0 + (k & 1); }
 FM_HD int tap_row(const Taps& t, int k) { return t.y0 + (k >> 1); }
 
 // ---------------------------------------------------------------------------------
-// One flow residual (used by the fused flow kernel): source pixel with ray/depth ->
-// destination image -> robust loss, and its analytic gradients.
-//   acc[0]      += ρ·m                      (loss numerator, unscaled)
-//   acc[1..3]   += g_X'                     (dL/dt of the relative pose)
-//   acc[4..12]  += g_X' ⊗ (z·[u,v,1])       (S; dL/dR = S·Kinvᵀ, dL/dKinv_src = Rᵀ·S)
-//   acc[13..18] += (g_u, g_v) ⊗ p           (rows 0,1 of dL/dK_dst)
-//   gz          += dL/dz of the source pixel
+// One flow residual of the FUSED flow loss (fm_flow.hip; tests/host_sim runs the same code).
+//
+// Per (source frame, direction) constants (wave-uniform, SGPRs on the GPU):
+//   m  = R·K⁻¹_src (3x3): X' = z·(m·[u,v,1]) + t — neither the source ray nor the
+//        camera-space point is formed, and dL/dz = g_X'·(m·[u,v,1]) reuses m·h;
+//   kd = rows 0,1 of the destination intrinsics PRE-SCALED by the aspect factors
+//        (fix_aspect_ratio, mapping.py:17-23): r = kd·p − aspect·(xy + flow).
+// Per pixel the residual's gradient enters every pose / intrinsics gradient only through
+//   ω = (q·w_u, q·w_v, q·(w_u·pu + w_v·pv)),   q = 1/(Z'+eps),  w = dL/d(kd·p),
+// so ONE 3x3 sum Ω = Σ ω ⊗ z[u,v,1] and σ = Σ ω carry all of them (flow_finalize_frame):
+//   dL/dX' = A·ω with A = [[kd00,kd10,0],[kd01,kd11,0],[kd02,kd12,-1]]
+//   S = Σ dL/dX' ⊗ z h = A·Ω     (dL/dR = S·K⁻ᵀ, dL/dK⁻¹_src = Rᵀ·S),   dL/dt = A·σ
+//   dL/dkd[a][b] = Σ w_a p_b = Σ_c m[b][c]·Ω[a][c] + t[b]·σ[a]          (p = q·X')
+//   acc[0] += ρ·mask    acc[1..3] += ω    acc[4..12] += ω ⊗ (z·u, z·v, z)
+//
+// Division / square root: hardware reciprocal and reciprocal-sqrt (1 ulp) on the GPU,
+// IEEE on the host.  The singular case Z'+1e-5 == 0 (reference: projection clamped to
+// ±1e8, GRADIENT NaN — SURVEY.md A.4) is dropped: that pixel's mask is zeroed.  The
+// function-level reproject kernels keep the exact clamp semantics.
 // ---------------------------------------------------------------------------------
-constexpr int kFlowAcc = 19;
+constexpr int kFlowAcc = 13;
 
-template <bool GRAD>
-FM_HD void flow_term(const Pose& tr, const Mat3& kd, const float ray[3], float z, float u, float v, float flow_x,
-                     float flow_y, float m, float scale, int kind, float delta, float ax, float ay, float (&acc)[kFlowAcc],
-                     float& gz) {
-  float x[3] = {ray[0] * z, ray[1] * z, ray[2] * z};
-  float xc[3];
-  apply_pose(tr, x, xc);
-  const Projected pr = project_point(xc, kd);
-  // Mapping.forward: fix_aspect_ratio(a) - fix_aspect_ratio(b) (mapping.py:41-43)
-  const float rx = aspect_diff(pr.u - u, flow_x, ax);
-  const float ry = aspect_diff(pr.v - v, flow_y, ay);
-  float drx, dry;
-  const float rho = robust_map(kind, delta, rx, ry, drx, dry);
-  acc[0] += rho * m;
-  if (GRAD) {
-    const float g = scale * m;
-    const float gu = g * drx * ax;
-    const float gv = g * dry * ay;
-    float gk[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float gxc[3];
-    project_point_bwd(pr, kd, gu, gv, gk, gxc);
-    for (int i = 0; i < 6; ++i) acc[13 + i] += gk[i];
-    const float zh[3] = {z * u, z * v, z};
-    for (int a = 0; a < 3; ++a) {
-      acc[1 + a] += gxc[a];
-      acc[4 + a * 3 + 0] += gxc[a] * zh[0];
-      acc[4 + a * 3 + 1] += gxc[a] * zh[1];
-      acc[4 + a * 3 + 2] += gxc[a] * zh[2];
+FM_HD float fm_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+FM_HD float fm_rsq(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+
+struct DirConst {
+  float m[9];
+  float t[3];
+  float kd[6];
+};
+
+FM_HD void make_dir(const Pose& pose, const Mat3& kinv, const Mat3& kd, float ax, float ay, DirConst& d) {
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c)
+      d.m[r * 3 + c] = pose.r[r * 3 + 0] * kinv.m[0 * 3 + c] + pose.r[r * 3 + 1] * kinv.m[1 * 3 + c] + pose.r[r * 3 + 2] * kinv.m[2 * 3 + c];
+    d.t[r] = pose.t[r];
+  }
+  for (int i = 0; i < 3; ++i) {
+    d.kd[i] = kd.m[i] * ax;
+    d.kd[3 + i] = kd.m[3 + i] * ay;
+  }
+}
+
+// row0..2 = m[:,1]·v + m[:,2] (constant along an image row); u_ax, v_ay = aspect·(u, v).
+template <int KIND, bool GRAD>
+FM_HD void flow_term_fast(const DirConst& d, float row0, float row1, float row2, float z, float u, float zu, float zv, float u_ax,
+                          float v_ay, float flow_x, float flow_y, float m, float scale, float delta, float inv_delta, float ax,
+                          float ay, float (&acc)[kFlowAcc], float& gz) {
+  const float mh0 = fmaf(d.m[0], u, row0);
+  const float mh1 = fmaf(d.m[3], u, row1);
+  const float mh2 = fmaf(d.m[6], u, row2);
+  const float x0 = fmaf(z, mh0, d.t[0]);
+  const float x1 = fmaf(z, mh1, d.t[1]);
+  const float x2 = fmaf(z, mh2, d.t[2]);
+  float q = fm_rcp(x2 + kProjEps);
+  const bool ok = fabsf(q) <= 3.0e38f;
+  q = ok ? q : 0.f;
+  m = ok ? m : 0.f;
+  const float p0 = x0 * q, p1 = x1 * q, p2 = x2 * q;
+  const float pu = fmaf(d.kd[0], p0, fmaf(d.kd[1], p1, d.kd[2] * p2));
+  const float pv = fmaf(d.kd[3], p0, fmaf(d.kd[4], p1, d.kd[5] * p2));
+  const float rx = pu - fmaf(flow_x, ax, u_ax);
+  const float ry = pv - fmaf(flow_y, ay, v_ay);
+  const float ss = fmaf(rx, rx, ry * ry);
+  float rho, coef;  // ρ and dρ/dr = coef·r
+  if (KIND == kL2) {
+    rho = 0.5f * ss;
+    coef = 1.f;
+  } else {
+    const float inv_n = ss > 0.f ? fm_rsq(ss) : 0.f;
+    const float n = ss * inv_n;
+    if (KIND == kL1) {
+      rho = n;
+      coef = inv_n;
+    } else {
+      const bool quad = n < delta;
+      rho = quad ? 0.5f * ss * inv_delta : n - 0.5f * delta;
+      coef = quad ? inv_delta : inv_n;
     }
-    float gx[3];
-    apply_rot_t(tr, gxc, gx);
-    gz += gx[0] * ray[0] + gx[1] * ray[1] + gx[2] * ray[2];
+  }
+  acc[0] = fmaf(rho, m, acc[0]);
+  if (GRAD) {
+    const float gc = (scale * m) * coef;
+    const float wu = gc * rx, wv = gc * ry;  // dL/d(kd·p)
+    const float o0 = q * wu, o1 = q * wv, o2 = q * fmaf(wu, pu, wv * pv);
+    acc[1] += o0;
+    acc[2] += o1;
+    acc[3] += o2;
+    acc[4] = fmaf(o0, zu, acc[4]);
+    acc[5] = fmaf(o0, zv, acc[5]);
+    acc[6] = fmaf(o0, z, acc[6]);
+    acc[7] = fmaf(o1, zu, acc[7]);
+    acc[8] = fmaf(o1, zv, acc[8]);
+    acc[9] = fmaf(o1, z, acc[9]);
+    acc[10] = fmaf(o2, zu, acc[10]);
+    acc[11] = fmaf(o2, zv, acc[11]);
+    acc[12] = fmaf(o2, z, acc[12]);
+    const float g0 = fmaf(d.kd[0], o0, d.kd[3] * o1);       // dL/dX'
+    const float g1 = fmaf(d.kd[1], o0, d.kd[4] * o1);
+    const float g2 = fmaf(d.kd[2], o0, fmaf(d.kd[5], o1, -o2));
+    gz = fmaf(g0, mh0, fmaf(g1, mh1, fmaf(g2, mh2, gz)));
   }
 }
 

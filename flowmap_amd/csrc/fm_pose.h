@@ -8,7 +8,7 @@
 
 namespace fm {
 
-constexpr int kFlowAccStride = 20;   // kFlowAcc (19) padded
+constexpr int kFlowAccStride = 20;   // kFlowAcc (13) padded; keeps the C-ABI workspace size
 constexpr int kStatStride = 16;      // [0]=Σw [1..3]=Σw·p [4..6]=Σw·q [7..15]=M
 constexpr int kAuxStride = 32;       // U(9) V(9) sig(3) pbar(3) qbar(3) wsum(1)
 constexpr int kPairGradStride = 20;  // gM(9) gqbar(3) gpbar(3) dbar(1) inv_wsum(1)
@@ -236,56 +236,87 @@ FM_HD void kinv_grad_to_k(const double* g, const float* ki, double* gk) {
     }
 }
 
-// ---- flow kernel finalisation for one frame (see fm_flow.hip) ---------------------------
-// acc: (B*F, 2, kFlowAccStride) sums indexed by SOURCE frame and direction.
-FM_HD void pose_grad_from_sums(const double* a, const float* kinv, float* g_t44) {
-  // dL/dR = S · Kinvᵀ ; dL/dt = Σ g_X'
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) {
-      double s = 0;
-      for (int j = 0; j < 3; ++j) s += a[4 + r * 3 + j] * (double)kinv[c * 3 + j];
-      g_t44[r * 4 + c] = (float)s;
-    }
-    g_t44[r * 4 + 3] = (float)a[1 + r];
+// ---- flow kernel finalisation for one frame (see fm_math.h "One flow residual") ---------
+// acc: (B*F, 2, kFlowAccStride) sums indexed by SOURCE frame and direction:
+//   [0] Σρ·mask   [1..3] σ = Σω   [4..12] Ω = Σ ω ⊗ z[u,v,1]
+// Everything below is per (frame, direction) 3x3 algebra in fp64.
+struct FlowDirGrads {
+  double s[9];    // S = A·Ω = Σ dL/dX' ⊗ z h
+  double gt[3];   // dL/dt = A·σ
+  double gkd[6];  // dL/dK_dst rows 0,1 (un-scaled intrinsics)
+};
+
+FM_HD void flow_dir_grads(const double* a, const float* pose44, const float* kinv_src, const float* k_dst, float ax, float ay,
+                          FlowDirGrads& o) {
+  const double* sig = a + 1;
+  const double* om = a + 4;
+  double kd[6];
+  for (int i = 0; i < 3; ++i) {
+    kd[i] = (double)k_dst[i] * (double)ax;
+    kd[3 + i] = (double)k_dst[3 + i] * (double)ay;
   }
-  for (int c = 0; c < 4; ++c) g_t44[12 + c] = 0.f;
+  const double A[9] = {kd[0], kd[3], 0.0, kd[1], kd[4], 0.0, kd[2], kd[5], -1.0};
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) o.s[r * 3 + c] = A[r * 3 + 0] * om[0 * 3 + c] + A[r * 3 + 1] * om[1 * 3 + c] + A[r * 3 + 2] * om[2 * 3 + c];
+    o.gt[r] = A[r * 3 + 0] * sig[0] + A[r * 3 + 1] * sig[1] + A[r * 3 + 2] * sig[2];
+  }
+  // m = R·K⁻¹_src ;  dL/dkd'[a][b] = Σ_c m[b][c]·Ω[a][c] + t[b]·σ[a] ; un-scale rows by (ax, ay)
+  double m[9], t[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c)
+      m[r * 3 + c] = (double)pose44[r * 4 + 0] * kinv_src[0 * 3 + c] + (double)pose44[r * 4 + 1] * kinv_src[1 * 3 + c] +
+                     (double)pose44[r * 4 + 2] * kinv_src[2 * 3 + c];
+    t[r] = pose44[r * 4 + 3];
+  }
+  for (int aa = 0; aa < 2; ++aa)
+    for (int bb = 0; bb < 3; ++bb) {
+      double v = t[bb] * sig[aa];
+      for (int c = 0; c < 3; ++c) v += m[bb * 3 + c] * om[aa * 3 + c];
+      o.gkd[aa * 3 + bb] = v * (aa == 0 ? (double)ax : (double)ay);
+    }
 }
 
-FM_HD void flow_finalize_frame(const double* acc, const float* kinv_all, const float* t_fwd, const float* t_bwd, int batch,
-                               int frames, int bf, float* g_t_fwd, float* g_t_bwd, float* g_k) {
+FM_HD void flow_finalize_frame(const double* acc, const float* k_all, const float* kinv_all, const float* t_fwd, const float* t_bwd,
+                               int batch, int frames, int bf, float ax, float ay, float* g_t_fwd, float* g_t_bwd, float* g_k) {
   (void)batch;
   const int f = bf % frames;
   const int b = bf / frames;
-  const double* af = acc + (size_t)bf * 2 * kFlowAccStride;
-  const double* ab = af + kFlowAccStride;
   const float* kinv = kinv_all + (size_t)bf * 9;
   const size_t pair_f = (size_t)b * (frames - 1) + f;
   double gkinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (f < frames - 1) {
-    pose_grad_from_sums(af, kinv, g_t_fwd + pair_f * 16);
-    const float* t = t_fwd + pair_f * 16;
-    for (int r = 0; r < 3; ++r)
+  FlowDirGrads d;
+  for (int dir = 0; dir < 2; ++dir) {  // this frame in its SOURCE role
+    if (dir == 0 ? f >= frames - 1 : f <= 0) continue;
+    const float* pose = dir == 0 ? t_fwd + pair_f * 16 : t_bwd + (pair_f - 1) * 16;
+    const float* kdst = k_all + (size_t)(dir == 0 ? bf + 1 : bf - 1) * 9;
+    flow_dir_grads(acc + ((size_t)bf * 2 + dir) * kFlowAccStride, pose, kinv, kdst, ax, ay, d);
+    float* g_t44 = dir == 0 ? g_t_fwd + pair_f * 16 : g_t_bwd + (pair_f - 1) * 16;
+    for (int r = 0; r < 3; ++r) {  // dL/dR = S·K⁻ᵀ ; dL/dt
+      for (int c = 0; c < 3; ++c) {
+        double v = 0;
+        for (int j = 0; j < 3; ++j) v += d.s[r * 3 + j] * (double)kinv[c * 3 + j];
+        g_t44[r * 4 + c] = (float)v;
+      }
+      g_t44[r * 4 + 3] = (float)d.gt[r];
+    }
+    for (int c = 0; c < 4; ++c) g_t44[12 + c] = 0.f;
+    for (int r = 0; r < 3; ++r)  // dL/dK⁻¹ += Rᵀ·S
       for (int c = 0; c < 3; ++c)
-        for (int j = 0; j < 3; ++j) gkinv[r * 3 + c] += (double)t[j * 4 + r] * af[4 + j * 3 + c];  // Rᵀ·S
-  }
-  if (f > 0) {
-    pose_grad_from_sums(ab, kinv, g_t_bwd + (pair_f - 1) * 16);
-    const float* t = t_bwd + (pair_f - 1) * 16;
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c)
-        for (int j = 0; j < 3; ++j) gkinv[r * 3 + c] += (double)t[j * 4 + r] * ab[4 + j * 3 + c];
+        for (int j = 0; j < 3; ++j) gkinv[r * 3 + c] += (double)pose[j * 4 + r] * d.s[j * 3 + c];
   }
   double gk[9];
   kinv_grad_to_k(gkinv, kinv, gk);
-  // destination role: frame f is the destination of the forward term sourced at f-1 and
-  // of the backward term sourced at f+1.
+  // DESTINATION role: frame f receives the forward term sourced at f-1 and the backward term
+  // sourced at f+1.
   if (f > 0) {
-    const double* s = acc + (size_t)(bf - 1) * 2 * kFlowAccStride;
-    for (int i = 0; i < 6; ++i) gk[i] += s[13 + i];
+    flow_dir_grads(acc + ((size_t)(bf - 1) * 2 + 0) * kFlowAccStride, t_fwd + (pair_f - 1) * 16, kinv_all + (size_t)(bf - 1) * 9,
+                   k_all + (size_t)bf * 9, ax, ay, d);
+    for (int i = 0; i < 6; ++i) gk[i] += d.gkd[i];
   }
   if (f < frames - 1) {
-    const double* s = acc + (size_t)(bf + 1) * 2 * kFlowAccStride + kFlowAccStride;
-    for (int i = 0; i < 6; ++i) gk[i] += s[13 + i];
+    flow_dir_grads(acc + ((size_t)(bf + 1) * 2 + 1) * kFlowAccStride, t_bwd + pair_f * 16, kinv_all + (size_t)(bf + 1) * 9,
+                   k_all + (size_t)bf * 9, ax, ay, d);
+    for (int i = 0; i < 6; ++i) gk[i] += d.gkd[i];
   }
   for (int i = 0; i < 9; ++i) g_k[(size_t)bf * 9 + i] = (float)gk[i];
 }

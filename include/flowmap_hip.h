@@ -63,8 +63,9 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
 /* Turns `acc` into: loss[0] = norm[0]·Σρm (loss.py:47 weight and loss_flow.py:70
  * normalisation folded into norm[0]); g_t_fwd / g_t_bwd (B,F-1,4,4) = dL/dT (bottom
  * rows 0); g_k (B,F,3,3) = dL/dK through both the projection (rows 0,1) and K⁻¹. */
-int fm_flow_loss_finalize(const double* acc, const float* kinv, const float* t_fwd, const float* t_bwd, const float* norm,
-                          int batch, int frames, float* loss, float* g_t_fwd, float* g_t_bwd, float* g_k, void* stream);
+int fm_flow_loss_finalize(const double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                          const float* norm, int batch, int frames, float aspect_x, float aspect_y, float* loss, float* g_t_fwd,
+                          float* g_t_bwd, float* g_k, void* stream);
 
 /* valid_sum of loss_flow.py:56,66,70: vsum[0] = Σmask_fwd + Σmask_bwd (fp64);
  * norm[0] = weight / (vsum or 1), norm[1] = (vsum or 1).  `count` = elements per mask. */

@@ -16,49 +16,54 @@
 
 using namespace fm;
 
-extern "C" {
-
-int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
-                       const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
-                       const float* scale, int batch, int frames, int height, int width, int mapping_kind, float delta,
-                       float ax, float ay, float* grad_depth, double* acc, int, void*) {
+template <int KIND>
+static void sim_flow(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                     const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, const float* scale,
+                     int batch, int frames, int height, int width, float delta, float ax, float ay, float* grad_depth, double* acc) {
   const size_t n = (size_t)height * width;
-  std::memset(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride);
   const float sc = scale ? scale[0] : 0.f;
+  const float inv_delta = KIND == kHuber ? 1.0f / delta : 0.f;
   for (int bf = 0; bf < batch * frames; ++bf) {
     const int f = bf % frames, b = bf / frames;
     const bool has_fwd = f < frames - 1, has_bwd = f > 0;
-    Mat3 ki, k_f, k_b;
-    Pose t_f, t_b;
+    Mat3 ki, kd;
+    Pose t;
+    DirConst df = {}, db = {};
     load_mat3(kinv + (size_t)bf * 9, ki);
     const size_t pair_f = (size_t)b * (frames - 1) + f, pair_b = pair_f - 1;
     if (has_fwd) {
-      load_mat3(k + (size_t)(bf + 1) * 9, k_f);
-      load_pose44(t_fwd + pair_f * 16, t_f);
+      load_mat3(k + (size_t)(bf + 1) * 9, kd);
+      load_pose44(t_fwd + pair_f * 16, t);
+      make_dir(t, ki, kd, ax, ay, df);
     }
     if (has_bwd) {
-      load_mat3(k + (size_t)(bf - 1) * 9, k_b);
-      load_pose44(t_bwd + pair_b * 16, t_b);
+      load_mat3(k + (size_t)(bf - 1) * 9, kd);
+      load_pose44(t_bwd + pair_b * 16, t);
+      make_dir(t, ki, kd, ax, ay, db);
     }
     double* dst = acc + (size_t)bf * 2 * kFlowAccStride;
-    for (int row = 0; row < height; ++row)
+    for (int row = 0; row < height; ++row) {
+      const float v = pixel_center(row, height), v_ay = v * ay;
+      const float rf0 = fmaf(df.m[1], v, df.m[2]), rf1 = fmaf(df.m[4], v, df.m[5]), rf2 = fmaf(df.m[7], v, df.m[8]);
+      const float rb0 = fmaf(db.m[1], v, db.m[2]), rb1 = fmaf(db.m[4], v, db.m[5]), rb2 = fmaf(db.m[7], v, db.m[8]);
       for (int col = 0; col < width; ++col) {
         const size_t px = (size_t)row * width + col;
-        const float u = pixel_center(col, width), v = pixel_center(row, height);
-        float ray[3];
-        ray_dir(ki, u, v, ray);
+        const float u = pixel_center(col, width);
         const float z = depth[(size_t)bf * n + px];
+        const float zu = z * u, zv = z * v, u_ax = u * ax;
         float gz = 0.f;
         float a_f[kFlowAcc] = {0}, a_b[kFlowAcc] = {0};
         if (has_fwd) {
           const float* fl = flow_fwd + (pair_f * n + px) * 2;
-          if (scale) flow_term<true>(t_f, k_f, ray, z, u, v, fl[0], fl[1], mask_fwd[pair_f * n + px], sc, mapping_kind, delta, ax, ay, a_f, gz);
-          else flow_term<false>(t_f, k_f, ray, z, u, v, fl[0], fl[1], mask_fwd[pair_f * n + px], sc, mapping_kind, delta, ax, ay, a_f, gz);
+          const float m = mask_fwd[pair_f * n + px];
+          if (scale) flow_term_fast<KIND, true>(df, rf0, rf1, rf2, z, u, zu, zv, u_ax, v_ay, fl[0], fl[1], m, sc, delta, inv_delta, ax, ay, a_f, gz);
+          else flow_term_fast<KIND, false>(df, rf0, rf1, rf2, z, u, zu, zv, u_ax, v_ay, fl[0], fl[1], m, sc, delta, inv_delta, ax, ay, a_f, gz);
         }
         if (has_bwd) {
           const float* fl = flow_bwd + (pair_b * n + px) * 2;
-          if (scale) flow_term<true>(t_b, k_b, ray, z, u, v, fl[0], fl[1], mask_bwd[pair_b * n + px], sc, mapping_kind, delta, ax, ay, a_b, gz);
-          else flow_term<false>(t_b, k_b, ray, z, u, v, fl[0], fl[1], mask_bwd[pair_b * n + px], sc, mapping_kind, delta, ax, ay, a_b, gz);
+          const float m = mask_bwd[pair_b * n + px];
+          if (scale) flow_term_fast<KIND, true>(db, rb0, rb1, rb2, z, u, zu, zv, u_ax, v_ay, fl[0], fl[1], m, sc, delta, inv_delta, ax, ay, a_b, gz);
+          else flow_term_fast<KIND, false>(db, rb0, rb1, rb2, z, u, zu, zv, u_ax, v_ay, fl[0], fl[1], m, sc, delta, inv_delta, ax, ay, a_b, gz);
         }
         for (int i = 0; i < kFlowAcc; ++i) {
           dst[i] += a_f[i];
@@ -66,15 +71,32 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
         }
         if (scale && grad_depth) grad_depth[(size_t)bf * n + px] = gz;
       }
+    }
   }
+}
+
+extern "C" {
+
+int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                       const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
+                       const float* scale, int batch, int frames, int height, int width, int mapping_kind, float delta,
+                       float ax, float ay, float* grad_depth, double* acc, int, void*) {
+  std::memset(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride);
+  if (mapping_kind == kHuber)
+    sim_flow<kHuber>(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, scale, batch, frames, height, width, delta, ax, ay, grad_depth, acc);
+  else if (mapping_kind == kL1)
+    sim_flow<kL1>(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, scale, batch, frames, height, width, delta, ax, ay, grad_depth, acc);
+  else
+    sim_flow<kL2>(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, scale, batch, frames, height, width, delta, ax, ay, grad_depth, acc);
   return 0;
 }
 
-int fm_flow_loss_finalize(const double* acc, const float* kinv, const float* t_fwd, const float* t_bwd, const float* norm,
-                          int batch, int frames, float* loss, float* g_t_fwd, float* g_t_bwd, float* g_k, void*) {
+int fm_flow_loss_finalize(const double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                          const float* norm, int batch, int frames, float ax, float ay, float* loss, float* g_t_fwd, float* g_t_bwd,
+                          float* g_k, void*) {
   double s = 0;
   for (int bf = 0; bf < batch * frames; ++bf) {
-    flow_finalize_frame(acc, kinv, t_fwd, t_bwd, batch, frames, bf, g_t_fwd, g_t_bwd, g_k);
+    flow_finalize_frame(acc, k, kinv, t_fwd, t_bwd, batch, frames, bf, ax, ay, g_t_fwd, g_t_bwd, g_k);
     s += acc[(size_t)bf * 2 * kFlowAccStride] + acc[(size_t)bf * 2 * kFlowAccStride + kFlowAccStride];
   }
   loss[0] = (float)(s * (double)norm[0]);
