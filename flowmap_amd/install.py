@@ -45,27 +45,39 @@ def install(lazy_surfaces: bool = True) -> None:
     if _saved:
         uninstall()
 
+    # Import every site module BEFORE patching anything, so that modules imported for the
+    # first time here bind (and uninstall() later restores) the reference's own functions.
+    sites = {}
+    for mod_name in _IMPORT_SITES:
+        try:
+            sites[mod_name] = importlib.import_module(mod_name)
+        except Exception:  # optional dependency of that module is absent (e.g. flow_vis_torch)
+            pass
     ref_projection = importlib.import_module("flowmap.model.projection")
     ref_procrustes = importlib.import_module("flowmap.model.procrustes")
+    ref_loss = importlib.import_module("flowmap.loss")
+    ref_mapping = importlib.import_module("flowmap.loss.mapping")
+    ref_extr = importlib.import_module("flowmap.model.extrinsics")
     public = [n for n in dir(our_projection) if not n.startswith("_") and hasattr(ref_projection, n) and callable(getattr(our_projection, n))]
     for name in public:
         _set(ref_projection, name, getattr(our_projection, name))
     _set(ref_procrustes, "align_rigid", our_procrustes.align_rigid)
 
     for mod_name, names in _IMPORT_SITES.items():
-        try:
-            mod = importlib.import_module(mod_name)
-        except Exception:  # optional dependency of that module is absent (e.g. flow_vis_torch)
+        mod = sites.get(mod_name)
+        if mod is None:
             continue
         for name in names:
             src = our_procrustes if name == "align_rigid" else our_projection
-            _set(mod, name, getattr(src, name))
+            value = getattr(src, name)
+            if name == "unproject" and mod_name.endswith("intrinsics_softmin"):
+                # IntrinsicsSoftmin reshapes / indexes the surfaces with einops right away
+                # (intrinsics_softmin.py:104-109): hand it the materialising variant.
+                value = our_projection.unproject_dense
+            _set(mod, name, value)
 
-    ref_loss = importlib.import_module("flowmap.loss")
     _set(ref_loss, "LOSSES", {**ref_loss.LOSSES, "flow": our_loss.LossFlow, "tracking": our_loss.LossTracking})
-    ref_mapping = importlib.import_module("flowmap.loss.mapping")
     _set(ref_mapping, "MAPPINGS", {**ref_mapping.MAPPINGS, **our_mapping.MAPPINGS})
-    ref_extr = importlib.import_module("flowmap.model.extrinsics")
     _set(ref_extr, "EXTRINSICS", {**ref_extr.EXTRINSICS, "procrustes": ExtrinsicsProcrustes})
 
     our_projection.set_lazy_surfaces(lazy_surfaces)

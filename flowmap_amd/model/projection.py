@@ -276,6 +276,11 @@ def unproject(coordinates: Tensor, z: Tensor, intrinsics: Tensor):
     return _unproject_dense(coordinates, z, intrinsics)
 
 
+def unproject_dense(coordinates: Tensor, z: Tensor, intrinsics: Tensor) -> Tensor:
+    """``unproject`` that always returns a real tensor (never a LazySurfaces)."""
+    return _unproject_dense(coordinates, z, intrinsics)
+
+
 # --------------------------------------------------------------------------------------
 # rigid transforms / projection on explicit points
 # --------------------------------------------------------------------------------------

@@ -88,3 +88,52 @@ def test_unmodified_reference_model_runs_on_our_kernels(patched_reference, name,
     assert_close(model.backbone.depth.grad, g["g_depth"], 1e-4, what="g_depth")
     assert_close(model.backbone.weights.grad, g["g_wlogit"], 3e-4, what="g_wlogit")
     assert_close(model.intrinsics.focal_length.grad, g["g_focal"], 1e-3, abs_=1e-4 * abs(float(g["total"])), what="g_focal")
+
+
+def test_reference_softmin_intrinsics_under_install():
+    """IntrinsicsSoftmin (the reference's DEFAULT intrinsics for the first 1000 steps,
+    intrinsics_softmin.py:63-141) calls unproject / align_surfaces / compute_backward_flow
+    with batch 60 and 1-D grids.  Unpatched reference vs the same code after install()."""
+    sys.dont_write_bytecode = True
+    added = [str(ROOT / "oracle" / "refstubs"), str(REF)]
+    sys.path[:0] = added
+    try:
+        from conftest import assert_close
+        from flowmap.dataset.types import Batch
+        from flowmap.flow.flow_predictor import Flows
+        from flowmap.model.backbone.backbone import BackboneOutput
+        from flowmap.model.intrinsics.intrinsics_softmin import IntrinsicsSoftmin, IntrinsicsSoftminCfg
+
+        import flowmap_amd
+        from flowmap_amd import _lib
+        from helpers import build_host_sim
+        from oracle import flowmap_oracle as orc
+
+        f, h, w = 3, 12, 16
+        depth, wlogit, fl = orc.synth_iid(f, h, w, seed=8)
+        flows = Flows(fl.forward, fl.backward, fl.forward_mask, fl.backward_mask)
+        batch = Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["s"], ["d"])
+        cfg = IntrinsicsSoftminCfg("softmin", 64, 0.5, 2.0, 12, None)
+
+        def run():
+            d = depth[None].clone().requires_grad_(True)
+            wt = (100 * wlogit).sigmoid()[None].clone().requires_grad_(True)
+            torch.manual_seed(0)  # the module draws torch.randperm
+            k = IntrinsicsSoftmin(cfg).forward(batch, flows, BackboneOutput(d, wt), 0)
+            (k * torch.arange(9.0).reshape(3, 3)).sum().backward()
+            return k.detach(), d.grad, wt.grad
+
+        k_ref, gd_ref, gw_ref = run()
+        _lib.set_library_for_testing(build_host_sim())
+        flowmap_amd.install()
+        try:
+            k_ours, gd_ours, gw_ours = run()
+        finally:
+            flowmap_amd.uninstall()
+            _lib.set_library_for_testing(None)
+        assert_close(k_ours, k_ref, 1e-4, what="softmin intrinsics")
+        assert_close(gd_ours, gd_ref, 2e-3, abs_=1e-6, what="g_depth")
+        assert_close(gw_ours, gw_ref, 2e-3, abs_=1e-6, what="g_weights")
+    finally:
+        for p in added:
+            sys.path.remove(p)
