@@ -65,6 +65,26 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v4f ld4(const float* base, int i) { return FM_LOAD(reinterpret_cast<const v4f*>(base) + i); }
 __device__ __forceinline__ v2f ld2(const float* base, int i) { return FM_LOAD(reinterpret_cast<const v2f*>(base) + i); }
 
+// One quad's raw inputs, kept as the 16-byte vectors they were loaded as.
+struct QuadIn {
+  v4f z, fa, fc, fm, ba, bc, bm;
+};
+
+__device__ __forceinline__ void load_quad(QuadIn& q, const float* depth, const float* ff, const float* mf, const float* fb,
+                                          const float* mb, int item, bool has_fwd, bool has_bwd) {
+  q.z = ld4(depth, item);
+  if (has_fwd) {
+    q.fa = ld4(ff, item * 2);
+    q.fc = ld4(ff, item * 2 + 1);
+    q.fm = ld4(mf, item);
+  }
+  if (has_bwd) {
+    q.ba = ld4(fb, item * 2);
+    q.bc = ld4(fb, item * 2 + 1);
+    q.bm = ld4(mb, item);
+  }
+}
+
 #ifndef FM_FLOW_WAVES
 // Waves per SIMD the register allocator must leave room for.  3 (<=168 VGPRs, 133 used, no
 // scratch) beat 4 (128 VGPRs) by 3-5 % and 2 by 4 % in interleaved A/B runs; 5 spills.
@@ -126,55 +146,11 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   // scheduler hoists all seven 16-byte loads and interleaves the eight residuals of a
   // quad, and the kernel spills (measured: 336 B/lane scratch, +40 % instructions).
   const int base = blockIdx.x * (blockDim.x * p.iters);
-  for (int it = 0; it < p.iters; ++it) {
-    const int item = base + it * blockDim.x + threadIdx.x;
-    if (item >= items) break;
-    float z[VEC], gz[VEC], fxf[VEC], fyf[VEC], mmf[VEC], fxb[VEC], fyb[VEC], mmb[VEC];
-    if (VEC == 4) {
-      const v4f zq = ld4(depth, item);
-      z[0] = zq.x; z[1] = zq.y; z[2] = zq.z; z[3] = zq.w;
-      if (has_fwd) {
-        const v4f a = ld4(ff, item * 2);
-        const v4f c = ld4(ff, item * 2 + 1);
-        const v4f mq = ld4(mf, item);
-        fxf[0] = a.x; fyf[0] = a.y; fxf[1] = a.z; fyf[1] = a.w;
-        fxf[2] = c.x; fyf[2] = c.y; fxf[3] = c.z; fyf[3] = c.w;
-        mmf[0] = mq.x; mmf[1] = mq.y; mmf[2] = mq.z; mmf[3] = mq.w;
-      }
-      if (has_bwd) {
-        const v4f a = ld4(fb, item * 2);
-        const v4f c = ld4(fb, item * 2 + 1);
-        const v4f mq = ld4(mb, item);
-        fxb[0] = a.x; fyb[0] = a.y; fxb[1] = a.z; fyb[1] = a.w;
-        fxb[2] = c.x; fyb[2] = c.y; fxb[3] = c.z; fyb[3] = c.w;
-        mmb[0] = mq.x; mmb[1] = mq.y; mmb[2] = mq.z; mmb[3] = mq.w;
-      }
-    } else if (VEC == 2) {
-      const v2f zq = ld2(depth, item);
-      z[0] = zq.x; z[VEC - 1] = zq.y;
-      if (has_fwd) {
-        const v4f a = ld4(ff, item);
-        const v2f mq = ld2(mf, item);
-        fxf[0] = a.x; fyf[0] = a.y; fxf[VEC - 1] = a.z; fyf[VEC - 1] = a.w;
-        mmf[0] = mq.x; mmf[VEC - 1] = mq.y;
-      }
-      if (has_bwd) {
-        const v4f a = ld4(fb, item);
-        const v2f mq = ld2(mb, item);
-        fxb[0] = a.x; fyb[0] = a.y; fxb[VEC - 1] = a.z; fyb[VEC - 1] = a.w;
-        mmb[0] = mq.x; mmb[VEC - 1] = mq.y;
-      }
-    } else {
-      z[0] = depth[item];
-      if (has_fwd) {
-        const float2 a = reinterpret_cast<const float2*>(ff)[item];
-        fxf[0] = a.x; fyf[0] = a.y; mmf[0] = mf[item];
-      }
-      if (has_bwd) {
-        const float2 a = reinterpret_cast<const float2*>(fb)[item];
-        fxb[0] = a.x; fyb[0] = a.y; mmb[0] = mb[item];
-      }
-    }
+
+  // Everything after the loads of one item: coordinates, both residual terms per pixel, store.
+  auto compute = [&](const float (&z)[VEC], const float (&fxf)[VEC], const float (&fyf)[VEC], const float (&mmf)[VEC],
+                     const float (&fxb)[VEC], const float (&fyb)[VEC], const float (&mmb)[VEC], int item) {
+    float gz[VEC];
     const int row = item / items_per_row;
     const int col0 = (item - row * items_per_row) * VEC;
     const float v = pixel_center(row, p.height);
@@ -207,6 +183,61 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
         gd[item] = gz[0];
       }
     }
+  };
+
+  auto compute_quad = [&](const QuadIn& q, int item) {
+    float z[VEC], fxf[VEC], fyf[VEC], mmf[VEC], fxb[VEC], fyb[VEC], mmb[VEC];
+    if (VEC == 4) {
+      z[0] = q.z.x; z[1 % VEC] = q.z.y; z[2 % VEC] = q.z.z; z[3 % VEC] = q.z.w;
+      fxf[0] = q.fa.x; fyf[0] = q.fa.y; fxf[1 % VEC] = q.fa.z; fyf[1 % VEC] = q.fa.w;
+      fxf[2 % VEC] = q.fc.x; fyf[2 % VEC] = q.fc.y; fxf[3 % VEC] = q.fc.z; fyf[3 % VEC] = q.fc.w;
+      mmf[0] = q.fm.x; mmf[1 % VEC] = q.fm.y; mmf[2 % VEC] = q.fm.z; mmf[3 % VEC] = q.fm.w;
+      fxb[0] = q.ba.x; fyb[0] = q.ba.y; fxb[1 % VEC] = q.ba.z; fyb[1 % VEC] = q.ba.w;
+      fxb[2 % VEC] = q.bc.x; fyb[2 % VEC] = q.bc.y; fxb[3 % VEC] = q.bc.z; fyb[3 % VEC] = q.bc.w;
+      mmb[0] = q.bm.x; mmb[1 % VEC] = q.bm.y; mmb[2 % VEC] = q.bm.z; mmb[3 % VEC] = q.bm.w;
+    }
+    compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item);
+  };
+
+  // (A depth-2 software pipeline of the loads — two QuadIn register sets, loop unrolled by
+  // two, 168 VGPRs — measured 0.856 vs 0.845 ms: no gain, removed.)
+  for (int it = 0; it < p.iters; ++it) {
+    const int item = base + it * blockDim.x + threadIdx.x;
+    if (item >= items) break;
+    if (VEC == 4) {
+      QuadIn q = {};
+      load_quad(q, depth, ff, mf, fb, mb, item, has_fwd, has_bwd);
+      compute_quad(q, item);
+      continue;
+    }
+    float z[VEC], fxf[VEC], fyf[VEC], mmf[VEC], fxb[VEC], fyb[VEC], mmb[VEC];
+    if (VEC == 2) {
+      const v2f zq = ld2(depth, item);
+      z[0] = zq.x; z[VEC - 1] = zq.y;
+      if (has_fwd) {
+        const v4f a = ld4(ff, item);
+        const v2f mq = ld2(mf, item);
+        fxf[0] = a.x; fyf[0] = a.y; fxf[VEC - 1] = a.z; fyf[VEC - 1] = a.w;
+        mmf[0] = mq.x; mmf[VEC - 1] = mq.y;
+      }
+      if (has_bwd) {
+        const v4f a = ld4(fb, item);
+        const v2f mq = ld2(mb, item);
+        fxb[0] = a.x; fyb[0] = a.y; fxb[VEC - 1] = a.z; fyb[VEC - 1] = a.w;
+        mmb[0] = mq.x; mmb[VEC - 1] = mq.y;
+      }
+    } else {
+      z[0] = depth[item];
+      if (has_fwd) {
+        const float2 a = reinterpret_cast<const float2*>(ff)[item];
+        fxf[0] = a.x; fyf[0] = a.y; mmf[0] = mf[item];
+      }
+      if (has_bwd) {
+        const float2 a = reinterpret_cast<const float2*>(fb)[item];
+        fxb[0] = a.x; fyb[0] = a.y; mmb[0] = mb[item];
+      }
+    }
+    compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item);
   }
 
   double* dst = p.acc + (size_t)bf * 2 * kFlowAccStride;
@@ -304,7 +335,7 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   hipStream_t st = (hipStream_t)stream;
   const bool grad = scale != nullptr;
   FlowParams p{depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, scale, grad_depth, acc,
-               frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 8};  // 8 measured best (4: 0.85, 8: 0.82, 16: 0.89, 32: 0.91 ms @C1)
+               frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 6};  // 1: 1.16, 2: 0.90, 3-8: 0.81-0.85 (noise ±3 %), 16: 0.87, 32: 0.91 ms @C1
   if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride, st) != hipSuccess) return FM_ERR_LAUNCH;
   auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool vec4 = (width % 4 == 0) && aligned(depth) && aligned(flow_fwd) && aligned(flow_bwd) && aligned(mask_fwd) &&

@@ -50,7 +50,7 @@ def launch(fn, grad, ipt):
               acc.data_ptr(), ipt, st)
 
 
-configs = [(n, True, i) for n in fns for i in (4, 8, 16)] + [("shipped", False, 8)]
+configs = [(n, True, i) for n in fns for i in (1, 2, 3, 4, 6, 8)] + [("shipped", False, 8)]
 times = {c: [] for c in configs}
 for rnd in range(6):
     for c in configs:
