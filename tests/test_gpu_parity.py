@@ -52,6 +52,7 @@ def test_step_vs_reference_golden(name, kind, lazy):
     [
         (16, 256, 256, 1000),  # C0 (BASELINE.json configs[0])
         (4, 720, 1280, 1000),  # C1's frame size, few frames (oracle finishes in seconds)
+        (3, 1080, 1920, 1000),  # C3/C4's frame size
         (5, 90, 122, None),  # width not a multiple of 4 -> scalar kernel path, dense Procrustes
         (3, 64, 96, 600),
     ],

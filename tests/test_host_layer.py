@@ -1,0 +1,102 @@
+"""Host-layer behaviour that needs no kernels at all, or only the host double: lazy handles,
+broadcast flattening, caches, error behaviour."""
+
+import pytest
+import torch
+
+import flowmap_amd
+from flowmap_amd import _lib
+from flowmap_amd.loss.loss import or_one
+from flowmap_amd.model import projection as fm
+from helpers import build_host_sim
+
+
+@pytest.fixture(autouse=True, scope="module")
+def host_double():
+    _lib.set_library_for_testing(build_host_sim())
+    yield
+    _lib.set_library_for_testing(None)
+
+
+def test_or_one_matches_python_or():
+    assert float(or_one(torch.tensor(0.0))) == 1.0
+    assert float(or_one(torch.tensor(3.5))) == 3.5
+    assert int(or_one(torch.tensor(0))) == 1 and int(or_one(torch.tensor(7))) == 7
+
+
+def test_grid_is_cached_and_matches_reference_arithmetic():
+    a, ia = fm.sample_image_grid((5, 7))
+    b, _ = fm.sample_image_grid((5, 7))
+    assert a is b  # identity is what lets unproject recognise the canonical grid
+    assert a.shape == (5, 7, 2) and ia.shape == (5, 7, 2) and ia.dtype == torch.int64
+    assert torch.equal(a[2, 3], torch.tensor([(3 + 0.5) / 7, (2 + 0.5) / 5], dtype=torch.float32))
+    assert torch.equal(ia[2, 3], torch.tensor([2, 3]))
+
+
+def test_lazy_surfaces_quack_and_materialise():
+    z = torch.rand((1, 3, 4, 6)) + 1
+    k = torch.eye(3).expand(1, 3, 3, 3).contiguous()
+    xy, _ = fm.sample_image_grid((4, 6))
+    dense = fm.unproject(xy, z, k[:, :, None, None])
+    fm.set_lazy_surfaces(True)
+    try:
+        lazy = fm.unproject(xy, z, k[:, :, None, None])
+        not_canonical = fm.unproject(xy.clone(), z, k[:, :, None, None])  # a different grid object: stays dense
+    finally:
+        fm.set_lazy_surfaces(False)
+    assert isinstance(lazy, fm.LazySurfaces) and isinstance(not_canonical, torch.Tensor)
+    assert lazy.shape == dense.shape and lazy.device == dense.device and lazy.ndim == 5 and lazy.dtype == torch.float32
+    sl = lazy[:, 1:3]  # frame slice stays lazy (loss_tracking.py:48)
+    assert isinstance(sl, fm.LazySurfaces) and sl.shape == (1, 2, 4, 6, 3)
+    assert torch.allclose(lazy.materialize(), dense)
+    assert torch.allclose(torch.sum(lazy, dim=-1), dense.sum(-1))  # torch function -> materialises
+    assert torch.allclose(lazy.mean(), dense.mean())  # attribute access -> materialises
+    assert torch.allclose(lazy[0, 1, 2], dense[0, 1, 2])  # general indexing -> materialises
+
+
+def test_lazy_weights_materialise_to_sigmoid():
+    logits = torch.randn((1, 2, 3, 4))
+    lw = fm.LazyWeights(logits, 100.0)
+    assert lw.shape == logits.shape
+    assert torch.allclose(lw.materialize(), (100 * logits).sigmoid())
+    assert torch.allclose(torch.ones_like(lw), torch.ones_like(logits))
+
+
+def test_unproject_broadcast_patterns():
+    g = torch.Generator().manual_seed(0)
+    xy = torch.rand((5, 2), generator=g)
+    z = torch.rand((2, 3, 5), generator=g) + 1
+    k = torch.eye(3).repeat(2, 3, 1, 1) + 0.1 * torch.rand((2, 3, 3, 3), generator=g)
+    ours = fm.unproject(xy, z, k[:, :, None])
+    ref = (torch.linalg.inv(k)[:, :, None] @ torch.cat([xy, torch.ones(5, 1)], -1)[..., None])[..., 0] * z[..., None]
+    assert torch.allclose(ours, ref, atol=1e-5)
+    # per-group coordinates
+    xyg = torch.rand((2, 3, 5, 2), generator=g)
+    ours = fm.unproject(xyg, z, k[:, :, None])
+    ref = (torch.linalg.inv(k)[:, :, None] @ torch.cat([xyg, torch.ones(2, 3, 5, 1)], -1)[..., None])[..., 0] * z[..., None]
+    assert torch.allclose(ours, ref, atol=1e-5)
+
+
+def test_dtype_and_shape_errors_are_loud():
+    with pytest.raises(RuntimeError, match="float32"):
+        fm.get_extrinsics(torch.eye(4, dtype=torch.float64).repeat(1, 2, 1, 1))
+    z = torch.rand((1, 3, 4, 6))
+    with pytest.raises(RuntimeError, match="shapes do not match"):
+        fm.align_surfaces(torch.rand((1, 3, 4, 6, 3)), torch.zeros((1, 2, 4, 5, 2)), torch.ones((1, 2, 4, 6)), None)
+    with pytest.raises(RuntimeError, match="int64"):
+        fm.align_surfaces(torch.rand((1, 3, 4, 6, 3)), torch.zeros((1, 2, 4, 6, 2)), torch.ones((1, 2, 4, 6)), torch.arange(4, dtype=torch.int32))
+    flow = torch.zeros((1, 2, 4, 6, 2), requires_grad=True)
+    with pytest.raises(RuntimeError, match="optical flow"):
+        fm.align_surfaces(torch.rand((1, 3, 4, 6, 3)), flow, torch.ones((1, 2, 4, 6)), None)
+    assert z is not None
+
+
+def test_version_bump_invalidates_mask_norm_cache():
+    from flowmap_amd import _ops
+
+    m1, m2 = torch.rand((1, 2, 3, 4)), torch.rand((1, 2, 3, 4))
+    a = _ops.flow_valid_norm(m1, m2, 10.0)
+    assert _ops.flow_valid_norm(m1, m2, 10.0) is a  # cached
+    m1.mul_(0.5)  # in-place edit bumps the version counter
+    b = _ops.flow_valid_norm(m1, m2, 10.0)
+    assert b is not a and abs(float(b[1]) - float(m1.sum() + m2.sum())) < 1e-4
