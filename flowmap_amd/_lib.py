@@ -79,10 +79,16 @@ def library() -> ctypes.CDLL:
     global _lib
     if _lib is None:
         if not LIB_PATH.exists():
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950).  flowmap_amd has no CPU or eager fallback."
-            )
+            try:  # a fresh checkout: compile the kernels in-tree (hipcc cross-compiles gfx950 anywhere)
+                from .build import build_library
+
+                build_library(verbose=False)
+            except Exception as exc:
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing and could not be built ({exc}); run "
+                    "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).  "
+                    "flowmap_amd has no CPU or eager fallback."
+                ) from exc
         _lib = _bind(ctypes.CDLL(str(LIB_PATH)))
     return _lib
 
