@@ -8,6 +8,7 @@ synchronises the device or falls back to eager PyTorch math.
 
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -283,7 +284,9 @@ def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=N
            float(weight), str(mask_fwd.device), id(reducer))
     hit = _norm_cache.get(key)
     if hit is not None:
-        return hit
+        norm, ref_f, ref_b = hit
+        if ref_f() is mask_fwd and ref_b() is mask_bwd:  # same live tensors, not a recycled address
+            return norm
     vsum = torch.empty((1,), dtype=torch.float64, device=mask_fwd.device)
     norm = torch.empty((2,), dtype=torch.float32, device=mask_fwd.device)
     with _guard(mask_fwd.device):
@@ -295,7 +298,7 @@ def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=N
         norm = torch.cat([float(weight) / veff, veff]).to(torch.float32)
     if len(_norm_cache) > 8:
         _norm_cache.clear()
-    _norm_cache[key] = norm
+    _norm_cache[key] = (norm, weakref.ref(mask_fwd), weakref.ref(mask_bwd))
     return norm
 
 
@@ -578,11 +581,15 @@ _packed_cache: dict = {}
 def pack_tracks(tracks, device) -> PackedTracks:
     key = tuple((t.xy.data_ptr(), t.xy._version, t.visibility.data_ptr(), int(t.start_frame), tuple(t.xy.shape)) for t in tracks) + (str(device),)
     hit = _packed_cache.get(key)
-    if hit is None:
-        if len(_packed_cache) > 4:
-            _packed_cache.clear()
-        hit = _packed_cache[key] = PackedTracks(tracks, device)
-    return hit
+    if hit is not None:
+        packed, refs = hit
+        if all(r() is t.xy for r, t in zip(refs, tracks)):  # live tensors, not recycled addresses
+            return packed
+    if len(_packed_cache) > 4:
+        _packed_cache.clear()
+    packed = PackedTracks(tracks, device)
+    _packed_cache[key] = (packed, [weakref.ref(t.xy) for t in tracks])
+    return packed
 
 
 class TrackLossFused(torch.autograd.Function):
