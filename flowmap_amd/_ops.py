@@ -177,7 +177,9 @@ class ProcrustesFit(torch.autograd.Function):
     evaluated at the gathered points only (BackboneExplicitDepth fused into the gather);
     the returned gradient is then w.r.t. the logits.
 
-    Returns the "inverse relative transformations" (B,F-1,4,4): later -> earlier camera.
+    Returns the "inverse relative transformations" (B,F-1,4,4): later -> earlier camera, and
+    their rigid inverses (earlier -> later camera) for consumers that want both directions
+    without going through the pose chain.
     """
 
     @staticmethod
@@ -211,12 +213,13 @@ class ProcrustesFit(torch.autograd.Function):
         pairs = b * (f - 1)
         stats = torch.empty((pairs, STAT_STRIDE), dtype=torch.float64, device=dev)
         t_bwd = torch.empty((b, f - 1, 4, 4), dtype=torch.float32, device=dev)
+        t_fwd = torch.empty_like(t_bwd)
         aux = torch.empty((pairs, AUX_STRIDE), dtype=torch.float64, device=dev)
         with _guard(dev):
             st = stream_for(weights)
             call("fm_procrustes_stats", ptr(depth) if from_depth else None, ptr(kinv), ptr(surfaces), ptr(bwd_flow),
                  ptr(weights), float(weight_sens), ptr(indices), points, b, f, h, w, ptr(stats), st)
-            call("fm_pose_solve", ptr(stats), pairs, ptr(t_bwd), None, ptr(aux), st)
+            call("fm_pose_solve", ptr(stats), pairs, ptr(t_bwd), ptr(t_fwd), ptr(aux), st)
         ctx.save_for_backward(depth if from_depth else surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux)
         ctx.from_depth, ctx.dims, ctx.points, ctx.weight_sens = from_depth, (b, f, h, w), points, float(weight_sens)
         # Carried depth gradient: when the fused flow loss consumes poses fitted from the very
@@ -226,15 +229,16 @@ class ProcrustesFit(torch.autograd.Function):
         ctx._fm_fit_depth_key = (depth.data_ptr(), depth._version, tuple(depth.shape)) if from_depth else None
         ctx._fm_carried = None
         ctx._fm_pending = []  # deferred scatters of other losses into the final dL/ddepth buffer
-        return t_bwd
+        return t_bwd, t_fwd
 
     @staticmethod
-    def backward(ctx, g_t):
+    def backward(ctx, g_t, g_t_fwd):
         src, kinv, weights, bwd_flow, indices, t_bwd, aux = ctx.saved_tensors
         b, f, h, w = ctx.dims
         pairs = b * (f - 1)
         dev = weights.device
-        g_t = _f32c(g_t, "grad")
+        g_t = None if g_t is None else _f32c(g_t, "grad")
+        g_t_fwd = None if g_t_fwd is None else _f32c(g_t_fwd, "grad")
         need_src = ctx.needs_input_grad[0] if ctx.from_depth else ctx.needs_input_grad[2]
         need_k = ctx.from_depth and ctx.needs_input_grad[1]
         need_w = ctx.needs_input_grad[3]
@@ -252,7 +256,7 @@ class ProcrustesFit(torch.autograd.Function):
         kinv_acc = torch.zeros((b * f, 9), dtype=torch.float64, device=dev) if need_k else None
         with _guard(dev):
             st = stream_for(weights)
-            call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t_bwd), ptr(aux), pairs, ptr(pair_grad), st)
+            call("fm_pose_solve_bwd", ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr(aux), pairs, ptr(pair_grad), st)
             call("fm_procrustes_scatter", ptr(src) if ctx.from_depth else None, ptr(kinv), None if ctx.from_depth else ptr(src),
                  ptr(bwd_flow), ptr(weights), ctx.weight_sens, ptr(indices), ctx.points, b, f, h, w, ptr(aux), ptr(pair_grad),
                  ptr(g_src) if ctx.from_depth else None, None if ctx.from_depth else ptr(g_src), ptr(g_w), ptr(kinv_acc), st)
@@ -328,9 +332,11 @@ class FlowLossFused(torch.autograd.Function):
         acc = torch.empty((b * f * 2 * FLOW_ACC_STRIDE,), dtype=torch.float64, device=dev)
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
         g_depth = torch.empty_like(depth) if (need and ctx.needs_input_grad[0]) else None
-        g_tf = torch.empty_like(t_fwd)
-        g_tb = torch.empty_like(t_bwd)
-        g_k = torch.empty_like(k)
+        # the three small gradients share one allocation so one launch rescales them in backward
+        small = torch.empty((2 * t_fwd.numel() + k.numel(),), dtype=torch.float32, device=dev)
+        g_tf = small[: t_fwd.numel()].view_as(t_fwd)
+        g_tb = small[t_fwd.numel() : 2 * t_fwd.numel()].view_as(t_bwd)
+        g_k = small[2 * t_fwd.numel() :].view_as(k)
         scale = (h * w) ** 0.5
         events = None
         if flow_kernel_events is not None and depth.is_cuda:
@@ -347,7 +353,7 @@ class FlowLossFused(torch.autograd.Function):
                 flow_kernel_events.append(events)
             call("fm_flow_loss_finalize", ptr(acc), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(norm), b, f, w / scale, h / scale,
                  ptr(loss), ptr(g_tf), ptr(g_tb), ptr(g_k), st)
-        ctx.grads = (g_depth, g_k, g_tf, g_tb) if need else None
+        ctx.grads = (g_depth, g_k, g_tf, g_tb, small) if need else None
         ctx.fit_node = None
         if carry and g_depth is not None:
             key = (depth.data_ptr(), depth._version, tuple(depth.shape))
@@ -360,12 +366,12 @@ class FlowLossFused(torch.autograd.Function):
     def backward(ctx, g):
         if ctx.grads is None:
             raise RuntimeError("flowmap_amd: FlowLossFused gradients are single-use; run the forward again")
-        g_depth, g_k, g_tf, g_tb = ctx.grads
+        g_depth, g_k, g_tf, g_tb, small = ctx.grads
         ctx.grads = None
         g = g.reshape(1).to(torch.float32).contiguous()
         with _guard(g.device):
             st = stream_for(g)
-            for buf in (g_depth, g_k, g_tf, g_tb):
+            for buf in (g_depth, small):
                 if buf is not None:
                     call("fm_scale_if_needed", ptr(buf), buf.numel(), ptr(g), st)
         node = ctx.fit_node

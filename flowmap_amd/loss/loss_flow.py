@@ -36,6 +36,8 @@ class LossFlow(Loss[LossFlowCfg]):
     carry_depth_grad: bool = True
     # frame sharding: maps the local Σmask (fp64 device tensor) to the global one
     valid_sum_reducer = None
+    # take the relative poses align_surfaces attached to the extrinsics instead of inverting the chain
+    use_fitted_poses: bool = True
 
     def __init__(self, cfg: LossFlowCfg) -> None:
         super().__init__(cfg)
@@ -49,7 +51,11 @@ class LossFlow(Loss[LossFlowCfg]):
 
     def _fused(self, flows, model_output, weight: float) -> Tensor:
         s: LazySurfaces = model_output.surfaces
-        rel_fwd, rel_bwd = _ops.RelativePoses.apply(model_output.extrinsics)
+        direct = getattr(model_output.extrinsics, "_fm_relative_poses", None) if self.use_fitted_poses else None
+        if direct is not None and direct[0].shape[:2] == (s.depths.shape[0], s.depths.shape[1] - 1):
+            rel_fwd, rel_bwd = direct  # straight from the Procrustes fit (align_surfaces)
+        else:
+            rel_fwd, rel_bwd = _ops.RelativePoses.apply(model_output.extrinsics)
         norm = _ops.flow_valid_norm(flows.forward_mask, flows.backward_mask, weight, self.valid_sum_reducer)
         return _ops.FlowLossFused.apply(
             s.depths, model_output.intrinsics, rel_fwd, rel_bwd, flows.forward, flows.backward, flows.forward_mask,

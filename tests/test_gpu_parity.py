@@ -111,7 +111,7 @@ def test_full_size_properties_c1():
 
     def run(lo, hi):  # frames [lo, hi]
         d = depth[:, lo : hi + 1].contiguous().requires_grad_(True)
-        rel = _ops.ProcrustesFit.apply(d, k[:, lo : hi + 1].contiguous(), None, wts[:, lo:hi].contiguous(), fb[:, lo:hi].contiguous(), idx)
+        rel, _ = _ops.ProcrustesFit.apply(d, k[:, lo : hi + 1].contiguous(), None, wts[:, lo:hi].contiguous(), fb[:, lo:hi].contiguous(), idx)
         ext = _ops.PoseChain.apply(rel)
         rf, rb = _ops.RelativePoses.apply(ext)
         norm = torch.tensor([1.0, 1.0], device=DEV)  # un-normalised numerator

@@ -26,7 +26,7 @@ def stages(depth, k, weights, flows, idx, dev):
     fl = [x.to(dev).contiguous() for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)]
     i = idx.to(dev)
     out["kinv"] = _ops.intrinsics_inverse(kk.detach())
-    rel_b = _ops.ProcrustesFit.apply(d, kk, None, w, fl[1], i)
+    rel_b, _ = _ops.ProcrustesFit.apply(d, kk, None, w, fl[1], i)
     out["t_bwd"] = rel_b.detach()
     ext = _ops.PoseChain.apply(rel_b)
     out["ext"] = ext.detach()
