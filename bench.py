@@ -54,21 +54,30 @@ def parse():
                     help="torch threads for the CPU baseline (16 measured fastest on the 256-thread EPYC 9575F host: "
                     "8 -> 0.42, 16 -> 0.25, 32 -> 0.35, 64 -> 0.45, 256 -> 5.2 s/iter at 4 frames @720p)")
     ap.add_argument("--items-per-thread", type=int, default=0)
+    ap.add_argument("--smooth-flows", action="store_true",
+                    help="spatially smooth synthetic flows (low-res noise upsampled) instead of i.i.d. per-pixel noise")
     ap.add_argument("--tracking", action="store_true",
                     help="BASELINE.json configs[2]: add the tracking loss (segments every 5 frames, +-20 frames, 35x35 tracks)")
     return ap.parse_args()
 
 
-def make_inputs(f, h, w, device, seed):
+def make_inputs(f, h, w, device, seed, smooth=False):
     """i.i.d. synthetic inputs of BASELINE.md §2, generated directly in HBM."""
     g = torch.Generator(device=device).manual_seed(seed)
     depth = 1.10 + 0.05 * torch.rand((f, h, w), device=device, generator=g)
     wlogit = 0.01 * torch.randn((f - 1, h, w), device=device, generator=g)
     from flowmap_amd import Flows
 
+    def flow_field():
+        if not smooth:
+            return 0.01 * torch.randn((1, f - 1, h, w, 2), device=device, generator=g)
+        low = 0.01 * torch.randn((f - 1, 2, max(h // 40, 2), max(w // 40, 2)), device=device, generator=g)
+        up = torch.nn.functional.interpolate(low, size=(h, w), mode="bicubic", align_corners=False)
+        return up.permute(0, 2, 3, 1)[None].contiguous()
+
     flows = Flows(
-        0.01 * torch.randn((1, f - 1, h, w, 2), device=device, generator=g),
-        0.01 * torch.randn((1, f - 1, h, w, 2), device=device, generator=g),
+        flow_field(),
+        flow_field(),
         torch.rand((1, f - 1, h, w), device=device, generator=g),
         torch.rand((1, f - 1, h, w), device=device, generator=g),
     )
@@ -127,7 +136,7 @@ def main():
 
     f, h, w = args.frames, args.height, args.width
     flowmap_amd.set_lazy_surfaces(True)
-    depth, wlogit, flows = make_inputs(f, h, w, device, seed=1 + rank)
+    depth, wlogit, flows = make_inputs(f, h, w, device, seed=1 + rank, smooth=args.smooth_flows)
     cfg = ModelCfg(
         BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
         IntrinsicsRegressedCfg("regressed", 0.85),

@@ -31,10 +31,10 @@ class Loss(nn.Module, ABC, Generic[T]):
         self.cfg = cfg
 
     def forward(self, batch, flows, tracks: Optional[list], model_output, global_step: int) -> Tensor:
-        # Before the loss is enabled, don't compute the loss (loss.py:39-41).
-        if global_step < self.cfg.enable_after:
-            return torch.tensor(0, dtype=torch.float32, device=batch.videos.device)
-        return self.compute_weighted_loss(batch, flows, tracks, model_output, global_step, self.cfg.weight)
+        enabled = global_step >= self.cfg.enable_after  # loss.py:39-41: a constant 0 until then
+        if enabled:
+            return self.compute_weighted_loss(batch, flows, tracks, model_output, global_step, self.cfg.weight)
+        return torch.zeros((), dtype=torch.float32, device=batch.videos.device)
 
     def compute_weighted_loss(self, batch, flows, tracks, model_output, global_step: int, weight: float) -> Tensor:
         """weight × compute_unweighted_loss (loss.py:43-47).  Fused subclasses fold the

@@ -68,26 +68,17 @@ class LossTracking(Loss[LossTrackingCfg]):
         if len(tracks) == 0:
             return torch.zeros((), dtype=torch.float32, device=batch.videos.device)
 
-        _, _, _, h, w = batch.videos.shape
-
-        loss_sum = 0
-        valid_sum = 0
-
-        for segment_tracks in tracks:
-            _, f, _, _ = segment_tracks.xy.shape
-            s = segment_tracks.start_frame
-
-            xy_target, visibility = compute_track_flow(
-                model_output.surfaces[:, s : s + f],
-                model_output.extrinsics[:, s : s + f],
-                model_output.intrinsics[:, s : s + f],
-                segment_tracks,
+        image_shape = tuple(batch.videos.shape[-2:])
+        numerators, counts = [], []
+        for segment in tracks:
+            # the frames this segment's tracks live on (loss_tracking.py:44-52)
+            window = slice(segment.start_frame, segment.start_frame + segment.xy.shape[1])
+            predicted, visible = compute_track_flow(
+                model_output.surfaces[:, window], model_output.extrinsics[:, window], model_output.intrinsics[:, window], segment
             )
-            xy_target_gt = segment_tracks.xy[:, None]  # "b ft p xy -> b () ft p xy"
-
-            loss = self.mapping.forward(xy_target, xy_target_gt, (h, w)) * visibility
-
-            loss_sum = loss_sum + loss.sum()
-            valid_sum = valid_sum + visibility.sum()
-
-        return loss_sum / or_one(valid_sum)
+            # every source frame is compared with the track position in every target frame
+            residual = self.mapping.forward(predicted, segment.xy[:, None], image_shape)
+            numerators.append((residual * visible).sum())
+            counts.append(visible.sum())
+        # ONE ratio over all segments (loss_tracking.py:58-61), `or 1` evaluated on the device
+        return torch.stack(numerators).sum() / or_one(torch.stack(counts).sum())

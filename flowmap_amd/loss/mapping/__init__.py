@@ -1,18 +1,30 @@
-"""Drop-in for flowmap/loss/mapping/__init__.py:1-16."""
+"""Robust residual mappings — counterpart of the reference package flowmap/loss/mapping
+(registry at flowmap/loss/mapping/__init__.py:6-16)."""
 
-from .mapping import Mapping, fix_aspect_ratio
-from .mapping_huber import MappingHuber, MappingHuberCfg
-from .mapping_l1 import MappingL1, MappingL1Cfg
-from .mapping_l2 import MappingL2, MappingL2Cfg
+from typing import Union
 
-MAPPINGS = {
-    "huber": MappingHuber,
-    "l1": MappingL1,
-    "l2": MappingL2,
-}
+from .mapping import (
+    Mapping,
+    MappingHuber,
+    MappingHuberCfg,
+    MappingL1,
+    MappingL1Cfg,
+    MappingL2,
+    MappingL2Cfg,
+    fix_aspect_ratio,
+)
 
-MappingCfg = MappingHuberCfg | MappingL1Cfg | MappingL2Cfg
+# cfg.name -> class; every class carries the name of the kernel variant it selects
+MAPPINGS = {cls.kind: cls for cls in (MappingHuber, MappingL1, MappingL2)}
+MappingCfg = Union[MappingHuberCfg, MappingL1Cfg, MappingL2Cfg]
 
 
-def get_mapping(cfg: MappingCfg) -> Mapping:
+def get_mapping(cfg) -> Mapping:
+    """Instantiate the mapping a config names (raises KeyError on an unknown name)."""
     return MAPPINGS[cfg.name](cfg)
+
+
+__all__ = [
+    "MAPPINGS", "Mapping", "MappingCfg", "MappingHuber", "MappingHuberCfg", "MappingL1", "MappingL1Cfg", "MappingL2", "MappingL2Cfg",
+    "fix_aspect_ratio", "get_mapping",
+]

@@ -58,3 +58,48 @@ class Mapping(nn.Module, ABC, Generic[T]):
         flat = delta.reshape(-1, 2)
         out = _ops.RobustMapping.apply(flat, torch.zeros_like(flat), _ops.MAPPING_KINDS[self.kind], self.delta, 1.0, 1.0)
         return out.reshape(delta.shape[:-1])
+
+
+# --------------------------------------------------------------------------------------
+# The three robust kernels.  In the reference each lives in its own module
+# (mapping_huber.py:18-34, mapping_l1.py:15-20, mapping_l2.py:15-21) and overrides
+# ``forward_undistorted`` with torch ops; here a subclass only selects the ``kind`` the
+# fused HIP kernel is instantiated for, so they fit in one place.
+# --------------------------------------------------------------------------------------
+from dataclasses import dataclass  # noqa: E402
+from typing import Literal  # noqa: E402
+
+
+@dataclass
+class MappingHuberCfg:
+    name: Literal["huber"]
+    delta: float  # knee of the Huber function, in aspect-corrected normalised units
+
+
+@dataclass
+class MappingL1Cfg:
+    name: Literal["l1"]
+
+
+@dataclass
+class MappingL2Cfg:
+    name: Literal["l2"]
+
+
+class MappingHuber(Mapping[MappingHuberCfg]):
+    """huber_loss(‖r‖, 0, delta) / delta: quadratic below the knee, ‖r‖ − delta/2 above, so the
+    gradient magnitude in the linear region equals L1's."""
+
+    kind = "huber"
+
+
+class MappingL1(Mapping[MappingL1Cfg]):
+    """‖r‖₂ (sub-gradient 0 at r = 0)."""
+
+    kind = "l1"
+
+
+class MappingL2(Mapping[MappingL2Cfg]):
+    """½‖r‖² (the ½ matches huber's quadratic branch)."""
+
+    kind = "l2"
