@@ -84,6 +84,25 @@ def make_inputs(f, h, w, device, seed, smooth=False):
     return depth, wlogit, flows
 
 
+def make_tracks(f, device, seed, interval=5, radius=20, grid=35):
+    """Synthetic track segments laid out as generate_video_tracks does
+    (flowmap/tracking/__init__.py:49-70): one segment around every `interval`-th frame,
+    +-radius frames, grid x grid query points drifting as a random walk; ~90 % visible."""
+    from flowmap_amd import Tracks
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    lin = (torch.arange(grid, device=device, dtype=torch.float32) + 0.5) / grid
+    query = torch.stack(torch.meshgrid(lin, lin, indexing="xy"), dim=-1).reshape(-1, 2)
+    out = []
+    for mid in range(0, f, interval):
+        start, end = max(0, mid - radius), min(f, mid + radius + 1)
+        drift = (0.003 * torch.randn((end - start, query.shape[0], 2), device=device, generator=g)).cumsum(0)
+        xy = query[None] + drift - drift[mid - start]
+        vis = (xy >= 0).all(-1) & (xy < 1).all(-1) & (torch.rand(xy.shape[:2], device=device, generator=g) < 0.9)
+        out.append(Tracks(xy[None].contiguous(), vis[None].contiguous(), start))
+    return out
+
+
 def cpu_baseline(frames, h, w, points, iters, threads):
     """The oracle (PyTorch CPU port of the reference path) on a bounded sample: same
     frame size, fewer frames; forward + backward, all host cores."""
@@ -115,7 +134,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("FLOWMAP_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one GPU
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -151,13 +170,14 @@ def main():
         loss_fn.items_per_thread = args.items_per_thread
     tracks, track_fn = None, None
     if args.tracking:
-        from flowmap_amd import Tracks
         from flowmap_amd.loss import LossTracking, LossTrackingCfg
-        from oracle import flowmap_oracle as orc  # input generator only (i.i.d. track layout of tracking/__init__.py:49-70)
 
-        tracks = [Tracks(t.xy.to(device), t.visibility.to(device), t.start_frame) for t in orc.synth_tracks(f, h, w, scene=None, seed=rank)]
+        tracks = make_tracks(f, device, seed=100 + rank)
         track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
-    shard = FrameShard(rank, world, dist)
+    shard = FrameShard(rank, world if dist is None else max(world, 1), dist)
+    if dist is not None and world == 1:
+        shard.world = 2  # single-rank RCCL self-test: run the collectives, there are no neighbours
+        shard.exchange_halo = lambda grad: None
     shard.prepare_flow_loss(loss_fn, flows)  # global valid-sum (one-time all-reduce)
 
     kernel_events = []
