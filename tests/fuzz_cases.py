@@ -1,0 +1,47 @@
+"""Randomised step-level parity sweep shared by the CPU (host double) and GPU modules."""
+
+from __future__ import annotations
+
+import random
+
+import torch
+
+from conftest import assert_close
+from helpers import run_oracle, run_ours
+from oracle import flowmap_oracle as orc
+
+
+def configs(seed: int, count: int):
+    rng = random.Random(seed)
+    out = []
+    for i in range(count):
+        f = rng.randint(2, 9)
+        h = rng.choice([5, 8, 12, 17, 24, 31, 40])
+        w = rng.choice([6, 8, 12, 13, 20, 28, 36, 44])
+        p = rng.choice([None, 16, 64, 300]) if h * w >= 64 else None
+        kind = rng.choice(["huber", "huber", "l1", "l2"])
+        tracks = rng.random() < 0.4 and f >= 3
+        lazy = rng.random() < 0.7
+        out.append((i, f, h, w, p, kind, tracks, lazy))
+    return out
+
+
+def run_case(cfg, device):
+    i, f, h, w, p, kind, with_tracks, lazy = cfg
+    sc = orc.synth_scene(f, h, w, seed=100 + i, depth_noise=0.03)
+    g = torch.Generator().manual_seed(i)
+    wl = 0.01 * torch.randn((f - 1, h, w), generator=g)
+    flows = sc["flows"]
+    flows.forward_mask = flows.forward_mask * torch.rand(flows.forward_mask.shape, generator=g)
+    flows.backward_mask = flows.backward_mask * torch.rand(flows.backward_mask.shape, generator=g)
+    tracks = orc.synth_tracks(f, h, w, scene=sc, seed=i, interval=2, radius=2, grid=5) if with_tracks else None
+    if p is not None:
+        p = min(p, h * w)
+    ours = run_ours(sc["depth_init"], wl, 0.8, flows, (h, w), p, tracks, kind, device=device, lazy=lazy)
+    ref = run_oracle(sc["depth_init"], wl, 0.8, flows, (h, w), p, tracks, kind, dtype=torch.float64)
+    tag = f"cfg{cfg}"
+    assert_close(ours["total"], ref["total"], 1e-4, what=f"total {tag}")
+    assert_close(ours["extrinsics"], ref["extrinsics"], 1e-4, what=f"extrinsics {tag}")
+    assert_close(ours["g_depth"], ref["g_depth"], 2e-4, what=f"g_depth {tag}")
+    assert_close(ours["g_wlogit"], ref["g_wlogit"], 5e-4, abs_=1e-7, what=f"g_wlogit {tag}")
+    assert_close(ours["g_focal"], ref["g_focal"], 2e-3, abs_=1e-4 * abs(float(ref["total"])), what=f"g_focal {tag}")
