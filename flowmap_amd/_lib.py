@@ -30,10 +30,10 @@ SIGNATURES = {
     "fm_flow_loss_finalize": [P] * 6 + [I, I, F, F] + [P] * 4 + [P],
     "fm_flow_valid_norm": [P, P, L, F, P, P, P],
     "fm_scale_if_needed": [P, L, P, P],
-    "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, P, P],
+    "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, I, P, P],
     "fm_pose_solve": [P, I, P, P, P, P],
     "fm_pose_solve_bwd": [P, P, P, P, I, P, P],
-    "fm_procrustes_scatter": [P] * 5 + [F, P, L, I, I, I, I] + [P] * 6 + [P],
+    "fm_procrustes_scatter": [P] * 5 + [F, P, L, I, I, I, I, I] + [P] * 6 + [P],
     "fm_pose_chain_fwd": [P, I, I, P, P],
     "fm_pose_chain_bwd": [P, P, P, I, I, P, P],
     "fm_relative_pose_fwd": [P, I, I, P, P, P],

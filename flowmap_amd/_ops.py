@@ -183,25 +183,32 @@ class ProcrustesFit(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, depth, k, surfaces, weights, bwd_flow, indices, weight_sens=0.0):
+    def forward(ctx, depth, k, surfaces, weights, bwd_flow, indices, weight_sens=0.0, batch_repeat=1):
         from_depth = surfaces is None
         check_device(depth if from_depth else surfaces, weights, bwd_flow, indices)
         weights = _f32c(weights, "weights")
         bwd_flow = _f32c(bwd_flow, "backward flow")
         if bwd_flow.requires_grad:
             raise RuntimeError("flowmap_amd: gradients w.r.t. optical flow are not supported (flows are constants)")
+        rep = int(batch_repeat)
         if from_depth:
             depth = _f32c(depth, "depth")
             k = _f32c(k, "intrinsics")
-            b, f, h, w = depth.shape
+            bd, f, h, w = depth.shape
+            b = bd * rep  # pose / intrinsics batch: every image-batch entry serves `rep` candidates
+            if tuple(k.shape) != (b, f, 3, 3):
+                raise RuntimeError("flowmap_amd: intrinsics shape does not match depth (x batch_repeat)")
             kinv = intrinsics_inverse(k)
             dev = depth.device
         else:
+            if rep != 1:
+                raise RuntimeError("flowmap_amd: batch_repeat needs depth-sourced surfaces")
             surfaces = _f32c(surfaces, "surfaces")
-            b, f, h, w, _ = surfaces.shape
+            bd, f, h, w, _ = surfaces.shape
+            b = bd
             kinv = None
             dev = surfaces.device
-        if tuple(weights.shape) != (b, f - 1, h, w) or tuple(bwd_flow.shape) != (b, f - 1, h, w, 2):
+        if tuple(weights.shape) != (bd, f - 1, h, w) or tuple(bwd_flow.shape) != (bd, f - 1, h, w, 2):
             raise RuntimeError("flowmap_amd: weights/backward-flow shapes do not match the surfaces")
         if indices is not None:
             if indices.dtype != torch.int64:
@@ -218,10 +225,10 @@ class ProcrustesFit(torch.autograd.Function):
         with _guard(dev):
             st = stream_for(weights)
             call("fm_procrustes_stats", ptr(depth) if from_depth else None, ptr(kinv), ptr(surfaces), ptr(bwd_flow),
-                 ptr(weights), float(weight_sens), ptr(indices), points, b, f, h, w, ptr(stats), st)
+                 ptr(weights), float(weight_sens), ptr(indices), points, b, rep, f, h, w, ptr(stats), st)
             call("fm_pose_solve", ptr(stats), pairs, ptr(t_bwd), ptr(t_fwd), ptr(aux), st)
         ctx.save_for_backward(depth if from_depth else surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux)
-        ctx.from_depth, ctx.dims, ctx.points, ctx.weight_sens = from_depth, (b, f, h, w), points, float(weight_sens)
+        ctx.from_depth, ctx.dims, ctx.points, ctx.weight_sens, ctx.rep = from_depth, (b, f, h, w), points, float(weight_sens), rep
         # Carried depth gradient: when the fused flow loss consumes poses fitted from the very
         # same depth tensor, it parks its dense dL/ddepth here instead of returning it, and
         # this node (which autograd always runs later) scatters its sparse part into that
@@ -258,14 +265,14 @@ class ProcrustesFit(torch.autograd.Function):
             st = stream_for(weights)
             call("fm_pose_solve_bwd", ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr(aux), pairs, ptr(pair_grad), st)
             call("fm_procrustes_scatter", ptr(src) if ctx.from_depth else None, ptr(kinv), None if ctx.from_depth else ptr(src),
-                 ptr(bwd_flow), ptr(weights), ctx.weight_sens, ptr(indices), ctx.points, b, f, h, w, ptr(aux), ptr(pair_grad),
+                 ptr(bwd_flow), ptr(weights), ctx.weight_sens, ptr(indices), ctx.points, b, ctx.rep, f, h, w, ptr(aux), ptr(pair_grad),
                  ptr(g_src) if ctx.from_depth else None, None if ctx.from_depth else ptr(g_src), ptr(g_w), ptr(kinv_acc), st)
             if need_k:
                 g_k = torch.empty_like(kinv)
                 call("fm_intrinsics_inverse_bwd", ptr(kinv_acc), ptr(kinv), b * f, ptr(g_k), 0, st)
         if ctx.from_depth:
-            return g_src, g_k, None, g_w, None, None, None
-        return None, None, g_src, g_w, None, None, None
+            return g_src, g_k, None, g_w, None, None, None, None
+        return None, None, g_src, g_w, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------

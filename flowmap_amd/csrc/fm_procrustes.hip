@@ -40,7 +40,8 @@ struct ProcParams {
   int frames, height, width;
   long points;
   float weight_sens;       // != 0: `weights` holds logits, w = sigmoid(weight_sens·logit)
-};
+  int batch_repeat;        // R >= 1: depth/surfaces/flows/weights (and their gradients) have B/R batch
+};                         //         entries, shared by R consecutive (kinv, pose) batch entries
 
 enum { SRC_DEPTH = 0, SRC_SURF = 1 };
 
@@ -48,7 +49,9 @@ enum { SRC_DEPTH = 0, SRC_SURF = 1 };
 template <int SRC>
 __device__ __forceinline__ CorrSrc pair_source(const ProcParams& p, size_t pair, int b, int i) {
   const size_t n = (size_t)p.height * p.width;
-  const size_t fe = (size_t)b * p.frames + i, fl = fe + 1;
+  const int bd = b / p.batch_repeat;  // batch entry of the image data
+  const size_t fe = (size_t)bd * p.frames + i, fl = fe + 1;
+  pair = (size_t)bd * (p.frames - 1) + i;
   CorrSrc s;
   s.depth_e = SRC == SRC_DEPTH ? p.depth + fe * n : nullptr;
   s.depth_l = SRC == SRC_DEPTH ? p.depth + fl * n : nullptr;
@@ -162,7 +165,10 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
   }
   g.dbar = (float)pg[15];
   g.inv_wsum = (float)pg[16];
-  const size_t fe = (size_t)b * p.frames + i, fl = fe + 1;
+  const int bd = b / p.batch_repeat;
+  const size_t fe = (size_t)bd * p.frames + i, fl = fe + 1;        // image-data frames
+  const size_t fk = (size_t)b * p.frames + i;                      // (kinv, pose) frame
+  const size_t dpair = (size_t)bd * (p.frames - 1) + i;            // image-data pair
 
   float acc[18];  // [0..8] dKinv later frame, [9..17] dKinv earlier frame
 #pragma unroll
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
     float gq[3], gp[3], gw;
     corr_backward(c, g, gq, gp, gw);
     if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
-    if (p.grad_weights) atomicAdd(p.grad_weights + pair * (size_t)n + c.idx, gw);
+    if (p.grad_weights) atomicAdd(p.grad_weights + dpair * (size_t)n + c.idx, gw);
     if (SRC == SRC_DEPTH) {
       const int row = c.idx / p.width, col = c.idx - row * p.width;
       const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
       ordered[k] = acc[9 + k];
       ordered[9 + k] = acc[k];
     }
-    block_accumulate<18>(ordered, red, p.kinv_acc + fe * 9);
+    block_accumulate<18>(ordered, red, p.kinv_acc + fk * 9);
   }
 }
 
@@ -447,9 +453,10 @@ extern "C" {
 
 int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                         const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
-                        int frames, int height, int width, double* stats, void* stream) {
+                        int batch_repeat, int frames, int height, int width, double* stats, void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
   FM_CHECK_ARG(bwd_flow && weights && stats && points >= 1 && batch >= 1 && frames >= 2);
+  FM_CHECK_ARG(batch_repeat >= 1 && batch % batch_repeat == 0);
   FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
   hipStream_t st = (hipStream_t)stream;
   const int pairs = batch * (frames - 1);
@@ -458,6 +465,7 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
   p.depth = depth; p.kinv = kinv; p.surfaces = surfaces; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
   p.stats = stats; p.frames = frames; p.height = height; p.width = width; p.points = points;
   p.weight_sens = weight_sensitivity;
+  p.batch_repeat = batch_repeat;
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
   if (surfaces) {
@@ -486,10 +494,11 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
 
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
-                          int frames, int height, int width, const double* aux, const double* pair_grad, float* grad_depth,
-                          float* grad_surfaces, float* grad_weights, double* kinv_acc, void* stream) {
+                          int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,
+                          float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
   FM_CHECK_ARG(bwd_flow && weights && aux && pair_grad && points >= 1);
+  FM_CHECK_ARG(batch_repeat >= 1 && batch % batch_repeat == 0);
   hipStream_t st = (hipStream_t)stream;
   const int pairs = batch * (frames - 1);
   ProcParams p{};
@@ -497,6 +506,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
   p.pair_grad = pair_grad; p.grad_depth = grad_depth; p.grad_surfaces = grad_surfaces; p.grad_weights = grad_weights;
   p.kinv_acc = kinv_acc; p.frames = frames; p.height = height; p.width = width; p.points = points;
   p.weight_sens = weight_sensitivity;
+  p.batch_repeat = batch_repeat;
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
   if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);

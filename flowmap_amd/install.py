@@ -33,9 +33,11 @@ def _set(obj, name, value):
     setattr(obj, name, value)
 
 
-def install(lazy_surfaces: bool = True) -> None:
+def install(lazy_surfaces: bool = True, fused_softmin: bool = True) -> None:
     """Patch the reference in place.  ``lazy_surfaces=True`` additionally lets
-    ``Model.forward``'s ``unproject`` hand a LazySurfaces to the fused consumers."""
+    ``Model.forward``'s ``unproject`` hand a LazySurfaces to the fused consumers;
+    ``fused_softmin=True`` registers the fused candidate sweep as INTRINSICS["softmin"]
+    (flowmap/model/intrinsics/__init__.py:6-10)."""
     from . import loss as our_loss
     from .loss import mapping as our_mapping
     from .model import procrustes as our_procrustes
@@ -79,6 +81,11 @@ def install(lazy_surfaces: bool = True) -> None:
     _set(ref_loss, "LOSSES", {**ref_loss.LOSSES, "flow": our_loss.LossFlow, "tracking": our_loss.LossTracking})
     _set(ref_mapping, "MAPPINGS", {**ref_mapping.MAPPINGS, **our_mapping.MAPPINGS})
     _set(ref_extr, "EXTRINSICS", {**ref_extr.EXTRINSICS, "procrustes": ExtrinsicsProcrustes})
+    if fused_softmin:
+        from .model.intrinsics_softmin import IntrinsicsSoftmin
+
+        ref_intr = importlib.import_module("flowmap.model.intrinsics")
+        _set(ref_intr, "INTRINSICS", {**ref_intr.INTRINSICS, "softmin": IntrinsicsSoftmin})
 
     our_projection.set_lazy_surfaces(lazy_surfaces)
 

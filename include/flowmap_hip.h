@@ -85,10 +85,14 @@ int fm_scale_if_needed(float* x, long count, const float* scalar, void* stream);
  * are LOGITS and w = sigmoid(s·logit) is applied at the gathered points only
  * (BackboneExplicitDepth, backbone_explicit_depth.py:38-41), grad_weights then being
  * the gradient w.r.t. the logits.
+ * batch_repeat R >= 1: kinv and the fitted poses have `batch` entries while depth /
+ * surfaces / bwd_flow / weights (and their gradients) have batch/R entries, each shared by
+ * R consecutive pose-batch entries — the candidate sweep of IntrinsicsSoftmin
+ * (intrinsics_softmin.py:92-103 repeats the images 60x; here they are read in place).
  */
 int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                         const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
-                        int frames, int height, int width, double* stats, void* stream);
+                        int batch_repeat, int frames, int height, int width, double* stats, void* stream);
 
 /* procrustes.py:35-51: R = U·diag(1,1,±1)·Vᵀ by in-register 3×3 SVD, t = q̄ − R·p̄.
  * t_bwd (pairs,4,4) = [R|t] ("inverse relative transformation", later -> earlier
@@ -107,8 +111,8 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
  * dL/dK⁻¹ accumulators (caller zeroes), depth source only.  Any output may be NULL. */
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
-                          int frames, int height, int width, const double* aux, const double* pair_grad, float* grad_depth,
-                          float* grad_surfaces, float* grad_weights, double* kinv_acc, void* stream);
+                          int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,
+                          float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, void* stream);
 
 /* get_extrinsics (projection.py:187-210): ext (B,steps+1,4,4), ext[0]=I,
  * ext[k] = ext[k-1]·rel[k-1]; and its backward (replaces the Python loop of matmuls). */

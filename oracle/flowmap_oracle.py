@@ -508,3 +508,32 @@ def ate(gt_positions: Tensor, predicted_positions: Tensor) -> float:
 
     a, b, _ = spatial.procrustes(gt_positions.detach().cpu().double().numpy(), predicted_positions.detach().cpu().double().numpy())
     return float(((torch.tensor(a, dtype=torch.float32) - torch.tensor(b, dtype=torch.float32)) ** 2).mean() ** 0.5)
+
+
+# --------------------------------------------------------------------------------------
+# IntrinsicsSoftmin candidate sweep (flowmap/model/intrinsics/intrinsics_softmin.py:85-131)
+# --------------------------------------------------------------------------------------
+
+
+def softmin_intrinsics(depths: Tensor, weights: Tensor, bwd_flow: Tensor, candidates: Tensor, indices: Tensor, hw) -> Tensor:
+    """depths (b,>=2,H,W), weights (b,>=1,H,W), bwd_flow (b,>=1,H,W,2), focal candidates
+    (n), indices (P) -> softmin-blended intrinsics (b,3,3).  Every candidate aligns frames
+    0/1 by Procrustes on the sampled points and is scored by the weighted L1 error of the
+    pose-induced backward flow (:92-121); softmin with temperature 10 (:123-127)."""
+    b = depths.shape[0]
+    n = candidates.shape[0]
+    h, w = hw
+    k = focal_to_k(candidates.to(depths.dtype), hw)  # (n,3,3)
+    xy, _ = pixel_grid(hw, depths.device, depths.dtype)
+    rep = lambda t: t[:, None].expand(b, n, *t.shape[1:]).reshape(b * n, *t.shape[1:])  # noqa: E731
+    surfaces = lift(xy, rep(depths[:, :2]), k[None, :, None, None, None].expand(b, n, 2, 1, 1, 3, 3).reshape(b * n, 2, 1, 1, 3, 3))
+    e = fit_poses(surfaces, rep(bwd_flow[:, :1]), rep(weights[:, :1]), indices)
+    pts = surfaces.reshape(b * n, 2, h * w, 3)[:, :, indices]
+    kk = k[None, :, None].expand(b, n, 2, 3, 3).reshape(b * n, 2, 3, 3)
+    back = backward_flow_positions(pts, e, kk).reshape(b, n, -1, 2)
+    flow = back - xy.reshape(h * w, 2)[indices]
+    flow_gt = bwd_flow[:, :1].reshape(b, 1, h * w, 2)[:, :, indices]
+    wts = weights[:, :1].reshape(b, 1, h * w, 1)[:, :, indices]
+    err = ((flow - flow_gt) * wts).abs().sum(dim=(2, 3))
+    soft = tnf.softmin((err - err.min(dim=1, keepdim=True).values) * 10, dim=1)
+    return (k[None] * soft[:, :, None, None]).sum(dim=1)

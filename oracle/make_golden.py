@@ -347,7 +347,37 @@ def gold_functions():
     save("fn_mapping", a=a, b=bb, image_shape=np.array([9, 16]), **m)
 
 
+def gold_softmin():
+    """IntrinsicsSoftmin.forward (intrinsics_softmin.py:63-141) with its internal
+    torch.randperm replaced by a recorded permutation."""
+    print("softmin fixture")
+    from flowmap.model.backbone.backbone import BackboneOutput
+    from flowmap.model.intrinsics import intrinsics_softmin as ism
+
+    f, h, w = 3, 14, 18
+    depth, wlogit, fl = orc.synth_iid(f, h, w, seed=31)
+    g = torch.Generator().manual_seed(31)
+    perm = torch.randperm(h * w, generator=g)
+    cfg = ism.IntrinsicsSoftminCfg("softmin", 96, 0.5, 2.0, 16, None)
+    d = depth[None].clone().requires_grad_(True)
+    wt = (100 * wlogit).sigmoid()[None].clone().requires_grad_(True)
+    batch = Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["s"], ["d"])
+    flows = Flows(fl.forward, fl.backward, fl.forward_mask, fl.backward_mask)
+    real_randperm = torch.randperm
+    torch.randperm = lambda *a, **k: perm.clone()
+    try:
+        module = ism.IntrinsicsSoftmin(cfg)
+        k = module.forward(batch, flows, BackboneOutput(d, wt), 0)
+    finally:
+        torch.randperm = real_randperm
+    cot = torch.arange(9.0).reshape(3, 3) / 9
+    (k[0, 0] * cot).sum().backward()
+    save("fn_softmin", depth=depth, weights=wt, bwd=fl.backward, indices=perm[:96], candidates=module.focal_length_candidates,
+         cot=cot, intrinsics=k[0, 0], g_depth=d.grad, g_weights=wt.grad)
+
+
 if __name__ == "__main__":
     gold_steps()
     gold_functions()
+    gold_softmin()
     print("done")

@@ -214,3 +214,38 @@ def case_loss_gating_and_empty_tracks(dev):
             assert float(fn(batch, flows, [], out, 60)) == 0.0
         finally:
             fm.set_lazy_surfaces(False)
+
+
+def case_softmin_intrinsics(dev, lazy_weights):
+    """The fused IntrinsicsSoftmin candidate sweep against the reference's golden output
+    (its torch.randperm replaced by the recorded indices)."""
+    from flowmap_amd import Batch, BackboneOutput, Flows
+    from flowmap_amd.model.intrinsics_softmin import IntrinsicsSoftmin, IntrinsicsSoftminCfg
+
+    g = load_golden("fn_softmin")
+    depth = t(g["depth"])[None].to(dev).requires_grad_(True)
+    f, h, w = depth.shape[1:]
+    idx = t(g["indices"]).to(dev)
+    module = IntrinsicsSoftmin(IntrinsicsSoftminCfg("softmin", idx.numel(), 0.5, 2.0, int(g["candidates"].shape[0]), None)).to(dev)
+    assert torch.allclose(module.focal_length_candidates.cpu(), t(g["candidates"]))
+    module._draw_indices = lambda count, device: idx
+    weights_ref = t(g["weights"])
+    if lazy_weights:
+        logits = (torch.logit(weights_ref.double()) / 100).float().to(dev).requires_grad_(True)
+        weights = fm.LazyWeights(logits, 100.0)
+    else:
+        logits = None
+        weights = weights_ref.to(dev).requires_grad_(True)
+    bwd = t(g["bwd"]).to(dev)
+    flows = Flows(bwd, bwd, torch.ones(bwd.shape[:-1], device=dev), torch.ones(bwd.shape[:-1], device=dev))
+    k = module(Batch(torch.zeros((1, f, 3, h, w), device=dev)), flows, BackboneOutput(depth, weights), 0)
+    assert k.shape == (1, f, 3, 3)
+    (k[0, 0] * t(g["cot"]).to(dev)).sum().backward()
+    tol = 2e-3 if lazy_weights else 5e-4  # the logit round trip costs a few ulps of the weights
+    assert_close(k[0, 0], g["intrinsics"], 1e-4, what="intrinsics")
+    assert_close(depth.grad[0], g["g_depth"][0], tol, abs_=1e-7, what="g_depth")
+    if lazy_weights:
+        sig = weights_ref
+        assert_close(logits.grad, t(g["g_weights"]) * 100 * sig * (1 - sig), tol, abs_=1e-7, what="g_logits")
+    else:
+        assert_close(weights.grad, g["g_weights"], tol, abs_=1e-7, what="g_weights")

@@ -120,9 +120,11 @@ int fm_scale_if_needed(float* x, long count, const float* scalar, void*) {
 }
 
 static CorrSrc make_src(const float* depth, const float* surfaces, const float* bwd_flow, const float* weights, float sens,
-                        size_t pair, int b, int i, int frames, int height, int width) {
+                        size_t pair, int b, int i, int frames, int height, int width, int repeat) {
   const size_t n = (size_t)height * width;
-  const size_t fe = (size_t)b * frames + i, fl = fe + 1;
+  const int bd = b / repeat;
+  const size_t fe = (size_t)bd * frames + i, fl = fe + 1;
+  pair = (size_t)bd * (frames - 1) + i;
   CorrSrc s;
   s.depth_e = surfaces ? nullptr : depth + fe * n;
   s.depth_l = surfaces ? nullptr : depth + fl * n;
@@ -137,8 +139,8 @@ static CorrSrc make_src(const float* depth, const float* surfaces, const float* 
 }
 
 int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
-                        const float* weights, float sens, const int64_t* indices, long points, int batch, int frames, int height,
-                        int width, double* stats, void*) {
+                        const float* weights, float sens, const int64_t* indices, long points, int batch, int repeat, int frames,
+                        int height, int width, double* stats, void*) {
   const int pairs = batch * (frames - 1);
   std::memset(stats, 0, sizeof(double) * (size_t)pairs * kStatStride);
   for (int pr = 0; pr < pairs; ++pr) {
@@ -148,7 +150,7 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
       load_mat3(kinv + ((size_t)b * frames + i) * 9, ke);
       load_mat3(kinv + ((size_t)b * frames + i + 1) * 9, kl);
     }
-    const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, sens, pr, b, i, frames, height, width);
+    const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, sens, pr, b, i, frames, height, width, repeat);
     double* st = stats + (size_t)pr * kStatStride;
     for (long j = 0; j < points; ++j) {
       const Corr c = corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j);
@@ -191,8 +193,8 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
 }
 
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
-                          const float* weights, float sens, const int64_t* indices, long points, int batch, int frames, int height,
-                          int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
+                          const float* weights, float sens, const int64_t* indices, long points, int batch, int repeat, int frames,
+                          int height, int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
                           float* grad_weights, double* kinv_acc, void*) {
   const int pairs = batch * (frames - 1);
   const size_t n = (size_t)height * width;
@@ -203,7 +205,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
       load_mat3(kinv + ((size_t)b * frames + i) * 9, ke);
       load_mat3(kinv + ((size_t)b * frames + i + 1) * 9, kl);
     }
-    const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, sens, pr, b, i, frames, height, width);
+    const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, sens, pr, b, i, frames, height, width, repeat);
     const double* pg = pair_grad + (size_t)pr * kPairGradStride;
     const double* ax = aux + (size_t)pr * kAuxStride;
     PairGrad g;
@@ -216,13 +218,15 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
     }
     g.dbar = (float)pg[15];
     g.inv_wsum = (float)pg[16];
-    const size_t fe = (size_t)b * frames + i, fl = fe + 1;
+    const int bd = b / repeat;
+    const size_t fe = (size_t)bd * frames + i, fl = fe + 1;
+    const size_t fk = (size_t)b * frames + i, dpair = (size_t)bd * (frames - 1) + i;
     for (long j = 0; j < points; ++j) {
       const Corr c = corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j);
       float gq[3], gp[3], gw;
       corr_backward(c, g, gq, gp, gw);
       if (sens != 0.f) gw *= sens * c.w * (1.f - c.w);
-      if (grad_weights) grad_weights[(size_t)pr * n + c.idx] += gw;
+      if (grad_weights) grad_weights[dpair * n + c.idx] += gw;
       if (!surfaces) {
         const int row = c.idx / width, col = c.idx - row * width;
         const float u = pixel_center(col, width), v = pixel_center(row, height);
@@ -230,7 +234,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
         const float zh[3] = {c.z_p * u, c.z_p * v, c.z_p};
         if (kinv_acc)
           for (int a = 0; a < 3; ++a)
-            for (int d = 0; d < 3; ++d) kinv_acc[fl * 9 + a * 3 + d] += gp[a] * zh[d];
+            for (int d = 0; d < 3; ++d) kinv_acc[(fk + 1) * 9 + a * 3 + d] += gp[a] * zh[d];
         for (int k = 0; k < 4; ++k) {
           if (!c.taps.in[k]) continue;
           const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
@@ -243,7 +247,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
           const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
           if (kinv_acc)
             for (int a = 0; a < 3; ++a)
-              for (int d = 0; d < 3; ++d) kinv_acc[fe * 9 + a * 3 + d] += gq[a] * zt[d];
+              for (int d = 0; d < 3; ++d) kinv_acc[fk * 9 + a * 3 + d] += gq[a] * zt[d];
         }
       } else if (grad_surfaces) {
         float* gl = grad_surfaces + (fl * n + c.idx) * 3;

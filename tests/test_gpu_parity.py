@@ -229,3 +229,8 @@ def test_fn_flow_loss_batched(lazy):
 
 def test_fn_loss_gating_and_empty_tracks():
     cases.case_loss_gating_and_empty_tracks(DEV)
+
+
+@pytest.mark.parametrize("lazy_weights", [False, True])
+def test_fn_softmin_intrinsics(lazy_weights):
+    cases.case_softmin_intrinsics(DEV, lazy_weights)

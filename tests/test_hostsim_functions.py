@@ -57,3 +57,8 @@ def test_flow_loss_batched(lazy):
 
 def test_loss_gating_and_empty_tracks():
     cases.case_loss_gating_and_empty_tracks("cpu")
+
+
+@pytest.mark.parametrize("lazy_weights", [False, True])
+def test_softmin_intrinsics(lazy_weights):
+    cases.case_softmin_intrinsics("cpu", lazy_weights)

@@ -125,15 +125,45 @@ def test_reference_softmin_intrinsics_under_install():
 
         k_ref, gd_ref, gw_ref = run()
         _lib.set_library_for_testing(build_host_sim())
-        flowmap_amd.install()
+        flowmap_amd.install(fused_softmin=False)  # the reference's class on our function-level kernels
         try:
             k_ours, gd_ours, gw_ours = run()
         finally:
             flowmap_amd.uninstall()
-            _lib.set_library_for_testing(None)
         assert_close(k_ours, k_ref, 1e-4, what="softmin intrinsics")
         assert_close(gd_ours, gd_ref, 2e-3, abs_=1e-6, what="g_depth")
         assert_close(gw_ours, gw_ref, 2e-3, abs_=1e-6, what="g_weights")
+
+        # the fused candidate sweep registered by install(): same numbers, no 60x repeats
+        import flowmap.model.intrinsics as ref_intr
+
+        flowmap_amd.install()
+        try:
+            fused_cls = ref_intr.INTRINSICS["softmin"]
+            assert fused_cls.__module__.startswith("flowmap_amd")
+
+            def run_fused(lazy_weights):
+                d = depth[None].clone().requires_grad_(True)
+                logits = wlogit[None].clone().requires_grad_(True)
+                if lazy_weights:
+                    wt = flowmap_amd.model.projection.LazyWeights(logits, 100.0)
+                else:
+                    wt = (100 * logits).sigmoid()
+                torch.manual_seed(0)
+                k = fused_cls(cfg).forward(batch, flows, BackboneOutput(d, wt), 0)
+                (k * torch.arange(9.0).reshape(3, 3)).sum().backward()
+                return k.detach(), d.grad, logits.grad
+
+            sig = (100 * wlogit).sigmoid()[None]
+            gl_ref = gw_ref * 100 * sig * (1 - sig)  # chain rule through the backbone's sigmoid
+            for lazy_weights in (False, True):
+                k_f, gd_f, gl_f = run_fused(lazy_weights)
+                assert_close(k_f, k_ref, 1e-4, what="fused softmin intrinsics")
+                assert_close(gd_f, gd_ref, 2e-3, abs_=1e-6, what="fused g_depth")
+                assert_close(gl_f, gl_ref, 2e-3, abs_=1e-6, what="fused g_logits")
+        finally:
+            flowmap_amd.uninstall()
+            _lib.set_library_for_testing(None)
     finally:
         for p in added:
             sys.path.remove(p)

@@ -175,3 +175,15 @@ def test_mappings(kind):
     assert_close(val, g[f"{kind}_val"], 1e-6)
     assert_close(a.grad, g[f"{kind}_g_a"], 1e-6)
     assert torch.isfinite(a.grad).all()
+
+
+def test_softmin_intrinsics():
+    g = load_golden("fn_softmin")
+    d = t(g["depth"])[None].requires_grad_(True)
+    w = t(g["weights"]).requires_grad_(True)
+    h, wd = d.shape[2:]
+    k = orc.softmin_intrinsics(d, w, t(g["bwd"]), t(g["candidates"]), t(g["indices"]), (h, wd))
+    (k[0] * t(g["cot"])).sum().backward()
+    assert_close(k[0], g["intrinsics"], TOL, what="intrinsics")
+    assert_close(d.grad[0], g["g_depth"][0], 5e-4, abs_=1e-7, what="g_depth")
+    assert_close(w.grad, g["g_weights"], 5e-4, abs_=1e-7, what="g_weights")

@@ -23,7 +23,7 @@ t_bwd = torch.empty((1, pairs, 4, 4), device=dev)
 aux = torch.empty((pairs, 32), dtype=torch.float64, device=dev)
 pg = torch.empty((pairs, 20), dtype=torch.float64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-call("fm_procrustes_stats", ptr(depth), ptr(kinv), None, ptr(fb), ptr(wl), 100.0, ptr(idx), P, 1, f, h, w, ptr(stats), st)
+call("fm_procrustes_stats", ptr(depth), ptr(kinv), None, ptr(fb), ptr(wl), 100.0, ptr(idx), P, 1, 1, f, h, w, ptr(stats), st)
 call("fm_pose_solve", ptr(stats), pairs, ptr(t_bwd), None, ptr(aux), st)
 g_t = torch.randn((1, pairs, 4, 4), device=dev, generator=g)
 call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t_bwd), ptr(aux), pairs, ptr(pg), st)
@@ -37,7 +37,7 @@ def run(name, a, b, c, reps=20):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(reps):
-        call("fm_procrustes_scatter", ptr(depth), ptr(kinv), None, ptr(fb), ptr(wl), 100.0, ptr(idx), P, 1, f, h, w, ptr(aux), ptr(pg),
+        call("fm_procrustes_scatter", ptr(depth), ptr(kinv), None, ptr(fb), ptr(wl), 100.0, ptr(idx), P, 1, 1, f, h, w, ptr(aux), ptr(pg),
              ptr(a), None, ptr(b), ptr(c), st)
     e.record()
     torch.cuda.synchronize()
@@ -53,6 +53,6 @@ for _ in range(2):
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for _ in range(20):
-    call("fm_procrustes_stats", ptr(depth), ptr(kinv), None, ptr(fb), ptr(wl), 100.0, ptr(idx), P, 1, f, h, w, ptr(stats), st)
+    call("fm_procrustes_stats", ptr(depth), ptr(kinv), None, ptr(fb), ptr(wl), 100.0, ptr(idx), P, 1, 1, f, h, w, ptr(stats), st)
 e.record(); torch.cuda.synchronize()
 print("stats (2 passes + memset)", s.elapsed_time(e) / 20 * 1e3, "us")
