@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--items-per-thread", type=int, default=0)
     ap.add_argument("--smooth-flows", action="store_true",
                     help="spatially smooth synthetic flows (low-res noise upsampled) instead of i.i.d. per-pixel noise")
+    ap.add_argument("--intrinsics", choices=["regressed", "softmin"], default="regressed",
+                    help="softmin = the reference's default first-1000-steps intrinsics (60-candidate sweep, 8192 points)")
     ap.add_argument("--tracking", action="store_true",
                     help="BASELINE.json configs[2]: add the tracking loss (segments every 5 frames, +-20 frames, 35x35 tracks)")
     return ap.parse_args()
@@ -156,9 +158,15 @@ def main():
     f, h, w = args.frames, args.height, args.width
     flowmap_amd.set_lazy_surfaces(True)
     depth, wlogit, flows = make_inputs(f, h, w, device, seed=1 + rank, smooth=args.smooth_flows)
+    if args.intrinsics == "softmin":
+        from flowmap_amd.model.intrinsics_softmin import IntrinsicsSoftminCfg, RegressionCfg
+
+        intrinsics_cfg = IntrinsicsSoftminCfg("softmin", 8192, 0.5, 2.0, 60, RegressionCfg(1000, 100))
+    else:
+        intrinsics_cfg = IntrinsicsRegressedCfg("regressed", 0.85)
     cfg = ModelCfg(
         BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
-        IntrinsicsRegressedCfg("regressed", 0.85),
+        intrinsics_cfg,
         ExtrinsicsProcrustesCfg("procrustes", args.points if args.points > 0 else None, False),
     )
     model = Model(cfg, num_frames=f, image_shape=(h, w)).to(device)
@@ -190,7 +198,7 @@ def main():
         if track_fn is not None:
             loss = loss + track_fn(batch, flows, tracks, out, 0)
         loss.backward()
-        shard.sync(loss, model.intrinsics.focal_length, model.backbone.depth)
+        shard.sync(loss, getattr(model.intrinsics, "focal_length", None), model.backbone.depth)
         return loss
 
     if dist is not None:  # create the RCCL communicators / P2P channels outside the timed region
@@ -244,7 +252,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE.json configs[1]: {f} frames @ {h}x{w}, flow loss only (huber 0.01, weight 1000), "
-                f"explicit-depth backbone, regressed intrinsics, Procrustes P={args.points}; fwd+bwd, no optimiser"
+                f"explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points}; fwd+bwd, no optimiser"
                 + (f"; + tracking loss (configs[2]): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else ""),
                 "frames_per_gpu": f,
                 "height": h,

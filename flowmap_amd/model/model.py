@@ -88,7 +88,7 @@ class ModelCfg:
     """flowmap/model/model.py:16-21"""
 
     backbone: BackboneExplicitDepthCfg
-    intrinsics: IntrinsicsRegressedCfg
+    intrinsics: "IntrinsicsRegressedCfg | IntrinsicsSoftminCfg"
     extrinsics: ExtrinsicsProcrustesCfg
     use_correspondence_weights: bool = True
 
@@ -100,7 +100,12 @@ class Model(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.backbone = BackboneExplicitDepth(cfg.backbone, num_frames, image_shape)
-        self.intrinsics = IntrinsicsRegressed(cfg.intrinsics)
+        if cfg.intrinsics.name == "softmin":  # model/intrinsics/__init__.py:16-20 registry, two entries here
+            from .intrinsics_softmin import IntrinsicsSoftmin
+
+            self.intrinsics = IntrinsicsSoftmin(cfg.intrinsics)
+        else:
+            self.intrinsics = IntrinsicsRegressed(cfg.intrinsics)
         self.extrinsics = ExtrinsicsProcrustes(cfg.extrinsics, num_frames)
 
     def forward(self, batch, flows, global_step: int) -> ModelOutput:

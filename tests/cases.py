@@ -249,3 +249,52 @@ def case_softmin_intrinsics(dev, lazy_weights):
         assert_close(logits.grad, t(g["g_weights"]) * 100 * sig * (1 - sig), tol, abs_=1e-7, what="g_logits")
     else:
         assert_close(weights.grad, g["g_weights"], tol, abs_=1e-7, what="g_weights")
+
+
+def case_softmin_step(dev, seed=5):
+    """A whole optimisation step with the softmin intrinsics module in the model
+    (the reference's default for its first 1000 steps) against the fp64 oracle."""
+    from flowmap_amd import Batch
+    from flowmap_amd.loss import LossFlow, LossFlowCfg
+    from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap_amd.model.intrinsics_softmin import IntrinsicsSoftminCfg
+    from flowmap_amd.model.model import BackboneExplicitDepthCfg, Model, ModelCfg
+    from helpers import mapping_cfg, to_flows
+
+    f, h, w, p_soft, p_proc, n = 4, 40, 56, 700, 600, 12
+    sc = orc.synth_scene(f, h, w, seed=seed)
+    depth, oflows = sc["depth_init"], sc["flows"]
+    wlogit = 0.01 * torch.randn((f - 1, h, w), generator=torch.Generator().manual_seed(seed + 1))
+    gen = torch.Generator().manual_seed(seed)
+    idx = torch.randperm(h * w, generator=gen)[:p_soft]
+    fm.set_lazy_surfaces(True)
+    try:
+        cfg = ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
+                       IntrinsicsSoftminCfg("softmin", p_soft, 0.5, 2.0, n, None),
+                       ExtrinsicsProcrustesCfg("procrustes", p_proc, False))
+        model = Model(cfg, num_frames=f, image_shape=(h, w))
+        model.backbone.depth.data = depth.clone()
+        model.backbone.weights.data = wlogit.clone()
+        model = model.to(dev)
+        model.intrinsics._draw_indices = lambda count, device: idx.to(device)
+        batch = Batch(torch.zeros((1, f, 3, h, w), device=dev))
+        out = model(batch, to_flows(oflows, dev), 0)
+        loss = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))(batch, to_flows(oflows, dev), None, out, 0)
+        loss.backward()
+    finally:
+        fm.set_lazy_surfaces(False)
+
+    dt = torch.float64
+    d = depth.to(dt).requires_grad_(True)
+    wl = wlogit.to(dt).requires_grad_(True)
+    fl = orc.OFlows(*(x.to(dt) for x in (oflows.forward, oflows.backward, oflows.forward_mask, oflows.backward_mask)))
+    weights = (100.0 * wl).sigmoid()[None]
+    k = orc.softmin_intrinsics(d[None], weights, fl.backward, torch.linspace(0.5, 2.0, n), idx, (h, w))
+    k = k[:, None].expand(1, f, 3, 3)
+    o = orc.model_forward(d[None], weights, k, fl, orc.procrustes_indices((h, w), p_proc, "cpu"))
+    ref = 1000.0 * orc.flow_loss(o.surfaces, o.extrinsics, k, fl, (h, w), "huber", 0.01)
+    ref.backward()
+    assert_close(out.intrinsics[0, 0], k[0, 0].detach(), 1e-4, what="intrinsics")
+    assert_close(loss, ref.detach(), 2e-4, what="loss")
+    assert_close(model.backbone.depth.grad, d.grad, 2e-3, abs_=1e-6, what="g_depth")
+    assert_close(model.backbone.weights.grad, wl.grad, 2e-3, abs_=1e-6, what="g_wlogit")

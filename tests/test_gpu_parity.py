@@ -234,3 +234,7 @@ def test_fn_loss_gating_and_empty_tracks():
 @pytest.mark.parametrize("lazy_weights", [False, True])
 def test_fn_softmin_intrinsics(lazy_weights):
     cases.case_softmin_intrinsics(DEV, lazy_weights)
+
+
+def test_softmin_whole_step():
+    cases.case_softmin_step(DEV)

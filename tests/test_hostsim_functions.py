@@ -62,3 +62,7 @@ def test_loss_gating_and_empty_tracks():
 @pytest.mark.parametrize("lazy_weights", [False, True])
 def test_softmin_intrinsics(lazy_weights):
     cases.case_softmin_intrinsics("cpu", lazy_weights)
+
+
+def test_softmin_whole_step():
+    cases.case_softmin_step("cpu")
