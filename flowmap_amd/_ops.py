@@ -313,13 +313,48 @@ def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=N
     return norm
 
 
+_mask_cache: dict = {}
+
+# Packed masks are on by default; tests flip this to exercise the fp32-mask kernels as well.
+use_packed_masks = True
+
+
+def packed_flow_masks(mask_fwd: Tensor, mask_bwd: Tensor) -> Optional[Tensor]:
+    """(B,F,ceil(HW/4)) uint8 produced by fm_flow_pack_masks, or None when the masks are not
+    0/1 images.  Like the valid-sum, the masks are constants of an optimisation
+    (flowmap/flow/common.py computes them once per video), so this runs once per Flows object:
+    cached per (storage, version) and validated against the live tensors."""
+    if not use_packed_masks:
+        return None
+    key = (mask_fwd.data_ptr(), mask_bwd.data_ptr(), mask_fwd._version, mask_bwd._version, tuple(mask_fwd.shape), str(mask_fwd.device))
+    hit = _mask_cache.get(key)
+    if hit is not None:
+        bits, ref_f, ref_b = hit
+        if ref_f() is mask_fwd and ref_b() is mask_bwd:
+            return bits
+    if tuple(mask_bwd.shape) != tuple(mask_fwd.shape) or mask_fwd.dim() != 4:
+        return None  # FlowLossFused reports the shape error
+    src_f, src_b = _f32c(mask_fwd, "forward mask"), _f32c(mask_bwd, "backward mask")
+    b, pairs, h, w = mask_fwd.shape
+    bits = torch.empty((b, pairs + 1, (h * w + 3) // 4), dtype=torch.uint8, device=mask_fwd.device)
+    flag = torch.empty((1,), dtype=torch.int32, device=mask_fwd.device)
+    with _guard(mask_fwd.device):
+        call("fm_flow_pack_masks", ptr(src_f), ptr(src_b), b, pairs + 1, h, w, ptr(bits), ptr(flag), stream_for(mask_fwd))
+    if int(flag.item()) != 0:  # one-time host sync per Flows object
+        bits = None
+    if len(_mask_cache) > 16:
+        _mask_cache.clear()
+    _mask_cache[key] = (bits, weakref.ref(mask_fwd), weakref.ref(mask_bwd))
+    return bits
+
+
 class FlowLossFused(torch.autograd.Function):
     """weight · LossFlow.compute_unweighted_loss (flowmap/loss/loss_flow.py:31-70,
     flowmap/loss/loss.py:47) evaluated from depth + intrinsics + relative poses, with the
     analytic gradient of every input produced in the same HBM pass."""
 
     @staticmethod
-    def forward(ctx, depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, kind, delta, carry, items):
+    def forward(ctx, depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, kind, delta, carry, items, bits=None):
         dev = check_device(depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm)
         depth = _f32c(depth, "depth")
         k = _f32c(k, "intrinsics")
@@ -336,6 +371,8 @@ class FlowLossFused(torch.autograd.Function):
             raise RuntimeError("flowmap_amd: intrinsics / pose shapes do not match depth")
         need = any(ctx.needs_input_grad[:4])
         kinv = intrinsics_inverse(k)
+        if bits is not None and (bits.dtype != torch.uint8 or tuple(bits.shape) != (b, f, (h * w + 3) // 4) or not bits.is_contiguous()):
+            raise RuntimeError("flowmap_amd: packed masks do not match the depth shape")
         acc = torch.empty((b * f * 2 * FLOW_ACC_STRIDE,), dtype=torch.float64, device=dev)
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
         g_depth = torch.empty_like(depth) if (need and ctx.needs_input_grad[0]) else None
@@ -353,7 +390,7 @@ class FlowLossFused(torch.autograd.Function):
             if events:
                 events[0].record()
             call("fm_flow_loss_fused", ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd),
-                 ptr(mask_fwd), ptr(mask_bwd), ptr(norm) if need else None, b, f, h, w, kind, float(delta), w / scale, h / scale,
+                 ptr(mask_fwd), ptr(mask_bwd), ptr(bits), ptr(norm) if need else None, b, f, h, w, kind, float(delta), w / scale, h / scale,
                  ptr(g_depth), ptr(acc), int(items), st)
             if events:
                 events[1].record()
@@ -388,7 +425,7 @@ class FlowLossFused(torch.autograd.Function):
             g_depth = None
         need = ctx.needs_input_grad
         return (g_depth if (need[0] and g_depth is not None) else None, g_k if need[1] else None, g_tf if need[2] else None,
-                g_tb if need[3] else None, None, None, None, None, None, None, None, None, None)
+                g_tb if need[3] else None, None, None, None, None, None, None, None, None, None, None)
 
 
 # --------------------------------------------------------------------------------------

@@ -79,9 +79,25 @@ extern "C" {
 
 int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
                        const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
-                       const float* scale, int batch, int frames, int height, int width, int mapping_kind, float delta,
-                       float ax, float ay, float* grad_depth, double* acc, int, void*) {
+                       const uint8_t* mask_bits, const float* scale, int batch, int frames, int height, int width, int mapping_kind,
+                       float delta, float ax, float ay, float* grad_depth, double* acc, int, void*) {
   std::memset(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride);
+  std::vector<float> unpacked_f, unpacked_b;
+  if (mask_bits) {  // expand the packed masks back to the fp32 layout the loop below reads
+    const size_t n = (size_t)height * width, groups = (n + 3) / 4;
+    unpacked_f.assign((size_t)batch * (frames - 1) * n, 0.f);
+    unpacked_b.assign((size_t)batch * (frames - 1) * n, 0.f);
+    for (int b = 0; b < batch; ++b)
+      for (int f = 0; f < frames; ++f)
+        for (size_t i = 0; i < n; ++i) {
+          const unsigned v = mask_bits[((size_t)b * frames + f) * groups + i / 4] >> (i % 4);
+          const size_t pair = (size_t)b * (frames - 1) + f;
+          if (f < frames - 1) unpacked_f[pair * n + i] = (v & 1u) ? 1.f : 0.f;
+          if (f > 0) unpacked_b[(pair - 1) * n + i] = (v & 16u) ? 1.f : 0.f;
+        }
+    mask_fwd = unpacked_f.data();
+    mask_bwd = unpacked_b.data();
+  }
   if (mapping_kind == kHuber)
     sim_flow<kHuber>(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, scale, batch, frames, height, width, delta, ax, ay, grad_depth, acc);
   else if (mapping_kind == kL1)
@@ -110,6 +126,23 @@ int fm_flow_valid_norm(const float* mask_fwd, const float* mask_bwd, long count,
   const double veff = s != 0.0 ? s : 1.0;
   norm[0] = (float)((double)weight / veff);
   norm[1] = (float)veff;
+  return 0;
+}
+
+int fm_flow_pack_masks(const float* mask_fwd, const float* mask_bwd, int batch, int frames, int height, int width,
+                       uint8_t* mask_bits, int* nonbinary, void*) {
+  const size_t n = (size_t)height * width, groups = (n + 3) / 4;
+  nonbinary[0] = 0;
+  std::memset(mask_bits, 0, (size_t)batch * frames * groups);
+  for (int b = 0; b < batch; ++b)
+    for (int f = 0; f < frames; ++f)
+      for (size_t i = 0; i < n; ++i) {
+        const size_t pair = (size_t)b * (frames - 1) + f;
+        const float a = f < frames - 1 ? mask_fwd[pair * n + i] : 0.f;
+        const float c = f > 0 ? mask_bwd[(pair - 1) * n + i] : 0.f;
+        if (!(a == 0.f || a == 1.f) || !(c == 0.f || c == 1.f)) nonbinary[0] = 1;
+        mask_bits[((size_t)b * frames + f) * groups + i / 4] |= (uint8_t)(((a != 0.f) ? 1u : 0u) << (i % 4) | ((c != 0.f) ? 16u : 0u) << (i % 4));
+      }
   return 0;
 }
 

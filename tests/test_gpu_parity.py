@@ -238,3 +238,8 @@ def test_fn_softmin_intrinsics(lazy_weights):
 
 def test_softmin_whole_step():
     cases.case_softmin_step(DEV)
+
+
+@pytest.mark.parametrize("hw", [(18, 28), (7, 9), (64, 96)])
+def test_packed_masks(hw):
+    cases.case_packed_masks(DEV, hw)

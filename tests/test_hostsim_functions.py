@@ -66,3 +66,8 @@ def test_softmin_intrinsics(lazy_weights):
 
 def test_softmin_whole_step():
     cases.case_softmin_step("cpu")
+
+
+@pytest.mark.parametrize("hw", [(18, 28), (7, 9)])
+def test_packed_masks(hw):
+    cases.case_packed_masks("cpu", hw)

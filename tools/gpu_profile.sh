@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 REPO=$PWD
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-ARGS="--steps 5 --warmup 2 --cpu-frames 0 ${BENCH_ARGS:-}"
+ARGS="--steps ${STEPS:-20} --warmup 2 --cpu-frames 0 ${BENCH_ARGS:-}"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_stats" -o stats -- python "$REPO/bench.py" $ARGS > "$REPO/gpurun_out/prof_stats.log" 2>&1
 echo "stats exit $?" >> "$REPO/gpurun_out/prof_stats.log"
