@@ -58,6 +58,9 @@ def parse():
                     help="spatially smooth synthetic flows (low-res noise upsampled) instead of i.i.d. per-pixel noise")
     ap.add_argument("--intrinsics", choices=["regressed", "softmin"], default="regressed",
                     help="softmin = the reference's default first-1000-steps intrinsics (60-candidate sweep, 8192 points)")
+    ap.add_argument("--optimizer", choices=["none", "fused", "torch"], default="none",
+                    help="add the Adam step (lr 3e-5, config/overfit.yaml:30) to every iteration: flowmap_amd.FusedAdam or "
+                         "torch.optim.Adam; the headline metric is fwd+bwd only (none)")
     ap.add_argument("--tracking", action="store_true",
                     help="BASELINE.json configs[2]: add the tracking loss (segments every 5 frames, +-20 frames, 35x35 tracks)")
     return ap.parse_args()
@@ -188,6 +191,12 @@ def main():
         shard.exchange_halo = lambda grad: None
     shard.prepare_flow_loss(loss_fn, flows)  # global valid-sum (one-time all-reduce)
 
+    optimizer = None
+    if args.optimizer == "fused":
+        optimizer = flowmap_amd.FusedAdam(model.parameters(), lr=3e-5)
+    elif args.optimizer == "torch":
+        optimizer = torch.optim.Adam(model.parameters(), lr=3e-5)
+
     kernel_events = []
     _ops.flow_kernel_events = kernel_events  # (start, end) per fused-kernel launch
 
@@ -199,6 +208,8 @@ def main():
             loss = loss + track_fn(batch, flows, tracks, out, 0)
         loss.backward()
         shard.sync(loss, getattr(model.intrinsics, "focal_length", None), model.backbone.depth)
+        if optimizer is not None:
+            optimizer.step()
         return loss
 
     if dist is not None:  # create the RCCL communicators / P2P channels outside the timed region
@@ -252,7 +263,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE.json configs[1]: {f} frames @ {h}x{w}, flow loss only (huber 0.01, weight 1000), "
-                f"explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points}; fwd+bwd, no optimiser"
+                f"explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points}; fwd+bwd, "
+                + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__})")
                 + (f"; + tracking loss (configs[2]): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else ""),
                 "frames_per_gpu": f,
                 "height": h,

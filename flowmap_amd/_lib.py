@@ -23,6 +23,7 @@ P = ctypes.c_void_p
 I = ctypes.c_int
 L = ctypes.c_long
 F = ctypes.c_float
+D = ctypes.c_double
 
 # name -> argtypes, in the order of include/flowmap_hip.h
 SIGNATURES = {
@@ -31,6 +32,7 @@ SIGNATURES = {
     "fm_flow_loss_finalize": [P] * 6 + [I, I, F, F] + [P] * 4 + [P],
     "fm_flow_valid_norm": [P, P, L, F, P, P, P],
     "fm_scale_if_needed": [P, L, P, P],
+    "fm_adam_step": [P, P, P, P, L, L, D, D, D, D, D, P],
     "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, I, P, P],
     "fm_pose_solve": [P, I, P, P, P, P],
     "fm_pose_solve_bwd": [P, P, P, P, I, P, P],

@@ -336,6 +336,24 @@ FM_HD void flow_term_fast(const DirConst& d, float row0, float row1, float row2,
 }
 
 // ---------------------------------------------------------------------------------
+// One Adam update (torch.optim.Adam as the reference configures it,
+// model_wrapper_overfit.py:104-105: no amsgrad, not maximising; optional L2 weight decay):
+//   g += wd·p;  m = lerp(m, g, 1-β1);  v = β2·v + (1-β2)·g²
+//   p -= step_size · m / (√v / √(1-β2ᵗ) + ε),   step_size = lr / (1-β1ᵗ)
+// ---------------------------------------------------------------------------------
+struct AdamCoef {
+  float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, weight_decay;
+};
+
+FM_HD void adam_update(const AdamCoef& c, float& p, float g, float& m, float& v) {
+  if (c.weight_decay != 0.f) g = fmaf(c.weight_decay, p, g);
+  m = fmaf(c.one_minus_b1, g - m, m);
+  v = fmaf(c.one_minus_b2 * g, g, v * c.b2);
+  const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+  p = p - c.step_size * (m / denom);
+}
+
+// ---------------------------------------------------------------------------------
 // One Procrustes correspondence of frame pair (earlier e, later l), evaluated
 // identically in the statistics passes and in the backward scatter.
 //   p = xyz_l[idx]                                   (projection.py:226-227)

@@ -232,6 +232,15 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
                      const int32_t* blocks, int nblocks, int pmax, const float* kinv, int height, int width, float* grad_depth,
                      void* stream);
 
+/* ---- optimiser step ------------------------------------------
+ * torch.optim.Adam as configured by ModelWrapperOverfit.configure_optimizers
+ * (flowmap/model/model_wrapper_overfit.py:104-105), one tensor per call, in place:
+ *   g += weight_decay·p; m = m + (1-β1)(g-m); v = β2·v + (1-β2)g²;
+ *   p -= lr/(1-β1^step) · m / (sqrt(v)/sqrt(1-β2^step) + eps)
+ * `step` is the 1-based step number AFTER the increment.  No amsgrad / maximize. */
+int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, long step, double lr, double beta1,
+                 double beta2, double eps, double weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -342,3 +342,42 @@ def case_packed_masks(dev, hw=(18, 28)):
     # identical arithmetic per residual; only the order of the float atomics differs run to run
     for key in ("total", "g_depth", "g_wlogit", "g_focal", "extrinsics"):
         assert_close(res[True][key], res[False][key], 1e-5, abs_=1e-9, what=key)
+
+
+def case_fused_adam(dev, weight_decay=0.0):
+    """FusedAdam against torch.optim.Adam (the optimiser the reference constructs,
+    model_wrapper_overfit.py:104-105) on CPU: same trajectory, interchangeable state."""
+    from flowmap_amd import FusedAdam
+
+    g = torch.Generator().manual_seed(21)
+    shapes = [(3, 17, 23), (2, 16, 24), ()]  # odd tail, vector path, 0-dim (focal length)
+    init = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) * (10.0 ** (k % 3 - 1)) for s in shapes] for k in range(12)]
+    for gs in grads:  # untouched entries, like the weights outside the Procrustes sample
+        gs[0][0] = 0.0
+    ref_p = [x.clone().requires_grad_(True) for x in init]
+    our_p = [x.clone().to(dev).requires_grad_(True) for x in init]
+    ref = torch.optim.Adam(ref_p, lr=3e-3, weight_decay=weight_decay)
+    ours = FusedAdam(our_p, lr=3e-3, weight_decay=weight_decay)
+    for k, gs in enumerate(grads):
+        for p, q, gr in zip(ref_p, our_p, gs):
+            p.grad = gr.clone()
+            q.grad = gr.clone().to(dev)
+        ref.step()
+        ours.step()
+        if k == 5:  # state round trip through the torch optimiser's format
+            sd = ours.state_dict()
+            ours = FusedAdam(our_p, lr=1.0)
+            ours.load_state_dict(sd)
+            assert ours.param_groups[0]["lr"] == 3e-3
+    for p, q in zip(ref_p, our_p):
+        assert_close(q.detach(), p.detach(), 2e-6, abs_=1e-7, what="param")
+    for p, q in zip(ref_p, our_p):
+        assert_close(ours.state[q]["exp_avg"], ref.state[p]["exp_avg"], 2e-6, abs_=1e-9, what="exp_avg")
+        assert_close(ours.state[q]["exp_avg_sq"], ref.state[p]["exp_avg_sq"], 2e-6, abs_=1e-12, what="exp_avg_sq")
+        assert float(ours.state[q]["step"]) == float(ref.state[p]["step"]) == len(grads)
+    if weight_decay == 0.0:
+        assert torch.equal(our_p[0].detach()[0].cpu(), init[0][0])  # zero gradient forever -> parameter never moves
+    # our state loads into torch's Adam
+    chk = torch.optim.Adam([x.detach().cpu().clone().requires_grad_(True) for x in our_p], lr=1.0)
+    chk.load_state_dict(ours.state_dict())

@@ -146,6 +146,15 @@ int fm_flow_pack_masks(const float* mask_fwd, const float* mask_bwd, int batch, 
   return 0;
 }
 
+int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, long step, double lr, double beta1,
+                 double beta2, double eps, double weight_decay, void*) {
+  const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+  AdamCoef c{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1), (float)std::sqrt(bc2), (float)eps,
+             (float)weight_decay};
+  for (long i = 0; i < count; ++i) adam_update(c, param[i], grad[i], exp_avg[i], exp_avg_sq[i]);
+  return 0;
+}
+
 int fm_scale_if_needed(float* x, long count, const float* scalar, void*) {
   if (scalar[0] == 1.0f) return 0;
   for (long i = 0; i < count; ++i) x[i] *= scalar[0];

@@ -71,3 +71,8 @@ def test_softmin_whole_step():
 @pytest.mark.parametrize("hw", [(18, 28), (7, 9)])
 def test_packed_masks(hw):
     cases.case_packed_masks("cpu", hw)
+
+
+@pytest.mark.parametrize("weight_decay", [0.0, 0.01])
+def test_fused_adam(weight_decay):
+    cases.case_fused_adam("cpu", weight_decay)
