@@ -11,7 +11,7 @@ All arithmetic runs in hand-written HIP kernels (flowmap_amd/csrc) loaded from
 libflowmap_hip.so through ctypes; there is no CPU or eager fallback.
 """
 
-from . import loss, model  # noqa: F401
+from . import flow, loss, model  # noqa: F401
 from .install import install, uninstall  # noqa: F401
 from .model.projection import set_lazy_surfaces  # noqa: F401
 from .optim import FusedAdam  # noqa: F401

@@ -429,6 +429,47 @@ class FlowLossFused(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------
+# Flow post-processing (no gradients: flows and masks are constants of the optimisation)
+# --------------------------------------------------------------------------------------
+
+
+def _check_video_flow(videos: Tensor, flow: Tensor):
+    check_device(videos, flow)
+    if videos.dim() != 5 or videos.shape[2] != 3:
+        raise RuntimeError("flowmap_amd: videos must be (batch, frame, 3, height, width)")
+    b, f, _, h, w = videos.shape
+    if f < 2 or tuple(flow.shape) != (b, f - 1, h, w, 2):
+        raise RuntimeError("flowmap_amd: flow must be (batch, frame-1, height, width, 2) at the video's resolution")
+    return b, f, h, w
+
+
+def consistency_mask(videos: Tensor, flow: Tensor) -> Tensor:
+    """FlowPredictor.compute_consistency_mask (flowmap/flow/flow_predictor.py:59-80)."""
+    b, f, h, w = _check_video_flow(videos, flow)
+    with torch.no_grad():
+        videos, flow = _f32c(videos, "videos"), _f32c(flow, "flow")
+        mask = torch.empty((b, f - 1, h, w), dtype=torch.float32, device=videos.device)
+        with _guard(videos.device):
+            call("fm_consistency_mask", ptr(videos), ptr(flow), b, f, h, w, ptr(mask), stream_for(videos))
+    return mask
+
+
+def flow_postprocess(videos: Tensor, raw_flow: Tensor, shape, reverse: bool):
+    """Consistency mask + rescale_flow + rescale_mask (+ the flips back when ``reverse``) of
+    compute_bidirectional_flow (flow_predictor.py:82-102).  -> (flow (b,f-1,*shape,2), mask)."""
+    b, f, h, w = _check_video_flow(videos, raw_flow)
+    oh, ow = int(shape[0]), int(shape[1])
+    with torch.no_grad():
+        videos, raw_flow = _f32c(videos, "videos"), _f32c(raw_flow, "flow")
+        out_flow = torch.empty((b, f - 1, oh, ow, 2), dtype=torch.float32, device=videos.device)
+        out_mask = torch.empty((b, f - 1, oh, ow), dtype=torch.float32, device=videos.device)
+        with _guard(videos.device):
+            call("fm_flow_postprocess", ptr(videos), ptr(raw_flow), b, f, h, w, oh, ow, 1 if reverse else 0, ptr(out_flow),
+                 ptr(out_mask), stream_for(videos))
+    return out_flow, out_mask
+
+
+# --------------------------------------------------------------------------------------
 # Function-level building blocks on explicit point sets
 # --------------------------------------------------------------------------------------
 

@@ -219,6 +219,90 @@ FM_HD int tap_col(const Taps& t, int k) { return t.x0 + (k & 1); }
 FM_HD int tap_row(const Taps& t, int k) { return t.y0 + (k >> 1); }
 
 // ---------------------------------------------------------------------------------
+// Flow post-processing (flowmap/flow/flow_predictor.py:39-102), SURVEY.md §8f rank 3.
+//
+// consistency_mask_at: FlowPredictor.compute_consistency_mask (:60-80) at ONE source pixel:
+//   target colour = grid_sample(target, (xy + flow)·2 − 1, bilinear, padding "zeros",
+//   align_corners=False);  δ = max_c |source_c − target_c|;  mask = (1 − δ)⁸.
+// src / tgt address one frame stored (3, H, W).
+// ---------------------------------------------------------------------------------
+FM_HD float consistency_mask_at(const float* src, const float* tgt, int h, int w, int row, int col, float flow_x, float flow_y) {
+#pragma clang fp contract(off)
+  const float gx = (pixel_center(col, w) + flow_x) * 2.f - 1.f;
+  const float gy = (pixel_center(row, h) + flow_y) * 2.f - 1.f;
+  const float ix = ((gx + 1.f) * (float)w - 1.f) / 2.f;
+  const float iy = ((gy + 1.f) * (float)h - 1.f) / 2.f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const float we = ix - fx, ww = 1.f - we, ws = iy - fy, wn = 1.f - ws;
+  // the float -> int conversions saturate, so far-away samples simply fail the range tests
+  const float cx = fminf(fmaxf(fx, -2.f), (float)w + 1.f), cy = fminf(fmaxf(fy, -2.f), (float)h + 1.f);
+  const int x0 = (int)cx, y0 = (int)cy;
+  const bool ok = ix == ix && iy == iy;  // NaN coordinates sample nothing
+  const bool xin0 = ok && x0 >= 0 && x0 < w, xin1 = ok && x0 + 1 >= 0 && x0 + 1 < w;
+  const bool yin0 = ok && y0 >= 0 && y0 < h, yin1 = ok && y0 + 1 >= 0 && y0 + 1 < h;
+  const size_t plane = (size_t)h * w;
+  float delta = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    const float* t = tgt + c * plane;
+    const float nw = (xin0 && yin0) ? t[(size_t)y0 * w + x0] : 0.f;
+    const float ne = (xin1 && yin0) ? t[(size_t)y0 * w + x0 + 1] : 0.f;
+    const float sw = (xin0 && yin1) ? t[(size_t)(y0 + 1) * w + x0] : 0.f;
+    const float se = (xin1 && yin1) ? t[(size_t)(y0 + 1) * w + x0 + 1] : 0.f;
+    const float sampled = nw * (wn * ww) + ne * (wn * we) + sw * (ws * ww) + se * (ws * we);
+    delta = fmaxf(delta, fabsf(src[c * plane + (size_t)row * w + col] - sampled));
+  }
+  const float b = 1.f - delta, b2 = b * b, b4 = b2 * b2;
+  return b4 * b4;
+}
+
+// F.interpolate(mode="bilinear", align_corners=False) source taps for output index `o`
+// (rescale_flow / rescale_mask, flow_predictor.py:39-57; ATen area_pixel_compute_source_index).
+struct ResizeTap {
+  int i0, i1;
+  float l0, l1;
+};
+
+FM_HD ResizeTap resize_tap(int o, int in_size, int out_size) {
+#pragma clang fp contract(off)
+  ResizeTap t;
+  if (in_size == out_size) {
+    t.i0 = t.i1 = o;
+    t.l0 = 1.f;
+    t.l1 = 0.f;
+    return t;
+  }
+  const float scale = (float)in_size / (float)out_size;
+  float real = scale * ((float)o + 0.5f) - 0.5f;
+  real = fminf(fmaxf(real, 0.f), (float)(in_size - 1));
+  t.i0 = (int)real;
+  t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+  t.l1 = fminf(fmaxf(real - (float)t.i0, 0.f), 1.f);
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+
+// One output pixel of the fused post-processing: bilinear resize of the raw flow AND of the
+// consistency mask, the mask being evaluated only at the four full-resolution taps the
+// resize reads (a 4x down-scale touches a quarter of the full-resolution pixels).
+FM_HD void flow_postprocess_at(const float* src, const float* tgt, const float* flow, int h, int w, int oh, int ow, int orow, int ocol,
+                               float out_flow[2], float& out_mask) {
+#pragma clang fp contract(off)
+  const ResizeTap ty = resize_tap(orow, h, oh), tx = resize_tap(ocol, w, ow);
+  const int rows[2] = {ty.i0, ty.i1}, cols[2] = {tx.i0, tx.i1};
+  float f[2][2][2], m[2][2];
+  for (int a = 0; a < 2; ++a)
+    for (int c = 0; c < 2; ++c) {
+      const float* fl = flow + ((size_t)rows[a] * w + cols[c]) * 2;
+      f[a][c][0] = fl[0];
+      f[a][c][1] = fl[1];
+      m[a][c] = consistency_mask_at(src, tgt, h, w, rows[a], cols[c], fl[0], fl[1]);
+    }
+  for (int k = 0; k < 2; ++k)
+    out_flow[k] = ty.l0 * (tx.l0 * f[0][0][k] + tx.l1 * f[0][1][k]) + ty.l1 * (tx.l0 * f[1][0][k] + tx.l1 * f[1][1][k]);
+  out_mask = ty.l0 * (tx.l0 * m[0][0] + tx.l1 * m[0][1]) + ty.l1 * (tx.l0 * m[1][0] + tx.l1 * m[1][1]);
+}
+
+// ---------------------------------------------------------------------------------
 // One flow residual of the FUSED flow loss (fm_flow.hip; tests/host_sim runs the same code).
 //
 // Per (source frame, direction) constants (wave-uniform, SGPRs on the GPU):

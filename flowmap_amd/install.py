@@ -28,16 +28,26 @@ _IMPORT_SITES: Dict[str, Tuple[str, ...]] = {
 }
 
 
+_MISSING = object()
+
+
 def _set(obj, name, value):
-    _saved.append((obj, name, getattr(obj, name, None)))
+    # classes: keep the raw descriptor (staticmethod objects survive the round trip)
+    old = obj.__dict__.get(name, _MISSING) if isinstance(obj, type) else getattr(obj, name, None)
+    _saved.append((obj, name, old))
     setattr(obj, name, value)
 
 
-def install(lazy_surfaces: bool = True, fused_softmin: bool = True) -> None:
+def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postprocess: bool = True, fused_adam: bool = True) -> None:
     """Patch the reference in place.  ``lazy_surfaces=True`` additionally lets
     ``Model.forward``'s ``unproject`` hand a LazySurfaces to the fused consumers;
     ``fused_softmin=True`` registers the fused candidate sweep as INTRINSICS["softmin"]
-    (flowmap/model/intrinsics/__init__.py:6-10)."""
+    (flowmap/model/intrinsics/__init__.py:6-10); ``flow_postprocess=True`` rebinds
+    ``FlowPredictor.compute_consistency_mask`` / ``compute_bidirectional_flow``
+    (flowmap/flow/flow_predictor.py:59-102) on the reference base class, so every concrete
+    predictor (RAFT, GMFlow) inherits the fused post-processing; ``fused_adam=True`` makes
+    ``ModelWrapperOverfit.configure_optimizers`` (model_wrapper_overfit.py:104-105) build
+    ``flowmap_amd.FusedAdam`` (skipped when lightning is not importable)."""
     from . import loss as our_loss
     from .loss import mapping as our_mapping
     from .model import procrustes as our_procrustes
@@ -87,6 +97,33 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True) -> None:
         ref_intr = importlib.import_module("flowmap.model.intrinsics")
         _set(ref_intr, "INTRINSICS", {**ref_intr.INTRINSICS, "softmin": IntrinsicsSoftmin})
 
+    if flow_postprocess:
+        from . import _ops
+
+        ref_fp = importlib.import_module("flowmap.flow.flow_predictor")
+
+        def compute_bidirectional_flow(self, batch, flow_shape):
+            videos = batch.videos
+            forward, forward_mask = _ops.flow_postprocess(videos, self.forward(videos), flow_shape, reverse=False)
+            backward, backward_mask = _ops.flow_postprocess(videos, self.forward(videos.flip(dims=(1,))), flow_shape, reverse=True)
+            return ref_fp.Flows(forward, backward, forward_mask, backward_mask)
+
+        _set(ref_fp.FlowPredictor, "compute_consistency_mask", staticmethod(_ops.consistency_mask))
+        _set(ref_fp.FlowPredictor, "compute_bidirectional_flow", compute_bidirectional_flow)
+
+    if fused_adam:
+        try:
+            ref_wrapper = importlib.import_module("flowmap.model.model_wrapper_overfit")
+        except Exception:  # lightning / hydra are not installed here; nothing to rebind
+            ref_wrapper = None
+        if ref_wrapper is not None:
+            from .optim import FusedAdam
+
+            def configure_optimizers(self):
+                return FusedAdam(self.parameters(), lr=self.cfg.lr)
+
+            _set(ref_wrapper.ModelWrapperOverfit, "configure_optimizers", configure_optimizers)
+
     our_projection.set_lazy_surfaces(lazy_surfaces)
 
 
@@ -95,5 +132,8 @@ def uninstall() -> None:
 
     while _saved:
         obj, name, old = _saved.pop()
-        setattr(obj, name, old)
+        if old is _MISSING:
+            delattr(obj, name)
+        else:
+            setattr(obj, name, old)
     our_projection.set_lazy_surfaces(False)

@@ -232,6 +232,24 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
                      const int32_t* blocks, int nblocks, int pmax, const float* kinv, int height, int width, float* grad_depth,
                      void* stream);
 
+/* ---- flow post-processing ---------------------------------------
+ * FlowPredictor.compute_consistency_mask (flowmap/flow/flow_predictor.py:60-80):
+ * videos (B,F,3,H,W), flow (B,F-1,H,W,2) in normalised image units -> mask (B,F-1,H,W) =
+ * (1 - max_c |frame_i - bilinear(frame_{i+1}, xy + flow)|)^8, zeros padding. */
+int fm_consistency_mask(const float* videos, const float* flow, int batch, int frames, int height, int width, float* mask,
+                        void* stream);
+
+/* Everything FlowPredictor.compute_bidirectional_flow (:82-102) does after the flow network,
+ * for one temporal direction: consistency mask at (height,width), then rescale_flow /
+ * rescale_mask (:39-57, bilinear, align_corners=False) to (out_height,out_width).
+ *   reverse = 0: flow[pair] maps frame pair -> pair+1; out_*[pair] is that pair.
+ *   reverse = 1: flow was predicted on the time-flipped video (videos.flip(1)), so
+ *                flow[j] maps frame F-1-j -> F-2-j; out_*[pair] = result for raw index
+ *                F-2-pair, i.e. already flipped back (:99-100).  `videos` is NOT flipped.
+ * out_flow (B,F-1,oh,ow,2), out_mask (B,F-1,oh,ow). */
+int fm_flow_postprocess(const float* videos, const float* flow, int batch, int frames, int height, int width, int out_height,
+                        int out_width, int reverse, float* out_flow, float* out_mask, void* stream);
+
 /* ---- optimiser step ------------------------------------------
  * torch.optim.Adam as configured by ModelWrapperOverfit.configure_optimizers
  * (flowmap/model/model_wrapper_overfit.py:104-105), one tensor per call, in place:

@@ -537,3 +537,58 @@ def softmin_intrinsics(depths: Tensor, weights: Tensor, bwd_flow: Tensor, candid
     err = ((flow - flow_gt) * wts).abs().sum(dim=(2, 3))
     soft = tnf.softmin((err - err.min(dim=1, keepdim=True).values) * 10, dim=1)
     return (k[None] * soft[:, :, None, None]).sum(dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# Flow post-processing — flowmap/flow/flow_predictor.py:39-102
+# --------------------------------------------------------------------------------------
+
+
+def consistency_mask(videos: Tensor, flow: Tensor) -> Tensor:
+    """flow_predictor.py:59-80.  videos (b,f,3,h,w), flow (b,f-1,h,w,2) -> (b,f-1,h,w):
+    (1 - max_c |source - bilinear_zeros(target, xy + flow)|)^8."""
+    b, f, _, h, w = videos.shape
+    src = videos[:, :-1].reshape(b * (f - 1), 3, h, w)
+    tgt = videos[:, 1:].reshape(b * (f - 1), 3, h, w)
+    xy, _ = pixel_grid((h, w), videos.device, videos.dtype)
+    pos = xy + flow.reshape(b * (f - 1), h, w, 2)
+    sampled = tnf.grid_sample(tgt, pos * 2 - 1, mode="bilinear", padding_mode="zeros", align_corners=False)
+    delta = (src - sampled).abs().max(dim=1).values
+    return ((1 - delta) ** 8).reshape(b, f - 1, h, w)
+
+
+def resize_bilinear(x: Tensor, shape) -> Tensor:
+    """F.interpolate(bilinear, align_corners=False) over the last two dims of (n,c,h,w)
+    (flow_predictor.py:45,55)."""
+    return tnf.interpolate(x, tuple(shape), mode="bilinear", align_corners=False)
+
+
+def bidirectional_flows(videos: Tensor, predictor, shape) -> OFlows:
+    """flow_predictor.py:82-102 around an arbitrary ``predictor(videos) -> raw flow``."""
+
+    def one_direction(v):
+        raw = predictor(v)
+        b, p, h, w, _ = raw.shape
+        mask = consistency_mask(v, raw)
+        flow = resize_bilinear(raw.permute(0, 1, 4, 2, 3).reshape(b * p, 2, h, w), shape).reshape(b, p, 2, *shape).permute(0, 1, 3, 4, 2)
+        return flow, resize_bilinear(mask.reshape(b * p, 1, h, w), shape).reshape(b, p, *shape)
+
+    fwd, fwd_mask = one_direction(videos)
+    bwd, bwd_mask = one_direction(videos.flip(dims=(1,)))
+    return OFlows(fwd, bwd.flip(dims=(1,)), fwd_mask, bwd_mask.flip(dims=(1,)))
+
+
+def synth_video(f: int, h: int, w: int, seed: int = 0) -> Tensor:
+    """Smooth random video (1,f,3,h,w) in [0,1] whose frames drift slowly, so that a
+    difference-based stand-in predictor yields small, spatially varying flows."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand((f * 3, 1, max(h // 6, 2), max(w // 6, 2)), generator=g)
+    base = tnf.interpolate(low, size=(h, w), mode="bicubic", align_corners=False).clamp(0, 1)
+    return base.reshape(1, f, 3, h, w).contiguous()
+
+
+def standin_predictor(videos: Tensor) -> Tensor:
+    """Deterministic stand-in for the optical-flow network (RAFT is out of scope): element-wise
+    ops only, so CPU and GPU agree bit for bit.  (b,f,3,h,w) -> (b,f-1,h,w,2)."""
+    d = (videos[:, 1:, :2] - videos[:, :-1, :2]) * 0.25 + (videos[:, :-1, 2:3] - 0.5) * 0.05
+    return d.permute(0, 1, 3, 4, 2).contiguous()

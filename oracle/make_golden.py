@@ -347,6 +347,34 @@ def gold_functions():
     save("fn_mapping", a=a, b=bb, image_shape=np.array([9, 16]), **m)
 
 
+def gold_flow_preprocess():
+    """FlowPredictor.compute_consistency_mask / rescale_* / compute_bidirectional_flow of the
+    reference around a deterministic stand-in network (oracle.standin_predictor)."""
+    from flowmap.flow.flow_predictor import FlowPredictor
+
+    class StandIn(FlowPredictor):
+        def forward(self, videos):
+            return orc.standin_predictor(videos)
+
+    arrays = {}
+    for tag, (f, h, w, shape) in {"a": (4, 24, 32, (6, 8)), "b": (3, 20, 28, (7, 9)), "c": (3, 12, 16, (12, 16)), "d": (2, 10, 14, (15, 21))}.items():
+        videos = orc.synth_video(f, h, w, seed=40 + ord(tag))
+        raw = orc.standin_predictor(videos)
+        raw[0, 0, 0, 0] = torch.tensor([0.9, -0.7])  # far outside the frame: zeros padding
+        raw[0, 0, 1, 1] = torch.tensor([-(1.5 / w), 0.0])  # straddles the left border
+
+        class Fixed(FlowPredictor):
+            def forward(self, v, raw=raw, videos=videos):
+                return raw if torch.equal(v, videos) else orc.standin_predictor(v)
+
+        flows = Fixed(None).compute_bidirectional_flow(Batch(videos, None, None, None), shape)
+        arrays.update({f"{tag}_videos": videos, f"{tag}_raw": raw, f"{tag}_shape": np.array(shape),
+                       f"{tag}_mask_full": FlowPredictor.compute_consistency_mask(videos, raw),
+                       f"{tag}_forward": flows.forward, f"{tag}_backward": flows.backward,
+                       f"{tag}_forward_mask": flows.forward_mask, f"{tag}_backward_mask": flows.backward_mask})
+    save("fn_flow_preprocess", **arrays)
+
+
 def gold_softmin():
     """IntrinsicsSoftmin.forward (intrinsics_softmin.py:63-141) with its internal
     torch.randperm replaced by a recorded permutation."""
@@ -380,4 +408,5 @@ if __name__ == "__main__":
     gold_steps()
     gold_functions()
     gold_softmin()
+    gold_flow_preprocess()
     print("done")

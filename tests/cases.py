@@ -381,3 +381,31 @@ def case_fused_adam(dev, weight_decay=0.0):
     # our state loads into torch's Adam
     chk = torch.optim.Adam([x.detach().cpu().clone().requires_grad_(True) for x in our_p], lr=1.0)
     chk.load_state_dict(ours.state_dict())
+
+
+def case_flow_preprocess(dev, tag):
+    """Consistency mask, resize and direction handling of FlowPredictor against the
+    reference's own outputs (golden) around the deterministic stand-in network."""
+    from flowmap_amd import Batch
+    from flowmap_amd.flow import FlowPredictor
+
+    g = load_golden("fn_flow_preprocess")
+    videos, raw = t(g[f"{tag}_videos"]).to(dev), t(g[f"{tag}_raw"]).to(dev)
+    shape = tuple(int(x) for x in g[f"{tag}_shape"])
+
+    class StandIn(FlowPredictor):
+        def forward(self, v):
+            return raw if torch.equal(v, videos) else orc.standin_predictor(v)
+
+    tol = 2e-5  # (1-δ)^8 by squaring vs pow, coordinate rounding of the two grid_sample formulas
+    assert_close(FlowPredictor.compute_consistency_mask(videos, raw), g[f"{tag}_mask_full"], tol, what="mask_full")
+    flows = StandIn(None).compute_bidirectional_flow(Batch(videos), shape)
+    for name in ("forward", "backward", "forward_mask", "backward_mask"):
+        got = getattr(flows, name)
+        assert got.shape == g[f"{tag}_{name}"].shape and got.is_contiguous()
+        assert_close(got, g[f"{tag}_{name}"], tol, what=name)
+    # the stand-alone helpers the fused path replaces give the same thing
+    b, p = raw.shape[:2]
+    assert_close(FlowPredictor.rescale_flow(raw, shape), g[f"{tag}_forward"], tol, what="rescale_flow")
+    assert_close(FlowPredictor.rescale_mask(FlowPredictor.compute_consistency_mask(videos, raw), shape), g[f"{tag}_forward_mask"], tol,
+                 what="rescale_mask")

@@ -146,6 +146,38 @@ int fm_flow_pack_masks(const float* mask_fwd, const float* mask_bwd, int batch, 
   return 0;
 }
 
+int fm_consistency_mask(const float* videos, const float* flow, int batch, int frames, int height, int width, float* mask, void*) {
+  const size_t n = (size_t)height * width;
+  for (int bp = 0; bp < batch * (frames - 1); ++bp) {
+    const int b = bp / (frames - 1), pair = bp % (frames - 1);
+    const float* src = videos + ((size_t)b * frames + pair) * 3 * n;
+    for (size_t i = 0; i < n; ++i)
+      mask[(size_t)bp * n + i] = consistency_mask_at(src, src + 3 * n, height, width, (int)(i / width), (int)(i % width),
+                                                     flow[((size_t)bp * n + i) * 2], flow[((size_t)bp * n + i) * 2 + 1]);
+  }
+  return 0;
+}
+
+int fm_flow_postprocess(const float* videos, const float* flow, int batch, int frames, int height, int width, int out_height,
+                        int out_width, int reverse, float* out_flow, float* out_mask, void*) {
+  const size_t n = (size_t)height * width, on = (size_t)out_height * out_width;
+  for (int bp = 0; bp < batch * (frames - 1); ++bp) {
+    const int b = bp / (frames - 1), pair = bp % (frames - 1);
+    const int fs = reverse ? pair + 1 : pair, ft = reverse ? pair : pair + 1, raw = reverse ? frames - 2 - pair : pair;
+    const float* src = videos + ((size_t)b * frames + fs) * 3 * n;
+    const float* tgt = videos + ((size_t)b * frames + ft) * 3 * n;
+    const float* fl = flow + ((size_t)b * (frames - 1) + raw) * n * 2;
+    for (size_t i = 0; i < on; ++i) {
+      float of[2], om;
+      flow_postprocess_at(src, tgt, fl, height, width, out_height, out_width, (int)(i / out_width), (int)(i % out_width), of, om);
+      out_flow[((size_t)bp * on + i) * 2] = of[0];
+      out_flow[((size_t)bp * on + i) * 2 + 1] = of[1];
+      out_mask[(size_t)bp * on + i] = om;
+    }
+  }
+  return 0;
+}
+
 int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, long step, double lr, double beta1,
                  double beta2, double eps, double weight_decay, void*) {
   const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);

@@ -248,3 +248,8 @@ def test_packed_masks(hw):
 @pytest.mark.parametrize("weight_decay", [0.0, 0.01])
 def test_fused_adam(weight_decay):
     cases.case_fused_adam(DEV, weight_decay)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_flow_preprocess(tag):
+    cases.case_flow_preprocess(DEV, tag)

@@ -167,3 +167,37 @@ def test_reference_softmin_intrinsics_under_install():
     finally:
         for p in added:
             sys.path.remove(p)
+
+
+def test_reference_flow_predictor_under_install(patched_reference):
+    """A predictor subclassing the REFERENCE's FlowPredictor inherits the fused
+    post-processing after install(), returns the reference's Flows type, and reproduces what
+    the unpatched reference computed (golden); uninstall() restores the static method."""
+    from conftest import assert_close, load_golden, t
+
+    import flowmap.flow.flow_predictor as ref_fp
+    from flowmap.dataset.types import Batch
+
+    import flowmap_amd
+    from oracle import flowmap_oracle as orc
+
+    g = load_golden("fn_flow_preprocess")
+    videos, raw = t(g["a_videos"]), t(g["a_raw"])
+    shape = tuple(int(x) for x in g["a_shape"])
+
+    class StandIn(ref_fp.FlowPredictor):
+        def forward(self, v):
+            return raw if torch.equal(v, videos) else orc.standin_predictor(v)
+
+    assert ref_fp.FlowPredictor.compute_bidirectional_flow.__module__.startswith("flowmap_amd")
+    flows = StandIn(None).compute_bidirectional_flow(Batch(videos, None, None, None), shape)
+    assert isinstance(flows, ref_fp.Flows)
+    for name in ("forward", "backward", "forward_mask", "backward_mask"):
+        assert_close(getattr(flows, name), g[f"a_{name}"], 2e-5, what=name)
+    assert_close(StandIn(None).compute_consistency_mask(videos, raw), g["a_mask_full"], 2e-5, what="mask (static, via instance)")
+
+    flowmap_amd.uninstall()
+    assert ref_fp.FlowPredictor.compute_bidirectional_flow.__module__ == "flowmap.flow.flow_predictor"
+    assert isinstance(ref_fp.FlowPredictor.__dict__["compute_consistency_mask"], staticmethod)
+    again = StandIn(None).compute_bidirectional_flow(Batch(videos, None, None, None), shape)  # reference code, CPU
+    assert_close(again.forward_mask, g["a_forward_mask"], 1e-6, what="unpatched")

@@ -187,3 +187,14 @@ def test_softmin_intrinsics():
     assert_close(k[0], g["intrinsics"], TOL, what="intrinsics")
     assert_close(d.grad[0], g["g_depth"][0], 5e-4, abs_=1e-7, what="g_depth")
     assert_close(w.grad, g["g_weights"], 5e-4, abs_=1e-7, what="g_weights")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_flow_preprocess(tag):
+    g = load_golden("fn_flow_preprocess")
+    videos, raw, shape = t(g[f"{tag}_videos"]), t(g[f"{tag}_raw"]), tuple(int(x) for x in g[f"{tag}_shape"])
+    assert_close(orc.consistency_mask(videos, raw), g[f"{tag}_mask_full"], 1e-6, what="mask_full")
+    flows = orc.bidirectional_flows(videos, lambda v: raw if torch.equal(v, videos) else orc.standin_predictor(v), shape)
+    for name, val in (("forward", flows.forward), ("backward", flows.backward), ("forward_mask", flows.forward_mask),
+                      ("backward_mask", flows.backward_mask)):
+        assert_close(val, g[f"{tag}_{name}"], 1e-6, what=name)
