@@ -286,6 +286,34 @@ __global__ void __launch_bounds__(256) rigid_bwd_kernel(const float* p, const fl
 
 using namespace fm;
 
+// World-space point cloud of export_to_colmap (flowmap/export/colmap.py:86-101): per frame
+//   xyz = unproject(xy, depth, K);  world = (E · [xyz; 1])[:3];  rgb (3,H,W) -> (H·W,3)
+// one streaming pass: 4 + 12 B in, 12 + 12 B out per pixel, frames concatenated.
+__global__ void __launch_bounds__(256) world_points_kernel(const float* depth, const float* kinv, const float* ext, const float* colors,
+                                                           int h, int w, float* out_xyz, float* out_rgb) {
+  const int fr = blockIdx.y;
+  const size_t n = (size_t)h * w;
+  Mat3 ki;
+  Pose e;
+  load_mat3(kinv + (size_t)fr * 9, ki);
+  load_pose44(ext + (size_t)fr * 16, e);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / w), col = (int)(i - (size_t)row * w);
+    float ray[3], xyz[3], xw[3];
+    ray_dir(ki, pixel_center(col, w), pixel_center(row, h), ray);
+    const float z = depth[(size_t)fr * n + i];
+    xyz[0] = ray[0] * z; xyz[1] = ray[1] * z; xyz[2] = ray[2] * z;
+    apply_pose(e, xyz, xw);
+    float* o = out_xyz + ((size_t)fr * n + i) * 3;
+    o[0] = xw[0]; o[1] = xw[1]; o[2] = xw[2];
+    if (colors) {
+      const float* c = colors + (size_t)fr * 3 * n + i;
+      float* oc = out_rgb + ((size_t)fr * n + i) * 3;
+      oc[0] = c[0]; oc[1] = c[n]; oc[2] = c[2 * n];
+    }
+  }
+}
+
 static inline unsigned blocks_for(long n, int per_thread = 4, unsigned cap = 4096) {
   long b = (n + 256L * per_thread - 1) / (256L * per_thread);
   if (b < 1) b = 1;
@@ -310,6 +338,15 @@ int fm_unproject_bwd(const float* xy, long xy_group_stride, const float* z, cons
   if (kinv_acc && hipMemsetAsync(kinv_acc, 0, sizeof(double) * (size_t)groups * 9, st) != hipSuccess) return FM_ERR_LAUNCH;
   hipLaunchKernelGGL(unproject_bwd_kernel, dim3(blocks_for(points), groups), dim3(256), 0, st, xy, xy_group_stride, z, kinv,
                      g_out, points, g_z, kinv_acc);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_world_points(const float* depth, const float* kinv, const float* ext, const float* colors, int frames, int height, int width,
+                    float* out_xyz, float* out_rgb, void* stream) {
+  FM_CHECK_ARG(depth && kinv && ext && out_xyz && frames >= 1 && frames <= 65535 && height >= 1 && width >= 1);
+  FM_CHECK_ARG(!colors || out_rgb);
+  hipLaunchKernelGGL(world_points_kernel, dim3(blocks_for((long)height * width), frames), dim3(256), 0, (hipStream_t)stream, depth,
+                     kinv, ext, colors, height, width, out_xyz, out_rgb);
   FM_LAUNCH_STATUS();
 }
 

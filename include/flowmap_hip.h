@@ -232,6 +232,13 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
                      const int32_t* blocks, int nblocks, int pmax, const float* kinv, int height, int width, float* grad_depth,
                      void* stream);
 
+/* ---- export ------------------------------------------------------
+ * Point cloud of export_to_colmap (flowmap/export/colmap.py:86-101): depth (F,H,W), kinv
+ * (F,3,3), ext (F,4,4) camera-to-world, colors (F,3,H,W) or NULL -> out_xyz (F·H·W,3) world
+ * points, out_rgb (F·H·W,3). */
+int fm_world_points(const float* depth, const float* kinv, const float* ext, const float* colors, int frames, int height, int width,
+                    float* out_xyz, float* out_rgb, void* stream);
+
 /* ---- flow post-processing ---------------------------------------
  * FlowPredictor.compute_consistency_mask (flowmap/flow/flow_predictor.py:60-80):
  * videos (B,F,3,H,W), flow (B,F-1,H,W,2) in normalised image units -> mask (B,F-1,H,W) =

@@ -592,3 +592,22 @@ def standin_predictor(videos: Tensor) -> Tensor:
     ops only, so CPU and GPU agree bit for bit.  (b,f,3,h,w) -> (b,f-1,h,w,2)."""
     d = (videos[:, 1:, :2] - videos[:, :-1, :2]) * 0.25 + (videos[:, :-1, 2:3] - 0.5) * 0.05
     return d.permute(0, 1, 3, 4, 2).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# Export — flowmap/export/colmap.py:86-101 (SURVEY.md §8f rank 4)
+# --------------------------------------------------------------------------------------
+
+
+def world_point_cloud(depths: Tensor, k: Tensor, extrinsics: Tensor, colors: Tensor):
+    """depths (F,H,W), k (F,3,3), extrinsics (F,4,4), colors (F,3,H,W) -> (F·H·W,3) world
+    points and (F·H·W,3) colours, frame after frame."""
+    f, h, w = depths.shape
+    xy, _ = pixel_grid((h, w), depths.device, depths.dtype)
+    pts, cols = [], []
+    for i in range(f):
+        xyz = lift(xy, depths[i], k[i])
+        world = matvec(extrinsics[i], append_one(xyz))[..., :3]
+        pts.append(world.reshape(h * w, 3))
+        cols.append(colors[i].permute(1, 2, 0).reshape(h * w, 3))
+    return torch.cat(pts), torch.cat(cols)

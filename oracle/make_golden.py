@@ -375,6 +375,35 @@ def gold_flow_preprocess():
     save("fn_flow_preprocess", **arrays)
 
 
+def gold_export():
+    """The point-cloud loop of export_to_colmap (flowmap/export/colmap.py:86-101) executed with
+    the reference's own unproject / homogenize_points (the module itself needs plyfile, which
+    is not installed), and compute_ate (flowmap/misc/ate.py)."""
+    from einops import einsum, rearrange
+
+    from flowmap.misc.ate import compute_ate
+
+    sc = orc.synth_scene(4, 14, 18, seed=9)
+    depths, ext = sc["depth_gt"], sc["extrinsics_gt"]
+    k = sc["intrinsics_gt"].expand(4, 3, 3).contiguous()
+    k[2, 0, 2] = 0.47  # an off-centre principal point, as COLMAP intrinsics may have
+    colors = torch.rand((4, 3, 14, 18), generator=torch.Generator().manual_seed(9))
+    xy, _ = rp.sample_image_grid((14, 18), depths.device)
+    points, cols = [], []
+    for e, kk, d, rgb in zip(ext, k, depths, colors):
+        xyz = rp.homogenize_points(rp.unproject(xy, d, kk))
+        xyz = einsum(e, xyz, "i j, ... j -> ... i")[..., :3]
+        points.append(rearrange(xyz, "h w xyz -> (h w) xyz"))
+        cols.append(rearrange(rgb, "c h w -> (h w) c"))
+    g = torch.Generator().manual_seed(10)
+    gt = torch.randn((12, 3), generator=g)
+    rot = torch.linalg.qr(torch.randn((3, 3), generator=g))[0]
+    pred = 2.5 * gt @ rot.T + 0.3 + 0.02 * torch.randn((12, 3), generator=g)
+    ate, a_gt, a_pred = compute_ate(gt, pred)
+    save("fn_export", depths=depths, intrinsics=k, extrinsics=ext, colors=colors, points=torch.cat(points), point_colors=torch.cat(cols),
+         ate_gt=gt, ate_pred=pred, ate=ate, ate_aligned_gt=a_gt, ate_aligned_pred=a_pred)
+
+
 def gold_softmin():
     """IntrinsicsSoftmin.forward (intrinsics_softmin.py:63-141) with its internal
     torch.randperm replaced by a recorded permutation."""
@@ -409,4 +438,5 @@ if __name__ == "__main__":
     gold_functions()
     gold_softmin()
     gold_flow_preprocess()
+    gold_export()
     print("done")

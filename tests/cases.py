@@ -409,3 +409,31 @@ def case_flow_preprocess(dev, tag):
     assert_close(FlowPredictor.rescale_flow(raw, shape), g[f"{tag}_forward"], tol, what="rescale_flow")
     assert_close(FlowPredictor.rescale_mask(FlowPredictor.compute_consistency_mask(videos, raw), shape), g[f"{tag}_forward_mask"], tol,
                  what="rescale_mask")
+
+
+def case_export(dev, tmp_path):
+    """World-space point cloud (one launch) against the reference's per-frame loop, the PLY
+    round trip, and compute_ate."""
+    import numpy as np
+    from flowmap_amd import export
+
+    g = load_golden("fn_export")
+    pts, cols = export.world_point_cloud(t(g["depths"]).to(dev), t(g["intrinsics"]).to(dev), t(g["extrinsics"]).to(dev), t(g["colors"]).to(dev))
+    assert_close(pts, g["points"], 2e-6, what="points")
+    assert torch.equal(cols.cpu(), t(g["point_colors"]))
+    only, none = export.world_point_cloud(t(g["depths"]).to(dev), t(g["intrinsics"]).to(dev), t(g["extrinsics"]).to(dev))
+    assert none is None and torch.equal(only, pts)
+
+    path = tmp_path / "points3D.ply"
+    export.write_ply(path, pts.cpu().numpy(), cols.cpu().numpy())
+    head = path.read_bytes()[:400].split(b"end_header\n")[0].decode()
+    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\n" % pts.shape[0])
+    assert head.rstrip().endswith("property uchar red\nproperty uchar green\nproperty uchar blue")
+    xyz, rgb = export.read_ply(path)
+    assert np.array_equal(xyz, pts.cpu().numpy())
+    assert np.array_equal(rgb, (cols.cpu().numpy() * 255).astype(np.uint8) / 255.0)
+
+    ate, a_gt, a_pred = export.compute_ate(t(g["ate_gt"]).to(dev), t(g["ate_pred"]).to(dev))
+    assert abs(float(ate) - float(g["ate"])) < 1e-7 and ate.device.type == torch.device(dev).type
+    assert_close(a_gt, g["ate_aligned_gt"], 1e-6, what="aligned gt")
+    assert_close(a_pred, g["ate_aligned_pred"], 1e-6, what="aligned predicted")

@@ -146,6 +146,29 @@ int fm_flow_pack_masks(const float* mask_fwd, const float* mask_bwd, int batch, 
   return 0;
 }
 
+int fm_world_points(const float* depth, const float* kinv, const float* ext, const float* colors, int frames, int height, int width,
+                    float* out_xyz, float* out_rgb, void*) {
+  const size_t n = (size_t)height * width;
+  for (int fr = 0; fr < frames; ++fr) {
+    Mat3 ki;
+    Pose e;
+    load_mat3(kinv + (size_t)fr * 9, ki);
+    load_pose44(ext + (size_t)fr * 16, e);
+    for (size_t i = 0; i < n; ++i) {
+      float ray[3], xyz[3], xw[3];
+      ray_dir(ki, pixel_center((int)(i % width), width), pixel_center((int)(i / width), height), ray);
+      const float z = depth[(size_t)fr * n + i];
+      xyz[0] = ray[0] * z; xyz[1] = ray[1] * z; xyz[2] = ray[2] * z;
+      apply_pose(e, xyz, xw);
+      for (int a = 0; a < 3; ++a) {
+        out_xyz[((size_t)fr * n + i) * 3 + a] = xw[a];
+        if (colors) out_rgb[((size_t)fr * n + i) * 3 + a] = colors[((size_t)fr * 3 + a) * n + i];
+      }
+    }
+  }
+  return 0;
+}
+
 int fm_consistency_mask(const float* videos, const float* flow, int batch, int frames, int height, int width, float* mask, void*) {
   const size_t n = (size_t)height * width;
   for (int bp = 0; bp < batch * (frames - 1); ++bp) {

@@ -253,3 +253,7 @@ def test_fused_adam(weight_decay):
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_flow_preprocess(tag):
     cases.case_flow_preprocess(DEV, tag)
+
+
+def test_export(tmp_path):
+    cases.case_export(DEV, tmp_path)

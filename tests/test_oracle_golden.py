@@ -198,3 +198,11 @@ def test_flow_preprocess(tag):
     for name, val in (("forward", flows.forward), ("backward", flows.backward), ("forward_mask", flows.forward_mask),
                       ("backward_mask", flows.backward_mask)):
         assert_close(val, g[f"{tag}_{name}"], 1e-6, what=name)
+
+
+def test_export_point_cloud_and_ate():
+    g = load_golden("fn_export")
+    pts, cols = orc.world_point_cloud(t(g["depths"]), t(g["intrinsics"]), t(g["extrinsics"]), t(g["colors"]))
+    assert_close(pts, g["points"], 1e-6, what="points")
+    assert torch.equal(cols, t(g["point_colors"]))
+    assert abs(orc.ate(t(g["ate_gt"]), t(g["ate_pred"])) - float(g["ate"])) < 1e-6
