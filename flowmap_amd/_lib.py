@@ -28,7 +28,7 @@ D = ctypes.c_double
 # name -> argtypes, in the order of include/flowmap_hip.h
 SIGNATURES = {
     "fm_flow_loss_fused": [P] * 11 + [I, I, I, I, I, F, F, F, P, P, I, P],
-    "fm_flow_pack_masks": [P, P, I, I, I, I, P, P, P],
+    "fm_flow_pack_inputs": [P, P, P, P, I, I, I, I, P, P],
     "fm_flow_loss_finalize": [P] * 6 + [I, I, F, F] + [P] * 4 + [P],
     "fm_flow_valid_norm": [P, P, L, F, P, P, P],
     "fm_scale_if_needed": [P, L, P, P],

@@ -313,39 +313,42 @@ def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=N
     return norm
 
 
-_mask_cache: dict = {}
+_pack_cache: dict = {}
 
-# Packed masks are on by default; tests flip this to exercise the fp32-mask kernels as well.
-use_packed_masks = True
+# The packed copy costs as much HBM as the flows and masks themselves (3.3 GB at C1); set to
+# False to stream the caller's tensors directly (tests exercise both kernels).
+use_packed_inputs = True
 
 
-def packed_flow_masks(mask_fwd: Tensor, mask_bwd: Tensor) -> Optional[Tensor]:
-    """(B,F,ceil(HW/4)) uint8 produced by fm_flow_pack_masks, or None when the masks are not
-    0/1 images.  Like the valid-sum, the masks are constants of an optimisation
-    (flowmap/flow/common.py computes them once per video), so this runs once per Flows object:
-    cached per (storage, version) and validated against the live tensors."""
-    if not use_packed_masks:
+def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mask_bwd: Tensor) -> Optional[Tensor]:
+    """Flows + masks in the layout of fm_flow_pack_inputs, or None when it does not apply
+    (width not a multiple of 4, unexpected shapes / dtypes).  Like the valid-sum, these are
+    constants of an optimisation (flow_predictor.py:82-102 runs once per video), so the
+    re-layout runs once per Flows object: cached per (storage, version) of all four tensors
+    and validated against the live tensors."""
+    if not use_packed_inputs:
         return None
-    key = (mask_fwd.data_ptr(), mask_bwd.data_ptr(), mask_fwd._version, mask_bwd._version, tuple(mask_fwd.shape), str(mask_fwd.device))
-    hit = _mask_cache.get(key)
-    if hit is not None:
-        bits, ref_f, ref_b = hit
-        if ref_f() is mask_fwd and ref_b() is mask_bwd:
-            return bits
-    if tuple(mask_bwd.shape) != tuple(mask_fwd.shape) or mask_fwd.dim() != 4:
-        return None  # FlowLossFused reports the shape error
-    src_f, src_b = _f32c(mask_fwd, "forward mask"), _f32c(mask_bwd, "backward mask")
+    srcs = (flow_fwd, flow_bwd, mask_fwd, mask_bwd)
+    if mask_fwd.dim() != 4 or mask_fwd.shape[-1] % 4 != 0 or tuple(mask_bwd.shape) != tuple(mask_fwd.shape):
+        return None
+    if tuple(flow_fwd.shape) != (*mask_fwd.shape, 2) or tuple(flow_bwd.shape) != (*mask_fwd.shape, 2):
+        return None
+    if any(t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 != 0 for t in srcs):
+        return None
+    key = tuple((t.data_ptr(), t._version) for t in srcs) + (tuple(mask_fwd.shape), str(mask_fwd.device))
+    hit = _pack_cache.get(key)
+    if hit is not None and all(ref() is t for ref, t in zip(hit[1], srcs)):
+        return hit[0]
     b, pairs, h, w = mask_fwd.shape
-    bits = torch.empty((b, pairs + 1, (h * w + 3) // 4), dtype=torch.uint8, device=mask_fwd.device)
-    flag = torch.empty((1,), dtype=torch.int32, device=mask_fwd.device)
+    chunks = (h * w // 4 + 63) // 64
+    packed = torch.empty((b * (pairs + 1), chunks, 6, 64, 4), dtype=torch.float32, device=mask_fwd.device)
     with _guard(mask_fwd.device):
-        call("fm_flow_pack_masks", ptr(src_f), ptr(src_b), b, pairs + 1, h, w, ptr(bits), ptr(flag), stream_for(mask_fwd))
-    if int(flag.item()) != 0:  # one-time host sync per Flows object
-        bits = None
-    if len(_mask_cache) > 16:
-        _mask_cache.clear()
-    _mask_cache[key] = (bits, weakref.ref(mask_fwd), weakref.ref(mask_bwd))
-    return bits
+        call("fm_flow_pack_inputs", ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd), b, pairs + 1, h, w, ptr(packed),
+             stream_for(mask_fwd))
+    if len(_pack_cache) > 4:
+        _pack_cache.clear()
+    _pack_cache[key] = (packed, [weakref.ref(t) for t in srcs])
+    return packed
 
 
 class FlowLossFused(torch.autograd.Function):
@@ -354,7 +357,7 @@ class FlowLossFused(torch.autograd.Function):
     analytic gradient of every input produced in the same HBM pass."""
 
     @staticmethod
-    def forward(ctx, depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, kind, delta, carry, items, bits=None):
+    def forward(ctx, depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, kind, delta, carry, items, packed=None):
         dev = check_device(depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm)
         depth = _f32c(depth, "depth")
         k = _f32c(k, "intrinsics")
@@ -371,8 +374,9 @@ class FlowLossFused(torch.autograd.Function):
             raise RuntimeError("flowmap_amd: intrinsics / pose shapes do not match depth")
         need = any(ctx.needs_input_grad[:4])
         kinv = intrinsics_inverse(k)
-        if bits is not None and (bits.dtype != torch.uint8 or tuple(bits.shape) != (b, f, (h * w + 3) // 4) or not bits.is_contiguous()):
-            raise RuntimeError("flowmap_amd: packed masks do not match the depth shape")
+        if packed is not None and (packed.dtype != torch.float32 or not packed.is_contiguous() or w % 4 != 0
+                                   or tuple(packed.shape) != (b * f, (h * w // 4 + 63) // 64, 6, 64, 4)):
+            raise RuntimeError("flowmap_amd: packed flow inputs do not match the depth shape")
         acc = torch.empty((b * f * 2 * FLOW_ACC_STRIDE,), dtype=torch.float64, device=dev)
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
         g_depth = torch.empty_like(depth) if (need and ctx.needs_input_grad[0]) else None
@@ -390,7 +394,7 @@ class FlowLossFused(torch.autograd.Function):
             if events:
                 events[0].record()
             call("fm_flow_loss_fused", ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd),
-                 ptr(mask_fwd), ptr(mask_bwd), ptr(bits), ptr(norm) if need else None, b, f, h, w, kind, float(delta), w / scale, h / scale,
+                 ptr(mask_fwd), ptr(mask_bwd), ptr(packed), ptr(norm) if need else None, b, f, h, w, kind, float(delta), w / scale, h / scale,
                  ptr(g_depth), ptr(acc), int(items), st)
             if events:
                 events[1].record()

@@ -35,7 +35,7 @@ struct FlowParams {
   const float* flow_bwd;  // (B,F-1,H,W,2)
   const float* mask_fwd;  // (B,F-1,H,W)
   const float* mask_bwd;  // (B,F-1,H,W)
-  const uint8_t* mask_bits;  // (B,F,ceil(HW/4)) packed binary masks (fm_flow_pack_masks) or null
+  const float* packed;    // (B·F, chunks, 6, 64, 4) re-laid-out flows + masks (fm_flow_pack_inputs) or null
   const float* scale;     // device scalar multiplied into every per-residual gradient
   float* grad_depth;      // (B,F,H,W) or null
   double* acc;            // (B*F, 2, kFlowAccStride)
@@ -66,36 +66,48 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v4f ld4(const float* base, int i) { return FM_LOAD(reinterpret_cast<const v4f*>(base) + i); }
 __device__ __forceinline__ v2f ld2(const float* base, int i) { return FM_LOAD(reinterpret_cast<const v2f*>(base) + i); }
 
-// One quad's raw inputs, kept as the 16-byte vectors they were loaded as.  With packed
-// masks (PACKED) the two mask quads shrink to one byte: bits 0-3 forward, 4-7 backward.
-template <bool PACKED>
+// One quad's raw inputs, kept as the 16-byte vectors they were loaded as.
 struct QuadIn {
   v4f z, fa, fc, fm, ba, bc, bm;
 };
-template <>
-struct QuadIn<true> {
-  v4f z, fa, fc, ba, bc;
-  unsigned bits;
-};
 
-template <bool PACKED>
-__device__ __forceinline__ void load_quad(QuadIn<PACKED>& q, const float* depth, const float* ff, const float* mf, const float* fb,
-                                          const float* mb, const uint8_t* bits, int item, bool has_fwd, bool has_bwd) {
+// Reference layout: five separate arrays (depth, 2 flows, 2 masks) = 7 streams of 16 B per lane.
+__device__ __forceinline__ void load_quad(QuadIn& q, const float* depth, const float* ff, const float* mf, const float* fb,
+                                          const float* mb, int item, bool has_fwd, bool has_bwd) {
   q.z = ld4(depth, item);
-  if constexpr (PACKED) q.bits = FM_LOAD(bits + item);
   if (has_fwd) {
     q.fa = ld4(ff, item * 2);
     q.fc = ld4(ff, item * 2 + 1);
-    if constexpr (!PACKED) q.fm = ld4(mf, item);
+    q.fm = ld4(mf, item);
   }
   if (has_bwd) {
     q.ba = ld4(fb, item * 2);
     q.bc = ld4(fb, item * 2 + 1);
-    if constexpr (!PACKED) q.bm = ld4(mb, item);
+    q.bm = ld4(mb, item);
   }
 }
 
-__device__ __forceinline__ float mask_bit(unsigned bits, int i) { return (bits >> i) & 1u ? 1.f : 0.f; }
+// Packed layout (fm_flow_pack_inputs): the six flow / mask vectors of the 64 quads a wave
+// handles are ONE contiguous 6 KB chunk, [chunk][vector 0..5][lane], so a wave's six loads hit
+// consecutive kilobytes of one stream instead of six arrays hundreds of MB apart.
+constexpr int kPackLanes = 64;
+constexpr int kPackVecs = 6;
+
+__device__ __forceinline__ void load_quad_packed(QuadIn& q, const float* depth, const float* packed, int item, bool has_fwd,
+                                                 bool has_bwd) {
+  q.z = ld4(depth, item);
+  const int base = (item / kPackLanes) * (kPackVecs * kPackLanes) + (item % kPackLanes);
+  if (has_fwd) {
+    q.fa = ld4(packed, base);
+    q.fc = ld4(packed, base + kPackLanes);
+    q.fm = ld4(packed, base + 2 * kPackLanes);
+  }
+  if (has_bwd) {
+    q.ba = ld4(packed, base + 3 * kPackLanes);
+    q.bc = ld4(packed, base + 4 * kPackLanes);
+    q.bm = ld4(packed, base + 5 * kPackLanes);
+  }
+}
 
 #ifndef FM_FLOW_WAVES
 // Waves per SIMD the register allocator must leave room for.  3 (<=168 VGPRs, 133 used, no
@@ -147,7 +159,8 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   const float* mf = p.mask_fwd + pair_f * (size_t)n;
   const float* fb = p.flow_bwd + pair_b * (size_t)n * 2;
   const float* mb = p.mask_bwd + pair_b * (size_t)n;
-  const uint8_t* bits = PACKED ? p.mask_bits + (size_t)bf * ((n + 3) / 4) : nullptr;
+  const size_t chunks = ((size_t)items + kPackLanes - 1) / kPackLanes;
+  const float* packed = PACKED ? p.packed + (size_t)bf * chunks * (kPackVecs * kPackLanes * 4) : nullptr;
   float* gd = GRAD && p.grad_depth ? p.grad_depth + (size_t)bf * n : nullptr;
 
   float acc_f[kFlowAcc], acc_b[kFlowAcc];
@@ -168,9 +181,9 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
     const int col0 = (item - row * items_per_row) * VEC;
     const float v = pixel_center(row, p.height);
     const float v_ay = v * p.ay;
-    // m[:,1]·v + m[:,2] is constant along the image row the quad lies in
-    const float rf0 = fmaf(df.m[1], v, df.m[2]), rf1 = fmaf(df.m[4], v, df.m[5]), rf2 = fmaf(df.m[7], v, df.m[8]);
-    const float rb0 = fmaf(db.m[1], v, db.m[2]), rb1 = fmaf(db.m[4], v, db.m[5]), rb2 = fmaf(db.m[7], v, db.m[8]);
+    // a1·v + a2 (and b, c alike) is constant along the image row the quad lies in
+    const float rf0 = fmaf(df.a1, v, df.a2), rf1 = fmaf(df.b1, v, df.b2), rf2 = fmaf(df.c1, v, df.c2);
+    const float rb0 = fmaf(db.a1, v, db.a2), rb1 = fmaf(db.b1, v, db.b2), rb2 = fmaf(db.c1, v, db.c2);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float u = u_tab[col0 + e];
@@ -198,22 +211,14 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
     }
   };
 
-  auto compute_quad = [&](const QuadIn<PACKED>& q, int item) {
+  auto compute_quad = [&](const QuadIn& q, int item) {
     float z[VEC], fxf[VEC], fyf[VEC], mmf[VEC], fxb[VEC], fyb[VEC], mmb[VEC];
     if (VEC == 4) {
       z[0] = q.z.x; z[1 % VEC] = q.z.y; z[2 % VEC] = q.z.z; z[3 % VEC] = q.z.w;
       fxf[0] = q.fa.x; fyf[0] = q.fa.y; fxf[1 % VEC] = q.fa.z; fyf[1 % VEC] = q.fa.w;
       fxf[2 % VEC] = q.fc.x; fyf[2 % VEC] = q.fc.y; fxf[3 % VEC] = q.fc.z; fyf[3 % VEC] = q.fc.w;
-      if constexpr (PACKED) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          mmf[e] = mask_bit(q.bits, e);
-          mmb[e] = mask_bit(q.bits, 4 + e);
-        }
-      } else {
-        mmf[0] = q.fm.x; mmf[1 % VEC] = q.fm.y; mmf[2 % VEC] = q.fm.z; mmf[3 % VEC] = q.fm.w;
-        mmb[0] = q.bm.x; mmb[1 % VEC] = q.bm.y; mmb[2 % VEC] = q.bm.z; mmb[3 % VEC] = q.bm.w;
-      }
+      mmf[0] = q.fm.x; mmf[1 % VEC] = q.fm.y; mmf[2 % VEC] = q.fm.z; mmf[3 % VEC] = q.fm.w;
+      mmb[0] = q.bm.x; mmb[1 % VEC] = q.bm.y; mmb[2 % VEC] = q.bm.z; mmb[3 % VEC] = q.bm.w;
       fxb[0] = q.ba.x; fyb[0] = q.ba.y; fxb[1 % VEC] = q.ba.z; fyb[1 % VEC] = q.ba.w;
       fxb[2 % VEC] = q.bc.x; fyb[2 % VEC] = q.bc.y; fxb[3 % VEC] = q.bc.z; fyb[3 % VEC] = q.bc.w;
     }
@@ -226,8 +231,9 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
     const int item = base + it * blockDim.x + threadIdx.x;
     if (item >= items) break;
     if (VEC == 4) {
-      QuadIn<PACKED> q = {};
-      load_quad<PACKED>(q, depth, ff, mf, fb, mb, bits, item, has_fwd, has_bwd);
+      QuadIn q = {};
+      if constexpr (PACKED) load_quad_packed(q, depth, packed, item, has_fwd, has_bwd);
+      else load_quad(q, depth, ff, mf, fb, mb, item, has_fwd, has_bwd);
       compute_quad(q, item);
       continue;
     }
@@ -235,37 +241,27 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
     if (VEC == 2) {
       const v2f zq = ld2(depth, item);
       z[0] = zq.x; z[VEC - 1] = zq.y;
-      const unsigned mbits = PACKED ? (unsigned)bits[item >> 1] >> ((item & 1) * 2) : 0u;
       if (has_fwd) {
         const v4f a = ld4(ff, item);
+        const v2f mq = ld2(mf, item);
         fxf[0] = a.x; fyf[0] = a.y; fxf[VEC - 1] = a.z; fyf[VEC - 1] = a.w;
-        if constexpr (PACKED) {
-          mmf[0] = mask_bit(mbits, 0); mmf[VEC - 1] = mask_bit(mbits, 1);
-        } else {
-          const v2f mq = ld2(mf, item);
-          mmf[0] = mq.x; mmf[VEC - 1] = mq.y;
-        }
+        mmf[0] = mq.x; mmf[VEC - 1] = mq.y;
       }
       if (has_bwd) {
         const v4f a = ld4(fb, item);
+        const v2f mq = ld2(mb, item);
         fxb[0] = a.x; fyb[0] = a.y; fxb[VEC - 1] = a.z; fyb[VEC - 1] = a.w;
-        if constexpr (PACKED) {
-          mmb[0] = mask_bit(mbits, 4); mmb[VEC - 1] = mask_bit(mbits, 5);
-        } else {
-          const v2f mq = ld2(mb, item);
-          mmb[0] = mq.x; mmb[VEC - 1] = mq.y;
-        }
+        mmb[0] = mq.x; mmb[VEC - 1] = mq.y;
       }
     } else {
       z[0] = depth[item];
-      const unsigned mbits = PACKED ? (unsigned)bits[item >> 2] >> (item & 3) : 0u;
       if (has_fwd) {
         const float2 a = reinterpret_cast<const float2*>(ff)[item];
-        fxf[0] = a.x; fyf[0] = a.y; mmf[0] = PACKED ? mask_bit(mbits, 0) : mf[item];
+        fxf[0] = a.x; fyf[0] = a.y; mmf[0] = mf[item];
       }
       if (has_bwd) {
         const float2 a = reinterpret_cast<const float2*>(fb)[item];
-        fxb[0] = a.x; fyb[0] = a.y; mmb[0] = PACKED ? mask_bit(mbits, 4) : mb[item];
+        fxb[0] = a.x; fyb[0] = a.y; mmb[0] = mb[item];
       }
     }
     compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item);
@@ -340,31 +336,34 @@ __global__ void flow_norm_kernel(const double* vsum, float weight, float* norm) 
   norm[1] = (float)veff;
 }
 
-// One-time packing of the two fp32 validity masks into one byte per (source frame, 4 pixels):
-// bits 0-3 = forward mask of the pair the frame starts, bits 4-7 = backward mask of the pair
-// it ends.  Masks are 0/1 indicator images in the reference (flow/common.py consistency
-// test) and constant over an optimisation, so the fused kernel reads 1 B instead of 32 B of
-// mask per quad.  flag[0] is set when a value is neither 0 nor 1 (caller keeps fp32 masks).
-__global__ void __launch_bounds__(256) pack_masks_kernel(const float* mask_fwd, const float* mask_bwd, int frames, int n,
-                                                         uint8_t* bits, int* flag) {
-  const int groups = (n + 3) / 4;
+// One-time re-layout of the optimisation's constants (flows and masks never change after
+// FlowPredictor.compute_bidirectional_flow): for source frame f, quad q = 4 consecutive pixels,
+//   vec 0,1 = forward flow of pair f   (x0 y0 x1 y1 | x2 y2 x3 y3)     vec 2 = forward mask
+//   vec 3,4 = backward flow of pair f-1                                  vec 5 = backward mask
+// stored [frame][q/64][vec][q%64] as float4; absent pairs and the padding lanes are zero.
+__global__ void __launch_bounds__(256) pack_inputs_kernel(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd,
+                                                          const float* mask_bwd, int frames, int n, float* packed) {
+  const int quads = n / 4;
+  const int chunks = (quads + kPackLanes - 1) / kPackLanes;
   const int bf = blockIdx.y, f = bf % frames, b = bf / frames;
   const size_t pair_f = (size_t)b * (frames - 1) + f;
-  const float* mf = f < frames - 1 ? mask_fwd + pair_f * (size_t)n : nullptr;
-  const float* mb = f > 0 ? mask_bwd + (pair_f - 1) * (size_t)n : nullptr;
-  bool bad = false;
-  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += gridDim.x * blockDim.x) {
-    unsigned v = 0;
-    for (int e = 0; e < 4; ++e) {
-      const int i = g * 4 + e;
-      if (i >= n) break;
-      const float a = mf ? mf[i] : 0.f, c = mb ? mb[i] : 0.f;
-      bad |= !(a == 0.f || a == 1.f) || !(c == 0.f || c == 1.f);
-      v |= (a != 0.f ? 1u : 0u) << e | (c != 0.f ? 1u : 0u) << (4 + e);
-    }
-    bits[(size_t)bf * groups + g] = (uint8_t)v;
+  const bool has_fwd = f < frames - 1, has_bwd = f > 0;
+  const v4f zero = {0.f, 0.f, 0.f, 0.f};
+  v4f* out = reinterpret_cast<v4f*>(packed) + (size_t)bf * chunks * (kPackVecs * kPackLanes);
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < chunks * kPackLanes; q += gridDim.x * blockDim.x) {
+    const bool live = q < quads;
+    v4f* o = out + (size_t)(q / kPackLanes) * (kPackVecs * kPackLanes) + (q % kPackLanes);
+    const v4f* ff = reinterpret_cast<const v4f*>(flow_fwd + pair_f * (size_t)n * 2);
+    const v4f* fb = reinterpret_cast<const v4f*>(flow_bwd + (pair_f - 1) * (size_t)n * 2);
+    const v4f* mf = reinterpret_cast<const v4f*>(mask_fwd + pair_f * (size_t)n);
+    const v4f* mb = reinterpret_cast<const v4f*>(mask_bwd + (pair_f - 1) * (size_t)n);
+    o[0 * kPackLanes] = live && has_fwd ? ff[2 * q] : zero;
+    o[1 * kPackLanes] = live && has_fwd ? ff[2 * q + 1] : zero;
+    o[2 * kPackLanes] = live && has_fwd ? mf[q] : zero;
+    o[3 * kPackLanes] = live && has_bwd ? fb[2 * q] : zero;
+    o[4 * kPackLanes] = live && has_bwd ? fb[2 * q + 1] : zero;
+    o[5 * kPackLanes] = live && has_bwd ? mb[q] : zero;
   }
-  if (bad) atomicOr(flag, 1);
 }
 
 // In-place scale of gradient buffers by a device scalar, skipped entirely when the
@@ -383,24 +382,25 @@ extern "C" {
 
 int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
                        const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
-                       const uint8_t* mask_bits, const float* scale, int batch, int frames, int height, int width,
+                       const float* packed, const float* scale, int batch, int frames, int height, int width,
                        int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
                        int items_per_thread, void* stream) {
-  FM_CHECK_ARG(depth && k && kinv && flow_fwd && flow_bwd && acc);
-  FM_CHECK_ARG(mask_bits || (mask_fwd && mask_bwd));
+  FM_CHECK_ARG(depth && k && kinv && acc);
+  FM_CHECK_ARG(packed || (flow_fwd && flow_bwd && mask_fwd && mask_bwd));
   FM_CHECK_ARG(batch >= 1 && frames >= 2 && height >= 1 && width >= 1);
   FM_CHECK_ARG(mapping_kind >= 0 && mapping_kind <= 2);
   FM_CHECK_ARG((long)height * width < (1L << 30));
   FM_CHECK_ARG((long)batch * frames <= 65535);
   hipStream_t st = (hipStream_t)stream;
   const bool grad = scale != nullptr;
-  FlowParams p{depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, mask_bits, scale, grad_depth, acc,
-               frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 6};  // 1: 1.16, 2: 0.90, 3-8: 0.81-0.85 (noise ±3 %), 16: 0.87, 32: 0.91 ms @C1
+  FlowParams p{depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, grad_depth, acc,
+               frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 4};  // @C1: 2: 0.795, 4: 0.779, 6: 0.793, 8-12: 0.835 ms
   if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride, st) != hipSuccess) return FM_ERR_LAUNCH;
   auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  const bool packed = mask_bits != nullptr;
-  const bool vec4 = (width % 4 == 0) && aligned(depth) && aligned(flow_fwd) && aligned(flow_bwd) &&
-                    (packed || (aligned(mask_fwd) && aligned(mask_bwd))) && (!grad_depth || aligned(grad_depth));
+  const bool use_packed = packed != nullptr;
+  FM_CHECK_ARG(!use_packed || (width % 4 == 0 && aligned(packed) && aligned(depth) && (!grad_depth || aligned(grad_depth))));
+  const bool vec4 = use_packed || ((width % 4 == 0) && aligned(depth) && aligned(flow_fwd) && aligned(flow_bwd) && aligned(mask_fwd) &&
+                                   aligned(mask_bwd) && (!grad_depth || aligned(grad_depth)));
 #ifdef FM_FLOW_FORCE_VEC2
   const int vec = vec4 ? 2 : 1;
 #else
@@ -424,14 +424,14 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   } while (0)
 #define FM_FLOW_VEC(V)                 \
   do {                                 \
-    if (packed) FM_FLOW_KIND(V, true); \
+    if (use_packed) FM_FLOW_KIND(V, true); \
     else FM_FLOW_KIND(V, false);       \
   } while (0)
   if (vec == 4) FM_FLOW_VEC(4);
 #ifdef FM_FLOW_FORCE_VEC2
-  else if (vec == 2) FM_FLOW_VEC(2);
+  else if (vec == 2) FM_FLOW_KIND(2, false);
 #endif
-  else FM_FLOW_VEC(1);
+  else FM_FLOW_KIND(1, false);
 #undef FM_FLOW_VEC
 #undef FM_FLOW_KIND
 #undef FM_FLOW_LAUNCH
@@ -462,17 +462,17 @@ int fm_flow_valid_norm(const float* mask_fwd, const float* mask_bwd, long count,
   FM_LAUNCH_STATUS();
 }
 
-int fm_flow_pack_masks(const float* mask_fwd, const float* mask_bwd, int batch, int frames, int height, int width,
-                       uint8_t* mask_bits, int* nonbinary, void* stream) {
-  FM_CHECK_ARG(mask_fwd && mask_bwd && mask_bits && nonbinary);
-  FM_CHECK_ARG(batch >= 1 && frames >= 2 && height >= 1 && width >= 1 && (long)batch * frames <= 65535);
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(nonbinary, 0, sizeof(int), st) != hipSuccess) return FM_ERR_LAUNCH;
-  const int n = height * width, groups = (n + 3) / 4;
-  int bx = (groups + 255) / 256;
-  if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(pack_masks_kernel, dim3((unsigned)bx, (unsigned)(batch * frames)), dim3(256), 0, st, mask_fwd, mask_bwd, frames,
-                     n, mask_bits, nonbinary);
+int fm_flow_pack_inputs(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, int batch,
+                        int frames, int height, int width, float* packed, void* stream) {
+  FM_CHECK_ARG(flow_fwd && flow_bwd && mask_fwd && mask_bwd && packed);
+  FM_CHECK_ARG(batch >= 1 && frames >= 2 && height >= 1 && width >= 1 && width % 4 == 0 && (long)batch * frames <= 65535);
+  auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  FM_CHECK_ARG(aligned(flow_fwd) && aligned(flow_bwd) && aligned(mask_fwd) && aligned(mask_bwd) && aligned(packed));
+  const int n = height * width, quads = n / 4;
+  int bx = (quads + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)bx, (unsigned)(batch * frames)), dim3(256), 0, (hipStream_t)stream, flow_fwd,
+                     flow_bwd, mask_fwd, mask_bwd, frames, n, packed);
   FM_LAUNCH_STATUS();
 }
 

@@ -340,42 +340,55 @@ FM_HD float fm_rsq(float x) {
 #endif
 }
 
+// kd·X' is affine in the source pixel:  kd·(z·m·[u,v,1] + t) = z·(au·u + a1·v + a2) + ta  etc.
+// (kd = aspect-scaled rows 0,1 of K_dst, m = R·K⁻¹_src), so neither the camera-space point nor
+// p = X'/(Z'+eps) is ever formed:  pu = q·(z·a + ta),  dL/dz = ω·(a, b, −c).
 struct DirConst {
-  float m[9];
-  float t[3];
-  float kd[6];
+  float au, a1, a2, ta;  // a(u,v) = kd_row0·m·[u,v,1],  ta = kd_row0·t
+  float bu, b1, b2, tb;  // b(u,v) = kd_row1·m·[u,v,1],  tb = kd_row1·t
+  float cu, c1, c2, tc;  // c(u,v) = m_row2·[u,v,1] (Z' = z·c + tc),  tc = t[2]
 };
 
 FM_HD void make_dir(const Pose& pose, const Mat3& kinv, const Mat3& kd, float ax, float ay, DirConst& d) {
-  for (int r = 0; r < 3; ++r) {
+  double m[9], k0[3], k1[3];
+  for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c)
-      d.m[r * 3 + c] = pose.r[r * 3 + 0] * kinv.m[0 * 3 + c] + pose.r[r * 3 + 1] * kinv.m[1 * 3 + c] + pose.r[r * 3 + 2] * kinv.m[2 * 3 + c];
-    d.t[r] = pose.t[r];
-  }
+      m[r * 3 + c] = (double)pose.r[r * 3 + 0] * kinv.m[0 * 3 + c] + (double)pose.r[r * 3 + 1] * kinv.m[1 * 3 + c] +
+                     (double)pose.r[r * 3 + 2] * kinv.m[2 * 3 + c];
   for (int i = 0; i < 3; ++i) {
-    d.kd[i] = kd.m[i] * ax;
-    d.kd[3 + i] = kd.m[3 + i] * ay;
+    k0[i] = (double)kd.m[i] * ax;
+    k1[i] = (double)kd.m[3 + i] * ay;
   }
+  float* a = &d.au;
+  float* b = &d.bu;
+  float* c = &d.cu;
+  for (int j = 0; j < 3; ++j) {
+    a[j] = (float)(k0[0] * m[j] + k0[1] * m[3 + j] + k0[2] * m[6 + j]);
+    b[j] = (float)(k1[0] * m[j] + k1[1] * m[3 + j] + k1[2] * m[6 + j]);
+    c[j] = (float)m[6 + j];
+  }
+  d.ta = (float)(k0[0] * pose.t[0] + k0[1] * pose.t[1] + k0[2] * pose.t[2]);
+  d.tb = (float)(k1[0] * pose.t[0] + k1[1] * pose.t[1] + k1[2] * pose.t[2]);
+  d.tc = pose.t[2];
 }
 
-// row0..2 = m[:,1]·v + m[:,2] (constant along an image row); u_ax, v_ay = aspect·(u, v).
+// arow / brow / crow = a1·v + a2 etc. (constant along an image row); u_ax, v_ay = aspect·(u, v).
 template <int KIND, bool GRAD>
-FM_HD void flow_term_fast(const DirConst& d, float row0, float row1, float row2, float z, float u, float zu, float zv, float u_ax,
+FM_HD void flow_term_fast(const DirConst& d, float arow, float brow, float crow, float z, float u, float zu, float zv, float u_ax,
                           float v_ay, float flow_x, float flow_y, float m, float scale, float delta, float inv_delta, float ax,
                           float ay, float (&acc)[kFlowAcc], float& gz) {
-  const float mh0 = fmaf(d.m[0], u, row0);
-  const float mh1 = fmaf(d.m[3], u, row1);
-  const float mh2 = fmaf(d.m[6], u, row2);
-  const float x0 = fmaf(z, mh0, d.t[0]);
-  const float x1 = fmaf(z, mh1, d.t[1]);
-  const float x2 = fmaf(z, mh2, d.t[2]);
+  const float a = fmaf(d.au, u, arow);
+  const float b = fmaf(d.bu, u, brow);
+  const float c = fmaf(d.cu, u, crow);
+  const float xu = fmaf(z, a, d.ta);
+  const float xv = fmaf(z, b, d.tb);
+  const float x2 = fmaf(z, c, d.tc);
   float q = fm_rcp(x2 + kProjEps);
   const bool ok = fabsf(q) <= 3.0e38f;
   q = ok ? q : 0.f;
   m = ok ? m : 0.f;
-  const float p0 = x0 * q, p1 = x1 * q, p2 = x2 * q;
-  const float pu = fmaf(d.kd[0], p0, fmaf(d.kd[1], p1, d.kd[2] * p2));
-  const float pv = fmaf(d.kd[3], p0, fmaf(d.kd[4], p1, d.kd[5] * p2));
+  const float pu = xu * q;
+  const float pv = xv * q;
   const float rx = pu - fmaf(flow_x, ax, u_ax);
   const float ry = pv - fmaf(flow_y, ay, v_ay);
   const float ss = fmaf(rx, rx, ry * ry);
@@ -412,10 +425,7 @@ FM_HD void flow_term_fast(const DirConst& d, float row0, float row1, float row2,
     acc[10] = fmaf(o2, zu, acc[10]);
     acc[11] = fmaf(o2, zv, acc[11]);
     acc[12] = fmaf(o2, z, acc[12]);
-    const float g0 = fmaf(d.kd[0], o0, d.kd[3] * o1);       // dL/dX'
-    const float g1 = fmaf(d.kd[1], o0, d.kd[4] * o1);
-    const float g2 = fmaf(d.kd[2], o0, fmaf(d.kd[5], o1, -o2));
-    gz = fmaf(g0, mh0, fmaf(g1, mh1, fmaf(g2, mh2, gz)));
+    gz = fmaf(o0, a, fmaf(o1, b, fmaf(-o2, c, gz)));  // dL/dz = ω·(a, b, −c)
   }
 }
 

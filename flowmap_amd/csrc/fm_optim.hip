@@ -4,12 +4,33 @@
 // depth (F·N) + correspondence-weight logits ((F−1)·N) are 275 M fp32 parameters at C1, and
 // Adam moves 28 B per parameter (read p, g, m, v; write p, m, v) = 7.7 GB — 1.75x the bytes
 // of the fused loss kernel.  One streaming pass, 16-byte non-temporal accesses, nothing kept.
+//
+// Elements whose gradient AND both moments are exactly zero are fixed points of the update
+// (m = v = 0 -> step 0/(0+eps) = 0), so their three stores are skipped — bit-identical, and
+// it is the common case for the correspondence weights: only the P Procrustes sample points
+// of each pair (1000 of 921 600 at C1) ever receive a gradient (extrinsics_procrustes.py:45-52).
 #include "fm_device.h"
 #include "fm_math.h"
 
 namespace fm {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+
+// A/B knobs (tools/adam_microbench.py --lib): FM_ADAM_NO_NT_LOAD / FM_ADAM_NO_NT_STORE drop the
+// non-temporal hints, FM_ADAM_BLOCKS_PER_CU sets the grid (grid-stride loop beyond it).
+#ifdef FM_ADAM_NO_NT_LOAD
+#define FM_ALOAD(p) (*(p))
+#else
+#define FM_ALOAD(p) __builtin_nontemporal_load(p)
+#endif
+#ifdef FM_ADAM_NO_NT_STORE
+#define FM_ASTORE(v, p) (*(p) = (v))
+#else
+#define FM_ASTORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+#ifndef FM_ADAM_BLOCKS_PER_CU
+#define FM_ADAM_BLOCKS_PER_CU 4
+#endif
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
                                                    float* __restrict__ exp_avg_sq, long count, AdamCoef c, int vec_ok) {
@@ -23,19 +44,22 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, co
     v4f* m4 = reinterpret_cast<v4f*>(exp_avg);
     v4f* v4 = reinterpret_cast<v4f*>(exp_avg_sq);
     for (long i = tid; i < quads; i += stride) {
-      v4f p = __builtin_nontemporal_load(p4 + i);
-      const v4f g = __builtin_nontemporal_load(g4 + i);
-      v4f m = __builtin_nontemporal_load(m4 + i);
-      v4f v = __builtin_nontemporal_load(v4 + i);
+      v4f p = FM_ALOAD(p4 + i);
+      const v4f g = FM_ALOAD(g4 + i);
+      v4f m = FM_ALOAD(m4 + i);
+      v4f v = FM_ALOAD(v4 + i);
+      bool idle = c.weight_decay == 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        idle = idle && g[e] == 0.f && m[e] == 0.f && v[e] == 0.f;
         float pe = p[e], me = m[e], ve = v[e];
         adam_update(c, pe, g[e], me, ve);
         p[e] = pe; m[e] = me; v[e] = ve;
       }
-      __builtin_nontemporal_store(p, p4 + i);
-      __builtin_nontemporal_store(m, m4 + i);
-      __builtin_nontemporal_store(v, v4 + i);
+      if (idle) continue;
+      FM_ASTORE(p, p4 + i);
+      FM_ASTORE(m, m4 + i);
+      FM_ASTORE(v, v4 + i);
     }
     done = quads * 4;
   }
@@ -74,7 +98,7 @@ int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
   const int vec_ok = aligned(param) && aligned(grad) && aligned(exp_avg) && aligned(exp_avg_sq);
   long blocks = (count / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
-  if (blocks > 256L * 16) blocks = 256L * 16;  // 16 blocks per CU, grid-stride beyond that
+  if (blocks > 256L * FM_ADAM_BLOCKS_PER_CU) blocks = 256L * FM_ADAM_BLOCKS_PER_CU;  // grid-stride beyond that
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, count, c,
                      vec_ok);
   FM_LAUNCH_STATUS();

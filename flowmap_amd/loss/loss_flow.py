@@ -57,11 +57,11 @@ class LossFlow(Loss[LossFlowCfg]):
         else:
             rel_fwd, rel_bwd = _ops.RelativePoses.apply(model_output.extrinsics)
         norm = _ops.flow_valid_norm(flows.forward_mask, flows.backward_mask, weight, self.valid_sum_reducer)
-        bits = _ops.packed_flow_masks(flows.forward_mask, flows.backward_mask)  # None: masks are not 0/1 images
+        packed = _ops.packed_flow_inputs(flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)  # cached
         return _ops.FlowLossFused.apply(
             s.depths, model_output.intrinsics, rel_fwd, rel_bwd, flows.forward, flows.backward, flows.forward_mask,
             flows.backward_mask, norm, _ops.MAPPING_KINDS[self.mapping.kind], self.mapping.delta, self.carry_depth_grad,
-            self.items_per_thread or 0, bits,
+            self.items_per_thread or 0, packed,
         )
 
     def compute_weighted_loss(self, batch, flows, tracks, model_output, global_step: int, weight: float) -> Tensor:

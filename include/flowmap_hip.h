@@ -53,24 +53,25 @@ extern "C" {
  *   grad_depth (B,F,H,W) out: dL/ddepth with poses held fixed (may be NULL).
  *   acc (B*F, 2, FM_FLOW_ACC_STRIDE) fp64 out: per (source frame, direction) sums,
  *          zeroed by this call, consumed by fm_flow_loss_finalize.
- *   mask_bits: NULL, or the masks packed by fm_flow_pack_masks — then mask_fwd / mask_bwd
- *          are not read (may be NULL) and the kernel moves 8 B less per pixel and pair.
+ *   packed: NULL, or flows + masks re-laid-out by fm_flow_pack_inputs — then flow_* / mask_*
+ *          are not read (may be NULL).  Same bytes, one stream instead of six (needs W % 4 == 0).
  *   items_per_thread: tuning knob (<=0 -> default).
  */
 int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
                        const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
-                       const uint8_t* mask_bits, const float* scale, int batch, int frames, int height, int width,
+                       const float* packed, const float* scale, int batch, int frames, int height, int width,
                        int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
                        int items_per_thread, void* stream);
 
-/* The flow masks of the reference are 0/1 indicator images (flowmap/flow/common.py: the
- * forward-backward consistency test, cast to float) that never change during an
- * optimisation.  Packs them once into mask_bits (B,F,ceil(H·W/4)) bytes: for source frame f
- * and pixel group g, bits 0-3 = mask_fwd[pair f][4g..4g+3], bits 4-7 = mask_bwd[pair f-1][…]
- * (absent pairs read as 0).  nonbinary[0] (device int) is set to 1 when some mask value is
- * neither 0 nor 1; the caller must then keep passing the fp32 masks. */
-int fm_flow_pack_masks(const float* mask_fwd, const float* mask_bwd, int batch, int frames, int height, int width,
-                       uint8_t* mask_bits, int* nonbinary, void* stream);
+/* Flows and masks are constants of an optimisation (computed once by
+ * FlowPredictor.compute_bidirectional_flow, flowmap/flow/flow_predictor.py:82-102).  Copies them
+ * once into the layout the fused kernel streams best: per source frame f and quad q (4
+ * consecutive pixels), six float4 — forward flow of pair f (2), its mask (1), backward flow of
+ * pair f-1 (2), its mask (1) — stored [b·F+f][q/64][vector 0..5][q%64]; absent pairs and
+ * padding lanes are zero.  packed holds B·F·ceil(H·W/256)·6·64·4 floats (24 B per pixel and
+ * frame, i.e. the size of the originals).  Requires W % 4 == 0 and 16-byte aligned inputs. */
+int fm_flow_pack_inputs(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, int batch,
+                        int frames, int height, int width, float* packed, void* stream);
 
 /* Turns `acc` into: loss[0] = norm[0]·Σρm (loss.py:47 weight and loss_flow.py:70
  * normalisation folded into norm[0]); g_t_fwd / g_t_bwd (B,F-1,4,4) = dL/dT (bottom

@@ -300,9 +300,9 @@ def case_softmin_step(dev, seed=5):
     assert_close(model.backbone.weights.grad, wl.grad, 2e-3, abs_=1e-6, what="g_wlogit")
 
 
-def case_packed_masks(dev, hw=(18, 28)):
-    """fm_flow_pack_masks against a numpy packing, and the fused loss with packed masks
-    against the same loss with the fp32 masks (must be bit-identical: same arithmetic)."""
+def case_packed_inputs(dev, hw=(18, 28)):
+    """fm_flow_pack_inputs against a numpy re-layout, and the fused loss reading the packed
+    copy against the same loss reading the reference layout (identical arithmetic)."""
     import numpy as np
     from flowmap_amd import _ops
     from helpers import run_ours
@@ -311,34 +311,35 @@ def case_packed_masks(dev, hw=(18, 28)):
     f = 4
     depth, wlogit, oflows = orc.synth_iid(f, h, w, seed=11)
     focal = 0.85
-    g = torch.Generator().manual_seed(3)
-    oflows = orc.OFlows(oflows.forward, oflows.backward, (torch.rand((1, f - 1, h, w), generator=g) > 0.3).float(),
-                        (torch.rand((1, f - 1, h, w), generator=g) > 0.4).float())
-    mf, mb = oflows.forward_mask.to(dev), oflows.backward_mask.to(dev)
-    bits = _ops.packed_flow_masks(mf, mb)
-    assert bits is not None and bits.shape == (1, f, (h * w + 3) // 4)
-    n = h * w
-    pad = (-n) % 4
-    zero = np.zeros((1, n + pad), np.uint8)
-    for fr in range(f):
-        a = np.pad(mf[0, fr].reshape(1, n).cpu().numpy().astype(np.uint8), ((0, 0), (0, pad))) if fr < f - 1 else zero
-        c = np.pad(mb[0, fr - 1].reshape(1, n).cpu().numpy().astype(np.uint8), ((0, 0), (0, pad))) if fr > 0 else zero
-        shifts = np.arange(4, dtype=np.uint8)
-        want = (a.reshape(-1, 4) << shifts).sum(1) | ((c.reshape(-1, 4) << shifts).sum(1) << 4)
-        assert np.array_equal(bits[0, fr].cpu().numpy(), want.astype(np.uint8)), f"frame {fr}"
-    assert _ops.packed_flow_masks(mf, mb) is bits  # cached per Flows object
-
-    soft = mf.clone()
-    soft[0, 0, 0, 0] = 0.5  # a non-indicator mask keeps the fp32 path
-    assert _ops.packed_flow_masks(soft, mb) is None
+    ff, fb, mf, mb = (x.to(dev) for x in (oflows.forward, oflows.backward, oflows.forward_mask, oflows.backward_mask))
+    packed = _ops.packed_flow_inputs(ff, fb, mf, mb)
+    if w % 4 != 0:
+        assert packed is None  # the reference layout is streamed directly
+    else:
+        n, quads = h * w, h * w // 4
+        chunks = (quads + 63) // 64
+        assert packed.shape == (f, chunks, 6, 64, 4)
+        want = np.zeros((f, chunks * 64, 6, 4), np.float32)
+        for fr in range(f):
+            if fr < f - 1:
+                want[fr, :quads, 0:2] = ff[0, fr].reshape(quads, 2, 4).cpu().numpy()
+                want[fr, :quads, 2] = mf[0, fr].reshape(quads, 4).cpu().numpy()
+            if fr > 0:
+                want[fr, :quads, 3:5] = fb[0, fr - 1].reshape(quads, 2, 4).cpu().numpy()
+                want[fr, :quads, 5] = mb[0, fr - 1].reshape(quads, 4).cpu().numpy()
+        want = want.reshape(f, chunks, 64, 6, 4).transpose(0, 1, 3, 2, 4)
+        assert np.array_equal(packed.cpu().numpy(), want)
+        assert _ops.packed_flow_inputs(ff, fb, mf, mb) is packed  # cached per Flows object
+        mf.mul_(1.0)  # an in-place edit bumps the version: the copy is rebuilt
+        assert _ops.packed_flow_inputs(ff, fb, mf, mb) is not packed
 
     res = {}
-    for packed in (True, False):
-        _ops.use_packed_masks = packed
+    for use in (True, False):
+        _ops.use_packed_inputs = use
         try:
-            res[packed] = run_ours(depth, wlogit, focal, oflows, (h, w), 100, device=dev)
+            res[use] = run_ours(depth, wlogit, focal, oflows, (h, w), 100, device=dev)
         finally:
-            _ops.use_packed_masks = True
+            _ops.use_packed_inputs = True
     # identical arithmetic per residual; only the order of the float atomics differs run to run
     for key in ("total", "g_depth", "g_wlogit", "g_focal", "extrinsics"):
         assert_close(res[True][key], res[False][key], 1e-5, abs_=1e-9, what=key)

@@ -44,8 +44,8 @@ static void sim_flow(const float* depth, const float* k, const float* kinv, cons
     double* dst = acc + (size_t)bf * 2 * kFlowAccStride;
     for (int row = 0; row < height; ++row) {
       const float v = pixel_center(row, height), v_ay = v * ay;
-      const float rf0 = fmaf(df.m[1], v, df.m[2]), rf1 = fmaf(df.m[4], v, df.m[5]), rf2 = fmaf(df.m[7], v, df.m[8]);
-      const float rb0 = fmaf(db.m[1], v, db.m[2]), rb1 = fmaf(db.m[4], v, db.m[5]), rb2 = fmaf(db.m[7], v, db.m[8]);
+      const float rf0 = fmaf(df.a1, v, df.a2), rf1 = fmaf(df.b1, v, df.b2), rf2 = fmaf(df.c1, v, df.c2);
+      const float rb0 = fmaf(db.a1, v, db.a2), rb1 = fmaf(db.b1, v, db.b2), rb2 = fmaf(db.c1, v, db.c2);
       for (int col = 0; col < width; ++col) {
         const size_t px = (size_t)row * width + col;
         const float u = pixel_center(col, width);
@@ -79,24 +79,33 @@ extern "C" {
 
 int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
                        const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
-                       const uint8_t* mask_bits, const float* scale, int batch, int frames, int height, int width, int mapping_kind,
+                       const float* packed, const float* scale, int batch, int frames, int height, int width, int mapping_kind,
                        float delta, float ax, float ay, float* grad_depth, double* acc, int, void*) {
   std::memset(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride);
-  std::vector<float> unpacked_f, unpacked_b;
-  if (mask_bits) {  // expand the packed masks back to the fp32 layout the loop below reads
-    const size_t n = (size_t)height * width, groups = (n + 3) / 4;
-    unpacked_f.assign((size_t)batch * (frames - 1) * n, 0.f);
-    unpacked_b.assign((size_t)batch * (frames - 1) * n, 0.f);
+  std::vector<float> un_ff, un_fb, un_mf, un_mb;
+  if (packed) {  // expand back to the reference layout the loop below reads
+    const size_t n = (size_t)height * width, quads = n / 4, chunks = (quads + 63) / 64;
+    const size_t pairs = (size_t)batch * (frames - 1);
+    un_ff.assign(pairs * n * 2, 0.f); un_fb.assign(pairs * n * 2, 0.f); un_mf.assign(pairs * n, 0.f); un_mb.assign(pairs * n, 0.f);
     for (int b = 0; b < batch; ++b)
       for (int f = 0; f < frames; ++f)
-        for (size_t i = 0; i < n; ++i) {
-          const unsigned v = mask_bits[((size_t)b * frames + f) * groups + i / 4] >> (i % 4);
+        for (size_t q = 0; q < quads; ++q) {
+          const float* src = packed + ((((size_t)b * frames + f) * chunks + q / 64) * 6 * 64 + q % 64) * 4;
           const size_t pair = (size_t)b * (frames - 1) + f;
-          if (f < frames - 1) unpacked_f[pair * n + i] = (v & 1u) ? 1.f : 0.f;
-          if (f > 0) unpacked_b[(pair - 1) * n + i] = (v & 16u) ? 1.f : 0.f;
+          for (int e = 0; e < 4; ++e) {
+            if (f < frames - 1) {
+              un_ff[(pair * n + q * 4) * 2 + e] = src[0 * 256 + e];
+              un_ff[(pair * n + q * 4) * 2 + 4 + e] = src[1 * 256 + e];
+              un_mf[pair * n + q * 4 + e] = src[2 * 256 + e];
+            }
+            if (f > 0) {
+              un_fb[((pair - 1) * n + q * 4) * 2 + e] = src[3 * 256 + e];
+              un_fb[((pair - 1) * n + q * 4) * 2 + 4 + e] = src[4 * 256 + e];
+              un_mb[(pair - 1) * n + q * 4 + e] = src[5 * 256 + e];
+            }
+          }
         }
-    mask_fwd = unpacked_f.data();
-    mask_bwd = unpacked_b.data();
+    flow_fwd = un_ff.data(); flow_bwd = un_fb.data(); mask_fwd = un_mf.data(); mask_bwd = un_mb.data();
   }
   if (mapping_kind == kHuber)
     sim_flow<kHuber>(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, scale, batch, frames, height, width, delta, ax, ay, grad_depth, acc);
@@ -129,19 +138,28 @@ int fm_flow_valid_norm(const float* mask_fwd, const float* mask_bwd, long count,
   return 0;
 }
 
-int fm_flow_pack_masks(const float* mask_fwd, const float* mask_bwd, int batch, int frames, int height, int width,
-                       uint8_t* mask_bits, int* nonbinary, void*) {
-  const size_t n = (size_t)height * width, groups = (n + 3) / 4;
-  nonbinary[0] = 0;
-  std::memset(mask_bits, 0, (size_t)batch * frames * groups);
+int fm_flow_pack_inputs(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, int batch,
+                        int frames, int height, int width, float* packed, void*) {
+  if (width % 4 != 0) return 1;
+  const size_t n = (size_t)height * width, quads = n / 4, chunks = (quads + 63) / 64;
+  std::memset(packed, 0, sizeof(float) * (size_t)batch * frames * chunks * 6 * 64 * 4);
   for (int b = 0; b < batch; ++b)
     for (int f = 0; f < frames; ++f)
-      for (size_t i = 0; i < n; ++i) {
+      for (size_t q = 0; q < quads; ++q) {
+        float* dst = packed + ((((size_t)b * frames + f) * chunks + q / 64) * 6 * 64 + q % 64) * 4;
         const size_t pair = (size_t)b * (frames - 1) + f;
-        const float a = f < frames - 1 ? mask_fwd[pair * n + i] : 0.f;
-        const float c = f > 0 ? mask_bwd[(pair - 1) * n + i] : 0.f;
-        if (!(a == 0.f || a == 1.f) || !(c == 0.f || c == 1.f)) nonbinary[0] = 1;
-        mask_bits[((size_t)b * frames + f) * groups + i / 4] |= (uint8_t)(((a != 0.f) ? 1u : 0u) << (i % 4) | ((c != 0.f) ? 16u : 0u) << (i % 4));
+        for (int e = 0; e < 4; ++e) {
+          if (f < frames - 1) {
+            dst[0 * 256 + e] = flow_fwd[(pair * n + q * 4) * 2 + e];
+            dst[1 * 256 + e] = flow_fwd[(pair * n + q * 4) * 2 + 4 + e];
+            dst[2 * 256 + e] = mask_fwd[pair * n + q * 4 + e];
+          }
+          if (f > 0) {
+            dst[3 * 256 + e] = flow_bwd[((pair - 1) * n + q * 4) * 2 + e];
+            dst[4 * 256 + e] = flow_bwd[((pair - 1) * n + q * 4) * 2 + 4 + e];
+            dst[5 * 256 + e] = mask_bwd[(pair - 1) * n + q * 4 + e];
+          }
+        }
       }
   return 0;
 }

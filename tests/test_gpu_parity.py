@@ -240,9 +240,9 @@ def test_softmin_whole_step():
     cases.case_softmin_step(DEV)
 
 
-@pytest.mark.parametrize("hw", [(18, 28), (7, 9), (64, 96)])
-def test_packed_masks(hw):
-    cases.case_packed_masks(DEV, hw)
+@pytest.mark.parametrize("hw", [(18, 28), (7, 9), (64, 96), (30, 52)])
+def test_packed_inputs(hw):
+    cases.case_packed_inputs(DEV, hw)
 
 
 @pytest.mark.parametrize("weight_decay", [0.0, 0.01])

@@ -69,8 +69,8 @@ def test_softmin_whole_step():
 
 
 @pytest.mark.parametrize("hw", [(18, 28), (7, 9)])
-def test_packed_masks(hw):
-    cases.case_packed_masks("cpu", hw)
+def test_packed_inputs(hw):
+    cases.case_packed_inputs("cpu", hw)
 
 
 @pytest.mark.parametrize("weight_decay", [0.0, 0.01])

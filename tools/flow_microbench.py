@@ -46,15 +46,20 @@ for name, path in libs.items():
 def launch(fn, grad, ipt):
     st = torch.cuda.current_stream().cuda_stream
     return fn(depth.data_ptr(), k.data_ptr(), kinv.data_ptr(), t.data_ptr(), t.data_ptr(), ff.data_ptr(), fb.data_ptr(), mf.data_ptr(),
-              mb.data_ptr(), norm.data_ptr() if grad else None, 1, f, h, w, 0, 0.01, w / sc, h / sc, gd.data_ptr() if grad else None,
+              mb.data_ptr(), packed.data_ptr() if PACKED[0] else None, norm.data_ptr() if grad else None, 1, f, h, w, 0, 0.01, w / sc, h / sc, gd.data_ptr() if grad else None,
               acc.data_ptr(), ipt, st)
 
 
-configs = [(n, True, i) for n in fns for i in (1, 2, 3, 4, 6, 8)] + [("shipped", False, 8)]
+pack = ctypes.CDLL(libs["shipped"]).fm_flow_pack_inputs
+pack.argtypes = _lib.SIGNATURES["fm_flow_pack_inputs"]
+packed = torch.empty((f, (h * w // 4 + 63) // 64, 6, 64, 4), device=dev)
+assert pack(ff.data_ptr(), fb.data_ptr(), mf.data_ptr(), mb.data_ptr(), 1, f, h, w, packed.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+PACKED = [False]
+configs = [(n, True, i, pk) for n in fns for i in (2, 4, 6, 8) for pk in (False, True)] + [("shipped", False, 4, False), ("shipped", False, 4, True)]
 times = {c: [] for c in configs}
 for rnd in range(6):
     for c in configs:
-        name, grad, ipt = c
+        name, grad, ipt, PACKED[0] = c
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(3):
@@ -66,4 +71,4 @@ for rnd in range(6):
 for c, v in times.items():
     v.sort()
     med = v[len(v) // 2]
-    print(f"{c[0]:8s} grad={int(c[1])} ipt={c[2]:2d}  median {med:.4f} ms  min {v[0]:.4f}  -> {algo / med / 1e6:.0f} GB/s algorithmic (grad=1 bytes)")
+    print(f"{c[0]:8s} grad={int(c[1])} ipt={c[2]:2d} packed={int(c[3])}  median {med:.4f} ms  min {v[0]:.4f}  -> {algo / med / 1e6:.0f} GB/s algorithmic (grad=1 bytes)")

@@ -1,0 +1,64 @@
+"""Time the fused flow post-processing against the reference's op sequence on the same GPU
+(run through gpurun).  The reference sequence is restated with torch ops by the oracle
+(oracle.bidirectional_flows = flow_predictor.py:82-102); the network is a stand-in.
+
+    python tools/preprocess_bench.py [--frames 12 --height 2880 --width 5120 --scale 4]
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from flowmap_amd import _ops  # noqa: E402
+from oracle import flowmap_oracle as orc  # noqa: E402  (comparison only)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--height", type=int, default=2880)
+    ap.add_argument("--width", type=int, default=5120)
+    ap.add_argument("--scale", type=int, default=4)
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    f, h, w = args.frames, args.height, args.width
+    shape = (h // args.scale, w // args.scale)
+    g = torch.Generator(device=dev).manual_seed(0)
+    videos = torch.rand((1, f, 3, h, w), device=dev, generator=g)
+    raw_f = 0.01 * torch.randn((1, f - 1, h, w, 2), device=dev, generator=g)
+    raw_b = 0.01 * torch.randn((1, f - 1, h, w, 2), device=dev, generator=g)
+    flipped = videos.flip(dims=(1,))
+
+    def ours():
+        a = _ops.flow_postprocess(videos, raw_f, shape, reverse=False)
+        b = _ops.flow_postprocess(videos, raw_b, shape, reverse=True)
+        return a, b
+
+    def reference_ops():
+        return orc.bidirectional_flows(videos, lambda v: raw_f if v is videos else raw_b, shape)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.iters * 1e3, out
+
+    ms_ours, (fa, fb) = timed(ours)
+    ms_ref, fl = timed(reference_ops)
+    err = max(float((fa[0] - fl.forward).abs().max()), float((fa[1] - fl.forward_mask).abs().max()),
+              float((fb[0] - fl.backward).abs().max()), float((fb[1] - fl.backward_mask).abs().max()))
+    print(json.dumps({"frames": f, "full_res": [h, w], "flow_shape": list(shape), "ms_fused_hip": ms_ours,
+                      "ms_reference_ops_on_gpu": ms_ref, "speedup": ms_ref / ms_ours, "max_abs_diff": err}))
+
+
+if __name__ == "__main__":
+    main()
