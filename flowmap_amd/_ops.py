@@ -259,6 +259,9 @@ class ProcrustesFit(torch.autograd.Function):
             for scatter in pending:
                 scatter(g_src)
         if need_w:
+            # (zero-filling this 549 MB buffer early on a side stream, behind the latency-bound
+            # fit kernels, was measured: the fill's blocks delay those kernels and then contend
+            # with the fused flow kernel — step 1.126 -> 1.187 ms.  Kept in line.)
             g_w = torch.zeros_like(weights)
         kinv_acc = torch.zeros((b * f, 9), dtype=torch.float64, device=dev) if need_k else None
         with _guard(dev):

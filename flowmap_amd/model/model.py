@@ -20,17 +20,30 @@ from .extrinsics_procrustes import ExtrinsicsProcrustes, ExtrinsicsProcrustesCfg
 from .projection import LazyWeights, lazy_surfaces_enabled, sample_image_grid, unproject
 
 
+_K_CONSTANTS: dict = {}
+
+
+def _k_constants(image_shape: Tuple[int, int], device) -> Tuple[Tensor, Tensor]:
+    """(offset, divisor) with K = offset + f / divisor: the divisor is inf off the two focal
+    entries, so f/inf adds an exact 0 to the 0.5 / 1 / 0 entries of the offset."""
+    key = (tuple(image_shape), str(device))
+    if key not in _K_CONSTANTS:
+        h, w = image_shape
+        offset = torch.tensor([[0.0, 0.0, 0.5], [0.0, 0.0, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float32, device=device)
+        divisor = torch.full((3, 3), float("inf"), dtype=torch.float32, device=device)
+        divisor[0, 0], divisor[1, 1] = float(w), float(h)
+        _K_CONSTANTS[key] = (offset, divisor)
+    return _K_CONSTANTS[key]
+
+
 def focal_lengths_to_intrinsics(focal_lengths: Tensor, image_shape: Tuple[int, int]) -> Tensor:
-    """flowmap/model/intrinsics/common.py:6-20"""
-    device = focal_lengths.device
+    """flowmap/model/intrinsics/common.py:6-20: fx = f·√(hw)/w, fy = f·√(hw)/h, cx = cy = 0.5 —
+    the same two roundings (multiply, then divide), as one fused multiply-free launch pair
+    instead of eye / fill / broadcast-copy / two indexed assignments (and their backward)."""
     h, w = image_shape
-    focal_lengths = focal_lengths * (h * w) ** 0.5
-    intrinsics = torch.eye(3, dtype=torch.float32, device=device)
-    intrinsics[:2, 2] = 0.5
-    intrinsics = intrinsics.broadcast_to((*focal_lengths.shape, 3, 3)).contiguous()
-    intrinsics[..., 0, 0] = focal_lengths / w  # fx
-    intrinsics[..., 1, 1] = focal_lengths / h  # fy
-    return intrinsics
+    offset, divisor = _k_constants(image_shape, focal_lengths.device)
+    scaled = focal_lengths * (h * w) ** 0.5
+    return torch.addcdiv(offset, scaled[..., None, None], divisor)
 
 
 @dataclass
@@ -80,7 +93,9 @@ class IntrinsicsRegressed(nn.Module):
     def forward(self, batch, flows, backbone_output, global_step: int) -> Tensor:
         b, f, _, h, w = batch.videos.shape
         intrinsics = focal_lengths_to_intrinsics(self.focal_length, (h, w))
-        return intrinsics.expand(b, f, 3, 3)
+        # the reference returns the expanded view; every consumer here wants (b,f,3,3) in memory,
+        # so materialise it once instead of once per consumer
+        return intrinsics.expand(b, f, 3, 3).contiguous()
 
 
 @dataclass
