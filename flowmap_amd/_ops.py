@@ -166,6 +166,57 @@ def _find_fit_node(t: Tensor, depth_key, max_depth: int = 4):
     return None
 
 
+# Dense gradient buffers this backward pass has already handed to autograd, by source tensor:
+# (data_ptr, version, shape) -> weakref(buffer).  A later node whose own contribution to the same
+# tensor is tiny adds it into that buffer in place instead of emitting a second full-size tensor
+# for autograd to sum (see LeadingFrames).  Single use; a dead or missing entry means "emit".
+_emitted: dict = {}
+counters = {"leading_frames_in_place": 0, "leading_frames_dense": 0}  # which path LeadingFrames.backward took (tests)
+
+
+def _tensor_key(t: Tensor):
+    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+
+
+def _note_emitted(source_key, buffer: Optional[Tensor]) -> None:
+    if buffer is not None and source_key is not None:
+        if len(_emitted) > 8:
+            _emitted.clear()
+        _emitted[source_key] = weakref.ref(buffer)
+
+
+class LeadingFrames(torch.autograd.Function):
+    """``x[:, :count].contiguous()`` for (b, F, H, W) image stacks.  The softmin sweep reads two of
+    the 150 depth frames; autograd's slice backward would zero-fill a full-size tensor and add it
+    densely to the main path's gradient (1.7 GB of traffic at C1).  Autograd runs this node's
+    backward AFTER the nodes that consume the intrinsics it helped to produce, so the dense
+    gradient of ``x`` from the flow loss / extrinsics fit is already sitting in autograd's input
+    buffer: the ``count`` frames are added into it in place and nothing is returned.  Falls back
+    to the zero-padded tensor whenever that buffer is not known."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, count: int):
+        if x.dim() != 4 or not 1 <= count <= x.shape[1]:
+            raise RuntimeError("flowmap_amd: LeadingFrames expects (batch, frame, height, width) and 1 <= count <= frame")
+        ctx.shape, ctx.count, ctx.key = tuple(x.shape), count, _tensor_key(x)
+        return x[:, :count].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        ref = _emitted.pop(ctx.key, None)
+        buf = ref() if ref is not None else None
+        if buf is not None and tuple(buf.shape) == ctx.shape and buf.dtype == g.dtype and buf.device == g.device:
+            buf[:, : ctx.count].add_(g)
+            counters["leading_frames_in_place"] += 1
+            return None, None
+        counters["leading_frames_dense"] += 1
+        if ctx.count == ctx.shape[1]:
+            return g, None
+        full = g.new_zeros(ctx.shape)
+        full[:, : ctx.count] = g
+        return full, None
+
+
 class ProcrustesFit(torch.autograd.Function):
     """align_surfaces up to (not including) the pose chain (projection.py:213-249) with
     align_rigid (procrustes.py:7-51) inside.  Source of xyz is either
@@ -233,6 +284,8 @@ class ProcrustesFit(torch.autograd.Function):
         # same depth tensor, it parks its dense dL/ddepth here instead of returning it, and
         # this node (which autograd always runs later) scatters its sparse part into that
         # buffer and returns the sum once — no second dense tensor, no dense add.
+        ctx._fm_src_key = _tensor_key(depth if from_depth else surfaces)
+        ctx._fm_weights_key = _tensor_key(weights)
         ctx._fm_fit_depth_key = (depth.data_ptr(), depth._version, tuple(depth.shape)) if from_depth else None
         ctx._fm_carried = None
         ctx._fm_pending = []  # deferred scatters of other losses into the final dL/ddepth buffer
@@ -273,6 +326,8 @@ class ProcrustesFit(torch.autograd.Function):
             if need_k:
                 g_k = torch.empty_like(kinv)
                 call("fm_intrinsics_inverse_bwd", ptr(kinv_acc), ptr(kinv), b * f, ptr(g_k), 0, st)
+        _note_emitted(ctx._fm_src_key, g_src)
+        _note_emitted(ctx._fm_weights_key, g_w)
         if ctx.from_depth:
             return g_src, g_k, None, g_w, None, None, None, None
         return None, None, g_src, g_w, None, None, None, None

@@ -280,7 +280,11 @@ def case_softmin_step(dev, seed=5):
         batch = Batch(torch.zeros((1, f, 3, h, w), device=dev))
         out = model(batch, to_flows(oflows, dev), 0)
         loss = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))(batch, to_flows(oflows, dev), None, out, 0)
+        before = dict(fm._ops.counters)
         loss.backward()
+        # depth and weight-logit gradients of the sweep joined the main buffers in place
+        assert fm._ops.counters["leading_frames_in_place"] == before["leading_frames_in_place"] + 2
+        assert fm._ops.counters["leading_frames_dense"] == before["leading_frames_dense"]
     finally:
         fm.set_lazy_surfaces(False)
 
