@@ -51,3 +51,15 @@ def test_no_cpu_fallback():
     _lib.set_library_for_testing(None)
     with pytest.raises(RuntimeError, match="no CPU fallback|needs a GPU"):
         fm.get_extrinsics(torch.eye(4).repeat(1, 3, 1, 1))
+
+
+@pytest.mark.parametrize("name", sorted(_lib.SIGNATURES))
+def test_null_arguments_are_rejected_without_touching_the_gpu(name):
+    """Every entry point validates its arguments before the first HIP call and reports
+    FM_ERR_ARG (1) as a status — nothing is thrown across the boundary, nothing is launched."""
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    fn = getattr(lib, name)
+    fn.argtypes = _lib.SIGNATURES[name]
+    fn.restype = ctypes.c_int
+    zeros = [None if t is ctypes.c_void_p else t(0) for t in _lib.SIGNATURES[name]]
+    assert fn(*zeros) == 1
