@@ -91,14 +91,16 @@ def test_loss_scale_and_carry_gpu():
     assert_close(c["g_depth"], a["g_depth"], 1e-5)
 
 
-def test_full_size_properties_c1():
-    """BASELINE.json configs[1] at full size (150 x 720 x 1280): too big for the CPU
+@pytest.mark.parametrize("f,h,w,packed", [(150, 720, 1280, False), (150, 720, 1280, True), (150, 1080, 1920, True)],
+                         ids=["c1-reference-layout", "c1-packed", "c4-per-gpu-shard-packed"])
+def test_full_size_properties(f, h, w, packed):
+    """BASELINE.json configs[1] (150 x 720 x 1280) and one GPU's share of configs[4]
+    (150 x 1080 x 1920, 3.1e8 pixels: 64-bit base offsets) at full size: too big for the CPU
     oracle in test time, so check size-independent properties: run-to-run agreement and
     additivity of the loss numerator over frame shards (pairs [0,75) + [75,149))."""
     from flowmap_amd import _ops
     from flowmap_amd.model.projection import sample_image_grid  # noqa: F401
 
-    f, h, w = 150, 720, 1280
     g = torch.Generator(device=DEV).manual_seed(0)
     depth = 1.10 + 0.05 * torch.rand((1, f, h, w), device=DEV, generator=g)
     k = torch.tensor([[0.85 * (h * w) ** 0.5 / w, 0, 0.5], [0, 0.85 * (h * w) ** 0.5 / h, 0.5], [0, 0, 1.0]], device=DEV).expand(1, f, 3, 3).contiguous()
@@ -115,8 +117,10 @@ def test_full_size_properties_c1():
         ext = _ops.PoseChain.apply(rel)
         rf, rb = _ops.RelativePoses.apply(ext)
         norm = torch.tensor([1.0, 1.0], device=DEV)  # un-normalised numerator
-        loss = _ops.FlowLossFused.apply(d, k[:, lo : hi + 1].contiguous(), rf, rb, ff[:, lo:hi].contiguous(), fb[:, lo:hi].contiguous(),
-                                        mf[:, lo:hi].contiguous(), mb[:, lo:hi].contiguous(), norm, 0, 0.01, True, 0)
+        parts = [x[:, lo:hi].contiguous() for x in (ff, fb, mf, mb)]
+        pk = _ops.packed_flow_inputs(*parts) if packed else None
+        assert (pk is not None) == packed
+        loss = _ops.FlowLossFused.apply(d, k[:, lo : hi + 1].contiguous(), rf, rb, *parts, norm, 0, 0.01, True, 0, pk)
         loss.backward()
         return loss.detach().double().cpu(), d.grad
 
