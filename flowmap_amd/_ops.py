@@ -23,6 +23,7 @@ FLOW_ACC_STRIDE = 20
 STAT_STRIDE = 16
 AUX_STRIDE = 32
 PAIR_GRAD_STRIDE = 20
+TRACK_TILE = 6  # FM_TRACK_TILE (include/flowmap_hip.h; tests/test_abi.py checks they agree)
 
 
 def _f32c(t: Tensor, what: str) -> Tensor:
@@ -706,7 +707,7 @@ class PackedTracks:
     arrays fm_track_* expects.  Tracks are constants of the optimisation: packed once."""
 
     def __init__(self, tracks, device):
-        xy, vis, seg, blocks = [], [], [], []
+        xy, vis, seg, blocks, tiles = [], [], [], [], []
         offset = 0
         for s_idx, t in enumerate(tracks):
             b, f, p, _ = t.xy.shape
@@ -716,6 +717,7 @@ class PackedTracks:
             vis.append(t.visibility[0].reshape(f * p).to(device=device, dtype=torch.uint8))
             seg.append([int(t.start_frame), f, p, offset])
             blocks.extend([s_idx, fr] for fr in range(f))
+            tiles.extend([s_idx, fr] for fr in range(0, f, TRACK_TILE))
             offset += f * p
         self.total = offset
         self.xy = torch.cat(xy).contiguous()
@@ -723,6 +725,8 @@ class PackedTracks:
         self.seg = torch.tensor(seg, dtype=torch.int32).to(device)
         self.blocks = torch.tensor(blocks, dtype=torch.int32).to(device)
         self.nblocks = len(blocks)
+        self.tiles = torch.tensor(tiles, dtype=torch.int32).to(device)  # (segment, first source frame) per register tile
+        self.ntiles = len(tiles)
         self.pmax = max(s_[2] for s_ in seg)
         self.fmax = max(s_[1] for s_ in seg)
         self.last_frame = max(s_[0] + s_[1] for s_ in seg)
@@ -760,22 +764,30 @@ class TrackLossFused(torch.autograd.Function):
             raise RuntimeError("flowmap_amd: a track segment extends past the last frame")
         kinv = intrinsics_inverse(k)
         ext_inv = torch.empty_like(ext)
-        ws = torch.empty((packed.total, 6), dtype=torch.float32, device=dev)
+        ws = torch.empty((packed.total, 9), dtype=torch.float32, device=dev)
         flag = torch.empty((packed.total,), dtype=torch.uint8, device=dev)
-        acc = torch.empty((f * 20 + 2,), dtype=torch.float64, device=dev)
+        acc = torch.empty((f * 20,), dtype=torch.float64, device=dev)
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
         scale = torch.empty((2,), dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad[:3])
+        # every residual is evaluated once: the (unscaled) gradients come out of the same launch
+        gws = torch.empty((packed.total, 3), dtype=torch.float32, device=dev) if need else None
+        acc2 = torch.empty((f * 24,), dtype=torch.float64, device=dev) if need else None
+        tgt = torch.empty((f, 12), dtype=torch.float32, device=dev)
+        partial = torch.empty((packed.ntiles * ((packed.pmax + 63) // 64) * (packed.fmax * 14 + TRACK_TILE * 21),), dtype=torch.float32,
+                              device=dev)  # per-wave sums (FM_TRACK_PARTIAL), reduced per frame without atomics
         sc = (h * w) ** 0.5
         with _guard(dev):
             st = stream_for(depth)
             call("fm_extrinsics_inverse", ptr(ext), f, ptr(ext_inv), st)
-            call("fm_track_points", ptr(depth), ptr(kinv), ptr(ext), ptr(packed.xy), ptr(packed.vis), ptr(packed.seg),
-                 ptr(packed.blocks), packed.nblocks, packed.pmax, h, w, ptr(ws), ptr(flag), st)
-            call("fm_track_loss_fwd", ptr(ws), ptr(flag), ptr(packed.xy), ptr(packed.vis), ptr(packed.seg), ptr(packed.blocks),
-                 packed.nblocks, packed.pmax, ptr(ext_inv), ptr(k), f, h, w, kind, float(delta), w / sc, h / sc, float(weight),
-                 ptr(acc), ptr(loss), ptr(scale), st)
-        ctx.save_for_backward(depth, k, ext, kinv, ext_inv, ws, flag, acc, scale)
-        ctx.packed, ctx.cfg, ctx.dims = packed, (kind, float(delta), w / sc, h / sc), (f, h, w)
+            call("fm_track_points", ptr(depth), ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), f, ptr(packed.xy), ptr(packed.vis),
+                 ptr(packed.seg), ptr(packed.blocks), packed.nblocks, packed.pmax, h, w, ptr(ws), ptr(flag), ptr(tgt), st)
+            call("fm_track_loss_fwd", ptr(ws), ptr(flag), ptr(packed.xy), ptr(packed.vis), ptr(packed.seg), ptr(packed.tiles),
+                 packed.ntiles, packed.pmax, packed.fmax, ptr(ext), ptr(tgt), f, h, w, kind, float(delta), w / sc, h / sc,
+                 float(weight), ptr(partial), ptr(acc), ptr(loss), ptr(scale), ptr(gws), ptr(acc2), st)
+        ctx.save_for_backward(k, kinv, ext_inv, flag, acc, scale)
+        ctx.grads = (gws, acc2) if need else None
+        ctx.packed, ctx.dims, ctx.shapes = packed, (f, h, w), (tuple(depth.shape), tuple(k.shape), tuple(ext.shape))
         ctx.fit_node = None
         if defer and ctx.needs_input_grad[0]:
             node = _find_fit_node(ext, (depth.data_ptr(), depth._version, tuple(depth.shape)))
@@ -785,25 +797,26 @@ class TrackLossFused(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        depth, k, ext, kinv, ext_inv, ws, flag, acc, scale = ctx.saved_tensors
+        if ctx.grads is None:
+            raise RuntimeError("flowmap_amd: TrackLossFused gradients are single-use; run the forward again")
+        k, kinv, ext_inv, flag, acc, scale = ctx.saved_tensors
+        gws, acc2 = ctx.grads
+        ctx.grads = None
+        depth_shape, k_shape, ext_shape = ctx.shapes
         pk: PackedTracks = ctx.packed
-        kind, delta, ax, ay = ctx.cfg
         f, h, w = ctx.dims
-        dev = depth.device
+        dev = kinv.device
         g = g.reshape(1).to(torch.float32).contiguous()
-        gws = torch.empty((pk.total, 3), dtype=torch.float32, device=dev)
-        acc2 = torch.empty((f * 24,), dtype=torch.float64, device=dev)
-        g_ext = torch.empty_like(ext)
-        g_k = torch.empty_like(k)
+        g_ext = torch.empty(ext_shape, dtype=torch.float32, device=dev)
+        g_k = torch.empty(k_shape, dtype=torch.float32, device=dev)
         with _guard(dev):
-            call("fm_track_loss_bwd", ptr(ws), ptr(flag), ptr(pk.xy), ptr(pk.vis), ptr(pk.seg), ptr(pk.blocks), pk.nblocks, pk.pmax,
-                 pk.fmax, ptr(depth), ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), f, h, w, kind, delta, ax, ay, ptr(acc), ptr(scale),
-                 ptr(g), ptr(gws), ptr(acc2), ptr(g_ext), ptr(g_k), stream_for(depth))
+            call("fm_track_loss_bwd", ptr(acc), ptr(acc2), ptr(scale), ptr(g), ptr(ext_inv), ptr(k), ptr(kinv), f, ptr(g_ext), ptr(g_k),
+                 stream_for(kinv))
 
         def scatter(buffer: Tensor) -> None:
             with _guard(dev):
                 call("fm_track_scatter", ptr(gws), ptr(flag), ptr(pk.xy), ptr(pk.vis), ptr(pk.seg), ptr(pk.blocks), pk.nblocks,
-                     pk.pmax, ptr(kinv), h, w, ptr(buffer), stream_for(buffer))
+                     pk.pmax, ptr(kinv), ptr(scale), ptr(g), h, w, ptr(buffer), stream_for(buffer))
 
         g_depth = None
         if ctx.needs_input_grad[0]:
@@ -812,7 +825,7 @@ class TrackLossFused(torch.autograd.Function):
             if node is not None:
                 node._fm_pending.append(scatter)  # lands in the buffer ProcrustesFit.backward returns
             else:
-                g_depth = torch.zeros_like(depth)
+                g_depth = torch.zeros(depth_shape, dtype=torch.float32, device=dev)
                 scatter(g_depth)
         need = ctx.needs_input_grad
         return g_depth, g_k if need[1] else None, g_ext if need[2] else None, None, None, None, None, None

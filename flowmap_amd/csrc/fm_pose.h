@@ -321,4 +321,139 @@ FM_HD void flow_finalize_frame(const double* acc, const float* k_all, const floa
   for (int i = 0; i < 9; ++i) g_k[(size_t)bf * 9 + i] = (float)gk[i];
 }
 
+// ---------------------------------------------------------------------------------
+// Point-tracking loss (compute_track_flow, projection.py:255-298; LossTracking,
+// loss_tracking.py:28-61) — the per-residual, per-source and per-frame steps shared by
+// fm_track.hip and the host double.
+//
+// Work-space per (frame-in-segment, point): ws[kTrackWs] =
+//   [0..2] xyz   camera-space point sampled from the source frame's surface
+//   [3..5] X_w   = E_fs · [xyz; 1]
+//   [6..8] h     = Σ_taps w_k · z_k · [u_k, v_k, 1]   (xyz = K⁻¹ · h: carries dL/dK⁻¹)
+// Per target frame, kTrackTgt constants (track_target): with Einv = inv(E_ft)[:3,:] (3x4),
+//   au = K_row0 · Einv, av = K_row1 · Einv, c = Einv_row2   =>   u = q·(au·[X_w;1]),
+//   v = q·(av·[X_w;1]), q = 1/(c·[X_w;1] + eps)   (the affine form of fm_math.h's flow term).
+// Per-frame accumulators (fp64), all UNSCALED (the visible count is only known at the end):
+//   acc [kTrackAccStride]  target role: [0..11] S = Σ ω ⊗ [X_w;1] with
+//                          ω = (q·w_u, q·w_v, q·(w_u·u + w_v·v)), w = dL/d(u,v);  [18] Σ ρ, [19] count
+//   acc2[kTrackAcc2Stride] source role: [0..11] Σ gX_w ⊗ [xyz;1], [12..20] Σ gxyz ⊗ h
+// ---------------------------------------------------------------------------------
+constexpr int kTrackWs = 9;
+constexpr int kTrackTgt = 12;
+constexpr int kTrackAccStride = 20;
+constexpr int kTrackAcc2Stride = 24;
+constexpr int kTrackSums = 14;  // values track_pair_term accumulates: S (12), Σρ, count
+
+FM_HD void track_target(const float* ext_inv44, const float* k33, float* tgt) {
+  for (int j = 0; j < 4; ++j) {
+    double au = 0, av = 0;
+    for (int r = 0; r < 3; ++r) {
+      au += (double)k33[r] * ext_inv44[r * 4 + j];
+      av += (double)k33[3 + r] * ext_inv44[r * 4 + j];
+    }
+    tgt[j] = (float)au;
+    tgt[4 + j] = (float)av;
+    tgt[8 + j] = ext_inv44[8 + j];
+  }
+}
+
+// One (source fs, target ft, point) residual: adds into the target-role sums a[kTrackSums]
+// (S in [0..11], Σρ in [12], count in [13]) and the source point's dL/dX_w.  Branch-free:
+// hardware rcp / rsq, mapping kind a template parameter, invisibility (projection.py:290-296:
+// the target must land inside [0,1)²) a 0/1 factor.  A point exactly on the camera plane
+// (Z'+eps == 0) projects to ±1e8 in the reference and is invisible there too.
+template <int KIND, bool GRAD>
+FM_HD void track_pair_term(const float (&tg)[kTrackTgt], const float xw[3], float gt_x, float gt_y, float m, float delta,
+                           float inv_delta, float ax, float ay, float (&a)[kTrackSums], float gxw[3]) {
+  const float xu = fmaf(tg[0], xw[0], fmaf(tg[1], xw[1], fmaf(tg[2], xw[2], tg[3])));
+  const float xv = fmaf(tg[4], xw[0], fmaf(tg[5], xw[1], fmaf(tg[6], xw[2], tg[7])));
+  const float x2 = fmaf(tg[8], xw[0], fmaf(tg[9], xw[1], fmaf(tg[10], xw[2], tg[11])));
+  float q = fm_rcp(x2 + kProjEps);
+  const bool ok = fabsf(q) <= 3.0e38f;
+  q = ok ? q : 0.f;
+  const float u = xu * q, v = xv * q;
+  const bool inside = ok && u >= 0.f && v >= 0.f && u < 1.f && v < 1.f;
+  m = inside ? m : 0.f;
+  const float rx = (u - gt_x) * ax, ry = (v - gt_y) * ay;  // exact 0 for equal inputs (cf. aspect_diff)
+  const float ss = fmaf(rx, rx, ry * ry);
+  float rho, coef;  // ρ and dρ/dr = coef·r
+  if (KIND == kL2) {
+    rho = 0.5f * ss;
+    coef = 1.f;
+  } else {
+    const float inv_n = ss > 0.f ? fm_rsq(ss) : 0.f;
+    const float n = ss * inv_n;
+    if (KIND == kL1) {
+      rho = n;
+      coef = inv_n;
+    } else {
+      const bool quad = n < delta;
+      rho = quad ? 0.5f * ss * inv_delta : n - 0.5f * delta;
+      coef = quad ? inv_delta : inv_n;
+    }
+  }
+  a[12] = fmaf(rho, m, a[12]);
+  a[13] += m;
+  if (!GRAD) return;
+  const float gc = m * coef;
+  const float wu = gc * rx * ax, wv = gc * ry * ay;  // dL/du, dL/dv (unscaled)
+  const float o0 = q * wu, o1 = q * wv, o2 = q * fmaf(wu, u, wv * v);
+  a[0] = fmaf(o0, xw[0], a[0]);
+  a[1] = fmaf(o0, xw[1], a[1]);
+  a[2] = fmaf(o0, xw[2], a[2]);
+  a[3] += o0;
+  a[4] = fmaf(o1, xw[0], a[4]);
+  a[5] = fmaf(o1, xw[1], a[5]);
+  a[6] = fmaf(o1, xw[2], a[6]);
+  a[7] += o1;
+  a[8] = fmaf(o2, xw[0], a[8]);
+  a[9] = fmaf(o2, xw[1], a[9]);
+  a[10] = fmaf(o2, xw[2], a[10]);
+  a[11] += o2;
+  gxw[0] = fmaf(o0, tg[0], fmaf(o1, tg[4], fmaf(-o2, tg[8], gxw[0])));  // dL/dX_w = ω·(au, av, −c)
+  gxw[1] = fmaf(o0, tg[1], fmaf(o1, tg[5], fmaf(-o2, tg[9], gxw[1])));
+  gxw[2] = fmaf(o0, tg[2], fmaf(o1, tg[6], fmaf(-o2, tg[10], gxw[2])));
+}
+
+// Source-role step of one point once its dL/dX_w is complete: b[21] = this point's terms of
+// acc2, gxyz = dL/dxyz = R_fsᵀ · gX_w (scattered into dL/ddepth by fm_track_scatter).
+FM_HD void track_source_term(const Pose& e_s, const float* ws9, const float gxw[3], float (&b)[21], float gxyz[3]) {
+  for (int r = 0; r < 3; ++r) {
+    b[r * 4 + 0] = gxw[r] * ws9[0];
+    b[r * 4 + 1] = gxw[r] * ws9[1];
+    b[r * 4 + 2] = gxw[r] * ws9[2];
+    b[r * 4 + 3] = gxw[r];
+  }
+  apply_rot_t(e_s, gxw, gxyz);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) b[12 + r * 3 + c] = gxyz[r] * ws9[6 + c];
+}
+
+// dL/dE (4x4) and dL/dK (3x3) of one frame from its two accumulators; sc = weight/count·upstream.
+FM_HD void track_frame_grads(const double* a, const double* b, double sc, const float* ext_inv, const float* k, const float* kinv,
+                             float* g_ext, float* g_k) {
+  // target role.  au = K_row0·Einv, av = K_row1·Einv, c = Einv_row2 and S_i = Σ ω_i [X_w;1]:
+  //   dL/dEinv[r][j] = K[0][r]·S0[j] + K[1][r]·S1[j] − (r == 2)·S2[j];   dL/dK[i][r] = Einv[r,:]·S_i
+  // then dE = −Einvᵀ·dEinv·Einvᵀ (E⁻¹ of a general 4x4, bottom row of dEinv zero).
+  double ginv[16], inv[16], tmp[16], tmp2[16], gk[9];
+  for (int i = 0; i < 16; ++i) inv[i] = ext_inv[i];
+  for (int r = 0; r < 3; ++r)
+    for (int j = 0; j < 4; ++j)
+      ginv[r * 4 + j] = ((double)k[r] * a[j] + (double)k[3 + r] * a[4 + j] - (r == 2 ? a[8 + j] : 0.0)) * sc;
+  for (int i = 12; i < 16; ++i) ginv[i] = 0.0;
+  mat4_mul_tn(inv, ginv, tmp);
+  mat4_mul_nt(tmp, inv, tmp2);
+  for (int i = 0; i < 16; ++i) g_ext[i] = (float)(-tmp2[i] + (i < 12 ? b[i] * sc : 0.0));
+  // intrinsics: source role through K⁻¹ (rows of b[12..20]) + destination role (rows 0,1)
+  kinv_grad_to_k(b + 12, kinv, gk);
+  for (int i = 0; i < 9; ++i) gk[i] *= sc;
+  for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 3; ++r) {
+      double d = 0;
+      for (int j = 0; j < 4; ++j) d += inv[r * 4 + j] * a[i * 4 + j];
+      gk[i * 3 + r] += d * sc;
+    }
+  for (int i = 0; i < 9; ++i) g_k[i] = (float)gk[i];
+}
+
 }  // namespace fm

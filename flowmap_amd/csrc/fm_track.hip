@@ -13,26 +13,30 @@
 //   L     = weight · Σ ρ(uv, xy[ft,p]) · vis / max(Σ vis, 1)          (loss_tracking.py:55-61)
 // surfaces are recomputed from depth and K⁻¹ (never stored).
 //
-// Launch plan (VALU/latency-bound, inputs ≈ 13 MB -> L2 resident):
+// Launch plan (VALU/latency-bound, inputs ≈ 13 MB):
 //   track_points   one thread per (frame-in-segment, point): sample xyz, lift to world
-//                  X_w = E_fs·xyz, fold visibility ∧ source-in-frame into one byte.
-//   track_fwd      block per (segment, TARGET frame, point chunk), loop over sources:
-//                  loss sum, visible count, Σ gX' ⊗ [X_w;1] (-> dL/d inv(E_ft)) and the
-//                  K_ft gradient, all UNSCALED (count is not known yet).
+//                  X_w = E_fs·xyz, keep h = Σ w_k z_k [u_k,v_k,1], fold visibility ∧
+//                  source-in-frame into one byte.
+//   track_pairs    EVERY residual evaluated ONCE.  A thread owns one point and a tile of
+//                  kTrackTile source frames held in registers (X_w and its running gradient),
+//                  and loops over all target frames: the target-role sums (loss, count,
+//                  Σ gX'⊗[X_w;1], dK) are block-reduced per target frame, the source-role
+//                  gradient gX_w accumulates in registers and is finished in an epilogue
+//                  (dL/dxyz per point, dL/dE_fs, dL/dK⁻¹ sums).  All UNSCALED: the visible
+//                  count is not known until the launch ends.
 //   finalize_fwd   loss, count, scale = weight / max(count, 1).
-//   track_bwd      block per (segment, SOURCE frame, point chunk), loop over targets:
-//                  gX_w = Σ_ft R_invᵀ gX' in registers, then one scatter per point into
-//                  dL/ddepth (4 taps, atomics) + per-frame sums for dL/dE_fs, dL/dK⁻¹.
-//   finalize_bwd   small-matrix chain rules -> dL/dE (F,4,4), dL/dK (F,3,3).
-// The forward chain is evaluated twice (once per pass) instead of keeping per-(fs,ft,p)
-// state or doing a 20-value block reduction per (fs,ft) pair.
+//   finalize_bwd   small-matrix chain rules -> dL/dE (F,4,4), dL/dK (F,3,3), scaled.
+//   track_scatter  per-point dL/dxyz -> dL/ddepth through the 4 bilinear taps (atomics), scaled.
+// (First version: a target-major and a source-major pass, each re-evaluating the whole
+// chain: 0.47 ms at C2; this one: see DESIGN.md §3.4.)
+#include "../../include/flowmap_hip.h"
 #include "fm_device.h"
 #include "fm_pose.h"
 
 namespace fm {
 
-constexpr int kTrackAccStride = 20;   // per frame: [0..11] Σ gX'⊗[X_w;1], [12..17] dK rows 0,1
-constexpr int kTrackAcc2Stride = 24;  // per frame: [0..11] Σ gX_w⊗[xyz;1], [12..20] dKinv
+constexpr int kTrackTile = FM_TRACK_TILE;  // source frames per thread (registers: 2 x 3 x kTrackTile floats)
+__host__ __device__ constexpr size_t track_partial_stride(int fmax) { return (size_t)fmax * kTrackSums + kTrackTile * 21; }
 
 struct TrackGeom {
   const float* xy;        // (total, 2) packed track positions
@@ -58,206 +62,213 @@ __global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const fl
   load_pose44(ext + (size_t)frame * 16, e);
   const Taps t = bilinear_taps(q.x, q.y, g.height, g.width);
   const float* d = depth + (size_t)frame * g.height * g.width;
-  float xyz[3] = {0.f, 0.f, 0.f};
+  float xyz[3] = {0.f, 0.f, 0.f}, hh[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (!t.in[k]) continue;
     const int tc = tap_col(t, k), tr = tap_row(t, k);
+    const float ut = pixel_center(tc, g.width), vt = pixel_center(tr, g.height);
     float ray[3];
-    ray_dir(ki, pixel_center(tc, g.width), pixel_center(tr, g.height), ray);
+    ray_dir(ki, ut, vt, ray);
     const float z = d[tr * g.width + tc];
     xyz[0] += (ray[0] * z) * t.w[k];
     xyz[1] += (ray[1] * z) * t.w[k];
     xyz[2] += (ray[2] * z) * t.w[k];
+    hh[0] += z * ut * t.w[k];
+    hh[1] += z * vt * t.w[k];
+    hh[2] += z * t.w[k];
   }
   float xw[3];
   apply_pose(e, xyz, xw);
-  float* o = ws + idx * 6;
+  float* o = ws + idx * kTrackWs;
   o[0] = xyz[0]; o[1] = xyz[1]; o[2] = xyz[2];
   o[3] = xw[0];  o[4] = xw[1];  o[5] = xw[2];
+  o[6] = hh[0];  o[7] = hh[1];  o[8] = hh[2];
   const bool inside = q.x >= 0.f && q.y >= 0.f && q.x < 1.f && q.y < 1.f;
   flag[idx] = (g.vis[idx] != 0 && inside) ? 1 : 0;
 }
 
-// One (source, target, point) residual.  Returns false when not visible.
-struct TrackEval {
-  Projected pr;
-  float drx, dry, rho;
-};
-
-__device__ __forceinline__ bool track_eval(const Pose& einv_t, const Mat3& k_t, const float xw[3], float gt_x, float gt_y, int kind,
-                                           float delta, float ax, float ay, TrackEval& o) {
-  float xc[3];
-  apply_pose(einv_t, xw, xc);
-  o.pr = project_point(xc, k_t);
-  if (!(o.pr.u >= 0.f && o.pr.v >= 0.f && o.pr.u < 1.f && o.pr.v < 1.f)) return false;
-  o.rho = robust_map(kind, delta, aspect_diff(o.pr.u, gt_x, ax), aspect_diff(o.pr.v, gt_y, ay), o.drx, o.dry);
-  return true;
+// Per frame: the target-role constants (au, av, c) of track_target (fm_pose.h).
+__global__ void track_targets_kernel(const float* ext_inv, const float* k, int frames, float* tgt) {
+  const int fr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (fr < frames) track_target(ext_inv + (size_t)fr * 16, k + (size_t)fr * 9, tgt + (size_t)fr * kTrackTgt);
 }
 
-// ------------------------------------------------------------------- track_fwd ------
-__global__ void __launch_bounds__(256) track_fwd_kernel(TrackGeom g, const float* ws, const uint8_t* flag, const float* ext_inv,
-                                                        const float* k, int kind, float delta, float ax, float ay, int frames,
-                                                        double* acc) {
-  __shared__ double red[4 * 20];
-  const int sg = g.blocks[blockIdx.x * 2], ft = g.blocks[blockIdx.x * 2 + 1];
+// ----------------------------------------------------------------- track_pairs ------
+// One wave per block: 64 points x kTrackTile source frames.  grid: (source tiles, point groups);
+// tiles[(segment, first local source frame)].  Waves never synchronise with each other: the
+// per-target sums are reduced inside the wave (DPP) and added by lane 63 with fp64 atomics.
+// Wave sum of NV per-lane values, written by lane 63 as this wave's partial (plain stores: the
+// partials of all waves are summed per frame by track_reduce_kernel — no atomics, deterministic).
+template <int NV>
+__device__ __forceinline__ void wave_store(const float (&v)[NV], float* dst) {
+  float tot[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) tot[i] = wave_sum_lane63(v[i]);
+  if ((threadIdx.x & (kWave - 1)) == kWave - 1) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dst[i] = tot[i];
+  }
+}
+
+template <int KIND, bool GRAD>
+__global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const int32_t* tiles, const float* ws, const uint8_t* flag,
+                                                            const float* ext, const float* tgt, float delta, float ax, float ay, int fmax,
+                                                            float* partial, float* gws) {
+  const float inv_delta = KIND == kHuber ? 1.0f / delta : 0.f;
+  // this wave's slice of the partial-sum workspace: [fmax][14] target role, then [kTrackTile][21] source role
+  float* mine = partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * track_partial_stride(fmax);
+  const int sg = tiles[blockIdx.x * 2], fs0 = tiles[blockIdx.x * 2 + 1];
   const int start = g.seg[sg * 4], f = g.seg[sg * 4 + 1], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
   const int p = blockIdx.y * blockDim.x + threadIdx.x;
-  const int frame_t = start + ft;
-  Pose einv;
-  Mat3 kt;
-  load_pose44(ext_inv + (size_t)frame_t * 16, einv);
-  load_mat3(k + (size_t)frame_t * 9, kt);
-  float a[20];
+  const bool active = p < p_count;
+  const int pp = active ? p : p_count - 1;  // clamped: loads stay in bounds, results are masked
+
+  float xw[kTrackTile][3], gxw[kTrackTile][3];
+  float live[kTrackTile];  // 1 when the source role is visible (projection.py:290-294), else 0
 #pragma unroll
-  for (int i = 0; i < 20; ++i) a[i] = 0.f;
-  if (p < p_count) {
-    const size_t it = (size_t)off + (size_t)ft * p_count + p;
-    if (g.vis[it] != 0) {  // target role needs only the track's visibility (projection.py:290)
-      const float2 gt = reinterpret_cast<const float2*>(g.xy)[it];
-      {
-        for (int fs = 0; fs < f; ++fs) {
-          const size_t is = (size_t)off + (size_t)fs * p_count + p;
-          if (flag[is] == 0) continue;
-          const float* w6 = ws + is * 6;
-          const float xw[3] = {w6[3], w6[4], w6[5]};
-          TrackEval ev;
-          if (!track_eval(einv, kt, xw, gt.x, gt.y, kind, delta, ax, ay, ev)) continue;
-          a[18] += ev.rho;
-          a[19] += 1.f;
-          float gk[6] = {0, 0, 0, 0, 0, 0}, gxc[3];
-          project_point_bwd(ev.pr, kt, ev.drx * ax, ev.dry * ay, gk, gxc);
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            a[r * 4 + 0] += gxc[r] * xw[0];
-            a[r * 4 + 1] += gxc[r] * xw[1];
-            a[r * 4 + 2] += gxc[r] * xw[2];
-            a[r * 4 + 3] += gxc[r];
-          }
-#pragma unroll
-          for (int r = 0; r < 6; ++r) a[12 + r] += gk[r];
-        }
+  for (int t = 0; t < kTrackTile; ++t) {
+    live[t] = 0.f;
+    xw[t][0] = xw[t][1] = xw[t][2] = 0.f;
+    gxw[t][0] = gxw[t][1] = gxw[t][2] = 0.f;
+    const int fs = fs0 + t;
+    if (active && fs < f) {
+      const size_t is = (size_t)off + (size_t)fs * p_count + p;
+      if (flag[is] != 0) {
+        live[t] = 1.f;
+        const float* w9 = ws + is * kTrackWs;
+        xw[t][0] = w9[3]; xw[t][1] = w9[4]; xw[t][2] = w9[5];
       }
     }
   }
-  // per-frame sums [0..17]; global loss / count live after the last frame
-  float per_frame[18], glob[2] = {a[18], a[19]};
+
+  // the target's visibility and position are prefetched one iteration ahead
+  size_t it = (size_t)off + pp;
+  uint8_t tv_next = g.vis[it];
+  float2 gt_next = reinterpret_cast<const float2*>(g.xy)[it];
+  for (int ft = 0; ft < f; ++ft) {
+    const float tv = active && tv_next != 0 ? 1.f : 0.f;  // target role needs only the track's visibility (projection.py:290)
+    const float2 gt = gt_next;
+    if (ft + 1 < f) {
+      it += p_count;
+      tv_next = g.vis[it];
+      gt_next = reinterpret_cast<const float2*>(g.xy)[it];
+    }
+    float tg[kTrackTgt];
 #pragma unroll
-  for (int i = 0; i < 18; ++i) per_frame[i] = a[i];
-  block_accumulate<18>(per_frame, red, acc + (size_t)frame_t * kTrackAccStride);
-  block_accumulate<2>(glob, red, acc + (size_t)frames * kTrackAccStride);
+    for (int i = 0; i < kTrackTgt; ++i) tg[i] = tgt[(size_t)(start + ft) * kTrackTgt + i];  // wave-uniform: scalar loads
+    float a[kTrackSums];
+#pragma unroll
+    for (int i = 0; i < kTrackSums; ++i) a[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < kTrackTile; ++t)
+      track_pair_term<KIND, GRAD>(tg, xw[t], gt.x, gt.y, tv * live[t], delta, inv_delta, ax, ay, a, gxw[t]);
+    if (GRAD) {
+      wave_store<kTrackSums>(a, mine + (size_t)ft * kTrackSums);
+    } else {
+      const float lc[2] = {a[12], a[13]};
+      wave_store<2>(lc, mine + (size_t)ft * kTrackSums + 12);
+    }
+  }
+
+  if (GRAD) {
+#pragma unroll
+    for (int t = 0; t < kTrackTile; ++t) {
+      const int fs = fs0 + t;
+      if (fs >= f) break;  // wave-uniform
+      float b[21];
+#pragma unroll
+      for (int i = 0; i < 21; ++i) b[i] = 0.f;
+      if (live[t] != 0.f) {
+        const size_t is = (size_t)off + (size_t)fs * p_count + p;
+        Pose e;
+        load_pose44(ext + (size_t)(start + fs) * 16, e);
+        float gxyz[3];
+        track_source_term(e, ws + is * kTrackWs, gxw[t], b, gxyz);
+        gws[is * 3 + 0] = gxyz[0];
+        gws[is * 3 + 1] = gxyz[1];
+        gws[is * 3 + 2] = gxyz[2];
+      }
+      wave_store<21>(b, mine + (size_t)fmax * kTrackSums + t * 21);
+    }
+  }
+}
+
+// Per frame: sum the partials of every wave that touched it (fp64, fixed order: bit-reproducible).
+// grid: frames.  Each thread walks (tile, point group) entries, keeps the 14 target-role and 21
+// source-role sums of the entries covering this frame, then the block reduces them through LDS.
+__global__ void __launch_bounds__(256) track_reduce_kernel(const int32_t* seg, const int32_t* tiles, int ntiles, int pgroups, int fmax,
+                                                           const float* partial, int grad, double* acc, double* acc2) {
+  constexpr int kVals = kTrackSums + 21;
+  __shared__ double red[kVals][kWave + 1];
+  const int frame = blockIdx.x;
+  const size_t stride = track_partial_stride(fmax);
+  double v[kVals];
+#pragma unroll
+  for (int i = 0; i < kVals; ++i) v[i] = 0.0;
+  for (int e = threadIdx.x; e < ntiles * pgroups; e += blockDim.x) {
+    const int j = e / pgroups;
+    const int sg = tiles[j * 2], fs0 = tiles[j * 2 + 1];
+    const int ft = frame - seg[sg * 4];
+    if (ft < 0 || ft >= seg[sg * 4 + 1]) continue;
+    const float* w = partial + (size_t)e * stride;
+    const float* tw = w + (size_t)ft * kTrackSums;
+    if (grad) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) v[i] += (double)tw[i];
+    }
+    v[12] += (double)tw[12];
+    v[13] += (double)tw[13];
+    const int t = ft - fs0;  // this frame as a source of the tile
+    if (grad && t >= 0 && t < kTrackTile) {
+      const float* sw = w + (size_t)fmax * kTrackSums + t * 21;
+#pragma unroll
+      for (int i = 0; i < 21; ++i) v[kTrackSums + i] += (double)sw[i];
+    }
+  }
+  // 256 -> 64 partial sums per value in registers/LDS, then one wave finishes each value
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  for (int w4 = 0; w4 < 4; ++w4) {
+    if (wave == w4) {
+#pragma unroll
+      for (int i = 0; i < kVals; ++i) red[i][lane] = (w4 == 0 ? 0.0 : red[i][lane]) + v[i];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < kVals) {
+    double tot = 0.0;
+    for (int l = 0; l < kWave; ++l) tot += red[threadIdx.x][l];
+    const int i = threadIdx.x;
+    // acc: [0..11] S, [12..17] unused (0), [18] Σρ, [19] count;  acc2: [0..20], [21..23] unused
+    if (i < 12) acc[(size_t)frame * kTrackAccStride + i] = tot;
+    else if (i < kTrackSums) acc[(size_t)frame * kTrackAccStride + i + 6] = tot;
+    else if (grad) acc2[(size_t)frame * kTrackAcc2Stride + (i - kTrackSums)] = tot;
+  }
+  if (threadIdx.x >= 12 && threadIdx.x < 18) acc[(size_t)frame * kTrackAccStride + threadIdx.x] = 0.0;
+  if (grad && threadIdx.x >= 21 && threadIdx.x < kTrackAcc2Stride) acc2[(size_t)frame * kTrackAcc2Stride + threadIdx.x] = 0.0;
 }
 
 // loss[0] = weight·Σρ/max(count,1); scale[0] = weight/max(count,1); scale[1] = count
 __global__ void track_finalize_fwd_kernel(const double* acc, int frames, float weight, float* loss, float* scale) {
-  const double sum = acc[(size_t)frames * kTrackAccStride], cnt = acc[(size_t)frames * kTrackAccStride + 1];
+  double sum = 0.0, cnt = 0.0;  // one wave
+  for (int fr = threadIdx.x; fr < frames; fr += kWave) {
+    sum += acc[(size_t)fr * kTrackAccStride + 18];
+    cnt += acc[(size_t)fr * kTrackAccStride + 19];
+  }
+  sum = wave_sum(sum);
+  cnt = wave_sum(cnt);
+  if (threadIdx.x != 0) return;
   const double den = cnt != 0.0 ? cnt : 1.0;  // `valid_sum or 1` (loss_tracking.py:61)
   loss[0] = (float)((double)weight * sum / den);
   scale[0] = (float)((double)weight / den);
   scale[1] = (float)cnt;
 }
 
-// ------------------------------------------------------------------- track_bwd ------
-__global__ void __launch_bounds__(256) track_bwd_kernel(TrackGeom g, const float* ws, const uint8_t* flag, const float* depth,
-                                                        const float* kinv, const float* ext, const float* ext_inv, const float* k,
-                                                        int kind, float delta, float ax, float ay, const float* scale,
-                                                        const float* upstream, float* gws, double* acc2) {
-  extern __shared__ double lds_d[];  // reduction scratch (fp64), then [f][21] target poses + intrinsics
-  const int sg = g.blocks[blockIdx.x * 2], fs = g.blocks[blockIdx.x * 2 + 1];
-  const int start = g.seg[sg * 4], f = g.seg[sg * 4 + 1], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
-  double* red = lds_d;
-  float* tgt = reinterpret_cast<float*>(lds_d + 4 * 21);
-  for (int i = threadIdx.x; i < f * 21; i += blockDim.x) {
-    const int ft = i / 21, e = i % 21;
-    const int frame = start + ft;
-    tgt[i] = e < 12 ? ext_inv[(size_t)frame * 16 + (e / 4) * 4 + (e % 4)] : k[(size_t)frame * 9 + (e - 12)];
-  }
-  __syncthreads();
-  const int p = blockIdx.y * blockDim.x + threadIdx.x;
-  const int frame_s = start + fs;
-  const float sc = scale[0] * (upstream ? upstream[0] : 1.f);
-  float a[21];
-#pragma unroll
-  for (int i = 0; i < 21; ++i) a[i] = 0.f;
-  if (p < p_count) {
-    const size_t is = (size_t)off + (size_t)fs * p_count + p;
-    if (flag[is] != 0) {
-      const float* w6 = ws + is * 6;
-      const float xyz[3] = {w6[0], w6[1], w6[2]};
-      const float xw[3] = {w6[3], w6[4], w6[5]};
-      float gxw[3] = {0.f, 0.f, 0.f};
-      for (int ft = 0; ft < f; ++ft) {
-        const size_t it = (size_t)off + (size_t)ft * p_count + p;
-        if (g.vis[it] == 0) continue;
-        const float* tp = tgt + ft * 21;
-        Pose einv;
-        Mat3 kt;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          einv.r[r * 3 + 0] = tp[r * 4 + 0];
-          einv.r[r * 3 + 1] = tp[r * 4 + 1];
-          einv.r[r * 3 + 2] = tp[r * 4 + 2];
-          einv.t[r] = tp[r * 4 + 3];
-        }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) kt.m[i] = tp[12 + i];
-        const float2 gt = reinterpret_cast<const float2*>(g.xy)[it];
-        TrackEval ev;
-        if (!track_eval(einv, kt, xw, gt.x, gt.y, kind, delta, ax, ay, ev)) continue;
-        float gk[6] = {0, 0, 0, 0, 0, 0}, gxc[3], gx[3];
-        project_point_bwd(ev.pr, kt, ev.drx * ax, ev.dry * ay, gk, gxc);
-        apply_rot_t(einv, gxc, gx);
-        gxw[0] += gx[0];
-        gxw[1] += gx[1];
-        gxw[2] += gx[2];
-      }
-      gxw[0] *= sc;
-      gxw[1] *= sc;
-      gxw[2] *= sc;
-      // X_w = E_fs·[xyz;1]
-      Pose e;
-      load_pose44(ext + (size_t)frame_s * 16, e);
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        a[r * 4 + 0] = gxw[r] * xyz[0];
-        a[r * 4 + 1] = gxw[r] * xyz[1];
-        a[r * 4 + 2] = gxw[r] * xyz[2];
-        a[r * 4 + 3] = gxw[r];
-      }
-      float gxyz[3];
-      apply_rot_t(e, gxw, gxyz);
-      // xyz = Σ taps w_k · z_k · Kinv·[u_k, v_k, 1]
-      const float2 q = reinterpret_cast<const float2*>(g.xy)[is];
-      const Taps t = bilinear_taps(q.x, q.y, g.height, g.width);
-      const float* d = depth + (size_t)frame_s * g.height * g.width;
-      gws[is * 3 + 0] = gxyz[0];
-      gws[is * 3 + 1] = gxyz[1];
-      gws[is * 3 + 2] = gxyz[2];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if (!t.in[kk]) continue;
-        const int tc = tap_col(t, kk), tr = tap_row(t, kk);
-        const float ut = pixel_center(tc, g.width), vt = pixel_center(tr, g.height);
-        const float wt = t.w[kk];
-        const float z = d[tr * g.width + tc];
-        const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          a[12 + r * 3 + 0] += gxyz[r] * zt[0];
-          a[12 + r * 3 + 1] += gxyz[r] * zt[1];
-          a[12 + r * 3 + 2] += gxyz[r] * zt[2];
-        }
-      }
-    }
-  }
-  block_accumulate<21>(a, red, acc2 + (size_t)frame_s * kTrackAcc2Stride);
-}
-
 // Scatter of the per-point surface gradients gws (total,3) into dL/ddepth through the
 // bilinear taps: xyz = Σ_k w_k · z_k · Kinv·[u_k, v_k, 1].  Separate launch so the caller
 // can aim it at whichever dense buffer will finally hold dL/ddepth.
 __global__ void __launch_bounds__(256) track_scatter_kernel(TrackGeom g, const uint8_t* flag, const float* gws, const float* kinv,
-                                                            float* grad_depth) {
+                                                            const float* scale, const float* upstream, float* grad_depth) {
   const int sg = g.blocks[blockIdx.x * 2], fs = g.blocks[blockIdx.x * 2 + 1];
   const int start = g.seg[sg * 4], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
   const int p = blockIdx.y * blockDim.x + threadIdx.x;
@@ -267,7 +278,8 @@ __global__ void __launch_bounds__(256) track_scatter_kernel(TrackGeom g, const u
   const int frame_s = start + fs;
   Mat3 ki;
   load_mat3(kinv + (size_t)frame_s * 9, ki);
-  const float gx = gws[is * 3], gy = gws[is * 3 + 1], gz = gws[is * 3 + 2];
+  const float sc = scale[0] * (upstream ? upstream[0] : 1.f);
+  const float gx = gws[is * 3] * sc, gy = gws[is * 3 + 1] * sc, gz = gws[is * 3 + 2] * sc;
   const float2 q = reinterpret_cast<const float2*>(g.xy)[is];
   const Taps t = bilinear_taps(q.x, q.y, g.height, g.width);
   float* gd = grad_depth + (size_t)frame_s * g.height * g.width;
@@ -283,26 +295,13 @@ __global__ void __launch_bounds__(256) track_scatter_kernel(TrackGeom g, const u
 
 // dL/dE and dL/dK per frame from the two accumulators.
 __global__ void track_finalize_bwd_kernel(const double* acc, const double* acc2, const float* scale, const float* upstream,
-                                          const float* ext_inv, const float* kinv, int frames, float* g_ext, float* g_k) {
+                                          const float* ext_inv, const float* k, const float* kinv, int frames, float* g_ext,
+                                          float* g_k) {
   const int fr = blockIdx.x * blockDim.x + threadIdx.x;
   if (fr >= frames) return;
   const double sc = (double)scale[0] * (upstream ? (double)upstream[0] : 1.0);
-  const double* a = acc + (size_t)fr * kTrackAccStride;
-  const double* b = acc2 + (size_t)fr * kTrackAcc2Stride;
-  // target role: X' = inv(E)·X_w, G_inv = Σ gX'⊗[X_w;1] (top 3 rows) -> dE = −invᵀ·G_inv·invᵀ
-  double ginv[16], inv[16], tmp[16], tmp2[16];
-  for (int i = 0; i < 12; ++i) ginv[i] = a[i] * sc;
-  for (int i = 12; i < 16; ++i) ginv[i] = 0.0;
-  for (int i = 0; i < 16; ++i) inv[i] = ext_inv[(size_t)fr * 16 + i];
-  mat4_mul_tn(inv, ginv, tmp);
-  mat4_mul_nt(tmp, inv, tmp2);
-  float* ge = g_ext + (size_t)fr * 16;
-  for (int i = 0; i < 16; ++i) ge[i] = (float)(-tmp2[i] + (i < 12 ? b[i] : 0.0));
-  // intrinsics: destination role (rows 0,1; unscaled in acc) + source role through K⁻¹
-  double gk[9];
-  kinv_grad_to_k(b + 12, kinv + (size_t)fr * 9, gk);
-  for (int i = 0; i < 6; ++i) gk[i] += a[12 + i] * sc;
-  for (int i = 0; i < 9; ++i) g_k[(size_t)fr * 9 + i] = (float)gk[i];
+  track_frame_grads(acc + (size_t)fr * kTrackAccStride, acc2 + (size_t)fr * kTrackAcc2Stride, sc, ext_inv + (size_t)fr * 16,
+                    k + (size_t)fr * 9, kinv + (size_t)fr * 9, g_ext + (size_t)fr * 16, g_k + (size_t)fr * 9);
 }
 
 __global__ void inv4_kernel(const float* m, int count, float* out) {
@@ -326,54 +325,63 @@ int fm_extrinsics_inverse(const float* ext, int count, float* inv, void* stream)
   FM_LAUNCH_STATUS();
 }
 
-int fm_track_points(const float* depth, const float* kinv, const float* ext, const float* xy, const uint8_t* vis,
-                    const int32_t* seg, const int32_t* blocks, int nblocks, int pmax, int height, int width, float* ws,
-                    uint8_t* flag, void* stream) {
-  FM_CHECK_ARG(depth && kinv && ext && xy && vis && seg && blocks && ws && flag && nblocks >= 1 && pmax >= 1);
+int fm_track_points(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
+                    const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int pmax, int height,
+                    int width, float* ws, uint8_t* flag, float* tgt, void* stream) {
+  FM_CHECK_ARG(depth && kinv && ext && ext_inv && k && xy && vis && seg && blocks && ws && flag && tgt);
+  FM_CHECK_ARG(nblocks >= 1 && pmax >= 1 && frames >= 1);
+  hipStream_t st = (hipStream_t)stream;
   TrackGeom g{xy, vis, seg, blocks, height, width};
-  hipLaunchKernelGGL(track_points_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, depth, kinv, ext,
-                     ws, flag);
+  hipLaunchKernelGGL(track_points_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, st, g, depth, kinv, ext, ws, flag);
+  hipLaunchKernelGGL(track_targets_kernel, dim3((frames + 63) / 64), dim3(64), 0, st, ext_inv, k, frames, tgt);
   FM_LAUNCH_STATUS();
 }
 
 int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
-                      const int32_t* blocks, int nblocks, int pmax, const float* ext_inv, const float* k, int frames, int height,
-                      int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, double* acc,
-                      float* loss, float* scale, void* stream) {
-  FM_CHECK_ARG(ws && flag && xy && vis && seg && blocks && ext_inv && k && acc && loss && scale && nblocks >= 1 && pmax >= 1);
+                      const int32_t* tiles, int ntiles, int pmax, int fmax, const float* ext, const float* tgt, int frames, int height,
+                      int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* partial,
+                      double* acc, float* loss, float* scale, float* gws, double* acc2, void* stream) {
+  FM_CHECK_ARG(ws && flag && xy && vis && seg && tiles && ext && tgt && partial && acc && loss && scale);
+  FM_CHECK_ARG(ntiles >= 1 && pmax >= 1 && fmax >= 1 && frames >= 1 && mapping_kind >= 0 && mapping_kind <= 2);
+  FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr));
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(acc, 0, sizeof(double) * ((size_t)frames * kTrackAccStride + 2), st) != hipSuccess) return FM_ERR_LAUNCH;
-  TrackGeom g{xy, vis, seg, blocks, height, width};
-  hipLaunchKernelGGL(track_fwd_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, st, g, ws, flag, ext_inv, k, mapping_kind,
-                     delta, aspect_x, aspect_y, frames, acc);
-  hipLaunchKernelGGL(track_finalize_fwd_kernel, dim3(1), dim3(1), 0, st, acc, frames, weight, loss, scale);
+  TrackGeom g{xy, vis, seg, nullptr, height, width};
+  const int pgroups = (pmax + kWave - 1) / kWave;
+  const dim3 grid(ntiles, pgroups);
+#define FM_TRACK_LAUNCH(K)                                                                                                          \
+  do {                                                                                                                               \
+    if (gws)                                                                                                                         \
+      hipLaunchKernelGGL((track_pairs_kernel<K, true>), grid, dim3(kWave), 0, st, g, tiles, ws, flag, ext, tgt, delta,              \
+                         aspect_x, aspect_y, fmax, partial, gws);                                                                    \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((track_pairs_kernel<K, false>), grid, dim3(kWave), 0, st, g, tiles, ws, flag, ext, tgt, delta,             \
+                         aspect_x, aspect_y, fmax, partial, gws);                                                                    \
+  } while (0)
+  if (mapping_kind == kHuber) FM_TRACK_LAUNCH(kHuber);
+  else if (mapping_kind == kL1) FM_TRACK_LAUNCH(kL1);
+  else FM_TRACK_LAUNCH(kL2);
+#undef FM_TRACK_LAUNCH
+  hipLaunchKernelGGL(track_reduce_kernel, dim3(frames), dim3(256), 0, st, seg, tiles, ntiles, pgroups, fmax, partial, gws ? 1 : 0, acc,
+                     acc2);
+  hipLaunchKernelGGL(track_finalize_fwd_kernel, dim3(1), dim3(kWave), 0, st, acc, frames, weight, loss, scale);
   FM_LAUNCH_STATUS();
 }
 
-int fm_track_loss_bwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
-                      const int32_t* blocks, int nblocks, int pmax, int fmax, const float* depth, const float* kinv, const float* ext,
-                      const float* ext_inv, const float* k, int frames, int height, int width, int mapping_kind, float delta,
-                      float aspect_x, float aspect_y, const double* acc, const float* scale, const float* upstream,
-                      float* gws, double* acc2, float* g_ext, float* g_k, void* stream) {
-  FM_CHECK_ARG(ws && flag && xy && vis && seg && blocks && depth && kinv && ext && ext_inv && k && acc && scale && gws && acc2 && g_ext && g_k);
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(acc2, 0, sizeof(double) * (size_t)frames * kTrackAcc2Stride, st) != hipSuccess) return FM_ERR_LAUNCH;
-  TrackGeom g{xy, vis, seg, blocks, height, width};
-  const size_t lds = sizeof(float) * (size_t)fmax * 21 + sizeof(double) * 4 * 21;
-  hipLaunchKernelGGL(track_bwd_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), lds, st, g, ws, flag, depth, kinv, ext, ext_inv,
-                     k, mapping_kind, delta, aspect_x, aspect_y, scale, upstream, gws, acc2);
-  hipLaunchKernelGGL(track_finalize_bwd_kernel, dim3((frames + 63) / 64), dim3(64), 0, st, acc, acc2, scale, upstream, ext_inv, kinv,
-                     frames, g_ext, g_k);
+int fm_track_loss_bwd(const double* acc, const double* acc2, const float* scale, const float* upstream, const float* ext_inv,
+                      const float* k, const float* kinv, int frames, float* g_ext, float* g_k, void* stream) {
+  FM_CHECK_ARG(acc && acc2 && scale && ext_inv && k && kinv && g_ext && g_k && frames >= 1);
+  hipLaunchKernelGGL(track_finalize_bwd_kernel, dim3((frames + 63) / 64), dim3(64), 0, (hipStream_t)stream, acc, acc2, scale, upstream,
+                     ext_inv, k, kinv, frames, g_ext, g_k);
   FM_LAUNCH_STATUS();
 }
 
 int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
-                     const int32_t* blocks, int nblocks, int pmax, const float* kinv, int height, int width, float* grad_depth,
-                     void* stream) {
-  FM_CHECK_ARG(gws && flag && xy && vis && seg && blocks && kinv && grad_depth && nblocks >= 1 && pmax >= 1);
+                     const int32_t* blocks, int nblocks, int pmax, const float* kinv, const float* scale, const float* upstream,
+                     int height, int width, float* grad_depth, void* stream) {
+  FM_CHECK_ARG(gws && flag && xy && vis && seg && blocks && kinv && scale && grad_depth && nblocks >= 1 && pmax >= 1);
   TrackGeom g{xy, vis, seg, blocks, height, width};
   hipLaunchKernelGGL(track_scatter_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, flag, gws, kinv,
-                     grad_depth);
+                     scale, upstream, grad_depth);
   FM_LAUNCH_STATUS();
 }
 

@@ -679,9 +679,10 @@ int fm_extrinsics_inverse(const float* ext, int count, float* inv, void*) {
   return 0;
 }
 
-int fm_track_points(const float* depth, const float* kinv, const float* ext, const float* xy, const uint8_t* vis,
-                    const int32_t* seg, const int32_t* blocks, int nblocks, int, int height, int width, float* ws,
-                    uint8_t* flag, void*) {
+int fm_track_points(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
+                    const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int, int height,
+                    int width, float* ws, uint8_t* flag, float* tgt, void*) {
+  for (int fr = 0; fr < frames; ++fr) track_target(ext_inv + (size_t)fr * 16, k + (size_t)fr * 9, tgt + (size_t)fr * kTrackTgt);
   for (int blk = 0; blk < nblocks; ++blk) {
     const int sg = blocks[blk * 2], fl = blocks[blk * 2 + 1];
     const int start = seg[sg * 4], pc = seg[sg * 4 + 2], off = seg[sg * 4 + 3];
@@ -695,20 +696,25 @@ int fm_track_points(const float* depth, const float* kinv, const float* ext, con
       const size_t idx = (size_t)off + (size_t)fl * pc + p;
       const float qx = xy[idx * 2], qy = xy[idx * 2 + 1];
       const Taps t = bilinear_taps(qx, qy, height, width);
-      float xyz[3] = {0, 0, 0};
+      float xyz[3] = {0, 0, 0}, hh[3] = {0, 0, 0};
       for (int k = 0; k < 4; ++k) {
         if (!t.in[k]) continue;
         const int tc = tap_col(t, k), tr = tap_row(t, k);
+        const float ut = pixel_center(tc, width), vt = pixel_center(tr, height);
         float ray[3];
-        ray_dir(ki, pixel_center(tc, width), pixel_center(tr, height), ray);
+        ray_dir(ki, ut, vt, ray);
         const float z = d[tr * width + tc];
         for (int a = 0; a < 3; ++a) xyz[a] += (ray[a] * z) * t.w[k];
+        hh[0] += z * ut * t.w[k];
+        hh[1] += z * vt * t.w[k];
+        hh[2] += z * t.w[k];
       }
       float xw[3];
       apply_pose(e, xyz, xw);
       for (int a = 0; a < 3; ++a) {
-        ws[idx * 6 + a] = xyz[a];
-        ws[idx * 6 + 3 + a] = xw[a];
+        ws[idx * kTrackWs + a] = xyz[a];
+        ws[idx * kTrackWs + 3 + a] = xw[a];
+        ws[idx * kTrackWs + 6 + a] = hh[a];
       }
       const bool inside = qx >= 0.f && qy >= 0.f && qx < 1.f && qy < 1.f;
       flag[idx] = (vis[idx] != 0 && inside) ? 1 : 0;
@@ -717,57 +723,57 @@ int fm_track_points(const float* depth, const float* kinv, const float* ext, con
   return 0;
 }
 
-struct SimEval {
-  Projected pr;
-  float drx, dry, rho;
-};
-static bool sim_track_eval(const Pose& einv, const Mat3& kt, const float* xw, float gx, float gy, int kind, float delta, float ax,
-                           float ay, SimEval& o) {
-  float xc[3];
-  apply_pose(einv, xw, xc);
-  o.pr = project_point(xc, kt);
-  if (!(o.pr.u >= 0.f && o.pr.v >= 0.f && o.pr.u < 1.f && o.pr.v < 1.f)) return false;
-  o.rho = robust_map(kind, delta, aspect_diff(o.pr.u, gx, ax), aspect_diff(o.pr.v, gy, ay), o.drx, o.dry);
-  return true;
-}
-
 int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
-                      const int32_t* blocks, int nblocks, int, const float* ext_inv, const float* k, int frames, int, int,
-                      int kind, float delta, float ax, float ay, float weight, double* acc, float* loss, float* scale, void*) {
-  std::memset(acc, 0, sizeof(double) * ((size_t)frames * 20 + 2));
-  for (int blk = 0; blk < nblocks; ++blk) {
-    const int sg = blocks[blk * 2], ft = blocks[blk * 2 + 1];
+                      const int32_t* tiles, int ntiles, int, int, const float* ext, const float* tgt, int frames, int, int, int kind,
+                      float delta, float ax, float ay, float weight, float*, double* acc, float* loss, float* scale, float* gws,
+                      double* acc2, void*) {
+  std::memset(acc, 0, sizeof(double) * (size_t)frames * kTrackAccStride);
+  if (acc2) std::memset(acc2, 0, sizeof(double) * (size_t)frames * kTrackAcc2Stride);
+  const float invd = 1.0f / delta;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int sg = tiles[tile * 2], fs0 = tiles[tile * 2 + 1];
     const int start = seg[sg * 4], f = seg[sg * 4 + 1], pc = seg[sg * 4 + 2], off = seg[sg * 4 + 3];
-    const int frame_t = start + ft;
-    Pose einv;
-    Mat3 kt;
-    load_pose44(ext_inv + (size_t)frame_t * 16, einv);
-    load_mat3(k + (size_t)frame_t * 9, kt);
-    double* a = acc + (size_t)frame_t * 20;
-    for (int p = 0; p < pc; ++p) {
-      const size_t it = (size_t)off + (size_t)ft * pc + p;
-      if (vis[it] == 0) continue;
-      for (int fs = 0; fs < f; ++fs) {
+    for (int fs = fs0; fs < fs0 + FM_TRACK_TILE && fs < f; ++fs) {
+      Pose e;
+      load_pose44(ext + (size_t)(start + fs) * 16, e);
+      for (int p = 0; p < pc; ++p) {
         const size_t is = (size_t)off + (size_t)fs * pc + p;
         if (flag[is] == 0) continue;
-        const float* xw = ws + is * 6 + 3;
-        SimEval ev;
-        if (!sim_track_eval(einv, kt, xw, xy[it * 2], xy[it * 2 + 1], kind, delta, ax, ay, ev)) continue;
-        acc[(size_t)frames * 20] += ev.rho;
-        acc[(size_t)frames * 20 + 1] += 1.0;
-        float gk[6] = {0, 0, 0, 0, 0, 0}, gxc[3];
-        project_point_bwd(ev.pr, kt, ev.drx * ax, ev.dry * ay, gk, gxc);
-        for (int r = 0; r < 3; ++r) {
-          a[r * 4 + 0] += gxc[r] * xw[0];
-          a[r * 4 + 1] += gxc[r] * xw[1];
-          a[r * 4 + 2] += gxc[r] * xw[2];
-          a[r * 4 + 3] += gxc[r];
+        const float* w9 = ws + is * kTrackWs;
+        const float* xw = w9 + 3;
+        float gxw[3] = {0, 0, 0};
+        for (int ft = 0; ft < f; ++ft) {
+          const size_t it = (size_t)off + (size_t)ft * pc + p;
+          if (vis[it] == 0) continue;
+          float tg[kTrackTgt];
+          for (int i = 0; i < kTrackTgt; ++i) tg[i] = tgt[(size_t)(start + ft) * kTrackTgt + i];
+          float a[kTrackSums] = {};
+          const float gx = xy[it * 2], gy = xy[it * 2 + 1];
+          if (kind == kHuber) gws ? track_pair_term<kHuber, true>(tg, xw, gx, gy, 1.f, delta, invd, ax, ay, a, gxw)
+                                  : track_pair_term<kHuber, false>(tg, xw, gx, gy, 1.f, delta, invd, ax, ay, a, gxw);
+          else if (kind == kL1) gws ? track_pair_term<kL1, true>(tg, xw, gx, gy, 1.f, delta, invd, ax, ay, a, gxw)
+                                    : track_pair_term<kL1, false>(tg, xw, gx, gy, 1.f, delta, invd, ax, ay, a, gxw);
+          else gws ? track_pair_term<kL2, true>(tg, xw, gx, gy, 1.f, delta, invd, ax, ay, a, gxw)
+                   : track_pair_term<kL2, false>(tg, xw, gx, gy, 1.f, delta, invd, ax, ay, a, gxw);
+          double* dst = acc + (size_t)(start + ft) * kTrackAccStride;
+          for (int i = 0; i < 12; ++i) dst[i] += a[i];
+          dst[18] += a[12];
+          dst[19] += a[13];
         }
-        for (int r = 0; r < 6; ++r) a[12 + r] += gk[r];
+        if (gws) {
+          float b[21], gxyz[3];
+          track_source_term(e, w9, gxw, b, gxyz);
+          for (int r = 0; r < 3; ++r) gws[is * 3 + r] = gxyz[r];
+          for (int i = 0; i < 21; ++i) acc2[(size_t)(start + fs) * kTrackAcc2Stride + i] += b[i];
+        }
       }
     }
   }
-  const double sum = acc[(size_t)frames * 20], cnt = acc[(size_t)frames * 20 + 1];
+  double sum = 0, cnt = 0;
+  for (int fr = 0; fr < frames; ++fr) {
+    sum += acc[(size_t)fr * kTrackAccStride + 18];
+    cnt += acc[(size_t)fr * kTrackAccStride + 19];
+  }
   const double den = cnt != 0.0 ? cnt : 1.0;
   loss[0] = (float)((double)weight * sum / den);
   scale[0] = (float)((double)weight / den);
@@ -775,85 +781,19 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
   return 0;
 }
 
-int fm_track_loss_bwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
-                      const int32_t* blocks, int nblocks, int, int, const float* depth, const float* kinv, const float* ext,
-                      const float* ext_inv, const float* k, int frames, int height, int width, int kind, float delta, float ax,
-                      float ay, const double* acc, const float* scale, const float* upstream, float* gws, double* acc2,
-                      float* g_ext, float* g_k, void*) {
-  std::memset(acc2, 0, sizeof(double) * (size_t)frames * 24);
-  const float sc = scale[0] * (upstream ? upstream[0] : 1.f);
-  for (int blk = 0; blk < nblocks; ++blk) {
-    const int sg = blocks[blk * 2], fs = blocks[blk * 2 + 1];
-    const int start = seg[sg * 4], f = seg[sg * 4 + 1], pc = seg[sg * 4 + 2], off = seg[sg * 4 + 3];
-    const int frame_s = start + fs;
-    Pose e;
-    load_pose44(ext + (size_t)frame_s * 16, e);
-    double* a = acc2 + (size_t)frame_s * 24;
-    for (int p = 0; p < pc; ++p) {
-      const size_t is = (size_t)off + (size_t)fs * pc + p;
-      if (flag[is] == 0) continue;
-      const float* xyz = ws + is * 6;
-      const float* xw = ws + is * 6 + 3;
-      float gxw[3] = {0, 0, 0};
-      for (int ft = 0; ft < f; ++ft) {
-        const size_t it = (size_t)off + (size_t)ft * pc + p;
-        if (vis[it] == 0) continue;
-        Pose einv;
-        Mat3 kt;
-        load_pose44(ext_inv + (size_t)(start + ft) * 16, einv);
-        load_mat3(k + (size_t)(start + ft) * 9, kt);
-        SimEval ev;
-        if (!sim_track_eval(einv, kt, xw, xy[it * 2], xy[it * 2 + 1], kind, delta, ax, ay, ev)) continue;
-        float gk[6] = {0, 0, 0, 0, 0, 0}, gxc[3], gx[3];
-        project_point_bwd(ev.pr, kt, ev.drx * ax, ev.dry * ay, gk, gxc);
-        apply_rot_t(einv, gxc, gx);
-        for (int r = 0; r < 3; ++r) gxw[r] += gx[r];
-      }
-      for (int r = 0; r < 3; ++r) gxw[r] *= sc;
-      for (int r = 0; r < 3; ++r) {
-        a[r * 4 + 0] += gxw[r] * xyz[0];
-        a[r * 4 + 1] += gxw[r] * xyz[1];
-        a[r * 4 + 2] += gxw[r] * xyz[2];
-        a[r * 4 + 3] += gxw[r];
-      }
-      float gxyz[3];
-      apply_rot_t(e, gxw, gxyz);
-      const Taps t = bilinear_taps(xy[is * 2], xy[is * 2 + 1], height, width);
-      const float* d = depth + (size_t)frame_s * height * width;
-      for (int r = 0; r < 3; ++r) gws[is * 3 + r] = gxyz[r];
-      for (int kk = 0; kk < 4; ++kk) {
-        if (!t.in[kk]) continue;
-        const int tc = tap_col(t, kk), tr = tap_row(t, kk);
-        const float ut = pixel_center(tc, width), vt = pixel_center(tr, height);
-        const float wt = t.w[kk];
-        const float z = d[tr * width + tc];
-        const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
-        for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c) a[12 + r * 3 + c] += gxyz[r] * zt[c];
-      }
-    }
-  }
-  for (int fr = 0; fr < frames; ++fr) {
-    const double scd = (double)scale[0] * (upstream ? (double)upstream[0] : 1.0);
-    const double* a = acc + (size_t)fr * 20;
-    const double* b = acc2 + (size_t)fr * 24;
-    double ginv[16], inv[16], tmp[16], tmp2[16];
-    for (int i = 0; i < 12; ++i) ginv[i] = a[i] * scd;
-    for (int i = 12; i < 16; ++i) ginv[i] = 0.0;
-    for (int i = 0; i < 16; ++i) inv[i] = ext_inv[(size_t)fr * 16 + i];
-    mat4_mul_tn(inv, ginv, tmp);
-    mat4_mul_nt(tmp, inv, tmp2);
-    for (int i = 0; i < 16; ++i) g_ext[(size_t)fr * 16 + i] = (float)(-tmp2[i] + (i < 12 ? b[i] : 0.0));
-    double gk[9];
-    kinv_grad_to_k(b + 12, kinv + (size_t)fr * 9, gk);
-    for (int i = 0; i < 6; ++i) gk[i] += a[12 + i] * scd;
-    for (int i = 0; i < 9; ++i) g_k[(size_t)fr * 9 + i] = (float)gk[i];
-  }
+int fm_track_loss_bwd(const double* acc, const double* acc2, const float* scale, const float* upstream, const float* ext_inv,
+                      const float* k, const float* kinv, int frames, float* g_ext, float* g_k, void*) {
+  const double sc = (double)scale[0] * (upstream ? (double)upstream[0] : 1.0);
+  for (int fr = 0; fr < frames; ++fr)
+    track_frame_grads(acc + (size_t)fr * kTrackAccStride, acc2 + (size_t)fr * kTrackAcc2Stride, sc, ext_inv + (size_t)fr * 16,
+                      k + (size_t)fr * 9, kinv + (size_t)fr * 9, g_ext + (size_t)fr * 16, g_k + (size_t)fr * 9);
   return 0;
 }
 
 int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, const uint8_t*, const int32_t* seg,
-                     const int32_t* blocks, int nblocks, int, const float* kinv, int height, int width, float* grad_depth, void*) {
+                     const int32_t* blocks, int nblocks, int, const float* kinv, const float* scale, const float* upstream, int height,
+                     int width, float* grad_depth, void*) {
+  const float sc = scale[0] * (upstream ? upstream[0] : 1.f);
   for (int blk = 0; blk < nblocks; ++blk) {
     const int sg = blocks[blk * 2], fs = blocks[blk * 2 + 1];
     const int start = seg[sg * 4], pc = seg[sg * 4 + 2], off = seg[sg * 4 + 3];
@@ -870,7 +810,7 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
         float ray[3];
         ray_dir(ki, pixel_center(tc, width), pixel_center(tr, height), ray);
         grad_depth[(size_t)frame_s * height * width + tr * width + tc] +=
-            t.w[kk] * (gws[is * 3] * ray[0] + gws[is * 3 + 1] * ray[1] + gws[is * 3 + 2] * ray[2]);
+            t.w[kk] * (gws[is * 3] * sc * ray[0] + gws[is * 3 + 1] * sc * ray[1] + gws[is * 3 + 2] * sc * ray[2]);
       }
     }
   }

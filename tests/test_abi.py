@@ -63,3 +63,9 @@ def test_null_arguments_are_rejected_without_touching_the_gpu(name):
     fn.restype = ctypes.c_int
     zeros = [None if t is ctypes.c_void_p else t(0) for t in _lib.SIGNATURES[name]]
     assert fn(*zeros) == 1
+
+
+def test_track_tile_constant_matches_header():
+    from flowmap_amd import _ops
+
+    assert int(re.search(r"#define FM_TRACK_TILE (\d+)", HEADER).group(1)) == _ops.TRACK_TILE
