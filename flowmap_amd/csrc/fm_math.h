@@ -475,7 +475,10 @@ struct Corr {
   float z_p;
 };
 
-FM_HD Corr corr_load(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, int idx) {
+// `tap(row, col)` reads the EARLIER frame's depth (global memory, or an LDS-staged window in the
+// dense tiled kernels); only used when the surfaces are depth-sourced.
+template <class DepthTap>
+FM_HD Corr corr_load_with(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, int idx, const DepthTap& tap) {
   Corr c;
   c.idx = idx;
   const int row = idx / s.width, col = idx - row * s.width;
@@ -496,7 +499,7 @@ FM_HD Corr corr_load(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, i
     for (int k = 0; k < 4; ++k) {
       if (!c.taps.in[k]) continue;
       const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
-      const float z = s.depth_e[tr * s.width + tc];
+      const float z = tap(tr, tc);
       float ray[3];
       ray_dir(kinv_e, pixel_center(tc, s.width), pixel_center(tr, s.height), ray);
       c.q[0] += (ray[0] * z) * c.taps.w[k];
@@ -517,6 +520,68 @@ FM_HD Corr corr_load(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, i
     }
   }
   return c;
+}
+
+// One-pass Procrustes statistics.  The reference centres the clouds first and then forms
+// M = Σ w (q−q̄)(p−p̄)ᵀ (procrustes.py:23-32): two passes over the correspondences, each paying the
+// full gather chain.  Here ONE pass accumulates the raw moments about a per-pair reference point s
+// (the later-frame point of the middle sample: inside the cloud, so nothing large cancels),
+//   W = Σw,  P = Σ w p',  Q = Σ w q',  C = Σ w q' p'ᵀ      (p' = p − s, q' = q − s),
+// and moments_finish recovers exactly the reference's quantities in fp64:
+//   p − p̄ = p' − p̃,  p̃ = P/(W+ε) − s·ε/(W+ε)   (p̄ uses weights/(Σw+ε), ε = 1e-8),
+//   M = C − q̃ Pᵀ − Q p̃ᵀ + W q̃ p̃ᵀ.
+constexpr int kMomentCount = 16;
+
+FM_HD void later_point(const CorrSrc& s, const Mat3& kinv_l, int idx, float out[3]) {
+  if (s.surf_l == nullptr) {
+    const int row = idx / s.width, col = idx - row * s.width;
+    float ray[3];
+    ray_dir(kinv_l, pixel_center(col, s.width), pixel_center(row, s.height), ray);
+    const float z = s.depth_l[idx];
+    out[0] = ray[0] * z; out[1] = ray[1] * z; out[2] = ray[2] * z;
+  } else {
+    out[0] = s.surf_l[(size_t)idx * 3]; out[1] = s.surf_l[(size_t)idx * 3 + 1]; out[2] = s.surf_l[(size_t)idx * 3 + 2];
+  }
+  for (int a = 0; a < 3; ++a)
+    if (!(fabsf(out[a]) <= 3.0e38f)) out[a] = 0.f;  // a non-finite sample must not poison every term
+}
+
+FM_HD void moments_add(const Corr& c, const float s[3], float (&acc)[kMomentCount]) {
+  const float p0 = c.p[0] - s[0], p1 = c.p[1] - s[1], p2 = c.p[2] - s[2];
+  acc[0] += c.w;
+  acc[1] = fmaf(c.w, p0, acc[1]);
+  acc[2] = fmaf(c.w, p1, acc[2]);
+  acc[3] = fmaf(c.w, p2, acc[3]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float wq = c.w * (c.q[a] - s[a]);
+    acc[4 + a] += wq;
+    acc[7 + a * 3 + 0] = fmaf(wq, p0, acc[7 + a * 3 + 0]);
+    acc[7 + a * 3 + 1] = fmaf(wq, p1, acc[7 + a * 3 + 1]);
+    acc[7 + a * 3 + 2] = fmaf(wq, p2, acc[7 + a * 3 + 2]);
+  }
+}
+
+// In place: raw moments -> [0] Σw, [1..3] Σw·p, [4..6] Σw·q, [7..15] M (the layout pose_solve_one reads).
+FM_HD void moments_finish(double* st, const float s[3]) {
+  const double w = st[0], inv = 1.0 / (w + 1e-8);
+  double pt[3], qt[3], pm[3], qm[3];
+  for (int a = 0; a < 3; ++a) {
+    pm[a] = st[1 + a];
+    qm[a] = st[4 + a];
+    pt[a] = pm[a] * inv - (double)s[a] * 1e-8 * inv;
+    qt[a] = qm[a] * inv - (double)s[a] * 1e-8 * inv;
+  }
+  for (int a = 0; a < 3; ++a)
+    for (int d = 0; d < 3; ++d) st[7 + a * 3 + d] += -qt[a] * pm[d] - qm[a] * pt[d] + w * qt[a] * pt[d];
+  for (int a = 0; a < 3; ++a) {
+    st[1 + a] = pm[a] + w * (double)s[a];
+    st[4 + a] = qm[a] + w * (double)s[a];
+  }
+}
+
+FM_HD Corr corr_load(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, int idx) {
+  return corr_load_with(s, kinv_e, kinv_l, idx, [&](int tr, int tc) { return s.depth_e[tr * s.width + tc]; });
 }
 
 // Per-pair constants of the Procrustes backward (produced by the pose-solve backward).

@@ -9,8 +9,9 @@
 //   p_j = xyz_{i+1}[idx_j]                                   (projection.py:226-227)
 //   q_j = bilinear(xyz_i, xy[idx_j] + bwd_flow_i[idx_j])     (:231-242, border padding)
 //   w_j = weights_i[idx_j]                                    (:245-249)
-//   pass 1: Σw, Σw·p, Σw·q  -> centroids with weights/(Σw+1e-8)   (procrustes.py:23-25)
-//   pass 2: M = Σ w (q−q̄)(p−p̄)ᵀ with RAW weights                 (procrustes.py:28-32)
+//   one pass: raw moments about a per-pair reference point; from them, exactly, the centroids
+//   with weights/(Σw+1e-8) (procrustes.py:23-25) and M = Σ w (q−q̄)(p−p̄)ᵀ with RAW weights
+//   (procrustes.py:28-32) — moments_add / moments_finish, fm_math.h
 //   solve : R = Ũ Ṽᵀ (in-register Jacobi, fp64), t = q̄ − R p̄     (procrustes.py:35-42)
 // xyz comes either from an explicit surfaces tensor (function-level API) or is
 // recomputed on the fly from depth and K⁻¹ (fused path: surfaces never exist in HBM).
@@ -65,10 +66,18 @@ __device__ __forceinline__ CorrSrc pair_source(const ProcParams& p, size_t pair,
   return s;
 }
 
-// grid: (chunks, B*(F-1)); PASS 1 accumulates stats[0..6], PASS 2 stats[7..15].
-template <int SRC, int PASS>
-__global__ void __launch_bounds__(256) procrustes_stats_kernel(ProcParams p, int iters) {
-  __shared__ double red[4 * 9];
+// The per-pair reference point of the one-pass moments (fm_math.h): the later-frame point of the
+// middle sample.
+template <int SRC>
+__device__ __forceinline__ void pair_shift(const ProcParams& p, const CorrSrc& src, const Mat3& kinv_l, float s[3]) {
+  const long mid = p.points / 2;
+  later_point(src, kinv_l, p.indices ? (int)p.indices[mid] : (int)mid, s);
+}
+
+// grid: (chunks, B*(F-1)): raw moments of every correspondence into stats[0..15] (fp64 atomics).
+template <int SRC>
+__global__ void __launch_bounds__(256) procrustes_moments_kernel(ProcParams p, int iters) {
+  __shared__ double red[4 * kMomentCount];
   const size_t pair = blockIdx.y;
   const int b = (int)(pair / (p.frames - 1));
   const int i = (int)(pair % (p.frames - 1));
@@ -78,41 +87,107 @@ __global__ void __launch_bounds__(256) procrustes_stats_kernel(ProcParams p, int
     load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
   }
   const CorrSrc src = pair_source<SRC>(p, pair, b, i);
-  double* st = p.stats + pair * kStatStride;
-  float pbar[3] = {0, 0, 0}, qbar[3] = {0, 0, 0};
-  if (PASS == 2) {
-    const double inv = 1.0 / (st[0] + 1e-8);
-    for (int a = 0; a < 3; ++a) {
-      pbar[a] = (float)(st[1 + a] * inv);
-      qbar[a] = (float)(st[4 + a] * inv);
-    }
-  }
-  constexpr int NV = PASS == 1 ? 7 : 9;
-  float acc[NV];
+  float shift[3];
+  pair_shift<SRC>(p, src, kinv_l, shift);
+  float acc[kMomentCount];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+  for (int k = 0; k < kMomentCount; ++k) acc[k] = 0.f;
   const long base = (long)blockIdx.x * blockDim.x * iters;
   for (int it = 0; it < iters; ++it) {
     const long j = base + (long)it * blockDim.x + threadIdx.x;
     if (j >= p.points) break;
-    const Corr c = corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j);
-    if (PASS == 1) {
-      acc[0] += c.w;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        acc[1 + a] += c.w * c.p[a];
-        acc[4 + a] += c.w * c.q[a];
-      }
-    } else {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float wq = c.w * (c.q[a] - qbar[a]);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) acc[a * 3 + d] += wq * (c.p[d] - pbar[d]);
-      }
-    }
+    moments_add(corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j), shift, acc);
   }
-  block_accumulate<NV>(acc, red, st + (PASS == 1 ? 0 : 7));
+  block_accumulate<kMomentCount>(acc, red, p.stats + pair * kStatStride);
+}
+
+// One thread per pair: raw moments -> (Σw, Σw·p, Σw·q, M) in place.
+template <int SRC>
+__global__ void procrustes_moments_finish_kernel(ProcParams p, int pairs) {
+  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= pairs) return;
+  const int b = pair / (p.frames - 1), i = pair % (p.frames - 1);
+  Mat3 kinv_l{};
+  if (SRC == SRC_DEPTH) load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
+  const CorrSrc src = pair_source<SRC>(p, pair, b, i);
+  float shift[3];
+  pair_shift<SRC>(p, src, kinv_l, shift);
+  moments_finish(p.stats + (size_t)pair * kStatStride, shift);
+}
+
+// ---------------------------------------------------------------------------------
+// Dense mode (all H·W pixels are correspondences: `num_points: null`, the reference's
+// explicit-depth configuration, config/experiment/ablation_explicit_depth.yaml).  The generic
+// kernels above pay four scattered depth gathers per point and, in backward, four scattered float
+// atomics on cold lines (22 ms at C1).  Here a block owns a 16x64 tile of later-frame pixels and
+// an LDS window of the EARLIER frame around where the tile's samples land (tile displaced by the
+// backward flow at its centre, +-16 rows / +-24 columns): the depth taps are LDS reads, the tap
+// gradients LDS atomics, and the window is flushed with coalesced atomics.  Samples that leave the
+// window fall back to global memory.
+// ---------------------------------------------------------------------------------
+constexpr int kTileH = 16, kTileW = 64, kHaloY = 16, kHaloX = 24;
+constexpr int kWinH = kTileH + 2 * kHaloY, kWinW = kTileW + 2 * kHaloX;  // 48 x 112 floats = 21 KB
+
+struct DenseTile {
+  int tx0, ty0;  // tile origin (later frame)
+  int wx0, wy0;  // window origin (earlier frame)
+};
+
+__device__ __forceinline__ DenseTile dense_tile(const ProcParams& p, const CorrSrc& src) {
+  DenseTile t;
+  t.tx0 = blockIdx.x * kTileW;
+  t.ty0 = blockIdx.y * kTileH;
+  const int cx = min(t.tx0 + kTileW / 2, p.width - 1), cy = min(t.ty0 + kTileH / 2, p.height - 1);
+  const float fx = src.bwd_flow[2 * ((size_t)cy * p.width + cx)], fy = src.bwd_flow[2 * ((size_t)cy * p.width + cx) + 1];
+  const float ox = fminf(fmaxf(rintf(fx * (float)p.width), -1.0e6f), 1.0e6f);
+  const float oy = fminf(fmaxf(rintf(fy * (float)p.height), -1.0e6f), 1.0e6f);
+  t.wx0 = t.tx0 - kHaloX + (ox == ox ? (int)ox : 0);
+  t.wy0 = t.ty0 - kHaloY + (oy == oy ? (int)oy : 0);
+  return t;
+}
+
+__device__ __forceinline__ void stage_depth_window(const ProcParams& p, const CorrSrc& src, const DenseTile& t, float* win) {
+  for (int i = threadIdx.x; i < kWinH * kWinW; i += blockDim.x) {
+    const int gy = t.wy0 + i / kWinW, gx = t.wx0 + i % kWinW;
+    win[i] = (gy >= 0 && gy < p.height && gx >= 0 && gx < p.width) ? src.depth_e[(size_t)gy * p.width + gx] : 0.f;
+  }
+}
+
+// window cell of image pixel (row, col), or -1
+__device__ __forceinline__ int window_cell(const DenseTile& t, int row, int col) {
+  const int r = row - t.wy0, c = col - t.wx0;
+  return (r >= 0 && r < kWinH && c >= 0 && c < kWinW) ? r * kWinW + c : -1;
+}
+
+// grid: (ceil(W/64), ceil(H/16), pairs).  Raw moments of all pixels of the tile.
+__global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParams p) {
+  __shared__ double red[4 * kMomentCount];
+  __shared__ float win[kWinH * kWinW];
+  const size_t pair = blockIdx.z;
+  const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
+  Mat3 kinv_e, kinv_l;
+  load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
+  load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
+  const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
+  float shift[3];
+  pair_shift<SRC_DEPTH>(p, src, kinv_l, shift);
+  const DenseTile t = dense_tile(p, src);
+  stage_depth_window(p, src, t, win);
+  __syncthreads();
+  float acc[kMomentCount];
+#pragma unroll
+  for (int k = 0; k < kMomentCount; ++k) acc[k] = 0.f;
+  const int col = t.tx0 + (threadIdx.x & (kTileW - 1));
+  for (int r = threadIdx.x / kTileW; r < kTileH; r += 256 / kTileW) {
+    const int row = t.ty0 + r;
+    if (row >= p.height || col >= p.width) continue;
+    const Corr c = corr_load_with(src, kinv_e, kinv_l, row * p.width + col, [&](int tr, int tc) {
+      const int cell = window_cell(t, tr, tc);
+      return cell >= 0 ? win[cell] : src.depth_e[(size_t)tr * p.width + tc];
+    });
+    moments_add(c, shift, acc);
+  }
+  block_accumulate<kMomentCount>(acc, red, p.stats + pair * kStatStride);
 }
 
 // ---------------------------------------------------------------------------------
@@ -235,6 +310,103 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
       ordered[9 + k] = acc[k];
     }
     block_accumulate<18>(ordered, red, p.kinv_acc + fk * 9);
+  }
+}
+
+// Dense backward: per-pixel gradients of the tile; dL/dweights is STORED (every pixel of every pair
+// is written exactly once: the caller need not zero it), the later-frame depth gradient is one
+// coalesced atomic per pixel, the four tap gradients go to the LDS window, flushed at the end.
+__global__ void __launch_bounds__(256) procrustes_scatter_dense_kernel(ProcParams p, const double* aux) {
+  __shared__ double red[4 * 18];
+  __shared__ float win[kWinH * kWinW];
+  __shared__ float gwin[kWinH * kWinW];
+  const size_t pair = blockIdx.z;
+  const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
+  const int n = p.height * p.width;
+  Mat3 kinv_e, kinv_l;
+  load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
+  load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
+  const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
+  const double* pg = p.pair_grad + pair * kPairGradStride;
+  const double* ax = aux + pair * kAuxStride;
+  PairGrad g;
+  for (int k = 0; k < 9; ++k) g.gM[k] = (float)pg[k];
+  for (int a = 0; a < 3; ++a) {
+    g.gqbar[a] = (float)pg[9 + a];
+    g.gpbar[a] = (float)pg[12 + a];
+    g.pbar[a] = (float)ax[21 + a];
+    g.qbar[a] = (float)ax[24 + a];
+  }
+  g.dbar = (float)pg[15];
+  g.inv_wsum = (float)pg[16];
+  const size_t fe = (size_t)b * p.frames + i, fl = fe + 1;
+  const DenseTile t = dense_tile(p, src);
+  stage_depth_window(p, src, t, win);
+  for (int c = threadIdx.x; c < kWinH * kWinW; c += blockDim.x) gwin[c] = 0.f;
+  __syncthreads();
+
+  float acc[18];  // [0..8] dKinv later frame, [9..17] dKinv earlier frame
+#pragma unroll
+  for (int k = 0; k < 18; ++k) acc[k] = 0.f;
+  const int col = t.tx0 + (threadIdx.x & (kTileW - 1));
+  for (int r = threadIdx.x / kTileW; r < kTileH; r += 256 / kTileW) {
+    const int row = t.ty0 + r;
+    if (row >= p.height || col >= p.width) continue;
+    const int idx = row * p.width + col;
+    const Corr c = corr_load_with(src, kinv_e, kinv_l, idx, [&](int tr, int tc) {
+      const int cell = window_cell(t, tr, tc);
+      return cell >= 0 ? win[cell] : src.depth_e[(size_t)tr * p.width + tc];
+    });
+    float gq[3], gp[3], gw;
+    corr_backward(c, g, gq, gp, gw);
+    if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
+    if (p.grad_weights) p.grad_weights[pair * (size_t)n + idx] = gw;
+    const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
+    if (p.grad_depth) atomicAdd(p.grad_depth + fl * n + idx, gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2]);
+    const float zh[3] = {c.z_p * u, c.z_p * v, c.z_p};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) acc[a * 3 + d] += gp[a] * zh[d];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!c.taps.in[k]) continue;
+      const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
+      const float ut = pixel_center(tc, p.width), vt = pixel_center(tr, p.height);
+      const int cell = window_cell(t, tr, tc);
+      const float z = cell >= 0 ? win[cell] : p.depth[fe * n + (size_t)tr * p.width + tc];
+      float ray[3];
+      ray_dir(kinv_e, ut, vt, ray);
+      const float wt = c.taps.w[k];
+      const float gz = wt * (gq[0] * ray[0] + gq[1] * ray[1] + gq[2] * ray[2]);
+      if (p.grad_depth) {
+        if (cell >= 0) atomicAdd(gwin + cell, gz);
+        else atomicAdd(p.grad_depth + fe * n + (size_t)tr * p.width + tc, gz);
+      }
+      const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[9 + a * 3 + d] += gq[a] * zt[d];
+    }
+  }
+  __syncthreads();
+  if (p.grad_depth) {
+    for (int c = threadIdx.x; c < kWinH * kWinW; c += blockDim.x) {
+      const float v = gwin[c];
+      if (v == 0.f) continue;  // cells outside the image or never hit
+      const int gy = t.wy0 + c / kWinW, gx = t.wx0 + c % kWinW;
+      atomicAdd(p.grad_depth + fe * n + (size_t)gy * p.width + gx, v);
+    }
+  }
+  if (p.kinv_acc) {
+    float ordered[18];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      ordered[k] = acc[9 + k];
+      ordered[9 + k] = acc[k];
+    }
+    block_accumulate<18>(ordered, red, p.kinv_acc + fe * 9);
   }
 }
 
@@ -442,6 +614,13 @@ __global__ void kinv_grad_to_k_kernel(const double* kinv_acc, const float* kinv,
 
 using namespace fm;
 
+// The tiled dense kernels apply to depth-sourced surfaces with every pixel a correspondence.
+static inline bool dense_tiled(const float* depth, const float* surfaces, const int64_t* indices, long points, int batch_repeat,
+                               int height, int width) {
+  return depth && !surfaces && !indices && batch_repeat == 1 && points == (long)height * width &&
+         (height + kTileH - 1) / kTileH <= 65535;
+}
+
 static inline int choose_iters(long points) {
   // P ~ 1000: the work per pair is a latency chain of gathers, so spread it over as many
   // blocks as possible (4 blocks x 149 pairs instead of 149 blocks: 105 -> ~35 us for the
@@ -468,12 +647,17 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
   p.batch_repeat = batch_repeat;
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
-  if (surfaces) {
-    hipLaunchKernelGGL((procrustes_stats_kernel<SRC_SURF, 1>), grid, dim3(256), 0, st, p, iters);
-    hipLaunchKernelGGL((procrustes_stats_kernel<SRC_SURF, 2>), grid, dim3(256), 0, st, p, iters);
+  const dim3 fgrid((unsigned)((pairs + 63) / 64));
+  if (dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width)) {
+    const dim3 tgrid((width + kTileW - 1) / kTileW, (height + kTileH - 1) / kTileH, pairs);
+    hipLaunchKernelGGL(procrustes_moments_dense_kernel, tgrid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((procrustes_moments_finish_kernel<SRC_DEPTH>), fgrid, dim3(64), 0, st, p, pairs);
+  } else if (surfaces) {
+    hipLaunchKernelGGL((procrustes_moments_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, iters);
+    hipLaunchKernelGGL((procrustes_moments_finish_kernel<SRC_SURF>), fgrid, dim3(64), 0, st, p, pairs);
   } else {
-    hipLaunchKernelGGL((procrustes_stats_kernel<SRC_DEPTH, 1>), grid, dim3(256), 0, st, p, iters);
-    hipLaunchKernelGGL((procrustes_stats_kernel<SRC_DEPTH, 2>), grid, dim3(256), 0, st, p, iters);
+    hipLaunchKernelGGL((procrustes_moments_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, iters);
+    hipLaunchKernelGGL((procrustes_moments_finish_kernel<SRC_DEPTH>), fgrid, dim3(64), 0, st, p, pairs);
   }
   FM_LAUNCH_STATUS();
 }
@@ -509,7 +693,10 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
   p.batch_repeat = batch_repeat;
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
-  if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);
+  if (dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width)) {
+    const dim3 tgrid((width + kTileW - 1) / kTileW, (height + kTileH - 1) / kTileH, pairs);
+    hipLaunchKernelGGL(procrustes_scatter_dense_kernel, tgrid, dim3(256), 0, st, p, aux);
+  } else if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);
   else hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, aux, iters);
   FM_LAUNCH_STATUS();
 }

@@ -267,27 +267,16 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
     }
     const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, sens, pr, b, i, frames, height, width, repeat);
     double* st = stats + (size_t)pr * kStatStride;
-    for (long j = 0; j < points; ++j) {
-      const Corr c = corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j);
-      st[0] += c.w;
-      for (int a = 0; a < 3; ++a) {
-        st[1 + a] += c.w * c.p[a];
-        st[4 + a] += c.w * c.q[a];
-      }
+    float shift[3];
+    const long mid = points / 2;
+    later_point(src, kl, indices ? (int)indices[mid] : (int)mid, shift);
+    for (long j0 = 0; j0 < points; j0 += 256) {  // fp32 partial sums per 256 points, fp64 across (as the kernel)
+      float acc[kMomentCount] = {};
+      for (long j = j0; j < points && j < j0 + 256; ++j)
+        moments_add(corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j), shift, acc);
+      for (int k = 0; k < kMomentCount; ++k) st[k] += acc[k];
     }
-    const double inv = 1.0 / (st[0] + 1e-8);
-    float pbar[3], qbar[3];
-    for (int a = 0; a < 3; ++a) {
-      pbar[a] = (float)(st[1 + a] * inv);
-      qbar[a] = (float)(st[4 + a] * inv);
-    }
-    for (long j = 0; j < points; ++j) {
-      const Corr c = corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j);
-      for (int a = 0; a < 3; ++a) {
-        const float wq = c.w * (c.q[a] - qbar[a]);
-        for (int d = 0; d < 3; ++d) st[7 + a * 3 + d] += wq * (c.p[d] - pbar[d]);
-      }
-    }
+    moments_finish(st, shift);
   }
   return 0;
 }
