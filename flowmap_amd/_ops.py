@@ -316,7 +316,10 @@ class ProcrustesFit(torch.autograd.Function):
             # (zero-filling this 549 MB buffer early on a side stream, behind the latency-bound
             # fit kernels, was measured: the fill's blocks delay those kernels and then contend
             # with the fused flow kernel — step 1.126 -> 1.187 ms.  Kept in line.)
-            g_w = torch.zeros_like(weights)
+            # the tiled dense kernels (depth-sourced, every pixel a correspondence) STORE every
+            # element of dL/dweights; all other paths accumulate atomically into zeros
+            dense_tiled = ctx.from_depth and indices is None and ctx.rep == 1
+            g_w = torch.empty_like(weights) if dense_tiled else torch.zeros_like(weights)
         kinv_acc = torch.zeros((b * f, 9), dtype=torch.float64, device=dev) if need_k else None
         with _guard(dev):
             st = stream_for(weights)

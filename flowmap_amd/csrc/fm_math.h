@@ -475,17 +475,37 @@ struct Corr {
   float z_p;
 };
 
-// `tap(row, col)` reads the EARLIER frame's depth (global memory, or an LDS-staged window in the
-// dense tiled kernels); only used when the surfaces are depth-sourced.
-template <class DepthTap>
-FM_HD Corr corr_load_with(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, int idx, const DepthTap& tap) {
+// `tap(row, col, u, v)` returns the EARLIER frame's depth at that pixel and its pixel-centre
+// coordinates (global memory + two true divisions, or an LDS-staged window with coordinate tables
+// in the dense tiled kernels); only used when the surfaces are depth-sourced.
+// The later-frame pixel of a correspondence: flat index and pixel-centre coordinates.
+struct PixelRef {
+  int idx;
+  float u, v;
+};
+FM_HD PixelRef pixel_ref(int idx, int height, int width) {
+  const int row = idx / width, col = idx - row * width;
+  return {idx, pixel_center(col, width), pixel_center(row, height)};
+}
+
+// sigmoid(x); FAST uses the hardware exp2 / rcp (about 2 ulp) on the device.
+template <bool FAST>
+FM_HD float fm_sigmoid(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (FAST) return fm_rcp(1.0f + __expf(-x));
+#endif
+  return 1.0f / (1.0f + expf(-x));
+}
+
+template <bool FAST, class DepthTap>
+FM_HD Corr corr_load_with(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, const PixelRef& px, const DepthTap& tap) {
   Corr c;
+  const int idx = px.idx;
   c.idx = idx;
-  const int row = idx / s.width, col = idx - row * s.width;
-  const float u = pixel_center(col, s.width), v = pixel_center(row, s.height);
+  const float u = px.u, v = px.v;
   const float fx = s.bwd_flow[2 * (size_t)idx], fy = s.bwd_flow[2 * (size_t)idx + 1];
   c.w = s.weights[idx];
-  if (s.weight_sens != 0.f) c.w = 1.0f / (1.0f + expf(-s.weight_sens * c.w));
+  if (s.weight_sens != 0.f) c.w = fm_sigmoid<FAST>(s.weight_sens * c.w);
   c.taps = bilinear_taps(u + fx, v + fy, s.height, s.width);
   c.q[0] = c.q[1] = c.q[2] = 0.f;
   c.z_p = 0.f;
@@ -499,9 +519,10 @@ FM_HD Corr corr_load_with(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv
     for (int k = 0; k < 4; ++k) {
       if (!c.taps.in[k]) continue;
       const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
-      const float z = tap(tr, tc);
+      float ut, vt;
+      const float z = tap(tr, tc, ut, vt);
       float ray[3];
-      ray_dir(kinv_e, pixel_center(tc, s.width), pixel_center(tr, s.height), ray);
+      ray_dir(kinv_e, ut, vt, ray);
       c.q[0] += (ray[0] * z) * c.taps.w[k];
       c.q[1] += (ray[1] * z) * c.taps.w[k];
       c.q[2] += (ray[2] * z) * c.taps.w[k];
@@ -581,7 +602,11 @@ FM_HD void moments_finish(double* st, const float s[3]) {
 }
 
 FM_HD Corr corr_load(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, int idx) {
-  return corr_load_with(s, kinv_e, kinv_l, idx, [&](int tr, int tc) { return s.depth_e[tr * s.width + tc]; });
+  return corr_load_with<false>(s, kinv_e, kinv_l, pixel_ref(idx, s.height, s.width), [&](int tr, int tc, float& ut, float& vt) {
+    ut = pixel_center(tc, s.width);
+    vt = pixel_center(tr, s.height);
+    return s.depth_e[tr * s.width + tc];
+  });
 }
 
 // Per-pair constants of the Procrustes backward (produced by the pose-solve backward).

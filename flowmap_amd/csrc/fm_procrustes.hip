@@ -131,12 +131,39 @@ constexpr int kWinH = kTileH + 2 * kHaloY, kWinW = kTileW + 2 * kHaloX;  // 48 x
 struct DenseTile {
   int tx0, ty0;  // tile origin (later frame)
   int wx0, wy0;  // window origin (earlier frame)
+  float inv_w, inv_h;
 };
 
-__device__ __forceinline__ DenseTile dense_tile(const ProcParams& p, const CorrSrc& src) {
+// 1-D grid -> (pair, tile).  Workgroups are handed to the 8 XCDs round-robin by linear id and
+// each XCD has its own L2, so consecutive ids are sent to the SAME XCD's contiguous run of tiles:
+// neighbouring tiles (whose earlier-frame windows overlap five-fold) then share an L2.
+constexpr int kXcds = 8;
+struct DenseBlock {
+  long pair;
+  int tile_x, tile_y;
+  bool valid;
+};
+
+__device__ __forceinline__ DenseBlock dense_block(const ProcParams& p, long total) {
+  const int tiles_x = (p.width + kTileW - 1) / kTileW, tiles_y = (p.height + kTileH - 1) / kTileH;
+  const long per_xcd = (total + kXcds - 1) / kXcds;
+  const long logical = (long)(blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+  DenseBlock d;
+  d.valid = blockIdx.x / kXcds < per_xcd && logical < total;
+  const long per_pair = (long)tiles_x * tiles_y;
+  d.pair = logical / per_pair;
+  const int tile = (int)(logical - d.pair * per_pair);
+  d.tile_y = tile / tiles_x;
+  d.tile_x = tile - d.tile_y * tiles_x;
+  return d;
+}
+
+__device__ __forceinline__ DenseTile dense_tile(const ProcParams& p, const CorrSrc& src, const DenseBlock& blk) {
   DenseTile t;
-  t.tx0 = blockIdx.x * kTileW;
-  t.ty0 = blockIdx.y * kTileH;
+  t.tx0 = blk.tile_x * kTileW;
+  t.ty0 = blk.tile_y * kTileH;
+  t.inv_w = 1.0f / (float)p.width;
+  t.inv_h = 1.0f / (float)p.height;
   const int cx = min(t.tx0 + kTileW / 2, p.width - 1), cy = min(t.ty0 + kTileH / 2, p.height - 1);
   const float fx = src.bwd_flow[2 * ((size_t)cy * p.width + cx)], fy = src.bwd_flow[2 * ((size_t)cy * p.width + cx) + 1];
   const float ox = fminf(fmaxf(rintf(fx * (float)p.width), -1.0e6f), 1.0e6f);
@@ -146,11 +173,25 @@ __device__ __forceinline__ DenseTile dense_tile(const ProcParams& p, const CorrS
   return t;
 }
 
-__device__ __forceinline__ void stage_depth_window(const ProcParams& p, const CorrSrc& src, const DenseTile& t, float* win) {
+// Window of the earlier frame's depth plus the pixel-centre coordinates of its columns / rows
+// (sample_image_grid's true divisions, done once per block instead of ten times per pixel).
+struct DenseWindow {
+  float z[kWinH * kWinW];
+  float u[kWinW];
+  float v[kWinH];
+  float tile_u[kTileW];  // the tile's own (later-frame) columns / rows
+  float tile_v[kTileH];
+};
+
+__device__ __forceinline__ void stage_depth_window(const ProcParams& p, const CorrSrc& src, const DenseTile& t, DenseWindow& win) {
   for (int i = threadIdx.x; i < kWinH * kWinW; i += blockDim.x) {
     const int gy = t.wy0 + i / kWinW, gx = t.wx0 + i % kWinW;
-    win[i] = (gy >= 0 && gy < p.height && gx >= 0 && gx < p.width) ? src.depth_e[(size_t)gy * p.width + gx] : 0.f;
+    win.z[i] = (gy >= 0 && gy < p.height && gx >= 0 && gx < p.width) ? src.depth_e[(size_t)gy * p.width + gx] : 0.f;
   }
+  for (int i = threadIdx.x; i < kWinW; i += blockDim.x) win.u[i] = pixel_center(t.wx0 + i, p.width);
+  for (int i = threadIdx.x; i < kWinH; i += blockDim.x) win.v[i] = pixel_center(t.wy0 + i, p.height);
+  for (int i = threadIdx.x; i < kTileW; i += blockDim.x) win.tile_u[i] = pixel_center(t.tx0 + i, p.width);
+  for (int i = threadIdx.x; i < kTileH; i += blockDim.x) win.tile_v[i] = pixel_center(t.ty0 + i, p.height);
 }
 
 // window cell of image pixel (row, col), or -1
@@ -159,11 +200,30 @@ __device__ __forceinline__ int window_cell(const DenseTile& t, int row, int col)
   return (r >= 0 && r < kWinH && c >= 0 && c < kWinW) ? r * kWinW + c : -1;
 }
 
-// grid: (ceil(W/64), ceil(H/16), pairs).  Raw moments of all pixels of the tile.
-__global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParams p) {
+// depth + coordinates of earlier-frame pixel (row, col): window hit or global fallback
+__device__ __forceinline__ float window_tap(const ProcParams& p, const CorrSrc& src, const DenseTile& t, const DenseWindow& win, int row,
+                                            int col, float& ut, float& vt) {
+  const int r = row - t.wy0, c = col - t.wx0;
+  if (r >= 0 && r < kWinH && c >= 0 && c < kWinW) {
+    ut = win.u[c];
+    vt = win.v[r];
+    return win.z[r * kWinW + c];
+  }
+  // sample left the window (rare with real flows): reciprocal multiply instead of the true
+  // division of sample_image_grid — within 1 ulp, and the divisions would otherwise run for every
+  // wave in which a single lane misses
+  ut = ((float)col + 0.5f) * t.inv_w;
+  vt = ((float)row + 0.5f) * t.inv_h;
+  return src.depth_e[(size_t)row * p.width + col];
+}
+
+// grid: 1-D, >= tiles·pairs blocks (dense_block).  Raw moments of all pixels of the tile.
+__global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParams p, long total) {
   __shared__ double red[4 * kMomentCount];
-  __shared__ float win[kWinH * kWinW];
-  const size_t pair = blockIdx.z;
+  __shared__ DenseWindow win;
+  const DenseBlock blk = dense_block(p, total);
+  if (!blk.valid) return;
+  const size_t pair = (size_t)blk.pair;
   const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
   Mat3 kinv_e, kinv_l;
   load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
@@ -171,7 +231,7 @@ __global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParam
   const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
   float shift[3];
   pair_shift<SRC_DEPTH>(p, src, kinv_l, shift);
-  const DenseTile t = dense_tile(p, src);
+  const DenseTile t = dense_tile(p, src, blk);
   stage_depth_window(p, src, t, win);
   __syncthreads();
   float acc[kMomentCount];
@@ -181,10 +241,9 @@ __global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParam
   for (int r = threadIdx.x / kTileW; r < kTileH; r += 256 / kTileW) {
     const int row = t.ty0 + r;
     if (row >= p.height || col >= p.width) continue;
-    const Corr c = corr_load_with(src, kinv_e, kinv_l, row * p.width + col, [&](int tr, int tc) {
-      const int cell = window_cell(t, tr, tc);
-      return cell >= 0 ? win[cell] : src.depth_e[(size_t)tr * p.width + tc];
-    });
+    const PixelRef px{row * p.width + col, win.tile_u[threadIdx.x & (kTileW - 1)], win.tile_v[r]};
+    const Corr c = corr_load_with<true>(src, kinv_e, kinv_l, px,
+                                        [&](int tr, int tc, float& ut, float& vt) { return window_tap(p, src, t, win, tr, tc, ut, vt); });
     moments_add(c, shift, acc);
   }
   block_accumulate<kMomentCount>(acc, red, p.stats + pair * kStatStride);
@@ -316,11 +375,13 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
 // Dense backward: per-pixel gradients of the tile; dL/dweights is STORED (every pixel of every pair
 // is written exactly once: the caller need not zero it), the later-frame depth gradient is one
 // coalesced atomic per pixel, the four tap gradients go to the LDS window, flushed at the end.
-__global__ void __launch_bounds__(256) procrustes_scatter_dense_kernel(ProcParams p, const double* aux) {
+__global__ void __launch_bounds__(256) procrustes_scatter_dense_kernel(ProcParams p, const double* aux, long total) {
   __shared__ double red[4 * 18];
-  __shared__ float win[kWinH * kWinW];
+  __shared__ DenseWindow win;
   __shared__ float gwin[kWinH * kWinW];
-  const size_t pair = blockIdx.z;
+  const DenseBlock blk = dense_block(p, total);
+  if (!blk.valid) return;
+  const size_t pair = (size_t)blk.pair;
   const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
   const int n = p.height * p.width;
   Mat3 kinv_e, kinv_l;
@@ -340,7 +401,7 @@ __global__ void __launch_bounds__(256) procrustes_scatter_dense_kernel(ProcParam
   g.dbar = (float)pg[15];
   g.inv_wsum = (float)pg[16];
   const size_t fe = (size_t)b * p.frames + i, fl = fe + 1;
-  const DenseTile t = dense_tile(p, src);
+  const DenseTile t = dense_tile(p, src, blk);
   stage_depth_window(p, src, t, win);
   for (int c = threadIdx.x; c < kWinH * kWinW; c += blockDim.x) gwin[c] = 0.f;
   __syncthreads();
@@ -353,17 +414,15 @@ __global__ void __launch_bounds__(256) procrustes_scatter_dense_kernel(ProcParam
     const int row = t.ty0 + r;
     if (row >= p.height || col >= p.width) continue;
     const int idx = row * p.width + col;
-    const Corr c = corr_load_with(src, kinv_e, kinv_l, idx, [&](int tr, int tc) {
-      const int cell = window_cell(t, tr, tc);
-      return cell >= 0 ? win[cell] : src.depth_e[(size_t)tr * p.width + tc];
-    });
+    const PixelRef px{idx, win.tile_u[threadIdx.x & (kTileW - 1)], win.tile_v[r]};
+    const Corr c = corr_load_with<true>(src, kinv_e, kinv_l, px,
+                                        [&](int tr, int tc, float& ut, float& vt) { return window_tap(p, src, t, win, tr, tc, ut, vt); });
     float gq[3], gp[3], gw;
     corr_backward(c, g, gq, gp, gw);
     if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
     if (p.grad_weights) p.grad_weights[pair * (size_t)n + idx] = gw;
-    const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
     if (p.grad_depth) atomicAdd(p.grad_depth + fl * n + idx, gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2]);
-    const float zh[3] = {c.z_p * u, c.z_p * v, c.z_p};
+    const float zh[3] = {c.z_p * px.u, c.z_p * px.v, c.z_p};
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -372,9 +431,9 @@ __global__ void __launch_bounds__(256) procrustes_scatter_dense_kernel(ProcParam
     for (int k = 0; k < 4; ++k) {
       if (!c.taps.in[k]) continue;
       const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
-      const float ut = pixel_center(tc, p.width), vt = pixel_center(tr, p.height);
       const int cell = window_cell(t, tr, tc);
-      const float z = cell >= 0 ? win[cell] : p.depth[fe * n + (size_t)tr * p.width + tc];
+      float ut, vt;
+      const float z = window_tap(p, src, t, win, tr, tc, ut, vt);
       float ray[3];
       ray_dir(kinv_e, ut, vt, ray);
       const float wt = c.taps.w[k];
@@ -615,10 +674,14 @@ __global__ void kinv_grad_to_k_kernel(const double* kinv_acc, const float* kinv,
 using namespace fm;
 
 // The tiled dense kernels apply to depth-sourced surfaces with every pixel a correspondence.
+static inline long dense_blocks(int height, int width, int pairs) {
+  return (long)((width + kTileW - 1) / kTileW) * ((height + kTileH - 1) / kTileH) * pairs;
+}
+static inline unsigned dense_grid(long total) { return (unsigned)(((total + kXcds - 1) / kXcds) * kXcds); }
 static inline bool dense_tiled(const float* depth, const float* surfaces, const int64_t* indices, long points, int batch_repeat,
-                               int height, int width) {
+                               int height, int width, int pairs) {
   return depth && !surfaces && !indices && batch_repeat == 1 && points == (long)height * width &&
-         (height + kTileH - 1) / kTileH <= 65535;
+         dense_blocks(height, width, pairs) < (1L << 31) - kXcds;
 }
 
 static inline int choose_iters(long points) {
@@ -648,9 +711,9 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
   const dim3 fgrid((unsigned)((pairs + 63) / 64));
-  if (dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width)) {
-    const dim3 tgrid((width + kTileW - 1) / kTileW, (height + kTileH - 1) / kTileH, pairs);
-    hipLaunchKernelGGL(procrustes_moments_dense_kernel, tgrid, dim3(256), 0, st, p);
+  if (dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width, pairs)) {
+    const long total = dense_blocks(height, width, pairs);
+    hipLaunchKernelGGL(procrustes_moments_dense_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, total);
     hipLaunchKernelGGL((procrustes_moments_finish_kernel<SRC_DEPTH>), fgrid, dim3(64), 0, st, p, pairs);
   } else if (surfaces) {
     hipLaunchKernelGGL((procrustes_moments_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, iters);
@@ -693,9 +756,9 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
   p.batch_repeat = batch_repeat;
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
-  if (dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width)) {
-    const dim3 tgrid((width + kTileW - 1) / kTileW, (height + kTileH - 1) / kTileH, pairs);
-    hipLaunchKernelGGL(procrustes_scatter_dense_kernel, tgrid, dim3(256), 0, st, p, aux);
+  if (dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width, pairs)) {
+    const long total = dense_blocks(height, width, pairs);
+    hipLaunchKernelGGL(procrustes_scatter_dense_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, aux, total);
   } else if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);
   else hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, aux, iters);
   FM_LAUNCH_STATUS();
