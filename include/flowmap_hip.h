@@ -121,7 +121,10 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
  * projection.py:226-249).  ATOMICALLY ADDS into grad_depth (B,F,H,W) or grad_surfaces
  * (B,F,H,W,3) and grad_weights (B,F-1,H,W): callers zero them (or pass a buffer that
  * already holds another gradient to fuse the accumulation).  kinv_acc (B*F,9) fp64:
- * dL/dK⁻¹ accumulators (caller zeroes), depth source only.  Any output may be NULL. */
+ * dL/dK⁻¹ accumulators (caller zeroes), depth source only.  Any output may be NULL.
+ * Exception — dense depth-sourced mode (surfaces == NULL, indices == NULL, points == H·W,
+ * batch_repeat == 1): every element of grad_weights is STORED exactly once (it need not be
+ * zeroed and must not hold another gradient); grad_depth is still added to. */
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
                           int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,

@@ -330,7 +330,13 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
       float gq[3], gp[3], gw;
       corr_backward(c, g, gq, gp, gw);
       if (sens != 0.f) gw *= sens * c.w * (1.f - c.w);
-      if (grad_weights) grad_weights[dpair * n + c.idx] += gw;
+      // dense depth-sourced mode: every element is written exactly once and the real library STORES it
+      // (the caller does not zero the buffer); every other mode accumulates into zeros
+      const bool stores = depth && !surfaces && !indices && repeat == 1 && points == (long)n;
+      if (grad_weights) {
+        if (stores) grad_weights[dpair * n + c.idx] = gw;
+        else grad_weights[dpair * n + c.idx] += gw;
+      }
       if (!surfaces) {
         const int row = c.idx / width, col = c.idx - row * width;
         const float u = pixel_center(col, width), v = pixel_center(row, height);
