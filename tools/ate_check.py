@@ -65,7 +65,7 @@ def run(args):
     flows = to_flows(sc["flows"], dev)
     batch = Batch(torch.zeros((1, f, 3, 1, 1), device=dev).expand(1, f, 3, h, w))
     loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    opt = flowmap_amd.FusedAdam(model.parameters(), lr=args.lr)  # the reference leg above uses torch.optim.Adam
     if dev.type == "cuda":
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -91,6 +91,7 @@ def run(args):
         "ate_abs_diff": abs(ate_ref - ate_ours),
         "final_loss_reference_path": loss_ref, "final_loss_flowmap_amd": loss_ours,
         "seconds_reference_path_cpu": t_ref, "seconds_flowmap_amd": t_ours, "device": str(dev),
+        "optimizer": "reference path: torch.optim.Adam; flowmap_amd: flowmap_amd.FusedAdam",
     }
 
 
