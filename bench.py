@@ -273,7 +273,7 @@ def main():
                 "loss": float(loss.item()),
             },
             "roofline": {
-                "kernel": "fm::flow_fused_kernel<4,true>",
+                "kernel": "fm::flow_fused_kernel<VEC=4, huber, GRAD, PACKED>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -30,9 +30,15 @@ def main():
     f, h, w = args.frames, args.height, args.width
     shape = (h // args.scale, w // args.scale)
     g = torch.Generator(device=dev).manual_seed(0)
-    videos = torch.rand((1, f, 3, h, w), device=dev, generator=g)
-    raw_f = 0.01 * torch.randn((1, f - 1, h, w, 2), device=dev, generator=g)
-    raw_b = 0.01 * torch.randn((1, f - 1, h, w, 2), device=dev, generator=g)
+    # smooth video and flows (i.i.d. noise at 5120 px makes the photometric mask ill-conditioned:
+    # a 1-ulp difference in a sampling coordinate moves (1-d)^8 by 1e-3)
+    def smooth(shape_low, channels):
+        low = torch.rand((channels, 1, *shape_low), device=dev, generator=g)
+        return torch.nn.functional.interpolate(low, size=(h, w), mode="bicubic", align_corners=False)[:, 0]
+
+    videos = smooth((h // 64, w // 64), f * 3).clamp(0, 1).reshape(1, f, 3, h, w).contiguous()
+    raw_f = (0.02 * (smooth((h // 128, w // 128), (f - 1) * 2) - 0.5)).reshape(1, f - 1, 2, h, w).permute(0, 1, 3, 4, 2).contiguous()
+    raw_b = (0.02 * (smooth((h // 128, w // 128), (f - 1) * 2) - 0.5)).reshape(1, f - 1, 2, h, w).permute(0, 1, 3, 4, 2).contiguous()
     flipped = videos.flip(dims=(1,))
 
     def ours():
