@@ -183,7 +183,10 @@ def main():
     if args.tracking:
         from flowmap_amd.loss import LossTracking, LossTrackingCfg
 
-        tracks = make_tracks(f, device, seed=100 + rank)
+        sharded_tracks = dist is not None and world > 1
+        # sharded: ONE track set over the whole (world x 149 + 1)-frame video, global frame indices,
+        # identical on every rank; each rank evaluates the sources it owns (FrameShard.tracking_loss)
+        tracks = make_tracks(world * (f - 1) + 1 if sharded_tracks else f, device, seed=100 if sharded_tracks else 100 + rank)
         track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
     shard = FrameShard(rank, world if dist is None else max(world, 1), dist)
     if dist is not None and world == 1:
@@ -204,10 +207,15 @@ def main():
         model.zero_grad(set_to_none=True)
         out = model(batch, flows, 0)
         loss = loss_fn(batch, flows, None, out, 0)
-        if track_fn is not None:
-            loss = loss + track_fn(batch, flows, tracks, out, 0)
-        loss.backward()
-        shard.sync(loss, getattr(model.intrinsics, "focal_length", None), model.backbone.depth)
+        tracked = None
+        if track_fn is not None and dist is not None and world > 1:
+            tracked = shard.tracking_loss(track_fn, tracks, out, world * (f - 1))  # global value, this rank's gradients
+            (loss + tracked).backward()
+        else:
+            if track_fn is not None:
+                loss = loss + track_fn(batch, flows, tracks, out, 0)
+            loss.backward()
+        shard.sync(loss, getattr(model.intrinsics, "focal_length", None), model.backbone.depth, already_global=tracked)
         if optimizer is not None:
             optimizer.step()
         return loss

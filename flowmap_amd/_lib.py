@@ -59,10 +59,10 @@ SIGNATURES = {
     "fm_align_rigid_stats": [P, P, P, I, L, P, P],
     "fm_align_rigid_bwd": [P, P, P, I, L, P, P, P, P, P, P],
     "fm_extrinsics_inverse": [P, I, P, P],
-    "fm_track_points": [P] * 5 + [I] + [P] * 4 + [I, I, I, I, P, P, P, P],
-    "fm_track_loss_fwd": [P] * 6 + [I, I, I, P, P, I, I, I, I, F, F, F, F] + [P] * 6 + [P],
+    "fm_track_points": [P, I] + [P] * 4 + [I] + [P] * 4 + [I, I, I, I, P, P, P, P],
+    "fm_track_loss_fwd": [P] * 6 + [I, I, I, P, P, I, I, I, I, F, F, F, F] + [P] * 7 + [P],
     "fm_track_loss_bwd": [P] * 7 + [I, P, P, P],
-    "fm_track_scatter": [P] * 6 + [I, I, P, P, P, I, I, P, P],
+    "fm_track_scatter": [P] * 6 + [I, I, P, P, P, I, I, I, P, P],
 }
 
 _lib: Optional[ctypes.CDLL] = None

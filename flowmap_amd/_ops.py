@@ -707,28 +707,33 @@ class AlignRigid(torch.autograd.Function):
 
 class PackedTracks:
     """All track segments (flowmap/tracking/track_predictor.py:13-20) packed into the flat
-    arrays fm_track_* expects.  Tracks are constants of the optimisation: packed once."""
+    arrays fm_track_* expects.  Tracks are constants of the optimisation: packed once.
+    ``own = (first, end)``: frame sharding — only frames first <= frame < end act as SOURCES on
+    this rank (the targets of a segment can lie on any rank; they need poses, not depth)."""
 
-    def __init__(self, tracks, device):
+    def __init__(self, tracks, device, own=None):
         xy, vis, seg, blocks, tiles = [], [], [], [], []
         offset = 0
+        owned = (lambda frame: True) if own is None else (lambda frame: own[0] <= frame < own[1])
         for s_idx, t in enumerate(tracks):
             b, f, p, _ = t.xy.shape
             if b != 1:
                 raise RuntimeError("flowmap_amd: the fused tracking loss supports batch size 1 (as the reference asserts)")
+            start = int(t.start_frame)
             xy.append(t.xy[0].reshape(f * p, 2).to(device=device, dtype=torch.float32))
             vis.append(t.visibility[0].reshape(f * p).to(device=device, dtype=torch.uint8))
-            seg.append([int(t.start_frame), f, p, offset])
-            blocks.extend([s_idx, fr] for fr in range(f))
-            tiles.extend([s_idx, fr] for fr in range(0, f, TRACK_TILE))
+            seg.append([start, f, p, offset])
+            blocks.extend([s_idx, fr] for fr in range(f) if owned(start + fr))
+            tiles.extend([s_idx, fr] for fr in range(0, f, TRACK_TILE) if any(owned(start + q) for q in range(fr, min(fr + TRACK_TILE, f))))
             offset += f * p
         self.total = offset
+        self.partial = own is not None  # some (segment, frame) entries are not sources here: flags start at 0
         self.xy = torch.cat(xy).contiguous()
         self.vis = torch.cat(vis).contiguous()
         self.seg = torch.tensor(seg, dtype=torch.int32).to(device)
-        self.blocks = torch.tensor(blocks, dtype=torch.int32).to(device)
+        self.blocks = torch.tensor(blocks, dtype=torch.int32).reshape(-1, 2).to(device)
         self.nblocks = len(blocks)
-        self.tiles = torch.tensor(tiles, dtype=torch.int32).to(device)  # (segment, first source frame) per register tile
+        self.tiles = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 2).to(device)  # (segment, first source frame) per register tile
         self.ntiles = len(tiles)
         self.pmax = max(s_[2] for s_ in seg)
         self.fmax = max(s_[1] for s_ in seg)
@@ -738,8 +743,8 @@ class PackedTracks:
 _packed_cache: dict = {}
 
 
-def pack_tracks(tracks, device) -> PackedTracks:
-    key = tuple((t.xy.data_ptr(), t.xy._version, t.visibility.data_ptr(), int(t.start_frame), tuple(t.xy.shape)) for t in tracks) + (str(device),)
+def pack_tracks(tracks, device, own=None) -> PackedTracks:
+    key = tuple((t.xy.data_ptr(), t.xy._version, t.visibility.data_ptr(), int(t.start_frame), tuple(t.xy.shape)) for t in tracks) + (str(device), own)
     hit = _packed_cache.get(key)
     if hit is not None:
         packed, refs = hit
@@ -747,53 +752,76 @@ def pack_tracks(tracks, device) -> PackedTracks:
             return packed
     if len(_packed_cache) > 4:
         _packed_cache.clear()
-    packed = PackedTracks(tracks, device)
+    packed = PackedTracks(tracks, device, own)
     _packed_cache[key] = (packed, [weakref.ref(t.xy) for t in tracks])
     return packed
 
 
 class TrackLossFused(torch.autograd.Function):
     """weight · LossTracking.compute_unweighted_loss (flowmap/loss/loss_tracking.py:28-61,
-    flowmap/loss/loss.py:47) over all segments, from depth + intrinsics + extrinsics."""
+    flowmap/loss/loss.py:47) over all segments, from depth + intrinsics + extrinsics.
+
+    Frame sharding (flowmap_amd/sharding.py): ``depth`` holds the rank's frames from ``frame0`` on,
+    ``k`` / ``ext`` the whole video; ``packed`` was built with this rank's ``own`` source range;
+    ``reducer`` sums the fp64 pair [Σρ, count] over the ranks.  The result is then the GLOBAL loss,
+    the gradients this rank's share of it (autograd / FrameShard.sync sum them)."""
 
     @staticmethod
-    def forward(ctx, depth, k, ext, packed: PackedTracks, weight, kind, delta, defer):
+    def forward(ctx, depth, k, ext, packed: PackedTracks, weight, kind, delta, defer, frame0=0, reducer=None, fit_from=None):
         dev = check_device(depth, k, ext, packed.xy)
         depth, k, ext = _f32c(depth, "depth"), _f32c(k, "intrinsics"), _f32c(ext, "extrinsics")
-        b, f, h, w = depth.shape
+        b, f_local, h, w = depth.shape
+        f = ext.shape[1]
         if b != 1:
             raise RuntimeError("flowmap_amd: the fused tracking loss supports batch size 1")
+        if tuple(k.shape) != (1, f, 3, 3) or tuple(ext.shape) != (1, f, 4, 4) or frame0 < 0 or frame0 + f_local > f:
+            raise RuntimeError("flowmap_amd: intrinsics / extrinsics must cover the whole video and depth a window of it")
         if packed.last_frame > f:
             raise RuntimeError("flowmap_amd: a track segment extends past the last frame")
         kinv = intrinsics_inverse(k)
         ext_inv = torch.empty_like(ext)
         ws = torch.empty((packed.total, 9), dtype=torch.float32, device=dev)
-        flag = torch.empty((packed.total,), dtype=torch.uint8, device=dev)
+        flag = (torch.zeros if packed.partial else torch.empty)((packed.total,), dtype=torch.uint8, device=dev)
         acc = torch.empty((f * 20,), dtype=torch.float64, device=dev)
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
         scale = torch.empty((2,), dtype=torch.float32, device=dev)
+        totals = torch.empty((2,), dtype=torch.float64, device=dev)
         need = any(ctx.needs_input_grad[:3])
         # every residual is evaluated once: the (unscaled) gradients come out of the same launch
         gws = torch.empty((packed.total, 3), dtype=torch.float32, device=dev) if need else None
         acc2 = torch.empty((f * 24,), dtype=torch.float64, device=dev) if need else None
         tgt = torch.empty((f, 12), dtype=torch.float32, device=dev)
-        partial = torch.empty((packed.ntiles * ((packed.pmax + 63) // 64) * (packed.fmax * 14 + TRACK_TILE * 21),), dtype=torch.float32,
+        partial = torch.empty((max(packed.ntiles, 1) * ((packed.pmax + 63) // 64) * (packed.fmax * 14 + TRACK_TILE * 21),), dtype=torch.float32,
                               device=dev)  # per-wave sums (FM_TRACK_PARTIAL), reduced per frame without atomics
         sc = (h * w) ** 0.5
         with _guard(dev):
             st = stream_for(depth)
             call("fm_extrinsics_inverse", ptr(ext), f, ptr(ext_inv), st)
-            call("fm_track_points", ptr(depth), ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), f, ptr(packed.xy), ptr(packed.vis),
-                 ptr(packed.seg), ptr(packed.blocks), packed.nblocks, packed.pmax, h, w, ptr(ws), ptr(flag), ptr(tgt), st)
-            call("fm_track_loss_fwd", ptr(ws), ptr(flag), ptr(packed.xy), ptr(packed.vis), ptr(packed.seg), ptr(packed.tiles),
-                 packed.ntiles, packed.pmax, packed.fmax, ptr(ext), ptr(tgt), f, h, w, kind, float(delta), w / sc, h / sc,
-                 float(weight), ptr(partial), ptr(acc), ptr(loss), ptr(scale), ptr(gws), ptr(acc2), st)
+            if packed.ntiles > 0:
+                call("fm_track_points", ptr(depth), int(frame0), ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), f, ptr(packed.xy), ptr(packed.vis),
+                     ptr(packed.seg), ptr(packed.blocks), packed.nblocks, packed.pmax, h, w, ptr(ws), ptr(flag), ptr(tgt), st)
+                call("fm_track_loss_fwd", ptr(ws), ptr(flag), ptr(packed.xy), ptr(packed.vis), ptr(packed.seg), ptr(packed.tiles),
+                     packed.ntiles, packed.pmax, packed.fmax, ptr(ext), ptr(tgt), f, h, w, kind, float(delta), w / sc, h / sc,
+                     float(weight), ptr(partial), ptr(acc), ptr(loss), ptr(scale), ptr(totals), ptr(gws), ptr(acc2), st)
+        if packed.ntiles == 0:  # this rank owns no source frame of any segment
+            acc.zero_()
+            totals.zero_()
+            loss.zero_()
+            scale.copy_(torch.tensor([float(weight), 0.0], device=dev))
+            if need:
+                acc2.zero_()
+        if reducer is not None:
+            totals = reducer(totals)
+            den = torch.where(totals[1] == 0, torch.ones_like(totals[1]), totals[1])  # `valid_sum or 1` (loss_tracking.py:61)
+            loss = (float(weight) * totals[0] / den).to(torch.float32).reshape(1)
+            scale = torch.stack([float(weight) / den, totals[1]]).to(torch.float32)
         ctx.save_for_backward(k, kinv, ext_inv, flag, acc, scale)
         ctx.grads = (gws, acc2) if need else None
         ctx.packed, ctx.dims, ctx.shapes = packed, (f, h, w), (tuple(depth.shape), tuple(k.shape), tuple(ext.shape))
+        ctx.frame0 = int(frame0)
         ctx.fit_node = None
         if defer and ctx.needs_input_grad[0]:
-            node = _find_fit_node(ext, (depth.data_ptr(), depth._version, tuple(depth.shape)))
+            node = _find_fit_node(ext if fit_from is None else fit_from, (depth.data_ptr(), depth._version, tuple(depth.shape)))
             if node is not None and node.needs_input_grad[0]:
                 ctx.fit_node = node
         return loss.reshape(())
@@ -816,10 +844,14 @@ class TrackLossFused(torch.autograd.Function):
             call("fm_track_loss_bwd", ptr(acc), ptr(acc2), ptr(scale), ptr(g), ptr(ext_inv), ptr(k), ptr(kinv), f, ptr(g_ext), ptr(g_k),
                  stream_for(kinv))
 
+        frame0 = ctx.frame0
+
         def scatter(buffer: Tensor) -> None:
+            if pk.nblocks == 0:
+                return
             with _guard(dev):
                 call("fm_track_scatter", ptr(gws), ptr(flag), ptr(pk.xy), ptr(pk.vis), ptr(pk.seg), ptr(pk.blocks), pk.nblocks,
-                     pk.pmax, ptr(kinv), ptr(scale), ptr(g), h, w, ptr(buffer), stream_for(buffer))
+                     pk.pmax, ptr(kinv), ptr(scale), ptr(g), h, w, frame0, ptr(buffer), stream_for(buffer))
 
         g_depth = None
         if ctx.needs_input_grad[0]:
@@ -831,4 +863,4 @@ class TrackLossFused(torch.autograd.Function):
                 g_depth = torch.zeros(depth_shape, dtype=torch.float32, device=dev)
                 scatter(g_depth)
         need = ctx.needs_input_grad
-        return g_depth, g_k if need[1] else None, g_ext if need[2] else None, None, None, None, None, None
+        return g_depth, g_k if need[1] else None, g_ext if need[2] else None, None, None, None, None, None, None, None, None

@@ -47,8 +47,8 @@ struct TrackGeom {
 };
 
 // ---------------------------------------------------------------- track_points ------
-__global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const float* depth, const float* kinv, const float* ext,
-                                                           float* ws, uint8_t* flag) {
+__global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const float* depth, int depth_frame0, const float* kinv,
+                                                           const float* ext, float* ws, uint8_t* flag) {
   const int sg = g.blocks[blockIdx.x * 2], fl = g.blocks[blockIdx.x * 2 + 1];
   const int start = g.seg[sg * 4], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
   const int p = blockIdx.y * blockDim.x + threadIdx.x;
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const fl
   load_mat3(kinv + (size_t)frame * 9, ki);
   load_pose44(ext + (size_t)frame * 16, e);
   const Taps t = bilinear_taps(q.x, q.y, g.height, g.width);
-  const float* d = depth + (size_t)frame * g.height * g.width;
+  const float* d = depth + (size_t)(frame - depth_frame0) * g.height * g.width;
   float xyz[3] = {0.f, 0.f, 0.f}, hh[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) track_reduce_kernel(const int32_t* seg, c
 }
 
 // loss[0] = weight·Σρ/max(count,1); scale[0] = weight/max(count,1); scale[1] = count
-__global__ void track_finalize_fwd_kernel(const double* acc, int frames, float weight, float* loss, float* scale) {
+__global__ void track_finalize_fwd_kernel(const double* acc, int frames, float weight, float* loss, float* scale, double* totals) {
   double sum = 0.0, cnt = 0.0;  // one wave
   for (int fr = threadIdx.x; fr < frames; fr += kWave) {
     sum += acc[(size_t)fr * kTrackAccStride + 18];
@@ -258,6 +258,10 @@ __global__ void track_finalize_fwd_kernel(const double* acc, int frames, float w
   sum = wave_sum(sum);
   cnt = wave_sum(cnt);
   if (threadIdx.x != 0) return;
+  if (totals) {
+    totals[0] = sum;
+    totals[1] = cnt;
+  }
   const double den = cnt != 0.0 ? cnt : 1.0;  // `valid_sum or 1` (loss_tracking.py:61)
   loss[0] = (float)((double)weight * sum / den);
   scale[0] = (float)((double)weight / den);
@@ -268,7 +272,8 @@ __global__ void track_finalize_fwd_kernel(const double* acc, int frames, float w
 // bilinear taps: xyz = Σ_k w_k · z_k · Kinv·[u_k, v_k, 1].  Separate launch so the caller
 // can aim it at whichever dense buffer will finally hold dL/ddepth.
 __global__ void __launch_bounds__(256) track_scatter_kernel(TrackGeom g, const uint8_t* flag, const float* gws, const float* kinv,
-                                                            const float* scale, const float* upstream, float* grad_depth) {
+                                                            const float* scale, const float* upstream, int depth_frame0,
+                                                            float* grad_depth) {
   const int sg = g.blocks[blockIdx.x * 2], fs = g.blocks[blockIdx.x * 2 + 1];
   const int start = g.seg[sg * 4], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
   const int p = blockIdx.y * blockDim.x + threadIdx.x;
@@ -282,7 +287,7 @@ __global__ void __launch_bounds__(256) track_scatter_kernel(TrackGeom g, const u
   const float gx = gws[is * 3] * sc, gy = gws[is * 3 + 1] * sc, gz = gws[is * 3 + 2] * sc;
   const float2 q = reinterpret_cast<const float2*>(g.xy)[is];
   const Taps t = bilinear_taps(q.x, q.y, g.height, g.width);
-  float* gd = grad_depth + (size_t)frame_s * g.height * g.width;
+  float* gd = grad_depth + (size_t)(frame_s - depth_frame0) * g.height * g.width;
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     if (!t.in[kk]) continue;
@@ -325,14 +330,15 @@ int fm_extrinsics_inverse(const float* ext, int count, float* inv, void* stream)
   FM_LAUNCH_STATUS();
 }
 
-int fm_track_points(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
-                    const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int pmax, int height,
-                    int width, float* ws, uint8_t* flag, float* tgt, void* stream) {
+int fm_track_points(const float* depth, int depth_frame0, const float* kinv, const float* ext, const float* ext_inv, const float* k,
+                    int frames, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int pmax,
+                    int height, int width, float* ws, uint8_t* flag, float* tgt, void* stream) {
   FM_CHECK_ARG(depth && kinv && ext && ext_inv && k && xy && vis && seg && blocks && ws && flag && tgt);
-  FM_CHECK_ARG(nblocks >= 1 && pmax >= 1 && frames >= 1);
+  FM_CHECK_ARG(nblocks >= 1 && pmax >= 1 && frames >= 1 && depth_frame0 >= 0);
   hipStream_t st = (hipStream_t)stream;
   TrackGeom g{xy, vis, seg, blocks, height, width};
-  hipLaunchKernelGGL(track_points_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, st, g, depth, kinv, ext, ws, flag);
+  hipLaunchKernelGGL(track_points_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, st, g, depth, depth_frame0, kinv, ext,
+                     ws, flag);
   hipLaunchKernelGGL(track_targets_kernel, dim3((frames + 63) / 64), dim3(64), 0, st, ext_inv, k, frames, tgt);
   FM_LAUNCH_STATUS();
 }
@@ -340,7 +346,7 @@ int fm_track_points(const float* depth, const float* kinv, const float* ext, con
 int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
                       const int32_t* tiles, int ntiles, int pmax, int fmax, const float* ext, const float* tgt, int frames, int height,
                       int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* partial,
-                      double* acc, float* loss, float* scale, float* gws, double* acc2, void* stream) {
+                      double* acc, float* loss, float* scale, double* totals, float* gws, double* acc2, void* stream) {
   FM_CHECK_ARG(ws && flag && xy && vis && seg && tiles && ext && tgt && partial && acc && loss && scale);
   FM_CHECK_ARG(ntiles >= 1 && pmax >= 1 && fmax >= 1 && frames >= 1 && mapping_kind >= 0 && mapping_kind <= 2);
   FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr));
@@ -363,7 +369,7 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
 #undef FM_TRACK_LAUNCH
   hipLaunchKernelGGL(track_reduce_kernel, dim3(frames), dim3(256), 0, st, seg, tiles, ntiles, pgroups, fmax, partial, gws ? 1 : 0, acc,
                      acc2);
-  hipLaunchKernelGGL(track_finalize_fwd_kernel, dim3(1), dim3(kWave), 0, st, acc, frames, weight, loss, scale);
+  hipLaunchKernelGGL(track_finalize_fwd_kernel, dim3(1), dim3(kWave), 0, st, acc, frames, weight, loss, scale, totals);
   FM_LAUNCH_STATUS();
 }
 
@@ -377,11 +383,11 @@ int fm_track_loss_bwd(const double* acc, const double* acc2, const float* scale,
 
 int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
                      const int32_t* blocks, int nblocks, int pmax, const float* kinv, const float* scale, const float* upstream,
-                     int height, int width, float* grad_depth, void* stream) {
-  FM_CHECK_ARG(gws && flag && xy && vis && seg && blocks && kinv && scale && grad_depth && nblocks >= 1 && pmax >= 1);
+                     int height, int width, int depth_frame0, float* grad_depth, void* stream) {
+  FM_CHECK_ARG(gws && flag && xy && vis && seg && blocks && kinv && scale && grad_depth && nblocks >= 1 && pmax >= 1 && depth_frame0 >= 0);
   TrackGeom g{xy, vis, seg, blocks, height, width};
   hipLaunchKernelGGL(track_scatter_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, flag, gws, kinv,
-                     scale, upstream, grad_depth);
+                     scale, upstream, depth_frame0, grad_depth);
   FM_LAUNCH_STATUS();
 }
 

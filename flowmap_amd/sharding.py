@@ -10,7 +10,10 @@ sits in the data path; per step there is
   * ONE neighbour exchange of the halo frame's dL/ddepth (N floats each way), because
     both owners of that frame hold a copy of its depth parameter;
   * at set-up, one all-reduce of the constant valid-mask sum so every shard normalises
-    by the GLOBAL Σmask (loss_flow.py:70).
+    by the GLOBAL Σmask (loss_flow.py:70);
+  * with the tracking loss (track windows of <= 41 frames straddle shard borders): one
+    all-gather of the local poses (F·16 floats), one all-reduce of [Σρ, count], and in backward
+    one all-reduce of the pose gradients (``FrameShard.tracking_loss``).
 
 Everything goes through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on
 ROCm; "gloo" in the CPU tests).
@@ -64,12 +67,16 @@ class FrameShard:
             loss_fn.valid_sum_reducer = self.reduce_valid_sum
 
     # -- per step -------------------------------------------------------------------------
-    def sync(self, loss: Tensor, shared_param: Optional[Tensor], depth_param: Optional[Tensor]) -> Tensor:
+    def sync(self, loss: Tensor, shared_param: Optional[Tensor], depth_param: Optional[Tensor],
+             already_global: Optional[Tensor] = None) -> Tensor:
         """All-reduce the scalar loss and the shared (intrinsics) gradient in one packed
         buffer; sum the halo frame's depth gradient with the neighbours.  Returns the
-        global loss (detached).  No-op for world == 1."""
+        global loss (detached).  ``loss`` is this rank's share (the flow term);
+        ``already_global`` (the value ``tracking_loss`` returns) is added after the reduction.
+        No-op for world == 1."""
+        extra = 0.0 if already_global is None else already_global.detach()
         if not self.active:
-            return loss.detach()
+            return loss.detach() + extra
         dist = self.dist
         parts = [loss.detach().reshape(1).to(torch.float32)]
         if shared_param is not None and shared_param.grad is not None:
@@ -80,7 +87,7 @@ class FrameShard:
             shared_param.grad.copy_(packed[1:].reshape(shared_param.grad.shape))
         if depth_param is not None and depth_param.grad is not None:
             self.exchange_halo(depth_param.grad)
-        return packed[0]
+        return packed[0] + extra
 
     def exchange_halo(self, depth_grad: Tensor) -> None:
         """depth_grad (F_local, H, W): the LAST local frame is rank+1's FIRST local frame.
@@ -102,3 +109,86 @@ class FrameShard:
             depth_grad[0].add_(recv_prev)
         if recv_next is not None:
             depth_grad[-1].add_(recv_next)
+
+
+class _GatherPoses(torch.autograd.Function):
+    """All-gather of every rank's local camera-to-world poses (F_local, 4, 4) into
+    (world, F_max, 4, 4).  Each rank differentiates ITS loss terms w.r.t. all slots; the true
+    gradient of slot r is the sum over ranks, so backward is one all-reduce and a slice."""
+
+    @staticmethod
+    def forward(ctx, local: Tensor, shard: "FrameShard", counts):
+        fmax = max(counts)
+        padded = torch.zeros((fmax, 4, 4), dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+        out = [torch.empty_like(padded) for _ in range(shard.world)]
+        shard.dist.all_gather(out, padded, group=shard.group)
+        ctx.shard, ctx.count = shard, local.shape[0]
+        return torch.stack(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        ctx.shard.dist.all_reduce(g, op=ctx.shard.dist.ReduceOp.SUM, group=ctx.shard.group)
+        return g[ctx.shard.rank, : ctx.count], None, None
+
+
+def _frame_layout(total_pairs: int, world: int):
+    """Per rank: (first frame, last frame inclusive) and the frames it OWNS as tracking sources
+    [first, end): the halo frame belongs to the next rank, the very last frame to the last rank."""
+    ranges = [shard_frames(r) for r in shard_pairs(total_pairs, world)]
+    own = [(lo, hi if r < world - 1 else hi + 1) for r, (lo, hi) in enumerate(ranges)]
+    return ranges, own
+
+
+def _global_extrinsics(shard: "FrameShard", local_ext: Tensor, total_pairs: int) -> Tensor:
+    """(1, F_local, 4, 4) poses relative to the shard's first frame -> (1, F, 4, 4) poses of the
+    whole video relative to frame 0 (get_extrinsics, projection.py:187-210, across shards): the
+    pose of a shard's last (halo) frame is the transform to the next shard's first frame."""
+    ranges, _ = _frame_layout(total_pairs, shard.world)
+    counts = [hi - lo + 1 for lo, hi in ranges]
+    gathered = _GatherPoses.apply(local_ext[0], shard, counts)  # (world, F_max, 4, 4)
+    prefix = torch.eye(4, dtype=local_ext.dtype, device=local_ext.device)
+    blocks = []
+    for r, n in enumerate(counts):
+        block = gathered[r, :n]
+        last = r == shard.world - 1
+        blocks.append(prefix @ (block if last else block[:-1]))
+        prefix = prefix @ block[-1]
+    return torch.cat(blocks)[None]
+
+
+def _tracking_loss(shard: "FrameShard", loss_fn, tracks, model_output, total_pairs: int, global_step: int = 0) -> Tensor:
+    """LossTracking over a frame-sharded video.  ``tracks`` carry GLOBAL frame
+    indices; ``model_output`` is this rank's (depths, intrinsics, extrinsics of its own frames).
+    Every rank evaluates the (source, target) pairs whose SOURCE frame it owns — it has that
+    frame's depth — against targets anywhere in the segment, for which only poses and intrinsics are
+    needed: the local poses are all-gathered and chained (_global_extrinsics), the [Σρ, count]
+    pair is all-reduced, and the pose gradients travel back through the gather's backward.
+    Returns the GLOBAL weighted loss; its gradients are this rank's share."""
+    from . import _ops
+    from .model.projection import LazySurfaces
+
+    if global_step < loss_fn.cfg.enable_after:
+        return torch.zeros((), dtype=torch.float32, device=model_output.depths.device)
+    depths = model_output.surfaces.depths if isinstance(model_output.surfaces, LazySurfaces) else model_output.depths
+    ranges, owns = _frame_layout(total_pairs, shard.world)
+    lo, _ = ranges[shard.rank]
+    frames = total_pairs + 1
+    ext = _global_extrinsics(shard, model_output.extrinsics, total_pairs)
+    k = model_output.intrinsics
+    if k.shape[1] != frames:  # intrinsics are shared by all frames (regressed / softmin): extend to the whole video
+        k = k[:, :1].expand(1, frames, 3, 3).contiguous()
+    packed = _ops.pack_tracks(tracks, depths.device, own=owns[shard.rank])
+
+    def reducer(totals: Tensor) -> Tensor:
+        shard.dist.all_reduce(totals, op=shard.dist.ReduceOp.SUM, group=shard.group)
+        return totals
+
+    return _ops.TrackLossFused.apply(depths, k, ext, packed, loss_fn.cfg.weight, _ops.MAPPING_KINDS[loss_fn.mapping.kind],
+                                     loss_fn.mapping.delta, loss_fn.defer_depth_scatter, lo, reducer, model_output.extrinsics)
+
+
+FrameShard.global_extrinsics = lambda self, local_ext, total_pairs: _global_extrinsics(self, local_ext, total_pairs)
+FrameShard.tracking_loss = lambda self, loss_fn, tracks, model_output, total_pairs, global_step=0: _tracking_loss(
+    self, loss_fn, tracks, model_output, total_pairs, global_step)

@@ -212,10 +212,14 @@ int fm_extrinsics_inverse(const float* ext, int count, float* inv, void* stream)
  * source frame's surface (projection.py:266-274) | X_w = E·xyz | h = Σ_taps w·z·[u,v,1]];
  * flag (total) = visibility ∧ source-in-frame (projection.py:290-294).  Per frame: tgt
  * (frames,12) = rows 0,1 of K·inv(E)[:3,:] and row 2 of inv(E) (the target-role projection
- * u = q·(au·[X_w;1]), q = 1/(c·[X_w;1]+eps), projection.py:288,49-58). */
-int fm_track_points(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
-                    const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int pmax, int height,
-                    int width, float* ws, uint8_t* flag, float* tgt, void* stream);
+ * u = q·(au·[X_w;1]), q = 1/(c·[X_w;1]+eps), projection.py:288,49-58).
+ * Frame sharding: kinv / ext / ext_inv / k cover all `frames` of the video, `depth` only the
+ * frames from depth_frame0 on (0 = unsharded); `blocks` then lists only the (segment, frame)
+ * entries this rank owns as SOURCES and the caller zeroes `flag` first (an unlisted entry is an
+ * invisible source). */
+int fm_track_points(const float* depth, int depth_frame0, const float* kinv, const float* ext, const float* ext_inv, const float* k,
+                    int frames, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int pmax,
+                    int height, int width, float* ws, uint8_t* flag, float* tgt, void* stream);
 
 /* All (source, target, point) residuals of all segments, each evaluated once.
  *   tiles (ntiles,2) int32: (segment, first local source frame) for source tiles of
@@ -223,7 +227,9 @@ int fm_track_points(const float* depth, const float* kinv, const float* ext, con
  *   partial: fp32 workspace of ntiles·ceil(pmax/64)·FM_TRACK_PARTIAL(fmax) floats (per-wave sums,
  *   reduced per frame without atomics: results are bit-reproducible run to run);
  *   acc (frames*20) fp64 out.
- *   loss[0] = weight·Σρ·vis/max(Σvis,1); scale[0] = weight/max(Σvis,1), scale[1] = Σvis.
+ *   loss[0] = weight·Σρ·vis/max(Σvis,1); scale[0] = weight/max(Σvis,1), scale[1] = Σvis;
+ *   totals (2 doubles, may be NULL) = [Σρ·vis, Σvis] for callers that reduce them across
+ *   shards and overwrite loss / scale before the backward calls read `scale`.
  *   gws (total,3) and acc2 (frames*24): both NULL = loss only; else UNSCALED dL/dxyz per
  *   track point and the per-frame source-role sums for fm_track_loss_bwd. */
 #define FM_TRACK_TILE 6
@@ -231,17 +237,18 @@ int fm_track_points(const float* depth, const float* kinv, const float* ext, con
 int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
                       const int32_t* tiles, int ntiles, int pmax, int fmax, const float* ext, const float* tgt, int frames, int height,
                       int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* partial,
-                      double* acc, float* loss, float* scale, float* gws, double* acc2, void* stream);
+                      double* acc, float* loss, float* scale, double* totals, float* gws, double* acc2, void* stream);
 
 /* g_ext (F,4,4), g_k (F,3,3) from acc / acc2, multiplied by scale[0]·upstream[0]
  * (upstream NULL = 1). */
 int fm_track_loss_bwd(const double* acc, const double* acc2, const float* scale, const float* upstream, const float* ext_inv,
                       const float* k, const float* kinv, int frames, float* g_ext, float* g_k, void* stream);
 
-/* Scatter scale[0]·upstream[0]·gws through the bilinear taps: ATOMICALLY ADDS into grad_depth (F,H,W). */
+/* Scatter scale[0]·upstream[0]·gws through the bilinear taps: ATOMICALLY ADDS into grad_depth,
+ * which holds the frames from depth_frame0 on (as `depth` in fm_track_points). */
 int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
                      const int32_t* blocks, int nblocks, int pmax, const float* kinv, const float* scale, const float* upstream,
-                     int height, int width, float* grad_depth, void* stream);
+                     int height, int width, int depth_frame0, float* grad_depth, void* stream);
 
 /* ---- export ------------------------------------------------------
  * Point cloud of export_to_colmap (flowmap/export/colmap.py:86-101): depth (F,H,W), kinv

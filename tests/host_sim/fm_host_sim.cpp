@@ -674,9 +674,9 @@ int fm_extrinsics_inverse(const float* ext, int count, float* inv, void*) {
   return 0;
 }
 
-int fm_track_points(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
-                    const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int, int height,
-                    int width, float* ws, uint8_t* flag, float* tgt, void*) {
+int fm_track_points(const float* depth, int depth_frame0, const float* kinv, const float* ext, const float* ext_inv, const float* k,
+                    int frames, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int,
+                    int height, int width, float* ws, uint8_t* flag, float* tgt, void*) {
   for (int fr = 0; fr < frames; ++fr) track_target(ext_inv + (size_t)fr * 16, k + (size_t)fr * 9, tgt + (size_t)fr * kTrackTgt);
   for (int blk = 0; blk < nblocks; ++blk) {
     const int sg = blocks[blk * 2], fl = blocks[blk * 2 + 1];
@@ -686,7 +686,7 @@ int fm_track_points(const float* depth, const float* kinv, const float* ext, con
     Pose e;
     load_mat3(kinv + (size_t)frame * 9, ki);
     load_pose44(ext + (size_t)frame * 16, e);
-    const float* d = depth + (size_t)frame * height * width;
+    const float* d = depth + (size_t)(frame - depth_frame0) * height * width;
     for (int p = 0; p < pc; ++p) {
       const size_t idx = (size_t)off + (size_t)fl * pc + p;
       const float qx = xy[idx * 2], qy = xy[idx * 2 + 1];
@@ -720,8 +720,8 @@ int fm_track_points(const float* depth, const float* kinv, const float* ext, con
 
 int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
                       const int32_t* tiles, int ntiles, int, int, const float* ext, const float* tgt, int frames, int, int, int kind,
-                      float delta, float ax, float ay, float weight, float*, double* acc, float* loss, float* scale, float* gws,
-                      double* acc2, void*) {
+                      float delta, float ax, float ay, float weight, float*, double* acc, float* loss, float* scale, double* totals,
+                      float* gws, double* acc2, void*) {
   std::memset(acc, 0, sizeof(double) * (size_t)frames * kTrackAccStride);
   if (acc2) std::memset(acc2, 0, sizeof(double) * (size_t)frames * kTrackAcc2Stride);
   const float invd = 1.0f / delta;
@@ -769,6 +769,10 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
     sum += acc[(size_t)fr * kTrackAccStride + 18];
     cnt += acc[(size_t)fr * kTrackAccStride + 19];
   }
+  if (totals) {
+    totals[0] = sum;
+    totals[1] = cnt;
+  }
   const double den = cnt != 0.0 ? cnt : 1.0;
   loss[0] = (float)((double)weight * sum / den);
   scale[0] = (float)((double)weight / den);
@@ -787,7 +791,7 @@ int fm_track_loss_bwd(const double* acc, const double* acc2, const float* scale,
 
 int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, const uint8_t*, const int32_t* seg,
                      const int32_t* blocks, int nblocks, int, const float* kinv, const float* scale, const float* upstream, int height,
-                     int width, float* grad_depth, void*) {
+                     int width, int depth_frame0, float* grad_depth, void*) {
   const float sc = scale[0] * (upstream ? upstream[0] : 1.f);
   for (int blk = 0; blk < nblocks; ++blk) {
     const int sg = blocks[blk * 2], fs = blocks[blk * 2 + 1];
@@ -804,7 +808,7 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
         const int tc = tap_col(t, kk), tr = tap_row(t, kk);
         float ray[3];
         ray_dir(ki, pixel_center(tc, width), pixel_center(tr, height), ray);
-        grad_depth[(size_t)frame_s * height * width + tr * width + tc] +=
+        grad_depth[(size_t)(frame_s - depth_frame0) * height * width + tr * width + tc] +=
             t.w[kk] * (gws[is * 3] * sc * ray[0] + gws[is * 3 + 1] * sc * ray[1] + gws[is * 3 + 2] * sc * ray[2]);
       }
     }

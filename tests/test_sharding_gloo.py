@@ -36,7 +36,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, f, h, w, points, out_path):
+def _worker(rank, world, port, f, h, w, points, out_path, with_tracks=False):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -45,7 +45,7 @@ def _worker(rank, world, port, f, h, w, points, out_path):
     torch.set_num_threads(1)
     import flowmap_amd
     from flowmap_amd import Batch, Flows, _lib
-    from flowmap_amd.loss import LossFlow, LossFlowCfg
+    from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
     from flowmap_amd.loss.mapping import MappingHuberCfg
     from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
     from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
@@ -75,10 +75,20 @@ def _worker(rank, world, port, f, h, w, points, out_path):
     shard.prepare_flow_loss(loss_fn, local)
     out = model(batch, local, 0)
     loss = loss_fn(batch, local, None, out, 0)
-    loss.backward()
-    total = shard.sync(loss, model.intrinsics.focal_length, model.backbone.depth)
+    track_total = None
+    if with_tracks:
+        from helpers import to_tracks
+
+        tracks = to_tracks(orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5), "cpu")  # GLOBAL frame indices
+        track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
+        # global value on every rank; its autograd gradients are this rank's share of the term
+        track_total = shard.tracking_loss(track_fn, tracks, out, f - 1)
+        (loss + track_total).backward()
+    else:
+        loss.backward()
+    total = shard.sync(loss, model.intrinsics.focal_length, model.backbone.depth, already_global=track_total)
     torch.save(
-        {"loss": total.clone(), "g_focal": model.intrinsics.focal_length.grad.clone(), "g_depth": model.backbone.depth.grad.clone(),
+        {"loss": total.clone(), "track": None if track_total is None else track_total.detach().clone(), "g_focal": model.intrinsics.focal_length.grad.clone(), "g_depth": model.backbone.depth.grad.clone(),
          "g_w": model.backbone.weights.grad.clone(), "frames": (lo, hi), "pairs": (a, b)},
         f"{out_path}.{rank}",
     )
@@ -107,3 +117,32 @@ def test_two_rank_shards_match_unsharded_oracle(tmp_path):
         a, b = r["pairs"]
         assert_close(r["g_depth"], ref["g_depth"][lo : hi + 1], 1e-4, what="g_depth shard (halo summed)")
         assert_close(r["g_w"], ref["g_wlogit"][a:b], 3e-4, what="g_wlogit shard")
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_tracking_matches_unsharded_oracle(tmp_path, world):
+    """Flow + tracking losses with the video split over `world` ranks: track segments straddle
+    the shard borders (sources evaluated where their depth lives, poses all-gathered and chained,
+    [sum, count] and the pose gradients all-reduced) — loss and every gradient as unsharded."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import assert_close
+    from helpers import run_oracle
+    from oracle import flowmap_oracle as orc
+
+    f, h, w, points = 8, 12, 16, 40
+    out = str(tmp_path / "shard")
+    mp.spawn(_worker, args=(world, _free_port(), f, h, w, points, out, True), nprocs=world, join=True)
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
+    otracks = orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5)
+    ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float64)
+    assert float(ref["loss_tracking"]) > 0
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    for r in res:
+        assert_close(r["track"], ref["loss_tracking"], 1e-5, what="global tracking loss")
+        assert_close(r["loss"], ref["total"], 1e-5, what="global loss")
+        assert_close(r["g_focal"], ref["g_focal"], 1e-3, abs_=1e-4 * abs(float(ref["total"])), what="g_focal")
+        lo, hi = r["frames"]
+        a, b = r["pairs"]
+        assert_close(r["g_depth"], ref["g_depth"][lo : hi + 1], 2e-4, what="g_depth shard (halo summed)")
+        assert_close(r["g_w"], ref["g_wlogit"][a:b], 5e-4, what="g_wlogit shard")
