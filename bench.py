@@ -134,8 +134,19 @@ def cpu_baseline(frames, h, w, points, iters, threads):
     return dt, cores
 
 
+def _reserve_stdout():
+    """The driver reads ONE JSON line from stdout, but RCCL prints a version banner to the C-level
+    stdout (fd 1) when the communicator comes up.  Keep a private handle on the real stdout for the
+    result line and point fd 1 at stderr for everything else."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse()
+    result_stream = _reserve_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -308,7 +319,7 @@ def main():
                 f"to {f} frames",
                 "sample_seconds_per_iter": dt,
             }
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=result_stream, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
