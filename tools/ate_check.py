@@ -23,11 +23,11 @@ from oracle import flowmap_oracle as orc  # noqa: E402
 def run(args):
     import flowmap_amd
     from flowmap_amd import Batch, _lib
-    from flowmap_amd.loss import LossFlow, LossFlowCfg
+    from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
     from flowmap_amd.loss.mapping import MappingHuberCfg
     from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
     from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
-    from helpers import to_flows
+    from helpers import to_flows, to_tracks
 
     f, h, w = args.frames, args.height, args.width
     dev = torch.device(args.device)
@@ -38,6 +38,7 @@ def run(args):
     sc = orc.synth_scene(f, h, w, seed=args.seed, focal=0.85, depth_noise=args.noise)
     gt_pos = sc["extrinsics_gt"][:, :3, 3]
     focal0 = 0.85 * 1.1  # start 10 % off
+    otracks = orc.synth_tracks(f, h, w, scene=sc, seed=args.seed, interval=5, radius=min(20, f), grid=args.track_grid) if args.tracking else None
 
     # ---- oracle run (CPU) ----------------------------------------------------------------
     d = sc["depth_init"].clone().requires_grad_(True)
@@ -47,12 +48,12 @@ def run(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         opt.zero_grad(set_to_none=True)
-        total, _, out = orc.explicit_depth_step(d, wl, fo, sc["flows"], (h, w), num_points=args.points)
+        total, _, out = orc.explicit_depth_step(d, wl, fo, sc["flows"], (h, w), num_points=args.points, tracks=otracks)
         total.backward()
         opt.step()
     t_ref = time.perf_counter() - t0
     with torch.no_grad():
-        _, _, out = orc.explicit_depth_step(d, wl, fo, sc["flows"], (h, w), num_points=args.points)
+        _, _, out = orc.explicit_depth_step(d, wl, fo, sc["flows"], (h, w), num_points=args.points, tracks=otracks)
     ate_ref, loss_ref = orc.ate(gt_pos, out.extrinsics[0, :, :3, 3]), float(total.detach())
 
     # ---- flowmap_amd run -------------------------------------------------------------------
@@ -65,6 +66,8 @@ def run(args):
     flows = to_flows(sc["flows"], dev)
     batch = Batch(torch.zeros((1, f, 3, 1, 1), device=dev).expand(1, f, 3, h, w))
     loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
+    track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01))) if args.tracking else None
+    tracks = to_tracks(otracks, dev)
     opt = flowmap_amd.FusedAdam(model.parameters(), lr=args.lr)  # the reference leg above uses torch.optim.Adam
     if dev.type == "cuda":
         torch.cuda.synchronize()
@@ -73,6 +76,8 @@ def run(args):
         opt.zero_grad(set_to_none=True)
         out = model(batch, flows, 0)
         loss = loss_fn(batch, flows, None, out, 0)
+        if track_fn is not None:
+            loss = loss + track_fn(batch, flows, tracks, out, 0)
         loss.backward()
         opt.step()
     if dev.type == "cuda":
@@ -87,6 +92,7 @@ def run(args):
     return {
         "scene": f"synthetic consistent scene, {f} frames @ {h}x{w}, seed {args.seed}, depth noise {args.noise}, focal init +10%",
         "steps": args.steps, "lr": args.lr, "procrustes_points": args.points,
+        "losses": "flow (1000) + tracking (100)" if args.tracking else "flow (1000)",
         "ate_initial": init, "ate_reference_path_cpu": ate_ref, "ate_flowmap_amd": ate_ours,
         "ate_abs_diff": abs(ate_ref - ate_ours),
         "final_loss_reference_path": loss_ref, "final_loss_flowmap_amd": loss_ours,
@@ -106,6 +112,8 @@ if __name__ == "__main__":
     ap.add_argument("--points", type=int, default=1000)
     ap.add_argument("--noise", type=float, default=0.05)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--tracking", action="store_true", help="add the tracking loss (tracks = oracle projections of the true surface)")
+    ap.add_argument("--track-grid", type=int, default=12)
     ap.add_argument("--threads", type=int, default=16, help="torch CPU threads for the reference-path leg")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
