@@ -394,7 +394,7 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   hipStream_t st = (hipStream_t)stream;
   const bool grad = scale != nullptr;
   FlowParams p{depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, grad_depth, acc,
-               frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 4};  // @C1: 2: 0.795, 4: 0.779, 6: 0.793, 8-12: 0.835 ms
+               frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 4};
   if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride, st) != hipSuccess) return FM_ERR_LAUNCH;
   auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool use_packed = packed != nullptr;
@@ -408,6 +408,18 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
 #endif
   const long items = (long)height * width / vec;
   const int threads = 256;
+  if (items_per_thread <= 0) {
+    // Quads per thread.  At C1 (230 400 quads per frame): 2: 0.795, 3: 0.751, 4: 0.715-0.779, 5: 0.720,
+    // 6: 0.793, 8-12: 0.835 ms.  A partially filled tail block per frame costs 2-5 % (1080p, 518 400
+    // quads: 3 -> 675 full blocks 1.68 ms, 4 -> 506.25 blocks 1.73 ms, 6 -> 337.5 blocks 1.82 ms), so
+    // take the first of 4, 3, 5 that tiles the frame exactly.
+    p.iters = 4;
+    for (int cand : {4, 3, 5})
+      if (items % ((long)threads * cand) == 0) {
+        p.iters = cand;
+        break;
+      }
+  }
   const long per_block = (long)threads * p.iters;
   dim3 grid((unsigned)((items + per_block - 1) / per_block), (unsigned)(batch * frames));
   const size_t lds = sizeof(float) * (size_t)width + sizeof(double) * (threads / 64) * kFlowAcc;
