@@ -494,6 +494,22 @@ class FlowLossFused(torch.autograd.Function):
                 g_tb if need[3] else None, None, None, None, None, None, None, None, None, None, None)
 
 
+def random_subset(n: int, count: int, device, seed: Optional[int] = None) -> Tensor:
+    """``count`` distinct pseudo-random indices of [0, n) in pseudo-random order (int64) — what
+    ``torch.randperm(n, device=device)[:count]`` is used for — from one launch of fm_random_subset.
+    ``seed`` defaults to a draw from torch's CPU generator, so ``torch.manual_seed`` reproduces it."""
+    if not 1 <= count <= n:
+        raise RuntimeError("flowmap_amd: random_subset needs 1 <= count <= n")
+    device = torch.device(device)
+    if seed is None:
+        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+    out = torch.empty((count,), dtype=torch.int64, device=device)
+    check_device(out)
+    with _guard(device):
+        call("fm_random_subset", int(seed), int(n), int(count), ptr(out), stream_for(out))
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # Flow post-processing (no gradients: flows and masks are constants of the optimisation)
 # --------------------------------------------------------------------------------------

@@ -430,6 +430,48 @@ FM_HD void flow_term_fast(const DirConst& d, float arow, float brow, float crow,
 }
 
 // ---------------------------------------------------------------------------------
+// Random subset without replacement: element i of a keyed pseudo-random PERMUTATION of [0, n).
+// IntrinsicsSoftmin draws `torch.randperm(h*w)[:P]` every step (intrinsics_softmin.py:90) — a
+// full device sort of 921 600 keys at 720p for 8192 samples.  A 4-round Feistel network over
+// 2·ceil(bits/2) bits with cycle walking is a bijection on [0, n); evaluating it at 0..P-1 gives P
+// distinct pseudo-random indices in pseudo-random order with no sorting at all.
+// ---------------------------------------------------------------------------------
+FM_HD uint32_t fm_mix32(uint32_t x) {  // lowbias32 (Wellons): a good 32-bit avalanche
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+FM_HD uint64_t permuted_index(uint64_t i, uint64_t n, uint64_t seed) {
+  int half = 1;
+  while ((1ULL << (2 * half)) < n) ++half;  // domain 2^(2·half) >= n, < 4n
+  const uint32_t mask = (uint32_t)((1ULL << half) - 1);
+  uint32_t keys[4];
+  uint64_t z = seed;
+  for (int r = 0; r < 4; ++r) {  // splitmix64 round keys
+    z += 0x9e3779b97f4a7c15ULL;
+    uint64_t k = z;
+    k = (k ^ (k >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    k = (k ^ (k >> 27)) * 0x94d049bb133111ebULL;
+    keys[r] = (uint32_t)(k ^ (k >> 31));
+  }
+  uint64_t x = i;
+  do {  // cycle walking: re-apply until the value falls inside [0, n)
+    uint32_t left = (uint32_t)(x >> half) & mask, right = (uint32_t)x & mask;
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t next = left ^ (fm_mix32(right ^ keys[r]) & mask);
+      left = right;
+      right = next;
+    }
+    x = ((uint64_t)left << half) | right;
+  } while (x >= n);
+  return x;
+}
+
+// ---------------------------------------------------------------------------------
 // One Adam update (torch.optim.Adam as the reference configures it,
 // model_wrapper_overfit.py:104-105: no amsgrad, not maximising; optional L2 weight decay):
 //   g += wd·p;  m = lerp(m, g, 1-β1);  v = β2·v + (1-β2)·g²

@@ -314,6 +314,11 @@ __global__ void __launch_bounds__(256) world_points_kernel(const float* depth, c
   }
 }
 
+__global__ void __launch_bounds__(256) random_subset_kernel(unsigned long long seed, long n, long count, int64_t* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = (int64_t)permuted_index((uint64_t)i, (uint64_t)n, seed);
+}
+
 static inline unsigned blocks_for(long n, int per_thread = 4, unsigned cap = 4096) {
   long b = (n + 256L * per_thread - 1) / (256L * per_thread);
   if (b < 1) b = 1;
@@ -347,6 +352,12 @@ int fm_world_points(const float* depth, const float* kinv, const float* ext, con
   FM_CHECK_ARG(!colors || out_rgb);
   hipLaunchKernelGGL(world_points_kernel, dim3(blocks_for((long)height * width), frames), dim3(256), 0, (hipStream_t)stream, depth,
                      kinv, ext, colors, height, width, out_xyz, out_rgb);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_random_subset(unsigned long long seed, long n, long count, int64_t* out, void* stream) {
+  FM_CHECK_ARG(out && n >= 1 && count >= 1 && count <= n && n < (1L << 40));
+  hipLaunchKernelGGL(random_subset_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, n, count, out);
   FM_LAUNCH_STATUS();
 }
 

@@ -115,6 +115,103 @@ __global__ void procrustes_moments_finish_kernel(ProcParams p, int pairs) {
   moments_finish(p.stats + (size_t)pair * kStatStride, shift);
 }
 
+// Backward for batch_repeat > 1 (the softmin candidate sweep: R = 60 (K, pose) entries share one
+// image pair).  The generic kernel would run one thread per (candidate, point) and have 60 threads
+// add atomically to the same depth / weight pixels.  Here a thread owns one point and walks a GROUP
+// of candidates, summing their gradients in registers (the taps and the sampled values are the same
+// for every candidate; only the rays differ): R/GROUP-fold fewer atomics and contention.
+// grid: (chunks of 256 points, image pairs x candidate groups).  One point per thread.
+constexpr int kRepeatGroup = 6;
+
+__global__ void __launch_bounds__(256) procrustes_scatter_repeat_kernel(ProcParams p, const double* aux) {
+  __shared__ double red[4 * 18];
+  const int rep = p.batch_repeat;
+  const int groups = (rep + kRepeatGroup - 1) / kRepeatGroup;
+  const size_t dpair = blockIdx.y / groups;  // image-data pair
+  const int gid = (int)(blockIdx.y % groups);
+  const int bd = (int)(dpair / (p.frames - 1)), i = (int)(dpair % (p.frames - 1));
+  const int n = p.height * p.width;
+  const size_t fe = (size_t)bd * p.frames + i, fl = fe + 1;  // image-data frames
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = j < p.points;
+  const int idx = active ? (p.indices ? (int)p.indices[j] : (int)j) : 0;
+
+  float s_gw = 0.f, s_later = 0.f, s_tap[4] = {0.f, 0.f, 0.f, 0.f};
+  Taps taps = {};
+  for (int r = gid * kRepeatGroup; r < rep && r < (gid + 1) * kRepeatGroup; ++r) {
+    const int b = bd * rep + r;
+    const size_t pair = (size_t)b * (p.frames - 1) + i;  // (kinv, pose) pair
+    Mat3 kinv_e, kinv_l;
+    load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
+    load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
+    const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
+    const double* pg = p.pair_grad + pair * kPairGradStride;
+    const double* ax = aux + pair * kAuxStride;
+    PairGrad g;
+    for (int k = 0; k < 9; ++k) g.gM[k] = (float)pg[k];
+    for (int a = 0; a < 3; ++a) {
+      g.gqbar[a] = (float)pg[9 + a];
+      g.gpbar[a] = (float)pg[12 + a];
+      g.pbar[a] = (float)ax[21 + a];
+      g.qbar[a] = (float)ax[24 + a];
+    }
+    g.dbar = (float)pg[15];
+    g.inv_wsum = (float)pg[16];
+    float acc[18];  // [0..8] dKinv later frame, [9..17] dKinv earlier frame
+#pragma unroll
+    for (int k = 0; k < 18; ++k) acc[k] = 0.f;
+    if (active) {
+      const Corr c = corr_load(src, kinv_e, kinv_l, idx);
+      taps = c.taps;
+      float gq[3], gp[3], gw;
+      corr_backward(c, g, gq, gp, gw);
+      if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
+      s_gw += gw;
+      s_later += gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2];
+      const int row = idx / p.width, col = idx - row * p.width;
+      const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
+      const float zh[3] = {c.z_p * u, c.z_p * v, c.z_p};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[a * 3 + d] += gp[a] * zh[d];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!c.taps.in[k]) continue;
+        const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
+        const float ut = pixel_center(tc, p.width), vt = pixel_center(tr, p.height);
+        const float z = p.depth[fe * n + tr * p.width + tc];
+        float ray[3];
+        ray_dir(kinv_e, ut, vt, ray);
+        const float wt = c.taps.w[k];
+        s_tap[k] += wt * (gq[0] * ray[0] + gq[1] * ray[1] + gq[2] * ray[2]);
+        const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) acc[9 + a * 3 + d] += gq[a] * zt[d];
+      }
+    }
+    if (p.kinv_acc) {
+      float ordered[18];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        ordered[k] = acc[9 + k];
+        ordered[9 + k] = acc[k];
+      }
+      block_accumulate<18>(ordered, red, p.kinv_acc + ((size_t)b * p.frames + i) * 9);
+    }
+  }
+  if (!active) return;
+  if (p.grad_weights) atomicAdd(p.grad_weights + dpair * (size_t)n + idx, s_gw);
+  if (p.grad_depth) {
+    atomicAdd(p.grad_depth + fl * n + idx, s_later);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (taps.in[k]) atomicAdd(p.grad_depth + fe * n + tap_row(taps, k) * p.width + tap_col(taps, k), s_tap[k]);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // Dense mode (all H·W pixels are correspondences: `num_points: null`, the reference's
 // explicit-depth configuration, config/experiment/ablation_explicit_depth.yaml).  The generic
@@ -759,6 +856,10 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
   if (dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width, pairs)) {
     const long total = dense_blocks(height, width, pairs);
     hipLaunchKernelGGL(procrustes_scatter_dense_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, aux, total);
+  } else if (batch_repeat > 1 && !surfaces) {
+    const int image_pairs = pairs / batch_repeat, groups = (batch_repeat + kRepeatGroup - 1) / kRepeatGroup;
+    const dim3 rgrid((unsigned)((points + 255) / 256), (unsigned)(image_pairs * groups));
+    hipLaunchKernelGGL(procrustes_scatter_repeat_kernel, rgrid, dim3(256), 0, st, p, aux);
   } else if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);
   else hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, aux, iters);
   FM_LAUNCH_STATUS();

@@ -59,23 +59,13 @@ class IntrinsicsSoftmin(nn.Module):
             self.intrinsics_regressed = IntrinsicsRegressed(IntrinsicsRegressedCfg("regressed", 0.0))
             self.window = []
 
-    # The reference draws torch.randperm(h*w)[:P] per step (intrinsics_softmin.py:90); tests
-    # override this hook to feed identical indices to both implementations.  P distinct pixels in
-    # uniformly random order = the first P distinct values of an i.i.d. uniform sequence, so for
-    # P << h*w we draw P + margin values and drop repeats (two sorts of ~9k keys) instead of
-    # permuting all 921 600 pixels (a full device radix sort, 0.27 ms per step at 720p).  Fixed
-    # shapes throughout: no host sync.
+    # The reference draws torch.randperm(h*w)[:P] per step (intrinsics_softmin.py:90) — a full
+    # device sort of 921 600 keys at 720p (0.27 ms) for 8192 samples.  _ops.random_subset evaluates
+    # a keyed pseudo-random permutation at 0..P-1 instead: one launch, no sort, no host sync (the
+    # seed comes from torch's CPU generator, so torch.manual_seed still reproduces a run).  Tests
+    # override this hook to feed identical indices to both implementations.
     def _draw_indices(self, count: int, device) -> Tensor:
-        k = self.cfg.num_procrustes_points
-        if k * 16 > count:
-            return torch.randperm(count, device=device)[:k]
-        m = k + max(1024, k // 4)  # expected repeats ~ m^2 / (2 count) << margin
-        draw = torch.randint(count, (m,), device=device)
-        ordered, where = draw.sort(stable=True)  # equal values keep their draw order
-        repeat = torch.zeros((m,), dtype=torch.bool, device=device)
-        repeat[where[1:]] = ordered[1:] == ordered[:-1]  # every occurrence after the first
-        first_k = repeat.to(torch.uint8).sort(stable=True).indices[:k]  # non-repeats first, in draw order
-        return draw[first_k]
+        return _ops.random_subset(count, self.cfg.num_procrustes_points, device)
 
     def forward(self, batch, flows, backbone_output, global_step: int) -> Tensor:
         b, f, _, h, w = batch.videos.shape

@@ -250,6 +250,11 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
                      const int32_t* blocks, int nblocks, int pmax, const float* kinv, const float* scale, const float* upstream,
                      int height, int width, int depth_frame0, float* grad_depth, void* stream);
 
+/* `count` distinct pseudo-random indices of [0, n) in pseudo-random order — the role of
+ * torch.randperm(n)[:count] in IntrinsicsSoftmin (intrinsics_softmin.py:90) without sorting n
+ * keys: out[i] = π_seed(i) for a keyed Feistel permutation π of [0, n). */
+int fm_random_subset(unsigned long long seed, long n, long count, int64_t* out, void* stream);
+
 /* ---- export ------------------------------------------------------
  * Point cloud of export_to_colmap (flowmap/export/colmap.py:86-101): depth (F,H,W), kinv
  * (F,3,3), ext (F,4,4) camera-to-world, colors (F,3,H,W) or NULL -> out_xyz (F·H·W,3) world

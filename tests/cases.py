@@ -442,3 +442,33 @@ def case_export(dev, tmp_path):
     assert abs(float(ate) - float(g["ate"])) < 1e-7 and ate.device.type == torch.device(dev).type
     assert_close(a_gt, g["ate_aligned_gt"], 1e-6, what="aligned gt")
     assert_close(a_pred, g["ate_aligned_pred"], 1e-6, what="aligned predicted")
+
+
+def case_random_subset(dev):
+    """fm_random_subset: distinct, in range, reproducible per seed, different across seeds, and
+    plausibly uniform (chi-square over 64 buckets; first-position histogram over many seeds)."""
+    from flowmap_amd import _ops
+
+    n, k = 921600, 8192
+    a = _ops.random_subset(n, k, dev, seed=1234)
+    assert a.dtype == torch.int64 and a.shape == (k,) and a.device.type == torch.device(dev).type
+    assert int(a.min()) >= 0 and int(a.max()) < n and a.unique().numel() == k
+    assert torch.equal(a, _ops.random_subset(n, k, dev, seed=1234))
+    b = _ops.random_subset(n, k, dev, seed=1235)
+    assert (a == b).float().mean().item() < 0.01
+    # order is random too: about half of the successive differences are positive
+    assert abs((a[1:] > a[:-1]).float().mean().item() - 0.5) < 0.03
+    counts = torch.bincount((a.cpu() * 64) // n, minlength=64).double()
+    chi2 = float(((counts - k / 64) ** 2 / (k / 64)).sum())
+    assert chi2 < 120.0, chi2  # 63 dof: mean 63, 99.99th percentile ~ 115
+    # small domains and count == n (a full permutation), incl. non-power-of-two sizes
+    for m in (1, 2, 7, 64, 100, 1000):
+        full = _ops.random_subset(m, m, dev, seed=m)
+        assert torch.equal(full.sort().values.cpu(), torch.arange(m))
+    firsts = torch.stack([_ops.random_subset(10, 1, dev, seed=s) for s in range(400)]).flatten().cpu()
+    hist = torch.bincount(firsts, minlength=10).double()
+    assert float(((hist - 40) ** 2 / 40).sum()) < 40.0  # 9 dof
+    torch.manual_seed(7)
+    c = _ops.random_subset(n, 16, dev)
+    torch.manual_seed(7)
+    assert torch.equal(c, _ops.random_subset(n, 16, dev))

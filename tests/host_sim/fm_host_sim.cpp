@@ -164,6 +164,11 @@ int fm_flow_pack_inputs(const float* flow_fwd, const float* flow_bwd, const floa
   return 0;
 }
 
+int fm_random_subset(unsigned long long seed, long n, long count, int64_t* out, void*) {
+  for (long i = 0; i < count; ++i) out[i] = (int64_t)permuted_index((uint64_t)i, (uint64_t)n, seed);
+  return 0;
+}
+
 int fm_world_points(const float* depth, const float* kinv, const float* ext, const float* colors, int frames, int height, int width,
                     float* out_xyz, float* out_rgb, void*) {
   const size_t n = (size_t)height * width;

@@ -287,3 +287,7 @@ def test_dense_tiled_procrustes_matches_generic_kernels(h, w, flow_sigma):
     for a, b, what in zip(res["tiled"], res["generic"], ("t_bwd", "g_depth", "g_logits", "g_k")):
         assert torch.isfinite(a).all(), what
         assert_close(a, b, 2e-5, abs_=1e-7, what=what)
+
+
+def test_random_subset():
+    cases.case_random_subset(DEV)

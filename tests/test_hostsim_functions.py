@@ -85,3 +85,7 @@ def test_flow_preprocess(tag):
 
 def test_export(tmp_path):
     cases.case_export("cpu", tmp_path)
+
+
+def test_random_subset():
+    cases.case_random_subset("cpu")
