@@ -55,6 +55,8 @@ def test_step_vs_reference_golden(name, kind, lazy):
         (3, 1080, 1920, 1000),  # C3/C4's frame size
         (5, 90, 122, None),  # width not a multiple of 4 -> scalar kernel path, dense Procrustes
         (3, 64, 96, 600),
+        (2, 32, 48, 100),  # a single pair
+        (2, 24, 40, None),
     ],
 )
 def test_step_vs_oracle(f, h, w, p):

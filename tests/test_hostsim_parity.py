@@ -46,7 +46,7 @@ def test_step_vs_reference_golden(name, kind, lazy):
     compare(ours, ref)
 
 
-@pytest.mark.parametrize("f,h,w,p", [(4, 16, 24, 64), (3, 9, 13, None), (6, 32, 20, 200)])
+@pytest.mark.parametrize("f,h,w,p", [(4, 16, 24, 64), (3, 9, 13, None), (6, 32, 20, 200), (2, 8, 12, 30), (2, 8, 12, None)])
 def test_step_vs_oracle_fp64(f, h, w, p):
     depth, wlogit, flows = orc.synth_iid(f, h, w, seed=f * 7 + h)
     ours = run_ours(depth, wlogit, 0.85, flows, (h, w), p)
