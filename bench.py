@@ -102,7 +102,10 @@ def make_tracks(f, device, seed, interval=5, radius=20, grid=35):
     for mid in range(0, f, interval):
         start, end = max(0, mid - radius), min(f, mid + radius + 1)
         drift = (0.003 * torch.randn((end - start, query.shape[0], 2), device=device, generator=g)).cumsum(0)
-        xy = query[None] + drift - drift[mid - start]
+        # every segment tracks its own points (a tracker's query grid sits on the segment's middle
+        # frame): jitter the grid inside its cells so that segments do not share pixels exactly
+        jitter = (torch.rand((query.shape[0], 2), device=device, generator=g) - 0.5) / grid
+        xy = (query + jitter)[None] + drift - drift[mid - start]
         vis = (xy >= 0).all(-1) & (xy < 1).all(-1) & (torch.rand(xy.shape[:2], device=device, generator=g) < 0.9)
         out.append(Tracks(xy[None].contiguous(), vis[None].contiguous(), start))
     return out

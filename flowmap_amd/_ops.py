@@ -747,6 +747,10 @@ class PackedTracks:
         self.xy = torch.cat(xy).contiguous()
         self.vis = torch.cat(vis).contiguous()
         self.seg = torch.tensor(seg, dtype=torch.int32).to(device)
+        # frame-major launch order for the per-(segment, frame) kernels (track_points, track_scatter):
+        # the ~8 segments that cover a frame gather from / scatter into the SAME depth image back to
+        # back, so their 4-tap accesses share DRAM pages and L2 lines instead of sweeping 41 images
+        blocks.sort(key=lambda sf: (seg[sf[0]][0] + sf[1], sf[0]))
         self.blocks = torch.tensor(blocks, dtype=torch.int32).reshape(-1, 2).to(device)
         self.nblocks = len(blocks)
         self.tiles = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 2).to(device)  # (segment, first source frame) per register tile
