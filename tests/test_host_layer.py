@@ -100,3 +100,54 @@ def test_version_bump_invalidates_mask_norm_cache():
     m1.mul_(0.5)  # in-place edit bumps the version counter
     b = _ops.flow_valid_norm(m1, m2, 10.0)
     assert b is not a and abs(float(b[1]) - float(m1.sum() + m2.sum())) < 1e-4
+
+
+def test_errors_of_the_newer_entry_points_are_loud():
+    from flowmap_amd import FusedAdam, Tracks, _ops, export
+
+    videos = torch.rand((1, 3, 3, 8, 10))
+    with pytest.raises(RuntimeError, match="video's resolution"):
+        _ops.flow_postprocess(videos, torch.zeros((1, 2, 4, 5, 2)), (4, 5), reverse=False)
+    with pytest.raises(RuntimeError, match="batch, frame, 3"):
+        _ops.consistency_mask(torch.rand((1, 3, 8, 10)), torch.zeros((1, 2, 8, 10, 2)))
+    with pytest.raises(RuntimeError, match="1 <= count <= n"):
+        _ops.random_subset(10, 11, "cpu")
+    with pytest.raises(RuntimeError, match="frame, height, width"):
+        export.world_point_cloud(torch.rand((1, 3, 4, 6)), torch.eye(3).repeat(3, 1, 1), torch.eye(4).repeat(3, 1, 1))
+    with pytest.raises(RuntimeError, match="do not match"):
+        export.world_point_cloud(torch.rand((3, 4, 6)), torch.eye(3).repeat(2, 1, 1), torch.eye(4).repeat(3, 1, 1))
+    with pytest.raises(ValueError, match="amsgrad"):
+        FusedAdam([torch.zeros(3, requires_grad=True)], amsgrad=True)
+    p = torch.zeros(4, dtype=torch.float64, requires_grad=True)
+    p.grad = torch.ones_like(p)
+    with pytest.raises(RuntimeError, match="float32"):
+        FusedAdam([p]).step()
+    with pytest.raises(RuntimeError, match="LeadingFrames expects"):
+        _ops.LeadingFrames.apply(torch.rand((2, 3, 4)), 1)
+    # tracking: a segment past the last frame, and a depth window outside the video
+    depth, k, ext = torch.rand((1, 3, 6, 8)) + 1, torch.eye(3).repeat(1, 3, 1, 1), torch.eye(4).repeat(1, 3, 1, 1)
+    tracks = [Tracks(torch.rand((1, 4, 5, 2)), torch.ones((1, 4, 5), dtype=torch.bool), 0)]
+    with pytest.raises(RuntimeError, match="past the last frame"):
+        _ops.TrackLossFused.apply(depth, k, ext, _ops.pack_tracks(tracks, "cpu"), 1.0, 0, 0.01, False)
+    short = [Tracks(torch.rand((1, 2, 5, 2)), torch.ones((1, 2, 5), dtype=torch.bool), 0)]
+    with pytest.raises(RuntimeError, match="window of it"):
+        _ops.TrackLossFused.apply(depth, k, ext, _ops.pack_tracks(short, "cpu"), 1.0, 0, 0.01, False, 2)
+
+
+def test_packed_tracks_ownership_filters_sources():
+    from flowmap_amd import Tracks, _ops
+
+    tracks = [Tracks(torch.rand((1, 7, 3, 2)), torch.ones((1, 7, 3), dtype=torch.bool), 2),
+              Tracks(torch.rand((1, 4, 3, 2)), torch.ones((1, 4, 3), dtype=torch.bool), 8)]
+    whole = _ops.PackedTracks(tracks, "cpu")
+    assert whole.nblocks == 11 and not whole.partial and whole.last_frame == 12
+    # frame-major order of the (segment, frame) blocks
+    frames = [int(whole.seg[s, 0]) + fr for s, fr in whole.blocks.tolist()]
+    assert frames == sorted(frames)
+    own = _ops.PackedTracks(tracks, "cpu", own=(4, 9))  # frames 4..8: five of segment 0, one of segment 1
+    assert own.partial and own.nblocks == 6
+    assert {(s, fr) for s, fr in own.blocks.tolist()} == {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 0)}
+    # tiles of TRACK_TILE source frames are kept when ANY of their frames is owned
+    assert own.tiles.tolist() == [[0, 0], [0, _ops.TRACK_TILE], [1, 0]] if _ops.TRACK_TILE < 7 else True
+    none = _ops.PackedTracks(tracks, "cpu", own=(20, 30))
+    assert none.nblocks == 0 and none.ntiles == 0 and tuple(none.blocks.shape) == (0, 2)
