@@ -494,6 +494,51 @@ class FlowLossFused(torch.autograd.Function):
                 g_tb if need[3] else None, None, None, None, None, None, None, None, None, None, None)
 
 
+class SoftminScore(torch.autograd.Function):
+    """IntrinsicsSoftmin's per-candidate weighted L1 flow error (intrinsics_softmin.py:105-121) from
+    the images themselves: depth (B,2,H,W) frames 0/1, weights (B,1,H,W) of pair 0 (logits when
+    ``weight_sens`` != 0), bwd_flow (B,1,H,W,2), indices (P) distinct pixels, candidate intrinsics
+    (N,3,3) [constants], rel (B·N,4,4) the fitted later->earlier poses  ->  error (B,N)."""
+
+    @staticmethod
+    def forward(ctx, depth, weights, bwd_flow, indices, k, rel, weight_sens):
+        dev = check_device(depth, weights, bwd_flow, indices, k, rel)
+        depth, weights, bwd_flow = _f32c(depth, "depth"), _f32c(weights, "weights"), _f32c(bwd_flow, "backward flow")
+        k, rel = _f32c(k, "intrinsics"), _f32c(rel, "poses")
+        b, two, h, w = depth.shape
+        n = k.shape[0]
+        if two != 2 or tuple(weights.shape) != (b, 1, h, w) or tuple(bwd_flow.shape) != (b, 1, h, w, 2):
+            raise RuntimeError("flowmap_amd: SoftminScore expects depth (b,2,h,w), weights (b,1,h,w), backward flow (b,1,h,w,2)")
+        if tuple(k.shape) != (n, 3, 3) or tuple(rel.shape) != (b * n, 4, 4) or indices.dtype != torch.int64:
+            raise RuntimeError("flowmap_amd: SoftminScore expects intrinsics (n,3,3), poses (b*n,4,4), int64 indices")
+        if k.requires_grad or bwd_flow.requires_grad:
+            raise RuntimeError("flowmap_amd: the softmin candidates and the optical flow are constants")
+        indices = indices.contiguous()
+        kinv = intrinsics_inverse(k)
+        err = torch.empty((b * n,), dtype=torch.float64, device=dev)
+        with _guard(dev):
+            call("fm_softmin_score_fwd", ptr(depth), ptr(weights), float(weight_sens), ptr(bwd_flow), ptr(indices), indices.numel(),
+                 ptr(k), ptr(kinv), ptr(rel), b, n, h, w, ptr(err), stream_for(depth))
+        ctx.save_for_backward(depth, weights, bwd_flow, indices, k, kinv, rel)
+        ctx.sens = float(weight_sens)
+        return err.to(torch.float32).reshape(b, n)
+
+    @staticmethod
+    def backward(ctx, g_err):
+        depth, weights, bwd_flow, indices, k, kinv, rel = ctx.saved_tensors
+        b, _, h, w = depth.shape
+        n = k.shape[0]
+        g_err = _f32c(g_err, "grad").reshape(b * n)
+        g_depth = torch.zeros_like(depth) if ctx.needs_input_grad[0] else None
+        g_weights = torch.zeros_like(weights) if ctx.needs_input_grad[1] else None
+        acc = torch.empty((b * n, 12), dtype=torch.float64, device=depth.device)
+        g_rel = torch.empty_like(rel)
+        with _guard(depth.device):
+            call("fm_softmin_score_bwd", ptr(depth), ptr(weights), ctx.sens, ptr(bwd_flow), ptr(indices), indices.numel(), ptr(k),
+                 ptr(kinv), ptr(rel), b, n, h, w, ptr(g_err), ptr(g_depth), ptr(g_weights), ptr(acc), ptr(g_rel), stream_for(depth))
+        return g_depth, g_weights, None, None, None, g_rel if ctx.needs_input_grad[5] else None, None
+
+
 def random_subset(n: int, count: int, device, seed: Optional[int] = None) -> Tensor:
     """``count`` distinct pseudo-random indices of [0, n) in pseudo-random order (int64) — what
     ``torch.randperm(n, device=device)[:count]`` is used for — from one launch of fm_random_subset.

@@ -430,6 +430,49 @@ FM_HD void flow_term_fast(const DirConst& d, float arow, float brow, float crow,
 }
 
 // ---------------------------------------------------------------------------------
+// One (candidate, sampled pixel) term of IntrinsicsSoftmin's score (intrinsics_softmin.py:105-121):
+//   X = z·K⁻¹[u,v,1] (unproject the later frame's pixel), X' = T·X (fitted pose, later -> earlier),
+//   xy = project_camera_space(X', K) (exact ±1e8 / NaN->0 semantics), flow = xy − (u,v),
+//   e = |w·(flow_x − gt_x)| + |w·(flow_y − gt_y)|.
+// softmin_term_bwd: with g = dL/de, the gradients w.r.t. z, w and T (top 3 rows, gt[12]); K is a
+// constant (the candidates are a buffer).
+// ---------------------------------------------------------------------------------
+struct SoftminTerm {
+  float ray[3], x[3];
+  Projected pr;
+  float dx, dy;  // flow − gt
+};
+
+FM_HD float softmin_term(const Mat3& k, const Mat3& kinv, const Pose& t, float u, float v, float z, float gt_x, float gt_y, float w,
+                         SoftminTerm& o) {
+  ray_dir(kinv, u, v, o.ray);
+  o.x[0] = o.ray[0] * z; o.x[1] = o.ray[1] * z; o.x[2] = o.ray[2] * z;
+  float xc[3];
+  apply_pose(t, o.x, xc);
+  o.pr = project_point(xc, k);
+  o.dx = (o.pr.u - u) - gt_x;
+  o.dy = (o.pr.v - v) - gt_y;
+  return fabsf(o.dx * w) + fabsf(o.dy * w);
+}
+
+FM_HD float fm_sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+FM_HD void softmin_term_bwd(const Mat3& k, const Pose& t, const SoftminTerm& o, float w, float g, float& gz, float& gw, float (&gt)[12]) {
+  const float sx = fm_sign(o.dx * w), sy = fm_sign(o.dy * w);  // d|x|/dx = sign(x), 0 at 0 (torch.abs)
+  gw += g * (sx * o.dx + sy * o.dy);
+  float gk[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gxc[3], gx[3];
+  project_point_bwd(o.pr, k, g * sx * w, g * sy * w, gk, gxc);
+  apply_rot_t(t, gxc, gx);
+  gz += gx[0] * o.ray[0] + gx[1] * o.ray[1] + gx[2] * o.ray[2];
+  for (int r = 0; r < 3; ++r) {
+    gt[r * 4 + 0] += gxc[r] * o.x[0];
+    gt[r * 4 + 1] += gxc[r] * o.x[1];
+    gt[r * 4 + 2] += gxc[r] * o.x[2];
+    gt[r * 4 + 3] += gxc[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Random subset without replacement: element i of a keyed pseudo-random PERMUTATION of [0, n).
 // IntrinsicsSoftmin draws `torch.randperm(h*w)[:P]` every step (intrinsics_softmin.py:90) — a
 // full device sort of 921 600 keys at 720p for 8192 samples.  A 4-round Feistel network over

@@ -314,6 +314,104 @@ __global__ void __launch_bounds__(256) world_points_kernel(const float* depth, c
   }
 }
 
+// ---------------------------------------------------------------------------------
+// IntrinsicsSoftmin candidate score (intrinsics_softmin.py:105-121), straight from the images:
+// the sampled pixels' depth / weight / flow are gathered here (no gathered copies, no (60, P, 3)
+// point clouds).  depth (B,2,H,W): frame 1 is the later frame; weights, flow: pair 0.
+// ---------------------------------------------------------------------------------
+struct SoftminArgs {
+  const float* depth;      // (B,2,H,W)
+  const float* weights;    // (B,H,W) weights or logits (weight_sens != 0)
+  const float* bwd_flow;   // (B,H,W,2)
+  const int64_t* indices;  // (P)
+  const float* k;          // (N,3,3)
+  const float* kinv;       // (N,3,3)
+  const float* rel;        // (B*N,4,4) later -> earlier
+  long points;
+  int batch, candidates, height, width;
+  float weight_sens;
+};
+
+struct SoftminPoint {
+  float u, v, z, w, wraw, gx, gy;
+  int idx;
+};
+
+__device__ __forceinline__ SoftminPoint softmin_point(const SoftminArgs& a, int b, long j) {
+  SoftminPoint s;
+  s.idx = (int)a.indices[j];
+  const size_t n = (size_t)a.height * a.width;
+  const int row = s.idx / a.width, col = s.idx - row * a.width;
+  s.u = pixel_center(col, a.width);
+  s.v = pixel_center(row, a.height);
+  s.z = a.depth[((size_t)b * 2 + 1) * n + s.idx];
+  s.wraw = a.weights[(size_t)b * n + s.idx];
+  s.w = a.weight_sens != 0.f ? 1.0f / (1.0f + expf(-a.weight_sens * s.wraw)) : s.wraw;
+  s.gx = a.bwd_flow[((size_t)b * n + s.idx) * 2];
+  s.gy = a.bwd_flow[((size_t)b * n + s.idx) * 2 + 1];
+  return s;
+}
+
+// grid: (point chunks, B*N).  err[b*N + n] += Σ_j e(n, j)   (fp64, zeroed by the entry point)
+__global__ void __launch_bounds__(256) softmin_score_fwd_kernel(SoftminArgs a, double* err) {
+  __shared__ double red[4];
+  const int bn = blockIdx.y, b = bn / a.candidates, n = bn % a.candidates;
+  Mat3 k, kinv;
+  Pose t;
+  load_mat3(a.k + (size_t)n * 9, k);
+  load_mat3(a.kinv + (size_t)n * 9, kinv);
+  load_pose44(a.rel + (size_t)bn * 16, t);
+  float e[1] = {0.f};
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < a.points) {
+    const SoftminPoint s = softmin_point(a, b, j);
+    SoftminTerm o;
+    e[0] = softmin_term(k, kinv, t, s.u, s.v, s.z, s.gx, s.gy, s.w, o);
+  }
+  block_accumulate<1>(e, red, err + bn);
+}
+
+// grid: (point chunks, B).  One thread per sampled pixel walks all candidates: dL/dz and dL/dw sum in
+// registers (stored once: the indices are distinct), dL/dT per candidate is block-reduced.
+__global__ void __launch_bounds__(256) softmin_score_bwd_kernel(SoftminArgs a, const float* g_err, float* g_depth, float* g_weights,
+                                                                double* g_rel) {
+  __shared__ double red[4 * 12];
+  const int b = blockIdx.y;
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = j < a.points;
+  SoftminPoint s = {};
+  if (active) s = softmin_point(a, b, j);
+  float gz = 0.f, gw = 0.f;
+  for (int n = 0; n < a.candidates; ++n) {
+    const int bn = b * a.candidates + n;
+    Mat3 k, kinv;
+    Pose t;
+    load_mat3(a.k + (size_t)n * 9, k);
+    load_mat3(a.kinv + (size_t)n * 9, kinv);
+    load_pose44(a.rel + (size_t)bn * 16, t);
+    float gt[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gt[i] = 0.f;
+    if (active) {
+      SoftminTerm o;
+      softmin_term(k, kinv, t, s.u, s.v, s.z, s.gx, s.gy, s.w, o);
+      softmin_term_bwd(k, t, o, s.w, g_err[bn], gz, gw, gt);
+    }
+    block_accumulate<12>(gt, red, g_rel + (size_t)bn * 12);
+  }
+  if (!active) return;
+  const size_t npx = (size_t)a.height * a.width;
+  if (g_depth) g_depth[((size_t)b * 2 + 1) * npx + s.idx] = gz;
+  if (g_weights) g_weights[(size_t)b * npx + s.idx] = a.weight_sens != 0.f ? gw * a.weight_sens * s.w * (1.f - s.w) : gw;
+}
+
+__global__ void softmin_rel_grad_kernel(const double* acc, int count, float* g_rel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  for (int e = 0; e < 12; ++e) g_rel[(size_t)i * 16 + e] = (float)acc[(size_t)i * 12 + e];
+  for (int e = 12; e < 16; ++e) g_rel[(size_t)i * 16 + e] = 0.f;
+}
+
 __global__ void __launch_bounds__(256) random_subset_kernel(unsigned long long seed, long n, long count, int64_t* out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) out[i] = (int64_t)permuted_index((uint64_t)i, (uint64_t)n, seed);
@@ -352,6 +450,34 @@ int fm_world_points(const float* depth, const float* kinv, const float* ext, con
   FM_CHECK_ARG(!colors || out_rgb);
   hipLaunchKernelGGL(world_points_kernel, dim3(blocks_for((long)height * width), frames), dim3(256), 0, (hipStream_t)stream, depth,
                      kinv, ext, colors, height, width, out_xyz, out_rgb);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_softmin_score_fwd(const float* depth, const float* weights, float weight_sensitivity, const float* bwd_flow,
+                         const int64_t* indices, long points, const float* k, const float* kinv, const float* rel, int batch,
+                         int candidates, int height, int width, double* err, void* stream) {
+  FM_CHECK_ARG(depth && weights && bwd_flow && indices && k && kinv && rel && err);
+  FM_CHECK_ARG(points >= 1 && batch >= 1 && candidates >= 1 && (long)batch * candidates <= 65535 && height >= 1 && width >= 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(err, 0, sizeof(double) * (size_t)batch * candidates, st) != hipSuccess) return FM_ERR_LAUNCH;
+  const SoftminArgs a{depth, weights, bwd_flow, indices, k, kinv, rel, points, batch, candidates, height, width, weight_sensitivity};
+  hipLaunchKernelGGL(softmin_score_fwd_kernel, dim3((unsigned)((points + 255) / 256), batch * candidates), dim3(256), 0, st, a, err);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_softmin_score_bwd(const float* depth, const float* weights, float weight_sensitivity, const float* bwd_flow,
+                         const int64_t* indices, long points, const float* k, const float* kinv, const float* rel, int batch,
+                         int candidates, int height, int width, const float* g_err, float* g_depth, float* g_weights,
+                         double* g_rel_acc, float* g_rel, void* stream) {
+  FM_CHECK_ARG(depth && weights && bwd_flow && indices && k && kinv && rel && g_err && g_rel_acc && g_rel);
+  FM_CHECK_ARG(points >= 1 && batch >= 1 && candidates >= 1 && (long)batch * candidates <= 65535 && height >= 1 && width >= 1);
+  hipStream_t st = (hipStream_t)stream;
+  const int bn = batch * candidates;
+  if (hipMemsetAsync(g_rel_acc, 0, sizeof(double) * (size_t)bn * 12, st) != hipSuccess) return FM_ERR_LAUNCH;
+  const SoftminArgs a{depth, weights, bwd_flow, indices, k, kinv, rel, points, batch, candidates, height, width, weight_sensitivity};
+  hipLaunchKernelGGL(softmin_score_bwd_kernel, dim3((unsigned)((points + 255) / 256), batch), dim3(256), 0, st, a, g_err, g_depth,
+                     g_weights, g_rel_acc);
+  hipLaunchKernelGGL(softmin_rel_grad_kernel, dim3((bn + 63) / 64), dim3(64), 0, st, g_rel_acc, bn, g_rel);
   FM_LAUNCH_STATUS();
 }
 

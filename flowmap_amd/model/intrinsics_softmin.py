@@ -24,7 +24,7 @@ from torch import Tensor, nn
 
 from .. import _ops
 from .model import IntrinsicsRegressed, IntrinsicsRegressedCfg, focal_lengths_to_intrinsics
-from .projection import LazyWeights, sample_image_grid
+from .projection import LazyWeights
 
 
 @dataclass
@@ -81,7 +81,7 @@ class IntrinsicsSoftmin(nn.Module):
 
         candidate_k = focal_lengths_to_intrinsics(self.focal_length_candidates, (h, w))  # (n,3,3)
         idx = self._draw_indices(h * w, device)
-        points = idx.numel()
+        bwd_01 = flows.backward[:, :1].contiguous()  # (b,1,h,w,2): the only pair the sweep looks at
 
         # ---- per-candidate Procrustes fit of frames (0, 1), images read in place -----------
         depths = _ops.LeadingFrames.apply(backbone_output.depths, 2)
@@ -92,27 +92,15 @@ class IntrinsicsSoftmin(nn.Module):
         else:
             weights_01 = _ops.LeadingFrames.apply(weights, 1)
         k_pair = candidate_k[None, :, None].expand(b, n, 2, 3, 3).reshape(b * n, 2, 3, 3)
-        rel, _ = _ops.ProcrustesFit.apply(depths, k_pair, None, weights_01,
-                                          flows.backward[:, :1].contiguous(), idx, sens, n)  # (b*n,1,4,4): frame 1 -> frame 0
+        rel, _ = _ops.ProcrustesFit.apply(depths, k_pair, None, weights_01, bwd_01, idx, sens, n)  # (b*n,1,4,4): frame 1 -> frame 0
 
-        # ---- pose-induced backward flow at the sampled pixels (intrinsics_softmin.py:105-117) --
-        xy, _ = sample_image_grid((h, w), device)
-        xy_p = xy.reshape(h * w, 2)[idx]  # (P,2)
-        z1 = depths[:, 1].reshape(b, h * w)[:, idx]  # (b,P)
-        z1 = z1[:, None].expand(b, n, points).reshape(b * n, points)
-        k_flat = candidate_k[None].expand(b, n, 3, 3).reshape(b * n, 3, 3)
-        later_pts = _ops.Unproject.apply(xy_p.contiguous(), z1, k_flat)  # (b*n,P,3)
-        xy_back = _ops.Reproject.apply(later_pts, rel.reshape(b * n, 4, 4), k_flat).reshape(b, n, points, 2)
-        flow = xy_back - xy_p
-
-        # ---- weighted L1 flow error per candidate, softmin (intrinsics_softmin.py:119-131) ----
-        flow_gt = flows.backward[:, 0].reshape(b, 1, h * w, 2)[:, :, idx]
-        w_dense = weights.materialize()[:, :1] if isinstance(weights, LazyWeights) and sens == 0.0 else None
-        if sens != 0.0:
-            w_pts = (sens * weights_01.reshape(b, 1, h * w)[:, :, idx]).sigmoid()[..., None]
-        else:
-            w_pts = (w_dense if w_dense is not None else weights_01).reshape(b, 1, h * w)[:, :, idx][..., None]
-        error = ((flow - flow_gt) * w_pts).abs().sum(dim=(2, 3))  # (b,n)
+        # ---- pose-induced backward flow error per candidate (intrinsics_softmin.py:105-121): one
+        # launch reads the sampled pixels' depth / weight / flow straight from the images
+        if sens != 0.0 or not isinstance(weights, LazyWeights):
+            score_weights, score_sens = weights_01, sens
+        else:  # a LazyWeights with sensitivity 0 cannot be folded into the kernel
+            score_weights, score_sens = _ops.LeadingFrames.apply(weights.materialize(), 1), 0.0
+        error = _ops.SoftminScore.apply(depths, score_weights, bwd_01, idx, candidate_k, rel.reshape(b * n, 4, 4), score_sens)  # (b,n)
         soft = F.softmin((error - error.min(dim=1, keepdim=True).values) * 10, dim=1)
         intrinsics = (candidate_k[None] * soft[:, :, None, None]).sum(dim=1)  # (b,3,3)
 

@@ -250,6 +250,23 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
                      const int32_t* blocks, int nblocks, int pmax, const float* kinv, const float* scale, const float* upstream,
                      int height, int width, int depth_frame0, float* grad_depth, void* stream);
 
+/* IntrinsicsSoftmin's per-candidate score (intrinsics_softmin.py:105-121), straight from the
+ * images: depth (B,2,H,W) frames 0/1 (the later frame 1 is un-projected), weights (B,H,W) of pair
+ * 0 (logits when weight_sensitivity != 0), bwd_flow (B,H,W,2) of pair 0, indices (P) DISTINCT
+ * sampled pixels, k / kinv (N,3,3) candidates, rel (B·N,4,4) fitted poses later -> earlier.
+ *   err (B·N) fp64 out (zeroed here): Σ_j |w_j (flow_x − gt_x)| + |w_j (flow_y − gt_y)|. */
+int fm_softmin_score_fwd(const float* depth, const float* weights, float weight_sensitivity, const float* bwd_flow,
+                         const int64_t* indices, long points, const float* k, const float* kinv, const float* rel, int batch,
+                         int candidates, int height, int width, double* err, void* stream);
+
+/* Backward: g_err (B·N) fp32.  g_depth (B,2,H,W) and g_weights (B,H,W): STORED at the sampled
+ * pixels of frame 1 / pair 0 (caller zeroes the buffers; either may be NULL); g_rel (B·N,4,4)
+ * out, bottom rows 0; g_rel_acc (B·N,12) fp64 workspace (zeroed here). */
+int fm_softmin_score_bwd(const float* depth, const float* weights, float weight_sensitivity, const float* bwd_flow,
+                         const int64_t* indices, long points, const float* k, const float* kinv, const float* rel, int batch,
+                         int candidates, int height, int width, const float* g_err, float* g_depth, float* g_weights,
+                         double* g_rel_acc, float* g_rel, void* stream);
+
 /* `count` distinct pseudo-random indices of [0, n) in pseudo-random order — the role of
  * torch.randperm(n)[:count] in IntrinsicsSoftmin (intrinsics_softmin.py:90) without sorting n
  * keys: out[i] = π_seed(i) for a keyed Feistel permutation π of [0, n). */

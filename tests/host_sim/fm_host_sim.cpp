@@ -164,6 +164,76 @@ int fm_flow_pack_inputs(const float* flow_fwd, const float* flow_bwd, const floa
   return 0;
 }
 
+static void sim_softmin_point(const float* depth, const float* weights, float sens, const float* flow, const int64_t* indices, int b, long j,
+                              int height, int width, float& u, float& v, float& z, float& w, float& gx, float& gy, int& idx) {
+  idx = (int)indices[j];
+  const size_t n = (size_t)height * width;
+  const int row = idx / width, col = idx - row * width;
+  u = pixel_center(col, width);
+  v = pixel_center(row, height);
+  z = depth[((size_t)b * 2 + 1) * n + idx];
+  const float raw = weights[(size_t)b * n + idx];
+  w = sens != 0.f ? 1.0f / (1.0f + expf(-sens * raw)) : raw;
+  gx = flow[((size_t)b * n + idx) * 2];
+  gy = flow[((size_t)b * n + idx) * 2 + 1];
+}
+
+int fm_softmin_score_fwd(const float* depth, const float* weights, float sens, const float* bwd_flow, const int64_t* indices, long points,
+                         const float* k, const float* kinv, const float* rel, int batch, int candidates, int height, int width,
+                         double* err, void*) {
+  for (int bn = 0; bn < batch * candidates; ++bn) {
+    const int b = bn / candidates, n = bn % candidates;
+    Mat3 km, ki;
+    Pose t;
+    load_mat3(k + (size_t)n * 9, km);
+    load_mat3(kinv + (size_t)n * 9, ki);
+    load_pose44(rel + (size_t)bn * 16, t);
+    double s = 0;
+    for (long j = 0; j < points; ++j) {
+      float u, v, z, w, gx, gy;
+      int idx;
+      sim_softmin_point(depth, weights, sens, bwd_flow, indices, b, j, height, width, u, v, z, w, gx, gy, idx);
+      SoftminTerm o;
+      s += softmin_term(km, ki, t, u, v, z, gx, gy, w, o);
+    }
+    err[bn] = s;
+  }
+  return 0;
+}
+
+int fm_softmin_score_bwd(const float* depth, const float* weights, float sens, const float* bwd_flow, const int64_t* indices, long points,
+                         const float* k, const float* kinv, const float* rel, int batch, int candidates, int height, int width,
+                         const float* g_err, float* g_depth, float* g_weights, double* g_rel_acc, float* g_rel, void*) {
+  const size_t npx = (size_t)height * width;
+  std::memset(g_rel_acc, 0, sizeof(double) * (size_t)batch * candidates * 12);
+  for (int b = 0; b < batch; ++b)
+    for (long j = 0; j < points; ++j) {
+      float u, v, z, w, gx, gy, gz = 0.f, gw = 0.f;
+      int idx;
+      sim_softmin_point(depth, weights, sens, bwd_flow, indices, b, j, height, width, u, v, z, w, gx, gy, idx);
+      for (int n = 0; n < candidates; ++n) {
+        const int bn = b * candidates + n;
+        Mat3 km, ki;
+        Pose t;
+        load_mat3(k + (size_t)n * 9, km);
+        load_mat3(kinv + (size_t)n * 9, ki);
+        load_pose44(rel + (size_t)bn * 16, t);
+        SoftminTerm o;
+        softmin_term(km, ki, t, u, v, z, gx, gy, w, o);
+        float gt[12] = {};
+        softmin_term_bwd(km, t, o, w, g_err[bn], gz, gw, gt);
+        for (int e = 0; e < 12; ++e) g_rel_acc[(size_t)bn * 12 + e] += gt[e];
+      }
+      if (g_depth) g_depth[((size_t)b * 2 + 1) * npx + idx] = gz;
+      if (g_weights) g_weights[(size_t)b * npx + idx] = sens != 0.f ? gw * sens * w * (1.f - w) : gw;
+    }
+  for (int bn = 0; bn < batch * candidates; ++bn) {
+    for (int e = 0; e < 12; ++e) g_rel[(size_t)bn * 16 + e] = (float)g_rel_acc[(size_t)bn * 12 + e];
+    for (int e = 12; e < 16; ++e) g_rel[(size_t)bn * 16 + e] = 0.f;
+  }
+  return 0;
+}
+
 int fm_random_subset(unsigned long long seed, long n, long count, int64_t* out, void*) {
   for (long i = 0; i < count; ++i) out[i] = (int64_t)permuted_index((uint64_t)i, (uint64_t)n, seed);
   return 0;

@@ -29,12 +29,20 @@ batch = Batch(torch.zeros((1, f, 3, 1, 1), device=dev).expand(1, f, 3, h, w))
 loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
 track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
 tracks = bench.make_tracks(f, dev, seed=100)
+from flowmap_amd.model.intrinsics_softmin import IntrinsicsSoftminCfg, RegressionCfg  # noqa: E402
+
+soft = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsSoftminCfg("softmin", 8192, 0.5, 2.0, 60, RegressionCfg(1000, 100)),
+                      ExtrinsicsProcrustesCfg("procrustes", 1000, False)), num_frames=f, image_shape=(h, w)).to(dev)
+soft.backbone.depth.data = depth
+soft.backbone.weights.data = wlogit
 opt = flowmap_amd.FusedAdam(model.parameters(), lr=3e-5)
 out = {}
-for name, with_tracks, with_opt in (("flow", False, False), ("flow+tracking", True, False), ("flow+tracking+adam", True, True)):
+for name, with_tracks, with_opt, use_soft in (("flow", False, False, False), ("flow+tracking", True, False, False),
+                                                ("flow+tracking+adam", True, True, False), ("flow, softmin intrinsics", False, False, True)):
+    model_used = soft if use_soft else model
     def step():
-        model.zero_grad(set_to_none=True)
-        o = model(batch, flows, 0)
+        model_used.zero_grad(set_to_none=True)
+        o = model_used(batch, flows, 0)
         loss = loss_fn(batch, flows, None, o, 0)
         if with_tracks:
             loss = loss + track_fn(batch, flows, tracks, o, 0)
