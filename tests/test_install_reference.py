@@ -205,3 +205,73 @@ def test_reference_flow_predictor_under_install(patched_reference):
     assert isinstance(ref_fp.FlowPredictor.__dict__["compute_consistency_mask"], staticmethod)
     again = StandIn(None).compute_bidirectional_flow(Batch(videos, None, None, None), shape)  # reference code, CPU
     assert_close(again.forward_mask, g["a_forward_mask"], 1e-6, what="unpatched")
+
+
+def test_reference_overfit_loop_under_install_tracks_the_unpatched_loop():
+    """The loop body of ModelWrapperOverfit.training_step + Adam (model_wrapper_overfit.py:51-62,
+    104-105) for a few steps: the unmodified reference (CPU, torch.optim.Adam) against the same
+    reference Model / losses after install() with flowmap_amd.FusedAdam — parameters stay together."""
+    sys.dont_write_bytecode = True
+    added = [str(ROOT / "oracle" / "refstubs"), str(REF)]
+    sys.path[:0] = added
+    try:
+        from conftest import assert_close, load_golden, t
+
+        import flowmap.loss as ref_loss
+        from flowmap.dataset.types import Batch
+        from flowmap.flow.flow_predictor import Flows
+        from flowmap.loss.loss_flow import LossFlowCfg
+        from flowmap.loss.loss_tracking import LossTrackingCfg
+        from flowmap.loss.mapping.mapping_huber import MappingHuberCfg
+        from flowmap.model.backbone.backbone_explicit_depth import BackboneExplicitDepthCfg
+        from flowmap.model.extrinsics.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+        from flowmap.model.intrinsics.intrinsics_regressed import IntrinsicsRegressedCfg
+        from flowmap.model.model import Model, ModelCfg
+        from flowmap.tracking.track_predictor import Tracks
+
+        import flowmap_amd
+        from flowmap_amd import _lib
+        from helpers import build_host_sim
+
+        g = load_golden("step_scene_flow_tracking")
+        depth, wlogit = t(g["depth"]), t(g["wlogit"])
+        f, h, w = depth.shape
+        flows = Flows(t(g["fwd"]), t(g["bwd"]), t(g["fwd_mask"]), t(g["bwd_mask"]))
+        tracks = [Tracks(t(g[f"trk{i}_xy"]), t(g[f"trk{i}_vis"]), int(g[f"trk{i}_start"])) for i in range(int(g["n_segments"]))]
+        batch = Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["s"], ["d"])
+        cfgs = [LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)), LossTrackingCfg(2, 100.0, "tracking", MappingHuberCfg("huber", 0.01))]
+
+        def loop(make_optimizer):
+            cfg = ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", float(g["focal"])),
+                           ExtrinsicsProcrustesCfg("procrustes", None if int(g["num_points"]) < 0 else int(g["num_points"]), False), True)
+            model = Model(cfg, num_frames=f, image_shape=(h, w))
+            model.backbone.depth.data = depth.clone()
+            model.backbone.weights.data = wlogit.clone()
+            losses = ref_loss.get_losses(cfgs)
+            opt = make_optimizer(model.parameters())
+            history = []
+            for step in range(6):  # the tracking loss switches on at step 2 (enable_after)
+                opt.zero_grad()
+                out = model(batch, flows, step)
+                total = sum(fn(batch, flows, tracks, out, step) for fn in losses)
+                total.backward()
+                opt.step()
+                history.append(float(total.detach()))
+            return history, model
+
+        hist_ref, model_ref = loop(lambda params: torch.optim.Adam(params, lr=1e-3))
+        _lib.set_library_for_testing(build_host_sim())
+        flowmap_amd.install()
+        try:
+            hist_ours, model_ours = loop(lambda params: flowmap_amd.FusedAdam(params, lr=1e-3))
+        finally:
+            flowmap_amd.uninstall()
+            _lib.set_library_for_testing(None)
+        assert hist_ref[2] != hist_ref[1]  # the tracking loss came in at step 2
+        assert_close(torch.tensor(hist_ours), torch.tensor(hist_ref), 2e-4, what="loss history")
+        assert_close(model_ours.backbone.depth, model_ref.backbone.depth, 1e-5, what="depth after 6 steps")
+        assert_close(model_ours.backbone.weights, model_ref.backbone.weights, 1e-4, abs_=1e-6, what="weight logits after 6 steps")
+        assert_close(model_ours.intrinsics.focal_length, model_ref.intrinsics.focal_length, 1e-5, what="focal length after 6 steps")
+    finally:
+        for p in added:
+            sys.path.remove(p)
