@@ -14,7 +14,6 @@ from typing import Optional
 import torch
 from torch import Tensor
 
-from . import _lib
 from ._lib import call, check_device, ptr, stream_for
 
 MAPPING_KINDS = {"huber": 0, "l1": 1, "l2": 2}

@@ -13,7 +13,6 @@ from __future__ import annotations
 from typing import Iterable, Tuple
 
 import torch
-from torch import Tensor
 
 from ._lib import call, check_device, ptr, stream_for
 from ._ops import _guard
