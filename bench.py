@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--optimizer", choices=["none", "fused", "torch"], default="none",
                     help="add the Adam step (lr 3e-5, config/overfit.yaml:30) to every iteration: flowmap_amd.FusedAdam or "
                          "torch.optim.Adam; the headline metric is fwd+bwd only (none)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step in a hipGraph (flowmap_amd.GraphedStep) and replay it: for the launch-bound regime "
+                         "(small frames); single GPU only")
     ap.add_argument("--tracking", action="store_true",
                     help="BASELINE.json configs[2]: add the tracking loss (segments every 5 frames, +-20 frames, 35x35 tracks)")
     return ap.parse_args()
@@ -210,7 +213,7 @@ def main():
 
     optimizer = None
     if args.optimizer == "fused":
-        optimizer = flowmap_amd.FusedAdam(model.parameters(), lr=3e-5)
+        optimizer = flowmap_amd.FusedAdam(model.parameters(), lr=3e-5, capturable=args.graph)
     elif args.optimizer == "torch":
         optimizer = torch.optim.Adam(model.parameters(), lr=3e-5)
 
@@ -234,6 +237,12 @@ def main():
             optimizer.step()
         return loss
 
+    if args.graph:
+        if dist is not None or args.optimizer == "torch":
+            raise SystemExit("--graph: single GPU, and --optimizer none|fused")
+        eager_step = step
+        graphed = flowmap_amd.GraphedStep(eager_step, warmup=3)  # disables the per-launch events: kernel_ms stays 0
+        step = graphed  # noqa: F811
     if dist is not None:  # create the RCCL communicators / P2P channels outside the timed region
         shard.exchange_halo(torch.zeros((2, h, w), device=device))
         dist.all_reduce(torch.zeros(4, device=device))
@@ -287,6 +296,7 @@ def main():
                 "workload": f"BASELINE.json configs[1]: {f} frames @ {h}x{w}, flow loss only (huber 0.01, weight 1000), "
                 f"explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points}; fwd+bwd, "
                 + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__})")
+                + ("; whole step replayed as one hipGraph" if args.graph else "")
                 + (f"; + tracking loss (configs[2]): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else ""),
                 "frames_per_gpu": f,
                 "height": h,

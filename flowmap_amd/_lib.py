@@ -35,10 +35,12 @@ SIGNATURES = {
     "fm_softmin_score_fwd": [P, P, F, P, P, L, P, P, P, I, I, I, I, P, P],
     "fm_softmin_score_bwd": [P, P, F, P, P, L, P, P, P, I, I, I, I, P, P, P, P, P, P],
     "fm_random_subset": [ctypes.c_ulonglong, L, L, P, P],
+    "fm_random_subset_stateful": [P, L, L, P, P],
     "fm_world_points": [P, P, P, P, I, I, I, P, P, P],
     "fm_consistency_mask": [P, P, I, I, I, I, P, P],
     "fm_flow_postprocess": [P, P, I, I, I, I, I, I, I, P, P, P],
     "fm_adam_step": [P, P, P, P, L, L, D, D, D, D, D, P],
+    "fm_adam_step_capturable": [P, P, P, P, L, P, D, D, D, D, D, P],
     "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, I, P, P],
     "fm_pose_solve": [P, I, P, P, P, P],
     "fm_pose_solve_bwd": [P, P, P, P, I, P, P],

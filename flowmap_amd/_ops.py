@@ -538,17 +538,32 @@ class SoftminScore(torch.autograd.Function):
         return g_depth, g_weights, None, None, None, g_rel if ctx.needs_input_grad[5] else None, None
 
 
+# hipGraph capture (flowmap_amd.graph.GraphedStep): a captured launch cannot carry a host value that
+# changes between replays, so while this is on random_subset keeps its seed in device memory.
+graph_capturable = False
+_rng_states: dict = {}
+
+
 def random_subset(n: int, count: int, device, seed: Optional[int] = None) -> Tensor:
     """``count`` distinct pseudo-random indices of [0, n) in pseudo-random order (int64) — what
     ``torch.randperm(n, device=device)[:count]`` is used for — from one launch of fm_random_subset.
-    ``seed`` defaults to a draw from torch's CPU generator, so ``torch.manual_seed`` reproduces it."""
+    ``seed`` defaults to a draw from torch's CPU generator, so ``torch.manual_seed`` reproduces it.
+    With ``graph_capturable`` the seed is a per-device state tensor that every call advances."""
     if not 1 <= count <= n:
         raise RuntimeError("flowmap_amd: random_subset needs 1 <= count <= n")
     device = torch.device(device)
-    if seed is None:
-        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
     out = torch.empty((count,), dtype=torch.int64, device=device)
     check_device(out)
+    if seed is None and graph_capturable:
+        state = _rng_states.get(str(out.device))
+        if state is None:  # created OUTSIDE any capture (GraphedStep warms the step up first)
+            first = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+            state = _rng_states[str(out.device)] = torch.tensor([first], dtype=torch.int64).to(out.device)
+        with _guard(device):
+            call("fm_random_subset_stateful", ptr(state), int(n), int(count), ptr(out), stream_for(out))
+        return out
+    if seed is None:
+        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
     with _guard(device):
         call("fm_random_subset", int(seed), int(n), int(count), ptr(out), stream_for(out))
     return out

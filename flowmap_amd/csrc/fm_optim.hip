@@ -32,8 +32,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define FM_ADAM_BLOCKS_PER_CU 4
 #endif
 
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
-                                                   float* __restrict__ exp_avg_sq, long count, AdamCoef c, int vec_ok) {
+__device__ __forceinline__ void adam_apply(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
+                                           float* __restrict__ exp_avg_sq, long count, const AdamCoef& c, int vec_ok) {
   const long stride = (long)gridDim.x * blockDim.x;
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long done = 0;
@@ -72,6 +72,35 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, co
   }
 }
 
+// bias corrections in double, exactly as torch.optim.adam._single_tensor_adam
+__host__ __device__ inline AdamCoef adam_coefficients(double step, double lr, double beta1, double beta2, double eps, double weight_decay) {
+  const double bc1 = 1.0 - pow(beta1, step);
+  const double bc2 = 1.0 - pow(beta2, step);
+  AdamCoef c;
+  c.one_minus_b1 = (float)(1.0 - beta1);
+  c.b2 = (float)beta2;
+  c.one_minus_b2 = (float)(1.0 - beta2);
+  c.step_size = (float)(lr / bc1);
+  c.bc2_sqrt = (float)sqrt(bc2);
+  c.eps = (float)eps;
+  c.weight_decay = (float)weight_decay;
+  return c;
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count,
+                                                   AdamCoef c, int vec_ok) {
+  adam_apply(param, grad, exp_avg, exp_avg_sq, count, c, vec_ok);
+}
+
+// hipGraph-capturable variant: the step number lives in device memory (a captured launch cannot
+// carry a host value that changes from replay to replay), the coefficients are derived per thread.
+__global__ void __launch_bounds__(256) adam_capturable_kernel(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                                              long count, const float* step, double lr, double beta1, double beta2,
+                                                              double eps, double weight_decay, int vec_ok) {
+  const AdamCoef c = adam_coefficients((double)step[0], lr, beta1, beta2, eps, weight_decay);
+  adam_apply(param, grad, exp_avg, exp_avg_sq, count, c, vec_ok);
+}
+
 }  // namespace fm
 
 using namespace fm;
@@ -83,17 +112,7 @@ int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
   FM_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && count >= 0 && step >= 1);
   FM_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0);
   if (count == 0) return FM_OK;
-  // bias corrections in double on the host, exactly as torch.optim.adam._single_tensor_adam
-  const double bc1 = 1.0 - std::pow(beta1, (double)step);
-  const double bc2 = 1.0 - std::pow(beta2, (double)step);
-  AdamCoef c;
-  c.one_minus_b1 = (float)(1.0 - beta1);
-  c.b2 = (float)beta2;
-  c.one_minus_b2 = (float)(1.0 - beta2);
-  c.step_size = (float)(lr / bc1);
-  c.bc2_sqrt = (float)std::sqrt(bc2);
-  c.eps = (float)eps;
-  c.weight_decay = (float)weight_decay;
+  const AdamCoef c = adam_coefficients((double)step, lr, beta1, beta2, eps, weight_decay);
   auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const int vec_ok = aligned(param) && aligned(grad) && aligned(exp_avg) && aligned(exp_avg_sq);
   long blocks = (count / 4 + 255) / 256;
@@ -101,6 +120,21 @@ int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
   if (blocks > 256L * FM_ADAM_BLOCKS_PER_CU) blocks = 256L * FM_ADAM_BLOCKS_PER_CU;  // grid-stride beyond that
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, count, c,
                      vec_ok);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, const float* step,
+                            double lr, double beta1, double beta2, double eps, double weight_decay, void* stream) {
+  FM_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step && count >= 0);
+  FM_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0);
+  if (count == 0) return FM_OK;
+  auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const int vec_ok = aligned(param) && aligned(grad) && aligned(exp_avg) && aligned(exp_avg_sq);
+  long blocks = (count / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256L * FM_ADAM_BLOCKS_PER_CU) blocks = 256L * FM_ADAM_BLOCKS_PER_CU;
+  hipLaunchKernelGGL(adam_capturable_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, count, step, lr, beta1, beta2, eps, weight_decay, vec_ok);
   FM_LAUNCH_STATUS();
 }
 

@@ -417,6 +417,19 @@ __global__ void __launch_bounds__(256) random_subset_kernel(unsigned long long s
   if (i < count) out[i] = (int64_t)permuted_index((uint64_t)i, (uint64_t)n, seed);
 }
 
+// hipGraph-capturable variant: the seed lives in device memory and is advanced by a follow-up
+// launch, so every replay of a captured step draws a fresh subset.
+__global__ void __launch_bounds__(256) random_subset_state_kernel(const unsigned long long* state, long n, long count, int64_t* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = (int64_t)permuted_index((uint64_t)i, (uint64_t)n, state[0]);
+}
+__global__ void random_state_advance_kernel(unsigned long long* state) {
+  unsigned long long z = state[0] + 0x9e3779b97f4a7c15ULL;  // splitmix64
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  state[0] = z ^ (z >> 31);
+}
+
 static inline unsigned blocks_for(long n, int per_thread = 4, unsigned cap = 4096) {
   long b = (n + 256L * per_thread - 1) / (256L * per_thread);
   if (b < 1) b = 1;
@@ -484,6 +497,14 @@ int fm_softmin_score_bwd(const float* depth, const float* weights, float weight_
 int fm_random_subset(unsigned long long seed, long n, long count, int64_t* out, void* stream) {
   FM_CHECK_ARG(out && n >= 1 && count >= 1 && count <= n && n < (1L << 40));
   hipLaunchKernelGGL(random_subset_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, n, count, out);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_random_subset_stateful(unsigned long long* state, long n, long count, int64_t* out, void* stream) {
+  FM_CHECK_ARG(state && out && n >= 1 && count >= 1 && count <= n && n < (1L << 40));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(random_subset_state_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, state, n, count, out);
+  hipLaunchKernelGGL(random_state_advance_kernel, dim3(1), dim3(1), 0, st, state);
   FM_LAUNCH_STATUS();
 }
 

@@ -1,0 +1,53 @@
+"""hipGraph capture of one optimisation step.
+
+``GraphedStep`` captures the whole step — zeroed gradients, forward, losses, backward and,
+optionally, the optimiser — into one hipGraph (``torch.cuda.CUDAGraph``) and replays it; every
+kernel of this package launches on torch's current stream and allocates through torch, so it is
+captured like any torch op.  What it buys is HOST time: a replay costs the CPU a few microseconds
+instead of the 0.5-0.9 ms it takes to enqueue the ~50-70 launches of a step (8 ranks on one host,
+or a slow host).  It does NOT shorten the step on this stack: at the reference's default resolution
+(150 frames of 180x240, flow + tracking + Adam) the step is bound by the dependent chain of short
+kernels on the GPU — 0.856 ms eager, 0.872 ms replayed — and at 720p by HBM.
+
+Requirements on ``fn``: static input tensors (parameters, flows, tracks: true for an overfit loop),
+no host synchronisation, and for an optimiser inside it ``FusedAdam(..., capturable=True)``.
+While a GraphedStep exists the softmin sweep draws its random pixels from a device-side state
+(``_ops.graph_capturable``), so each replay still samples afresh.
+"""
+
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+
+from . import _ops
+
+
+class GraphedStep:
+    def __init__(self, fn: Callable[[], object], warmup: int = 3, device=None) -> None:
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._previous = _ops.graph_capturable
+        _ops.graph_capturable = True
+        events, _ops.flow_kernel_events = _ops.flow_kernel_events, None  # event records do not belong in a graph
+        try:
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):  # fills every cache (packed constants, valid sums, indices, RNG state)
+                for _ in range(max(1, warmup)):
+                    fn()
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.output = fn()
+        finally:
+            _ops.flow_kernel_events = events
+
+    def __call__(self):
+        """Replay the captured step; returns the tensors ``fn`` returned (refreshed in place)."""
+        self.graph.replay()
+        return self.output
+
+    def close(self) -> None:
+        _ops.graph_capturable = self._previous

@@ -20,7 +20,7 @@ from ._ops import _guard
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params: Iterable, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, amsgrad: bool = False, *, maximize: bool = False) -> None:
+                 weight_decay: float = 0.0, amsgrad: bool = False, *, maximize: bool = False, capturable: bool = False) -> None:
         # argument checks and messages of torch.optim.Adam
         if not 0.0 <= lr:
             raise ValueError(f"Invalid learning rate: {lr}")
@@ -34,7 +34,10 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError(f"Invalid weight_decay value: {weight_decay}")
         if amsgrad or maximize:
             raise ValueError("flowmap_amd.FusedAdam: amsgrad / maximize are not implemented (the reference uses neither)")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False))
+        # capturable (as torch.optim.Adam(capturable=True)): the step counter is a device tensor and
+        # the kernel derives the bias corrections from it, so step() can sit inside a hipGraph
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                                      capturable=bool(capturable)))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -57,13 +60,22 @@ class FusedAdam(torch.optim.Optimizer):
                 check_device(p, grad)
                 grad = grad.contiguous()
                 state = self.state[p]
+                capturable = bool(group.get("capturable", False))
                 if len(state) == 0:
-                    state["step"] = torch.tensor(0.0, dtype=torch.float32)  # host counter, as torch's default Adam
+                    # host counter as torch's default Adam; device counter when capturable
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32, device=p.device if capturable else "cpu")
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] += 1
                 with _guard(p.device):
-                    call("fm_adam_step", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
-                         int(state["step"].item()), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
-                         float(group["weight_decay"]), stream_for(p))
+                    if capturable:
+                        if state["step"].device != p.device:
+                            raise RuntimeError("flowmap_amd.FusedAdam: capturable=True needs the step counter on the parameter's device")
+                        call("fm_adam_step_capturable", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
+                             ptr(state["step"]), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
+                             float(group["weight_decay"]), stream_for(p))
+                    else:
+                        call("fm_adam_step", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
+                             int(state["step"].item()), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
+                             float(group["weight_decay"]), stream_for(p))
         return loss

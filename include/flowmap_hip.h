@@ -272,6 +272,10 @@ int fm_softmin_score_bwd(const float* depth, const float* weights, float weight_
  * keys: out[i] = π_seed(i) for a keyed Feistel permutation π of [0, n). */
 int fm_random_subset(unsigned long long seed, long n, long count, int64_t* out, void* stream);
 
+/* As fm_random_subset with the seed in device memory: uses state[0], then advances it
+ * (splitmix64).  Capturable in a hipGraph: every replay draws a fresh subset. */
+int fm_random_subset_stateful(unsigned long long* state, long n, long count, int64_t* out, void* stream);
+
 /* ---- export ------------------------------------------------------
  * Point cloud of export_to_colmap (flowmap/export/colmap.py:86-101): depth (F,H,W), kinv
  * (F,3,3), ext (F,4,4) camera-to-world, colors (F,3,H,W) or NULL -> out_xyz (F·H·W,3) world
@@ -305,6 +309,11 @@ int fm_flow_postprocess(const float* videos, const float* flow, int batch, int f
  * `step` is the 1-based step number AFTER the increment.  No amsgrad / maximize. */
 int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, long step, double lr, double beta1,
                  double beta2, double eps, double weight_decay, void* stream);
+
+/* As fm_adam_step with the step number read from device memory (step[0], a float holding the
+ * 1-based step AFTER the increment): capturable in a hipGraph, like torch.optim.Adam(capturable=True). */
+int fm_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, const float* step,
+                            double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -472,3 +472,33 @@ def case_random_subset(dev):
     c = _ops.random_subset(n, 16, dev)
     torch.manual_seed(7)
     assert torch.equal(c, _ops.random_subset(n, 16, dev))
+
+
+def case_capturable_pieces(dev):
+    """The two host values a captured step cannot carry — Adam's step number and the sampler's
+    seed — live in device memory in capturable mode and behave as their host-side versions."""
+    from flowmap_amd import FusedAdam, _ops
+
+    g = torch.Generator().manual_seed(5)
+    init = torch.randn((3, 10, 12), generator=g)
+    grads = [torch.randn((3, 10, 12), generator=g) for _ in range(5)]
+    a = init.clone().to(dev).requires_grad_(True)
+    b = init.clone().to(dev).requires_grad_(True)
+    plain, capt = FusedAdam([a], lr=1e-2), FusedAdam([b], lr=1e-2, capturable=True)
+    for gr in grads:
+        a.grad, b.grad = gr.clone().to(dev), gr.clone().to(dev)
+        plain.step()
+        capt.step()
+    assert capt.state[b]["step"].device.type == torch.device(dev).type and float(capt.state[b]["step"]) == 5.0
+    assert_close(b.detach(), a.detach(), 1e-6, abs_=1e-8, what="capturable Adam")
+
+    previous = _ops.graph_capturable
+    _ops.graph_capturable = True
+    try:
+        x = _ops.random_subset(5000, 64, dev)
+        y = _ops.random_subset(5000, 64, dev)
+        assert x.unique().numel() == 64 and y.unique().numel() == 64 and not torch.equal(x, y)  # the state advanced
+        z = _ops.random_subset(5000, 64, dev, seed=3)
+        assert torch.equal(z, _ops.random_subset(5000, 64, dev, seed=3))  # explicit seeds stay stateless
+    finally:
+        _ops.graph_capturable = previous

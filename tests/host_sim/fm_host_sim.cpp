@@ -239,6 +239,15 @@ int fm_random_subset(unsigned long long seed, long n, long count, int64_t* out, 
   return 0;
 }
 
+int fm_random_subset_stateful(unsigned long long* state, long n, long count, int64_t* out, void*) {
+  for (long i = 0; i < count; ++i) out[i] = (int64_t)permuted_index((uint64_t)i, (uint64_t)n, state[0]);
+  unsigned long long z = state[0] + 0x9e3779b97f4a7c15ULL;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  state[0] = z ^ (z >> 31);
+  return 0;
+}
+
 int fm_world_points(const float* depth, const float* kinv, const float* ext, const float* colors, int frames, int height, int width,
                     float* out_xyz, float* out_rgb, void*) {
   const size_t n = (size_t)height * width;
@@ -301,6 +310,11 @@ int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
              (float)weight_decay};
   for (long i = 0; i < count; ++i) adam_update(c, param[i], grad[i], exp_avg[i], exp_avg_sq[i]);
   return 0;
+}
+
+int fm_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, const float* step, double lr,
+                            double beta1, double beta2, double eps, double weight_decay, void* stream) {
+  return fm_adam_step(param, grad, exp_avg, exp_avg_sq, count, (long)step[0], lr, beta1, beta2, eps, weight_decay, stream);
 }
 
 int fm_scale_if_needed(float* x, long count, const float* scalar, void*) {

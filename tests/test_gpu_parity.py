@@ -293,3 +293,103 @@ def test_dense_tiled_procrustes_matches_generic_kernels(h, w, flow_sigma):
 
 def test_random_subset():
     cases.case_random_subset(DEV)
+
+
+def test_capturable_pieces():
+    cases.case_capturable_pieces(DEV)
+
+
+def _graph_problem(f=6, h=48, w=64, softmin=False, tracking=True):
+    from flowmap_amd import Batch
+    from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
+    from flowmap_amd.loss.mapping import MappingHuberCfg
+    from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap_amd.model.intrinsics_softmin import IntrinsicsSoftminCfg
+    from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
+    from helpers import to_flows, to_tracks
+
+    import flowmap_amd
+
+    sc = orc.synth_scene(f, h, w, seed=12)
+    flowmap_amd.set_lazy_surfaces(True)
+    intr = IntrinsicsSoftminCfg("softmin", 400, 0.5, 2.0, 8, None) if softmin else IntrinsicsRegressedCfg("regressed", 0.9)
+    model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), intr, ExtrinsicsProcrustesCfg("procrustes", 300, False)),
+                  num_frames=f, image_shape=(h, w))
+    model.backbone.depth.data = sc["depth_init"].clone()
+    model = model.to(DEV)
+    flows = to_flows(sc["flows"], DEV)
+    tracks = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=12, interval=2, radius=2, grid=6), DEV) if tracking else None
+    batch = Batch(torch.zeros((1, f, 3, h, w), device=DEV))
+    flow_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
+    track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
+
+    def loss_of(out):
+        total = flow_fn(batch, flows, None, out, 0)
+        return total + track_fn(batch, flows, tracks, out, 0) if tracking else total
+
+    return model, batch, flows, loss_of
+
+
+def test_graphed_step_replays_the_eager_optimisation():
+    """flowmap_amd.GraphedStep: forward + flow and tracking losses + backward + FusedAdam captured
+    in one hipGraph; five replays follow five eager steps parameter for parameter."""
+    import flowmap_amd
+
+    try:
+        results = {}
+        for mode in ("eager", "graph"):
+            model, batch, flows, loss_of = _graph_problem()
+            opt = flowmap_amd.FusedAdam(model.parameters(), lr=1e-3, capturable=(mode == "graph"))
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                loss = loss_of(model(batch, flows, 0))
+                loss.backward()
+                opt.step()
+                return loss
+
+            losses = []
+            if mode == "eager":
+                for _ in range(3 + 5):  # the graph variant runs 3 eager warm-up steps; the capture itself executes nothing
+                    losses.append(float(step()))
+            else:
+                graphed = flowmap_amd.GraphedStep(step, warmup=3)
+                try:
+                    for _ in range(5):
+                        losses.append(float(graphed()))
+                finally:
+                    graphed.close()
+            results[mode] = (losses[-5:], model.backbone.depth.detach().clone(), model.intrinsics.focal_length.detach().clone())
+        assert_close(torch.tensor(results["graph"][0]), torch.tensor(results["eager"][0]), 1e-5, what="loss history")
+        assert results["eager"][0][-1] < results["eager"][0][0]  # it optimises
+        assert_close(results["graph"][1], results["eager"][1], 1e-5, what="depth")
+        assert_close(results["graph"][2], results["eager"][2], 1e-5, what="focal length")
+    finally:
+        flowmap_amd.set_lazy_surfaces(False)
+
+
+def test_graphed_step_with_softmin_samples_afresh():
+    """Inside a hipGraph the softmin sweep still draws new pixels on every replay (device-side
+    sampler state): the loss changes from replay to replay although no parameter does."""
+    import flowmap_amd
+
+    try:
+        model, batch, flows, loss_of = _graph_problem(softmin=True, tracking=False)
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            out = model(batch, flows, 0)
+            loss = loss_of(out)
+            loss.backward()
+            return out.intrinsics
+
+        graphed = flowmap_amd.GraphedStep(step, warmup=2)
+        try:
+            ks = [graphed()[0, 0].clone() for _ in range(4)]
+        finally:
+            graphed.close()
+        assert all(torch.isfinite(k).all() for k in ks)
+        assert len({round(float(k[0, 0]), 7) for k in ks}) > 1  # different samples -> slightly different blends
+        assert model.backbone.depth.grad is not None and torch.isfinite(model.backbone.depth.grad).all()
+    finally:
+        flowmap_amd.set_lazy_surfaces(False)

@@ -89,3 +89,7 @@ def test_export(tmp_path):
 
 def test_random_subset():
     cases.case_random_subset("cpu")
+
+
+def test_capturable_pieces():
+    cases.case_capturable_pieces("cpu")
