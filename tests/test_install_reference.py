@@ -275,3 +275,80 @@ def test_reference_overfit_loop_under_install_tracks_the_unpatched_loop():
     finally:
         for p in added:
             sys.path.remove(p)
+
+
+@pytest.mark.parametrize(
+    "f,h,w,points,mapping,use_weights,randomize",
+    [
+        (4, 10, 12, 60, "huber", True, True),  # randomize_points: torch.randint indices, duplicates included
+        (4, 10, 12, 30, "huber", True, False),
+        (3, 9, 14, None, "l1", True, False),  # every pixel a correspondence
+        (5, 8, 12, 40, "l2", False, False),  # use_correspondence_weights: false -> constant ones
+    ],
+)
+def test_reference_configurations_under_install(f, h, w, points, mapping, use_weights, randomize):
+    """The reference's Model + flow loss in several configurations, unpatched vs after install()."""
+    sys.dont_write_bytecode = True
+    added = [str(ROOT / "oracle" / "refstubs"), str(REF)]
+    sys.path[:0] = added
+    try:
+        from conftest import assert_close
+
+        import flowmap.loss as ref_loss
+        from flowmap.dataset.types import Batch
+        from flowmap.flow.flow_predictor import Flows
+        from flowmap.loss.loss_flow import LossFlowCfg
+        from flowmap.loss.mapping.mapping_huber import MappingHuberCfg
+        from flowmap.loss.mapping.mapping_l1 import MappingL1Cfg
+        from flowmap.loss.mapping.mapping_l2 import MappingL2Cfg
+        from flowmap.model.backbone.backbone_explicit_depth import BackboneExplicitDepthCfg
+        from flowmap.model.extrinsics.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+        from flowmap.model.intrinsics.intrinsics_regressed import IntrinsicsRegressedCfg
+        from flowmap.model.model import Model, ModelCfg
+
+        import flowmap_amd
+        from flowmap_amd import _lib
+        from helpers import build_host_sim
+
+        mapping_cfg = {"huber": MappingHuberCfg("huber", 0.01), "l1": MappingL1Cfg("l1"), "l2": MappingL2Cfg("l2")}[mapping]
+
+        def run():
+            g = torch.Generator().manual_seed(f * h + w)
+            depth = 1.0 + 0.3 * torch.rand((f, h, w), generator=g)
+            logits = 0.01 * torch.randn((f - 1, h, w), generator=g)
+            flows = Flows(0.02 * torch.randn((1, f - 1, h, w, 2), generator=g), 0.02 * torch.randn((1, f - 1, h, w, 2), generator=g),
+                          torch.rand((1, f - 1, h, w), generator=g), torch.rand((1, f - 1, h, w), generator=g))
+            cfg = ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", 0.8),
+                           ExtrinsicsProcrustesCfg("procrustes", points, randomize), use_weights)
+            model = Model(cfg, num_frames=f, image_shape=(h, w))
+            model.backbone.depth.data = depth.clone()
+            model.backbone.weights.data = logits.clone()
+            batch = Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["s"], ["d"])
+            losses = ref_loss.get_losses([LossFlowCfg(0, 1000.0, "flow", mapping_cfg)])
+            torch.manual_seed(3)  # randomize_points draws torch.randint
+            out = model(batch, flows, 0)
+            total = sum(fn(batch, flows, None, out, 0) for fn in losses)
+            total.backward()
+            return (total.detach(), out.extrinsics.detach(), model.backbone.depth.grad, model.backbone.weights.grad,
+                    model.intrinsics.focal_length.grad)
+
+        ref = run()
+        _lib.set_library_for_testing(build_host_sim())
+        flowmap_amd.install()
+        try:
+            ours = run()
+        finally:
+            flowmap_amd.uninstall()
+            _lib.set_library_for_testing(None)
+        scale = abs(float(ref[0]))
+        assert_close(ours[0], ref[0], 1e-4, what="total")
+        assert_close(ours[1], ref[1], 1e-4, what="extrinsics")
+        assert_close(ours[2], ref[2], 1e-3, abs_=1e-4 * scale, what="g_depth")
+        assert_close(ours[4], ref[4], 1e-2, abs_=1e-4 * scale, what="g_focal")
+        if ref[3] is None:
+            assert ours[3] is None or float(ours[3].abs().max()) == 0.0
+        else:
+            assert_close(ours[3], ref[3], 2e-3, abs_=1e-6, what="g_weight_logits")
+    finally:
+        for p in added:
+            sys.path.remove(p)
