@@ -46,12 +46,20 @@ class _guard:
             self.ctx.__exit__(*exc)
 
 
+_kinv_last = None  # (weakref to K, its version, K⁻¹): the extrinsics fit and the flow loss of a step share one K
+
+
 def intrinsics_inverse(k: Tensor) -> Tensor:
-    """K⁻¹ for a (..., 3, 3) stack (no autograd; callers chain the backward)."""
+    """K⁻¹ for a (..., 3, 3) stack (no autograd; callers chain the backward).  The result for the
+    most recent K tensor object is kept, so the consumers of one step invert it once."""
+    global _kinv_last
     k = _f32c(k, "intrinsics")
+    if _kinv_last is not None and _kinv_last[0]() is k and _kinv_last[1] == k._version:
+        return _kinv_last[2]
     out = torch.empty_like(k)
     with _guard(k.device):
         call("fm_intrinsics_inverse", ptr(k), k.numel() // 9, ptr(out), stream_for(k))
+    _kinv_last = (weakref.ref(k), k._version, out)
     return out
 
 
