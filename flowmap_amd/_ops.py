@@ -188,9 +188,13 @@ def _tensor_key(t: Tensor):
 
 def _note_emitted(source_key, buffer: Optional[Tensor]) -> None:
     if buffer is not None and source_key is not None:
-        if len(_emitted) > 8:
-            _emitted.clear()
+        _emitted.pop(source_key, None)  # re-insert at the end: the dict is kept in age order
         _emitted[source_key] = weakref.ref(buffer)
+        if len(_emitted) > 16:  # entries nobody collected (no LeadingFrames consumer): drop dead ones, then the oldest
+            for key in [k for k, ref in _emitted.items() if ref() is None]:
+                del _emitted[key]
+            while len(_emitted) > 16:
+                del _emitted[next(iter(_emitted))]
 
 
 class LeadingFrames(torch.autograd.Function):

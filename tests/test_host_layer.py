@@ -151,3 +151,17 @@ def test_packed_tracks_ownership_filters_sources():
     assert own.tiles.tolist() == [[0, 0], [0, _ops.TRACK_TILE], [1, 0]] if _ops.TRACK_TILE < 7 else True
     none = _ops.PackedTracks(tracks, "cpu", own=(20, 30))
     assert none.nblocks == 0 and none.ntiles == 0 and tuple(none.blocks.shape) == (0, 2)
+
+
+def test_emitted_registry_keeps_the_newest_entries():
+    """Gradient buffers registered for in-place hand-over are evicted oldest-first, never the
+    pair that the current backward pass has just registered."""
+    from flowmap_amd import _ops
+
+    _ops._emitted.clear()
+    keep = [torch.zeros(1) for _ in range(40)]
+    for i, buf in enumerate(keep):
+        _ops._note_emitted(("key", i), buf)
+        assert ("key", i) in _ops._emitted and (i == 0 or ("key", i - 1) in _ops._emitted)
+    assert len(_ops._emitted) <= 16 and ("key", 0) not in _ops._emitted
+    _ops._emitted.clear()
