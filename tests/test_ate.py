@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def test_ate_matches_reference_path_small():
     out = subprocess.run(
-        [sys.executable, str(ROOT / "tools" / "ate_check.py"), "--device", "cpu", "--frames", "6", "--height", "24", "--width", "32",
+        [sys.executable, str(ROOT / "tests" / "tools" / "ate_check.py"), "--device", "cpu", "--frames", "6", "--height", "24", "--width", "32",
          "--steps", "40", "--points", "200", "--threads", "4"],
         check=True, capture_output=True, text=True,
     ).stdout.strip().splitlines()[-1]
@@ -23,7 +23,7 @@ def test_ate_matches_reference_path_small():
 
 def test_ate_matches_reference_path_with_tracking():
     out = subprocess.run(
-        [sys.executable, str(ROOT / "tools" / "ate_check.py"), "--device", "cpu", "--frames", "6", "--height", "24", "--width", "32",
+        [sys.executable, str(ROOT / "tests" / "tools" / "ate_check.py"), "--device", "cpu", "--frames", "6", "--height", "24", "--width", "32",
          "--steps", "30", "--points", "200", "--threads", "4", "--tracking", "--track-grid", "5"],
         check=True, capture_output=True, text=True,
     ).stdout.strip().splitlines()[-1]

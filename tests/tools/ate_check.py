@@ -2,7 +2,7 @@
 (the reference's path restated on the CPU) and with flowmap_amd from identical initial
 parameters and the same Adam schedule, then report ATE (flowmap/misc/ate.py) of both.
 
-    python tools/ate_check.py --device cuda:0 --frames 16 --height 256 --width 256 --steps 200
+    python tests/tools/ate_check.py --device cuda:0 --frames 16 --height 256 --width 256 --steps 200
 Prints one JSON line.  `--device cpu` runs flowmap_amd on the host test double (tests only).
 """
 import argparse
@@ -13,7 +13,7 @@ from pathlib import Path
 
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 

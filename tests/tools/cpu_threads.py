@@ -2,7 +2,7 @@
 import sys, time
 from pathlib import Path
 import torch
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from oracle import flowmap_oracle as orc
 f, h, w = 4, 720, 1280

@@ -1,12 +1,12 @@
 """Extended randomised parity sweep (same generator as tests/fuzz_cases.py, other seeds, more
-and larger cases).  `python tools/extended_fuzz.py --device cuda:0 --count 150 --seed 11`;
+and larger cases).  `python tests/tools/extended_fuzz.py --device cuda:0 --count 150 --seed 11`;
 `--device cpu` runs on the host test double."""
 import argparse
 import random
 import sys
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
 import fuzz_cases  # noqa: E402
 

@@ -2,7 +2,7 @@
 (run through gpurun).  The reference sequence is restated with torch ops by the oracle
 (oracle.bidirectional_flows = flow_predictor.py:82-102); the network is a stand-in.
 
-    python tools/preprocess_bench.py [--frames 12 --height 2880 --width 5120 --scale 4]
+    python tests/tools/preprocess_bench.py [--frames 12 --height 2880 --width 5120 --scale 4]
 """
 import argparse
 import json
@@ -12,7 +12,7 @@ from pathlib import Path
 
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from flowmap_amd import _ops  # noqa: E402
 from oracle import flowmap_oracle as orc  # noqa: E402  (comparison only)
