@@ -305,11 +305,11 @@ FM_HD void flow_postprocess_at(const float* src, const float* tgt, const float* 
 // ---------------------------------------------------------------------------------
 // One flow residual of the FUSED flow loss (fm_flow.hip; tests/host_sim runs the same code).
 //
-// Per (source frame, direction) constants (wave-uniform, SGPRs on the GPU):
-//   m  = R·K⁻¹_src (3x3): X' = z·(m·[u,v,1]) + t — neither the source ray nor the
-//        camera-space point is formed, and dL/dz = g_X'·(m·[u,v,1]) reuses m·h;
-//   kd = rows 0,1 of the destination intrinsics PRE-SCALED by the aspect factors
-//        (fix_aspect_ratio, mapping.py:17-23): r = kd·p − aspect·(xy + flow).
+// With m = R·K⁻¹_src (X' = z·m·[u,v,1] + t) and kd = rows 0,1 of the destination intrinsics
+// PRE-SCALED by the aspect factors (fix_aspect_ratio, mapping.py:17-23; r = kd·p − aspect·(xy+flow)),
+// the per (source frame, direction) constants are the twelve numbers of DirConst below
+// (wave-uniform, SGPRs on the GPU): kd·X' and Z' are affine in the pixel, so neither the source
+// ray, nor the camera-space point, nor p = X'/(Z'+eps) is formed, and dL/dz = ω·(a, b, −c).
 // Per pixel the residual's gradient enters every pose / intrinsics gradient only through
 //   ω = (q·w_u, q·w_v, q·(w_u·pu + w_v·pv)),   q = 1/(Z'+eps),  w = dL/d(kd·p),
 // so ONE 3x3 sum Ω = Σ ω ⊗ z[u,v,1] and σ = Σ ω carry all of them (flow_finalize_frame):
