@@ -39,6 +39,7 @@ SIGNATURES = {
     "fm_world_points": [P, P, P, P, I, I, I, P, P, P],
     "fm_consistency_mask": [P, P, I, I, I, I, P, P],
     "fm_flow_postprocess": [P, P, I, I, I, I, I, I, I, P, P, P],
+    "fm_resize_crop": [P, L, I, I, I, I, I, I, I, I, P, P],
     "fm_adam_step": [P, P, P, P, L, L, D, D, D, D, D, P],
     "fm_adam_step_capturable": [P, P, P, P, L, P, D, D, D, D, D, P],
     "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, I, P, P],

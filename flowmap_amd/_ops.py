@@ -622,6 +622,32 @@ def flow_postprocess(videos: Tensor, raw_flow: Tensor, shape, reverse: bool):
     return out_flow, out_mask
 
 
+def resize_crop(images: Tensor, resized_shape, crop_shape) -> Tensor:
+    """``center_crop_images(F.interpolate(images, resized_shape, bilinear), crop_shape)``
+    (flowmap/misc/cropping.py:19-51) for (..., H, W) images in one launch; no gradients (it is
+    data preparation)."""
+    check_device(images)
+    *lead, h, w = images.shape
+    rh, rw = int(resized_shape[0]), int(resized_shape[1])
+    oh, ow = int(crop_shape[0]), int(crop_shape[1])
+    if oh > rh or ow > rw or min(oh, ow, rh, rw) < 1:
+        raise RuntimeError("flowmap_amd: the crop must fit inside the resized image")
+    planes = 1
+    for d in lead:
+        planes *= int(d)
+    with torch.no_grad():
+        images = _f32c(images, "images")
+        out = torch.empty((*lead, oh, ow), dtype=torch.float32, device=images.device)
+        done = 0
+        with _guard(images.device):
+            while done < planes:  # the launch takes at most 65535 planes
+                chunk = min(planes - done, 65535)
+                call("fm_resize_crop", images.data_ptr() + done * h * w * 4, chunk, h, w, rh, rw, (rh - oh) // 2, (rw - ow) // 2, oh, ow,
+                     out.data_ptr() + done * oh * ow * 4, stream_for(images))
+                done += chunk
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # Function-level building blocks on explicit point sets
 # --------------------------------------------------------------------------------------

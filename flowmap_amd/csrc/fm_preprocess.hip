@@ -58,6 +58,24 @@ __global__ void __launch_bounds__(256) flow_postprocess_kernel(const float* vide
   }
 }
 
+// resize_batch + center_crop_images (flowmap/misc/cropping.py:19-51) in one pass: only the pixels
+// that survive the crop are interpolated, and the uncropped resized video never exists.
+//   out[p][y][x] = bilinear_resize(in[p] -> (rh, rw))[y + row0][x + col0]
+__global__ void __launch_bounds__(256) resize_crop_kernel(const float* in, int h, int w, int rh, int rw, int row0, int col0, int oh, int ow,
+                                                          float* out) {
+  const size_t plane = blockIdx.y;
+  const float* src = in + plane * (size_t)h * w;
+  float* dst = out + plane * (size_t)oh * ow;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)oh * ow; i += (size_t)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)
+    const int y = (int)(i / ow), x = (int)(i - (size_t)y * ow);
+    const ResizeTap ty = resize_tap(y + row0, h, rh), tx = resize_tap(x + col0, w, rw);
+    const float v00 = src[(size_t)ty.i0 * w + tx.i0], v01 = src[(size_t)ty.i0 * w + tx.i1];
+    const float v10 = src[(size_t)ty.i1 * w + tx.i0], v11 = src[(size_t)ty.i1 * w + tx.i1];
+    dst[i] = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+  }
+}
+
 }  // namespace fm
 
 using namespace fm;
@@ -85,6 +103,19 @@ int fm_flow_postprocess(const float* videos, const float* flow, int batch, int f
   if (bx > 4096) bx = 4096;
   hipLaunchKernelGGL(flow_postprocess_kernel, dim3((unsigned)bx, (unsigned)(batch * (frames - 1))), dim3(256), 0, (hipStream_t)stream,
                      videos, flow, frames, height, width, out_height, out_width, reverse ? 1 : 0, out_flow, out_mask);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_resize_crop(const float* in, long planes, int height, int width, int resized_height, int resized_width, int row0, int col0,
+                   int out_height, int out_width, float* out, void* stream) {
+  FM_CHECK_ARG(in && out && planes >= 1 && planes <= 65535 && height >= 1 && width >= 1 && resized_height >= 1 && resized_width >= 1);
+  FM_CHECK_ARG(row0 >= 0 && col0 >= 0 && out_height >= 1 && out_width >= 1 && row0 + out_height <= resized_height &&
+               col0 + out_width <= resized_width);
+  const long n = (long)out_height * out_width;
+  long bx = (n + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(resize_crop_kernel, dim3((unsigned)bx, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, in, height, width,
+                     resized_height, resized_width, row0, col0, out_height, out_width, out);
   FM_LAUNCH_STATUS();
 }
 

@@ -38,7 +38,13 @@ def _set(obj, name, value):
     setattr(obj, name, value)
 
 
-def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postprocess: bool = True, fused_adam: bool = True) -> None:
+_CROPPING_NAMES = ("resize_batch", "crop_and_resize_batch_for_model", "crop_and_resize_batch_for_flow")
+# modules that bind those names at import (overfit.py:29-32, model_wrapper_pretrain.py:12-16)
+_CROPPING_SITES = ("flowmap.overfit", "flowmap.model.model_wrapper_pretrain")
+
+
+def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postprocess: bool = True, fused_adam: bool = True,
+            cropping: bool = True) -> None:
     """Patch the reference in place.  ``lazy_surfaces=True`` additionally lets
     ``Model.forward``'s ``unproject`` hand a LazySurfaces to the fused consumers;
     ``fused_softmin=True`` registers the fused candidate sweep as INTRINSICS["softmin"]
@@ -47,7 +53,9 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
     (flowmap/flow/flow_predictor.py:59-102) on the reference base class, so every concrete
     predictor (RAFT, GMFlow) inherits the fused post-processing; ``fused_adam=True`` makes
     ``ModelWrapperOverfit.configure_optimizers`` (model_wrapper_overfit.py:104-105) build
-    ``flowmap_amd.FusedAdam`` (skipped when lightning is not importable)."""
+    ``flowmap_amd.FusedAdam`` (skipped when lightning is not importable); ``cropping=True`` rebinds
+    ``resize_batch`` / ``crop_and_resize_batch_for_model`` / ``_for_flow`` (flowmap/misc/cropping.py)
+    to the one-pass resize+crop, which uploads a host batch once and prepares both videos in HBM."""
     from . import loss as our_loss
     from .loss import mapping as our_mapping
     from .model import procrustes as our_procrustes
@@ -123,6 +131,22 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
                 return FusedAdam(self.parameters(), lr=self.cfg.lr)
 
             _set(ref_wrapper.ModelWrapperOverfit, "configure_optimizers", configure_optimizers)
+
+    if cropping:
+        from .misc import cropping as our_cropping
+
+        ref_cropping = importlib.import_module("flowmap.misc.cropping")
+        crop_sites = []
+        for mod_name in _CROPPING_SITES:  # import first: they must bind the reference's functions
+            try:
+                crop_sites.append(importlib.import_module(mod_name))
+            except Exception:  # hydra / lightning are not installed
+                pass
+        for name in _CROPPING_NAMES:
+            _set(ref_cropping, name, getattr(our_cropping, name))
+            for mod in crop_sites:
+                if hasattr(mod, name):
+                    _set(mod, name, getattr(our_cropping, name))
 
     our_projection.set_lazy_surfaces(lazy_surfaces)
 

@@ -1,0 +1,104 @@
+"""flowmap/misc/cropping.py — the resize + centre crop that prepares the optimisation's videos and
+the (4x larger) videos the optical-flow network sees.  Same names and results; resize and crop
+happen in ONE pass (fm_resize_crop): only the pixels that survive the crop are interpolated and the
+uncropped resized video (F x 3 x 2880 x 5120 floats for a 720p run) is never written.
+The PIL helpers of the reference (resize_to_cover*) are image-file utilities and stay there.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+
+from .. import _lib, _ops
+
+
+@dataclass
+class CroppingCfg:
+    """cropping.py:12-16"""
+
+    image_shape: Union[Tuple[int, int], int]
+    flow_scale_multiplier: int
+    patch_size: int
+
+
+def compute_patch_cropped_shape(shape: Tuple[int, int], patch_size: int) -> Tuple[int, int]:
+    """cropping.py:31-40: the largest multiples of the patch size that fit."""
+    h, w = shape
+    return (h // patch_size) * patch_size, (w // patch_size) * patch_size
+
+
+def center_crop_images(images: Tensor, new_shape: Tuple[int, int]) -> Tensor:
+    """cropping.py:43-51 (a view, as in the reference)."""
+    *_, h, w = images.shape
+    h_new, w_new = new_shape
+    row, col = (h - h_new) // 2, (w - w_new) // 2
+    return images[..., row : row + h_new, col : col + w_new]
+
+
+def center_crop_intrinsics(intrinsics: Optional[Tensor], old_shape: Tuple[int, int], new_shape: Tuple[int, int]) -> Optional[Tensor]:
+    """cropping.py:54-70: normalised focal lengths grow by the crop ratio."""
+    if intrinsics is None:
+        return None
+    (h_old, w_old), (h_new, w_new) = old_shape, new_shape
+    out = intrinsics.clone()
+    out[..., 0, 0] *= w_old / w_new
+    out[..., 1, 1] *= h_old / h_new
+    return out
+
+
+def get_image_shape(original_shape: Tuple[int, int], cfg: CroppingCfg) -> Tuple[int, int]:
+    """cropping.py:85-96: an exact shape, or an approximate pixel count at the original aspect."""
+    if isinstance(cfg.image_shape, tuple):
+        return cfg.image_shape
+    h, w = original_shape
+    scale = (cfg.image_shape / (h * w)) ** 0.5
+    return round(h * scale), round(w * scale)
+
+
+def _resident(batch, device=None):
+    """The reference resizes on the host, where its data loader leaves the batch
+    (flowmap/overfit.py:52-62); here a host batch is uploaded once at its original resolution and
+    everything derived from it is produced in HBM (``Batch.to`` later is then a no-op)."""
+    if device is None:
+        if batch.videos.is_cuda or _lib.using_test_double():
+            return batch
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else batch.videos.device
+    return batch.to(device)
+
+
+def resize_batch(batch, shape: Tuple[int, int], device=None):
+    """cropping.py:19-28."""
+    batch = _resident(batch, device)
+    return replace(batch, videos=_ops.resize_crop(batch.videos, shape, shape))
+
+
+def patch_crop_batch(batch, patch_size: int):
+    """cropping.py:73-82."""
+    h, w = batch.videos.shape[-2:]
+    new_shape = compute_patch_cropped_shape((h, w), patch_size)
+    return replace(batch, intrinsics=center_crop_intrinsics(batch.intrinsics, (h, w), new_shape),
+                   videos=center_crop_images(batch.videos, new_shape))
+
+
+def _resize_then_patch_crop(batch, shape: Tuple[int, int], patch_size: int, device=None):
+    batch = _resident(batch, device)
+    cropped = compute_patch_cropped_shape(shape, patch_size)
+    return replace(batch, intrinsics=center_crop_intrinsics(batch.intrinsics, shape, cropped),
+                   videos=_ops.resize_crop(batch.videos, shape, cropped))
+
+
+def crop_and_resize_batch_for_model(batch, cfg: CroppingCfg, device=None):
+    """cropping.py:99-111 -> (batch, pre-crop shape)."""
+    shape = get_image_shape(tuple(batch.videos.shape[-2:]), cfg)
+    return _resize_then_patch_crop(batch, shape, cfg.patch_size, device), shape
+
+
+def crop_and_resize_batch_for_flow(batch, cfg: CroppingCfg, device=None):
+    """cropping.py:114-125: the flow network's input, flow_scale_multiplier times larger."""
+    shape = get_image_shape(tuple(batch.videos.shape[-2:]), cfg)
+    flow_shape = tuple(dim * cfg.flow_scale_multiplier for dim in shape)
+    return _resize_then_patch_crop(batch, flow_shape, cfg.patch_size * cfg.flow_scale_multiplier, device)

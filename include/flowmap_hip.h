@@ -301,6 +301,13 @@ int fm_consistency_mask(const float* videos, const float* flow, int batch, int f
 int fm_flow_postprocess(const float* videos, const float* flow, int batch, int frames, int height, int width, int out_height,
                         int out_width, int reverse, float* out_flow, float* out_mask, void* stream);
 
+/* resize_batch followed by center_crop_images (flowmap/misc/cropping.py:19-51, the body of
+ * crop_and_resize_batch_for_model / _for_flow) in one pass over `planes` images (H,W):
+ * out[p][y][x] = F.interpolate(in[p], (resized_height, resized_width), bilinear,
+ * align_corners=False)[y + row0][x + col0], out (planes, out_height, out_width). */
+int fm_resize_crop(const float* in, long planes, int height, int width, int resized_height, int resized_width, int row0, int col0,
+                   int out_height, int out_width, float* out, void* stream);
+
 /* ---- optimiser step ------------------------------------------
  * torch.optim.Adam as configured by ModelWrapperOverfit.configure_optimizers
  * (flowmap/model/model_wrapper_overfit.py:104-105), one tensor per call, in place:

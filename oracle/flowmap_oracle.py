@@ -563,6 +563,36 @@ def resize_bilinear(x: Tensor, shape) -> Tensor:
     return tnf.interpolate(x, tuple(shape), mode="bilinear", align_corners=False)
 
 
+def cropped_shapes(original_hw, image_shape, patch_size: int, multiplier: int = 1):
+    """get_image_shape + compute_patch_cropped_shape (flowmap/misc/cropping.py:31-40,85-96):
+    -> (resize target, patch-cropped shape), both times ``multiplier`` for the flow network's input
+    (cropping.py:114-125)."""
+    if isinstance(image_shape, tuple):
+        h, w = image_shape
+    else:
+        oh, ow = original_hw
+        scale = (image_shape / (oh * ow)) ** 0.5
+        h, w = round(oh * scale), round(ow * scale)
+    h, w, patch = h * multiplier, w * multiplier, patch_size * multiplier
+    return (h, w), ((h // patch) * patch, (w // patch) * patch)
+
+
+def crop_and_resize(videos: Tensor, intrinsics, image_shape, patch_size: int, multiplier: int = 1):
+    """crop_and_resize_batch_for_model (multiplier 1) / _for_flow (cropping.py:99-125): bilinear
+    resize of (b,f,3,h,w) videos, centre crop to whole patches, and the matching change of the
+    normalised focal lengths (cropping.py:54-70)."""
+    b, f, c, h, w = videos.shape
+    resized, cropped = cropped_shapes((h, w), image_shape, patch_size, multiplier)
+    full = resize_bilinear(videos.reshape(b * f, c, h, w), resized).reshape(b, f, c, *resized)
+    row, col = (resized[0] - cropped[0]) // 2, (resized[1] - cropped[1]) // 2
+    out = full[..., row : row + cropped[0], col : col + cropped[1]]
+    if intrinsics is not None:
+        intrinsics = intrinsics.clone()
+        intrinsics[..., 0, 0] *= resized[1] / cropped[1]
+        intrinsics[..., 1, 1] *= resized[0] / cropped[0]
+    return out, intrinsics, resized
+
+
 def bidirectional_flows(videos: Tensor, predictor, shape) -> OFlows:
     """flow_predictor.py:82-102 around an arbitrary ``predictor(videos) -> raw flow``."""
 

@@ -375,6 +375,34 @@ def gold_flow_preprocess():
     save("fn_flow_preprocess", **arrays)
 
 
+CROPPING_CASES = {
+    # tag: (frames, h, w, image_shape, flow_scale_multiplier, patch_size)
+    "a": (3, 30, 44, (18, 26), 4, 8),
+    "b": (2, 37, 53, 400, 2, 4),  # approximate pixel count -> rounded shape
+    "c": (2, 24, 32, (24, 32), 1, 8),  # identity resize, no crop
+    "d": (2, 16, 20, (27, 35), 3, 5),  # upsampling
+}
+
+
+def gold_cropping():
+    """crop_and_resize_batch_for_model / _for_flow of the reference (flowmap/misc/cropping.py)."""
+    from flowmap.misc import cropping as rc
+
+    arrays = {}
+    for tag, (f, h, w, image_shape, mult, patch) in CROPPING_CASES.items():
+        videos = orc.synth_video(f, h, w, seed=70 + ord(tag))
+        k = torch.eye(3).repeat(1, f, 1, 1)
+        k[..., 0, 0], k[..., 1, 1], k[..., 0, 2], k[..., 1, 2] = 0.8 + 0.05 * (ord(tag) - 97), 1.1, 0.5, 0.5
+        cfg = rc.CroppingCfg(image_shape, mult, patch)
+        batch = Batch(videos, torch.arange(f)[None], ["s"], ["d"], None, k)
+        model_batch, pre_crop = rc.crop_and_resize_batch_for_model(batch, cfg)
+        flow_batch = rc.crop_and_resize_batch_for_flow(batch, cfg)
+        arrays.update({f"{tag}_videos": videos, f"{tag}_intrinsics": k, f"{tag}_pre_crop": np.array(pre_crop),
+                       f"{tag}_model_videos": model_batch.videos, f"{tag}_flow_videos": flow_batch.videos,
+                       f"{tag}_model_intrinsics": model_batch.intrinsics, f"{tag}_flow_intrinsics": flow_batch.intrinsics})
+    save("fn_cropping", **arrays)
+
+
 def gold_export():
     """The point-cloud loop of export_to_colmap (flowmap/export/colmap.py:86-101) executed with
     the reference's own unproject / homogenize_points (the module itself needs plyfile, which
@@ -439,4 +467,5 @@ if __name__ == "__main__":
     gold_softmin()
     gold_flow_preprocess()
     gold_export()
+    gold_cropping()
     print("done")

@@ -416,6 +416,42 @@ def case_flow_preprocess(dev, tag):
                  what="rescale_mask")
 
 
+CROPPING_CASES = {  # oracle/make_golden.py: tag -> (image_shape, flow_scale_multiplier, patch_size)
+    "a": ((18, 26), 4, 8),
+    "b": (400, 2, 4),
+    "c": ((24, 32), 1, 8),
+    "d": ((27, 35), 3, 5),
+}
+
+
+def case_cropping(dev, tag):
+    """crop_and_resize_batch_for_model / _for_flow against the reference's outputs (golden)."""
+    from flowmap_amd import Batch
+    from flowmap_amd.misc import cropping
+
+    g = load_golden("fn_cropping")
+    image_shape, mult, patch = CROPPING_CASES[tag]
+    cfg = cropping.CroppingCfg(image_shape, mult, patch)
+    videos, k = t(g[f"{tag}_videos"]).to(dev), t(g[f"{tag}_intrinsics"]).to(dev)
+    batch = Batch(videos, intrinsics=k)
+    model_batch, pre_crop = cropping.crop_and_resize_batch_for_model(batch, cfg)
+    flow_batch = cropping.crop_and_resize_batch_for_flow(batch, cfg)
+    assert tuple(pre_crop) == tuple(int(x) for x in g[f"{tag}_pre_crop"])
+    for name, got in (("model", model_batch), ("flow", flow_batch)):
+        want = g[f"{tag}_{name}_videos"]
+        assert got.videos.shape == want.shape and got.videos.is_contiguous()
+        assert_close(got.videos, want, 2e-6, what=f"{name}_videos")
+        assert_close(got.intrinsics, g[f"{tag}_{name}_intrinsics"], 1e-6, what=f"{name}_intrinsics")
+    assert torch.equal(batch.intrinsics, k) and batch.videos is videos  # inputs untouched
+    # the unfused pieces agree with the fused pass
+    resized = cropping.resize_batch(batch, tuple(pre_crop))
+    two_step = cropping.patch_crop_batch(resized, patch)
+    assert torch.equal(two_step.videos, model_batch.videos)
+    assert_close(two_step.intrinsics, model_batch.intrinsics, 1e-6, what="two_step_intrinsics")
+    none = cropping.crop_and_resize_batch_for_flow(Batch(videos), cfg)
+    assert none.intrinsics is None and torch.equal(none.videos, flow_batch.videos)
+
+
 def case_export(dev, tmp_path):
     """World-space point cloud (one launch) against the reference's per-frame loop, the PLY
     round trip, and compute_ate."""

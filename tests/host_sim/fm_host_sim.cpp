@@ -303,6 +303,18 @@ int fm_flow_postprocess(const float* videos, const float* flow, int batch, int f
   return 0;
 }
 
+int fm_resize_crop(const float* in, long planes, int h, int w, int rh, int rw, int row0, int col0, int oh, int ow, float* out, void*) {
+  for (long p = 0; p < planes; ++p)
+    for (int y = 0; y < oh; ++y)
+      for (int x = 0; x < ow; ++x) {
+        const ResizeTap ty = resize_tap(y + row0, h, rh), tx = resize_tap(x + col0, w, rw);
+        const float* s = in + (size_t)p * h * w;
+        out[((size_t)p * oh + y) * ow + x] = ty.l0 * (tx.l0 * s[(size_t)ty.i0 * w + tx.i0] + tx.l1 * s[(size_t)ty.i0 * w + tx.i1]) +
+                                            ty.l1 * (tx.l0 * s[(size_t)ty.i1 * w + tx.i0] + tx.l1 * s[(size_t)ty.i1 * w + tx.i1]);
+      }
+  return 0;
+}
+
 int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, long step, double lr, double beta1,
                  double beta2, double eps, double weight_decay, void*) {
   const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);

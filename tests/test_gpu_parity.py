@@ -261,6 +261,11 @@ def test_flow_preprocess(tag):
     cases.case_flow_preprocess(DEV, tag)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_cropping(tag):
+    cases.case_cropping(DEV, tag)
+
+
 def test_export(tmp_path):
     cases.case_export(DEV, tmp_path)
 

@@ -83,6 +83,11 @@ def test_flow_preprocess(tag):
     cases.case_flow_preprocess("cpu", tag)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_cropping(tag):
+    cases.case_cropping("cpu", tag)
+
+
 def test_export(tmp_path):
     cases.case_export("cpu", tmp_path)
 

@@ -207,6 +207,36 @@ def test_reference_flow_predictor_under_install(patched_reference):
     assert_close(again.forward_mask, g["a_forward_mask"], 1e-6, what="unpatched")
 
 
+def test_reference_cropping_under_install(patched_reference):
+    """After install() the reference's cropping module runs the one-pass resize+crop on the
+    reference's own Batch type and reproduces the unpatched outputs (golden); uninstall() restores."""
+    from cases import CROPPING_CASES
+    from conftest import assert_close, load_golden, t
+
+    import flowmap.misc.cropping as ref_cropping
+    from flowmap.dataset.types import Batch
+
+    import flowmap_amd
+
+    g = load_golden("fn_cropping")
+    image_shape, mult, patch = CROPPING_CASES["b"]
+    cfg = ref_cropping.CroppingCfg(image_shape, mult, patch)
+    batch = Batch(t(g["b_videos"]), torch.arange(2)[None], ["s"], ["d"], None, t(g["b_intrinsics"]))
+    assert ref_cropping.crop_and_resize_batch_for_model.__module__ == "flowmap_amd.misc.cropping"
+    model_batch, pre_crop = ref_cropping.crop_and_resize_batch_for_model(batch, cfg)
+    flow_batch = ref_cropping.crop_and_resize_batch_for_flow(batch, cfg)
+    assert isinstance(model_batch, Batch) and model_batch.scenes == ["s"]
+    assert tuple(pre_crop) == tuple(int(x) for x in g["b_pre_crop"])
+    assert_close(model_batch.videos, g["b_model_videos"], 2e-6, what="model videos")
+    assert_close(flow_batch.videos, g["b_flow_videos"], 2e-6, what="flow videos")
+    assert_close(flow_batch.intrinsics, g["b_flow_intrinsics"], 1e-6, what="flow intrinsics")
+
+    flowmap_amd.uninstall()
+    assert ref_cropping.crop_and_resize_batch_for_model.__module__ == "flowmap.misc.cropping"
+    again, _ = ref_cropping.crop_and_resize_batch_for_model(batch, cfg)
+    assert_close(again.videos, g["b_model_videos"], 1e-6, what="unpatched")
+
+
 def test_reference_overfit_loop_under_install_tracks_the_unpatched_loop():
     """The loop body of ModelWrapperOverfit.training_step + Adam (model_wrapper_overfit.py:51-62,
     104-105) for a few steps: the unmodified reference (CPU, torch.optim.Adam) against the same

@@ -200,6 +200,21 @@ def test_flow_preprocess(tag):
         assert_close(val, g[f"{tag}_{name}"], 1e-6, what=name)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_cropping(tag):
+    from cases import CROPPING_CASES
+
+    g = load_golden("fn_cropping")
+    image_shape, mult, patch = CROPPING_CASES[tag]
+    videos, k = t(g[f"{tag}_videos"]), t(g[f"{tag}_intrinsics"])
+    for name, m in (("model", 1), ("flow", mult)):
+        out, k_out, resized = orc.crop_and_resize(videos, k, image_shape, patch, m)
+        assert_close(out, g[f"{tag}_{name}_videos"], 1e-6, what=f"{name}_videos")
+        assert_close(k_out, g[f"{tag}_{name}_intrinsics"], 1e-6, what=f"{name}_intrinsics")
+        if m == 1:
+            assert tuple(resized) == tuple(int(x) for x in g[f"{tag}_pre_crop"])
+
+
 def test_export_point_cloud_and_ate():
     g = load_golden("fn_export")
     pts, cols = orc.world_point_cloud(t(g["depths"]), t(g["intrinsics"]), t(g["extrinsics"]), t(g["colors"]))
