@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--width", type=int, default=5120)
     ap.add_argument("--scale", type=int, default=4)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--crop-frames", type=int, default=24)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     f, h, w = args.frames, args.height, args.width
@@ -73,6 +74,30 @@ def main():
     print(json.dumps({"frames": f, "full_res": [h, w], "flow_shape": list(shape), "ms_fused_hip": ms_ours,
                       "ms_reference_ops_on_gpu": ms_ref, "speedup": ms_ref / ms_ours, "max_abs_diff_vs_torch_gpu_ops": err_gpu,
                       "max_abs_diff_mask_vs_torch_cpu_ops_first_pair": err_cpu}))
+    del raw_f, raw_b, flipped, fa, fb, fl
+
+    # cropping.py: the loaded video (1080p) -> the flow network's input (4x the optimisation's
+    # 720x1280, patch-cropped); reference = resize_batch then center_crop on the same GPU
+    from flowmap_amd import Batch
+    from flowmap_amd.misc import cropping
+
+    cf = args.crop_frames
+    src = smooth((1080 // 64, 1920 // 64), 3)[:, :1080, :1920].clamp(0, 1)
+    src = src[None, None].expand(1, cf, 3, 1080, 1920).contiguous()
+    cfg = cropping.CroppingCfg((h // args.scale, w // args.scale), args.scale, 32)
+
+    def ours_crop():
+        return cropping.crop_and_resize_batch_for_flow(Batch(src), cfg).videos
+
+    def reference_crop():
+        out, _, _ = orc.crop_and_resize(src, None, cfg.image_shape, cfg.patch_size, cfg.flow_scale_multiplier)
+        return out.contiguous()  # the reference's crop is a view; its consumers copy it (Batch.to / the network)
+
+    ms_crop, got = timed(ours_crop)
+    ms_crop_ref, want = timed(reference_crop)
+    print(json.dumps({"what": "crop_and_resize_batch_for_flow", "frames": cf, "source": [1080, 1920], "out": list(got.shape[-2:]),
+                      "ms_fused_hip": ms_crop, "ms_reference_ops_on_gpu": ms_crop_ref, "speedup": ms_crop_ref / ms_crop,
+                      "write_GBps": got.numel() * 4 / ms_crop / 1e6, "max_abs_diff_vs_torch_gpu_ops": float((got - want).abs().max())}))
 
 
 if __name__ == "__main__":
