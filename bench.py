@@ -248,6 +248,7 @@ def main():
         dist.all_reduce(torch.zeros(4, device=device))
     for _ in range(args.warmup):
         step()
+    flowmap_amd.freeze_gc()  # a full cyclic-GC pass over torch's import-time objects costs ~50 ms (flowmap_amd/host.py)
     kernel_events.clear()
     if dist is not None:
         dist.barrier()

@@ -52,6 +52,8 @@ SIGNATURES = {
     "fm_relative_pose_bwd": [P, P, P, I, I, P, P],
     "fm_allpairs_pose_fwd": [P, I, I, P, P],
     "fm_allpairs_pose_bwd": [P, P, I, I, P, P],
+    "fm_focal_intrinsics_fwd": [P, L, L, I, I, P, P, P],
+    "fm_focal_intrinsics_bwd": [P, L, L, I, I, P, P],
     "fm_intrinsics_inverse": [P, I, P, P],
     "fm_intrinsics_inverse_bwd": [P, P, I, P, I, P],
     "fm_unproject_fwd": [P, L, P, P, I, L, P, P],

@@ -51,16 +51,68 @@ _kinv_last = None  # (weakref to K, its version, K⁻¹): the extrinsics fit and
 
 def intrinsics_inverse(k: Tensor) -> Tensor:
     """K⁻¹ for a (..., 3, 3) stack (no autograd; callers chain the backward).  The result for the
-    most recent K tensor object is kept, so the consumers of one step invert it once."""
+    most recent K is kept, so the consumers of one step invert it once.  "The same K" = the same
+    root tensor object (views of it included: they share its version counter), same memory, same
+    version — a recycled allocation belongs to a different root object and misses."""
     global _kinv_last
     k = _f32c(k, "intrinsics")
-    if _kinv_last is not None and _kinv_last[0]() is k and _kinv_last[1] == k._version:
-        return _kinv_last[2]
+    root = k if k._base is None else k._base
+    if (
+        _kinv_last is not None
+        and _kinv_last[0]() is root
+        and _kinv_last[1] == (k._version, k.data_ptr(), k.numel())
+    ):
+        return _kinv_last[2].view(k.shape)
     out = torch.empty_like(k)
     with _guard(k.device):
         call("fm_intrinsics_inverse", ptr(k), k.numel() // 9, ptr(out), stream_for(k))
-    _kinv_last = (weakref.ref(k), k._version, out)
+    _kinv_last = (weakref.ref(root), (k._version, k.data_ptr(), k.numel()), out)
     return out
+
+
+class FocalIntrinsics(torch.autograd.Function):
+    """focal_lengths_to_intrinsics spread over the frames (intrinsics/common.py:6-20 as used by
+    intrinsics_regressed.py:34-41): focal (*lead) -> K (*lead, *repeat_shape, 3, 3) in one launch that
+    also leaves K^-1 behind for the step's consumers; the backward is one reduction."""
+
+    @staticmethod
+    def forward(ctx, focal, repeat_shape, image_shape):
+        check_device(focal)
+        focal = _f32c(focal, "focal lengths")
+        h, w = int(image_shape[0]), int(image_shape[1])
+        repeat = 1
+        for d in repeat_shape:
+            repeat *= int(d)
+        count = focal.numel()
+        k = torch.empty((*focal.shape, *repeat_shape, 3, 3), dtype=torch.float32, device=focal.device)
+        kinv = torch.empty_like(k)
+        with _guard(focal.device):
+            call("fm_focal_intrinsics_fwd", ptr(focal), count, repeat, h, w, ptr(k), ptr(kinv), stream_for(focal))
+        ctx.geometry = (count, repeat, h, w, tuple(focal.shape))
+        ctx.kinv = kinv  # handed to the cache by focal_intrinsics() below, not needed for backward
+        return k
+
+    @staticmethod
+    def backward(ctx, g_k):
+        count, repeat, h, w, shape = ctx.geometry
+        g_k = _f32c(g_k, "grad")
+        g_focal = torch.empty(shape, dtype=torch.float32, device=g_k.device)
+        with _guard(g_k.device):
+            call("fm_focal_intrinsics_bwd", ptr(g_k), count, repeat, h, w, ptr(g_focal), stream_for(g_k))
+        return g_focal, None, None
+
+
+def focal_intrinsics(focal: Tensor, repeat_shape, image_shape) -> Tensor:
+    """K (*focal.shape, *repeat_shape, 3, 3) from normalised focal lengths; K^-1 is computed in the
+    same launch and parked where intrinsics_inverse() finds it."""
+    global _kinv_last
+    k = FocalIntrinsics.apply(focal, tuple(repeat_shape), tuple(image_shape))
+    node = k.grad_fn
+    kinv = getattr(node, "kinv", None) if node is not None else None
+    if kinv is not None:
+        node.kinv = None
+        _kinv_last = (weakref.ref(k), (k._version, k.data_ptr(), k.numel()), kinv)
+    return k
 
 
 # --------------------------------------------------------------------------------------

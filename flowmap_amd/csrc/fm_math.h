@@ -866,6 +866,21 @@ FM_HD void inv3(const float* k, float* o) {
   o[8] = (float)((a * e - b * d) * inv_det);
 }
 
+// focal_lengths_to_intrinsics (flowmap/model/intrinsics/common.py:6-20): normalised K of one
+// focal length — the reference's two roundings (f·√(hw) in fp32, then a true division).
+FM_HD void focal_to_k(float focal, int height, int width, float* k) {
+#pragma clang fp contract(off)
+  const float scaled = focal * (float)sqrt((double)height * (double)width);
+  k[0] = scaled / (float)width, k[1] = 0.f, k[2] = 0.5f;
+  k[3] = 0.f, k[4] = scaled / (float)height, k[5] = 0.5f;
+  k[6] = 0.f, k[7] = 0.f, k[8] = 1.f;
+}
+
+// ... and the part of its backward that one K contributes: d/d focal of (gK00·fx + gK11·fy).
+FM_HD double focal_grad_term(const float* g_k, int height, int width) {
+  return (double)g_k[0] / (double)width + (double)g_k[4] / (double)height;
+}
+
 // General 4x4 inverse in double (Tensor.inverse() on poses, projection.py:46,154,176,288).
 // Returns false when singular.
 FM_HD bool inv4(const double* m, double* o) {

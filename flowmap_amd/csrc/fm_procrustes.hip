@@ -750,6 +750,34 @@ __global__ void allpairs_pose_bwd_kernel(const float* ext, const float* g_rel, i
 
 // K⁻¹ for every frame, and the map of a K⁻¹ gradient (fp64 accumulators) back to K:
 //   dK += −K⁻ᵀ · dKinv · K⁻ᵀ
+// IntrinsicsRegressed.forward (intrinsics_regressed.py:34-41): each focal length spread over
+// `repeat` frames as K and K^-1 (the inverse every consumer of the step asks for).
+__global__ void focal_intrinsics_fwd_kernel(const float* focal, long count, long repeat, int height, int width, float* k, float* kinv) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count * repeat) return;
+  float m[9], inv[9];
+  focal_to_k(focal[j / repeat], height, width, m);
+  inv3(m, inv);
+#pragma unroll
+  for (int e = 0; e < 9; ++e) k[j * 9 + e] = m[e];
+  if (kinv) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) kinv[j * 9 + e] = inv[e];
+  }
+}
+
+// one block per focal length: dL/df = sqrt(hw) * sum over its frames of (gK00/w + gK11/h)
+__global__ void __launch_bounds__(256) focal_intrinsics_bwd_kernel(const float* g_k, long repeat, int height, int width, float* g_focal) {
+  __shared__ double red[4];
+  const long i = blockIdx.x;
+  double acc = 0.0;
+  for (long r = threadIdx.x; r < repeat; r += blockDim.x) acc += focal_grad_term(g_k + (i * repeat + r) * 9, height, width);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) g_focal[i] = (float)((red[0] + red[1] + red[2] + red[3]) * (double)(float)sqrt((double)height * (double)width));
+}
+
 __global__ void inv3_kernel(const float* k, int count, float* kinv) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) inv3(k + (size_t)i * 9, kinv + (size_t)i * 9);
@@ -906,6 +934,21 @@ int fm_allpairs_pose_bwd(const float* ext, const float* g_rel, int batch, int fr
   FM_CHECK_ARG(ext && g_rel && g_ext && batch >= 1 && frames >= 1);
   const int n = batch * frames;
   hipLaunchKernelGGL(allpairs_pose_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, ext, g_rel, batch, frames, g_ext);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_focal_intrinsics_fwd(const float* focal, long count, long repeat, int height, int width, float* k, float* kinv, void* stream) {
+  FM_CHECK_ARG(focal && k && count >= 1 && repeat >= 1 && height >= 1 && width >= 1);
+  const long n = count * repeat;
+  hipLaunchKernelGGL(focal_intrinsics_fwd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, focal, count, repeat,
+                     height, width, k, kinv);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_focal_intrinsics_bwd(const float* grad_k, long count, long repeat, int height, int width, float* grad_focal, void* stream) {
+  FM_CHECK_ARG(grad_k && grad_focal && count >= 1 && count <= 0x7fffffffL && repeat >= 1 && height >= 1 && width >= 1);
+  hipLaunchKernelGGL(focal_intrinsics_bwd_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, grad_k, repeat, height, width,
+                     grad_focal);
   FM_LAUNCH_STATUS();
 }
 

@@ -44,7 +44,7 @@ _CROPPING_SITES = ("flowmap.overfit", "flowmap.model.model_wrapper_pretrain")
 
 
 def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postprocess: bool = True, fused_adam: bool = True,
-            cropping: bool = True) -> None:
+            cropping: bool = True, fused_regressed: bool = True) -> None:
     """Patch the reference in place.  ``lazy_surfaces=True`` additionally lets
     ``Model.forward``'s ``unproject`` hand a LazySurfaces to the fused consumers;
     ``fused_softmin=True`` registers the fused candidate sweep as INTRINSICS["softmin"]
@@ -55,7 +55,9 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
     ``ModelWrapperOverfit.configure_optimizers`` (model_wrapper_overfit.py:104-105) build
     ``flowmap_amd.FusedAdam`` (skipped when lightning is not importable); ``cropping=True`` rebinds
     ``resize_batch`` / ``crop_and_resize_batch_for_model`` / ``_for_flow`` (flowmap/misc/cropping.py)
-    to the one-pass resize+crop, which uploads a host batch once and prepares both videos in HBM."""
+    to the one-pass resize+crop, which uploads a host batch once and prepares both videos in HBM;
+    ``fused_regressed=True`` registers INTRINSICS["regressed"] = ``flowmap_amd``'s IntrinsicsRegressed
+    (same cfg and parameter name; K and K⁻¹ for all frames from one launch, one-launch backward)."""
     from . import loss as our_loss
     from .loss import mapping as our_mapping
     from .model import procrustes as our_procrustes
@@ -104,6 +106,12 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
 
         ref_intr = importlib.import_module("flowmap.model.intrinsics")
         _set(ref_intr, "INTRINSICS", {**ref_intr.INTRINSICS, "softmin": IntrinsicsSoftmin})
+
+    if fused_regressed:
+        from .model.model import IntrinsicsRegressed
+
+        ref_intr = importlib.import_module("flowmap.model.intrinsics")
+        _set(ref_intr, "INTRINSICS", {**ref_intr.INTRINSICS, "regressed": IntrinsicsRegressed})
 
     if flow_postprocess:
         from . import _ops

@@ -55,6 +55,7 @@ class IntrinsicsSoftmin(nn.Module):
         self.cfg = cfg
         candidates = torch.linspace(cfg.min_focal_length, cfg.max_focal_length, cfg.num_candidates)
         self.register_buffer("focal_length_candidates", candidates, persistent=False)
+        self._candidate_cache = None
         if cfg.regression is not None:
             self.intrinsics_regressed = IntrinsicsRegressed(IntrinsicsRegressedCfg("regressed", 0.0))
             self.window = []
@@ -66,6 +67,18 @@ class IntrinsicsSoftmin(nn.Module):
     # override this hook to feed identical indices to both implementations.
     def _draw_indices(self, count: int, device) -> Tensor:
         return _ops.random_subset(count, self.cfg.num_procrustes_points, device)
+
+    def _candidate_intrinsics(self, b: int, image_shape):
+        """K of every candidate and its (b*n, 2, 3, 3) spread over the frame pair the sweep fits.
+        The candidates are a constant buffer: built once per (shape, device), not once per step."""
+        c = self.focal_length_candidates
+        key = (b, tuple(image_shape), str(c.device), c.data_ptr(), c._version)
+        if self._candidate_cache is None or self._candidate_cache[0] != key:
+            n = c.numel()
+            candidate_k = focal_lengths_to_intrinsics(c, image_shape)  # (n,3,3)
+            k_pair = candidate_k[None, :, None].expand(b, n, 2, 3, 3).reshape(b * n, 2, 3, 3)
+            self._candidate_cache = (key, candidate_k, k_pair)
+        return self._candidate_cache[1], self._candidate_cache[2]
 
     def forward(self, batch, flows, backbone_output, global_step: int) -> Tensor:
         b, f, _, h, w = batch.videos.shape
@@ -79,7 +92,7 @@ class IntrinsicsSoftmin(nn.Module):
                 self.intrinsics_regressed.focal_length.data = torch.stack(self.window).mean()
             return self.intrinsics_regressed(batch, flows, backbone_output, global_step)
 
-        candidate_k = focal_lengths_to_intrinsics(self.focal_length_candidates, (h, w))  # (n,3,3)
+        candidate_k, k_pair = self._candidate_intrinsics(b, (h, w))  # (n,3,3), (b*n,2,3,3)
         idx = self._draw_indices(h * w, device)
         bwd_01 = flows.backward[:, :1].contiguous()  # (b,1,h,w,2): the only pair the sweep looks at
 
@@ -91,7 +104,6 @@ class IntrinsicsSoftmin(nn.Module):
             weights_01, sens = _ops.LeadingFrames.apply(weights.logits, 1), weights.sensitivity
         else:
             weights_01 = _ops.LeadingFrames.apply(weights, 1)
-        k_pair = candidate_k[None, :, None].expand(b, n, 2, 3, 3).reshape(b * n, 2, 3, 3)
         rel, _ = _ops.ProcrustesFit.apply(depths, k_pair, None, weights_01, bwd_01, idx, sens, n)  # (b*n,1,4,4): frame 1 -> frame 0
 
         # ---- pose-induced backward flow error per candidate (intrinsics_softmin.py:105-121): one
@@ -107,7 +119,9 @@ class IntrinsicsSoftmin(nn.Module):
         if reg is not None and global_step >= reg.after_step - reg.window and self.training:
             self.window.append((self.focal_length_candidates * soft).sum().detach())
 
-        return intrinsics[:, None].expand(b, f, 3, 3)
+        # the reference returns the expanded view; materialised once here, every consumer of the
+        # step (Procrustes fit, fused losses) reads the same (b,f,3,3) tensor and shares its inverse
+        return intrinsics[:, None].expand(b, f, 3, 3).contiguous()
 
     def unnormalized_focal_lengths(self, image_shape) -> Tensor:
         """intrinsics_softmin.py:143-156"""

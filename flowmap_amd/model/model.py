@@ -15,6 +15,7 @@ from typing import Literal, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
+from .. import _ops
 from ..types import BackboneOutput, ModelOutput
 from .extrinsics_procrustes import ExtrinsicsProcrustes, ExtrinsicsProcrustesCfg
 from .projection import LazyWeights, lazy_surfaces_enabled, sample_image_grid, unproject
@@ -92,10 +93,9 @@ class IntrinsicsRegressed(nn.Module):
 
     def forward(self, batch, flows, backbone_output, global_step: int) -> Tensor:
         b, f, _, h, w = batch.videos.shape
-        intrinsics = focal_lengths_to_intrinsics(self.focal_length, (h, w))
-        # the reference returns the expanded view; every consumer here wants (b,f,3,3) in memory,
-        # so materialise it once instead of once per consumer
-        return intrinsics.expand(b, f, 3, 3).contiguous()
+        # the reference returns focal_lengths_to_intrinsics(...) as an expanded view; every consumer
+        # here wants (b,f,3,3) in memory (and its inverse), so one launch writes both
+        return _ops.focal_intrinsics(self.focal_length, (b, f), (h, w))
 
 
 @dataclass

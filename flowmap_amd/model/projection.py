@@ -261,6 +261,25 @@ def _unproject_dense(coordinates: Tensor, z: Tensor, intrinsics: Tensor) -> Tens
     return _ops.Unproject.apply(xy, zz, k).reshape(*out_shape, 3)
 
 
+def _squeeze_intrinsics(intrinsics: Tensor) -> Tensor:
+    """(b,f,1,1,3,3) -> (b,f,3,3) without leaving work for autograd: the caller's own tensor when
+    the argument is ``K[:, :, None, None]`` of a contiguous (b,f,3,3) K (model/model.py:69-74 —
+    gradients then reach K directly and every consumer of the step sees ONE tensor object),
+    otherwise a reshape (a view; indexing ``[:, :, 0, 0]`` would cost two select_backward
+    zero-fill + copy launches per step)."""
+    b, f = intrinsics.shape[:2]
+    base = intrinsics._base
+    if (
+        base is not None
+        and tuple(base.shape) == (b, f, 3, 3)
+        and base.is_contiguous()
+        and base.data_ptr() == intrinsics.data_ptr()
+        and base.requires_grad == intrinsics.requires_grad
+    ):
+        return base
+    return intrinsics.reshape(b, f, 3, 3)
+
+
 def unproject(coordinates: Tensor, z: Tensor, intrinsics: Tensor):
     """flowmap/model/projection.py:76-90: (K⁻¹·[x,y,1])·z."""
     if (
@@ -272,7 +291,7 @@ def unproject(coordinates: Tensor, z: Tensor, intrinsics: Tensor):
         and coordinates is sample_image_grid(tuple(z.shape[2:]), z.device)[0]
     ):
         check_device(z, intrinsics)
-        return LazySurfaces(z, intrinsics[:, :, 0, 0])
+        return LazySurfaces(z, _squeeze_intrinsics(intrinsics))
     return _unproject_dense(coordinates, z, intrinsics)
 
 

@@ -148,6 +148,14 @@ int fm_relative_pose_bwd(const float* ext, const float* g_fwd, const float* g_bw
 int fm_allpairs_pose_fwd(const float* ext, int batch, int frames, float* rel, void* stream);
 int fm_allpairs_pose_bwd(const float* ext, const float* g_rel, int batch, int frames, float* g_ext, void* stream);
 
+/* focal_lengths_to_intrinsics (flowmap/model/intrinsics/common.py:6-20) as IntrinsicsRegressed.forward
+ * uses it (flowmap/model/intrinsics/intrinsics_regressed.py:34-41): focal (count) -> k (count*repeat, 3, 3),
+ * each focal length repeated over `repeat` consecutive frames, fx = f*sqrt(hw)/w, fy = f*sqrt(hw)/h,
+ * cx = cy = 0.5; kinv (optional, same shape) receives K^-1 as fm_intrinsics_inverse computes it. */
+int fm_focal_intrinsics_fwd(const float* focal, long count, long repeat, int height, int width, float* k, float* kinv, void* stream);
+/* Its backward: grad_focal[i] = sqrt(hw) * sum over the i-th `repeat` frames of (grad_k[0][0]/w + grad_k[1][1]/h). */
+int fm_focal_intrinsics_bwd(const float* grad_k, long count, long repeat, int height, int width, float* grad_focal, void* stream);
+
 /* intrinsics.inverse() of unproject (projection.py:86) for `count` 3×3 matrices, and
  * g_k (+)= −K⁻ᵀ·kinv_acc·K⁻ᵀ. */
 int fm_intrinsics_inverse(const float* k, int count, float* kinv, void* stream);

@@ -416,6 +416,45 @@ def case_flow_preprocess(dev, tag):
                  what="rescale_mask")
 
 
+def case_focal_intrinsics(dev):
+    """IntrinsicsRegressed's K in one launch: bit-identical to focal_lengths_to_intrinsics
+    (the reference's two roundings) spread over the frames, K^-1 left for the step's consumers,
+    and the gradient of autograd through the reference formulation."""
+    from flowmap_amd import _ops
+    from flowmap_amd.model.model import focal_lengths_to_intrinsics
+
+    for (h, w), lead, rep in (((720, 1280), (), (1, 150)), ((37, 53), (3,), (4,)), ((256, 256), (2, 2), (1, 3))):
+        g = torch.Generator().manual_seed(h)
+        focal = (0.5 + torch.rand(lead, generator=g)).to(dev).requires_grad_(True)
+        k = _ops.focal_intrinsics(focal, rep, (h, w))
+        ref_focal = focal.detach().clone().requires_grad_(True)
+        want = focal_lengths_to_intrinsics(ref_focal, (h, w))
+        want = want.reshape(*lead, *([1] * len(rep)), 3, 3).expand(*lead, *rep, 3, 3)
+        assert k.shape == want.shape and k.is_contiguous()
+        assert torch.equal(k, want)
+        calls = dict(_ops.counters)
+        kinv = _ops.intrinsics_inverse(k)  # parked by the same launch
+        assert float((kinv.cpu().double() - torch.linalg.inv(k.detach().double().cpu())).abs().max()) < 1e-6
+        fresh = torch.empty_like(kinv)
+        from flowmap_amd._lib import call, ptr, stream_for
+        call("fm_intrinsics_inverse", ptr(k.detach()), k.numel() // 9, ptr(fresh), stream_for(k))
+        assert torch.equal(kinv, fresh)
+        cot = torch.randn(k.shape, generator=g).to(dev)
+        (k * cot).sum().backward()
+        (want * cot).sum().backward()
+        assert_close(focal.grad, ref_focal.grad, 2e-6, what="g_focal")
+        assert calls == dict(_ops.counters)
+    # a different K object at the same address is not served the parked inverse
+    focal = torch.tensor(0.9, device=dev, requires_grad=True)
+    k1 = _ops.focal_intrinsics(focal, (1, 4), (48, 64))
+    inv1 = _ops.intrinsics_inverse(k1).clone()
+    other = k1.detach().clone()
+    other[..., 0, 0] *= 2
+    assert not torch.equal(_ops.intrinsics_inverse(other), inv1)
+    view = k1[:, :, None, None]
+    assert _ops.intrinsics_inverse(view.reshape(1, 4, 3, 3)).data_ptr() == _ops.intrinsics_inverse(k1).data_ptr()
+
+
 CROPPING_CASES = {  # oracle/make_golden.py: tag -> (image_shape, flow_scale_multiplier, patch_size)
     "a": ((18, 26), 4, 8),
     "b": (400, 2, 4),

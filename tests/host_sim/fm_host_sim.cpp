@@ -526,6 +526,23 @@ int fm_allpairs_pose_bwd(const float* ext, const float* g_rel, int batch, int f,
   return 0;
 }
 
+int fm_focal_intrinsics_fwd(const float* focal, long count, long repeat, int height, int width, float* k, float* kinv, void*) {
+  for (long j = 0; j < count * repeat; ++j) {
+    focal_to_k(focal[j / repeat], height, width, k + j * 9);
+    if (kinv) inv3(k + j * 9, kinv + j * 9);
+  }
+  return 0;
+}
+
+int fm_focal_intrinsics_bwd(const float* grad_k, long count, long repeat, int height, int width, float* grad_focal, void*) {
+  for (long i = 0; i < count; ++i) {
+    double acc = 0.0;
+    for (long r = 0; r < repeat; ++r) acc += focal_grad_term(grad_k + (i * repeat + r) * 9, height, width);
+    grad_focal[i] = (float)(acc * (double)(float)sqrt((double)height * (double)width));
+  }
+  return 0;
+}
+
 int fm_intrinsics_inverse(const float* k, int count, float* kinv, void*) {
   for (int i = 0; i < count; ++i) inv3(k + (size_t)i * 9, kinv + (size_t)i * 9);
   return 0;

@@ -266,6 +266,10 @@ def test_cropping(tag):
     cases.case_cropping(DEV, tag)
 
 
+def test_focal_intrinsics():
+    cases.case_focal_intrinsics(DEV)
+
+
 def test_export(tmp_path):
     cases.case_export(DEV, tmp_path)
 

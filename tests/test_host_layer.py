@@ -165,3 +165,16 @@ def test_emitted_registry_keeps_the_newest_entries():
         assert ("key", i) in _ops._emitted and (i == 0 or ("key", i - 1) in _ops._emitted)
     assert len(_ops._emitted) <= 16 and ("key", 0) not in _ops._emitted
     _ops._emitted.clear()
+
+
+def test_freeze_gc_moves_live_objects_to_the_permanent_generation():
+    import gc
+
+    import flowmap_amd
+
+    try:
+        frozen = flowmap_amd.freeze_gc()
+        assert frozen > 1000 and gc.get_freeze_count() == frozen
+    finally:
+        gc.unfreeze()
+    assert gc.get_freeze_count() == 0

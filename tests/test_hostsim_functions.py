@@ -88,6 +88,10 @@ def test_cropping(tag):
     cases.case_cropping("cpu", tag)
 
 
+def test_focal_intrinsics():
+    cases.case_focal_intrinsics("cpu")
+
+
 def test_export(tmp_path):
     cases.case_export("cpu", tmp_path)
 

@@ -207,6 +207,34 @@ def test_reference_flow_predictor_under_install(patched_reference):
     assert_close(again.forward_mask, g["a_forward_mask"], 1e-6, what="unpatched")
 
 
+def test_reference_regressed_intrinsics_under_install(patched_reference):
+    """install() registers the one-launch IntrinsicsRegressed: same parameter name, K bit-identical
+    to the reference class, same focal-length gradient; uninstall() restores the registry."""
+    from conftest import assert_close
+
+    import flowmap.model.intrinsics as ref_intr
+    from flowmap.dataset.types import Batch
+    from flowmap.model.intrinsics.intrinsics_regressed import IntrinsicsRegressed as RefRegressed
+    from flowmap.model.intrinsics.intrinsics_regressed import IntrinsicsRegressedCfg
+
+    import flowmap_amd
+
+    cfg = IntrinsicsRegressedCfg("regressed", 0.85)
+    ours = ref_intr.get_intrinsics(cfg)
+    assert type(ours).__module__.startswith("flowmap_amd")
+    theirs = RefRegressed(cfg)
+    assert list(ours.state_dict()) == list(theirs.state_dict()) == ["focal_length"]
+    batch = Batch(torch.zeros((2, 5, 3, 30, 44)), None, None, None)
+    k_ours, k_theirs = ours(batch, None, None, 0), theirs(batch, None, None, 0)
+    assert k_ours.shape == k_theirs.shape and torch.equal(k_ours, k_theirs)
+    cot = torch.randn(k_ours.shape, generator=torch.Generator().manual_seed(0))
+    (k_ours * cot).sum().backward()
+    (k_theirs * cot).sum().backward()
+    assert_close(ours.focal_length.grad, theirs.focal_length.grad, 2e-6, what="g_focal")
+    flowmap_amd.uninstall()
+    assert ref_intr.INTRINSICS["regressed"] is RefRegressed
+
+
 def test_reference_cropping_under_install(patched_reference):
     """After install() the reference's cropping module runs the one-pass resize+crop on the
     reference's own Batch type and reproduces the unpatched outputs (golden); uninstall() restores."""
