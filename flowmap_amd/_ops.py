@@ -46,27 +46,39 @@ class _guard:
             self.ctx.__exit__(*exc)
 
 
-_kinv_last = None  # (weakref to K, its version, K⁻¹): the extrinsics fit and the flow loss of a step share one K
+# K⁻¹ of the few K tensors alive in a step (the model's K shared by the extrinsics fit and the fused
+# losses; the softmin sweep's constant candidate sets): id(root K) -> (weakref, key, K⁻¹)
+_kinv_cache: dict = {}
+_KINV_CACHE_SLOTS = 4
+
+
+def _kinv_key(k: Tensor):
+    return (k._version, k.data_ptr(), k.numel())
+
+
+def _kinv_store(root: Tensor, key, kinv: Tensor) -> None:
+    for ident in [i for i, entry in _kinv_cache.items() if entry[0]() is None]:  # their K died
+        del _kinv_cache[ident]
+    while len(_kinv_cache) >= _KINV_CACHE_SLOTS:
+        del _kinv_cache[next(iter(_kinv_cache))]  # oldest first
+    _kinv_cache[id(root)] = (weakref.ref(root), key, kinv)
 
 
 def intrinsics_inverse(k: Tensor) -> Tensor:
-    """K⁻¹ for a (..., 3, 3) stack (no autograd; callers chain the backward).  The result for the
-    most recent K is kept, so the consumers of one step invert it once.  "The same K" = the same
-    root tensor object (views of it included: they share its version counter), same memory, same
-    version — a recycled allocation belongs to a different root object and misses."""
-    global _kinv_last
+    """K⁻¹ for a (..., 3, 3) stack (no autograd; callers chain the backward).  Results are kept for
+    the last few K tensors, so the consumers of one step invert each K once and constant K sets are
+    inverted once per run.  "The same K" = the same root tensor object (views of it included: they
+    share its version counter), same memory, same version — a recycled allocation belongs to a
+    different root object and misses."""
     k = _f32c(k, "intrinsics")
     root = k if k._base is None else k._base
-    if (
-        _kinv_last is not None
-        and _kinv_last[0]() is root
-        and _kinv_last[1] == (k._version, k.data_ptr(), k.numel())
-    ):
-        return _kinv_last[2].view(k.shape)
+    entry = _kinv_cache.get(id(root))
+    if entry is not None and entry[0]() is root and entry[1] == _kinv_key(k):
+        return entry[2].view(k.shape)
     out = torch.empty_like(k)
     with _guard(k.device):
         call("fm_intrinsics_inverse", ptr(k), k.numel() // 9, ptr(out), stream_for(k))
-    _kinv_last = (weakref.ref(root), (k._version, k.data_ptr(), k.numel()), out)
+    _kinv_store(root, _kinv_key(k), out)
     return out
 
 
@@ -105,13 +117,8 @@ class FocalIntrinsics(torch.autograd.Function):
 def focal_intrinsics(focal: Tensor, repeat_shape, image_shape) -> Tensor:
     """K (*focal.shape, *repeat_shape, 3, 3) from normalised focal lengths; K^-1 is computed in the
     same launch and parked where intrinsics_inverse() finds it."""
-    global _kinv_last
     k = FocalIntrinsics.apply(focal, tuple(repeat_shape), tuple(image_shape))
-    node = k.grad_fn
-    kinv = getattr(node, "kinv", None) if node is not None else None
-    if kinv is not None:
-        node.kinv = None
-        _kinv_last = (weakref.ref(k), (k._version, k.data_ptr(), k.numel()), kinv)
+    _park_inverse(k)
     return k
 
 
@@ -565,41 +572,106 @@ class SoftminScore(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, depth, weights, bwd_flow, indices, k, rel, weight_sens):
-        dev = check_device(depth, weights, bwd_flow, indices, k, rel)
-        depth, weights, bwd_flow = _f32c(depth, "depth"), _f32c(weights, "weights"), _f32c(bwd_flow, "backward flow")
-        k, rel = _f32c(k, "intrinsics"), _f32c(rel, "poses")
-        b, two, h, w = depth.shape
-        n = k.shape[0]
-        if two != 2 or tuple(weights.shape) != (b, 1, h, w) or tuple(bwd_flow.shape) != (b, 1, h, w, 2):
-            raise RuntimeError("flowmap_amd: SoftminScore expects depth (b,2,h,w), weights (b,1,h,w), backward flow (b,1,h,w,2)")
-        if tuple(k.shape) != (n, 3, 3) or tuple(rel.shape) != (b * n, 4, 4) or indices.dtype != torch.int64:
-            raise RuntimeError("flowmap_amd: SoftminScore expects intrinsics (n,3,3), poses (b*n,4,4), int64 indices")
-        if k.requires_grad or bwd_flow.requires_grad:
-            raise RuntimeError("flowmap_amd: the softmin candidates and the optical flow are constants")
-        indices = indices.contiguous()
-        kinv = intrinsics_inverse(k)
-        err = torch.empty((b * n,), dtype=torch.float64, device=dev)
-        with _guard(dev):
-            call("fm_softmin_score_fwd", ptr(depth), ptr(weights), float(weight_sens), ptr(bwd_flow), ptr(indices), indices.numel(),
-                 ptr(k), ptr(kinv), ptr(rel), b, n, h, w, ptr(err), stream_for(depth))
-        ctx.save_for_backward(depth, weights, bwd_flow, indices, k, kinv, rel)
+        saved, err = _softmin_score_forward(depth, weights, bwd_flow, indices, k, rel, weight_sens)
+        ctx.save_for_backward(*saved)
         ctx.sens = float(weight_sens)
-        return err.to(torch.float32).reshape(b, n)
+        return err.to(torch.float32).reshape(saved[0].shape[0], saved[4].shape[0])
 
     @staticmethod
     def backward(ctx, g_err):
-        depth, weights, bwd_flow, indices, k, kinv, rel = ctx.saved_tensors
-        b, _, h, w = depth.shape
-        n = k.shape[0]
-        g_err = _f32c(g_err, "grad").reshape(b * n)
-        g_depth = torch.zeros_like(depth) if ctx.needs_input_grad[0] else None
-        g_weights = torch.zeros_like(weights) if ctx.needs_input_grad[1] else None
-        acc = torch.empty((b * n, 12), dtype=torch.float64, device=depth.device)
-        g_rel = torch.empty_like(rel)
-        with _guard(depth.device):
-            call("fm_softmin_score_bwd", ptr(depth), ptr(weights), ctx.sens, ptr(bwd_flow), ptr(indices), indices.numel(), ptr(k),
-                 ptr(kinv), ptr(rel), b, n, h, w, ptr(g_err), ptr(g_depth), ptr(g_weights), ptr(acc), ptr(g_rel), stream_for(depth))
-        return g_depth, g_weights, None, None, None, g_rel if ctx.needs_input_grad[5] else None, None
+        g_depth, g_weights, g_rel = _softmin_score_backward(ctx.saved_tensors, ctx.sens, _f32c(g_err, "grad"), ctx.needs_input_grad)
+        return g_depth, g_weights, None, None, None, g_rel, None
+
+
+def _softmin_score_forward(depth, weights, bwd_flow, indices, k, rel, weight_sens):
+    """Checks + launch shared by SoftminScore and SoftminIntrinsics -> (tensors to save, err fp64 (b*n))."""
+    dev = check_device(depth, weights, bwd_flow, indices, k, rel)
+    depth, weights, bwd_flow = _f32c(depth, "depth"), _f32c(weights, "weights"), _f32c(bwd_flow, "backward flow")
+    k, rel = _f32c(k, "intrinsics"), _f32c(rel, "poses")
+    b, two, h, w = depth.shape
+    n = k.shape[0]
+    if two != 2 or tuple(weights.shape) != (b, 1, h, w) or tuple(bwd_flow.shape) != (b, 1, h, w, 2):
+        raise RuntimeError("flowmap_amd: SoftminScore expects depth (b,2,h,w), weights (b,1,h,w), backward flow (b,1,h,w,2)")
+    if tuple(k.shape) != (n, 3, 3) or tuple(rel.shape) != (b * n, 4, 4) or indices.dtype != torch.int64:
+        raise RuntimeError("flowmap_amd: SoftminScore expects intrinsics (n,3,3), poses (b*n,4,4), int64 indices")
+    if k.requires_grad or bwd_flow.requires_grad:
+        raise RuntimeError("flowmap_amd: the softmin candidates and the optical flow are constants")
+    indices = indices.contiguous()
+    kinv = intrinsics_inverse(k)
+    err = torch.empty((b * n,), dtype=torch.float64, device=dev)
+    with _guard(dev):
+        call("fm_softmin_score_fwd", ptr(depth), ptr(weights), float(weight_sens), ptr(bwd_flow), ptr(indices), indices.numel(),
+             ptr(k), ptr(kinv), ptr(rel), b, n, h, w, ptr(err), stream_for(depth))
+    return (depth, weights, bwd_flow, indices, k, kinv, rel), err
+
+
+def _softmin_score_backward(saved, sens, g_err, needs):
+    """g_err (b*n) fp32 -> (g_depth, g_weights, g_rel); ``needs`` indexes like SoftminScore's inputs."""
+    depth, weights, bwd_flow, indices, k, kinv, rel = saved
+    b, _, h, w = depth.shape
+    n = k.shape[0]
+    g_err = g_err.reshape(b * n)
+    g_depth = torch.zeros_like(depth) if needs[0] else None
+    g_weights = torch.zeros_like(weights) if needs[1] else None
+    acc = torch.empty((b * n, 12), dtype=torch.float64, device=depth.device)
+    g_rel = torch.empty_like(rel)
+    with _guard(depth.device):
+        call("fm_softmin_score_bwd", ptr(depth), ptr(weights), sens, ptr(bwd_flow), ptr(indices), indices.numel(), ptr(k),
+             ptr(kinv), ptr(rel), b, n, h, w, ptr(g_err), ptr(g_depth), ptr(g_weights), ptr(acc), ptr(g_rel), stream_for(depth))
+    return g_depth, g_weights, g_rel if needs[5] else None
+
+
+class SoftminIntrinsics(torch.autograd.Function):
+    """SoftminScore followed by the tail of IntrinsicsSoftmin.forward (intrinsics_softmin.py:105-141)
+    as three launches forward, three backward: the candidates' flow errors stay in their fp64
+    accumulator, one wave per batch entry turns them into the softmin weights, the blended K for every
+    frame and its inverse.  -> (K (B,frames,3,3), soft (B,N) [not differentiable: the window's input])."""
+
+    @staticmethod
+    def forward(ctx, depth, weights, bwd_flow, indices, k, rel, weight_sens, frames):
+        saved, err = _softmin_score_forward(depth, weights, bwd_flow, indices, k, rel, weight_sens)
+        b, n, frames = saved[0].shape[0], saved[4].shape[0], int(frames)
+        dev = err.device
+        soft = torch.empty((b, n), dtype=torch.float32, device=dev)
+        out = torch.empty((b, frames, 3, 3), dtype=torch.float32, device=dev)
+        kinv_out = torch.empty_like(out)
+        with _guard(dev):
+            call("fm_softmin_blend_fwd", ptr(err), ptr(saved[4]), b, n, frames, ptr(soft), ptr(out), ptr(kinv_out), stream_for(out))
+        ctx.save_for_backward(*saved, soft)
+        ctx.sens, ctx.frames = float(weight_sens), frames
+        ctx.kinv = kinv_out  # handed to the K^-1 cache by softmin_intrinsics()
+        ctx.mark_non_differentiable(soft)
+        ctx.set_materialize_grads(False)  # no zeros tensor for soft's (absent) gradient
+        return out, soft
+
+    @staticmethod
+    def backward(ctx, g_k, _g_soft):
+        if g_k is None:
+            return (None,) * 8
+        *saved, soft = ctx.saved_tensors
+        b, n = soft.shape
+        g_k = _f32c(g_k, "grad")
+        g_err = torch.empty((b * n,), dtype=torch.float32, device=g_k.device)
+        with _guard(g_k.device):
+            call("fm_softmin_blend_bwd", ptr(g_k), ptr(soft), ptr(saved[4]), b, n, ctx.frames, ptr(g_err), stream_for(g_k))
+        g_depth, g_weights, g_rel = _softmin_score_backward(saved, ctx.sens, g_err, ctx.needs_input_grad)
+        return g_depth, g_weights, None, None, None, g_rel, None, None
+
+
+def _park_inverse(k: Tensor) -> None:
+    """Move the K^-1 a fused producer computed alongside ``k`` into intrinsics_inverse()'s cache."""
+    node = k.grad_fn
+    kinv = getattr(node, "kinv", None) if node is not None else None
+    if kinv is not None:
+        node.kinv = None
+        _kinv_store(k, _kinv_key(k), kinv)
+
+
+def softmin_intrinsics(depth, weights, bwd_flow, indices, candidate_k, rel, weight_sens, frames):
+    """-> (K (b,frames,3,3) blended over the candidates, softmin weights (b,n))."""
+    k, soft = SoftminIntrinsics.apply(depth, weights, bwd_flow, indices, candidate_k, rel, weight_sens, frames)
+    _park_inverse(k)
+    return k, soft
 
 
 # hipGraph capture (flowmap_amd.graph.GraphedStep): a captured launch cannot carry a host value that

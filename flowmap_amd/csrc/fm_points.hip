@@ -412,6 +412,75 @@ __global__ void softmin_rel_grad_kernel(const double* acc, int count, float* g_r
   for (int e = 12; e < 16; ++e) g_rel[(size_t)i * 16 + e] = 0.f;
 }
 
+// The tail of IntrinsicsSoftmin.forward (intrinsics_softmin.py:123-141), one wave per batch entry:
+//   soft = softmin((err − min err)·10) over the candidates   (fp32, like the reference's F.softmin)
+//   K    = Σ_n soft[n]·candidate_k[n], written for every frame, with K^-1 beside it.
+__global__ void __launch_bounds__(kWave) softmin_blend_fwd_kernel(const double* err, const float* cand_k, int candidates, int frames,
+                                                                  float* soft, float* k, float* kinv) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const double* e = err + (size_t)b * candidates;
+  float lo = 3.0e38f;
+  for (int n = lane; n < candidates; n += kWave) lo = fminf(lo, (float)e[n]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) lo = fminf(lo, __shfl_xor(lo, off, kWave));
+  float total = 0.f;
+  for (int n = lane; n < candidates; n += kWave) total += expf(-(((float)e[n] - lo) * 10.f));
+  total = wave_sum(total);
+  float m[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m[i] = 0.f;
+  for (int n = lane; n < candidates; n += kWave) {
+    const float sn = expf(-(((float)e[n] - lo) * 10.f)) / total;
+    soft[(size_t)b * candidates + n] = sn;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] += cand_k[(size_t)n * 9 + i] * sn;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m[i] = wave_sum(m[i]);
+  float inv[9];
+  inv3(m, inv);
+  for (int f = lane; f < frames; f += kWave) {
+    float* ko = k + ((size_t)b * frames + f) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ko[i] = m[i];
+    if (kinv) {
+      float* io = kinv + ((size_t)b * frames + f) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) io[i] = inv[i];
+    }
+  }
+}
+
+// Backward: G = Σ_f dL/dK[f];  gs[n] = <candidate_k[n], G>;  dL/derr[n] = −10·soft[n]·(gs[n] − Σ soft·gs).
+// (Autograd also routes Σ_n of that — analytically 0, rounding noise in fp32 — to the arg-min entry.)
+__global__ void __launch_bounds__(kWave) softmin_blend_bwd_kernel(const float* g_k, const float* soft, const float* cand_k, int candidates,
+                                                                  int frames, float* g_err) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float g[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) g[i] = 0.f;
+  for (int f = lane; f < frames; f += kWave)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g[i] += g_k[((size_t)b * frames + f) * 9 + i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) g[i] = wave_sum(g[i]);
+  const float* sb = soft + (size_t)b * candidates;
+  float dot = 0.f;
+  for (int n = lane; n < candidates; n += kWave) {
+    float gs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gs += cand_k[(size_t)n * 9 + i] * g[i];
+    dot += sb[n] * gs;
+  }
+  dot = wave_sum(dot);
+  for (int n = lane; n < candidates; n += kWave) {
+    float gs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gs += cand_k[(size_t)n * 9 + i] * g[i];
+    g_err[(size_t)b * candidates + n] = -10.f * sb[n] * (gs - dot);
+  }
+}
+
 __global__ void __launch_bounds__(256) random_subset_kernel(unsigned long long seed, long n, long count, int64_t* out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) out[i] = (int64_t)permuted_index((uint64_t)i, (uint64_t)n, seed);
@@ -491,6 +560,22 @@ int fm_softmin_score_bwd(const float* depth, const float* weights, float weight_
   hipLaunchKernelGGL(softmin_score_bwd_kernel, dim3((unsigned)((points + 255) / 256), batch), dim3(256), 0, st, a, g_err, g_depth,
                      g_weights, g_rel_acc);
   hipLaunchKernelGGL(softmin_rel_grad_kernel, dim3((bn + 63) / 64), dim3(64), 0, st, g_rel_acc, bn, g_rel);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_softmin_blend_fwd(const double* err, const float* candidate_k, int batch, int candidates, int frames, float* soft, float* k,
+                         float* kinv, void* stream) {
+  FM_CHECK_ARG(err && candidate_k && soft && k && batch >= 1 && candidates >= 1 && frames >= 1);
+  hipLaunchKernelGGL(softmin_blend_fwd_kernel, dim3(batch), dim3(kWave), 0, (hipStream_t)stream, err, candidate_k, candidates, frames, soft,
+                     k, kinv);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_softmin_blend_bwd(const float* grad_k, const float* soft, const float* candidate_k, int batch, int candidates, int frames,
+                         float* grad_err, void* stream) {
+  FM_CHECK_ARG(grad_k && soft && candidate_k && grad_err && batch >= 1 && candidates >= 1 && frames >= 1);
+  hipLaunchKernelGGL(softmin_blend_bwd_kernel, dim3(batch), dim3(kWave), 0, (hipStream_t)stream, grad_k, soft, candidate_k, candidates,
+                     frames, grad_err);
   FM_LAUNCH_STATUS();
 }
 

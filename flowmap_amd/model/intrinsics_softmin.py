@@ -15,11 +15,11 @@ Same constructor, buffers, sub-modules and state (``focal_length_candidates``,
 
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass
 from typing import Literal, Optional
 
 import torch
-import torch.nn.functional as F
 from torch import Tensor, nn
 
 from .. import _ops
@@ -56,6 +56,7 @@ class IntrinsicsSoftmin(nn.Module):
         candidates = torch.linspace(cfg.min_focal_length, cfg.max_focal_length, cfg.num_candidates)
         self.register_buffer("focal_length_candidates", candidates, persistent=False)
         self._candidate_cache = None
+        self._flow_cache = None
         if cfg.regression is not None:
             self.intrinsics_regressed = IntrinsicsRegressed(IntrinsicsRegressedCfg("regressed", 0.0))
             self.window = []
@@ -76,9 +77,20 @@ class IntrinsicsSoftmin(nn.Module):
         if self._candidate_cache is None or self._candidate_cache[0] != key:
             n = c.numel()
             candidate_k = focal_lengths_to_intrinsics(c, image_shape)  # (n,3,3)
-            k_pair = candidate_k[None, :, None].expand(b, n, 2, 3, 3).reshape(b * n, 2, 3, 3)
+            k_pair = candidate_k[None, :, None].expand(b, n, 2, 3, 3).reshape(b * n, 2, 3, 3).contiguous()
             self._candidate_cache = (key, candidate_k, k_pair)
         return self._candidate_cache[1], self._candidate_cache[2]
+
+    def _first_pair_flow(self, backward: Tensor) -> Tensor:
+        """``flows.backward[:, :1]`` in memory of its own; flows are constants of the optimisation,
+        so the copy is made once per flow tensor (for b = 1 the slice is already contiguous)."""
+        first = backward[:, :1]
+        if first.is_contiguous():
+            return first
+        key = (backward.data_ptr(), backward._version, tuple(backward.shape))
+        if self._flow_cache is None or self._flow_cache[0]() is not backward or self._flow_cache[1] != key:
+            self._flow_cache = (weakref.ref(backward), key, first.contiguous())
+        return self._flow_cache[2]
 
     def forward(self, batch, flows, backbone_output, global_step: int) -> Tensor:
         b, f, _, h, w = batch.videos.shape
@@ -94,7 +106,7 @@ class IntrinsicsSoftmin(nn.Module):
 
         candidate_k, k_pair = self._candidate_intrinsics(b, (h, w))  # (n,3,3), (b*n,2,3,3)
         idx = self._draw_indices(h * w, device)
-        bwd_01 = flows.backward[:, :1].contiguous()  # (b,1,h,w,2): the only pair the sweep looks at
+        bwd_01 = self._first_pair_flow(flows.backward)  # (b,1,h,w,2): the only pair the sweep looks at
 
         # ---- per-candidate Procrustes fit of frames (0, 1), images read in place -----------
         depths = _ops.LeadingFrames.apply(backbone_output.depths, 2)
@@ -112,16 +124,15 @@ class IntrinsicsSoftmin(nn.Module):
             score_weights, score_sens = weights_01, sens
         else:  # a LazyWeights with sensitivity 0 cannot be folded into the kernel
             score_weights, score_sens = _ops.LeadingFrames.apply(weights.materialize(), 1), 0.0
-        error = _ops.SoftminScore.apply(depths, score_weights, bwd_01, idx, candidate_k, rel.reshape(b * n, 4, 4), score_sens)  # (b,n)
-        soft = F.softmin((error - error.min(dim=1, keepdim=True).values) * 10, dim=1)
-        intrinsics = (candidate_k[None] * soft[:, :, None, None]).sum(dim=1)  # (b,3,3)
+        # ... reduced to the softmin weights, the blended K of every frame and its inverse
+        # (intrinsics_softmin.py:123-141).  The reference returns K as an expanded view; here it is
+        # materialised once and every consumer of the step reads this tensor.
+        intrinsics, soft = _ops.softmin_intrinsics(depths, score_weights, bwd_01, idx, candidate_k, rel.reshape(b * n, 4, 4), score_sens, f)
 
         if reg is not None and global_step >= reg.after_step - reg.window and self.training:
             self.window.append((self.focal_length_candidates * soft).sum().detach())
 
-        # the reference returns the expanded view; materialised once here, every consumer of the
-        # step (Procrustes fit, fused losses) reads the same (b,f,3,3) tensor and shares its inverse
-        return intrinsics[:, None].expand(b, f, 3, 3).contiguous()
+        return intrinsics
 
     def unnormalized_focal_lengths(self, image_shape) -> Tensor:
         """intrinsics_softmin.py:143-156"""

@@ -258,6 +258,16 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
                      const int32_t* blocks, int nblocks, int pmax, const float* kinv, const float* scale, const float* upstream,
                      int height, int width, int depth_frame0, float* grad_depth, void* stream);
 
+/* The tail of IntrinsicsSoftmin.forward (flowmap/model/intrinsics/intrinsics_softmin.py:123-141):
+ * soft = softmin((err - min err) * 10) over the N candidates (fp32), K = sum_n soft[n] * candidate_k[n],
+ * repeated over `frames`.  err (B,N) fp64 as fm_softmin_score_fwd leaves it; candidate_k (N,3,3);
+ * out: soft (B,N), k (B,frames,3,3), kinv (optional, same shape: K^-1 as fm_intrinsics_inverse). */
+int fm_softmin_blend_fwd(const double* err, const float* candidate_k, int batch, int candidates, int frames, float* soft, float* k,
+                         float* kinv, void* stream);
+/* Its backward: grad_k (B,frames,3,3) -> grad_err (B,N) fp32 (feeds fm_softmin_score_bwd). */
+int fm_softmin_blend_bwd(const float* grad_k, const float* soft, const float* candidate_k, int batch, int candidates, int frames,
+                         float* grad_err, void* stream);
+
 /* IntrinsicsSoftmin's per-candidate score (intrinsics_softmin.py:105-121), straight from the
  * images: depth (B,2,H,W) frames 0/1 (the later frame 1 is un-projected), weights (B,H,W) of pair
  * 0 (logits when weight_sensitivity != 0), bwd_flow (B,H,W,2) of pair 0, indices (P) DISTINCT

@@ -251,6 +251,42 @@ def case_softmin_intrinsics(dev, lazy_weights):
         assert_close(weights.grad, g["g_weights"], tol, abs_=1e-7, what="g_weights")
 
 
+def case_softmin_blend(dev):
+    """fm_softmin_blend_fwd/bwd (the tail of IntrinsicsSoftmin.forward) against the reference's torch
+    formulation on the same errors: softmin weights, blended K for every frame, parked K^-1 and the
+    gradient w.r.t. the errors; batch > 1, more candidates than lanes."""
+    import torch.nn.functional as F
+
+    from flowmap_amd import _ops
+    from flowmap_amd._lib import call, ptr, stream_for
+    from flowmap_amd.model.model import focal_lengths_to_intrinsics
+
+    for b, n, frames in ((1, 60, 7), (3, 8, 2), (2, 150, 70)):
+        g = torch.Generator().manual_seed(n)
+        err = (torch.rand((b, n), generator=g) * 0.4 + 0.3).double()
+        err[0, n // 3] = 0.05  # a clear winner in one batch entry, a flat distribution in the others
+        cand = focal_lengths_to_intrinsics(torch.linspace(0.5, 2.0, n), (48, 64)).to(dev)
+        err_d = err.to(dev)
+        soft = torch.empty((b, n), dtype=torch.float32, device=dev)
+        k = torch.empty((b, frames, 3, 3), dtype=torch.float32, device=dev)
+        kinv = torch.empty_like(k)
+        call("fm_softmin_blend_fwd", ptr(err_d), ptr(cand), b, n, frames, ptr(soft), ptr(k), ptr(kinv), stream_for(k))
+        e32 = err.float().requires_grad_(True)
+        w_ref = F.softmin((e32 - e32.min(dim=1, keepdim=True).values) * 10, dim=1)
+        k_ref = (cand.cpu()[None] * w_ref[:, :, None, None]).sum(dim=1)[:, None].expand(b, frames, 3, 3)
+        assert_close(soft, w_ref.detach(), 2e-6, what="soft")
+        assert_close(k, k_ref.detach(), 2e-6, what="blended K")
+        fresh = torch.empty_like(k)
+        call("fm_intrinsics_inverse", ptr(k), b * frames, ptr(fresh), stream_for(k))
+        assert torch.equal(kinv, fresh)
+        cot = torch.randn((b, frames, 3, 3), generator=g)
+        (k_ref * cot).sum().backward()
+        g_err = torch.empty((b, n), dtype=torch.float32, device=dev)
+        cot_d = cot.to(dev)
+        call("fm_softmin_blend_bwd", ptr(cot_d), ptr(soft), ptr(cand), b, n, frames, ptr(g_err), stream_for(k))
+        assert_close(g_err, e32.grad, 2e-5, abs_=1e-7, what="g_err")
+
+
 def case_softmin_step(dev, seed=5):
     """A whole optimisation step with the softmin intrinsics module in the model
     (the reference's default for its first 1000 steps) against the fp64 oracle."""

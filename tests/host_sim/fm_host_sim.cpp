@@ -178,6 +178,47 @@ static void sim_softmin_point(const float* depth, const float* weights, float se
   gy = flow[((size_t)b * n + idx) * 2 + 1];
 }
 
+int fm_softmin_blend_fwd(const double* err, const float* cand_k, int batch, int n, int frames, float* soft, float* k, float* kinv, void*) {
+  for (int b = 0; b < batch; ++b) {
+    const double* e = err + (size_t)b * n;
+    float lo = (float)e[0];
+    for (int c = 1; c < n; ++c) lo = std::fmin(lo, (float)e[c]);
+    double total = 0.0;
+    for (int c = 0; c < n; ++c) total += std::exp(-(((float)e[c] - lo) * 10.f));
+    float m[9] = {0};
+    for (int c = 0; c < n; ++c) {
+      const float sn = (float)(std::exp(-(((float)e[c] - lo) * 10.f)) / total);
+      soft[(size_t)b * n + c] = sn;
+      for (int i = 0; i < 9; ++i) m[i] += cand_k[(size_t)c * 9 + i] * sn;
+    }
+    float inv[9];
+    inv3(m, inv);
+    for (int f = 0; f < frames; ++f)
+      for (int i = 0; i < 9; ++i) {
+        k[((size_t)b * frames + f) * 9 + i] = m[i];
+        if (kinv) kinv[((size_t)b * frames + f) * 9 + i] = inv[i];
+      }
+  }
+  return 0;
+}
+
+int fm_softmin_blend_bwd(const float* g_k, const float* soft, const float* cand_k, int batch, int n, int frames, float* g_err, void*) {
+  for (int b = 0; b < batch; ++b) {
+    double g[9] = {0};
+    for (int f = 0; f < frames; ++f)
+      for (int i = 0; i < 9; ++i) g[i] += g_k[((size_t)b * frames + f) * 9 + i];
+    std::vector<double> gs(n);
+    double dot = 0.0;
+    for (int c = 0; c < n; ++c) {
+      gs[c] = 0.0;
+      for (int i = 0; i < 9; ++i) gs[c] += cand_k[(size_t)c * 9 + i] * g[i];
+      dot += soft[(size_t)b * n + c] * gs[c];
+    }
+    for (int c = 0; c < n; ++c) g_err[(size_t)b * n + c] = (float)(-10.0 * soft[(size_t)b * n + c] * (gs[c] - dot));
+  }
+  return 0;
+}
+
 int fm_softmin_score_fwd(const float* depth, const float* weights, float sens, const float* bwd_flow, const int64_t* indices, long points,
                          const float* k, const float* kinv, const float* rel, int batch, int candidates, int height, int width,
                          double* err, void*) {

@@ -266,6 +266,10 @@ def test_cropping(tag):
     cases.case_cropping(DEV, tag)
 
 
+def test_softmin_blend():
+    cases.case_softmin_blend(DEV)
+
+
 def test_focal_intrinsics():
     cases.case_focal_intrinsics(DEV)
 

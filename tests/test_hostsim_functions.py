@@ -88,6 +88,10 @@ def test_cropping(tag):
     cases.case_cropping("cpu", tag)
 
 
+def test_softmin_blend():
+    cases.case_softmin_blend("cpu")
+
+
 def test_focal_intrinsics():
     cases.case_focal_intrinsics("cpu")
 
