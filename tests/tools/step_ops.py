@@ -1,7 +1,7 @@
 """List what ONE optimisation step launches, in order: C-ABI calls and the torch ops around them
 (runs on the CPU against the host test double; every listed op is one launch on the GPU).
 
-    python tools/step_ops.py [--tracking] [--softmin] [--adam]
+    python tests/tools/step_ops.py [--tracking] [--softmin] [--adam]
 """
 import argparse
 import sys
@@ -10,7 +10,7 @@ from pathlib import Path
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
 from helpers import build_host_sim, to_tracks  # noqa: E402
 
