@@ -47,7 +47,7 @@ class _guard:
 
 
 # K⁻¹ of the few K tensors alive in a step (the model's K shared by the extrinsics fit and the fused
-# losses; the softmin sweep's constant candidate sets): id(root K) -> (weakref, key, K⁻¹)
+# losses; the softmin sweep's constant candidate sets): (id(root K), address, numel) -> (weakref, key, K⁻¹)
 _kinv_cache: dict = {}
 _KINV_CACHE_SLOTS = 4
 
@@ -61,7 +61,7 @@ def _kinv_store(root: Tensor, key, kinv: Tensor) -> None:
         del _kinv_cache[ident]
     while len(_kinv_cache) >= _KINV_CACHE_SLOTS:
         del _kinv_cache[next(iter(_kinv_cache))]  # oldest first
-    _kinv_cache[id(root)] = (weakref.ref(root), key, kinv)
+    _kinv_cache[(id(root), *key[1:])] = (weakref.ref(root), key, kinv)
 
 
 def intrinsics_inverse(k: Tensor) -> Tensor:
@@ -72,13 +72,14 @@ def intrinsics_inverse(k: Tensor) -> Tensor:
     different root object and misses."""
     k = _f32c(k, "intrinsics")
     root = k if k._base is None else k._base
-    entry = _kinv_cache.get(id(root))
-    if entry is not None and entry[0]() is root and entry[1] == _kinv_key(k):
+    key = _kinv_key(k)
+    entry = _kinv_cache.get((id(root), *key[1:]))
+    if entry is not None and entry[0]() is root and entry[1] == key:
         return entry[2].view(k.shape)
     out = torch.empty_like(k)
     with _guard(k.device):
         call("fm_intrinsics_inverse", ptr(k), k.numel() // 9, ptr(out), stream_for(k))
-    _kinv_store(root, _kinv_key(k), out)
+    _kinv_store(root, key, out)
     return out
 
 

@@ -178,3 +178,29 @@ def test_freeze_gc_moves_live_objects_to_the_permanent_generation():
     finally:
         gc.unfreeze()
     assert gc.get_freeze_count() == 0
+
+
+def test_intrinsics_inverse_cache_follows_object_version_and_views():
+    from flowmap_amd import _ops
+
+    k = torch.eye(3).repeat(2, 3, 1, 1)
+    k[..., 0, 0], k[..., 1, 1], k[..., :2, 2] = 0.9, 1.2, 0.5
+    first = _ops.intrinsics_inverse(k)
+    assert _ops.intrinsics_inverse(k).data_ptr() == first.data_ptr()  # same object, same version
+    view = k[:, :, None, None].reshape(2, 3, 3, 3)
+    assert view._base is k and _ops.intrinsics_inverse(view).data_ptr() == first.data_ptr()  # a view of it
+    part = _ops.intrinsics_inverse(k[1:])  # a view of other memory: its own inverse
+    assert part.data_ptr() != first.data_ptr() and torch.equal(part, first[1:])
+    assert _ops.intrinsics_inverse(k).data_ptr() == first.data_ptr()  # ... beside the whole tensor's, not instead of it
+    k[..., 0, 0] *= 2  # in-place update: version bump, recomputed
+    second = _ops.intrinsics_inverse(k)
+    assert not torch.equal(second, first) and torch.allclose(second @ k, torch.eye(3).expand(2, 3, 3, 3), atol=1e-6)
+    clone = k.clone()  # equal values, different object: never served another tensor's entry
+    assert _ops.intrinsics_inverse(clone).data_ptr() != second.data_ptr()
+    # more K tensors than slots: the oldest entries go, the live ones keep hitting
+    keep = [torch.eye(3)[None].clone() * (i + 1) for i in range(_ops._KINV_CACHE_SLOTS + 2)]
+    for m in keep:
+        _ops.intrinsics_inverse(m)
+    assert len(_ops._kinv_cache) <= _ops._KINV_CACHE_SLOTS
+    last = _ops.intrinsics_inverse(keep[-1])
+    assert _ops.intrinsics_inverse(keep[-1]).data_ptr() == last.data_ptr()
