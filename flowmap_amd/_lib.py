@@ -31,7 +31,7 @@ SIGNATURES = {
     "fm_flow_pack_inputs": [P, P, P, P, I, I, I, I, P, P],
     "fm_flow_loss_finalize": [P] * 6 + [I, I, F, F] + [P] * 4 + [P],
     "fm_flow_valid_norm": [P, P, L, F, P, P, P],
-    "fm_scale_if_needed": [P, L, P, P],
+    "fm_scale_if_needed": [P, L, P, L, P, P],
     "fm_softmin_blend_fwd": [P, P, I, I, I, P, P, P, P],
     "fm_softmin_blend_bwd": [P, P, P, I, I, I, P, P],
     "fm_softmin_score_fwd": [P, P, F, P, P, L, P, P, P, I, I, I, I, P, P],
@@ -45,8 +45,9 @@ SIGNATURES = {
     "fm_adam_step": [P, P, P, P, L, L, D, D, D, D, D, P],
     "fm_adam_step_capturable": [P, P, P, P, L, P, D, D, D, D, D, P],
     "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, I, P, P],
+    "fm_procrustes_fit": [P] * 5 + [F, P, L, I, I, I, I, I, P, P, P, P, P],
     "fm_pose_solve": [P, I, P, P, P, P],
-    "fm_pose_solve_bwd": [P, P, P, P, I, P, P],
+    "fm_pose_solve_bwd": [P, P, P, P, I, P, P, L, P],
     "fm_procrustes_scatter": [P] * 5 + [F, P, L, I, I, I, I, I] + [P] * 6 + [P],
     "fm_pose_chain_fwd": [P, I, I, P, P],
     "fm_pose_chain_bwd": [P, P, P, I, I, P, P],

@@ -347,9 +347,8 @@ class ProcrustesFit(torch.autograd.Function):
         aux = torch.empty((pairs, AUX_STRIDE), dtype=torch.float64, device=dev)
         with _guard(dev):
             st = stream_for(weights)
-            call("fm_procrustes_stats", ptr(depth) if from_depth else None, ptr(kinv), ptr(surfaces), ptr(bwd_flow),
-                 ptr(weights), float(weight_sens), ptr(indices), points, b, rep, f, h, w, ptr(stats), st)
-            call("fm_pose_solve", ptr(stats), pairs, ptr(t_bwd), ptr(t_fwd), ptr(aux), st)
+            call("fm_procrustes_fit", ptr(depth) if from_depth else None, ptr(kinv), ptr(surfaces), ptr(bwd_flow),
+                 ptr(weights), float(weight_sens), ptr(indices), points, b, rep, f, h, w, ptr(stats), ptr(t_bwd), ptr(t_fwd), ptr(aux), st)
         ctx.save_for_backward(depth if from_depth else surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux)
         ctx.from_depth, ctx.dims, ctx.points, ctx.weight_sens, ctx.rep = from_depth, (b, f, h, w), points, float(weight_sens), rep
         # Carried depth gradient: when the fused flow loss consumes poses fitted from the very
@@ -391,10 +390,11 @@ class ProcrustesFit(torch.autograd.Function):
             # element of dL/dweights; all other paths accumulate atomically into zeros
             dense_tiled = ctx.from_depth and indices is None and ctx.rep == 1
             g_w = torch.empty_like(weights) if dense_tiled else torch.zeros_like(weights)
-        kinv_acc = torch.zeros((b * f, 9), dtype=torch.float64, device=dev) if need_k else None
+        kinv_acc = torch.empty((b * f, 9), dtype=torch.float64, device=dev) if need_k else None  # zeroed by fm_pose_solve_bwd
         with _guard(dev):
             st = stream_for(weights)
-            call("fm_pose_solve_bwd", ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr(aux), pairs, ptr(pair_grad), st)
+            call("fm_pose_solve_bwd", ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr(aux), pairs, ptr(pair_grad), ptr(kinv_acc),
+                 0 if kinv_acc is None else kinv_acc.numel(), st)
             call("fm_procrustes_scatter", ptr(src) if ctx.from_depth else None, ptr(kinv), None if ctx.from_depth else ptr(src),
                  ptr(bwd_flow), ptr(weights), ctx.weight_sens, ptr(indices), ctx.points, b, ctx.rep, f, h, w, ptr(aux), ptr(pair_grad),
                  ptr(g_src) if ctx.from_depth else None, None if ctx.from_depth else ptr(g_src), ptr(g_w), ptr(kinv_acc), st)
@@ -552,9 +552,7 @@ class FlowLossFused(torch.autograd.Function):
         g = g.reshape(1).to(torch.float32).contiguous()
         with _guard(g.device):
             st = stream_for(g)
-            for buf in (g_depth, small):
-                if buf is not None:
-                    call("fm_scale_if_needed", ptr(buf), buf.numel(), ptr(g), st)
+            call("fm_scale_if_needed", ptr(g_depth), 0 if g_depth is None else g_depth.numel(), ptr(small), small.numel(), ptr(g), st)
         node = ctx.fit_node
         ctx.fit_node = None
         if node is not None and g_depth is not None and node._fm_carried is None:
@@ -933,7 +931,7 @@ class AlignRigid(torch.autograd.Function):
         g_w = torch.empty_like(w) if ctx.needs_input_grad[2] else None
         with _guard(p.device):
             st = stream_for(p)
-            call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t), ptr(aux), g, ptr(pair_grad), st)
+            call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t), ptr(aux), g, ptr(pair_grad), None, 0, st)
             call("fm_align_rigid_bwd", ptr(p), ptr(q), ptr(w), g, n, ptr(aux), ptr(pair_grad), ptr(g_p), ptr(g_q), ptr(g_w), st)
         return g_p, g_q, g_w
 

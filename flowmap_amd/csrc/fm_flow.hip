@@ -368,10 +368,13 @@ __global__ void __launch_bounds__(256) pack_inputs_kernel(const float* flow_fwd,
 
 // In-place scale of gradient buffers by a device scalar, skipped entirely when the
 // scalar is exactly 1 (the autograd root case): every block exits after one load.
-__global__ void __launch_bounds__(256) scale_if_needed_kernel(float* x, long n, const float* s) {
+__global__ void __launch_bounds__(256) scale_if_needed_kernel(float* x, long n, float* y, long ny, const float* s) {
   const float sv = s[0];
   if (sv == 1.0f) return;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= sv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n + ny; i += (long)gridDim.x * blockDim.x) {
+    if (i < n) x[i] *= sv;
+    else y[i - n] *= sv;
+  }
 }
 
 }  // namespace fm
@@ -488,12 +491,12 @@ int fm_flow_pack_inputs(const float* flow_fwd, const float* flow_bwd, const floa
   FM_LAUNCH_STATUS();
 }
 
-int fm_scale_if_needed(float* x, long count, const float* scalar, void* stream) {
-  FM_CHECK_ARG(x && scalar && count >= 0);
-  if (count == 0) return FM_OK;
-  long blocks = (count + 256 * 8 - 1) / (256 * 8);
+int fm_scale_if_needed(float* x, long count, float* y, long count_y, const float* scalar, void* stream) {
+  FM_CHECK_ARG(scalar && count >= 0 && count_y >= 0 && (x || count == 0) && (y || count_y == 0));
+  if (count + count_y == 0) return FM_OK;
+  long blocks = (count + count_y + 256 * 8 - 1) / (256 * 8);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(scale_if_needed_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, count, scalar);
+  hipLaunchKernelGGL(scale_if_needed_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, count, y, count_y, scalar);
   FM_LAUNCH_STATUS();
 }
 

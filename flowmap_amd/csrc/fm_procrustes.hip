@@ -115,6 +115,22 @@ __global__ void procrustes_moments_finish_kernel(ProcParams p, int pairs) {
   moments_finish(p.stats + (size_t)pair * kStatStride, shift);
 }
 
+// The same, followed by the solve for that pair (fm_procrustes_fit: one launch instead of two).
+template <int SRC>
+__global__ void procrustes_finish_solve_kernel(ProcParams p, int pairs, float* t_bwd, float* t_fwd, double* aux) {
+  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= pairs) return;
+  const int b = pair / (p.frames - 1), i = pair % (p.frames - 1);
+  Mat3 kinv_l{};
+  if (SRC == SRC_DEPTH) load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
+  const CorrSrc src = pair_source<SRC>(p, pair, b, i);
+  float shift[3];
+  pair_shift<SRC>(p, src, kinv_l, shift);
+  double* st = p.stats + (size_t)pair * kStatStride;
+  moments_finish(st, shift);
+  pose_solve_one(st, t_bwd + (size_t)pair * 16, t_fwd ? t_fwd + (size_t)pair * 16 : nullptr, aux + (size_t)pair * kAuxStride);
+}
+
 // Backward for batch_repeat > 1 (the softmin candidate sweep: R = 60 (K, pose) entries share one
 // image pair).  The generic kernel would run one thread per (candidate, point) and have 60 threads
 // add atomically to the same depth / weight pixels.  Here a thread owns one point and walks a GROUP
@@ -363,8 +379,10 @@ __global__ void pose_solve_kernel(const double* stats, int pairs, float* t_bwd, 
 // bottom rows ignored.  Output per pair: gM, total centroid gradients, and the scalars
 // the per-point pass needs.
 __global__ void pose_solve_bwd_kernel(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux,
-                                      int pairs, double* pair_grad) {
+                                      int pairs, double* pair_grad, double* clear, long clear_count) {
   const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+  // the accumulator the per-point pass (next launch on this stream) adds into
+  for (long i = pr; i < clear_count; i += (long)gridDim.x * blockDim.x) clear[i] = 0.0;
   if (pr >= pairs) return;
   pose_solve_bwd_one(g_t_bwd ? g_t_bwd + (size_t)pr * 16 : nullptr, g_t_fwd ? g_t_fwd + (size_t)pr * 16 : nullptr,
                      t_bwd + (size_t)pr * 16, aux + (size_t)pr * kAuxStride, pair_grad + (size_t)pr * kPairGradStride);
@@ -818,14 +836,10 @@ static inline int choose_iters(long points) {
 
 extern "C" {
 
-int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
-                        const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
-                        int batch_repeat, int frames, int height, int width, double* stats, void* stream) {
-  FM_CHECK_ARG((depth && kinv) || surfaces);
-  FM_CHECK_ARG(bwd_flow && weights && stats && points >= 1 && batch >= 1 && frames >= 2);
-  FM_CHECK_ARG(batch_repeat >= 1 && batch % batch_repeat == 0);
-  FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
-  hipStream_t st = (hipStream_t)stream;
+static int procrustes_stats_launch(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                                   const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
+                                   int batch_repeat, int frames, int height, int width, double* stats, float* t_bwd, float* t_fwd,
+                                   double* aux, hipStream_t st) {
   const int pairs = batch * (frames - 1);
   if (hipMemsetAsync(stats, 0, sizeof(double) * (size_t)pairs * kStatStride, st) != hipSuccess) return FM_ERR_LAUNCH;
   ProcParams p{};
@@ -836,18 +850,46 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
   const dim3 fgrid((unsigned)((pairs + 63) / 64));
-  if (dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width, pairs)) {
+  const bool dense = dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width, pairs);
+  if (dense) {
     const long total = dense_blocks(height, width, pairs);
     hipLaunchKernelGGL(procrustes_moments_dense_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, total);
-    hipLaunchKernelGGL((procrustes_moments_finish_kernel<SRC_DEPTH>), fgrid, dim3(64), 0, st, p, pairs);
   } else if (surfaces) {
     hipLaunchKernelGGL((procrustes_moments_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, iters);
-    hipLaunchKernelGGL((procrustes_moments_finish_kernel<SRC_SURF>), fgrid, dim3(64), 0, st, p, pairs);
   } else {
     hipLaunchKernelGGL((procrustes_moments_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, iters);
+  }
+  if (t_bwd) {  // finish + solve per pair in one launch
+    if (surfaces) hipLaunchKernelGGL((procrustes_finish_solve_kernel<SRC_SURF>), fgrid, dim3(64), 0, st, p, pairs, t_bwd, t_fwd, aux);
+    else hipLaunchKernelGGL((procrustes_finish_solve_kernel<SRC_DEPTH>), fgrid, dim3(64), 0, st, p, pairs, t_bwd, t_fwd, aux);
+  } else if (surfaces) {
+    hipLaunchKernelGGL((procrustes_moments_finish_kernel<SRC_SURF>), fgrid, dim3(64), 0, st, p, pairs);
+  } else {
     hipLaunchKernelGGL((procrustes_moments_finish_kernel<SRC_DEPTH>), fgrid, dim3(64), 0, st, p, pairs);
   }
   FM_LAUNCH_STATUS();
+}
+
+int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                        const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
+                        int batch_repeat, int frames, int height, int width, double* stats, void* stream) {
+  FM_CHECK_ARG((depth && kinv) || surfaces);
+  FM_CHECK_ARG(bwd_flow && weights && stats && points >= 1 && batch >= 1 && frames >= 2);
+  FM_CHECK_ARG(batch_repeat >= 1 && batch % batch_repeat == 0);
+  FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
+  return procrustes_stats_launch(depth, kinv, surfaces, bwd_flow, weights, weight_sensitivity, indices, points, batch, batch_repeat,
+                                 frames, height, width, stats, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                      float weight_sensitivity, const int64_t* indices, long points, int batch, int batch_repeat, int frames,
+                      int height, int width, double* stats, float* t_bwd, float* t_fwd, double* aux, void* stream) {
+  FM_CHECK_ARG((depth && kinv) || surfaces);
+  FM_CHECK_ARG(bwd_flow && weights && stats && t_bwd && aux && points >= 1 && batch >= 1 && frames >= 2);
+  FM_CHECK_ARG(batch_repeat >= 1 && batch % batch_repeat == 0);
+  FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
+  return procrustes_stats_launch(depth, kinv, surfaces, bwd_flow, weights, weight_sensitivity, indices, points, batch, batch_repeat,
+                                 frames, height, width, stats, t_bwd, t_fwd, aux, (hipStream_t)stream);
 }
 
 int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux, void* stream) {
@@ -857,10 +899,10 @@ int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, do
 }
 
 int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux, int pairs,
-                      double* pair_grad, void* stream) {
-  FM_CHECK_ARG(t_bwd && aux && pair_grad && pairs >= 1);
+                      double* pair_grad, double* clear, long clear_count, void* stream) {
+  FM_CHECK_ARG(t_bwd && aux && pair_grad && pairs >= 1 && clear_count >= 0 && (clear || clear_count == 0));
   hipLaunchKernelGGL(pose_solve_bwd_kernel, dim3((pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, g_t_bwd, g_t_fwd, t_bwd,
-                     aux, pairs, pair_grad);
+                     aux, pairs, pair_grad, clear, clear_count);
   FM_LAUNCH_STATUS();
 }
 

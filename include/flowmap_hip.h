@@ -85,8 +85,9 @@ int fm_flow_loss_finalize(const double* acc, const float* k, const float* kinv, 
 int fm_flow_valid_norm(const float* mask_fwd, const float* mask_bwd, long count, float weight, double* vsum, float* norm,
                        void* stream);
 
-/* x[i] *= scalar[0] unless scalar[0] == 1 (autograd's grad_output at the root). */
-int fm_scale_if_needed(float* x, long count, const float* scalar, void* stream);
+/* x[i] *= scalar[0] and y[i] *= scalar[0] unless scalar[0] == 1 (autograd's grad_output at the
+ * root); either buffer may be NULL with a count of 0. */
+int fm_scale_if_needed(float* x, long count, float* y, long count_y, const float* scalar, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Procrustes pose fit.  Replaces align_surfaces (projection.py:213-252) +
@@ -107,15 +108,24 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
                         const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
                         int batch_repeat, int frames, int height, int width, double* stats, void* stream);
 
+/* fm_procrustes_stats followed by fm_pose_solve (below) for the same pairs, the per-pair
+ * normalisation and the solve sharing one launch: what align_surfaces does up to the pose chain
+ * (projection.py:213-249).  `stats` is the workspace / by-product. */
+int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                      float weight_sensitivity, const int64_t* indices, long points, int batch, int batch_repeat, int frames,
+                      int height, int width, double* stats, float* t_bwd, float* t_fwd, double* aux, void* stream);
+
 /* procrustes.py:35-51: R = U·diag(1,1,±1)·Vᵀ by in-register 3×3 SVD, t = q̄ − R·p̄.
  * t_bwd (pairs,4,4) = [R|t] ("inverse relative transformation", later -> earlier
  * camera); t_fwd (pairs,4,4) = its inverse (may be NULL); aux (pairs, FM_AUX_STRIDE). */
 int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux, void* stream);
 
 /* Backward of fm_pose_solve (replaces linalg_svd_backward et al.).  g_t_bwd / g_t_fwd
- * (pairs,4,4) may be NULL.  pair_grad (pairs, FM_PAIR_GRAD_STRIDE) fp64 out. */
+ * (pairs,4,4) may be NULL.  pair_grad (pairs, FM_PAIR_GRAD_STRIDE) fp64 out.  `clear` (optional,
+ * clear_count doubles) is zeroed by the same launch: the kinv_acc that fm_procrustes_scatter,
+ * next on the stream, accumulates into. */
 int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux, int pairs,
-                      double* pair_grad, void* stream);
+                      double* pair_grad, double* clear, long clear_count, void* stream);
 
 /* Per-point backward (replaces grid_sampler_2d_backward + index_put of
  * projection.py:226-249).  ATOMICALLY ADDS into grad_depth (B,F,H,W) or grad_surfaces

@@ -370,9 +370,10 @@ int fm_adam_step_capturable(float* param, const float* grad, float* exp_avg, flo
   return fm_adam_step(param, grad, exp_avg, exp_avg_sq, count, (long)step[0], lr, beta1, beta2, eps, weight_decay, stream);
 }
 
-int fm_scale_if_needed(float* x, long count, const float* scalar, void*) {
+int fm_scale_if_needed(float* x, long count, float* y, long count_y, const float* scalar, void*) {
   if (scalar[0] == 1.0f) return 0;
   for (long i = 0; i < count; ++i) x[i] *= scalar[0];
+  for (long i = 0; i < count_y; ++i) y[i] *= scalar[0];
   return 0;
 }
 
@@ -423,6 +424,13 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
   return 0;
 }
 
+int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                      float sens, const int64_t* indices, long points, int batch, int repeat, int frames, int height, int width,
+                      double* stats, float* t_bwd, float* t_fwd, double* aux, void* stream) {
+  fm_procrustes_stats(depth, kinv, surfaces, bwd_flow, weights, sens, indices, points, batch, repeat, frames, height, width, stats, stream);
+  return fm_pose_solve(stats, batch * (frames - 1), t_bwd, t_fwd, aux, stream);
+}
+
 int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux, void*) {
   for (int pr = 0; pr < pairs; ++pr)
     pose_solve_one(stats + (size_t)pr * kStatStride, t_bwd + (size_t)pr * 16, t_fwd ? t_fwd + (size_t)pr * 16 : nullptr,
@@ -431,7 +439,8 @@ int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, do
 }
 
 int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux, int pairs,
-                      double* pair_grad, void*) {
+                      double* pair_grad, double* clear, long clear_count, void*) {
+  for (long i = 0; i < clear_count; ++i) clear[i] = 0.0;
   for (int pr = 0; pr < pairs; ++pr)
     pose_solve_bwd_one(g_t_bwd ? g_t_bwd + (size_t)pr * 16 : nullptr, g_t_fwd ? g_t_fwd + (size_t)pr * 16 : nullptr,
                        t_bwd + (size_t)pr * 16, aux + (size_t)pr * kAuxStride, pair_grad + (size_t)pr * kPairGradStride);

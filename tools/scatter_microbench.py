@@ -26,7 +26,7 @@ st = torch.cuda.current_stream().cuda_stream
 call("fm_procrustes_stats", ptr(depth), ptr(kinv), None, ptr(fb), ptr(wl), 100.0, ptr(idx), P, 1, 1, f, h, w, ptr(stats), st)
 call("fm_pose_solve", ptr(stats), pairs, ptr(t_bwd), None, ptr(aux), st)
 g_t = torch.randn((1, pairs, 4, 4), device=dev, generator=g)
-call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t_bwd), ptr(aux), pairs, ptr(pg), st)
+call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t_bwd), ptr(aux), pairs, ptr(pg), None, 0, st)
 gd = torch.zeros_like(depth)
 gw = torch.zeros_like(wl)
 ka = torch.zeros((f, 9), dtype=torch.float64, device=dev)
