@@ -76,7 +76,7 @@ class FrameShard:
         No-op for world == 1."""
         extra = 0.0 if already_global is None else already_global.detach()
         if not self.active:
-            return loss.detach() + extra
+            return loss.detach() if already_global is None else loss.detach() + extra
         dist = self.dist
         parts = [loss.detach().reshape(1).to(torch.float32)]
         if shared_param is not None and shared_param.grad is not None:
