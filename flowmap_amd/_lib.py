@@ -74,6 +74,8 @@ SIGNATURES = {
     "fm_track_loss_fwd": [P] * 6 + [I, I, I, P, P, I, I, I, I, F, F, F, F] + [P] * 7 + [P],
     "fm_track_loss_bwd": [P] * 7 + [I, P, P, P],
     "fm_track_scatter": [P] * 6 + [I, I, P, P, P, I, I, I, P, P],
+    "fm_track_scatter_plan": [P, P, P, P, I, I, I, I, P, P, P],
+    "fm_depth_gather": [P, P, P, P, P, L, P, P, P, I, I, L, P, P],
 }
 
 _lib: Optional[ctypes.CDLL] = None

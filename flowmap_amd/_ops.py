@@ -978,6 +978,32 @@ class PackedTracks:
         self.pmax = max(s_[2] for s_ in seg)
         self.fmax = max(s_[1] for s_ in seg)
         self.last_frame = max(s_[0] + s_[1] for s_ in seg)
+        self._plans: dict = {}
+
+    def scatter_plan(self, height: int, width: int):
+        """Where the tracking gradient lands in dL/ddepth, planned once per image shape (tracks are
+        constants): (pixels int64 ascending, first int32, source point of each entry int32, weights)
+        for fm_depth_gather.  Built with one launch + a sort; None when nothing is scattered."""
+        key = (int(height), int(width))
+        if key not in self._plans:
+            plan = None
+            if self.nblocks > 0:
+                dev = self.xy.device
+                keys = torch.full((self.total * 4,), -1, dtype=torch.int64, device=dev)
+                weights = torch.empty((self.total * 4,), dtype=torch.float32, device=dev)
+                with _guard(dev):
+                    call("fm_track_scatter_plan", ptr(self.xy), ptr(self.vis), ptr(self.seg), ptr(self.blocks), self.nblocks, self.pmax,
+                         key[0], key[1], ptr(keys), ptr(weights), stream_for(self.xy))
+                used = torch.nonzero(keys >= 0).reshape(-1)
+                if used.numel() > 0:
+                    sorted_keys, order = torch.sort(keys[used], stable=True)
+                    entries = used[order]
+                    pixels, counts = torch.unique_consecutive(sorted_keys, return_counts=True)
+                    first = torch.zeros((pixels.numel() + 1,), dtype=torch.int32, device=dev)
+                    first[1:] = torch.cumsum(counts, 0).to(torch.int32)
+                    plan = (pixels.contiguous(), first, (entries // 4).to(torch.int32).contiguous(), weights[entries].contiguous())
+            self._plans[key] = plan
+        return self._plans[key]
 
 
 _packed_cache: dict = {}
@@ -1060,6 +1086,7 @@ class TrackLossFused(torch.autograd.Function):
         ctx.packed, ctx.dims, ctx.shapes = packed, (f, h, w), (tuple(depth.shape), tuple(k.shape), tuple(ext.shape))
         ctx.frame0 = int(frame0)
         ctx.fit_node = None
+        ctx.plan = packed.scatter_plan(h, w) if ctx.needs_input_grad[0] else None  # built at the first step
         if defer and ctx.needs_input_grad[0]:
             node = _find_fit_node(ext if fit_from is None else fit_from, (depth.data_ptr(), depth._version, tuple(depth.shape)))
             if node is not None and node.needs_input_grad[0]:
@@ -1086,12 +1113,15 @@ class TrackLossFused(torch.autograd.Function):
 
         frame0 = ctx.frame0
 
+        plan = ctx.plan
+
         def scatter(buffer: Tensor) -> None:
-            if pk.nblocks == 0:
+            if plan is None:
                 return
-            with _guard(dev):
-                call("fm_track_scatter", ptr(gws), ptr(flag), ptr(pk.xy), ptr(pk.vis), ptr(pk.seg), ptr(pk.blocks), pk.nblocks,
-                     pk.pmax, ptr(kinv), ptr(scale), ptr(g), h, w, frame0, ptr(buffer), stream_for(buffer))
+            pixels, first, entries, weights = plan
+            with _guard(dev):  # the planned gather: no atomics (fm_track_scatter is the unplanned form)
+                call("fm_depth_gather", ptr(gws), ptr(pixels), ptr(first), ptr(entries), ptr(weights), pixels.numel(), ptr(kinv),
+                     ptr(scale), ptr(g), h, w, frame0, ptr(buffer), stream_for(buffer))
 
         g_depth = None
         if ctx.needs_input_grad[0]:

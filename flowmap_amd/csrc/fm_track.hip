@@ -298,6 +298,59 @@ __global__ void __launch_bounds__(256) track_scatter_kernel(TrackGeom g, const u
   }
 }
 
+// The scatter pattern is static (track positions and visibility are inputs of the optimisation):
+// tap k of source point i lands on pixel keys[4i+k] = frame·H·W + row·W + col with weight
+// weights[4i+k]; -1 marks a tap that contributes nothing.  Same arithmetic as track_scatter_kernel.
+__global__ void __launch_bounds__(256) track_scatter_plan_kernel(TrackGeom g, int64_t* keys, float* weights) {
+  const int sg = g.blocks[blockIdx.x * 2], fs = g.blocks[blockIdx.x * 2 + 1];
+  const int start = g.seg[sg * 4], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
+  const int p = blockIdx.y * blockDim.x + threadIdx.x;
+  if (p >= p_count) return;
+  const size_t is = (size_t)off + (size_t)fs * p_count + p;
+  const float2 q = reinterpret_cast<const float2*>(g.xy)[is];
+  const bool live = g.vis[is] != 0 && q.x >= 0.f && q.y >= 0.f && q.x < 1.f && q.y < 1.f;  // the flag of track_points_kernel
+  const Taps t = bilinear_taps(q.x, q.y, g.height, g.width);
+  const int64_t base = (int64_t)(start + fs) * g.height * g.width;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const bool used = live && t.in[kk];
+    keys[is * 4 + kk] = used ? base + (int64_t)tap_row(t, kk) * g.width + tap_col(t, kk) : (int64_t)-1;
+    weights[is * 4 + kk] = used ? t.w[kk] : 0.f;
+  }
+}
+
+// A planned scatter executed as a gather over the touched pixels: one thread owns one pixel of
+// dL/ddepth and sums the contributions the plan lists for it,
+//   grad_depth[pixel] += s · Σ_e weights[e] · < vectors[entries[e]], K⁻¹(frame)·[u, v, 1] >,
+// — no atomics (device-scope float atomics run at the memory side on this part, ≈10-26 G/s however
+// hot the line), one read-modify-write per pixel, and a result that does not depend on scheduling.
+// Serves the tracking loss (vectors = dL/dxyz per source point) and the sparse Procrustes backward
+// (vectors = dL/dq, dL/dp per correspondence).
+__global__ void __launch_bounds__(256) depth_gather_kernel(const float* vectors, const int64_t* pixels, const int32_t* first,
+                                                           const int32_t* entries, const float* weights, long count, const float* kinv,
+                                                           const float* scale, const float* upstream, int height, int width,
+                                                           long frame0, float* grad_depth) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= count) return;
+  const int64_t n = (int64_t)height * width;
+  const int64_t key = pixels[m];
+  const int64_t frame = key / n;
+  const int px = (int)(key - frame * n);
+  const int row = px / width, col = px - row * width;
+  Mat3 ki;
+  load_mat3(kinv + (size_t)frame * 9, ki);
+  float ray[3];
+  ray_dir(ki, pixel_center(col, width), pixel_center(row, height), ray);
+  const float sc = (scale ? scale[0] : 1.f) * (upstream ? upstream[0] : 1.f);
+  float sum = 0.f;
+  for (int e = first[m]; e < first[m + 1]; ++e) {
+    const float* v = vectors + (size_t)entries[e] * 3;
+    const float gx = v[0] * sc, gy = v[1] * sc, gz = v[2] * sc;
+    sum += weights[e] * (gx * ray[0] + gy * ray[1] + gz * ray[2]);
+  }
+  grad_depth[(size_t)(frame - frame0) * n + px] += sum;
+}
+
 // dL/dE and dL/dK per frame from the two accumulators.
 __global__ void track_finalize_bwd_kernel(const double* acc, const double* acc2, const float* scale, const float* upstream,
                                           const float* ext_inv, const float* k, const float* kinv, int frames, float* g_ext,
@@ -388,6 +441,24 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
   TrackGeom g{xy, vis, seg, blocks, height, width};
   hipLaunchKernelGGL(track_scatter_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, flag, gws, kinv,
                      scale, upstream, depth_frame0, grad_depth);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_track_scatter_plan(const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int pmax, int height,
+                          int width, int64_t* keys, float* weights, void* stream) {
+  FM_CHECK_ARG(xy && vis && seg && blocks && keys && weights && nblocks >= 1 && pmax >= 1 && height >= 1 && width >= 1);
+  TrackGeom g{xy, vis, seg, blocks, height, width};
+  hipLaunchKernelGGL(track_scatter_plan_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, keys, weights);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_depth_gather(const float* vectors, const int64_t* pixels, const int32_t* first, const int32_t* entries, const float* weights,
+                    long count, const float* kinv, const float* scale, const float* upstream, int height, int width, long frame0,
+                    float* grad_depth, void* stream) {
+  FM_CHECK_ARG(vectors && pixels && first && entries && weights && kinv && grad_depth && count >= 0 && frame0 >= 0);
+  if (count == 0) return FM_OK;
+  hipLaunchKernelGGL(depth_gather_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vectors, pixels, first,
+                     entries, weights, count, kinv, scale, upstream, height, width, frame0, grad_depth);
   FM_LAUNCH_STATUS();
 }
 

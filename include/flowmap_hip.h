@@ -268,6 +268,25 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
                      const int32_t* blocks, int nblocks, int pmax, const float* kinv, const float* scale, const float* upstream,
                      int height, int width, int depth_frame0, float* grad_depth, void* stream);
 
+/* The pattern of fm_track_scatter is static — track positions and visibility are inputs of the
+ * optimisation — so it can be planned once: keys (total,4) int64 = frame·H·W + row·W + col of tap k
+ * of source point i (global frame index), -1 for a tap that contributes nothing (invisible /
+ * outside / clipped); weights (total,4) its bilinear weight.  Only the (segment, frame) entries of
+ * `blocks` are written: pre-fill keys with -1. */
+int fm_track_scatter_plan(const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int pmax, int height,
+                          int width, int64_t* keys, float* weights, void* stream);
+
+/* A planned scatter executed as a gather, without atomics and deterministic: pixels (count) int64 =
+ * the distinct keys >= 0 of a plan in ascending order (key = frame·H·W + row·W + col); first
+ * (count+1) int32 = where each pixel's entries begin; entries (E) int32 = index of the 3-vector
+ * each entry contributes, weights (E) its weight, both sorted by key.
+ *   grad_depth[key − frame0·H·W] += scale[0]·upstream[0]·Σ_e weights[e]·<vectors[entries[e]], K⁻¹(frame)·[u,v,1]>
+ * (scale / upstream NULL = 1).  With fm_track_scatter_plan: vectors = gws, entries = plan index / 4.
+ * With fm_procrustes_scatter_plan: vectors = point_grads of fm_procrustes_scatter. */
+int fm_depth_gather(const float* vectors, const int64_t* pixels, const int32_t* first, const int32_t* entries, const float* weights,
+                    long count, const float* kinv, const float* scale, const float* upstream, int height, int width, long frame0,
+                    float* grad_depth, void* stream);
+
 /* The tail of IntrinsicsSoftmin.forward (flowmap/model/intrinsics/intrinsics_softmin.py:123-141):
  * soft = softmin((err - min err) * 10) over the N candidates (fp32), K = sum_n soft[n] * candidate_k[n],
  * repeated over `frames`.  err (B,N) fp64 as fm_softmin_score_fwd leaves it; candidate_k (N,3,3);

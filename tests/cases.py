@@ -185,6 +185,53 @@ def case_flow_loss_batched(dev, lazy):
     assert_close(kk.grad, k64.grad, 1e-3, abs_=1e-4 * abs(float(ref.detach())), what="g_k")
 
 
+def case_track_scatter_plan(dev):
+    """The planned gather (fm_track_scatter_plan + fm_depth_gather) lands exactly where the atomic
+    fm_track_scatter does, for visible / invisible / out-of-frame / border-clipped track points and
+    for a shard that owns only some source frames; two runs of the gather are bit-identical."""
+    from flowmap_amd import _ops
+    from flowmap_amd._lib import call, ptr, stream_for
+    from helpers import to_tracks
+
+    f, h, w = 7, 20, 28
+    otracks = orc.synth_tracks(f, h, w, seed=3, interval=3, radius=2, grid=5, p_visible=0.8)
+    otracks[0].xy[0, 0, :3] = torch.tensor([[-0.2, 0.5], [0.5, 1.3], [0.999, 0.001]])  # outside, outside, on the border (clipped taps)
+    otracks[1].xy[0, 1, :2] = torch.tensor([[0.5 / w, 0.5 / h], [1 - 0.4 / w, 1 - 0.4 / h]])  # exactly on / beyond the corner pixel centres
+    otracks[1].visibility[0, 1, :2] = True
+    tracks = to_tracks(otracks, dev)
+    g = torch.Generator().manual_seed(5)
+    k = torch.eye(3).repeat(f, 1, 1)
+    k[:, 0, 0], k[:, 1, 1], k[:, :2, 2] = 0.9, 1.1, 0.5
+    kinv = torch.linalg.inv(k).contiguous().to(dev)
+    for own, frame0, f_local in ((None, 0, f), ((2, 5), 2, 4)):
+        pk = _ops.PackedTracks(tracks, torch.device(dev), own)
+        gws = torch.randn((pk.total, 3), generator=g).to(dev)
+        flag = ((pk.vis != 0) & (pk.xy >= 0).all(-1) & (pk.xy < 1).all(-1)).to(torch.uint8)
+        if own is not None:  # flags of sources this shard does not own stay 0 (track_points never visits them)
+            owned = torch.zeros_like(flag)
+            for sg, fr in pk.blocks.tolist():
+                start, fl, p, off = pk.seg[sg].tolist()
+                owned[off + fr * p : off + (fr + 1) * p] = 1
+            flag = flag * owned
+        scale = torch.tensor([0.37, 1.0], device=dev)
+        up = torch.tensor([1.9], device=dev)
+        atomic = torch.zeros((f_local, h, w), device=dev)
+        call("fm_track_scatter", ptr(gws), ptr(flag), ptr(pk.xy), ptr(pk.vis), ptr(pk.seg), ptr(pk.blocks), pk.nblocks, pk.pmax, ptr(kinv),
+             ptr(scale), ptr(up), h, w, frame0, ptr(atomic), stream_for(atomic))
+        pixels, first, entries, weights = pk.scatter_plan(h, w)
+        assert pk.scatter_plan(h, w)[0] is pixels  # planned once
+        assert bool((pixels[1:] > pixels[:-1]).all()) and int(first[-1]) == entries.numel() == weights.numel()
+        runs = []
+        for _ in range(2):
+            out = torch.full((f_local, h, w), 0.25, device=dev)  # the gather ADDS into what is there
+            call("fm_depth_gather", ptr(gws), ptr(pixels), ptr(first), ptr(entries), ptr(weights), pixels.numel(), ptr(kinv),
+                 ptr(scale), ptr(up), h, w, frame0, ptr(out), stream_for(out))
+            runs.append(out)
+        assert torch.equal(runs[0], runs[1])
+        assert_close(runs[0] - 0.25, atomic, 2e-6, abs_=1e-6, what=f"gather vs atomic scatter (own={own})")
+        assert 0 < int((atomic != 0).sum()) <= pixels.numel()  # (taps of weight exactly 0 are planned too)
+
+
 def case_loss_gating_and_empty_tracks(dev):
     """Loss.forward's enable_after gate (loss.py:39-41) and the degenerate inputs: no track
     segments, all-invisible tracks (valid_sum or 1)."""

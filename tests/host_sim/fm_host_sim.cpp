@@ -984,4 +984,46 @@ int fm_track_scatter(const float* gws, const uint8_t* flag, const float* xy, con
   return 0;
 }
 
+int fm_track_scatter_plan(const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int, int height,
+                          int width, int64_t* keys, float* weights, void*) {
+  for (int blk = 0; blk < nblocks; ++blk) {
+    const int sg = blocks[blk * 2], fs = blocks[blk * 2 + 1];
+    const int start = seg[sg * 4], pc = seg[sg * 4 + 2], off = seg[sg * 4 + 3];
+    for (int p = 0; p < pc; ++p) {
+      const size_t is = (size_t)off + (size_t)fs * pc + p;
+      const float x = xy[is * 2], y = xy[is * 2 + 1];
+      const bool live = vis[is] != 0 && x >= 0.f && y >= 0.f && x < 1.f && y < 1.f;
+      const Taps t = bilinear_taps(x, y, height, width);
+      for (int kk = 0; kk < 4; ++kk) {
+        const bool used = live && t.in[kk];
+        keys[is * 4 + kk] = used ? (int64_t)(start + fs) * height * width + (int64_t)tap_row(t, kk) * width + tap_col(t, kk) : (int64_t)-1;
+        weights[is * 4 + kk] = used ? t.w[kk] : 0.f;
+      }
+    }
+  }
+  return 0;
+}
+
+int fm_depth_gather(const float* vectors, const int64_t* pixels, const int32_t* first, const int32_t* entries, const float* weights,
+                    long count, const float* kinv, const float* scale, const float* upstream, int height, int width, long frame0,
+                    float* grad_depth, void*) {
+  const float sc = (scale ? scale[0] : 1.f) * (upstream ? upstream[0] : 1.f);
+  const int64_t n = (int64_t)height * width;
+  for (long m = 0; m < count; ++m) {
+    const int64_t frame = pixels[m] / n;
+    const int px = (int)(pixels[m] - frame * n);
+    Mat3 ki;
+    load_mat3(kinv + (size_t)frame * 9, ki);
+    float ray[3];
+    ray_dir(ki, pixel_center(px % width, width), pixel_center(px / width, height), ray);
+    float sum = 0.f;
+    for (int e = first[m]; e < first[m + 1]; ++e) {
+      const float* v = vectors + (size_t)entries[e] * 3;
+      sum += weights[e] * (v[0] * sc * ray[0] + v[1] * sc * ray[1] + v[2] * sc * ray[2]);
+    }
+    grad_depth[(size_t)(frame - frame0) * n + px] += sum;
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -266,6 +266,10 @@ def test_cropping(tag):
     cases.case_cropping(DEV, tag)
 
 
+def test_track_scatter_plan():
+    cases.case_track_scatter_plan(DEV)
+
+
 def test_softmin_blend():
     cases.case_softmin_blend(DEV)
 

@@ -88,6 +88,10 @@ def test_cropping(tag):
     cases.case_cropping("cpu", tag)
 
 
+def test_track_scatter_plan():
+    cases.case_track_scatter_plan("cpu")
+
+
 def test_softmin_blend():
     cases.case_softmin_blend("cpu")
 

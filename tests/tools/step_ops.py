@@ -85,7 +85,7 @@ def main():
         step()
     print("\n".join(calls))
     fm = sum(1 for c in calls if not c.startswith("  "))
-    print(f"-- {len(calls)} launches ({fm} C-ABI calls, {len(calls) - fm} torch ops; fm_procrustes_stats = 2 kernels, some fm calls more)")
+    print(f"-- {len(calls)} launches ({fm} C-ABI calls, {len(calls) - fm} torch ops; some C-ABI calls are two or three kernels)")
 
 
 if __name__ == "__main__":
