@@ -48,7 +48,8 @@ SIGNATURES = {
     "fm_procrustes_fit": [P] * 5 + [F, P, L, I, I, I, I, I, P, P, P, P, P],
     "fm_pose_solve": [P, I, P, P, P, P],
     "fm_pose_solve_bwd": [P, P, P, P, I, P, P, L, P],
-    "fm_procrustes_scatter": [P] * 5 + [F, P, L, I, I, I, I, I] + [P] * 6 + [P],
+    "fm_procrustes_scatter": [P] * 5 + [F, P, L, I, I, I, I, I] + [P] * 7 + [P],
+    "fm_procrustes_scatter_plan": [P, P, L, I, I, I, I, P, P, P],
     "fm_pose_chain_fwd": [P, I, I, P, P],
     "fm_pose_chain_bwd": [P, P, P, I, I, P, P],
     "fm_relative_pose_fwd": [P, I, I, P, P, P],

@@ -38,6 +38,7 @@ struct ProcParams {
   float* grad_surfaces;    // (B,F,H,W,3)  atomically accumulated [scatter, SRC_SURF]
   float* grad_weights;     // (B,F-1,H,W)  atomically accumulated [scatter]
   double* kinv_acc;        // (B*F, 9) fp64 accumulators          [scatter, SRC_DEPTH]
+  float* point_grads;      // (B*(F-1)*P, 2, 3) dL/dq, dL/dp per correspondence instead of the depth atomics [planned scatter]
   int frames, height, width;
   long points;
   float weight_sens;       // != 0: `weights` holds logits, w = sigmoid(weight_sens·logit)
@@ -362,6 +363,32 @@ __global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParam
   block_accumulate<kMomentCount>(acc, red, p.stats + pair * kStatStride);
 }
 
+// Static pattern of the sparse depth-sourced scatter (indices and flows are constants of the
+// optimisation): correspondence j of pair `pair` touches its four taps in the earlier frame and its
+// own pixel in the later frame.  keys[(pair·P + j)·5 + slot] = frame·H·W + pixel (slot 0..3 taps with
+// their bilinear weights, slot 4 the later pixel with weight 1), -1 for a tap outside the image.
+__global__ void __launch_bounds__(256) procrustes_scatter_plan_kernel(const float* bwd_flow, const int64_t* indices, long points, int frames,
+                                                                      int height, int width, int64_t* keys, float* weights) {
+  const size_t pair = blockIdx.y;
+  const int b = (int)(pair / (frames - 1)), i = (int)(pair % (frames - 1));
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= points) return;
+  const int64_t n = (int64_t)height * width;
+  const int idx = indices ? (int)indices[j] : (int)j;
+  const PixelRef px = pixel_ref(idx, height, width);
+  const float* fl = bwd_flow + (pair * (size_t)n + (size_t)idx) * 2;
+  const Taps t = bilinear_taps(px.u + fl[0], px.v + fl[1], height, width);  // as corr_load_with
+  const int64_t fe = (int64_t)b * frames + i;
+  const size_t o = (pair * (size_t)points + (size_t)j) * 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    keys[o + k] = t.in[k] ? fe * n + (int64_t)tap_row(t, k) * width + tap_col(t, k) : (int64_t)-1;
+    weights[o + k] = t.in[k] ? t.w[k] : 0.f;
+  }
+  keys[o + 4] = (fe + 1) * n + idx;
+  weights[o + 4] = 1.f;
+}
+
 // ---------------------------------------------------------------------------------
 // Pose solve: one thread per pair.
 //   t_bwd[pair] = [R | t]  maps later-camera -> earlier-camera ("inverse relative
@@ -431,11 +458,19 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
     float gq[3], gp[3], gw;
     corr_backward(c, g, gq, gp, gw);
     if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
-    if (p.grad_weights) atomicAdd(p.grad_weights + dpair * (size_t)n + c.idx, gw);
+    const bool planned = SRC == SRC_DEPTH && p.point_grads != nullptr;  // distinct indices: plain stores, depth by fm_depth_gather
+    if (p.grad_weights) {
+      if (planned) p.grad_weights[dpair * (size_t)n + c.idx] = gw;
+      else atomicAdd(p.grad_weights + dpair * (size_t)n + c.idx, gw);
+    }
+    if (planned) {
+      float* o = p.point_grads + (pair * (size_t)p.points + (size_t)j) * 6;
+      o[0] = gq[0], o[1] = gq[1], o[2] = gq[2], o[3] = gp[0], o[4] = gp[1], o[5] = gp[2];
+    }
     if (SRC == SRC_DEPTH) {
       const int row = c.idx / p.width, col = c.idx - row * p.width;
       const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
-      if (p.grad_depth) atomicAdd(p.grad_depth + fl * n + c.idx, gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2]);
+      if (p.grad_depth && !planned) atomicAdd(p.grad_depth + fl * n + c.idx, gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2]);
       const float zh[3] = {c.z_p * u, c.z_p * v, c.z_p};
 #pragma unroll
       for (int a = 0; a < 3; ++a)
@@ -450,7 +485,7 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
         float ray[3];
         ray_dir(kinv_e, ut, vt, ray);
         const float wt = c.taps.w[k];
-        if (p.grad_depth) atomicAdd(p.grad_depth + fe * n + tr * p.width + tc, wt * (gq[0] * ray[0] + gq[1] * ray[1] + gq[2] * ray[2]));
+        if (p.grad_depth && !planned) atomicAdd(p.grad_depth + fe * n + tr * p.width + tc, wt * (gq[0] * ray[0] + gq[1] * ray[1] + gq[2] * ray[2]));
         const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -909,16 +944,19 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
                           int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,
-                          float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, void* stream) {
+                          float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, float* point_grads,
+                          void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
   FM_CHECK_ARG(bwd_flow && weights && aux && pair_grad && points >= 1);
   FM_CHECK_ARG(batch_repeat >= 1 && batch % batch_repeat == 0);
+  FM_CHECK_ARG(!point_grads || (depth && !surfaces && indices && batch_repeat == 1));
   hipStream_t st = (hipStream_t)stream;
   const int pairs = batch * (frames - 1);
   ProcParams p{};
   p.depth = depth; p.kinv = kinv; p.surfaces = surfaces; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
   p.pair_grad = pair_grad; p.grad_depth = grad_depth; p.grad_surfaces = grad_surfaces; p.grad_weights = grad_weights;
   p.kinv_acc = kinv_acc; p.frames = frames; p.height = height; p.width = width; p.points = points;
+  p.point_grads = point_grads;
   p.weight_sens = weight_sensitivity;
   p.batch_repeat = batch_repeat;
   const int iters = choose_iters(points);
@@ -932,6 +970,15 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
     hipLaunchKernelGGL(procrustes_scatter_repeat_kernel, rgrid, dim3(256), 0, st, p, aux);
   } else if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);
   else hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, aux, iters);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_procrustes_scatter_plan(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                               int64_t* keys, float* weights, void* stream) {
+  FM_CHECK_ARG(bwd_flow && keys && weights && points >= 1 && batch >= 1 && frames >= 2 && height >= 1 && width >= 1);
+  FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
+  hipLaunchKernelGGL(procrustes_scatter_plan_kernel, dim3((unsigned)((points + 255) / 256), (unsigned)(batch * (frames - 1))), dim3(256), 0,
+                     (hipStream_t)stream, bwd_flow, indices, points, frames, height, width, keys, weights);
   FM_LAUNCH_STATUS();
 }
 

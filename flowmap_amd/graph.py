@@ -34,7 +34,7 @@ class GraphedStep:
             side = torch.cuda.Stream(device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):  # fills every cache (packed constants, valid sums, indices, RNG state)
-                for _ in range(max(1, warmup)):
+                for _ in range(max(2, warmup)):  # the second step builds the scatter plans (a sort, host-synchronising)
                     fn()
             torch.cuda.current_stream(device).wait_stream(side)
             torch.cuda.synchronize(device)

@@ -138,7 +138,20 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
                           int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,
-                          float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, void* stream);
+                          float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, float* point_grads,
+                          void* stream);
+
+/* Planned form of the sparse depth-sourced scatter.  With DISTINCT `indices` and constant flows the
+ * pixels a step's Procrustes gradient touches never change: fm_procrustes_scatter_plan lists them
+ * once — keys (B·(F-1)·P, 5) int64 = frame·H·W + pixel for the four taps in the earlier frame and
+ * (slot 4) the correspondence's own pixel in the later frame, -1 for a tap outside; weights the
+ * bilinear weights (1 for slot 4).  Per step fm_procrustes_scatter is then called with
+ * point_grads (B·(F-1)·P, 2, 3) != NULL (depth source, indices given, batch_repeat 1): it writes
+ * dL/dq, dL/dp per correspondence there, STORES grad_weights at the sampled pixels and leaves
+ * grad_depth alone; fm_depth_gather (vectors = point_grads, entries = 2·(key index / 5) + (slot == 4))
+ * adds the depth gradient without atomics. */
+int fm_procrustes_scatter_plan(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                               int64_t* keys, float* weights, void* stream);
 
 /* get_extrinsics (projection.py:187-210): ext (B,steps+1,4,4), ext[0]=I,
  * ext[k] = ext[k-1]·rel[k-1]; and its backward (replaces the Python loop of matmuls). */

@@ -185,6 +185,51 @@ def case_flow_loss_batched(dev, lazy):
     assert_close(kk.grad, k64.grad, 1e-3, abs_=1e-4 * abs(float(ref.detach())), what="g_k")
 
 
+def case_procrustes_planned_backward(dev):
+    """The sparse Procrustes backward switches from atomics to the planned gather when the same
+    (indices, flows) come back: same gradients (first step: atomics; later steps: plan), bit-identical
+    repeats; index sets with duplicates and per-step indices never get a plan."""
+    from flowmap_amd import _ops
+
+    f, h, w, points = 5, 22, 30, 90
+    depth, wlogit, of = orc.synth_iid(f, h, w, seed=21)
+    of.backward[0, 1, 3, 4] = torch.tensor([0.6, -0.8])  # far outside: taps clamped to the border
+    k = torch.eye(3).repeat(1, f, 1, 1)
+    k[..., 0, 0], k[..., 1, 1], k[..., :2, 2] = 0.9, 1.15, 0.5
+    k, bwd = k.to(dev), of.backward.to(dev)
+    cot = torch.randn((1, f - 1, 4, 4), generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def run(indices):
+        d = depth[None].to(dev).requires_grad_(True)
+        lg = wlogit[None].to(dev).requires_grad_(True)
+        kk = k.clone().requires_grad_(True)
+        t_bwd, t_fwd = _ops.ProcrustesFit.apply(d, kk, None, lg, bwd, indices, 100.0, 1)
+        ((t_bwd + 0.5 * t_fwd) * cot).sum().backward()
+        return d.grad, lg.grad, kk.grad
+
+    idx = torch.linspace(0, h * w - 1, points).to(torch.int64).to(dev)
+    before = _ops.counters["procrustes_planned"]
+    first = run(idx)  # atomics (first sighting)
+    assert _ops.counters["procrustes_planned"] == before
+    second = run(idx)  # builds the plan
+    third = run(idx)
+    assert _ops.counters["procrustes_planned"] == before + 2
+    for a, b_, c, name in zip(first, second, third, ("g_depth", "g_logits", "g_k")):
+        assert_close(b_, a, 2e-5, abs_=1e-7, what=f"planned vs atomic {name}")
+        if name != "g_k":  # (dL/dK sums blocks with fp64 atomics: order-dependent in the last bit)
+            assert torch.equal(b_, c), name
+        assert_close(c, b_, 1e-6, abs_=1e-9, what=f"repeat {name}")
+    dup = idx.clone()
+    dup[1] = dup[0]
+    for _ in range(3):
+        got = run(dup)
+    assert _ops.counters["procrustes_planned"] == before + 2  # duplicates: atomics every time
+    for _ in range(3):
+        run(idx.clone())  # a new index tensor each step (randomize_points): never planned
+    assert _ops.counters["procrustes_planned"] == before + 2
+    assert got[0].isfinite().all()
+
+
 def case_track_scatter_plan(dev):
     """The planned gather (fm_track_scatter_plan + fm_depth_gather) lands exactly where the atomic
     fm_track_scatter does, for visible / invisible / out-of-frame / border-clipped track points and

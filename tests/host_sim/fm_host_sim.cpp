@@ -431,6 +431,29 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
   return fm_pose_solve(stats, batch * (frames - 1), t_bwd, t_fwd, aux, stream);
 }
 
+int fm_procrustes_scatter_plan(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                               int64_t* keys, float* weights, void*) {
+  const int64_t n = (int64_t)height * width;
+  for (int pr = 0; pr < batch * (frames - 1); ++pr) {
+    const int b = pr / (frames - 1), i = pr % (frames - 1);
+    for (long j = 0; j < points; ++j) {
+      const int idx = indices ? (int)indices[j] : (int)j;
+      const PixelRef px = pixel_ref(idx, height, width);
+      const float* fl = bwd_flow + ((size_t)pr * n + idx) * 2;
+      const Taps t = bilinear_taps(px.u + fl[0], px.v + fl[1], height, width);
+      const int64_t fe = (int64_t)b * frames + i;
+      const size_t o = ((size_t)pr * points + j) * 5;
+      for (int k = 0; k < 4; ++k) {
+        keys[o + k] = t.in[k] ? fe * n + (int64_t)tap_row(t, k) * width + tap_col(t, k) : (int64_t)-1;
+        weights[o + k] = t.in[k] ? t.w[k] : 0.f;
+      }
+      keys[o + 4] = (fe + 1) * n + idx;
+      weights[o + 4] = 1.f;
+    }
+  }
+  return 0;
+}
+
 int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux, void*) {
   for (int pr = 0; pr < pairs; ++pr)
     pose_solve_one(stats + (size_t)pr * kStatStride, t_bwd + (size_t)pr * 16, t_fwd ? t_fwd + (size_t)pr * 16 : nullptr,
@@ -450,9 +473,10 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float sens, const int64_t* indices, long points, int batch, int repeat, int frames,
                           int height, int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
-                          float* grad_weights, double* kinv_acc, void*) {
+                          float* grad_weights, double* kinv_acc, float* point_grads, void*) {
   const int pairs = batch * (frames - 1);
   const size_t n = (size_t)height * width;
+  if (point_grads) grad_depth = nullptr;  // planned form: the depth part goes through fm_depth_gather
   for (int pr = 0; pr < pairs; ++pr) {
     const int b = pr / (frames - 1), i = pr % (frames - 1);
     Mat3 ke{}, kl{};
@@ -483,7 +507,12 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
       if (sens != 0.f) gw *= sens * c.w * (1.f - c.w);
       // dense depth-sourced mode: every element is written exactly once and the real library STORES it
       // (the caller does not zero the buffer); every other mode accumulates into zeros
-      const bool stores = depth && !surfaces && !indices && repeat == 1 && points == (long)n;
+      const bool stores = (depth && !surfaces && !indices && repeat == 1 && points == (long)n) || point_grads;
+      if (point_grads)
+        for (int a = 0; a < 3; ++a) {
+          point_grads[((size_t)pr * points + j) * 6 + a] = gq[a];
+          point_grads[((size_t)pr * points + j) * 6 + 3 + a] = gp[a];
+        }
       if (grad_weights) {
         if (stores) grad_weights[dpair * n + c.idx] = gw;
         else grad_weights[dpair * n + c.idx] += gw;

@@ -266,6 +266,10 @@ def test_cropping(tag):
     cases.case_cropping(DEV, tag)
 
 
+def test_procrustes_planned_backward():
+    cases.case_procrustes_planned_backward(DEV)
+
+
 def test_track_scatter_plan():
     cases.case_track_scatter_plan(DEV)
 

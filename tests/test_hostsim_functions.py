@@ -88,6 +88,10 @@ def test_cropping(tag):
     cases.case_cropping("cpu", tag)
 
 
+def test_procrustes_planned_backward():
+    cases.case_procrustes_planned_backward("cpu")
+
+
 def test_track_scatter_plan():
     cases.case_track_scatter_plan("cpu")
 
