@@ -43,5 +43,6 @@ python tools/probes/bw_probe.py > "$OUT/r01_hbm_stream_probe.json" 2>/dev/null
 python tools/adam_microbench.py > "$OUT/r01_adam_microbench.json" 2>/dev/null
 python tests/tools/preprocess_bench.py > "$OUT/r01_preprocess_bench.jsonl" 2>/dev/null
 python tests/tools/ate_check.py --device cuda > "$OUT/ate.log" 2>&1; tail -1 "$OUT/ate.log" > "$OUT/r01_ate_c0_16x256x256.json"
+python tests/tools/ate_check.py --device cuda --height 192 --width 256 --tracking > "$OUT/ate_tracking.log" 2>&1; tail -1 "$OUT/ate_tracking.log" > "$OUT/r01_ate_16x192x256_flow_tracking.json"
 rm -rf gpurun_out/prof_track gpurun_out/prof_dense gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_stats
 ls -la "$OUT"; cat "$OUT/r01_bench_c1.json"; cat "$OUT/r01_flow_kernel_traffic.json" | tail -8
