@@ -42,13 +42,15 @@ SIGNATURES = {
     "fm_consistency_mask": [P, P, I, I, I, I, P, P],
     "fm_flow_postprocess": [P, P, I, I, I, I, I, I, I, P, P, P],
     "fm_resize_crop": [P, L, I, I, I, I, I, I, I, I, P, P],
+    "fm_fill_zero": [P, L, I, P],
     "fm_adam_step": [P, P, P, P, L, L, D, D, D, D, D, P],
     "fm_adam_step_capturable": [P, P, P, P, L, P, D, D, D, D, D, P],
     "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, I, P, P],
     "fm_procrustes_fit": [P] * 5 + [F, P, L, I, I, I, I, I, P, P, P, P, P],
     "fm_pose_solve": [P, I, P, P, P, P],
     "fm_pose_solve_bwd": [P, P, P, P, I, P, P, L, P],
-    "fm_procrustes_scatter": [P] * 5 + [F, P, L, I, I, I, I, I] + [P] * 7 + [P],
+    "fm_procrustes_scatter": [P] * 5 + [F, P, L, I, I, I, I, I] + [P] * 8 + [P],
+    "fm_sparse_store": [P, P, L, I, L, P, P],
     "fm_procrustes_scatter_plan": [P, P, L, I, I, I, I, P, P, P],
     "fm_pose_chain_fwd": [P, I, I, P, P],
     "fm_pose_chain_bwd": [P, P, P, I, I, P, P],

@@ -8,6 +8,7 @@ synchronises the device or falls back to eager PyTorch math.
 
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional
 
@@ -290,6 +291,33 @@ class LeadingFrames(torch.autograd.Function):
         return full, None
 
 
+# Early zero fill of the sparse fit's dense dL/dweights (549 MB at C1) on a side stream: started when
+# the backward pass begins (by the fused flow loss, the first node to run), behind everything the
+# forward enqueued, with a bounded number of workgroups — it then overlaps the latency-bound kernels
+# of the backward pass instead of standing in line between them.  Off under hipGraph capture.
+prefill_weight_grads = os.environ.get("FLOWMAP_PREFILL", "1") != "0"
+PREFILL_BLOCKS = int(os.environ.get("FLOWMAP_PREFILL_BLOCKS", "512"))
+_side_streams: dict = {}
+
+
+def _start_weight_grad_prefill(node) -> None:
+    weights = node._fm_weights_like
+    if (not prefill_weight_grads or graph_capturable or weights is None or not weights.is_cuda or not node.needs_input_grad[3]
+            or getattr(node, "_fm_prefilled", None) is not None):
+        return
+    dev = weights.device
+    main = torch.cuda.current_stream(dev)
+    side = _side_streams.get(dev.index)
+    if side is None:
+        side = _side_streams[dev.index] = torch.cuda.Stream(dev)
+    side.wait_stream(main)  # not before the forward's kernels (the flow kernel owns the HBM while it runs)
+    with torch.cuda.stream(side):
+        g_w = torch.empty_like(weights)
+        with _guard(dev):
+            call("fm_fill_zero", ptr(g_w), g_w.numel(), PREFILL_BLOCKS, side.cuda_stream)
+    node._fm_prefilled = (g_w, side)
+
+
 # Plans of the sparse Procrustes backward (fm_procrustes_scatter_plan): with constant flows and a
 # constant, duplicate-free index set, the pixels the gradient touches never change.
 _scatter_plans: dict = {}
@@ -402,6 +430,9 @@ class ProcrustesFit(torch.autograd.Function):
         ctx._fm_fit_depth_key = (depth.data_ptr(), depth._version, tuple(depth.shape)) if from_depth else None
         ctx._fm_carried = None
         ctx._fm_pending = []  # deferred scatters of other losses into the final dL/ddepth buffer
+        # sparse fits accumulate into a zeroed dL/dweights: the fused flow loss may start that fill early
+        ctx._fm_weights_like = weights if (indices is not None and rep == 1) else None
+        ctx._fm_prefilled = None
         return t_bwd, t_fwd
 
     @staticmethod
@@ -416,7 +447,7 @@ class ProcrustesFit(torch.autograd.Function):
         need_k = ctx.from_depth and ctx.needs_input_grad[1]
         need_w = ctx.needs_input_grad[3]
         pair_grad = torch.empty((pairs, PAIR_GRAD_STRIDE), dtype=torch.float64, device=dev)
-        g_src = g_k = g_w = None
+        g_src = g_k = g_w = fill_stream = None
         carried = ctx._fm_carried
         ctx._fm_carried = None
         pending, ctx._fm_pending = ctx._fm_pending, []
@@ -425,22 +456,33 @@ class ProcrustesFit(torch.autograd.Function):
             for scatter in pending:
                 scatter(g_src)
         if need_w:
-            # (zero-filling this 549 MB buffer early on a side stream, behind the latency-bound
-            # fit kernels, was measured: the fill's blocks delay those kernels and then contend
-            # with the fused flow kernel — step 1.126 -> 1.187 ms.  Kept in line.)
+            # (zero-filling this 549 MB buffer at FORWARD time on a side stream was measured and
+            # rejected: the fill contends with the fused flow kernel — step 1.126 -> 1.187 ms.  What
+            # works is _start_weight_grad_prefill: started when the backward pass begins, bounded
+            # footprint, and the P values per pair placed by fm_sparse_store after the join.)
             # the tiled dense kernels (depth-sourced, every pixel a correspondence) STORE every
             # element of dL/dweights; all other paths accumulate atomically into zeros
             dense_tiled = ctx.from_depth and indices is None and ctx.rep == 1
-            g_w = torch.empty_like(weights) if dense_tiled else torch.zeros_like(weights)
+            prefilled, ctx._fm_prefilled = ctx._fm_prefilled, None
+            if prefilled is not None:
+                g_w, fill_stream = prefilled  # being zeroed on the side stream; joined below
+                g_w.record_stream(torch.cuda.current_stream(dev))
+            else:
+                g_w = torch.empty_like(weights) if dense_tiled else torch.zeros_like(weights)
         kinv_acc = torch.empty((b * f, 9), dtype=torch.float64, device=dev) if need_k else None  # zeroed by fm_pose_solve_bwd
         # sparse depth-sourced fit with constant indices / flows: the depth gradient is gathered along a
         # plan instead of scattered with atomics (which run at the memory side: 100 us for 0.9 M adds)
-        plan = point_grads = None
+        plan = point_grads = point_gw = None
         if ctx.from_depth and indices is not None and ctx.rep == 1:
             plan = _procrustes_scatter_plan(indices, bwd_flow, b, f, h, w)
             if plan is not None:
                 point_grads = torch.empty((pairs * ctx.points, 2, 3), dtype=torch.float32, device=dev)
                 counters["procrustes_planned"] += 1
+                if fill_stream is not None and g_w is not None:  # keep the per-point pass off the buffer still being zeroed
+                    point_gw = torch.empty((pairs * ctx.points,), dtype=torch.float32, device=dev)
+        if fill_stream is not None and point_gw is None:
+            torch.cuda.current_stream(dev).wait_stream(fill_stream)  # the scatter writes into g_w directly
+            fill_stream = None
         with _guard(dev):
             st = stream_for(weights)
             call("fm_pose_solve_bwd", ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr(aux), pairs, ptr(pair_grad), ptr(kinv_acc),
@@ -448,11 +490,14 @@ class ProcrustesFit(torch.autograd.Function):
             call("fm_procrustes_scatter", ptr(src) if ctx.from_depth else None, ptr(kinv), None if ctx.from_depth else ptr(src),
                  ptr(bwd_flow), ptr(weights), ctx.weight_sens, ptr(indices), ctx.points, b, ctx.rep, f, h, w, ptr(aux), ptr(pair_grad),
                  ptr(g_src) if ctx.from_depth else None, None if ctx.from_depth else ptr(g_src), ptr(g_w), ptr(kinv_acc),
-                 ptr(point_grads), st)
+                 ptr(point_grads), ptr(point_gw), st)
             if plan is not None and g_src is not None:
                 pixels, first, vectors, weights_e = plan
                 call("fm_depth_gather", ptr(point_grads), ptr(pixels), ptr(first), ptr(vectors), ptr(weights_e), pixels.numel(), ptr(kinv),
                      None, None, h, w, 0, ptr(g_src), st)
+            if point_gw is not None:
+                torch.cuda.current_stream(dev).wait_stream(fill_stream)  # the zero fill is done: place the P values per pair
+                call("fm_sparse_store", ptr(point_gw), ptr(indices), ctx.points, pairs, h * w, ptr(g_w), st)
             if need_k:
                 g_k = torch.empty_like(kinv)
                 call("fm_intrinsics_inverse_bwd", ptr(kinv_acc), ptr(kinv), b * f, ptr(g_k), 0, st)
@@ -604,6 +649,8 @@ class FlowLossFused(torch.autograd.Function):
             raise RuntimeError("flowmap_amd: FlowLossFused gradients are single-use; run the forward again")
         g_depth, g_k, g_tf, g_tb, small = ctx.grads
         ctx.grads = None
+        if ctx.fit_node is not None:
+            _start_weight_grad_prefill(ctx.fit_node)
         g = g.reshape(1).to(torch.float32).contiguous()
         with _guard(g.device):
             st = stream_for(g)

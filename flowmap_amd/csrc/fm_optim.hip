@@ -101,6 +101,18 @@ __global__ void __launch_bounds__(256) adam_capturable_kernel(float* param, cons
   adam_apply(param, grad, exp_avg, exp_avg_sq, count, c, vec_ok);
 }
 
+// Zero fill with a bounded footprint: `blocks` workgroups stream 16-byte non-temporal stores over the
+// buffer, so the fill can share the GPU with latency-bound kernels on another stream instead of
+// flooding every CU with its own workgroups.
+__global__ void __launch_bounds__(256) fill_zero_kernel(float* x, long count) {
+  const long quads = count >> 2;
+  v4f* q = reinterpret_cast<v4f*>(x);
+  const v4f z = {0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (long)gridDim.x * blockDim.x)
+    __builtin_nontemporal_store(z, q + i);
+  for (long i = (quads << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) x[i] = 0.f;
+}
+
 }  // namespace fm
 
 using namespace fm;
@@ -135,6 +147,16 @@ int fm_adam_step_capturable(float* param, const float* grad, float* exp_avg, flo
   if (blocks > 256L * FM_ADAM_BLOCKS_PER_CU) blocks = 256L * FM_ADAM_BLOCKS_PER_CU;
   hipLaunchKernelGGL(adam_capturable_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, count, step, lr, beta1, beta2, eps, weight_decay, vec_ok);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_fill_zero(float* x, long count, int blocks, void* stream) {
+  FM_CHECK_ARG(x && count >= 0 && blocks >= 1 && (reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (count == 0) return FM_OK;
+  long need = (count / 4 + 255) / 256;
+  if (need < 1) need = 1;
+  if (need > blocks) need = blocks;
+  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)need), dim3(256), 0, (hipStream_t)stream, x, count);
   FM_LAUNCH_STATUS();
 }
 

@@ -39,6 +39,7 @@ struct ProcParams {
   float* grad_weights;     // (B,F-1,H,W)  atomically accumulated [scatter]
   double* kinv_acc;        // (B*F, 9) fp64 accumulators          [scatter, SRC_DEPTH]
   float* point_grads;      // (B*(F-1)*P, 2, 3) dL/dq, dL/dp per correspondence instead of the depth atomics [planned scatter]
+  float* point_weight_grads;  // (B*(F-1)*P) dL/dweight per correspondence instead of the store into grad_weights [planned scatter]
   int frames, height, width;
   long points;
   float weight_sens;       // != 0: `weights` holds logits, w = sigmoid(weight_sens·logit)
@@ -389,6 +390,14 @@ __global__ void __launch_bounds__(256) procrustes_scatter_plan_kernel(const floa
   weights[o + 4] = 1.f;
 }
 
+// out[group·stride + indices[j]] = values[group·points + j]: the per-correspondence weight gradients
+// dropped into the (zeroed) dense dL/dweights.
+__global__ void __launch_bounds__(256) sparse_store_kernel(const float* values, const int64_t* indices, long points, long stride, float* out) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= points) return;
+  out[(size_t)blockIdx.y * stride + (size_t)indices[j]] = values[(size_t)blockIdx.y * points + j];
+}
+
 // ---------------------------------------------------------------------------------
 // Pose solve: one thread per pair.
 //   t_bwd[pair] = [R | t]  maps later-camera -> earlier-camera ("inverse relative
@@ -459,7 +468,9 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
     corr_backward(c, g, gq, gp, gw);
     if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
     const bool planned = SRC == SRC_DEPTH && p.point_grads != nullptr;  // distinct indices: plain stores, depth by fm_depth_gather
-    if (p.grad_weights) {
+    if (planned && p.point_weight_grads) {
+      p.point_weight_grads[pair * (size_t)p.points + (size_t)j] = gw;  // placed by fm_sparse_store once the buffer is zeroed
+    } else if (p.grad_weights) {
       if (planned) p.grad_weights[dpair * (size_t)n + c.idx] = gw;
       else atomicAdd(p.grad_weights + dpair * (size_t)n + c.idx, gw);
     }
@@ -945,11 +956,12 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
                           const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
                           int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,
                           float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, float* point_grads,
-                          void* stream) {
+                          float* point_weight_grads, void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
   FM_CHECK_ARG(bwd_flow && weights && aux && pair_grad && points >= 1);
   FM_CHECK_ARG(batch_repeat >= 1 && batch % batch_repeat == 0);
   FM_CHECK_ARG(!point_grads || (depth && !surfaces && indices && batch_repeat == 1));
+  FM_CHECK_ARG(!point_weight_grads || point_grads);
   hipStream_t st = (hipStream_t)stream;
   const int pairs = batch * (frames - 1);
   ProcParams p{};
@@ -957,6 +969,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
   p.pair_grad = pair_grad; p.grad_depth = grad_depth; p.grad_surfaces = grad_surfaces; p.grad_weights = grad_weights;
   p.kinv_acc = kinv_acc; p.frames = frames; p.height = height; p.width = width; p.points = points;
   p.point_grads = point_grads;
+  p.point_weight_grads = point_weight_grads;
   p.weight_sens = weight_sensitivity;
   p.batch_repeat = batch_repeat;
   const int iters = choose_iters(points);
@@ -979,6 +992,13 @@ int fm_procrustes_scatter_plan(const float* bwd_flow, const int64_t* indices, lo
   FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
   hipLaunchKernelGGL(procrustes_scatter_plan_kernel, dim3((unsigned)((points + 255) / 256), (unsigned)(batch * (frames - 1))), dim3(256), 0,
                      (hipStream_t)stream, bwd_flow, indices, points, frames, height, width, keys, weights);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_sparse_store(const float* values, const int64_t* indices, long points, int groups, long stride, float* out, void* stream) {
+  FM_CHECK_ARG(values && indices && out && points >= 1 && groups >= 1 && groups <= 65535 && stride >= 1);
+  hipLaunchKernelGGL(sparse_store_kernel, dim3((unsigned)((points + 255) / 256), (unsigned)groups), dim3(256), 0, (hipStream_t)stream, values,
+                     indices, points, stride, out);
   FM_LAUNCH_STATUS();
 }
 

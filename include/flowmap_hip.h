@@ -139,7 +139,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
                           const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
                           int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,
                           float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, float* point_grads,
-                          void* stream);
+                          float* point_weight_grads, void* stream);
 
 /* Planned form of the sparse depth-sourced scatter.  With DISTINCT `indices` and constant flows the
  * pixels a step's Procrustes gradient touches never change: fm_procrustes_scatter_plan lists them
@@ -149,9 +149,14 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
  * point_grads (B·(F-1)·P, 2, 3) != NULL (depth source, indices given, batch_repeat 1): it writes
  * dL/dq, dL/dp per correspondence there, STORES grad_weights at the sampled pixels and leaves
  * grad_depth alone; fm_depth_gather (vectors = point_grads, entries = 2·(key index / 5) + (slot == 4))
- * adds the depth gradient without atomics. */
+ * adds the depth gradient without atomics.  With point_weight_grads (B·(F-1)·P) != NULL as well, dL/dweight
+ * per correspondence goes there instead of into grad_weights, and fm_sparse_store places it later —
+ * so the dense buffer can still be being zeroed (fm_fill_zero on another stream) while this runs. */
 int fm_procrustes_scatter_plan(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
                                int64_t* keys, float* weights, void* stream);
+
+/* out[g·stride + indices[j]] = values[g·points + j] for g < groups, j < points (see above). */
+int fm_sparse_store(const float* values, const int64_t* indices, long points, int groups, long stride, float* out, void* stream);
 
 /* get_extrinsics (projection.py:187-210): ext (B,steps+1,4,4), ext[0]=I,
  * ext[k] = ext[k-1]·rel[k-1]; and its backward (replaces the Python loop of matmuls). */
@@ -367,6 +372,12 @@ int fm_flow_postprocess(const float* videos, const float* flow, int batch, int f
  * align_corners=False)[y + row0][x + col0], out (planes, out_height, out_width). */
 int fm_resize_crop(const float* in, long planes, int height, int width, int resized_height, int resized_width, int row0, int col0,
                    int out_height, int out_width, float* out, void* stream);
+
+/* x[0..count) = 0 with at most `blocks` workgroups (16-byte non-temporal stores, x 16-byte aligned):
+ * the zero fill of a dense gradient buffer that only a few entries will be written into
+ * (dL/dweights of the sparse Procrustes fit, projection.py:226-249), sized so that it can run beside
+ * latency-bound kernels on another stream. */
+int fm_fill_zero(float* x, long count, int blocks, void* stream);
 
 /* ---- optimiser step ------------------------------------------
  * torch.optim.Adam as configured by ModelWrapperOverfit.configure_optimizers

@@ -356,6 +356,11 @@ int fm_resize_crop(const float* in, long planes, int h, int w, int rh, int rw, i
   return 0;
 }
 
+int fm_fill_zero(float* x, long count, int, void*) {
+  for (long i = 0; i < count; ++i) x[i] = 0.f;
+  return 0;
+}
+
 int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, long step, double lr, double beta1,
                  double beta2, double eps, double weight_decay, void*) {
   const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
@@ -454,6 +459,12 @@ int fm_procrustes_scatter_plan(const float* bwd_flow, const int64_t* indices, lo
   return 0;
 }
 
+int fm_sparse_store(const float* values, const int64_t* indices, long points, int groups, long stride, float* out, void*) {
+  for (int g = 0; g < groups; ++g)
+    for (long j = 0; j < points; ++j) out[(size_t)g * stride + indices[j]] = values[(size_t)g * points + j];
+  return 0;
+}
+
 int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux, void*) {
   for (int pr = 0; pr < pairs; ++pr)
     pose_solve_one(stats + (size_t)pr * kStatStride, t_bwd + (size_t)pr * 16, t_fwd ? t_fwd + (size_t)pr * 16 : nullptr,
@@ -473,7 +484,7 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float sens, const int64_t* indices, long points, int batch, int repeat, int frames,
                           int height, int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
-                          float* grad_weights, double* kinv_acc, float* point_grads, void*) {
+                          float* grad_weights, double* kinv_acc, float* point_grads, float* point_weight_grads, void*) {
   const int pairs = batch * (frames - 1);
   const size_t n = (size_t)height * width;
   if (point_grads) grad_depth = nullptr;  // planned form: the depth part goes through fm_depth_gather
@@ -513,7 +524,9 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
           point_grads[((size_t)pr * points + j) * 6 + a] = gq[a];
           point_grads[((size_t)pr * points + j) * 6 + 3 + a] = gp[a];
         }
-      if (grad_weights) {
+      if (point_grads && point_weight_grads) {
+        point_weight_grads[(size_t)pr * points + j] = gw;
+      } else if (grad_weights) {
         if (stores) grad_weights[dpair * n + c.idx] = gw;
         else grad_weights[dpair * n + c.idx] += gw;
       }

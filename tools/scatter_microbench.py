@@ -38,7 +38,7 @@ def run(name, a, b, c, reps=20):
     s.record()
     for _ in range(reps):
         call("fm_procrustes_scatter", ptr(depth), ptr(kinv), None, ptr(fb), ptr(wl), 100.0, ptr(idx), P, 1, 1, f, h, w, ptr(aux), ptr(pg),
-             ptr(a), None, ptr(b), ptr(c), None, st)
+             ptr(a), None, ptr(b), ptr(c), None, None, st)
     e.record()
     torch.cuda.synchronize()
     print(f"{name:28s} {s.elapsed_time(e) / reps * 1e3:8.1f} us")
