@@ -230,6 +230,25 @@ def case_procrustes_planned_backward(dev):
     assert got[0].isfinite().all()
 
 
+def case_fill_and_sparse_store(dev):
+    """fm_fill_zero (any count, bounded grid) and fm_sparse_store (out[g·stride + idx[j]] = values[g][j])."""
+    from flowmap_amd._lib import call, ptr, stream_for
+
+    for count, blocks in ((1, 4), (3, 1), (4, 1), (1027, 2), (50_001, 512), (262_144, 3)):
+        x = torch.full((count + 8,), 7.0, device=dev)
+        call("fm_fill_zero", ptr(x), count, blocks, stream_for(x))
+        assert bool((x[:count] == 0).all()) and bool((x[count:] == 7).all()), (count, blocks)
+    g = torch.Generator().manual_seed(0)
+    groups, points, stride = 5, 37, 211
+    idx = torch.randperm(stride, generator=g)[:points].to(dev)
+    values = torch.randn((groups, points), generator=g).to(dev)
+    out = torch.zeros((groups, stride), device=dev)
+    call("fm_sparse_store", ptr(values), ptr(idx), points, groups, stride, ptr(out), stream_for(out))
+    want = torch.zeros((groups, stride), device=dev)
+    want[:, idx] = values
+    assert torch.equal(out, want)
+
+
 def case_track_scatter_plan(dev):
     """The planned gather (fm_track_scatter_plan + fm_depth_gather) lands exactly where the atomic
     fm_track_scatter does, for visible / invisible / out-of-frame / border-clipped track points and

@@ -92,6 +92,10 @@ def test_procrustes_planned_backward():
     cases.case_procrustes_planned_backward("cpu")
 
 
+def test_fill_and_sparse_store():
+    cases.case_fill_and_sparse_store("cpu")
+
+
 def test_track_scatter_plan():
     cases.case_track_scatter_plan("cpu")
 
