@@ -204,3 +204,33 @@ def test_intrinsics_inverse_cache_follows_object_version_and_views():
     assert len(_ops._kinv_cache) <= _ops._KINV_CACHE_SLOTS
     last = _ops.intrinsics_inverse(keep[-1])
     assert _ops.intrinsics_inverse(keep[-1]).data_ptr() == last.data_ptr()
+
+
+def test_errors_of_the_preparation_and_intrinsics_entry_points_are_loud():
+    from flowmap_amd import Batch, _ops
+    from flowmap_amd.misc import cropping
+
+    videos = torch.rand((1, 2, 3, 12, 16))
+    with pytest.raises(RuntimeError, match="crop must fit"):
+        _ops.resize_crop(videos, (8, 8), (9, 8))
+    with pytest.raises(RuntimeError, match="float32"):
+        _ops.resize_crop(videos.double(), (8, 8), (8, 8))
+    out = _ops.resize_crop(videos, (12, 16), (12, 16))  # identity resize, no crop: a copy
+    assert torch.equal(out, videos) and out.data_ptr() != videos.data_ptr()
+    assert cropping.get_image_shape((37, 53), cropping.CroppingCfg(400, 2, 4)) == (17, 24)
+    assert cropping.compute_patch_cropped_shape((17, 24), 4) == (16, 24)
+    assert cropping.center_crop_intrinsics(None, (4, 4), (2, 2)) is None
+    with pytest.raises(RuntimeError, match="float32"):
+        _ops.focal_intrinsics(torch.tensor(0.9, dtype=torch.float64), (1, 2), (8, 8))
+    k = _ops.focal_intrinsics(torch.tensor(0.9), (1, 2), (8, 8))  # no gradient asked for: still fine, nothing parked
+    assert k.shape == (1, 2, 3, 3) and k.grad_fn is None
+    # the fused softmin tail: constants must not carry gradients, shapes are checked
+    depth, w, bwd = torch.rand((1, 2, 6, 8)) + 1, torch.rand((1, 1, 6, 8)), torch.zeros((1, 1, 6, 8, 2))
+    idx, cand, rel = torch.arange(5), torch.eye(3).repeat(4, 1, 1), torch.eye(4).repeat(4, 1, 1)
+    with pytest.raises(RuntimeError, match="constants"):
+        _ops.softmin_intrinsics(depth, w, bwd, idx, cand.clone().requires_grad_(True), rel, 0.0, 3)
+    with pytest.raises(RuntimeError, match="poses"):
+        _ops.softmin_intrinsics(depth, w, bwd, idx, cand, rel[:3], 0.0, 3)
+    k_soft, soft = _ops.softmin_intrinsics(depth, w, bwd, idx, cand, rel, 0.0, 3)
+    assert k_soft.shape == (1, 3, 3, 3) and soft.shape == (1, 4) and abs(float(soft.sum()) - 1) < 1e-6
+    assert Batch(videos).intrinsics is None
