@@ -1,39 +1,43 @@
-"""Drop-in for flowmap/loss/loss.py."""
+"""Drop-in for flowmap/loss/loss.py: the gate and the weight every loss shares."""
 
 from __future__ import annotations
 
-from abc import ABC, abstractmethod
 from dataclasses import dataclass
-from typing import Generic, Optional, TypeVar
+from typing import Optional
 
 import torch
 from torch import Tensor, nn
 
 
+def or_one(valid_sum: Tensor) -> Tensor:
+    """``valid_sum or 1`` (loss_flow.py:70, loss_tracking.py:61) without the device->host
+    sync of ``bool(tensor)``."""
+    return torch.where(valid_sum == 0, torch.ones_like(valid_sum), valid_sum)
+
+
 @dataclass
 class LossCfgCommon:
-    """flowmap/loss/loss.py:15-18"""
+    """flowmap/loss/loss.py:15-18: first step at which the loss counts, and its weight."""
 
     enable_after: int
     weight: float
 
 
-T = TypeVar("T", bound=LossCfgCommon)
+class Loss(nn.Module):
+    """flowmap/loss/loss.py:24-58.  ``Loss[Cfg]`` is accepted like the reference's generic base and
+    means nothing at run time."""
 
+    def __class_getitem__(cls, _cfg_type):
+        return cls
 
-class Loss(nn.Module, ABC, Generic[T]):
-    """flowmap/loss/loss.py:24-58: gate on ``enable_after``, multiply by ``weight``."""
-
-    cfg: T
-
-    def __init__(self, cfg: T) -> None:
+    def __init__(self, cfg: LossCfgCommon) -> None:
         super().__init__()
         self.cfg = cfg
 
     def forward(self, batch, flows, tracks: Optional[list], model_output, global_step: int) -> Tensor:
-        enabled = global_step >= self.cfg.enable_after  # loss.py:39-41: a constant 0 until then
-        if enabled:
+        if global_step >= self.cfg.enable_after:
             return self.compute_weighted_loss(batch, flows, tracks, model_output, global_step, self.cfg.weight)
+        # loss.py:39-41: a constant 0 until the loss is switched on
         return torch.zeros((), dtype=torch.float32, device=batch.videos.device)
 
     def compute_weighted_loss(self, batch, flows, tracks, model_output, global_step: int, weight: float) -> Tensor:
@@ -41,12 +45,5 @@ class Loss(nn.Module, ABC, Generic[T]):
         weight into the kernel's normaliser instead of launching a scalar multiply."""
         return weight * self.compute_unweighted_loss(batch, flows, tracks, model_output, global_step)
 
-    @abstractmethod
     def compute_unweighted_loss(self, batch, flows, tracks: Optional[list], model_output, global_step: int) -> Tensor:
-        pass
-
-
-def or_one(valid_sum: Tensor) -> Tensor:
-    """``valid_sum or 1`` (loss_flow.py:70, loss_tracking.py:61) without the device->host
-    sync of ``bool(tensor)``."""
-    return torch.where(valid_sum == 0, torch.ones_like(valid_sum), valid_sum)
+        raise NotImplementedError(f"{type(self).__name__} must implement compute_unweighted_loss (loss.py:49-58)")
