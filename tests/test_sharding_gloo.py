@@ -120,7 +120,7 @@ def test_two_rank_shards_match_unsharded_oracle(tmp_path):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_tracking_matches_unsharded_oracle(tmp_path, world):
     """Flow + tracking losses with the video split over `world` ranks: track segments straddle
     the shard borders (sources evaluated where their depth lives, poses all-gathered and chained,
