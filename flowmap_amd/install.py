@@ -8,6 +8,7 @@ both have to be patched.  After ``install()``, an unmodified
 
 from __future__ import annotations
 
+import dataclasses
 import importlib
 from typing import Dict, List, Tuple
 
@@ -156,7 +157,29 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
                 if hasattr(mod, name):
                     _set(mod, name, getattr(our_cropping, name))
 
+    if lazy_surfaces:
+        # flowmap/overfit.py:15-19 imports the package under jaxtyping's import hook, which type-checks
+        # dataclass fields on construction: ModelOutput(surfaces=<LazySurfaces>) would be rejected
+        # (model/model.py:24-30,83-89).  Model.forward therefore builds a subclass with the same fields
+        # and a plain constructor; every `model_output: ModelOutput` annotation still accepts it.
+        ref_model = importlib.import_module("flowmap.model.model")
+        _set(ref_model, "ModelOutput", _plain_constructor_subclass(ref_model.ModelOutput))
+
     our_projection.set_lazy_surfaces(lazy_surfaces)
+
+
+def _plain_constructor_subclass(base):
+    names = tuple(f.name for f in dataclasses.fields(base))
+
+    def __init__(self, *args, **kwargs):
+        values = dict(zip(names, args))
+        values.update(kwargs)
+        if set(values) != set(names) or len(args) > len(names):
+            raise TypeError(f"{base.__name__} takes the fields {names}")
+        for name in names:
+            setattr(self, name, values[name])
+
+    return type(base.__name__, (base,), {"__init__": __init__, "__module__": base.__module__, "__doc__": base.__doc__})
 
 
 def uninstall() -> None:

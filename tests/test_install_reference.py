@@ -207,6 +207,66 @@ def test_reference_flow_predictor_under_install(patched_reference):
     assert_close(again.forward_mask, g["a_forward_mask"], 1e-6, what="unpatched")
 
 
+def test_model_output_survives_a_field_checking_constructor():
+    """Under jaxtyping's import hook (flowmap/overfit.py:15-19) the reference's dataclasses check
+    their fields on construction.  Simulated here by a constructor that insists on tensors: after
+    install() Model.forward still returns a ModelOutput (a subclass with a plain constructor) that
+    carries the LazySurfaces; uninstall() restores the class."""
+    sys.dont_write_bytecode = True
+    added = [str(ROOT / "oracle" / "refstubs"), str(REF)]
+    sys.path[:0] = added
+    try:
+        import flowmap.model.model as ref_model
+        from flowmap.dataset.types import Batch
+        from flowmap.flow.flow_predictor import Flows
+        from flowmap.model.backbone.backbone_explicit_depth import BackboneExplicitDepthCfg
+        from flowmap.model.extrinsics.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+        from flowmap.model.intrinsics.intrinsics_regressed import IntrinsicsRegressedCfg
+
+        import flowmap_amd
+        from flowmap_amd import _lib
+        from flowmap_amd.model.projection import LazySurfaces
+        from helpers import build_host_sim
+        from oracle import flowmap_oracle as orc
+
+        original_cls, original_init = ref_model.ModelOutput, ref_model.ModelOutput.__init__
+
+        def checking_init(self, depths, surfaces, intrinsics, extrinsics, backward_correspondence_weights):
+            for value in (depths, surfaces, intrinsics, extrinsics, backward_correspondence_weights):
+                if not isinstance(value, torch.Tensor):
+                    raise TypeError("field is not a Tensor")
+            original_init(self, depths, surfaces, intrinsics, extrinsics, backward_correspondence_weights)
+
+        ref_model.ModelOutput.__init__ = checking_init
+        _lib.set_library_for_testing(build_host_sim())
+        try:
+            flowmap_amd.install()
+            f, h, w = 4, 12, 16
+            depth, _, of = orc.synth_iid(f, h, w, seed=3)
+            cfg = ref_model.ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", 0.85),
+                                     ExtrinsicsProcrustesCfg("procrustes", 50, False), True)
+            model = ref_model.Model(cfg, num_frames=f, image_shape=(h, w))
+            model.backbone.depth.data = depth
+            flows = Flows(of.forward, of.backward, of.forward_mask, of.backward_mask)
+            out = model(Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["s"], ["d"]), flows, 0)
+            assert isinstance(out, original_cls) and type(out) is not original_cls and type(out).__name__ == "ModelOutput"
+            assert isinstance(out.surfaces, LazySurfaces) and out.extrinsics.shape == (1, f, 4, 4)
+            assert [fl.name for fl in __import__("dataclasses").fields(out)][-1] == "backward_correspondence_weights"
+            with pytest.raises(TypeError):
+                type(out)(out.depths, out.surfaces)  # still needs every field
+            flowmap_amd.uninstall()
+            assert ref_model.ModelOutput is original_cls
+            with pytest.raises(TypeError, match="not a Tensor"):
+                original_cls(out.depths, out.surfaces, out.intrinsics, out.extrinsics, out.backward_correspondence_weights)
+        finally:
+            flowmap_amd.uninstall()
+            ref_model.ModelOutput.__init__ = original_init
+            _lib.set_library_for_testing(None)
+    finally:
+        for p in added:
+            sys.path.remove(p)
+
+
 def test_reference_regressed_intrinsics_under_install(patched_reference):
     """install() registers the one-launch IntrinsicsRegressed: same parameter name, K bit-identical
     to the reference class, same focal-length gradient; uninstall() restores the registry."""
