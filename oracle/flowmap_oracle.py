@@ -383,18 +383,21 @@ def synth_iid(f: int, h: int, w: int, seed: int = 0, dtype=torch.float32):
     return depth, wlogit, flows
 
 
-def synth_scene(f: int, h: int, w: int, seed: int = 0, focal: float = 0.85, depth_noise: float = 0.05):
+def synth_scene(f: int, h: int, w: int, seed: int = 0, focal: float = 0.85, depth_noise: float = 0.05, device="cpu"):
     """A geometrically consistent scene: static bumpy surface seen by a smoothly moving
     camera.  Ground-truth depth per frame is produced by fixed-point ray casting
     against a height field; ground-truth flows come from the oracle's own
     reprojection.  Returns dict with gt depth/poses/K, Flows, and a noisy init depth.
-    All fp32 outputs (generated in fp64).
+    All fp32 outputs (generated in fp64) on the CPU.  ``device``: where the generation runs
+    (the full-size fixtures of BASELINE.json configs[1..2] take minutes on host cores and
+    seconds on the GPU; the random draws are made on the CPU either way, so a scene is a
+    function of (seed, sizes) up to the rounding of the device's elementary functions).
     """
     g = torch.Generator().manual_seed(seed)
     dt = torch.float64
     hw = (h, w)
-    k = focal_to_k(torch.tensor(focal, dtype=dt), hw)
-    xy, _ = pixel_grid(hw, dtype=dt)
+    k = focal_to_k(torch.tensor(focal, dtype=dt), hw).to(device)
+    xy, _ = pixel_grid(hw, device=device, dtype=dt)
     rays = matvec(torch.linalg.inv(k), append_one(xy))  # (h, w, 3), z component 1
 
     # camera path: small translations + rotations
@@ -421,16 +424,16 @@ def synth_scene(f: int, h: int, w: int, seed: int = 0, focal: float = 0.85, dept
     for i in range(f):
         e[i, :3, :3] = rot(ang[i])
         e[i, :3, 3] = trans[i]
-    e = torch.linalg.inv(e[0])[None] @ e  # first pose = identity, like get_extrinsics
+    e = (torch.linalg.inv(e[0])[None] @ e).to(device)  # first pose = identity, like get_extrinsics
 
     def height(xw, yw):  # world surface z = height(x, y)
         return 2.0 + 0.25 * torch.sin(1.7 * xw + 0.3) * torch.cos(1.3 * yw - 0.2) + 0.1 * torch.sin(3.1 * xw * yw)
 
-    depth = torch.empty((f, h, w), dtype=dt)
+    depth = torch.empty((f, h, w), dtype=dt, device=device)
     for i in range(f):
         r = e[i, :3, :3]
         c = e[i, :3, 3]
-        d = torch.full((h, w), 2.0, dtype=dt)
+        d = torch.full((h, w), 2.0, dtype=dt, device=device)
         for _ in range(40):
             pw = matvec(r, rays * d[..., None]) + c
             # move along the ray so that the point lands on the surface
@@ -447,17 +450,19 @@ def synth_scene(f: int, h: int, w: int, seed: int = 0, focal: float = 0.85, dept
         return ((pos >= 0).all(-1) & (pos < 1).all(-1)).to(dt)
 
     flows = OFlows(
-        fwd.float(), bwd.float(), inside(fwd + xy).float(), inside(bwd + xy).float()
+        fwd.float().cpu(), bwd.float().cpu(), inside(fwd + xy).float().cpu(), inside(bwd + xy).float().cpu()
     )
+    del fwd, bwd, surfaces
     smooth = tnf.interpolate(
-        torch.randn((1, f, max(h // 16, 2), max(w // 16, 2)), generator=g, dtype=dt), size=(h, w), mode="bilinear", align_corners=False
+        torch.randn((1, f, max(h // 16, 2), max(w // 16, 2)), generator=g, dtype=dt).to(device), size=(h, w), mode="bilinear",
+        align_corners=False,
     )[0]
     init = depth * (1 + depth_noise * smooth)
     return {
-        "depth_gt": depth.float(),
-        "depth_init": init.float(),
-        "extrinsics_gt": e.float(),
-        "intrinsics_gt": k.float(),
+        "depth_gt": depth.float().cpu(),
+        "depth_init": init.float().cpu(),
+        "extrinsics_gt": e.float().cpu(),
+        "intrinsics_gt": k.float().cpu(),
         "focal": focal,
         "flows": flows,
     }
@@ -495,6 +500,50 @@ def synth_tracks(
         vis = inside & (torch.rand(inside.shape, generator=g) < p_visible)
         out.append(OTracks(xyt[None].contiguous(), vis[None].contiguous(), s))
     return out
+
+
+def _tap_pixels(xy01: Tensor, h: int, w: int):
+    """The (row, col) of the <= 4 pixels ``grid_sample(bilinear, border, align_corners=False)``
+    reads for normalised coordinates xy01 (..., 2), as (rows (..., 4), cols (..., 4), inside (..., 4))."""
+    ix = (xy01[..., 0].double() * w - 0.5).clamp(0, w - 1)
+    iy = (xy01[..., 1].double() * h - 0.5).clamp(0, h - 1)
+    x0, y0 = ix.floor().long(), iy.floor().long()
+    cols = torch.stack([x0, x0 + 1, x0, x0 + 1], dim=-1)
+    rows = torch.stack([y0, y0, y0 + 1, y0 + 1], dim=-1)
+    return rows, cols, (cols < w) & (rows < h)
+
+
+def procrustes_touched(hw, indices: Tensor, bwd_flow: Tensor) -> Tensor:
+    """Pixels of dL/ddepth the Procrustes fit writes to (projection.py:226-242): the sampled pixel
+    of every later frame and the bilinear taps of its flowed position in the earlier frame.
+    bwd_flow (1, F-1, H, W, 2) -> bool (F, H, W).  For the masked comparisons of the parity tests."""
+    h, w = hw
+    pairs = bwd_flow.shape[1]
+    mask = torch.zeros((pairs + 1, h * w), dtype=torch.bool)
+    xy, _ = pixel_grid(hw)
+    where = (xy + bwd_flow[0].cpu().float()).reshape(pairs, h * w, 2)[:, indices.cpu()]
+    rows, cols, inside = _tap_pixels(where, h, w)
+    flat = (rows * w + cols).clamp(0, h * w - 1)
+    for i in range(pairs):
+        mask[i + 1, indices.cpu()] = True
+        mask[i, flat[i][inside[i]]] = True
+    return mask.reshape(pairs + 1, h, w)
+
+
+def tracks_touched(hw, frames: int, tracks: Sequence[OTracks]) -> Tensor:
+    """Pixels of dL/ddepth the tracking loss writes to (projection.py:266-272): the bilinear taps of
+    every visible, in-frame track point.  -> bool (F, H, W)."""
+    h, w = hw
+    mask = torch.zeros((frames, h * w), dtype=torch.bool)
+    for seg in tracks:
+        xy = seg.xy[0].cpu().float()  # (f, P, 2)
+        live = seg.visibility[0].cpu() & (xy >= 0).all(-1) & (xy < 1).all(-1)
+        rows, cols, inside = _tap_pixels(xy, h, w)
+        flat = (rows * w + cols).clamp(0, h * w - 1)
+        keep = inside & live[..., None]
+        for j in range(xy.shape[0]):
+            mask[seg.start_frame + j, flat[j][keep[j]]] = True
+    return mask.reshape(frames, h, w)
 
 
 # --------------------------------------------------------------------------------------

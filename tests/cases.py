@@ -7,7 +7,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from conftest import assert_close, load_golden, t
+from conftest import assert_close, load_golden, maxerr, t
 from flowmap_amd import Tracks
 from flowmap_amd.loss.mapping import get_mapping
 from flowmap_amd.model import procrustes as fp
@@ -723,3 +723,73 @@ def case_capturable_pieces(dev):
         assert torch.equal(z, _ops.random_subset(5000, 64, dev, seed=3))  # explicit seeds stay stateless
     finally:
         _ops.graph_capturable = previous
+
+
+def _random_rigid(n, gen, angle=0.03, shift=0.05):
+    """n small rigid 4x4 transforms (fp64)."""
+    a = angle * torch.randn((n, 3), generator=gen, dtype=torch.float64)
+    zero = torch.zeros(n, dtype=torch.float64)
+    skew = torch.stack([zero, -a[:, 2], a[:, 1], a[:, 2], zero, -a[:, 0], -a[:, 1], a[:, 0], zero], dim=-1).reshape(n, 3, 3)
+    out = torch.eye(4, dtype=torch.float64).repeat(n, 1, 1)
+    out[:, :3, :3] = torch.linalg.matrix_exp(skew)
+    out[:, :3, 3] = shift * torch.randn((n, 3), generator=gen, dtype=torch.float64)
+    return out
+
+
+def case_flow_fused_leaves(dev, f, h, w, packed, kind="huber", seed=0, tol=TOL):
+    """The fused flow loss on its own, with the relative poses and a GENERAL per-frame K (all nine
+    entries free, different per frame) held as leaves: loss, dL/ddepth, per-frame dL/dK (b,F,3,3) and
+    dL/dT_fwd / dL/dT_bwd (b,F-1,4,4) against the fp64 oracle's autograd — every FRAME compared on
+    its own, so the per-frame reduction chain of the kernel (per-thread fp32 partials -> DPP wave
+    sum -> fp64 across waves -> fp64 atomics -> flow_finalize_frame) is pinned, not only dL/dfocal.
+    loss_flow.py:31-70, projection.py:76-90,116-134,143-184."""
+    from flowmap_amd import _ops
+
+    gen = torch.Generator().manual_seed(seed)
+    depth = 1.0 + 0.3 * torch.rand((1, f, h, w), generator=gen, dtype=torch.float64)
+    k = orc.focal_to_k(torch.tensor(0.85, dtype=torch.float64), (h, w)).repeat(1, f, 1, 1)
+    k = k + 0.02 * torch.randn((1, f, 3, 3), generator=gen, dtype=torch.float64)  # skew, free last row, per-frame
+    t_fwd = _random_rigid(f - 1, gen)[None]
+    t_bwd = _random_rigid(f - 1, gen)[None]  # an independent leaf, not the inverse of t_fwd
+    fl = orc.OFlows(
+        0.01 * torch.randn((1, f - 1, h, w, 2), generator=gen, dtype=torch.float64),
+        0.01 * torch.randn((1, f - 1, h, w, 2), generator=gen, dtype=torch.float64),
+        torch.rand((1, f - 1, h, w), generator=gen, dtype=torch.float64),
+        torch.rand((1, f - 1, h, w), generator=gen, dtype=torch.float64),
+    )
+    weight = 1000.0
+
+    # oracle, fp64 (the fp32 inputs ours sees, widened)
+    leaves32 = [x.float() for x in (depth, k, t_fwd, t_bwd)]
+    d64, k64, tf64, tb64 = (x.double().requires_grad_(True) for x in leaves32)
+    fl64 = orc.OFlows(*(x.float().double() for x in (fl.forward, fl.backward, fl.forward_mask, fl.backward_mask)))
+    xy, _ = orc.pixel_grid((h, w), dtype=torch.float64)
+    surfaces = orc.lift(xy, d64, k64[:, :, None, None])
+    fpos = orc.warp_points(surfaces[:, :-1], tf64[:, :, None, None], k64[:, 1:, None, None])
+    bpos = orc.warp_points(surfaces[:, 1:], tb64[:, :, None, None], k64[:, :-1, None, None])
+    num = (orc.robust(fpos - xy, fl64.forward, (h, w), kind) * fl64.forward_mask).sum() + (
+        orc.robust(bpos - xy, fl64.backward, (h, w), kind) * fl64.backward_mask).sum()
+    ref = weight * num / (fl64.forward_mask.sum() + fl64.backward_mask.sum())
+    ref.backward()
+
+    # ours
+    d, kk, tf, tb = (x.to(dev).requires_grad_(True) for x in leaves32)
+    ff, fb, mf, mb = (x.float().to(dev) for x in (fl.forward, fl.backward, fl.forward_mask, fl.backward_mask))
+    norm = _ops.flow_valid_norm(mf, mb, weight)
+    pk = None
+    if packed:
+        pk = _ops.packed_flow_inputs(ff, fb, mf, mb)
+        assert pk is not None, "the packed layout needs width % 4 == 0"
+    loss = _ops.FlowLossFused.apply(d, kk, tf, tb, ff, fb, mf, mb, norm, _ops.MAPPING_KINDS[kind], 0.01, False, 0, pk)
+    loss.backward()
+
+    assert_close(loss, ref, tol, what="loss")
+    assert_close(d.grad, d64.grad, tol, what="dL/ddepth")
+    assert maxerr(d.grad, d64.grad) <= 10 * tol, "dL/ddepth: max-abs"
+    for fr in range(f):
+        assert_close(d.grad[0, fr], d64.grad[0, fr], tol, what=f"dL/ddepth frame {fr}")
+        assert_close(kk.grad[0, fr], k64.grad[0, fr], tol, what=f"dL/dK frame {fr}")
+    for pr in range(f - 1):
+        assert_close(tf.grad[0, pr, :3], tf64.grad[0, pr, :3], tol, what=f"dL/dT_fwd pair {pr}")
+        assert_close(tb.grad[0, pr, :3], tb64.grad[0, pr, :3], tol, what=f"dL/dT_bwd pair {pr}")
+    assert float(tf.grad[0, :, 3].abs().max()) == 0.0 and float(tb.grad[0, :, 3].abs().max()) == 0.0  # [..., :3] drops the last row

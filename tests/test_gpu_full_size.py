@@ -1,0 +1,95 @@
+"""Parity at the sizes the headline numbers are quoted on: BASELINE.json configs[1] (150 frames @
+720x1280, flow loss, Procrustes P = 1000) and configs[2] (+ tracking: 30 segments x 1225 tracks, the
+layout of flowmap/tracking/__init__.py:49-70), HIP path vs the oracle run ONCE on the GPU box's host
+cores (about a minute: one forward, one backward per loss).  The scene is the consistent one of SURVEY.md §8d (generated
+on the GPU by the oracle's own functions, seconds instead of minutes), so every gradient —
+dL/dfocal included — is well conditioned and held to 1e-4; dL/ddepth is also compared element-wise
+and on the pixels the Procrustes fit / the tracks write to.
+
+FLOWMAP_SKIP_FULL_SIZE=1 skips the module (iteration runs); the oracle runs in fp64 when the host has
+the memory for it (>= 256 GB free), else in fp32 — the reference's own precision — and says which."""
+
+import os
+
+import pytest
+import torch
+
+from conftest import assert_close, assert_grad_close, relerr
+from helpers import mapping_cfg, run_ours, step_masks
+from oracle import flowmap_oracle as orc
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("FLOWMAP_SKIP_FULL_SIZE") == "1", reason="FLOWMAP_SKIP_FULL_SIZE=1")]
+DEV = "cuda:0"
+F, H, W, P = 150, 720, 1280, 1000
+FOCAL = 0.8  # not the scene's 0.85: dL/dfocal is then a first-order quantity
+
+
+def _host_memory_gb():
+    try:
+        import psutil
+
+        return psutil.virtual_memory().available / 2**30
+    except Exception:
+        return 0.0
+
+
+def build_reference(f, h, w, p, dev, dtype, **track_layout):
+    """(scene, weight logits, tracks, oracle results): one oracle forward, one backward per loss."""
+    sc = orc.synth_scene(f, h, w, seed=1, device=dev)
+    tracks = orc.synth_tracks(f, h, w, scene=sc, seed=1, **track_layout)  # default: every 5th frame, +-20 frames, 35 x 35 queries
+    wl = 0.01 * torch.randn((f - 1, h, w), generator=torch.Generator().manual_seed(7))
+    d = sc["depth_init"].to(dtype).requires_grad_(True)
+    wp = wl.to(dtype).requires_grad_(True)
+    fo = torch.tensor(FOCAL, dtype=dtype, requires_grad=True)
+    fl = orc.OFlows(*(x.to(dtype) for x in (sc["flows"].forward, sc["flows"].backward, sc["flows"].forward_mask, sc["flows"].backward_mask)))
+    tr = [orc.OTracks(t.xy.to(dtype), t.visibility, t.start_frame) for t in tracks]
+    total, parts, out = orc.explicit_depth_step(d, wp, fo, fl, (h, w), num_points=p, tracks=tr)
+    ref = {"dtype": dtype, "extrinsics": out.extrinsics.detach(), "loss_flow": parts["flow"].detach(), "loss_tracking": parts["tracking"].detach()}
+    for name, last in (("flow", False), ("tracking", True)):
+        g = torch.autograd.grad(parts[name], (d, wp, fo), retain_graph=not last)
+        ref[name] = {"g_depth": g[0], "g_wlogit": g[1], "g_focal": g[2]}
+    return sc, wl, tracks, ref
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    dtype = torch.float64 if _host_memory_gb() >= 256 else torch.float32
+    sc, wl, tracks, ref = build_reference(F, H, W, P, DEV, dtype)
+    assert len(tracks) == 30 and tracks[0].xy.shape[2] == 1225
+    return sc, wl, tracks, ref
+
+
+def check(ours, ref, grads, masks, what):
+    tol = 1e-4
+    print(f"[{what}] oracle dtype {ref['dtype']}")
+    for key in ("g_depth", "g_wlogit", "g_focal"):
+        print(f"[{what}] {key}: rel err {relerr(ours[key], grads[key]):.3e}")
+    assert_close(ours["extrinsics"], ref["extrinsics"], tol, what="extrinsics")
+    assert_grad_close(ours["g_depth"], grads["g_depth"], tol, masks=masks, what="g_depth")
+    assert_grad_close(ours["g_wlogit"], grads["g_wlogit"], tol, what="g_wlogit")
+    assert_close(ours["g_focal"], grads["g_focal"], tol, what="g_focal")
+
+
+def compare_flow_only(built, hw, p, dev):
+    sc, wl, _, ref = built
+    ours = run_ours(sc["depth_init"], wl, FOCAL, sc["flows"], hw, p, device=dev)
+    assert_close(ours["loss_flow"], ref["loss_flow"], 1e-4, what="loss_flow")
+    check(ours, ref, ref["flow"], step_masks(hw, p, sc["flows"]), "C1")
+
+
+def compare_flow_and_tracking(built, hw, p, dev):
+    sc, wl, tracks, ref = built
+    ours = run_ours(sc["depth_init"], wl, FOCAL, sc["flows"], hw, p, tracks, device=dev)
+    assert_close(ours["loss_flow"], ref["loss_flow"], 1e-4, what="loss_flow")
+    assert_close(ours["loss_tracking"], ref["loss_tracking"], 1e-4, what="loss_tracking")
+    both = {k: ref["flow"][k] + ref["tracking"][k] for k in ("g_depth", "g_wlogit", "g_focal")}
+    check(ours, ref, both, step_masks(hw, p, sc["flows"], tracks, frames=sc["depth_init"].shape[0]), "C2")
+
+
+def test_c1_flow_loss_150x720x1280_vs_oracle(full_size):
+    compare_flow_only(full_size, (H, W), P, DEV)
+
+
+def test_c2_flow_and_tracking_150x720x1280_vs_oracle(full_size):
+    compare_flow_and_tracking(full_size, (H, W), P, DEV)

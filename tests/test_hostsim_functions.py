@@ -118,3 +118,9 @@ def test_random_subset():
 
 def test_capturable_pieces():
     cases.case_capturable_pieces("cpu")
+
+
+@pytest.mark.parametrize("f,h,w,packed,kind", [(5, 12, 16, True, "huber"), (5, 12, 16, False, "huber"), (4, 9, 13, False, "l1"),
+                                                (3, 10, 12, True, "l2")])
+def test_flow_fused_leaves(f, h, w, packed, kind):
+    cases.case_flow_fused_leaves("cpu", f, h, w, packed, kind)

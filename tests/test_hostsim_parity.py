@@ -10,7 +10,7 @@ import torch
 import flowmap_amd
 from flowmap_amd import _lib
 from conftest import assert_close, load_golden, t
-from helpers import build_host_sim, run_oracle, run_ours
+from helpers import build_host_sim, compare_step, run_oracle, run_ours, step_masks
 from oracle import flowmap_oracle as orc
 from test_oracle_golden import _flows, _tracks
 
@@ -22,14 +22,8 @@ def host_double():
     _lib.set_library_for_testing(None)
 
 
-def compare(ours, ref, tol=1e-4, focal_tol=1e-3):
-    assert_close(ours["total"], ref["total"], tol, what="total")
-    assert_close(ours["loss_flow"], ref["loss_flow"], tol, what="loss_flow")
-    assert_close(ours["loss_tracking"], ref["loss_tracking"], tol, what="loss_tracking")
-    assert_close(ours["extrinsics"], ref["extrinsics"], tol, what="extrinsics")
-    assert_close(ours["g_depth"], ref["g_depth"], tol, what="g_depth")
-    assert_close(ours["g_wlogit"], ref["g_wlogit"], 3 * tol, what="g_wlogit")
-    assert_close(ours["g_focal"], ref["g_focal"], focal_tol, abs_=1e-4 * abs(float(ref["total"])), what="g_focal")
+def compare(ours, truth, ref32=None, masks=None):
+    compare_step(ours, truth, ref32, masks=masks)
 
 
 @pytest.mark.parametrize("lazy", [True, False])
@@ -42,16 +36,22 @@ def test_step_vs_reference_golden(name, kind, lazy):
     depth, wlogit = t(g["depth"]), t(g["wlogit"])
     npts = int(g["num_points"])
     ours = run_ours(depth, wlogit, float(g["focal"]), _flows(g), depth.shape[1:], None if npts < 0 else npts, _tracks(g), kind, lazy=lazy)
-    ref = {k: t(g[k]) for k in ("total", "loss_flow", "loss_tracking", "extrinsics", "g_depth", "g_wlogit", "g_focal")}
-    compare(ours, ref)
+    golden = {k: t(g[k]) for k in ("total", "loss_flow", "loss_tracking", "extrinsics", "g_depth", "g_wlogit", "g_focal")}
+    # the truth is the fp64 oracle on the golden inputs; the reference's fp32 golden values give its own gap
+    truth = run_oracle(depth, wlogit, float(g["focal"]), _flows(g), depth.shape[1:], None if npts < 0 else npts, _tracks(g), kind,
+                       dtype=torch.float64)
+    for key in ("total", "loss_flow", "loss_tracking", "extrinsics"):  # values: straight against the reference's own numbers too
+        assert_close(ours[key], golden[key], 1e-4, what=f"{key} vs golden")
+    compare(ours, truth, golden, masks=step_masks(depth.shape[1:], None if npts < 0 else npts, _flows(g), _tracks(g)))
 
 
 @pytest.mark.parametrize("f,h,w,p", [(4, 16, 24, 64), (3, 9, 13, None), (6, 32, 20, 200), (2, 8, 12, 30), (2, 8, 12, None)])
 def test_step_vs_oracle_fp64(f, h, w, p):
     depth, wlogit, flows = orc.synth_iid(f, h, w, seed=f * 7 + h)
     ours = run_ours(depth, wlogit, 0.85, flows, (h, w), p)
-    ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), p, dtype=torch.float64)
-    compare(ours, ref)
+    truth = run_oracle(depth, wlogit, 0.85, flows, (h, w), p, dtype=torch.float64)
+    ref32 = run_oracle(depth, wlogit, 0.85, flows, (h, w), p, dtype=torch.float32)
+    compare(ours, truth, ref32, masks=step_masks((h, w), p, flows))
 
 
 def test_loss_scale_and_carry():
@@ -81,3 +81,13 @@ def test_zero_masks_give_zero_loss():
     ours = run_ours(depth, wlogit, 0.85, flows, (h, w), 30)
     assert float(ours["total"]) == 0.0
     assert float(ours["g_depth"].abs().max()) == 0.0
+
+
+def test_full_size_module_logic_at_toy_size():
+    """tests/test_gpu_full_size.py (C1 / C2 at 150 x 720 x 1280 on the GPU) driven at 12 x 40 x 56 through
+    the host double: one oracle forward, one backward per loss, masked + element-wise comparison."""
+    import test_gpu_full_size as full
+
+    built = full.build_reference(12, 40, 56, 300, "cpu", torch.float64, interval=3, radius=4, grid=9)
+    full.compare_flow_only(built, (40, 56), 300, "cpu")
+    full.compare_flow_and_tracking(built, (40, 56), 300, "cpu")
