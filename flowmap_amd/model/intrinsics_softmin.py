@@ -67,7 +67,8 @@ class IntrinsicsSoftmin(nn.Module):
     # seed comes from torch's CPU generator, so torch.manual_seed still reproduces a run).  Tests
     # override this hook to feed identical indices to both implementations.
     def _draw_indices(self, count: int, device) -> Tensor:
-        return _ops.random_subset(count, self.cfg.num_procrustes_points, device)
+        # randperm(h*w)[:P] simply returns all h*w pixels when the image has fewer than P (intrinsics_softmin.py:90)
+        return _ops.random_subset(count, min(self.cfg.num_procrustes_points, count), device)
 
     def _candidate_intrinsics(self, b: int, image_shape):
         """K of every candidate and its (b*n, 2, 3, 3) spread over the frame pair the sweep fits.

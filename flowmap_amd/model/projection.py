@@ -137,7 +137,8 @@ class LazySurfaces:
 
     def __getitem__(self, item):
         # frame slices keep laziness: surfaces[:, s:e]  (loss_tracking.py:48-49)
-        if isinstance(item, tuple) and len(item) == 2 and item[0] == slice(None) and isinstance(item[1], slice):
+        if (isinstance(item, tuple) and len(item) == 2 and isinstance(item[0], slice) and item[0] == slice(None)
+                and isinstance(item[1], slice)):
             return LazySurfaces(self.depths[item], self.intrinsics[item])
         return self.materialize()[item]
 

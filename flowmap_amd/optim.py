@@ -78,4 +78,7 @@ class FusedAdam(torch.optim.Optimizer):
                         call("fm_adam_step", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
                              int(state["step"].item()), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
                              float(group["weight_decay"]), stream_for(p))
+                # the kernel wrote through raw pointers: tell autograd (saved-tensor checks) and every
+                # version-keyed cache that p, exp_avg and exp_avg_sq changed, as torch.optim.Adam's in-place ops do
+                torch._C._increment_version((p, state["exp_avg"], state["exp_avg_sq"]))
         return loss
