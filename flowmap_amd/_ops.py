@@ -359,6 +359,35 @@ def _procrustes_scatter_plan(indices: Tensor, bwd_flow: Tensor, b: int, f: int, 
     return entry[2]
 
 
+def _dense_procrustes_plan(bwd_flow: Tensor, b: int, f: int, h: int, w: int):
+    """(first int64 (pairs*tiles + 1), list uint32-as-int32 (entries)) of fm_procrustes_dense_plan: for every tile of
+    every pair's earlier frame, the later pixels whose bilinear taps land in it.  The flows are constants
+    of the optimisation, so this is built once per flow tensor and kept ON that tensor (it lives and dies
+    with it; an in-place edit bumps the version and the plan is rebuilt)."""
+    key = (bwd_flow._version, b, f, h, w)
+    hit = getattr(bwd_flow, "_fm_dense_plan", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    import ctypes
+
+    tiles = ctypes.c_int(0)
+    call("fm_procrustes_dense_tiles", h, w, ctypes.addressof(tiles))
+    dev = bwd_flow.device
+    slots = b * (f - 1) * tiles.value
+    with _guard(dev):
+        st = stream_for(bwd_flow)
+        counts = torch.zeros((slots,), dtype=torch.int32, device=dev)
+        call("fm_procrustes_dense_plan", ptr(bwd_flow), b, f, h, w, ptr(counts), None, None, st)
+        first = torch.zeros((slots + 1,), dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=first[1:])
+        total = int(first[-1].item())  # one host sync, when the plan is built
+        entries = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
+        counts.zero_()
+        call("fm_procrustes_dense_plan", ptr(bwd_flow), b, f, h, w, ptr(counts), ptr(first), ptr(entries), st)
+    bwd_flow._fm_dense_plan = (key, first, entries)
+    return first, entries
+
+
 class ProcrustesFit(torch.autograd.Function):
     """align_surfaces up to (not including) the pose chain (projection.py:213-249) with
     align_rigid (procrustes.py:7-51) inside.  Source of xyz is either
@@ -462,7 +491,7 @@ class ProcrustesFit(torch.autograd.Function):
             # footprint, and the P values per pair placed by fm_sparse_store after the join.)
             # the tiled dense kernels (depth-sourced, every pixel a correspondence) STORE every
             # element of dL/dweights; all other paths accumulate atomically into zeros
-            dense_tiled = ctx.from_depth and indices is None and ctx.rep == 1
+            dense_tiled = ctx.from_depth and indices is None and ctx.rep == 1 and h <= 65535 and w <= 65535
             prefilled, ctx._fm_prefilled = ctx._fm_prefilled, None
             if prefilled is not None:
                 g_w, fill_stream = prefilled  # being zeroed on the side stream; joined below
@@ -483,14 +512,22 @@ class ProcrustesFit(torch.autograd.Function):
         if fill_stream is not None and point_gw is None:
             torch.cuda.current_stream(dev).wait_stream(fill_stream)  # the scatter writes into g_w directly
             fill_stream = None
+        dense = ctx.from_depth and indices is None and ctx.rep == 1 and h <= 65535 and w <= 65535
         with _guard(dev):
             st = stream_for(weights)
             call("fm_pose_solve_bwd", ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr(aux), pairs, ptr(pair_grad), ptr(kinv_acc),
                  0 if kinv_acc is None else kinv_acc.numel(), st)
-            call("fm_procrustes_scatter", ptr(src) if ctx.from_depth else None, ptr(kinv), None if ctx.from_depth else ptr(src),
-                 ptr(bwd_flow), ptr(weights), ctx.weight_sens, ptr(indices), ctx.points, b, ctx.rep, f, h, w, ptr(aux), ptr(pair_grad),
-                 ptr(g_src) if ctx.from_depth else None, None if ctx.from_depth else ptr(g_src), ptr(g_w), ptr(kinv_acc),
-                 ptr(point_grads), ptr(point_gw), st)
+            if dense:  # every pixel a correspondence: tiled, planned, no atomics (fm_procrustes_scatter_dense)
+                first = entries = None
+                if g_src is not None:
+                    first, entries = _dense_procrustes_plan(bwd_flow, b, f, h, w)
+                call("fm_procrustes_scatter_dense", ptr(src), ptr(kinv), ptr(bwd_flow), ptr(weights), ctx.weight_sens, b, f, h, w, ptr(aux),
+                     ptr(pair_grad), ptr(g_src), ptr(g_w), ptr(kinv_acc), ptr(first), ptr(entries), st)
+            else:
+                call("fm_procrustes_scatter", ptr(src) if ctx.from_depth else None, ptr(kinv), None if ctx.from_depth else ptr(src),
+                     ptr(bwd_flow), ptr(weights), ctx.weight_sens, ptr(indices), ctx.points, b, ctx.rep, f, h, w, ptr(aux), ptr(pair_grad),
+                     ptr(g_src) if ctx.from_depth else None, None if ctx.from_depth else ptr(g_src), ptr(g_w), ptr(kinv_acc),
+                     ptr(point_grads), ptr(point_gw), st)
             if plan is not None and g_src is not None:
                 pixels, first, vectors, weights_e = plan
                 call("fm_depth_gather", ptr(point_grads), ptr(pixels), ptr(first), ptr(vectors), ptr(weights_e), pixels.numel(), ptr(kinv),

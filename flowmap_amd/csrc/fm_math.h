@@ -940,4 +940,158 @@ FM_HD void mat4_mul_nt(const double* a, const double* b, double* o) {  // a bᵀ
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Dense Procrustes (`num_points: null`: every pixel of every pair is a correspondence,
+// config/experiment/ablation_explicit_depth.yaml:11-12) in PIXEL SPACE.
+//
+// With g = z_l·[u, v, 1] (the later pixel) and h = Σ_taps w_k·z_k·[u_k, v_k, 1] (the bilinear
+// sample of the earlier frame, projection.py:231-242), the two points of a correspondence are
+//   p = K⁻¹_l·g,   q = K⁻¹_e·h,
+// linear maps that are CONSTANT per pair.  So the sums of align_rigid (procrustes.py:23-32) are
+// accumulated on (g, h) — no ray, no camera-space point per pixel — and the intrinsics are applied
+// once per pair in fp64 (dense_moments_finish).  The backward pass likewise: with the centred
+// gc = g − K_l·p̄, hc = h − K_e·q̄ and the per-pair constants of DenseBwd,
+//   t = Bm·gc + b0   ( = K⁻ᵀ_e·dL/dq / w )      s = Bmᵀ·hc + a0   ( = K⁻ᵀ_l·dL/dp / w )
+//   dL/dw       = hc·t + a0·gc
+//   dL/dz_l     = w·(s·[u, v, 1])
+//   dL/dz_tap k = w_k·w·(t·[u_k, v_k, 1])
+//   dL/dK⁻¹_l   = K_lᵀ·Σ (w·s) ⊗ g          dL/dK⁻¹_e = K_eᵀ·Σ (w·t) ⊗ h
+// (corr_backward above, rewritten; ≈60 flops per correspondence instead of ≈250).
+// ---------------------------------------------------------------------------------
+constexpr int kDenseTileH = 16, kDenseTileW = 64;  // tile of one workgroup (and of the static tap lists)
+
+// h from the four taps (nw, ne, sw, se): values z[k], west / east column coordinates u0 / u1,
+// north / south row coordinates v0 / v1.  Taps outside the image contribute nothing.
+FM_HD void dense_h(const Taps& t, const float z[4], float u0, float u1, float v0, float v1, float h[3]) {
+  const float t0 = t.in[0] ? t.w[0] * z[0] : 0.f, t1 = t.in[1] ? t.w[1] * z[1] : 0.f;
+  const float t2 = t.in[2] ? t.w[2] * z[2] : 0.f, t3 = t.in[3] ? t.w[3] * z[3] : 0.f;
+  h[0] = u0 * (t0 + t2) + u1 * (t1 + t3);
+  h[1] = v0 * (t0 + t1) + v1 * (t2 + t3);
+  h[2] = (t0 + t1) + (t2 + t3);
+}
+
+// Raw moments about the per-pair shift gs (a point inside both clouds):
+//   [0] Σw  [1..3] Σ w g'  [4..6] Σ w h'  [7..15] Σ w h' g'ᵀ      g' = g − gs, h' = h − gs
+FM_HD void dense_moments_add(const float g[3], const float h[3], float w, const float gs[3], float (&acc)[kMomentCount]) {
+  const float g0 = g[0] - gs[0], g1 = g[1] - gs[1], g2 = g[2] - gs[2];
+  acc[0] += w;
+  acc[1] = fmaf(w, g0, acc[1]);
+  acc[2] = fmaf(w, g1, acc[2]);
+  acc[3] = fmaf(w, g2, acc[3]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float wh = w * (h[a] - gs[a]);
+    acc[4 + a] += wh;
+    acc[7 + a * 3 + 0] = fmaf(wh, g0, acc[7 + a * 3 + 0]);
+    acc[7 + a * 3 + 1] = fmaf(wh, g1, acc[7 + a * 3 + 1]);
+    acc[7 + a * 3 + 2] = fmaf(wh, g2, acc[7 + a * 3 + 2]);
+  }
+}
+
+// The shift of a pair: g of its middle pixel (non-finite depth -> 0, as later_point).
+FM_HD void dense_shift(const float* depth_l, int height, int width, float gs[3]) {
+  const int idx = (int)(((long)height * width) / 2);
+  const int row = idx / width, col = idx - row * width;
+  const float z = depth_l[idx];
+  gs[0] = z * pixel_center(col, width);
+  gs[1] = z * pixel_center(row, height);
+  gs[2] = z;
+  for (int a = 0; a < 3; ++a)
+    if (!(fabsf(gs[a]) <= 3.0e38f)) gs[a] = 0.f;
+}
+
+// In place: raw pixel-space moments -> [0] Σw, [1..3] Σw·p, [4..6] Σw·q, [7..15] M = Σ w (q−q̄)(p−p̄)ᵀ
+// (the layout pose_solve_one reads), all in fp64.
+FM_HD void dense_moments_finish(double* st, const float gs[3], const float* kinv_e, const float* kinv_l) {
+  const double w = st[0];
+  double gsum[3], hsum[3], hg[9];
+  for (int a = 0; a < 3; ++a) {
+    gsum[a] = st[1 + a] + w * (double)gs[a];  // Σ w g
+    hsum[a] = st[4 + a] + w * (double)gs[a];  // Σ w h
+  }
+  for (int a = 0; a < 3; ++a)
+    for (int d = 0; d < 3; ++d)  // Σ w h gᵀ = Σ w (h'+gs)(g'+gs)ᵀ
+      hg[a * 3 + d] = st[7 + a * 3 + d] + st[4 + a] * (double)gs[d] + (double)gs[a] * st[1 + d] + w * (double)gs[a] * (double)gs[d];
+  double ke[9], kl[9], psum[3], qsum[3], tmp[9], c[9];
+  for (int i = 0; i < 9; ++i) {
+    ke[i] = kinv_e[i];
+    kl[i] = kinv_l[i];
+  }
+  for (int a = 0; a < 3; ++a) {
+    psum[a] = kl[a * 3 + 0] * gsum[0] + kl[a * 3 + 1] * gsum[1] + kl[a * 3 + 2] * gsum[2];
+    qsum[a] = ke[a * 3 + 0] * hsum[0] + ke[a * 3 + 1] * hsum[1] + ke[a * 3 + 2] * hsum[2];
+  }
+  mat3_mul(ke, hg, tmp);
+  mat3_mul_nt(tmp, kl, c);  // Σ w q pᵀ
+  const double inv = 1.0 / (w + 1e-8);
+  for (int a = 0; a < 3; ++a)
+    for (int d = 0; d < 3; ++d) {
+      const double qb = qsum[a] * inv, pb = psum[d] * inv;
+      st[7 + a * 3 + d] = c[a * 3 + d] - qb * psum[d] - qsum[a] * pb + w * qb * pb;
+    }
+  for (int a = 0; a < 3; ++a) {
+    st[1 + a] = psum[a];
+    st[4 + a] = qsum[a];
+  }
+}
+
+struct DenseBwd {
+  float bm[9];    // K⁻ᵀ_e·dL/dM·K⁻¹_l
+  float a0[3];    // K⁻ᵀ_l·dL/dp̄ / (Σw + 1e-8)
+  float b0[3];    // K⁻ᵀ_e·dL/dq̄ / (Σw + 1e-8)
+  float gbar[3];  // K_l·p̄
+  float hbar[3];  // K_e·q̄
+};
+
+FM_HD void inv3d(const double* m, double* o) {
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const double inv_det = 1.0 / (a * A + b * B + c * C);
+  o[0] = A * inv_det, o[1] = -(b * i - c * h) * inv_det, o[2] = (b * f - c * e) * inv_det;
+  o[3] = B * inv_det, o[4] = (a * i - c * g) * inv_det, o[5] = -(a * f - c * d) * inv_det;
+  o[6] = C * inv_det, o[7] = -(a * h - b * g) * inv_det, o[8] = (a * e - b * d) * inv_det;
+}
+
+// pg: the pair's row of pair_grad (gM 9, dL/dq̄ 3, dL/dp̄ 3, d̄, 1/(Σw+1e-8)); ax: its row of aux (p̄ at 21, q̄ at 24).
+// k_e / k_l (out, fp64 3x3): the forward intrinsics of the two frames (inverse of K⁻¹).
+FM_HD void dense_bwd_consts(const double* pg, const double* ax, const float* kinv_e, const float* kinv_l, DenseBwd& o, double* k_e,
+                            double* k_l) {
+  double ke[9], kl[9], tmp[9], bm[9];
+  for (int i = 0; i < 9; ++i) {
+    ke[i] = kinv_e[i];
+    kl[i] = kinv_l[i];
+  }
+  mat3_mul_tn(ke, pg, tmp);
+  mat3_mul(tmp, kl, bm);
+  inv3d(ke, k_e);
+  inv3d(kl, k_l);
+  const double iw = pg[16];
+  for (int i = 0; i < 9; ++i) o.bm[i] = (float)bm[i];
+  for (int a = 0; a < 3; ++a) {
+    o.a0[a] = (float)((kl[0 * 3 + a] * pg[12] + kl[1 * 3 + a] * pg[13] + kl[2 * 3 + a] * pg[14]) * iw);
+    o.b0[a] = (float)((ke[0 * 3 + a] * pg[9] + ke[1 * 3 + a] * pg[10] + ke[2 * 3 + a] * pg[11]) * iw);
+    o.gbar[a] = (float)(k_l[a * 3 + 0] * ax[21] + k_l[a * 3 + 1] * ax[22] + k_l[a * 3 + 2] * ax[23]);
+    o.hbar[a] = (float)(k_e[a * 3 + 0] * ax[24] + k_e[a * 3 + 1] * ax[25] + k_e[a * 3 + 2] * ax[26]);
+  }
+}
+
+// t (needs only g: the earlier-role scatter does not sample the earlier frame)
+FM_HD void dense_bwd_t(const DenseBwd& c, const float g[3], float t[3], float gc[3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) gc[a] = g[a] - c.gbar[a];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) t[a] = fmaf(c.bm[a * 3 + 0], gc[0], fmaf(c.bm[a * 3 + 1], gc[1], fmaf(c.bm[a * 3 + 2], gc[2], c.b0[a])));
+}
+
+// s and dL/dw (need h as well)
+FM_HD void dense_bwd_s(const DenseBwd& c, const float h[3], const float t[3], const float gc[3], float s[3], float& gw) {
+  float hc[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) hc[a] = h[a] - c.hbar[a];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) s[a] = fmaf(c.bm[0 * 3 + a], hc[0], fmaf(c.bm[1 * 3 + a], hc[1], fmaf(c.bm[2 * 3 + a], hc[2], c.a0[a])));
+  gw = hc[0] * t[0] + hc[1] * t[1] + hc[2] * t[2] + c.a0[0] * gc[0] + c.a0[1] * gc[1] + c.a0[2] * gc[2];
+}
+
 }  // namespace fm

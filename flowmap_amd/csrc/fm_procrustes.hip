@@ -232,15 +232,22 @@ __global__ void __launch_bounds__(256) procrustes_scatter_repeat_kernel(ProcPara
 
 // ---------------------------------------------------------------------------------
 // Dense mode (all H·W pixels are correspondences: `num_points: null`, the reference's
-// explicit-depth configuration, config/experiment/ablation_explicit_depth.yaml).  The generic
-// kernels above pay four scattered depth gathers per point and, in backward, four scattered float
-// atomics on cold lines (22 ms at C1).  Here a block owns a 16x64 tile of later-frame pixels and
-// an LDS window of the EARLIER frame around where the tile's samples land (tile displaced by the
-// backward flow at its centre, +-16 rows / +-24 columns): the depth taps are LDS reads, the tap
-// gradients LDS atomics, and the window is flushed with coalesced atomics.  Samples that leave the
-// window fall back to global memory.
+// explicit-depth configuration, config/experiment/ablation_explicit_depth.yaml:11-12), in pixel
+// space (fm_math.h "Dense Procrustes"): per correspondence ≈110 instructions forward, no ray, no
+// camera-space point.  Three tiled kernels, NO atomics on dL/ddepth or dL/dweights:
+//   moments      block = 16x64 tile of LATER-frame pixels + an LDS window of the EARLIER frame's
+//                depth around where the tile's samples land (tile displaced by the backward flow at
+//                its centre, +-16 rows / +-24 columns; samples outside fall back to global memory)
+//   bwd_later    same blocks: dL/dweights (stored), the later pixel's own dL/ddepth (plain +=),
+//                the intrinsics sums of both roles
+//   bwd_taps     block = 16x64 tile of EARLIER-frame pixels; walks the static list of the later
+//                pixels whose bilinear taps land in the tile (flows are constants of the
+//                optimisation: the list is built once, fm_procrustes_dense_plan_*), accumulates
+//                their tap gradients in an LDS tile and adds the tile to dL/ddepth with plain,
+//                coalesced read-modify-writes.  Needs only (flow, weight, z) of the later pixel —
+//                dL/dq does not depend on the sampled point.
 // ---------------------------------------------------------------------------------
-constexpr int kTileH = 16, kTileW = 64, kHaloY = 16, kHaloX = 24;
+constexpr int kTileH = kDenseTileH, kTileW = kDenseTileW, kHaloY = 16, kHaloX = 24;
 constexpr int kWinH = kTileH + 2 * kHaloY, kWinW = kTileW + 2 * kHaloX;  // 48 x 112 floats = 21 KB
 
 struct DenseTile {
@@ -259,8 +266,8 @@ struct DenseBlock {
   bool valid;
 };
 
-__device__ __forceinline__ DenseBlock dense_block(const ProcParams& p, long total) {
-  const int tiles_x = (p.width + kTileW - 1) / kTileW, tiles_y = (p.height + kTileH - 1) / kTileH;
+__device__ __forceinline__ DenseBlock dense_block(int height, int width, long total) {
+  const int tiles_x = (width + kTileW - 1) / kTileW, tiles_y = (height + kTileH - 1) / kTileH;
   const long per_xcd = (total + kXcds - 1) / kXcds;
   const long logical = (long)(blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
   DenseBlock d;
@@ -309,59 +316,255 @@ __device__ __forceinline__ void stage_depth_window(const ProcParams& p, const Co
   for (int i = threadIdx.x; i < kTileH; i += blockDim.x) win.tile_v[i] = pixel_center(t.ty0 + i, p.height);
 }
 
-// window cell of image pixel (row, col), or -1
-__device__ __forceinline__ int window_cell(const DenseTile& t, int row, int col) {
-  const int r = row - t.wy0, c = col - t.wx0;
-  return (r >= 0 && r < kWinH && c >= 0 && c < kWinW) ? r * kWinW + c : -1;
-}
+// One dense correspondence before any intrinsics: g, h, w and its taps.  The four tap depths and
+// their coordinates come from the LDS window when the 2x2 footprint lies inside it, else from
+// global memory (reciprocal multiply instead of sample_image_grid's true division there: within
+// 1 ulp, and the divisions would otherwise run for every wave in which a single lane misses).
+struct DensePixel {
+  float g[3], h[3], w, u, v;
+  Taps taps;
+};
 
-// depth + coordinates of earlier-frame pixel (row, col): window hit or global fallback
-__device__ __forceinline__ float window_tap(const ProcParams& p, const CorrSrc& src, const DenseTile& t, const DenseWindow& win, int row,
-                                            int col, float& ut, float& vt) {
-  const int r = row - t.wy0, c = col - t.wx0;
-  if (r >= 0 && r < kWinH && c >= 0 && c < kWinW) {
-    ut = win.u[c];
-    vt = win.v[r];
-    return win.z[r * kWinW + c];
+template <bool FAST>
+__device__ __forceinline__ DensePixel dense_pixel(const ProcParams& p, const CorrSrc& src, const DenseTile& t, const DenseWindow& win, int row,
+                                                  int col, int r, int c) {
+  DensePixel o;
+  const int idx = row * p.width + col;
+  o.u = win.tile_u[c];
+  o.v = win.tile_v[r];
+  const float2 fl = reinterpret_cast<const float2*>(src.bwd_flow)[idx];
+  float w = src.weights[idx];
+  if (src.weight_sens != 0.f) w = fm_sigmoid<FAST>(src.weight_sens * w);
+  o.w = w;
+  const float z = src.depth_l[idx];
+  o.g[0] = z * o.u;
+  o.g[1] = z * o.v;
+  o.g[2] = z;
+  o.taps = bilinear_taps(o.u + fl.x, o.v + fl.y, p.height, p.width);
+  const int wr = o.taps.y0 - t.wy0, wc = o.taps.x0 - t.wx0;
+  float zt[4], u0, u1, v0, v1;
+  if (wr >= 0 && wr + 1 < kWinH && wc >= 0 && wc + 1 < kWinW) {
+    const float* zw = win.z + wr * kWinW + wc;
+    zt[0] = zw[0], zt[1] = zw[1], zt[2] = zw[kWinW], zt[3] = zw[kWinW + 1];
+    u0 = win.u[wc], u1 = win.u[wc + 1], v0 = win.v[wr], v1 = win.v[wr + 1];
+  } else {
+    const int x1 = min(o.taps.x0 + 1, p.width - 1), y1 = min(o.taps.y0 + 1, p.height - 1);  // clamped reads; masked by taps.in
+    const float* d0 = src.depth_e + (size_t)o.taps.y0 * p.width;
+    const float* d1 = src.depth_e + (size_t)y1 * p.width;
+    zt[0] = d0[o.taps.x0], zt[1] = d0[x1], zt[2] = d1[o.taps.x0], zt[3] = d1[x1];
+    u0 = ((float)o.taps.x0 + 0.5f) * t.inv_w, u1 = ((float)o.taps.x0 + 1.5f) * t.inv_w;
+    v0 = ((float)o.taps.y0 + 0.5f) * t.inv_h, v1 = ((float)o.taps.y0 + 1.5f) * t.inv_h;
   }
-  // sample left the window (rare with real flows): reciprocal multiply instead of the true
-  // division of sample_image_grid — within 1 ulp, and the divisions would otherwise run for every
-  // wave in which a single lane misses
-  ut = ((float)col + 0.5f) * t.inv_w;
-  vt = ((float)row + 0.5f) * t.inv_h;
-  return src.depth_e[(size_t)row * p.width + col];
+  dense_h(o.taps, zt, u0, u1, v0, v1, o.h);
+  return o;
 }
 
-// grid: 1-D, >= tiles·pairs blocks (dense_block).  Raw moments of all pixels of the tile.
+// grid: 1-D, >= tiles·pairs blocks (dense_block).  Raw pixel-space moments of the tile's pixels.
 __global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParams p, long total) {
   __shared__ double red[4 * kMomentCount];
   __shared__ DenseWindow win;
-  const DenseBlock blk = dense_block(p, total);
+  const DenseBlock blk = dense_block(p.height, p.width, total);
   if (!blk.valid) return;
   const size_t pair = (size_t)blk.pair;
   const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
-  Mat3 kinv_e, kinv_l;
-  load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
-  load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
   const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
-  float shift[3];
-  pair_shift<SRC_DEPTH>(p, src, kinv_l, shift);
+  float gs[3];
+  dense_shift(src.depth_l, p.height, p.width, gs);
   const DenseTile t = dense_tile(p, src, blk);
   stage_depth_window(p, src, t, win);
   __syncthreads();
   float acc[kMomentCount];
 #pragma unroll
   for (int k = 0; k < kMomentCount; ++k) acc[k] = 0.f;
-  const int col = t.tx0 + (threadIdx.x & (kTileW - 1));
+  const int c = threadIdx.x & (kTileW - 1);
+  const int col = t.tx0 + c;
   for (int r = threadIdx.x / kTileW; r < kTileH; r += 256 / kTileW) {
     const int row = t.ty0 + r;
     if (row >= p.height || col >= p.width) continue;
-    const PixelRef px{row * p.width + col, win.tile_u[threadIdx.x & (kTileW - 1)], win.tile_v[r]};
-    const Corr c = corr_load_with<true>(src, kinv_e, kinv_l, px,
-                                        [&](int tr, int tc, float& ut, float& vt) { return window_tap(p, src, t, win, tr, tc, ut, vt); });
-    moments_add(c, shift, acc);
+    const DensePixel px = dense_pixel<true>(p, src, t, win, row, col, r, c);
+    dense_moments_add(px.g, px.h, px.w, gs, acc);
   }
   block_accumulate<kMomentCount>(acc, red, p.stats + pair * kStatStride);
+}
+
+// One thread per pair: pixel-space raw moments -> the statistics of align_rigid -> the pose.
+__global__ void procrustes_finish_solve_dense_kernel(ProcParams p, int pairs, float* t_bwd, float* t_fwd, double* aux) {
+  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= pairs) return;
+  const int b = pair / (p.frames - 1), i = pair % (p.frames - 1);
+  const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
+  float gs[3];
+  dense_shift(src.depth_l, p.height, p.width, gs);
+  double* st = p.stats + (size_t)pair * kStatStride;
+  dense_moments_finish(st, gs, p.kinv + ((size_t)b * p.frames + i) * 9, p.kinv + ((size_t)b * p.frames + i + 1) * 9);
+  if (t_bwd) pose_solve_one(st, t_bwd + (size_t)pair * 16, t_fwd ? t_fwd + (size_t)pair * 16 : nullptr, aux + (size_t)pair * kAuxStride);
+}
+
+// The per-pair constants of the dense backward, computed by the first threads of a block (fp64).
+struct DenseBwdShared {
+  DenseBwd c;
+  double k_e[9], k_l[9];
+};
+
+__device__ __forceinline__ void dense_bwd_setup(const ProcParams& p, const double* aux, size_t pair, int b, int i, DenseBwdShared& sh) {
+  if (threadIdx.x == 0)
+    dense_bwd_consts(p.pair_grad + pair * kPairGradStride, aux + pair * kAuxStride, p.kinv + ((size_t)b * p.frames + i) * 9,
+                     p.kinv + ((size_t)b * p.frames + i + 1) * 9, sh.c, sh.k_e, sh.k_l);
+}
+
+// Dense backward, later role.  dL/dweights STORED (every element of every pair exactly once),
+// dL/ddepth of the later pixel added in place (this launch is the only writer of that pixel),
+// Σ (w·s) ⊗ g and Σ (w·t) ⊗ h reduced per block and mapped through K_lᵀ / K_eᵀ into kinv_acc.
+__global__ void __launch_bounds__(256) procrustes_dense_bwd_later_kernel(ProcParams p, const double* aux, long total) {
+  __shared__ double red[4 * 18];
+  __shared__ double tot[18];
+  __shared__ DenseWindow win;
+  __shared__ DenseBwdShared sh;
+  const DenseBlock blk = dense_block(p.height, p.width, total);
+  if (!blk.valid) return;
+  const size_t pair = (size_t)blk.pair;
+  const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
+  const size_t n = (size_t)p.height * p.width;
+  const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
+  const size_t fe = (size_t)b * p.frames + i, fl = fe + 1;
+  const DenseTile t = dense_tile(p, src, blk);
+  dense_bwd_setup(p, aux, pair, b, i, sh);
+  stage_depth_window(p, src, t, win);
+  __syncthreads();
+  const DenseBwd cst = sh.c;
+
+  float acc[18];  // [0..8] Σ (w·t) ⊗ h (earlier frame), [9..17] Σ (w·s) ⊗ g (later frame)
+#pragma unroll
+  for (int k = 0; k < 18; ++k) acc[k] = 0.f;
+  const int c = threadIdx.x & (kTileW - 1);
+  const int col = t.tx0 + c;
+  for (int r = threadIdx.x / kTileW; r < kTileH; r += 256 / kTileW) {
+    const int row = t.ty0 + r;
+    if (row >= p.height || col >= p.width) continue;
+    const int idx = row * p.width + col;
+    const DensePixel px = dense_pixel<true>(p, src, t, win, row, col, r, c);
+    float tv[3], gc[3], sv[3], gw;
+    dense_bwd_t(cst, px.g, tv, gc);
+    dense_bwd_s(cst, px.h, tv, gc, sv, gw);
+    if (p.weight_sens != 0.f) gw *= p.weight_sens * px.w * (1.f - px.w);  // d sigmoid(s·x)/dx
+    if (p.grad_weights) p.grad_weights[pair * n + idx] = gw;
+    if (p.grad_depth) p.grad_depth[fl * n + idx] += px.w * fmaf(sv[0], px.u, fmaf(sv[1], px.v, sv[2]));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float wt = px.w * tv[a], ws = px.w * sv[a];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        acc[a * 3 + d] = fmaf(wt, px.h[d], acc[a * 3 + d]);
+        acc[9 + a * 3 + d] = fmaf(ws, px.g[d], acc[9 + a * 3 + d]);
+      }
+    }
+  }
+  if (p.kinv_acc) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      const float sum = wave_sum_lane63(acc[k]);
+      if (lane == kWave - 1) red[wave * 18 + k] = (double)sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 18) tot[threadIdx.x] = red[threadIdx.x] + red[18 + threadIdx.x] + red[36 + threadIdx.x] + red[54 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 18) {  // dL/dK⁻¹ = Kᵀ·(Σ …): element (r, d) of frame `which`
+      const int which = threadIdx.x / 9, r = (threadIdx.x % 9) / 3, d = threadIdx.x % 3;
+      const double* k = which == 0 ? sh.k_e : sh.k_l;
+      const double* a = tot + which * 9;
+      const double v = k[0 * 3 + r] * a[0 * 3 + d] + k[1 * 3 + r] * a[1 * 3 + d] + k[2 * 3 + r] * a[2 * 3 + d];
+      if (v != 0.0) atomicAdd(p.kinv_acc + fe * 9 + threadIdx.x, v);
+    }
+  }
+}
+
+// Later pixels are listed per earlier-frame tile as (row << 16 | col).
+__device__ __forceinline__ uint32_t pack_pixel(int row, int col) { return ((uint32_t)row << 16) | (uint32_t)col; }
+
+// The <= 4 earlier-frame tiles the taps of later pixel (row, col) of `pair` land in; fn(tile index).
+template <class Fn>
+__device__ __forceinline__ void dense_tap_tiles(const float* bwd_flow_pair, int height, int width, int row, int col, const Fn& fn) {
+  const float2 fl = reinterpret_cast<const float2*>(bwd_flow_pair)[(size_t)row * width + col];
+  const Taps t = bilinear_taps(pixel_center(col, width) + fl.x, pixel_center(row, height) + fl.y, height, width);
+  const int tiles_x = (width + kTileW - 1) / kTileW;
+  const int txa = t.x0 / kTileW, tya = t.y0 / kTileH;
+  const int txb = (t.x0 + 1 < width) ? (t.x0 + 1) / kTileW : txa, tyb = (t.y0 + 1 < height) ? (t.y0 + 1) / kTileH : tya;
+  fn(tya * tiles_x + txa);
+  if (txb != txa) fn(tya * tiles_x + txb);
+  if (tyb != tya) {
+    fn(tyb * tiles_x + txa);
+    if (txb != txa) fn(tyb * tiles_x + txb);
+  }
+}
+
+// Plan, pass 1 (list == null): counts[pair·tiles + tile] += 1 per (later pixel, tile it touches);
+// pass 2: list[first[...] + cursor++] = packed later pixel.  grid: (pixel chunks, pairs).
+__global__ void __launch_bounds__(256) procrustes_dense_plan_kernel(const float* bwd_flow, int height, int width, int* counts,
+                                                                     const int64_t* first, uint32_t* list) {
+  const size_t pair = blockIdx.y;
+  const long n = (long)height * width;
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int row = (int)(j / width), col = (int)(j - (long)row * width);
+  const int tiles = ((width + kTileW - 1) / kTileW) * ((height + kTileH - 1) / kTileH);
+  int* cnt = counts + pair * tiles;
+  dense_tap_tiles(bwd_flow + pair * (size_t)n * 2, height, width, row, col, [&](int tile) {
+    const int pos = atomicAdd(cnt + tile, 1);
+    if (list) list[first[pair * tiles + tile] + pos] = pack_pixel(row, col);
+  });
+}
+
+// Dense backward, earlier role: block = (pair, tile of the EARLIER frame).
+__global__ void __launch_bounds__(256) procrustes_dense_bwd_taps_kernel(ProcParams p, const double* aux, const int64_t* first,
+                                                                         const uint32_t* list, long total) {
+  __shared__ float gacc[kTileH * kTileW];
+  __shared__ float tile_u[kTileW + 1], tile_v[kTileH + 1];
+  __shared__ DenseBwdShared sh;
+  const DenseBlock blk = dense_block(p.height, p.width, total);
+  if (!blk.valid) return;
+  const size_t pair = (size_t)blk.pair;
+  const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
+  const size_t n = (size_t)p.height * p.width;
+  const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
+  const size_t fe = (size_t)b * p.frames + i;
+  const int tx0 = blk.tile_x * kTileW, ty0 = blk.tile_y * kTileH;
+  const int tiles_x = (p.width + kTileW - 1) / kTileW, tiles_y = (p.height + kTileH - 1) / kTileH;
+  dense_bwd_setup(p, aux, pair, b, i, sh);
+  for (int c = threadIdx.x; c < kTileH * kTileW; c += blockDim.x) gacc[c] = 0.f;
+  for (int c = threadIdx.x; c <= kTileW; c += blockDim.x) tile_u[c] = pixel_center(tx0 + c, p.width);
+  for (int c = threadIdx.x; c <= kTileH; c += blockDim.x) tile_v[c] = pixel_center(ty0 + c, p.height);
+  __syncthreads();
+  const DenseBwd cst = sh.c;
+  const size_t slot = pair * ((size_t)tiles_x * tiles_y) + (size_t)blk.tile_y * tiles_x + blk.tile_x;
+  const int64_t lo = first[slot], hi = first[slot + 1];
+  for (int64_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+    const uint32_t pk = list[e];
+    const int row = (int)(pk >> 16), col = (int)(pk & 0xffffu);
+    const int idx = row * p.width + col;
+    const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
+    const float2 fl = reinterpret_cast<const float2*>(src.bwd_flow)[idx];
+    float w = src.weights[idx];
+    if (src.weight_sens != 0.f) w = fm_sigmoid<true>(src.weight_sens * w);
+    const float z = src.depth_l[idx];
+    const float g[3] = {z * u, z * v, z};
+    float tv[3], gc[3];
+    dense_bwd_t(cst, g, tv, gc);
+    const float b0 = w * tv[0], b1 = w * tv[1], b2 = w * tv[2];  // K⁻ᵀ_e·dL/dq
+    const Taps tp = bilinear_taps(u + fl.x, v + fl.y, p.height, p.width);  // exactly as the plan and the other dense kernels
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = tp.y0 + (k >> 1) - ty0, cc = tp.x0 + (k & 1) - tx0;
+      if (!tp.in[k] || rr < 0 || rr >= kTileH || cc < 0 || cc >= kTileW) continue;
+      atomicAdd(gacc + rr * kTileW + cc, tp.w[k] * fmaf(b0, tile_u[cc], fmaf(b1, tile_v[rr], b2)));
+    }
+  }
+  __syncthreads();
+  float* gd = p.grad_depth + fe * n;
+  for (int c = threadIdx.x; c < kTileH * kTileW; c += blockDim.x) {
+    const int gy = ty0 + c / kTileW, gx = tx0 + c % kTileW;
+    if (gy < p.height && gx < p.width) gd[(size_t)gy * p.width + gx] += gacc[c];
+  }
 }
 
 // Static pattern of the sparse depth-sourced scatter (indices and flows are constants of the
@@ -530,103 +733,6 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
       ordered[9 + k] = acc[k];
     }
     block_accumulate<18>(ordered, red, p.kinv_acc + fk * 9);
-  }
-}
-
-// Dense backward: per-pixel gradients of the tile; dL/dweights is STORED (every pixel of every pair
-// is written exactly once: the caller need not zero it), the later-frame depth gradient is one
-// coalesced atomic per pixel, the four tap gradients go to the LDS window, flushed at the end.
-__global__ void __launch_bounds__(256) procrustes_scatter_dense_kernel(ProcParams p, const double* aux, long total) {
-  __shared__ double red[4 * 18];
-  __shared__ DenseWindow win;
-  __shared__ float gwin[kWinH * kWinW];
-  const DenseBlock blk = dense_block(p, total);
-  if (!blk.valid) return;
-  const size_t pair = (size_t)blk.pair;
-  const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
-  const int n = p.height * p.width;
-  Mat3 kinv_e, kinv_l;
-  load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
-  load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
-  const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
-  const double* pg = p.pair_grad + pair * kPairGradStride;
-  const double* ax = aux + pair * kAuxStride;
-  PairGrad g;
-  for (int k = 0; k < 9; ++k) g.gM[k] = (float)pg[k];
-  for (int a = 0; a < 3; ++a) {
-    g.gqbar[a] = (float)pg[9 + a];
-    g.gpbar[a] = (float)pg[12 + a];
-    g.pbar[a] = (float)ax[21 + a];
-    g.qbar[a] = (float)ax[24 + a];
-  }
-  g.dbar = (float)pg[15];
-  g.inv_wsum = (float)pg[16];
-  const size_t fe = (size_t)b * p.frames + i, fl = fe + 1;
-  const DenseTile t = dense_tile(p, src, blk);
-  stage_depth_window(p, src, t, win);
-  for (int c = threadIdx.x; c < kWinH * kWinW; c += blockDim.x) gwin[c] = 0.f;
-  __syncthreads();
-
-  float acc[18];  // [0..8] dKinv later frame, [9..17] dKinv earlier frame
-#pragma unroll
-  for (int k = 0; k < 18; ++k) acc[k] = 0.f;
-  const int col = t.tx0 + (threadIdx.x & (kTileW - 1));
-  for (int r = threadIdx.x / kTileW; r < kTileH; r += 256 / kTileW) {
-    const int row = t.ty0 + r;
-    if (row >= p.height || col >= p.width) continue;
-    const int idx = row * p.width + col;
-    const PixelRef px{idx, win.tile_u[threadIdx.x & (kTileW - 1)], win.tile_v[r]};
-    const Corr c = corr_load_with<true>(src, kinv_e, kinv_l, px,
-                                        [&](int tr, int tc, float& ut, float& vt) { return window_tap(p, src, t, win, tr, tc, ut, vt); });
-    float gq[3], gp[3], gw;
-    corr_backward(c, g, gq, gp, gw);
-    if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
-    if (p.grad_weights) p.grad_weights[pair * (size_t)n + idx] = gw;
-    if (p.grad_depth) atomicAdd(p.grad_depth + fl * n + idx, gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2]);
-    const float zh[3] = {c.z_p * px.u, c.z_p * px.v, c.z_p};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int d = 0; d < 3; ++d) acc[a * 3 + d] += gp[a] * zh[d];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (!c.taps.in[k]) continue;
-      const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
-      const int cell = window_cell(t, tr, tc);
-      float ut, vt;
-      const float z = window_tap(p, src, t, win, tr, tc, ut, vt);
-      float ray[3];
-      ray_dir(kinv_e, ut, vt, ray);
-      const float wt = c.taps.w[k];
-      const float gz = wt * (gq[0] * ray[0] + gq[1] * ray[1] + gq[2] * ray[2]);
-      if (p.grad_depth) {
-        if (cell >= 0) atomicAdd(gwin + cell, gz);
-        else atomicAdd(p.grad_depth + fe * n + (size_t)tr * p.width + tc, gz);
-      }
-      const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) acc[9 + a * 3 + d] += gq[a] * zt[d];
-    }
-  }
-  __syncthreads();
-  if (p.grad_depth) {
-    for (int c = threadIdx.x; c < kWinH * kWinW; c += blockDim.x) {
-      const float v = gwin[c];
-      if (v == 0.f) continue;  // cells outside the image or never hit
-      const int gy = t.wy0 + c / kWinW, gx = t.wx0 + c % kWinW;
-      atomicAdd(p.grad_depth + fe * n + (size_t)gy * p.width + gx, v);
-    }
-  }
-  if (p.kinv_acc) {
-    float ordered[18];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      ordered[k] = acc[9 + k];
-      ordered[9 + k] = acc[k];
-    }
-    block_accumulate<18>(ordered, red, p.kinv_acc + fe * 9);
   }
 }
 
@@ -869,7 +975,7 @@ static inline long dense_blocks(int height, int width, int pairs) {
 static inline unsigned dense_grid(long total) { return (unsigned)(((total + kXcds - 1) / kXcds) * kXcds); }
 static inline bool dense_tiled(const float* depth, const float* surfaces, const int64_t* indices, long points, int batch_repeat,
                                int height, int width, int pairs) {
-  return depth && !surfaces && !indices && batch_repeat == 1 && points == (long)height * width &&
+  return depth && !surfaces && !indices && batch_repeat == 1 && points == (long)height * width && height <= 65535 && width <= 65535 &&
          dense_blocks(height, width, pairs) < (1L << 31) - kXcds;
 }
 
@@ -905,7 +1011,9 @@ static int procrustes_stats_launch(const float* depth, const float* kinv, const 
   } else {
     hipLaunchKernelGGL((procrustes_moments_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, iters);
   }
-  if (t_bwd) {  // finish + solve per pair in one launch
+  if (dense) {  // pixel-space sums: intrinsics applied here, then the solve (t_bwd may be null: statistics only)
+    hipLaunchKernelGGL(procrustes_finish_solve_dense_kernel, fgrid, dim3(64), 0, st, p, pairs, t_bwd, t_fwd, aux);
+  } else if (t_bwd) {  // finish + solve per pair in one launch
     if (surfaces) hipLaunchKernelGGL((procrustes_finish_solve_kernel<SRC_SURF>), fgrid, dim3(64), 0, st, p, pairs, t_bwd, t_fwd, aux);
     else hipLaunchKernelGGL((procrustes_finish_solve_kernel<SRC_DEPTH>), fgrid, dim3(64), 0, st, p, pairs, t_bwd, t_fwd, aux);
   } else if (surfaces) {
@@ -974,15 +1082,48 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
   p.batch_repeat = batch_repeat;
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
-  if (dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width, pairs)) {
-    const long total = dense_blocks(height, width, pairs);
-    hipLaunchKernelGGL(procrustes_scatter_dense_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, aux, total);
-  } else if (batch_repeat > 1 && !surfaces) {
+  if (batch_repeat > 1 && !surfaces) {
     const int image_pairs = pairs / batch_repeat, groups = (batch_repeat + kRepeatGroup - 1) / kRepeatGroup;
     const dim3 rgrid((unsigned)((points + 255) / 256), (unsigned)(image_pairs * groups));
     hipLaunchKernelGGL(procrustes_scatter_repeat_kernel, rgrid, dim3(256), 0, st, p, aux);
   } else if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);
   else hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, aux, iters);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_procrustes_dense_tiles(int height, int width, int* tiles) {
+  FM_CHECK_ARG(tiles && height >= 1 && width >= 1);
+  *tiles = ((width + kTileW - 1) / kTileW) * ((height + kTileH - 1) / kTileH);
+  return FM_OK;
+}
+
+int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int height, int width, int* counts, const int64_t* first,
+                             uint32_t* list, void* stream) {
+  FM_CHECK_ARG(bwd_flow && counts && batch >= 1 && frames >= 2 && height >= 1 && width >= 1 && height <= 65535 && width <= 65535);
+  FM_CHECK_ARG((list == nullptr) == (first == nullptr) && (long)batch * (frames - 1) <= 65535);
+  const long n = (long)height * width;
+  hipLaunchKernelGGL(procrustes_dense_plan_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(batch * (frames - 1))), dim3(256), 0,
+                     (hipStream_t)stream, bwd_flow, height, width, counts, first, list);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights,
+                                float weight_sensitivity, int batch, int frames, int height, int width, const double* aux,
+                                const double* pair_grad, float* grad_depth, float* grad_weights, double* kinv_acc, const int64_t* first,
+                                const uint32_t* list, void* stream) {
+  FM_CHECK_ARG(depth && kinv && bwd_flow && weights && aux && pair_grad && batch >= 1 && frames >= 2);
+  FM_CHECK_ARG(height >= 1 && width >= 1 && height <= 65535 && width <= 65535 && (long)height * width < (1L << 30));
+  FM_CHECK_ARG(!grad_depth || (first && list));
+  const int pairs = batch * (frames - 1);
+  FM_CHECK_ARG(dense_blocks(height, width, pairs) < (1L << 31) - kXcds);
+  hipStream_t st = (hipStream_t)stream;
+  ProcParams p{};
+  p.depth = depth; p.kinv = kinv; p.bwd_flow = bwd_flow; p.weights = weights; p.pair_grad = pair_grad; p.grad_depth = grad_depth;
+  p.grad_weights = grad_weights; p.kinv_acc = kinv_acc; p.frames = frames; p.height = height; p.width = width;
+  p.points = (long)height * width; p.weight_sens = weight_sensitivity; p.batch_repeat = 1;
+  const long total = dense_blocks(height, width, pairs);
+  hipLaunchKernelGGL(procrustes_dense_bwd_later_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, aux, total);
+  if (grad_depth) hipLaunchKernelGGL(procrustes_dense_bwd_taps_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, aux, first, list, total);
   FM_LAUNCH_STATUS();
 }
 

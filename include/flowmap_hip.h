@@ -132,14 +132,36 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
  * (B,F,H,W,3) and grad_weights (B,F-1,H,W): callers zero them (or pass a buffer that
  * already holds another gradient to fuse the accumulation).  kinv_acc (B*F,9) fp64:
  * dL/dK⁻¹ accumulators (caller zeroes), depth source only.  Any output may be NULL.
- * Exception — dense depth-sourced mode (surfaces == NULL, indices == NULL, points == H·W,
- * batch_repeat == 1): every element of grad_weights is STORED exactly once (it need not be
- * zeroed and must not hold another gradient); grad_depth is still added to. */
+ * The dense depth-sourced case (surfaces == NULL, indices == NULL, points == H·W, batch_repeat == 1)
+ * has its own atomic-free entry point, fm_procrustes_scatter_dense below; through this one it runs on
+ * the generic kernels. */
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
                           int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,
                           float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, float* point_grads,
                           float* point_weight_grads, void* stream);
+
+/* Dense Procrustes backward (`num_points: null`, config/experiment/ablation_explicit_depth.yaml:11-12:
+ * every pixel of every pair is a correspondence; replaces grid_sampler_2d_backward + index_put of
+ * projection.py:226-249 over all H·W pixels) WITHOUT atomics on the big tensors.  The pattern is static
+ * (the flows are constants of the optimisation), so it is planned once per flow tensor:
+ *   fm_procrustes_dense_tiles(H, W, &tiles)                      tiles of the earlier frame per pair (host only)
+ *   pass 1: fm_procrustes_dense_plan(bwd_flow, B, F, H, W, counts, NULL, NULL)   counts (B·(F-1)·tiles) int32,
+ *           zeroed by the caller, += 1 per (later pixel, tile its bilinear taps land in)
+ *   first  = exclusive prefix sum of counts, (B·(F-1)·tiles + 1) int64            [caller]
+ *   pass 2: fm_procrustes_dense_plan(bwd_flow, B, F, H, W, cursor, first, list)   cursor: zeroed int32 of the
+ *           same size; list (first[last]) uint32 = row << 16 | col of the later pixels, grouped by tile.
+ * Per step fm_procrustes_scatter_dense: grad_weights (B,F-1,H,W) is STORED (every element exactly once:
+ * need not be zeroed, must not hold another gradient); grad_depth (B,F,H,W) is ADDED to with plain
+ * read-modify-writes (each pixel has one writer per launch); kinv_acc (B·F,9) fp64 is added to (caller
+ * zeroes).  grad_depth / grad_weights / kinv_acc may be NULL; first / list are needed for grad_depth. */
+int fm_procrustes_dense_tiles(int height, int width, int* tiles);
+int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int height, int width, int* counts, const int64_t* first,
+                             uint32_t* list, void* stream);
+int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights,
+                                float weight_sensitivity, int batch, int frames, int height, int width, const double* aux,
+                                const double* pair_grad, float* grad_depth, float* grad_weights, double* kinv_acc, const int64_t* first,
+                                const uint32_t* list, void* stream);
 
 /* Planned form of the sparse depth-sourced scatter.  With DISTINCT `indices` and constant flows the
  * pixels a step's Procrustes gradient touches never change: fm_procrustes_scatter_plan lists them

@@ -793,3 +793,47 @@ def case_flow_fused_leaves(dev, f, h, w, packed, kind="huber", seed=0, tol=TOL):
         assert_close(tf.grad[0, pr, :3], tf64.grad[0, pr, :3], tol, what=f"dL/dT_fwd pair {pr}")
         assert_close(tb.grad[0, pr, :3], tb64.grad[0, pr, :3], tol, what=f"dL/dT_bwd pair {pr}")
     assert float(tf.grad[0, :, 3].abs().max()) == 0.0 and float(tb.grad[0, :, 3].abs().max()) == 0.0  # [..., :3] drops the last row
+
+
+def case_dense_procrustes(dev, h, w, flow_sigma, f=4):
+    """`num_points: null` (every pixel a correspondence, ablation_explicit_depth.yaml:11-12): the tiled,
+    planned, atomic-free dense kernels (pixel-space sums, fm_procrustes_scatter_dense) against the fp64
+    oracle's align_rigid on the same correspondences (projection.py:226-249, procrustes.py:7-51) — poses
+    and the gradients w.r.t. depth, weight logits and a per-frame K — and against the generic
+    gather / atomic kernels (explicit arange indices).  Large flows push samples out of a tile's LDS
+    window (global fallback), across several tiles of the static tap lists, and against the image
+    border (clamped taps)."""
+    from flowmap_amd import _ops
+
+    g = torch.Generator().manual_seed(h * w)
+    depth = 1.0 + 0.3 * torch.rand((1, f, h, w), generator=g)
+    k = orc.focal_to_k(torch.tensor(0.85), (h, w)).repeat(1, f, 1, 1) + 0.01 * torch.randn((1, f, 3, 3), generator=g)
+    flow = flow_sigma * torch.randn((1, f - 1, h, w, 2), generator=g)
+    logits = 0.01 * torch.randn((1, f - 1, h, w), generator=g)
+    cot_b, cot_f = torch.randn((1, f - 1, 4, 4), generator=g), torch.randn((1, f - 1, 4, 4), generator=g)
+    cot_b[..., 3, :] = 0
+    cot_f[..., 3, :] = 0
+
+    # fp64 oracle
+    d64, k64, l64 = (x.double().requires_grad_(True) for x in (depth, k, logits))
+    xy, _ = orc.pixel_grid((h, w), dtype=torch.float64)
+    surfaces = orc.lift(xy, d64, k64[:, :, None, None])
+    later = surfaces[:, 1:].reshape(1, f - 1, h * w, 3)
+    where = (xy + flow.double()).reshape(1, f - 1, h * w, 2)
+    earlier = orc.bilinear_border(surfaces[:, :-1], where)
+    rel64 = orc.rigid_fit(later, earlier, (100.0 * l64).sigmoid().reshape(1, f - 1, h * w))
+    ((rel64 * cot_b.double()).sum() + (torch.linalg.inv(rel64) * cot_f.double()).sum()).backward()
+
+    res = {}
+    for name, idx in (("tiled", None), ("generic", torch.arange(h * w, device=dev))):
+        d, kk, lg = (x.clone().to(dev).requires_grad_(True) for x in (depth, k, logits))
+        t_bwd, t_fwd = _ops.ProcrustesFit.apply(d, kk, None, lg, flow.to(dev), idx, 100.0, 1)
+        ((t_bwd * cot_b.to(dev)).sum() + (t_fwd * cot_f.to(dev)).sum()).backward()
+        res[name] = (t_bwd.detach(), d.grad, lg.grad, kk.grad)
+    truth = (rel64.detach(), d64.grad, l64.grad, k64.grad)
+    for a, b, c, what in zip(res["tiled"], res["generic"], truth, ("t_bwd", "g_depth", "g_logits", "g_k")):
+        assert torch.isfinite(a).all(), what
+        assert_close(a, c, TOL, what=f"{what} vs fp64 oracle")
+        assert_close(a, b, TOL, abs_=1e-7, what=f"{what} vs generic kernels")
+    assert maxerr(res["tiled"][1], truth[1]) <= 10 * TOL, "g_depth: max-abs"
+    assert maxerr(res["tiled"][2], truth[2]) <= 10 * TOL, "g_logits: max-abs"

@@ -7,6 +7,7 @@
 // analytic gradients can be checked against the oracle in the GPU-less build
 // container before GPU minutes are spent.  Launch geometry, coalescing, wave
 // reductions and atomics are what it does NOT cover — the `-m gpu` tests do.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -401,11 +402,40 @@ static CorrSrc make_src(const float* depth, const float* surfaces, const float* 
   return s;
 }
 
+static bool dense_mode(const float* depth, const float* surfaces, const int64_t* indices, long points, int repeat, int height, int width) {
+  return depth && !surfaces && !indices && repeat == 1 && points == (long)height * width && height <= 65535 && width <= 65535;
+}
+
+// One dense correspondence in pixel space (fm_math.h "Dense Procrustes"), taps read from memory.
+struct SimDensePixel {
+  float g[3], h[3], w, u, v;
+  Taps taps;
+};
+static SimDensePixel sim_dense_pixel(const CorrSrc& src, int row, int col) {
+  SimDensePixel o;
+  const int idx = row * src.width + col;
+  o.u = pixel_center(col, src.width);
+  o.v = pixel_center(row, src.height);
+  float w = src.weights[idx];
+  if (src.weight_sens != 0.f) w = fm_sigmoid<false>(src.weight_sens * w);
+  o.w = w;
+  const float z = src.depth_l[idx];
+  o.g[0] = z * o.u; o.g[1] = z * o.v; o.g[2] = z;
+  o.taps = bilinear_taps(o.u + src.bwd_flow[2 * (size_t)idx], o.v + src.bwd_flow[2 * (size_t)idx + 1], src.height, src.width);
+  const int x1 = std::min(o.taps.x0 + 1, src.width - 1), y1 = std::min(o.taps.y0 + 1, src.height - 1);
+  const float zt[4] = {src.depth_e[(size_t)o.taps.y0 * src.width + o.taps.x0], src.depth_e[(size_t)o.taps.y0 * src.width + x1],
+                       src.depth_e[(size_t)y1 * src.width + o.taps.x0], src.depth_e[(size_t)y1 * src.width + x1]};
+  dense_h(o.taps, zt, pixel_center(o.taps.x0, src.width), pixel_center(o.taps.x0 + 1, src.width), pixel_center(o.taps.y0, src.height),
+          pixel_center(o.taps.y0 + 1, src.height), o.h);
+  return o;
+}
+
 int fm_procrustes_stats(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                         const float* weights, float sens, const int64_t* indices, long points, int batch, int repeat, int frames,
                         int height, int width, double* stats, void*) {
   const int pairs = batch * (frames - 1);
   std::memset(stats, 0, sizeof(double) * (size_t)pairs * kStatStride);
+  const bool dense = dense_mode(depth, surfaces, indices, points, repeat, height, width);
   for (int pr = 0; pr < pairs; ++pr) {
     const int b = pr / (frames - 1), i = pr % (frames - 1);
     Mat3 ke{}, kl{};
@@ -415,6 +445,20 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
     }
     const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, sens, pr, b, i, frames, height, width, repeat);
     double* st = stats + (size_t)pr * kStatStride;
+    if (dense) {  // pixel-space sums, intrinsics applied once per pair (as the tiled kernels)
+      float gs[3];
+      dense_shift(src.depth_l, height, width, gs);
+      for (long j0 = 0; j0 < points; j0 += 256) {
+        float acc[kMomentCount] = {};
+        for (long j = j0; j < points && j < j0 + 256; ++j) {
+          const SimDensePixel px = sim_dense_pixel(src, (int)(j / width), (int)(j % width));
+          dense_moments_add(px.g, px.h, px.w, gs, acc);
+        }
+        for (int k = 0; k < kMomentCount; ++k) st[k] += acc[k];
+      }
+      dense_moments_finish(st, gs, kinv + ((size_t)b * frames + i) * 9, kinv + ((size_t)b * frames + i + 1) * 9);
+      continue;
+    }
     float shift[3];
     const long mid = points / 2;
     later_point(src, kl, indices ? (int)indices[mid] : (int)mid, shift);
@@ -425,6 +469,111 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
       for (int k = 0; k < kMomentCount; ++k) st[k] += acc[k];
     }
     moments_finish(st, shift);
+  }
+  return 0;
+}
+
+int fm_procrustes_dense_tiles(int height, int width, int* tiles) {
+  if (!tiles || height < 1 || width < 1) return 1;
+  *tiles = ((width + kDenseTileW - 1) / kDenseTileW) * ((height + kDenseTileH - 1) / kDenseTileH);
+  return 0;
+}
+
+}  // extern "C"
+template <class Fn>
+static void sim_tap_tiles(const float* flow_pair, int height, int width, int row, int col, const Fn& fn) {
+  const float* fl = flow_pair + 2 * ((size_t)row * width + col);
+  const Taps t = bilinear_taps(pixel_center(col, width) + fl[0], pixel_center(row, height) + fl[1], height, width);
+  const int tiles_x = (width + kDenseTileW - 1) / kDenseTileW;
+  const int txa = t.x0 / kDenseTileW, tya = t.y0 / kDenseTileH;
+  const int txb = (t.x0 + 1 < width) ? (t.x0 + 1) / kDenseTileW : txa, tyb = (t.y0 + 1 < height) ? (t.y0 + 1) / kDenseTileH : tya;
+  fn(tya * tiles_x + txa);
+  if (txb != txa) fn(tya * tiles_x + txb);
+  if (tyb != tya) {
+    fn(tyb * tiles_x + txa);
+    if (txb != txa) fn(tyb * tiles_x + txb);
+  }
+}
+
+extern "C" {
+int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int height, int width, int* counts, const int64_t* first,
+                             uint32_t* list, void*) {
+  if (!bwd_flow || !counts || (list == nullptr) != (first == nullptr) || height > 65535 || width > 65535) return 1;
+  int tiles = 0;
+  fm_procrustes_dense_tiles(height, width, &tiles);
+  const size_t n = (size_t)height * width;
+  for (int pr = 0; pr < batch * (frames - 1); ++pr)
+    for (int row = 0; row < height; ++row)
+      for (int col = 0; col < width; ++col)
+        sim_tap_tiles(bwd_flow + (size_t)pr * n * 2, height, width, row, col, [&](int tile) {
+          const int pos = counts[(size_t)pr * tiles + tile]++;
+          if (list) list[first[(size_t)pr * tiles + tile] + pos] = ((uint32_t)row << 16) | (uint32_t)col;
+        });
+  return 0;
+}
+
+int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float sens, int batch,
+                                int frames, int height, int width, const double* aux, const double* pair_grad, float* grad_depth,
+                                float* grad_weights, double* kinv_acc, const int64_t* first, const uint32_t* list, void*) {
+  if (!depth || !kinv || !bwd_flow || !weights || !aux || !pair_grad || (grad_depth && (!first || !list))) return 1;
+  int tiles = 0;
+  fm_procrustes_dense_tiles(height, width, &tiles);
+  const int tiles_x = (width + kDenseTileW - 1) / kDenseTileW;
+  const size_t n = (size_t)height * width;
+  for (int pr = 0; pr < batch * (frames - 1); ++pr) {
+    const int b = pr / (frames - 1), i = pr % (frames - 1);
+    const size_t fe = (size_t)b * frames + i, fl = fe + 1;
+    const CorrSrc src = make_src(depth, nullptr, bwd_flow, weights, sens, pr, b, i, frames, height, width, 1);
+    DenseBwd c;
+    double k_e[9], k_l[9];
+    dense_bwd_consts(pair_grad + (size_t)pr * kPairGradStride, aux + (size_t)pr * kAuxStride, kinv + fe * 9, kinv + fl * 9, c, k_e, k_l);
+    double a_e[9] = {}, a_l[9] = {};
+    // later role: every pixel of the later frame
+    for (int row = 0; row < height; ++row)
+      for (int col = 0; col < width; ++col) {
+        const size_t idx = (size_t)row * width + col;
+        const SimDensePixel px = sim_dense_pixel(src, row, col);
+        float tv[3], gc[3], sv[3], gw;
+        dense_bwd_t(c, px.g, tv, gc);
+        dense_bwd_s(c, px.h, tv, gc, sv, gw);
+        if (sens != 0.f) gw *= sens * px.w * (1.f - px.w);
+        if (grad_weights) grad_weights[(size_t)pr * n + idx] = gw;
+        if (grad_depth) grad_depth[fl * n + idx] += px.w * fmaf(sv[0], px.u, fmaf(sv[1], px.v, sv[2]));
+        for (int a = 0; a < 3; ++a)
+          for (int d = 0; d < 3; ++d) {
+            a_e[a * 3 + d] += (double)(px.w * tv[a]) * px.h[d];
+            a_l[a * 3 + d] += (double)(px.w * sv[a]) * px.g[d];
+          }
+      }
+    if (kinv_acc)
+      for (int r = 0; r < 3; ++r)
+        for (int d = 0; d < 3; ++d) {
+          kinv_acc[fe * 9 + r * 3 + d] += k_e[0 * 3 + r] * a_e[0 * 3 + d] + k_e[1 * 3 + r] * a_e[1 * 3 + d] + k_e[2 * 3 + r] * a_e[2 * 3 + d];
+          kinv_acc[fl * 9 + r * 3 + d] += k_l[0 * 3 + r] * a_l[0 * 3 + d] + k_l[1 * 3 + r] * a_l[1 * 3 + d] + k_l[2 * 3 + r] * a_l[2 * 3 + d];
+        }
+    if (!grad_depth) continue;
+    // earlier role: per tile of the earlier frame, the listed later pixels (only taps inside the tile count)
+    for (int tile = 0; tile < tiles; ++tile) {
+      const int tx0 = (tile % tiles_x) * kDenseTileW, ty0 = (tile / tiles_x) * kDenseTileH;
+      for (int64_t e = first[(size_t)pr * tiles + tile]; e < first[(size_t)pr * tiles + tile + 1]; ++e) {
+        const int row = (int)(list[e] >> 16), col = (int)(list[e] & 0xffffu);
+        const size_t idx = (size_t)row * width + col;
+        const float u = pixel_center(col, width), v = pixel_center(row, height);
+        float w = src.weights[idx];
+        if (sens != 0.f) w = fm_sigmoid<false>(sens * w);
+        const float z = src.depth_l[idx];
+        const float g[3] = {z * u, z * v, z};
+        float tv[3], gc[3];
+        dense_bwd_t(c, g, tv, gc);
+        const Taps tp = bilinear_taps(u + src.bwd_flow[2 * idx], v + src.bwd_flow[2 * idx + 1], height, width);
+        for (int k = 0; k < 4; ++k) {
+          const int rr = tp.y0 + (k >> 1) - ty0, cc = tp.x0 + (k & 1) - tx0;
+          if (!tp.in[k] || rr < 0 || rr >= kDenseTileH || cc < 0 || cc >= kDenseTileW) continue;
+          grad_depth[fe * n + (size_t)(ty0 + rr) * width + tx0 + cc] +=
+              tp.w[k] * fmaf(w * tv[0], pixel_center(tx0 + cc, width), fmaf(w * tv[1], pixel_center(ty0 + rr, height), w * tv[2]));
+        }
+      }
+    }
   }
   return 0;
 }

@@ -71,18 +71,14 @@ def test_track_tile_constant_matches_header():
     assert int(re.search(r"#define FM_TRACK_TILE (\d+)", HEADER).group(1)) == _ops.TRACK_TILE
 
 
-def test_docs_quote_the_current_entry_point_count():
-    """DESIGN.md / INTEGRATION.md state how many entry points the header declares; keep them honest,
-    and every entry point must be named in INTEGRATION.md's table (x_fwd/bwd and x(_suffix) shorthands
-    included)."""
+def test_integration_doc_names_every_entry_point():
+    """Every entry point the header declares is named in INTEGRATION.md's table (x_fwd/bwd and x(_suffix)
+    shorthands included)."""
     import re
 
     header = (ROOT / "include" / "flowmap_hip.h").read_text()
     names = set(re.findall(r"\bint (fm_\w+)\(", header))
-    design = (ROOT / "DESIGN.md").read_text()
     integration = (ROOT / "INTEGRATION.md").read_text()
-    assert f"({len(names)} entry points)" in design
-    assert f"declares {len(names)} `extern" in integration
     mentioned = integration
     for base in re.findall(r"`(fm_\w+)_fwd/bwd`", integration):
         mentioned += f" {base}_fwd {base}_bwd"

@@ -9,12 +9,13 @@ and on the pixels the Procrustes fit / the tracks write to.
 FLOWMAP_SKIP_FULL_SIZE=1 skips the module (iteration runs); the oracle runs in fp64 when the host has
 the memory for it (>= 256 GB free), else in fp32 — the reference's own precision — and says which."""
 
+import json
 import os
 
 import pytest
 import torch
 
-from conftest import assert_close, assert_grad_close, relerr
+from conftest import assert_close, assert_grad_close, maxerr, relerr
 from helpers import mapping_cfg, run_ours, step_masks
 from oracle import flowmap_oracle as orc
 
@@ -62,9 +63,17 @@ def full_size():
 
 def check(ours, ref, grads, masks, what):
     tol = 1e-4
-    print(f"[{what}] oracle dtype {ref['dtype']}")
+    record = {"case": what, "oracle_dtype": str(ref["dtype"]), "extrinsics": relerr(ours["extrinsics"], ref["extrinsics"])}
     for key in ("g_depth", "g_wlogit", "g_focal"):
-        print(f"[{what}] {key}: rel err {relerr(ours[key], grads[key]):.3e}")
+        record[key] = relerr(ours[key], grads[key])
+        record[key + "_max_abs_over_max_ref"] = maxerr(ours[key], grads[key])
+    for name, mask in masks.items():
+        record[f"g_depth[{name}]"] = relerr(ours["g_depth"][mask], grads["g_depth"][mask])
+    print(record)
+    out = os.environ.get("FLOWMAP_PARITY_RECORD")  # tools/gpu_call.sh points this under gpurun_out/
+    if out:
+        with open(out, "a") as fh:
+            fh.write(json.dumps(record) + "\n")
     assert_close(ours["extrinsics"], ref["extrinsics"], tol, what="extrinsics")
     assert_grad_close(ours["g_depth"], grads["g_depth"], tol, masks=masks, what="g_depth")
     assert_grad_close(ours["g_wlogit"], grads["g_wlogit"], tol, what="g_wlogit")

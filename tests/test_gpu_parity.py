@@ -290,30 +290,9 @@ def test_export(tmp_path):
     cases.case_export(DEV, tmp_path)
 
 
-@pytest.mark.parametrize("h,w,flow_sigma", [(90, 122, 0.01), (70, 150, 0.25), (33, 200, 0.08), (16, 64, 0.5)])
-def test_dense_tiled_procrustes_matches_generic_kernels(h, w, flow_sigma):
-    """num_points=None runs the LDS-tiled dense kernels; explicit arange indices run the generic
-    gather/atomic kernels on the same correspondences.  Large flows push samples out of the
-    tile's LDS window (global fallback) and against the image border (clamped taps)."""
-    from flowmap_amd import _ops
-
-    f = 4
-    g = torch.Generator().manual_seed(h * w)
-    depth = (1.0 + 0.3 * torch.rand((1, f, h, w), generator=g)).to(DEV)
-    focal = 0.85 * (h * w) ** 0.5
-    k = torch.tensor([[focal / w, 0, 0.5], [0, focal / h, 0.5], [0, 0, 1.0]]).expand(1, f, 3, 3).contiguous().to(DEV)
-    flow = (flow_sigma * torch.randn((1, f - 1, h, w, 2), generator=g)).to(DEV)
-    logits = (0.01 * torch.randn((1, f - 1, h, w), generator=g)).to(DEV)
-    cot_b, cot_f = torch.randn((1, f - 1, 4, 4), generator=g).to(DEV), torch.randn((1, f - 1, 4, 4), generator=g).to(DEV)
-    res = {}
-    for name, idx in (("tiled", None), ("generic", torch.arange(h * w, device=DEV))):
-        d, kk, lg = depth.clone().requires_grad_(True), k.clone().requires_grad_(True), logits.clone().requires_grad_(True)
-        t_bwd, t_fwd = _ops.ProcrustesFit.apply(d, kk, None, lg, flow, idx, 100.0, 1)
-        ((t_bwd * cot_b).sum() + (t_fwd * cot_f).sum()).backward()
-        res[name] = (t_bwd.detach(), d.grad, lg.grad, kk.grad)
-    for a, b, what in zip(res["tiled"], res["generic"], ("t_bwd", "g_depth", "g_logits", "g_k")):
-        assert torch.isfinite(a).all(), what
-        assert_close(a, b, 2e-5, abs_=1e-7, what=what)
+@pytest.mark.parametrize("h,w,flow_sigma", [(90, 122, 0.01), (70, 150, 0.25), (33, 200, 0.08), (16, 64, 0.5), (144, 256, 0.01)])
+def test_dense_tiled_procrustes(h, w, flow_sigma):
+    cases.case_dense_procrustes(DEV, h, w, flow_sigma)
 
 
 def test_random_subset():

@@ -124,3 +124,8 @@ def test_capturable_pieces():
                                                 (3, 10, 12, True, "l2")])
 def test_flow_fused_leaves(f, h, w, packed, kind):
     cases.case_flow_fused_leaves("cpu", f, h, w, packed, kind)
+
+
+@pytest.mark.parametrize("h,w,flow_sigma", [(20, 70, 0.02), (18, 66, 0.3), (33, 130, 0.08)])
+def test_dense_procrustes(h, w, flow_sigma):
+    cases.case_dense_procrustes("cpu", h, w, flow_sigma, f=3)
