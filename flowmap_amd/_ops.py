@@ -23,6 +23,7 @@ FLOW_ACC_STRIDE = 20
 STAT_STRIDE = 16
 AUX_STRIDE = 32
 PAIR_GRAD_STRIDE = 20
+DENSE_CONST_STRIDE = 40  # FM_DENSE_CONST_STRIDE
 TRACK_TILE = 6  # FM_TRACK_TILE (include/flowmap_hip.h; tests/test_abi.py checks they agree)
 
 
@@ -521,8 +522,9 @@ class ProcrustesFit(torch.autograd.Function):
                 first = entries = None
                 if g_src is not None:
                     first, entries = _dense_procrustes_plan(bwd_flow, b, f, h, w)
+                consts = torch.empty((pairs, DENSE_CONST_STRIDE), dtype=torch.float64, device=dev)
                 call("fm_procrustes_scatter_dense", ptr(src), ptr(kinv), ptr(bwd_flow), ptr(weights), ctx.weight_sens, b, f, h, w, ptr(aux),
-                     ptr(pair_grad), ptr(g_src), ptr(g_w), ptr(kinv_acc), ptr(first), ptr(entries), st)
+                     ptr(pair_grad), ptr(g_src), ptr(g_w), ptr(kinv_acc), ptr(first), ptr(entries), ptr(consts), st)
             else:
                 call("fm_procrustes_scatter", ptr(src) if ctx.from_depth else None, ptr(kinv), None if ctx.from_depth else ptr(src),
                      ptr(bwd_flow), ptr(weights), ctx.weight_sens, ptr(indices), ctx.points, b, ctx.rep, f, h, w, ptr(aux), ptr(pair_grad),

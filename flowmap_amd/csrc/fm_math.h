@@ -959,7 +959,41 @@ FM_HD void mat4_mul_nt(const double* a, const double* b, double* o) {  // a bᵀ
 //   dL/dK⁻¹_l   = K_lᵀ·Σ (w·s) ⊗ g          dL/dK⁻¹_e = K_eᵀ·Σ (w·t) ⊗ h
 // (corr_backward above, rewritten; ≈60 flops per correspondence instead of ≈250).
 // ---------------------------------------------------------------------------------
-constexpr int kDenseTileH = 16, kDenseTileW = 64;  // tile of one workgroup (and of the static tap lists)
+constexpr int kDenseTileH = 32, kDenseTileW = 64;  // tile of one workgroup (and of the static tap lists)
+
+// (i + 0.5) / n as sample_image_grid divides it (projection.py:109), by reciprocal + one Newton step:
+// the correctly rounded quotient in all but rare double-rounding cases (then 1 ulp off).  Every dense
+// kernel and the plan use THIS function, so their taps agree exactly with each other.
+FM_HD float center_fast(int i, float n, float rcp_n) {
+  const float a = (float)i + 0.5f;
+  const float q = a * rcp_n;
+  return fmaf(fmaf(-q, n, a), rcp_n, q);
+}
+
+// bilinear_taps for the dense kernels: after the border clamp the north-west tap is always inside, so
+// only the east / south range tests remain.
+FM_HD Taps dense_taps(float x01, float y01, int h, int w) {
+  Taps t;
+  const float gx = x01 * 2.f - 1.f, gy = y01 * 2.f - 1.f;
+  float ix = ((gx + 1.f) * (float)w - 1.f) * 0.5f;
+  float iy = ((gy + 1.f) * (float)h - 1.f) * 0.5f;
+  ix = fminf((float)(w - 1), fmaxf(ix, 0.f));
+  iy = fminf((float)(h - 1), fmaxf(iy, 0.f));
+  const float fx = floorf(ix), fy = floorf(iy);
+  t.x0 = (int)fx;
+  t.y0 = (int)fy;
+  const float ax = ix - fx, ay = iy - fy, bx = (fx + 1.f) - ix, by = (fy + 1.f) - iy;
+  t.w[0] = bx * by;
+  t.w[1] = ax * by;
+  t.w[2] = bx * ay;
+  t.w[3] = ax * ay;
+  const bool xin1 = t.x0 + 1 < w, yin1 = t.y0 + 1 < h;
+  t.in[0] = true;
+  t.in[1] = xin1;
+  t.in[2] = yin1;
+  t.in[3] = xin1 && yin1;
+  return t;
+}
 
 // h from the four taps (nw, ne, sw, se): values z[k], west / east column coordinates u0 / u1,
 // north / south row coordinates v0 / v1.  Taps outside the image contribute nothing.
@@ -991,9 +1025,8 @@ FM_HD void dense_moments_add(const float g[3], const float h[3], float w, const 
 
 // The shift of a pair: g of its middle pixel (non-finite depth -> 0, as later_point).
 FM_HD void dense_shift(const float* depth_l, int height, int width, float gs[3]) {
-  const int idx = (int)(((long)height * width) / 2);
-  const int row = idx / width, col = idx - row * width;
-  const float z = depth_l[idx];
+  const int row = height / 2, col = width / 2;
+  const float z = depth_l[(size_t)row * width + col];
   gs[0] = z * pixel_center(col, width);
   gs[1] = z * pixel_center(row, height);
   gs[2] = z;

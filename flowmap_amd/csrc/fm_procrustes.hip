@@ -247,144 +247,184 @@ __global__ void __launch_bounds__(256) procrustes_scatter_repeat_kernel(ProcPara
 //                coalesced read-modify-writes.  Needs only (flow, weight, z) of the later pixel —
 //                dL/dq does not depend on the sampled point.
 // ---------------------------------------------------------------------------------
-constexpr int kTileH = kDenseTileH, kTileW = kDenseTileW, kHaloY = 16, kHaloX = 24;
-constexpr int kWinH = kTileH + 2 * kHaloY, kWinW = kTileW + 2 * kHaloX;  // 48 x 112 floats = 21 KB
+constexpr int kTileH = kDenseTileH, kTileW = kDenseTileW;    // 32 x 64 later-frame pixels per workgroup, 8 per thread
+constexpr int kWinH = kTileH + 32, kWinW = kTileW + 64;       // earlier-frame window: +-16 rows, +-32 columns (32 KB)
+constexpr int kRowsPerThread = kTileH / (256 / kTileW);
+static_assert(kTileW == 64 && kWinW % 4 == 0 && kTileH % 4 == 0, "thread mapping: one column, every 4th row");
 
-struct DenseTile {
-  int tx0, ty0;  // tile origin (later frame)
-  int wx0, wy0;  // window origin (earlier frame)
-  float inv_w, inv_h;
-};
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-// 1-D grid -> (pair, tile).  Workgroups are handed to the 8 XCDs round-robin by linear id and
-// each XCD has its own L2, so consecutive ids are sent to the SAME XCD's contiguous run of tiles:
-// neighbouring tiles (whose earlier-frame windows overlap five-fold) then share an L2.
+// 1-D grid -> (pair, tile).  Workgroups are handed to the 8 XCDs round-robin by linear id and each
+// XCD has its own L2, so consecutive ids are sent to the SAME XCD's contiguous run of tiles:
+// neighbouring tiles (whose earlier-frame windows overlap) then share an L2.  32-bit arithmetic
+// (the host checks pairs·tiles < 2^31): a 64-bit integer division costs hundreds of instructions.
 constexpr int kXcds = 8;
 struct DenseBlock {
-  long pair;
-  int tile_x, tile_y;
+  int pair, tile_x, tile_y;
   bool valid;
 };
 
-__device__ __forceinline__ DenseBlock dense_block(int height, int width, long total) {
-  const int tiles_x = (width + kTileW - 1) / kTileW, tiles_y = (height + kTileH - 1) / kTileH;
-  const long per_xcd = (total + kXcds - 1) / kXcds;
-  const long logical = (long)(blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+__device__ __forceinline__ DenseBlock dense_block(int height, int width, unsigned total) {
+  const unsigned tiles_x = (width + kTileW - 1) / kTileW, tiles_y = (height + kTileH - 1) / kTileH;
+  const unsigned per_xcd = (total + kXcds - 1) / kXcds;
+  const unsigned logical = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
   DenseBlock d;
   d.valid = blockIdx.x / kXcds < per_xcd && logical < total;
-  const long per_pair = (long)tiles_x * tiles_y;
-  d.pair = logical / per_pair;
-  const int tile = (int)(logical - d.pair * per_pair);
-  d.tile_y = tile / tiles_x;
-  d.tile_x = tile - d.tile_y * tiles_x;
+  const unsigned per_pair = tiles_x * tiles_y;
+  const unsigned pair = logical / per_pair, tile = logical - pair * per_pair;
+  d.pair = (int)pair;
+  d.tile_y = (int)(tile / tiles_x);
+  d.tile_x = (int)(tile - (unsigned)d.tile_y * tiles_x);
   return d;
 }
 
-__device__ __forceinline__ DenseTile dense_tile(const ProcParams& p, const CorrSrc& src, const DenseBlock& blk) {
-  DenseTile t;
-  t.tx0 = blk.tile_x * kTileW;
-  t.ty0 = blk.tile_y * kTileH;
-  t.inv_w = 1.0f / (float)p.width;
-  t.inv_h = 1.0f / (float)p.height;
-  const int cx = min(t.tx0 + kTileW / 2, p.width - 1), cy = min(t.ty0 + kTileH / 2, p.height - 1);
-  const float fx = src.bwd_flow[2 * ((size_t)cy * p.width + cx)], fy = src.bwd_flow[2 * ((size_t)cy * p.width + cx) + 1];
-  const float ox = fminf(fmaxf(rintf(fx * (float)p.width), -1.0e6f), 1.0e6f);
-  const float oy = fminf(fmaxf(rintf(fy * (float)p.height), -1.0e6f), 1.0e6f);
-  t.wx0 = t.tx0 - kHaloX + (ox == ox ? (int)ox : 0);
-  t.wy0 = t.ty0 - kHaloY + (oy == oy ? (int)oy : 0);
-  return t;
+// Everything a dense block knows about its pair and tile.
+struct DenseCtx {
+  const float* depth_e;   // earlier frame (H,W)
+  const float* depth_l;   // later frame
+  const float* bwd_flow;  // (H,W,2) of the pair
+  const float* weights;   // (H,W) of the pair (logits when sens != 0)
+  float sens;
+  int height, width;
+  float fw, fh, rcp_w, rcp_h;
+  int tx0, ty0;           // tile origin
+  int wx0, wy0;           // window origin in the earlier frame (wx0 % 4 == 0)
+  size_t pair, fe;        // pair index, earlier frame index (batch folded in)
+};
+
+__device__ __forceinline__ DenseCtx dense_ctx(const ProcParams& p, const DenseBlock& blk, bool window) {
+  DenseCtx c;
+  const int pairs_per_batch = p.frames - 1;
+  const int b = blk.pair / pairs_per_batch, i = blk.pair - b * pairs_per_batch;
+  const size_t n = (size_t)p.height * p.width;
+  c.pair = (size_t)blk.pair;
+  c.fe = (size_t)b * p.frames + i;
+  c.depth_e = p.depth + c.fe * n;
+  c.depth_l = c.depth_e + n;
+  c.bwd_flow = p.bwd_flow + c.pair * n * 2;
+  c.weights = p.weights + c.pair * n;
+  c.sens = p.weight_sens;
+  c.height = p.height;
+  c.width = p.width;
+  c.fw = (float)p.width;
+  c.fh = (float)p.height;
+  c.rcp_w = 1.0f / c.fw;
+  c.rcp_h = 1.0f / c.fh;
+  c.tx0 = blk.tile_x * kTileW;
+  c.ty0 = blk.tile_y * kTileH;
+  c.wx0 = c.wy0 = 0;
+  if (window) {  // the window follows the backward flow at the tile's centre
+    const int cx = min(c.tx0 + kTileW / 2, p.width - 1), cy = min(c.ty0 + kTileH / 2, p.height - 1);
+    const float2 fl = reinterpret_cast<const float2*>(c.bwd_flow)[(size_t)cy * p.width + cx];
+    const float ox = fminf(fmaxf(rintf(fl.x * c.fw), -1.0e6f), 1.0e6f);
+    const float oy = fminf(fmaxf(rintf(fl.y * c.fh), -1.0e6f), 1.0e6f);
+    c.wx0 = (c.tx0 - (kWinW - kTileW) / 2 + (ox == ox ? (int)ox : 0)) & ~3;
+    c.wy0 = c.ty0 - (kWinH - kTileH) / 2 + (oy == oy ? (int)oy : 0);
+  }
+  return c;
 }
 
-// Window of the earlier frame's depth plus the pixel-centre coordinates of its columns / rows
-// (sample_image_grid's true divisions, done once per block instead of ten times per pixel).
+// Window of the earlier frame's depth plus the pixel-centre coordinates of its columns / rows.
 struct DenseWindow {
   float z[kWinH * kWinW];
   float u[kWinW];
   float v[kWinH];
-  float tile_u[kTileW];  // the tile's own (later-frame) columns / rows
-  float tile_v[kTileH];
 };
 
-__device__ __forceinline__ void stage_depth_window(const ProcParams& p, const CorrSrc& src, const DenseTile& t, DenseWindow& win) {
-  for (int i = threadIdx.x; i < kWinH * kWinW; i += blockDim.x) {
-    const int gy = t.wy0 + i / kWinW, gx = t.wx0 + i % kWinW;
-    win.z[i] = (gy >= 0 && gy < p.height && gx >= 0 && gx < p.width) ? src.depth_e[(size_t)gy * p.width + gx] : 0.f;
+__device__ __forceinline__ void stage_depth_window(const DenseCtx& c, DenseWindow& win) {
+  if ((c.width & 3) == 0) {  // 16-byte loads: the window's columns start at a multiple of 4
+    for (int i = threadIdx.x; i < kWinH * (kWinW / 4); i += 256) {
+      const int r = i / (kWinW / 4), q = i - r * (kWinW / 4);
+      const int gy = c.wy0 + r, gx = c.wx0 + q * 4;
+      v4f val = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < c.height && gx >= 0 && gx < c.width) val = *reinterpret_cast<const v4f*>(c.depth_e + (size_t)gy * c.width + gx);
+      *reinterpret_cast<v4f*>(win.z + r * kWinW + q * 4) = val;
+    }
+  } else {
+    for (int i = threadIdx.x; i < kWinH * kWinW; i += 256) {
+      const int r = i / kWinW, q = i - r * kWinW;
+      const int gy = c.wy0 + r, gx = c.wx0 + q;
+      win.z[i] = (gy >= 0 && gy < c.height && gx >= 0 && gx < c.width) ? c.depth_e[(size_t)gy * c.width + gx] : 0.f;
+    }
   }
-  for (int i = threadIdx.x; i < kWinW; i += blockDim.x) win.u[i] = pixel_center(t.wx0 + i, p.width);
-  for (int i = threadIdx.x; i < kWinH; i += blockDim.x) win.v[i] = pixel_center(t.wy0 + i, p.height);
-  for (int i = threadIdx.x; i < kTileW; i += blockDim.x) win.tile_u[i] = pixel_center(t.tx0 + i, p.width);
-  for (int i = threadIdx.x; i < kTileH; i += blockDim.x) win.tile_v[i] = pixel_center(t.ty0 + i, p.height);
+  if (threadIdx.x < kWinW) win.u[threadIdx.x] = center_fast(c.wx0 + (int)threadIdx.x, c.fw, c.rcp_w);
+  else if (threadIdx.x < kWinW + kWinH) win.v[threadIdx.x - kWinW] = center_fast(c.wy0 + (int)threadIdx.x - kWinW, c.fh, c.rcp_h);
 }
 
-// One dense correspondence before any intrinsics: g, h, w and its taps.  The four tap depths and
-// their coordinates come from the LDS window when the 2x2 footprint lies inside it, else from
-// global memory (reciprocal multiply instead of sample_image_grid's true division there: within
-// 1 ulp, and the divisions would otherwise run for every wave in which a single lane misses).
+// The raw inputs of one later pixel (issued one loop iteration ahead of their use).
+struct DenseRaw {
+  float2 fl;
+  float wt, z;
+};
+__device__ __forceinline__ DenseRaw dense_load(const DenseCtx& c, int idx) {
+  DenseRaw r;
+  r.fl = reinterpret_cast<const float2*>(c.bwd_flow)[idx];
+  r.wt = c.weights[idx];
+  r.z = c.depth_l[idx];
+  return r;
+}
+
+// One dense correspondence before any intrinsics: g, h, w and its taps.  The four tap depths and their
+// coordinates come from the LDS window when the 2x2 footprint lies inside it, else from global memory.
 struct DensePixel {
-  float g[3], h[3], w, u, v;
+  float g[3], h[3], w;
   Taps taps;
 };
 
-template <bool FAST>
-__device__ __forceinline__ DensePixel dense_pixel(const ProcParams& p, const CorrSrc& src, const DenseTile& t, const DenseWindow& win, int row,
-                                                  int col, int r, int c) {
+__device__ __forceinline__ DensePixel dense_pixel(const DenseCtx& c, const DenseWindow& win, const DenseRaw& in, float u, float v) {
   DensePixel o;
-  const int idx = row * p.width + col;
-  o.u = win.tile_u[c];
-  o.v = win.tile_v[r];
-  const float2 fl = reinterpret_cast<const float2*>(src.bwd_flow)[idx];
-  float w = src.weights[idx];
-  if (src.weight_sens != 0.f) w = fm_sigmoid<FAST>(src.weight_sens * w);
-  o.w = w;
-  const float z = src.depth_l[idx];
-  o.g[0] = z * o.u;
-  o.g[1] = z * o.v;
-  o.g[2] = z;
-  o.taps = bilinear_taps(o.u + fl.x, o.v + fl.y, p.height, p.width);
-  const int wr = o.taps.y0 - t.wy0, wc = o.taps.x0 - t.wx0;
+  o.w = c.sens != 0.f ? fm_sigmoid<true>(c.sens * in.wt) : in.wt;
+  o.g[0] = in.z * u;
+  o.g[1] = in.z * v;
+  o.g[2] = in.z;
+  o.taps = dense_taps(u + in.fl.x, v + in.fl.y, c.height, c.width);
+  const int wr = o.taps.y0 - c.wy0, wc = o.taps.x0 - c.wx0;
   float zt[4], u0, u1, v0, v1;
-  if (wr >= 0 && wr + 1 < kWinH && wc >= 0 && wc + 1 < kWinW) {
+  if ((unsigned)wr < (unsigned)(kWinH - 1) && (unsigned)wc < (unsigned)(kWinW - 1)) {
     const float* zw = win.z + wr * kWinW + wc;
     zt[0] = zw[0], zt[1] = zw[1], zt[2] = zw[kWinW], zt[3] = zw[kWinW + 1];
     u0 = win.u[wc], u1 = win.u[wc + 1], v0 = win.v[wr], v1 = win.v[wr + 1];
   } else {
-    const int x1 = min(o.taps.x0 + 1, p.width - 1), y1 = min(o.taps.y0 + 1, p.height - 1);  // clamped reads; masked by taps.in
-    const float* d0 = src.depth_e + (size_t)o.taps.y0 * p.width;
-    const float* d1 = src.depth_e + (size_t)y1 * p.width;
+    const int x1 = min(o.taps.x0 + 1, c.width - 1), y1 = min(o.taps.y0 + 1, c.height - 1);  // clamped reads; masked by taps.in
+    const float* d0 = c.depth_e + (size_t)o.taps.y0 * c.width;
+    const float* d1 = c.depth_e + (size_t)y1 * c.width;
     zt[0] = d0[o.taps.x0], zt[1] = d0[x1], zt[2] = d1[o.taps.x0], zt[3] = d1[x1];
-    u0 = ((float)o.taps.x0 + 0.5f) * t.inv_w, u1 = ((float)o.taps.x0 + 1.5f) * t.inv_w;
-    v0 = ((float)o.taps.y0 + 0.5f) * t.inv_h, v1 = ((float)o.taps.y0 + 1.5f) * t.inv_h;
+    u0 = center_fast(o.taps.x0, c.fw, c.rcp_w), u1 = center_fast(o.taps.x0 + 1, c.fw, c.rcp_w);
+    v0 = center_fast(o.taps.y0, c.fh, c.rcp_h), v1 = center_fast(o.taps.y0 + 1, c.fh, c.rcp_h);
   }
   dense_h(o.taps, zt, u0, u1, v0, v1, o.h);
   return o;
 }
 
 // grid: 1-D, >= tiles·pairs blocks (dense_block).  Raw pixel-space moments of the tile's pixels.
-__global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParams p, long total) {
+__global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParams p, unsigned total) {
   __shared__ double red[4 * kMomentCount];
   __shared__ DenseWindow win;
   const DenseBlock blk = dense_block(p.height, p.width, total);
   if (!blk.valid) return;
-  const size_t pair = (size_t)blk.pair;
-  const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
-  const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
+  const DenseCtx c = dense_ctx(p, blk, true);
   float gs[3];
-  dense_shift(src.depth_l, p.height, p.width, gs);
-  const DenseTile t = dense_tile(p, src, blk);
-  stage_depth_window(p, src, t, win);
-  __syncthreads();
+  dense_shift(c.depth_l, p.height, p.width, gs);
+  stage_depth_window(c, win);
   float acc[kMomentCount];
 #pragma unroll
   for (int k = 0; k < kMomentCount; ++k) acc[k] = 0.f;
-  const int c = threadIdx.x & (kTileW - 1);
-  const int col = t.tx0 + c;
-  for (int r = threadIdx.x / kTileW; r < kTileH; r += 256 / kTileW) {
-    const int row = t.ty0 + r;
-    if (row >= p.height || col >= p.width) continue;
-    const DensePixel px = dense_pixel<true>(p, src, t, win, row, col, r, c);
+  const int col = c.tx0 + (threadIdx.x & (kTileW - 1));
+  int row = c.ty0 + threadIdx.x / kTileW;
+  const bool live = col < p.width;
+  const float u = center_fast(col, c.fw, c.rcp_w);
+  DenseRaw next = {};
+  if (live && row < p.height) next = dense_load(c, row * p.width + col);
+  __syncthreads();
+#pragma unroll 2
+  for (int k = 0; k < kRowsPerThread; ++k, row += 256 / kTileW) {
+    if (!live || row >= p.height) break;
+    const DenseRaw cur = next;
+    if (k + 1 < kRowsPerThread && row + 256 / kTileW < p.height) next = dense_load(c, (row + 256 / kTileW) * p.width + col);
+    const DensePixel px = dense_pixel(c, win, cur, u, center_fast(row, c.fh, c.rcp_h));
     dense_moments_add(px.g, px.h, px.w, gs, acc);
   }
-  block_accumulate<kMomentCount>(acc, red, p.stats + pair * kStatStride);
+  block_accumulate<kMomentCount>(acc, red, p.stats + c.pair * kStatStride);
 }
 
 // One thread per pair: pixel-space raw moments -> the statistics of align_rigid -> the pose.
@@ -400,55 +440,77 @@ __global__ void procrustes_finish_solve_dense_kernel(ProcParams p, int pairs, fl
   if (t_bwd) pose_solve_one(st, t_bwd + (size_t)pair * 16, t_fwd ? t_fwd + (size_t)pair * 16 : nullptr, aux + (size_t)pair * kAuxStride);
 }
 
-// The per-pair constants of the dense backward, computed by the first threads of a block (fp64).
-struct DenseBwdShared {
+// Per-pair constants of the dense backward, once per pair (fp64): consts (pairs, kDenseConstStride)
+// = DenseBwd (21 floats' worth), K_e (9), K_l (9).
+constexpr int kDenseConstStride = 40;
+__global__ void procrustes_dense_consts_kernel(ProcParams p, const double* aux, int pairs, double* consts) {
+  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= pairs) return;
+  const int b = pair / (p.frames - 1), i = pair % (p.frames - 1);
   DenseBwd c;
-  double k_e[9], k_l[9];
-};
+  double* o = consts + (size_t)pair * kDenseConstStride;
+  dense_bwd_consts(p.pair_grad + (size_t)pair * kPairGradStride, aux + (size_t)pair * kAuxStride, p.kinv + ((size_t)b * p.frames + i) * 9,
+                   p.kinv + ((size_t)b * p.frames + i + 1) * 9, c, o + 21, o + 30);
+  const float* f = c.bm;
+  for (int k = 0; k < 21; ++k) o[k] = (double)f[k];  // bm, a0, b0, gbar, hbar are contiguous
+}
 
-__device__ __forceinline__ void dense_bwd_setup(const ProcParams& p, const double* aux, size_t pair, int b, int i, DenseBwdShared& sh) {
-  if (threadIdx.x == 0)
-    dense_bwd_consts(p.pair_grad + pair * kPairGradStride, aux + pair * kAuxStride, p.kinv + ((size_t)b * p.frames + i) * 9,
-                     p.kinv + ((size_t)b * p.frames + i + 1) * 9, sh.c, sh.k_e, sh.k_l);
+__device__ __forceinline__ DenseBwd dense_load_consts(const double* consts, size_t pair) {
+  DenseBwd c;
+  float* f = c.bm;
+  const double* o = consts + pair * kDenseConstStride;
+#pragma unroll
+  for (int k = 0; k < 21; ++k) f[k] = (float)o[k];  // wave-uniform: scalar loads
+  return c;
 }
 
 // Dense backward, later role.  dL/dweights STORED (every element of every pair exactly once),
 // dL/ddepth of the later pixel added in place (this launch is the only writer of that pixel),
 // Σ (w·s) ⊗ g and Σ (w·t) ⊗ h reduced per block and mapped through K_lᵀ / K_eᵀ into kinv_acc.
-__global__ void __launch_bounds__(256) procrustes_dense_bwd_later_kernel(ProcParams p, const double* aux, long total) {
+__global__ void __launch_bounds__(256) procrustes_dense_bwd_later_kernel(ProcParams p, const double* consts, unsigned total) {
   __shared__ double red[4 * 18];
   __shared__ double tot[18];
   __shared__ DenseWindow win;
-  __shared__ DenseBwdShared sh;
   const DenseBlock blk = dense_block(p.height, p.width, total);
   if (!blk.valid) return;
-  const size_t pair = (size_t)blk.pair;
-  const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
+  const DenseCtx c = dense_ctx(p, blk, true);
   const size_t n = (size_t)p.height * p.width;
-  const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
-  const size_t fe = (size_t)b * p.frames + i, fl = fe + 1;
-  const DenseTile t = dense_tile(p, src, blk);
-  dense_bwd_setup(p, aux, pair, b, i, sh);
-  stage_depth_window(p, src, t, win);
-  __syncthreads();
-  const DenseBwd cst = sh.c;
-
+  const DenseBwd cst = dense_load_consts(consts, c.pair);
+  stage_depth_window(c, win);
   float acc[18];  // [0..8] Σ (w·t) ⊗ h (earlier frame), [9..17] Σ (w·s) ⊗ g (later frame)
 #pragma unroll
   for (int k = 0; k < 18; ++k) acc[k] = 0.f;
-  const int c = threadIdx.x & (kTileW - 1);
-  const int col = t.tx0 + c;
-  for (int r = threadIdx.x / kTileW; r < kTileH; r += 256 / kTileW) {
-    const int row = t.ty0 + r;
-    if (row >= p.height || col >= p.width) continue;
+  const int col = c.tx0 + (threadIdx.x & (kTileW - 1));
+  int row = c.ty0 + threadIdx.x / kTileW;
+  const bool live = col < p.width;
+  const float u = center_fast(col, c.fw, c.rcp_w);
+  float* gw_out = p.grad_weights ? p.grad_weights + c.pair * n : nullptr;
+  float* gd_out = p.grad_depth ? p.grad_depth + (c.fe + 1) * n : nullptr;
+  DenseRaw next = {};
+  float gd_next = 0.f;
+  if (live && row < p.height) {
+    next = dense_load(c, row * p.width + col);
+    if (gd_out) gd_next = gd_out[row * p.width + col];
+  }
+  __syncthreads();
+#pragma unroll 2
+  for (int k = 0; k < kRowsPerThread; ++k, row += 256 / kTileW) {
+    if (!live || row >= p.height) break;
     const int idx = row * p.width + col;
-    const DensePixel px = dense_pixel<true>(p, src, t, win, row, col, r, c);
+    const DenseRaw cur = next;
+    const float gd_cur = gd_next;
+    if (k + 1 < kRowsPerThread && row + 256 / kTileW < p.height) {
+      next = dense_load(c, idx + (256 / kTileW) * p.width);
+      if (gd_out) gd_next = gd_out[idx + (256 / kTileW) * p.width];
+    }
+    const float v = center_fast(row, c.fh, c.rcp_h);
+    const DensePixel px = dense_pixel(c, win, cur, u, v);
     float tv[3], gc[3], sv[3], gw;
     dense_bwd_t(cst, px.g, tv, gc);
     dense_bwd_s(cst, px.h, tv, gc, sv, gw);
-    if (p.weight_sens != 0.f) gw *= p.weight_sens * px.w * (1.f - px.w);  // d sigmoid(s·x)/dx
-    if (p.grad_weights) p.grad_weights[pair * n + idx] = gw;
-    if (p.grad_depth) p.grad_depth[fl * n + idx] += px.w * fmaf(sv[0], px.u, fmaf(sv[1], px.v, sv[2]));
+    if (c.sens != 0.f) gw *= c.sens * px.w * (1.f - px.w);  // d sigmoid(s·x)/dx
+    if (gw_out) gw_out[idx] = gw;
+    if (gd_out) gd_out[idx] = gd_cur + px.w * fmaf(sv[0], u, fmaf(sv[1], v, sv[2]));
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float wt = px.w * tv[a], ws = px.w * sv[a];
@@ -471,10 +533,10 @@ __global__ void __launch_bounds__(256) procrustes_dense_bwd_later_kernel(ProcPar
     __syncthreads();
     if (threadIdx.x < 18) {  // dL/dK⁻¹ = Kᵀ·(Σ …): element (r, d) of frame `which`
       const int which = threadIdx.x / 9, r = (threadIdx.x % 9) / 3, d = threadIdx.x % 3;
-      const double* k = which == 0 ? sh.k_e : sh.k_l;
+      const double* k = consts + c.pair * kDenseConstStride + 21 + which * 9;
       const double* a = tot + which * 9;
-      const double v = k[0 * 3 + r] * a[0 * 3 + d] + k[1 * 3 + r] * a[1 * 3 + d] + k[2 * 3 + r] * a[2 * 3 + d];
-      if (v != 0.0) atomicAdd(p.kinv_acc + fe * 9 + threadIdx.x, v);
+      const double val = k[0 * 3 + r] * a[0 * 3 + d] + k[1 * 3 + r] * a[1 * 3 + d] + k[2 * 3 + r] * a[2 * 3 + d];
+      if (val != 0.0) atomicAdd(p.kinv_acc + c.fe * 9 + threadIdx.x, val);
     }
   }
 }
@@ -482,88 +544,93 @@ __global__ void __launch_bounds__(256) procrustes_dense_bwd_later_kernel(ProcPar
 // Later pixels are listed per earlier-frame tile as (row << 16 | col).
 __device__ __forceinline__ uint32_t pack_pixel(int row, int col) { return ((uint32_t)row << 16) | (uint32_t)col; }
 
-// The <= 4 earlier-frame tiles the taps of later pixel (row, col) of `pair` land in; fn(tile index).
-template <class Fn>
-__device__ __forceinline__ void dense_tap_tiles(const float* bwd_flow_pair, int height, int width, int row, int col, const Fn& fn) {
-  const float2 fl = reinterpret_cast<const float2*>(bwd_flow_pair)[(size_t)row * width + col];
-  const Taps t = bilinear_taps(pixel_center(col, width) + fl.x, pixel_center(row, height) + fl.y, height, width);
-  const int tiles_x = (width + kTileW - 1) / kTileW;
-  const int txa = t.x0 / kTileW, tya = t.y0 / kTileH;
-  const int txb = (t.x0 + 1 < width) ? (t.x0 + 1) / kTileW : txa, tyb = (t.y0 + 1 < height) ? (t.y0 + 1) / kTileH : tya;
-  fn(tya * tiles_x + txa);
-  if (txb != txa) fn(tya * tiles_x + txb);
-  if (tyb != tya) {
-    fn(tyb * tiles_x + txa);
-    if (txb != txa) fn(tyb * tiles_x + txb);
-  }
-}
-
-// Plan, pass 1 (list == null): counts[pair·tiles + tile] += 1 per (later pixel, tile it touches);
+// Plan, pass 1 (list == null): counts[pair·tiles + tile] += 1 per (later pixel, tile its taps land in);
 // pass 2: list[first[...] + cursor++] = packed later pixel.  grid: (pixel chunks, pairs).
 __global__ void __launch_bounds__(256) procrustes_dense_plan_kernel(const float* bwd_flow, int height, int width, int* counts,
                                                                      const int64_t* first, uint32_t* list) {
   const size_t pair = blockIdx.y;
-  const long n = (long)height * width;
-  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = height * width;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const int row = (int)(j / width), col = (int)(j - (long)row * width);
-  const int tiles = ((width + kTileW - 1) / kTileW) * ((height + kTileH - 1) / kTileH);
-  int* cnt = counts + pair * tiles;
-  dense_tap_tiles(bwd_flow + pair * (size_t)n * 2, height, width, row, col, [&](int tile) {
+  const int row = j / width, col = j - row * width;
+  const float fw = (float)width, fh = (float)height;
+  const float2 fl = reinterpret_cast<const float2*>(bwd_flow + pair * (size_t)n * 2)[j];
+  const Taps t = dense_taps(center_fast(col, fw, 1.0f / fw) + fl.x, center_fast(row, fh, 1.0f / fh) + fl.y, height, width);
+  const int tiles_x = (width + kTileW - 1) / kTileW, tiles_y = (height + kTileH - 1) / kTileH;
+  const int txa = t.x0 / kTileW, tya = t.y0 / kTileH;
+  const int txb = t.in[1] ? (t.x0 + 1) / kTileW : txa, tyb = t.in[2] ? (t.y0 + 1) / kTileH : tya;
+  int* cnt = counts + pair * ((size_t)tiles_x * tiles_y);
+  const int64_t* fst = first ? first + pair * ((size_t)tiles_x * tiles_y) : nullptr;
+  auto note = [&](int tile) {
     const int pos = atomicAdd(cnt + tile, 1);
-    if (list) list[first[pair * tiles + tile] + pos] = pack_pixel(row, col);
-  });
+    if (list) list[fst[tile] + pos] = pack_pixel(row, col);
+  };
+  note(tya * tiles_x + txa);
+  if (txb != txa) note(tya * tiles_x + txb);
+  if (tyb != tya) {
+    note(tyb * tiles_x + txa);
+    if (txb != txa) note(tyb * tiles_x + txb);
+  }
 }
 
 // Dense backward, earlier role: block = (pair, tile of the EARLIER frame).
-__global__ void __launch_bounds__(256) procrustes_dense_bwd_taps_kernel(ProcParams p, const double* aux, const int64_t* first,
-                                                                         const uint32_t* list, long total) {
+__global__ void __launch_bounds__(256) procrustes_dense_bwd_taps_kernel(ProcParams p, const double* consts, const int64_t* first,
+                                                                         const uint32_t* list, unsigned total) {
   __shared__ float gacc[kTileH * kTileW];
-  __shared__ float tile_u[kTileW + 1], tile_v[kTileH + 1];
-  __shared__ DenseBwdShared sh;
+  __shared__ float tile_u[kTileW], tile_v[kTileH];
   const DenseBlock blk = dense_block(p.height, p.width, total);
   if (!blk.valid) return;
-  const size_t pair = (size_t)blk.pair;
-  const int b = (int)(pair / (p.frames - 1)), i = (int)(pair % (p.frames - 1));
+  const DenseCtx c = dense_ctx(p, blk, false);
   const size_t n = (size_t)p.height * p.width;
-  const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
-  const size_t fe = (size_t)b * p.frames + i;
-  const int tx0 = blk.tile_x * kTileW, ty0 = blk.tile_y * kTileH;
+  const DenseBwd cst = dense_load_consts(consts, c.pair);
   const int tiles_x = (p.width + kTileW - 1) / kTileW, tiles_y = (p.height + kTileH - 1) / kTileH;
-  dense_bwd_setup(p, aux, pair, b, i, sh);
-  for (int c = threadIdx.x; c < kTileH * kTileW; c += blockDim.x) gacc[c] = 0.f;
-  for (int c = threadIdx.x; c <= kTileW; c += blockDim.x) tile_u[c] = pixel_center(tx0 + c, p.width);
-  for (int c = threadIdx.x; c <= kTileH; c += blockDim.x) tile_v[c] = pixel_center(ty0 + c, p.height);
-  __syncthreads();
-  const DenseBwd cst = sh.c;
-  const size_t slot = pair * ((size_t)tiles_x * tiles_y) + (size_t)blk.tile_y * tiles_x + blk.tile_x;
+  for (int i = threadIdx.x; i < kTileH * kTileW; i += 256) gacc[i] = 0.f;
+  if (threadIdx.x < kTileW) tile_u[threadIdx.x] = center_fast(c.tx0 + (int)threadIdx.x, c.fw, c.rcp_w);
+  else if (threadIdx.x < kTileW + kTileH) tile_v[threadIdx.x - kTileW] = center_fast(c.ty0 + (int)threadIdx.x - kTileW, c.fh, c.rcp_h);
+  const size_t slot = c.pair * ((size_t)tiles_x * tiles_y) + (size_t)blk.tile_y * tiles_x + blk.tile_x;
   const int64_t lo = first[slot], hi = first[slot + 1];
-  for (int64_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
-    const uint32_t pk = list[e];
-    const int row = (int)(pk >> 16), col = (int)(pk & 0xffffu);
-    const int idx = row * p.width + col;
-    const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
-    const float2 fl = reinterpret_cast<const float2*>(src.bwd_flow)[idx];
-    float w = src.weights[idx];
-    if (src.weight_sens != 0.f) w = fm_sigmoid<true>(src.weight_sens * w);
-    const float z = src.depth_l[idx];
-    const float g[3] = {z * u, z * v, z};
+  // this thread's share of the tile's dL/ddepth, fetched early (added to at the end)
+  float* gd = p.grad_depth + c.fe * n;
+  const int col = c.tx0 + (threadIdx.x & (kTileW - 1));
+  const int row0 = c.ty0 + threadIdx.x / kTileW;
+  float old[kRowsPerThread];
+#pragma unroll
+  for (int k = 0; k < kRowsPerThread; ++k) {
+    const int row = row0 + k * (256 / kTileW);
+    old[k] = (col < p.width && row < p.height) ? gd[(size_t)row * p.width + col] : 0.f;
+  }
+  int64_t e = lo + threadIdx.x;
+  uint32_t pk = e < hi ? list[e] : 0u;
+  DenseRaw next = {};
+  if (e < hi) next = dense_load(c, (int)(pk >> 16) * p.width + (int)(pk & 0xffffu));
+  __syncthreads();
+  for (; e < hi; e += 256) {
+    const int row = (int)(pk >> 16), colx = (int)(pk & 0xffffu);
+    const DenseRaw cur = next;
+    if (e + 256 < hi) {
+      pk = list[e + 256];
+      next = dense_load(c, (int)(pk >> 16) * p.width + (int)(pk & 0xffffu));
+    }
+    const float u = center_fast(colx, c.fw, c.rcp_w), v = center_fast(row, c.fh, c.rcp_h);
+    const float w = c.sens != 0.f ? fm_sigmoid<true>(c.sens * cur.wt) : cur.wt;
+    const float g[3] = {cur.z * u, cur.z * v, cur.z};
     float tv[3], gc[3];
     dense_bwd_t(cst, g, tv, gc);
     const float b0 = w * tv[0], b1 = w * tv[1], b2 = w * tv[2];  // K⁻ᵀ_e·dL/dq
-    const Taps tp = bilinear_taps(u + fl.x, v + fl.y, p.height, p.width);  // exactly as the plan and the other dense kernels
+    const Taps tp = dense_taps(u + cur.fl.x, v + cur.fl.y, p.height, p.width);  // exactly as the plan and the other dense kernels
+    const int rr = tp.y0 - c.ty0, cc = tp.x0 - c.tx0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int rr = tp.y0 + (k >> 1) - ty0, cc = tp.x0 + (k & 1) - tx0;
-      if (!tp.in[k] || rr < 0 || rr >= kTileH || cc < 0 || cc >= kTileW) continue;
-      atomicAdd(gacc + rr * kTileW + cc, tp.w[k] * fmaf(b0, tile_u[cc], fmaf(b1, tile_v[rr], b2)));
+      const int r1 = rr + (k >> 1), c1 = cc + (k & 1);
+      if (!tp.in[k] || (unsigned)r1 >= (unsigned)kTileH || (unsigned)c1 >= (unsigned)kTileW) continue;
+      atomicAdd(gacc + r1 * kTileW + c1, tp.w[k] * fmaf(b0, tile_u[c1], fmaf(b1, tile_v[r1], b2)));
     }
   }
   __syncthreads();
-  float* gd = p.grad_depth + fe * n;
-  for (int c = threadIdx.x; c < kTileH * kTileW; c += blockDim.x) {
-    const int gy = ty0 + c / kTileW, gx = tx0 + c % kTileW;
-    if (gy < p.height && gx < p.width) gd[(size_t)gy * p.width + gx] += gacc[c];
+#pragma unroll
+  for (int k = 0; k < kRowsPerThread; ++k) {
+    const int row = row0 + k * (256 / kTileW);
+    if (col < p.width && row < p.height) gd[(size_t)row * p.width + col] = old[k] + gacc[(row - c.ty0) * kTileW + (col - c.tx0)];
   }
 }
 
@@ -1005,7 +1072,7 @@ static int procrustes_stats_launch(const float* depth, const float* kinv, const 
   const bool dense = dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width, pairs);
   if (dense) {
     const long total = dense_blocks(height, width, pairs);
-    hipLaunchKernelGGL(procrustes_moments_dense_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, total);
+    hipLaunchKernelGGL(procrustes_moments_dense_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, (unsigned)total);
   } else if (surfaces) {
     hipLaunchKernelGGL((procrustes_moments_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, iters);
   } else {
@@ -1110,8 +1177,8 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
 int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights,
                                 float weight_sensitivity, int batch, int frames, int height, int width, const double* aux,
                                 const double* pair_grad, float* grad_depth, float* grad_weights, double* kinv_acc, const int64_t* first,
-                                const uint32_t* list, void* stream) {
-  FM_CHECK_ARG(depth && kinv && bwd_flow && weights && aux && pair_grad && batch >= 1 && frames >= 2);
+                                const uint32_t* list, double* consts, void* stream) {
+  FM_CHECK_ARG(depth && kinv && bwd_flow && weights && aux && pair_grad && consts && batch >= 1 && frames >= 2);
   FM_CHECK_ARG(height >= 1 && width >= 1 && height <= 65535 && width <= 65535 && (long)height * width < (1L << 30));
   FM_CHECK_ARG(!grad_depth || (first && list));
   const int pairs = batch * (frames - 1);
@@ -1121,9 +1188,10 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
   p.depth = depth; p.kinv = kinv; p.bwd_flow = bwd_flow; p.weights = weights; p.pair_grad = pair_grad; p.grad_depth = grad_depth;
   p.grad_weights = grad_weights; p.kinv_acc = kinv_acc; p.frames = frames; p.height = height; p.width = width;
   p.points = (long)height * width; p.weight_sens = weight_sensitivity; p.batch_repeat = 1;
-  const long total = dense_blocks(height, width, pairs);
-  hipLaunchKernelGGL(procrustes_dense_bwd_later_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, aux, total);
-  if (grad_depth) hipLaunchKernelGGL(procrustes_dense_bwd_taps_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, aux, first, list, total);
+  const unsigned total = (unsigned)dense_blocks(height, width, pairs);
+  hipLaunchKernelGGL(procrustes_dense_consts_kernel, dim3((pairs + 63) / 64), dim3(64), 0, st, p, aux, pairs, consts);
+  hipLaunchKernelGGL(procrustes_dense_bwd_later_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, consts, total);
+  if (grad_depth) hipLaunchKernelGGL(procrustes_dense_bwd_taps_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, consts, first, list, total);
   FM_LAUNCH_STATUS();
 }
 

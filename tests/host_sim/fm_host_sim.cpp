@@ -414,19 +414,20 @@ struct SimDensePixel {
 static SimDensePixel sim_dense_pixel(const CorrSrc& src, int row, int col) {
   SimDensePixel o;
   const int idx = row * src.width + col;
-  o.u = pixel_center(col, src.width);
-  o.v = pixel_center(row, src.height);
+  const float fw = (float)src.width, fh = (float)src.height;
+  o.u = center_fast(col, fw, 1.0f / fw);
+  o.v = center_fast(row, fh, 1.0f / fh);
   float w = src.weights[idx];
   if (src.weight_sens != 0.f) w = fm_sigmoid<false>(src.weight_sens * w);
   o.w = w;
   const float z = src.depth_l[idx];
   o.g[0] = z * o.u; o.g[1] = z * o.v; o.g[2] = z;
-  o.taps = bilinear_taps(o.u + src.bwd_flow[2 * (size_t)idx], o.v + src.bwd_flow[2 * (size_t)idx + 1], src.height, src.width);
+  o.taps = dense_taps(o.u + src.bwd_flow[2 * (size_t)idx], o.v + src.bwd_flow[2 * (size_t)idx + 1], src.height, src.width);
   const int x1 = std::min(o.taps.x0 + 1, src.width - 1), y1 = std::min(o.taps.y0 + 1, src.height - 1);
   const float zt[4] = {src.depth_e[(size_t)o.taps.y0 * src.width + o.taps.x0], src.depth_e[(size_t)o.taps.y0 * src.width + x1],
                        src.depth_e[(size_t)y1 * src.width + o.taps.x0], src.depth_e[(size_t)y1 * src.width + x1]};
-  dense_h(o.taps, zt, pixel_center(o.taps.x0, src.width), pixel_center(o.taps.x0 + 1, src.width), pixel_center(o.taps.y0, src.height),
-          pixel_center(o.taps.y0 + 1, src.height), o.h);
+  dense_h(o.taps, zt, center_fast(o.taps.x0, fw, 1.0f / fw), center_fast(o.taps.x0 + 1, fw, 1.0f / fw), center_fast(o.taps.y0, fh, 1.0f / fh),
+          center_fast(o.taps.y0 + 1, fh, 1.0f / fh), o.h);
   return o;
 }
 
@@ -483,7 +484,8 @@ int fm_procrustes_dense_tiles(int height, int width, int* tiles) {
 template <class Fn>
 static void sim_tap_tiles(const float* flow_pair, int height, int width, int row, int col, const Fn& fn) {
   const float* fl = flow_pair + 2 * ((size_t)row * width + col);
-  const Taps t = bilinear_taps(pixel_center(col, width) + fl[0], pixel_center(row, height) + fl[1], height, width);
+  const float fw = (float)width, fh = (float)height;
+  const Taps t = dense_taps(center_fast(col, fw, 1.0f / fw) + fl[0], center_fast(row, fh, 1.0f / fh) + fl[1], height, width);
   const int tiles_x = (width + kDenseTileW - 1) / kDenseTileW;
   const int txa = t.x0 / kDenseTileW, tya = t.y0 / kDenseTileH;
   const int txb = (t.x0 + 1 < width) ? (t.x0 + 1) / kDenseTileW : txa, tyb = (t.y0 + 1 < height) ? (t.y0 + 1) / kDenseTileH : tya;
@@ -514,7 +516,7 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
 
 int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float sens, int batch,
                                 int frames, int height, int width, const double* aux, const double* pair_grad, float* grad_depth,
-                                float* grad_weights, double* kinv_acc, const int64_t* first, const uint32_t* list, void*) {
+                                float* grad_weights, double* kinv_acc, const int64_t* first, const uint32_t* list, double*, void*) {
   if (!depth || !kinv || !bwd_flow || !weights || !aux || !pair_grad || (grad_depth && (!first || !list))) return 1;
   int tiles = 0;
   fm_procrustes_dense_tiles(height, width, &tiles);
@@ -558,19 +560,20 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
       for (int64_t e = first[(size_t)pr * tiles + tile]; e < first[(size_t)pr * tiles + tile + 1]; ++e) {
         const int row = (int)(list[e] >> 16), col = (int)(list[e] & 0xffffu);
         const size_t idx = (size_t)row * width + col;
-        const float u = pixel_center(col, width), v = pixel_center(row, height);
+        const float fw = (float)width, fh = (float)height;
+        const float u = center_fast(col, fw, 1.0f / fw), v = center_fast(row, fh, 1.0f / fh);
         float w = src.weights[idx];
         if (sens != 0.f) w = fm_sigmoid<false>(sens * w);
         const float z = src.depth_l[idx];
         const float g[3] = {z * u, z * v, z};
         float tv[3], gc[3];
         dense_bwd_t(c, g, tv, gc);
-        const Taps tp = bilinear_taps(u + src.bwd_flow[2 * idx], v + src.bwd_flow[2 * idx + 1], height, width);
+        const Taps tp = dense_taps(u + src.bwd_flow[2 * idx], v + src.bwd_flow[2 * idx + 1], height, width);
         for (int k = 0; k < 4; ++k) {
           const int rr = tp.y0 + (k >> 1) - ty0, cc = tp.x0 + (k & 1) - tx0;
           if (!tp.in[k] || rr < 0 || rr >= kDenseTileH || cc < 0 || cc >= kDenseTileW) continue;
           grad_depth[fe * n + (size_t)(ty0 + rr) * width + tx0 + cc] +=
-              tp.w[k] * fmaf(w * tv[0], pixel_center(tx0 + cc, width), fmaf(w * tv[1], pixel_center(ty0 + rr, height), w * tv[2]));
+              tp.w[k] * fmaf(w * tv[0], center_fast(tx0 + cc, fw, 1.0f / fw), fmaf(w * tv[1], center_fast(ty0 + rr, fh, 1.0f / fh), w * tv[2]));
         }
       }
     }
