@@ -573,6 +573,38 @@ __global__ void __launch_bounds__(256) procrustes_dense_plan_kernel(const float*
   }
 }
 
+// Plan, pass 3: every tile's list in ascending (row, col) order, so that a wave of the tap kernel reads
+// (nearly) consecutive pixels.  The order the atomic cursors of pass 2 produce is arbitrary — adjacent
+// lanes would gather from unrelated cache lines (measured: 2.9 ms per step instead of 0.9).  One block per
+// list, bitonic sort in LDS, in chunks of kSortChunk entries (a longer list ends up sorted chunk-wise:
+// the order only matters for coalescing, not for the result).
+constexpr int kSortChunk = 4096;
+__global__ void __launch_bounds__(256) procrustes_dense_plan_sort_kernel(const int64_t* first, uint32_t* list) {
+  __shared__ uint32_t buf[kSortChunk];
+  const int64_t lo = first[blockIdx.x], hi = first[blockIdx.x + 1];
+  for (int64_t base = lo; base < hi; base += kSortChunk) {
+    const int count = (int)min((int64_t)kSortChunk, hi - base);
+    for (int i = threadIdx.x; i < kSortChunk; i += 256) buf[i] = i < count ? list[base + i] : 0xffffffffu;
+    __syncthreads();
+    for (int size = 2; size <= kSortChunk; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = threadIdx.x; i < kSortChunk / 2; i += 256) {
+          const int lo_i = 2 * i - (i & (stride - 1));  // index with bit `stride` clear
+          const int hi_i = lo_i + stride;
+          const bool up = (lo_i & size) == 0;
+          const uint32_t a = buf[lo_i], b = buf[hi_i];
+          if ((a > b) == up) {
+            buf[lo_i] = b;
+            buf[hi_i] = a;
+          }
+        }
+        __syncthreads();
+      }
+    for (int i = threadIdx.x; i < count; i += 256) list[base + i] = buf[i];
+    __syncthreads();
+  }
+}
+
 // Dense backward, earlier role: block = (pair, tile of the EARLIER frame).
 __global__ void __launch_bounds__(256) procrustes_dense_bwd_taps_kernel(ProcParams p, const double* consts, const int64_t* first,
                                                                          const uint32_t* list, unsigned total) {
@@ -1171,6 +1203,11 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
   const long n = (long)height * width;
   hipLaunchKernelGGL(procrustes_dense_plan_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(batch * (frames - 1))), dim3(256), 0,
                      (hipStream_t)stream, bwd_flow, height, width, counts, first, list);
+  if (list) {  // pass 2 is followed by the per-tile sort
+    int tiles = 0;
+    fm_procrustes_dense_tiles(height, width, &tiles);
+    hipLaunchKernelGGL(procrustes_dense_plan_sort_kernel, dim3((unsigned)(batch * (frames - 1) * tiles)), dim3(256), 0, (hipStream_t)stream, first, list);
+  }
   FM_LAUNCH_STATUS();
 }
 

@@ -150,7 +150,9 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
  *           zeroed by the caller, += 1 per (later pixel, tile its bilinear taps land in)
  *   first  = exclusive prefix sum of counts, (B·(F-1)·tiles + 1) int64            [caller]
  *   pass 2: fm_procrustes_dense_plan(bwd_flow, B, F, H, W, cursor, first, list)   cursor: zeroed int32 of the
- *           same size; list (first[last]) uint32 = row << 16 | col of the later pixels, grouped by tile.
+ *           same size; list (first[last]) uint32 = row << 16 | col of the later pixels, grouped by tile and, inside a
+ *           tile, in ascending order (sorted by the same call: a wave of the per-step kernel then reads nearly
+ *           consecutive pixels).
  * Per step fm_procrustes_scatter_dense: grad_weights (B,F-1,H,W) is STORED (every element exactly once:
  * need not be zeroed, must not hold another gradient); grad_depth (B,F,H,W) is ADDED to with plain
  * read-modify-writes (each pixel has one writer per launch); kinv_acc (B·F,9) fp64 is added to (caller

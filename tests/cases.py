@@ -827,10 +827,21 @@ def case_dense_procrustes(dev, h, w, flow_sigma, f=4):
     res = {}
     for name, idx in (("tiled", None), ("generic", torch.arange(h * w, device=dev))):
         d, kk, lg = (x.clone().to(dev).requires_grad_(True) for x in (depth, k, logits))
-        t_bwd, t_fwd = _ops.ProcrustesFit.apply(d, kk, None, lg, flow.to(dev), idx, 100.0, 1)
+        fl_dev = flow.to(dev)
+        t_bwd, t_fwd = _ops.ProcrustesFit.apply(d, kk, None, lg, fl_dev, idx, 100.0, 1)
         ((t_bwd * cot_b.to(dev)).sum() + (t_fwd * cot_f.to(dev)).sum()).backward()
         res[name] = (t_bwd.detach(), d.grad, lg.grad, kk.grad)
+        if idx is None:
+            res["plan"] = fl_dev._fm_dense_plan[1:]
     truth = (rel64.detach(), d64.grad, l64.grad, k64.grad)
+    # the static tap lists: one entry per (later pixel, earlier-frame tile its taps touch), every tile's list ascending
+    first, entries = _ops._dense_procrustes_plan(flow.to(dev), 1, f, h, w) if False else res["plan"]
+    first, entries = first.cpu(), entries.cpu().numpy().view(np.uint32)
+    assert int(first[-1]) >= (f - 1) * h * w and int(first[-1]) <= 4 * (f - 1) * h * w
+    for lo, hi in zip(first[:-1].tolist(), first[1:].tolist()):
+        seg = entries[lo:hi]
+        assert (seg[1:] > seg[:-1]).all(), "tile list not in ascending pixel order"
+        assert ((seg >> 16) < h).all() and ((seg & 0xFFFF) < w).all()
     for a, b, c, what in zip(res["tiled"], res["generic"], truth, ("t_bwd", "g_depth", "g_logits", "g_k")):
         assert torch.isfinite(a).all(), what
         assert_close(a, c, TOL, what=f"{what} vs fp64 oracle")

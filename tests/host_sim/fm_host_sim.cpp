@@ -511,6 +511,7 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
           const int pos = counts[(size_t)pr * tiles + tile]++;
           if (list) list[first[(size_t)pr * tiles + tile] + pos] = ((uint32_t)row << 16) | (uint32_t)col;
         });
+  // (row-major enumeration: every tile's list is already in ascending order, as the device's sort leaves it)
   return 0;
 }
 
