@@ -631,31 +631,41 @@ __global__ void __launch_bounds__(256) procrustes_dense_bwd_taps_kernel(ProcPara
     const int row = row0 + k * (256 / kTileW);
     old[k] = (col < p.width && row < p.height) ? gd[(size_t)row * p.width + col] : 0.f;
   }
-  int64_t e = lo + threadIdx.x;
-  uint32_t pk = e < hi ? list[e] : 0u;
-  DenseRaw next = {};
-  if (e < hi) next = dense_load(c, (int)(pk >> 16) * p.width + (int)(pk & 0xffffu));
   __syncthreads();
-  for (; e < hi; e += 256) {
-    const int row = (int)(pk >> 16), colx = (int)(pk & 0xffffu);
-    const DenseRaw cur = next;
-    if (e + 256 < hi) {
-      pk = list[e + 256];
-      next = dense_load(c, (int)(pk >> 16) * p.width + (int)(pk & 0xffffu));
-    }
-    const float u = center_fast(colx, c.fw, c.rcp_w), v = center_fast(row, c.fh, c.rcp_h);
-    const float w = c.sens != 0.f ? fm_sigmoid<true>(c.sens * cur.wt) : cur.wt;
-    const float g[3] = {cur.z * u, cur.z * v, cur.z};
-    float tv[3], gc[3];
-    dense_bwd_t(cst, g, tv, gc);
-    const float b0 = w * tv[0], b1 = w * tv[1], b2 = w * tv[2];  // K⁻ᵀ_e·dL/dq
-    const Taps tp = dense_taps(u + cur.fl.x, v + cur.fl.y, p.height, p.width);  // exactly as the plan and the other dense kernels
-    const int rr = tp.y0 - c.ty0, cc = tp.x0 - c.tx0;
+  // The list is walked in batches of kTapBatch entries per thread: all list words of a batch are loaded
+  // first, then all the pixel data they point to, then the arithmetic — two memory latencies per batch of
+  // 2048 correspondences instead of two per 256 (a one-ahead prefetch still left the dependent
+  // list -> address -> data chain exposed every iteration: 3.0 ms per step; measured with this: see DESIGN.md).
+  constexpr int kTapBatch = 8;
+  for (int64_t base = lo; base < hi; base += kTapBatch * 256) {
+    uint32_t pk[kTapBatch];
+    DenseRaw raw[kTapBatch];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int r1 = rr + (k >> 1), c1 = cc + (k & 1);
-      if (!tp.in[k] || (unsigned)r1 >= (unsigned)kTileH || (unsigned)c1 >= (unsigned)kTileW) continue;
-      atomicAdd(gacc + r1 * kTileW + c1, tp.w[k] * fmaf(b0, tile_u[c1], fmaf(b1, tile_v[r1], b2)));
+    for (int j = 0; j < kTapBatch; ++j) {
+      const int64_t e = base + j * 256 + threadIdx.x;
+      pk[j] = list[e < hi ? e : lo];  // clamped: the entry is ignored below
+    }
+#pragma unroll
+    for (int j = 0; j < kTapBatch; ++j) raw[j] = dense_load(c, (int)(pk[j] >> 16) * p.width + (int)(pk[j] & 0xffffu));
+#pragma unroll
+    for (int j = 0; j < kTapBatch; ++j) {
+      if (base + j * 256 + threadIdx.x >= hi) continue;
+      const int row = (int)(pk[j] >> 16), colx = (int)(pk[j] & 0xffffu);
+      const DenseRaw cur = raw[j];
+      const float u = center_fast(colx, c.fw, c.rcp_w), v = center_fast(row, c.fh, c.rcp_h);
+      const float w = c.sens != 0.f ? fm_sigmoid<true>(c.sens * cur.wt) : cur.wt;
+      const float g[3] = {cur.z * u, cur.z * v, cur.z};
+      float tv[3], gc[3];
+      dense_bwd_t(cst, g, tv, gc);
+      const float b0 = w * tv[0], b1 = w * tv[1], b2 = w * tv[2];  // K⁻ᵀ_e·dL/dq
+      const Taps tp = dense_taps(u + cur.fl.x, v + cur.fl.y, p.height, p.width);  // exactly as the plan and the other dense kernels
+      const int rr = tp.y0 - c.ty0, cc = tp.x0 - c.tx0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r1 = rr + (k >> 1), c1 = cc + (k & 1);
+        if (!tp.in[k] || (unsigned)r1 >= (unsigned)kTileH || (unsigned)c1 >= (unsigned)kTileW) continue;
+        atomicAdd(gacc + r1 * kTileW + c1, tp.w[k] * fmaf(b0, tile_u[c1], fmaf(b1, tile_v[r1], b2)));
+      }
     }
   }
   __syncthreads();
