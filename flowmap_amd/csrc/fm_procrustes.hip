@@ -606,37 +606,44 @@ __global__ void __launch_bounds__(256) procrustes_dense_plan_sort_kernel(const i
 }
 
 // Dense backward, earlier role: block = (pair, tile of the EARLIER frame).
+//
+// The tap gradients of the listed correspondences are summed per tile cell in LDS with 64-bit INTEGER
+// atomics on a per-batch fixed-point scale: ds_add_f32 runs at about half a lane per clock on this
+// part (measured, tools/dense_microbench.py: 227 M float LDS atomics 0.71 ms, the same adds as
+// ds_add_u64 0.02 ms), and integer sums do not depend on the order of arrival, so dL/ddepth is
+// bit-reproducible.  Per batch of kTapBatch·256 list entries: (1) load, form β = w·t and the bound
+// |β0|+|β1|+|β2| >= |any tap value|, (2) block maximum -> scale 2^e with |value|·2^e <= 2^30, (3) taps,
+// values converted to 49-bit fixed point and added as 64-bit words, (4) every thread folds the cells it
+// owns into its fp32 running sums and clears them.
+constexpr int kTapBatch = 8;
+
 __global__ void __launch_bounds__(256) procrustes_dense_bwd_taps_kernel(ProcParams p, const double* consts, const int64_t* first,
                                                                          const uint32_t* list, unsigned total) {
-  __shared__ float gacc[kTileH * kTileW];
+  __shared__ unsigned long long iacc[kTileH * kTileW];
   __shared__ float tile_u[kTileW], tile_v[kTileH];
+  __shared__ float wave_max[4];
   const DenseBlock blk = dense_block(p.height, p.width, total);
   if (!blk.valid) return;
   const DenseCtx c = dense_ctx(p, blk, false);
   const size_t n = (size_t)p.height * p.width;
   const DenseBwd cst = dense_load_consts(consts, c.pair);
   const int tiles_x = (p.width + kTileW - 1) / kTileW, tiles_y = (p.height + kTileH - 1) / kTileH;
-  for (int i = threadIdx.x; i < kTileH * kTileW; i += 256) gacc[i] = 0.f;
+  for (int i = threadIdx.x; i < kTileH * kTileW; i += 256) iacc[i] = 0ull;
   if (threadIdx.x < kTileW) tile_u[threadIdx.x] = center_fast(c.tx0 + (int)threadIdx.x, c.fw, c.rcp_w);
   else if (threadIdx.x < kTileW + kTileH) tile_v[threadIdx.x - kTileW] = center_fast(c.ty0 + (int)threadIdx.x - kTileW, c.fh, c.rcp_h);
   const size_t slot = c.pair * ((size_t)tiles_x * tiles_y) + (size_t)blk.tile_y * tiles_x + blk.tile_x;
   const int64_t lo = first[slot], hi = first[slot + 1];
-  // this thread's share of the tile's dL/ddepth, fetched early (added to at the end)
+  // this thread's cells of the tile: the gradient already there is fetched early, added to at the end
   float* gd = p.grad_depth + c.fe * n;
-  const int col = c.tx0 + (threadIdx.x & (kTileW - 1));
-  const int row0 = c.ty0 + threadIdx.x / kTileW;
-  float old[kRowsPerThread];
+  const int lcol = threadIdx.x & (kTileW - 1), lrow0 = threadIdx.x / kTileW;
+  const int col = c.tx0 + lcol;
+  float sum[kRowsPerThread];
 #pragma unroll
   for (int k = 0; k < kRowsPerThread; ++k) {
-    const int row = row0 + k * (256 / kTileW);
-    old[k] = (col < p.width && row < p.height) ? gd[(size_t)row * p.width + col] : 0.f;
+    const int row = c.ty0 + lrow0 + k * (256 / kTileW);
+    sum[k] = (col < p.width && row < p.height) ? gd[(size_t)row * p.width + col] : 0.f;
   }
   __syncthreads();
-  // The list is walked in batches of kTapBatch entries per thread: all list words of a batch are loaded
-  // first, then all the pixel data they point to, then the arithmetic — two memory latencies per batch of
-  // 2048 correspondences instead of two per 256 (a one-ahead prefetch still left the dependent
-  // list -> address -> data chain exposed every iteration: 3.0 ms per step; measured with this: see DESIGN.md).
-  constexpr int kTapBatch = 8;
   for (int64_t base = lo; base < hi; base += kTapBatch * 256) {
     uint32_t pk[kTapBatch];
     DenseRaw raw[kTapBatch];
@@ -647,32 +654,72 @@ __global__ void __launch_bounds__(256) procrustes_dense_bwd_taps_kernel(ProcPara
     }
 #pragma unroll
     for (int j = 0; j < kTapBatch; ++j) raw[j] = dense_load(c, (int)(pk[j] >> 16) * p.width + (int)(pk[j] & 0xffffu));
+    // (1) β per entry and the bound of the batch
+    float beta[kTapBatch][3], uu[kTapBatch], vv[kTapBatch];
+    float bound = 0.f;
 #pragma unroll
     for (int j = 0; j < kTapBatch; ++j) {
-      if (base + j * 256 + threadIdx.x >= hi) continue;
-      const int row = (int)(pk[j] >> 16), colx = (int)(pk[j] & 0xffffu);
-      const DenseRaw cur = raw[j];
-      const float u = center_fast(colx, c.fw, c.rcp_w), v = center_fast(row, c.fh, c.rcp_h);
-      const float w = c.sens != 0.f ? fm_sigmoid<true>(c.sens * cur.wt) : cur.wt;
-      const float g[3] = {cur.z * u, cur.z * v, cur.z};
+      const bool used = base + j * 256 + threadIdx.x < hi;
+      uu[j] = center_fast((int)(pk[j] & 0xffffu), c.fw, c.rcp_w);
+      vv[j] = center_fast((int)(pk[j] >> 16), c.fh, c.rcp_h);
+      const float w = c.sens != 0.f ? fm_sigmoid<true>(c.sens * raw[j].wt) : raw[j].wt;
+      const float g[3] = {raw[j].z * uu[j], raw[j].z * vv[j], raw[j].z};
       float tv[3], gc[3];
       dense_bwd_t(cst, g, tv, gc);
-      const float b0 = w * tv[0], b1 = w * tv[1], b2 = w * tv[2];  // K⁻ᵀ_e·dL/dq
-      const Taps tp = dense_taps(u + cur.fl.x, v + cur.fl.y, p.height, p.width);  // exactly as the plan and the other dense kernels
-      const int rr = tp.y0 - c.ty0, cc = tp.x0 - c.tx0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int r1 = rr + (k >> 1), c1 = cc + (k & 1);
-        if (!tp.in[k] || (unsigned)r1 >= (unsigned)kTileH || (unsigned)c1 >= (unsigned)kTileW) continue;
-        atomicAdd(gacc + r1 * kTileW + c1, tp.w[k] * fmaf(b0, tile_u[c1], fmaf(b1, tile_v[r1], b2)));
+      for (int a = 0; a < 3; ++a) {
+        const float bv = w * tv[a];  // K⁻ᵀ_e·dL/dq
+        beta[j][a] = (used && fabsf(bv) <= 3.0e38f) ? bv : 0.f;  // a non-finite gradient contributes nothing here (and would poison the scale)
+      }
+      bound = fmaxf(bound, fabsf(beta[j][0]) + fabsf(beta[j][1]) + fabsf(beta[j][2]));
+    }
+    // (2) block maximum -> power-of-two scale
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bound = fmaxf(bound, __shfl_xor(bound, off, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0) wave_max[threadIdx.x >> 6] = bound;
+    __syncthreads();
+    bound = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+    int ex = 0;
+    (void)frexpf(bound, &ex);                       // bound < 2^ex
+    const float scale = ldexpf(1.0f, 25 - ex);      // |value|·scale < 2^25; 24 more fractional bits below
+    const double unscale = ldexp(1.0, ex - 49);
+    // (3) taps
+    if (bound > 0.f) {
+#pragma unroll
+      for (int j = 0; j < kTapBatch; ++j) {
+        const Taps tp = dense_taps(uu[j] + raw[j].fl.x, vv[j] + raw[j].fl.y, p.height, p.width);  // exactly as the plan and the other dense kernels
+        const int rr = tp.y0 - c.ty0, cc = tp.x0 - c.tx0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r1 = rr + (k >> 1), c1 = cc + (k & 1);
+          if (!tp.in[k] || (unsigned)r1 >= (unsigned)kTileH || (unsigned)c1 >= (unsigned)kTileW) continue;
+          const float val = tp.w[k] * fmaf(beta[j][0], tile_u[c1], fmaf(beta[j][1], tile_v[r1], beta[j][2]));
+          // 49-bit fixed point in two exact steps: integer part, then the remainder scaled by 2^24 — every
+          // fp32 value within 2^-25 of the batch maximum is represented exactly, smaller ones to 2^-49 of it;
+          // |q| < 2^49 and a batch has at most 8192 tap contributions, so a cell cannot overflow 64 bits
+          const float sv = val * scale, hi = rintf(sv);
+          const long long q = ((long long)(int)hi << 24) + (long long)__float2int_rn((sv - hi) * 16777216.f);
+          if (q != 0) atomicAdd(iacc + r1 * kTileW + c1, (unsigned long long)q);
+        }
       }
     }
+    __syncthreads();
+    // (4) fold this thread's cells
+#pragma unroll
+    for (int k = 0; k < kRowsPerThread; ++k) {
+      const int cell = (lrow0 + k * (256 / kTileW)) * kTileW + lcol;
+      const long long v = (long long)iacc[cell];
+      if (v != 0) {
+        sum[k] += (float)((double)v * unscale);
+        iacc[cell] = 0ull;
+      }
+    }
+    // (the next batch's atomics come after its own barrier in step 2)
   }
-  __syncthreads();
 #pragma unroll
   for (int k = 0; k < kRowsPerThread; ++k) {
-    const int row = row0 + k * (256 / kTileW);
-    if (col < p.width && row < p.height) gd[(size_t)row * p.width + col] = old[k] + gacc[(row - c.ty0) * kTileW + (col - c.tx0)];
+    const int row = c.ty0 + lrow0 + k * (256 / kTileW);
+    if (col < p.width && row < p.height) gd[(size_t)row * p.width + col] = sum[k];
   }
 }
 
