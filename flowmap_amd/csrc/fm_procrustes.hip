@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) procrustes_scatter_repeat_kernel(ProcPara
 //                coalesced read-modify-writes.  Needs only (flow, weight, z) of the later pixel —
 //                dL/dq does not depend on the sampled point.
 // ---------------------------------------------------------------------------------
-constexpr int kTileH = kDenseTileH, kTileW = kDenseTileW;    // 32 x 64 later-frame pixels per workgroup, 8 per thread
+constexpr int kTileH = kDenseTileH, kTileW = kDenseTileW;    // 32 x 64 later-frame pixels per workgroup, 8 per thread (64 x 64: no faster, 3 blocks/CU)
 constexpr int kWinH = kTileH + 32, kWinW = kTileW + 64;       // earlier-frame window: +-16 rows, +-32 columns (32 KB)
 constexpr int kRowsPerThread = kTileH / (256 / kTileW);
 static_assert(kTileW == 64 && kWinW % 4 == 0 && kTileH % 4 == 0, "thread mapping: one column, every 4th row");
