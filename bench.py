@@ -1,29 +1,41 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path: overfit iters/sec on synthetic F-frame H×W video.
+"""Benchmark of the hot path: overfit iters/sec on synthetic F-frame H×W video (BASELINE.json's metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                   # N = 1: config c1, 20 warm-up + 100 timed steps
+    python bench.py --config c2|c3|c4 [--scaling strong|weak] [--inputs scene|iid]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = what ModelWrapperOverfit.training_step + backward do per optimisation
-iteration (model_wrapper_overfit.py:51-62): explicit-depth backbone ->
-regressed intrinsics -> unproject -> Procrustes extrinsics -> flow loss -> backward to
-(depth, weight logits, focal length).  No optimiser step, exactly like the CPU baseline
-in BASELINE.md.  Workload at N=1: BASELINE.json configs[1] (150 frames @ 720x1280, flow
-loss only, Procrustes P=1000), inputs resident in HBM.  For N>1 every rank owns its own
-150-frame shard of a longer video (weak scaling; frame pairs shard with a one-frame
-halo), with one packed all-reduce of the shared-intrinsics gradient + loss and a halo
-exchange of the boundary frame's depth gradient over RCCL.
+One "step" = what ModelWrapperOverfit.training_step + backward do per optimisation iteration
+(model_wrapper_overfit.py:51-62): explicit-depth backbone -> intrinsics -> unproject ->
+Procrustes extrinsics -> enabled losses -> backward to (depth, weight logits, focal length).  No optimiser
+step unless --optimizer says so, exactly like the CPU baseline in BASELINE.md.
 
-Prints ONE JSON line (rank 0) carrying `roofline` for the fused flow kernel (HIP-event
-timed on its launch stream inside the timed region) and `cpu_baseline` (the oracle — a
-PyTorch-CPU port of the reference path — timed on a bounded sample of the same workload).
+Configs (BASELINE.json configs[1..4]), all inputs resident in HBM:
+    c1  150 frames @ 720x1280, flow loss, Procrustes P = 1000            (the headline; default)
+    c2  c1 + tracking loss: 30 segments x 1225 tracks
+    c3  65 frames @ 1080x1920, flow loss                                 (BASELINE: 4 GPUs x 16 pairs)
+    c4  1200 frames @ 1080x1920 i.i.d. inputs over 8 GPUs = 150 frames per GPU (weak scaling by definition)
+Inputs: `scene` = a geometrically consistent scene (static bumpy surface, smooth camera path, flows induced
+by the true geometry; the default of c1-c3 as §8d specifies), `iid` = independent noise per pixel (c4).
+
+Scaling for N > 1: `strong` (default for c1-c3: the metric is "150 frames @ 720p at 1/2/4/8 GPUs") shards
+the ONE video by frame pairs over the ranks (flowmap_amd.sharding.shard_pairs: a one-frame halo, one packed
+all-reduce of [loss, shared-parameter gradients], a neighbour exchange of the halo frame's dL/ddepth; with
+tracking an all-gather of the poses and an all-reduce of their gradients); `weak` (c4) gives every rank its
+own 150-frame shard.  `value` is whole-job throughput either way: iterations of the whole workload per second.
+
+Prints ONE JSON line (rank 0) with `roofline` for the fused flow kernel (HIP events on its launch stream
+inside the timed region), `roofline_tracking` when the tracking loss runs (track_pairs: VALU-bound, GFLOP/s)
+and, at N = 1, `cpu_baseline` (the oracle — a PyTorch-CPU port of the reference path — timed on a bounded
+sample of the same workload).
 """
 
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -36,26 +48,38 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP32_PEAK_GFLOPS = 157300.0  # same guide: fp32 vector peak with packed FMA
+TRACK_FLOPS_PER_RESIDUAL = 90.0  # track_pair_term (csrc/fm_pose.h): ~60 VALU instructions, FMAs counted twice
+
+CONFIGS = {
+    "c1": dict(frames=150, height=720, width=1280, tracking=False, inputs="scene", scaling="strong", ref="BASELINE.json configs[1]"),
+    "c2": dict(frames=150, height=720, width=1280, tracking=True, inputs="scene", scaling="strong", ref="BASELINE.json configs[2]"),
+    "c3": dict(frames=65, height=1080, width=1920, tracking=False, inputs="scene", scaling="strong", ref="BASELINE.json configs[3]"),
+    "c4": dict(frames=150, height=1080, width=1920, tracking=False, inputs="iid", scaling="weak",
+               ref="BASELINE.json configs[4] (1200 frames over 8 GPUs: 150 frames per GPU)"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=150)
-    ap.add_argument("--height", type=int, default=720)
-    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c1")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="default: the config's (strong for c1-c3, weak for c4)")
+    ap.add_argument("--inputs", choices=["scene", "iid"], default=None, help="default: the config's (scene for c1-c3, iid for c4)")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--tracking", action="store_true", help="add the tracking loss to any config (c2 = c1 --tracking)")
     ap.add_argument("--points", type=int, default=1000,
                     help="Procrustes points (config/model/extrinsics/procrustes.yaml:3); 0 = all pixels (ablation_explicit_depth.yaml:11-12)")
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads for the CPU baseline (16 measured fastest on the 256-thread EPYC 9575F host: "
                     "8 -> 0.42, 16 -> 0.25, 32 -> 0.35, 64 -> 0.45, 256 -> 5.2 s/iter at 4 frames @720p)")
     ap.add_argument("--items-per-thread", type=int, default=0)
-    ap.add_argument("--smooth-flows", action="store_true",
-                    help="spatially smooth synthetic flows (low-res noise upsampled) instead of i.i.d. per-pixel noise")
     ap.add_argument("--intrinsics", choices=["regressed", "softmin"], default="regressed",
                     help="softmin = the reference's default first-1000-steps intrinsics (60-candidate sweep, 8192 points)")
     ap.add_argument("--optimizer", choices=["none", "fused", "torch"], default="none",
@@ -64,39 +88,97 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the step in a hipGraph (flowmap_amd.GraphedStep) and replay it: for the launch-bound regime "
                          "(small frames); single GPU only")
-    ap.add_argument("--tracking", action="store_true",
-                    help="BASELINE.json configs[2]: add the tracking loss (segments every 5 frames, +-20 frames, 35x35 tracks)")
     return ap.parse_args()
 
 
-def make_inputs(f, h, w, device, seed, smooth=False):
-    """i.i.d. synthetic inputs of BASELINE.md §2, generated directly in HBM."""
+# --------------------------------------------------------------------------------------
+# Synthetic inputs, generated directly in HBM
+# --------------------------------------------------------------------------------------
+
+
+def make_iid(f, h, w, device, seed):
+    """i.i.d. inputs of BASELINE.md §2: depth U(1.10,1.15), flows N(0,0.01²), masks U(0,1), weight logits N(0,0.01²)."""
+    from flowmap_amd import Flows
+
     g = torch.Generator(device=device).manual_seed(seed)
     depth = 1.10 + 0.05 * torch.rand((f, h, w), device=device, generator=g)
     wlogit = 0.01 * torch.randn((f - 1, h, w), device=device, generator=g)
-    from flowmap_amd import Flows
-
-    def flow_field():
-        if not smooth:
-            return 0.01 * torch.randn((1, f - 1, h, w, 2), device=device, generator=g)
-        low = 0.01 * torch.randn((f - 1, 2, max(h // 40, 2), max(w // 40, 2)), device=device, generator=g)
-        up = torch.nn.functional.interpolate(low, size=(h, w), mode="bicubic", align_corners=False)
-        return up.permute(0, 2, 3, 1)[None].contiguous()
-
     flows = Flows(
-        flow_field(),
-        flow_field(),
+        0.01 * torch.randn((1, f - 1, h, w, 2), device=device, generator=g),
+        0.01 * torch.randn((1, f - 1, h, w, 2), device=device, generator=g),
         torch.rand((1, f - 1, h, w), device=device, generator=g),
         torch.rand((1, f - 1, h, w), device=device, generator=g),
     )
-    return depth, wlogit, flows
+    return depth, wlogit, flows, None
 
 
-def make_tracks(f, device, seed, interval=5, radius=20, grid=35):
-    """Synthetic track segments laid out as generate_video_tracks does
-    (flowmap/tracking/__init__.py:49-70): one segment around every `interval`-th frame,
-    +-radius frames, grid x grid query points drifting as a random walk; ~90 % visible."""
+def make_scene(f, h, w, device, seed, focal=0.85, depth_noise=0.05):
+    """A consistent scene (§8d): a static bumpy surface z = height(x, y) seen by a smoothly moving camera.  Depth per
+    frame by fixed-point ray casting; flows = where the true geometry sends every pixel (computed with this
+    package's own compute_forward_flow / compute_backward_flow: the inputs of a TIMING run, not a parity
+    check); masks = 1 where the target stays in frame; initial depth = truth x (1 + 5 % smooth noise)."""
+    from flowmap_amd import Flows
+    from flowmap_amd.model import projection as fm
+
+    gen = torch.Generator().manual_seed(seed)
+    t_axis = torch.linspace(0, 1, f, dtype=torch.float64)
+    ph = torch.rand(6, generator=gen, dtype=torch.float64) * 2 * math.pi
+    trans = torch.stack([0.25 * torch.sin(2 * math.pi * t_axis + ph[0]), 0.10 * torch.sin(4 * math.pi * t_axis + ph[1]), 0.15 * t_axis], -1)
+    ang = torch.stack([0.04 * torch.sin(2 * math.pi * t_axis + ph[2]), 0.06 * torch.sin(2 * math.pi * t_axis + ph[3]),
+                       0.02 * torch.sin(2 * math.pi * t_axis + ph[4])], -1)
+    cx, cy, cz, sx, sy, sz = *torch.cos(ang).unbind(-1), *torch.sin(ang).unbind(-1)
+    one, zero = torch.ones_like(cx), torch.zeros_like(cx)
+    rx = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], -1).reshape(f, 3, 3)
+    ry = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], -1).reshape(f, 3, 3)
+    rz = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], -1).reshape(f, 3, 3)
+    ext = torch.eye(4, dtype=torch.float64).repeat(f, 1, 1)
+    ext[:, :3, :3] = rz @ ry @ rx
+    ext[:, :3, 3] = trans
+    ext = (torch.linalg.inv(ext[0])[None] @ ext).float().to(device)  # first pose = identity, like get_extrinsics
+    s = (h * w) ** 0.5
+    k = torch.tensor([[focal * s / w, 0, 0.5], [0, focal * s / h, 0.5], [0, 0, 1.0]], device=device)
+    xy, _ = fm.sample_image_grid((h, w), device)
+    rays = torch.cat([xy, torch.ones_like(xy[..., :1])], -1) @ torch.linalg.inv(k).T  # (h, w, 3), z component 1
+
+    def height(xw, yw):
+        return 2.0 + 0.25 * torch.sin(1.7 * xw + 0.3) * torch.cos(1.3 * yw - 0.2) + 0.1 * torch.sin(3.1 * xw * yw)
+
+    depth = torch.empty((f, h, w), device=device)
+    for i in range(f):  # frame by frame: a few hundred MB of temporaries instead of tens of GB
+        r, c = ext[i, :3, :3], ext[i, :3, 3]
+        d = torch.full((h, w), 2.0, device=device)
+        for _ in range(40):
+            pw = (rays * d[..., None]) @ r.T + c
+            d = d + (height(pw[..., 0], pw[..., 1]) - pw[..., 2]) / r[2, 2].clamp_min(0.5)
+        depth[i] = d
+    with torch.no_grad():
+        kk = k.expand(1, f, 3, 3).contiguous()
+        fwd = torch.empty((1, f - 1, h, w, 2), device=device)
+        bwd = torch.empty_like(fwd)
+        for a in range(0, f - 1, 16):  # in chunks: the explicit (frames, h, w, 3) surfaces are 11 MB per frame at 720p
+            b = min(a + 16, f - 1)
+            surf = fm.unproject_dense(xy, depth[None, a : b + 1], kk[:, a : b + 1, None, None])
+            fwd[:, a:b] = fm.compute_forward_flow(surf, ext[None, a : b + 1], kk[:, a : b + 1]) - xy
+            bwd[:, a:b] = fm.compute_backward_flow(surf, ext[None, a : b + 1], kk[:, a : b + 1]) - xy
+
+    def inside(flow):
+        pos = flow + xy
+        return ((pos >= 0).all(-1) & (pos < 1).all(-1)).float()
+
+    flows = Flows(fwd, bwd, inside(fwd), inside(bwd))
+    smooth = torch.nn.functional.interpolate(torch.randn((1, f, max(h // 16, 2), max(w // 16, 2)), generator=gen).to(device), size=(h, w),
+                                             mode="bilinear", align_corners=False)[0]
+    wlogit = 0.01 * torch.randn((f - 1, h, w), generator=torch.Generator(device=device).manual_seed(seed), device=device)
+    return depth * (1 + depth_noise * smooth), wlogit, flows, {"depth": depth, "extrinsics": ext, "intrinsics": k}
+
+
+def make_tracks(f, device, seed, scene=None, hw=None, interval=5, radius=20, grid=35):
+    """Track segments laid out as generate_video_tracks does (flowmap/tracking/__init__.py:49-70): one segment
+    around every `interval`-th frame, +-radius frames, grid x grid query points on the middle frame; ~90 % visible.
+    With a scene the tracks follow the true surface points (projected with this package's kernels), otherwise
+    they drift as a random walk."""
     from flowmap_amd import Tracks
+    from flowmap_amd.model import projection as fm
 
     g = torch.Generator(device=device).manual_seed(seed)
     lin = (torch.arange(grid, device=device, dtype=torch.float32) + 0.5) / grid
@@ -104,19 +186,32 @@ def make_tracks(f, device, seed, interval=5, radius=20, grid=35):
     out = []
     for mid in range(0, f, interval):
         start, end = max(0, mid - radius), min(f, mid + radius + 1)
-        drift = (0.003 * torch.randn((end - start, query.shape[0], 2), device=device, generator=g)).cumsum(0)
-        # every segment tracks its own points (a tracker's query grid sits on the segment's middle
-        # frame): jitter the grid inside its cells so that segments do not share pixels exactly
-        jitter = (torch.rand((query.shape[0], 2), device=device, generator=g) - 0.5) / grid
-        xy = (query + jitter)[None] + drift - drift[mid - start]
-        vis = (xy >= 0).all(-1) & (xy < 1).all(-1) & (torch.rand(xy.shape[:2], device=device, generator=g) < 0.9)
-        out.append(Tracks(xy[None].contiguous(), vis[None].contiguous(), start))
+        # every segment tracks its own points (a tracker's query grid sits on the segment's middle frame):
+        # jitter the grid inside its cells so that segments do not share pixels exactly
+        q = query + (torch.rand((query.shape[0], 2), device=device, generator=g) - 0.5) / grid
+        if scene is not None:
+            h, w = hw
+            with torch.no_grad():
+                xy, _ = fm.sample_image_grid((h, w), device)
+                kk = scene["intrinsics"].expand(1, 1, 3, 3).contiguous()
+                surf = fm.unproject_dense(xy, scene["depth"][None, mid : mid + 1], kk[:, :, None, None])  # (1,1,h,w,3)
+                pts = torch.nn.functional.grid_sample(surf[0].permute(0, 3, 1, 2), (q * 2 - 1)[None, :, None], mode="bilinear",
+                                                      padding_mode="border", align_corners=False)[0, :, :, 0].T  # (P,3)
+                rel = torch.linalg.inv(scene["extrinsics"][start:end]) @ scene["extrinsics"][mid]  # (n,4,4)
+                cam = pts @ rel[:, :3, :3].transpose(1, 2) + rel[:, None, :3, 3]
+                proj = cam / (cam[..., 2:] + 1e-5)
+                xy_t = (proj @ scene["intrinsics"].T)[..., :2]
+        else:
+            drift = (0.003 * torch.randn((end - start, q.shape[0], 2), device=device, generator=g)).cumsum(0)
+            xy_t = q[None] + drift - drift[mid - start]
+        vis = (xy_t >= 0).all(-1) & (xy_t < 1).all(-1) & (torch.rand(xy_t.shape[:2], device=device, generator=g) < 0.9)
+        out.append(Tracks(xy_t[None].contiguous(), vis[None].contiguous(), start))
     return out
 
 
 def cpu_baseline(frames, h, w, points, iters, threads):
-    """The oracle (PyTorch CPU port of the reference path) on a bounded sample: same
-    frame size, fewer frames; forward + backward, all host cores."""
+    """The oracle (PyTorch CPU port of the reference path) on a bounded sample: same frame size, fewer frames;
+    forward + backward on `threads` host cores."""
     from oracle import flowmap_oracle as orc
 
     cores = max(1, min(threads, os.cpu_count() or 1))
@@ -136,8 +231,7 @@ def cpu_baseline(frames, h, w, points, iters, threads):
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
-    dt = (time.perf_counter() - t0) / iters
-    return dt, cores
+    return (time.perf_counter() - t0) / iters, cores
 
 
 def _reserve_stdout():
@@ -168,71 +262,93 @@ def main():
     torch.cuda.set_device(device)
 
     import flowmap_amd
-    from flowmap_amd import Batch, _ops
+    from flowmap_amd import Batch, Flows, _ops
     from flowmap_amd.loss import LossFlow, LossFlowCfg
     from flowmap_amd.loss.mapping import MappingHuberCfg
     from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
     from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
-    from flowmap_amd.sharding import FrameShard
+    from flowmap_amd.sharding import FrameShard, shard_frames, shard_pairs
 
-    f, h, w = args.frames, args.height, args.width
+    cfg = dict(CONFIGS[args.config])
+    for key in ("frames", "height", "width", "scaling", "inputs"):
+        if getattr(args, key) is not None:
+            cfg[key] = getattr(args, key)
+    cfg["tracking"] = cfg["tracking"] or args.tracking
+    f_video, h, w = cfg["frames"], cfg["height"], cfg["width"]
+    strong = cfg["scaling"] == "strong" and world > 1
     flowmap_amd.set_lazy_surfaces(True)
-    depth, wlogit, flows = make_inputs(f, h, w, device, seed=1 + rank, smooth=args.smooth_flows)
+
+    # ---- inputs: the whole video of this rank's job, then (strong scaling) its shard of it ----
+    seed = 1 if (strong or world == 1) else 1 + rank  # strong: every rank builds the SAME video and keeps its frames
+    maker = make_scene if cfg["inputs"] == "scene" else make_iid
+    depth, wlogit, flows, scene = maker(f_video, h, w, device, seed)
+    tracks = None
+    if cfg["tracking"]:
+        if world > 1 and not strong:
+            raise SystemExit("--tracking with weak scaling: every rank would need its own track set over a shared video; use --scaling strong")
+        tracks = make_tracks(f_video, device, seed=100, scene=scene, hw=(h, w))
+    total_pairs = f_video - 1
+    if strong:
+        a, b = shard_pairs(total_pairs, world)[rank]
+        lo, hi = shard_frames((a, b))
+        depth, wlogit = depth[lo : hi + 1].clone(), wlogit[a:b].clone()
+        flows = Flows(*(x[:, a:b].contiguous() for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)))
+        del scene
+        torch.cuda.empty_cache()
+    f = depth.shape[0]  # frames resident on this rank
+
     if args.intrinsics == "softmin":
         from flowmap_amd.model.intrinsics_softmin import IntrinsicsSoftminCfg, RegressionCfg
 
         intrinsics_cfg = IntrinsicsSoftminCfg("softmin", 8192, 0.5, 2.0, 60, RegressionCfg(1000, 100))
     else:
-        intrinsics_cfg = IntrinsicsRegressedCfg("regressed", 0.85)
-    cfg = ModelCfg(
+        intrinsics_cfg = IntrinsicsRegressedCfg("regressed", 0.85 if cfg["inputs"] == "iid" else 0.8)
+    model_cfg = ModelCfg(
         BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
         intrinsics_cfg,
         ExtrinsicsProcrustesCfg("procrustes", args.points if args.points > 0 else None, False),
     )
-    model = Model(cfg, num_frames=f, image_shape=(h, w)).to(device)
+    model = Model(model_cfg, num_frames=f, image_shape=(h, w)).to(device)
     model.backbone.depth.data = depth
     model.backbone.weights.data = wlogit
     batch = Batch(torch.zeros((1, f, 3, 1, 1), device=device).expand(1, f, 3, h, w))
     loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
     if args.items_per_thread:
         loss_fn.items_per_thread = args.items_per_thread
-    tracks, track_fn = None, None
-    if args.tracking:
+    track_fn = None
+    if tracks is not None:
         from flowmap_amd.loss import LossTracking, LossTrackingCfg
 
-        sharded_tracks = dist is not None and world > 1
-        # sharded: ONE track set over the whole (world x 149 + 1)-frame video, global frame indices,
-        # identical on every rank; each rank evaluates the sources it owns (FrameShard.tracking_loss)
-        tracks = make_tracks(world * (f - 1) + 1 if sharded_tracks else f, device, seed=100 if sharded_tracks else 100 + rank)
         track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
     shard = FrameShard(rank, world if dist is None else max(world, 1), dist)
     if dist is not None and world == 1:
         shard.world = 2  # single-rank RCCL self-test: run the collectives, there are no neighbours
         shard.exchange_halo = lambda grad: None
-    shard.prepare_flow_loss(loss_fn, flows)  # global valid-sum (one-time all-reduce)
+    if strong or (dist is not None and world == 1):
+        shard.prepare_flow_loss(loss_fn, flows)  # global valid-sum (one-time all-reduce)
+        shard.prepare_model(model)  # softmin sweep on rank 0, broadcast (flowmap_amd/sharding.py)
 
     optimizer = None
     if args.optimizer == "fused":
         optimizer = flowmap_amd.FusedAdam(model.parameters(), lr=3e-5, capturable=args.graph)
     elif args.optimizer == "torch":
         optimizer = torch.optim.Adam(model.parameters(), lr=3e-5)
-
-    kernel_events = []
-    _ops.flow_kernel_events = kernel_events  # (start, end) per fused-kernel launch
+    shared = [p for name, p in model.named_parameters() if not name.startswith("backbone.")]  # intrinsics: shared by all frames
 
     def step():
         model.zero_grad(set_to_none=True)
         out = model(batch, flows, 0)
         loss = loss_fn(batch, flows, None, out, 0)
         tracked = None
-        if track_fn is not None and dist is not None and world > 1:
-            tracked = shard.tracking_loss(track_fn, tracks, out, world * (f - 1))  # global value, this rank's gradients
+        if track_fn is not None and strong:
+            tracked = shard.tracking_loss(track_fn, tracks, out, total_pairs)  # global value, this rank's gradients
             (loss + tracked).backward()
         else:
             if track_fn is not None:
                 loss = loss + track_fn(batch, flows, tracks, out, 0)
             loss.backward()
-        shard.sync(loss, getattr(model.intrinsics, "focal_length", None), model.backbone.depth, already_global=tracked)
+        if strong or (dist is not None and world == 1):
+            loss = shard.sync(loss, shared, model.backbone.depth, already_global=tracked)
         if optimizer is not None:
             optimizer.step()
         return loss
@@ -240,21 +356,20 @@ def main():
     # one-time precompute, outside warm-up and timing whatever W is: the first step packs the constant
     # flows / masks and reduces the valid sums, the second one plans the static scatters (SURVEY §8d:
     # the metric excludes one-time precompute)
-    for _ in range(2):
+    for _ in range(3):
         step()
     if args.graph:
         if dist is not None or args.optimizer == "torch":
             raise SystemExit("--graph: single GPU, and --optimizer none|fused")
-        eager_step = step
-        graphed = flowmap_amd.GraphedStep(eager_step, warmup=3)  # disables the per-launch events: kernel_ms stays 0
-        step = graphed  # noqa: F811
+        step = flowmap_amd.GraphedStep(step, warmup=3)  # noqa: F811  (kernel events are not recorded inside a graph: kernel_ms stays 0)
     if dist is not None:  # create the RCCL communicators / P2P channels outside the timed region
         shard.exchange_halo(torch.zeros((2, h, w), device=device))
         dist.all_reduce(torch.zeros(4, device=device))
     for _ in range(args.warmup):
         step()
     flowmap_amd.freeze_gc()  # a full cyclic-GC pass over torch's import-time objects costs ~50 ms (flowmap_amd/host.py)
-    kernel_events.clear()
+    if not args.graph:
+        _ops.flow_kernel_timing(True)  # HIP events on the launch stream around the fused flow kernel / track_pairs
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -270,44 +385,56 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    kernel_ms = sum(s.elapsed_time(e) for s, e in kernel_events) / max(len(kernel_events), 1)
+    flow_ms = _ops.flow_kernel_times()
+    track_ms = _ops.flow_kernel_times(tracking=True)
+    _ops.flow_kernel_timing(False)
+    kernel_ms = sum(flow_ms) / max(len(flow_ms), 1)
     traffic, traffic_src = None, None
-    try:  # HBM bytes per launch from the PMC passes committed under profiles/ (same workload only)
-        rec = json.loads((ROOT / "profiles" / "r01_flow_kernel_traffic.json").read_text())
-        if rec["workload"] == {"frames": args.frames, "height": args.height, "width": args.width}:
-            traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_flow_kernel_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"
-    except Exception:
-        pass
+    for name in ("r02_flow_kernel_traffic.json", "r01_flow_kernel_traffic.json"):  # HBM bytes per launch from the PMC passes (same workload only)
+        try:
+            rec = json.loads((ROOT / "profiles" / name).read_text())
+            if rec["workload"] == {"frames": f, "height": h, "width": w}:
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], f"profiles/{name} (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"
+                break
+        except Exception:
+            pass
     n = h * w
-    algo_bytes = n * (8 * f + 24 * (f - 1))  # B_flow per launch
+    algo_bytes = n * (8 * f + 24 * (f - 1))  # B_flow per launch (this rank's frames)
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
-    result = None
     if rank == 0:
+        jobs = 1 if (strong or world == 1) else world  # weak scaling: every rank completes its own workload per step
         ms_per_step = elapsed / args.steps * 1e3
+        workload = (f"{cfg['ref']}: {f_video} frames @ {h}x{w}, {cfg['inputs']} inputs, flow loss (huber 0.01, weight 1000)"
+                    + (f" + tracking loss (weight 100): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else "")
+                    + f", explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points if args.points > 0 else 'all pixels'}; fwd+bwd, "
+                    + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__})")
+                    + ("; whole step replayed as one hipGraph" if args.graph else ""))
         result = {
             "metric": "overfit iters/sec (150 frames @ 720p) at 1/2/4/8 MI355X; final ATE vs ref",
-            "value": world * args.steps / elapsed,
-            "unit": "iters/sec (one iter = fwd+bwd over one 150-frame shard; aggregate over GPUs)",
+            "value": jobs * args.steps / elapsed,
+            "unit": "iters/sec (one iter = fwd+bwd over the whole video"
+                    + (", sharded by frame pairs over the GPUs)" if strong else "; weak scaling: one video per GPU, aggregate over GPUs)" if world > 1 else ")"),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": cfg["scaling"],
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE.json configs[1]: {f} frames @ {h}x{w}, flow loss only (huber 0.01, weight 1000), "
-                f"explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points}; fwd+bwd, "
-                + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__})")
-                + ("; whole step replayed as one hipGraph" if args.graph else "")
-                + (f"; + tracking loss (configs[2]): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else ""),
+                "workload": workload,
+                "config": args.config,
+                "inputs": cfg["inputs"],
+                "video_frames": f_video if (strong or world == 1) else f_video * world,
                 "frames_per_gpu": f,
+                "pairs_per_gpu": f - 1,
                 "height": h,
                 "width": w,
-                "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU",
+                "parallelism": (f"frame-pair shards x{world} (1-frame halo, packed all-reduce of loss + shared gradients, halo exchange)" if strong
+                                else f"{world} independent 150-frame shards" if world > 1 else "single GPU"),
                 "loss": float(loss.item()),
             },
             "roofline": {
@@ -321,21 +448,43 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": kernel_ms,
-                "launches_timed": len(kernel_events),
+                "launches_timed": len(flow_ms),
             },
         }
+        if track_ms:
+            residuals = sum(int(t.xy.shape[1]) ** 2 * int(t.xy.shape[2]) for t in tracks)
+            if strong:  # this rank evaluates the sources it owns: its share of the residuals
+                own = FrameShard.owned_sources(total_pairs, world, rank)
+                residuals = sum(sum(1 for fr in range(t.xy.shape[1]) if own[0] <= t.start_frame + fr < own[1]) * int(t.xy.shape[1]) * int(t.xy.shape[2])
+                                for t in tracks)
+            t_ms = sum(track_ms) / len(track_ms)
+            gflops = residuals * TRACK_FLOPS_PER_RESIDUAL / (t_ms * 1e-3) / 1e9
+            result["roofline_tracking"] = {
+                "kernel": "fm::track_pairs_kernel<huber, GRAD> (+ track_reduce, finalize: one fm_track_loss_fwd call)",
+                "bound": "valu",
+                "achieved": gflops,
+                "peak": FP32_PEAK_GFLOPS,
+                "unit": "GFLOP/s",
+                "frac": gflops / FP32_PEAK_GFLOPS,
+                "traffic": None,
+                "residuals_per_launch": residuals,
+                "flops_per_residual": TRACK_FLOPS_PER_RESIDUAL,
+                "kernel_ms": t_ms,
+                "launches_timed": len(track_ms),
+            }
         if world == 1 and args.cpu_frames >= 2:
-            dt, cores = cpu_baseline(args.cpu_frames, h, w, args.points, args.cpu_iters, args.cpu_threads)
-            scaled = dt * (f - 1) / (args.cpu_frames - 1)  # per-pair cost is constant (optimistic for the CPU)
+            dt, cores = cpu_baseline(args.cpu_frames, h, w, args.points if args.points > 0 else None, args.cpu_iters, args.cpu_threads)
+            scaled = dt * (f_video - 1) / (args.cpu_frames - 1)  # per-pair cost is constant (optimistic for the CPU)
             result["cpu_baseline"] = {
                 "value": 1.0 / scaled,
                 "unit": "iters/sec",
                 "cores": cores,
                 "kind": "port",
+                "frames": args.cpu_frames,
                 "host_logical_cpus": os.cpu_count(),
-                "sample": f"oracle (PyTorch-CPU port of the reference path), {cores} torch threads, {args.cpu_frames} frames @ {h}x{w}, fwd+bwd, "
-                f"{args.cpu_iters} timed iters after 1 warm-up: {dt:.3f} s/iter, scaled by pairs ({f - 1}/{args.cpu_frames - 1}) "
-                f"to {f} frames",
+                "sample": f"oracle (PyTorch-CPU port of the reference path, flow loss), {cores} torch threads, {args.cpu_frames} frames @ {h}x{w} (i.i.d. inputs), "
+                f"fwd+bwd, {args.cpu_iters} timed iters after 1 warm-up: {dt:.3f} s/iter, scaled by pairs ({f_video - 1}/{args.cpu_frames - 1}) "
+                f"to {f_video} frames",
                 "sample_seconds_per_iter": dt,
             }
         print(json.dumps(result), file=result_stream, flush=True)

@@ -118,6 +118,30 @@ def library() -> ctypes.CDLL:
     return _lib
 
 
+TORCH_LIB_PATH = _HERE / "libflowmap_torch.so"
+_torch_ops = None
+
+
+def torch_ops():
+    """``torch.ops.flowmap_amd``: the C++ operators of libflowmap_torch.so (csrc/fm_torch.cpp), bound to the
+    same build of the C ABI as ``library()``.  Loaded on first use; built in-tree if missing."""
+    global _torch_ops
+    if _torch_ops is None:
+        if not TORCH_LIB_PATH.exists():
+            try:
+                from .build import build_torch_binding
+
+                build_torch_binding(verbose=False)
+            except Exception as exc:
+                raise RuntimeError(f"{TORCH_LIB_PATH} is missing and could not be built ({exc}); run "
+                                   "`python -c 'import __graft_entry__ as g; g.build()'`.  flowmap_amd has no CPU or eager fallback.") from exc
+        torch.ops.load_library(str(TORCH_LIB_PATH))
+        library()  # the C ABI itself (builds it if need be)
+        torch.ops.flowmap_amd.set_library(str(_lib._name), _lib_is_test_double)
+        _torch_ops = torch.ops.flowmap_amd
+    return _torch_ops
+
+
 def set_library_for_testing(path: Optional[os.PathLike]) -> None:
     """Inject a different build of the same C ABI (tests only), or reset with None."""
     global _lib, _lib_is_test_double
@@ -125,6 +149,9 @@ def set_library_for_testing(path: Optional[os.PathLike]) -> None:
         _lib, _lib_is_test_double = None, False
     else:
         _lib, _lib_is_test_double = _bind(ctypes.CDLL(str(path))), True
+    if _torch_ops is not None:  # keep the C++ operators on the same library
+        library()
+        _torch_ops.set_library(str(_lib._name), _lib_is_test_double)
 
 
 def using_test_double() -> bool:

@@ -1,21 +1,31 @@
-"""torch.autograd.Function wrappers around the C ABI (include/flowmap_hip.h).
+"""The differentiable building blocks the reference-shaped call surface (flowmap_amd.model.projection,
+flowmap_amd.loss) is assembled from.
 
-These are the differentiable building blocks the reference-shaped call surface
-(flowmap_amd.model.projection, flowmap_amd.loss) is assembled from.  Every Function
-launches hand-written HIP kernels on the current stream through ctypes; none of them
-synchronises the device or falls back to eager PyTorch math.
+Per-step operators — K from the focal length, the Procrustes pose fit, the pose chain, the fused flow and
+tracking losses, Adam — are C++ ``torch::autograd::Function``s in libflowmap_torch.so
+(csrc/fm_torch.cpp, registered with TORCH_LIBRARY as ``torch.ops.flowmap_amd.*``); the classes of the same
+names below are thin facades that gather what those operators take explicitly.  Function-level
+operators on explicit point sets (Unproject, Reproject, BilinearSample, ...) and the data-preparation
+kernels are ``torch.autograd.Function``s over the same C ABI through ctypes.  Nothing here synchronises
+the device or falls back to eager PyTorch math.
+
+State: there is no module-level cache.  Everything derived from a constant input lives ON that
+input's tensor object (a Python attribute, validated against the tensor's version counter) and dies
+with it: K^-1 on K, the packed flows / valid sums on the flow and mask tensors, the static scatter
+plans on the backward-flow tensor, the packed tracks on the first segment's coordinates.  What one
+step hands from operator to operator travels in explicit objects: ``DepthSink`` (one per depth tensor
+object, i.e. per step) and ``GradArena`` (one per weight parameter).
 """
 
 from __future__ import annotations
 
-import os
-import weakref
+import ctypes
 from typing import Optional
 
 import torch
 from torch import Tensor
 
-from ._lib import call, check_device, ptr, stream_for
+from ._lib import call, check_device, ptr, stream_for, torch_ops
 
 MAPPING_KINDS = {"huber": 0, "l1": 1, "l2": 2}
 
@@ -48,81 +58,98 @@ class _guard:
             self.ctx.__exit__(*exc)
 
 
-# K⁻¹ of the few K tensors alive in a step (the model's K shared by the extrinsics fit and the fused
-# losses; the softmin sweep's constant candidate sets): (id(root K), address, numel) -> (weakref, key, K⁻¹)
-_kinv_cache: dict = {}
-_KINV_CACHE_SLOTS = 4
+def _derived(owner: Tensor, name: str, key, build):
+    """``build()`` once per (owner tensor object, key): the value is kept on the tensor itself."""
+    slot = owner.__dict__.get(name)
+    if slot is not None and slot[0] == key:
+        return slot[1]
+    value = build()
+    owner.__dict__[name] = (key, value)
+    return value
 
 
-def _kinv_key(k: Tensor):
-    return (k._version, k.data_ptr(), k.numel())
-
-
-def _kinv_store(root: Tensor, key, kinv: Tensor) -> None:
-    for ident in [i for i, entry in _kinv_cache.items() if entry[0]() is None]:  # their K died
-        del _kinv_cache[ident]
-    while len(_kinv_cache) >= _KINV_CACHE_SLOTS:
-        del _kinv_cache[next(iter(_kinv_cache))]  # oldest first
-    _kinv_cache[(id(root), *key[1:])] = (weakref.ref(root), key, kinv)
+# --------------------------------------------------------------------------------------
+# Intrinsics
+# --------------------------------------------------------------------------------------
 
 
 def intrinsics_inverse(k: Tensor) -> Tensor:
-    """K⁻¹ for a (..., 3, 3) stack (no autograd; callers chain the backward).  Results are kept for
-    the last few K tensors, so the consumers of one step invert each K once and constant K sets are
-    inverted once per run.  "The same K" = the same root tensor object (views of it included: they
-    share its version counter), same memory, same version — a recycled allocation belongs to a
-    different root object and misses."""
+    """K^-1 for a (..., 3, 3) stack (no autograd; callers chain the backward).  The result stays on the
+    K tensor object it was computed for — views of it included: ``K[:, :, None, None]`` or ``K[:, 1:]`` look
+    it up on their base, each window of memory beside the others — so the consumers of one step invert
+    each K once and constant K sets once per run; an in-place edit of K (version counter) or another
+    tensor object misses."""
     k = _f32c(k, "intrinsics")
     root = k if k._base is None else k._base
-    key = _kinv_key(k)
-    entry = _kinv_cache.get((id(root), *key[1:]))
-    if entry is not None and entry[0]() is root and entry[1] == key:
-        return entry[2].view(k.shape)
-    out = torch.empty_like(k)
-    with _guard(k.device):
-        call("fm_intrinsics_inverse", ptr(k), k.numel() // 9, ptr(out), stream_for(k))
-    _kinv_store(root, key, out)
-    return out
+    slots = root.__dict__.setdefault("_fm_kinv", {})
+    hit = slots.get((k.data_ptr(), k.numel()))
+    if hit is not None and hit[0] == k._version:
+        return hit[1].view(k.shape)
+    kinv = torch_ops().intrinsics_inverse(k)
+    if len(slots) >= 4:
+        slots.clear()
+    slots[(k.data_ptr(), k.numel())] = (k._version, kinv)
+    return kinv
 
 
-class FocalIntrinsics(torch.autograd.Function):
-    """focal_lengths_to_intrinsics spread over the frames (intrinsics/common.py:6-20 as used by
-    intrinsics_regressed.py:34-41): focal (*lead) -> K (*lead, *repeat_shape, 3, 3) in one launch that
-    also leaves K^-1 behind for the step's consumers; the backward is one reduction."""
-
-    @staticmethod
-    def forward(ctx, focal, repeat_shape, image_shape):
-        check_device(focal)
-        focal = _f32c(focal, "focal lengths")
-        h, w = int(image_shape[0]), int(image_shape[1])
-        repeat = 1
-        for d in repeat_shape:
-            repeat *= int(d)
-        count = focal.numel()
-        k = torch.empty((*focal.shape, *repeat_shape, 3, 3), dtype=torch.float32, device=focal.device)
-        kinv = torch.empty_like(k)
-        with _guard(focal.device):
-            call("fm_focal_intrinsics_fwd", ptr(focal), count, repeat, h, w, ptr(k), ptr(kinv), stream_for(focal))
-        ctx.geometry = (count, repeat, h, w, tuple(focal.shape))
-        ctx.kinv = kinv  # handed to the cache by focal_intrinsics() below, not needed for backward
-        return k
-
-    @staticmethod
-    def backward(ctx, g_k):
-        count, repeat, h, w, shape = ctx.geometry
-        g_k = _f32c(g_k, "grad")
-        g_focal = torch.empty(shape, dtype=torch.float32, device=g_k.device)
-        with _guard(g_k.device):
-            call("fm_focal_intrinsics_bwd", ptr(g_k), count, repeat, h, w, ptr(g_focal), stream_for(g_k))
-        return g_focal, None, None
+def _attach_inverse(k: Tensor, kinv: Tensor) -> None:
+    k.__dict__.setdefault("_fm_kinv", {})[(k.data_ptr(), k.numel())] = (k._version, kinv)
 
 
 def focal_intrinsics(focal: Tensor, repeat_shape, image_shape) -> Tensor:
-    """K (*focal.shape, *repeat_shape, 3, 3) from normalised focal lengths; K^-1 is computed in the
-    same launch and parked where intrinsics_inverse() finds it."""
-    k = FocalIntrinsics.apply(focal, tuple(repeat_shape), tuple(image_shape))
-    _park_inverse(k)
+    """focal_lengths_to_intrinsics spread over the frames (intrinsics/common.py:6-20 as used by
+    intrinsics_regressed.py:34-41): K (*focal.shape, *repeat_shape, 3, 3) from normalised focal lengths in
+    one launch that also computes K^-1, left on K for the step's consumers (intrinsics_inverse)."""
+    k, kinv = torch_ops().focal_intrinsics(focal, [int(d) for d in repeat_shape], int(image_shape[0]), int(image_shape[1]))
+    _attach_inverse(k, kinv)
     return k
+
+
+# --------------------------------------------------------------------------------------
+# What one step hands between its operators
+# --------------------------------------------------------------------------------------
+
+
+def depth_sink(depth: Tensor):
+    """The DepthSink of this depth tensor OBJECT (csrc/fm_torch.cpp): the model makes a fresh
+    ``depth[None]`` view per step, so this is one sink per step, reachable by every consumer that is
+    handed the same tensor — the Procrustes fit, the fused losses, the softmin sweep's LeadingFrames."""
+    sink = depth.__dict__.get("_fm_sink")
+    if sink is None:
+        sink = depth.__dict__["_fm_sink"] = torch.classes.flowmap_amd.DepthSink()
+    return sink
+
+
+def grad_arena(weights: Tensor):
+    """The persistent dL/dweights storage of the PARAMETER behind ``weights`` (GradArena), or None when
+    the weights are not a view of a leaf that wants gradients."""
+    root = weights if weights._base is None else weights._base
+    if not (root.is_leaf and root.requires_grad):
+        return None
+    arena = root.__dict__.get("_fm_arena")
+    if arena is None:
+        arena = root.__dict__["_fm_arena"] = torch.classes.flowmap_amd.GradArena()
+    return arena
+
+
+# Persistent dL/dweights storage (GradArena) for sparse fits with a constant index set; False = fresh zeros every step
+use_grad_arena = True
+
+# which backward path the facades selected (tests)
+counters = {"procrustes_planned": 0, "procrustes_dense_planned": 0}
+
+
+class LeadingFrames:
+    """``x[:, :count].contiguous()`` for (b, F, H, W) image stacks (csrc/fm_torch.cpp: LeadingFrames).  The
+    softmin sweep reads two of the 150 depth frames; autograd's slice backward would zero-fill a full-size
+    tensor and add it densely to the main path's gradient (1.7 GB of traffic at C1).  The node's backward
+    runs AFTER the consumers of the intrinsics it helped to produce, so the ``count`` frames are added into
+    the buffer the Procrustes fit has already returned for ``x`` (known through x's DepthSink); it falls
+    back to the zero-padded tensor whenever that buffer is not known."""
+
+    @staticmethod
+    def apply(x: Tensor, count: int) -> Tensor:
+        return torch_ops().leading_frames(x, int(count), depth_sink(x) if x.dim() == 4 else None)
 
 
 # --------------------------------------------------------------------------------------
@@ -130,60 +157,21 @@ def focal_intrinsics(focal: Tensor, repeat_shape, image_shape) -> Tensor:
 # --------------------------------------------------------------------------------------
 
 
-class PoseChain(torch.autograd.Function):
+class PoseChain:
     """get_extrinsics (flowmap/model/projection.py:187-210)."""
 
     @staticmethod
-    def forward(ctx, rel: Tensor) -> Tensor:
-        check_device(rel)
-        rel = _f32c(rel, "relative transformations")
-        *batch, steps, _, _ = rel.shape
-        nb = 1
-        for d in batch:
-            nb *= d
-        ext = torch.empty((*batch, steps + 1, 4, 4), dtype=torch.float32, device=rel.device)
-        with _guard(rel.device):
-            call("fm_pose_chain_fwd", ptr(rel), nb, steps, ptr(ext), stream_for(rel))
-        ctx.save_for_backward(rel, ext)
-        ctx.nb, ctx.steps = nb, steps
-        return ext
-
-    @staticmethod
-    def backward(ctx, g_ext: Tensor):
-        rel, ext = ctx.saved_tensors
-        g_ext = _f32c(g_ext, "grad")
-        g_rel = torch.empty_like(rel)
-        with _guard(rel.device):
-            call("fm_pose_chain_bwd", ptr(rel), ptr(ext), ptr(g_ext), ctx.nb, ctx.steps, ptr(g_rel), stream_for(rel))
-        return g_rel
+    def apply(rel: Tensor) -> Tensor:
+        return torch_ops().pose_chain(rel)
 
 
-class RelativePoses(torch.autograd.Function):
+class RelativePoses:
     """later(E).inverse() @ earlier(E) and earlier(E).inverse() @ later(E)
     (flowmap/model/projection.py:154,176).  extrinsics (B,F,4,4) -> two (B,F-1,4,4)."""
 
     @staticmethod
-    def forward(ctx, ext: Tensor):
-        check_device(ext)
-        ext = _f32c(ext, "extrinsics")
-        b, f = ext.shape[:2]
-        fwd = torch.empty((b, f - 1, 4, 4), dtype=torch.float32, device=ext.device)
-        bwd = torch.empty_like(fwd)
-        with _guard(ext.device):
-            call("fm_relative_pose_fwd", ptr(ext), b, f, ptr(fwd), ptr(bwd), stream_for(ext))
-        ctx.save_for_backward(ext)
-        return fwd, bwd
-
-    @staticmethod
-    def backward(ctx, g_fwd: Optional[Tensor], g_bwd: Optional[Tensor]):
-        (ext,) = ctx.saved_tensors
-        b, f = ext.shape[:2]
-        g_fwd = None if g_fwd is None else _f32c(g_fwd, "grad")
-        g_bwd = None if g_bwd is None else _f32c(g_bwd, "grad")
-        g_ext = torch.empty_like(ext)
-        with _guard(ext.device):
-            call("fm_relative_pose_bwd", ptr(ext), ptr(g_fwd), ptr(g_bwd), b, f, ptr(g_ext), stream_for(ext))
-        return g_ext
+    def apply(ext: Tensor):
+        return torch_ops().relative_poses(ext)
 
 
 class AllPairsPoses(torch.autograd.Function):
@@ -217,131 +205,21 @@ class AllPairsPoses(torch.autograd.Function):
 # --------------------------------------------------------------------------------------
 
 
-def _find_fit_node(t: Tensor, depth_key, max_depth: int = 4):
-    """Walk up the autograd graph from a pose tensor looking for the ProcrustesFit node
-    that produced it from the SAME depth tensor (see "carried depth gradient" below)."""
-    start = t.grad_fn
-    if start is None:
-        return None
-    frontier = [start]
-    for _ in range(max_depth):
-        nxt = []
-        for node in frontier:
-            if getattr(node, "_fm_fit_depth_key", None) == depth_key:
-                return node
-            nxt.extend(fn for fn, _ in getattr(node, "next_functions", ()) if fn is not None)
-        frontier = nxt
-        if not frontier:
-            break
-    return None
-
-
-# Dense gradient buffers this backward pass has already handed to autograd, by source tensor:
-# (data_ptr, version, shape) -> weakref(buffer).  A later node whose own contribution to the same
-# tensor is tiny adds it into that buffer in place instead of emitting a second full-size tensor
-# for autograd to sum (see LeadingFrames).  Single use; a dead or missing entry means "emit".
-_emitted: dict = {}
-# which path LeadingFrames.backward / the sparse Procrustes backward took (tests)
-counters = {"leading_frames_in_place": 0, "leading_frames_dense": 0, "procrustes_planned": 0}
-
-
-def _tensor_key(t: Tensor):
-    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
-
-
-def _note_emitted(source_key, buffer: Optional[Tensor]) -> None:
-    if buffer is not None and source_key is not None:
-        _emitted.pop(source_key, None)  # re-insert at the end: the dict is kept in age order
-        _emitted[source_key] = weakref.ref(buffer)
-        if len(_emitted) > 16:  # entries nobody collected (no LeadingFrames consumer): drop dead ones, then the oldest
-            for key in [k for k, ref in _emitted.items() if ref() is None]:
-                del _emitted[key]
-            while len(_emitted) > 16:
-                del _emitted[next(iter(_emitted))]
-
-
-class LeadingFrames(torch.autograd.Function):
-    """``x[:, :count].contiguous()`` for (b, F, H, W) image stacks.  The softmin sweep reads two of
-    the 150 depth frames; autograd's slice backward would zero-fill a full-size tensor and add it
-    densely to the main path's gradient (1.7 GB of traffic at C1).  Autograd runs this node's
-    backward AFTER the nodes that consume the intrinsics it helped to produce, so the dense
-    gradient of ``x`` from the flow loss / extrinsics fit is already sitting in autograd's input
-    buffer: the ``count`` frames are added into it in place and nothing is returned.  Falls back
-    to the zero-padded tensor whenever that buffer is not known."""
-
-    @staticmethod
-    def forward(ctx, x: Tensor, count: int):
-        if x.dim() != 4 or not 1 <= count <= x.shape[1]:
-            raise RuntimeError("flowmap_amd: LeadingFrames expects (batch, frame, height, width) and 1 <= count <= frame")
-        ctx.shape, ctx.count, ctx.key = tuple(x.shape), count, _tensor_key(x)
-        return x[:, :count].contiguous()
-
-    @staticmethod
-    def backward(ctx, g):
-        ref = _emitted.pop(ctx.key, None)
-        buf = ref() if ref is not None else None
-        if buf is not None and tuple(buf.shape) == ctx.shape and buf.dtype == g.dtype and buf.device == g.device:
-            buf[:, : ctx.count].add_(g)
-            counters["leading_frames_in_place"] += 1
-            return None, None
-        counters["leading_frames_dense"] += 1
-        if ctx.count == ctx.shape[1]:
-            return g, None
-        full = g.new_zeros(ctx.shape)
-        full[:, : ctx.count] = g
-        return full, None
-
-
-# Early zero fill of the sparse fit's dense dL/dweights (549 MB at C1) on a side stream: started when
-# the backward pass begins (by the fused flow loss, the first node to run), behind everything the
-# forward enqueued, with a bounded number of workgroups — it then overlaps the latency-bound kernels
-# of the backward pass instead of standing in line between them.  Off under hipGraph capture.
-prefill_weight_grads = os.environ.get("FLOWMAP_PREFILL", "1") != "0"
-PREFILL_BLOCKS = int(os.environ.get("FLOWMAP_PREFILL_BLOCKS", "512"))
-_side_streams: dict = {}
-
-
-def _start_weight_grad_prefill(node) -> None:
-    weights = node._fm_weights_like
-    if (not prefill_weight_grads or graph_capturable or weights is None or not weights.is_cuda or not node.needs_input_grad[3]
-            or getattr(node, "_fm_prefilled", None) is not None):
-        return
-    dev = weights.device
-    main = torch.cuda.current_stream(dev)
-    side = _side_streams.get(dev.index)
-    if side is None:
-        side = _side_streams[dev.index] = torch.cuda.Stream(dev)
-    side.wait_stream(main)  # not before the forward's kernels (the flow kernel owns the HBM while it runs)
-    with torch.cuda.stream(side):
-        g_w = torch.empty_like(weights)
-        with _guard(dev):
-            call("fm_fill_zero", ptr(g_w), g_w.numel(), PREFILL_BLOCKS, side.cuda_stream)
-    node._fm_prefilled = (g_w, side)
-
-
-# Plans of the sparse Procrustes backward (fm_procrustes_scatter_plan): with constant flows and a
-# constant, duplicate-free index set, the pixels the gradient touches never change.
-_scatter_plans: dict = {}
-_SCATTER_PLAN_SLOTS = 4
-
-
 def _procrustes_scatter_plan(indices: Tensor, bwd_flow: Tensor, b: int, f: int, h: int, w: int):
-    """(pixels, first, vector index per entry, weights) for fm_depth_gather, or None.  A plan costs a
-    sort, so it is built when the same (indices, flows) tensors come back a second time — per-step
-    random indices never qualify — and only for index sets without duplicates."""
-    key = (indices.data_ptr(), indices._version, indices.numel(), bwd_flow.data_ptr(), bwd_flow._version, b, f, h, w)
-    entry = _scatter_plans.get(key)
-    if entry is not None and (entry[0]() is not indices or entry[1]() is not bwd_flow):
-        entry = None  # recycled addresses
+    """(pixels, first, vector index per entry, weights) for fm_depth_gather, or None: with constant flows and
+    a constant, duplicate-free index set, the pixels the sparse Procrustes gradient touches never change.
+    A plan costs a sort, so it is built when the same (indices, flows) come back a second time — per-step
+    random indices never qualify.  Kept on the flow tensor, keyed by the index tensor's identity."""
+    plans = bwd_flow.__dict__.setdefault("_fm_sparse_plans", {})
+    key = (id(indices), indices._version, indices.data_ptr(), indices.numel(), bwd_flow._version, b, f, h, w)
+    entry = plans.get(key)
     if entry is None:
-        for stale in [k_ for k_, e_ in _scatter_plans.items() if e_[0]() is None or e_[1]() is None]:
-            del _scatter_plans[stale]
-        while len(_scatter_plans) >= _SCATTER_PLAN_SLOTS:
-            del _scatter_plans[next(iter(_scatter_plans))]
-        _scatter_plans[key] = [weakref.ref(indices), weakref.ref(bwd_flow), None, False]  # [.., plan, built]
+        if len(plans) >= 4:
+            plans.clear()
+        plans[key] = [indices, None, False]  # [the index tensor (kept alive: its id is the key), plan, decided]
         return None
-    if not entry[3]:
-        entry[3] = True
+    if not entry[2]:
+        entry[2] = True
         points = indices.numel()
         if torch.unique(indices).numel() == points:
             dev = bwd_flow.device
@@ -356,8 +234,8 @@ def _procrustes_scatter_plan(indices: Tensor, bwd_flow: Tensor, b: int, f: int, 
             first = torch.zeros((pixels.numel() + 1,), dtype=torch.int32, device=dev)
             first[1:] = torch.cumsum(counts, 0).to(torch.int32)
             vectors = (torch.div(entries, 5, rounding_mode="floor") * 2 + (entries % 5 == 4)).to(torch.int32)
-            entry[2] = (pixels.contiguous(), first, vectors.contiguous(), weights[entries].contiguous())
-    return entry[2]
+            entry[1] = (pixels.contiguous(), first, vectors.contiguous(), weights[entries].contiguous())
+    return entry[1]
 
 
 def _dense_procrustes_plan(bwd_flow: Tensor, b: int, f: int, h: int, w: int):
@@ -365,33 +243,30 @@ def _dense_procrustes_plan(bwd_flow: Tensor, b: int, f: int, h: int, w: int):
     every pair's earlier frame, the later pixels whose bilinear taps land in it.  The flows are constants
     of the optimisation, so this is built once per flow tensor and kept ON that tensor (it lives and dies
     with it; an in-place edit bumps the version and the plan is rebuilt)."""
-    key = (bwd_flow._version, b, f, h, w)
-    hit = getattr(bwd_flow, "_fm_dense_plan", None)
-    if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
-    import ctypes
 
-    tiles = ctypes.c_int(0)
-    call("fm_procrustes_dense_tiles", h, w, ctypes.addressof(tiles))
-    dev = bwd_flow.device
-    slots = b * (f - 1) * tiles.value
-    with _guard(dev):
-        st = stream_for(bwd_flow)
-        counts = torch.zeros((slots,), dtype=torch.int32, device=dev)
-        call("fm_procrustes_dense_plan", ptr(bwd_flow), b, f, h, w, ptr(counts), None, None, st)
-        first = torch.zeros((slots + 1,), dtype=torch.int64, device=dev)
-        torch.cumsum(counts, 0, out=first[1:])
-        total = int(first[-1].item())  # one host sync, when the plan is built
-        entries = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
-        counts.zero_()
-        call("fm_procrustes_dense_plan", ptr(bwd_flow), b, f, h, w, ptr(counts), ptr(first), ptr(entries), st)
-    bwd_flow._fm_dense_plan = (key, first, entries)
-    return first, entries
+    def build():
+        tiles = ctypes.c_int(0)
+        call("fm_procrustes_dense_tiles", h, w, ctypes.addressof(tiles))
+        dev = bwd_flow.device
+        slots = b * (f - 1) * tiles.value
+        with _guard(dev):
+            st = stream_for(bwd_flow)
+            counts = torch.zeros((slots,), dtype=torch.int32, device=dev)
+            call("fm_procrustes_dense_plan", ptr(bwd_flow), b, f, h, w, ptr(counts), None, None, st)
+            first = torch.zeros((slots + 1,), dtype=torch.int64, device=dev)
+            torch.cumsum(counts, 0, out=first[1:])
+            total = int(first[-1].item())  # one host sync, when the plan is built
+            entries = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
+            counts.zero_()
+            call("fm_procrustes_dense_plan", ptr(bwd_flow), b, f, h, w, ptr(counts), ptr(first), ptr(entries), st)
+        return first, entries
+
+    return _derived(bwd_flow, "_fm_dense_plan", (bwd_flow._version, b, f, h, w), build)
 
 
-class ProcrustesFit(torch.autograd.Function):
+class ProcrustesFit:
     """align_surfaces up to (not including) the pose chain (projection.py:213-249) with
-    align_rigid (procrustes.py:7-51) inside.  Source of xyz is either
+    align_rigid (procrustes.py:7-51) inside (csrc/fm_torch.cpp: ProcrustesFit).  Source of xyz is either
 
       depth (B,F,H,W) + intrinsics (B,F,3,3)   [surfaces never materialised], or
       surfaces (B,F,H,W,3).
@@ -403,189 +278,81 @@ class ProcrustesFit(torch.autograd.Function):
     Returns the "inverse relative transformations" (B,F-1,4,4): later -> earlier camera, and
     their rigid inverses (earlier -> later camera) for consumers that want both directions
     without going through the pose chain.
-    """
+
+    This facade adds what the operator takes explicitly: K^-1, the step's DepthSink, the weight
+    parameter's GradArena and the static backward plans (planned gather for a constant sparse index
+    set, tile lists for the dense case)."""
 
     @staticmethod
-    def forward(ctx, depth, k, surfaces, weights, bwd_flow, indices, weight_sens=0.0, batch_repeat=1):
+    def apply(depth, k, surfaces, weights, bwd_flow, indices, weight_sens=0.0, batch_repeat=1):
         from_depth = surfaces is None
-        check_device(depth if from_depth else surfaces, weights, bwd_flow, indices)
-        weights = _f32c(weights, "weights")
-        bwd_flow = _f32c(bwd_flow, "backward flow")
-        if bwd_flow.requires_grad:
-            raise RuntimeError("flowmap_amd: gradients w.r.t. optical flow are not supported (flows are constants)")
         rep = int(batch_repeat)
+        kinv = sink = wsink = arena = None
+        sparse = (None, None, None, None)
+        dense = (None, None)
         if from_depth:
-            depth = _f32c(depth, "depth")
-            k = _f32c(k, "intrinsics")
-            bd, f, h, w = depth.shape
-            b = bd * rep  # pose / intrinsics batch: every image-batch entry serves `rep` candidates
-            if tuple(k.shape) != (b, f, 3, 3):
-                raise RuntimeError("flowmap_amd: intrinsics shape does not match depth (x batch_repeat)")
+            if depth is None or k is None:
+                raise RuntimeError("flowmap_amd: the Procrustes fit needs depth + intrinsics or surfaces")
             kinv = intrinsics_inverse(k)
-            dev = depth.device
-        else:
-            if rep != 1:
-                raise RuntimeError("flowmap_amd: batch_repeat needs depth-sourced surfaces")
-            surfaces = _f32c(surfaces, "surfaces")
-            bd, f, h, w, _ = surfaces.shape
-            b = bd
-            kinv = None
-            dev = surfaces.device
-        if tuple(weights.shape) != (bd, f - 1, h, w) or tuple(bwd_flow.shape) != (bd, f - 1, h, w, 2):
-            raise RuntimeError("flowmap_amd: weights/backward-flow shapes do not match the surfaces")
-        if indices is not None:
-            if indices.dtype != torch.int64:
-                raise RuntimeError("flowmap_amd: indices must be int64")
-            indices = indices.contiguous()
-            points = indices.numel()
-        else:
-            points = h * w
-        pairs = b * (f - 1)
-        stats = torch.empty((pairs, STAT_STRIDE), dtype=torch.float64, device=dev)
-        t_bwd = torch.empty((b, f - 1, 4, 4), dtype=torch.float32, device=dev)
-        t_fwd = torch.empty_like(t_bwd)
-        aux = torch.empty((pairs, AUX_STRIDE), dtype=torch.float64, device=dev)
-        with _guard(dev):
-            st = stream_for(weights)
-            call("fm_procrustes_fit", ptr(depth) if from_depth else None, ptr(kinv), ptr(surfaces), ptr(bwd_flow),
-                 ptr(weights), float(weight_sens), ptr(indices), points, b, rep, f, h, w, ptr(stats), ptr(t_bwd), ptr(t_fwd), ptr(aux), st)
-        ctx.save_for_backward(depth if from_depth else surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux)
-        ctx.from_depth, ctx.dims, ctx.points, ctx.weight_sens, ctx.rep = from_depth, (b, f, h, w), points, float(weight_sens), rep
-        # Carried depth gradient: when the fused flow loss consumes poses fitted from the very
-        # same depth tensor, it parks its dense dL/ddepth here instead of returning it, and
-        # this node (which autograd always runs later) scatters its sparse part into that
-        # buffer and returns the sum once — no second dense tensor, no dense add.
-        ctx._fm_src_key = _tensor_key(depth if from_depth else surfaces)
-        ctx._fm_weights_key = _tensor_key(weights)
-        ctx._fm_fit_depth_key = (depth.data_ptr(), depth._version, tuple(depth.shape)) if from_depth else None
-        ctx._fm_carried = None
-        ctx._fm_pending = []  # deferred scatters of other losses into the final dL/ddepth buffer
-        # sparse fits accumulate into a zeroed dL/dweights: the fused flow loss may start that fill early
-        ctx._fm_weights_like = weights if (indices is not None and rep == 1) else None
-        ctx._fm_prefilled = None
-        return t_bwd, t_fwd
-
-    @staticmethod
-    def backward(ctx, g_t, g_t_fwd):
-        src, kinv, weights, bwd_flow, indices, t_bwd, aux = ctx.saved_tensors
-        b, f, h, w = ctx.dims
-        pairs = b * (f - 1)
-        dev = weights.device
-        g_t = None if g_t is None else _f32c(g_t, "grad")
-        g_t_fwd = None if g_t_fwd is None else _f32c(g_t_fwd, "grad")
-        need_src = ctx.needs_input_grad[0] if ctx.from_depth else ctx.needs_input_grad[2]
-        need_k = ctx.from_depth and ctx.needs_input_grad[1]
-        need_w = ctx.needs_input_grad[3]
-        pair_grad = torch.empty((pairs, PAIR_GRAD_STRIDE), dtype=torch.float64, device=dev)
-        g_src = g_k = g_w = fill_stream = None
-        carried = ctx._fm_carried
-        ctx._fm_carried = None
-        pending, ctx._fm_pending = ctx._fm_pending, []
-        if need_src:
-            g_src = carried if carried is not None else torch.zeros_like(src)
-            for scatter in pending:
-                scatter(g_src)
-        if need_w:
-            # (zero-filling this 549 MB buffer at FORWARD time on a side stream was measured and
-            # rejected: the fill contends with the fused flow kernel — step 1.126 -> 1.187 ms.  What
-            # works is _start_weight_grad_prefill: started when the backward pass begins, bounded
-            # footprint, and the P values per pair placed by fm_sparse_store after the join.)
-            # the tiled dense kernels (depth-sourced, every pixel a correspondence) STORE every
-            # element of dL/dweights; all other paths accumulate atomically into zeros
-            dense_tiled = ctx.from_depth and indices is None and ctx.rep == 1 and h <= 65535 and w <= 65535
-            prefilled, ctx._fm_prefilled = ctx._fm_prefilled, None
-            if prefilled is not None:
-                g_w, fill_stream = prefilled  # being zeroed on the side stream; joined below
-                g_w.record_stream(torch.cuda.current_stream(dev))
-            else:
-                g_w = torch.empty_like(weights) if dense_tiled else torch.zeros_like(weights)
-        kinv_acc = torch.empty((b * f, 9), dtype=torch.float64, device=dev) if need_k else None  # zeroed by fm_pose_solve_bwd
-        # sparse depth-sourced fit with constant indices / flows: the depth gradient is gathered along a
-        # plan instead of scattered with atomics (which run at the memory side: 100 us for 0.9 M adds)
-        plan = point_grads = point_gw = None
-        if ctx.from_depth and indices is not None and ctx.rep == 1:
-            plan = _procrustes_scatter_plan(indices, bwd_flow, b, f, h, w)
-            if plan is not None:
-                point_grads = torch.empty((pairs * ctx.points, 2, 3), dtype=torch.float32, device=dev)
-                counters["procrustes_planned"] += 1
-                if fill_stream is not None and g_w is not None:  # keep the per-point pass off the buffer still being zeroed
-                    point_gw = torch.empty((pairs * ctx.points,), dtype=torch.float32, device=dev)
-        if fill_stream is not None and point_gw is None:
-            torch.cuda.current_stream(dev).wait_stream(fill_stream)  # the scatter writes into g_w directly
-            fill_stream = None
-        dense = ctx.from_depth and indices is None and ctx.rep == 1 and h <= 65535 and w <= 65535
-        with _guard(dev):
-            st = stream_for(weights)
-            call("fm_pose_solve_bwd", ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr(aux), pairs, ptr(pair_grad), ptr(kinv_acc),
-                 0 if kinv_acc is None else kinv_acc.numel(), st)
-            if dense:  # every pixel a correspondence: tiled, planned, no atomics (fm_procrustes_scatter_dense)
-                first = entries = None
-                if g_src is not None:
-                    first, entries = _dense_procrustes_plan(bwd_flow, b, f, h, w)
-                consts = torch.empty((pairs, DENSE_CONST_STRIDE), dtype=torch.float64, device=dev)
-                call("fm_procrustes_scatter_dense", ptr(src), ptr(kinv), ptr(bwd_flow), ptr(weights), ctx.weight_sens, b, f, h, w, ptr(aux),
-                     ptr(pair_grad), ptr(g_src), ptr(g_w), ptr(kinv_acc), ptr(first), ptr(entries), ptr(consts), st)
-            else:
-                call("fm_procrustes_scatter", ptr(src) if ctx.from_depth else None, ptr(kinv), None if ctx.from_depth else ptr(src),
-                     ptr(bwd_flow), ptr(weights), ctx.weight_sens, ptr(indices), ctx.points, b, ctx.rep, f, h, w, ptr(aux), ptr(pair_grad),
-                     ptr(g_src) if ctx.from_depth else None, None if ctx.from_depth else ptr(g_src), ptr(g_w), ptr(kinv_acc),
-                     ptr(point_grads), ptr(point_gw), st)
-            if plan is not None and g_src is not None:
-                pixels, first, vectors, weights_e = plan
-                call("fm_depth_gather", ptr(point_grads), ptr(pixels), ptr(first), ptr(vectors), ptr(weights_e), pixels.numel(), ptr(kinv),
-                     None, None, h, w, 0, ptr(g_src), st)
-            if point_gw is not None:
-                torch.cuda.current_stream(dev).wait_stream(fill_stream)  # the zero fill is done: place the P values per pair
-                call("fm_sparse_store", ptr(point_gw), ptr(indices), ctx.points, pairs, h * w, ptr(g_w), st)
-            if need_k:
-                g_k = torch.empty_like(kinv)
-                call("fm_intrinsics_inverse_bwd", ptr(kinv_acc), ptr(kinv), b * f, ptr(g_k), 0, st)
-        _note_emitted(ctx._fm_src_key, g_src)
-        _note_emitted(ctx._fm_weights_key, g_w)
-        if ctx.from_depth:
-            return g_src, g_k, None, g_w, None, None, None, None
-        return None, None, g_src, g_w, None, None, None, None
+            wants_grad = torch.is_grad_enabled() and depth.requires_grad and rep == 1
+            static_flow = bwd_flow.dtype == torch.float32 and bwd_flow.is_contiguous() and depth.dim() == 4 and bwd_flow.dim() == 5
+            if rep == 1:
+                sink = depth_sink(depth)
+            if wants_grad and static_flow:
+                b, f, h, w = depth.shape
+                if indices is None:
+                    if h <= 65535 and w <= 65535:
+                        dense = _dense_procrustes_plan(bwd_flow, b, f, h, w)
+                        counters["procrustes_dense_planned"] += 1
+                elif indices.dtype == torch.int64 and indices.is_contiguous():
+                    plan = _procrustes_scatter_plan(indices, bwd_flow, b, f, h, w)
+                    if plan is not None:
+                        sparse = plan
+                        counters["procrustes_planned"] += 1
+                        if use_grad_arena and torch.is_tensor(weights) and weights.requires_grad:
+                            arena = grad_arena(weights)
+            wsink = weights.__dict__.get("_fm_sink")  # exists when the softmin sweep took LeadingFrames of the weights
+        return torch_ops().procrustes_fit(depth, k, kinv, surfaces, weights, bwd_flow, indices, float(weight_sens), rep, sink, wsink, arena,
+                                          *sparse, *dense)
 
 
 # --------------------------------------------------------------------------------------
 # Fused flow loss
 # --------------------------------------------------------------------------------------
 
-_norm_cache: dict = {}
 
-# bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs around every
-# launch of the fused flow kernel (same stream as the launch).
-flow_kernel_events = None
+def flow_kernel_timing(enable: bool) -> None:
+    """bench.py: record HIP events on the launch stream around every launch of the fused flow kernel."""
+    torch_ops().flow_timing_enable(bool(enable))
+
+
+def flow_kernel_times(tracking: bool = False):
+    """Milliseconds of every fused flow kernel launch (``tracking``: of every fm_track_loss_fwd call, i.e.
+    track_pairs + its reduction) since the last call (synchronise first)."""
+    return list(torch_ops().flow_timing_collect(bool(tracking)))
 
 
 def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=None) -> Tensor:
     """Device tensor [weight/(V or 1), (V or 1)] with V = Σmask_fwd + Σmask_bwd
-    (loss_flow.py:56,66,70).  Masks are constants of the optimisation, so the result is
-    cached per (storage, version, weight) and costs nothing after the first step.
+    (loss_flow.py:56,66,70).  Masks are constants of the optimisation, so the result is kept on the
+    forward-mask tensor (per backward mask, weight and reducer) and costs nothing after the first step.
     ``reducer`` (frame sharding) maps the local fp64 sum to the global one."""
-    key = (mask_fwd.data_ptr(), mask_bwd.data_ptr(), mask_fwd._version, mask_bwd._version, tuple(mask_fwd.shape),
-           float(weight), str(mask_fwd.device), id(reducer))
-    hit = _norm_cache.get(key)
-    if hit is not None:
-        norm, ref_f, ref_b = hit
-        if ref_f() is mask_fwd and ref_b() is mask_bwd:  # same live tensors, not a recycled address
-            return norm
-    vsum = torch.empty((1,), dtype=torch.float64, device=mask_fwd.device)
-    norm = torch.empty((2,), dtype=torch.float32, device=mask_fwd.device)
-    with _guard(mask_fwd.device):
-        call("fm_flow_valid_norm", ptr(mask_fwd), ptr(mask_bwd), mask_fwd.numel(), float(weight), ptr(vsum), ptr(norm),
-             stream_for(mask_fwd))
-    if reducer is not None:
-        vsum = reducer(vsum)
-        veff = torch.where(vsum == 0, torch.ones_like(vsum), vsum)
-        norm = torch.cat([float(weight) / veff, veff]).to(torch.float32)
-    if len(_norm_cache) > 8:
-        _norm_cache.clear()
-    _norm_cache[key] = (norm, weakref.ref(mask_fwd), weakref.ref(mask_bwd))
-    return norm
 
+    def build():
+        vsum = torch.empty((1,), dtype=torch.float64, device=mask_fwd.device)
+        norm = torch.empty((2,), dtype=torch.float32, device=mask_fwd.device)
+        with _guard(mask_fwd.device):
+            call("fm_flow_valid_norm", ptr(mask_fwd), ptr(mask_bwd), mask_fwd.numel(), float(weight), ptr(vsum), ptr(norm),
+                 stream_for(mask_fwd))
+        if reducer is not None:
+            total = reducer(vsum)
+            veff = torch.where(total == 0, torch.ones_like(total), total)
+            norm = torch.cat([float(weight) / veff, veff]).to(torch.float32)
+        return (mask_bwd, reducer, norm)  # the other mask and the reducer are kept alive: their ids are part of the key
 
-_pack_cache: dict = {}
+    key = (mask_fwd._version, id(mask_bwd), mask_bwd._version, mask_bwd.data_ptr(), tuple(mask_fwd.shape), float(weight), id(reducer))
+    return _derived(mask_fwd, "_fm_norm", key, build)[2]
+
 
 # The packed copy costs as much HBM as the flows and masks themselves (3.3 GB at C1); set to
 # False to stream the caller's tensors directly (tests exercise both kernels).
@@ -596,8 +363,8 @@ def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mas
     """Flows + masks in the layout of fm_flow_pack_inputs, or None when it does not apply
     (width not a multiple of 4, unexpected shapes / dtypes).  Like the valid-sum, these are
     constants of an optimisation (flow_predictor.py:82-102 runs once per video), so the
-    re-layout runs once per Flows object: cached per (storage, version) of all four tensors
-    and validated against the live tensors."""
+    re-layout runs once per Flows object: kept on the forward-flow tensor and validated against the
+    identity and version of all four tensors."""
     if not use_packed_inputs:
         return None
     srcs = (flow_fwd, flow_bwd, mask_fwd, mask_bwd)
@@ -607,101 +374,33 @@ def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mas
         return None
     if any(t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 != 0 for t in srcs):
         return None
-    key = tuple((t.data_ptr(), t._version) for t in srcs) + (tuple(mask_fwd.shape), str(mask_fwd.device))
-    hit = _pack_cache.get(key)
-    if hit is not None and all(ref() is t for ref, t in zip(hit[1], srcs)):
-        return hit[0]
-    b, pairs, h, w = mask_fwd.shape
-    chunks = (h * w // 4 + 63) // 64
-    packed = torch.empty((b * (pairs + 1), chunks, 6, 64, 4), dtype=torch.float32, device=mask_fwd.device)
-    with _guard(mask_fwd.device):
-        call("fm_flow_pack_inputs", ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd), b, pairs + 1, h, w, ptr(packed),
-             stream_for(mask_fwd))
-    if len(_pack_cache) > 4:
-        _pack_cache.clear()
-    _pack_cache[key] = (packed, [weakref.ref(t) for t in srcs])
-    return packed
+
+    def build():
+        b, pairs, h, w = mask_fwd.shape
+        chunks = (h * w // 4 + 63) // 64
+        packed = torch.empty((b * (pairs + 1), chunks, 6, 64, 4), dtype=torch.float32, device=mask_fwd.device)
+        with _guard(mask_fwd.device):
+            call("fm_flow_pack_inputs", ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd), b, pairs + 1, h, w, ptr(packed),
+                 stream_for(mask_fwd))
+        return (srcs[1:], packed)  # the three other tensors are kept alive: their ids are part of the key
+
+    key = tuple((id(t), t._version, t.data_ptr()) for t in srcs) + (tuple(mask_fwd.shape),)
+    return _derived(flow_fwd, "_fm_packed", key, build)[1]
 
 
-class FlowLossFused(torch.autograd.Function):
+class FlowLossFused:
     """weight · LossFlow.compute_unweighted_loss (flowmap/loss/loss_flow.py:31-70,
     flowmap/loss/loss.py:47) evaluated from depth + intrinsics + relative poses, with the
-    analytic gradient of every input produced in the same HBM pass."""
+    analytic gradient of every input produced in the same HBM pass (csrc/fm_torch.cpp: FlowLossFused).
+    ``carry``: let the dense dL/ddepth travel through the step's DepthSink to the Procrustes fit's
+    node (which returns it once, summed with the sparse parts) when the poses come from that fit."""
 
     @staticmethod
-    def forward(ctx, depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, kind, delta, carry, items, packed=None):
-        dev = check_device(depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm)
-        depth = _f32c(depth, "depth")
-        k = _f32c(k, "intrinsics")
-        t_fwd = _f32c(t_fwd, "forward poses")
-        t_bwd = _f32c(t_bwd, "backward poses")
-        flow_fwd, flow_bwd = _f32c(flow_fwd, "forward flow"), _f32c(flow_bwd, "backward flow")
-        mask_fwd, mask_bwd = _f32c(mask_fwd, "forward mask"), _f32c(mask_bwd, "backward mask")
-        b, f, h, w = depth.shape
-        if tuple(flow_fwd.shape) != (b, f - 1, h, w, 2) or tuple(flow_bwd.shape) != (b, f - 1, h, w, 2):
-            raise RuntimeError("flowmap_amd: flow shape does not match depth")
-        if tuple(mask_fwd.shape) != (b, f - 1, h, w) or tuple(mask_bwd.shape) != (b, f - 1, h, w):
-            raise RuntimeError("flowmap_amd: mask shape does not match depth")
-        if tuple(k.shape) != (b, f, 3, 3) or tuple(t_fwd.shape) != (b, f - 1, 4, 4) or tuple(t_bwd.shape) != (b, f - 1, 4, 4):
-            raise RuntimeError("flowmap_amd: intrinsics / pose shapes do not match depth")
-        need = any(ctx.needs_input_grad[:4])
+    def apply(depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, kind, delta, carry, items, packed=None):
         kinv = intrinsics_inverse(k)
-        if packed is not None and (packed.dtype != torch.float32 or not packed.is_contiguous() or w % 4 != 0
-                                   or tuple(packed.shape) != (b * f, (h * w // 4 + 63) // 64, 6, 64, 4)):
-            raise RuntimeError("flowmap_amd: packed flow inputs do not match the depth shape")
-        acc = torch.empty((b * f * 2 * FLOW_ACC_STRIDE,), dtype=torch.float64, device=dev)
-        loss = torch.empty((1,), dtype=torch.float32, device=dev)
-        g_depth = torch.empty_like(depth) if (need and ctx.needs_input_grad[0]) else None
-        # the three small gradients share one allocation so one launch rescales them in backward
-        small = torch.empty((2 * t_fwd.numel() + k.numel(),), dtype=torch.float32, device=dev)
-        g_tf = small[: t_fwd.numel()].view_as(t_fwd)
-        g_tb = small[t_fwd.numel() : 2 * t_fwd.numel()].view_as(t_bwd)
-        g_k = small[2 * t_fwd.numel() :].view_as(k)
-        scale = (h * w) ** 0.5
-        events = None
-        if flow_kernel_events is not None and depth.is_cuda:
-            events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        with _guard(dev):
-            st = stream_for(depth)
-            if events:
-                events[0].record()
-            call("fm_flow_loss_fused", ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd),
-                 ptr(mask_fwd), ptr(mask_bwd), ptr(packed), ptr(norm) if need else None, b, f, h, w, kind, float(delta), w / scale, h / scale,
-                 ptr(g_depth), ptr(acc), int(items), st)
-            if events:
-                events[1].record()
-                flow_kernel_events.append(events)
-            call("fm_flow_loss_finalize", ptr(acc), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(norm), b, f, w / scale, h / scale,
-                 ptr(loss), ptr(g_tf), ptr(g_tb), ptr(g_k), st)
-        ctx.grads = (g_depth, g_k, g_tf, g_tb, small) if need else None
-        ctx.fit_node = None
-        if carry and g_depth is not None:
-            key = (depth.data_ptr(), depth._version, tuple(depth.shape))
-            node = _find_fit_node(t_bwd, key)
-            if node is not None and node.needs_input_grad[0] and _find_fit_node(t_fwd, key) is node:
-                ctx.fit_node = node
-        return loss.reshape(())
-
-    @staticmethod
-    def backward(ctx, g):
-        if ctx.grads is None:
-            raise RuntimeError("flowmap_amd: FlowLossFused gradients are single-use; run the forward again")
-        g_depth, g_k, g_tf, g_tb, small = ctx.grads
-        ctx.grads = None
-        if ctx.fit_node is not None:
-            _start_weight_grad_prefill(ctx.fit_node)
-        g = g.reshape(1).to(torch.float32).contiguous()
-        with _guard(g.device):
-            st = stream_for(g)
-            call("fm_scale_if_needed", ptr(g_depth), 0 if g_depth is None else g_depth.numel(), ptr(small), small.numel(), ptr(g), st)
-        node = ctx.fit_node
-        ctx.fit_node = None
-        if node is not None and g_depth is not None and node._fm_carried is None:
-            node._fm_carried = g_depth  # returned (summed) by ProcrustesFit.backward
-            g_depth = None
-        need = ctx.needs_input_grad
-        return (g_depth if (need[0] and g_depth is not None) else None, g_k if need[1] else None, g_tf if need[2] else None,
-                g_tb if need[3] else None, None, None, None, None, None, None, None, None, None, None)
+        sink = depth_sink(depth) if carry else None
+        return torch_ops().flow_loss(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, int(kind), float(delta),
+                                     sink, int(items))
 
 
 class SoftminScore(torch.autograd.Function):
@@ -799,12 +498,12 @@ class SoftminIntrinsics(torch.autograd.Function):
 
 
 def _park_inverse(k: Tensor) -> None:
-    """Move the K^-1 a fused producer computed alongside ``k`` into intrinsics_inverse()'s cache."""
+    """Leave the K^-1 a fused producer computed alongside ``k`` where intrinsics_inverse() finds it."""
     node = k.grad_fn
     kinv = getattr(node, "kinv", None) if node is not None else None
     if kinv is not None:
         node.kinv = None
-        _kinv_store(k, _kinv_key(k), kinv)
+        _attach_inverse(k, kinv)
 
 
 def softmin_intrinsics(depth, weights, bwd_flow, indices, candidate_k, rel, weight_sens, frames):
@@ -1119,6 +818,7 @@ class PackedTracks:
         self.pmax = max(s_[2] for s_ in seg)
         self.fmax = max(s_[1] for s_ in seg)
         self.last_frame = max(s_[0] + s_[1] for s_ in seg)
+        self.counts = [self.nblocks, self.ntiles, self.pmax, self.fmax, self.total, int(self.partial), self.last_frame]
         self._plans: dict = {}
 
     def scatter_plan(self, height: int, width: int):
@@ -1147,26 +847,18 @@ class PackedTracks:
         return self._plans[key]
 
 
-_packed_cache: dict = {}
-
-
 def pack_tracks(tracks, device, own=None) -> PackedTracks:
-    key = tuple((t.xy.data_ptr(), t.xy._version, t.visibility.data_ptr(), int(t.start_frame), tuple(t.xy.shape)) for t in tracks) + (str(device), own)
-    hit = _packed_cache.get(key)
-    if hit is not None:
-        packed, refs = hit
-        if all(r() is t.xy for r, t in zip(refs, tracks)):  # live tensors, not recycled addresses
-            return packed
-    if len(_packed_cache) > 4:
-        _packed_cache.clear()
-    packed = PackedTracks(tracks, device, own)
-    _packed_cache[key] = (packed, [weakref.ref(t.xy) for t in tracks])
-    return packed
+    """The packed form of a track list, built once: kept on the first segment's coordinate tensor and
+    validated against every segment's identity and version."""
+    key = tuple((id(t.xy), t.xy._version, id(t.visibility), t.visibility._version, int(t.start_frame), tuple(t.xy.shape)) for t in tracks)
+    key += (str(device), own)
+    return _derived(tracks[0].xy, "_fm_packed_tracks", key, lambda: (list(tracks), PackedTracks(tracks, device, own)))[1]
 
 
-class TrackLossFused(torch.autograd.Function):
+class TrackLossFused:
     """weight · LossTracking.compute_unweighted_loss (flowmap/loss/loss_tracking.py:28-61,
-    flowmap/loss/loss.py:47) over all segments, from depth + intrinsics + extrinsics.
+    flowmap/loss/loss.py:47) over all segments, from depth + intrinsics + extrinsics
+    (csrc/fm_torch.cpp: TrackLossFused).
 
     Frame sharding (flowmap_amd/sharding.py): ``depth`` holds the rank's frames from ``frame0`` on,
     ``k`` / ``ext`` the whole video; ``packed`` was built with this rank's ``own`` source range;
@@ -1174,104 +866,21 @@ class TrackLossFused(torch.autograd.Function):
     the gradients this rank's share of it (autograd / FrameShard.sync sum them)."""
 
     @staticmethod
-    def forward(ctx, depth, k, ext, packed: PackedTracks, weight, kind, delta, defer, frame0=0, reducer=None, fit_from=None):
-        dev = check_device(depth, k, ext, packed.xy)
-        depth, k, ext = _f32c(depth, "depth"), _f32c(k, "intrinsics"), _f32c(ext, "extrinsics")
-        b, f_local, h, w = depth.shape
-        f = ext.shape[1]
-        if b != 1:
-            raise RuntimeError("flowmap_amd: the fused tracking loss supports batch size 1")
-        if tuple(k.shape) != (1, f, 3, 3) or tuple(ext.shape) != (1, f, 4, 4) or frame0 < 0 or frame0 + f_local > f:
-            raise RuntimeError("flowmap_amd: intrinsics / extrinsics must cover the whole video and depth a window of it")
-        if packed.last_frame > f:
-            raise RuntimeError("flowmap_amd: a track segment extends past the last frame")
+    def apply(depth, k, ext, packed: PackedTracks, weight, kind, delta, defer, frame0=0, reducer=None, fit_from=None):
+        check_device(depth, k, ext, packed.xy)
         kinv = intrinsics_inverse(k)
-        ext_inv = torch.empty_like(ext)
-        ws = torch.empty((packed.total, 9), dtype=torch.float32, device=dev)
-        flag = (torch.zeros if packed.partial else torch.empty)((packed.total,), dtype=torch.uint8, device=dev)
-        acc = torch.empty((f * 20,), dtype=torch.float64, device=dev)
-        loss = torch.empty((1,), dtype=torch.float32, device=dev)
-        scale = torch.empty((2,), dtype=torch.float32, device=dev)
-        totals = torch.empty((2,), dtype=torch.float64, device=dev)
-        need = any(ctx.needs_input_grad[:3])
-        # every residual is evaluated once: the (unscaled) gradients come out of the same launch
-        gws = torch.empty((packed.total, 3), dtype=torch.float32, device=dev) if need else None
-        acc2 = torch.empty((f * 24,), dtype=torch.float64, device=dev) if need else None
-        tgt = torch.empty((f, 12), dtype=torch.float32, device=dev)
-        partial = torch.empty((max(packed.ntiles, 1) * ((packed.pmax + 63) // 64) * (packed.fmax * 14 + TRACK_TILE * 21),), dtype=torch.float32,
-                              device=dev)  # per-wave sums (FM_TRACK_PARTIAL), reduced per frame without atomics
-        sc = (h * w) ** 0.5
-        with _guard(dev):
-            st = stream_for(depth)
-            call("fm_extrinsics_inverse", ptr(ext), f, ptr(ext_inv), st)
-            if packed.ntiles > 0:
-                call("fm_track_points", ptr(depth), int(frame0), ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), f, ptr(packed.xy), ptr(packed.vis),
-                     ptr(packed.seg), ptr(packed.blocks), packed.nblocks, packed.pmax, h, w, ptr(ws), ptr(flag), ptr(tgt), st)
-                call("fm_track_loss_fwd", ptr(ws), ptr(flag), ptr(packed.xy), ptr(packed.vis), ptr(packed.seg), ptr(packed.tiles),
-                     packed.ntiles, packed.pmax, packed.fmax, ptr(ext), ptr(tgt), f, h, w, kind, float(delta), w / sc, h / sc,
-                     float(weight), ptr(partial), ptr(acc), ptr(loss), ptr(scale), ptr(totals), ptr(gws), ptr(acc2), st)
-        if packed.ntiles == 0:  # this rank owns no source frame of any segment
-            acc.zero_()
-            totals.zero_()
-            loss.zero_()
-            scale.copy_(torch.tensor([float(weight), 0.0], device=dev))
-            if need:
-                acc2.zero_()
+        needs_depth = torch.is_grad_enabled() and depth.requires_grad
+        plan = packed.scatter_plan(depth.shape[2], depth.shape[3]) if needs_depth and depth.dim() == 4 else None  # built at the first step
+        sink = depth_sink(depth) if defer else None
+        loss, scale, totals = torch_ops().track_loss(depth, k, kinv, ext, packed.xy, packed.vis, packed.seg, packed.blocks, packed.tiles,
+                                                     packed.counts, float(weight), int(kind), float(delta), sink, int(frame0),
+                                                     *(plan if plan is not None else (None, None, None, None)), fit_from)
         if reducer is not None:
-            totals = reducer(totals)
-            den = torch.where(totals[1] == 0, torch.ones_like(totals[1]), totals[1])  # `valid_sum or 1` (loss_tracking.py:61)
-            loss = (float(weight) * totals[0] / den).to(torch.float32).reshape(1)
-            scale = torch.stack([float(weight) / den, totals[1]]).to(torch.float32)
-        ctx.save_for_backward(k, kinv, ext_inv, flag, acc, scale)
-        ctx.grads = (gws, acc2) if need else None
-        ctx.packed, ctx.dims, ctx.shapes = packed, (f, h, w), (tuple(depth.shape), tuple(k.shape), tuple(ext.shape))
-        ctx.frame0 = int(frame0)
-        ctx.fit_node = None
-        ctx.plan = packed.scatter_plan(h, w) if ctx.needs_input_grad[0] else None  # built at the first step
-        if defer and ctx.needs_input_grad[0]:
-            node = _find_fit_node(ext if fit_from is None else fit_from, (depth.data_ptr(), depth._version, tuple(depth.shape)))
-            if node is not None and node.needs_input_grad[0]:
-                ctx.fit_node = node
-        return loss.reshape(())
-
-    @staticmethod
-    def backward(ctx, g):
-        if ctx.grads is None:
-            raise RuntimeError("flowmap_amd: TrackLossFused gradients are single-use; run the forward again")
-        k, kinv, ext_inv, flag, acc, scale = ctx.saved_tensors
-        gws, acc2 = ctx.grads
-        ctx.grads = None
-        depth_shape, k_shape, ext_shape = ctx.shapes
-        pk: PackedTracks = ctx.packed
-        f, h, w = ctx.dims
-        dev = kinv.device
-        g = g.reshape(1).to(torch.float32).contiguous()
-        g_ext = torch.empty(ext_shape, dtype=torch.float32, device=dev)
-        g_k = torch.empty(k_shape, dtype=torch.float32, device=dev)
-        with _guard(dev):
-            call("fm_track_loss_bwd", ptr(acc), ptr(acc2), ptr(scale), ptr(g), ptr(ext_inv), ptr(k), ptr(kinv), f, ptr(g_ext), ptr(g_k),
-                 stream_for(kinv))
-
-        frame0 = ctx.frame0
-
-        plan = ctx.plan
-
-        def scatter(buffer: Tensor) -> None:
-            if plan is None:
-                return
-            pixels, first, entries, weights = plan
-            with _guard(dev):  # the planned gather: no atomics (fm_track_scatter is the unplanned form)
-                call("fm_depth_gather", ptr(gws), ptr(pixels), ptr(first), ptr(entries), ptr(weights), pixels.numel(), ptr(kinv),
-                     ptr(scale), ptr(g), h, w, frame0, ptr(buffer), stream_for(buffer))
-
-        g_depth = None
-        if ctx.needs_input_grad[0]:
-            node = ctx.fit_node
-            ctx.fit_node = None
-            if node is not None:
-                node._fm_pending.append(scatter)  # lands in the buffer ProcrustesFit.backward returns
-            else:
-                g_depth = torch.zeros(depth_shape, dtype=torch.float32, device=dev)
-                scatter(g_depth)
-        need = ctx.needs_input_grad
-        return g_depth, g_k if need[1] else None, g_ext if need[2] else None, None, None, None, None, None, None, None, None
+            # the operator's gradients follow the `scale` tensor they find at backward time: overwrite it with the
+            # global normaliser and report the global value through the local node
+            total = reducer(totals)
+            den = torch.where(total[1] == 0, torch.ones_like(total[1]), total[1])  # `valid_sum or 1` (loss_tracking.py:61)
+            scale.copy_(torch.stack([float(weight) / den, total[1]]).to(torch.float32))
+            value = (float(weight) * total[0] / den).to(torch.float32)
+            loss = loss + (value - loss).detach()
+        return loss

@@ -56,6 +56,43 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
     return OUT
 
 
+TORCH_SRC = CSRC / "fm_torch.cpp"
+TORCH_OUT = HERE / "libflowmap_torch.so"
+
+
+def torch_binding_up_to_date() -> bool:
+    if not TORCH_OUT.exists():
+        return False
+    newest = max(p.stat().st_mtime for p in [TORCH_SRC, HERE.parent / "include" / "flowmap_hip.h"])
+    return TORCH_OUT.stat().st_mtime >= newest
+
+
+def build_torch_binding(force: bool = False, verbose: bool = True) -> Path:
+    """libflowmap_torch.so: the at::Tensor / autograd shims over the C ABI (csrc/fm_torch.cpp), registered with
+    TORCH_LIBRARY.  Host-only C++ against this torch's headers and HIP's (c10::hip stream / device guards):
+    include / library paths come from torch.utils.cpp_extension, the compiler is g++ (no device code, no hipify)."""
+    if not force and torch_binding_up_to_date():
+        return TORCH_OUT
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    rocm = ce.ROCM_HOME or "/opt/rocm"
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("g++ not found; a C++17 compiler is required to build the torch binding")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wall", "-Wno-unused-function", "-Wno-sign-compare"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + [f"-I{rocm}/include", str(TORCH_SRC), "-o", str(TORCH_OUT)]
+    for lib_dir in ce.library_paths():
+        cmd += [f"-L{lib_dir}", f"-Wl,-rpath,{lib_dir}"]
+    cmd += ["-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ldl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return TORCH_OUT
+
+
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv)
-    print(OUT)
+    build_torch_binding(force="--force" in sys.argv)
+    print(OUT, TORCH_OUT)

@@ -1,0 +1,979 @@
+// libflowmap_torch.so — the torch binding of the C ABI in include/flowmap_hip.h.
+//
+// The reference (dcharatan/flowmap) is pure Python: its hot path is autograd walking chains of
+// ATen ops.  Here the per-step operators of that path — IntrinsicsRegressed's K
+// (flowmap/model/intrinsics/common.py:6-20), align_surfaces + align_rigid + get_extrinsics
+// (flowmap/model/projection.py:187-252, flowmap/model/procrustes.py:7-51), LossFlow
+// (flowmap/loss/loss_flow.py:31-70), LossTracking (flowmap/loss/loss_tracking.py:28-61) and the Adam
+// update (flowmap/model/model_wrapper_overfit.py:104-105) — are C++ torch::autograd::Functions
+// registered with TORCH_LIBRARY under the namespace `flowmap_amd`: at::Tensor shims that check their
+// arguments (TORCH_CHECK -> RuntimeError), allocate outputs / workspaces with the caching allocator,
+// select the tensor's device and launch the hand-written HIP kernels through the C ABI on
+// c10::hip::getCurrentHIPStream().  No kernel lives here (this file is host-only C++, built with g++);
+// no state lives here either, beyond the table of C-ABI entry points: what one step hands from one
+// operator to the next (the shared dense dL/ddepth, the persistent dL/dweights storage) travels in
+// explicit objects (DepthSink, GradArena) that the Python layer creates and passes in.
+//
+// The C ABI is resolved with dlopen / dlsym so that the CPU test-suite can point the same binding at
+// tests/host_sim's serial build of the ABI (set_library); the product only ever loads libflowmap_hip.so.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <dlfcn.h>
+#include <torch/autograd.h>
+#include <torch/custom_class.h>
+#include <torch/library.h>
+
+#include <cmath>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/flowmap_hip.h"
+
+namespace fmt {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::Function;
+using torch::autograd::variable_list;
+using OptTensor = std::optional<Tensor>;
+
+// ------------------------------------------------------------------------------------------
+// The C ABI, resolved at run time
+// ------------------------------------------------------------------------------------------
+#define FM_API_LIST(X)                                                                                                                    \
+  X(fm_flow_loss_fused) X(fm_flow_loss_finalize) X(fm_scale_if_needed) X(fm_intrinsics_inverse) X(fm_intrinsics_inverse_bwd)              \
+  X(fm_focal_intrinsics_fwd) X(fm_focal_intrinsics_bwd) X(fm_pose_chain_fwd) X(fm_pose_chain_bwd) X(fm_relative_pose_fwd)                  \
+  X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_pose_solve_bwd) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense)                \
+  X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_points) X(fm_track_loss_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
+  X(fm_adam_step_capturable)
+
+struct Api {
+#define X(name) decltype(&::name) name = nullptr;
+  FM_API_LIST(X)
+#undef X
+  void* handle = nullptr;
+  bool test_double = false;
+  std::string path;
+};
+
+static Api& api_storage() {
+  static Api a;
+  return a;
+}
+static std::mutex& api_mutex() {
+  static std::mutex m;
+  return m;
+}
+
+static void set_library(const std::string& path, bool test_double) {
+  std::lock_guard<std::mutex> lock(api_mutex());
+  void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  TORCH_CHECK(h != nullptr, "flowmap_amd: cannot load ", path, ": ", dlerror(),
+              " — build it with `python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU or eager fallback");
+  Api a;
+  a.handle = h;
+  a.test_double = test_double;
+  a.path = path;
+#define X(name)                                                                    \
+  a.name = reinterpret_cast<decltype(&::name)>(dlsym(h, #name));                   \
+  TORCH_CHECK(a.name != nullptr, "flowmap_amd: ", path, " does not export ", #name);
+  FM_API_LIST(X)
+#undef X
+  api_storage() = a;
+}
+
+static const Api& api() {
+  const Api& a = api_storage();
+  TORCH_CHECK(a.handle != nullptr, "flowmap_amd: the native library is not loaded (flowmap_amd._lib loads it on import)");
+  return a;
+}
+
+static void fm_check(int status, const char* name) {
+  TORCH_CHECK(status == 0, "flowmap_amd: ", name, " failed: ", status == 1 ? "invalid argument" : "HIP launch/runtime failure");
+}
+#define FM_CALL(fn, ...) fm_check(api().fn(__VA_ARGS__), #fn)
+
+// ------------------------------------------------------------------------------------------
+// Small helpers
+// ------------------------------------------------------------------------------------------
+static Tensor f32c(const Tensor& t, const char* what) {
+  TORCH_CHECK(t.scalar_type() == at::kFloat, "flowmap_amd: ", what, " must be float32 (got ", t.scalar_type(), ")");
+  return t.contiguous();
+}
+
+static c10::Device check_device(std::initializer_list<const Tensor*> tensors) {
+  std::optional<c10::Device> dev;
+  for (const Tensor* t : tensors) {
+    if (t == nullptr || !t->defined()) continue;
+    if (!dev) dev = t->device();
+    else TORCH_CHECK(t->device() == *dev, "flowmap_amd: tensors on different devices (", *dev, " vs ", t->device(), ")");
+  }
+  TORCH_CHECK(dev.has_value(), "flowmap_amd: no tensor arguments");
+  const bool dbl = api().test_double;
+  TORCH_CHECK(dev->is_cuda() || dbl, "flowmap_amd: tensors are on ", *dev,
+              "; the HIP path needs a GPU (device 'cuda' on ROCm). There is no CPU fallback.");
+  TORCH_CHECK(!(dev->is_cuda() && dbl), "flowmap_amd: the host test double cannot take GPU tensors");
+  return *dev;
+}
+
+struct DeviceScope {  // select the tensors' GPU for the launches inside; no-op for the host double
+  std::optional<c10::hip::HIPGuard> guard;
+  void* stream = nullptr;
+  explicit DeviceScope(const c10::Device& dev) {
+    if (dev.is_cuda()) {
+      guard.emplace(dev);
+      stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
+    }
+  }
+};
+
+template <class T = float>
+static T* ptr(const Tensor& t) {
+  return t.defined() ? static_cast<T*>(t.data_ptr()) : nullptr;
+}
+template <class T = float>
+static T* ptr(const OptTensor& t) {
+  return (t.has_value() && t->defined()) ? static_cast<T*>(t->data_ptr()) : nullptr;
+}
+static Tensor opt(const OptTensor& t) { return t.has_value() ? *t : Tensor(); }
+
+static Tensor empty_like_shape(at::IntArrayRef shape, const Tensor& like, at::ScalarType dtype = at::kFloat) {
+  return at::empty(shape, like.options().dtype(dtype));
+}
+
+// ------------------------------------------------------------------------------------------
+// Objects one optimisation step hands between its operators
+// ------------------------------------------------------------------------------------------
+// DepthSink: the dense dL/ddepth of a step has three producers — the fused flow loss (every pixel),
+// the tracking loss and the Procrustes fit (sparse) — and autograd would sum three full-size
+// tensors (1.7 GB of traffic at C1).  The fit's node always runs after the two losses (they consume
+// its poses), so the losses park what they have here and the fit returns ONE buffer.  Created per
+// step by align_surfaces (Python), passed to the three operators explicitly; nothing global.
+struct DepthSink : torch::CustomClassHolder {
+  bool active = false;        // the fit node will run and return dL/ddepth for `depth`
+  const void* depth_ptr = nullptr;
+  int64_t depth_version = -1;
+  std::vector<int64_t> depth_sizes;
+  Tensor carried;                                         // dense gradient parked by the flow loss
+  std::vector<std::function<void(Tensor&)>> pending;      // sparse scatters into the final buffer (tracking loss)
+  // what the fit returned for this tensor, WEAKLY (a strong reference would make AccumulateGrad deep-copy the
+  // 553 MB gradient instead of adopting it): LeadingFrames adds its frames into it while autograd still holds it
+  using WeakImpl = c10::weak_intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl>;
+  std::optional<WeakImpl> final_buffer;
+  bool expect_leading = false;
+  void note_final(const Tensor& t) {
+    if (expect_leading && t.defined()) final_buffer.emplace(t.getIntrusivePtr());
+  }
+  Tensor take_final() {
+    Tensor t;
+    if (final_buffer.has_value() && !final_buffer->expired()) t = Tensor(final_buffer->lock());
+    final_buffer.reset();
+    return t;
+  }
+  const torch::autograd::Node* fit_node = nullptr;        // the fit's autograd node (identity only): a loss parks its gradient
+                                                          // only when its poses come from this node, i.e. the node WILL run later
+  int64_t leading_in_place = 0, leading_dense = 0, planned_steps = 0;  // which path ran (tests)
+
+  void arm(const Tensor& depth) {
+    active = true;
+    depth_ptr = depth.data_ptr();
+    depth_version = (int64_t)depth._version();
+    depth_sizes = depth.sizes().vec();
+  }
+  bool accepts(const Tensor& depth) const {
+    return active && depth.data_ptr() == depth_ptr && (int64_t)depth._version() == depth_version && depth.sizes().vec() == depth_sizes;
+  }
+};
+
+// GradArena: the dL/dweights of a sparse fit (P points per pair) is a dense (B,F-1,H,W) tensor that is
+// zero except at P·(F-1) slots — 549 MB of zeros written per step at C1.  The arena keeps ONE storage
+// across steps: zeroed once; every step the planned per-correspondence pass overwrites the same slots
+// (constant index set) and autograd is handed a fresh alias of the storage, which AccumulateGrad adopts
+// without a copy.  If a previous alias is still alive (gradient accumulation without zero_grad), or
+// somebody wrote into the gradient in place (version counter moved), the step falls back to fresh zeros.
+struct GradArena : torch::CustomClassHolder {
+  Tensor buffer;
+  const void* indices_ptr = nullptr;
+  int64_t indices_version = -1, version = -1;
+  int64_t reused = 0, refilled = 0;  // (tests)
+
+  // a tensor shaped like `like`, zero everywhere except (possibly) at the slots `indices` selects in every pair
+  Tensor acquire(const Tensor& like, const Tensor& indices) {
+    const bool same_layout = buffer.defined() && buffer.sizes() == like.sizes() && buffer.device() == like.device();
+    const bool same_slots = indices.data_ptr() == indices_ptr && (int64_t)indices._version() == indices_version;
+    const bool untouched = same_layout && (int64_t)buffer._version() == version && buffer.storage().use_count() == 1;
+    if (same_layout && same_slots && untouched) {
+      ++reused;
+    } else {
+      if (!(same_layout && buffer.storage().use_count() == 1)) buffer = at::empty_like(like);  // never write under a live alias
+      buffer.zero_();
+      ++refilled;
+    }
+    indices_ptr = indices.data_ptr();
+    indices_version = (int64_t)indices._version();
+    version = (int64_t)buffer._version();
+    return buffer;
+  }
+  Tensor alias() const { return buffer.alias(); }  // a new tensor over the same storage: autograd's to keep
+};
+
+// does the autograd graph above `from` contain `target` within `depth` hops?  (poses -> [chain ->] fit)
+static bool reaches(const std::shared_ptr<torch::autograd::Node>& from, const torch::autograd::Node* target, int depth) {
+  if (!from || target == nullptr) return false;
+  if (from.get() == target) return true;
+  if (depth == 0) return false;
+  for (const auto& edge : from->next_edges())
+    if (edge.function && reaches(edge.function, target, depth - 1)) return true;
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// Intrinsics
+// ------------------------------------------------------------------------------------------
+static Tensor intrinsics_inverse(const Tensor& k_in) {
+  const auto dev = check_device({&k_in});
+  TORCH_CHECK(k_in.dim() >= 2 && k_in.size(-1) == 3 && k_in.size(-2) == 3, "flowmap_amd: intrinsics must be (..., 3, 3)");
+  const Tensor k = f32c(k_in, "intrinsics");
+  Tensor out = at::empty_like(k);
+  DeviceScope scope(dev);
+  FM_CALL(fm_intrinsics_inverse, ptr(k), (int)(k.numel() / 9), ptr(out), scope.stream);
+  return out;
+}
+
+// focal_lengths_to_intrinsics spread over the frames (intrinsics/common.py:6-20 as used by
+// intrinsics_regressed.py:34-41): focal (*lead) -> K (*lead, *repeat_shape, 3, 3) in one launch that also
+// leaves K^-1 behind for the step's consumers; the backward is one reduction.
+struct FocalIntrinsics : public Function<FocalIntrinsics> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& focal_in, std::vector<int64_t> repeat_shape, int64_t h, int64_t w) {
+    const auto dev = check_device({&focal_in});
+    const Tensor focal = f32c(focal_in, "focal lengths");
+    int64_t repeat = 1;
+    for (auto d : repeat_shape) repeat *= d;
+    std::vector<int64_t> shape = focal.sizes().vec();
+    shape.insert(shape.end(), repeat_shape.begin(), repeat_shape.end());
+    shape.push_back(3);
+    shape.push_back(3);
+    Tensor k = empty_like_shape(shape, focal), kinv = empty_like_shape(shape, focal);
+    DeviceScope scope(dev);
+    FM_CALL(fm_focal_intrinsics_fwd, ptr(focal), (long)focal.numel(), (long)repeat, (int)h, (int)w, ptr(k), ptr(kinv), scope.stream);
+    ctx->saved_data["geometry"] = std::vector<int64_t>{focal.numel(), repeat, h, w};
+    ctx->saved_data["shape"] = focal.sizes().vec();
+    ctx->mark_non_differentiable({kinv});
+    return {k, kinv};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    if (!grads[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor()};
+    const auto geo = ctx->saved_data["geometry"].toIntVector();
+    const Tensor g_k = f32c(grads[0], "grad");
+    Tensor g_focal = empty_like_shape(ctx->saved_data["shape"].toIntVector(), g_k);
+    DeviceScope scope(g_k.device());
+    FM_CALL(fm_focal_intrinsics_bwd, ptr(g_k), (long)geo[0], (long)geo[1], (int)geo[2], (int)geo[3], ptr(g_focal), scope.stream);
+    return {g_focal, Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Pose plumbing
+// ------------------------------------------------------------------------------------------
+struct PoseChain : public Function<PoseChain> {  // get_extrinsics (projection.py:187-210)
+  static Tensor forward(AutogradContext* ctx, const Tensor& rel_in) {
+    const auto dev = check_device({&rel_in});
+    const Tensor rel = f32c(rel_in, "relative transformations");
+    TORCH_CHECK(rel.dim() >= 3 && rel.size(-1) == 4 && rel.size(-2) == 4, "flowmap_amd: relative transformations must be (..., steps, 4, 4)");
+    const int64_t steps = rel.size(-3);
+    const int64_t nb = steps > 0 ? rel.numel() / (steps * 16) : 1;
+    std::vector<int64_t> shape = rel.sizes().vec();
+    shape[shape.size() - 3] = steps + 1;
+    Tensor ext = empty_like_shape(shape, rel);
+    DeviceScope scope(dev);
+    FM_CALL(fm_pose_chain_fwd, ptr(rel), (int)nb, (int)steps, ptr(ext), scope.stream);
+    ctx->save_for_backward({rel, ext});
+    ctx->saved_data["dims"] = std::vector<int64_t>{nb, steps};
+    return ext;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    if (!grads[0].defined()) return {Tensor()};
+    const auto saved = ctx->get_saved_variables();
+    const auto dims = ctx->saved_data["dims"].toIntVector();
+    const Tensor g_ext = f32c(grads[0], "grad");
+    Tensor g_rel = at::empty_like(saved[0]);
+    DeviceScope scope(g_ext.device());
+    FM_CALL(fm_pose_chain_bwd, ptr(saved[0]), ptr(saved[1]), ptr(g_ext), (int)dims[0], (int)dims[1], ptr(g_rel), scope.stream);
+    return {g_rel};
+  }
+};
+
+// later(E).inverse() @ earlier(E) and earlier(E).inverse() @ later(E) (projection.py:154,176)
+struct RelativePoses : public Function<RelativePoses> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& ext_in) {
+    const auto dev = check_device({&ext_in});
+    const Tensor ext = f32c(ext_in, "extrinsics");
+    TORCH_CHECK(ext.dim() == 4 && ext.size(1) >= 2 && ext.size(2) == 4 && ext.size(3) == 4, "flowmap_amd: extrinsics must be (batch, frame >= 2, 4, 4)");
+    const int64_t b = ext.size(0), f = ext.size(1);
+    Tensor fwd = empty_like_shape({b, f - 1, 4, 4}, ext), bwd = empty_like_shape({b, f - 1, 4, 4}, ext);
+    DeviceScope scope(dev);
+    FM_CALL(fm_relative_pose_fwd, ptr(ext), (int)b, (int)f, ptr(fwd), ptr(bwd), scope.stream);
+    ctx->save_for_backward({ext});
+    return {fwd, bwd};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const Tensor ext = ctx->get_saved_variables()[0];
+    if (!grads[0].defined() && !grads[1].defined()) return {Tensor()};
+    const Tensor g_fwd = grads[0].defined() ? f32c(grads[0], "grad") : Tensor();
+    const Tensor g_bwd = grads[1].defined() ? f32c(grads[1], "grad") : Tensor();
+    Tensor g_ext = at::empty_like(ext);
+    DeviceScope scope(ext.device());
+    FM_CALL(fm_relative_pose_bwd, ptr(ext), ptr(g_fwd), ptr(g_bwd), (int)ext.size(0), (int)ext.size(1), ptr(g_ext), scope.stream);
+    return {g_ext};
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Procrustes fit of adjacent frames: align_surfaces up to (not including) the pose chain
+// (projection.py:213-249) with align_rigid (procrustes.py:7-51) inside.
+//   depth (B,F,H,W) + k, kinv (B·R,F,3,3)  [surfaces never materialised]   or   surfaces (B,F,H,W,3)
+//   weights (B,F-1,H,W)  (LOGITS when weight_sens != 0: w = sigmoid(weight_sens·logit), evaluated at the
+//   gathered points only — BackboneExplicitDepth fused into the gather; the gradient is then w.r.t. the logits)
+//   -> t_bwd (B·R,F-1,4,4) later -> earlier camera ("inverse relative transformations"), t_fwd its rigid inverse.
+// Backward plans (built by the Python layer from the constant flows / indices, or undefined):
+//   sparse: plan_pixels, plan_first, plan_vectors, plan_weights (fm_procrustes_scatter_plan, sorted) -> fm_depth_gather
+//   dense:  dense_first, dense_list (fm_procrustes_dense_plan) -> fm_procrustes_scatter_dense
+// ------------------------------------------------------------------------------------------
+struct ProcrustesFit : public Function<ProcrustesFit> {
+  // NB: needs_input_grad(i) indexes the i-th tensor argument that is PRESENT (an empty optional<Tensor> is not an
+  // autograd input; an undefined plain Tensor is not accepted at all), so the indices are worked out in forward.
+  static variable_list forward(AutogradContext* ctx, const OptTensor& depth_o, const OptTensor& k_o, const OptTensor& kinv_o,
+                               const OptTensor& surfaces_o, const Tensor& weights_in, const Tensor& bwd_flow_in, const OptTensor& indices_o,
+                               double weight_sens, int64_t rep, const c10::intrusive_ptr<DepthSink>& sink,
+                               const c10::intrusive_ptr<DepthSink>& wsink, const c10::intrusive_ptr<GradArena>& arena,
+                               const OptTensor& plan_pixels, const OptTensor& plan_first, const OptTensor& plan_vectors,
+                               const OptTensor& plan_weights, const OptTensor& dense_first, const OptTensor& dense_list,
+                               bool grad_enabled) {  // (forward runs with grad mode off: the caller's mode is passed in)
+    Tensor depth = opt(depth_o), k = opt(k_o), kinv = opt(kinv_o), surfaces = opt(surfaces_o), indices = opt(indices_o);
+    const bool from_depth = !surfaces.defined();
+    {  // edge index of depth / k / surfaces / weights among the present tensor arguments
+      int64_t at_depth = 0, at_k = depth.defined(), at_surf = at_k + k.defined() + kinv.defined(), at_w = at_surf + surfaces.defined();
+      ctx->saved_data["edges"] = std::vector<int64_t>{at_depth, at_k, at_surf, at_w};
+    }
+    const Tensor& src_in = from_depth ? depth : surfaces;
+    TORCH_CHECK(src_in.defined(), "flowmap_amd: the Procrustes fit needs depth + intrinsics or surfaces");
+    const auto dev = check_device({&src_in, &weights_in, &bwd_flow_in, &indices, &k, &kinv});
+    const Tensor weights = f32c(weights_in, "weights"), bwd_flow = f32c(bwd_flow_in, "backward flow");
+    TORCH_CHECK(!bwd_flow_in.requires_grad(), "flowmap_amd: gradients w.r.t. optical flow are not supported (flows are constants)");
+    TORCH_CHECK(rep >= 1, "flowmap_amd: batch_repeat must be >= 1");
+    int64_t bd, f, h, w, b;
+    if (from_depth) {
+      depth = f32c(depth, "depth");
+      TORCH_CHECK(depth.dim() == 4, "flowmap_amd: depth must be (batch, frame, height, width)");
+      bd = depth.size(0), f = depth.size(1), h = depth.size(2), w = depth.size(3);
+      b = bd * rep;  // pose / intrinsics batch: every image-batch entry serves `rep` candidates
+      TORCH_CHECK(k.defined() && kinv.defined(), "flowmap_amd: depth-sourced surfaces need intrinsics and their inverse");
+      k = f32c(k, "intrinsics");
+      kinv = f32c(kinv, "inverse intrinsics");
+      TORCH_CHECK(k.sizes() == at::IntArrayRef({b, f, 3, 3}) && kinv.sizes() == k.sizes(),
+                  "flowmap_amd: intrinsics shape does not match depth (x batch_repeat)");
+    } else {
+      TORCH_CHECK(rep == 1, "flowmap_amd: batch_repeat needs depth-sourced surfaces");
+      surfaces = f32c(surfaces, "surfaces");
+      TORCH_CHECK(surfaces.dim() == 5 && surfaces.size(4) == 3, "flowmap_amd: surfaces must be (batch, frame, height, width, 3)");
+      bd = surfaces.size(0), f = surfaces.size(1), h = surfaces.size(2), w = surfaces.size(3);
+      b = bd;
+    }
+    TORCH_CHECK(f >= 2, "flowmap_amd: at least two frames are needed");
+    TORCH_CHECK(weights.sizes() == at::IntArrayRef({bd, f - 1, h, w}) && bwd_flow.sizes() == at::IntArrayRef({bd, f - 1, h, w, 2}),
+                "flowmap_amd: weights/backward-flow shapes do not match the surfaces");
+    int64_t points = h * w;
+    if (indices.defined()) {
+      TORCH_CHECK(indices.scalar_type() == at::kLong, "flowmap_amd: indices must be int64");
+      indices = indices.contiguous();
+      points = indices.numel();
+    }
+    const int64_t pairs = b * (f - 1);
+    Tensor stats = at::empty({pairs, FM_STAT_STRIDE}, weights.options().dtype(at::kDouble));
+    Tensor aux = at::empty({pairs, FM_AUX_STRIDE}, weights.options().dtype(at::kDouble));
+    Tensor t_bwd = empty_like_shape({b, f - 1, 4, 4}, weights), t_fwd = empty_like_shape({b, f - 1, 4, 4}, weights);
+    {
+      DeviceScope scope(dev);
+      FM_CALL(fm_procrustes_fit, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights), (float)weight_sens,
+              ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(stats), ptr(t_bwd), ptr(t_fwd),
+              ptr<double>(aux), scope.stream);
+    }
+    ctx->save_for_backward({from_depth ? depth : surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux, opt(plan_pixels), opt(plan_first),
+                            opt(plan_vectors), opt(plan_weights), opt(dense_first), opt(dense_list)});
+    ctx->saved_data["dims"] = std::vector<int64_t>{b, f, h, w, points, rep, from_depth ? 1 : 0};
+    ctx->saved_data["weight_sens"] = weight_sens;
+    if (sink) ctx->saved_data["sink"] = sink;
+    if (wsink) ctx->saved_data["wsink"] = wsink;
+    if (arena) ctx->saved_data["arena"] = arena;
+    if (wsink && grad_enabled && weights_in.requires_grad()) {  // identity of the weights tensor LeadingFrames was given
+      wsink->depth_ptr = weights_in.data_ptr();
+      wsink->depth_version = (int64_t)weights_in._version();
+    }
+    if (sink && from_depth && rep == 1 && depth.requires_grad() && grad_enabled) sink->arm(depth);
+    return {t_bwd, t_fwd};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &src = saved[0], &kinv = saved[1], &weights = saved[2], &bwd_flow = saved[3], &indices = saved[4], &t_bwd = saved[5],
+                 &aux = saved[6];
+    const Tensor &plan_pixels = saved[7], &plan_first = saved[8], &plan_vectors = saved[9], &plan_weights = saved[10],
+                 &dense_first = saved[11], &dense_list = saved[12];
+    const auto dims = ctx->saved_data["dims"].toIntVector();
+    const int64_t b = dims[0], f = dims[1], h = dims[2], w = dims[3], points = dims[4], rep = dims[5];
+    const bool from_depth = dims[6] != 0;
+    const float sens = (float)ctx->saved_data["weight_sens"].toDouble();
+    auto sink = ctx->saved_data.count("sink") ? ctx->saved_data["sink"].toCustomClass<DepthSink>() : c10::intrusive_ptr<DepthSink>();
+    auto arena = ctx->saved_data.count("arena") ? ctx->saved_data["arena"].toCustomClass<GradArena>() : c10::intrusive_ptr<GradArena>();
+    auto wsink = ctx->saved_data.count("wsink") ? ctx->saved_data["wsink"].toCustomClass<DepthSink>() : c10::intrusive_ptr<DepthSink>();
+    const int64_t pairs = b * (f - 1);
+    const auto dev = weights.device();
+    const Tensor g_t = grads[0].defined() ? f32c(grads[0], "grad") : Tensor();
+    const Tensor g_t_fwd = grads[1].defined() ? f32c(grads[1], "grad") : Tensor();
+    const auto edges = ctx->saved_data["edges"].toIntVector();  // depth, k, surfaces, weights
+    const bool need_src = ctx->needs_input_grad(from_depth ? edges[0] : edges[2]);
+    const bool need_k = from_depth && ctx->needs_input_grad(edges[1]);
+    const bool need_w = ctx->needs_input_grad(edges[3]);
+    Tensor pair_grad = at::empty({pairs, FM_PAIR_GRAD_STRIDE}, weights.options().dtype(at::kDouble));
+    Tensor g_src, g_k, g_w;
+
+    // The dense dL/ddepth: what the losses parked (the sink is armed only for depth-sourced, un-repeated fits)
+    Tensor carried;
+    std::vector<std::function<void(Tensor&)>> pending;
+    if (sink) {
+      carried = std::move(sink->carried);
+      sink->carried = Tensor();
+      pending.swap(sink->pending);
+      sink->active = false;
+    }
+    if (need_src) {
+      g_src = carried.defined() ? carried : at::zeros_like(src);
+      for (auto& scatter : pending) scatter(g_src);
+    }
+    const bool dense = from_depth && !indices.defined() && rep == 1 && h <= 65535 && w <= 65535 && (!need_src || dense_first.defined());
+    const bool planned = from_depth && indices.defined() && rep == 1 && plan_pixels.defined();
+    bool arena_used = false;
+    if (need_w) {
+      if (dense) g_w = at::empty_like(weights);  // every element stored exactly once
+      else if (planned && arena && g_src.defined()) {  // (the planned pass STORES dL/dweights at its slots)
+        g_w = arena->acquire(weights, indices);         // zero except at the slots this very pass overwrites
+        arena_used = true;
+      } else g_w = at::zeros_like(weights);
+    }
+    Tensor kinv_acc = need_k ? at::empty({b * f, 9}, weights.options().dtype(at::kDouble)) : Tensor();  // zeroed by fm_pose_solve_bwd
+    Tensor point_grads = (planned && g_src.defined()) ? at::empty({pairs * points, 2, 3}, weights.options()) : Tensor();
+    {
+      DeviceScope scope(dev);
+      FM_CALL(fm_pose_solve_bwd, ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr<double>(aux), (int)pairs, ptr<double>(pair_grad), ptr<double>(kinv_acc),
+              kinv_acc.defined() ? (long)kinv_acc.numel() : 0L, scope.stream);
+      if (dense) {  // every pixel a correspondence: tiled, planned, no atomics
+        Tensor consts = at::empty({pairs, FM_DENSE_CONST_STRIDE}, weights.options().dtype(at::kDouble));
+        FM_CALL(fm_procrustes_scatter_dense, ptr(src), ptr(kinv), ptr(bwd_flow), ptr(weights), sens, (int)b, (int)f, (int)h, (int)w,
+                ptr<double>(aux), ptr<double>(pair_grad), ptr(g_src), ptr(g_w), ptr<double>(kinv_acc), ptr<int64_t>(dense_first),
+                ptr<uint32_t>(dense_list), ptr<double>(consts), scope.stream);
+      } else {
+        FM_CALL(fm_procrustes_scatter, from_depth ? ptr(src) : nullptr, ptr(kinv), from_depth ? nullptr : ptr(src), ptr(bwd_flow), ptr(weights),
+                sens, ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(aux), ptr<double>(pair_grad),
+                from_depth ? ptr(g_src) : nullptr, from_depth ? nullptr : ptr(g_src), ptr(g_w), ptr<double>(kinv_acc), ptr(point_grads),
+                nullptr, scope.stream);
+        if (point_grads.defined()) {  // the planned scatter runs as a gather: one plain read-modify-write per touched pixel
+          FM_CALL(fm_depth_gather, ptr(point_grads), ptr<int64_t>(plan_pixels), ptr<int32_t>(plan_first), ptr<int32_t>(plan_vectors),
+                  ptr(plan_weights), (long)plan_pixels.numel(), ptr(kinv), nullptr, nullptr, (int)h, (int)w, 0L, ptr(g_src), scope.stream);
+          if (sink) ++sink->planned_steps;
+        }
+      }
+      if (need_k) {
+        g_k = at::empty_like(kinv);
+        FM_CALL(fm_intrinsics_inverse_bwd, ptr<double>(kinv_acc), ptr(kinv), (int)(b * f), ptr(g_k), 0, scope.stream);
+      }
+    }
+    if (arena_used) g_w = arena->alias();
+    if (sink) sink->note_final(g_src);
+    if (wsink) wsink->note_final(g_w);
+    variable_list out(19);
+    if (from_depth) {
+      out[0] = g_src;
+      out[1] = g_k;
+    } else {
+      out[3] = g_src;
+    }
+    out[4] = g_w;
+    return out;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Fused flow loss: weight · LossFlow.compute_unweighted_loss (loss_flow.py:31-70, loss.py:47) from depth +
+// intrinsics + relative poses, with the analytic gradient of every input produced in the same HBM pass.
+// The gradients are computed in forward (one pass over 4.4 GB at C1) and handed out by backward; a second
+// backward through a retained graph recomputes them (one more launch) from the saved inputs.
+// ------------------------------------------------------------------------------------------
+static std::mutex& timing_mutex() {
+  static std::mutex m;
+  return m;
+}
+struct FlowTimings {
+  bool enabled = false;
+  std::vector<std::pair<void*, void*>> events;        // hipEvent_t pairs around every fused flow kernel launch
+  std::vector<std::pair<void*, void*>> track_events;  // ... and around every fm_track_loss_fwd (track_pairs + its reduction)
+  void* (*create)() = nullptr;
+  void (*record)(void*, void*) = nullptr;
+  float (*elapsed)(void*, void*) = nullptr;
+};
+static FlowTimings& flow_timings() {
+  static FlowTimings t;
+  return t;
+}
+
+struct FlowLaunch {
+  Tensor loss, g_depth, small, g_tf, g_tb, g_k;
+};
+
+static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& t_fwd, const Tensor& t_bwd,
+                              const Tensor& flow_fwd, const Tensor& flow_bwd, const Tensor& mask_fwd, const Tensor& mask_bwd, const Tensor& norm,
+                              const Tensor& packed, int64_t kind, double delta, int64_t items, bool need, bool need_depth) {
+  const int64_t b = depth.size(0), f = depth.size(1), h = depth.size(2), w = depth.size(3);
+  const auto dev = depth.device();
+  FlowLaunch o;
+  Tensor acc = at::empty({b * f * 2 * FM_FLOW_ACC_STRIDE}, depth.options().dtype(at::kDouble));
+  o.loss = at::empty({1}, depth.options());
+  if (need && need_depth) o.g_depth = at::empty_like(depth);
+  // the three small gradients share one allocation so one launch rescales them in backward
+  o.small = at::empty({2 * t_fwd.numel() + k.numel()}, depth.options());
+  o.g_tf = o.small.narrow(0, 0, t_fwd.numel()).view_as(t_fwd);
+  o.g_tb = o.small.narrow(0, t_fwd.numel(), t_fwd.numel()).view_as(t_bwd);
+  o.g_k = o.small.narrow(0, 2 * t_fwd.numel(), k.numel()).view_as(k);
+  const float scale = std::sqrt((float)(h * w));
+  DeviceScope scope(dev);
+  FlowTimings& tm = flow_timings();
+  void *e0 = nullptr, *e1 = nullptr;
+  if (tm.enabled && dev.is_cuda() && tm.create) {
+    e0 = tm.create();
+    e1 = tm.create();
+    tm.record(e0, scope.stream);
+  }
+  FM_CALL(fm_flow_loss_fused, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd),
+          ptr(packed), need ? ptr(norm) : nullptr, (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
+          ptr(o.g_depth), ptr<double>(acc), (int)items, scope.stream);
+  if (e0) {
+    tm.record(e1, scope.stream);
+    std::lock_guard<std::mutex> lock(timing_mutex());
+    tm.events.emplace_back(e0, e1);
+  }
+  FM_CALL(fm_flow_loss_finalize, ptr<double>(acc), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(norm), (int)b, (int)f, (float)w / scale,
+          (float)h / scale, ptr(o.loss), ptr(o.g_tf), ptr(o.g_tb), ptr(o.g_k), scope.stream);
+  return o;
+}
+
+struct FlowLossFused : public Function<FlowLossFused> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& depth_in, const Tensor& k_in, const Tensor& kinv_in, const Tensor& t_fwd_in,
+                        const Tensor& t_bwd_in, const Tensor& flow_fwd_in, const Tensor& flow_bwd_in, const Tensor& mask_fwd_in,
+                        const Tensor& mask_bwd_in, const Tensor& norm, const OptTensor& packed_o, int64_t kind, double delta,
+                        const c10::intrusive_ptr<DepthSink>& sink, int64_t items, bool grad_enabled, bool park) {
+    check_device({&depth_in, &k_in, &kinv_in, &t_fwd_in, &t_bwd_in, &flow_fwd_in, &flow_bwd_in, &mask_fwd_in, &mask_bwd_in, &norm});
+    const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics");
+    const Tensor t_fwd = f32c(t_fwd_in, "forward poses"), t_bwd = f32c(t_bwd_in, "backward poses");
+    const Tensor flow_fwd = f32c(flow_fwd_in, "forward flow"), flow_bwd = f32c(flow_bwd_in, "backward flow");
+    const Tensor mask_fwd = f32c(mask_fwd_in, "forward mask"), mask_bwd = f32c(mask_bwd_in, "backward mask");
+    TORCH_CHECK(depth.dim() == 4, "flowmap_amd: depth must be (batch, frame, height, width)");
+    const int64_t b = depth.size(0), f = depth.size(1), h = depth.size(2), w = depth.size(3);
+    TORCH_CHECK(flow_fwd.sizes() == at::IntArrayRef({b, f - 1, h, w, 2}) && flow_bwd.sizes() == flow_fwd.sizes(),
+                "flowmap_amd: flow shape does not match depth");
+    TORCH_CHECK(mask_fwd.sizes() == at::IntArrayRef({b, f - 1, h, w}) && mask_bwd.sizes() == mask_fwd.sizes(),
+                "flowmap_amd: mask shape does not match depth");
+    TORCH_CHECK(k.sizes() == at::IntArrayRef({b, f, 3, 3}) && kinv.sizes() == k.sizes() && t_fwd.sizes() == at::IntArrayRef({b, f - 1, 4, 4}) &&
+                    t_bwd.sizes() == t_fwd.sizes(),
+                "flowmap_amd: intrinsics / pose shapes do not match depth");
+    TORCH_CHECK(norm.scalar_type() == at::kFloat && norm.numel() >= 1, "flowmap_amd: the normaliser must be a float32 device tensor");
+    TORCH_CHECK(!flow_fwd_in.requires_grad() && !flow_bwd_in.requires_grad(), "flowmap_amd: gradients w.r.t. optical flow are not supported (flows are constants)");
+    Tensor packed = opt(packed_o);
+    if (packed.defined())
+      TORCH_CHECK(packed.scalar_type() == at::kFloat && packed.is_contiguous() && w % 4 == 0 &&
+                      packed.sizes() == at::IntArrayRef({b * f, (h * w / 4 + 63) / 64, 6, 64, 4}),
+                  "flowmap_amd: packed flow inputs do not match the depth shape");
+    const bool need = grad_enabled && (depth_in.requires_grad() || k_in.requires_grad() || t_fwd_in.requires_grad() || t_bwd_in.requires_grad());
+    FlowLaunch run = flow_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, items, need,
+                                 depth_in.requires_grad());
+    ctx->save_for_backward({depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed});
+    ctx->saved_data["cfg"] = std::vector<int64_t>{kind, items};
+    ctx->saved_data["delta"] = delta;
+    if (sink && park) ctx->saved_data["sink"] = sink;
+    ctx->saved_data["g_depth"] = run.g_depth;
+    ctx->saved_data["small"] = run.small;
+    ctx->saved_data["fresh"] = need;
+    return run.loss.reshape({});
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    variable_list out(17);
+    if (!grads[0].defined()) return out;
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &depth = saved[0], &k = saved[1], &t_fwd = saved[3];
+    Tensor g_depth, small;
+    if (ctx->saved_data["fresh"].toBool()) {
+      if (ctx->saved_data["g_depth"].isTensor()) g_depth = ctx->saved_data["g_depth"].toTensor();
+      small = ctx->saved_data["small"].toTensor();
+      ctx->saved_data["fresh"] = false;  // the buffers are scaled in place below and belong to autograd afterwards
+      ctx->saved_data["g_depth"] = Tensor();
+      ctx->saved_data["small"] = Tensor();
+    } else {  // a second backward through a retained graph: one more pass from the saved inputs
+      const auto cfg = ctx->saved_data["cfg"].toIntVector();
+      FlowLaunch run = flow_launch(saved[0], saved[1], saved[2], saved[3], saved[4], saved[5], saved[6], saved[7], saved[8], saved[9], saved[10],
+                                   cfg[0], ctx->saved_data["delta"].toDouble(), cfg[1], true, ctx->needs_input_grad(0));
+      g_depth = run.g_depth;
+      small = run.small;
+    }
+    TORCH_CHECK(small.defined(), "flowmap_amd: the flow loss was evaluated without gradients (no input required grad)");
+    const Tensor g = grads[0].reshape({1}).to(at::kFloat).contiguous();
+    {
+      DeviceScope scope(g.device());
+      FM_CALL(fm_scale_if_needed, ptr(g_depth), g_depth.defined() ? (long)g_depth.numel() : 0L, ptr(small), (long)small.numel(), ptr(g),
+              scope.stream);
+    }
+    auto sink = ctx->saved_data.count("sink") ? ctx->saved_data["sink"].toCustomClass<DepthSink>() : c10::intrusive_ptr<DepthSink>();
+    if (sink && g_depth.defined() && sink->accepts(depth) && !sink->carried.defined()) {
+      sink->carried = g_depth;  // returned (summed with the sparse parts) by the Procrustes fit's node, which runs later
+      g_depth = Tensor();
+    }
+    const int64_t nt = t_fwd.numel();
+    if (ctx->needs_input_grad(0)) out[0] = g_depth;
+    if (ctx->needs_input_grad(1)) out[1] = small.narrow(0, 2 * nt, k.numel()).view_as(k);
+    if (ctx->needs_input_grad(3)) out[3] = small.narrow(0, 0, nt).view_as(t_fwd);
+    if (ctx->needs_input_grad(4)) out[4] = small.narrow(0, nt, nt).view_as(t_fwd);
+    return out;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Fused tracking loss: weight · LossTracking.compute_unweighted_loss (loss_tracking.py:28-61, loss.py:47) over
+// all segments, from depth + intrinsics + extrinsics.  The track arrays are the packed form the Python layer
+// builds once per track set (PackedTracks); `depth` may be a window of the video starting at frame0 (frame
+// sharding) while k / ext cover the whole video.  Outputs: loss (differentiable), scale = [weight/max(count,1),
+// count] and totals = [Σρ, count] (fp64) — a sharded caller all-reduces totals and overwrites `scale` in place
+// before backward; the gradients follow the scale they find.
+// ------------------------------------------------------------------------------------------
+struct TrackArrays {
+  Tensor xy, vis, seg, blocks, tiles;
+  int64_t nblocks, ntiles, pmax, fmax, total, partial;
+};
+
+struct TrackLossFused : public Function<TrackLossFused> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& depth_in, const Tensor& k_in, const Tensor& kinv_in, const Tensor& ext_in,
+                               const Tensor& xy, const Tensor& vis, const Tensor& seg, const Tensor& blocks, const Tensor& tiles,
+                               std::vector<int64_t> counts, double weight, int64_t kind, double delta,
+                               const c10::intrusive_ptr<DepthSink>& sink, int64_t frame0, const OptTensor& plan_pixels,
+                               const OptTensor& plan_first, const OptTensor& plan_entries, const OptTensor& plan_weights, bool grad_enabled,
+                               bool park) {
+    const auto dev = check_device({&depth_in, &k_in, &kinv_in, &ext_in, &xy});
+    const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics"),
+                 ext = f32c(ext_in, "extrinsics");
+    TORCH_CHECK(counts.size() == 7, "flowmap_amd: packed track counts");
+    const int64_t nblocks = counts[0], ntiles = counts[1], pmax = counts[2], fmax = counts[3], total = counts[4], partial = counts[5],
+                  last_frame = counts[6];
+    TORCH_CHECK(depth.dim() == 4 && depth.size(0) == 1, "flowmap_amd: the fused tracking loss supports batch size 1 (as the reference asserts)");
+    const int64_t f_local = depth.size(1), h = depth.size(2), w = depth.size(3), f = ext.size(1);
+    TORCH_CHECK(k.sizes() == at::IntArrayRef({1, f, 3, 3}) && kinv.sizes() == k.sizes() && ext.sizes() == at::IntArrayRef({1, f, 4, 4}) &&
+                    frame0 >= 0 && frame0 + f_local <= f,
+                "flowmap_amd: intrinsics / extrinsics must cover the whole video and depth a window of it");
+    TORCH_CHECK(last_frame <= f, "flowmap_amd: a track segment extends past the last frame");
+    const auto fopt = depth.options();
+    Tensor ext_inv = at::empty_like(ext);
+    Tensor ws = at::empty({total, 9}, fopt);
+    Tensor flag = partial ? at::zeros({total}, fopt.dtype(at::kByte)) : at::empty({total}, fopt.dtype(at::kByte));
+    Tensor acc = at::empty({f * 20}, fopt.dtype(at::kDouble));
+    Tensor loss = at::empty({1}, fopt), scale = at::empty({2}, fopt), totals = at::empty({2}, fopt.dtype(at::kDouble));
+    const bool need = (depth_in.requires_grad() || k_in.requires_grad() || ext_in.requires_grad()) && grad_enabled;
+    // every residual is evaluated once: the (unscaled) gradients come out of the same launch
+    Tensor gws = need ? at::empty({total, 3}, fopt) : Tensor();
+    Tensor acc2 = need ? at::empty({f * 24}, fopt.dtype(at::kDouble)) : Tensor();
+    Tensor tgt = at::empty({f, 12}, fopt);
+    Tensor part = at::empty({std::max<int64_t>(ntiles, 1) * ((pmax + 63) / 64) * (fmax * 14 + FM_TRACK_TILE * 21)}, fopt);
+    const float sc = std::sqrt((float)(h * w));
+    {
+      DeviceScope scope(dev);
+      FM_CALL(fm_extrinsics_inverse, ptr(ext), (int)f, ptr(ext_inv), scope.stream);
+      if (ntiles > 0) {
+        FM_CALL(fm_track_points, ptr(depth), (int)frame0, ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), (int)f, ptr(xy), ptr<uint8_t>(vis),
+                ptr<int32_t>(seg), ptr<int32_t>(blocks), (int)nblocks, (int)pmax, (int)h, (int)w, ptr(ws), ptr<uint8_t>(flag), ptr(tgt),
+                scope.stream);
+        FlowTimings& tm = flow_timings();
+        void *e0 = nullptr, *e1 = nullptr;
+        if (tm.enabled && dev.is_cuda() && tm.create) {
+          e0 = tm.create();
+          e1 = tm.create();
+          tm.record(e0, scope.stream);
+        }
+        FM_CALL(fm_track_loss_fwd, ptr(ws), ptr<uint8_t>(flag), ptr(xy), ptr<uint8_t>(vis), ptr<int32_t>(seg), ptr<int32_t>(tiles), (int)ntiles,
+                (int)pmax, (int)fmax, ptr(ext), ptr(tgt), (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / sc, (float)h / sc,
+                (float)weight, ptr(part), ptr<double>(acc), ptr(loss), ptr(scale), ptr<double>(totals), ptr(gws), ptr<double>(acc2), scope.stream);
+        if (e0) {
+          tm.record(e1, scope.stream);
+          std::lock_guard<std::mutex> lock(timing_mutex());
+          tm.track_events.emplace_back(e0, e1);
+        }
+      }
+    }
+    if (ntiles == 0) {  // this rank owns no source frame of any segment
+      acc.zero_();
+      totals.zero_();
+      loss.zero_();
+      scale.zero_();
+      scale.narrow(0, 0, 1).fill_(weight);
+      if (need) acc2.zero_();
+    }
+    // (`scale` is deliberately NOT a version-checked saved tensor: a sharded caller overwrites it with the global normaliser)
+    ctx->save_for_backward({k, kinv, ext_inv, acc, opt(plan_pixels), opt(plan_first), opt(plan_entries), opt(plan_weights), depth});
+    ctx->saved_data["scale"] = scale;
+    ctx->saved_data["gws"] = gws;
+    ctx->saved_data["acc2"] = acc2;
+    ctx->saved_data["dims"] = std::vector<int64_t>{f, h, w, frame0};
+    if (sink && park) ctx->saved_data["sink"] = sink;
+    ctx->mark_non_differentiable({scale, totals});
+    return {loss.reshape({}), scale, totals};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    variable_list out(21);
+    if (!grads[0].defined()) return out;
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &k = saved[0], &kinv = saved[1], &ext_inv = saved[2], &acc = saved[3];
+    const Tensor scale = ctx->saved_data["scale"].toTensor();
+    const Tensor &plan_pixels = saved[4], &plan_first = saved[5], &plan_entries = saved[6], &plan_weights = saved[7], &depth = saved[8];
+    const Tensor gws = ctx->saved_data["gws"].toTensor(), acc2 = ctx->saved_data["acc2"].toTensor();
+    TORCH_CHECK(gws.defined(), "flowmap_amd: the tracking loss was evaluated without gradients (no input required grad)");
+    const auto dims = ctx->saved_data["dims"].toIntVector();
+    const int64_t f = dims[0], h = dims[1], w = dims[2], frame0 = dims[3];
+    const auto dev = kinv.device();
+    const Tensor g = grads[0].reshape({1}).to(at::kFloat).contiguous();
+    Tensor g_ext = at::empty({1, f, 4, 4}, kinv.options()), g_k = at::empty_like(k);
+    {
+      DeviceScope scope(dev);
+      FM_CALL(fm_track_loss_bwd, ptr<double>(acc), ptr<double>(acc2), ptr(scale), ptr(g), ptr(ext_inv), ptr(k), ptr(kinv), (int)f, ptr(g_ext),
+              ptr(g_k), scope.stream);
+    }
+    // the depth part: a planned gather over the touched pixels (no atomics; gws / scale stay untouched, so a second
+    // backward through a retained graph repeats it)
+    auto scatter = [=](Tensor& buffer) {
+      if (!plan_pixels.defined()) return;
+      DeviceScope scope(dev);
+      FM_CALL(fm_depth_gather, ptr(gws), ptr<int64_t>(plan_pixels), ptr<int32_t>(plan_first), ptr<int32_t>(plan_entries), ptr(plan_weights),
+              (long)plan_pixels.numel(), ptr(kinv), ptr(scale), ptr(g), (int)h, (int)w, (long)frame0, ptr(buffer), scope.stream);
+    };
+    if (ctx->needs_input_grad(0)) {
+      auto sink = ctx->saved_data.count("sink") ? ctx->saved_data["sink"].toCustomClass<DepthSink>() : c10::intrusive_ptr<DepthSink>();
+      if (sink && sink->accepts(depth)) {
+        sink->pending.push_back(scatter);  // lands in the buffer the Procrustes fit's node returns
+      } else {
+        Tensor g_depth = at::zeros_like(depth);
+        scatter(g_depth);
+        out[0] = g_depth;
+      }
+    }
+    if (ctx->needs_input_grad(1)) out[1] = g_k;
+    if (ctx->needs_input_grad(3)) out[3] = g_ext;
+    return out;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// LeadingFrames: x[:, :count].contiguous() for (b, F, H, W) image stacks.  The softmin sweep reads two of the
+// 150 depth frames; autograd's slice backward would zero-fill a full-size tensor and add it densely to the main
+// path's gradient (1.7 GB of traffic at C1).  Autograd runs this node's backward AFTER the nodes that consume
+// the intrinsics it helped to produce, so when the step's DepthSink says the fit has already returned the dense
+// gradient of `x`, the `count` frames are added into that buffer and nothing is returned.
+// ------------------------------------------------------------------------------------------
+struct LeadingFrames : public Function<LeadingFrames> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, int64_t count, const c10::intrusive_ptr<DepthSink>& sink) {
+    TORCH_CHECK(x.dim() == 4 && count >= 1 && count <= x.size(1), "flowmap_amd: LeadingFrames expects (batch, frame, height, width) and 1 <= count <= frame");
+    ctx->saved_data["shape"] = x.sizes().vec();
+    ctx->saved_data["count"] = count;
+    if (sink) ctx->saved_data["sink"] = sink;
+    ctx->saved_data["ident"] = std::vector<int64_t>{(int64_t)(uintptr_t)x.data_ptr(), (int64_t)x._version()};
+    if (sink) sink->expect_leading = true;
+    return x.narrow(1, 0, count).contiguous();
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    if (!grads[0].defined()) return {Tensor(), Tensor(), Tensor()};
+    const auto shape = ctx->saved_data["shape"].toIntVector();
+    const int64_t count = ctx->saved_data["count"].toInt();
+    const auto ident = ctx->saved_data["ident"].toIntVector();
+    auto sink = ctx->saved_data.count("sink") ? ctx->saved_data["sink"].toCustomClass<DepthSink>() : c10::intrusive_ptr<DepthSink>();
+    const Tensor& g = grads[0];
+    Tensor buffer = sink ? sink->take_final() : Tensor();
+    if (buffer.defined() && (int64_t)(uintptr_t)sink->depth_ptr == ident[0] && sink->depth_version == ident[1] && buffer.sizes().vec() == shape &&
+        buffer.scalar_type() == g.scalar_type() && buffer.device() == g.device()) {
+      buffer.narrow(1, 0, count).add_(g);
+      ++sink->leading_in_place;
+      return {Tensor(), Tensor(), Tensor()};
+    }
+    if (sink) ++sink->leading_dense;
+    if (count == shape[1]) return {g, Tensor(), Tensor()};
+    Tensor full = at::zeros(shape, g.options());
+    full.narrow(1, 0, count).copy_(g);
+    return {full, Tensor(), Tensor()};
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Adam (model_wrapper_overfit.py:104-105), in place; the version counters are bumped as an in-place ATen op would
+// ------------------------------------------------------------------------------------------
+static void adam_step(Tensor p, const Tensor& grad_in, Tensor m, Tensor v, int64_t step, const OptTensor& step_tensor, double lr, double beta1,
+                      double beta2, double eps, double weight_decay) {
+  const auto dev = check_device({&p, &grad_in, &m, &v});
+  TORCH_CHECK(p.scalar_type() == at::kFloat && grad_in.scalar_type() == at::kFloat, "flowmap_amd.FusedAdam: parameters and gradients must be float32");
+  TORCH_CHECK(p.is_contiguous() && m.is_contiguous() && v.is_contiguous(), "flowmap_amd.FusedAdam: parameters must be contiguous");
+  const Tensor grad = grad_in.contiguous();
+  DeviceScope scope(dev);
+  if (step_tensor.has_value() && step_tensor->defined()) {
+    TORCH_CHECK(step_tensor->device() == p.device(), "flowmap_amd.FusedAdam: capturable=True needs the step counter on the parameter's device");
+    FM_CALL(fm_adam_step_capturable, ptr(p), ptr(grad), ptr(m), ptr(v), (long)p.numel(), ptr(*step_tensor), lr, beta1, beta2, eps, weight_decay,
+            scope.stream);
+  } else {
+    FM_CALL(fm_adam_step, ptr(p), ptr(grad), ptr(m), ptr(v), (long)p.numel(), (long)step, lr, beta1, beta2, eps, weight_decay, scope.stream);
+  }
+  p.unsafeGetTensorImpl()->bump_version();
+  m.unsafeGetTensorImpl()->bump_version();
+  v.unsafeGetTensorImpl()->bump_version();
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel timing for bench.py: hipEvents recorded on the launch stream around every fused flow kernel
+// ------------------------------------------------------------------------------------------
+static void flow_timing_enable(bool on) {
+  FlowTimings& tm = flow_timings();
+  std::lock_guard<std::mutex> lock(timing_mutex());
+  if (on && tm.create == nullptr) {
+    // the HIP runtime is already in the process (torch links it); resolve the three calls we need
+    using CreateFn = int (*)(void**);
+    using RecordFn = int (*)(void*, void*);
+    using ElapsedFn = int (*)(float*, void*, void*);
+    static CreateFn create = reinterpret_cast<CreateFn>(dlsym(RTLD_DEFAULT, "hipEventCreate"));
+    static RecordFn record = reinterpret_cast<RecordFn>(dlsym(RTLD_DEFAULT, "hipEventRecord"));
+    static ElapsedFn elapsed = reinterpret_cast<ElapsedFn>(dlsym(RTLD_DEFAULT, "hipEventElapsedTime"));
+    TORCH_CHECK(create && record && elapsed, "flowmap_amd: the HIP runtime is not loaded");
+    tm.create = []() -> void* {
+      void* e = nullptr;
+      create(&e);
+      return e;
+    };
+    tm.record = [](void* e, void* stream) { record(e, stream); };
+    tm.elapsed = [](void* a, void* b) -> float {
+      float ms = 0.f;
+      elapsed(&ms, a, b);
+      return ms;
+    };
+  }
+  tm.enabled = on;
+  tm.events.clear();
+  tm.track_events.clear();
+}
+
+// milliseconds of every launch recorded since the last call (synchronise the device first)
+static std::vector<double> flow_timing_collect(bool tracking) {
+  FlowTimings& tm = flow_timings();
+  std::lock_guard<std::mutex> lock(timing_mutex());
+  auto& events = tracking ? tm.track_events : tm.events;
+  std::vector<double> ms;
+  for (auto& ev : events) ms.push_back((double)tm.elapsed(ev.first, ev.second));
+  events.clear();
+  return ms;
+}
+
+// ------------------------------------------------------------------------------------------
+// Registration
+// ------------------------------------------------------------------------------------------
+static std::tuple<Tensor, Tensor> focal_intrinsics_op(const Tensor& focal, std::vector<int64_t> repeat_shape, int64_t h, int64_t w) {
+  auto out = FocalIntrinsics::apply(focal, repeat_shape, h, w);
+  return {out[0], out[1]};
+}
+static Tensor pose_chain_op(const Tensor& rel) { return PoseChain::apply(rel); }
+static std::tuple<Tensor, Tensor> relative_poses_op(const Tensor& ext) {
+  auto out = RelativePoses::apply(ext);
+  return {out[0], out[1]};
+}
+using OptSink = std::optional<c10::intrusive_ptr<DepthSink>>;
+using OptArena = std::optional<c10::intrusive_ptr<GradArena>>;
+static c10::intrusive_ptr<DepthSink> sink_of(const OptSink& s) { return s.has_value() ? *s : c10::intrusive_ptr<DepthSink>(); }
+
+static std::tuple<Tensor, Tensor> procrustes_fit_op(const OptTensor& depth, const OptTensor& k, const OptTensor& kinv, const OptTensor& surfaces,
+                                                    const Tensor& weights, const Tensor& bwd_flow, const OptTensor& indices, double weight_sens,
+                                                    int64_t batch_repeat, const OptSink& sink, const OptSink& wsink, const OptArena& arena,
+                                                    const OptTensor& plan_pixels,
+                                                    const OptTensor& plan_first, const OptTensor& plan_vectors, const OptTensor& plan_weights,
+                                                    const OptTensor& dense_first, const OptTensor& dense_list) {
+  auto out = ProcrustesFit::apply(depth, k, kinv, surfaces, weights, bwd_flow, indices, weight_sens, batch_repeat, sink_of(sink), sink_of(wsink),
+                                  arena.has_value() ? *arena : c10::intrusive_ptr<GradArena>(), plan_pixels, plan_first, plan_vectors, plan_weights,
+                                  dense_first, dense_list, at::GradMode::is_enabled());
+  if (sink.has_value() && *sink) (*sink)->fit_node = out[0].grad_fn().get();  // null when no graph is being built
+  return {out[0], out[1]};
+}
+static Tensor flow_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& t_fwd, const Tensor& t_bwd, const Tensor& flow_fwd,
+                           const Tensor& flow_bwd, const Tensor& mask_fwd, const Tensor& mask_bwd, const Tensor& norm, const OptTensor& packed,
+                           int64_t kind, double delta, const OptSink& sink, int64_t items) {
+  auto s = sink_of(sink);
+  // park dL/ddepth in the sink only when both pose tensors come from the fit that armed it: that node then runs after this one
+  const bool park = s && s->fit_node != nullptr && reaches(t_fwd.grad_fn(), s->fit_node, 3) && reaches(t_bwd.grad_fn(), s->fit_node, 3);
+  return FlowLossFused::apply(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, s, items,
+                              at::GradMode::is_enabled(), park);
+}
+static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& ext, const Tensor& xy,
+                                                        const Tensor& vis, const Tensor& seg, const Tensor& blocks, const Tensor& tiles,
+                                                        std::vector<int64_t> counts, double weight, int64_t kind, double delta,
+                                                        const OptSink& sink, int64_t frame0, const OptTensor& plan_pixels,
+                                                        const OptTensor& plan_first, const OptTensor& plan_entries, const OptTensor& plan_weights,
+                                                        const OptTensor& anchor) {
+  auto s = sink_of(sink);
+  // `anchor`: the tensor whose history leads to the fit (the local extrinsics under frame sharding, where `ext` is the gathered chain)
+  const Tensor& from = (anchor.has_value() && anchor->defined()) ? *anchor : ext;
+  const bool park = s && s->fit_node != nullptr && reaches(from.grad_fn(), s->fit_node, 3);
+  auto out = TrackLossFused::apply(depth, k, kinv, ext, xy, vis, seg, blocks, tiles, counts, weight, kind, delta, s, frame0, plan_pixels, plan_first,
+                                   plan_entries, plan_weights, at::GradMode::is_enabled(), park);
+  return {out[0], out[1], out[2]};
+}
+static Tensor leading_frames_op(const Tensor& x, int64_t count, const OptSink& sink) {
+  return LeadingFrames::apply(x, count, sink_of(sink));
+}
+
+}  // namespace fmt
+
+TORCH_LIBRARY(flowmap_amd, m) {
+  m.class_<fmt::DepthSink>("DepthSink")
+      .def(torch::init<>())
+      .def("leading_in_place", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->leading_in_place; })
+      .def("leading_dense", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->leading_dense; })
+      .def("planned_steps", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->planned_steps; })
+      .def("is_active", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->active; });
+  m.class_<fmt::GradArena>("GradArena")
+      .def(torch::init<>())
+      .def("reused", [](const c10::intrusive_ptr<fmt::GradArena>& a) { return a->reused; })
+      .def("refilled", [](const c10::intrusive_ptr<fmt::GradArena>& a) { return a->refilled; });
+  m.def("set_library(str path, bool test_double) -> ()", fmt::set_library);
+  m.def("intrinsics_inverse(Tensor k) -> Tensor", fmt::intrinsics_inverse);
+  m.def("focal_intrinsics(Tensor focal, int[] repeat_shape, int height, int width) -> (Tensor, Tensor)", fmt::focal_intrinsics_op);
+  m.def("pose_chain(Tensor rel) -> Tensor", fmt::pose_chain_op);
+  m.def("relative_poses(Tensor ext) -> (Tensor, Tensor)", fmt::relative_poses_op);
+  m.def(
+      "procrustes_fit(Tensor? depth, Tensor? k, Tensor? kinv, Tensor? surfaces, Tensor weights, Tensor bwd_flow, Tensor? indices, float weight_sens, "
+      "int batch_repeat, __torch__.torch.classes.flowmap_amd.DepthSink? sink, __torch__.torch.classes.flowmap_amd.DepthSink? wsink, "
+      "__torch__.torch.classes.flowmap_amd.GradArena? arena, "
+      "Tensor? plan_pixels, Tensor? plan_first, Tensor? plan_vectors, Tensor? plan_weights, Tensor? dense_first, Tensor? dense_list) -> (Tensor, Tensor)",
+      fmt::procrustes_fit_op);
+  m.def(
+      "flow_loss(Tensor depth, Tensor k, Tensor kinv, Tensor t_fwd, Tensor t_bwd, Tensor flow_fwd, Tensor flow_bwd, Tensor mask_fwd, Tensor mask_bwd, "
+      "Tensor norm, Tensor? packed, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int items) -> Tensor",
+      fmt::flow_loss_op);
+  m.def(
+      "track_loss(Tensor depth, Tensor k, Tensor kinv, Tensor ext, Tensor xy, Tensor vis, Tensor seg, Tensor blocks, Tensor tiles, int[] counts, "
+      "float weight, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int frame0, Tensor? plan_pixels, Tensor? plan_first, "
+      "Tensor? plan_entries, Tensor? plan_weights, Tensor? anchor) -> (Tensor, Tensor, Tensor)",
+      fmt::track_loss_op);
+  m.def("leading_frames(Tensor x, int count, __torch__.torch.classes.flowmap_amd.DepthSink? sink) -> Tensor", fmt::leading_frames_op);
+  m.def("adam_step(Tensor(a!) p, Tensor grad, Tensor(b!) m, Tensor(c!) v, int step, Tensor? step_tensor, float lr, float beta1, float beta2, float eps, "
+        "float weight_decay) -> ()",
+        fmt::adam_step);
+  m.def("flow_timing_enable(bool on) -> ()", fmt::flow_timing_enable);
+  m.def("flow_timing_collect(bool tracking) -> float[]", fmt::flow_timing_collect);
+}

@@ -29,7 +29,7 @@ class GraphedStep:
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._previous = _ops.graph_capturable
         _ops.graph_capturable = True
-        events, _ops.flow_kernel_events = _ops.flow_kernel_events, None  # event records do not belong in a graph
+        _ops.flow_kernel_timing(False)  # event records do not belong in a graph
         try:
             side = torch.cuda.Stream(device)
             side.wait_stream(torch.cuda.current_stream(device))
@@ -42,7 +42,7 @@ class GraphedStep:
             with torch.cuda.graph(self.graph):
                 self.output = fn()
         finally:
-            _ops.flow_kernel_events = events
+            pass
 
     def __call__(self):
         """Replay the captured step; returns the tensors ``fn`` returned (refreshed in place)."""

@@ -57,6 +57,7 @@ class IntrinsicsSoftmin(nn.Module):
         self.register_buffer("focal_length_candidates", candidates, persistent=False)
         self._candidate_cache = None
         self._flow_cache = None
+        self.shard = None  # flowmap_amd.sharding.FrameShard.prepare_model: the sweep runs on rank 0 and is broadcast
         if cfg.regression is not None:
             self.intrinsics_regressed = IntrinsicsRegressed(IntrinsicsRegressedCfg("regressed", 0.0))
             self.window = []
@@ -105,30 +106,37 @@ class IntrinsicsSoftmin(nn.Module):
                 self.intrinsics_regressed.focal_length.data = torch.stack(self.window).mean()
             return self.intrinsics_regressed(batch, flows, backbone_output, global_step)
 
-        candidate_k, k_pair = self._candidate_intrinsics(b, (h, w))  # (n,3,3), (b*n,2,3,3)
-        idx = self._draw_indices(h * w, device)
-        bwd_01 = self._first_pair_flow(flows.backward)  # (b,1,h,w,2): the only pair the sweep looks at
+        def sweep():
+            candidate_k, k_pair = self._candidate_intrinsics(b, (h, w))  # (n,3,3), (b*n,2,3,3)
+            idx = self._draw_indices(h * w, device)
+            bwd_01 = self._first_pair_flow(flows.backward)  # (b,1,h,w,2): the only pair the sweep looks at
 
-        # ---- per-candidate Procrustes fit of frames (0, 1), images read in place -----------
-        depths = _ops.LeadingFrames.apply(backbone_output.depths, 2)
-        weights = backbone_output.weights
-        sens = 0.0
-        if isinstance(weights, LazyWeights):
-            weights_01, sens = _ops.LeadingFrames.apply(weights.logits, 1), weights.sensitivity
+            # ---- per-candidate Procrustes fit of frames (0, 1), images read in place -----------
+            depths = _ops.LeadingFrames.apply(backbone_output.depths, 2)
+            weights = backbone_output.weights
+            sens = 0.0
+            if isinstance(weights, LazyWeights):
+                weights_01, sens = _ops.LeadingFrames.apply(weights.logits, 1), weights.sensitivity
+            else:
+                weights_01 = _ops.LeadingFrames.apply(weights, 1)
+            rel, _ = _ops.ProcrustesFit.apply(depths, k_pair, None, weights_01, bwd_01, idx, sens, n)  # (b*n,1,4,4): frame 1 -> frame 0
+
+            # ---- pose-induced backward flow error per candidate (intrinsics_softmin.py:105-121): one
+            # launch reads the sampled pixels' depth / weight / flow straight from the images
+            if sens != 0.0 or not isinstance(weights, LazyWeights):
+                score_weights, score_sens = weights_01, sens
+            else:  # a LazyWeights with sensitivity 0 cannot be folded into the kernel
+                score_weights, score_sens = _ops.LeadingFrames.apply(weights.materialize(), 1), 0.0
+            # ... reduced to the softmin weights, the blended K of every frame and its inverse
+            # (intrinsics_softmin.py:123-141).  The reference returns K as an expanded view; here it is
+            # materialised once and every consumer of the step reads this tensor.
+            return _ops.softmin_intrinsics(depths, score_weights, bwd_01, idx, candidate_k, rel.reshape(b * n, 4, 4), score_sens, f)
+
+        if self.shard is not None and self.shard.active:  # frames (0, 1) of the VIDEO live on rank 0
+            intrinsics, soft = self.shard.softmin_from_rank0(sweep, b, n, f, device)
         else:
-            weights_01 = _ops.LeadingFrames.apply(weights, 1)
-        rel, _ = _ops.ProcrustesFit.apply(depths, k_pair, None, weights_01, bwd_01, idx, sens, n)  # (b*n,1,4,4): frame 1 -> frame 0
+            intrinsics, soft = sweep()
 
-        # ---- pose-induced backward flow error per candidate (intrinsics_softmin.py:105-121): one
-        # launch reads the sampled pixels' depth / weight / flow straight from the images
-        if sens != 0.0 or not isinstance(weights, LazyWeights):
-            score_weights, score_sens = weights_01, sens
-        else:  # a LazyWeights with sensitivity 0 cannot be folded into the kernel
-            score_weights, score_sens = _ops.LeadingFrames.apply(weights.materialize(), 1), 0.0
-        # ... reduced to the softmin weights, the blended K of every frame and its inverse
-        # (intrinsics_softmin.py:123-141).  The reference returns K as an expanded view; here it is
-        # materialised once and every consumer of the step reads this tensor.
-        intrinsics, soft = _ops.softmin_intrinsics(depths, score_weights, bwd_01, idx, candidate_k, rel.reshape(b * n, 4, 4), score_sens, f)
 
         if reg is not None and global_step >= reg.after_step - reg.window and self.training:
             self.window.append((self.focal_length_candidates * soft).sum().detach())

@@ -14,8 +14,7 @@ from typing import Iterable, Tuple
 
 import torch
 
-from ._lib import call, check_device, ptr, stream_for
-from ._ops import _guard
+from ._lib import check_device, torch_ops
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -58,7 +57,6 @@ class FusedAdam(torch.optim.Optimizer):
                 if not p.is_contiguous():
                     raise RuntimeError("flowmap_amd.FusedAdam: parameters must be contiguous")
                 check_device(p, grad)
-                grad = grad.contiguous()
                 state = self.state[p]
                 capturable = bool(group.get("capturable", False))
                 if len(state) == 0:
@@ -67,18 +65,8 @@ class FusedAdam(torch.optim.Optimizer):
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] += 1
-                with _guard(p.device):
-                    if capturable:
-                        if state["step"].device != p.device:
-                            raise RuntimeError("flowmap_amd.FusedAdam: capturable=True needs the step counter on the parameter's device")
-                        call("fm_adam_step_capturable", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
-                             ptr(state["step"]), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
-                             float(group["weight_decay"]), stream_for(p))
-                    else:
-                        call("fm_adam_step", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
-                             int(state["step"].item()), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
-                             float(group["weight_decay"]), stream_for(p))
-                # the kernel wrote through raw pointers: tell autograd (saved-tensor checks) and every
-                # version-keyed cache that p, exp_avg and exp_avg_sq changed, as torch.optim.Adam's in-place ops do
-                torch._C._increment_version((p, state["exp_avg"], state["exp_avg_sq"]))
+                # (the operator bumps the version counters of p, exp_avg and exp_avg_sq, as torch.optim.Adam's in-place ops do)
+                torch_ops().adam_step(p, grad, state["exp_avg"], state["exp_avg_sq"], 0 if capturable else int(state["step"].item()),
+                                      state["step"] if capturable else None, float(group["lr"]), float(beta1), float(beta2),
+                                      float(group["eps"]), float(group["weight_decay"]))
         return loss

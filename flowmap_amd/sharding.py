@@ -6,9 +6,11 @@ frames i, i+1, so rank r owns a contiguous range of pairs [a_r, b_r) and the fra
 [a_r, b_r] — the last frame is a one-frame HALO shared with rank r+1.  No collective
 sits in the data path; per step there is
 
-  * ONE packed all-reduce (sum) of [loss, dL/dfocal] — a few floats, latency-bound;
+  * ONE packed all-reduce (sum) of [loss, the gradients of every shared parameter] — a few floats for
+    regressed intrinsics (what the reference's DDP all-reduces for them, overfit.py:94-108);
   * ONE neighbour exchange of the halo frame's dL/ddepth (N floats each way), because
-    both owners of that frame hold a copy of its depth parameter;
+    both owners of that frame hold a copy of its depth parameter; it is posted from a gradient hook the
+    moment that gradient is final and overlaps the all-reduce;
   * at set-up, one all-reduce of the constant valid-mask sum so every shard normalises
     by the GLOBAL Σmask (loss_flow.py:70);
   * with the tracking loss (track windows of <= 41 frames straddle shard borders): one
@@ -45,15 +47,40 @@ def shard_frames(pair_range: Tuple[int, int]) -> Tuple[int, int]:
     return a, b  # pairs [a, b) touch frames a .. b
 
 
+class _FromRankZero(torch.autograd.Function):
+    """Broadcast of a small tensor rank 0 computed (the softmin sweep's K and weights) with the matching
+    backward: every rank's gradient w.r.t. the broadcast value is summed onto rank 0, where the sweep's own
+    backward continues.  Other ranks pass a dummy of the same shape (its gradient is discarded)."""
+
+    @staticmethod
+    def forward(ctx, value: Tensor, shard: "FrameShard"):
+        out = value.detach().clone().contiguous()
+        shard.dist.broadcast(out, src=0, group=shard.group)
+        ctx.shard = shard
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        ctx.shard.dist.reduce(g, dst=0, op=ctx.shard.dist.ReduceOp.SUM, group=ctx.shard.group)
+        return (g if ctx.shard.rank == 0 else torch.zeros_like(g)), None
+
+
 class FrameShard:
     """Per-rank communication of the sharded optimisation step."""
 
     def __init__(self, rank: int = 0, world: int = 1, dist=None, group=None):
         self.rank, self.world, self.dist, self.group = rank, world, dist, group
+        self._halo = None  # (requests, recv_prev, recv_next, gradient) of the exchange in flight
 
     @property
     def active(self) -> bool:
         return self.world > 1 and self.dist is not None
+
+    @staticmethod
+    def owned_sources(total_pairs: int, world: int, rank: int) -> Tuple[int, int]:
+        """Frames [first, end) whose tracking terms (as SOURCE frame) this rank evaluates."""
+        return _frame_layout(total_pairs, world)[1][rank]
 
     # -- set-up ---------------------------------------------------------------------------
     def reduce_valid_sum(self, vsum: Tensor) -> Tensor:
@@ -66,32 +93,74 @@ class FrameShard:
         if self.active:
             loss_fn.valid_sum_reducer = self.reduce_valid_sum
 
+    def prepare_model(self, model) -> None:
+        """Shared (not frame-local) parts of the model under sharding.
+
+        * The softmin intrinsics sweep (the reference's default for its first 1000 steps,
+          intrinsics_softmin.py:85-131) fits frames (0, 1) OF THE VIDEO: they live on rank 0.  Run on every
+          rank's local frames it would give every rank a different K, softmin window and hand-over focal
+          length, and nothing downstream would ever reconcile them.  So rank 0 runs the sweep and broadcasts
+          [K, softmin weights]; the gradient w.r.t. K is reduced back onto rank 0.  After the hand-over the
+          regressed focal length is an ordinary shared parameter (sync() all-reduces its gradient).
+        * The halo exchange of dL/ddepth starts from a gradient hook, as soon as that gradient is final."""
+        if not self.active:
+            return
+        from .model.intrinsics_softmin import IntrinsicsSoftmin
+
+        intr = getattr(model, "intrinsics", None)
+        if isinstance(intr, IntrinsicsSoftmin):
+            intr.shard = self
+        depth = getattr(getattr(model, "backbone", None), "depth", None)
+        if depth is not None and depth.requires_grad:
+            depth.register_post_accumulate_grad_hook(lambda param: self.start_halo_exchange(param.grad))
+
+    def softmin_from_rank0(self, sweep, batch: int, candidates: int, frames: int, device):
+        """``sweep() -> (K (b,frames,3,3), softmin weights (b,n))`` evaluated on rank 0 only -> the same pair on
+        every rank (K differentiable on rank 0)."""
+        if self.rank == 0:
+            k, soft = sweep()
+            packed = torch.cat([k[:, :1].reshape(-1), soft.reshape(-1).detach()])
+        else:
+            packed = torch.zeros((batch * 9 + batch * candidates,), dtype=torch.float32, device=device, requires_grad=True)
+        packed = _FromRankZero.apply(packed, self)
+        k = packed[: batch * 9].reshape(batch, 1, 3, 3).expand(batch, frames, 3, 3).contiguous()
+        return k, packed[batch * 9 :].reshape(batch, candidates).detach()
+
     # -- per step -------------------------------------------------------------------------
-    def sync(self, loss: Tensor, shared_param: Optional[Tensor], depth_param: Optional[Tensor],
-             already_global: Optional[Tensor] = None) -> Tensor:
-        """All-reduce the scalar loss and the shared (intrinsics) gradient in one packed
-        buffer; sum the halo frame's depth gradient with the neighbours.  Returns the
-        global loss (detached).  ``loss`` is this rank's share (the flow term);
-        ``already_global`` (the value ``tracking_loss`` returns) is added after the reduction.
-        No-op for world == 1."""
+    def sync(self, loss: Tensor, shared_params, depth_param: Optional[Tensor], already_global: Optional[Tensor] = None) -> Tensor:
+        """All-reduce the scalar loss and the gradients of every SHARED parameter (intrinsics, a shared
+        backbone: what the reference's DDP all-reduces, overfit.py:94-108) in ONE packed buffer; sum the
+        halo frame's depth gradient with the neighbours (the exchange usually started from the gradient hook
+        and overlaps the all-reduce).  Returns the global loss (detached).  ``loss`` is this rank's share (the
+        flow term); ``already_global`` (the value ``tracking_loss`` returns) is added after the reduction.
+        ``shared_params``: a parameter, a list of parameters, or None.  No-op for world == 1."""
         extra = 0.0 if already_global is None else already_global.detach()
         if not self.active:
             return loss.detach() if already_global is None else loss.detach() + extra
         dist = self.dist
-        parts = [loss.detach().reshape(1).to(torch.float32)]
-        if shared_param is not None and shared_param.grad is not None:
-            parts.append(shared_param.grad.reshape(-1))
-        packed = torch.cat(parts)
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
-        if len(parts) > 1:
-            shared_param.grad.copy_(packed[1:].reshape(shared_param.grad.shape))
-        if depth_param is not None and depth_param.grad is not None:
-            self.exchange_halo(depth_param.grad)
+        if shared_params is None:
+            shared_params = []
+        elif torch.is_tensor(shared_params):
+            shared_params = [shared_params]
+        with_grad = [p for p in shared_params if p.grad is not None]
+        if depth_param is not None and depth_param.grad is not None and self._halo is None:
+            self.start_halo_exchange(depth_param.grad)  # (no hook registered: start it now)
+        packed = torch.cat([loss.detach().reshape(1).to(torch.float32)] + [p.grad.reshape(-1).to(torch.float32) for p in with_grad])
+        work = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.finish_halo_exchange()
+        work.wait()
+        offset = 1
+        for p in with_grad:
+            n = p.grad.numel()
+            p.grad.copy_(packed[offset : offset + n].reshape(p.grad.shape))
+            offset += n
         return packed[0] + extra
 
-    def exchange_halo(self, depth_grad: Tensor) -> None:
-        """depth_grad (F_local, H, W): the LAST local frame is rank+1's FIRST local frame.
-        Both copies end up with the sum of the two partial gradients."""
+    def start_halo_exchange(self, depth_grad: Tensor) -> None:
+        """depth_grad (F_local, H, W): the LAST local frame is rank+1's FIRST local frame; post the sends and
+        receives of the two boundary frames (asynchronous)."""
+        if not self.active or self._halo is not None:
+            return
         dist = self.dist
         ops, recv_prev, recv_next = [], None, None
         if self.rank > 0:
@@ -102,13 +171,25 @@ class FrameShard:
             recv_next = torch.empty_like(depth_grad[-1])
             ops.append(dist.P2POp(dist.isend, depth_grad[-1].contiguous(), self.rank + 1, self.group))
             ops.append(dist.P2POp(dist.irecv, recv_next, self.rank + 1, self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        self._halo = (dist.batch_isend_irecv(ops) if ops else [], recv_prev, recv_next, depth_grad)
+
+    def finish_halo_exchange(self) -> None:
+        """Wait for the exchange and add the neighbours' parts: both copies of a shared frame end up with
+        the sum of the two partial gradients."""
+        if self._halo is None:
+            return
+        requests, recv_prev, recv_next, depth_grad = self._halo
+        self._halo = None
+        for req in requests:
+            req.wait()
         if recv_prev is not None:
             depth_grad[0].add_(recv_prev)
         if recv_next is not None:
             depth_grad[-1].add_(recv_next)
+
+    def exchange_halo(self, depth_grad: Tensor) -> None:
+        self.start_halo_exchange(depth_grad)
+        self.finish_halo_exchange()
 
 
 class _GatherPoses(torch.autograd.Function):

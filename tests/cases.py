@@ -426,11 +426,10 @@ def case_softmin_step(dev, seed=5):
         batch = Batch(torch.zeros((1, f, 3, h, w), device=dev))
         out = model(batch, to_flows(oflows, dev), 0)
         loss = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))(batch, to_flows(oflows, dev), None, out, 0)
-        before = dict(fm._ops.counters)
+        sinks = [fm._ops.depth_sink(out.depths), out.backward_correspondence_weights.logits.__dict__["_fm_sink"]]  # the step's sinks of the two parameter views
         loss.backward()
         # depth and weight-logit gradients of the sweep joined the main buffers in place
-        assert fm._ops.counters["leading_frames_in_place"] == before["leading_frames_in_place"] + 2
-        assert fm._ops.counters["leading_frames_dense"] == before["leading_frames_dense"]
+        assert [s_.leading_in_place() for s_ in sinks] == [1, 1] and [s_.leading_dense() for s_ in sinks] == [0, 0]
     finally:
         fm.set_lazy_surfaces(False)
 
@@ -832,10 +831,10 @@ def case_dense_procrustes(dev, h, w, flow_sigma, f=4):
         ((t_bwd * cot_b.to(dev)).sum() + (t_fwd * cot_f.to(dev)).sum()).backward()
         res[name] = (t_bwd.detach(), d.grad, lg.grad, kk.grad)
         if idx is None:
-            res["plan"] = fl_dev._fm_dense_plan[1:]
+            res["plan"] = fl_dev._fm_dense_plan[1]
     truth = (rel64.detach(), d64.grad, l64.grad, k64.grad)
     # the static tap lists: one entry per (later pixel, earlier-frame tile its taps touch), every tile's list ascending
-    first, entries = _ops._dense_procrustes_plan(flow.to(dev), 1, f, h, w) if False else res["plan"]
+    first, entries = res["plan"]
     first, entries = first.cpu(), entries.cpu().numpy().view(np.uint32)
     assert int(first[-1]) >= (f - 1) * h * w and int(first[-1]) <= 4 * (f - 1) * h * w
     for lo, hi in zip(first[:-1].tolist(), first[1:].tolist()):
@@ -848,3 +847,171 @@ def case_dense_procrustes(dev, h, w, flow_sigma, f=4):
         assert_close(a, b, TOL, abs_=1e-7, what=f"{what} vs generic kernels")
     assert maxerr(res["tiled"][1], truth[1]) <= 10 * TOL, "g_depth: max-abs"
     assert maxerr(res["tiled"][2], truth[2]) <= 10 * TOL, "g_logits: max-abs"
+
+
+def _small_problem(dev, f=5, h=24, w=32, points=60, tracking=True, seed=21):
+    """(model, batch, flows, loss(out)) of a consistent scene: flow + tracking losses, regressed intrinsics."""
+    import flowmap_amd
+    from flowmap_amd import Batch
+    from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
+    from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
+    from helpers import to_flows, to_tracks
+
+    sc = orc.synth_scene(f, h, w, seed=seed)
+    flowmap_amd.set_lazy_surfaces(True)
+    model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", 0.9),
+                           ExtrinsicsProcrustesCfg("procrustes", points, False)), num_frames=f, image_shape=(h, w))
+    model.backbone.depth.data = sc["depth_init"].clone()
+    model.backbone.weights.data = 0.01 * torch.randn((f - 1, h, w), generator=torch.Generator().manual_seed(seed))
+    model = model.to(dev)
+    flows = to_flows(sc["flows"], dev)
+    tracks = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=seed, interval=2, radius=2, grid=5), dev) if tracking else None
+    batch = Batch(torch.zeros((1, f, 3, h, w), device=dev))
+    flow_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
+    track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", mapping_cfg("huber")))
+
+    def loss_of(out):
+        total = flow_fn(batch, flows, None, out, 0)
+        return total + track_fn(batch, flows, tracks, out, 0) if tracking else total
+
+    return model, batch, flows, loss_of
+
+
+def _grads(model):
+    return [p.grad.detach().clone() for p in (model.backbone.depth, model.backbone.weights, model.intrinsics.focal_length)]
+
+
+def case_grad_arena(dev):
+    """The persistent dL/dweights storage (GradArena, csrc/fm_torch.cpp): the same gradients as fresh zeros every
+    step; one storage reused from the first planned step on; a gradient that is kept (accumulation without
+    zero_grad) or edited in place (clipping) is never written under — the step falls back to a fresh buffer."""
+    import flowmap_amd
+    from flowmap_amd import _ops
+
+    try:
+        history = {}
+        for arena in (False, True):
+            _ops.use_grad_arena = arena
+            model, batch, flows, loss_of = _small_problem(dev, tracking=False)
+            steps = []
+            for _ in range(5):  # step 1: atomics into zeros; step 2 builds the plan; from then on the arena
+                model.zero_grad(set_to_none=True)
+                loss_of(model(batch, flows, 0)).backward()
+                steps.append(_grads(model))
+            history[arena] = (steps, model)
+        for step, (a, b) in enumerate(zip(history[False][0], history[True][0])):
+            for x, y, what in zip(a, b, ("g_depth", "g_weights", "g_focal")):
+                assert_close(y, x, 2e-5, abs_=1e-7, what=f"{what} step {step}")
+            assert torch.equal(a[1] != 0, b[1] != 0), step  # the same sparsity pattern: nothing stale left behind
+        model = history[True][1]
+        arena = model.backbone.weights.__dict__["_fm_arena"]
+        assert arena.reused() >= 2 and arena.refilled() == 1
+        g_w = history[True][0][-1][1]
+        assert 0 < int((g_w != 0).sum()) <= g_w.shape[0] * 60  # P entries per pair at most, zeros elsewhere
+
+        # gradient accumulation: .grad from the previous step is still alive -> a fresh buffer, and autograd's own sum
+        model.zero_grad(set_to_none=True)
+        loss_of(model(batch, flows, 0)).backward()
+        once = _grads(model)
+        loss_of(model(batch, flows, 0)).backward()  # no zero_grad in between
+        twice = _grads(model)
+        for x, y, what in zip(once, twice, ("g_depth", "g_weights", "g_focal")):
+            assert_close(y, 2 * x, 2e-5, abs_=1e-7, what=f"accumulated {what}")
+        # an in-place edit of the gradient (clipping) moves its version counter: the next step starts from zeros again
+        model.zero_grad(set_to_none=True)
+        loss_of(model(batch, flows, 0)).backward()
+        refills = arena.refilled()
+        model.backbone.weights.grad.add_(1.0)  # junk everywhere, as a careless in-place op would leave it
+        model.zero_grad(set_to_none=True)
+        loss_of(model(batch, flows, 0)).backward()
+        assert arena.refilled() == refills + 1
+        assert_close(model.backbone.weights.grad, once[1], 2e-5, abs_=1e-7, what="g_weights after an in-place edit")
+    finally:
+        _ops.use_grad_arena = True
+        flowmap_amd.set_lazy_surfaces(False)
+
+
+def case_second_backward(dev):
+    """What the reference's plain autograd graph allows, the fused operators allow too: a second backward through a
+    retained graph (the fused losses re-launch from their saved inputs) and torch.autograd.grad w.r.t. a subset."""
+    import flowmap_amd
+
+    try:
+        model, batch, flows, loss_of = _small_problem(dev)
+        model.zero_grad(set_to_none=True)
+        loss = loss_of(model(batch, flows, 0))
+        loss.backward(retain_graph=True)
+        first = _grads(model)
+        model.zero_grad(set_to_none=True)
+        loss.backward()  # the retained graph, again
+        second = _grads(model)
+        for x, y, what in zip(first, second, ("g_depth", "g_weights", "g_focal")):
+            assert_close(y, x, 2e-5, abs_=1e-7, what=f"second backward {what}")
+        # torch.autograd.grad for one parameter only
+        loss = loss_of(model(batch, flows, 0))
+        (g_focal,) = torch.autograd.grad(loss, [model.intrinsics.focal_length], retain_graph=True)
+        assert_close(g_focal, first[2], 2e-5, abs_=1e-7, what="autograd.grad focal")
+        (g_depth,) = torch.autograd.grad(loss, [model.backbone.depth])
+        assert_close(g_depth, first[0], 2e-5, abs_=1e-7, what="autograd.grad depth")
+        # an optimiser step between forward and backward is an error, as it is for any autograd graph
+        loss = loss_of(model(batch, flows, 0))
+        with torch.no_grad():
+            model.backbone.depth.add_(1e-3)
+        try:
+            loss.backward()
+        except RuntimeError as exc:
+            assert "modified by an inplace operation" in str(exc)
+        else:
+            raise AssertionError("a stale graph was accepted")
+    finally:
+        flowmap_amd.set_lazy_surfaces(False)
+
+
+def case_threads_and_hooks(dev):
+    """Autograd runs backward on its own worker thread, DDP adds gradient hooks: two independent models stepped
+    concurrently from two Python threads (shared process state would cross their gradients), with
+    post-accumulate-grad hooks on every parameter (as DistributedDataParallel registers them) that must fire
+    exactly once per step and see the final gradient."""
+    import threading
+
+    import flowmap_amd
+
+    try:
+        problems = [_small_problem(dev, seed=31), _small_problem(dev, seed=32)]
+        expected = []
+        for model, batch, flows, loss_of in problems:  # serial reference
+            model.zero_grad(set_to_none=True)
+            loss_of(model(batch, flows, 0)).backward()
+            expected.append(_grads(model))
+        seen = [dict() for _ in problems]
+        for which, (model, *_rest) in enumerate(problems):
+            for name, p in model.named_parameters():
+                p.register_post_accumulate_grad_hook(lambda param, which=which, name=name: seen[which].setdefault(name, []).append(param.grad.detach().clone()))
+        errors = []
+
+        def work(which):
+            try:
+                model, batch, flows, loss_of = problems[which]
+                for _ in range(6):
+                    model.zero_grad(set_to_none=True)
+                    loss_of(model(batch, flows, 0)).backward()
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(problems))]
+        for t_ in threads:
+            t_.start()
+        for t_ in threads:
+            t_.join()
+        assert not errors, errors
+        for which, (model, *_rest) in enumerate(problems):
+            got = _grads(model)
+            for x, y, what in zip(expected[which], got, ("g_depth", "g_weights", "g_focal")):
+                assert_close(y, x, 2e-5, abs_=1e-7, what=f"thread {which} {what}")
+            assert all(len(v) == 6 for v in seen[which].values()) and len(seen[which]) == 3
+            last = {name: v[-1] for name, v in seen[which].items()}
+            assert_close(last["backbone.depth"], expected[which][0], 2e-5, abs_=1e-7, what="hook saw the final depth gradient")
+            assert_close(last["backbone.weights"], expected[which][1], 2e-5, abs_=1e-7, what="hook saw the final weight gradient")
+    finally:
+        flowmap_amd.set_lazy_surfaces(False)

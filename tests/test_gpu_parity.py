@@ -22,8 +22,9 @@ def test_native_library_is_the_one_loaded():
 
     assert not _lib.using_test_double()
     assert _lib.library() is not None
+    _lib.torch_ops()
     maps = open("/proc/self/maps").read()
-    assert "libflowmap_hip.so" in maps
+    assert "libflowmap_hip.so" in maps and "libflowmap_torch.so" in maps
 
 
 @pytest.mark.parametrize("lazy", [True, False])
@@ -399,37 +400,16 @@ def test_graphed_step_with_softmin_samples_afresh():
         flowmap_amd.set_lazy_surfaces(False)
 
 
-def test_overlapped_zero_fill_gives_the_same_gradients():
-    """The dense dL/dweights filled on the side stream during the backward pass (with the deferred
-    fm_sparse_store) against the in-line fill: the same gradients, step after step, and zeros
-    everywhere but the sampled pixels."""
-    import flowmap_amd
-    from flowmap_amd import _ops
+def test_grad_arena():
+    cases.case_grad_arena(DEV)
 
-    saved = _ops.prefill_weight_grads
-    try:
-        grads = {}
-        for prefill in (False, True):
-            _ops.prefill_weight_grads = prefill
-            model, batch, flows, loss_of = _graph_problem()
-            history = []
-            for _ in range(4):  # step 1: atomics; from step 2 on the planned scatter (and, with prefill, the deferred store)
-                model.zero_grad(set_to_none=True)
-                loss_of(model(batch, flows, 0)).backward()
-                history.append((model.backbone.depth.grad.clone(), model.backbone.weights.grad.clone(), model.intrinsics.focal_length.grad.clone()))
-            torch.cuda.synchronize()
-            grads[prefill] = history
-        for step, (a, b) in enumerate(zip(grads[False], grads[True])):
-            tol = 2e-5 if step == 0 else 2e-6  # planned steps are free of float atomics on the big tensors
-            assert_close(b[0], a[0], tol, abs_=1e-7, what=f"g_depth step {step}")
-            assert_close(b[1], a[1], tol, abs_=1e-7, what=f"g_weights step {step}")
-            assert torch.equal(a[1] != 0, b[1] != 0), step  # same sparsity pattern
-            assert_close(b[2], a[2], 1e-4, abs_=1e-6, what=f"g_focal step {step}")
-        g_w = grads[True][-1][1]
-        assert 0 < int((g_w != 0).sum()) <= g_w.shape[0] * 1000  # P entries per pair at most, zeros elsewhere
-    finally:
-        _ops.prefill_weight_grads = saved
-        flowmap_amd.set_lazy_surfaces(False)
+
+def test_second_backward_and_autograd_grad():
+    cases.case_second_backward(DEV)
+
+
+def test_backward_on_worker_threads_with_grad_hooks():
+    cases.case_threads_and_hooks(DEV)
 
 
 @pytest.mark.parametrize(

@@ -153,18 +153,26 @@ def test_packed_tracks_ownership_filters_sources():
     assert none.nblocks == 0 and none.ntiles == 0 and tuple(none.blocks.shape) == (0, 2)
 
 
-def test_emitted_registry_keeps_the_newest_entries():
-    """Gradient buffers registered for in-place hand-over are evicted oldest-first, never the
-    pair that the current backward pass has just registered."""
+def test_derived_constants_live_on_their_tensor_and_follow_its_version():
+    """No module-level caches: what is derived from a constant input (packed flows, valid sums, plans,
+    K^-1) is kept on the input tensor object, rebuilt after an in-place edit, gone with the tensor."""
+    import gc
+    import weakref
+
     from flowmap_amd import _ops
 
-    _ops._emitted.clear()
-    keep = [torch.zeros(1) for _ in range(40)]
-    for i, buf in enumerate(keep):
-        _ops._note_emitted(("key", i), buf)
-        assert ("key", i) in _ops._emitted and (i == 0 or ("key", i - 1) in _ops._emitted)
-    assert len(_ops._emitted) <= 16 and ("key", 0) not in _ops._emitted
-    _ops._emitted.clear()
+    mf, mb = torch.rand((1, 3, 8, 12)), torch.rand((1, 3, 8, 12))
+    norm = _ops.flow_valid_norm(mf, mb, 1000.0)
+    assert _ops.flow_valid_norm(mf, mb, 1000.0) is norm  # same tensors, same versions
+    assert _ops.flow_valid_norm(mf, mb, 10.0) is not norm  # another weight
+    again = _ops.flow_valid_norm(mf, mb, 1000.0)
+    mb.mul_(0.5)  # in-place edit of the OTHER mask: rebuilt
+    assert not torch.equal(_ops.flow_valid_norm(mf, mb, 1000.0), again)
+    assert not [name for name in vars(_ops) if name.endswith("_cache")]  # nothing module-level left
+    held = weakref.ref(_ops.flow_valid_norm(mf, mb, 1000.0))
+    del mf, norm, again
+    gc.collect()
+    assert held() is None  # the derived tensor died with its owner
 
 
 def test_freeze_gc_moves_live_objects_to_the_permanent_generation():
@@ -197,13 +205,14 @@ def test_intrinsics_inverse_cache_follows_object_version_and_views():
     assert not torch.equal(second, first) and torch.allclose(second @ k, torch.eye(3).expand(2, 3, 3, 3), atol=1e-6)
     clone = k.clone()  # equal values, different object: never served another tensor's entry
     assert _ops.intrinsics_inverse(clone).data_ptr() != second.data_ptr()
-    # more K tensors than slots: the oldest entries go, the live ones keep hitting
-    keep = [torch.eye(3)[None].clone() * (i + 1) for i in range(_ops._KINV_CACHE_SLOTS + 2)]
-    for m in keep:
-        _ops.intrinsics_inverse(m)
-    assert len(_ops._kinv_cache) <= _ops._KINV_CACHE_SLOTS
-    last = _ops.intrinsics_inverse(keep[-1])
-    assert _ops.intrinsics_inverse(keep[-1]).data_ptr() == last.data_ptr()
+    # the inverse lives on the K tensor object: it goes when K goes
+    import gc
+    import weakref
+
+    held = weakref.ref(_ops.intrinsics_inverse(clone))
+    del clone
+    gc.collect()
+    assert held() is None
 
 
 def test_errors_of_the_preparation_and_intrinsics_entry_points_are_loud():

@@ -129,3 +129,15 @@ def test_flow_fused_leaves(f, h, w, packed, kind):
 @pytest.mark.parametrize("h,w,flow_sigma", [(20, 70, 0.02), (18, 66, 0.3), (33, 130, 0.08)])
 def test_dense_procrustes(h, w, flow_sigma):
     cases.case_dense_procrustes("cpu", h, w, flow_sigma, f=3)
+
+
+def test_grad_arena():
+    cases.case_grad_arena("cpu")
+
+
+def test_second_backward_and_autograd_grad():
+    cases.case_second_backward("cpu")
+
+
+def test_backward_on_worker_threads_with_grad_hooks():
+    cases.case_threads_and_hooks("cpu")
