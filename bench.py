@@ -253,7 +253,8 @@ def main():
     if world > 1 or os.environ.get("FLOWMAP_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one GPU
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        for key, value in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(key, value)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:

@@ -9,7 +9,7 @@
 // registered with TORCH_LIBRARY under the namespace `flowmap_amd`: at::Tensor shims that check their
 // arguments (TORCH_CHECK -> RuntimeError), allocate outputs / workspaces with the caching allocator,
 // select the tensor's device and launch the hand-written HIP kernels through the C ABI on
-// c10::hip::getCurrentHIPStream().  No kernel lives here (this file is host-only C++, built with g++);
+// the current HIP stream (c10::hip::getCurrentHIPStreamMasqueradingAsCUDA: PyTorch-ROCm names its devices "cuda").  No kernel lives here (this file is host-only C++, built with g++);
 // no state lives here either, beyond the table of C-ABI entry points: what one step hands from one
 // operator to the next (the shared dense dL/ddepth, the persistent dL/dweights storage) travels in
 // explicit objects (DepthSink, GradArena) that the Python layer creates and passes in.
@@ -17,8 +17,8 @@
 // The C ABI is resolved with dlopen / dlsym so that the CPU test-suite can point the same binding at
 // tests/host_sim's serial build of the ABI (set_library); the product only ever loads libflowmap_hip.so.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>  // PyTorch-ROCm calls its HIP devices "cuda": these are the
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>     // guard / stream types that go with that device type
 #include <dlfcn.h>
 #include <torch/autograd.h>
 #include <torch/custom_class.h>
@@ -120,12 +120,12 @@ static c10::Device check_device(std::initializer_list<const Tensor*> tensors) {
 }
 
 struct DeviceScope {  // select the tensors' GPU for the launches inside; no-op for the host double
-  std::optional<c10::hip::HIPGuard> guard;
+  std::optional<c10::hip::HIPGuardMasqueradingAsCUDA> guard;
   void* stream = nullptr;
   explicit DeviceScope(const c10::Device& dev) {
     if (dev.is_cuda()) {
       guard.emplace(dev);
-      stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
+      stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
     }
   }
 };
