@@ -324,7 +324,7 @@ def main():
     shard = FrameShard(rank, world if dist is None else max(world, 1), dist)
     if dist is not None and world == 1:
         shard.world = 2  # single-rank RCCL self-test: run the collectives, there are no neighbours
-        shard.exchange_halo = lambda grad: None
+        shard.start_halo_exchange = lambda grad: None
     if strong or (dist is not None and world == 1):
         shard.prepare_flow_loss(loss_fn, flows)  # global valid-sum (one-time all-reduce)
         shard.prepare_model(model)  # softmin sweep on rank 0, broadcast (flowmap_amd/sharding.py)

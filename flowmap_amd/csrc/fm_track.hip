@@ -111,6 +111,105 @@ __device__ __forceinline__ void wave_store(const float (&v)[NV], float* dst) {
   }
 }
 
+// The per-target-frame reduction of the 14 sums runs once per target frame and wave: as compiled from
+// wave_sum_lane63 it took 234 of the loop's 529 instructions (every DPP step a v_mov_b32 of the identity, a
+// v_mov_b32_dpp and an add).  Here each step is ONE v_add_f32_dpp (lanes the row mask disables keep their
+// value), the values interleaved so that no instruction reads a register written less than 7 instructions
+// earlier — 7 registers per group — (the VALU -> DPP hazard needs 2 wait states; the leading s_nop covers the
+// compiler's own last write).
+__device__ __forceinline__ void wave_sum7_lane63(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6) {
+#define FM_DPP7(ctrl)                                                                                                              \
+  asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl          \
+               "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\tv_add_f32_dpp %4, %4, %4 " ctrl "\n\tv_add_f32_dpp %5, %5, %5 " ctrl    \
+               "\n\tv_add_f32_dpp %6, %6, %6 " ctrl                                                                               \
+               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6))
+  asm volatile("s_nop 1");
+  FM_DPP7("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+  FM_DPP7("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+  FM_DPP7("row_half_mirror row_mask:0xf bank_mask:0xf");
+  FM_DPP7("row_mirror row_mask:0xf bank_mask:0xf");
+  FM_DPP7("row_bcast:15 row_mask:0xa bank_mask:0xf");
+  FM_DPP7("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef FM_DPP7
+}
+
+// NV (a multiple of 7) per-lane values -> their wave totals in lane 63, in place
+template <int NV>
+__device__ __forceinline__ void wave_sum_lane63_x7(float (&v)[NV]) {
+  static_assert(NV % 7 == 0, "groups of seven registers");
+#pragma unroll
+  for (int i = 0; i < NV; i += 7) wave_sum7_lane63(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6]);
+}
+
+// track_pair_term (fm_pose.h) for TWO source frames of the same point at once, the pair held as the two halves
+// of packed registers: the multiply-adds of the projection, of the twelve S sums and of dL/dX_w become
+// v_pk_fma_f32 / v_pk_mul_f32 (two fp32 lanes per instruction); reciprocal, reciprocal square root, the range
+// tests and the selects of the robust kernel stay per element.  Same arithmetic per element as the scalar
+// function (which the host double runs).  `a` holds a partial sum per half, added together after the tile.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int KIND, bool GRAD>
+__device__ __forceinline__ void track_pair_term2(const float (&tg)[kTrackTgt], const v2f (&xw)[3], float gt_x, float gt_y, v2f m, float delta,
+                                                 float inv_delta, float ax, float ay, v2f (&a)[kTrackSums], v2f (&gxw)[3]) {
+  const v2f xu = tg[0] * xw[0] + (tg[1] * xw[1] + (tg[2] * xw[2] + tg[3]));
+  const v2f xv = tg[4] * xw[0] + (tg[5] * xw[1] + (tg[6] * xw[2] + tg[7]));
+  const v2f x2 = tg[8] * xw[0] + (tg[9] * xw[1] + (tg[10] * xw[2] + tg[11]));
+  v2f q;
+  q.x = fm_rcp(x2.x + kProjEps);
+  q.y = fm_rcp(x2.y + kProjEps);
+  const bool ok0 = fabsf(q.x) <= 3.0e38f, ok1 = fabsf(q.y) <= 3.0e38f;
+  q.x = ok0 ? q.x : 0.f;
+  q.y = ok1 ? q.y : 0.f;
+  const v2f u = xu * q, v = xv * q;
+  m.x = (ok0 && u.x >= 0.f && v.x >= 0.f && u.x < 1.f && v.x < 1.f) ? m.x : 0.f;
+  m.y = (ok1 && u.y >= 0.f && v.y >= 0.f && u.y < 1.f && v.y < 1.f) ? m.y : 0.f;
+  const v2f rx = (u - gt_x) * ax, ry = (v - gt_y) * ay;  // exact 0 for equal inputs (cf. aspect_diff)
+  const v2f ss = rx * rx + ry * ry;
+  v2f rho, coef;  // ρ and dρ/dr = coef·r
+  if (KIND == kL2) {
+    rho = 0.5f * ss;
+    coef = 1.f;
+  } else {
+    v2f inv_n;
+    inv_n.x = ss.x > 0.f ? fm_rsq(ss.x) : 0.f;
+    inv_n.y = ss.y > 0.f ? fm_rsq(ss.y) : 0.f;
+    const v2f n = ss * inv_n;
+    if (KIND == kL1) {
+      rho = n;
+      coef = inv_n;
+    } else {
+      const v2f quad_rho = (0.5f * inv_delta) * ss, lin_rho = n - 0.5f * delta;
+      rho.x = n.x < delta ? quad_rho.x : lin_rho.x;
+      rho.y = n.y < delta ? quad_rho.y : lin_rho.y;
+      coef.x = n.x < delta ? inv_delta : inv_n.x;
+      coef.y = n.y < delta ? inv_delta : inv_n.y;
+    }
+  }
+  a[12] = rho * m + a[12];
+  a[13] += m;
+  if (!GRAD) return;
+  const v2f gc = m * coef;
+  const v2f wu = gc * rx * ax, wv = gc * ry * ay;  // dL/du, dL/dv (unscaled)
+  const v2f o0 = q * wu, o1 = q * wv, o2 = q * (wu * u + wv * v);
+  a[0] = o0 * xw[0] + a[0];
+  a[1] = o0 * xw[1] + a[1];
+  a[2] = o0 * xw[2] + a[2];
+  a[3] += o0;
+  a[4] = o1 * xw[0] + a[4];
+  a[5] = o1 * xw[1] + a[5];
+  a[6] = o1 * xw[2] + a[6];
+  a[7] += o1;
+  a[8] = o2 * xw[0] + a[8];
+  a[9] = o2 * xw[1] + a[9];
+  a[10] = o2 * xw[2] + a[10];
+  a[11] += o2;
+  gxw[0] = o0 * tg[0] + (o1 * tg[4] + (gxw[0] - o2 * tg[8]));  // dL/dX_w = ω·(au, av, −c)
+  gxw[1] = o0 * tg[1] + (o1 * tg[5] + (gxw[1] - o2 * tg[9]));
+  gxw[2] = o0 * tg[2] + (o1 * tg[6] + (gxw[2] - o2 * tg[10]));
+}
+
+static_assert(kTrackTile % 2 == 0, "the source frames of a tile are processed in pairs");
+
 template <int KIND, bool GRAD>
 __global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const int32_t* tiles, const float* ws, const uint8_t* flag,
                                                             const float* ext, const float* tgt, float delta, float ax, float ay, int fmax,
@@ -124,22 +223,27 @@ __global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const i
   const bool active = p < p_count;
   const int pp = active ? p : p_count - 1;  // clamped: loads stay in bounds, results are masked
 
-  float xw[kTrackTile][3], gxw[kTrackTile][3];
-  float live[kTrackTile];  // 1 when the source role is visible (projection.py:290-294), else 0
+  // source frames fs0 + 2j (.x) and fs0 + 2j + 1 (.y) share packed registers
+  v2f xw[kTrackTile / 2][3], gxw[kTrackTile / 2][3];
+  v2f live[kTrackTile / 2];  // 1 when the source role is visible (projection.py:290-294), else 0
 #pragma unroll
   for (int t = 0; t < kTrackTile; ++t) {
-    live[t] = 0.f;
-    xw[t][0] = xw[t][1] = xw[t][2] = 0.f;
-    gxw[t][0] = gxw[t][1] = gxw[t][2] = 0.f;
+    float lv = 0.f, x0 = 0.f, x1 = 0.f, x2 = 0.f;
     const int fs = fs0 + t;
     if (active && fs < f) {
       const size_t is = (size_t)off + (size_t)fs * p_count + p;
       if (flag[is] != 0) {
-        live[t] = 1.f;
+        lv = 1.f;
         const float* w9 = ws + is * kTrackWs;
-        xw[t][0] = w9[3]; xw[t][1] = w9[4]; xw[t][2] = w9[5];
+        x0 = w9[3]; x1 = w9[4]; x2 = w9[5];
       }
     }
+    if (t & 1) {
+      live[t / 2].y = lv; xw[t / 2][0].y = x0; xw[t / 2][1].y = x1; xw[t / 2][2].y = x2;
+    } else {
+      live[t / 2].x = lv; xw[t / 2][0].x = x0; xw[t / 2][1].x = x1; xw[t / 2][2].x = x2;
+    }
+    gxw[t / 2][0] = gxw[t / 2][1] = gxw[t / 2][2] = 0.f;
   }
 
   // the target's visibility and position are prefetched one iteration ahead
@@ -157,14 +261,21 @@ __global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const i
     float tg[kTrackTgt];
 #pragma unroll
     for (int i = 0; i < kTrackTgt; ++i) tg[i] = tgt[(size_t)(start + ft) * kTrackTgt + i];  // wave-uniform: scalar loads
+    v2f a2[kTrackSums];
+#pragma unroll
+    for (int i = 0; i < kTrackSums; ++i) a2[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < kTrackTile / 2; ++j)
+      track_pair_term2<KIND, GRAD>(tg, xw[j], gt.x, gt.y, tv * live[j], delta, inv_delta, ax, ay, a2, gxw[j]);
     float a[kTrackSums];
 #pragma unroll
-    for (int i = 0; i < kTrackSums; ++i) a[i] = 0.f;
-#pragma unroll
-    for (int t = 0; t < kTrackTile; ++t)
-      track_pair_term<KIND, GRAD>(tg, xw[t], gt.x, gt.y, tv * live[t], delta, inv_delta, ax, ay, a, gxw[t]);
+    for (int i = 0; i < kTrackSums; ++i) a[i] = a2[i].x + a2[i].y;
     if (GRAD) {
-      wave_store<kTrackSums>(a, mine + (size_t)ft * kTrackSums);
+      wave_sum_lane63_x7<kTrackSums>(a);  // the totals are valid in lane 63
+      if (threadIdx.x == kWave - 1) {
+#pragma unroll
+        for (int i = 0; i < kTrackSums; ++i) mine[(size_t)ft * kTrackSums + i] = a[i];
+      }
     } else {
       const float lc[2] = {a[12], a[13]};
       wave_store<2>(lc, mine + (size_t)ft * kTrackSums + 12);
@@ -179,17 +290,23 @@ __global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const i
       float b[21];
 #pragma unroll
       for (int i = 0; i < 21; ++i) b[i] = 0.f;
-      if (live[t] != 0.f) {
+      if (((t & 1) ? live[t / 2].y : live[t / 2].x) != 0.f) {
         const size_t is = (size_t)off + (size_t)fs * p_count + p;
         Pose e;
         load_pose44(ext + (size_t)(start + fs) * 16, e);
         float gxyz[3];
-        track_source_term(e, ws + is * kTrackWs, gxw[t], b, gxyz);
+        const float gx[3] = {(t & 1) ? gxw[t / 2][0].y : gxw[t / 2][0].x, (t & 1) ? gxw[t / 2][1].y : gxw[t / 2][1].x,
+                             (t & 1) ? gxw[t / 2][2].y : gxw[t / 2][2].x};
+        track_source_term(e, ws + is * kTrackWs, gx, b, gxyz);
         gws[is * 3 + 0] = gxyz[0];
         gws[is * 3 + 1] = gxyz[1];
         gws[is * 3 + 2] = gxyz[2];
       }
-      wave_store<21>(b, mine + (size_t)fmax * kTrackSums + t * 21);
+      wave_sum_lane63_x7<21>(b);
+      if (threadIdx.x == kWave - 1) {
+#pragma unroll
+        for (int i = 0; i < 21; ++i) mine[(size_t)fmax * kTrackSums + t * 21 + i] = b[i];
+      }
     }
   }
 }
