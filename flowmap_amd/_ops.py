@@ -818,7 +818,8 @@ class PackedTracks:
         self.pmax = max(s_[2] for s_ in seg)
         self.fmax = max(s_[1] for s_ in seg)
         self.last_frame = max(s_[0] + s_[1] for s_ in seg)
-        self.counts = [self.nblocks, self.ntiles, self.pmax, self.fmax, self.total, int(self.partial), self.last_frame]
+        self.counts = [self.nblocks, self.ntiles, self.pmax, self.fmax, self.total, int(self.partial), self.last_frame,
+                       0 if own is None else int(own[0]), -1 if own is None else int(own[1])]  # ..., source frames owned here [first, end)
         self._plans: dict = {}
 
     def scatter_plan(self, height: int, width: int):

@@ -47,7 +47,7 @@ using OptTensor = std::optional<Tensor>;
   X(fm_flow_loss_fused) X(fm_flow_loss_finalize) X(fm_scale_if_needed) X(fm_intrinsics_inverse) X(fm_intrinsics_inverse_bwd)              \
   X(fm_focal_intrinsics_fwd) X(fm_focal_intrinsics_bwd) X(fm_pose_chain_fwd) X(fm_pose_chain_bwd) X(fm_relative_pose_fwd)                  \
   X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_pose_solve_bwd) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense)                \
-  X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_points) X(fm_track_loss_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
+  X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_loss_fused_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
   X(fm_adam_step_capturable)
 
 struct Api {
@@ -670,15 +670,15 @@ struct TrackLossFused : public Function<TrackLossFused> {
     const auto dev = check_device({&depth_in, &k_in, &kinv_in, &ext_in, &xy});
     const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics"),
                  ext = f32c(ext_in, "extrinsics");
-    TORCH_CHECK(counts.size() == 7, "flowmap_amd: packed track counts");
-    const int64_t nblocks = counts[0], ntiles = counts[1], pmax = counts[2], fmax = counts[3], total = counts[4], partial = counts[5],
-                  last_frame = counts[6];
+    TORCH_CHECK(counts.size() == 9, "flowmap_amd: packed track counts");
+    const int64_t ntiles = counts[1], pmax = counts[2], fmax = counts[3], total = counts[4], partial = counts[5], last_frame = counts[6];
     TORCH_CHECK(depth.dim() == 4 && depth.size(0) == 1, "flowmap_amd: the fused tracking loss supports batch size 1 (as the reference asserts)");
     const int64_t f_local = depth.size(1), h = depth.size(2), w = depth.size(3), f = ext.size(1);
     TORCH_CHECK(k.sizes() == at::IntArrayRef({1, f, 3, 3}) && kinv.sizes() == k.sizes() && ext.sizes() == at::IntArrayRef({1, f, 4, 4}) &&
                     frame0 >= 0 && frame0 + f_local <= f,
                 "flowmap_amd: intrinsics / extrinsics must cover the whole video and depth a window of it");
     TORCH_CHECK(last_frame <= f, "flowmap_amd: a track segment extends past the last frame");
+    const int64_t own_first = std::max<int64_t>(counts[7], frame0), own_end = std::min<int64_t>(counts[8] < 0 ? f : counts[8], frame0 + f_local);
     const auto fopt = depth.options();
     Tensor ext_inv = at::empty_like(ext);
     Tensor ws = at::empty({total, 9}, fopt);
@@ -696,9 +696,6 @@ struct TrackLossFused : public Function<TrackLossFused> {
       DeviceScope scope(dev);
       FM_CALL(fm_extrinsics_inverse, ptr(ext), (int)f, ptr(ext_inv), scope.stream);
       if (ntiles > 0) {
-        FM_CALL(fm_track_points, ptr(depth), (int)frame0, ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), (int)f, ptr(xy), ptr<uint8_t>(vis),
-                ptr<int32_t>(seg), ptr<int32_t>(blocks), (int)nblocks, (int)pmax, (int)h, (int)w, ptr(ws), ptr<uint8_t>(flag), ptr(tgt),
-                scope.stream);
         FlowTimings& tm = flow_timings();
         void *e0 = nullptr, *e1 = nullptr;
         if (tm.enabled && dev.is_cuda() && tm.create) {
@@ -706,9 +703,10 @@ struct TrackLossFused : public Function<TrackLossFused> {
           e1 = tm.create();
           tm.record(e0, scope.stream);
         }
-        FM_CALL(fm_track_loss_fwd, ptr(ws), ptr<uint8_t>(flag), ptr(xy), ptr<uint8_t>(vis), ptr<int32_t>(seg), ptr<int32_t>(tiles), (int)ntiles,
-                (int)pmax, (int)fmax, ptr(ext), ptr(tgt), (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / sc, (float)h / sc,
-                (float)weight, ptr(part), ptr<double>(acc), ptr(loss), ptr(scale), ptr<double>(totals), ptr(gws), ptr<double>(acc2), scope.stream);
+FM_CALL(fm_track_loss_fused_fwd, ptr(depth), (int)frame0, (int)own_first, (int)own_end, ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), (int)f,
+                ptr(xy), ptr<uint8_t>(vis), ptr<int32_t>(seg), ptr<int32_t>(tiles), (int)ntiles, (int)pmax, (int)fmax, (int)h, (int)w, (int)kind,
+                (float)delta, (float)w / sc, (float)h / sc, (float)weight, ptr(ws), ptr<uint8_t>(flag), ptr(tgt), ptr(part), ptr<double>(acc),
+                ptr(loss), ptr(scale), ptr<double>(totals), ptr(gws), ptr<double>(acc2), scope.stream);
         if (e0) {
           tm.record(e1, scope.stream);
           std::lock_guard<std::mutex> lock(timing_mutex());

@@ -47,14 +47,9 @@ struct TrackGeom {
 };
 
 // ---------------------------------------------------------------- track_points ------
-__global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const float* depth, int depth_frame0, const float* kinv,
-                                                           const float* ext, float* ws, uint8_t* flag) {
-  const int sg = g.blocks[blockIdx.x * 2], fl = g.blocks[blockIdx.x * 2 + 1];
-  const int start = g.seg[sg * 4], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
-  const int p = blockIdx.y * blockDim.x + threadIdx.x;
-  if (p >= p_count) return;
-  const int frame = start + fl;
-  const size_t idx = (size_t)off + (size_t)fl * p_count + p;
+// One track point of one frame: ws[idx] = [xyz | X_w | h], flag[idx]; returns the flag, X_w in xw.
+__device__ __forceinline__ bool track_sample(const TrackGeom& g, const float* depth, int depth_frame0, const float* kinv, const float* ext,
+                                             int frame, size_t idx, float* ws, uint8_t* flag, float xw[3]) {
   const float2 q = reinterpret_cast<const float2*>(g.xy)[idx];
   Mat3 ki;
   Pose e;
@@ -78,14 +73,25 @@ __global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const fl
     hh[1] += z * vt * t.w[k];
     hh[2] += z * t.w[k];
   }
-  float xw[3];
   apply_pose(e, xyz, xw);
   float* o = ws + idx * kTrackWs;
   o[0] = xyz[0]; o[1] = xyz[1]; o[2] = xyz[2];
   o[3] = xw[0];  o[4] = xw[1];  o[5] = xw[2];
   o[6] = hh[0];  o[7] = hh[1];  o[8] = hh[2];
   const bool inside = q.x >= 0.f && q.y >= 0.f && q.x < 1.f && q.y < 1.f;
-  flag[idx] = (g.vis[idx] != 0 && inside) ? 1 : 0;
+  const bool live = g.vis[idx] != 0 && inside;
+  flag[idx] = live ? 1 : 0;
+  return live;
+}
+
+__global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const float* depth, int depth_frame0, const float* kinv,
+                                                           const float* ext, float* ws, uint8_t* flag) {
+  const int sg = g.blocks[blockIdx.x * 2], fl = g.blocks[blockIdx.x * 2 + 1];
+  const int start = g.seg[sg * 4], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
+  const int p = blockIdx.y * blockDim.x + threadIdx.x;
+  if (p >= p_count) return;
+  float xw[3];
+  track_sample(g, depth, depth_frame0, kinv, ext, start + fl, (size_t)off + (size_t)fl * p_count + p, ws, flag, xw);
 }
 
 // Per frame: the target-role constants (au, av, c) of track_target (fm_pose.h).
@@ -210,10 +216,20 @@ __device__ __forceinline__ void track_pair_term2(const float (&tg)[kTrackTgt], c
 
 static_assert(kTrackTile % 2 == 0, "the source frames of a tile are processed in pairs");
 
+// Sampling inside the pair kernel (fm_track_loss_fused_fwd): the wave samples the points of its own tile's source
+// frames in its prologue (every (segment, frame, point) belongs to exactly one tile, so nothing is sampled twice)
+// and writes ws / flag for its epilogue and for the backward — the separate track_points launch (0.10 ms at C2,
+// a chain of gathers with nothing to overlap) disappears into the first microseconds of 4 000 waves.
+struct TrackSampling {
+  const float* depth;  // null: ws / flag were filled by fm_track_points
+  const float* kinv;
+  int depth_frame0, own_first, own_end;  // frames [own_first, own_end) are sources on this rank (frame sharding)
+};
+
 template <int KIND, bool GRAD>
-__global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const int32_t* tiles, const float* ws, const uint8_t* flag,
+__global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const int32_t* tiles, float* ws, uint8_t* flag,
                                                             const float* ext, const float* tgt, float delta, float ax, float ay, int fmax,
-                                                            float* partial, float* gws) {
+                                                            float* partial, float* gws, TrackSampling smp) {
   const float inv_delta = KIND == kHuber ? 1.0f / delta : 0.f;
   // this wave's slice of the partial-sum workspace: [fmax][14] target role, then [kTrackTile][21] source role
   float* mine = partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * track_partial_stride(fmax);
@@ -232,7 +248,18 @@ __global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const i
     const int fs = fs0 + t;
     if (active && fs < f) {
       const size_t is = (size_t)off + (size_t)fs * p_count + p;
-      if (flag[is] != 0) {
+      if (smp.depth != nullptr) {
+        const int frame = start + fs;
+        if (frame >= smp.own_first && frame < smp.own_end) {
+          float xs[3];
+          if (track_sample(g, smp.depth, smp.depth_frame0, smp.kinv, ext, frame, is, ws, flag, xs)) {
+            lv = 1.f;
+            x0 = xs[0]; x1 = xs[1]; x2 = xs[2];
+          }
+        } else {
+          flag[is] = 0;  // another rank's source
+        }
+      } else if (flag[is] != 0) {
         lv = 1.f;
         const float* w9 = ws + is * kTrackWs;
         x0 = w9[3]; x1 = w9[4]; x2 = w9[5];
@@ -513,14 +540,10 @@ int fm_track_points(const float* depth, int depth_frame0, const float* kinv, con
   FM_LAUNCH_STATUS();
 }
 
-int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
-                      const int32_t* tiles, int ntiles, int pmax, int fmax, const float* ext, const float* tgt, int frames, int height,
-                      int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* partial,
-                      double* acc, float* loss, float* scale, double* totals, float* gws, double* acc2, void* stream) {
-  FM_CHECK_ARG(ws && flag && xy && vis && seg && tiles && ext && tgt && partial && acc && loss && scale);
-  FM_CHECK_ARG(ntiles >= 1 && pmax >= 1 && fmax >= 1 && frames >= 1 && mapping_kind >= 0 && mapping_kind <= 2);
-  FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr));
-  hipStream_t st = (hipStream_t)stream;
+static int track_loss_launch(float* ws, uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* tiles,
+                             int ntiles, int pmax, int fmax, const float* ext, const float* tgt, int frames, int height, int width,
+                             int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* partial, double* acc,
+                             float* loss, float* scale, double* totals, float* gws, double* acc2, TrackSampling smp, hipStream_t st) {
   TrackGeom g{xy, vis, seg, nullptr, height, width};
   const int pgroups = (pmax + kWave - 1) / kWave;
   const dim3 grid(ntiles, pgroups);
@@ -528,10 +551,10 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
   do {                                                                                                                               \
     if (gws)                                                                                                                         \
       hipLaunchKernelGGL((track_pairs_kernel<K, true>), grid, dim3(kWave), 0, st, g, tiles, ws, flag, ext, tgt, delta,              \
-                         aspect_x, aspect_y, fmax, partial, gws);                                                                    \
+                         aspect_x, aspect_y, fmax, partial, gws, smp);                                                               \
     else                                                                                                                             \
       hipLaunchKernelGGL((track_pairs_kernel<K, false>), grid, dim3(kWave), 0, st, g, tiles, ws, flag, ext, tgt, delta,             \
-                         aspect_x, aspect_y, fmax, partial, gws);                                                                    \
+                         aspect_x, aspect_y, fmax, partial, gws, smp);                                                               \
   } while (0)
   if (mapping_kind == kHuber) FM_TRACK_LAUNCH(kHuber);
   else if (mapping_kind == kL1) FM_TRACK_LAUNCH(kL1);
@@ -541,6 +564,33 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
                      acc2);
   hipLaunchKernelGGL(track_finalize_fwd_kernel, dim3(1), dim3(kWave), 0, st, acc, frames, weight, loss, scale, totals);
   FM_LAUNCH_STATUS();
+}
+
+int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg,
+                      const int32_t* tiles, int ntiles, int pmax, int fmax, const float* ext, const float* tgt, int frames, int height,
+                      int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* partial,
+                      double* acc, float* loss, float* scale, double* totals, float* gws, double* acc2, void* stream) {
+  FM_CHECK_ARG(ws && flag && xy && vis && seg && tiles && ext && tgt && partial && acc && loss && scale);
+  FM_CHECK_ARG(ntiles >= 1 && pmax >= 1 && fmax >= 1 && frames >= 1 && mapping_kind >= 0 && mapping_kind <= 2);
+  FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr));
+  return track_loss_launch(const_cast<float*>(ws), const_cast<uint8_t*>(flag), xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames,
+                           height, width, mapping_kind, delta, aspect_x, aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
+                           TrackSampling{nullptr, nullptr, 0, 0, 0}, (hipStream_t)stream);
+}
+
+int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first, int own_end, const float* kinv, const float* ext,
+                            const float* ext_inv, const float* k, int frames, const float* xy, const uint8_t* vis, const int32_t* seg,
+                            const int32_t* tiles, int ntiles, int pmax, int fmax, int height, int width, int mapping_kind, float delta,
+                            float aspect_x, float aspect_y, float weight, float* ws, uint8_t* flag, float* tgt, float* partial, double* acc,
+                            float* loss, float* scale, double* totals, float* gws, double* acc2, void* stream) {
+  FM_CHECK_ARG(depth && kinv && ext && ext_inv && k && xy && vis && seg && tiles && ws && flag && tgt && partial && acc && loss && scale);
+  FM_CHECK_ARG(ntiles >= 1 && pmax >= 1 && fmax >= 1 && frames >= 1 && mapping_kind >= 0 && mapping_kind <= 2 && depth_frame0 >= 0);
+  FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr) && own_first >= depth_frame0 && own_end >= own_first);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(track_targets_kernel, dim3((frames + 63) / 64), dim3(64), 0, st, ext_inv, k, frames, tgt);
+  return track_loss_launch(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, mapping_kind, delta, aspect_x,
+                           aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
+                           TrackSampling{depth, kinv, depth_frame0, own_first, own_end}, st);
 }
 
 int fm_track_loss_bwd(const double* acc, const double* acc2, const float* scale, const float* upstream, const float* ext_inv,

@@ -301,6 +301,17 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
                       int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* partial,
                       double* acc, float* loss, float* scale, double* totals, float* gws, double* acc2, void* stream);
 
+/* fm_track_points + fm_track_loss_fwd in one call, the sampling done by the pair kernel itself: every wave samples
+ * the points of its own tile's source frames in its prologue and writes ws / flag (outputs here) for its epilogue and
+ * for the backward calls; tgt (frames,12) is an output too.  own_first / own_end: the frames [own_first, own_end)
+ * whose points act as SOURCES here (frame sharding; 0 and `frames` when the whole video is local) — `tiles` lists
+ * the tiles with at least one such frame, other frames of a listed tile get flag = 0. */
+int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first, int own_end, const float* kinv, const float* ext,
+                            const float* ext_inv, const float* k, int frames, const float* xy, const uint8_t* vis, const int32_t* seg,
+                            const int32_t* tiles, int ntiles, int pmax, int fmax, int height, int width, int mapping_kind, float delta,
+                            float aspect_x, float aspect_y, float weight, float* ws, uint8_t* flag, float* tgt, float* partial, double* acc,
+                            float* loss, float* scale, double* totals, float* gws, double* acc2, void* stream);
+
 /* g_ext (F,4,4), g_k (F,3,3) from acc / acc2, multiplied by scale[0]·upstream[0]
  * (upstream NULL = 1). */
 int fm_track_loss_bwd(const double* acc, const double* acc2, const float* scale, const float* upstream, const float* ext_inv,

@@ -1143,6 +1143,32 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
   return 0;
 }
 
+int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first, int own_end, const float* kinv, const float* ext,
+                            const float* ext_inv, const float* k, int frames, const float* xy, const uint8_t* vis, const int32_t* seg,
+                            const int32_t* tiles, int ntiles, int pmax, int fmax, int height, int width, int kind, float delta, float ax,
+                            float ay, float weight, float* ws, uint8_t* flag, float* tgt, float* partial, double* acc, float* loss,
+                            float* scale, double* totals, float* gws, double* acc2, void* stream) {
+  // the (segment, frame) entries of the listed tiles: owned ones are sampled, the others flagged invisible
+  std::vector<int32_t> blocks;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int sg = tiles[tile * 2], fs0 = tiles[tile * 2 + 1];
+    const int start = seg[sg * 4], f = seg[sg * 4 + 1], pc = seg[sg * 4 + 2], off = seg[sg * 4 + 3];
+    for (int fs = fs0; fs < fs0 + FM_TRACK_TILE && fs < f; ++fs) {
+      if (start + fs >= own_first && start + fs < own_end) {
+        blocks.push_back(sg);
+        blocks.push_back(fs);
+      } else {
+        for (int p = 0; p < pc; ++p) flag[(size_t)off + (size_t)fs * pc + p] = 0;
+      }
+    }
+  }
+  if (fm_track_points(depth, depth_frame0, kinv, ext, ext_inv, k, frames, xy, vis, seg, blocks.data(), (int)(blocks.size() / 2), pmax, height,
+                      width, ws, flag, tgt, stream) != 0)
+    return 2;
+  return fm_track_loss_fwd(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, kind, delta, ax, ay, weight,
+                           partial, acc, loss, scale, totals, gws, acc2, stream);
+}
+
 int fm_track_loss_bwd(const double* acc, const double* acc2, const float* scale, const float* upstream, const float* ext_inv,
                       const float* k, const float* kinv, int frames, float* g_ext, float* g_k, void*) {
   const double sc = (double)scale[0] * (upstream ? (double)upstream[0] : 1.0);
