@@ -285,6 +285,14 @@ class ProcrustesFit:
 
     @staticmethod
     def apply(depth, k, surfaces, weights, bwd_flow, indices, weight_sens=0.0, batch_repeat=1):
+        t_bwd, t_fwd, _ext = ProcrustesFit.apply_chained(depth, k, surfaces, weights, bwd_flow, indices, weight_sens, batch_repeat, chain=False)
+        return t_bwd, t_fwd
+
+    @staticmethod
+    def apply_chained(depth, k, surfaces, weights, bwd_flow, indices, weight_sens=0.0, batch_repeat=1, chain=True):
+        """-> (t_bwd, t_fwd, extrinsics or None).  ``chain``: let the fit's own launch chain the poses into the
+        extrinsics (get_extrinsics, projection.py:187-210) when it can — a sparse index set, no repeat; the
+        persistent, self-cleaning workspace this needs is kept on the flow tensor."""
         from_depth = surfaces is None
         rep = int(batch_repeat)
         kinv = sink = wsink = arena = None
@@ -312,8 +320,14 @@ class ProcrustesFit:
                         if use_grad_arena and torch.is_tensor(weights) and weights.requires_grad:
                             arena = grad_arena(weights)
             wsink = weights.__dict__.get("_fm_sink")  # exists when the softmin sweep took LeadingFrames of the weights
-        return torch_ops().procrustes_fit(depth, k, kinv, surfaces, weights, bwd_flow, indices, float(weight_sens), rep, sink, wsink, arena,
-                                          *sparse, *dense)
+        work = None
+        if chain and rep == 1 and indices is not None and bwd_flow.dim() == 5:
+            pairs = bwd_flow.shape[0] * bwd_flow.shape[1]
+            work = _derived(bwd_flow, "_fm_fit_work", (pairs, str(bwd_flow.device)),
+                            lambda: torch.zeros((pairs * STAT_STRIDE + (pairs + 2) // 2 + 1,), dtype=torch.float64, device=bwd_flow.device))
+        t_bwd, t_fwd, ext = torch_ops().procrustes_fit(depth, k, kinv, surfaces, weights, bwd_flow, indices, float(weight_sens), rep, sink, wsink,
+                                                       arena, *sparse, *dense, work)
+        return t_bwd, t_fwd, (ext if ext.numel() > 0 else None)
 
 
 # --------------------------------------------------------------------------------------
@@ -399,8 +413,11 @@ class FlowLossFused:
     def apply(depth, k, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, kind, delta, carry, items, packed=None):
         kinv = intrinsics_inverse(k)
         sink = depth_sink(depth) if carry else None
+        # the per-(frame, direction) fp64 sums: a workspace kept on the mask tensor, zeroed once (the finalize launch leaves it zero)
+        size = depth.shape[0] * depth.shape[1] * 2 * FLOW_ACC_STRIDE if depth.dim() == 4 else 0
+        acc = _derived(mask_fwd, "_fm_flow_acc", (size, str(depth.device)), lambda: torch.zeros((size,), dtype=torch.float64, device=depth.device))
         return torch_ops().flow_loss(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, int(kind), float(delta),
-                                     sink, int(items))
+                                     sink, int(items), acc)
 
 
 class SoftminScore(torch.autograd.Function):

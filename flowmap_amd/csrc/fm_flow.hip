@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
 // One thread per frame; loss summed by thread 0 of block 0 (B·F ≤ a few thousand).
 // ---------------------------------------------------------------------------------
 struct FlowFinalizeParams {
-  const double* acc;
+  double* acc;
   const float* k;
   const float* kinv;
   const float* t_fwd;
@@ -295,18 +295,20 @@ struct FlowFinalizeParams {
   float ax, ay;
 };
 
-__global__ void flow_finalize_kernel(FlowFinalizeParams p) {
-  const int bf = blockIdx.x * blockDim.x + threadIdx.x;
+// ONE block (frames read each other's sums — a frame's dL/dK has a destination-role part from its neighbours —
+// so the clearing of `acc` must wait for every frame: a block-wide barrier).
+__global__ void __launch_bounds__(256) flow_finalize_kernel(FlowFinalizeParams p) {
   const int total = p.batch * p.frames;
-  if (bf < total) flow_finalize_frame(p.acc, p.k, p.kinv, p.t_fwd, p.t_bwd, p.batch, p.frames, bf, p.ax, p.ay, p.g_t_fwd, p.g_t_bwd, p.g_k);
-  if (blockIdx.x == 0) {
-    // loss numerator: sum over all (frame, direction) in fp64 by one wave
-    double s = 0.0;
-    if (threadIdx.x < kWave)
-      for (int i = threadIdx.x; i < total * 2; i += kWave) s += p.acc[(size_t)i * kFlowAccStride];
-    if (threadIdx.x < kWave) s = wave_sum(s);
-    if (threadIdx.x == 0) p.loss[0] = (float)(s * (double)p.norm[0]);
-  }
+  for (int bf = threadIdx.x; bf < total; bf += blockDim.x)
+    flow_finalize_frame(p.acc, p.k, p.kinv, p.t_fwd, p.t_bwd, p.batch, p.frames, bf, p.ax, p.ay, p.g_t_fwd, p.g_t_bwd, p.g_k);
+  // loss numerator: sum over all (frame, direction) in fp64 by one wave
+  double s = 0.0;
+  if (threadIdx.x < kWave)
+    for (int i = threadIdx.x; i < total * 2; i += kWave) s += p.acc[(size_t)i * kFlowAccStride];
+  if (threadIdx.x < kWave) s = wave_sum(s);
+  if (threadIdx.x == 0) p.loss[0] = (float)(s * (double)p.norm[0]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < total * 2 * kFlowAccStride; i += blockDim.x) p.acc[i] = 0.0;  // clean for the next launch
 }
 
 // ---------------------------------------------------------------------------------
@@ -398,7 +400,8 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   const bool grad = scale != nullptr;
   FlowParams p{depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, grad_depth, acc,
                frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 4};
-  if (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride, st) != hipSuccess) return FM_ERR_LAUNCH;
+  // (`acc` is zero on entry: fm_flow_loss_finalize clears what it has read, so a workspace kept across steps never
+  // needs a memset launch)
   auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool use_packed = packed != nullptr;
   FM_CHECK_ARG(!use_packed || (width % 4 == 0 && aligned(packed) && aligned(depth) && (!grad_depth || aligned(grad_depth))));
@@ -453,13 +456,12 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   FM_LAUNCH_STATUS();
 }
 
-int fm_flow_loss_finalize(const double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+int fm_flow_loss_finalize(double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
                           const float* norm, int batch, int frames, float aspect_x, float aspect_y, float* loss, float* g_t_fwd,
                           float* g_t_bwd, float* g_k, void* stream) {
   FM_CHECK_ARG(acc && k && kinv && t_fwd && t_bwd && norm && loss && g_t_fwd && g_t_bwd && g_k);
   FlowFinalizeParams p{acc, k, kinv, t_fwd, t_bwd, norm, loss, g_t_fwd, g_t_bwd, g_k, batch, frames, aspect_x, aspect_y};
-  const int total = batch * frames;
-  hipLaunchKernelGGL(flow_finalize_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(flow_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
   FM_LAUNCH_STATUS();
 }
 

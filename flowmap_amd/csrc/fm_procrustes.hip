@@ -76,9 +76,77 @@ __device__ __forceinline__ void pair_shift(const ProcParams& p, const CorrSrc& s
   later_point(src, kinv_l, p.indices ? (int)p.indices[mid] : (int)mid, s);
 }
 
+// get_extrinsics for one batch element by ONE wave of a block whose 256 threads all call this (the barriers are
+// block-wide): chunk products, Hillis-Steele scan over 64 chunks in LDS, re-walk (as pose_chain_fwd_kernel).
+__device__ __forceinline__ void pose_chain_by_wave0(const float* r, int steps, float* e, double (*buf)[64][16]) {
+  const int t = threadIdx.x;
+  const bool on = t < 64;
+  const int chunk = (steps + 63) / 64;
+  const int lo = t * chunk, hi = min(steps, lo + chunk);
+  double prod[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  if (on) {
+    for (int s = lo; s < hi; ++s) {
+      double m[16], nxt[16];
+      for (int k = 0; k < 16; ++k) m[k] = r[(size_t)s * 16 + k];
+      mat4_mul(prod, m, nxt);
+      for (int k = 0; k < 16; ++k) prod[k] = nxt[k];
+    }
+    for (int k = 0; k < 16; ++k) buf[0][t][k] = prod[k];
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int off = 1; off < 64; off <<= 1) {
+    if (on) {
+      double mine[16], out[16];
+      for (int k = 0; k < 16; ++k) mine[k] = buf[cur][t][k];
+      if (t >= off) {
+        double left[16];
+        for (int k = 0; k < 16; ++k) left[k] = buf[cur][t - off][k];
+        mat4_mul(left, mine, out);
+      } else {
+        for (int k = 0; k < 16; ++k) out[k] = mine[k];
+      }
+      for (int k = 0; k < 16; ++k) buf[cur ^ 1][t][k] = out[k];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (on) {
+    double run[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (t > 0) {
+      for (int k = 0; k < 16; ++k) run[k] = buf[cur][t - 1][k];
+    } else {
+      for (int k = 0; k < 16; ++k) e[k] = (float)run[k];  // E_0 = I
+    }
+    for (int s = lo; s < hi; ++s) {
+      double m[16], nxt[16];
+      for (int k = 0; k < 16; ++k) m[k] = r[(size_t)s * 16 + k];
+      mat4_mul(run, m, nxt);
+      for (int k = 0; k < 16; ++k) {
+        run[k] = nxt[k];
+        e[(size_t)(s + 1) * 16 + k] = (float)nxt[k];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// What fm_procrustes_fit_chain adds to the moments kernel: the LAST block of a pair (a counter per pair) turns the
+// pair's sums into its pose, clears the sums and the counter for the next step (the workspace is persistent and
+// self-cleaning: no memset launch), and the last pair to finish (one more counter) chains the poses into the
+// extrinsics — moments, finish + solve and get_extrinsics in one launch instead of a memset and three kernels.
+struct FitChain {
+  int* counters;  // (pairs + 1) ints, zero between launches; null = plain moments kernel
+  float* t_bwd;
+  float* t_fwd;
+  double* aux;
+  float* ext;     // (B, F, 4, 4)
+  int batch;
+};
+
 // grid: (chunks, B*(F-1)): raw moments of every correspondence into stats[0..15] (fp64 atomics).
 template <int SRC>
-__global__ void __launch_bounds__(256) procrustes_moments_kernel(ProcParams p, int iters) {
+__global__ void __launch_bounds__(256) procrustes_moments_kernel(ProcParams p, int iters, FitChain fc) {
   __shared__ double red[4 * kMomentCount];
   const size_t pair = blockIdx.y;
   const int b = (int)(pair / (p.frames - 1));
@@ -101,6 +169,36 @@ __global__ void __launch_bounds__(256) procrustes_moments_kernel(ProcParams p, i
     moments_add(corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j), shift, acc);
   }
   block_accumulate<kMomentCount>(acc, red, p.stats + pair * kStatStride);
+  if (fc.counters == nullptr) return;
+  // ---- fused tail (block-uniform branches) ----
+  __shared__ int last_of_pair, last_of_all;
+  __shared__ double chain_buf[2][64][16];
+  if (threadIdx.x == 0) {
+    __threadfence();  // this block's sums are visible before the counter says so
+    last_of_pair = atomicAdd(fc.counters + pair, 1) == (int)gridDim.x - 1;
+    last_of_all = 0;
+    if (last_of_pair) {
+      __threadfence();  // see the other blocks' sums
+      double* st = p.stats + pair * kStatStride;
+      double local[kStatStride];
+      for (int k = 0; k < kStatStride; ++k) {
+        local[k] = __hip_atomic_load(st + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st[k] = 0.0;  // clean for the next launch
+      }
+      fc.counters[pair] = 0;
+      moments_finish(local, shift);
+      pose_solve_one(local, fc.t_bwd + pair * 16, fc.t_fwd ? fc.t_fwd + pair * 16 : nullptr, fc.aux + pair * kAuxStride);
+      __threadfence();  // the pose is visible before the global counter says so
+      const int pairs = (int)gridDim.y;
+      last_of_all = atomicAdd(fc.counters + pairs, 1) == pairs - 1;
+      if (last_of_all) fc.counters[pairs] = 0;
+    }
+  }
+  __syncthreads();
+  if (!last_of_all || fc.ext == nullptr) return;
+  __threadfence();  // see every pair's pose
+  for (int bb = 0; bb < fc.batch; ++bb)
+    pose_chain_by_wave0(fc.t_bwd + (size_t)bb * (p.frames - 1) * 16, p.frames - 1, fc.ext + (size_t)bb * p.frames * 16, chain_buf);
 }
 
 // One thread per pair: raw moments -> (Σw, Σw·p, Σw·q, M) in place.
@@ -1163,9 +1261,9 @@ static int procrustes_stats_launch(const float* depth, const float* kinv, const 
     const long total = dense_blocks(height, width, pairs);
     hipLaunchKernelGGL(procrustes_moments_dense_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, (unsigned)total);
   } else if (surfaces) {
-    hipLaunchKernelGGL((procrustes_moments_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, iters);
+    hipLaunchKernelGGL((procrustes_moments_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, iters, FitChain{});
   } else {
-    hipLaunchKernelGGL((procrustes_moments_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, iters);
+    hipLaunchKernelGGL((procrustes_moments_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, iters, FitChain{});
   }
   if (dense) {  // pixel-space sums: intrinsics applied here, then the solve (t_bwd may be null: statistics only)
     hipLaunchKernelGGL(procrustes_finish_solve_dense_kernel, fgrid, dim3(64), 0, st, p, pairs, t_bwd, t_fwd, aux);
@@ -1200,6 +1298,26 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
   FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
   return procrustes_stats_launch(depth, kinv, surfaces, bwd_flow, weights, weight_sensitivity, indices, points, batch, batch_repeat,
                                  frames, height, width, stats, t_bwd, t_fwd, aux, (hipStream_t)stream);
+}
+
+int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                            float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, void* stream) {
+  FM_CHECK_ARG((depth && kinv) || surfaces);
+  FM_CHECK_ARG(bwd_flow && weights && work && t_bwd && aux && ext && points >= 1 && batch >= 1 && frames >= 2);
+  FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
+  const int pairs = batch * (frames - 1);
+  ProcParams p{};
+  p.depth = depth; p.kinv = kinv; p.surfaces = surfaces; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
+  p.stats = work; p.frames = frames; p.height = height; p.width = width; p.points = points;
+  p.weight_sens = weight_sensitivity;
+  p.batch_repeat = 1;
+  FitChain fc{reinterpret_cast<int*>(work + (size_t)pairs * kStatStride), t_bwd, t_fwd, aux, ext, batch};
+  const int iters = choose_iters(points);
+  dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
+  if (surfaces) hipLaunchKernelGGL((procrustes_moments_kernel<SRC_SURF>), grid, dim3(256), 0, (hipStream_t)stream, p, iters, fc);
+  else hipLaunchKernelGGL((procrustes_moments_kernel<SRC_DEPTH>), grid, dim3(256), 0, (hipStream_t)stream, p, iters, fc);
+  FM_LAUNCH_STATUS();
 }
 
 int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux, void* stream) {

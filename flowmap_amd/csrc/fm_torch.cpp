@@ -46,7 +46,7 @@ using OptTensor = std::optional<Tensor>;
 #define FM_API_LIST(X)                                                                                                                    \
   X(fm_flow_loss_fused) X(fm_flow_loss_finalize) X(fm_scale_if_needed) X(fm_intrinsics_inverse) X(fm_intrinsics_inverse_bwd)              \
   X(fm_focal_intrinsics_fwd) X(fm_focal_intrinsics_bwd) X(fm_pose_chain_fwd) X(fm_pose_chain_bwd) X(fm_relative_pose_fwd)                  \
-  X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_pose_solve_bwd) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense)                \
+  X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense)                \
   X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_loss_fused_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
   X(fm_adam_step_capturable)
 
@@ -158,6 +158,8 @@ struct DepthSink : torch::CustomClassHolder {
   int64_t depth_version = -1;
   std::vector<int64_t> depth_sizes;
   Tensor carried;                                         // dense gradient parked by the flow loss
+  Tensor carried_k;                                       // ... and its dL/dK (B,F,3,3): the fit adds its own part into it
+  const void* k_ptr = nullptr;                            // identity of the K tensor the fit was given
   std::vector<std::function<void(Tensor&)>> pending;      // sparse scatters into the final buffer (tracking loss)
   // what the fit returned for this tensor, WEAKLY (a strong reference would make AccumulateGrad deep-copy the
   // 553 MB gradient instead of adopting it): LeadingFrames adds its frames into it while autograd still holds it
@@ -351,7 +353,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                                const c10::intrusive_ptr<DepthSink>& wsink, const c10::intrusive_ptr<GradArena>& arena,
                                const OptTensor& plan_pixels, const OptTensor& plan_first, const OptTensor& plan_vectors,
                                const OptTensor& plan_weights, const OptTensor& dense_first, const OptTensor& dense_list,
-                               bool grad_enabled) {  // (forward runs with grad mode off: the caller's mode is passed in)
+                               const OptTensor& work_o, bool grad_enabled) {  // (forward runs with grad mode off: the caller's mode is passed in)
     Tensor depth = opt(depth_o), k = opt(k_o), kinv = opt(kinv_o), surfaces = opt(surfaces_o), indices = opt(indices_o);
     const bool from_depth = !surfaces.defined();
     {  // edge index of depth / k / surfaces / weights among the present tensor arguments
@@ -392,17 +394,29 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       points = indices.numel();
     }
     const int64_t pairs = b * (f - 1);
-    Tensor stats = at::empty({pairs, FM_STAT_STRIDE}, weights.options().dtype(at::kDouble));
     Tensor aux = at::empty({pairs, FM_AUX_STRIDE}, weights.options().dtype(at::kDouble));
     Tensor t_bwd = empty_like_shape({b, f - 1, 4, 4}, weights), t_fwd = empty_like_shape({b, f - 1, 4, 4}, weights);
+    // With a persistent workspace (sparse index set, no repeat): moments, finish + solve and the pose chain in ONE launch
+    Tensor work = opt(work_o), ext;
+    const bool chained = work.defined() && indices.defined() && rep == 1;
     {
       DeviceScope scope(dev);
-      FM_CALL(fm_procrustes_fit, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights), (float)weight_sens,
-              ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(stats), ptr(t_bwd), ptr(t_fwd),
-              ptr<double>(aux), scope.stream);
+      if (chained) {
+        TORCH_CHECK(work.scalar_type() == at::kDouble && work.is_contiguous() && work.numel() >= pairs * FM_STAT_STRIDE + (pairs + 2) / 2 + 1,
+                    "flowmap_amd: the fit workspace is too small");
+        ext = empty_like_shape({b, f, 4, 4}, weights);
+        FM_CALL(fm_procrustes_fit_chain, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights),
+                (float)weight_sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(work), ptr(t_bwd), ptr(t_fwd),
+                ptr<double>(aux), ptr(ext), scope.stream);
+      } else {
+        Tensor stats = at::empty({pairs, FM_STAT_STRIDE}, weights.options().dtype(at::kDouble));
+        FM_CALL(fm_procrustes_fit, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights), (float)weight_sens,
+                ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(stats), ptr(t_bwd), ptr(t_fwd),
+                ptr<double>(aux), scope.stream);
+      }
     }
     ctx->save_for_backward({from_depth ? depth : surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux, opt(plan_pixels), opt(plan_first),
-                            opt(plan_vectors), opt(plan_weights), opt(dense_first), opt(dense_list)});
+                            opt(plan_vectors), opt(plan_weights), opt(dense_first), opt(dense_list), ext});
     ctx->saved_data["dims"] = std::vector<int64_t>{b, f, h, w, points, rep, from_depth ? 1 : 0};
     ctx->saved_data["weight_sens"] = weight_sens;
     if (sink) ctx->saved_data["sink"] = sink;
@@ -412,8 +426,12 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       wsink->depth_ptr = weights_in.data_ptr();
       wsink->depth_version = (int64_t)weights_in._version();
     }
-    if (sink && from_depth && rep == 1 && depth.requires_grad() && grad_enabled) sink->arm(depth);
-    return {t_bwd, t_fwd};
+    if (sink && from_depth && rep == 1 && depth.requires_grad() && grad_enabled) {
+      sink->arm(depth);
+      sink->k_ptr = (k_o.has_value() && k_o->requires_grad()) ? k.data_ptr() : nullptr;
+    }
+    if (!chained) ext = at::empty({0}, weights.options());  // placeholder output: the caller chains the poses itself
+    return {t_bwd, t_fwd, ext};
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -421,7 +439,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     const Tensor &src = saved[0], &kinv = saved[1], &weights = saved[2], &bwd_flow = saved[3], &indices = saved[4], &t_bwd = saved[5],
                  &aux = saved[6];
     const Tensor &plan_pixels = saved[7], &plan_first = saved[8], &plan_vectors = saved[9], &plan_weights = saved[10],
-                 &dense_first = saved[11], &dense_list = saved[12];
+                 &dense_first = saved[11], &dense_list = saved[12], &ext = saved[13];
     const auto dims = ctx->saved_data["dims"].toIntVector();
     const int64_t b = dims[0], f = dims[1], h = dims[2], w = dims[3], points = dims[4], rep = dims[5];
     const bool from_depth = dims[6] != 0;
@@ -431,8 +449,15 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     auto wsink = ctx->saved_data.count("wsink") ? ctx->saved_data["wsink"].toCustomClass<DepthSink>() : c10::intrusive_ptr<DepthSink>();
     const int64_t pairs = b * (f - 1);
     const auto dev = weights.device();
-    const Tensor g_t = grads[0].defined() ? f32c(grads[0], "grad") : Tensor();
+    Tensor g_t = grads[0].defined() ? f32c(grads[0], "grad") : Tensor();
     const Tensor g_t_fwd = grads[1].defined() ? f32c(grads[1], "grad") : Tensor();
+    if (grads.size() > 2 && grads[2].defined() && ext.defined() && ext.numel() > 0) {  // the chain's backward (get_extrinsics), then summed into dL/dT
+      const Tensor g_ext = f32c(grads[2], "grad");
+      Tensor g_rel = at::empty_like(t_bwd);
+      DeviceScope scope(weights.device());
+      FM_CALL(fm_pose_chain_bwd, ptr(t_bwd), ptr(ext), ptr(g_ext), (int)b, (int)(f - 1), ptr(g_rel), scope.stream);
+      g_t = g_t.defined() ? g_t + g_rel : g_rel;
+    }
     const auto edges = ctx->saved_data["edges"].toIntVector();  // depth, k, surfaces, weights
     const bool need_src = ctx->needs_input_grad(from_depth ? edges[0] : edges[2]);
     const bool need_k = from_depth && ctx->needs_input_grad(edges[1]);
@@ -441,11 +466,13 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     Tensor g_src, g_k, g_w;
 
     // The dense dL/ddepth: what the losses parked (the sink is armed only for depth-sourced, un-repeated fits)
-    Tensor carried;
+    Tensor carried, carried_k;
     std::vector<std::function<void(Tensor&)>> pending;
     if (sink) {
       carried = std::move(sink->carried);
       sink->carried = Tensor();
+      carried_k = std::move(sink->carried_k);
+      sink->carried_k = Tensor();
       pending.swap(sink->pending);
       sink->active = false;
     }
@@ -479,21 +506,25 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                 sens, ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(aux), ptr<double>(pair_grad),
                 from_depth ? ptr(g_src) : nullptr, from_depth ? nullptr : ptr(g_src), ptr(g_w), ptr<double>(kinv_acc), ptr(point_grads),
                 nullptr, scope.stream);
-        if (point_grads.defined()) {  // the planned scatter runs as a gather: one plain read-modify-write per touched pixel
-          FM_CALL(fm_depth_gather, ptr(point_grads), ptr<int64_t>(plan_pixels), ptr<int32_t>(plan_first), ptr<int32_t>(plan_vectors),
-                  ptr(plan_weights), (long)plan_pixels.numel(), ptr(kinv), nullptr, nullptr, (int)h, (int)w, 0L, ptr(g_src), scope.stream);
-          if (sink) ++sink->planned_steps;
-        }
       }
-      if (need_k) {
-        g_k = at::empty_like(kinv);
-        FM_CALL(fm_intrinsics_inverse_bwd, ptr<double>(kinv_acc), ptr(kinv), (int)(b * f), ptr(g_k), 0, scope.stream);
+      // dL/dK = −K⁻ᵀ·dK⁻¹·K⁻ᵀ, added to the flow loss's own dL/dK when that was parked here (one gradient for autograd,
+      // no separate add); with a planned scatter it rides in the gather's launch
+      const bool add_k = need_k && carried_k.defined() && carried_k.sizes() == kinv.sizes() && carried_k.is_contiguous();
+      if (need_k) g_k = add_k ? carried_k : at::empty_like(kinv);
+      if (point_grads.defined()) {  // the planned scatter runs as a gather: one plain read-modify-write per touched pixel
+        FM_CALL(fm_depth_gather_kgrad, ptr(point_grads), ptr<int64_t>(plan_pixels), ptr<int32_t>(plan_first), ptr<int32_t>(plan_vectors),
+                ptr(plan_weights), (long)plan_pixels.numel(), ptr(kinv), (int)h, (int)w, ptr(g_src), ptr<double>(kinv_acc),
+                need_k ? (int)(b * f) : 0, ptr(g_k), add_k ? 1 : 0, scope.stream);
+        if (sink) ++sink->planned_steps;
+      } else if (need_k) {
+        FM_CALL(fm_intrinsics_inverse_bwd, ptr<double>(kinv_acc), ptr(kinv), (int)(b * f), ptr(g_k), add_k ? 1 : 0, scope.stream);
       }
+      if (carried_k.defined() && !add_k) g_k = g_k.defined() ? g_k + carried_k : carried_k;  // (unexpected layout: plain sum)
     }
     if (arena_used) g_w = arena->alias();
     if (sink) sink->note_final(g_src);
     if (wsink) wsink->note_final(g_w);
-    variable_list out(19);
+    variable_list out(20);
     if (from_depth) {
       out[0] = g_src;
       out[1] = g_k;
@@ -534,11 +565,14 @@ struct FlowLaunch {
 
 static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& t_fwd, const Tensor& t_bwd,
                               const Tensor& flow_fwd, const Tensor& flow_bwd, const Tensor& mask_fwd, const Tensor& mask_bwd, const Tensor& norm,
-                              const Tensor& packed, int64_t kind, double delta, int64_t items, bool need, bool need_depth) {
+                              const Tensor& packed, int64_t kind, double delta, int64_t items, bool need, bool need_depth, const Tensor& acc_work) {
   const int64_t b = depth.size(0), f = depth.size(1), h = depth.size(2), w = depth.size(3);
   const auto dev = depth.device();
   FlowLaunch o;
-  Tensor acc = at::empty({b * f * 2 * FM_FLOW_ACC_STRIDE}, depth.options().dtype(at::kDouble));
+  // the per-(frame, direction) sums: a persistent workspace the finalize launch leaves zero, or fresh zeros
+  const bool persistent = acc_work.defined() && acc_work.scalar_type() == at::kDouble && acc_work.is_contiguous() &&
+                          acc_work.numel() == b * f * 2 * FM_FLOW_ACC_STRIDE && acc_work.device() == dev;
+  Tensor acc = persistent ? acc_work : at::zeros({b * f * 2 * FM_FLOW_ACC_STRIDE}, depth.options().dtype(at::kDouble));
   o.loss = at::empty({1}, depth.options());
   if (need && need_depth) o.g_depth = at::empty_like(depth);
   // the three small gradients share one allocation so one launch rescales them in backward
@@ -572,7 +606,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
   static Tensor forward(AutogradContext* ctx, const Tensor& depth_in, const Tensor& k_in, const Tensor& kinv_in, const Tensor& t_fwd_in,
                         const Tensor& t_bwd_in, const Tensor& flow_fwd_in, const Tensor& flow_bwd_in, const Tensor& mask_fwd_in,
                         const Tensor& mask_bwd_in, const Tensor& norm, const OptTensor& packed_o, int64_t kind, double delta,
-                        const c10::intrusive_ptr<DepthSink>& sink, int64_t items, bool grad_enabled, bool park) {
+                        const c10::intrusive_ptr<DepthSink>& sink, int64_t items, const OptTensor& acc_work, bool grad_enabled, bool park) {
     check_device({&depth_in, &k_in, &kinv_in, &t_fwd_in, &t_bwd_in, &flow_fwd_in, &flow_bwd_in, &mask_fwd_in, &mask_bwd_in, &norm});
     const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics");
     const Tensor t_fwd = f32c(t_fwd_in, "forward poses"), t_bwd = f32c(t_bwd_in, "backward poses");
@@ -596,8 +630,9 @@ struct FlowLossFused : public Function<FlowLossFused> {
                   "flowmap_amd: packed flow inputs do not match the depth shape");
     const bool need = grad_enabled && (depth_in.requires_grad() || k_in.requires_grad() || t_fwd_in.requires_grad() || t_bwd_in.requires_grad());
     FlowLaunch run = flow_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, items, need,
-                                 depth_in.requires_grad());
+                                 depth_in.requires_grad(), opt(acc_work));
     ctx->save_for_backward({depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed});
+    ctx->saved_data["acc_work"] = opt(acc_work);
     ctx->saved_data["cfg"] = std::vector<int64_t>{kind, items};
     ctx->saved_data["delta"] = delta;
     if (sink && park) ctx->saved_data["sink"] = sink;
@@ -608,7 +643,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    variable_list out(17);
+    variable_list out(18);
     if (!grads[0].defined()) return out;
     const auto saved = ctx->get_saved_variables();
     const Tensor &depth = saved[0], &k = saved[1], &t_fwd = saved[3];
@@ -622,7 +657,8 @@ struct FlowLossFused : public Function<FlowLossFused> {
     } else {  // a second backward through a retained graph: one more pass from the saved inputs
       const auto cfg = ctx->saved_data["cfg"].toIntVector();
       FlowLaunch run = flow_launch(saved[0], saved[1], saved[2], saved[3], saved[4], saved[5], saved[6], saved[7], saved[8], saved[9], saved[10],
-                                   cfg[0], ctx->saved_data["delta"].toDouble(), cfg[1], true, ctx->needs_input_grad(0));
+                                   cfg[0], ctx->saved_data["delta"].toDouble(), cfg[1], true, ctx->needs_input_grad(0),
+                                   ctx->saved_data["acc_work"].isTensor() ? ctx->saved_data["acc_work"].toTensor() : Tensor());
       g_depth = run.g_depth;
       small = run.small;
     }
@@ -640,7 +676,11 @@ struct FlowLossFused : public Function<FlowLossFused> {
     }
     const int64_t nt = t_fwd.numel();
     if (ctx->needs_input_grad(0)) out[0] = g_depth;
-    if (ctx->needs_input_grad(1)) out[1] = small.narrow(0, 2 * nt, k.numel()).view_as(k);
+    if (ctx->needs_input_grad(1)) {
+      Tensor g_k = small.narrow(0, 2 * nt, k.numel()).view_as(k);
+      if (sink && sink->active && sink->k_ptr == k.data_ptr() && !sink->carried_k.defined()) sink->carried_k = g_k;  // the fit adds its part and returns the sum
+      else out[1] = g_k;
+    }
     if (ctx->needs_input_grad(3)) out[3] = small.narrow(0, 0, nt).view_as(t_fwd);
     if (ctx->needs_input_grad(4)) out[4] = small.narrow(0, nt, nt).view_as(t_fwd);
     return out;
@@ -896,25 +936,25 @@ using OptSink = std::optional<c10::intrusive_ptr<DepthSink>>;
 using OptArena = std::optional<c10::intrusive_ptr<GradArena>>;
 static c10::intrusive_ptr<DepthSink> sink_of(const OptSink& s) { return s.has_value() ? *s : c10::intrusive_ptr<DepthSink>(); }
 
-static std::tuple<Tensor, Tensor> procrustes_fit_op(const OptTensor& depth, const OptTensor& k, const OptTensor& kinv, const OptTensor& surfaces,
+static std::tuple<Tensor, Tensor, Tensor> procrustes_fit_op(const OptTensor& depth, const OptTensor& k, const OptTensor& kinv, const OptTensor& surfaces,
                                                     const Tensor& weights, const Tensor& bwd_flow, const OptTensor& indices, double weight_sens,
                                                     int64_t batch_repeat, const OptSink& sink, const OptSink& wsink, const OptArena& arena,
                                                     const OptTensor& plan_pixels,
                                                     const OptTensor& plan_first, const OptTensor& plan_vectors, const OptTensor& plan_weights,
-                                                    const OptTensor& dense_first, const OptTensor& dense_list) {
+                                                    const OptTensor& dense_first, const OptTensor& dense_list, const OptTensor& work) {
   auto out = ProcrustesFit::apply(depth, k, kinv, surfaces, weights, bwd_flow, indices, weight_sens, batch_repeat, sink_of(sink), sink_of(wsink),
                                   arena.has_value() ? *arena : c10::intrusive_ptr<GradArena>(), plan_pixels, plan_first, plan_vectors, plan_weights,
-                                  dense_first, dense_list, at::GradMode::is_enabled());
+                                  dense_first, dense_list, work, at::GradMode::is_enabled());
   if (sink.has_value() && *sink) (*sink)->fit_node = out[0].grad_fn().get();  // null when no graph is being built
-  return {out[0], out[1]};
+  return {out[0], out[1], out[2]};
 }
 static Tensor flow_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& t_fwd, const Tensor& t_bwd, const Tensor& flow_fwd,
                            const Tensor& flow_bwd, const Tensor& mask_fwd, const Tensor& mask_bwd, const Tensor& norm, const OptTensor& packed,
-                           int64_t kind, double delta, const OptSink& sink, int64_t items) {
+                           int64_t kind, double delta, const OptSink& sink, int64_t items, const OptTensor& acc_work) {
   auto s = sink_of(sink);
   // park dL/ddepth in the sink only when both pose tensors come from the fit that armed it: that node then runs after this one
   const bool park = s && s->fit_node != nullptr && reaches(t_fwd.grad_fn(), s->fit_node, 3) && reaches(t_bwd.grad_fn(), s->fit_node, 3);
-  return FlowLossFused::apply(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, s, items,
+  return FlowLossFused::apply(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, s, items, acc_work,
                               at::GradMode::is_enabled(), park);
 }
 static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& ext, const Tensor& xy,
@@ -957,11 +997,12 @@ TORCH_LIBRARY(flowmap_amd, m) {
       "procrustes_fit(Tensor? depth, Tensor? k, Tensor? kinv, Tensor? surfaces, Tensor weights, Tensor bwd_flow, Tensor? indices, float weight_sens, "
       "int batch_repeat, __torch__.torch.classes.flowmap_amd.DepthSink? sink, __torch__.torch.classes.flowmap_amd.DepthSink? wsink, "
       "__torch__.torch.classes.flowmap_amd.GradArena? arena, "
-      "Tensor? plan_pixels, Tensor? plan_first, Tensor? plan_vectors, Tensor? plan_weights, Tensor? dense_first, Tensor? dense_list) -> (Tensor, Tensor)",
+      "Tensor? plan_pixels, Tensor? plan_first, Tensor? plan_vectors, Tensor? plan_weights, Tensor? dense_first, Tensor? dense_list, Tensor? work) "
+      "-> (Tensor, Tensor, Tensor)",
       fmt::procrustes_fit_op);
   m.def(
       "flow_loss(Tensor depth, Tensor k, Tensor kinv, Tensor t_fwd, Tensor t_bwd, Tensor flow_fwd, Tensor flow_bwd, Tensor mask_fwd, Tensor mask_bwd, "
-      "Tensor norm, Tensor? packed, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int items) -> Tensor",
+      "Tensor norm, Tensor? packed, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int items, Tensor? acc_work) -> Tensor",
       fmt::flow_loss_op);
   m.def(
       "track_loss(Tensor depth, Tensor k, Tensor kinv, Tensor ext, Tensor xy, Tensor vis, Tensor seg, Tensor blocks, Tensor tiles, int[] counts, "

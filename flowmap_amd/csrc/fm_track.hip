@@ -495,6 +495,42 @@ __global__ void __launch_bounds__(256) depth_gather_kernel(const float* vectors,
   grad_depth[(size_t)(frame - frame0) * n + px] += sum;
 }
 
+// The planned gather (scale = upstream = 1, frame0 = 0) with the map of the K⁻¹ gradient back to K in the same launch:
+// the blocks past the gather's do dK = [g_k] − K⁻ᵀ·dK⁻¹·K⁻ᵀ for 64 frames each.
+__global__ void __launch_bounds__(256) depth_gather_kgrad_kernel(const float* vectors, const int64_t* pixels, const int32_t* first,
+                                                                 const int32_t* entries, const float* weights, long count, const float* kinv,
+                                                                 int height, int width, float* grad_depth, unsigned gather_blocks,
+                                                                 const double* kinv_acc, int frames_k, float* g_k, int accumulate) {
+  if (blockIdx.x >= gather_blocks) {
+    const int i = (int)(blockIdx.x - gather_blocks) * 64 + (int)threadIdx.x;
+    if (threadIdx.x >= 64 || i >= frames_k) return;
+    double gk[9];
+    kinv_grad_to_k(kinv_acc + (size_t)i * 9, kinv + (size_t)i * 9, gk);
+    for (int e = 0; e < 9; ++e) {
+      float* o = g_k + (size_t)i * 9 + e;
+      *o = (accumulate ? *o : 0.f) + (float)gk[e];
+    }
+    return;
+  }
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= count) return;
+  const int64_t n = (int64_t)height * width;
+  const int64_t key = pixels[m];
+  const int64_t frame = key / n;
+  const int px = (int)(key - frame * n);
+  const int row = px / width, col = px - row * width;
+  Mat3 ki;
+  load_mat3(kinv + (size_t)frame * 9, ki);
+  float ray[3];
+  ray_dir(ki, pixel_center(col, width), pixel_center(row, height), ray);
+  float sum = 0.f;
+  for (int e = first[m]; e < first[m + 1]; ++e) {
+    const float* v = vectors + (size_t)entries[e] * 3;
+    sum += weights[e] * (v[0] * ray[0] + v[1] * ray[1] + v[2] * ray[2]);
+  }
+  grad_depth[(size_t)frame * n + px] += sum;
+}
+
 // dL/dE and dL/dK per frame from the two accumulators.
 __global__ void track_finalize_bwd_kernel(const double* acc, const double* acc2, const float* scale, const float* upstream,
                                           const float* ext_inv, const float* k, const float* kinv, int frames, float* g_ext,
@@ -626,6 +662,18 @@ int fm_depth_gather(const float* vectors, const int64_t* pixels, const int32_t* 
   if (count == 0) return FM_OK;
   hipLaunchKernelGGL(depth_gather_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vectors, pixels, first,
                      entries, weights, count, kinv, scale, upstream, height, width, frame0, grad_depth);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_depth_gather_kgrad(const float* vectors, const int64_t* pixels, const int32_t* first, const int32_t* entries, const float* weights,
+                          long count, const float* kinv, int height, int width, float* grad_depth, const double* kinv_acc, int frames_k,
+                          float* g_k, int accumulate, void* stream) {
+  FM_CHECK_ARG(kinv && count >= 0 && frames_k >= 0 && (count == 0 || (vectors && pixels && first && entries && weights && grad_depth)));
+  FM_CHECK_ARG(frames_k == 0 || (kinv_acc && g_k));
+  const unsigned gather_blocks = (unsigned)((count + 255) / 256), k_blocks = (unsigned)((frames_k + 63) / 64);
+  if (gather_blocks + k_blocks == 0) return FM_OK;
+  hipLaunchKernelGGL(depth_gather_kgrad_kernel, dim3(gather_blocks + k_blocks), dim3(256), 0, (hipStream_t)stream, vectors, pixels, first, entries,
+                     weights, count, kinv, height, width, grad_depth, gather_blocks, kinv_acc, frames_k, g_k, accumulate);
   FM_LAUNCH_STATUS();
 }
 

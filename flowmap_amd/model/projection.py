@@ -428,10 +428,11 @@ def align_surfaces(surfaces, backward_flows: Tensor, backward_weights: Tensor, i
         else:
             backward_weights = backward_weights.materialize()
     if isinstance(surfaces, LazySurfaces):
-        rel, rel_inv = _ops.ProcrustesFit.apply(surfaces.depths, surfaces.intrinsics, None, backward_weights, backward_flows, idx, sens)
+        rel, rel_inv, extrinsics = _ops.ProcrustesFit.apply_chained(surfaces.depths, surfaces.intrinsics, None, backward_weights, backward_flows, idx, sens)
     else:
-        rel, rel_inv = _ops.ProcrustesFit.apply(None, None, surfaces, backward_weights, backward_flows, idx, sens)
-    extrinsics = _ops.PoseChain.apply(rel)
+        rel, rel_inv, extrinsics = _ops.ProcrustesFit.apply_chained(None, None, surfaces, backward_weights, backward_flows, idx, sens)
+    if extrinsics is None:  # (dense fits chain the poses in a launch of their own)
+        extrinsics = _ops.PoseChain.apply(rel)
     # The per-pair poses the chain was built from: later(E)⁻¹·earlier(E) and its inverse up to
     # rounding (the chain cancels).  The fused flow loss reads them from here
     # instead of re-deriving them from the chain (two launches + three in the backward).

@@ -51,8 +51,9 @@ extern "C" {
  *   scale: device scalar multiplied into every residual's gradient (weight/valid_sum
  *          from fm_flow_valid_norm); NULL = loss only, no gradients.
  *   grad_depth (B,F,H,W) out: dL/ddepth with poses held fixed (may be NULL).
- *   acc (B*F, 2, FM_FLOW_ACC_STRIDE) fp64 out: per (source frame, direction) sums,
- *          zeroed by this call, consumed by fm_flow_loss_finalize.
+ *   acc (B*F, 2, FM_FLOW_ACC_STRIDE) fp64 in/out: per (source frame, direction) sums are ADDED into it: it must
+ *          be zero on entry.  fm_flow_loss_finalize consumes it and leaves it zero again, so a workspace kept
+ *          across steps is zeroed once, when it is allocated.
  *   packed: NULL, or flows + masks re-laid-out by fm_flow_pack_inputs — then flow_* / mask_*
  *          are not read (may be NULL).  Same bytes, one stream instead of six (needs W % 4 == 0).
  *   items_per_thread: tuning knob (<=0 -> default).
@@ -73,10 +74,10 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
 int fm_flow_pack_inputs(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, int batch,
                         int frames, int height, int width, float* packed, void* stream);
 
-/* Turns `acc` into: loss[0] = norm[0]·Σρm (loss.py:47 weight and loss_flow.py:70
+/* Turns `acc` into (and then clears it): loss[0] = norm[0]·Σρm (loss.py:47 weight and loss_flow.py:70
  * normalisation folded into norm[0]); g_t_fwd / g_t_bwd (B,F-1,4,4) = dL/dT (bottom
  * rows 0); g_k (B,F,3,3) = dL/dK through both the projection (rows 0,1) and K⁻¹. */
-int fm_flow_loss_finalize(const double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+int fm_flow_loss_finalize(double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
                           const float* norm, int batch, int frames, float aspect_x, float aspect_y, float* loss, float* g_t_fwd,
                           float* g_t_bwd, float* g_k, void* stream);
 
@@ -114,6 +115,14 @@ int fm_procrustes_stats(const float* depth, const float* kinv, const float* surf
 int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
                       float weight_sensitivity, const int64_t* indices, long points, int batch, int batch_repeat, int frames,
                       int height, int width, double* stats, float* t_bwd, float* t_fwd, double* aux, void* stream);
+
+/* fm_procrustes_fit (batch_repeat 1) AND fm_pose_chain_fwd in ONE launch: the last workgroup of a pair turns the
+ * pair's sums into its pose, the last pair chains the poses into ext (B,F,4,4) (projection.py:187-252 entire).
+ * work: persistent workspace of B·(F-1)·FM_STAT_STRIDE doubles followed by B·(F-1)+1 ints, ZERO on entry and left
+ * zero (self-cleaning: zero it once, when it is allocated; one launch at a time per workspace). */
+int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                            float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, void* stream);
 
 /* procrustes.py:35-51: R = U·diag(1,1,±1)·Vᵀ by in-register 3×3 SVD, t = q̄ − R·p̄.
  * t_bwd (pairs,4,4) = [R|t] ("inverse relative transformation", later -> earlier
@@ -341,6 +350,11 @@ int fm_track_scatter_plan(const float* xy, const uint8_t* vis, const int32_t* se
 int fm_depth_gather(const float* vectors, const int64_t* pixels, const int32_t* first, const int32_t* entries, const float* weights,
                     long count, const float* kinv, const float* scale, const float* upstream, int height, int width, long frame0,
                     float* grad_depth, void* stream);
+/* fm_depth_gather (scale = upstream = NULL, frame0 = 0) with fm_intrinsics_inverse_bwd riding in the same launch (a few
+ * extra workgroups): g_k (frames_k,3,3) = [accumulate ? g_k : 0] − K⁻ᵀ·kinv_acc·K⁻ᵀ. */
+int fm_depth_gather_kgrad(const float* vectors, const int64_t* pixels, const int32_t* first, const int32_t* entries, const float* weights,
+                          long count, const float* kinv, int height, int width, float* grad_depth, const double* kinv_acc, int frames_k,
+                          float* g_k, int accumulate, void* stream);
 
 /* The tail of IntrinsicsSoftmin.forward (flowmap/model/intrinsics/intrinsics_softmin.py:123-141):
  * soft = softmin((err - min err) * 10) over the N candidates (fp32), K = sum_n soft[n] * candidate_k[n],

@@ -117,7 +117,7 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   return 0;
 }
 
-int fm_flow_loss_finalize(const double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+int fm_flow_loss_finalize(double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
                           const float* norm, int batch, int frames, float ax, float ay, float* loss, float* g_t_fwd, float* g_t_bwd,
                           float* g_k, void*) {
   double s = 0;
@@ -126,6 +126,7 @@ int fm_flow_loss_finalize(const double* acc, const float* k, const float* kinv, 
     s += acc[(size_t)bf * 2 * kFlowAccStride] + acc[(size_t)bf * 2 * kFlowAccStride + kFlowAccStride];
   }
   loss[0] = (float)(s * (double)norm[0]);
+  std::memset(acc, 0, sizeof(double) * (size_t)batch * frames * 2 * kFlowAccStride);  // consumed: clean for the next launch
   return 0;
 }
 
@@ -587,6 +588,19 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
                       double* stats, float* t_bwd, float* t_fwd, double* aux, void* stream) {
   fm_procrustes_stats(depth, kinv, surfaces, bwd_flow, weights, sens, indices, points, batch, repeat, frames, height, width, stats, stream);
   return fm_pose_solve(stats, batch * (frames - 1), t_bwd, t_fwd, aux, stream);
+}
+
+int fm_pose_chain_fwd(const float* rel, int batch, int steps, float* ext, void*);
+int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                            float sens, const int64_t* indices, long points, int batch, int frames, int height, int width, double* work,
+                            float* t_bwd, float* t_fwd, double* aux, float* ext, void* stream) {
+  const int pairs = batch * (frames - 1);
+  std::vector<double> stats((size_t)pairs * kStatStride);
+  (void)work;  // stays zero, as the device leaves it
+  if (fm_procrustes_fit(depth, kinv, surfaces, bwd_flow, weights, sens, indices, points, batch, 1, frames, height, width, stats.data(), t_bwd,
+                        t_fwd, aux, stream) != 0)
+    return 2;
+  return fm_pose_chain_fwd(t_bwd, batch, frames - 1, ext, stream);
 }
 
 int fm_procrustes_scatter_plan(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
@@ -1245,6 +1259,14 @@ int fm_depth_gather(const float* vectors, const int64_t* pixels, const int32_t* 
     grad_depth[(size_t)(frame - frame0) * n + px] += sum;
   }
   return 0;
+}
+
+int fm_depth_gather_kgrad(const float* vectors, const int64_t* pixels, const int32_t* first, const int32_t* entries, const float* weights,
+                          long count, const float* kinv, int height, int width, float* grad_depth, const double* kinv_acc, int frames_k,
+                          float* g_k, int accumulate, void* stream) {
+  if (count > 0 && fm_depth_gather(vectors, pixels, first, entries, weights, count, kinv, nullptr, nullptr, height, width, 0, grad_depth, stream) != 0)
+    return 2;
+  return frames_k > 0 ? fm_intrinsics_inverse_bwd(kinv_acc, kinv, frames_k, g_k, accumulate, stream) : 0;
 }
 
 }  // extern "C"

@@ -28,7 +28,7 @@ t[..., :3, 3] = 0.01 * torch.randn((1, f - 1, 3), device=dev, generator=g)
 t = t.contiguous()
 norm = torch.tensor([1e-3, 1.0], device=dev)
 gd = torch.empty_like(depth)
-acc = torch.empty((f * 2 * 20,), dtype=torch.float64, device=dev)
+acc = torch.zeros((f * 2 * 20,), dtype=torch.float64, device=dev)  # the kernel adds into it (timing only: never finalised)
 sc = (h * w) ** 0.5
 algo = h * w * (8 * f + 24 * (f - 1))
 
