@@ -354,6 +354,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                                const OptTensor& plan_pixels, const OptTensor& plan_first, const OptTensor& plan_vectors,
                                const OptTensor& plan_weights, const OptTensor& dense_first, const OptTensor& dense_list,
                                const OptTensor& work_o, bool grad_enabled) {  // (forward runs with grad mode off: the caller's mode is passed in)
+    ctx->set_materialize_grads(false);  // an unused output (the extrinsics of a flow-only step) must not cost a zeros tensor + the chain's backward
     Tensor depth = opt(depth_o), k = opt(k_o), kinv = opt(kinv_o), surfaces = opt(surfaces_o), indices = opt(indices_o);
     const bool from_depth = !surfaces.defined();
     {  // edge index of depth / k / surfaces / weights among the present tensor arguments
