@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--items-per-thread", type=int, default=0)
     ap.add_argument("--intrinsics", choices=["regressed", "softmin"], default="regressed",
                     help="softmin = the reference's default first-1000-steps intrinsics (60-candidate sweep, 8192 points)")
-    ap.add_argument("--optimizer", choices=["none", "fused", "torch"], default="none",
+    ap.add_argument("--optimizer", choices=["none", "fused", "in_pass", "torch"], default="none",
                     help="add the Adam step (lr 3e-5, config/overfit.yaml:30) to every iteration: flowmap_amd.FusedAdam or "
                          "torch.optim.Adam; the headline metric is fwd+bwd only (none)")
     ap.add_argument("--graph", action="store_true",
@@ -330,8 +330,12 @@ def main():
         shard.prepare_model(model)  # softmin sweep on rank 0, broadcast (flowmap_amd/sharding.py)
 
     optimizer = None
-    if args.optimizer == "fused":
+    if args.optimizer in ("fused", "in_pass"):
         optimizer = flowmap_amd.FusedAdam(model.parameters(), lr=3e-5, capturable=args.graph)
+        if args.optimizer == "in_pass":  # the depth update applied by the flow-loss pass itself (FusedAdam.fuse_depth_update)
+            if args.graph or dist is not None:
+                raise SystemExit("--optimizer in_pass: single GPU, no --graph")
+            optimizer.fuse_depth_update(model.backbone.depth)
     elif args.optimizer == "torch":
         optimizer = torch.optim.Adam(model.parameters(), lr=3e-5)
     shared = [p for name, p in model.named_parameters() if not name.startswith("backbone.")]  # intrinsics: shared by all frames
@@ -409,7 +413,8 @@ def main():
         workload = (f"{cfg['ref']}: {f_video} frames @ {h}x{w}, {cfg['inputs']} inputs, flow loss (huber 0.01, weight 1000)"
                     + (f" + tracking loss (weight 100): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else "")
                     + f", explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points if args.points > 0 else 'all pixels'}; fwd+bwd, "
-                    + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__})")
+                    + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__}"
+                       + (", depth update inside the flow pass)" if args.optimizer == "in_pass" else ")"))
                     + ("; whole step replayed as one hipGraph" if args.graph else ""))
         result = {
             "metric": "overfit iters/sec (150 frames @ 720p) at 1/2/4/8 MI355X; final ATE vs ref",

@@ -28,6 +28,7 @@ D = ctypes.c_double
 # name -> argtypes, in the order of include/flowmap_hip.h
 SIGNATURES = {
     "fm_flow_loss_fused": [P] * 11 + [I, I, I, I, I, F, F, F, P, P, I, P],
+    "fm_flow_loss_fused_adam": [P] * 11 + [I, I, I, I, I, F, F, F, P, P, I, P, P, P, L, D, D, D, D, P],
     "fm_flow_pack_inputs": [P, P, P, P, I, I, I, I, P, P],
     "fm_flow_loss_finalize": [P] * 6 + [I, I, F, F] + [P] * 4 + [P],
     "fm_flow_valid_norm": [P, P, L, F, P, P, P],
@@ -44,6 +45,7 @@ SIGNATURES = {
     "fm_resize_crop": [P, L, I, I, I, I, I, I, I, I, P, P],
     "fm_fill_zero": [P, L, I, P],
     "fm_adam_step": [P, P, P, P, L, L, D, D, D, D, D, P],
+    "fm_adam_step_elements": [P, P, P, P, P, L, L, D, D, D, D, D, P],
     "fm_adam_step_capturable": [P, P, P, P, L, P, D, D, D, D, D, P],
     "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, I, P, P],
     "fm_procrustes_fit": [P] * 5 + [F, P, L, I, I, I, I, I, P, P, P, P, P],

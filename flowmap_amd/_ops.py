@@ -132,6 +132,60 @@ def grad_arena(weights: Tensor):
     return arena
 
 
+def _root(t: Tensor) -> Tensor:
+    return t if t._base is None else t._base
+
+
+def note_touched(depth: Tensor, consumer: str, pixels: Optional[Tensor]) -> None:
+    """A consumer of ``depth`` other than the fused flow loss (the Procrustes fit, the tracking loss) records the
+    STATIC set of elements it reads / adds gradient to (flat indices into ``depth``) on the parameter behind it.
+    FusedAdam.fuse_depth_update needs the union: those elements are left to the element-list update."""
+    root = _root(depth)
+    registry = root.__dict__.setdefault("_fm_touched", {})
+    if registry.get(consumer) is pixels:
+        return
+    optimizer = root.__dict__.get("_fm_fused_adam")
+    if optimizer is not None and pixels is not None and optimizer.in_pass_pending(root):
+        raise RuntimeError(
+            f"flowmap_amd: the {consumer} operator reads depth values the flow loss has already updated in this step "
+            "(FusedAdam.fuse_depth_update): every consumer of depth must have run once, or announced its pixels with "
+            "flowmap_amd._ops.note_touched, before the first fused step")
+    if pixels is None:
+        registry.pop(consumer, None)
+    else:
+        registry[consumer] = pixels
+
+
+def announce_track_pixels(depth: Tensor, tracks) -> None:
+    """The tracking loss while it is still gated off (loss.py:39-41, `enable_after`): its static set of depth taps is
+    recorded now, so that an in-pass depth update never has to learn about it in the middle of a step."""
+    root = _root(depth)
+    if root.__dict__.get("_fm_fused_adam") is None or depth.dim() != 4 or not tracks:
+        return
+    plan = pack_tracks(tracks, depth.device).scatter_plan(depth.shape[2], depth.shape[3])
+    note_touched(depth, "tracking", plan[0])
+
+
+def touched_elements(depth: Tensor):
+    """(sorted unique flat indices, per-quad bit mask uint8 (numel/4)) of everything recorded by note_touched, built
+    once per combination of recorded sets; None when nothing was recorded or a 4-element quad layout does not apply."""
+    root = _root(depth)
+    registry = root.__dict__.get("_fm_touched")
+    if not registry or depth.numel() % 4 != 0:
+        return None
+
+    def build():
+        keys = torch.unique(torch.cat([v.reshape(-1) for v in registry.values()]))
+        mask = torch.zeros((depth.numel() // 4,), dtype=torch.uint8, device=depth.device)
+        quad, bit = torch.div(keys, 4, rounding_mode="floor"), keys % 4
+        for e in range(4):
+            mask[quad[bit == e]] |= 1 << e
+        return list(registry.values()), keys.contiguous(), mask
+
+    key = tuple((name, id(v), v._version) for name, v in sorted(registry.items())) + (depth.numel(),)
+    return _derived(root, "_fm_touched_union", key, build)[1:]
+
+
 # Persistent dL/dweights storage (GradArena) for sparse fits with a constant index set; False = fresh zeros every step
 use_grad_arena = True
 
@@ -309,11 +363,13 @@ class ProcrustesFit:
             if wants_grad and static_flow:
                 b, f, h, w = depth.shape
                 if indices is None:
+                    note_touched(depth, "procrustes", None)  # every pixel is a correspondence: nothing is left to an in-pass update
                     if h <= 65535 and w <= 65535:
                         dense = _dense_procrustes_plan(bwd_flow, b, f, h, w)
                         counters["procrustes_dense_planned"] += 1
                 elif indices.dtype == torch.int64 and indices.is_contiguous():
                     plan = _procrustes_scatter_plan(indices, bwd_flow, b, f, h, w)
+                    note_touched(depth, "procrustes", None if plan is None else plan[0])
                     if plan is not None:
                         sparse = plan
                         counters["procrustes_planned"] += 1
@@ -416,8 +472,12 @@ class FlowLossFused:
         # the per-(frame, direction) fp64 sums: a workspace kept on the mask tensor, zeroed once (the finalize launch leaves it zero)
         size = depth.shape[0] * depth.shape[1] * 2 * FLOW_ACC_STRIDE if depth.dim() == 4 else 0
         acc = _derived(mask_fwd, "_fm_flow_acc", (size, str(depth.device)), lambda: torch.zeros((size,), dtype=torch.float64, device=depth.device))
+        adam = (None, None, None, 0, [])
+        optimizer = _root(depth).__dict__.get("_fm_fused_adam")
+        if optimizer is not None and sink is not None and torch.is_grad_enabled():
+            adam = optimizer.begin_in_pass(depth, sink, t_fwd, t_bwd) or adam
         return torch_ops().flow_loss(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, int(kind), float(delta),
-                                     sink, int(items), acc)
+                                     sink, int(items), acc, *adam)
 
 
 class SoftminScore(torch.autograd.Function):
@@ -889,6 +949,8 @@ class TrackLossFused:
         kinv = intrinsics_inverse(k)
         needs_depth = torch.is_grad_enabled() and depth.requires_grad
         plan = packed.scatter_plan(depth.shape[2], depth.shape[3]) if needs_depth and depth.dim() == 4 else None  # built at the first step
+        if plan is not None:
+            note_touched(depth, "tracking", plan[0] if frame0 == 0 else plan[0] - int(frame0) * depth.shape[2] * depth.shape[3])
         sink = depth_sink(depth) if defer else None
         loss, scale, totals = torch_ops().track_loss(depth, k, kinv, ext, packed.xy, packed.vis, packed.seg, packed.blocks, packed.tiles,
                                                      packed.counts, float(weight), int(kind), float(delta), sink, int(frame0),

@@ -43,6 +43,13 @@ struct FlowParams {
   int kind;
   float delta, ax, ay;
   int iters;              // items per thread
+  // fm_flow_loss_fused_adam: the Adam update of `depth` applied by this very pass (depth, exp_avg, exp_avg_sq rewritten
+  // in place) for every pixel whose bit in `touched` is clear; the others keep their values and get dL/ddepth written
+  float* depth_rw;        // = depth
+  float* exp_avg;         // (B,F,H,W)
+  float* exp_avg_sq;      // (B,F,H,W)
+  const uint8_t* touched; // (B·F·H·W/4): bit e of byte q = pixel 4q+e receives gradient from (or is read by) another operator
+  AdamCoef adam;
 };
 
 // 16-byte streaming accesses.  Every input element is read exactly once and the gradient is
@@ -115,8 +122,9 @@ __device__ __forceinline__ void load_quad_packed(QuadIn& q, const float* depth, 
 #define FM_FLOW_WAVES 3
 #endif
 
-template <int VEC, int KIND, bool GRAD, bool PACKED>
+template <int VEC, int KIND, bool GRAD, bool PACKED, bool ADAM = false>
 __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowParams p) {
+  static_assert(!ADAM || (VEC == 4 && GRAD), "the in-pass Adam update runs on the 16-byte gradient path");
   extern __shared__ double lds[];  // reduction scratch (fp64), then the [width] u-table
   double* red = lds;
   float* u_tab = reinterpret_cast<float*>(lds + (256 / 64) * kFlowAcc);
@@ -196,7 +204,27 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
         flow_term_fast<KIND, GRAD>(db, rb0, rb1, rb2, z[e], u, zu, zv, u_ax, v_ay, fxb[e], fyb[e], mmb[e], scale, p.delta, inv_delta, p.ax,
                                    p.ay, acc_b, gz[e]);
     }
-    if (GRAD && gd) {
+    if (ADAM) {
+      // depth, exp_avg, exp_avg_sq of this quad rewritten in place (model_wrapper_overfit.py:104-105: torch.optim.Adam);
+      // pixels another operator still reads from / adds gradient to keep their values and get dL/ddepth stored instead
+      const size_t q = (size_t)bf * items + item;
+      const unsigned bits = p.touched[q];
+      v4f m4 = FM_LOAD(reinterpret_cast<const v4f*>(p.exp_avg) + q), v4 = FM_LOAD(reinterpret_cast<const v4f*>(p.exp_avg_sq) + q);
+      v4f z4;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float pe = z[e], me = m4[e], ve = v4[e];
+        adam_update(p.adam, pe, gz[e], me, ve);
+        const bool keep = (bits >> e) & 1u;
+        z4[e] = keep ? z[e] : pe;
+        m4[e] = keep ? m4[e] : me;
+        v4[e] = keep ? v4[e] : ve;
+        if (keep) gd[(size_t)item * VEC + e] = gz[e];
+      }
+      FM_STORE(z4, reinterpret_cast<v4f*>(p.depth_rw) + q);
+      FM_STORE(m4, reinterpret_cast<v4f*>(p.exp_avg) + q);
+      FM_STORE(v4, reinterpret_cast<v4f*>(p.exp_avg_sq) + q);
+    } else if (GRAD && gd) {
       if (VEC == 4) {
         v4f o;
         o.x = gz[0]; o.y = gz[1]; o.z = gz[2]; o.w = gz[3];
@@ -385,11 +413,18 @@ using namespace fm;
 
 extern "C" {
 
-int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
-                       const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
-                       const float* packed, const float* scale, int batch, int frames, int height, int width,
-                       int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
-                       int items_per_thread, void* stream) {
+struct FlowAdam {
+  float* exp_avg;
+  float* exp_avg_sq;
+  const uint8_t* touched;
+  AdamCoef coef;
+};
+
+static int flow_loss_launch(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                            const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
+                            const float* packed, const float* scale, int batch, int frames, int height, int width,
+                            int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
+                            int items_per_thread, const FlowAdam* adam, void* stream) {
   FM_CHECK_ARG(depth && k && kinv && acc);
   FM_CHECK_ARG(packed || (flow_fwd && flow_bwd && mask_fwd && mask_bwd));
   FM_CHECK_ARG(batch >= 1 && frames >= 2 && height >= 1 && width >= 1);
@@ -400,6 +435,13 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   const bool grad = scale != nullptr;
   FlowParams p{depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, grad_depth, acc,
                frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 4};
+  if (adam) {
+    p.depth_rw = const_cast<float*>(depth);
+    p.exp_avg = adam->exp_avg;
+    p.exp_avg_sq = adam->exp_avg_sq;
+    p.touched = adam->touched;
+    p.adam = adam->coef;
+  }
   // (`acc` is zero on entry: fm_flow_loss_finalize clears what it has read, so a workspace kept across steps never
   // needs a memset launch)
   auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -431,7 +473,9 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   const size_t lds = sizeof(float) * (size_t)width + sizeof(double) * (threads / 64) * kFlowAcc;
 #define FM_FLOW_LAUNCH(V, K, P)                                                                              \
   do {                                                                                                       \
-    if (grad) hipLaunchKernelGGL((flow_fused_kernel<V, K, true, P>), grid, dim3(threads), lds, st, p);       \
+    if (adam) {                                                                                              \
+      if constexpr (V == 4) hipLaunchKernelGGL((flow_fused_kernel<4, K, true, P, true>), grid, dim3(threads), lds, st, p); \
+    } else if (grad) hipLaunchKernelGGL((flow_fused_kernel<V, K, true, P>), grid, dim3(threads), lds, st, p);  \
     else hipLaunchKernelGGL((flow_fused_kernel<V, K, false, P>), grid, dim3(threads), lds, st, p);          \
   } while (0)
 #define FM_FLOW_KIND(V, P)                                          \
@@ -445,6 +489,7 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
     if (use_packed) FM_FLOW_KIND(V, true); \
     else FM_FLOW_KIND(V, false);       \
   } while (0)
+  FM_CHECK_ARG(!adam || (vec == 4 && grad && grad_depth));
   if (vec == 4) FM_FLOW_VEC(4);
 #ifdef FM_FLOW_FORCE_VEC2
   else if (vec == 2) FM_FLOW_KIND(2, false);
@@ -454,6 +499,29 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
 #undef FM_FLOW_KIND
 #undef FM_FLOW_LAUNCH
   FM_LAUNCH_STATUS();
+}
+
+int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                       const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
+                       const float* packed, const float* scale, int batch, int frames, int height, int width,
+                       int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
+                       int items_per_thread, void* stream) {
+  return flow_loss_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
+                          mapping_kind, delta, aspect_x, aspect_y, grad_depth, acc, items_per_thread, nullptr, stream);
+}
+
+int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd, const float* flow_fwd,
+                            const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, const float* packed, const float* scale,
+                            int batch, int frames, int height, int width, int mapping_kind, float delta, float aspect_x, float aspect_y,
+                            float* grad_depth, double* acc, int items_per_thread, float* exp_avg, float* exp_avg_sq, const uint8_t* touched,
+                            long step, double lr, double beta1, double beta2, double eps, void* stream) {
+  FM_CHECK_ARG(exp_avg && exp_avg_sq && touched && scale && grad_depth && step >= 1 && width % 4 == 0);
+  FM_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0);
+  auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  FM_CHECK_ARG(aligned(exp_avg) && aligned(exp_avg_sq));
+  const FlowAdam adam{exp_avg, exp_avg_sq, touched, adam_coefficients((double)step, lr, beta1, beta2, eps, 0.0)};
+  return flow_loss_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
+                          mapping_kind, delta, aspect_x, aspect_y, grad_depth, acc, items_per_thread, &adam, stream);
 }
 
 int fm_flow_loss_finalize(double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,

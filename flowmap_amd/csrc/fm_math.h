@@ -524,6 +524,21 @@ struct AdamCoef {
   float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, weight_decay;
 };
 
+// bias corrections in double, exactly as torch.optim.adam._single_tensor_adam
+FM_HD AdamCoef adam_coefficients(double step, double lr, double beta1, double beta2, double eps, double weight_decay) {
+  const double bc1 = 1.0 - pow(beta1, step);
+  const double bc2 = 1.0 - pow(beta2, step);
+  AdamCoef c;
+  c.one_minus_b1 = (float)(1.0 - beta1);
+  c.b2 = (float)beta2;
+  c.one_minus_b2 = (float)(1.0 - beta2);
+  c.step_size = (float)(lr / bc1);
+  c.bc2_sqrt = (float)sqrt(bc2);
+  c.eps = (float)eps;
+  c.weight_decay = (float)weight_decay;
+  return c;
+}
+
 FM_HD void adam_update(const AdamCoef& c, float& p, float g, float& m, float& v) {
   if (c.weight_decay != 0.f) g = fmaf(c.weight_decay, p, g);
   m = fmaf(c.one_minus_b1, g - m, m);

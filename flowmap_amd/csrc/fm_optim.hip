@@ -72,21 +72,6 @@ __device__ __forceinline__ void adam_apply(float* __restrict__ param, const floa
   }
 }
 
-// bias corrections in double, exactly as torch.optim.adam._single_tensor_adam
-__host__ __device__ inline AdamCoef adam_coefficients(double step, double lr, double beta1, double beta2, double eps, double weight_decay) {
-  const double bc1 = 1.0 - pow(beta1, step);
-  const double bc2 = 1.0 - pow(beta2, step);
-  AdamCoef c;
-  c.one_minus_b1 = (float)(1.0 - beta1);
-  c.b2 = (float)beta2;
-  c.one_minus_b2 = (float)(1.0 - beta2);
-  c.step_size = (float)(lr / bc1);
-  c.bc2_sqrt = (float)sqrt(bc2);
-  c.eps = (float)eps;
-  c.weight_decay = (float)weight_decay;
-  return c;
-}
-
 __global__ void __launch_bounds__(256) adam_kernel(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count,
                                                    AdamCoef c, int vec_ok) {
   adam_apply(param, grad, exp_avg, exp_avg_sq, count, c, vec_ok);
@@ -99,6 +84,20 @@ __global__ void __launch_bounds__(256) adam_capturable_kernel(float* param, cons
                                                               double eps, double weight_decay, int vec_ok) {
   const AdamCoef c = adam_coefficients((double)step[0], lr, beta1, beta2, eps, weight_decay);
   adam_apply(param, grad, exp_avg, exp_avg_sq, count, c, vec_ok);
+}
+
+// Adam on a LIST of elements (the pixels of dL/ddepth that the sparse losses touch, when the fused flow loss has
+// already updated every other pixel in its own pass — fm_flow_loss_fused_adam): one thread per listed element.
+__global__ void __launch_bounds__(256) adam_elements_kernel(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                                            const int64_t* elements, long count, AdamCoef c) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int64_t e = elements[i];
+  float p = param[e], m = exp_avg[e], v = exp_avg_sq[e];
+  adam_update(c, p, grad[e], m, v);
+  param[e] = p;
+  exp_avg[e] = m;
+  exp_avg_sq[e] = v;
 }
 
 // Zero fill with a bounded footprint: `blocks` workgroups stream 16-byte non-temporal stores over the
@@ -147,6 +146,17 @@ int fm_adam_step_capturable(float* param, const float* grad, float* exp_avg, flo
   if (blocks > 256L * FM_ADAM_BLOCKS_PER_CU) blocks = 256L * FM_ADAM_BLOCKS_PER_CU;
   hipLaunchKernelGGL(adam_capturable_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, count, step, lr, beta1, beta2, eps, weight_decay, vec_ok);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_adam_step_elements(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* elements, long count, long step,
+                          double lr, double beta1, double beta2, double eps, double weight_decay, void* stream) {
+  FM_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && count >= 0 && step >= 1 && (elements || count == 0));
+  FM_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0);
+  if (count == 0) return FM_OK;
+  const AdamCoef c = adam_coefficients((double)step, lr, beta1, beta2, eps, weight_decay);
+  hipLaunchKernelGGL(adam_elements_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, elements, count, c);
   FM_LAUNCH_STATUS();
 }
 

@@ -44,7 +44,7 @@ using OptTensor = std::optional<Tensor>;
 // The C ABI, resolved at run time
 // ------------------------------------------------------------------------------------------
 #define FM_API_LIST(X)                                                                                                                    \
-  X(fm_flow_loss_fused) X(fm_flow_loss_finalize) X(fm_scale_if_needed) X(fm_intrinsics_inverse) X(fm_intrinsics_inverse_bwd)              \
+  X(fm_flow_loss_fused) X(fm_flow_loss_fused_adam) X(fm_adam_step_elements) X(fm_flow_loss_finalize) X(fm_scale_if_needed) X(fm_intrinsics_inverse) X(fm_intrinsics_inverse_bwd)              \
   X(fm_focal_intrinsics_fwd) X(fm_focal_intrinsics_bwd) X(fm_pose_chain_fwd) X(fm_pose_chain_bwd) X(fm_relative_pose_fwd)                  \
   X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense)                \
   X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_loss_fused_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
@@ -566,7 +566,9 @@ struct FlowLaunch {
 
 static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& t_fwd, const Tensor& t_bwd,
                               const Tensor& flow_fwd, const Tensor& flow_bwd, const Tensor& mask_fwd, const Tensor& mask_bwd, const Tensor& norm,
-                              const Tensor& packed, int64_t kind, double delta, int64_t items, bool need, bool need_depth, const Tensor& acc_work) {
+                              const Tensor& packed, int64_t kind, double delta, int64_t items, bool need, bool need_depth, const Tensor& acc_work,
+                              const Tensor& exp_avg = Tensor(), const Tensor& exp_avg_sq = Tensor(), const Tensor& touched = Tensor(),
+                              int64_t adam_step = 0, const std::vector<double>& adam = {}) {
   const int64_t b = depth.size(0), f = depth.size(1), h = depth.size(2), w = depth.size(3);
   const auto dev = depth.device();
   FlowLaunch o;
@@ -590,9 +592,16 @@ static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor
     e1 = tm.create();
     tm.record(e0, scope.stream);
   }
-  FM_CALL(fm_flow_loss_fused, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd),
-          ptr(packed), need ? ptr(norm) : nullptr, (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
-          ptr(o.g_depth), ptr<double>(acc), (int)items, scope.stream);
+  if (exp_avg.defined()) {  // the depth parameter's Adam update applied by the same pass (fm_flow_loss_fused_adam)
+    FM_CALL(fm_flow_loss_fused_adam, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd),
+            ptr(mask_bwd), ptr(packed), ptr(norm), (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
+            ptr(o.g_depth), ptr<double>(acc), (int)items, ptr(exp_avg), ptr(exp_avg_sq), ptr<uint8_t>(touched), (long)adam_step, adam[0], adam[1],
+            adam[2], adam[3], scope.stream);
+  } else {
+    FM_CALL(fm_flow_loss_fused, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd),
+            ptr(packed), need ? ptr(norm) : nullptr, (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
+            ptr(o.g_depth), ptr<double>(acc), (int)items, scope.stream);
+  }
   if (e0) {
     tm.record(e1, scope.stream);
     std::lock_guard<std::mutex> lock(timing_mutex());
@@ -607,7 +616,9 @@ struct FlowLossFused : public Function<FlowLossFused> {
   static Tensor forward(AutogradContext* ctx, const Tensor& depth_in, const Tensor& k_in, const Tensor& kinv_in, const Tensor& t_fwd_in,
                         const Tensor& t_bwd_in, const Tensor& flow_fwd_in, const Tensor& flow_bwd_in, const Tensor& mask_fwd_in,
                         const Tensor& mask_bwd_in, const Tensor& norm, const OptTensor& packed_o, int64_t kind, double delta,
-                        const c10::intrusive_ptr<DepthSink>& sink, int64_t items, const OptTensor& acc_work, bool grad_enabled, bool park) {
+                        const c10::intrusive_ptr<DepthSink>& sink, int64_t items, const OptTensor& acc_work, const OptTensor& exp_avg_o,
+                        const OptTensor& exp_avg_sq_o, const OptTensor& touched_o, int64_t adam_step, std::vector<double> adam,
+                        bool grad_enabled, bool park) {
     check_device({&depth_in, &k_in, &kinv_in, &t_fwd_in, &t_bwd_in, &flow_fwd_in, &flow_bwd_in, &mask_fwd_in, &mask_bwd_in, &norm});
     const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics");
     const Tensor t_fwd = f32c(t_fwd_in, "forward poses"), t_bwd = f32c(t_bwd_in, "backward poses");
@@ -630,8 +641,21 @@ struct FlowLossFused : public Function<FlowLossFused> {
                       packed.sizes() == at::IntArrayRef({b * f, (h * w / 4 + 63) / 64, 6, 64, 4}),
                   "flowmap_amd: packed flow inputs do not match the depth shape");
     const bool need = grad_enabled && (depth_in.requires_grad() || k_in.requires_grad() || t_fwd_in.requires_grad() || t_bwd_in.requires_grad());
+    // In-pass Adam (FusedAdam.fuse_depth_update): depth itself is rewritten, so it must be the caller's memory, not a copy;
+    // the update assumes the gradient is final as computed, i.e. that the loss reaches backward() unscaled
+    const Tensor exp_avg = opt(exp_avg_o), exp_avg_sq = opt(exp_avg_sq_o), touched = opt(touched_o);
+    const bool in_pass_adam = exp_avg.defined();
+    if (in_pass_adam) {
+      TORCH_CHECK(need && park && depth_in.requires_grad() && depth.data_ptr() == depth_in.data_ptr() && w % 4 == 0 && adam.size() == 4 && adam_step >= 1,
+                  "flowmap_amd: the in-pass Adam update needs a contiguous float32 depth parameter whose gradient travels through the step's DepthSink");
+      TORCH_CHECK(exp_avg.sizes() == depth.sizes() && exp_avg_sq.sizes() == depth.sizes() && exp_avg.is_contiguous() && exp_avg_sq.is_contiguous() &&
+                      exp_avg.scalar_type() == at::kFloat && exp_avg_sq.scalar_type() == at::kFloat && touched.defined() &&
+                      touched.scalar_type() == at::kByte && touched.is_contiguous() && touched.numel() * 4 == depth.numel(),
+                  "flowmap_amd: Adam state / touched-pixel mask do not match the depth tensor");
+    }
     FlowLaunch run = flow_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, items, need,
-                                 depth_in.requires_grad(), opt(acc_work));
+                                 depth_in.requires_grad(), opt(acc_work), exp_avg, exp_avg_sq, touched, adam_step, adam);
+    ctx->saved_data["in_pass_adam"] = in_pass_adam;
     ctx->save_for_backward({depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed});
     ctx->saved_data["acc_work"] = opt(acc_work);
     ctx->saved_data["cfg"] = std::vector<int64_t>{kind, items};
@@ -644,7 +668,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    variable_list out(18);
+    variable_list out(23);
     if (!grads[0].defined()) return out;
     const auto saved = ctx->get_saved_variables();
     const Tensor &depth = saved[0], &k = saved[1], &t_fwd = saved[3];
@@ -656,6 +680,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
       ctx->saved_data["g_depth"] = Tensor();
       ctx->saved_data["small"] = Tensor();
     } else {  // a second backward through a retained graph: one more pass from the saved inputs
+      TORCH_CHECK(!ctx->saved_data["in_pass_adam"].toBool(), "flowmap_amd: a step whose flow loss already applied the Adam update cannot be differentiated twice");
       const auto cfg = ctx->saved_data["cfg"].toIntVector();
       FlowLaunch run = flow_launch(saved[0], saved[1], saved[2], saved[3], saved[4], saved[5], saved[6], saved[7], saved[8], saved[9], saved[10],
                                    cfg[0], ctx->saved_data["delta"].toDouble(), cfg[1], true, ctx->needs_input_grad(0),
@@ -951,12 +976,13 @@ static std::tuple<Tensor, Tensor, Tensor> procrustes_fit_op(const OptTensor& dep
 }
 static Tensor flow_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& t_fwd, const Tensor& t_bwd, const Tensor& flow_fwd,
                            const Tensor& flow_bwd, const Tensor& mask_fwd, const Tensor& mask_bwd, const Tensor& norm, const OptTensor& packed,
-                           int64_t kind, double delta, const OptSink& sink, int64_t items, const OptTensor& acc_work) {
+                           int64_t kind, double delta, const OptSink& sink, int64_t items, const OptTensor& acc_work, const OptTensor& exp_avg,
+                           const OptTensor& exp_avg_sq, const OptTensor& touched, int64_t adam_step, std::vector<double> adam) {
   auto s = sink_of(sink);
   // park dL/ddepth in the sink only when both pose tensors come from the fit that armed it: that node then runs after this one
   const bool park = s && s->fit_node != nullptr && reaches(t_fwd.grad_fn(), s->fit_node, 3) && reaches(t_bwd.grad_fn(), s->fit_node, 3);
   return FlowLossFused::apply(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, s, items, acc_work,
-                              at::GradMode::is_enabled(), park);
+                              exp_avg, exp_avg_sq, touched, adam_step, adam, at::GradMode::is_enabled(), park);
 }
 static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& ext, const Tensor& xy,
                                                         const Tensor& vis, const Tensor& seg, const Tensor& blocks, const Tensor& tiles,
@@ -972,6 +998,29 @@ static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, con
                                    plan_entries, plan_weights, at::GradMode::is_enabled(), park);
   return {out[0], out[1], out[2]};
 }
+// would a flow loss fed these poses hand its dL/ddepth to the sink's fit (i.e. is the in-pass Adam update possible)?
+static bool flow_loss_parks(const Tensor& t_fwd, const Tensor& t_bwd, const c10::intrusive_ptr<DepthSink>& sink) {
+  return sink && sink->active && !sink->expect_leading && sink->fit_node != nullptr && reaches(t_fwd.grad_fn(), sink->fit_node, 3) &&
+         reaches(t_bwd.grad_fn(), sink->fit_node, 3);
+}
+
+// Adam on a list of elements (the touched pixels of the in-pass update), versions bumped like adam_step
+static void adam_step_elements(Tensor p, const Tensor& grad_in, Tensor m, Tensor v, const Tensor& elements, int64_t step, double lr, double beta1,
+                               double beta2, double eps, double weight_decay) {
+  const auto dev = check_device({&p, &grad_in, &m, &v, &elements});
+  TORCH_CHECK(p.scalar_type() == at::kFloat && grad_in.scalar_type() == at::kFloat && elements.scalar_type() == at::kLong,
+              "flowmap_amd.FusedAdam: float32 parameters / gradients and int64 element indices");
+  TORCH_CHECK(p.is_contiguous() && m.is_contiguous() && v.is_contiguous() && grad_in.is_contiguous() && elements.is_contiguous() &&
+                  grad_in.numel() == p.numel(),
+              "flowmap_amd.FusedAdam: contiguous tensors of one size");
+  DeviceScope scope(dev);
+  FM_CALL(fm_adam_step_elements, ptr(p), ptr(grad_in), ptr(m), ptr(v), ptr<int64_t>(elements), (long)elements.numel(), (long)step, lr, beta1, beta2,
+          eps, weight_decay, scope.stream);
+  p.unsafeGetTensorImpl()->bump_version();
+  m.unsafeGetTensorImpl()->bump_version();
+  v.unsafeGetTensorImpl()->bump_version();
+}
+
 static Tensor leading_frames_op(const Tensor& x, int64_t count, const OptSink& sink) {
   return LeadingFrames::apply(x, count, sink_of(sink));
 }
@@ -1003,7 +1052,8 @@ TORCH_LIBRARY(flowmap_amd, m) {
       fmt::procrustes_fit_op);
   m.def(
       "flow_loss(Tensor depth, Tensor k, Tensor kinv, Tensor t_fwd, Tensor t_bwd, Tensor flow_fwd, Tensor flow_bwd, Tensor mask_fwd, Tensor mask_bwd, "
-      "Tensor norm, Tensor? packed, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int items, Tensor? acc_work) -> Tensor",
+      "Tensor norm, Tensor? packed, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int items, Tensor? acc_work, "
+      "Tensor? exp_avg, Tensor? exp_avg_sq, Tensor? touched, int adam_step, float[] adam) -> Tensor",
       fmt::flow_loss_op);
   m.def(
       "track_loss(Tensor depth, Tensor k, Tensor kinv, Tensor ext, Tensor xy, Tensor vis, Tensor seg, Tensor blocks, Tensor tiles, int[] counts, "
@@ -1014,6 +1064,10 @@ TORCH_LIBRARY(flowmap_amd, m) {
   m.def("adam_step(Tensor(a!) p, Tensor grad, Tensor(b!) m, Tensor(c!) v, int step, Tensor? step_tensor, float lr, float beta1, float beta2, float eps, "
         "float weight_decay) -> ()",
         fmt::adam_step);
+  m.def("flow_loss_parks(Tensor t_fwd, Tensor t_bwd, __torch__.torch.classes.flowmap_amd.DepthSink sink) -> bool", fmt::flow_loss_parks);
+  m.def("adam_step_elements(Tensor(a!) p, Tensor grad, Tensor(b!) m, Tensor(c!) v, Tensor elements, int step, float lr, float beta1, float beta2, "
+        "float eps, float weight_decay) -> ()",
+        fmt::adam_step_elements);
   m.def("flow_timing_enable(bool on) -> ()", fmt::flow_timing_enable);
   m.def("flow_timing_collect(bool tracking) -> float[]", fmt::flow_timing_collect);
 }

@@ -54,6 +54,11 @@ class LossTracking(Loss[LossTrackingCfg]):
             self.mapping.delta, self.defer_depth_scatter,
         )
 
+    def forward(self, batch, flows, tracks, model_output, global_step: int) -> Tensor:
+        if global_step < self.cfg.enable_after and tracks is not None and self._fusable(model_output, tracks):
+            _ops.announce_track_pixels(model_output.surfaces.depths, tracks)
+        return super().forward(batch, flows, tracks, model_output, global_step)
+
     def compute_weighted_loss(self, batch, flows, tracks, model_output, global_step: int, weight: float) -> Tensor:
         assert tracks is not None
         if self._fusable(model_output, tracks):

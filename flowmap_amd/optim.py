@@ -37,6 +37,61 @@ class FusedAdam(torch.optim.Optimizer):
         # the kernel derives the bias corrections from it, so step() can sit inside a hipGraph
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
                                       capturable=bool(capturable)))
+        self._in_pass = {}  # parameter -> (step number, element list) of an update the fused flow loss has already applied
+
+    # -- the depth parameter's update inside the fused flow loss (SURVEY.md §8f-2's end state) -----------------------
+    def fuse_depth_update(self, param: torch.Tensor, enabled: bool = True) -> None:
+        """Opt in: from now on the fused flow loss (flowmap_amd.loss.LossFlow on lazy surfaces) applies THIS optimiser's
+        update of ``param`` (the explicit-depth parameter, backbone_explicit_depth.py:34-41) in its own pass over HBM —
+        depth, exp_avg and exp_avg_sq rewritten in place, no dL/ddepth round trip, no separate pass over depth (48 B per
+        pixel and frame instead of 32 + 28) — for every pixel that only the flow loss touches.  The pixels the Procrustes
+        fit and the tracking loss read or add gradient to (a static set, a fraction of a per cent) are updated by
+        ``step()`` from their complete gradient, with the same step number.  Same arithmetic as the separate update.
+
+        What changes for the caller: the parameter moves during ``loss.forward`` instead of ``step()``; ``param.grad``
+        is meaningful at those sparse pixels only; the loss must reach ``backward()`` unscaled (the update uses the
+        gradient as the forward pass computes it) and cannot be differentiated twice.  It engages only when it can:
+        regressed intrinsics (the softmin sweep reads random pixels), a sparse planned Procrustes fit, no weight decay,
+        not capturable, no frame sharding; otherwise the step runs as usual."""
+        if not any(p is param for group in self.param_groups for p in group["params"]):
+            raise ValueError("flowmap_amd.FusedAdam.fuse_depth_update: the parameter does not belong to this optimiser")
+        if enabled:
+            param.__dict__["_fm_fused_adam"] = self
+        else:
+            param.__dict__.pop("_fm_fused_adam", None)
+
+    def in_pass_pending(self, param: torch.Tensor) -> bool:
+        return param in self._in_pass
+
+    def begin_in_pass(self, depth: torch.Tensor, sink, t_fwd: torch.Tensor, t_bwd: torch.Tensor):
+        """Called by the fused flow loss: (exp_avg, exp_avg_sq, touched mask, step number, [lr, beta1, beta2, eps]) when the
+        update of the parameter behind ``depth`` can run inside its pass, else None."""
+        from . import _ops
+
+        param = depth if depth._base is None else depth._base
+        group = next((g for g in self.param_groups if any(p is param for p in g["params"])), None)
+        if (group is None or group["weight_decay"] != 0 or group.get("capturable") or not param.is_contiguous() or param.dtype != torch.float32
+                or depth.data_ptr() != param.data_ptr() or depth.numel() != param.numel() or param in self._in_pass):
+            return None
+        if not torch_ops().flow_loss_parks(t_fwd, t_bwd, sink):
+            return None  # the gradient would not travel through the step's DepthSink (poses not from the fit, softmin sweep, ...)
+        registry = param.__dict__.get("_fm_touched", {})
+        if "procrustes" not in registry:
+            return None  # the fit's backward is not planned (yet): the pixels it reads are not known
+        union = _ops.touched_elements(depth)
+        if union is None:
+            return None
+        elements, mask = union
+        state = self.state[param]
+        if len(state) == 0:
+            state["step"] = torch.tensor(0.0, dtype=torch.float32)
+            state["exp_avg"] = torch.zeros_like(param, memory_format=torch.preserve_format)
+            state["exp_avg_sq"] = torch.zeros_like(param, memory_format=torch.preserve_format)
+        state["step"] += 1
+        step = int(state["step"].item())
+        self._in_pass[param] = (step, elements)
+        beta1, beta2 = group["betas"]
+        return (state["exp_avg"].view(depth.shape), state["exp_avg_sq"].view(depth.shape), mask, step, [float(group["lr"]), float(beta1), float(beta2), float(group["eps"])])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -47,6 +102,14 @@ class FusedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             for p in group["params"]:
+                if p in self._in_pass:  # the fused flow loss has updated every other element in its own pass
+                    step, elements = self._in_pass.pop(p)
+                    if p.grad is None:
+                        raise RuntimeError("flowmap_amd.FusedAdam: the flow loss applied the depth update but backward() never ran")
+                    state = self.state[p]
+                    torch_ops().adam_step_elements(p, p.grad.contiguous(), state["exp_avg"], state["exp_avg_sq"], elements, step,
+                                                   float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), 0.0)
+                    continue
                 if p.grad is None:
                     continue
                 grad = p.grad

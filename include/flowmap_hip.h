@@ -64,6 +64,21 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
                        int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
                        int items_per_thread, void* stream);
 
+/* fm_flow_loss_fused with the Adam update of the depth parameter (model_wrapper_overfit.py:104-105: torch.optim.Adam,
+ * no weight decay) applied BY THE SAME PASS — SURVEY.md §8f-2's end state: no dL/ddepth round trip through HBM and no
+ * separate optimiser pass over depth (48 B per pixel and frame instead of 32 + 28).  `depth`, `exp_avg`, `exp_avg_sq`
+ * (B,F,H,W) are rewritten in place for every pixel whose bit in `touched` is clear; `touched` (B·F·H·W/4 bytes: bit e of
+ * byte q = pixel 4q+e) marks the pixels another operator of the step still reads or adds gradient to (the Procrustes
+ * samples and their taps, the track taps): they keep their values and get dL/ddepth written to grad_depth (only those
+ * entries of grad_depth are written); fm_adam_step_elements updates them once their gradient is complete.  The gradient
+ * is final as computed (`scale` must already hold everything upstream).  Needs W % 4 == 0; step >= 1 is the step number
+ * of the bias corrections. */
+int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd, const float* flow_fwd,
+                            const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, const float* packed, const float* scale,
+                            int batch, int frames, int height, int width, int mapping_kind, float delta, float aspect_x, float aspect_y,
+                            float* grad_depth, double* acc, int items_per_thread, float* exp_avg, float* exp_avg_sq, const uint8_t* touched,
+                            long step, double lr, double beta1, double beta2, double eps, void* stream);
+
 /* Flows and masks are constants of an optimisation (computed once by
  * FlowPredictor.compute_bidirectional_flow, flowmap/flow/flow_predictor.py:82-102).  Copies them
  * once into the layout the fused kernel streams best: per source frame f and quad q (4
@@ -443,6 +458,10 @@ int fm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * 1-based step AFTER the increment): capturable in a hipGraph, like torch.optim.Adam(capturable=True). */
 int fm_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, const float* step,
                             double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
+/* The same update on a LIST of elements (`elements` (count) int64 flat indices): the touched pixels of
+ * fm_flow_loss_fused_adam. */
+int fm_adam_step_elements(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* elements, long count, long step,
+                          double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

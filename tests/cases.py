@@ -5,6 +5,7 @@ vectors (tests/golden, made by oracle/make_golden.py) and/or the oracle."""
 from __future__ import annotations
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import assert_close, load_golden, maxerr, t
@@ -1013,5 +1014,109 @@ def case_threads_and_hooks(dev):
             last = {name: v[-1] for name, v in seen[which].items()}
             assert_close(last["backbone.depth"], expected[which][0], 2e-5, abs_=1e-7, what="hook saw the final depth gradient")
             assert_close(last["backbone.weights"], expected[which][1], 2e-5, abs_=1e-7, what="hook saw the final weight gradient")
+    finally:
+        flowmap_amd.set_lazy_surfaces(False)
+
+
+def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3):
+    """FusedAdam.fuse_depth_update: the depth update applied inside the fused flow pass (fm_flow_loss_fused_adam) + the
+    element-list update of the touched pixels (fm_adam_step_elements) walk the same trajectory as torch.optim.Adam on the
+    same losses (model_wrapper_overfit.py:104-105) — flow loss from step 0, tracking loss switched on later
+    (config/loss/tracking.yaml: enable_after), which must not surprise the fused update."""
+    import flowmap_amd
+    from flowmap_amd import Batch, FusedAdam, _ops
+    from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
+    from helpers import to_tracks
+
+    f, h, w = 5, 24, 32
+    trajectories, engaged = {}, 0
+    try:
+        for mode in ("torch", "fused", "in_pass"):
+            model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False)
+            sc = orc.synth_scene(f, h, w, seed=21)
+            tracks = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=21, interval=2, radius=2, grid=5), dev)
+            flow_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
+            track_fn = LossTracking(LossTrackingCfg(track_after, 100.0, "tracking", mapping_cfg("huber")))
+            optimizer = torch.optim.Adam(model.parameters(), lr=lr) if mode == "torch" else FusedAdam(model.parameters(), lr=lr)
+            if mode == "in_pass":
+                optimizer.fuse_depth_update(model.backbone.depth)
+            history = []
+            for step in range(steps):
+                optimizer.zero_grad(set_to_none=True)
+                before = model.backbone.depth.detach().clone()
+                out = model(batch, flows, step)
+                total = flow_fn(batch, flows, tracks, out, step)
+                moved = mode == "in_pass" and not torch.equal(before, model.backbone.depth.detach())
+                engaged += int(moved)
+                total = total + track_fn(batch, flows, tracks, out, step)
+                total.backward()
+                optimizer.step()
+                history.append([p.detach().clone() for p in (model.backbone.depth, model.backbone.weights, model.intrinsics.focal_length)]
+                               + [total.detach().clone()])
+            trajectories[mode] = (history, optimizer, model)
+    finally:
+        flowmap_amd.set_lazy_surfaces(False)
+    assert engaged >= steps - 3, engaged  # the plan exists from the third step on
+    ref = trajectories["torch"][0]
+    for mode in ("fused", "in_pass"):
+        for step, (a, b) in enumerate(zip(trajectories[mode][0], ref)):
+            for x, y, what in zip(a, b, ("depth", "weights", "focal", "loss")):
+                err = float((x - y).abs().max())
+                bound = 2e-6 * max(1.0, float(y.abs().max())) if what != "loss" else 2e-5 * max(1.0, float(y.abs().max()))
+                assert err <= bound, (mode, step, what, err, bound)
+    # the same optimiser state as the separate update, for every element (touched or not)
+    sa, sb = (trajectories[m][1].state[trajectories[m][2].backbone.depth] for m in ("fused", "in_pass"))
+    assert float(sa["step"]) == float(sb["step"]) == steps
+    for name in ("exp_avg", "exp_avg_sq"):
+        scale = float(sa[name].abs().max())
+        assert float((sa[name] - sb[name]).abs().max()) <= 1e-4 * scale, name
+    # the update has moved depth well beyond the tolerance (the comparison above is not vacuous)
+    assert float((ref[-1][0] - ref[0][0]).abs().max()) > 1e-2
+
+
+def case_in_pass_adam_refusals(dev):
+    """Where the in-pass update cannot run it does not: weight decay, a dense fit (every pixel is a correspondence), a
+    consumer of depth that shows up after the update has been applied (loud), a second backward."""
+    import flowmap_amd
+    from flowmap_amd import FusedAdam, _ops
+
+    try:
+        model, batch, flows, loss_of = _small_problem(dev, tracking=False)
+        optimizer = FusedAdam(model.parameters(), lr=1e-3, weight_decay=0.1)
+        optimizer.fuse_depth_update(model.backbone.depth)
+        for step in range(4):
+            optimizer.zero_grad(set_to_none=True)
+            before = model.backbone.depth.detach().clone()
+            out = model(batch, flows, step)
+            total = loss_of(out)
+            assert torch.equal(before, model.backbone.depth.detach())  # weight decay: the usual path
+            total.backward()
+            optimizer.step()
+
+        model, batch, flows, loss_of = _small_problem(dev, tracking=False)
+        optimizer = FusedAdam(model.parameters(), lr=1e-3)
+        optimizer.fuse_depth_update(model.backbone.depth)
+        with pytest.raises(ValueError):
+            optimizer.fuse_depth_update(torch.zeros(3, device=dev, requires_grad=True))
+        for step in range(3):
+            optimizer.zero_grad(set_to_none=True)
+            loss_of(model(batch, flows, step)).backward()
+            optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+        out = model(batch, flows, 3)
+        total = loss_of(out)  # applied in the pass
+        assert optimizer.in_pass_pending(model.backbone.depth)
+        with pytest.raises(RuntimeError, match="already updated"):
+            _ops.note_touched(out.depths, "late consumer", torch.zeros((4,), dtype=torch.int64, device=dev))
+        total.backward(retain_graph=True)
+        with pytest.raises(RuntimeError, match="twice"):
+            total.backward()
+        optimizer.step()
+        assert not optimizer.in_pass_pending(model.backbone.depth)
+        optimizer.fuse_depth_update(model.backbone.depth, enabled=False)
+        optimizer.zero_grad(set_to_none=True)
+        before = model.backbone.depth.detach().clone()
+        total = loss_of(model(batch, flows, 4))
+        assert torch.equal(before, model.backbone.depth.detach())
     finally:
         flowmap_amd.set_lazy_surfaces(False)

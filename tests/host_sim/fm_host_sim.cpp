@@ -117,6 +117,25 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
   return 0;
 }
 
+int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd, const float* flow_fwd,
+                            const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, const float* packed, const float* scale,
+                            int batch, int frames, int height, int width, int mapping_kind, float delta, float ax, float ay,
+                            float* grad_depth, double* acc, int items, float* exp_avg, float* exp_avg_sq, const uint8_t* touched, long step,
+                            double lr, double beta1, double beta2, double eps, void* stream) {
+  if (!exp_avg || !exp_avg_sq || !touched || !scale || !grad_depth || step < 1 || width % 4 != 0) return 1;
+  const size_t total = (size_t)batch * frames * height * width;
+  std::vector<float> g(total);  // the full gradient, then the update where the kernel applies it in its own pass
+  if (fm_flow_loss_fused(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
+                         mapping_kind, delta, ax, ay, g.data(), acc, items, stream) != 0)
+    return 2;
+  const AdamCoef c = adam_coefficients((double)step, lr, beta1, beta2, eps, 0.0);
+  for (size_t i = 0; i < total; ++i) {
+    if ((touched[i / 4] >> (i % 4)) & 1u) grad_depth[i] = g[i];
+    else adam_update(c, depth[i], g[i], exp_avg[i], exp_avg_sq[i]);
+  }
+  return 0;
+}
+
 int fm_flow_loss_finalize(double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
                           const float* norm, int batch, int frames, float ax, float ay, float* loss, float* g_t_fwd, float* g_t_bwd,
                           float* g_k, void*) {
@@ -355,6 +374,14 @@ int fm_resize_crop(const float* in, long planes, int h, int w, int rh, int rw, i
         out[((size_t)p * oh + y) * ow + x] = ty.l0 * (tx.l0 * s[(size_t)ty.i0 * w + tx.i0] + tx.l1 * s[(size_t)ty.i0 * w + tx.i1]) +
                                             ty.l1 * (tx.l0 * s[(size_t)ty.i1 * w + tx.i0] + tx.l1 * s[(size_t)ty.i1 * w + tx.i1]);
       }
+  return 0;
+}
+
+int fm_adam_step_elements(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* elements, long count, long step,
+                          double lr, double beta1, double beta2, double eps, double weight_decay, void*) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1 || (count > 0 && !elements)) return 1;
+  const AdamCoef c = adam_coefficients((double)step, lr, beta1, beta2, eps, weight_decay);
+  for (long i = 0; i < count; ++i) adam_update(c, param[elements[i]], grad[elements[i]], exp_avg[elements[i]], exp_avg_sq[elements[i]]);
   return 0;
 }
 

@@ -422,3 +422,13 @@ def test_flow_fused_leaves(f, h, w, packed, kind):
     poses, on the GPU (DPP wave sums, fp64 LDS/atomic reduction, flow_finalize_frame), both input
     layouts, a width that is not a multiple of 4, all three mappings, and a 720p frame."""
     cases.case_flow_fused_leaves(DEV, f, h, w, packed, kind)
+
+
+@pytest.mark.gpu
+def test_depth_adam_update_inside_the_flow_pass_follows_torch_adam():
+    cases.case_in_pass_adam(DEV, steps=200)
+
+
+@pytest.mark.gpu
+def test_in_pass_adam_update_refuses_what_it_cannot_do():
+    cases.case_in_pass_adam_refusals(DEV)

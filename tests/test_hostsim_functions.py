@@ -141,3 +141,11 @@ def test_second_backward_and_autograd_grad():
 
 def test_backward_on_worker_threads_with_grad_hooks():
     cases.case_threads_and_hooks("cpu")
+
+
+def test_depth_adam_update_inside_the_flow_pass_follows_torch_adam():
+    cases.case_in_pass_adam("cpu")
+
+
+def test_in_pass_adam_update_refuses_what_it_cannot_do():
+    cases.case_in_pass_adam_refusals("cpu")

@@ -15,6 +15,9 @@ for w in $what; do
     bench) python bench.py > $out/bench_c1.json 2> $out/bench_c1.err; cat $out/bench_c1.json ;;
     dense) python bench.py --points 0 --cpu-frames 0 > $out/bench_dense.json 2> $out/bench_dense.err; cat $out/bench_dense.json ;;
     track) python bench.py --tracking --cpu-frames 0 > $out/bench_c2.json 2> $out/bench_c2.err; cat $out/bench_c2.json ;;
+    run-*)  # run-<name>:<bench args with + for spaces>   -> one bench line
+      name=${w#run-}; args=${name#*:}; name=${name%%:*}; args=${args//+/ }
+      python bench.py --cpu-frames 0 $args > $out/bench_$name.json 2> $out/bench_$name.err; cat $out/bench_$name.json; tail -3 $out/bench_$name.err ;;
     prof-*)  # prof-<name>:<bench args with + for spaces>, e.g. prof-dense:--points+0   -> rocprofv3 kernel stats
       name=${w#prof-}; args=${name#*:}; name=${name%%:*}; args=${args//+/ }
       (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $REPO/$out/prof_$name -o stats -- python $REPO/bench.py --steps 10 --warmup 3 --cpu-frames 0 $args > /dev/null 2> $REPO/$out/prof_$name.err)
