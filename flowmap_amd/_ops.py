@@ -136,6 +136,23 @@ def _root(t: Tensor) -> Tensor:
     return t if t._base is None else t._base
 
 
+def _note_sparse_grad(weights: Tensor, arena, indices: Tensor, pixels_per_pair: int) -> None:
+    """dL/dweights of a planned fit lives in the arena and is zero outside the slots ``indices`` selects in every pair
+    (projection.py:226-249 gathers P weights per pair): the parameter carries (arena, flat slot list) so that FusedAdam
+    can update those elements only — exactly torch.optim.Adam as long as the moments are zero everywhere else."""
+    root = _root(weights)
+    if weights.numel() != root.numel() or indices.dim() != 1:
+        return
+
+    def build():
+        pairs = root.numel() // int(pixels_per_pair)  # one index list (projection.py:227: Int64[" point"]) for every pair
+        offsets = torch.arange(pairs, dtype=torch.int64, device=indices.device)[:, None] * int(pixels_per_pair)
+        return indices, torch.unique((indices.reshape(1, -1) + offsets).reshape(-1)).contiguous()
+
+    elements = _derived(root, "_fm_sparse_elements", (id(indices), indices._version, int(pixels_per_pair)), build)[1]
+    root.__dict__["_fm_sparse_grad"] = (arena, elements)
+
+
 def note_touched(depth: Tensor, consumer: str, pixels: Optional[Tensor]) -> None:
     """A consumer of ``depth`` other than the fused flow loss (the Procrustes fit, the tracking loss) records the
     STATIC set of elements it reads / adds gradient to (flat indices into ``depth``) on the parameter behind it.
@@ -375,6 +392,7 @@ class ProcrustesFit:
                         counters["procrustes_planned"] += 1
                         if use_grad_arena and torch.is_tensor(weights) and weights.requires_grad:
                             arena = grad_arena(weights)
+                            _note_sparse_grad(weights, arena, indices, h * w)
             wsink = weights.__dict__.get("_fm_sink")  # exists when the softmin sweep took LeadingFrames of the weights
         work = None
         if chain and rep == 1 and indices is not None and bwd_flow.dim() == 5:

@@ -220,6 +220,11 @@ struct GradArena : torch::CustomClassHolder {
     return buffer;
   }
   Tensor alias() const { return buffer.alias(); }  // a new tensor over the same storage: autograd's to keep
+  // is `grad` this arena's storage exactly as the last backward left it (zero outside the slots, nothing added or edited)?
+  bool holds(const Tensor& grad) const {
+    return buffer.defined() && grad.defined() && grad.data_ptr() == buffer.data_ptr() && grad.numel() == buffer.numel() &&
+           (int64_t)grad._version() == version && grad.is_contiguous();
+  }
 };
 
 // does the autograd graph above `from` contain `target` within `depth` hops?  (poses -> [chain ->] fit)
@@ -1037,7 +1042,8 @@ TORCH_LIBRARY(flowmap_amd, m) {
   m.class_<fmt::GradArena>("GradArena")
       .def(torch::init<>())
       .def("reused", [](const c10::intrusive_ptr<fmt::GradArena>& a) { return a->reused; })
-      .def("refilled", [](const c10::intrusive_ptr<fmt::GradArena>& a) { return a->refilled; });
+      .def("refilled", [](const c10::intrusive_ptr<fmt::GradArena>& a) { return a->refilled; })
+      .def("holds", [](const c10::intrusive_ptr<fmt::GradArena>& a, const at::Tensor& grad) { return a->holds(grad); });
   m.def("set_library(str path, bool test_double) -> ()", fmt::set_library);
   m.def("intrinsics_inverse(Tensor k) -> Tensor", fmt::intrinsics_inverse);
   m.def("focal_intrinsics(Tensor focal, int[] repeat_shape, int height, int width) -> (Tensor, Tensor)", fmt::focal_intrinsics_op);

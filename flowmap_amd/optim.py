@@ -37,6 +37,8 @@ class FusedAdam(torch.optim.Optimizer):
         # the kernel derives the bias corrections from it, so step() can sit inside a hipGraph
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
                                       capturable=bool(capturable)))
+        self.counters = {"sparse_updates": 0, "in_pass_updates": 0}  # (tests, bench notes)
+        self._support = {}  # parameter -> element list outside which exp_avg / exp_avg_sq are exactly zero, or "dense"
         self._in_pass = {}  # parameter -> (step number, element list) of an update the fused flow loss has already applied
 
     # -- the depth parameter's update inside the fused flow loss (SURVEY.md §8f-2's end state) -----------------------
@@ -59,6 +61,51 @@ class FusedAdam(torch.optim.Optimizer):
             param.__dict__["_fm_fused_adam"] = self
         else:
             param.__dict__.pop("_fm_fused_adam", None)
+
+    # -- parameters whose gradient is zero outside a static element list (the correspondence-weight logits) ----------
+    def _sparse_update(self, p: torch.Tensor, group) -> bool:
+        """dL/dweights of the planned Procrustes fit is zero outside P slots per pair, the same slots every step
+        (extrinsics_procrustes.py:33-38 draws them once).  Where exp_avg and exp_avg_sq are zero and the gradient is
+        zero, Adam leaves a parameter exactly where it is (0 / (0 + eps)), so updating the slot list alone IS the dense
+        update — 28 B x 138 M elements per step saved at 150 x 720p.  Taken only when that premise is known to hold:
+        the gradient is the GradArena's storage untouched since backward, no weight decay, and the moments are zero
+        outside the list (a fresh state, or verified once after dense steps)."""
+        note = p.__dict__.get("_fm_sparse_grad")
+        if note is None or group["weight_decay"] != 0 or group.get("capturable"):
+            self._support[p] = "dense"
+            return False
+        arena, elements = note
+        if not arena.holds(p.grad) or p.dtype != torch.float32 or not p.is_contiguous():
+            self._support[p] = "dense"
+            return False
+        state = self.state[p]
+        if len(state) == 0:
+            state["step"] = torch.tensor(0.0, dtype=torch.float32)
+            state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            self._support[p] = elements
+        support = self._support.get(p, "dense")
+        if support is not elements:
+            if isinstance(support, str) and support == "dense-nonzero":
+                return False
+            # once: are the moments zero everywhere else?  (earlier dense steps saw the same sparse gradient)
+            outside = torch.ones((p.numel(),), dtype=torch.bool, device=p.device)
+            outside[elements] = False
+            clean = not bool(((state["exp_avg"].reshape(-1) != 0) & outside).any() | ((state["exp_avg_sq"].reshape(-1) != 0) & outside).any())
+            self._support[p] = elements if clean else "dense-nonzero"
+            if not clean:
+                return False
+        state["step"] += 1
+        beta1, beta2 = group["betas"]
+        torch_ops().adam_step_elements(p, p.grad, state["exp_avg"], state["exp_avg_sq"], elements, int(state["step"].item()),
+                                       float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), 0.0)
+        self.counters["sparse_updates"] += 1
+        return True
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        self._support.clear()  # loaded moments: where they are zero is verified again before the next element-list update
+        self._in_pass.clear()
 
     def in_pass_pending(self, param: torch.Tensor) -> bool:
         return param in self._in_pass
@@ -90,6 +137,7 @@ class FusedAdam(torch.optim.Optimizer):
         state["step"] += 1
         step = int(state["step"].item())
         self._in_pass[param] = (step, elements)
+        self.counters["in_pass_updates"] += 1
         beta1, beta2 = group["betas"]
         return (state["exp_avg"].view(depth.shape), state["exp_avg_sq"].view(depth.shape), mask, step, [float(group["lr"]), float(beta1), float(beta2), float(group["eps"])])
 
@@ -113,6 +161,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if p.grad is None:
                     continue
                 grad = p.grad
+                if self._sparse_update(p, group):
+                    continue
                 if grad.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
                 if p.dtype != torch.float32 or grad.dtype != torch.float32:

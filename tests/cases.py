@@ -1057,6 +1057,9 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3):
     finally:
         flowmap_amd.set_lazy_surfaces(False)
     assert engaged >= steps - 3, engaged  # the plan exists from the third step on
+    for mode in ("fused", "in_pass"):  # the weight logits: element-list update from the first planned step on
+        assert trajectories[mode][1].counters["sparse_updates"] >= steps - 3, trajectories[mode][1].counters
+    assert trajectories["in_pass"][1].counters["in_pass_updates"] == engaged
     ref = trajectories["torch"][0]
     for mode in ("fused", "in_pass"):
         for step, (a, b) in enumerate(zip(trajectories[mode][0], ref)):
@@ -1092,6 +1095,26 @@ def case_in_pass_adam_refusals(dev):
             assert torch.equal(before, model.backbone.depth.detach())  # weight decay: the usual path
             total.backward()
             optimizer.step()
+
+        # the element-list update of the weight logits: not when the gradient was edited after backward (clipping) —
+        # the dense update runs, and the list is taken up again once the moments are verified zero elsewhere
+        model, batch, flows, loss_of = _small_problem(dev, tracking=False)
+        twin, _, _, twin_loss = _small_problem(dev, tracking=False)
+        optimizer, reference = FusedAdam(model.parameters(), lr=1e-3), torch.optim.Adam(twin.parameters(), lr=1e-3)
+        for step in range(7):
+            for m, o, fn in ((model, optimizer, loss_of), (twin, reference, twin_loss)):
+                o.zero_grad(set_to_none=True)
+                fn(m(batch, flows, step)).backward()
+                if step == 4:
+                    m.backbone.weights.grad.mul_(0.5)
+                o.step()
+            assert optimizer.counters["sparse_updates"] == (0, 1, 2, 3, 3, 4, 5)[step], (step, optimizer.counters)
+            assert_close(model.backbone.weights.detach(), twin.backbone.weights.detach(), 2e-6, abs_=2e-6, what=f"weights step {step}")
+        optimizer.load_state_dict(optimizer.state_dict())  # loaded moments are verified before the list is used again
+        optimizer.zero_grad(set_to_none=True)
+        loss_of(model(batch, flows, 7)).backward()
+        optimizer.step()
+        assert optimizer.counters["sparse_updates"] == 6
 
         model, batch, flows, loss_of = _small_problem(dev, tracking=False)
         optimizer = FusedAdam(model.parameters(), lr=1e-3)
