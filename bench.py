@@ -398,13 +398,16 @@ def main():
     for name in ("r02_flow_kernel_traffic.json", "r01_flow_kernel_traffic.json"):  # HBM bytes per launch from the PMC passes (same workload only)
         try:
             rec = json.loads((ROOT / "profiles" / name).read_text())
-            if rec["workload"] == {"frames": f, "height": h, "width": w}:
-                traffic, traffic_src = rec["hbm_bytes_per_launch"], f"profiles/{name} (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"
+            if {k: rec["workload"][k] for k in ("frames", "height", "width")} == {"frames": f, "height": h, "width": w}:
+                entry = rec["flow_fused_kernel_adam"] if args.optimizer == "in_pass" else rec
+                traffic, traffic_src = entry["hbm_bytes_per_launch"], f"profiles/{name} (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"
                 break
         except Exception:
             pass
     n = h * w
     algo_bytes = n * (8 * f + 24 * (f - 1))  # B_flow per launch (this rank's frames)
+    if args.optimizer == "in_pass":  # depth, exp_avg, exp_avg_sq read and rewritten (24 B per pixel and frame), no dL/ddepth written
+        algo_bytes = n * (24 * f + 24 * (f - 1))
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
     if rank == 0:
@@ -444,7 +447,7 @@ def main():
                 "loss": float(loss.item()),
             },
             "roofline": {
-                "kernel": "fm::flow_fused_kernel<VEC=4, huber, GRAD, PACKED>",
+                "kernel": "fm::flow_fused_kernel<VEC=4, huber, GRAD, PACKED" + (", ADAM>" if args.optimizer == "in_pass" else ">"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

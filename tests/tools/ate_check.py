@@ -69,6 +69,8 @@ def run(args):
     track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01))) if args.tracking else None
     tracks = to_tracks(otracks, dev)
     opt = flowmap_amd.FusedAdam(model.parameters(), lr=args.lr)  # the reference leg above uses torch.optim.Adam
+    if args.in_pass:
+        opt.fuse_depth_update(model.backbone.depth)  # the depth update applied by the flow-loss pass itself
     if dev.type == "cuda":
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -97,7 +99,9 @@ def run(args):
         "ate_abs_diff": abs(ate_ref - ate_ours),
         "final_loss_reference_path": loss_ref, "final_loss_flowmap_amd": loss_ours,
         "seconds_reference_path_cpu": t_ref, "seconds_flowmap_amd": t_ours, "device": str(dev),
-        "optimizer": "reference path: torch.optim.Adam; flowmap_amd: flowmap_amd.FusedAdam",
+        "optimizer": "reference path: torch.optim.Adam; flowmap_amd: flowmap_amd.FusedAdam"
+                     + (f" with fuse_depth_update ({opt.counters['in_pass_updates']} of {args.steps} depth updates inside the flow pass, "
+                        f"{opt.counters['sparse_updates']} element-list updates of the weight logits)" if args.in_pass else ""),
     }
 
 
@@ -113,6 +117,7 @@ if __name__ == "__main__":
     ap.add_argument("--noise", type=float, default=0.05)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tracking", action="store_true", help="add the tracking loss (tracks = oracle projections of the true surface)")
+    ap.add_argument("--in-pass", action="store_true", help="FusedAdam.fuse_depth_update: depth update inside the fused flow pass")
     ap.add_argument("--track-grid", type=int, default=12)
     ap.add_argument("--threads", type=int, default=16, help="torch CPU threads for the reference-path leg")
     a = ap.parse_args()

@@ -20,11 +20,22 @@ def short(name, n=90):
 
 
 def kernel_table(path):
+    """This package's kernels (namespace fm) one per row; everything else — torch's elementwise / GEMM kernels of the
+    synthetic-scene construction before the timed region — summed into one row."""
     con = sqlite3.connect(path)
     rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
     print("kernel,calls,total_us,avg_us,percent")
+    other = [0, 0.0, 0.0]
     for name, calls, total, avg, pct in rows:
-        print(f"\"{short(name)}\",{calls},{total:.1f},{avg:.2f},{pct:.2f}")
+        if "fm::" in name:
+            print(f"\"{short(name)}\",{calls},{total:.1f},{avg:.2f},{pct:.2f}")
+        else:
+            other[0] += calls
+            other[1] += total
+            other[2] += pct
+    if other[0]:
+        print(f"\"(not fm::) torch kernels of the scene / track synthesis and set-up, outside the timed steps\",{other[0]},{other[1]:.1f},"
+              f"{other[1] / other[0]:.2f},{other[2]:.2f}")
 
 
 def pmc_table(path):

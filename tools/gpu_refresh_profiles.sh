@@ -1,48 +1,77 @@
 #!/bin/bash
-# Regenerate every artefact kept under profiles/ (run through gpurun; results land in
-# gpurun_out/profiles_new/, copy them into profiles/ afterwards).
+# Regenerate every artefact kept under profiles/ for one round (run through gpurun; results land in
+# gpurun_out/profiles_new/, copy them into profiles/ afterwards).   ROUND=r02 bash tools/gpu_refresh_profiles.sh [part...]
+# parts: bench variants stats pmc ate misc      (default: all)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 REPO=$PWD
+R=${ROUND:-r02}
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/profiles_new
 mkdir -p "$OUT"
-python bench.py --steps 30 --warmup 5 > "$OUT/r01_bench_c1.json" 2> "$OUT/bench_c1.err"
-python bench.py --steps 30 --warmup 5 --cpu-frames 0 --tracking > "$OUT/r01_bench_c2_tracking.json" 2>/dev/null
-{ for a in "--intrinsics softmin" "--optimizer fused" "--optimizer torch" "--points 0" "--points 0 --smooth-flows" "--tracking --intrinsics softmin --optimizer fused"; do
-    python bench.py --steps 20 --warmup 5 --cpu-frames 0 $a 2>/dev/null; done; } > "$OUT/r01_bench_variants.jsonl"
-STEPS=20 bash tools/gpu_profile.sh > /dev/null 2>&1
-cp gpurun_out/profile_summary.txt "$OUT/r01_c1_bench_rocprofv3_summary.csv"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_track" -o stats -- python "$REPO/bench.py" --steps 20 --warmup 2 --cpu-frames 0 --tracking > /dev/null 2>&1)
-python tools/export_profile.py gpurun_out/prof_track > "$OUT/r01_c2_tracking_rocprofv3_summary.csv"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_dense" -o stats -- python "$REPO/bench.py" --steps 6 --warmup 2 --cpu-frames 0 --points 0 > /dev/null 2>&1)
-python tools/export_profile.py gpurun_out/prof_dense > "$OUT/r01_dense_procrustes_rocprofv3_summary.csv"
-python - <<'PY' > "$OUT/r01_flow_kernel_traffic.json"
-import glob, json, sqlite3
-def avg(d, counter):
+parts=${*:-bench variants stats pmc ate misc}
+stats() {  # stats <name> <bench args...>: rocprofv3 kernel trace of a short bench run -> per-kernel table
+  local name=$1; shift
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_$name" -o stats -- python "$REPO/bench.py" --steps 20 --warmup 3 --cpu-frames 0 "$@" > /dev/null 2> "$OUT/prof_$name.err")
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --cpu-frames 0 $*   (calls = 3 set-up + 3 warm-up + 20 timed steps)"; python tools/export_profile.py "gpurun_out/prof_$name"; } > "$OUT/${R}_${name}_rocprofv3_summary.csv" 2>> "$OUT/prof_$name.err"
+  rm -rf "gpurun_out/prof_$name"
+}
+for part in $parts; do
+case $part in
+bench)
+  python bench.py > "$OUT/${R}_bench_c1.json" 2> "$OUT/bench_c1.err"
+  python bench.py --config c2 > "$OUT/${R}_bench_c2_tracking.json" 2> "$OUT/bench_c2.err" ;;
+variants)
+  { for a in "--config c3" "--config c4" "--inputs iid" "--intrinsics softmin" "--optimizer fused" "--optimizer in_pass" "--optimizer torch" \
+             "--config c2 --optimizer in_pass" "--points 0" "--config c2 --intrinsics softmin --optimizer fused" \
+             "--height 180 --width 240" "--height 180 --width 240 --optimizer fused" "--height 180 --width 240 --optimizer fused --graph" \
+             "--height 180 --width 240 --intrinsics softmin" "--height 180 --width 240 --tracking --optimizer fused" \
+             "--height 180 --width 240 --tracking --optimizer fused --graph"; do
+      python bench.py --cpu-frames 0 $a 2>> "$OUT/variants.err"; done; } > "$OUT/${R}_bench_variants.jsonl"
+  FLOWMAP_BENCH_FORCE_DIST=1 python bench.py --cpu-frames 0 --config c2 > "$OUT/${R}_bench_c2_rccl_single_rank_selftest.json" 2>> "$OUT/variants.err" ;;
+stats)
+  stats c1_bench
+  stats c2_tracking --config c2
+  stats dense_procrustes --points 0
+  stats c1_adam_in_pass --optimizer in_pass
+  stats default_resolution_180x240_tracking_adam --height 180 --width 240 --tracking --optimizer fused ;;
+pmc)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c -d "$REPO/gpurun_out/prof_$c" -o pmc -- python "$REPO/bench.py" --steps 20 --warmup 3 --cpu-frames 0 > /dev/null 2> "$OUT/prof_$c.err")
+    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c -d "$REPO/gpurun_out/prof_adam_$c" -o pmc -- python "$REPO/bench.py" --steps 20 --warmup 3 --cpu-frames 0 --optimizer in_pass > /dev/null 2> "$OUT/prof_adam_$c.err")
+  done
+  python - "$R" <<'PY' > "$OUT/${R}_flow_kernel_traffic.json"
+import glob, json, sqlite3, sys
+def avg(d, counter, like):
     con = sqlite3.connect(glob.glob(d + "/**/*.db", recursive=True)[0])
-    n, v = con.execute("select count(*), avg(value) from counters_collection where kernel_name like '%flow_fused_kernel%' and counter_name = ?", (counter,)).fetchone()
-    return n, v
-nf, fetch = avg("gpurun_out/prof_fetch", "FETCH_SIZE")
-nw, write = avg("gpurun_out/prof_write", "WRITE_SIZE")
+    return con.execute("select count(*), avg(value) from counters_collection where kernel_name like ? and counter_name = ?", (like, counter)).fetchone()
 f, h, w = 150, 720, 1280
-algo = h * w * (8 * f + 24 * (f - 1))
-rd, wr = fetch * 1024 * 2, write * 1024
-print(json.dumps({
-    "round": 1,
-    "kernel": "fm::flow_fused_kernel<4, 0, true, true> (affine projection form, packed constants, non-temporal accesses)",
-    "workload": {"frames": f, "height": h, "width": w},
-    "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), python bench.py --steps 20 --warmup 2 --cpu-frames 0; {nf} / {nw} dispatches; see r01_c1_bench_rocprofv3_summary.csv",
-    "fetch_size_kb_raw_avg": fetch, "write_size_kb_raw_avg": write,
-    "fetch_correction": "x2: on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streaming reads (MI355X_MICROARCH.md HBM section); confirmed earlier in this round on torch's sigmoid kernel (reads 549.2 MB, FETCH_SIZE 268220 KB) and on fm::sum2_kernel (reads 1098.4 MB, reports 549.3 MB)",
-    "write_correction": "x1: confirmed on torch's sigmoid kernel (writes 549.2 MB, WRITE_SIZE 536400 KB)",
-    "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
-    "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": round((rd + wr) / algo, 4)}, indent=2))
+out = {"round": int(sys.argv[1][1:]), "workload": {"frames": f, "height": h, "width": w, "inputs": "scene"},
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), python bench.py --steps 20 --warmup 3 --cpu-frames 0 [--optimizer in_pass]",
+       "fetch_correction": "x2: on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streaming reads (MI355X_MICROARCH.md HBM section); confirmed in round 1 on torch's sigmoid kernel (reads 549.2 MB, FETCH_SIZE 268220 KB) and on fm::sum2_kernel (reads 1098.4 MB, reports 549.3 MB)",
+       "write_correction": "x1: confirmed on torch's sigmoid kernel (writes 549.2 MB, WRITE_SIZE 536400 KB)"}
+for key, prefix, like, per_px in (("flow_fused_kernel", "gpurun_out/prof_", "%flow_fused_kernel<4, 0, true, true, false>%", (8, 24)),
+                                   ("flow_fused_kernel_adam", "gpurun_out/prof_adam_", "%flow_fused_kernel<4, 0, true, true, true>%", (24, 24))):
+    nf, fetch = avg(prefix + "FETCH_SIZE", "FETCH_SIZE", like)
+    nw, write = avg(prefix + "WRITE_SIZE", "WRITE_SIZE", like)
+    algo = h * w * (per_px[0] * f + per_px[1] * (f - 1))
+    rd, wr = fetch * 1024 * 2, write * 1024
+    entry = {"kernel": like.strip("%"), "dispatches": [nf, nw], "fetch_size_kb_raw_avg": fetch, "write_size_kb_raw_avg": write,
+             "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
+             "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": round((rd + wr) / algo, 4)}
+    if key == "flow_fused_kernel":
+        out.update(entry)  # (bench.py reads these keys)
+    else:
+        out[key] = entry
+print(json.dumps(out, indent=2))
 PY
-python tools/probes/bw_probe.py > "$OUT/r01_hbm_stream_probe.json" 2>/dev/null
-python tools/adam_microbench.py > "$OUT/r01_adam_microbench.json" 2>/dev/null
-python tests/tools/preprocess_bench.py > "$OUT/r01_preprocess_bench.jsonl" 2>/dev/null
-python tests/tools/ate_check.py --device cuda > "$OUT/ate.log" 2>&1; tail -1 "$OUT/ate.log" > "$OUT/r01_ate_c0_16x256x256.json"
-python tests/tools/ate_check.py --device cuda --height 192 --width 256 --tracking > "$OUT/ate_tracking.log" 2>&1; tail -1 "$OUT/ate_tracking.log" > "$OUT/r01_ate_16x192x256_flow_tracking.json"
-rm -rf gpurun_out/prof_track gpurun_out/prof_dense gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_stats
-ls -la "$OUT"; cat "$OUT/r01_bench_c1.json"; cat "$OUT/r01_flow_kernel_traffic.json" | tail -8
+  rm -rf gpurun_out/prof_FETCH_SIZE gpurun_out/prof_WRITE_SIZE gpurun_out/prof_adam_FETCH_SIZE gpurun_out/prof_adam_WRITE_SIZE ;;
+ate)
+  python tests/tools/ate_check.py --device cuda --in-pass 2> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_c0_16x256x256.json"
+  python tests/tools/ate_check.py --device cuda --height 192 --width 256 --tracking --in-pass 2>> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_16x192x256_flow_tracking.json"
+  python tests/tools/ate_check.py --device cuda --frames 32 --height 360 --width 640 --tracking --in-pass 2>> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_32x360x640_flow_tracking.json" ;;
+misc)
+  python tools/dense_microbench.py > "$OUT/${R}_dense_microbench.txt" 2>&1 ;;
+esac
+done
+ls -la "$OUT"; cat "$OUT/${R}_bench_c1.json" 2>/dev/null
