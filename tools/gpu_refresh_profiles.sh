@@ -37,8 +37,9 @@ stats)
   stats default_resolution_180x240_tracking_adam --height 180 --width 240 --tracking --optimizer fused ;;
 pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c -d "$REPO/gpurun_out/prof_$c" -o pmc -- python "$REPO/bench.py" --steps 20 --warmup 3 --cpu-frames 0 > /dev/null 2> "$OUT/prof_$c.err")
-    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c -d "$REPO/gpurun_out/prof_adam_$c" -o pmc -- python "$REPO/bench.py" --steps 20 --warmup 3 --cpu-frames 0 --optimizer in_pass > /dev/null 2> "$OUT/prof_adam_$c.err")
+    # (i.i.d. inputs and a kernel filter: with the scene synthesis' 126 000 torch launches in the counter pass rocprofv3 crashed)
+    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "flow_fused_kernel" -d "$REPO/gpurun_out/prof_$c" -o pmc -- python "$REPO/bench.py" --steps 20 --warmup 3 --cpu-frames 0 --inputs iid > /dev/null 2> "$OUT/prof_$c.err")
+    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "flow_fused_kernel" -d "$REPO/gpurun_out/prof_adam_$c" -o pmc -- python "$REPO/bench.py" --steps 20 --warmup 3 --cpu-frames 0 --inputs iid --optimizer in_pass > /dev/null 2> "$OUT/prof_adam_$c.err")
   done
   python - "$R" <<'PY' > "$OUT/${R}_flow_kernel_traffic.json"
 import glob, json, sqlite3, sys
@@ -46,8 +47,8 @@ def avg(d, counter, like):
     con = sqlite3.connect(glob.glob(d + "/**/*.db", recursive=True)[0])
     return con.execute("select count(*), avg(value) from counters_collection where kernel_name like ? and counter_name = ?", (like, counter)).fetchone()
 f, h, w = 150, 720, 1280
-out = {"round": int(sys.argv[1][1:]), "workload": {"frames": f, "height": h, "width": w, "inputs": "scene"},
-       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), python bench.py --steps 20 --warmup 3 --cpu-frames 0 [--optimizer in_pass]",
+out = {"round": int(sys.argv[1][1:]), "workload": {"frames": f, "height": h, "width": w, "inputs": "iid"},
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) --kernel-include-regex flow_fused_kernel, python bench.py --steps 20 --warmup 3 --cpu-frames 0 --inputs iid [--optimizer in_pass]",
        "fetch_correction": "x2: on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streaming reads (MI355X_MICROARCH.md HBM section); confirmed in round 1 on torch's sigmoid kernel (reads 549.2 MB, FETCH_SIZE 268220 KB) and on fm::sum2_kernel (reads 1098.4 MB, reports 549.3 MB)",
        "write_correction": "x1: confirmed on torch's sigmoid kernel (writes 549.2 MB, WRITE_SIZE 536400 KB)"}
 for key, prefix, like, per_px in (("flow_fused_kernel", "gpurun_out/prof_", "%flow_fused_kernel<4, 0, true, true, false>%", (8, 24)),
