@@ -20,6 +20,7 @@ object, i.e. per step) and ``GradArena`` (one per weight parameter).
 from __future__ import annotations
 
 import ctypes
+import warnings
 from typing import Optional
 
 import torch
@@ -40,7 +41,11 @@ TRACK_TILE = 6  # FM_TRACK_TILE (include/flowmap_hip.h; tests/test_abi.py checks
 def _f32c(t: Tensor, what: str) -> Tensor:
     if t.dtype != torch.float32:
         raise RuntimeError(f"flowmap_amd: {what} must be float32 (got {t.dtype})")
-    return t if t.is_contiguous() else t.contiguous()
+    if t.is_contiguous():
+        return t
+    if t.numel() >= 1 << 24:  # a copy the size of a pass over the step's tensors: say so (SURVEY.md §8b "Ownership")
+        warnings.warn(f"flowmap_amd: {what} is a non-contiguous view of {t.numel() * 4 >> 20} MB and is copied on every call; pass a contiguous tensor")
+    return t.contiguous()
 
 
 class _guard:

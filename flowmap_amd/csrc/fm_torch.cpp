@@ -99,8 +99,13 @@ static void fm_check(int status, const char* name) {
 // ------------------------------------------------------------------------------------------
 // Small helpers
 // ------------------------------------------------------------------------------------------
+// The C ABI takes dense row-major buffers.  A view is accepted and copied; a copy that costs as much as a pass of the
+// step is said out loud, once per argument kind, instead of silently (SURVEY.md §8b "Ownership": the reference's own
+// tensors are contiguous at b = 1 — `depth[None]`, the Flows fields — so this is the day a caller passes a real view).
 static Tensor f32c(const Tensor& t, const char* what) {
   TORCH_CHECK(t.scalar_type() == at::kFloat, "flowmap_amd: ", what, " must be float32 (got ", t.scalar_type(), ")");
+  if (!t.is_contiguous() && t.numel() >= (int64_t(16) << 20))
+    TORCH_WARN("flowmap_amd: ", what, " is a non-contiguous view of ", t.numel() * 4 / (1 << 20), " MB and is copied on every call; pass a contiguous tensor");
   return t.contiguous();
 }
 

@@ -1,11 +1,4 @@
-"""Host-side runtime helpers for launch-bound optimisation loops.
-
-A step enqueues ~20-60 small launches from Python and allocates a few hundred short-lived
-container objects.  CPython's cyclic collector therefore runs a full (generation 2) pass every few
-hundred steps, and a full pass walks every object torch and its dependencies created at import:
-≈50 ms on the GPU box, i.e. the cost of ~40 steps (measured: 1.38 vs 2.4-2.8 ms per step for a
-30-step window, depending on whether the pass fell inside it).
-"""
+"""Host-side helper for launch-bound optimisation loops."""
 
 from __future__ import annotations
 
@@ -13,10 +6,8 @@ import gc
 
 
 def freeze_gc() -> int:
-    """Collect once, then move everything alive now (modules, the model, cached inputs) to the
-    permanent generation, so later full passes only look at objects created afterwards.  Call after
-    the model / optimiser / inputs exist and before the optimisation loop.  Returns the number of
-    objects frozen; ``gc.unfreeze()`` undoes it."""
+    """Collect once, then move everything alive now to the permanent generation: a full pass of the cyclic collector
+    over torch's import-time objects costs ≈50 ms, i.e. ≈40 steps.  Returns the number of objects frozen."""
     gc.collect()
     gc.freeze()
     return gc.get_freeze_count()

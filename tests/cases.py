@@ -1143,3 +1143,25 @@ def case_in_pass_adam_refusals(dev):
         assert torch.equal(before, model.backbone.depth.detach())
     finally:
         flowmap_amd.set_lazy_surfaces(False)
+
+
+def case_views_are_copied_loudly(dev):
+    """A non-contiguous input is accepted (the C ABI takes dense buffers: it is copied) with the result of the
+    contiguous call, and a copy the size of a pass of the step warns instead of happening silently."""
+    import warnings
+
+    f, h, w = 3, 1024, 2731  # 2 pairs x 2.8 M pixels x 2 floats = 22 M elements per flow tensor: above the 16 M threshold
+    sc = orc.synth_scene(f, 8, 8, seed=3)  # poses / intrinsics only
+    k = sc["intrinsics_gt"].expand(1, f, 3, 3).contiguous().to(dev)
+    ext = sc["extrinsics_gt"][None].contiguous().to(dev)
+    g = torch.Generator().manual_seed(0)
+    surfaces = (1.0 + torch.rand((1, f, h, w, 3), generator=g)).to(dev)
+    wide = (1.0 + torch.rand((1, f, h, w, 4), generator=g)).to(dev)
+    view = wide[..., :3]
+    assert not view.is_contiguous()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        a = fm.compute_forward_flow(view, ext, k)
+    assert any("non-contiguous view" in str(c.message) for c in caught), [str(c.message) for c in caught]
+    b = fm.compute_forward_flow(view.contiguous(), ext, k)
+    assert torch.equal(a, b)

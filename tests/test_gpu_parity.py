@@ -432,3 +432,7 @@ def test_depth_adam_update_inside_the_flow_pass_follows_torch_adam():
 @pytest.mark.gpu
 def test_in_pass_adam_update_refuses_what_it_cannot_do():
     cases.case_in_pass_adam_refusals(DEV)
+
+
+def test_noncontiguous_views_are_copied_loudly():
+    cases.case_views_are_copied_loudly(DEV)
