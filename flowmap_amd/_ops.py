@@ -178,6 +178,22 @@ def note_touched(depth: Tensor, consumer: str, pixels: Optional[Tensor]) -> None
         registry[consumer] = pixels
 
 
+def note_leading_frames(depth: Tensor, count: int) -> None:
+    """The softmin sweep (intrinsics_softmin.py:85-131) reads `count` leading frames of ``depth`` at pixels it draws anew
+    every step: for FusedAdam.fuse_depth_update every element of those frames counts as touched.  count = 0 withdraws."""
+    root = _root(depth)
+    if root.__dict__.get("_fm_fused_adam") is None or depth.dim() != 4:
+        return
+    if count == 0:
+        if "softmin" in root.__dict__.get("_fm_touched", {}):
+            note_touched(depth, "softmin", None)
+        return
+    total = int(count) * depth.shape[2] * depth.shape[3]
+    elements = _derived(root, "_fm_leading_elements", (total, str(depth.device)),
+                        lambda: (None, torch.arange(total, dtype=torch.int64, device=depth.device)))[1]
+    note_touched(depth, "softmin", elements)
+
+
 def announce_track_pixels(depth: Tensor, tracks) -> None:
     """The tracking loss while it is still gated off (loss.py:39-41, `enable_after`): its static set of depth taps is
     recorded now, so that an in-pass depth update never has to learn about it in the middle of a step."""

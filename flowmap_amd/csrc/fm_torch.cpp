@@ -1009,9 +1009,12 @@ static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, con
   return {out[0], out[1], out[2]};
 }
 // would a flow loss fed these poses hand its dL/ddepth to the sink's fit (i.e. is the in-pass Adam update possible)?
-static bool flow_loss_parks(const Tensor& t_fwd, const Tensor& t_bwd, const c10::intrusive_ptr<DepthSink>& sink) {
-  return sink && sink->active && !sink->expect_leading && sink->fit_node != nullptr && reaches(t_fwd.grad_fn(), sink->fit_node, 3) &&
-         reaches(t_bwd.grad_fn(), sink->fit_node, 3);
+// `leading_covered`: the frames a LeadingFrames node of this step reads (the softmin sweep: random pixels of frames 0 / 1, new every
+// step) are wholly in the caller's touched set, so the sweep's gradient — added in place into the final buffer later — lands
+// on elements the in-pass update leaves alone
+static bool flow_loss_parks(const Tensor& t_fwd, const Tensor& t_bwd, const c10::intrusive_ptr<DepthSink>& sink, bool leading_covered) {
+  return sink && sink->active && (!sink->expect_leading || leading_covered) && sink->fit_node != nullptr &&
+         reaches(t_fwd.grad_fn(), sink->fit_node, 3) && reaches(t_bwd.grad_fn(), sink->fit_node, 3);
 }
 
 // Adam on a list of elements (the touched pixels of the in-pass update), versions bumped like adam_step
@@ -1075,7 +1078,8 @@ TORCH_LIBRARY(flowmap_amd, m) {
   m.def("adam_step(Tensor(a!) p, Tensor grad, Tensor(b!) m, Tensor(c!) v, int step, Tensor? step_tensor, float lr, float beta1, float beta2, float eps, "
         "float weight_decay) -> ()",
         fmt::adam_step);
-  m.def("flow_loss_parks(Tensor t_fwd, Tensor t_bwd, __torch__.torch.classes.flowmap_amd.DepthSink sink) -> bool", fmt::flow_loss_parks);
+  m.def("flow_loss_parks(Tensor t_fwd, Tensor t_bwd, __torch__.torch.classes.flowmap_amd.DepthSink sink, bool leading_covered) -> bool",
+        fmt::flow_loss_parks);
   m.def("adam_step_elements(Tensor(a!) p, Tensor grad, Tensor(b!) m, Tensor(c!) v, Tensor elements, int step, float lr, float beta1, float beta2, "
         "float eps, float weight_decay) -> ()",
         fmt::adam_step_elements);

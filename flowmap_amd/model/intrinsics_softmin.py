@@ -104,6 +104,7 @@ class IntrinsicsSoftmin(nn.Module):
         if reg is not None and global_step >= reg.after_step:
             if global_step == reg.after_step:
                 self.intrinsics_regressed.focal_length.data = torch.stack(self.window).mean()
+            _ops.note_leading_frames(backbone_output.depths, 0)  # the sweep no longer reads depth
             return self.intrinsics_regressed(batch, flows, backbone_output, global_step)
 
         def sweep():
@@ -113,6 +114,7 @@ class IntrinsicsSoftmin(nn.Module):
 
             # ---- per-candidate Procrustes fit of frames (0, 1), images read in place -----------
             depths = _ops.LeadingFrames.apply(backbone_output.depths, 2)
+            _ops.note_leading_frames(backbone_output.depths, 2)  # random pixels of frames 0 / 1: an in-pass depth update skips both frames
             weights = backbone_output.weights
             sens = 0.0
             if isinstance(weights, LazyWeights):

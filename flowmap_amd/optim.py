@@ -120,9 +120,9 @@ class FusedAdam(torch.optim.Optimizer):
         if (group is None or group["weight_decay"] != 0 or group.get("capturable") or not param.is_contiguous() or param.dtype != torch.float32
                 or depth.data_ptr() != param.data_ptr() or depth.numel() != param.numel() or param in self._in_pass):
             return None
-        if not torch_ops().flow_loss_parks(t_fwd, t_bwd, sink):
-            return None  # the gradient would not travel through the step's DepthSink (poses not from the fit, softmin sweep, ...)
         registry = param.__dict__.get("_fm_touched", {})
+        if not torch_ops().flow_loss_parks(t_fwd, t_bwd, sink, "softmin" in registry):
+            return None  # the gradient would not travel through the step's DepthSink (poses not from the fit, ...)
         if "procrustes" not in registry:
             return None  # the fit's backward is not planned (yet): the pixels it reads are not known
         union = _ops.touched_elements(depth)

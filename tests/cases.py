@@ -850,7 +850,7 @@ def case_dense_procrustes(dev, h, w, flow_sigma, f=4):
     assert maxerr(res["tiled"][2], truth[2]) <= 10 * TOL, "g_logits: max-abs"
 
 
-def _small_problem(dev, f=5, h=24, w=32, points=60, tracking=True, seed=21):
+def _small_problem(dev, f=5, h=24, w=32, points=60, tracking=True, seed=21, intrinsics=None):
     """(model, batch, flows, loss(out)) of a consistent scene: flow + tracking losses, regressed intrinsics."""
     import flowmap_amd
     from flowmap_amd import Batch
@@ -861,7 +861,7 @@ def _small_problem(dev, f=5, h=24, w=32, points=60, tracking=True, seed=21):
 
     sc = orc.synth_scene(f, h, w, seed=seed)
     flowmap_amd.set_lazy_surfaces(True)
-    model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", 0.9),
+    model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), intrinsics or IntrinsicsRegressedCfg("regressed", 0.9),
                            ExtrinsicsProcrustesCfg("procrustes", points, False)), num_frames=f, image_shape=(h, w))
     model.backbone.depth.data = sc["depth_init"].clone()
     model.backbone.weights.data = 0.01 * torch.randn((f - 1, h, w), generator=torch.Generator().manual_seed(seed))
@@ -1018,7 +1018,7 @@ def case_threads_and_hooks(dev):
         flowmap_amd.set_lazy_surfaces(False)
 
 
-def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3):
+def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3, softmin=False):
     """FusedAdam.fuse_depth_update: the depth update applied inside the fused flow pass (fm_flow_loss_fused_adam) + the
     element-list update of the touched pixels (fm_adam_step_elements) walk the same trajectory as torch.optim.Adam on the
     same losses (model_wrapper_overfit.py:104-105) — flow loss from step 0, tracking loss switched on later
@@ -1028,11 +1028,17 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3):
     from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
     from helpers import to_tracks
 
+    from flowmap_amd.model.intrinsics_softmin import IntrinsicsSoftminCfg, RegressionCfg
+
     f, h, w = 5, 24, 32
     trajectories, engaged = {}, 0
+    # softmin: the reference's default intrinsics (config/model/intrinsics/softmin.yaml) — the sweep reads random pixels of
+    # frames 0 / 1, new every step, then hands over to a regressed focal length; both phases and the hand-over are crossed
+    intrinsics = IntrinsicsSoftminCfg("softmin", 200, 0.5, 2.0, 8, RegressionCfg(steps // 2, 5)) if softmin else None
     try:
         for mode in ("torch", "fused", "in_pass"):
-            model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False)
+            torch.manual_seed(7)  # the sweep draws its pixels from torch's CPU generator
+            model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False, intrinsics=intrinsics)
             sc = orc.synth_scene(f, h, w, seed=21)
             tracks = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=21, interval=2, radius=2, grid=5), dev)
             flow_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
@@ -1051,22 +1057,44 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3):
                 total = total + track_fn(batch, flows, tracks, out, step)
                 total.backward()
                 optimizer.step()
-                history.append([p.detach().clone() for p in (model.backbone.depth, model.backbone.weights, model.intrinsics.focal_length)]
+                focal = next(p for name, p in model.named_parameters() if name.endswith("focal_length"))
+                history.append([p.detach().clone() for p in (model.backbone.depth, model.backbone.weights, focal)]
                                + [total.detach().clone()])
             trajectories[mode] = (history, optimizer, model)
     finally:
         flowmap_amd.set_lazy_surfaces(False)
     assert engaged >= steps - 3, engaged  # the plan exists from the third step on
     for mode in ("fused", "in_pass"):  # the weight logits: element-list update from the first planned step on
-        assert trajectories[mode][1].counters["sparse_updates"] >= steps - 3, trajectories[mode][1].counters
+        if not softmin:  # (the sweep adds gradient at random pixels of the first weight image: dense update while it runs)
+            assert trajectories[mode][1].counters["sparse_updates"] >= steps - 3, trajectories[mode][1].counters
     assert trajectories["in_pass"][1].counters["in_pass_updates"] == engaged
+    # (1) the in-pass update IS the separate FusedAdam update: same arithmetic per element, only the pass it runs in differs
+    # (asserted on the serial host double; on the GPU the unplanned scatters of the first steps and of the softmin sweep are
+    # float atomics whose order differs from run to run, and the comparison below carries the weight)
+    for step, (a, b) in enumerate(zip(trajectories["in_pass"][0], trajectories["fused"][0])):
+        for x, y, what in zip(a, b, ("depth", "weights", "focal", "loss")):
+            err = float((x - y).abs().max())
+            assert str(dev) != "cpu" or err <= 2e-7 * max(1.0, float(y.abs().max())), ("in_pass vs fused", step, what, err)
+    # (2) FusedAdam follows torch.optim.Adam: 2e-6 of the largest parameter at every step (lr here is 100x the reference's
+    # 3e-5, so one-ulp differences between the two implementations' roundings are amplified 100x more than in a real run)
     ref = trajectories["torch"][0]
+    worst = {}
     for mode in ("fused", "in_pass"):
         for step, (a, b) in enumerate(zip(trajectories[mode][0], ref)):
             for x, y, what in zip(a, b, ("depth", "weights", "focal", "loss")):
                 err = float((x - y).abs().max())
                 bound = 2e-6 * max(1.0, float(y.abs().max())) if what != "loss" else 2e-5 * max(1.0, float(y.abs().max()))
+                if softmin and what == "weights":
+                    # Adam moves an element by ~lr whatever the size of its gradient.  The sweep's gradient of a weight logit
+                    # (a few hundred random pixels of the FIRST weight image per step) passes through dL/dK, a sum that cancels
+                    # to rounding level: one ulp of difference in depth upstream changes it by tens of per cent, so those
+                    # elements follow no reproducible trajectory in any implementation.  The other images are held to the bar.
+                    err = float((x[1:] - y[1:]).abs().max())
+                if softmin:
+                    bound *= 2  # the same noise reaches K, hence every pose and every gradient, on top of their well-conditioned parts
+                worst[(mode, what)] = max(worst.get((mode, what), 0.0), err / bound)
                 assert err <= bound, (mode, step, what, err, bound)
+    print("in-pass Adam: worst error / bound", {k: round(v, 3) for k, v in worst.items()})
     # the same optimiser state as the separate update, for every element (touched or not)
     sa, sb = (trajectories[m][1].state[trajectories[m][2].backbone.depth] for m in ("fused", "in_pass"))
     assert float(sa["step"]) == float(sb["step"]) == steps

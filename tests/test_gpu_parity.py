@@ -436,3 +436,7 @@ def test_in_pass_adam_update_refuses_what_it_cannot_do():
 
 def test_noncontiguous_views_are_copied_loudly():
     cases.case_views_are_copied_loudly(DEV)
+
+
+def test_depth_adam_update_inside_the_flow_pass_with_the_softmin_sweep():
+    cases.case_in_pass_adam(DEV, steps=60, softmin=True)
