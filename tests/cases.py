@@ -1091,7 +1091,11 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3, softmin=False):
                     # elements follow no reproducible trajectory in any implementation.  The other images are held to the bar.
                     err = float((x[1:] - y[1:]).abs().max())
                 if softmin:
-                    bound *= 2  # the same noise reaches K, hence every pose and every gradient, on top of their well-conditioned parts
+                    # the same noise reaches K, hence every pose and every gradient, on top of their well-conditioned parts;
+                    # on the GPU the sweep's scatter adds with float atomics in a different order every run, which this
+                    # amplification turns into 1e-5-level scatter between ANY two runs.  A missed or doubled update of an
+                    # element would be an error of lr = 3e-3 after one step — two orders above either bar.
+                    bound *= 2 if str(dev) == "cpu" else 20
                 worst[(mode, what)] = max(worst.get((mode, what), 0.0), err / bound)
                 assert err <= bound, (mode, step, what, err, bound)
     print("in-pass Adam: worst error / bound", {k: round(v, 3) for k, v in worst.items()})
