@@ -250,17 +250,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # tests/test_bench_dryrun.py runs this file's multi-rank glue over gloo with CPU tensors and the host test double
+    # injected by its launcher; without that launcher CPU tensors raise in the first operator (there is no CPU path)
+    on_gpu = os.environ.get("FLOWMAP_BENCH_DEVICE", "cuda") == "cuda"
     if world > 1 or os.environ.get("FLOWMAP_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one GPU
         import torch.distributed as dist
 
         for key, value in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(key, value)
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         dist = None
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(device)
+    sync_device = torch.cuda.synchronize if on_gpu else (lambda: None)
 
     import flowmap_amd
     from flowmap_amd import Batch, Flows, _ops
@@ -295,7 +303,8 @@ def main():
         depth, wlogit = depth[lo : hi + 1].clone(), wlogit[a:b].clone()
         flows = Flows(*(x[:, a:b].contiguous() for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)))
         del scene
-        torch.cuda.empty_cache()
+        if on_gpu:
+            torch.cuda.empty_cache()
     f = depth.shape[0]  # frames resident on this rank
 
     if args.intrinsics == "softmin":
@@ -373,17 +382,17 @@ def main():
     for _ in range(args.warmup):
         step()
     flowmap_amd.freeze_gc()  # a full cyclic-GC pass over torch's import-time objects costs ~50 ms (flowmap_amd/host.py)
-    if not args.graph:
+    if not args.graph and on_gpu:
         _ops.flow_kernel_timing(True)  # HIP events on the launch stream around the fused flow kernel / track_pairs
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync_device()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync_device()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)

@@ -1,0 +1,52 @@
+"""bench.py's strong-scaling glue (shard the video, tracking windows across shard borders, packed all-reduce, halo
+exchange, the one JSON line) run end to end with 1, 2 and 3 ranks over gloo on the host test double: every world size
+must report the loss of the whole video.  The GPU runs of the same file are the driver's; nothing is measured here."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+ARGS = ["--frames", "9", "--height", "24", "--width", "32", "--points", "60", "--steps", "2", "--warmup", "1", "--cpu-frames", "0"]
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world: int, extra):
+    launcher = str(ROOT / "tests" / "tools" / "bench_dryrun.py")
+    if world == 1:
+        cmd = [sys.executable, launcher, "--gpus", "1", *ARGS, *extra]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), launcher, "--gpus", str(world), *ARGS, *extra]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, done.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [["--config", "c1"], ["--config", "c2"], ["--config", "c1", "--intrinsics", "softmin"]], ids=["flow", "flow+tracking", "softmin"])
+def test_strong_scaling_reports_the_whole_video(extra):
+    single = _run(1, extra)
+    assert single["n_gpus"] == 1 and single["config"]["frames_per_gpu"] == 9
+    for world in (2, 3):
+        line = _run(world, extra)
+        assert line["n_gpus"] == world and line["scaling"] == "strong" and line["steps"] == 2
+        assert line["config"]["video_frames"] == 9 and line["config"]["frames_per_gpu"] < 9
+        assert abs(line["config"]["loss"] - single["config"]["loss"]) <= 2e-5 * abs(single["config"]["loss"]), (world, line["config"]["loss"], single["config"]["loss"])
+
+
+def test_weak_scaling_runs_one_video_per_rank():
+    line = _run(2, ["--config", "c1", "--scaling", "weak"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["frames_per_gpu"] == 9
