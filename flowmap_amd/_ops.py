@@ -149,12 +149,19 @@ def _note_sparse_grad(weights: Tensor, arena, indices: Tensor, pixels_per_pair: 
     if weights.numel() != root.numel() or indices.dim() != 1:
         return
 
+    # images the softmin sweep has added gradient into (random pixels, new every step: LeadingFrames): wholly listed.
+    # The list never shrinks — after the hand-over to regressed intrinsics their moments are still non-zero.
+    leading = int(root.__dict__.get("_fm_leading_count", 0))
+
     def build():
         pairs = root.numel() // int(pixels_per_pair)  # one index list (projection.py:227: Int64[" point"]) for every pair
         offsets = torch.arange(pairs, dtype=torch.int64, device=indices.device)[:, None] * int(pixels_per_pair)
-        return indices, torch.unique((indices.reshape(1, -1) + offsets).reshape(-1)).contiguous()
+        slots = (indices.reshape(1, -1) + offsets).reshape(-1)
+        if leading > 0:
+            slots = torch.cat([torch.arange(min(leading, pairs) * int(pixels_per_pair), dtype=torch.int64, device=indices.device), slots])
+        return indices, torch.unique(slots).contiguous()
 
-    elements = _derived(root, "_fm_sparse_elements", (id(indices), indices._version, int(pixels_per_pair)), build)[1]
+    elements = _derived(root, "_fm_sparse_elements", (id(indices), indices._version, int(pixels_per_pair), leading), build)[1]
     root.__dict__["_fm_sparse_grad"] = (arena, elements)
 
 
@@ -241,6 +248,7 @@ class LeadingFrames:
 
     @staticmethod
     def apply(x: Tensor, count: int) -> Tensor:
+        _root(x).__dict__["_fm_leading_count"] = max(int(count), _root(x).__dict__.get("_fm_leading_count", 0))
         return torch_ops().leading_frames(x, int(count), depth_sink(x) if x.dim() == 4 else None)
 
 

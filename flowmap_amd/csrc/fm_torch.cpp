@@ -170,6 +170,7 @@ struct DepthSink : torch::CustomClassHolder {
   // 553 MB gradient instead of adopting it): LeadingFrames adds its frames into it while autograd still holds it
   using WeakImpl = c10::weak_intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl>;
   std::optional<WeakImpl> final_buffer;
+  std::function<void(const Tensor&, int64_t)> on_leading_add;  // told when LeadingFrames has added `count` frames into the final buffer
   bool expect_leading = false;
   void note_final(const Tensor& t) {
     if (expect_leading && t.defined()) final_buffer.emplace(t.getIntrusivePtr());
@@ -205,6 +206,7 @@ struct GradArena : torch::CustomClassHolder {
   Tensor buffer;
   const void* indices_ptr = nullptr;
   int64_t indices_version = -1, version = -1;
+  int64_t leading = 0;               // images at the front that another node adds into after the fit (the softmin sweep): re-zeroed per step
   int64_t reused = 0, refilled = 0;  // (tests)
 
   // a tensor shaped like `like`, zero everywhere except (possibly) at the slots `indices` selects in every pair
@@ -214,6 +216,7 @@ struct GradArena : torch::CustomClassHolder {
     const bool untouched = same_layout && (int64_t)buffer._version() == version && buffer.storage().use_count() == 1;
     if (same_layout && same_slots && untouched) {
       ++reused;
+      if (leading > 0) buffer.narrow(1, 0, std::min<int64_t>(leading, buffer.size(1))).zero_();  // (3.7 MB per image at 720p, not 549 MB)
     } else {
       if (!(same_layout && buffer.storage().use_count() == 1)) buffer = at::empty_like(like);  // never write under a live alias
       buffer.zero_();
@@ -225,6 +228,13 @@ struct GradArena : torch::CustomClassHolder {
     return buffer;
   }
   Tensor alias() const { return buffer.alias(); }  // a new tensor over the same storage: autograd's to keep
+  // LeadingFrames added `count` leading images into the alias it was handed: an expected edit — the storage still is
+  // "zero outside the slots and the first `leading` images"
+  void note_leading_add(const Tensor& into, int64_t count) {
+    if (!buffer.defined() || into.data_ptr() != buffer.data_ptr()) return;
+    leading = std::max(leading, count);
+    version = (int64_t)buffer._version();
+  }
   // is `grad` this arena's storage exactly as the last backward left it (zero outside the slots, nothing added or edited)?
   bool holds(const Tensor& grad) const {
     return buffer.defined() && grad.defined() && grad.data_ptr() == buffer.data_ptr() && grad.numel() == buffer.numel() &&
@@ -534,7 +544,10 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     }
     if (arena_used) g_w = arena->alias();
     if (sink) sink->note_final(g_src);
-    if (wsink) wsink->note_final(g_w);
+    if (wsink) {
+      wsink->note_final(g_w);
+      if (arena_used) wsink->on_leading_add = [arena](const Tensor& into, int64_t count) { arena->note_leading_add(into, count); };
+    }
     variable_list out(20);
     if (from_depth) {
       out[0] = g_src;
@@ -880,6 +893,8 @@ struct LeadingFrames : public Function<LeadingFrames> {
     if (buffer.defined() && (int64_t)(uintptr_t)sink->depth_ptr == ident[0] && sink->depth_version == ident[1] && buffer.sizes().vec() == shape &&
         buffer.scalar_type() == g.scalar_type() && buffer.device() == g.device()) {
       buffer.narrow(1, 0, count).add_(g);
+      if (sink->on_leading_add) sink->on_leading_add(buffer, count);
+      sink->on_leading_add = nullptr;
       ++sink->leading_in_place;
       return {Tensor(), Tensor(), Tensor()};
     }

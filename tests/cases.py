@@ -1036,8 +1036,9 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3, softmin=False):
     # frames 0 / 1, new every step, then hands over to a regressed focal length; both phases and the hand-over are crossed
     intrinsics = IntrinsicsSoftminCfg("softmin", 200, 0.5, 2.0, 8, RegressionCfg(steps // 2, 5)) if softmin else None
     try:
-        for mode in ("torch", "fused", "in_pass"):
+        for mode in ("torch", "fused", "in_pass", "fused_dense"):
             torch.manual_seed(7)  # the sweep draws its pixels from torch's CPU generator
+            _ops.use_grad_arena = mode != "fused_dense"  # fused_dense: fresh zeros for dL/dweights, dense update of the logits
             model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False, intrinsics=intrinsics)
             sc = orc.synth_scene(f, h, w, seed=21)
             tracks = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=21, interval=2, radius=2, grid=5), dev)
@@ -1063,18 +1064,22 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3, softmin=False):
             trajectories[mode] = (history, optimizer, model)
     finally:
         flowmap_amd.set_lazy_surfaces(False)
+        _ops.use_grad_arena = True
     assert engaged >= steps - 3, engaged  # the plan exists from the third step on
+    assert trajectories["fused_dense"][1].counters["sparse_updates"] == 0
     for mode in ("fused", "in_pass"):  # the weight logits: element-list update from the first planned step on
-        if not softmin:  # (the sweep adds gradient at random pixels of the first weight image: dense update while it runs)
-            assert trajectories[mode][1].counters["sparse_updates"] >= steps - 3, trajectories[mode][1].counters
+        # (under the softmin sweep too: the first weight image, where the sweep adds gradient at random pixels, is listed whole)
+        assert trajectories[mode][1].counters["sparse_updates"] >= steps - 3, trajectories[mode][1].counters
     assert trajectories["in_pass"][1].counters["in_pass_updates"] == engaged
     # (1) the in-pass update IS the separate FusedAdam update: same arithmetic per element, only the pass it runs in differs
+    # and the element-list update of the weight logits IS the dense one (fused vs fused_dense).
     # (asserted on the serial host double; on the GPU the unplanned scatters of the first steps and of the softmin sweep are
     # float atomics whose order differs from run to run, and the comparison below carries the weight)
-    for step, (a, b) in enumerate(zip(trajectories["in_pass"][0], trajectories["fused"][0])):
-        for x, y, what in zip(a, b, ("depth", "weights", "focal", "loss")):
-            err = float((x - y).abs().max())
-            assert str(dev) != "cpu" or err <= 2e-7 * max(1.0, float(y.abs().max())), ("in_pass vs fused", step, what, err)
+    for other in ("in_pass", "fused_dense"):
+        for step, (a, b) in enumerate(zip(trajectories[other][0], trajectories["fused"][0])):
+            for x, y, what in zip(a, b, ("depth", "weights", "focal", "loss")):
+                err = float((x - y).abs().max())
+                assert str(dev) != "cpu" or err <= 2e-7 * max(1.0, float(y.abs().max())), (other, "vs fused", step, what, err)
     # (2) FusedAdam follows torch.optim.Adam: 2e-6 of the largest parameter at every step (lr here is 100x the reference's
     # 3e-5, so one-ulp differences between the two implementations' roundings are amplified 100x more than in a real run)
     ref = trajectories["torch"][0]
