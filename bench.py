@@ -408,14 +408,15 @@ def main():
         try:
             rec = json.loads((ROOT / "profiles" / name).read_text())
             if {k: rec["workload"][k] for k in ("frames", "height", "width")} == {"frames": f, "height": h, "width": w}:
-                entry = rec["flow_fused_kernel_adam"] if args.optimizer == "in_pass" else rec
+                entry = rec["flow_fused_kernel_adam"] if (args.optimizer == "in_pass" and optimizer.counters["in_pass_updates"] > 0) else rec
                 traffic, traffic_src = entry["hbm_bytes_per_launch"], f"profiles/{name} (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"
                 break
         except Exception:
             pass
     n = h * w
     algo_bytes = n * (8 * f + 24 * (f - 1))  # B_flow per launch (this rank's frames)
-    if args.optimizer == "in_pass":  # depth, exp_avg, exp_avg_sq read and rewritten (24 B per pixel and frame), no dL/ddepth written
+    in_pass = args.optimizer == "in_pass" and optimizer.counters["in_pass_updates"] > 0
+    if in_pass:  # depth, exp_avg, exp_avg_sq read and rewritten (24 B per pixel and frame), no dL/ddepth written
         algo_bytes = n * (24 * f + 24 * (f - 1))
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
@@ -426,7 +427,8 @@ def main():
                     + (f" + tracking loss (weight 100): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else "")
                     + f", explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points if args.points > 0 else 'all pixels'}; fwd+bwd, "
                     + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__}"
-                       + (", depth update inside the flow pass)" if args.optimizer == "in_pass" else ")"))
+                       + (", depth update inside the flow pass)" if args.optimizer == "in_pass" and optimizer.counters["in_pass_updates"] > 0
+                          else ", fuse_depth_update requested but the touched set is too large: separate update)" if args.optimizer == "in_pass" else ")"))
                     + ("; whole step replayed as one hipGraph" if args.graph else ""))
         result = {
             "metric": "overfit iters/sec (150 frames @ 720p) at 1/2/4/8 MI355X; final ATE vs ref",
@@ -456,7 +458,7 @@ def main():
                 "loss": float(loss.item()),
             },
             "roofline": {
-                "kernel": "fm::flow_fused_kernel<VEC=4, huber, GRAD, PACKED" + (", ADAM>" if args.optimizer == "in_pass" else ">"),
+                "kernel": "fm::flow_fused_kernel<VEC=4, huber, GRAD, PACKED" + (", ADAM>" if in_pass else ">"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

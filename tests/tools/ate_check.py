@@ -70,7 +70,7 @@ def run(args):
     tracks = to_tracks(otracks, dev)
     opt = flowmap_amd.FusedAdam(model.parameters(), lr=args.lr)  # the reference leg above uses torch.optim.Adam
     if args.in_pass:
-        opt.fuse_depth_update(model.backbone.depth)  # the depth update applied by the flow-loss pass itself
+        opt.fuse_depth_update(model.backbone.depth, max_touched_fraction=1.0)  # the depth update applied by the flow-loss pass itself
     if dev.type == "cuda":
         torch.cuda.synchronize()
     t0 = time.perf_counter()
