@@ -371,8 +371,11 @@ __global__ void __launch_bounds__(256) softmin_score_fwd_kernel(SoftminArgs a, d
   block_accumulate<1>(e, red, err + bn);
 }
 
-// grid: (point chunks, B).  One thread per sampled pixel walks all candidates: dL/dz and dL/dw sum in
-// registers (stored once: the indices are distinct), dL/dT per candidate is block-reduced.
+// grid: (point chunks, B, candidate groups).  One thread per sampled pixel walks a group of kSoftminGroup candidates:
+// dL/dz and dL/dw sum in registers and are ADDED once per group (float atomics into the caller's zero-filled
+// images: 10 adds per pixel for 60 candidates), dL/dT per candidate is block-reduced.  (One group = all candidates
+// was 32 blocks each doing 60 block reductions in a row: 100 us; the groups run side by side.)
+constexpr int kSoftminGroup = 6;
 __global__ void __launch_bounds__(256) softmin_score_bwd_kernel(SoftminArgs a, const float* g_err, float* g_depth, float* g_weights,
                                                                 double* g_rel) {
   __shared__ double red[4 * 12];
@@ -382,7 +385,8 @@ __global__ void __launch_bounds__(256) softmin_score_bwd_kernel(SoftminArgs a, c
   SoftminPoint s = {};
   if (active) s = softmin_point(a, b, j);
   float gz = 0.f, gw = 0.f;
-  for (int n = 0; n < a.candidates; ++n) {
+  const int n0 = blockIdx.z * kSoftminGroup, n1 = min(n0 + kSoftminGroup, a.candidates);
+  for (int n = n0; n < n1; ++n) {
     const int bn = b * a.candidates + n;
     Mat3 k, kinv;
     Pose t;
@@ -401,8 +405,8 @@ __global__ void __launch_bounds__(256) softmin_score_bwd_kernel(SoftminArgs a, c
   }
   if (!active) return;
   const size_t npx = (size_t)a.height * a.width;
-  if (g_depth) g_depth[((size_t)b * 2 + 1) * npx + s.idx] = gz;
-  if (g_weights) g_weights[(size_t)b * npx + s.idx] = a.weight_sens != 0.f ? gw * a.weight_sens * s.w * (1.f - s.w) : gw;
+  if (g_depth) atomicAdd(g_depth + ((size_t)b * 2 + 1) * npx + s.idx, gz);
+  if (g_weights) atomicAdd(g_weights + (size_t)b * npx + s.idx, a.weight_sens != 0.f ? gw * a.weight_sens * s.w * (1.f - s.w) : gw);
 }
 
 __global__ void softmin_rel_grad_kernel(const double* acc, int count, float* g_rel) {
@@ -557,8 +561,8 @@ int fm_softmin_score_bwd(const float* depth, const float* weights, float weight_
   const int bn = batch * candidates;
   if (hipMemsetAsync(g_rel_acc, 0, sizeof(double) * (size_t)bn * 12, st) != hipSuccess) return FM_ERR_LAUNCH;
   const SoftminArgs a{depth, weights, bwd_flow, indices, k, kinv, rel, points, batch, candidates, height, width, weight_sensitivity};
-  hipLaunchKernelGGL(softmin_score_bwd_kernel, dim3((unsigned)((points + 255) / 256), batch), dim3(256), 0, st, a, g_err, g_depth,
-                     g_weights, g_rel_acc);
+  hipLaunchKernelGGL(softmin_score_bwd_kernel, dim3((unsigned)((points + 255) / 256), batch, (candidates + kSoftminGroup - 1) / kSoftminGroup),
+                     dim3(256), 0, st, a, g_err, g_depth, g_weights, g_rel_acc);
   hipLaunchKernelGGL(softmin_rel_grad_kernel, dim3((bn + 63) / 64), dim3(64), 0, st, g_rel_acc, bn, g_rel);
   FM_LAUNCH_STATUS();
 }

@@ -390,8 +390,8 @@ int fm_softmin_score_fwd(const float* depth, const float* weights, float weight_
                          const int64_t* indices, long points, const float* k, const float* kinv, const float* rel, int batch,
                          int candidates, int height, int width, double* err, void* stream);
 
-/* Backward: g_err (B·N) fp32.  g_depth (B,2,H,W) and g_weights (B,H,W): STORED at the sampled
- * pixels of frame 1 / pair 0 (caller zeroes the buffers; either may be NULL); g_rel (B·N,4,4)
+/* Backward: g_err (B·N) fp32.  g_depth (B,2,H,W) and g_weights (B,H,W): ADDED at the sampled
+ * pixels of frame 1 / pair 0, one add per group of candidates (caller zeroes the buffers; either may be NULL); g_rel (B·N,4,4)
  * out, bottom rows 0; g_rel_acc (B·N,12) fp64 workspace (zeroed here). */
 int fm_softmin_score_bwd(const float* depth, const float* weights, float weight_sensitivity, const float* bwd_flow,
                          const int64_t* indices, long points, const float* k, const float* kinv, const float* rel, int batch,

@@ -286,8 +286,8 @@ int fm_softmin_score_bwd(const float* depth, const float* weights, float sens, c
         softmin_term_bwd(km, t, o, w, g_err[bn], gz, gw, gt);
         for (int e = 0; e < 12; ++e) g_rel_acc[(size_t)bn * 12 + e] += gt[e];
       }
-      if (g_depth) g_depth[((size_t)b * 2 + 1) * npx + idx] = gz;
-      if (g_weights) g_weights[(size_t)b * npx + idx] = sens != 0.f ? gw * sens * w * (1.f - w) : gw;
+      if (g_depth) g_depth[((size_t)b * 2 + 1) * npx + idx] += gz;
+      if (g_weights) g_weights[(size_t)b * npx + idx] += sens != 0.f ? gw * sens * w * (1.f - w) : gw;
     }
   for (int bn = 0; bn < batch * candidates; ++bn) {
     for (int e = 0; e < 12; ++e) g_rel[(size_t)bn * 16 + e] = (float)g_rel_acc[(size_t)bn * 12 + e];
