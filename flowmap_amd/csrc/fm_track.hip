@@ -226,8 +226,15 @@ struct TrackSampling {
   int depth_frame0, own_first, own_end;  // frames [own_first, own_end) are sources on this rank (frame sharding)
 };
 
+// Points per lane (FM_TRACK_PG): with two, a wave covers 128 points and the per-target reduction of the 14 sums (a quarter
+// of the loop's instructions with one) is shared by twice the residuals.
+#ifndef FM_TRACK_PG
+#define FM_TRACK_PG 2
+#endif
+constexpr int kTrackPG = FM_TRACK_PG;
+
 template <int KIND, bool GRAD>
-__global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const int32_t* tiles, float* ws, uint8_t* flag,
+__global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(TrackGeom g, const int32_t* tiles, float* ws, uint8_t* flag,
                                                             const float* ext, const float* tgt, float delta, float ax, float ay, int fmax,
                                                             float* partial, float* gws, TrackSampling smp) {
   const float inv_delta = KIND == kHuber ? 1.0f / delta : 0.f;
@@ -235,55 +242,74 @@ __global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const i
   float* mine = partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * track_partial_stride(fmax);
   const int sg = tiles[blockIdx.x * 2], fs0 = tiles[blockIdx.x * 2 + 1];
   const int start = g.seg[sg * 4], f = g.seg[sg * 4 + 1], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
-  const int p = blockIdx.y * blockDim.x + threadIdx.x;
-  const bool active = p < p_count;
-  const int pp = active ? p : p_count - 1;  // clamped: loads stay in bounds, results are masked
+  int p[kTrackPG], pp[kTrackPG];
+  bool active[kTrackPG];
+#pragma unroll
+  for (int q = 0; q < kTrackPG; ++q) {
+    p[q] = (blockIdx.y * kTrackPG + q) * blockDim.x + threadIdx.x;
+    active[q] = p[q] < p_count;
+    pp[q] = active[q] ? p[q] : p_count - 1;  // clamped: loads stay in bounds, results are masked
+  }
 
   // source frames fs0 + 2j (.x) and fs0 + 2j + 1 (.y) share packed registers
-  v2f xw[kTrackTile / 2][3], gxw[kTrackTile / 2][3];
-  v2f live[kTrackTile / 2];  // 1 when the source role is visible (projection.py:290-294), else 0
+  v2f xw[kTrackPG][kTrackTile / 2][3], gxw[kTrackPG][kTrackTile / 2][3];
+  v2f live[kTrackPG][kTrackTile / 2];  // 1 when the source role is visible (projection.py:290-294), else 0
 #pragma unroll
-  for (int t = 0; t < kTrackTile; ++t) {
-    float lv = 0.f, x0 = 0.f, x1 = 0.f, x2 = 0.f;
-    const int fs = fs0 + t;
-    if (active && fs < f) {
-      const size_t is = (size_t)off + (size_t)fs * p_count + p;
-      if (smp.depth != nullptr) {
-        const int frame = start + fs;
-        if (frame >= smp.own_first && frame < smp.own_end) {
-          float xs[3];
-          if (track_sample(g, smp.depth, smp.depth_frame0, smp.kinv, ext, frame, is, ws, flag, xs)) {
-            lv = 1.f;
-            x0 = xs[0]; x1 = xs[1]; x2 = xs[2];
+  for (int q = 0; q < kTrackPG; ++q) {
+#pragma unroll
+    for (int t = 0; t < kTrackTile; ++t) {
+      float lv = 0.f, x0 = 0.f, x1 = 0.f, x2 = 0.f;
+      const int fs = fs0 + t;
+      if (active[q] && fs < f) {
+        const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
+        if (smp.depth != nullptr) {
+          const int frame = start + fs;
+          if (frame >= smp.own_first && frame < smp.own_end) {
+            float xs[3];
+            if (track_sample(g, smp.depth, smp.depth_frame0, smp.kinv, ext, frame, is, ws, flag, xs)) {
+              lv = 1.f;
+              x0 = xs[0]; x1 = xs[1]; x2 = xs[2];
+            }
+          } else {
+            flag[is] = 0;  // another rank's source
           }
-        } else {
-          flag[is] = 0;  // another rank's source
+        } else if (flag[is] != 0) {
+          lv = 1.f;
+          const float* w9 = ws + is * kTrackWs;
+          x0 = w9[3]; x1 = w9[4]; x2 = w9[5];
         }
-      } else if (flag[is] != 0) {
-        lv = 1.f;
-        const float* w9 = ws + is * kTrackWs;
-        x0 = w9[3]; x1 = w9[4]; x2 = w9[5];
       }
+      if (t & 1) {
+        live[q][t / 2].y = lv; xw[q][t / 2][0].y = x0; xw[q][t / 2][1].y = x1; xw[q][t / 2][2].y = x2;
+      } else {
+        live[q][t / 2].x = lv; xw[q][t / 2][0].x = x0; xw[q][t / 2][1].x = x1; xw[q][t / 2][2].x = x2;
+      }
+      gxw[q][t / 2][0] = gxw[q][t / 2][1] = gxw[q][t / 2][2] = 0.f;
     }
-    if (t & 1) {
-      live[t / 2].y = lv; xw[t / 2][0].y = x0; xw[t / 2][1].y = x1; xw[t / 2][2].y = x2;
-    } else {
-      live[t / 2].x = lv; xw[t / 2][0].x = x0; xw[t / 2][1].x = x1; xw[t / 2][2].x = x2;
-    }
-    gxw[t / 2][0] = gxw[t / 2][1] = gxw[t / 2][2] = 0.f;
   }
 
   // the target's visibility and position are prefetched one iteration ahead
-  size_t it = (size_t)off + pp;
-  uint8_t tv_next = g.vis[it];
-  float2 gt_next = reinterpret_cast<const float2*>(g.xy)[it];
+  size_t it[kTrackPG];
+  uint8_t tv_next[kTrackPG];
+  float2 gt_next[kTrackPG];
+#pragma unroll
+  for (int q = 0; q < kTrackPG; ++q) {
+    it[q] = (size_t)off + pp[q];
+    tv_next[q] = g.vis[it[q]];
+    gt_next[q] = reinterpret_cast<const float2*>(g.xy)[it[q]];
+  }
   for (int ft = 0; ft < f; ++ft) {
-    const float tv = active && tv_next != 0 ? 1.f : 0.f;  // target role needs only the track's visibility (projection.py:290)
-    const float2 gt = gt_next;
-    if (ft + 1 < f) {
-      it += p_count;
-      tv_next = g.vis[it];
-      gt_next = reinterpret_cast<const float2*>(g.xy)[it];
+    float tv[kTrackPG];
+    float2 gt[kTrackPG];
+#pragma unroll
+    for (int q = 0; q < kTrackPG; ++q) {
+      tv[q] = active[q] && tv_next[q] != 0 ? 1.f : 0.f;  // target role needs only the track's visibility (projection.py:290)
+      gt[q] = gt_next[q];
+      if (ft + 1 < f) {
+        it[q] += p_count;
+        tv_next[q] = g.vis[it[q]];
+        gt_next[q] = reinterpret_cast<const float2*>(g.xy)[it[q]];
+      }
     }
     float tg[kTrackTgt];
 #pragma unroll
@@ -292,8 +318,11 @@ __global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const i
 #pragma unroll
     for (int i = 0; i < kTrackSums; ++i) a2[i] = 0.f;
 #pragma unroll
-    for (int j = 0; j < kTrackTile / 2; ++j)
-      track_pair_term2<KIND, GRAD>(tg, xw[j], gt.x, gt.y, tv * live[j], delta, inv_delta, ax, ay, a2, gxw[j]);
+    for (int q = 0; q < kTrackPG; ++q) {
+#pragma unroll
+      for (int j = 0; j < kTrackTile / 2; ++j)
+        track_pair_term2<KIND, GRAD>(tg, xw[q][j], gt[q].x, gt[q].y, tv[q] * live[q][j], delta, inv_delta, ax, ay, a2, gxw[q][j]);
+    }
     float a[kTrackSums];
 #pragma unroll
     for (int i = 0; i < kTrackSums; ++i) a[i] = a2[i].x + a2[i].y;
@@ -317,17 +346,23 @@ __global__ void __launch_bounds__(64, 4) track_pairs_kernel(TrackGeom g, const i
       float b[21];
 #pragma unroll
       for (int i = 0; i < 21; ++i) b[i] = 0.f;
-      if (((t & 1) ? live[t / 2].y : live[t / 2].x) != 0.f) {
-        const size_t is = (size_t)off + (size_t)fs * p_count + p;
-        Pose e;
-        load_pose44(ext + (size_t)(start + fs) * 16, e);
-        float gxyz[3];
-        const float gx[3] = {(t & 1) ? gxw[t / 2][0].y : gxw[t / 2][0].x, (t & 1) ? gxw[t / 2][1].y : gxw[t / 2][1].x,
-                             (t & 1) ? gxw[t / 2][2].y : gxw[t / 2][2].x};
-        track_source_term(e, ws + is * kTrackWs, gx, b, gxyz);
-        gws[is * 3 + 0] = gxyz[0];
-        gws[is * 3 + 1] = gxyz[1];
-        gws[is * 3 + 2] = gxyz[2];
+      Pose e;
+      load_pose44(ext + (size_t)(start + fs) * 16, e);
+#pragma unroll
+      for (int q = 0; q < kTrackPG; ++q) {
+        if (((t & 1) ? live[q][t / 2].y : live[q][t / 2].x) != 0.f) {
+          const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
+          float gxyz[3];
+          const float gx[3] = {(t & 1) ? gxw[q][t / 2][0].y : gxw[q][t / 2][0].x, (t & 1) ? gxw[q][t / 2][1].y : gxw[q][t / 2][1].x,
+                               (t & 1) ? gxw[q][t / 2][2].y : gxw[q][t / 2][2].x};
+          float b1[21];
+          track_source_term(e, ws + is * kTrackWs, gx, b1, gxyz);
+#pragma unroll
+          for (int i = 0; i < 21; ++i) b[i] += b1[i];
+          gws[is * 3 + 0] = gxyz[0];
+          gws[is * 3 + 1] = gxyz[1];
+          gws[is * 3 + 2] = gxyz[2];
+        }
       }
       wave_sum_lane63_x7<21>(b);
       if (threadIdx.x == kWave - 1) {
@@ -581,7 +616,7 @@ static int track_loss_launch(float* ws, uint8_t* flag, const float* xy, const ui
                              int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* partial, double* acc,
                              float* loss, float* scale, double* totals, float* gws, double* acc2, TrackSampling smp, hipStream_t st) {
   TrackGeom g{xy, vis, seg, nullptr, height, width};
-  const int pgroups = (pmax + kWave - 1) / kWave;
+  const int pgroups = (pmax + kWave * kTrackPG - 1) / (kWave * kTrackPG);  // (the caller sized `partial` for groups of kWave points: enough)
   const dim3 grid(ntiles, pgroups);
 #define FM_TRACK_LAUNCH(K)                                                                                                          \
   do {                                                                                                                               \
