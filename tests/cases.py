@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close, load_golden, maxerr, t
+from conftest import assert_close, assert_close_or_reference_gap, load_golden, maxerr, t
 from flowmap_amd import Tracks
 from flowmap_amd.loss.mapping import get_mapping
 from flowmap_amd.model import procrustes as fp
@@ -109,9 +109,15 @@ def case_align_surfaces(dev, lazy):
         fm.set_lazy_surfaces(False)
     (e * t(g["cot"]).to(dev)).sum().backward()
     assert_close(e, g["extrinsics"], 1e-5, what="extrinsics")
-    assert_close(z.grad, g["g_z"], 3e-4, what="g_z")
-    assert_close(k.grad, g["g_k"], 3e-4, what="g_k")
-    assert_close(w.grad, g["g_weights"], 3e-4, what="g_weights")
+    # the golden gradients are the reference's fp32 svd_backward, itself ~1e-4 from the truth on this fixture: the bar is
+    # the fp64 oracle at 1e-4 — or, where the fp32 reference is further than that from it, 4x the reference's own gap
+    z64, k64, w64 = (t(g[n]).double().requires_grad_(True) for n in ("z", "k", "weights"))
+    xy64, _ = orc.pixel_grid((h, wd), dtype=torch.float64)
+    e64 = orc.fit_poses(orc.lift(xy64, z64, k64[:, :, None, None]), t(g["bwd_flow"]).double(), w64, t(g["indices"]))
+    (e64 * t(g["cot"]).double()).sum().backward()
+    assert_close(e, e64, 1e-5, what="extrinsics vs fp64")
+    for ours, truth, gold, what in ((z.grad, z64.grad, g["g_z"], "g_z"), (k.grad, k64.grad, g["g_k"], "g_k"), (w.grad, w64.grad, g["g_weights"], "g_weights")):
+        assert_close_or_reference_gap(ours, truth, t(gold), TOL, what=what)
 
 
 def case_track_flow(dev):
@@ -183,7 +189,12 @@ def case_flow_loss_batched(dev, lazy):
     assert_close(ext, o.extrinsics, TOL, what="extrinsics")
     assert_close(d.grad, d64.grad, TOL, what="g_depth")
     assert_close(wt.grad, w64.grad, 3 * TOL, what="g_weights")
-    assert_close(kk.grad, k64.grad, 1e-3, abs_=1e-4 * abs(float(ref.detach())), what="g_k")
+    # dL/dK on i.i.d. inputs is a sum that cancels to ~1e-3 of its terms: held to the fp64 truth at 1e-4, or to 4x the gap the
+    # reference's own fp32 evaluation (the oracle in fp32) has on the same inputs — measured here
+    d32, w32, k32 = (x.detach().clone().requires_grad_(True) for x in (depth, weights, k))
+    o32 = orc.model_forward(d32, w32, k32, fl, idx)
+    (1000.0 * orc.flow_loss(o32.surfaces, o32.extrinsics, k32, fl, (h, w))).backward()
+    assert_close_or_reference_gap(kk.grad, k64.grad, k32.grad, TOL, what="g_k")
 
 
 def case_procrustes_planned_backward(dev):
@@ -320,7 +331,7 @@ def case_loss_gating_and_empty_tracks(dev):
             assert float(gated) == 0.0 and gated.dtype == torch.float32
             invisible = [Tracks(torch.rand((1, f, 7, 2), device=dev), torch.zeros((1, f, 7), dtype=torch.bool, device=dev), 0)]
             val = fn(batch, flows, invisible, out, 60)
-            assert float(val) == 0.0
+            assert float(val.detach()) == 0.0
             val.backward()
             assert float(fn(batch, flows, [], out, 60)) == 0.0
         finally:
@@ -444,10 +455,21 @@ def case_softmin_step(dev, seed=5):
     o = orc.model_forward(d[None], weights, k, fl, orc.procrustes_indices((h, w), p_proc, "cpu"))
     ref = 1000.0 * orc.flow_loss(o.surfaces, o.extrinsics, k, fl, (h, w), "huber", 0.01)
     ref.backward()
+    # the same step by the oracle in fp32 = what the reference's arithmetic delivers on these inputs: the softmin over 12
+    # candidates and dL/dK behind it amplify rounding, so each quantity is held to 1e-4 of the fp64 truth or to 4x the fp32
+    # reference's own measured gap, whichever is larger
+    d32 = depth.detach().clone().requires_grad_(True)
+    wl32 = wlogit.detach().clone().requires_grad_(True)
+    weights32 = (100.0 * wl32).sigmoid()[None]
+    k32 = orc.softmin_intrinsics(d32[None], weights32, oflows.backward, torch.linspace(0.5, 2.0, n), idx, (h, w))
+    k32 = k32[:, None].expand(1, f, 3, 3)
+    o32 = orc.model_forward(d32[None], weights32, k32, oflows, orc.procrustes_indices((h, w), p_proc, "cpu"))
+    ref32 = 1000.0 * orc.flow_loss(o32.surfaces, o32.extrinsics, k32, oflows, (h, w), "huber", 0.01)
+    ref32.backward()
     assert_close(out.intrinsics[0, 0], k[0, 0].detach(), 1e-4, what="intrinsics")
-    assert_close(loss, ref.detach(), 2e-4, what="loss")
-    assert_close(model.backbone.depth.grad, d.grad, 2e-3, abs_=1e-6, what="g_depth")
-    assert_close(model.backbone.weights.grad, wl.grad, 2e-3, abs_=1e-6, what="g_wlogit")
+    assert_close_or_reference_gap(loss, ref.detach(), ref32.detach(), TOL, what="loss")
+    assert_close_or_reference_gap(model.backbone.depth.grad, d.grad, d32.grad, TOL, what="g_depth")
+    assert_close_or_reference_gap(model.backbone.weights.grad, wl.grad, wl32.grad, TOL, what="g_wlogit")
 
 
 def case_packed_inputs(dev, hw=(18, 28)):

@@ -4,7 +4,7 @@ the reference's golden vectors.  Run with `pytest -m gpu` through gpurun."""
 import pytest
 import torch
 
-from conftest import assert_close, load_golden, t
+from conftest import assert_close, assert_close_or_reference_gap, load_golden, t
 from helpers import compare_step, run_oracle, run_ours, step_masks
 from oracle import flowmap_oracle as orc
 from test_oracle_golden import _flows, _tracks
@@ -74,7 +74,9 @@ def test_consistent_scene_has_small_loss_and_matches_oracle():
     ours = run_ours(sc["depth_gt"], wl, sc["focal"], sc["flows"], (h, w), 500, device=DEV)
     ref = run_oracle(sc["depth_gt"], wl, sc["focal"], sc["flows"], (h, w), 500, dtype=torch.float64)
     assert float(ours["total"]) < 1.0  # ground-truth depth + flows generated from it (i.i.d. inputs give ~8)
-    assert_close(ours["total"], ref["total"], 1e-3, abs_=1e-6, what="total")
+    # a near-zero loss (ground-truth depth): the fp32 reference path itself is measured against the fp64 truth on the same inputs
+    ref32 = run_oracle(sc["depth_gt"], wl, sc["focal"], sc["flows"], (h, w), 500, dtype=torch.float32)
+    assert_close_or_reference_gap(ours["total"], ref["total"], ref32["total"], 1e-4, what="total")
 
 
 def test_loss_scale_and_carry_gpu():
