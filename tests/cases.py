@@ -1040,7 +1040,7 @@ def case_threads_and_hooks(dev):
         flowmap_amd.set_lazy_surfaces(False)
 
 
-def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3, softmin=False):
+def case_in_pass_adam(dev, steps=40, track_after=6, lr=1e-3, softmin=False):
     """FusedAdam.fuse_depth_update: the depth update applied inside the fused flow pass (fm_flow_loss_fused_adam) + the
     element-list update of the touched pixels (fm_adam_step_elements) walk the same trajectory as torch.optim.Adam on the
     same losses (model_wrapper_overfit.py:104-105) — flow loss from step 0, tracking loss switched on later
@@ -1102,8 +1102,9 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3, softmin=False):
             for x, y, what in zip(a, b, ("depth", "weights", "focal", "loss")):
                 err = float((x - y).abs().max())
                 assert str(dev) != "cpu" or err <= 2e-7 * max(1.0, float(y.abs().max())), (other, "vs fused", step, what, err)
-    # (2) FusedAdam follows torch.optim.Adam: 2e-6 of the largest parameter at every step (lr here is 100x the reference's
-    # 3e-5, so one-ulp differences between the two implementations' roundings are amplified 100x more than in a real run)
+    # (2) FusedAdam follows torch.optim.Adam: 2e-6 of the largest parameter at every step (lr here is 33x the reference's
+    # 3e-5 so that the parameters visibly move; one-ulp differences between the two implementations' roundings are amplified
+    # that much more than in a real run)
     ref = trajectories["torch"][0]
     worst = {}
     for mode in ("fused", "in_pass"):
@@ -1121,7 +1122,7 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3, softmin=False):
                     # the same noise reaches K, hence every pose and every gradient, on top of their well-conditioned parts;
                     # on the GPU the sweep's scatter adds with float atomics in a different order every run, which this
                     # amplification turns into 1e-5-level scatter between ANY two runs.  A missed or doubled update of an
-                    # element would be an error of lr = 3e-3 after one step — two orders above either bar.
+                    # element would be an error of lr = 1e-3 after one step — two orders above either bar.
                     bound *= 2 if str(dev) == "cpu" else 20
                 worst[(mode, what)] = max(worst.get((mode, what), 0.0), err / bound)
                 assert err <= bound, (mode, step, what, err, bound)
@@ -1133,7 +1134,7 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=3e-3, softmin=False):
         scale = float(sa[name].abs().max())
         assert float((sa[name] - sb[name]).abs().max()) <= 1e-4 * scale, name
     # the update has moved depth well beyond the tolerance (the comparison above is not vacuous)
-    assert float((ref[-1][0] - ref[0][0]).abs().max()) > 1e-2
+    assert float((ref[-1][0] - ref[0][0]).abs().max()) > 5e-3
 
 
 def case_in_pass_adam_refusals(dev):
