@@ -1121,9 +1121,9 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=1e-3, softmin=False):
                 if softmin:
                     # the same noise reaches K, hence every pose and every gradient, on top of their well-conditioned parts;
                     # on the GPU the sweep's scatter adds with float atomics in a different order every run, which this
-                    # amplification turns into 1e-5-level scatter between ANY two runs.  A missed or doubled update of an
+                    # amplification turns into scatter between ANY two runs (seen up to 1e-4 at 100x the reference's learning rate).  A missed or doubled update of an
                     # element would be an error of lr = 1e-3 after one step — two orders above either bar.
-                    bound *= 2 if str(dev) == "cpu" else 20
+                    bound *= 2 if str(dev) == "cpu" else 4
                 worst[(mode, what)] = max(worst.get((mode, what), 0.0), err / bound)
                 assert err <= bound, (mode, step, what, err, bound)
     print("in-pass Adam: worst error / bound", {k: round(v, 3) for k, v in worst.items()})
