@@ -346,7 +346,23 @@ __global__ void __launch_bounds__(256) procrustes_scatter_repeat_kernel(ProcPara
 //                dL/dq does not depend on the sampled point.
 // ---------------------------------------------------------------------------------
 constexpr int kTileH = kDenseTileH, kTileW = kDenseTileW;    // 32 x 64 later-frame pixels per workgroup, 8 per thread (64 x 64: no faster, 3 blocks/CU)
-constexpr int kWinH = kTileH + 32, kWinW = kTileW + 64;       // earlier-frame window: +-16 rows, +-32 columns (32 KB)
+#ifndef FM_DENSE_WIN_ROWS  // margins of the earlier-frame window around the flow-displaced tile (taps outside fall back to global loads)
+#define FM_DENSE_WIN_ROWS 16
+#define FM_DENSE_WIN_COLS 32
+#endif
+#ifndef FM_DENSE_UNROLL_MOMENTS
+#define FM_DENSE_UNROLL_MOMENTS 2
+#endif
+#ifndef FM_DENSE_UNROLL_LATER
+#define FM_DENSE_UNROLL_LATER 2
+#endif
+#ifndef FM_DENSE_LATER_BLOCKS
+#define FM_DENSE_LATER_BLOCKS 1
+#endif
+#ifndef FM_DENSE_TAPS_BLOCKS
+#define FM_DENSE_TAPS_BLOCKS 1
+#endif
+constexpr int kWinH = kTileH + FM_DENSE_WIN_ROWS, kWinW = kTileW + FM_DENSE_WIN_COLS;  // +-8 rows, +-16 columns: 18 KB, so the VGPRs and not the LDS set the occupancy (moments 0.88 -> 0.62 ms; +-16 / +-32 was 32 KB)
 constexpr int kRowsPerThread = kTileH / (256 / kTileW);
 static_assert(kTileW == 64 && kWinW % 4 == 0 && kTileH % 4 == 0, "thread mapping: one column, every 4th row");
 
@@ -514,7 +530,7 @@ __global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParam
   DenseRaw next = {};
   if (live && row < p.height) next = dense_load(c, row * p.width + col);
   __syncthreads();
-#pragma unroll 2
+#pragma unroll FM_DENSE_UNROLL_MOMENTS
   for (int k = 0; k < kRowsPerThread; ++k, row += 256 / kTileW) {
     if (!live || row >= p.height) break;
     const DenseRaw cur = next;
@@ -565,7 +581,7 @@ __device__ __forceinline__ DenseBwd dense_load_consts(const double* consts, size
 // Dense backward, later role.  dL/dweights STORED (every element of every pair exactly once),
 // dL/ddepth of the later pixel added in place (this launch is the only writer of that pixel),
 // Σ (w·s) ⊗ g and Σ (w·t) ⊗ h reduced per block and mapped through K_lᵀ / K_eᵀ into kinv_acc.
-__global__ void __launch_bounds__(256) procrustes_dense_bwd_later_kernel(ProcParams p, const double* consts, unsigned total) {
+__global__ void __launch_bounds__(256, FM_DENSE_LATER_BLOCKS) procrustes_dense_bwd_later_kernel(ProcParams p, const double* consts, unsigned total) {
   __shared__ double red[4 * 18];
   __shared__ double tot[18];
   __shared__ DenseWindow win;
@@ -591,7 +607,7 @@ __global__ void __launch_bounds__(256) procrustes_dense_bwd_later_kernel(ProcPar
     if (gd_out) gd_next = gd_out[row * p.width + col];
   }
   __syncthreads();
-#pragma unroll 2
+#pragma unroll FM_DENSE_UNROLL_LATER
   for (int k = 0; k < kRowsPerThread; ++k, row += 256 / kTileW) {
     if (!live || row >= p.height) break;
     const int idx = row * p.width + col;
@@ -715,7 +731,7 @@ __global__ void __launch_bounds__(256) procrustes_dense_plan_sort_kernel(const i
 // owns into its fp32 running sums and clears them.
 constexpr int kTapBatch = 8;
 
-__global__ void __launch_bounds__(256) procrustes_dense_bwd_taps_kernel(ProcParams p, const double* consts, const int64_t* first,
+__global__ void __launch_bounds__(256, FM_DENSE_TAPS_BLOCKS) procrustes_dense_bwd_taps_kernel(ProcParams p, const double* consts, const int64_t* first,
                                                                          const uint32_t* list, unsigned total) {
   __shared__ unsigned long long iacc[kTileH * kTileW];
   __shared__ float tile_u[kTileW], tile_v[kTileH];
