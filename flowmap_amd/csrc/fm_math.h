@@ -1124,6 +1124,41 @@ FM_HD void dense_bwd_consts(const double* pg, const double* ax, const float* kin
   }
 }
 
+// dL/dK⁻¹ of the two frames of a pair WITHOUT a per-pixel sum.  The per-point gradients of align_rigid's statistics are
+//   dL/dq_i = w_i·(G_M·(p_i − p̄) + g_q̄/(Σw+1e-8)),     dL/dp_i = w_i·(G_Mᵀ·(q_i − q̄) + g_p̄/(Σw+1e-8))
+// and dL/dK⁻¹_e = Σ dL/dq_i ⊗ h_i, dL/dK⁻¹_l = Σ dL/dp_i ⊗ g_i with h = K_e·q, g = K_l·p.  Both sums are linear in the
+// statistics the FORWARD pass already holds (st: Σw, Σw·p, Σw·q, M = Σ w (q−q̄)(p−p̄)ᵀ):
+//   Σ dL/dq ⊗ q = G_M·(Mᵀ + δ_p·q̄ᵀ) + g_q̄ ⊗ Σw·q /(Σw+1e-8),     δ_p = Σw·p − p̄·Σw  (= 1e-8·p̄)
+//   Σ dL/dp ⊗ p = G_Mᵀ·(M + δ_q·p̄ᵀ) + g_p̄ ⊗ Σw·p /(Σw+1e-8),     δ_q = Σw·q − q̄·Σw
+// mapped through K_eᵀ / K_lᵀ on the right.  (The dense backward used to accumulate 18 sums per pixel for this.)
+// st: the pair's final statistics; pg: its row of pair_grad; ax: its row of aux; out_e / out_l: 3x3, to be ADDED to kinv_acc.
+FM_HD void dense_kinv_grads(const double* st, const double* pg, const double* ax, const double* k_e, const double* k_l, double* out_e,
+                            double* out_l) {
+  const double w = st[0], iw = pg[16];
+  const double* sp = st + 1;
+  const double* sq = st + 4;
+  const double* m = st + 7;   // [a*3 + d]: a indexes q, d indexes p
+  const double* gm = pg;      // same layout
+  const double* pbar = ax + 21;
+  const double* qbar = ax + 24;
+  double de[9], dl[9];
+  for (int a = 0; a < 3; ++a)
+    for (int c = 0; c < 3; ++c) {
+      double e = 0.0, l = 0.0;
+      for (int d = 0; d < 3; ++d) {
+        e += gm[a * 3 + d] * (m[c * 3 + d] + (sp[d] - pbar[d] * w) * qbar[c]);  // G_M·(Mᵀ + δ_p q̄ᵀ)      [a][c]
+        l += gm[d * 3 + a] * (m[d * 3 + c] + (sq[d] - qbar[d] * w) * pbar[c]);  // G_Mᵀ·(M + δ_q p̄ᵀ)     [a][c]
+      }
+      de[a * 3 + c] = e + iw * pg[9 + a] * sq[c];
+      dl[a * 3 + c] = l + iw * pg[12 + a] * sp[c];
+    }
+  for (int a = 0; a < 3; ++a)
+    for (int d = 0; d < 3; ++d) {  // (D·Kᵀ)[a][d] = Σ_c D[a][c]·K[d][c]
+      out_e[a * 3 + d] = de[a * 3 + 0] * k_e[d * 3 + 0] + de[a * 3 + 1] * k_e[d * 3 + 1] + de[a * 3 + 2] * k_e[d * 3 + 2];
+      out_l[a * 3 + d] = dl[a * 3 + 0] * k_l[d * 3 + 0] + dl[a * 3 + 1] * k_l[d * 3 + 1] + dl[a * 3 + 2] * k_l[d * 3 + 2];
+    }
+}
+
 // t (needs only g: the earlier-role scatter does not sample the earlier frame)
 FM_HD void dense_bwd_t(const DenseBwd& c, const float g[3], float t[3], float gc[3]) {
 #pragma unroll

@@ -557,16 +557,28 @@ __global__ void procrustes_finish_solve_dense_kernel(ProcParams p, int pairs, fl
 // Per-pair constants of the dense backward, once per pair (fp64): consts (pairs, kDenseConstStride)
 // = DenseBwd (21 floats' worth), K_e (9), K_l (9).
 constexpr int kDenseConstStride = 40;
-__global__ void procrustes_dense_consts_kernel(ProcParams p, const double* aux, int pairs, double* consts) {
+// ... and dL/dK⁻¹ of the pair's two frames, which is linear in the statistics of the forward pass (dense_kinv_grads): added to
+// kinv_acc here, one thread per pair — the per-pixel kernels carry no sums for it.
+__global__ void procrustes_dense_consts_kernel(ProcParams p, const double* aux, const double* stats, int pairs, double* consts) {
   const int pair = blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= pairs) return;
   const int b = pair / (p.frames - 1), i = pair % (p.frames - 1);
   DenseBwd c;
   double* o = consts + (size_t)pair * kDenseConstStride;
-  dense_bwd_consts(p.pair_grad + (size_t)pair * kPairGradStride, aux + (size_t)pair * kAuxStride, p.kinv + ((size_t)b * p.frames + i) * 9,
-                   p.kinv + ((size_t)b * p.frames + i + 1) * 9, c, o + 21, o + 30);
+  const double* pg = p.pair_grad + (size_t)pair * kPairGradStride;
+  const double* ax = aux + (size_t)pair * kAuxStride;
+  dense_bwd_consts(pg, ax, p.kinv + ((size_t)b * p.frames + i) * 9, p.kinv + ((size_t)b * p.frames + i + 1) * 9, c, o + 21, o + 30);
   const float* f = c.bm;
   for (int k = 0; k < 21; ++k) o[k] = (double)f[k];  // bm, a0, b0, gbar, hbar are contiguous
+  if (p.kinv_acc) {
+    double ge[9], gl[9];
+    dense_kinv_grads(stats + (size_t)pair * kStatStride, pg, ax, o + 21, o + 30, ge, gl);
+    double* acc = p.kinv_acc + ((size_t)b * p.frames + i) * 9;  // frame i is the later frame of pair i-1 as well: atomics
+    for (int k = 0; k < 9; ++k) {
+      if (ge[k] != 0.0) atomicAdd(acc + k, ge[k]);
+      if (gl[k] != 0.0) atomicAdd(acc + 9 + k, gl[k]);
+    }
+  }
 }
 
 __device__ __forceinline__ DenseBwd dense_load_consts(const double* consts, size_t pair) {
@@ -579,11 +591,8 @@ __device__ __forceinline__ DenseBwd dense_load_consts(const double* consts, size
 }
 
 // Dense backward, later role.  dL/dweights STORED (every element of every pair exactly once),
-// dL/ddepth of the later pixel added in place (this launch is the only writer of that pixel),
-// Σ (w·s) ⊗ g and Σ (w·t) ⊗ h reduced per block and mapped through K_lᵀ / K_eᵀ into kinv_acc.
+// dL/ddepth of the later pixel added in place (this launch is the only writer of that pixel).
 __global__ void __launch_bounds__(256, FM_DENSE_LATER_BLOCKS) procrustes_dense_bwd_later_kernel(ProcParams p, const double* consts, unsigned total) {
-  __shared__ double red[4 * 18];
-  __shared__ double tot[18];
   __shared__ DenseWindow win;
   const DenseBlock blk = dense_block(p.height, p.width, total);
   if (!blk.valid) return;
@@ -591,9 +600,6 @@ __global__ void __launch_bounds__(256, FM_DENSE_LATER_BLOCKS) procrustes_dense_b
   const size_t n = (size_t)p.height * p.width;
   const DenseBwd cst = dense_load_consts(consts, c.pair);
   stage_depth_window(c, win);
-  float acc[18];  // [0..8] Σ (w·t) ⊗ h (earlier frame), [9..17] Σ (w·s) ⊗ g (later frame)
-#pragma unroll
-  for (int k = 0; k < 18; ++k) acc[k] = 0.f;
   const int col = c.tx0 + (threadIdx.x & (kTileW - 1));
   int row = c.ty0 + threadIdx.x / kTileW;
   const bool live = col < p.width;
@@ -625,33 +631,6 @@ __global__ void __launch_bounds__(256, FM_DENSE_LATER_BLOCKS) procrustes_dense_b
     if (c.sens != 0.f) gw *= c.sens * px.w * (1.f - px.w);  // d sigmoid(s·x)/dx
     if (gw_out) gw_out[idx] = gw;
     if (gd_out) gd_out[idx] = gd_cur + px.w * fmaf(sv[0], u, fmaf(sv[1], v, sv[2]));
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float wt = px.w * tv[a], ws = px.w * sv[a];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        acc[a * 3 + d] = fmaf(wt, px.h[d], acc[a * 3 + d]);
-        acc[9 + a * 3 + d] = fmaf(ws, px.g[d], acc[9 + a * 3 + d]);
-      }
-    }
-  }
-  if (p.kinv_acc) {
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 18; ++k) {
-      const float sum = wave_sum_lane63(acc[k]);
-      if (lane == kWave - 1) red[wave * 18 + k] = (double)sum;
-    }
-    __syncthreads();
-    if (threadIdx.x < 18) tot[threadIdx.x] = red[threadIdx.x] + red[18 + threadIdx.x] + red[36 + threadIdx.x] + red[54 + threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x < 18) {  // dL/dK⁻¹ = Kᵀ·(Σ …): element (r, d) of frame `which`
-      const int which = threadIdx.x / 9, r = (threadIdx.x % 9) / 3, d = threadIdx.x % 3;
-      const double* k = consts + c.pair * kDenseConstStride + 21 + which * 9;
-      const double* a = tot + which * 9;
-      const double val = k[0 * 3 + r] * a[0 * 3 + d] + k[1 * 3 + r] * a[1 * 3 + d] + k[2 * 3 + r] * a[2 * 3 + d];
-      if (val != 0.0) atomicAdd(p.kinv_acc + c.fe * 9 + threadIdx.x, val);
-    }
   }
 }
 
@@ -1404,9 +1383,10 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
 
 int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights,
                                 float weight_sensitivity, int batch, int frames, int height, int width, const double* aux,
-                                const double* pair_grad, float* grad_depth, float* grad_weights, double* kinv_acc, const int64_t* first,
-                                const uint32_t* list, double* consts, void* stream) {
+                                const double* stats, const double* pair_grad, float* grad_depth, float* grad_weights, double* kinv_acc,
+                                const int64_t* first, const uint32_t* list, double* consts, void* stream) {
   FM_CHECK_ARG(depth && kinv && bwd_flow && weights && aux && pair_grad && consts && batch >= 1 && frames >= 2);
+  FM_CHECK_ARG(!kinv_acc || stats);
   FM_CHECK_ARG(height >= 1 && width >= 1 && height <= 65535 && width <= 65535 && (long)height * width < (1L << 30));
   FM_CHECK_ARG(!grad_depth || (first && list));
   const int pairs = batch * (frames - 1);
@@ -1417,8 +1397,9 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
   p.grad_weights = grad_weights; p.kinv_acc = kinv_acc; p.frames = frames; p.height = height; p.width = width;
   p.points = (long)height * width; p.weight_sens = weight_sensitivity; p.batch_repeat = 1;
   const unsigned total = (unsigned)dense_blocks(height, width, pairs);
-  hipLaunchKernelGGL(procrustes_dense_consts_kernel, dim3((pairs + 63) / 64), dim3(64), 0, st, p, aux, pairs, consts);
-  hipLaunchKernelGGL(procrustes_dense_bwd_later_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, consts, total);
+  hipLaunchKernelGGL(procrustes_dense_consts_kernel, dim3((pairs + 63) / 64), dim3(64), 0, st, p, aux, stats, pairs, consts);
+  if (grad_depth || grad_weights)
+    hipLaunchKernelGGL(procrustes_dense_bwd_later_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, consts, total);
   if (grad_depth) hipLaunchKernelGGL(procrustes_dense_bwd_taps_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, consts, first, list, total);
   FM_LAUNCH_STATUS();
 }

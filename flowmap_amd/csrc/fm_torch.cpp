@@ -418,7 +418,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     Tensor aux = at::empty({pairs, FM_AUX_STRIDE}, weights.options().dtype(at::kDouble));
     Tensor t_bwd = empty_like_shape({b, f - 1, 4, 4}, weights), t_fwd = empty_like_shape({b, f - 1, 4, 4}, weights);
     // With a persistent workspace (sparse index set, no repeat): moments, finish + solve and the pose chain in ONE launch
-    Tensor work = opt(work_o), ext;
+    Tensor work = opt(work_o), ext, stats;
     const bool chained = work.defined() && indices.defined() && rep == 1;
     {
       DeviceScope scope(dev);
@@ -430,7 +430,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                 (float)weight_sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(work), ptr(t_bwd), ptr(t_fwd),
                 ptr<double>(aux), ptr(ext), scope.stream);
       } else {
-        Tensor stats = at::empty({pairs, FM_STAT_STRIDE}, weights.options().dtype(at::kDouble));
+        stats = at::empty({pairs, FM_STAT_STRIDE}, weights.options().dtype(at::kDouble));  // kept: the dense backward derives dL/dK⁻¹ from it
         FM_CALL(fm_procrustes_fit, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights), (float)weight_sens,
                 ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(stats), ptr(t_bwd), ptr(t_fwd),
                 ptr<double>(aux), scope.stream);
@@ -439,6 +439,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     ctx->save_for_backward({from_depth ? depth : surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux, opt(plan_pixels), opt(plan_first),
                             opt(plan_vectors), opt(plan_weights), opt(dense_first), opt(dense_list), ext});
     ctx->saved_data["dims"] = std::vector<int64_t>{b, f, h, w, points, rep, from_depth ? 1 : 0};
+    ctx->saved_data["stats"] = stats;
     ctx->saved_data["weight_sens"] = weight_sens;
     if (sink) ctx->saved_data["sink"] = sink;
     if (wsink) ctx->saved_data["wsink"] = wsink;
@@ -519,8 +520,10 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
               kinv_acc.defined() ? (long)kinv_acc.numel() : 0L, scope.stream);
       if (dense) {  // every pixel a correspondence: tiled, planned, no atomics
         Tensor consts = at::empty({pairs, FM_DENSE_CONST_STRIDE}, weights.options().dtype(at::kDouble));
+        const Tensor stats = ctx->saved_data["stats"].isTensor() ? ctx->saved_data["stats"].toTensor() : Tensor();
+        TORCH_CHECK(stats.defined(), "flowmap_amd: the dense Procrustes backward needs the statistics of its forward pass");
         FM_CALL(fm_procrustes_scatter_dense, ptr(src), ptr(kinv), ptr(bwd_flow), ptr(weights), sens, (int)b, (int)f, (int)h, (int)w,
-                ptr<double>(aux), ptr<double>(pair_grad), ptr(g_src), ptr(g_w), ptr<double>(kinv_acc), ptr<int64_t>(dense_first),
+                ptr<double>(aux), ptr<double>(stats), ptr<double>(pair_grad), ptr(g_src), ptr(g_w), ptr<double>(kinv_acc), ptr<int64_t>(dense_first),
                 ptr<uint32_t>(dense_list), ptr<double>(consts), scope.stream);
       } else {
         FM_CALL(fm_procrustes_scatter, from_depth ? ptr(src) : nullptr, ptr(kinv), from_depth ? nullptr : ptr(src), ptr(bwd_flow), ptr(weights),

@@ -180,7 +180,9 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
  * Per step fm_procrustes_scatter_dense: grad_weights (B,F-1,H,W) is STORED (every element exactly once:
  * need not be zeroed, must not hold another gradient); grad_depth (B,F,H,W) is ADDED to with plain
  * read-modify-writes (each pixel has one writer per launch); kinv_acc (B·F,9) fp64 is added to (caller
- * zeroes).  grad_depth / grad_weights / kinv_acc may be NULL; first / list are needed for grad_depth.
+ * zeroes) — from `stats`, the (B·(F-1), FM_STAT_STRIDE) statistics fm_procrustes_fit left behind for the same inputs: dL/dK⁻¹ is
+ * linear in them, so no per-pixel sum is formed (stats may be NULL when kinv_acc is).
+ * grad_depth / grad_weights / kinv_acc may be NULL; first / list are needed for grad_depth.
  * consts: workspace of B·(F-1)·FM_DENSE_CONST_STRIDE doubles (per-pair constants, written by the call). */
 #define FM_DENSE_CONST_STRIDE 40
 int fm_procrustes_dense_tiles(int height, int width, int* tiles);
@@ -188,8 +190,8 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
                              uint32_t* list, void* stream);
 int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights,
                                 float weight_sensitivity, int batch, int frames, int height, int width, const double* aux,
-                                const double* pair_grad, float* grad_depth, float* grad_weights, double* kinv_acc, const int64_t* first,
-                                const uint32_t* list, double* consts, void* stream);
+                                const double* stats, const double* pair_grad, float* grad_depth, float* grad_weights, double* kinv_acc,
+                                const int64_t* first, const uint32_t* list, double* consts, void* stream);
 
 /* Planned form of the sparse depth-sourced scatter.  With DISTINCT `indices` and constant flows the
  * pixels a step's Procrustes gradient touches never change: fm_procrustes_scatter_plan lists them

@@ -544,9 +544,10 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
 }
 
 int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float sens, int batch,
-                                int frames, int height, int width, const double* aux, const double* pair_grad, float* grad_depth,
-                                float* grad_weights, double* kinv_acc, const int64_t* first, const uint32_t* list, double*, void*) {
-  if (!depth || !kinv || !bwd_flow || !weights || !aux || !pair_grad || (grad_depth && (!first || !list))) return 1;
+                                int frames, int height, int width, const double* aux, const double* stats, const double* pair_grad,
+                                float* grad_depth, float* grad_weights, double* kinv_acc, const int64_t* first, const uint32_t* list, double*,
+                                void*) {
+  if (!depth || !kinv || !bwd_flow || !weights || !aux || !pair_grad || (grad_depth && (!first || !list)) || (kinv_acc && !stats)) return 1;
   int tiles = 0;
   fm_procrustes_dense_tiles(height, width, &tiles);
   const int tiles_x = (width + kDenseTileW - 1) / kDenseTileW;
@@ -576,12 +577,26 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
             a_l[a * 3 + d] += (double)(px.w * sv[a]) * px.g[d];
           }
       }
-    if (kinv_acc)
+    if (kinv_acc) {
+      // the device derives dL/dK⁻¹ from the forward statistics (dense_kinv_grads); the double also forms the per-pixel sums it
+      // replaces and refuses to go on when the two disagree — every CPU test of the dense path checks the algebra
+      double ge[9], gl[9], pe[9], pl[9], num = 0.0, den = 0.0;
+      dense_kinv_grads(stats + (size_t)pr * kStatStride, pair_grad + (size_t)pr * kPairGradStride, aux + (size_t)pr * kAuxStride, k_e, k_l, ge, gl);
       for (int r = 0; r < 3; ++r)
         for (int d = 0; d < 3; ++d) {
-          kinv_acc[fe * 9 + r * 3 + d] += k_e[0 * 3 + r] * a_e[0 * 3 + d] + k_e[1 * 3 + r] * a_e[1 * 3 + d] + k_e[2 * 3 + r] * a_e[2 * 3 + d];
-          kinv_acc[fl * 9 + r * 3 + d] += k_l[0 * 3 + r] * a_l[0 * 3 + d] + k_l[1 * 3 + r] * a_l[1 * 3 + d] + k_l[2 * 3 + r] * a_l[2 * 3 + d];
+          pe[r * 3 + d] = k_e[0 * 3 + r] * a_e[0 * 3 + d] + k_e[1 * 3 + r] * a_e[1 * 3 + d] + k_e[2 * 3 + r] * a_e[2 * 3 + d];
+          pl[r * 3 + d] = k_l[0 * 3 + r] * a_l[0 * 3 + d] + k_l[1 * 3 + r] * a_l[1 * 3 + d] + k_l[2 * 3 + r] * a_l[2 * 3 + d];
         }
+      for (int k = 0; k < 9; ++k) {
+        num += (ge[k] - pe[k]) * (ge[k] - pe[k]) + (gl[k] - pl[k]) * (gl[k] - pl[k]);
+        den += pe[k] * pe[k] + pl[k] * pl[k];
+      }
+      if (num > 1e-6 * den + 1e-30) return 3;  // (1e-3 relative: the per-pixel sums are fp32 products)
+      for (int k = 0; k < 9; ++k) {
+        kinv_acc[fe * 9 + k] += ge[k];
+        kinv_acc[fl * 9 + k] += gl[k];
+      }
+    }
     if (!grad_depth) continue;
     // earlier role: per tile of the earlier frame, the listed later pixels (only taps inside the tile count)
     for (int tile = 0; tile < tiles; ++tile) {
