@@ -708,7 +708,10 @@ __global__ void __launch_bounds__(256) procrustes_dense_plan_sort_kernel(const i
 // |β0|+|β1|+|β2| >= |any tap value|, (2) block maximum -> scale 2^e with |value|·2^e <= 2^30, (3) taps,
 // values converted to 49-bit fixed point and added as 64-bit words, (4) every thread folds the cells it
 // owns into its fp32 running sums and clears them.
-constexpr int kTapBatch = 8;
+#ifndef FM_DENSE_TAP_BATCH
+#define FM_DENSE_TAP_BATCH 6  // (8: 142 VGPRs, 3 waves per SIMD, 2.18 ms for later + taps; 6: 126 VGPRs, 4 waves, 1.98 ms; 4: 1.98; 2: 2.05)
+#endif
+constexpr int kTapBatch = FM_DENSE_TAP_BATCH;
 
 __global__ void __launch_bounds__(256, FM_DENSE_TAPS_BLOCKS) procrustes_dense_bwd_taps_kernel(ProcParams p, const double* consts, const int64_t* first,
                                                                          const uint32_t* list, unsigned total) {
