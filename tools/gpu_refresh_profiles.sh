@@ -23,7 +23,8 @@ bench)
   python bench.py --config c2 > "$OUT/${R}_bench_c2_tracking.json" 2> "$OUT/bench_c2.err" ;;
 variants)
   { for a in "--config c3" "--config c4" "--inputs iid" "--intrinsics softmin" "--optimizer fused" "--optimizer in_pass" "--optimizer torch" \
-             "--config c2 --optimizer in_pass" "--points 0" "--config c2 --intrinsics softmin --optimizer fused" \
+             "--config c2 --optimizer fused" "--config c2 --optimizer in_pass" "--intrinsics softmin --optimizer in_pass" "--points 0" \
+             "--config c2 --intrinsics softmin --optimizer fused" \
              "--height 180 --width 240" "--height 180 --width 240 --optimizer fused" "--height 180 --width 240 --optimizer fused --graph" \
              "--height 180 --width 240 --intrinsics softmin" "--height 180 --width 240 --tracking --optimizer fused" \
              "--height 180 --width 240 --tracking --optimizer fused --graph"; do
@@ -34,7 +35,8 @@ stats)
   stats c2_tracking --config c2
   stats dense_procrustes --points 0
   stats c1_adam_in_pass --optimizer in_pass
-  stats default_resolution_180x240_tracking_adam --height 180 --width 240 --tracking --optimizer fused ;;
+  stats default_resolution_180x240_tracking_adam --height 180 --width 240 --tracking --optimizer fused
+  stats softmin_sweep --intrinsics softmin ;;
 pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
     # (i.i.d. inputs and a kernel filter: with the scene synthesis' 126 000 torch launches in the counter pass rocprofv3 crashed)
