@@ -10,7 +10,6 @@ from __future__ import annotations
 from dataclasses import dataclass, replace
 from typing import Optional, Tuple, Union
 
-import weakref
 
 import torch
 from torch import Tensor
@@ -61,16 +60,12 @@ def get_image_shape(original_shape: Tuple[int, int], cfg: CroppingCfg) -> Tuple[
     return round(h * scale), round(w * scale)
 
 
-_uploaded = None  # (weakref to the host videos tensor, device, resident batch): ONE entry, the video being prepared
-
-
 def _resident(batch, device=None):
     """The reference resizes on the host, where its data loader leaves the batch
     (flowmap/overfit.py:52-62); here a host batch is uploaded once at its original resolution and
     everything derived from it is produced in HBM (``Batch.to`` later is then a no-op).  overfit.py
-    crops the same batch twice (model, flow network): the upload is remembered per videos tensor
-    (weakly: it goes away with the host batch) so the second call reuses it."""
-    global _uploaded
+    crops the same batch twice (model, flow network): the upload is kept ON the host videos tensor (it goes away
+    with the host batch; no module-level state) so the second call reuses it."""
     if device is None:
         if batch.videos.is_cuda or _lib.using_test_double():
             return batch
@@ -78,10 +73,11 @@ def _resident(batch, device=None):
     device = torch.device(device)
     if batch.videos.device == device:
         return batch
-    if _uploaded is not None and _uploaded[0]() is batch.videos and _uploaded[1] == device and _uploaded[2] == batch.videos._version:
-        return replace(_uploaded[3], **{k: v for k, v in vars(batch).items() if not isinstance(v, Tensor)})
+    kept = batch.videos.__dict__.get("_fm_resident")
+    if kept is not None and kept[0] == (str(device), batch.videos._version):
+        return replace(kept[1], **{k: v for k, v in vars(batch).items() if not isinstance(v, Tensor)})
     resident = batch.to(device)
-    _uploaded = (weakref.ref(batch.videos), device, batch.videos._version, resident)
+    batch.videos.__dict__["_fm_resident"] = ((str(device), batch.videos._version), resident)
     return resident
 
 
