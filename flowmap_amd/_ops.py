@@ -527,113 +527,12 @@ class FlowLossFused:
                                      sink, int(items), acc, *adam)
 
 
-class SoftminScore(torch.autograd.Function):
-    """IntrinsicsSoftmin's per-candidate weighted L1 flow error (intrinsics_softmin.py:105-121) from
-    the images themselves: depth (B,2,H,W) frames 0/1, weights (B,1,H,W) of pair 0 (logits when
-    ``weight_sens`` != 0), bwd_flow (B,1,H,W,2), indices (P) distinct pixels, candidate intrinsics
-    (N,3,3) [constants], rel (B·N,4,4) the fitted later->earlier poses  ->  error (B,N)."""
-
-    @staticmethod
-    def forward(ctx, depth, weights, bwd_flow, indices, k, rel, weight_sens):
-        saved, err = _softmin_score_forward(depth, weights, bwd_flow, indices, k, rel, weight_sens)
-        ctx.save_for_backward(*saved)
-        ctx.sens = float(weight_sens)
-        return err.to(torch.float32).reshape(saved[0].shape[0], saved[4].shape[0])
-
-    @staticmethod
-    def backward(ctx, g_err):
-        g_depth, g_weights, g_rel = _softmin_score_backward(ctx.saved_tensors, ctx.sens, _f32c(g_err, "grad"), ctx.needs_input_grad)
-        return g_depth, g_weights, None, None, None, g_rel, None
-
-
-def _softmin_score_forward(depth, weights, bwd_flow, indices, k, rel, weight_sens):
-    """Checks + launch shared by SoftminScore and SoftminIntrinsics -> (tensors to save, err fp64 (b*n))."""
-    dev = check_device(depth, weights, bwd_flow, indices, k, rel)
-    depth, weights, bwd_flow = _f32c(depth, "depth"), _f32c(weights, "weights"), _f32c(bwd_flow, "backward flow")
-    k, rel = _f32c(k, "intrinsics"), _f32c(rel, "poses")
-    b, two, h, w = depth.shape
-    n = k.shape[0]
-    if two != 2 or tuple(weights.shape) != (b, 1, h, w) or tuple(bwd_flow.shape) != (b, 1, h, w, 2):
-        raise RuntimeError("flowmap_amd: SoftminScore expects depth (b,2,h,w), weights (b,1,h,w), backward flow (b,1,h,w,2)")
-    if tuple(k.shape) != (n, 3, 3) or tuple(rel.shape) != (b * n, 4, 4) or indices.dtype != torch.int64:
-        raise RuntimeError("flowmap_amd: SoftminScore expects intrinsics (n,3,3), poses (b*n,4,4), int64 indices")
-    if k.requires_grad or bwd_flow.requires_grad:
-        raise RuntimeError("flowmap_amd: the softmin candidates and the optical flow are constants")
-    indices = indices.contiguous()
-    kinv = intrinsics_inverse(k)
-    err = torch.empty((b * n,), dtype=torch.float64, device=dev)
-    with _guard(dev):
-        call("fm_softmin_score_fwd", ptr(depth), ptr(weights), float(weight_sens), ptr(bwd_flow), ptr(indices), indices.numel(),
-             ptr(k), ptr(kinv), ptr(rel), b, n, h, w, ptr(err), stream_for(depth))
-    return (depth, weights, bwd_flow, indices, k, kinv, rel), err
-
-
-def _softmin_score_backward(saved, sens, g_err, needs):
-    """g_err (b*n) fp32 -> (g_depth, g_weights, g_rel); ``needs`` indexes like SoftminScore's inputs."""
-    depth, weights, bwd_flow, indices, k, kinv, rel = saved
-    b, _, h, w = depth.shape
-    n = k.shape[0]
-    g_err = g_err.reshape(b * n)
-    g_depth = torch.zeros_like(depth) if needs[0] else None
-    g_weights = torch.zeros_like(weights) if needs[1] else None
-    acc = torch.empty((b * n, 12), dtype=torch.float64, device=depth.device)
-    g_rel = torch.empty_like(rel)
-    with _guard(depth.device):
-        call("fm_softmin_score_bwd", ptr(depth), ptr(weights), sens, ptr(bwd_flow), ptr(indices), indices.numel(), ptr(k),
-             ptr(kinv), ptr(rel), b, n, h, w, ptr(g_err), ptr(g_depth), ptr(g_weights), ptr(acc), ptr(g_rel), stream_for(depth))
-    return g_depth, g_weights, g_rel if needs[5] else None
-
-
-class SoftminIntrinsics(torch.autograd.Function):
-    """SoftminScore followed by the tail of IntrinsicsSoftmin.forward (intrinsics_softmin.py:105-141)
-    as three launches forward, three backward: the candidates' flow errors stay in their fp64
-    accumulator, one wave per batch entry turns them into the softmin weights, the blended K for every
-    frame and its inverse.  -> (K (B,frames,3,3), soft (B,N) [not differentiable: the window's input])."""
-
-    @staticmethod
-    def forward(ctx, depth, weights, bwd_flow, indices, k, rel, weight_sens, frames):
-        saved, err = _softmin_score_forward(depth, weights, bwd_flow, indices, k, rel, weight_sens)
-        b, n, frames = saved[0].shape[0], saved[4].shape[0], int(frames)
-        dev = err.device
-        soft = torch.empty((b, n), dtype=torch.float32, device=dev)
-        out = torch.empty((b, frames, 3, 3), dtype=torch.float32, device=dev)
-        kinv_out = torch.empty_like(out)
-        with _guard(dev):
-            call("fm_softmin_blend_fwd", ptr(err), ptr(saved[4]), b, n, frames, ptr(soft), ptr(out), ptr(kinv_out), stream_for(out))
-        ctx.save_for_backward(*saved, soft)
-        ctx.sens, ctx.frames = float(weight_sens), frames
-        ctx.kinv = kinv_out  # handed to the K^-1 cache by softmin_intrinsics()
-        ctx.mark_non_differentiable(soft)
-        ctx.set_materialize_grads(False)  # no zeros tensor for soft's (absent) gradient
-        return out, soft
-
-    @staticmethod
-    def backward(ctx, g_k, _g_soft):
-        if g_k is None:
-            return (None,) * 8
-        *saved, soft = ctx.saved_tensors
-        b, n = soft.shape
-        g_k = _f32c(g_k, "grad")
-        g_err = torch.empty((b * n,), dtype=torch.float32, device=g_k.device)
-        with _guard(g_k.device):
-            call("fm_softmin_blend_bwd", ptr(g_k), ptr(soft), ptr(saved[4]), b, n, ctx.frames, ptr(g_err), stream_for(g_k))
-        g_depth, g_weights, g_rel = _softmin_score_backward(saved, ctx.sens, g_err, ctx.needs_input_grad)
-        return g_depth, g_weights, None, None, None, g_rel, None, None
-
-
-def _park_inverse(k: Tensor) -> None:
-    """Leave the K^-1 a fused producer computed alongside ``k`` where intrinsics_inverse() finds it."""
-    node = k.grad_fn
-    kinv = getattr(node, "kinv", None) if node is not None else None
-    if kinv is not None:
-        node.kinv = None
-        _attach_inverse(k, kinv)
-
-
 def softmin_intrinsics(depth, weights, bwd_flow, indices, candidate_k, rel, weight_sens, frames):
-    """-> (K (b,frames,3,3) blended over the candidates, softmin weights (b,n))."""
-    k, soft = SoftminIntrinsics.apply(depth, weights, bwd_flow, indices, candidate_k, rel, weight_sens, frames)
-    _park_inverse(k)
+    """-> (K (b,frames,3,3) blended over the candidates, softmin weights (b,n)): SoftminScore followed by the tail of
+    IntrinsicsSoftmin.forward (intrinsics_softmin.py:105-141), csrc/fm_torch.cpp: SoftminIntrinsics.  K⁻¹ comes out of
+    the same launch and is left where intrinsics_inverse() finds it."""
+    k, soft, kinv = torch_ops().softmin_intrinsics(depth, weights, bwd_flow, indices, candidate_k, rel, float(weight_sens), int(frames))
+    _attach_inverse(k, kinv)
     return k, soft
 
 
@@ -651,21 +550,15 @@ def random_subset(n: int, count: int, device, seed: Optional[int] = None) -> Ten
     if not 1 <= count <= n:
         raise RuntimeError("flowmap_amd: random_subset needs 1 <= count <= n")
     device = torch.device(device)
-    out = torch.empty((count,), dtype=torch.int64, device=device)
-    check_device(out)
     if seed is None and graph_capturable:
-        state = _rng_states.get(str(out.device))
+        state = _rng_states.get(str(device))
         if state is None:  # created OUTSIDE any capture (GraphedStep warms the step up first)
             first = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
-            state = _rng_states[str(out.device)] = torch.tensor([first], dtype=torch.int64).to(out.device)
-        with _guard(device):
-            call("fm_random_subset_stateful", ptr(state), int(n), int(count), ptr(out), stream_for(out))
-        return out
+            state = _rng_states[str(device)] = torch.tensor([first], dtype=torch.int64).to(device)
+        return torch_ops().random_subset(int(n), int(count), device, 0, state)
     if seed is None:
         seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
-    with _guard(device):
-        call("fm_random_subset", int(seed), int(n), int(count), ptr(out), stream_for(out))
-    return out
+    return torch_ops().random_subset(int(n), int(count), device, int(seed), None)
 
 
 # --------------------------------------------------------------------------------------

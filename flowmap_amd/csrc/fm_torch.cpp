@@ -48,7 +48,8 @@ using OptTensor = std::optional<Tensor>;
   X(fm_focal_intrinsics_fwd) X(fm_focal_intrinsics_bwd) X(fm_pose_chain_fwd) X(fm_pose_chain_bwd) X(fm_relative_pose_fwd)                  \
   X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense)                \
   X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_loss_fused_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
-  X(fm_adam_step_capturable)
+  X(fm_adam_step_capturable) X(fm_softmin_score_fwd) X(fm_softmin_score_bwd) X(fm_softmin_blend_fwd) X(fm_softmin_blend_bwd)         \
+  X(fm_random_subset) X(fm_random_subset_stateful)
 
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
@@ -869,6 +870,87 @@ FM_CALL(fm_track_loss_fused_fwd, ptr(depth), (int)frame0, (int)own_first, (int)o
 };
 
 // ------------------------------------------------------------------------------------------
+// IntrinsicsSoftmin's score + blend (intrinsics_softmin.py:105-141): per candidate the pose-induced backward-flow error at
+// the sampled pixels, straight from the images (fm_softmin_score_fwd), then softmin((err − min)·10), the blended K of every
+// frame and its inverse (fm_softmin_blend_fwd).  Two launches forward, three backward.
+//   depth (B,2,H,W) frames 0/1; weights (B,1,H,W) of pair 0 (logits when weight_sens != 0); bwd_flow (B,1,H,W,2);
+//   indices (P) int64 distinct; k (N,3,3) candidates; rel (B·N,4,4) fitted poses later -> earlier.
+//   -> K (B,frames,3,3), soft (B,N) [not differentiable: the window's input], K⁻¹ (B,frames,3,3) [not differentiable]
+// ------------------------------------------------------------------------------------------
+struct SoftminIntrinsics : public Function<SoftminIntrinsics> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& depth_in, const Tensor& weights_in, const Tensor& bwd_flow_in,
+                               const Tensor& indices_in, const Tensor& k_in, const Tensor& rel_in, double weight_sens, int64_t frames) {
+    const auto dev = check_device({&depth_in, &weights_in, &bwd_flow_in, &indices_in, &k_in, &rel_in});
+    const Tensor depth = f32c(depth_in, "depth"), weights = f32c(weights_in, "weights"), bwd_flow = f32c(bwd_flow_in, "backward flow");
+    const Tensor k = f32c(k_in, "intrinsics"), rel = f32c(rel_in, "poses");
+    TORCH_CHECK(depth.dim() == 4 && depth.size(1) == 2, "flowmap_amd: the softmin score expects depth (b,2,h,w)");
+    const int64_t b = depth.size(0), h = depth.size(2), w = depth.size(3), n = k.size(0);
+    TORCH_CHECK(weights.sizes() == at::IntArrayRef({b, 1, h, w}) && bwd_flow.sizes() == at::IntArrayRef({b, 1, h, w, 2}),
+                "flowmap_amd: the softmin score expects weights (b,1,h,w) and backward flow (b,1,h,w,2)");
+    TORCH_CHECK(k.sizes() == at::IntArrayRef({n, 3, 3}) && rel.sizes() == at::IntArrayRef({b * n, 4, 4}) && indices_in.scalar_type() == at::kLong &&
+                    frames >= 1,
+                "flowmap_amd: the softmin score expects intrinsics (n,3,3), poses (b*n,4,4), int64 indices");
+    TORCH_CHECK(!k_in.requires_grad() && !bwd_flow_in.requires_grad(), "flowmap_amd: the softmin candidates and the optical flow are constants");
+    const Tensor indices = indices_in.contiguous();
+    const Tensor kinv = intrinsics_inverse(k);
+    Tensor err = at::empty({b * n}, depth.options().dtype(at::kDouble));
+    Tensor soft = at::empty({b, n}, depth.options());
+    Tensor out = at::empty({b, frames, 3, 3}, depth.options()), kinv_out = at::empty({b, frames, 3, 3}, depth.options());
+    {
+      DeviceScope scope(dev);
+      FM_CALL(fm_softmin_score_fwd, ptr(depth), ptr(weights), (float)weight_sens, ptr(bwd_flow), ptr<int64_t>(indices), (long)indices.numel(), ptr(k),
+              ptr(kinv), ptr(rel), (int)b, (int)n, (int)h, (int)w, ptr<double>(err), scope.stream);
+      FM_CALL(fm_softmin_blend_fwd, ptr<double>(err), ptr(k), (int)b, (int)n, (int)frames, ptr(soft), ptr(out), ptr(kinv_out), scope.stream);
+    }
+    ctx->save_for_backward({depth, weights, bwd_flow, indices, k, kinv, rel, soft});
+    ctx->saved_data["weight_sens"] = weight_sens;
+    ctx->saved_data["frames"] = frames;
+    ctx->saved_data["needs"] = std::vector<int64_t>{depth_in.requires_grad(), weights_in.requires_grad(), rel_in.requires_grad()};
+    ctx->mark_non_differentiable({soft, kinv_out});
+    ctx->set_materialize_grads(false);
+    return {out, soft, kinv_out};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    variable_list out(8);
+    if (!grads[0].defined()) return out;
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &depth = saved[0], &weights = saved[1], &bwd_flow = saved[2], &indices = saved[3], &k = saved[4], &kinv = saved[5], &rel = saved[6],
+                 &soft = saved[7];
+    const auto needs = ctx->saved_data["needs"].toIntVector();
+    const int64_t b = depth.size(0), h = depth.size(2), w = depth.size(3), n = k.size(0), frames = ctx->saved_data["frames"].toInt();
+    const Tensor g_k = f32c(grads[0], "grad");
+    Tensor g_err = at::empty({b * n}, depth.options());
+    Tensor g_depth = needs[0] ? at::zeros_like(depth) : Tensor(), g_weights = needs[1] ? at::zeros_like(weights) : Tensor();
+    Tensor acc = at::empty({b * n, 12}, depth.options().dtype(at::kDouble)), g_rel = at::empty_like(rel);
+    DeviceScope scope(g_k.device());
+    FM_CALL(fm_softmin_blend_bwd, ptr(g_k), ptr(soft), ptr(k), (int)b, (int)n, (int)frames, ptr(g_err), scope.stream);
+    FM_CALL(fm_softmin_score_bwd, ptr(depth), ptr(weights), (float)ctx->saved_data["weight_sens"].toDouble(), ptr(bwd_flow), ptr<int64_t>(indices),
+            (long)indices.numel(), ptr(k), ptr(kinv), ptr(rel), (int)b, (int)n, (int)h, (int)w, ptr(g_err), ptr(g_depth), ptr(g_weights),
+            ptr<double>(acc), ptr(g_rel), scope.stream);
+    out[0] = g_depth;
+    out[1] = g_weights;
+    if (needs[2]) out[5] = g_rel;
+    return out;
+  }
+};
+
+// `count` distinct pseudo-random indices of [0, n) (what torch.randperm(n)[:count] is used for): one launch.  With `state` (a
+// one-element int64 device tensor) the seed lives in device memory and the call advances it — capturable in a hipGraph.
+static Tensor random_subset(int64_t n, int64_t count, c10::Device device, int64_t seed, const OptTensor& state) {
+  TORCH_CHECK(count >= 1 && count <= n, "flowmap_amd: random_subset needs 1 <= count <= n");
+  Tensor out = at::empty({count}, at::TensorOptions().dtype(at::kLong).device(device));
+  const auto dev = check_device({&out});
+  DeviceScope scope(dev);
+  if (state.has_value() && state->defined()) {
+    TORCH_CHECK(state->scalar_type() == at::kLong && state->numel() == 1 && state->device() == out.device(), "flowmap_amd: the sampler state is one int64 on the device");
+    FM_CALL(fm_random_subset_stateful, static_cast<unsigned long long*>(state->data_ptr()), (long)n, (long)count, ptr<int64_t>(out), scope.stream);
+  } else {
+    FM_CALL(fm_random_subset, (unsigned long long)seed, (long)n, (long)count, ptr<int64_t>(out), scope.stream);
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------
 // LeadingFrames: x[:, :count].contiguous() for (b, F, H, W) image stacks.  The softmin sweep reads two of the
 // 150 depth frames; autograd's slice backward would zero-fill a full-size tensor and add it densely to the main
 // path's gradient (1.7 GB of traffic at C1).  Autograd runs this node's backward AFTER the nodes that consume
@@ -1052,6 +1134,12 @@ static void adam_step_elements(Tensor p, const Tensor& grad_in, Tensor m, Tensor
   v.unsafeGetTensorImpl()->bump_version();
 }
 
+static std::tuple<Tensor, Tensor, Tensor> softmin_intrinsics_op(const Tensor& depth, const Tensor& weights, const Tensor& bwd_flow, const Tensor& indices,
+                                                                 const Tensor& k, const Tensor& rel, double weight_sens, int64_t frames) {
+  auto out = SoftminIntrinsics::apply(depth, weights, bwd_flow, indices, k, rel, weight_sens, frames);
+  return {out[0], out[1], out[2]};
+}
+
 static Tensor leading_frames_op(const Tensor& x, int64_t count, const OptSink& sink) {
   return LeadingFrames::apply(x, count, sink_of(sink));
 }
@@ -1101,6 +1189,10 @@ TORCH_LIBRARY(flowmap_amd, m) {
   m.def("adam_step_elements(Tensor(a!) p, Tensor grad, Tensor(b!) m, Tensor(c!) v, Tensor elements, int step, float lr, float beta1, float beta2, "
         "float eps, float weight_decay) -> ()",
         fmt::adam_step_elements);
+  m.def("softmin_intrinsics(Tensor depth, Tensor weights, Tensor bwd_flow, Tensor indices, Tensor k, Tensor rel, float weight_sens, int frames) "
+        "-> (Tensor, Tensor, Tensor)",
+        fmt::softmin_intrinsics_op);
+  m.def("random_subset(int n, int count, Device device, int seed, Tensor? state) -> Tensor", fmt::random_subset);
   m.def("flow_timing_enable(bool on) -> ()", fmt::flow_timing_enable);
   m.def("flow_timing_collect(bool tracking) -> float[]", fmt::flow_timing_collect);
 }
