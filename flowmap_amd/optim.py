@@ -121,7 +121,8 @@ class FusedAdam(torch.optim.Optimizer):
 
         param = depth if depth._base is None else depth._base
         group = next((g for g in self.param_groups if any(p is param for p in g["params"])), None)
-        if (group is None or group["weight_decay"] != 0 or group.get("capturable") or not param.is_contiguous() or param.dtype != torch.float32
+        if (group is None or group["weight_decay"] != 0 or group.get("capturable") or param.__dict__.get("_fm_sharded") or not param.is_contiguous()
+                or param.dtype != torch.float32
                 or depth.data_ptr() != param.data_ptr() or depth.numel() != param.numel() or param in self._in_pass):
             return None
         registry = param.__dict__.get("_fm_touched", {})

@@ -113,6 +113,8 @@ class FrameShard:
         depth = getattr(getattr(model, "backbone", None), "depth", None)
         if depth is not None and depth.requires_grad:
             depth.register_post_accumulate_grad_hook(lambda param: self.start_halo_exchange(param.grad))
+            # the halo frames' gradient is complete only after the exchange: no in-pass optimiser update on a shard
+            depth.__dict__["_fm_sharded"] = True
 
     def softmin_from_rank0(self, sweep, batch: int, candidates: int, frames: int, device):
         """``sweep() -> (K (b,frames,3,3), softmin weights (b,n))`` evaluated on rank 0 only -> the same pair on

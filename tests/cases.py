@@ -1166,6 +1166,17 @@ def case_in_pass_adam_refusals(dev):
             optimizer.step()
         assert optimizer.counters["in_pass_updates"] == 0 and optimizer.counters["sparse_updates"] == 3
 
+        # a frame shard (FrameShard.prepare_model marks the parameter): the halo frames' gradient is complete only after the exchange
+        model, batch, flows, loss_of = _small_problem(dev, tracking=False)
+        optimizer = FusedAdam(model.parameters(), lr=1e-3)
+        optimizer.fuse_depth_update(model.backbone.depth, max_touched_fraction=1.0)
+        model.backbone.depth.__dict__["_fm_sharded"] = True
+        for step in range(4):
+            optimizer.zero_grad(set_to_none=True)
+            loss_of(model(batch, flows, step)).backward()
+            optimizer.step()
+        assert optimizer.counters["in_pass_updates"] == 0
+
         # the element-list update of the weight logits: not when the gradient was edited after backward (clipping) —
         # the dense update runs, and the list is taken up again once the moments are verified zero elsewhere
         model, batch, flows, loss_of = _small_problem(dev, tracking=False)
