@@ -358,7 +358,7 @@ def test_graphed_step_replays_the_eager_optimisation():
             losses = []
             if mode == "eager":
                 for _ in range(3 + 5):  # the graph variant runs 3 eager warm-up steps; the capture itself executes nothing
-                    losses.append(float(step()))
+                    losses.append(float(step().detach()))
             else:
                 graphed = flowmap_amd.GraphedStep(step, warmup=3)
                 try:
