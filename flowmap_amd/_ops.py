@@ -233,6 +233,8 @@ def touched_elements(depth: Tensor):
 
 # Persistent dL/dweights storage (GradArena) for sparse fits with a constant index set; False = fresh zeros every step
 use_grad_arena = True
+# Moments, finish + solve and the pose chain as ONE launch (fm_procrustes_fit_chain) instead of a memset and three kernels.
+use_fit_chain = True
 
 # which backward path the facades selected (tests)
 counters = {"procrustes_planned": 0, "procrustes_dense_planned": 0}
@@ -424,7 +426,7 @@ class ProcrustesFit:
                             _note_sparse_grad(weights, arena, indices, h * w)
             wsink = weights.__dict__.get("_fm_sink")  # exists when the softmin sweep took LeadingFrames of the weights
         work = None
-        if chain and rep == 1 and indices is not None and bwd_flow.dim() == 5:
+        if chain and use_fit_chain and rep == 1 and indices is not None and bwd_flow.dim() == 5:
             pairs = bwd_flow.shape[0] * bwd_flow.shape[1]
             work = _derived(bwd_flow, "_fm_fit_work", (pairs, str(bwd_flow.device)),
                             lambda: torch.zeros((pairs * STAT_STRIDE + (pairs + 2) // 2 + 1,), dtype=torch.float64, device=bwd_flow.device))

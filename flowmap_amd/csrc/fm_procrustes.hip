@@ -173,18 +173,26 @@ __global__ void __launch_bounds__(256) procrustes_moments_kernel(ProcParams p, i
   // ---- fused tail (block-uniform branches) ----
   __shared__ int last_of_pair, last_of_all;
   __shared__ double chain_buf[2][64][16];
+  __shared__ double pair_stats[kStatStride];
   if (threadIdx.x == 0) {
     __threadfence();  // this block's sums are visible before the counter says so
     last_of_pair = atomicAdd(fc.counters + pair, 1) == (int)gridDim.x - 1;
     last_of_all = 0;
-    if (last_of_pair) {
+  }
+  __syncthreads();
+  if (last_of_pair) {  // block-uniform
+    // the pair's 16 sums in ONE round trip to L2 (16 lanes, one load each): read by one thread one after the other, each
+    // agent-scope load waited for the previous one — 28 of this kernel's 60 us at 149 pairs
+    if (threadIdx.x < kStatStride) {
       __threadfence();  // see the other blocks' sums
       double* st = p.stats + pair * kStatStride;
+      pair_stats[threadIdx.x] = __hip_atomic_load(st + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st[threadIdx.x] = 0.0;  // clean for the next launch
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
       double local[kStatStride];
-      for (int k = 0; k < kStatStride; ++k) {
-        local[k] = __hip_atomic_load(st + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        st[k] = 0.0;  // clean for the next launch
-      }
+      for (int k = 0; k < kStatStride; ++k) local[k] = pair_stats[k];
       fc.counters[pair] = 0;
       moments_finish(local, shift);
       pose_solve_one(local, fc.t_bwd + pair * 16, fc.t_fwd ? fc.t_fwd + pair * 16 : nullptr, fc.aux + pair * kAuxStride);
@@ -193,9 +201,70 @@ __global__ void __launch_bounds__(256) procrustes_moments_kernel(ProcParams p, i
       last_of_all = atomicAdd(fc.counters + pairs, 1) == pairs - 1;
       if (last_of_all) fc.counters[pairs] = 0;
     }
+    __syncthreads();
+  }
+  if (!last_of_all || fc.ext == nullptr) return;
+  __threadfence();  // see every pair's pose
+  for (int bb = 0; bb < fc.batch; ++bb)
+    pose_chain_by_wave0(fc.t_bwd + (size_t)bb * (p.frames - 1) * 16, p.frames - 1, fc.ext + (size_t)bb * p.frames * 16, chain_buf);
+}
+
+// The same work with ONE block of 1024 threads per pair, for index sets of a few thousand points (the reference's P = 1000):
+// the pair's sums never leave the block — wave sums (DPP) -> LDS -> 16 threads add the waves in fp64 -> thread 0 finishes,
+// solves and stores the pose — so there are no fp64 atomics, no per-pair counter and no agent-scope fence before the solve.
+// At 149 pairs the four-blocks-per-pair form above spent 28 of its 60 us in those 596 + 149 fences (each one writes the
+// XCD's L2 back): 63 -> see DESIGN.md §3.2.  What is left is one fence per pair before the global counter that elects the
+// block which chains the poses.  `counter`: one int, zero between launches.
+template <int SRC>
+__global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p, FitChain fc, int* counter) {
+  __shared__ double red[16 * kMomentCount];
+  __shared__ double pair_stats[kStatStride];
+  __shared__ double chain_buf[2][64][16];
+  __shared__ int last_of_all;
+  const size_t pair = blockIdx.x;
+  const int b = (int)(pair / (p.frames - 1));
+  const int i = (int)(pair % (p.frames - 1));
+  Mat3 kinv_e, kinv_l;
+  if (SRC == SRC_DEPTH) {
+    load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
+    load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
+  }
+  const CorrSrc src = pair_source<SRC>(p, pair, b, i);
+  float shift[3];
+  pair_shift<SRC>(p, src, kinv_l, shift);
+  float acc[kMomentCount];
+#pragma unroll
+  for (int k = 0; k < kMomentCount; ++k) acc[k] = 0.f;
+  for (long j = threadIdx.x; j < p.points; j += blockDim.x)
+    moments_add(corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j), shift, acc);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kMomentCount; ++k) {
+    const float sum = wave_sum_lane63(acc[k]);
+    if (lane == kWave - 1) red[wave * kMomentCount + k] = (double)sum;
+  }
+  if (threadIdx.x == 0) last_of_all = 0;
+  __syncthreads();
+  if (threadIdx.x < kStatStride) {
+    double tot = 0.0;
+    if (threadIdx.x < kMomentCount)
+      for (int w = 0; w < nwaves; ++w) tot += red[w * kMomentCount + threadIdx.x];
+    pair_stats[threadIdx.x] = tot;
   }
   __syncthreads();
-  if (!last_of_all || fc.ext == nullptr) return;
+  if (threadIdx.x == 0) {
+    double local[kStatStride];
+    for (int k = 0; k < kStatStride; ++k) local[k] = pair_stats[k];
+    moments_finish(local, shift);
+    pose_solve_one(local, fc.t_bwd + pair * 16, fc.t_fwd ? fc.t_fwd + pair * 16 : nullptr, fc.aux + pair * kAuxStride);
+    if (fc.ext != nullptr) {
+      __threadfence();  // the pose is visible before the counter says so
+      last_of_all = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+      if (last_of_all) *counter = 0;
+    }
+  }
+  __syncthreads();
+  if (!last_of_all) return;
   __threadfence();  // see every pair's pose
   for (int bb = 0; bb < fc.batch; ++bb)
     pose_chain_by_wave0(fc.t_bwd + (size_t)bb * (p.frames - 1) * 16, p.frames - 1, fc.ext + (size_t)bb * p.frames * 16, chain_buf);
@@ -1302,7 +1371,7 @@ int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* 
                             float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
                             double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
-  FM_CHECK_ARG(bwd_flow && weights && work && t_bwd && aux && ext && points >= 1 && batch >= 1 && frames >= 2);
+  FM_CHECK_ARG(bwd_flow && weights && work && t_bwd && aux && points >= 1 && batch >= 1 && frames >= 2);
   FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
   const int pairs = batch * (frames - 1);
   ProcParams p{};
@@ -1311,6 +1380,12 @@ int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* 
   p.weight_sens = weight_sensitivity;
   p.batch_repeat = 1;
   FitChain fc{reinterpret_cast<int*>(work + (size_t)pairs * kStatStride), t_bwd, t_fwd, aux, ext, batch};
+  if (points <= 4096) {  // one block per pair: the sums stay in the block (procrustes_fit_pair_kernel)
+    int* counter = fc.counters + pairs;  // the last of the workspace's ints
+    if (surfaces) hipLaunchKernelGGL((procrustes_fit_pair_kernel<SRC_SURF>), dim3(pairs), dim3(1024), 0, (hipStream_t)stream, p, fc, counter);
+    else hipLaunchKernelGGL((procrustes_fit_pair_kernel<SRC_DEPTH>), dim3(pairs), dim3(1024), 0, (hipStream_t)stream, p, fc, counter);
+    FM_LAUNCH_STATUS();
+  }
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
   if (surfaces) hipLaunchKernelGGL((procrustes_moments_kernel<SRC_SURF>), grid, dim3(256), 0, (hipStream_t)stream, p, iters, fc);
