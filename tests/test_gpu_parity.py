@@ -442,3 +442,15 @@ def test_noncontiguous_views_are_copied_loudly():
 
 def test_depth_adam_update_inside_the_flow_pass_with_the_softmin_sweep():
     cases.case_in_pass_adam(DEV, steps=60, lr=3e-4, softmin=True)
+
+
+def test_one_launch_fit_agrees_with_the_three_launch_form_under_stress():
+    """fm_procrustes_fit_chain (one block per pair, last-block election for the pose chain) against fm_procrustes_fit +
+    fm_pose_chain_fwd over 1 200 back-to-back launches on changing inputs; the persistent workspace stays clean."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("fit_stress", Path(__file__).resolve().parent.parent / "tools" / "fit_stress.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(300, dev=str(DEV), verbose=False) < 1e-5
