@@ -628,7 +628,7 @@ __global__ void procrustes_finish_solve_dense_kernel(ProcParams p, int pairs, fl
 constexpr int kDenseConstStride = 40;
 // ... and dL/dK⁻¹ of the pair's two frames, which is linear in the statistics of the forward pass (dense_kinv_grads): added to
 // kinv_acc here, one thread per pair — the per-pixel kernels carry no sums for it.
-__global__ void procrustes_dense_consts_kernel(ProcParams p, const double* aux, const double* stats, int pairs, double* consts) {
+__global__ void __launch_bounds__(64) procrustes_dense_consts_kernel(ProcParams p, const double* aux, const double* stats, int pairs, double* consts) {
   const int pair = blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= pairs) return;
   const int b = pair / (p.frames - 1), i = pair % (p.frames - 1);
@@ -1199,7 +1199,7 @@ __global__ void __launch_bounds__(kChainThreads) pose_chain_bwd_kernel(const flo
 //   fwd[i] = inv(E_{i+1}) · E_i       bwd[i] = inv(E_i) · E_{i+1}
 // and their backward  dE = −A⁻ᵀ·G·A⁻ᵀ  /  Aᵀ-products.  One thread per pair.
 // ---------------------------------------------------------------------------------
-__global__ void relative_pose_fwd_kernel(const float* ext, int batch, int frames, float* fwd, float* bwd) {
+__global__ void __launch_bounds__(64) relative_pose_fwd_kernel(const float* ext, int batch, int frames, float* fwd, float* bwd) {
   const int pr = blockIdx.x * blockDim.x + threadIdx.x;
   const int pairs = batch * (frames - 1);
   if (pr >= pairs) return;
@@ -1208,7 +1208,7 @@ __global__ void relative_pose_fwd_kernel(const float* ext, int batch, int frames
 }
 
 // g_ext must be zero-initialised; adjacent pairs touch the same frame -> atomics.
-__global__ void relative_pose_bwd_kernel(const float* ext, const float* g_fwd, const float* g_bwd, int batch, int frames,
+__global__ void __launch_bounds__(64) relative_pose_bwd_kernel(const float* ext, const float* g_fwd, const float* g_bwd, int batch, int frames,
                                          float* g_ext) {
   const int pr = blockIdx.x * blockDim.x + threadIdx.x;
   const int pairs = batch * (frames - 1);
@@ -1225,14 +1225,14 @@ __global__ void relative_pose_bwd_kernel(const float* ext, const float* g_fwd, c
 }
 
 // All-pairs relative poses inside a track segment: rel (B,f,f,4,4), one thread each.
-__global__ void allpairs_pose_fwd_kernel(const float* ext, int batch, int f, float* rel) {
+__global__ void __launch_bounds__(64) allpairs_pose_fwd_kernel(const float* ext, int batch, int f, float* rel) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch * f * f) return;
   const int b = i / (f * f), r = i % (f * f);
   allpairs_pose_fwd_one(ext + (size_t)b * f * 16, r / f, r % f, rel + (size_t)i * 16);
 }
 
-__global__ void allpairs_pose_bwd_kernel(const float* ext, const float* g_rel, int batch, int f, float* g_ext) {
+__global__ void __launch_bounds__(64) allpairs_pose_bwd_kernel(const float* ext, const float* g_rel, int batch, int f, float* g_ext) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch * f) return;
   const int b = i / f;

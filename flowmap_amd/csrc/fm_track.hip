@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const fl
 }
 
 // Per frame: the target-role constants (au, av, c) of track_target (fm_pose.h).
-__global__ void track_targets_kernel(const float* ext_inv, const float* k, int frames, float* tgt) {
+__global__ void __launch_bounds__(64) track_targets_kernel(const float* ext_inv, const float* k, int frames, float* tgt) {
   const int fr = blockIdx.x * blockDim.x + threadIdx.x;
   if (fr < frames) track_target(ext_inv + (size_t)fr * 16, k + (size_t)fr * 9, tgt + (size_t)fr * kTrackTgt);
 }
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(256) depth_gather_kgrad_kernel(const float* ve
 }
 
 // dL/dE and dL/dK per frame from the two accumulators.
-__global__ void track_finalize_bwd_kernel(const double* acc, const double* acc2, const float* scale, const float* upstream,
+__global__ void __launch_bounds__(64) track_finalize_bwd_kernel(const double* acc, const double* acc2, const float* scale, const float* upstream,
                                           const float* ext_inv, const float* k, const float* kinv, int frames, float* g_ext,
                                           float* g_k) {
   const int fr = blockIdx.x * blockDim.x + threadIdx.x;
@@ -577,7 +577,7 @@ __global__ void track_finalize_bwd_kernel(const double* acc, const double* acc2,
                     k + (size_t)fr * 9, kinv + (size_t)fr * 9, g_ext + (size_t)fr * 16, g_k + (size_t)fr * 9);
 }
 
-__global__ void inv4_kernel(const float* m, int count, float* out) {
+__global__ void __launch_bounds__(64) inv4_kernel(const float* m, int count, float* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   double a[16], o[16];
