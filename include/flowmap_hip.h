@@ -131,8 +131,10 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
                       float weight_sensitivity, const int64_t* indices, long points, int batch, int batch_repeat, int frames,
                       int height, int width, double* stats, float* t_bwd, float* t_fwd, double* aux, void* stream);
 
-/* fm_procrustes_fit (batch_repeat 1) AND fm_pose_chain_fwd in ONE launch: the last workgroup of a pair turns the
- * pair's sums into its pose, the last pair chains the poses into ext (B,F,4,4) (projection.py:187-252 entire).
+/* fm_procrustes_fit (batch_repeat 1) AND fm_pose_chain_fwd in ONE launch (projection.py:187-252 entire): up to 4096
+ * points one workgroup of 1024 threads per pair keeps the pair's sums in LDS, solves the pose, and the last workgroup to
+ * finish chains the poses into ext (B,F,4,4); larger index sets use four workgroups per pair and fp64 atomics, the last of a
+ * pair solving.  ext may be NULL (poses only).
  * work: persistent workspace of B·(F-1)·FM_STAT_STRIDE doubles followed by B·(F-1)+1 ints, ZERO on entry and left
  * zero (self-cleaning: zero it once, when it is allocated; one launch at a time per workspace). */
 int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
