@@ -78,7 +78,9 @@ __device__ __forceinline__ void pair_shift(const ProcParams& p, const CorrSrc& s
 
 // get_extrinsics for one batch element by ONE wave of a block whose 256 threads all call this (the barriers are
 // block-wide): chunk products, Hillis-Steele scan over 64 chunks in LDS, re-walk (as pose_chain_fwd_kernel).
-__device__ __forceinline__ void pose_chain_by_wave0(const float* r, int steps, float* e, double (*buf)[64][16]) {
+// LDS layout [matrix entry][lane]: consecutive lanes touch consecutive doubles (with [lane][entry] every lane of a
+// wave hit the same bank: the 128-byte stride of a 4x4 double matrix).
+__device__ __forceinline__ void pose_chain_by_wave0(const float* r, int steps, float* e, double (*buf)[16][64]) {
   const int t = threadIdx.x;
   const bool on = t < 64;
   const int chunk = (steps + 63) / 64;
@@ -91,22 +93,22 @@ __device__ __forceinline__ void pose_chain_by_wave0(const float* r, int steps, f
       mat4_mul(prod, m, nxt);
       for (int k = 0; k < 16; ++k) prod[k] = nxt[k];
     }
-    for (int k = 0; k < 16; ++k) buf[0][t][k] = prod[k];
+    for (int k = 0; k < 16; ++k) buf[0][k][t] = prod[k];
   }
   __syncthreads();
   int cur = 0;
   for (int off = 1; off < 64; off <<= 1) {
     if (on) {
       double mine[16], out[16];
-      for (int k = 0; k < 16; ++k) mine[k] = buf[cur][t][k];
+      for (int k = 0; k < 16; ++k) mine[k] = buf[cur][k][t];
       if (t >= off) {
         double left[16];
-        for (int k = 0; k < 16; ++k) left[k] = buf[cur][t - off][k];
+        for (int k = 0; k < 16; ++k) left[k] = buf[cur][k][t - off];
         mat4_mul(left, mine, out);
       } else {
         for (int k = 0; k < 16; ++k) out[k] = mine[k];
       }
-      for (int k = 0; k < 16; ++k) buf[cur ^ 1][t][k] = out[k];
+      for (int k = 0; k < 16; ++k) buf[cur ^ 1][k][t] = out[k];
     }
     __syncthreads();
     cur ^= 1;
@@ -114,7 +116,7 @@ __device__ __forceinline__ void pose_chain_by_wave0(const float* r, int steps, f
   if (on) {
     double run[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     if (t > 0) {
-      for (int k = 0; k < 16; ++k) run[k] = buf[cur][t - 1][k];
+      for (int k = 0; k < 16; ++k) run[k] = buf[cur][k][t - 1];
     } else {
       for (int k = 0; k < 16; ++k) e[k] = (float)run[k];  // E_0 = I
     }
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(256) procrustes_moments_kernel(ProcParams p, i
   if (fc.counters == nullptr) return;
   // ---- fused tail (block-uniform branches) ----
   __shared__ int last_of_pair, last_of_all;
-  __shared__ double chain_buf[2][64][16];
+  __shared__ double chain_buf[2][16][64];
   __shared__ double pair_stats[kStatStride];
   if (threadIdx.x == 0) {
     __threadfence();  // this block's sums are visible before the counter says so
@@ -219,7 +221,7 @@ template <int SRC>
 __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p, FitChain fc, int* counter) {
   __shared__ double red[16 * kMomentCount];
   __shared__ double pair_stats[kStatStride];
-  __shared__ double chain_buf[2][64][16];
+  __shared__ double chain_buf[2][16][64];
   __shared__ int last_of_all;
   const size_t pair = blockIdx.x;
   const int b = (int)(pair / (p.frames - 1));
@@ -1074,7 +1076,7 @@ __device__ __forceinline__ void load16(const float* p, double* o) {
 }
 
 __global__ void __launch_bounds__(kChainThreads) pose_chain_fwd_kernel(const float* rel, int batch, int steps, float* ext) {
-  __shared__ double buf[2][kChainThreads][16];
+  __shared__ double buf[2][16][kChainThreads];  // [entry][thread]: bank-conflict-free
   const int b = blockIdx.x, t = threadIdx.x;
   const float* r = rel + (size_t)b * steps * 16;
   float* e = ext + (size_t)b * (steps + 1) * 16;
@@ -1089,31 +1091,31 @@ __global__ void __launch_bounds__(kChainThreads) pose_chain_fwd_kernel(const flo
     for (int k = 0; k < 16; ++k) prod[k] = nxt[k];
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) buf[0][t][k] = prod[k];
+  for (int k = 0; k < 16; ++k) buf[0][k][t] = prod[k];
   __syncthreads();
   int cur = 0;
   for (int off = 1; off < kChainThreads; off <<= 1) {  // inclusive scan: buf[t] = C_0 · … · C_t
     double mine[16], out[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) mine[k] = buf[cur][t][k];
+    for (int k = 0; k < 16; ++k) mine[k] = buf[cur][k][t];
     if (t >= off) {
       double left[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) left[k] = buf[cur][t - off][k];
+      for (int k = 0; k < 16; ++k) left[k] = buf[cur][k][t - off];
       mat4_mul(left, mine, out);
     } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) out[k] = mine[k];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) buf[cur ^ 1][t][k] = out[k];
+    for (int k = 0; k < 16; ++k) buf[cur ^ 1][k][t] = out[k];
     __syncthreads();
     cur ^= 1;
   }
   double run[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   if (t > 0) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) run[k] = buf[cur][t - 1][k];  // exclusive prefix
+    for (int k = 0; k < 16; ++k) run[k] = buf[cur][k][t - 1];  // exclusive prefix
   } else {
 #pragma unroll
     for (int k = 0; k < 16; ++k) e[k] = (float)run[k];  // E_0 = I
@@ -1136,7 +1138,7 @@ __global__ void __launch_bounds__(kChainThreads) pose_chain_fwd_kernel(const flo
 // dL/dT_s = E_sᵀ·carry_{s+1}.
 __global__ void __launch_bounds__(kChainThreads) pose_chain_bwd_kernel(const float* rel, const float* ext, const float* g_ext,
                                                                      int batch, int steps, float* g_rel) {
-  __shared__ double buf[2][kChainThreads][16];
+  __shared__ double buf[2][16][kChainThreads];  // [entry][thread]: bank-conflict-free
   (void)rel;
   const int b = blockIdx.x, t = threadIdx.x;
   const float* e = ext + (size_t)b * (steps + 1) * 16;
@@ -1158,22 +1160,22 @@ __global__ void __launch_bounds__(kChainThreads) pose_chain_bwd_kernel(const flo
     for (int k = 0; k < 16; ++k) sum[k] += a[k];
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) buf[0][t][k] = sum[k];
+  for (int k = 0; k < 16; ++k) buf[0][k][t] = sum[k];
   __syncthreads();
   int cur = 0;
   for (int off = 1; off < kChainThreads; off <<= 1) {  // inclusive SUFFIX sum over chunks
     double v[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = buf[cur][t][k] + (t + off < kChainThreads ? buf[cur][t + off][k] : 0.0);
+    for (int k = 0; k < 16; ++k) v[k] = buf[cur][k][t] + (t + off < kChainThreads ? buf[cur][k][t + off] : 0.0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) buf[cur ^ 1][t][k] = v[k];
+    for (int k = 0; k < 16; ++k) buf[cur ^ 1][k][t] = v[k];
     __syncthreads();
     cur ^= 1;
   }
   // suffix[j] for j in this chunk, walking from the chunk's end: start with the sum of all later chunks
   double suf[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) suf[k] = (t + 1 < kChainThreads) ? buf[cur][t + 1][k] : 0.0;
+  for (int k = 0; k < 16; ++k) suf[k] = (t + 1 < kChainThreads) ? buf[cur][k][t + 1] : 0.0;
   for (int j = hi - 1; j >= lo; --j) {
     double g[16], ej[16], a[16];
     load16(ge + (size_t)j * 16, g);
