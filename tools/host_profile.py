@@ -19,7 +19,7 @@ from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegresse
 dev = torch.device("cuda", 0)
 f, h, w = 16, 720, 1280
 flowmap_amd.set_lazy_surfaces(True)
-depth, wlogit, flows = bench.make_inputs(f, h, w, dev, seed=1)
+depth, wlogit, flows, _ = bench.make_iid(f, h, w, dev, 1)
 model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", 0.85),
                        ExtrinsicsProcrustesCfg("procrustes", 1000, False)), num_frames=f, image_shape=(h, w)).to(dev)
 model.backbone.depth.data = depth
