@@ -55,7 +55,8 @@ SIGNATURES = {
     "fm_procrustes_scatter": [P] * 5 + [F, P, L, I, I, I, I, I] + [P] * 8 + [P],
     "fm_procrustes_dense_tiles": [I, I, P],
     "fm_procrustes_dense_plan": [P, I, I, I, I, P, P, P, P],
-    "fm_procrustes_scatter_dense": [P, P, P, P, F, I, I, I, I, P, P, P, P, P, P, P, P, P, P],
+    "fm_procrustes_scatter_dense": [P, P, P, P, F, I, I, I, I, P, P, P, P, P, P, P, P],
+    "fm_pose_solve_bwd_kinv": [P, P, P, P, P, I, I, P, P, P],
     "fm_sparse_store": [P, P, L, I, L, P, P],
     "fm_procrustes_scatter_plan": [P, P, L, I, I, I, I, P, P, P],
     "fm_pose_chain_fwd": [P, I, I, P, P],

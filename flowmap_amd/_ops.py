@@ -32,7 +32,7 @@ MAPPING_KINDS = {"huber": 0, "l1": 1, "l2": 2}
 
 FLOW_ACC_STRIDE = 20
 STAT_STRIDE = 16
-AUX_STRIDE = 32
+AUX_STRIDE = 40
 PAIR_GRAD_STRIDE = 20
 DENSE_CONST_STRIDE = 40  # FM_DENSE_CONST_STRIDE
 TRACK_TILE = 6  # FM_TRACK_TILE (include/flowmap_hip.h; tests/test_abi.py checks they agree)

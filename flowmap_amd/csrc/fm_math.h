@@ -1167,9 +1167,23 @@ FM_HD void dense_kinv_grads(const double* st, const double* pg, const double* ax
     }
   for (int a = 0; a < 3; ++a)
     for (int d = 0; d < 3; ++d) {  // (D·Kᵀ)[a][d] = Σ_c D[a][c]·K[d][c]
-      out_e[a * 3 + d] = de[a * 3 + 0] * k_e[d * 3 + 0] + de[a * 3 + 1] * k_e[d * 3 + 1] + de[a * 3 + 2] * k_e[d * 3 + 2];
-      out_l[a * 3 + d] = dl[a * 3 + 0] * k_l[d * 3 + 0] + dl[a * 3 + 1] * k_l[d * 3 + 1] + dl[a * 3 + 2] * k_l[d * 3 + 2];
+      if (out_e) out_e[a * 3 + d] = de[a * 3 + 0] * k_e[d * 3 + 0] + de[a * 3 + 1] * k_e[d * 3 + 1] + de[a * 3 + 2] * k_e[d * 3 + 2];
+      if (out_l) out_l[a * 3 + d] = dl[a * 3 + 0] * k_l[d * 3 + 0] + dl[a * 3 + 1] * k_l[d * 3 + 1] + dl[a * 3 + 2] * k_l[d * 3 + 2];
     }
+}
+
+// The same from a pair's row of `aux` alone (pose_solve_one keeps Σw, p̄, q̄ and M there): what the sparse fit's backward and
+// fm_pose_solve_bwd_kinv use.  out_e / out_l may be null (one role only; k of the absent role is not read).
+FM_HD void pair_kinv_grads(const double* pg, const double* ax, const double* k_e, const double* k_l, double* out_e, double* out_l) {
+  double st[16];
+  const double w = ax[27];
+  st[0] = w;
+  for (int a = 0; a < 3; ++a) {
+    st[1 + a] = ax[21 + a] * (w + 1e-8);  // p̄ = Σw·p / (Σw + 1e-8)
+    st[4 + a] = ax[24 + a] * (w + 1e-8);
+  }
+  for (int k = 0; k < 9; ++k) st[7 + k] = ax[28 + k];
+  dense_kinv_grads(st, pg, ax, out_e ? k_e : k_l, out_l ? k_l : k_e, out_e, out_l);
 }
 
 // t (needs only g: the earlier-role scatter does not sample the earlier frame)

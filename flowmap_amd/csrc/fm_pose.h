@@ -10,7 +10,7 @@ namespace fm {
 
 constexpr int kFlowAccStride = 20;   // kFlowAcc (13) padded; keeps the C-ABI workspace size
 constexpr int kStatStride = 16;      // [0]=Σw [1..3]=Σw·p [4..6]=Σw·q [7..15]=M
-constexpr int kAuxStride = 32;       // U(9) V(9) sig(3) pbar(3) qbar(3) wsum(1)
+constexpr int kAuxStride = 40;       // U(9) V(9) sig(3) pbar(3) qbar(3) wsum(1) M(9): [28..36]
 constexpr int kPairGradStride = 20;  // gM(9) gqbar(3) gpbar(3) dbar(1) inv_wsum(1)
 
 // ---- align_rigid, steps 1,4,5 (procrustes.py:23-25,35-51) -----------------------------
@@ -52,6 +52,7 @@ FM_HD void pose_solve_one(const double* st, float* tb, float* tf, double* ax) {
     ax[24 + a] = qbar[a];
   }
   ax[27] = st[0];
+  for (int k = 0; k < 9; ++k) ax[28 + k] = st[7 + k];  // M: the backward derives dL/dK⁻¹ from the statistics (pair_kinv_grad)
 }
 
 // Backward of pose_solve_one.  g_tb / g_tf: dL/dT_bwd, dL/dT_fwd (4x4 row-major, bottom

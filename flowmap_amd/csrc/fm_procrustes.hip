@@ -628,28 +628,17 @@ __global__ void procrustes_finish_solve_dense_kernel(ProcParams p, int pairs, fl
 // Per-pair constants of the dense backward, once per pair (fp64): consts (pairs, kDenseConstStride)
 // = DenseBwd (21 floats' worth), K_e (9), K_l (9).
 constexpr int kDenseConstStride = 40;
-// ... and dL/dK⁻¹ of the pair's two frames, which is linear in the statistics of the forward pass (dense_kinv_grads): added to
-// kinv_acc here, one thread per pair — the per-pixel kernels carry no sums for it.
-__global__ void __launch_bounds__(64) procrustes_dense_consts_kernel(ProcParams p, const double* aux, const double* stats, int pairs, double* consts) {
+// (dL/dK⁻¹ of the pair's two frames is linear in the statistics of the forward pass: fm_pose_solve_bwd_kinv has written it.)
+__global__ void __launch_bounds__(64) procrustes_dense_consts_kernel(ProcParams p, const double* aux, int pairs, double* consts) {
   const int pair = blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= pairs) return;
   const int b = pair / (p.frames - 1), i = pair % (p.frames - 1);
   DenseBwd c;
   double* o = consts + (size_t)pair * kDenseConstStride;
-  const double* pg = p.pair_grad + (size_t)pair * kPairGradStride;
-  const double* ax = aux + (size_t)pair * kAuxStride;
-  dense_bwd_consts(pg, ax, p.kinv + ((size_t)b * p.frames + i) * 9, p.kinv + ((size_t)b * p.frames + i + 1) * 9, c, o + 21, o + 30);
+  dense_bwd_consts(p.pair_grad + (size_t)pair * kPairGradStride, aux + (size_t)pair * kAuxStride, p.kinv + ((size_t)b * p.frames + i) * 9,
+                   p.kinv + ((size_t)b * p.frames + i + 1) * 9, c, o + 21, o + 30);
   const float* f = c.bm;
   for (int k = 0; k < 21; ++k) o[k] = (double)f[k];  // bm, a0, b0, gbar, hbar are contiguous
-  if (p.kinv_acc) {
-    double ge[9], gl[9];
-    dense_kinv_grads(stats + (size_t)pair * kStatStride, pg, ax, o + 21, o + 30, ge, gl);
-    double* acc = p.kinv_acc + ((size_t)b * p.frames + i) * 9;  // frame i is the later frame of pair i-1 as well: atomics
-    for (int k = 0; k < 9; ++k) {
-      if (ge[k] != 0.0) atomicAdd(acc + k, ge[k]);
-      if (gl[k] != 0.0) atomicAdd(acc + 9 + k, gl[k]);
-    }
-  }
 }
 
 __device__ __forceinline__ DenseBwd dense_load_consts(const double* consts, size_t pair) {
@@ -950,6 +939,40 @@ __global__ void pose_solve_bwd_kernel(const float* g_t_bwd, const float* g_t_fwd
                      t_bwd + (size_t)pr * 16, aux + (size_t)pr * kAuxStride, pair_grad + (size_t)pr * kPairGradStride);
 }
 
+// pose_solve_bwd_one for every pair AND dL/dK⁻¹ of every frame, which is linear in the statistics the forward pass kept in
+// `aux` (pair_kinv_grads): one thread per (batch entry, frame) writes its pair's row of pair_grad and
+//   kinv_acc[b, f] = earlier role of pair (b, f)  +  later role of pair (b, f−1)
+// (the neighbour's pair gradient is recomputed, 3 us of fp64, so that no value has two writers: no atomics, no zero fill,
+// and the per-point pass carries no sums for K at all).
+__global__ void __launch_bounds__(64) pose_solve_bwd_kinv_kernel(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux,
+                                                                const float* kinv, int batch, int frames, double* pair_grad, double* kinv_acc) {
+  const int bf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bf >= batch * frames) return;
+  const int b = bf / frames, f = bf % frames;
+  double kd[9], kf[9], acc[9];
+  for (int k = 0; k < 9; ++k) {
+    kd[k] = kinv[(size_t)bf * 9 + k];
+    acc[k] = 0.0;
+  }
+  inv3d(kd, kf);  // K of this frame
+  if (f < frames - 1) {  // this frame is the EARLIER frame of pair (b, f)
+    const size_t pr = (size_t)b * (frames - 1) + f;
+    double* pg = pair_grad + pr * kPairGradStride;
+    pose_solve_bwd_one(g_t_bwd ? g_t_bwd + pr * 16 : nullptr, g_t_fwd ? g_t_fwd + pr * 16 : nullptr, t_bwd + pr * 16, aux + pr * kAuxStride, pg);
+    double ge[9];
+    pair_kinv_grads(pg, aux + pr * kAuxStride, kf, nullptr, ge, nullptr);
+    for (int k = 0; k < 9; ++k) acc[k] += ge[k];
+  }
+  if (f > 0) {  // ... and the LATER frame of pair (b, f−1)
+    const size_t pr = (size_t)b * (frames - 1) + f - 1;
+    double pg[kPairGradStride], gl[9];
+    pose_solve_bwd_one(g_t_bwd ? g_t_bwd + pr * 16 : nullptr, g_t_fwd ? g_t_fwd + pr * 16 : nullptr, t_bwd + pr * 16, aux + pr * kAuxStride, pg);
+    pair_kinv_grads(pg, aux + pr * kAuxStride, nullptr, kf, nullptr, gl);
+    for (int k = 0; k < 9; ++k) acc[k] += gl[k];
+  }
+  for (int k = 0; k < 9; ++k) kinv_acc[(size_t)bf * 9 + k] = acc[k];
+}
+
 // Per-point backward + scatter.  grid: (chunks, B*(F-1)).
 template <int SRC>
 __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, const double* aux, int iters) {
@@ -1004,7 +1027,8 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
       float* o = p.point_grads + (pair * (size_t)p.points + (size_t)j) * 6;
       o[0] = gq[0], o[1] = gq[1], o[2] = gq[2], o[3] = gp[0], o[4] = gp[1], o[5] = gp[2];
     }
-    if (SRC == SRC_DEPTH) {
+    // (with kinv_acc == NULL — dL/dK⁻¹ comes from fm_pose_solve_bwd_kinv — and a planned scatter there is nothing left to do per tap)
+    if (SRC == SRC_DEPTH && (p.kinv_acc != nullptr || (p.grad_depth && !planned))) {
       const int row = c.idx / p.width, col = c.idx - row * p.width;
       const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
       if (p.grad_depth && !planned) atomicAdd(p.grad_depth + fl * n + c.idx, gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2]);
@@ -1029,7 +1053,7 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
 #pragma unroll
           for (int d = 0; d < 3; ++d) acc[9 + a * 3 + d] += gq[a] * zt[d];
       }
-    } else {
+    } else if (SRC != SRC_DEPTH) {
       if (p.grad_surfaces) {
         float* gl = p.grad_surfaces + (fl * n + c.idx) * 3;
         atomicAdd(gl + 0, gp[0]);
@@ -1409,6 +1433,15 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
   FM_LAUNCH_STATUS();
 }
 
+int fm_pose_solve_bwd_kinv(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux, const float* kinv, int batch,
+                           int frames, double* pair_grad, double* kinv_acc, void* stream) {
+  FM_CHECK_ARG(t_bwd && aux && kinv && pair_grad && kinv_acc && batch >= 1 && frames >= 2);
+  const int n = batch * frames;
+  hipLaunchKernelGGL(pose_solve_bwd_kinv_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, g_t_bwd, g_t_fwd, t_bwd, aux, kinv, batch,
+                     frames, pair_grad, kinv_acc);
+  FM_LAUNCH_STATUS();
+}
+
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
                           int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,
@@ -1463,10 +1496,9 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
 
 int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights,
                                 float weight_sensitivity, int batch, int frames, int height, int width, const double* aux,
-                                const double* stats, const double* pair_grad, float* grad_depth, float* grad_weights, double* kinv_acc,
-                                const int64_t* first, const uint32_t* list, double* consts, void* stream) {
+                                const double* pair_grad, float* grad_depth, float* grad_weights, const int64_t* first, const uint32_t* list,
+                                double* consts, void* stream) {
   FM_CHECK_ARG(depth && kinv && bwd_flow && weights && aux && pair_grad && consts && batch >= 1 && frames >= 2);
-  FM_CHECK_ARG(!kinv_acc || stats);
   FM_CHECK_ARG(height >= 1 && width >= 1 && height <= 65535 && width <= 65535 && (long)height * width < (1L << 30));
   FM_CHECK_ARG(!grad_depth || (first && list));
   const int pairs = batch * (frames - 1);
@@ -1474,10 +1506,10 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
   hipStream_t st = (hipStream_t)stream;
   ProcParams p{};
   p.depth = depth; p.kinv = kinv; p.bwd_flow = bwd_flow; p.weights = weights; p.pair_grad = pair_grad; p.grad_depth = grad_depth;
-  p.grad_weights = grad_weights; p.kinv_acc = kinv_acc; p.frames = frames; p.height = height; p.width = width;
+  p.grad_weights = grad_weights; p.frames = frames; p.height = height; p.width = width;
   p.points = (long)height * width; p.weight_sens = weight_sensitivity; p.batch_repeat = 1;
   const unsigned total = (unsigned)dense_blocks(height, width, pairs);
-  hipLaunchKernelGGL(procrustes_dense_consts_kernel, dim3((pairs + 63) / 64), dim3(64), 0, st, p, aux, stats, pairs, consts);
+  hipLaunchKernelGGL(procrustes_dense_consts_kernel, dim3((pairs + 63) / 64), dim3(64), 0, st, p, aux, pairs, consts);
   if (grad_depth || grad_weights)
     hipLaunchKernelGGL(procrustes_dense_bwd_later_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, consts, total);
   if (grad_depth) hipLaunchKernelGGL(procrustes_dense_bwd_taps_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, consts, first, list, total);

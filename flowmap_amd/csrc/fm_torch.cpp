@@ -46,7 +46,7 @@ using OptTensor = std::optional<Tensor>;
 #define FM_API_LIST(X)                                                                                                                    \
   X(fm_flow_loss_fused) X(fm_flow_loss_fused_adam) X(fm_adam_step_elements) X(fm_flow_loss_finalize) X(fm_scale_if_needed) X(fm_intrinsics_inverse) X(fm_intrinsics_inverse_bwd)              \
   X(fm_focal_intrinsics_fwd) X(fm_focal_intrinsics_bwd) X(fm_pose_chain_fwd) X(fm_pose_chain_bwd) X(fm_relative_pose_fwd)                  \
-  X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense)                \
+  X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_pose_solve_bwd_kinv) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense)                \
   X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_loss_fused_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
   X(fm_adam_step_capturable) X(fm_softmin_score_fwd) X(fm_softmin_score_bwd) X(fm_softmin_blend_fwd) X(fm_softmin_blend_bwd)         \
   X(fm_random_subset) X(fm_random_subset_stateful)
@@ -431,7 +431,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                 (float)weight_sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(work), ptr(t_bwd), ptr(t_fwd),
                 ptr<double>(aux), ptr(ext), scope.stream);
       } else {
-        stats = at::empty({pairs, FM_STAT_STRIDE}, weights.options().dtype(at::kDouble));  // kept: the dense backward derives dL/dK⁻¹ from it
+        stats = at::empty({pairs, FM_STAT_STRIDE}, weights.options().dtype(at::kDouble));
         FM_CALL(fm_procrustes_fit, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights), (float)weight_sens,
                 ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(stats), ptr(t_bwd), ptr(t_fwd),
                 ptr<double>(aux), scope.stream);
@@ -440,7 +440,6 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     ctx->save_for_backward({from_depth ? depth : surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux, opt(plan_pixels), opt(plan_first),
                             opt(plan_vectors), opt(plan_weights), opt(dense_first), opt(dense_list), ext});
     ctx->saved_data["dims"] = std::vector<int64_t>{b, f, h, w, points, rep, from_depth ? 1 : 0};
-    ctx->saved_data["stats"] = stats;
     ctx->saved_data["weight_sens"] = weight_sens;
     if (sink) ctx->saved_data["sink"] = sink;
     if (wsink) ctx->saved_data["wsink"] = wsink;
@@ -513,23 +512,31 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
         arena_used = true;
       } else g_w = at::zeros_like(weights);
     }
-    Tensor kinv_acc = need_k ? at::empty({b * f, 9}, weights.options().dtype(at::kDouble)) : Tensor();  // zeroed by fm_pose_solve_bwd
+    Tensor kinv_acc = need_k ? at::empty({b * f, 9}, weights.options().dtype(at::kDouble)) : Tensor();
     Tensor point_grads = (planned && g_src.defined()) ? at::empty({pairs * points, 2, 3}, weights.options()) : Tensor();
+    // dL/dK⁻¹ is linear in the statistics the forward pass left in aux: written by the pose-solve backward itself, and the per-point
+    // passes carry no sums for it (repeated batches — the softmin sweep's candidates — keep the per-point accumulation)
+    const bool k_closed_form = need_k && from_depth && rep == 1;
     {
       DeviceScope scope(dev);
-      FM_CALL(fm_pose_solve_bwd, ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr<double>(aux), (int)pairs, ptr<double>(pair_grad), ptr<double>(kinv_acc),
-              kinv_acc.defined() ? (long)kinv_acc.numel() : 0L, scope.stream);
+      if (k_closed_form) {
+        FM_CALL(fm_pose_solve_bwd_kinv, ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr<double>(aux), ptr(kinv), (int)b, (int)f, ptr<double>(pair_grad),
+                ptr<double>(kinv_acc), scope.stream);
+      } else {  // (kinv_acc is zeroed by the same launch)
+        FM_CALL(fm_pose_solve_bwd, ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr<double>(aux), (int)pairs, ptr<double>(pair_grad), ptr<double>(kinv_acc),
+                kinv_acc.defined() ? (long)kinv_acc.numel() : 0L, scope.stream);
+      }
+      double* per_point_k = k_closed_form ? nullptr : ptr<double>(kinv_acc);
       if (dense) {  // every pixel a correspondence: tiled, planned, no atomics
+        TORCH_CHECK(!need_k || k_closed_form, "flowmap_amd: the dense Procrustes backward derives dL/dK from the forward statistics (no batch repeat)");
         Tensor consts = at::empty({pairs, FM_DENSE_CONST_STRIDE}, weights.options().dtype(at::kDouble));
-        const Tensor stats = ctx->saved_data["stats"].isTensor() ? ctx->saved_data["stats"].toTensor() : Tensor();
-        TORCH_CHECK(stats.defined(), "flowmap_amd: the dense Procrustes backward needs the statistics of its forward pass");
         FM_CALL(fm_procrustes_scatter_dense, ptr(src), ptr(kinv), ptr(bwd_flow), ptr(weights), sens, (int)b, (int)f, (int)h, (int)w,
-                ptr<double>(aux), ptr<double>(stats), ptr<double>(pair_grad), ptr(g_src), ptr(g_w), ptr<double>(kinv_acc), ptr<int64_t>(dense_first),
-                ptr<uint32_t>(dense_list), ptr<double>(consts), scope.stream);
+                ptr<double>(aux), ptr<double>(pair_grad), ptr(g_src), ptr(g_w), ptr<int64_t>(dense_first), ptr<uint32_t>(dense_list),
+                ptr<double>(consts), scope.stream);
       } else {
         FM_CALL(fm_procrustes_scatter, from_depth ? ptr(src) : nullptr, ptr(kinv), from_depth ? nullptr : ptr(src), ptr(bwd_flow), ptr(weights),
                 sens, ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(aux), ptr<double>(pair_grad),
-                from_depth ? ptr(g_src) : nullptr, from_depth ? nullptr : ptr(g_src), ptr(g_w), ptr<double>(kinv_acc), ptr(point_grads),
+                from_depth ? ptr(g_src) : nullptr, from_depth ? nullptr : ptr(g_src), ptr(g_w), per_point_k, ptr(point_grads),
                 nullptr, scope.stream);
       }
       // dL/dK = −K⁻ᵀ·dK⁻¹·K⁻ᵀ, added to the flow loss's own dL/dK when that was parked here (one gradient for autograd,

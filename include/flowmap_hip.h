@@ -35,7 +35,7 @@ extern "C" {
 
 #define FM_FLOW_ACC_STRIDE 20  /* doubles per (frame, direction) in `acc` */
 #define FM_STAT_STRIDE 16      /* doubles per pair in `stats` */
-#define FM_AUX_STRIDE 32       /* doubles per pair in `aux` */
+#define FM_AUX_STRIDE 40       /* doubles per pair in `aux` */
 #define FM_PAIR_GRAD_STRIDE 20 /* doubles per pair in `pair_grad` */
 
 /* ---------------------------------------------------------------------------------
@@ -152,6 +152,12 @@ int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, do
  * next on the stream, accumulates into. */
 int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux, int pairs,
                       double* pair_grad, double* clear, long clear_count, void* stream);
+/* fm_pose_solve_bwd for the B·(F-1) pairs of a video batch AND dL/dK⁻¹ of every frame: it is linear in the statistics
+ * fm_pose_solve left in `aux` (Σw, p̄, q̄, M), so kinv_acc (B·F,9) fp64 is WRITTEN here, one thread per frame (earlier role of its
+ * pair + later role of the previous one), and the per-point passes (fm_procrustes_scatter / _scatter_dense with
+ * kinv_acc = NULL) carry no sums for it.  kinv (B,F,3,3): the inverse intrinsics the fit was given. */
+int fm_pose_solve_bwd_kinv(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux, const float* kinv, int batch,
+                           int frames, double* pair_grad, double* kinv_acc, void* stream);
 
 /* Per-point backward (replaces grid_sampler_2d_backward + index_put of
  * projection.py:226-249).  ATOMICALLY ADDS into grad_depth (B,F,H,W) or grad_surfaces
@@ -181,10 +187,9 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
  *           consecutive pixels).
  * Per step fm_procrustes_scatter_dense: grad_weights (B,F-1,H,W) is STORED (every element exactly once:
  * need not be zeroed, must not hold another gradient); grad_depth (B,F,H,W) is ADDED to with plain
- * read-modify-writes (each pixel has one writer per launch); kinv_acc (B·F,9) fp64 is added to (caller
- * zeroes) — from `stats`, the (B·(F-1), FM_STAT_STRIDE) statistics fm_procrustes_fit left behind for the same inputs: dL/dK⁻¹ is
- * linear in them, so no per-pixel sum is formed (stats may be NULL when kinv_acc is).
- * grad_depth / grad_weights / kinv_acc may be NULL; first / list are needed for grad_depth.
+ * read-modify-writes (each pixel has one writer per launch).  dL/dK⁻¹ is not formed here: it is linear in the
+ * statistics of the forward pass and comes from fm_pose_solve_bwd_kinv.
+ * grad_depth / grad_weights may be NULL; first / list are needed for grad_depth.
  * consts: workspace of B·(F-1)·FM_DENSE_CONST_STRIDE doubles (per-pair constants, written by the call). */
 #define FM_DENSE_CONST_STRIDE 40
 int fm_procrustes_dense_tiles(int height, int width, int* tiles);
@@ -192,8 +197,8 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
                              uint32_t* list, void* stream);
 int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights,
                                 float weight_sensitivity, int batch, int frames, int height, int width, const double* aux,
-                                const double* stats, const double* pair_grad, float* grad_depth, float* grad_weights, double* kinv_acc,
-                                const int64_t* first, const uint32_t* list, double* consts, void* stream);
+                                const double* pair_grad, float* grad_depth, float* grad_weights, const int64_t* first, const uint32_t* list,
+                                double* consts, void* stream);
 
 /* Planned form of the sparse depth-sourced scatter.  With DISTINCT `indices` and constant flows the
  * pixels a step's Procrustes gradient touches never change: fm_procrustes_scatter_plan lists them

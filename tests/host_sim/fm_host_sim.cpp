@@ -544,10 +544,9 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
 }
 
 int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float sens, int batch,
-                                int frames, int height, int width, const double* aux, const double* stats, const double* pair_grad,
-                                float* grad_depth, float* grad_weights, double* kinv_acc, const int64_t* first, const uint32_t* list, double*,
-                                void*) {
-  if (!depth || !kinv || !bwd_flow || !weights || !aux || !pair_grad || (grad_depth && (!first || !list)) || (kinv_acc && !stats)) return 1;
+                                int frames, int height, int width, const double* aux, const double* pair_grad, float* grad_depth,
+                                float* grad_weights, const int64_t* first, const uint32_t* list, double*, void*) {
+  if (!depth || !kinv || !bwd_flow || !weights || !aux || !pair_grad || (grad_depth && (!first || !list))) return 1;
   int tiles = 0;
   fm_procrustes_dense_tiles(height, width, &tiles);
   const int tiles_x = (width + kDenseTileW - 1) / kDenseTileW;
@@ -577,11 +576,11 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
             a_l[a * 3 + d] += (double)(px.w * sv[a]) * px.g[d];
           }
       }
-    if (kinv_acc) {
-      // the device derives dL/dK⁻¹ from the forward statistics (dense_kinv_grads); the double also forms the per-pixel sums it
-      // replaces and refuses to go on when the two disagree — every CPU test of the dense path checks the algebra
+    {
+      // the device derives dL/dK⁻¹ from the forward statistics (pair_kinv_grads, fm_pose_solve_bwd_kinv); the double also forms the
+      // per-pixel sums it replaces and refuses to go on when the two disagree — every CPU test of the dense path checks the algebra
       double ge[9], gl[9], pe[9], pl[9], num = 0.0, den = 0.0;
-      dense_kinv_grads(stats + (size_t)pr * kStatStride, pair_grad + (size_t)pr * kPairGradStride, aux + (size_t)pr * kAuxStride, k_e, k_l, ge, gl);
+      pair_kinv_grads(pair_grad + (size_t)pr * kPairGradStride, aux + (size_t)pr * kAuxStride, k_e, k_l, ge, gl);
       for (int r = 0; r < 3; ++r)
         for (int d = 0; d < 3; ++d) {
           pe[r * 3 + d] = k_e[0 * 3 + r] * a_e[0 * 3 + d] + k_e[1 * 3 + r] * a_e[1 * 3 + d] + k_e[2 * 3 + r] * a_e[2 * 3 + d];
@@ -592,10 +591,6 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
         den += pe[k] * pe[k] + pl[k] * pl[k];
       }
       if (num > 1e-6 * den + 1e-30) return 3;  // (1e-3 relative: the per-pixel sums are fp32 products)
-      for (int k = 0; k < 9; ++k) {
-        kinv_acc[fe * 9 + k] += ge[k];
-        kinv_acc[fl * 9 + k] += gl[k];
-      }
     }
     if (!grad_depth) continue;
     // earlier role: per tile of the earlier frame, the listed later pixels (only taps inside the tile count)
@@ -690,6 +685,33 @@ int fm_pose_solve_bwd(const float* g_t_bwd, const float* g_t_fwd, const float* t
   return 0;
 }
 
+int fm_pose_solve_bwd_kinv(const float* g_t_bwd, const float* g_t_fwd, const float* t_bwd, const double* aux, const float* kinv, int batch,
+                           int frames, double* pair_grad, double* kinv_acc, void*) {
+  for (int bf = 0; bf < batch * frames; ++bf) {
+    const int b = bf / frames, f = bf % frames;
+    double kd[9], kf[9], acc[9] = {};
+    for (int k = 0; k < 9; ++k) kd[k] = kinv[(size_t)bf * 9 + k];
+    inv3d(kd, kf);
+    if (f < frames - 1) {
+      const size_t pr = (size_t)b * (frames - 1) + f;
+      double* pg = pair_grad + pr * kPairGradStride;
+      pose_solve_bwd_one(g_t_bwd ? g_t_bwd + pr * 16 : nullptr, g_t_fwd ? g_t_fwd + pr * 16 : nullptr, t_bwd + pr * 16, aux + pr * kAuxStride, pg);
+      double ge[9];
+      pair_kinv_grads(pg, aux + pr * kAuxStride, kf, nullptr, ge, nullptr);
+      for (int k = 0; k < 9; ++k) acc[k] += ge[k];
+    }
+    if (f > 0) {
+      const size_t pr = (size_t)b * (frames - 1) + f - 1;
+      double pg[kPairGradStride], gl[9];
+      pose_solve_bwd_one(g_t_bwd ? g_t_bwd + pr * 16 : nullptr, g_t_fwd ? g_t_fwd + pr * 16 : nullptr, t_bwd + pr * 16, aux + pr * kAuxStride, pg);
+      pair_kinv_grads(pg, aux + pr * kAuxStride, nullptr, kf, nullptr, gl);
+      for (int k = 0; k < 9; ++k) acc[k] += gl[k];
+    }
+    for (int k = 0; k < 9; ++k) kinv_acc[(size_t)bf * 9 + k] = acc[k];
+  }
+  return 0;
+}
+
 int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float sens, const int64_t* indices, long points, int batch, int repeat, int frames,
                           int height, int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
@@ -720,6 +742,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
     const int bd = b / repeat;
     const size_t fe = (size_t)bd * frames + i, fl = fe + 1;
     const size_t fk = (size_t)b * frames + i, dpair = (size_t)bd * (frames - 1) + i;
+    double ksum_e[9] = {}, ksum_l[9] = {};  // the per-point sums of dL/dK⁻¹ (what the closed form of pair_kinv_grads replaces)
     for (long j = 0; j < points; ++j) {
       const Corr c = corr_load(src, ke, kl, indices ? (int)indices[j] : (int)j);
       float gq[3], gp[3], gw;
@@ -744,9 +767,8 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
         const float u = pixel_center(col, width), v = pixel_center(row, height);
         if (grad_depth) grad_depth[fl * n + c.idx] += gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2];
         const float zh[3] = {c.z_p * u, c.z_p * v, c.z_p};
-        if (kinv_acc)
-          for (int a = 0; a < 3; ++a)
-            for (int d = 0; d < 3; ++d) kinv_acc[(fk + 1) * 9 + a * 3 + d] += gp[a] * zh[d];
+        for (int a = 0; a < 3; ++a)
+          for (int d = 0; d < 3; ++d) ksum_l[a * 3 + d] += (double)(gp[a] * zh[d]);
         for (int k = 0; k < 4; ++k) {
           if (!c.taps.in[k]) continue;
           const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
@@ -757,9 +779,8 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
           const float wt = c.taps.w[k];
           if (grad_depth) grad_depth[fe * n + (size_t)tr * width + tc] += wt * (gq[0] * ray[0] + gq[1] * ray[1] + gq[2] * ray[2]);
           const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
-          if (kinv_acc)
-            for (int a = 0; a < 3; ++a)
-              for (int d = 0; d < 3; ++d) kinv_acc[fk * 9 + a * 3 + d] += gq[a] * zt[d];
+          for (int a = 0; a < 3; ++a)
+            for (int d = 0; d < 3; ++d) ksum_e[a * 3 + d] += (double)(gq[a] * zt[d]);
         }
       } else if (grad_surfaces) {
         float* gl = grad_surfaces + (fl * n + c.idx) * 3;
@@ -770,6 +791,28 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
           for (int a = 0; a < 3; ++a) ge[a] += gq[a] * c.taps.w[k];
         }
       }
+    }
+    if (!surfaces) {
+      // the device derives dL/dK⁻¹ from the statistics kept in aux (pair_kinv_grads, fm_pose_solve_bwd_kinv); the double forms the
+      // per-point sums as well and refuses to go on when the two disagree: every CPU test of a fit checks the algebra
+      double kde[9], kdl[9], k_e[9], k_l[9], ge[9], gl[9], num = 0.0, den = 0.0;
+      for (int k = 0; k < 9; ++k) {
+        kde[k] = kinv[((size_t)b * frames + i) * 9 + k];
+        kdl[k] = kinv[((size_t)b * frames + i + 1) * 9 + k];
+      }
+      inv3d(kde, k_e);
+      inv3d(kdl, k_l);
+      pair_kinv_grads(pg, ax, k_e, k_l, ge, gl);
+      for (int k = 0; k < 9; ++k) {
+        num += (ge[k] - ksum_e[k]) * (ge[k] - ksum_e[k]) + (gl[k] - ksum_l[k]) * (gl[k] - ksum_l[k]);
+        den += ksum_e[k] * ksum_e[k] + ksum_l[k] * ksum_l[k];
+      }
+      if (num > 1e-6 * den + 1e-24) return 3;  // (1e-3 relative: the per-point products are fp32)
+      if (kinv_acc)
+        for (int k = 0; k < 9; ++k) {
+          kinv_acc[fk * 9 + k] += ksum_e[k];
+          kinv_acc[(fk + 1) * 9 + k] += ksum_l[k];
+        }
     }
   }
   return 0;

@@ -31,7 +31,7 @@ pairs = f - 1
 stats = torch.empty((pairs, 16), dtype=torch.float64, device=dev)
 t_bwd = torch.empty((1, pairs, 4, 4), device=dev)
 t_fwd = torch.empty_like(t_bwd)
-aux = torch.empty((pairs, 32), dtype=torch.float64, device=dev)
+aux = torch.empty((pairs, 40), dtype=torch.float64, device=dev)
 pair_grad = torch.empty((pairs, 20), dtype=torch.float64, device=dev)
 g_t = torch.randn((1, pairs, 4, 4), device=dev, generator=g)
 g_depth = torch.zeros_like(depth)
@@ -88,10 +88,10 @@ for name, path in libs.items():
         assert lib.fm_pose_solve_bwd(P(g_t), None, P(t_bwd), P(aux), pairs, P(pair_grad), None, 0, st) == 0
 
         def later_only():
-            assert lib.fm_procrustes_scatter_dense(P(depth), P(kinv), P(flow), P(logit), 100.0, 1, f, h, w, P(aux), P(stats), P(pair_grad), None, P(g_w), P(kinv_acc), None, None, P(consts), st) == 0
+            assert lib.fm_procrustes_scatter_dense(P(depth), P(kinv), P(flow), P(logit), 100.0, 1, f, h, w, P(aux), P(pair_grad), None, P(g_w), None, None, P(consts), st) == 0
 
         def both():
-            assert lib.fm_procrustes_scatter_dense(P(depth), P(kinv), P(flow), P(logit), 100.0, 1, f, h, w, P(aux), P(stats), P(pair_grad), P(g_depth), P(g_w), P(kinv_acc), P(first), P(entries), P(consts), st) == 0
+            assert lib.fm_procrustes_scatter_dense(P(depth), P(kinv), P(flow), P(logit), 100.0, 1, f, h, w, P(aux), P(pair_grad), P(g_depth), P(g_w), P(first), P(entries), P(consts), st) == 0
 
         a, b, c = timed(fit), timed(later_only), timed(both)
         out[f"{name}/{kind}"] = {"fit_ms": round(a, 3), "later_no_depth_ms": round(b, 3), "later_plus_taps_ms": round(c, 3), "entries_per_pixel": round(entries.numel() / (pairs * h * w), 4)}

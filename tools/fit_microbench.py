@@ -30,7 +30,7 @@ stats = torch.empty((pairs, 16), dtype=torch.float64, device=dev)
 work = torch.zeros((pairs * 16 + (pairs + 2) // 2 + 1,), dtype=torch.float64, device=dev)
 t_bwd = torch.empty((1, pairs, 4, 4), device=dev)
 t_fwd = torch.empty_like(t_bwd)
-aux = torch.empty((pairs, 32), dtype=torch.float64, device=dev)
+aux = torch.empty((pairs, 40), dtype=torch.float64, device=dev)
 ext = torch.empty((1, f, 4, 4), device=dev)
 lib = _lib.library()
 P = lambda t: None if t is None else t.data_ptr()  # noqa: E731

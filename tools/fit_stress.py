@@ -35,7 +35,7 @@ def run(iters: int, dev: str = "cuda:0", verbose: bool = True) -> float:
         flow = 0.003 * torch.randn((1, pairs, h, w, 2), device=dev, generator=g)
         stats = torch.empty((pairs, 16), dtype=torch.float64, device=dev)
         work = torch.zeros((pairs * 16 + (pairs + 2) // 2 + 1,), dtype=torch.float64, device=dev)
-        aux, aux2 = (torch.empty((pairs, 32), dtype=torch.float64, device=dev) for _ in range(2))
+        aux, aux2 = (torch.empty((pairs, 40), dtype=torch.float64, device=dev) for _ in range(2))
         tb, tf, tb2, tf2 = (torch.empty((1, pairs, 4, 4), device=dev) for _ in range(4))
         ext, ext2 = (torch.empty((1, f, 4, 4), device=dev) for _ in range(2))
         n = iters if h * w < 500000 else max(iters // 10, 20)

@@ -20,7 +20,7 @@ idx = torch.linspace(0, h * w - 1, P, dtype=torch.int64).to(dev)
 pairs = f - 1
 stats = torch.empty((pairs, 16), dtype=torch.float64, device=dev)
 t_bwd = torch.empty((1, pairs, 4, 4), device=dev)
-aux = torch.empty((pairs, 32), dtype=torch.float64, device=dev)
+aux = torch.empty((pairs, 40), dtype=torch.float64, device=dev)
 pg = torch.empty((pairs, 20), dtype=torch.float64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 call("fm_procrustes_stats", ptr(depth), ptr(kinv), None, ptr(fb), ptr(wl), 100.0, ptr(idx), P, 1, 1, f, h, w, ptr(stats), st)
