@@ -144,13 +144,15 @@ def make_scene(f, h, w, device, seed, focal=0.85, depth_noise=0.05):
         return 2.0 + 0.25 * torch.sin(1.7 * xw + 0.3) * torch.cos(1.3 * yw - 0.2) + 0.1 * torch.sin(3.1 * xw * yw)
 
     depth = torch.empty((f, h, w), device=device)
-    for i in range(f):  # frame by frame: a few hundred MB of temporaries instead of tens of GB
-        r, c = ext[i, :3, :3], ext[i, :3, 3]
-        d = torch.full((h, w), 2.0, device=device)
+    group = max(1, min(f, (1 << 26) // (h * w)))  # frames per batch of the ray casting: ~0.8 GB of temporaries, 10x fewer launches
+    for i in range(0, f, group):
+        r, c = ext[i : i + group, :3, :3], ext[i : i + group, :3, 3]  # (g,3,3), (g,3)
+        d = torch.full((r.shape[0], h, w), 2.0, device=device)
+        step = r[:, 2, 2].clamp_min(0.5)[:, None, None]
         for _ in range(40):
-            pw = (rays * d[..., None]) @ r.T + c
-            d = d + (height(pw[..., 0], pw[..., 1]) - pw[..., 2]) / r[2, 2].clamp_min(0.5)
-        depth[i] = d
+            pw = torch.einsum("ghwk,gjk->ghwj", rays[None] * d[..., None], r) + c[:, None, None]
+            d = d + (height(pw[..., 0], pw[..., 1]) - pw[..., 2]) / step
+        depth[i : i + group] = d
     with torch.no_grad():
         kk = k.expand(1, f, 3, 3).contiguous()
         fwd = torch.empty((1, f - 1, h, w, 2), device=device)
