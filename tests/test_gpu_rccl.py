@@ -1,7 +1,8 @@
 """Frame-pair sharding over RCCL on the GPUs of one node: flow + tracking losses with the video split over
 ``torch.cuda.device_count()`` ranks (one process per GPU, backend "nccl" = RCCL over xGMI) against the unsharded
 fp64 oracle — the multi-GPU twin of tests/test_sharding_gloo.py.  Skips itself on a box with fewer than two GPUs
-(the 1-GPU gpurun boxes); the first multi-GPU lease validates the RCCL path."""
+(the 1-GPU gpurun boxes); the first multi-GPU lease validates the RCCL path.  The very same worker also runs over gloo on
+the host test double (CPU, two ranks) so that the test's own logic is exercised before that day."""
 
 import os
 import socket
@@ -13,18 +14,26 @@ import torch
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
-pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, f, h, w, points, out_path):
+def _worker(rank, world, port, f, h, w, points, out_path, on_gpu=True):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if on_gpu:
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:  # the same code over gloo on the host test double
+        from flowmap_amd import _lib
+        from helpers import build_host_sim
+
+        torch.set_num_threads(2)
+        _lib.set_library_for_testing(build_host_sim())
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import flowmap_amd
     from flowmap_amd import Batch, Flows
     from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
@@ -67,12 +76,7 @@ def _worker(rank, world, port, f, h, w, points, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_rccl_sharded_step_matches_unsharded_oracle(tmp_path):
-    world = torch.cuda.device_count()
-    if world < 2:
-        pytest.skip(f"needs >= 2 GPUs for an RCCL run (this box has {world})")
-    world = min(world, 8)
+def _run_and_compare(tmp_path, world, on_gpu):
     sys.path.insert(0, str(ROOT / "tests"))
     from conftest import assert_close
     from helpers import run_oracle
@@ -83,7 +87,7 @@ def test_rccl_sharded_step_matches_unsharded_oracle(tmp_path):
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
     out = str(tmp_path / "rccl")
-    mp.spawn(_worker, args=(world, port, f, h, w, points, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, f, h, w, points, out, on_gpu), nprocs=world, join=True)
     sc = orc.synth_scene(f, h, w, seed=5)
     wl = 0.01 * torch.randn((f - 1, h, w), generator=torch.Generator().manual_seed(5))
     tracks = orc.synth_tracks(f, h, w, scene=sc, seed=5, interval=3, radius=5, grid=8)
@@ -95,3 +99,17 @@ def test_rccl_sharded_step_matches_unsharded_oracle(tmp_path):
         assert_close(r["g_focal"], ref["g_focal"], 1e-4, what="g_focal (all-reduced)")
         assert_close(r["g_depth"], ref["g_depth"][lo : hi + 1], 1e-4, what="g_depth shard (halo summed)")
         assert_close(r["g_w"], ref["g_wlogit"][a:b], 1e-4, what="g_wlogit shard")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_sharded_step_matches_unsharded_oracle(tmp_path):
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip(f"needs >= 2 GPUs for an RCCL run (this box has {world})")
+    _run_and_compare(tmp_path, min(world, 8), on_gpu=True)
+
+
+@pytest.mark.timeout(600)
+def test_the_same_worker_over_gloo_on_the_host_double(tmp_path):
+    _run_and_compare(tmp_path, 2, on_gpu=False)
