@@ -88,6 +88,7 @@ SIGNATURES = {
     "fm_track_scatter_plan": [P, P, P, P, I, I, I, I, P, P, P],
     "fm_depth_gather": [P, P, P, P, P, L, P, P, P, I, I, L, P, P],
     "fm_depth_gather_kgrad": [P, P, P, P, P, L, P, I, I, P, P, I, P, I, P],
+    "fm_procrustes_bwd_planned": [P, P, P, P, F, P, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, P],
 }
 
 _lib: Optional[ctypes.CDLL] = None

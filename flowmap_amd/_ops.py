@@ -308,7 +308,7 @@ class AllPairsPoses(torch.autograd.Function):
 
 
 def _procrustes_scatter_plan(indices: Tensor, bwd_flow: Tensor, b: int, f: int, h: int, w: int):
-    """(pixels, first, vector index per entry, weights) for fm_depth_gather, or None: with constant flows and
+    """(pixels, first, vector index per entry, weights, first pixel of every frame) for fm_depth_gather / fm_procrustes_bwd_planned, or None: with constant flows and
     a constant, duplicate-free index set, the pixels the sparse Procrustes gradient touches never change.
     A plan costs a sort, so it is built when the same (indices, flows) come back a second time — per-step
     random indices never qualify.  Kept on the flow tensor, keyed by the index tensor's identity."""
@@ -336,7 +336,10 @@ def _procrustes_scatter_plan(indices: Tensor, bwd_flow: Tensor, b: int, f: int, 
             first = torch.zeros((pixels.numel() + 1,), dtype=torch.int32, device=dev)
             first[1:] = torch.cumsum(counts, 0).to(torch.int32)
             vectors = (torch.div(entries, 5, rounding_mode="floor") * 2 + (entries % 5 == 4)).to(torch.int32)
-            entry[1] = (pixels.contiguous(), first, vectors.contiguous(), weights[entries].contiguous())
+            # where every frame's pixels begin (the plan is sorted by frame·H·W + pixel): fm_procrustes_bwd_planned's blocks, one per frame
+            bounds = torch.arange(b * f + 1, dtype=torch.int64, device=dev) * (h * w)
+            frame_first = torch.searchsorted(pixels, bounds).to(torch.int32)
+            entry[1] = (pixels.contiguous(), first, vectors.contiguous(), weights[entries].contiguous(), frame_first.contiguous())
     return entry[1]
 
 
@@ -398,7 +401,7 @@ class ProcrustesFit:
         from_depth = surfaces is None
         rep = int(batch_repeat)
         kinv = sink = wsink = arena = None
-        sparse = (None, None, None, None)
+        sparse = (None, None, None, None, None)
         dense = (None, None)
         if from_depth:
             if depth is None or k is None:

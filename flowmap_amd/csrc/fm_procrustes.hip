@@ -19,6 +19,7 @@
 // Backward: dL/dT -> (polar differential) dL/dM, dL/dp̄, dL/dq̄ -> per-point gradients,
 // scattered with fp32 atomics into dL/ddepth (or dL/dsurfaces) and dL/dweights; the
 // K⁻¹ gradient is block-reduced into per-frame fp64 accumulators.
+#include "../../include/flowmap_hip.h"
 #include "fm_device.h"
 #include "fm_pose.h"
 
@@ -1084,6 +1085,141 @@ __global__ void __launch_bounds__(256) procrustes_scatter_kernel(ProcParams p, c
 }
 
 // ---------------------------------------------------------------------------------
+// The whole backward of a PLANNED sparse fit (depth source, constant distinct indices, constant flows) in one launch:
+// pose-solve backward, per-correspondence gradients, the planned gather into dL/ddepth and dL/dK — round 2 ran them as
+// fm_pose_solve_bwd_kinv -> fm_procrustes_scatter -> fm_depth_gather_kgrad, three dependent launches of 10 + 32 + 24 us for
+// ~1 us of arithmetic each.  One block per FRAME (b, f): everything that lands in dL/ddepth[b, f] comes from the two pairs the
+// frame belongs to — the tap gradients dL/dq of pair f (f is its earlier frame) and the pixel gradients dL/dp of pair f−1
+// (f is its later frame) — so the block evaluates both pairs' correspondences (each pair is evaluated by its two frames'
+// blocks: 2 x 1 us of arithmetic for two launches less), keeps the 2·P gradient vectors in LDS and walks ITS slice of
+// the gather plan (the plan is sorted by frame·H·W + pixel: `frame_first` marks where each frame's pixels begin).  No value
+// has two writers: dL/dweights of pair f is stored by block f, dL/dK[f] by block f.
+//   thread 0:  pose_solve_bwd_one(pair f)   -> LDS, earlier-role dL/dK⁻¹      (fp64, ~5 us of latency)
+//   thread 64: pose_solve_bwd_one(pair f−1) -> LDS, later-role  dL/dK⁻¹       (another wave: the two run side by side)
+// while the other waves already chase their correspondences' gather chains (index -> flow -> taps).
+// ---------------------------------------------------------------------------------
+struct FitBwdPlan {
+  const float* g_t_bwd;        // (B·(F−1),4,4) or null
+  const float* g_t_fwd;        // (B·(F−1),4,4) or null
+  const float* t_bwd;          // (B·(F−1),4,4)
+  const double* aux;           // (B·(F−1), kAuxStride)
+  const int64_t* pixels;       // plan: touched pixels, ascending frame·H·W + pixel
+  const int32_t* first;        //       entries of pixel m: [first[m], first[m+1])
+  const int32_t* vectors;      //       2·(pair·P + j) + (later role)
+  const float* tap_weights;    //       bilinear weight of the entry (1 for the later role)
+  const int32_t* frame_first;  // (B·F + 1) first plan pixel of every frame
+  float* g_k;                  // (B·F,3,3) or null
+  int accumulate_k;            // g_k += instead of =
+  int batch;
+};
+
+constexpr int kFitBwdThreads = 1024;
+
+__global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(ProcParams p, FitBwdPlan pl) {
+  extern __shared__ float vec_lds[];  // [role 0: dL/dq of pair f | role 1: dL/dp of pair f−1][P][3]
+  __shared__ double pg_lds[2][kPairGradStride];
+  __shared__ double kacc_lds[2][9];
+  const int bf = blockIdx.x;
+  const int b = bf / p.frames, f = bf % p.frames;
+  const int n = p.height * p.width;
+  const bool has_e = f < p.frames - 1;  // this frame is the EARLIER frame of pair (b, f)
+  const bool has_l = f > 0;             // ... and the LATER frame of pair (b, f−1)
+  const size_t pair_e = (size_t)b * (p.frames - 1) + f, pair_l = pair_e - 1;
+  const int t = threadIdx.x;
+
+  if (t == 0 || t == kWave) {
+    const int role = t == 0 ? 0 : 1;
+    const bool on = role == 0 ? has_e : has_l;
+    const size_t pr = role == 0 ? pair_e : pair_l;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (on) {
+      double* pg = pg_lds[role];
+      pose_solve_bwd_one(pl.g_t_bwd ? pl.g_t_bwd + pr * 16 : nullptr, pl.g_t_fwd ? pl.g_t_fwd + pr * 16 : nullptr, pl.t_bwd + pr * 16,
+                         pl.aux + pr * kAuxStride, pg);
+      if (pl.g_k) {
+        double kd[9], kf[9];
+        for (int k = 0; k < 9; ++k) kd[k] = p.kinv[(size_t)bf * 9 + k];
+        inv3d(kd, kf);  // K of this frame
+        if (role == 0) pair_kinv_grads(pg, pl.aux + pr * kAuxStride, kf, nullptr, acc, nullptr);
+        else pair_kinv_grads(pg, pl.aux + pr * kAuxStride, nullptr, kf, nullptr, acc);
+      }
+    }
+    for (int k = 0; k < 9; ++k) kacc_lds[role][k] = acc[k];
+  }
+  __syncthreads();
+  if (t == 0 && pl.g_k) {  // dK = [g_k] − K⁻ᵀ·dK⁻¹·K⁻ᵀ (kinv_grad_to_k), both roles summed in fp64
+    double tot[9], gk[9];
+    for (int k = 0; k < 9; ++k) tot[k] = kacc_lds[0][k] + kacc_lds[1][k];
+    kinv_grad_to_k(tot, p.kinv + (size_t)bf * 9, gk);
+    for (int k = 0; k < 9; ++k) {
+      float* o = pl.g_k + (size_t)bf * 9 + k;
+      *o = (pl.accumulate_k ? *o : 0.f) + (float)gk[k];
+    }
+  }
+
+  // ---- per-correspondence gradients of the two pairs -> LDS (and dL/dweights of pair f) ----
+  const int P = (int)p.points;
+#pragma unroll
+  for (int role = 0; role < 2; ++role) {
+    if (role == 0 ? !has_e : !has_l) continue;  // block-uniform
+    const size_t pair = role == 0 ? pair_e : pair_l;
+    const int i = role == 0 ? f : f - 1;
+    Mat3 kinv_e, kinv_l;
+    load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
+    load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
+    const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
+    const double* pg = pg_lds[role];
+    const double* ax = pl.aux + pair * kAuxStride;
+    PairGrad g;
+    for (int k = 0; k < 9; ++k) g.gM[k] = (float)pg[k];
+    for (int a = 0; a < 3; ++a) {
+      g.gqbar[a] = (float)pg[9 + a];
+      g.gpbar[a] = (float)pg[12 + a];
+      g.pbar[a] = (float)ax[21 + a];
+      g.qbar[a] = (float)ax[24 + a];
+    }
+    g.dbar = (float)pg[15];
+    g.inv_wsum = (float)pg[16];
+    float* out = vec_lds + (size_t)role * P * 3;
+    for (int j = t; j < P; j += kFitBwdThreads) {
+      const Corr c = corr_load(src, kinv_e, kinv_l, (int)p.indices[j]);
+      float gq[3], gp[3], gw;
+      corr_backward(c, g, gq, gp, gw);
+      if (role == 0) {
+        if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
+        if (p.grad_weights) p.grad_weights[pair * (size_t)n + c.idx] = gw;   // distinct indices: a plain store per slot
+        out[j * 3 + 0] = gq[0], out[j * 3 + 1] = gq[1], out[j * 3 + 2] = gq[2];
+      } else {
+        out[j * 3 + 0] = gp[0], out[j * 3 + 1] = gp[1], out[j * 3 + 2] = gp[2];
+      }
+    }
+  }
+  __syncthreads();
+  if (p.grad_depth == nullptr) return;
+
+  // ---- this frame's slice of the planned gather: one plain read-modify-write per touched pixel ----
+  Mat3 ki;
+  load_mat3(p.kinv + (size_t)bf * 9, ki);
+  const int lo = pl.frame_first[bf], hi = pl.frame_first[bf + 1];
+  const int64_t frame_base = (int64_t)bf * n;
+  const int base_e = (int)(pair_e * (size_t)P), base_l = (int)(pair_l * (size_t)P);
+  for (int m = lo + t; m < hi; m += kFitBwdThreads) {
+    const int px = (int)(pl.pixels[m] - frame_base);
+    const int row = px / p.width, col = px - row * p.width;
+    float ray[3];
+    ray_dir(ki, pixel_center(col, p.width), pixel_center(row, p.height), ray);
+    float sum = 0.f;
+    for (int e = pl.first[m]; e < pl.first[m + 1]; ++e) {
+      const int v = pl.vectors[e];
+      const int later = v & 1, j = (v >> 1) - (later ? base_l : base_e);
+      const float* g3 = vec_lds + ((size_t)later * P + j) * 3;
+      sum += pl.tap_weights[e] * (g3[0] * ray[0] + g3[1] * ray[1] + g3[2] * ray[2]);
+    }
+    p.grad_depth[frame_base + px] += sum;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Pose chain (get_extrinsics): E_0 = I, E_k = E_{k-1} · T_{k-1}.  One thread per batch
 // element walks the chain in fp64 (F ≤ a few thousand; latency ≈ tens of µs, replacing
 // F-1 dependent matmul launches).  Backward is the reverse scan.
@@ -1470,6 +1606,27 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
     hipLaunchKernelGGL(procrustes_scatter_repeat_kernel, rgrid, dim3(256), 0, st, p, aux);
   } else if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);
   else hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, aux, iters);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_procrustes_bwd_planned(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float weight_sensitivity,
+                              const int64_t* indices, long points, int batch, int frames, int height, int width, const double* aux,
+                              const float* t_bwd, const float* g_t_bwd, const float* g_t_fwd, const int64_t* plan_pixels,
+                              const int32_t* plan_first, const int32_t* plan_vectors, const float* plan_weights, const int32_t* frame_first,
+                              float* grad_depth, float* grad_weights, float* g_k, int accumulate_k, void* stream) {
+  FM_CHECK_ARG(depth && kinv && bwd_flow && weights && indices && aux && t_bwd);
+  FM_CHECK_ARG(points >= 1 && points <= FM_FIT_BWD_MAX_POINTS && batch >= 1 && frames >= 2 && height >= 1 && width >= 1);
+  FM_CHECK_ARG(!grad_depth || (plan_pixels && plan_first && plan_vectors && plan_weights && frame_first));
+  FM_CHECK_ARG((long)batch * (frames - 1) * points < (1L << 30));
+  ProcParams p{};
+  p.depth = depth; p.kinv = kinv; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
+  p.grad_depth = grad_depth; p.grad_weights = grad_weights;
+  p.frames = frames; p.height = height; p.width = width; p.points = points;
+  p.weight_sens = weight_sensitivity;
+  p.batch_repeat = 1;
+  FitBwdPlan pl{g_t_bwd, g_t_fwd, t_bwd, aux, plan_pixels, plan_first, plan_vectors, plan_weights, frame_first, g_k, accumulate_k, batch};
+  const size_t lds = sizeof(float) * 2 * 3 * (size_t)points;
+  hipLaunchKernelGGL(procrustes_bwd_frame_kernel, dim3((unsigned)(batch * frames)), dim3(kFitBwdThreads), lds, (hipStream_t)stream, p, pl);
   FM_LAUNCH_STATUS();
 }
 

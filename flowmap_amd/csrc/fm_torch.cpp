@@ -46,7 +46,7 @@ using OptTensor = std::optional<Tensor>;
 #define FM_API_LIST(X)                                                                                                                    \
   X(fm_flow_loss_fused) X(fm_flow_loss_fused_adam) X(fm_adam_step_elements) X(fm_flow_loss_finalize) X(fm_scale_if_needed) X(fm_intrinsics_inverse) X(fm_intrinsics_inverse_bwd)              \
   X(fm_focal_intrinsics_fwd) X(fm_focal_intrinsics_bwd) X(fm_pose_chain_fwd) X(fm_pose_chain_bwd) X(fm_relative_pose_fwd)                  \
-  X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_pose_solve_bwd_kinv) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense)                \
+  X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_pose_solve_bwd_kinv) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense) X(fm_procrustes_bwd_planned)                \
   X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_loss_fused_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
   X(fm_adam_step_capturable) X(fm_softmin_score_fwd) X(fm_softmin_score_bwd) X(fm_softmin_blend_fwd) X(fm_softmin_blend_bwd)         \
   X(fm_random_subset) X(fm_random_subset_stateful)
@@ -243,6 +243,14 @@ struct GradArena : torch::CustomClassHolder {
   }
 };
 
+// tests and A/B timing: the planned sparse fit's backward as one launch (default) or as the three launches it replaces
+static bool& one_launch_backward_flag() {
+  static bool on = true;
+  return on;
+}
+static bool use_one_launch_backward() { return one_launch_backward_flag(); }
+static void set_one_launch_backward(bool on) { one_launch_backward_flag() = on; }
+
 // does the autograd graph above `from` contain `target` within `depth` hops?  (poses -> [chain ->] fit)
 static bool reaches(const std::shared_ptr<torch::autograd::Node>& from, const torch::autograd::Node* target, int depth) {
   if (!from || target == nullptr) return false;
@@ -373,8 +381,8 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                                double weight_sens, int64_t rep, const c10::intrusive_ptr<DepthSink>& sink,
                                const c10::intrusive_ptr<DepthSink>& wsink, const c10::intrusive_ptr<GradArena>& arena,
                                const OptTensor& plan_pixels, const OptTensor& plan_first, const OptTensor& plan_vectors,
-                               const OptTensor& plan_weights, const OptTensor& dense_first, const OptTensor& dense_list,
-                               const OptTensor& work_o, bool grad_enabled) {  // (forward runs with grad mode off: the caller's mode is passed in)
+                               const OptTensor& plan_weights, const OptTensor& plan_frame_first, const OptTensor& dense_first,
+                               const OptTensor& dense_list, const OptTensor& work_o, bool grad_enabled) {  // (forward runs with grad mode off: the caller's mode is passed in)
     ctx->set_materialize_grads(false);  // an unused output (the extrinsics of a flow-only step) must not cost a zeros tensor + the chain's backward
     Tensor depth = opt(depth_o), k = opt(k_o), kinv = opt(kinv_o), surfaces = opt(surfaces_o), indices = opt(indices_o);
     const bool from_depth = !surfaces.defined();
@@ -438,7 +446,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       }
     }
     ctx->save_for_backward({from_depth ? depth : surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux, opt(plan_pixels), opt(plan_first),
-                            opt(plan_vectors), opt(plan_weights), opt(dense_first), opt(dense_list), ext});
+                            opt(plan_vectors), opt(plan_weights), opt(dense_first), opt(dense_list), ext, opt(plan_frame_first)});
     ctx->saved_data["dims"] = std::vector<int64_t>{b, f, h, w, points, rep, from_depth ? 1 : 0};
     ctx->saved_data["weight_sens"] = weight_sens;
     if (sink) ctx->saved_data["sink"] = sink;
@@ -461,7 +469,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     const Tensor &src = saved[0], &kinv = saved[1], &weights = saved[2], &bwd_flow = saved[3], &indices = saved[4], &t_bwd = saved[5],
                  &aux = saved[6];
     const Tensor &plan_pixels = saved[7], &plan_first = saved[8], &plan_vectors = saved[9], &plan_weights = saved[10],
-                 &dense_first = saved[11], &dense_list = saved[12], &ext = saved[13];
+                 &dense_first = saved[11], &dense_list = saved[12], &ext = saved[13], &plan_frame_first = saved[14];
     const auto dims = ctx->saved_data["dims"].toIntVector();
     const int64_t b = dims[0], f = dims[1], h = dims[2], w = dims[3], points = dims[4], rep = dims[5];
     const bool from_depth = dims[6] != 0;
@@ -484,7 +492,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     const bool need_src = ctx->needs_input_grad(from_depth ? edges[0] : edges[2]);
     const bool need_k = from_depth && ctx->needs_input_grad(edges[1]);
     const bool need_w = ctx->needs_input_grad(edges[3]);
-    Tensor pair_grad = at::empty({pairs, FM_PAIR_GRAD_STRIDE}, weights.options().dtype(at::kDouble));
+    Tensor pair_grad;
     Tensor g_src, g_k, g_w;
 
     // The dense dL/ddepth: what the losses parked (the sink is armed only for depth-sourced, un-repeated fits)
@@ -512,13 +520,30 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
         arena_used = true;
       } else g_w = at::zeros_like(weights);
     }
-    Tensor kinv_acc = need_k ? at::empty({b * f, 9}, weights.options().dtype(at::kDouble)) : Tensor();
-    Tensor point_grads = (planned && g_src.defined()) ? at::empty({pairs * points, 2, 3}, weights.options()) : Tensor();
     // dL/dK⁻¹ is linear in the statistics the forward pass left in aux: written by the pose-solve backward itself, and the per-point
     // passes carry no sums for it (repeated batches — the softmin sweep's candidates — keep the per-point accumulation)
     const bool k_closed_form = need_k && from_depth && rep == 1;
-    {
+    // A planned fit of up to FM_FIT_BWD_MAX_POINTS points per pair: pose-solve backward, per-correspondence gradients, the planned
+    // gather and dL/dK in ONE launch, one workgroup per frame (fm_procrustes_bwd_planned)
+    const bool one_launch = planned && g_src.defined() && plan_frame_first.defined() && points <= FM_FIT_BWD_MAX_POINTS && use_one_launch_backward();
+    if (one_launch) {
+      const bool add_k = need_k && carried_k.defined() && carried_k.sizes() == kinv.sizes() && carried_k.is_contiguous();
+      if (need_k) g_k = add_k ? carried_k : at::empty_like(kinv);
+      {
+        DeviceScope scope(dev);
+        FM_CALL(fm_procrustes_bwd_planned, ptr(src), ptr(kinv), ptr(bwd_flow), ptr(weights), sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f,
+                (int)h, (int)w, ptr<double>(aux), ptr(t_bwd), ptr(g_t), ptr(g_t_fwd), ptr<int64_t>(plan_pixels), ptr<int32_t>(plan_first),
+                ptr<int32_t>(plan_vectors), ptr(plan_weights), ptr<int32_t>(plan_frame_first), ptr(g_src), ptr(g_w), ptr(g_k), add_k ? 1 : 0,
+                scope.stream);
+      }
+      if (carried_k.defined() && !add_k) g_k = g_k.defined() ? g_k + carried_k : carried_k;  // (unexpected layout: plain sum)
+      if (sink) ++sink->planned_steps;
+    }
+    Tensor kinv_acc = (need_k && !one_launch) ? at::empty({b * f, 9}, weights.options().dtype(at::kDouble)) : Tensor();
+    Tensor point_grads = (planned && g_src.defined() && !one_launch) ? at::empty({pairs * points, 2, 3}, weights.options()) : Tensor();
+    if (!one_launch) {
       DeviceScope scope(dev);
+      pair_grad = at::empty({pairs, FM_PAIR_GRAD_STRIDE}, weights.options().dtype(at::kDouble));
       if (k_closed_form) {
         FM_CALL(fm_pose_solve_bwd_kinv, ptr(g_t), ptr(g_t_fwd), ptr(t_bwd), ptr<double>(aux), ptr(kinv), (int)b, (int)f, ptr<double>(pair_grad),
                 ptr<double>(kinv_acc), scope.stream);
@@ -559,7 +584,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       wsink->note_final(g_w);
       if (arena_used) wsink->on_leading_add = [arena](const Tensor& into, int64_t count) { arena->note_leading_add(into, count); };
     }
-    variable_list out(20);
+    variable_list out(21);
     if (from_depth) {
       out[0] = g_src;
       out[1] = g_k;
@@ -1084,10 +1109,11 @@ static std::tuple<Tensor, Tensor, Tensor> procrustes_fit_op(const OptTensor& dep
                                                     int64_t batch_repeat, const OptSink& sink, const OptSink& wsink, const OptArena& arena,
                                                     const OptTensor& plan_pixels,
                                                     const OptTensor& plan_first, const OptTensor& plan_vectors, const OptTensor& plan_weights,
-                                                    const OptTensor& dense_first, const OptTensor& dense_list, const OptTensor& work) {
+                                                    const OptTensor& plan_frame_first, const OptTensor& dense_first, const OptTensor& dense_list,
+                                                    const OptTensor& work) {
   auto out = ProcrustesFit::apply(depth, k, kinv, surfaces, weights, bwd_flow, indices, weight_sens, batch_repeat, sink_of(sink), sink_of(wsink),
                                   arena.has_value() ? *arena : c10::intrusive_ptr<GradArena>(), plan_pixels, plan_first, plan_vectors, plan_weights,
-                                  dense_first, dense_list, work, at::GradMode::is_enabled());
+                                  plan_frame_first, dense_first, dense_list, work, at::GradMode::is_enabled());
   if (sink.has_value() && *sink) (*sink)->fit_node = out[0].grad_fn().get();  // null when no graph is being built
   return {out[0], out[1], out[2]};
 }
@@ -1174,7 +1200,8 @@ TORCH_LIBRARY(flowmap_amd, m) {
       "procrustes_fit(Tensor? depth, Tensor? k, Tensor? kinv, Tensor? surfaces, Tensor weights, Tensor bwd_flow, Tensor? indices, float weight_sens, "
       "int batch_repeat, __torch__.torch.classes.flowmap_amd.DepthSink? sink, __torch__.torch.classes.flowmap_amd.DepthSink? wsink, "
       "__torch__.torch.classes.flowmap_amd.GradArena? arena, "
-      "Tensor? plan_pixels, Tensor? plan_first, Tensor? plan_vectors, Tensor? plan_weights, Tensor? dense_first, Tensor? dense_list, Tensor? work) "
+      "Tensor? plan_pixels, Tensor? plan_first, Tensor? plan_vectors, Tensor? plan_weights, Tensor? plan_frame_first, Tensor? dense_first, "
+      "Tensor? dense_list, Tensor? work) "
       "-> (Tensor, Tensor, Tensor)",
       fmt::procrustes_fit_op);
   m.def(
@@ -1200,6 +1227,7 @@ TORCH_LIBRARY(flowmap_amd, m) {
         "-> (Tensor, Tensor, Tensor)",
         fmt::softmin_intrinsics_op);
   m.def("random_subset(int n, int count, Device device, int seed, Tensor? state) -> Tensor", fmt::random_subset);
+  m.def("set_one_launch_backward(bool on) -> ()", fmt::set_one_launch_backward);
   m.def("flow_timing_enable(bool on) -> ()", fmt::flow_timing_enable);
   m.def("flow_timing_collect(bool tracking) -> float[]", fmt::flow_timing_collect);
 }

@@ -380,6 +380,21 @@ int fm_depth_gather_kgrad(const float* vectors, const int64_t* pixels, const int
                           long count, const float* kinv, int height, int width, float* grad_depth, const double* kinv_acc, int frames_k,
                           float* g_k, int accumulate, void* stream);
 
+/* The WHOLE backward of a planned sparse fit in one launch (fm_pose_solve_bwd_kinv + fm_procrustes_scatter with point_grads +
+ * fm_depth_gather_kgrad, projection.py:226-249 / procrustes.py:7-51 backward): one workgroup per frame (b, f) evaluates the
+ * correspondences of the two pairs the frame belongs to, keeps their gradient vectors in LDS and adds its slice of the gather
+ * plan into grad_depth (plain read-modify-writes, one writer per pixel), STORES grad_weights (B,F-1,H,W) at the sampled
+ * pixels of pair f and writes g_k[b, f] = [accumulate_k ? g_k : 0] − K⁻ᵀ·dK⁻¹·K⁻ᵀ with dK⁻¹ in closed form from `aux`.
+ * Depth source, batch_repeat 1, distinct `indices`, points <= FM_FIT_BWD_MAX_POINTS.  plan_* as fm_depth_gather takes them for
+ * fm_procrustes_scatter_plan; frame_first (B·F + 1) int32: index of the first plan pixel with key >= frame·H·W (the plan is
+ * sorted by key).  g_t_bwd / g_t_fwd (B·(F-1),4,4) may be NULL; grad_depth / grad_weights / g_k may be NULL. */
+#define FM_FIT_BWD_MAX_POINTS 2048
+int fm_procrustes_bwd_planned(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float weight_sensitivity,
+                              const int64_t* indices, long points, int batch, int frames, int height, int width, const double* aux,
+                              const float* t_bwd, const float* g_t_bwd, const float* g_t_fwd, const int64_t* plan_pixels,
+                              const int32_t* plan_first, const int32_t* plan_vectors, const float* plan_weights, const int32_t* frame_first,
+                              float* grad_depth, float* grad_weights, float* g_k, int accumulate_k, void* stream);
+
 /* The tail of IntrinsicsSoftmin.forward (flowmap/model/intrinsics/intrinsics_softmin.py:123-141):
  * soft = softmin((err - min err) * 10) over the N candidates (fp32), K = sum_n soft[n] * candidate_k[n],
  * repeated over `frames`.  err (B,N) fp64 as fm_softmin_score_fwd leaves it; candidate_k (N,3,3);

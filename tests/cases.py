@@ -230,6 +230,19 @@ def case_procrustes_planned_backward(dev):
         # planned steps have no float atomics on the big tensors (the small fp64 block sums before them
         # could still differ in a last bit between launches)
         assert_close(c, b_, 1e-6, abs_=1e-9, what=f"repeat {name}")
+    # round 3: the planned backward is ONE launch (fm_procrustes_bwd_planned, one workgroup per frame); the three launches it
+    # replaced (pose-solve backward, per-correspondence pass, planned gather) must give the same gradients
+    from flowmap_amd._lib import torch_ops
+
+    torch_ops().set_one_launch_backward(False)
+    try:
+        three = run(idx)
+    finally:
+        torch_ops().set_one_launch_backward(True)
+    assert _ops.counters["procrustes_planned"] == before + 3
+    for c, t3, name in zip(third, three, ("g_depth", "g_logits", "g_k")):
+        assert_close(c, t3, 1e-6, abs_=1e-9, what=f"one launch vs three {name}")
+    before += 1
     dup = idx.clone()
     dup[1] = dup[0]
     for _ in range(3):

@@ -1354,4 +1354,44 @@ int fm_depth_gather_kgrad(const float* vectors, const int64_t* pixels, const int
   return frames_k > 0 ? fm_intrinsics_inverse_bwd(kinv_acc, kinv, frames_k, g_k, accumulate, stream) : 0;
 }
 
+// The one-launch backward of the planned sparse fit: here the three steps it replaces, run one after the other, plus a check
+// that `frame_first` slices the plan the way the device kernel's per-frame blocks rely on.
+int fm_procrustes_bwd_planned(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float sens,
+                              const int64_t* indices, long points, int batch, int frames, int height, int width, const double* aux,
+                              const float* t_bwd, const float* g_t_bwd, const float* g_t_fwd, const int64_t* plan_pixels,
+                              const int32_t* plan_first, const int32_t* plan_vectors, const float* plan_weights, const int32_t* frame_first,
+                              float* grad_depth, float* grad_weights, float* g_k, int accumulate_k, void* stream) {
+  if (!(depth && kinv && bwd_flow && weights && indices && aux && t_bwd) || points < 1 || points > FM_FIT_BWD_MAX_POINTS) return 1;
+  if (grad_depth && !(plan_pixels && plan_first && plan_vectors && plan_weights && frame_first)) return 1;
+  const int pairs = batch * (frames - 1);
+  const int64_t n = (int64_t)height * width;
+  long count = 0;
+  if (grad_depth) {
+    count = frame_first[batch * frames];
+    if (frame_first[0] != 0) return 1;
+    for (int bf = 0; bf < batch * frames; ++bf) {
+      if (frame_first[bf] > frame_first[bf + 1]) return 1;
+      for (int m = frame_first[bf]; m < frame_first[bf + 1]; ++m) {
+        if (plan_pixels[m] / n != bf) return 1;
+        for (int e = plan_first[m]; e < plan_first[m + 1]; ++e) {  // the entries of a frame's pixels come from its two pairs only
+          const int v = plan_vectors[e], later = v & 1, pair = (v >> 1) / (int)points;
+          const int b = bf / frames, f = bf % frames;
+          if (pair != b * (frames - 1) + f - later) return 1;
+        }
+      }
+    }
+  }
+  std::vector<double> pair_grad((size_t)pairs * kPairGradStride), kinv_acc((size_t)batch * frames * 9);
+  std::vector<float> point_grads((size_t)pairs * points * 6);
+  if (fm_pose_solve_bwd_kinv(g_t_bwd, g_t_fwd, t_bwd, aux, kinv, batch, frames, pair_grad.data(), kinv_acc.data(), stream) != 0) return 2;
+  if (fm_procrustes_scatter(depth, kinv, nullptr, bwd_flow, weights, sens, indices, points, batch, 1, frames, height, width, aux, pair_grad.data(),
+                            nullptr, nullptr, grad_weights, nullptr, point_grads.data(), nullptr, stream) != 0)
+    return 2;
+  if (grad_depth && count > 0 &&
+      fm_depth_gather(point_grads.data(), plan_pixels, plan_first, plan_vectors, plan_weights, count, kinv, nullptr, nullptr, height, width, 0, grad_depth,
+                      stream) != 0)
+    return 2;
+  return g_k ? fm_intrinsics_inverse_bwd(kinv_acc.data(), kinv, batch * frames, g_k, accumulate_k, stream) : 0;
+}
+
 }  // extern "C"
