@@ -32,7 +32,8 @@ SIGNATURES = {
     "fm_flow_pack_inputs": [P, P, P, P, I, I, I, I, P, P],
     "fm_flow_loss_finalize": [P] * 6 + [I, I, F, F] + [P] * 4 + [P],
     "fm_flow_valid_norm": [P, P, L, F, P, P, P],
-    "fm_scale_if_needed": [P, L, P, L, P, P],
+    "fm_scale_if_needed": [P, L, P, L, P, P, P],
+    "fm_abi_version": [],
     "fm_softmin_blend_fwd": [P, P, I, I, I, P, P, P, P],
     "fm_softmin_blend_bwd": [P, P, P, I, I, I, P, P],
     "fm_softmin_score_fwd": [P, P, F, P, P, L, P, P, P, I, I, I, I, P, P],

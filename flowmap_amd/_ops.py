@@ -211,23 +211,38 @@ def announce_track_pixels(depth: Tensor, tracks) -> None:
     note_touched(depth, "tracking", plan[0])
 
 
-def touched_elements(depth: Tensor):
+def touched_elements(depth: Tensor, whole_frames=()):
     """(sorted unique flat indices, per-quad bit mask uint8 (numel/4)) of everything recorded by note_touched, built
-    once per combination of recorded sets; None when nothing was recorded or a 4-element quad layout does not apply."""
+    once per combination of recorded sets; None when nothing was recorded or a 4-element quad layout does not apply.
+    ``whole_frames`` (frame sharding: the halo frames, indices along dim 1 of a (1, F, H, W) depth): every element of these
+    frames is marked in the mask but left OUT of the index list — the caller updates them with a dense pass per frame."""
     root = _root(depth)
     registry = root.__dict__.get("_fm_touched")
     if not registry or depth.numel() % 4 != 0:
         return None
+    whole_frames = tuple(sorted(int(f) for f in whole_frames))
+    if whole_frames and (depth.dim() != 4 or depth.shape[0] != 1 or (depth.shape[2] * depth.shape[3]) % 4 != 0):
+        return None
 
     def build():
         keys = torch.unique(torch.cat([v.reshape(-1) for v in registry.values()]))
+        if whole_frames:
+            n = depth.shape[2] * depth.shape[3]
+            frame = torch.div(keys, n, rounding_mode="floor")
+            keep = torch.ones_like(keys, dtype=torch.bool)
+            for f in whole_frames:
+                keep &= frame != f
+            keys = keys[keep]
         mask = torch.zeros((depth.numel() // 4,), dtype=torch.uint8, device=depth.device)
         quad, bit = torch.div(keys, 4, rounding_mode="floor"), keys % 4
         for e in range(4):
             mask[quad[bit == e]] |= 1 << e
+        for f in whole_frames:
+            n4 = depth.shape[2] * depth.shape[3] // 4
+            mask[f * n4 : (f + 1) * n4] = 15
         return list(registry.values()), keys.contiguous(), mask
 
-    key = tuple((name, id(v), v._version) for name, v in sorted(registry.items())) + (depth.numel(),)
+    key = tuple((name, id(v), v._version) for name, v in sorted(registry.items())) + (depth.numel(), whole_frames)
     return _derived(root, "_fm_touched_union", key, build)[1:]
 
 
@@ -524,12 +539,17 @@ class FlowLossFused:
         # the per-(frame, direction) fp64 sums: a workspace kept on the mask tensor, zeroed once (the finalize launch leaves it zero)
         size = depth.shape[0] * depth.shape[1] * 2 * FLOW_ACC_STRIDE if depth.dim() == 4 else 0
         acc = _derived(mask_fwd, "_fm_flow_acc", (size, str(depth.device)), lambda: torch.zeros((size,), dtype=torch.float64, device=depth.device))
-        adam = (None, None, None, 0, [])
+        adam, ticket = (None, None, None, 0, [], None), None
         optimizer = _root(depth).__dict__.get("_fm_fused_adam")
         if optimizer is not None and sink is not None and torch.is_grad_enabled():
-            adam = optimizer.begin_in_pass(depth, sink, t_fwd, t_bwd) or adam
-        return torch_ops().flow_loss(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, int(kind), float(delta),
+            offer = optimizer.begin_in_pass(depth, sink, t_fwd, t_bwd)
+            if offer is not None:
+                adam, ticket = offer
+        loss = torch_ops().flow_loss(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, int(kind), float(delta),
                                      sink, int(items), acc, *adam)
+        if ticket is not None:  # the operator accepted the arguments and launched: only now does the optimiser's state advance
+            optimizer.commit_in_pass(ticket)
+        return loss
 
 
 def softmin_intrinsics(depth, weights, bwd_flow, indices, candidate_k, rel, weight_sens, frames):

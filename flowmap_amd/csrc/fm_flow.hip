@@ -20,6 +20,7 @@
 //   [4..12]  Ω = Σ ω ⊗ (z·[u,v,1])
 // from which flow_finalize_frame derives dL/dR, dL/dt, dL/dK⁻¹_src and dL/dK_dst.
 // DPP wave reduction -> LDS (fp64) -> one fp64 atomic per value per block.
+#include "../../include/flowmap_hip.h"
 #include "fm_device.h"
 #include "fm_pose.h"
 
@@ -324,11 +325,26 @@ struct FlowFinalizeParams {
 };
 
 // ONE block (frames read each other's sums — a frame's dL/dK has a destination-role part from its neighbours —
-// so the clearing of `acc` must wait for every frame: a block-wide barrier).
-__global__ void __launch_bounds__(256) flow_finalize_kernel(FlowFinalizeParams p) {
+// so the clearing of `acc` must wait for every frame: a block-wide barrier).  Four neighbouring lanes share a frame, one
+// per role (flow_finalize_role, fm_pose.h): the dependent fp64 chain per lane is one flow_dir_grads instead of four, and
+// the four parts of dL/dK meet in a quad reduction (two DPP-free shuffles of 9 doubles).
+constexpr int kFinalizeThreads = 1024;
+
+__global__ void __launch_bounds__(kFinalizeThreads) flow_finalize_kernel(FlowFinalizeParams p) {
   const int total = p.batch * p.frames;
-  for (int bf = threadIdx.x; bf < total; bf += blockDim.x)
-    flow_finalize_frame(p.acc, p.k, p.kinv, p.t_fwd, p.t_bwd, p.batch, p.frames, bf, p.ax, p.ay, p.g_t_fwd, p.g_t_bwd, p.g_k);
+  const int role = threadIdx.x & 3;
+  for (int bf0 = 0; bf0 < total; bf0 += kFinalizeThreads / 4) {  // (wave-uniform trip count)
+    const int bf = bf0 + (int)(threadIdx.x >> 2);
+    double gk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (bf < total) flow_finalize_role(p.acc, p.k, p.kinv, p.t_fwd, p.t_bwd, p.frames, bf, role, p.ax, p.ay, p.g_t_fwd, p.g_t_bwd, gk);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      gk[i] += __shfl_xor(gk[i], 1, kWave);  // (0 + 1), (2 + 3)
+      gk[i] += __shfl_xor(gk[i], 2, kWave);  // (0 + 1) + (2 + 3)
+    }
+    if (bf < total && role == 0)
+      for (int i = 0; i < 9; ++i) p.g_k[(size_t)bf * 9 + i] = (float)gk[i];
+  }
   // loss numerator: sum over all (frame, direction) in fp64 by one wave
   double s = 0.0;
   if (threadIdx.x < kWave)
@@ -398,9 +414,10 @@ __global__ void __launch_bounds__(256) pack_inputs_kernel(const float* flow_fwd,
 
 // In-place scale of gradient buffers by a device scalar, skipped entirely when the
 // scalar is exactly 1 (the autograd root case): every block exits after one load.
-__global__ void __launch_bounds__(256) scale_if_needed_kernel(float* x, long n, float* y, long ny, const float* s) {
+__global__ void __launch_bounds__(256) scale_if_needed_kernel(float* x, long n, float* y, long ny, const float* s, int* not_one) {
   const float sv = s[0];
   if (sv == 1.0f) return;
+  if (not_one && blockIdx.x == 0 && threadIdx.x == 0) *not_one = 1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n + ny; i += (long)gridDim.x * blockDim.x) {
     if (i < n) x[i] *= sv;
     else y[i - n] *= sv;
@@ -529,7 +546,7 @@ int fm_flow_loss_finalize(double* acc, const float* k, const float* kinv, const 
                           float* g_t_bwd, float* g_k, void* stream) {
   FM_CHECK_ARG(acc && k && kinv && t_fwd && t_bwd && norm && loss && g_t_fwd && g_t_bwd && g_k);
   FlowFinalizeParams p{acc, k, kinv, t_fwd, t_bwd, norm, loss, g_t_fwd, g_t_bwd, g_k, batch, frames, aspect_x, aspect_y};
-  hipLaunchKernelGGL(flow_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(flow_finalize_kernel, dim3(1), dim3(kFinalizeThreads), 0, (hipStream_t)stream, p);
   FM_LAUNCH_STATUS();
 }
 
@@ -561,12 +578,16 @@ int fm_flow_pack_inputs(const float* flow_fwd, const float* flow_bwd, const floa
   FM_LAUNCH_STATUS();
 }
 
-int fm_scale_if_needed(float* x, long count, float* y, long count_y, const float* scalar, void* stream) {
+int fm_abi_version(void) { return FM_ABI_VERSION; }
+
+int fm_scale_if_needed(float* x, long count, float* y, long count_y, const float* scalar, int* not_one, void* stream) {
   FM_CHECK_ARG(scalar && count >= 0 && count_y >= 0 && (x || count == 0) && (y || count_y == 0));
-  if (count + count_y == 0) return FM_OK;
+  if (count + count_y == 0 && !not_one) return FM_OK;
+  if (count + count_y == 0) count_y = 0;
   long blocks = (count + count_y + 256 * 8 - 1) / (256 * 8);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(scale_if_needed_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, count, y, count_y, scalar);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(scale_if_needed_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, count, y, count_y, scalar, not_one);
   FM_LAUNCH_STATUS();
 }
 

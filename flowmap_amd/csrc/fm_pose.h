@@ -277,21 +277,27 @@ FM_HD void flow_dir_grads(const double* a, const float* pose44, const float* kin
     }
 }
 
-FM_HD void flow_finalize_frame(const double* acc, const float* k_all, const float* kinv_all, const float* t_fwd, const float* t_bwd,
-                               int batch, int frames, int bf, float ax, float ay, float* g_t_fwd, float* g_t_bwd, float* g_k) {
-  (void)batch;
+// One of the four roles frame bf plays in the flow loss — 0: source of the forward term (into bf+1), 1: source of the
+// backward term (into bf−1), 2: destination of the forward term sourced at bf−1, 3: destination of the backward term sourced
+// at bf+1.  A source role writes its pair's dL/dT (g_t_fwd / g_t_bwd row) and contributes −K⁻ᵀ·(Rᵀ·S)·K⁻ᵀ to dL/dK[bf]
+// (kinv_grad_to_k is linear, so the two source roles need not be summed first); a destination role contributes rows 0, 1.
+// gk9 receives this role's part of dL/dK[bf] (zeros when the role does not exist at the ends of the video).  The device
+// kernel gives the four roles to four neighbouring lanes; flow_finalize_frame below (host double) runs them in turn.
+FM_HD void flow_finalize_role(const double* acc, const float* k_all, const float* kinv_all, const float* t_fwd, const float* t_bwd, int frames,
+                              int bf, int role, float ax, float ay, float* g_t_fwd, float* g_t_bwd, double* gk9) {
   const int f = bf % frames;
   const int b = bf / frames;
-  const float* kinv = kinv_all + (size_t)bf * 9;
   const size_t pair_f = (size_t)b * (frames - 1) + f;
-  double gkinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 9; ++i) gk9[i] = 0.0;
+  const bool needs_next = role == 0 || role == 3;  // roles that involve frame bf+1 / pair_f; the others frame bf−1 / pair_f−1
+  if (needs_next ? f >= frames - 1 : f <= 0) return;
   FlowDirGrads d;
-  for (int dir = 0; dir < 2; ++dir) {  // this frame in its SOURCE role
-    if (dir == 0 ? f >= frames - 1 : f <= 0) continue;
-    const float* pose = dir == 0 ? t_fwd + pair_f * 16 : t_bwd + (pair_f - 1) * 16;
-    const float* kdst = k_all + (size_t)(dir == 0 ? bf + 1 : bf - 1) * 9;
-    flow_dir_grads(acc + ((size_t)bf * 2 + dir) * kFlowAccStride, pose, kinv, kdst, ax, ay, d);
-    float* g_t44 = dir == 0 ? g_t_fwd + pair_f * 16 : g_t_bwd + (pair_f - 1) * 16;
+  if (role < 2) {
+    const float* kinv = kinv_all + (size_t)bf * 9;
+    const float* pose = role == 0 ? t_fwd + pair_f * 16 : t_bwd + (pair_f - 1) * 16;
+    const float* kdst = k_all + (size_t)(role == 0 ? bf + 1 : bf - 1) * 9;
+    flow_dir_grads(acc + ((size_t)bf * 2 + role) * kFlowAccStride, pose, kinv, kdst, ax, ay, d);
+    float* g_t44 = role == 0 ? g_t_fwd + pair_f * 16 : g_t_bwd + (pair_f - 1) * 16;
     for (int r = 0; r < 3; ++r) {  // dL/dR = S·K⁻ᵀ ; dL/dt
       for (int c = 0; c < 3; ++c) {
         double v = 0;
@@ -301,24 +307,34 @@ FM_HD void flow_finalize_frame(const double* acc, const float* k_all, const floa
       g_t44[r * 4 + 3] = (float)d.gt[r];
     }
     for (int c = 0; c < 4; ++c) g_t44[12 + c] = 0.f;
-    for (int r = 0; r < 3; ++r)  // dL/dK⁻¹ += Rᵀ·S
+    double gkinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < 3; ++r)  // dL/dK⁻¹ = Rᵀ·S
       for (int c = 0; c < 3; ++c)
         for (int j = 0; j < 3; ++j) gkinv[r * 3 + c] += (double)pose[j * 4 + r] * d.s[j * 3 + c];
-  }
-  double gk[9];
-  kinv_grad_to_k(gkinv, kinv, gk);
-  // DESTINATION role: frame f receives the forward term sourced at f-1 and the backward term
-  // sourced at f+1.
-  if (f > 0) {
+    kinv_grad_to_k(gkinv, kinv, gk9);
+  } else if (role == 2) {
     flow_dir_grads(acc + ((size_t)(bf - 1) * 2 + 0) * kFlowAccStride, t_fwd + (pair_f - 1) * 16, kinv_all + (size_t)(bf - 1) * 9,
                    k_all + (size_t)bf * 9, ax, ay, d);
-    for (int i = 0; i < 6; ++i) gk[i] += d.gkd[i];
-  }
-  if (f < frames - 1) {
+    for (int i = 0; i < 6; ++i) gk9[i] = d.gkd[i];
+  } else {
     flow_dir_grads(acc + ((size_t)(bf + 1) * 2 + 1) * kFlowAccStride, t_bwd + pair_f * 16, kinv_all + (size_t)(bf + 1) * 9,
                    k_all + (size_t)bf * 9, ax, ay, d);
-    for (int i = 0; i < 6; ++i) gk[i] += d.gkd[i];
+    for (int i = 0; i < 6; ++i) gk9[i] = d.gkd[i];
   }
+}
+
+FM_HD void flow_finalize_frame(const double* acc, const float* k_all, const float* kinv_all, const float* t_fwd, const float* t_bwd,
+                               int batch, int frames, int bf, float ax, float ay, float* g_t_fwd, float* g_t_bwd, float* g_k) {
+  (void)batch;
+  double gk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, part[9];
+  // (the order the device kernel's quad reduction adds them in: (0 + 1) + (2 + 3))
+  double pair01[9], pair23[9];
+  flow_finalize_role(acc, k_all, kinv_all, t_fwd, t_bwd, frames, bf, 0, ax, ay, g_t_fwd, g_t_bwd, pair01);
+  flow_finalize_role(acc, k_all, kinv_all, t_fwd, t_bwd, frames, bf, 1, ax, ay, g_t_fwd, g_t_bwd, part);
+  for (int i = 0; i < 9; ++i) pair01[i] += part[i];
+  flow_finalize_role(acc, k_all, kinv_all, t_fwd, t_bwd, frames, bf, 2, ax, ay, g_t_fwd, g_t_bwd, pair23);
+  flow_finalize_role(acc, k_all, kinv_all, t_fwd, t_bwd, frames, bf, 3, ax, ay, g_t_fwd, g_t_bwd, part);
+  for (int i = 0; i < 9; ++i) gk[i] = pair01[i] + (pair23[i] + part[i]);
   for (int i = 0; i < 9; ++i) g_k[(size_t)bf * 9 + i] = (float)gk[i];
 }
 

@@ -49,7 +49,7 @@ using OptTensor = std::optional<Tensor>;
   X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_pose_solve_bwd_kinv) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense) X(fm_procrustes_bwd_planned)                \
   X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_loss_fused_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
   X(fm_adam_step_capturable) X(fm_softmin_score_fwd) X(fm_softmin_score_bwd) X(fm_softmin_blend_fwd) X(fm_softmin_blend_bwd)         \
-  X(fm_random_subset) X(fm_random_subset_stateful)
+  X(fm_random_subset) X(fm_random_subset_stateful) X(fm_abi_version)
 
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
@@ -83,6 +83,8 @@ static void set_library(const std::string& path, bool test_double) {
   TORCH_CHECK(a.name != nullptr, "flowmap_amd: ", path, " does not export ", #name);
   FM_API_LIST(X)
 #undef X
+  TORCH_CHECK(a.fm_abi_version() == FM_ABI_VERSION, "flowmap_amd: ", path, " implements version ", a.fm_abi_version(),
+              " of the C ABI, this binding was built against version ", FM_ABI_VERSION, " (include/flowmap_hip.h): rebuild both");
   api_storage() = a;
 }
 
@@ -185,6 +187,7 @@ struct DepthSink : torch::CustomClassHolder {
   const torch::autograd::Node* fit_node = nullptr;        // the fit's autograd node (identity only): a loss parks its gradient
                                                           // only when its poses come from this node, i.e. the node WILL run later
   int64_t leading_in_place = 0, leading_dense = 0, planned_steps = 0;  // which path ran (tests)
+  bool in_pass_confirmed = false;  // the backward of a flow loss that applied the in-pass Adam update has run (FusedAdam.step checks)
 
   void arm(const Tensor& depth) {
     active = true;
@@ -651,6 +654,20 @@ static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor
     e1 = tm.create();
     tm.record(e0, scope.stream);
   }
+  // `acc` is self-cleaning (the finalize launch leaves it zero): if anything between the two launches fails, a persistent
+  // workspace would carry dirty sums into every later step — zero it before the error leaves this function
+  struct AccGuard {
+    Tensor acc;
+    bool armed;
+    ~AccGuard() {
+      if (armed && acc.defined()) {
+        try {
+          acc.zero_();
+        } catch (...) {
+        }
+      }
+    }
+  } acc_guard{persistent ? acc : Tensor(), true};
   if (exp_avg.defined()) {  // the depth parameter's Adam update applied by the same pass (fm_flow_loss_fused_adam)
     FM_CALL(fm_flow_loss_fused_adam, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd),
             ptr(mask_bwd), ptr(packed), ptr(norm), (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
@@ -668,6 +685,7 @@ static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor
   }
   FM_CALL(fm_flow_loss_finalize, ptr<double>(acc), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(norm), (int)b, (int)f, (float)w / scale,
           (float)h / scale, ptr(o.loss), ptr(o.g_tf), ptr(o.g_tb), ptr(o.g_k), scope.stream);
+  acc_guard.armed = false;
   return o;
 }
 
@@ -677,7 +695,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
                         const Tensor& mask_bwd_in, const Tensor& norm, const OptTensor& packed_o, int64_t kind, double delta,
                         const c10::intrusive_ptr<DepthSink>& sink, int64_t items, const OptTensor& acc_work, const OptTensor& exp_avg_o,
                         const OptTensor& exp_avg_sq_o, const OptTensor& touched_o, int64_t adam_step, std::vector<double> adam,
-                        bool grad_enabled, bool park) {
+                        const OptTensor& adam_flag_o, bool grad_enabled, bool park) {
     check_device({&depth_in, &k_in, &kinv_in, &t_fwd_in, &t_bwd_in, &flow_fwd_in, &flow_bwd_in, &mask_fwd_in, &mask_bwd_in, &norm});
     const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics");
     const Tensor t_fwd = f32c(t_fwd_in, "forward poses"), t_bwd = f32c(t_bwd_in, "backward poses");
@@ -715,6 +733,11 @@ struct FlowLossFused : public Function<FlowLossFused> {
     FlowLaunch run = flow_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, items, need,
                                  depth_in.requires_grad(), opt(acc_work), exp_avg, exp_avg_sq, touched, adam_step, adam);
     ctx->saved_data["in_pass_adam"] = in_pass_adam;
+    if (in_pass_adam && adam_flag_o.has_value() && adam_flag_o->defined()) {
+      TORCH_CHECK(adam_flag_o->scalar_type() == at::kInt && adam_flag_o->numel() == 1 && adam_flag_o->device() == depth.device(),
+                  "flowmap_amd: the in-pass Adam flag is one int32 on the depth tensor's device");
+      ctx->saved_data["adam_flag"] = *adam_flag_o;
+    }
     ctx->save_for_backward({depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed});
     ctx->saved_data["acc_work"] = opt(acc_work);
     ctx->saved_data["cfg"] = std::vector<int64_t>{kind, items};
@@ -727,7 +750,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    variable_list out(23);
+    variable_list out(24);
     if (!grads[0].defined()) return out;
     const auto saved = ctx->get_saved_variables();
     const Tensor &depth = saved[0], &k = saved[1], &t_fwd = saved[3];
@@ -751,10 +774,13 @@ struct FlowLossFused : public Function<FlowLossFused> {
     const Tensor g = grads[0].reshape({1}).to(at::kFloat).contiguous();
     {
       DeviceScope scope(g.device());
+      // (with the in-pass Adam update the gradient has ALREADY been used, unscaled: a scalar other than 1 raises the caller's flag)
+      Tensor flag = ctx->saved_data.count("adam_flag") ? ctx->saved_data["adam_flag"].toTensor() : Tensor();
       FM_CALL(fm_scale_if_needed, ptr(g_depth), g_depth.defined() ? (long)g_depth.numel() : 0L, ptr(small), (long)small.numel(), ptr(g),
-              scope.stream);
+              ptr<int>(flag), scope.stream);
     }
     auto sink = ctx->saved_data.count("sink") ? ctx->saved_data["sink"].toCustomClass<DepthSink>() : c10::intrusive_ptr<DepthSink>();
+    if (sink && ctx->saved_data["in_pass_adam"].toBool()) sink->in_pass_confirmed = true;
     if (sink && g_depth.defined() && sink->accepts(depth) && !sink->carried.defined()) {
       sink->carried = g_depth;  // returned (summed with the sparse parts) by the Procrustes fit's node, which runs later
       g_depth = Tensor();
@@ -1120,12 +1146,13 @@ static std::tuple<Tensor, Tensor, Tensor> procrustes_fit_op(const OptTensor& dep
 static Tensor flow_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& t_fwd, const Tensor& t_bwd, const Tensor& flow_fwd,
                            const Tensor& flow_bwd, const Tensor& mask_fwd, const Tensor& mask_bwd, const Tensor& norm, const OptTensor& packed,
                            int64_t kind, double delta, const OptSink& sink, int64_t items, const OptTensor& acc_work, const OptTensor& exp_avg,
-                           const OptTensor& exp_avg_sq, const OptTensor& touched, int64_t adam_step, std::vector<double> adam) {
+                           const OptTensor& exp_avg_sq, const OptTensor& touched, int64_t adam_step, std::vector<double> adam,
+                           const OptTensor& adam_flag) {
   auto s = sink_of(sink);
   // park dL/ddepth in the sink only when both pose tensors come from the fit that armed it: that node then runs after this one
   const bool park = s && s->fit_node != nullptr && reaches(t_fwd.grad_fn(), s->fit_node, 3) && reaches(t_bwd.grad_fn(), s->fit_node, 3);
   return FlowLossFused::apply(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, s, items, acc_work,
-                              exp_avg, exp_avg_sq, touched, adam_step, adam, at::GradMode::is_enabled(), park);
+                              exp_avg, exp_avg_sq, touched, adam_step, adam, adam_flag, at::GradMode::is_enabled(), park);
 }
 static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& ext, const Tensor& xy,
                                                         const Tensor& vis, const Tensor& seg, const Tensor& blocks, const Tensor& tiles,
@@ -1185,7 +1212,8 @@ TORCH_LIBRARY(flowmap_amd, m) {
       .def("leading_in_place", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->leading_in_place; })
       .def("leading_dense", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->leading_dense; })
       .def("planned_steps", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->planned_steps; })
-      .def("is_active", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->active; });
+      .def("is_active", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->active; })
+      .def("in_pass_confirmed", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->in_pass_confirmed; });
   m.class_<fmt::GradArena>("GradArena")
       .def(torch::init<>())
       .def("reused", [](const c10::intrusive_ptr<fmt::GradArena>& a) { return a->reused; })
@@ -1207,7 +1235,7 @@ TORCH_LIBRARY(flowmap_amd, m) {
   m.def(
       "flow_loss(Tensor depth, Tensor k, Tensor kinv, Tensor t_fwd, Tensor t_bwd, Tensor flow_fwd, Tensor flow_bwd, Tensor mask_fwd, Tensor mask_bwd, "
       "Tensor norm, Tensor? packed, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int items, Tensor? acc_work, "
-      "Tensor? exp_avg, Tensor? exp_avg_sq, Tensor? touched, int adam_step, float[] adam) -> Tensor",
+      "Tensor? exp_avg, Tensor? exp_avg_sq, Tensor? touched, int adam_step, float[] adam, Tensor? adam_flag) -> Tensor",
       fmt::flow_loss_op);
   m.def(
       "track_loss(Tensor depth, Tensor k, Tensor kinv, Tensor ext, Tensor xy, Tensor vis, Tensor seg, Tensor blocks, Tensor tiles, int[] counts, "

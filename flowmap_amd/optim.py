@@ -39,7 +39,9 @@ class FusedAdam(torch.optim.Optimizer):
                                       capturable=bool(capturable)))
         self.counters = {"sparse_updates": 0, "in_pass_updates": 0}  # (tests, bench notes)
         self._support = {}  # parameter -> element list outside which exp_avg / exp_avg_sq are exactly zero, or "dense"
-        self._in_pass = {}  # parameter -> (step number, element list) of an update the fused flow loss has already applied
+        self._scaled_flags = {}  # device -> int32 flag the flow loss's backward raises when its upstream gradient is not 1
+        self.verify_unit_upstream_every = 64  # steps between (synchronising) reads of that flag; 0 = never
+        self._in_pass = {}  # parameter -> (step number, element list, halo frames, the forward's DepthSink) of an update the fused flow loss has already applied
 
     # -- the depth parameter's update inside the fused flow loss (SURVEY.md §8f-2's end state) -----------------------
     def fuse_depth_update(self, param: torch.Tensor, enabled: bool = True, max_touched_fraction: float = 0.02) -> None:
@@ -53,11 +55,13 @@ class FusedAdam(torch.optim.Optimizer):
         What changes for the caller: the parameter moves during ``loss.forward`` instead of ``step()``; ``param.grad``
         is meaningful at those sparse pixels only; the loss must reach ``backward()`` unscaled (the update uses the
         gradient as the forward pass computes it) and cannot be differentiated twice.  It engages only when it can:
-        a sparse planned Procrustes fit, no weight decay, not capturable, no frame sharding, and at most
+        a sparse planned Procrustes fit, no weight decay, not capturable, and at most
         ``max_touched_fraction`` of the elements touched by other operators — the element-list update moves a 64-byte line
         per 4-byte element (≈0.08 ms per million elements on an MI355X) while the fused pass saves ≈0.25 ms per 138 M
         elements, so with the tracking loss at 720p (4.4 % touched) the separate update is the faster one and is kept;
-        otherwise the step runs as usual."""
+        otherwise the step runs as usual.  On a frame shard (flowmap_amd.sharding.FrameShard.prepare_model) the frames shared
+        with a neighbour count as touched whole: their gradient is complete only after the halo exchange, and ``step()``
+        updates them with one dense pass per frame; every interior frame is updated in the pass."""
         if not any(p is param for group in self.param_groups for p in group["params"]):
             raise ValueError("flowmap_amd.FusedAdam.fuse_depth_update: the parameter does not belong to this optimiser")
         if enabled:
@@ -115,22 +119,35 @@ class FusedAdam(torch.optim.Optimizer):
         return param in self._in_pass
 
     def begin_in_pass(self, depth: torch.Tensor, sink, t_fwd: torch.Tensor, t_bwd: torch.Tensor):
-        """Called by the fused flow loss: (exp_avg, exp_avg_sq, touched mask, step number, [lr, beta1, beta2, eps]) when the
-        update of the parameter behind ``depth`` can run inside its pass, else None."""
+        """Called by the fused flow loss.  -> None when the update of the parameter behind ``depth`` cannot run inside its
+        pass (the step then runs as usual), else ``(operator arguments, ticket)`` with the operator arguments
+        (exp_avg, exp_avg_sq, touched mask, step number, [lr, beta1, beta2, eps]).  NOTHING is committed here: the caller hands
+        the ticket to ``commit_in_pass`` once the operator has accepted its arguments and launched (an operator that
+        refuses — a width that is not a multiple of 4, a misaligned buffer — leaves the optimiser exactly as it was)."""
         from . import _ops
 
         param = depth if depth._base is None else depth._base
         group = next((g for g in self.param_groups if any(p is param for p in g["params"])), None)
-        if (group is None or group["weight_decay"] != 0 or group.get("capturable") or param.__dict__.get("_fm_sharded") or not param.is_contiguous()
-                or param.dtype != torch.float32
-                or depth.data_ptr() != param.data_ptr() or depth.numel() != param.numel() or param in self._in_pass):
+        if (group is None or group["weight_decay"] != 0 or group.get("capturable") or not param.is_contiguous() or param.dtype != torch.float32
+                or depth.data_ptr() != param.data_ptr() or depth.numel() != param.numel()):
             return None
+        if depth.dim() != 4 or depth.shape[-1] % 4 != 0 or depth.data_ptr() % 16 != 0:
+            return None  # the 16-byte vector path of the fused pass does not apply (fm_flow_loss_fused_adam would refuse)
+        if param in self._in_pass:
+            # the parameter has ALREADY moved in an earlier forward whose step() never came: a forward that was not followed by
+            # backward() + step() (a loss recomputed for logging, an exception, gradient accumulation over several forwards).
+            # Continuing would silently drop that step's update of every pixel outside the element list.
+            raise RuntimeError(
+                "flowmap_amd.FusedAdam: the fused flow loss has already applied this step's depth update (fuse_depth_update), but "
+                "optimizer.step() has not run since.  With fuse_depth_update every grad-enabled forward must be followed by backward() "
+                "and step(); evaluate under torch.no_grad() for logging, and switch fuse_depth_update off for gradient accumulation.")
         registry = param.__dict__.get("_fm_touched", {})
         if not torch_ops().flow_loss_parks(t_fwd, t_bwd, sink, "softmin" in registry):
             return None  # the gradient would not travel through the step's DepthSink (poses not from the fit, ...)
         if "procrustes" not in registry:
             return None  # the fit's backward is not planned (yet): the pixels it reads are not known
-        union = _ops.touched_elements(depth)
+        halo = tuple(param.__dict__.get("_fm_halo_frames", ()))  # frame sharding: frames whose gradient is complete only after the exchange
+        union = _ops.touched_elements(depth, halo)
         if union is None:
             return None
         elements, mask = union
@@ -141,12 +158,24 @@ class FusedAdam(torch.optim.Optimizer):
             state["step"] = torch.tensor(0.0, dtype=torch.float32)
             state["exp_avg"] = torch.zeros_like(param, memory_format=torch.preserve_format)
             state["exp_avg_sq"] = torch.zeros_like(param, memory_format=torch.preserve_format)
-        state["step"] += 1
-        step = int(state["step"].item())
-        self._in_pass[param] = (step, elements)
-        self.counters["in_pass_updates"] += 1
+        if state["exp_avg"].data_ptr() % 16 != 0 or state["exp_avg_sq"].data_ptr() % 16 != 0:
+            return None
+        step = int(state["step"].item()) + 1
         beta1, beta2 = group["betas"]
-        return (state["exp_avg"].view(depth.shape), state["exp_avg_sq"].view(depth.shape), mask, step, [float(group["lr"]), float(beta1), float(beta2), float(group["eps"])])
+        flag = self._scaled_flags.get(param.device)
+        if flag is None:  # raised by the loss's backward when its upstream gradient is not 1 (the in-pass update used the unscaled one)
+            flag = self._scaled_flags[param.device] = torch.zeros((1,), dtype=torch.int32, device=param.device)
+        args = (state["exp_avg"].view(depth.shape), state["exp_avg_sq"].view(depth.shape), mask, step,
+                [float(group["lr"]), float(beta1), float(beta2), float(group["eps"])], flag)
+        return args, (param, step, elements, halo, sink)
+
+    def commit_in_pass(self, ticket) -> None:
+        """The fused pass has launched with the arguments of ``begin_in_pass``: the step counter advances and ``step()`` will
+        finish the update (element list, halo frames) from the complete gradient."""
+        param, step, elements, halo, sink = ticket
+        self.state[param]["step"] += 1
+        self._in_pass[param] = (step, elements, halo, sink)
+        self.counters["in_pass_updates"] += 1
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -158,12 +187,22 @@ class FusedAdam(torch.optim.Optimizer):
             beta1, beta2 = group["betas"]
             for p in group["params"]:
                 if p in self._in_pass:  # the fused flow loss has updated every other element in its own pass
-                    step, elements = self._in_pass.pop(p)
-                    if p.grad is None:
-                        raise RuntimeError("flowmap_amd.FusedAdam: the flow loss applied the depth update but backward() never ran")
+                    step, elements, halo, sink = self._in_pass.pop(p)
+                    if p.grad is None or not sink.in_pass_confirmed():
+                        raise RuntimeError("flowmap_amd.FusedAdam: the flow loss applied the depth update (fuse_depth_update) but its backward() "
+                                           "never ran: the gradient of the pixels left to step() does not exist")
                     state = self.state[p]
-                    torch_ops().adam_step_elements(p, p.grad.contiguous(), state["exp_avg"], state["exp_avg_sq"], elements, step,
-                                                   float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), 0.0)
+                    grad = p.grad.contiguous()
+                    hyper = (float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), 0.0)
+                    for frame in halo:  # frame sharding: the frames shared with a neighbour, dense, from the exchanged (summed) gradient
+                        torch_ops().adam_step(p[frame], grad[frame], state["exp_avg"][frame], state["exp_avg_sq"][frame], step, None, *hyper)
+                    torch_ops().adam_step_elements(p, grad, state["exp_avg"], state["exp_avg_sq"], elements, step, *hyper)
+                    every = self.verify_unit_upstream_every
+                    if every and step % every == 0 and int(self._scaled_flags[p.device].item()) != 0:
+                        raise RuntimeError("flowmap_amd.FusedAdam: with fuse_depth_update the loss must reach backward() unscaled — the depth "
+                                           "update inside the flow pass used the gradient of the loss itself, but backward() delivered an upstream "
+                                           "gradient other than 1 (a scaled or averaged loss, a GradScaler): parameters and optimiser state of "
+                                           f"the last {every} steps are not those of torch.optim.Adam.  Switch fuse_depth_update off for this loop.")
                     continue
                 if p.grad is None:
                     continue

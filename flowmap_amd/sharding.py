@@ -7,7 +7,8 @@ frames i, i+1, so rank r owns a contiguous range of pairs [a_r, b_r) and the fra
 sits in the data path; per step there is
 
   * ONE packed all-reduce (sum) of [loss, the gradients of every shared parameter] — a few floats for
-    regressed intrinsics (what the reference's DDP all-reduces for them, overfit.py:94-108);
+    regressed intrinsics (what the reference's DDP all-reduces for them, overfit.py:94-108); a shared module with
+    millions of parameters goes through ``SharedGradientBuckets`` (25 MB buckets, reduced while backward still runs);
   * ONE neighbour exchange of the halo frame's dL/ddepth (N floats each way), because
     both owners of that frame hold a copy of its depth parameter; it is posted from a gradient hook the
     moment that gradient is final and overlaps the all-reduce;
@@ -67,11 +68,23 @@ class _FromRankZero(torch.autograd.Function):
 
 
 class FrameShard:
-    """Per-rank communication of the sharded optimisation step."""
+    """Per-rank communication of the sharded optimisation step.
 
-    def __init__(self, rank: int = 0, world: int = 1, dist=None, group=None):
-        self.rank, self.world, self.dist, self.group = rank, world, dist, group
+    Everything the step issues is asynchronous on the device and allocation-free after the first step — the packed
+    reduction buffer and the halo receive buffers are persistent — so the whole sharded step (collectives included: RCCL
+    work is stream-ordered) can be captured in a hipGraph (flowmap_amd.GraphedStep): no host wait, no per-step
+    ``torch.cat`` into a fresh tensor, no copy of the reduced values back into ``.grad`` (the parameters' gradients are
+    re-pointed at views of the reduced buffer).
+
+    ``proxy``: one rank's share of a `world`-GPU run on a single GPU (bench.py --share K): the process group has ONE member,
+    so every collective executes as a one-rank RCCL operation, and the halo exchange — which has no peer — is stood in for by
+    the local work it causes (a copy of the two boundary frames out, an accumulate of two received frames in)."""
+
+    def __init__(self, rank: int = 0, world: int = 1, dist=None, group=None, proxy: bool = False):
+        self.rank, self.world, self.dist, self.group, self.proxy = rank, world, dist, group, proxy
         self._halo = None  # (requests, recv_prev, recv_next, gradient) of the exchange in flight
+        self._halo_buffers = {}  # (shape, device) -> persistent receive (and proxy send) buffers
+        self._packed = None  # (key, buffer, views): [loss, gradients of the shared parameters] reduced in place every step
 
     @property
     def active(self) -> bool:
@@ -102,19 +115,21 @@ class FrameShard:
           length, and nothing downstream would ever reconcile them.  So rank 0 runs the sweep and broadcasts
           [K, softmin weights]; the gradient w.r.t. K is reduced back onto rank 0.  After the hand-over the
           regressed focal length is an ordinary shared parameter (sync() all-reduces its gradient).
-        * The halo exchange of dL/ddepth starts from a gradient hook, as soon as that gradient is final."""
+        * The halo exchange of dL/ddepth starts from a gradient hook, as soon as that gradient is final.
+        * The depth parameter is told which of its frames are shared with a neighbour (``_fm_halo_frames``): an in-pass
+          optimiser update (FusedAdam.fuse_depth_update) leaves those frames to a dense update after the exchange."""
         if not self.active:
             return
         from .model.intrinsics_softmin import IntrinsicsSoftmin
 
         intr = getattr(model, "intrinsics", None)
-        if isinstance(intr, IntrinsicsSoftmin):
+        if isinstance(intr, IntrinsicsSoftmin) and not self.proxy:
             intr.shard = self
         depth = getattr(getattr(model, "backbone", None), "depth", None)
         if depth is not None and depth.requires_grad:
             depth.register_post_accumulate_grad_hook(lambda param: self.start_halo_exchange(param.grad))
-            # the halo frames' gradient is complete only after the exchange: no in-pass optimiser update on a shard
-            depth.__dict__["_fm_sharded"] = True
+            halo = ([0] if self.rank > 0 else []) + ([depth.shape[0] - 1] if self.rank < self.world - 1 else [])
+            depth.__dict__["_fm_halo_frames"] = tuple(halo)
 
     def softmin_from_rank0(self, sweep, batch: int, candidates: int, frames: int, device):
         """``sweep() -> (K (b,frames,3,3), softmin weights (b,n))`` evaluated on rank 0 only -> the same pair on
@@ -129,13 +144,31 @@ class FrameShard:
         return k, packed[batch * 9 :].reshape(batch, candidates).detach()
 
     # -- per step -------------------------------------------------------------------------
+    def _packed_buffer(self, loss: Tensor, params):
+        """The persistent [loss, shared gradients] buffer and one view per parameter, rebuilt only when the parameter set
+        changes (which parameters carry a gradient can change once: the regressed focal length after the softmin hand-over)."""
+        key = (loss.device, tuple((id(p), tuple(p.shape)) for p in params))
+        if self._packed is None or self._packed[0] != key:
+            total = 1 + sum(p.numel() for p in params)
+            buffer = torch.zeros((total,), dtype=torch.float32, device=loss.device)
+            views, offset = [], 1
+            for p in params:
+                views.append(buffer[offset : offset + p.numel()].view(p.shape))
+                offset += p.numel()
+            self._packed = (key, buffer, views, list(params))
+        return self._packed[1], self._packed[2]
+
     def sync(self, loss: Tensor, shared_params, depth_param: Optional[Tensor], already_global: Optional[Tensor] = None) -> Tensor:
-        """All-reduce the scalar loss and the gradients of every SHARED parameter (intrinsics, a shared
-        backbone: what the reference's DDP all-reduces, overfit.py:94-108) in ONE packed buffer; sum the
-        halo frame's depth gradient with the neighbours (the exchange usually started from the gradient hook
-        and overlaps the all-reduce).  Returns the global loss (detached).  ``loss`` is this rank's share (the
-        flow term); ``already_global`` (the value ``tracking_loss`` returns) is added after the reduction.
-        ``shared_params``: a parameter, a list of parameters, or None.  No-op for world == 1."""
+        """All-reduce the scalar loss and the gradients of every SHARED parameter (intrinsics, a small shared module:
+        what the reference's DDP all-reduces, overfit.py:94-108) in ONE packed buffer; sum the halo frame's depth
+        gradient with the neighbours (the exchange usually started from the gradient hook and overlaps the
+        all-reduce).  Returns the global loss (detached).  ``loss`` is this rank's share (the flow term);
+        ``already_global`` (the value ``tracking_loss`` returns) is added after the reduction.
+        ``shared_params``: a parameter, a list of parameters, or None.  No-op for world == 1.
+
+        Afterwards every shared parameter's ``.grad`` IS a view of the reduced buffer (no copy back); the buffer is
+        rewritten by the next call.  A shared module with millions of parameters should use ``SharedGradientBuckets``
+        instead (bucketed, overlapped with backward)."""
         extra = 0.0 if already_global is None else already_global.detach()
         if not self.active:
             return loss.detach() if already_global is None else loss.detach() + extra
@@ -145,42 +178,59 @@ class FrameShard:
         elif torch.is_tensor(shared_params):
             shared_params = [shared_params]
         with_grad = [p for p in shared_params if p.grad is not None]
-        if depth_param is not None and depth_param.grad is not None and self._halo is None:
-            self.start_halo_exchange(depth_param.grad)  # (no hook registered: start it now)
-        packed = torch.cat([loss.detach().reshape(1).to(torch.float32)] + [p.grad.reshape(-1).to(torch.float32) for p in with_grad])
+        if depth_param is not None and depth_param.grad is not None:
+            self.start_halo_exchange(depth_param.grad)  # (no hook registered: start it now; a no-op when the hook has posted it)
+        packed, views = self._packed_buffer(loss, with_grad)
+        with torch.no_grad():
+            pieces = [loss.detach().reshape(1).to(torch.float32)] + [p.grad.reshape(-1).to(torch.float32) for p in with_grad]
+            torch.cat(pieces, out=packed)  # one launch, into the persistent buffer
         work = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.finish_halo_exchange()
-        work.wait()
-        offset = 1
-        for p in with_grad:
-            n = p.grad.numel()
-            p.grad.copy_(packed[offset : offset + n].reshape(p.grad.shape))
-            offset += n
+        work.wait()  # (RCCL: a stream dependency, not a host wait; gloo: blocks)
+        for p, view in zip(with_grad, views):
+            p.grad = view
         return packed[0] + extra
+
+    def _halo_buffer(self, like: Tensor, which: str) -> Tensor:
+        key = (which, tuple(like.shape), like.device, like.dtype)
+        buf = self._halo_buffers.get(key)
+        if buf is None:
+            buf = self._halo_buffers[key] = torch.zeros_like(like)
+        return buf
 
     def start_halo_exchange(self, depth_grad: Tensor) -> None:
         """depth_grad (F_local, H, W): the LAST local frame is rank+1's FIRST local frame; post the sends and
         receives of the two boundary frames (asynchronous)."""
-        if not self.active or self._halo is not None:
+        if not self.active:
             return
+        if self._halo is not None:
+            if self._halo[3] is depth_grad and self._halo[4] == depth_grad._version:
+                return  # already posted for this very gradient (the hook ran, sync() asks again)
+            self.finish_halo_exchange()  # a backward that never reached sync(): complete it (every rank does) before the next one
         dist = self.dist
         ops, recv_prev, recv_next = [], None, None
         if self.rank > 0:
-            recv_prev = torch.empty_like(depth_grad[0])
-            ops.append(dist.P2POp(dist.isend, depth_grad[0].contiguous(), self.rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, recv_prev, self.rank - 1, self.group))
+            recv_prev = self._halo_buffer(depth_grad[0], "prev")
+            if self.proxy:
+                self._halo_buffer(depth_grad[0], "send_prev").copy_(depth_grad[0])  # what the link would read
+            else:
+                ops.append(dist.P2POp(dist.isend, depth_grad[0].contiguous(), self.rank - 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, recv_prev, self.rank - 1, self.group))
         if self.rank < self.world - 1:
-            recv_next = torch.empty_like(depth_grad[-1])
-            ops.append(dist.P2POp(dist.isend, depth_grad[-1].contiguous(), self.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, recv_next, self.rank + 1, self.group))
-        self._halo = (dist.batch_isend_irecv(ops) if ops else [], recv_prev, recv_next, depth_grad)
+            recv_next = self._halo_buffer(depth_grad[-1], "next")
+            if self.proxy:
+                self._halo_buffer(depth_grad[-1], "send_next").copy_(depth_grad[-1])
+            else:
+                ops.append(dist.P2POp(dist.isend, depth_grad[-1].contiguous(), self.rank + 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, recv_next, self.rank + 1, self.group))
+        self._halo = (dist.batch_isend_irecv(ops) if ops else [], recv_prev, recv_next, depth_grad, depth_grad._version)
 
     def finish_halo_exchange(self) -> None:
         """Wait for the exchange and add the neighbours' parts: both copies of a shared frame end up with
-        the sum of the two partial gradients."""
+        the sum of the two partial gradients.  (Proxy: the receive buffers hold zeros — same launches, unchanged values.)"""
         if self._halo is None:
             return
-        requests, recv_prev, recv_next, depth_grad = self._halo
+        requests, recv_prev, recv_next, depth_grad, _ = self._halo
         self._halo = None
         for req in requests:
             req.wait()
@@ -192,6 +242,90 @@ class FrameShard:
     def exchange_halo(self, depth_grad: Tensor) -> None:
         self.start_halo_exchange(depth_grad)
         self.finish_halo_exchange()
+
+
+class SharedGradientBuckets:
+    """Gradient all-reduce of a SHARED module with many parameters under frame sharding — north_star's "RCCL all-reduce of
+    the intrinsics/shared-backbone gradients"; in the reference the shared backbone is BackboneMidas (~10⁷ parameters,
+    backbone_midas.py:42-127) and the mechanism Lightning's DDP strategy (overfit.py:94-108).
+
+    Parameters are laid out, in REVERSE registration order (the order backward produces their gradients in, as DDP
+    assumes), into flat persistent buckets of about ``bucket_mb`` (25 MB, DDP's default; over xGMI a ring all-reduce of a
+    25 MB bucket on 8 GPUs moves 2·7/8·25 MB per link ≈ 0.3 ms at ≈150 GB/s, well above the ≈20 µs launch latency).
+    A post-accumulate-grad hook copies a parameter's gradient into its slot and re-points ``.grad`` at the slot (one copy; the
+    optimiser then reads the bucket); when the last slot of a bucket is filled its all-reduce is launched asynchronously, so
+    the reduction of the late layers' buckets overlaps the backward of the early layers.  ``finish()`` (call it where
+    ``FrameShard.sync`` is called) waits for every bucket and, for ``average=True``, divides by the world size —
+    frame-pair sharding wants the SUM (every rank holds different loss terms), so the default is False.
+
+    A parameter that gets no gradient in a step leaves its bucket incomplete: ``finish()`` zero-fills the missing slots and
+    reduces the bucket then (no overlap for that bucket, same result)."""
+
+    def __init__(self, shard: FrameShard, params, bucket_mb: float = 25.0, average: bool = False):
+        self.shard, self.average = shard, average
+        self.params = [p for p in params if p.requires_grad]
+        limit = max(1, int(bucket_mb * (1 << 20) // 4))
+        self.buckets = []  # [buffer, [(param, view)], filled count, work]
+        current, size = [], 0
+        for p in reversed(self.params):
+            if current and size + p.numel() > limit:
+                self._close(current, size)
+                current, size = [], 0
+            current.append(p)
+            size += p.numel()
+        if current:
+            self._close(current, size)
+        self._where = {}
+        for bi, bucket in enumerate(self.buckets):
+            for p, view in bucket[1]:
+                self._where[id(p)] = (bi, view)
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _close(self, params, size):
+        first = params[0]
+        buffer = torch.zeros((size,), dtype=first.dtype, device=first.device)
+        slots, offset = [], 0
+        for p in params:
+            slots.append((p, buffer[offset : offset + p.numel()].view(p.shape)))
+            offset += p.numel()
+        self.buckets.append([buffer, slots, 0, None])
+
+    def _launch(self, bucket):
+        dist = self.shard.dist
+        bucket[3] = dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=self.shard.group, async_op=True)
+
+    def _on_grad(self, param):
+        bi, view = self._where[id(param)]
+        bucket = self.buckets[bi]
+        if param.grad is not view:
+            with torch.no_grad():
+                view.copy_(param.grad)
+            param.grad = view
+        bucket[2] += 1
+        if bucket[2] == len(bucket[1]) and self.shard.active:
+            self._launch(bucket)
+
+    def finish(self) -> None:
+        for bucket in self.buckets:
+            if bucket[3] is None and self.shard.active:
+                with torch.no_grad():
+                    for p, view in bucket[1]:
+                        if p.grad is None:
+                            view.zero_()
+                        elif p.grad is not view:  # (a gradient that arrived without the hook firing)
+                            view.copy_(p.grad)
+                            p.grad = view
+                self._launch(bucket)
+            if bucket[3] is not None:
+                bucket[3].wait()
+                bucket[3] = None
+            if self.average and self.shard.active:
+                bucket[0].div_(self.shard.world)
+            bucket[2] = 0
+
+    def remove(self) -> None:
+        for h in self._handles:
+            h.remove()
 
 
 class _GatherPoses(torch.autograd.Function):

@@ -34,6 +34,12 @@ extern "C" {
 #define FM_MAPPING_L2 2    /* flowmap/loss/mapping/mapping_l2.py:15-21 */
 
 #define FM_FLOW_ACC_STRIDE 20  /* doubles per (frame, direction) in `acc` */
+/* Version of this interface: bumped whenever an entry point changes its arguments or its contract (round 3: the workspaces of
+ * fm_flow_loss_fused / fm_procrustes_fit_chain are self-cleaning — zero on entry, left zero — instead of being cleared by the
+ * call; fm_scale_if_needed reports a non-unit scalar).  A binding checks fm_abi_version() == FM_ABI_VERSION when it loads the library. */
+#define FM_ABI_VERSION 3
+int fm_abi_version(void);
+
 #define FM_STAT_STRIDE 16      /* doubles per pair in `stats` */
 #define FM_AUX_STRIDE 40       /* doubles per pair in `aux` */
 #define FM_PAIR_GRAD_STRIDE 20 /* doubles per pair in `pair_grad` */
@@ -102,8 +108,10 @@ int fm_flow_valid_norm(const float* mask_fwd, const float* mask_bwd, long count,
                        void* stream);
 
 /* x[i] *= scalar[0] and y[i] *= scalar[0] unless scalar[0] == 1 (autograd's grad_output at the
- * root); either buffer may be NULL with a count of 0. */
-int fm_scale_if_needed(float* x, long count, float* y, long count_y, const float* scalar, void* stream);
+ * root); either buffer may be NULL with a count of 0.  not_one (optional, one int32 on the device): set to 1 when
+ * scalar[0] != 1 and left alone otherwise — the in-pass Adam update (fm_flow_loss_fused_adam) has used the UNSCALED gradient
+ * by then, so its caller watches this flag (round 3; FM_ABI_VERSION 3). */
+int fm_scale_if_needed(float* x, long count, float* y, long count_y, const float* scalar, int* not_one, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Procrustes pose fit.  Replaces align_surfaces (projection.py:213-252) +

@@ -1179,16 +1179,75 @@ def case_in_pass_adam_refusals(dev):
             optimizer.step()
         assert optimizer.counters["in_pass_updates"] == 0 and optimizer.counters["sparse_updates"] == 3
 
-        # a frame shard (FrameShard.prepare_model marks the parameter): the halo frames' gradient is complete only after the exchange
+        # a frame shard (FrameShard.prepare_model marks the frames shared with a neighbour): those frames' gradient is complete only
+        # after the exchange, so the pass leaves them whole to step(), which updates them densely; every interior frame is
+        # updated in the pass.  Same trajectory as torch.optim.Adam.
+        model, batch, flows, loss_of = _small_problem(dev, tracking=False)
+        twin, _, _, twin_loss = _small_problem(dev, tracking=False)
+        optimizer, reference = FusedAdam(model.parameters(), lr=1e-3), torch.optim.Adam(twin.parameters(), lr=1e-3)
+        optimizer.fuse_depth_update(model.backbone.depth, max_touched_fraction=1.0)
+        frames = model.backbone.depth.shape[0]
+        model.backbone.depth.__dict__["_fm_halo_frames"] = (0, frames - 1)
+        for step in range(6):
+            for m, o, fn in ((model, optimizer, loss_of), (twin, reference, twin_loss)):
+                o.zero_grad(set_to_none=True)
+                fn(m(batch, flows, step)).backward()
+                o.step()
+            assert_close(model.backbone.depth.detach(), twin.backbone.depth.detach(), 2e-6, abs_=2e-6, what=f"depth (halo frames dense) step {step}")
+        assert optimizer.counters["in_pass_updates"] == 5  # (step 0: the fit's backward is not planned yet)
+        state = optimizer.state[model.backbone.depth]
+        assert float(state["step"]) == 6
+        for name in ("exp_avg", "exp_avg_sq"):
+            assert_close(state[name], reference.state[twin.backbone.depth][name], 1e-4, abs_=1e-12, what=f"{name} with halo frames")
+
+        # a width the 16-byte path does not take (f=5, 24x30): the update must NOT engage, and nothing may be left pending
+        model, batch, flows, loss_of = _small_problem(dev, h=24, w=30, tracking=False)
+        twin, _, _, twin_loss = _small_problem(dev, h=24, w=30, tracking=False)
+        optimizer, reference = FusedAdam(model.parameters(), lr=1e-3), torch.optim.Adam(twin.parameters(), lr=1e-3)
+        optimizer.fuse_depth_update(model.backbone.depth, max_touched_fraction=1.0)
+        for step in range(5):
+            for m, o, fn in ((model, optimizer, loss_of), (twin, reference, twin_loss)):
+                o.zero_grad(set_to_none=True)
+                fn(m(batch, flows, step)).backward()
+                o.step()
+            assert not optimizer.in_pass_pending(model.backbone.depth)
+            assert_close(model.backbone.depth.detach(), twin.backbone.depth.detach(), 2e-6, abs_=2e-6, what=f"depth at width 30, step {step}")
+        assert optimizer.counters["in_pass_updates"] == 0 and float(optimizer.state[model.backbone.depth]["step"]) == 5
+
+        # a grad-enabled forward that never reaches backward() + step() (a loss recomputed for logging): the parameter has moved,
+        # so the NEXT forward refuses loudly instead of silently dropping the dense part of that step; step() without
+        # backward refuses too; a forward under no_grad is fine
         model, batch, flows, loss_of = _small_problem(dev, tracking=False)
         optimizer = FusedAdam(model.parameters(), lr=1e-3)
         optimizer.fuse_depth_update(model.backbone.depth, max_touched_fraction=1.0)
-        model.backbone.depth.__dict__["_fm_sharded"] = True
-        for step in range(4):
+        for step in range(3):
             optimizer.zero_grad(set_to_none=True)
             loss_of(model(batch, flows, step)).backward()
             optimizer.step()
-        assert optimizer.counters["in_pass_updates"] == 0
+        with torch.no_grad():
+            loss_of(model(batch, flows, 3))
+        assert not optimizer.in_pass_pending(model.backbone.depth)
+        optimizer.zero_grad(set_to_none=True)
+        loss_of(model(batch, flows, 3))  # applied in the pass, then abandoned
+        assert optimizer.in_pass_pending(model.backbone.depth)
+        with pytest.raises(RuntimeError, match="never ran"):
+            optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+        loss_of(model(batch, flows, 3))
+        with pytest.raises(RuntimeError, match="has not run since"):
+            loss_of(model(batch, flows, 3))
+
+        # a scaled loss: the in-pass update has used the unscaled gradient — reported at the next verification step
+        model, batch, flows, loss_of = _small_problem(dev, tracking=False)
+        optimizer = FusedAdam(model.parameters(), lr=1e-3)
+        optimizer.fuse_depth_update(model.backbone.depth, max_touched_fraction=1.0)
+        optimizer.verify_unit_upstream_every = 2
+        with pytest.raises(RuntimeError, match="unscaled"):
+            for step in range(6):
+                optimizer.zero_grad(set_to_none=True)
+                (0.5 * loss_of(model(batch, flows, step))).backward()
+                optimizer.step()
+        assert optimizer.counters["in_pass_updates"] >= 1
 
         # the element-list update of the weight logits: not when the gradient was edited after backward (clipping) —
         # the dense update runs, and the list is taken up again once the moments are verified zero elsewhere

@@ -404,8 +404,11 @@ int fm_adam_step_capturable(float* param, const float* grad, float* exp_avg, flo
   return fm_adam_step(param, grad, exp_avg, exp_avg_sq, count, (long)step[0], lr, beta1, beta2, eps, weight_decay, stream);
 }
 
-int fm_scale_if_needed(float* x, long count, float* y, long count_y, const float* scalar, void*) {
+int fm_abi_version(void) { return FM_ABI_VERSION; }
+
+int fm_scale_if_needed(float* x, long count, float* y, long count_y, const float* scalar, int* not_one, void*) {
   if (scalar[0] == 1.0f) return 0;
+  if (not_one) *not_one = 1;
   for (long i = 0; i < count; ++i) x[i] *= scalar[0];
   for (long i = 0; i < count_y; ++i) y[i] *= scalar[0];
   return 0;
