@@ -25,6 +25,12 @@ all-reduce of [loss, shared-parameter gradients], a neighbour exchange of the ha
 tracking an all-gather of the poses and an all-reduce of their gradients); `weak` (c4) gives every rank its
 own 150-frame shard.  `value` is whole-job throughput either way: iterations of the whole workload per second.
 
+Strong scaling on ONE GPU (`--share K [--share-rank R]`): rank R's share of a K-GPU strong-scaling run — its pairs, its halo
+frames, every collective executed on a one-rank RCCL communicator, the halo exchange stood in for by the local copies and
+adds it causes (flowmap_amd.sharding.FrameShard(proxy=True)) — i.e. everything a rank does per step except the time its
+bytes spend on xGMI.  `--graph` replays the step (collectives included) as one hipGraph.  tools/scaling_proxy.sh runs
+K = 1, 2, 4, 8 eager and graphed -> profiles/r03_strong_scaling_proxy.jsonl; DESIGN.md §5 turns it into a projection.
+
 Prints ONE JSON line (rank 0) with `roofline` for the fused flow kernel (HIP events on its launch stream
 inside the timed region), `roofline_tracking` when the tracking loss runs (track_pairs: VALU-bound, GFLOP/s)
 and, at N = 1, `cpu_baseline` (the oracle — a PyTorch-CPU port of the reference path — timed on a bounded
@@ -74,8 +80,11 @@ def parse():
     ap.add_argument("--tracking", action="store_true", help="add the tracking loss to any config (c2 = c1 --tracking)")
     ap.add_argument("--points", type=int, default=1000,
                     help="Procrustes points (config/model/extrinsics/procrustes.yaml:3); 0 = all pixels (ablation_explicit_depth.yaml:11-12)")
-    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=-1,
+                    help="frames of the CPU-baseline leg, taken from the front of the SAME inputs the GPU leg runs on (0 = skip; default: the whole "
+                         "video when the host has >= 96 GB of free memory — one iteration of 150 x 720p takes the oracle ~40 GB and ~30 s — "
+                         "else a 32-frame sample, labelled as such)")
+    ap.add_argument("--cpu-iters", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads for the CPU baseline (16 measured fastest on the 256-thread EPYC 9575F host: "
                     "8 -> 0.42, 16 -> 0.25, 32 -> 0.35, 64 -> 0.45, 256 -> 5.2 s/iter at 4 frames @720p)")
@@ -87,7 +96,12 @@ def parse():
                          "torch.optim.Adam; the headline metric is fwd+bwd only (none)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step in a hipGraph (flowmap_amd.GraphedStep) and replay it: for the launch-bound regime "
-                         "(small frames); single GPU only")
+                         "(small frames, or a rank's share of a strong-scaling run); the sharded step's RCCL collectives are captured too")
+    ap.add_argument("--share", type=int, default=0,
+                    help="K > 0: run ONE rank's share of a K-GPU strong-scaling run on this GPU (its pairs + halo frames, collectives on a "
+                         "one-rank RCCL communicator): the per-rank step time of a K-GPU run without the wire time")
+    ap.add_argument("--share-rank", type=int, default=-1, help="which rank's share (default: an interior rank with the largest share)")
+    ap.add_argument("--count-launches", action="store_true", help="count the kernel launches of one step with torch.profiler (after the timed region)")
     return ap.parse_args()
 
 
@@ -211,29 +225,47 @@ def make_tracks(f, device, seed, scene=None, hw=None, interval=5, radius=20, gri
     return out
 
 
-def cpu_baseline(frames, h, w, points, iters, threads):
-    """The oracle (PyTorch CPU port of the reference path) on a bounded sample: same frame size, fewer frames;
-    forward + backward on `threads` host cores."""
+def cpu_baseline(depth, wlogit, flows, focal, frames, h, w, points, iters, threads):
+    """The oracle (PyTorch CPU port of the reference path) on the first `frames` frames of the SAME inputs the GPU leg
+    runs on (copied to the host once): forward + backward on `threads` host cores."""
     from oracle import flowmap_oracle as orc
 
     cores = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(cores)
-    depth, wlogit, flows = orc.synth_iid(frames, h, w, seed=0)
-    depth.requires_grad_(True)
-    wlogit.requires_grad_(True)
-    focal = torch.tensor(0.85, requires_grad=True)
+    depth = depth[:frames].detach().cpu().clone().requires_grad_(True)
+    wlogit = wlogit[: frames - 1].detach().cpu().clone().requires_grad_(True)
+    oflows = orc.OFlows(*(x[:, : frames - 1].detach().cpu().contiguous() for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)))
+    focal = torch.tensor(float(focal), requires_grad=True)
 
     def step():
         for p in (depth, wlogit, focal):
             p.grad = None
-        total, _, _ = orc.explicit_depth_step(depth, wlogit, focal, flows, (h, w), num_points=points)
+        total, _, _ = orc.explicit_depth_step(depth, wlogit, focal, oflows, (h, w), num_points=points)
         total.backward()
+        return float(total.detach())
 
-    step()  # warm-up
+    t0 = time.perf_counter()
+    loss = step()  # warm-up (allocator, page faults: ~40 GB of autograd temporaries at 150 x 720p)
+    first = time.perf_counter() - t0
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
-    return (time.perf_counter() - t0) / iters, cores
+    return (time.perf_counter() - t0) / iters, cores, first, loss
+
+
+def count_launches(step, device):
+    """Kernel launches of one step, counted by torch.profiler's device activity (None when the profiler is unavailable)."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            step()
+            torch.cuda.synchronize(device)
+        names = [e.name for e in prof.events() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower()
+                 and not e.name.lower().startswith(("memcpy", "memset"))]
+        return len(names), sorted(set(names))
+    except Exception as exc:  # noqa: BLE001
+        return None, [f"torch.profiler failed: {exc}"]
 
 
 def _reserve_stdout():
@@ -255,7 +287,9 @@ def main():
     # tests/test_bench_dryrun.py runs this file's multi-rank glue over gloo with CPU tensors and the host test double
     # injected by its launcher; without that launcher CPU tensors raise in the first operator (there is no CPU path)
     on_gpu = os.environ.get("FLOWMAP_BENCH_DEVICE", "cuda") == "cuda"
-    if world > 1 or os.environ.get("FLOWMAP_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one GPU
+    if args.share and world > 1:
+        raise SystemExit("--share K runs one rank's share on ONE process")
+    if world > 1 or args.share > 1:  # --share: a one-rank process group, so that every collective of the sharded step executes
         import torch.distributed as dist
 
         for key, value in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
@@ -286,8 +320,18 @@ def main():
             cfg[key] = getattr(args, key)
     cfg["tracking"] = cfg["tracking"] or args.tracking
     f_video, h, w = cfg["frames"], cfg["height"], cfg["width"]
-    strong = cfg["scaling"] == "strong" and world > 1
+    # the (rank, world) the VIDEO is cut for: the process group's, or — `--share K` — rank R of K on this one GPU
+    cut_world, cut_rank = (args.share, args.share_rank) if args.share > 1 else (world, rank)
+    if args.share > 1 and cut_rank < 0:
+        cut_rank = 1 if args.share > 2 else 0  # an interior rank (two neighbours) with the largest share
+    if args.share > 1 and not 0 <= cut_rank < args.share:
+        raise SystemExit("--share-rank must be in [0, K)")
+    strong = (cfg["scaling"] == "strong" and world > 1) or args.share > 1
     flowmap_amd.set_lazy_surfaces(True)
+    if os.environ.get("FLOWMAP_THREE_LAUNCH_BWD"):  # A/B: the planned Procrustes backward as the three launches of round 2
+        from flowmap_amd._lib import torch_ops
+
+        torch_ops().set_one_launch_backward(False)
 
     # ---- inputs: the whole video of this rank's job, then (strong scaling) its shard of it ----
     seed = 1 if (strong or world == 1) else 1 + rank  # strong: every rank builds the SAME video and keeps its frames
@@ -295,12 +339,14 @@ def main():
     depth, wlogit, flows, scene = maker(f_video, h, w, device, seed)
     tracks = None
     if cfg["tracking"]:
+        if args.share > 1:
+            raise SystemExit("--share with the tracking loss: the pose all-gather needs the other ranks' poses; run the flow loss")
         if world > 1 and not strong:
             raise SystemExit("--tracking with weak scaling: every rank would need its own track set over a shared video; use --scaling strong")
         tracks = make_tracks(f_video, device, seed=100, scene=scene, hw=(h, w))
     total_pairs = f_video - 1
     if strong:
-        a, b = shard_pairs(total_pairs, world)[rank]
+        a, b = shard_pairs(total_pairs, cut_world)[cut_rank]
         lo, hi = shard_frames((a, b))
         depth, wlogit = depth[lo : hi + 1].clone(), wlogit[a:b].clone()
         flows = Flows(*(x[:, a:b].contiguous() for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)))
@@ -332,20 +378,17 @@ def main():
         from flowmap_amd.loss import LossTracking, LossTrackingCfg
 
         track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
-    shard = FrameShard(rank, world if dist is None else max(world, 1), dist)
-    if dist is not None and world == 1:
-        shard.world = 2  # single-rank RCCL self-test: run the collectives, there are no neighbours
-        shard.start_halo_exchange = lambda grad: None
-    if strong or (dist is not None and world == 1):
+    shard = FrameShard(cut_rank, cut_world, dist, proxy=args.share > 1)
+    if strong:
         shard.prepare_flow_loss(loss_fn, flows)  # global valid-sum (one-time all-reduce)
-        shard.prepare_model(model)  # softmin sweep on rank 0, broadcast (flowmap_amd/sharding.py)
+        shard.prepare_model(model)  # softmin sweep on rank 0, broadcast; halo exchange from the gradient hook (flowmap_amd/sharding.py)
 
     optimizer = None
     if args.optimizer in ("fused", "in_pass"):
         optimizer = flowmap_amd.FusedAdam(model.parameters(), lr=3e-5, capturable=args.graph)
         if args.optimizer == "in_pass":  # the depth update applied by the flow-loss pass itself (FusedAdam.fuse_depth_update)
-            if args.graph or dist is not None:
-                raise SystemExit("--optimizer in_pass: single GPU, no --graph")
+            if args.graph:
+                raise SystemExit("--optimizer in_pass: no --graph (the step number is a host value)")
             optimizer.fuse_depth_update(model.backbone.depth)
     elif args.optimizer == "torch":
         optimizer = torch.optim.Adam(model.parameters(), lr=3e-5)
@@ -363,7 +406,7 @@ def main():
             if track_fn is not None:
                 loss = loss + track_fn(batch, flows, tracks, out, 0)
             loss.backward()
-        if strong or (dist is not None and world == 1):
+        if strong:
             loss = shard.sync(loss, shared, model.backbone.depth, already_global=tracked)
         if optimizer is not None:
             optimizer.step()
@@ -374,13 +417,21 @@ def main():
     # the metric excludes one-time precompute)
     for _ in range(3):
         step()
-    if args.graph:
-        if dist is not None or args.optimizer == "torch":
-            raise SystemExit("--graph: single GPU, and --optimizer none|fused")
-        step = flowmap_amd.GraphedStep(step, warmup=3)  # noqa: F811  (kernel events are not recorded inside a graph: kernel_ms stays 0)
     if dist is not None:  # create the RCCL communicators / P2P channels outside the timed region
         shard.exchange_halo(torch.zeros((2, h, w), device=device))
         dist.all_reduce(torch.zeros(4, device=device))
+    eager_flow_ms = []
+    if args.graph:
+        if args.optimizer == "torch":
+            raise SystemExit("--graph: --optimizer none|fused")
+        if on_gpu:  # kernel events are not recorded inside a graph: time the flow kernel on a few eager steps first
+            _ops.flow_kernel_timing(True)
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize(device)
+            eager_flow_ms = _ops.flow_kernel_times()
+            _ops.flow_kernel_timing(False)
+        step = flowmap_amd.GraphedStep(step, warmup=3)  # noqa: F811
     for _ in range(args.warmup):
         step()
     flowmap_amd.freeze_gc()  # a full cyclic-GC pass over torch's import-time objects costs ~50 ms (flowmap_amd/host.py)
@@ -401,17 +452,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    flow_ms = _ops.flow_kernel_times()
+    flow_ms = _ops.flow_kernel_times() if not args.graph else eager_flow_ms
     track_ms = _ops.flow_kernel_times(tracking=True)
     _ops.flow_kernel_timing(False)
     kernel_ms = sum(flow_ms) / max(len(flow_ms), 1)
     traffic, traffic_src = None, None
-    for name in ("r02_flow_kernel_traffic.json", "r01_flow_kernel_traffic.json"):  # HBM bytes per launch from the PMC passes (same workload only)
+    for name in ("r03_flow_kernel_traffic.json", "r02_flow_kernel_traffic.json", "r01_flow_kernel_traffic.json"):  # HBM bytes per launch from the PMC passes (same workload only)
         try:
             rec = json.loads((ROOT / "profiles" / name).read_text())
             if {k: rec["workload"][k] for k in ("frames", "height", "width")} == {"frames": f, "height": h, "width": w}:
                 entry = rec["flow_fused_kernel_adam"] if (args.optimizer == "in_pass" and optimizer.counters["in_pass_updates"] > 0) else rec
-                traffic, traffic_src = entry["hbm_bytes_per_launch"], f"profiles/{name} (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"
+                traffic, traffic_src = entry["hbm_bytes_per_launch"], f"profiles/{name}"
                 break
         except Exception:
             pass
@@ -421,17 +472,24 @@ def main():
     if in_pass:  # depth, exp_avg, exp_avg_sq read and rewritten (24 B per pixel and frame), no dL/ddepth written
         algo_bytes = n * (24 * f + 24 * (f - 1))
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    launches, launch_names = (None, [])
+    under_rocprof = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_CTOR"))
+    if on_gpu and rank == 0 and (args.count_launches or (world == 1 and not args.graph and not under_rocprof and not os.environ.get("FLOWMAP_BENCH_NO_PROFILER"))):
+        launches, launch_names = count_launches(step, device)  # (two tracers in one process do not mix: skipped under rocprofv3)
 
     if rank == 0:
         jobs = 1 if (strong or world == 1) else world  # weak scaling: every rank completes its own workload per step
         ms_per_step = elapsed / args.steps * 1e3
+        step_gbs = algo_bytes / (ms_per_step * 1e-3) / 1e9
         workload = (f"{cfg['ref']}: {f_video} frames @ {h}x{w}, {cfg['inputs']} inputs, flow loss (huber 0.01, weight 1000)"
                     + (f" + tracking loss (weight 100): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else "")
                     + f", explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points if args.points > 0 else 'all pixels'}; fwd+bwd, "
                     + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__}"
                        + (", depth update inside the flow pass)" if args.optimizer == "in_pass" and optimizer.counters["in_pass_updates"] > 0
                           else ", fuse_depth_update requested but the touched set is too large: separate update)" if args.optimizer == "in_pass" else ")"))
-                    + ("; whole step replayed as one hipGraph" if args.graph else ""))
+                    + ("; whole step replayed as one hipGraph" if args.graph else "")
+                + (f"; PROXY: rank {cut_rank}'s share of a {cut_world}-GPU strong-scaling run on one GPU (pairs [{a}, {b}) of {total_pairs}, {f} frames incl. halo), "
+                   "every collective on a one-rank RCCL communicator, halo exchange replaced by its local copies/adds; xGMI wire time NOT included" if args.share > 1 else ""))
         result = {
             "metric": "overfit iters/sec (150 frames @ 720p) at 1/2/4/8 MI355X; final ATE vs ref",
             "value": jobs * args.steps / elapsed,
@@ -467,7 +525,14 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": traffic_src,
+                "traffic_measured_in": traffic_src,
+                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes of an earlier run of this workload (FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950 "
+                                "correction), not a live counter: traffic is data-independent" if traffic is not None else None,
+                "step_frac": step_gbs / HBM_PEAK_GBS,
+                "step_achieved": step_gbs,
+                "launches_per_step": launches,
+                "kernels_of_a_step": launch_names,
+                "kernel_timing": "HIP events on the launch stream, inside the timed region" if not args.graph else "HIP events on 5 eager steps before the capture (a replayed graph records none)",
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": kernel_ms,
                 "launches_timed": len(flow_ms),
@@ -494,20 +559,39 @@ def main():
                 "kernel_ms": t_ms,
                 "launches_timed": len(track_ms),
             }
-        if world == 1 and args.cpu_frames >= 2:
-            dt, cores = cpu_baseline(args.cpu_frames, h, w, args.points if args.points > 0 else None, args.cpu_iters, args.cpu_threads)
-            scaled = dt * (f_video - 1) / (args.cpu_frames - 1)  # per-pair cost is constant (optimistic for the CPU)
+        if args.share > 1:
+            result["proxy"] = {"share_of": cut_world, "rank": cut_rank, "pairs": [a, b], "frames_resident": f, "video_pairs": total_pairs,
+                               "per_rank_ms_per_step": ms_per_step, "wire_time_included": False}
+        cpu_frames = args.cpu_frames
+        if cpu_frames < 0:
+            try:
+                avail_gb = int(next(line for line in open("/proc/meminfo") if line.startswith("MemAvailable")).split()[1]) / 2**20
+            except Exception:  # noqa: BLE001
+                avail_gb = 0.0
+            cpu_frames = f_video if avail_gb >= 96 else min(32, f_video)
+        if world == 1 and args.share <= 1 and cpu_frames >= 2 and args.points > 0:
+            cpu_frames = min(cpu_frames, f)
+            focal0 = 0.85 if cfg["inputs"] == "iid" else 0.8
+            dt, cores, first, cpu_loss = cpu_baseline(model.backbone.depth.data, model.backbone.weights.data, flows, focal0, cpu_frames, h, w, args.points,
+                                                      args.cpu_iters, args.cpu_threads)
+            whole = cpu_frames == f_video
+            scaled = dt if whole else dt * (f_video - 1) / (cpu_frames - 1)  # per-pair cost is constant (optimistic for the CPU)
             result["cpu_baseline"] = {
                 "value": 1.0 / scaled,
                 "unit": "iters/sec",
                 "cores": cores,
                 "kind": "port",
-                "frames": args.cpu_frames,
+                "frames": cpu_frames,
+                "whole_workload": whole,
                 "host_logical_cpus": os.cpu_count(),
-                "sample": f"oracle (PyTorch-CPU port of the reference path, flow loss), {cores} torch threads, {args.cpu_frames} frames @ {h}x{w} (i.i.d. inputs), "
-                f"fwd+bwd, {args.cpu_iters} timed iters after 1 warm-up: {dt:.3f} s/iter, scaled by pairs ({f_video - 1}/{args.cpu_frames - 1}) "
-                f"to {f_video} frames",
+                "sample": (f"oracle (PyTorch-CPU port of the reference path, flow loss), {cores} torch threads, "
+                           + (f"the WHOLE workload: the same {f_video} frames @ {h}x{w} ({cfg['inputs']} inputs) the GPU leg ran on" if whole else
+                              f"SAMPLE: the first {cpu_frames} of the {f_video} frames @ {h}x{w} ({cfg['inputs']} inputs) the GPU leg ran on, scaled by pairs "
+                              f"({f_video - 1}/{cpu_frames - 1})")
+                           + f", fwd+bwd, {args.cpu_iters} timed iteration(s) after 1 warm-up ({first:.1f} s): {dt:.3f} s/iter"),
                 "sample_seconds_per_iter": dt,
+                "loss": cpu_loss,
+                "loss_rel_diff_vs_gpu": (abs(cpu_loss - float(loss.item())) / abs(cpu_loss)) if (whole and optimizer is None) else None,
             }
         print(json.dumps(result), file=result_stream, flush=True)
     if dist is not None:

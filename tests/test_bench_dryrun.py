@@ -50,3 +50,16 @@ def test_strong_scaling_reports_the_whole_video(extra):
 def test_weak_scaling_runs_one_video_per_rank():
     line = _run(2, ["--config", "c1", "--scaling", "weak"])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["frames_per_gpu"] == 9
+
+
+@pytest.mark.parametrize("extra", [[], ["--optimizer", "in_pass"], ["--optimizer", "fused"]], ids=["fwd+bwd", "in-pass adam", "fused adam"])
+def test_share_proxy_runs_one_ranks_share_with_every_collective(extra):
+    """bench.py --share K: rank R's share of a K-rank strong-scaling run in ONE process (a one-member process group, the halo
+    exchange replaced by its local copies/adds) — the line names the share and is flagged as a proxy."""
+    line = _run(1, ["--config", "c1", "--share", "3", *extra])
+    assert line["n_gpus"] == 1 and line["proxy"]["share_of"] == 3 and line["proxy"]["rank"] == 1 and line["proxy"]["wire_time_included"] is False
+    a, b = line["proxy"]["pairs"]
+    assert (a, b) == (3, 6) and line["config"]["frames_per_gpu"] == 4 and line["config"]["video_frames"] == 9  # 8 pairs over 3 ranks: 3 + 3 + 2
+    assert "PROXY" in line["config"]["workload"] and "cpu_baseline" not in line
+    edge = _run(1, ["--config", "c1", "--share", "3", "--share-rank", "2", *extra])
+    assert edge["proxy"]["pairs"] == [6, 8] and edge["config"]["frames_per_gpu"] == 3

@@ -91,3 +91,17 @@ def test_full_size_module_logic_at_toy_size():
     built = full.build_reference(12, 40, 56, 300, "cpu", torch.float64, interval=3, radius=4, grid=9)
     full.compare_flow_only(built, (40, 56), 300, "cpu")
     full.compare_flow_and_tracking(built, (40, 56), 300, "cpu")
+
+
+def test_full_size_cases_run_small_on_the_host_double():
+    """The bodies of the C3 / C4-shard full-size GPU tests (tests/test_gpu_full_size.py) at a size that takes a second,
+    on the host double: the comparison code itself is exercised by the CPU suite."""
+    import warnings
+
+    import test_gpu_full_size as full
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full.c3_case(12, 40, 56, 200, "cpu", torch.float64, "C3 body, small")
+        record = full.c4_shard_case(6, 24, 32, 60, "cpu", torch.float64, "C4-shard body, small")
+    assert record["oracle_dtype"] == "torch.float64" and "g_depth_fp32_reference_gap" in record

@@ -216,3 +216,193 @@ def test_sharded_softmin_intrinsics_match_the_unsharded_step(tmp_path):
         assert_close(r["loss"], loss.detach(), 1e-5, what="global loss")
         assert_close(r["g_depth"], model.backbone.depth.grad[lo : hi + 1], 1e-4, abs_=1e-7, what="g_depth shard (sweep gradient on rank 0, halo summed)")
         assert_close(r["g_w"], model.backbone.weights.grad[a:b], 3e-4, abs_=1e-7, what="g_wlogit shard")
+
+
+# ---- round 3: the capture-safe sync (persistent buffer over several steps), bucketed shared-module gradients, in-pass Adam on shards ----
+
+
+def _shared_backbone(frames_total, lo, hi, h, w, depth, wlogit, hidden):
+    """Test-only backbone: explicit depth / weight logits (frame-local) modulated by a SHARED network of ~hidden² parameters —
+    the role BackboneMidas plays in the reference (backbone_midas.py:42-127): every frame's depth depends on the same weights."""
+    from torch import nn
+
+    from flowmap_amd.model.projection import LazyWeights
+    from flowmap_amd.types import BackboneOutput
+
+    class SharedBackbone(nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(5)
+            self.depth = nn.Parameter(depth[lo : hi + 1].clone())
+            self.weights = nn.Parameter(wlogit[lo:hi].clone())
+            self.register_buffer("codes", torch.randn((frames_total, 8), generator=g)[lo : hi + 1].clone())
+            torch.manual_seed(11)  # the same initial weights on every rank and in the unsharded run
+            self.net = nn.Sequential(nn.Linear(8, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, h * w))
+
+        def forward(self, batch, flows):
+            offset = 0.05 * torch.tanh(self.net(self.codes)).view(-1, h, w)
+            return BackboneOutput((self.depth * torch.exp(offset))[None], LazyWeights(self.weights[None], 100.0))
+
+    return SharedBackbone()
+
+
+def _bucket_worker(rank, world, port, f, h, w, points, hidden, out_path):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import flowmap_amd
+    from flowmap_amd import Batch, Flows, _lib
+    from flowmap_amd.loss import LossFlow, LossFlowCfg
+    from flowmap_amd.loss.mapping import MappingHuberCfg
+    from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
+    from flowmap_amd.sharding import FrameShard, SharedGradientBuckets
+    from helpers import build_host_sim
+    from oracle import flowmap_oracle as orc
+
+    _lib.set_library_for_testing(build_host_sim())
+    flowmap_amd.set_lazy_surfaces(True)
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
+    a, b = shard_pairs(f - 1, world)[rank]
+    lo, hi = shard_frames((a, b))
+    nf = hi - lo + 1
+    model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", 0.85),
+                           ExtrinsicsProcrustesCfg("procrustes", points, False)), num_frames=nf, image_shape=(h, w))
+    model.backbone = _shared_backbone(f, lo, hi, h, w, depth, wlogit, hidden)
+    local = Flows(flows.forward[:, a:b].contiguous(), flows.backward[:, a:b].contiguous(),
+                  flows.forward_mask[:, a:b].contiguous(), flows.backward_mask[:, a:b].contiguous())
+    batch = Batch(torch.zeros((1, nf, 3, h, w)))
+    loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
+    shard = FrameShard(rank, world, dist if world > 1 else None)
+    shard.prepare_flow_loss(loss_fn, local)
+    shard.prepare_model(model)
+    net_params = list(model.backbone.net.parameters())
+    buckets = SharedGradientBuckets(shard, net_params, bucket_mb=25.0)
+    launched = []
+    for step in range(2):  # two steps: the persistent buffers are reused, `.grad` of the shared parameters lives in them
+        model.zero_grad(set_to_none=True)
+        out = model(batch, local, 0)
+        loss = loss_fn(batch, local, None, out, 0)
+        loss.backward()
+        launched.append(sum(bk[3] is not None for bk in buckets.buckets))  # buckets whose all-reduce started DURING backward
+        buckets.finish()
+        total = shard.sync(loss, [model.intrinsics.focal_length], model.backbone.depth)
+    if rank == 0:
+        assert sum(p.numel() for p in net_params) >= 10_000_000 or hidden < 3000
+        torch.save({"loss": total.clone(), "g_net": [p.grad.clone() for p in net_params], "g_focal": model.intrinsics.focal_length.grad.clone(),
+                    "g_depth": model.backbone.depth.grad.clone(), "frames": (lo, hi), "buckets": len(buckets.buckets), "launched": launched,
+                    "in_bucket": all(p.grad.data_ptr() == view.data_ptr() for bk in buckets.buckets for p, view in bk[1])}, out_path)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_shared_module_gradients_are_bucketed_and_match_the_unsharded_step(tmp_path):
+    """A 10^7-parameter shared module next to the explicit-depth parameters (north_star: "RCCL all-reduce of the
+    intrinsics/shared-backbone gradients"; BackboneMidas in the reference): SharedGradientBuckets reduces its gradient in
+    25 MB buckets launched from gradient hooks while backward still runs; the result equals the unsharded gradient."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import assert_close
+
+    f, h, w, points, hidden = 7, 12, 16, 40, 3162
+    sharded, single = str(tmp_path / "sharded.pt"), str(tmp_path / "single.pt")
+    mp.spawn(_bucket_worker, args=(2, _free_port(), f, h, w, points, hidden, sharded), nprocs=2, join=True)
+    mp.spawn(_bucket_worker, args=(1, _free_port(), f, h, w, points, hidden, single), nprocs=1, join=True)
+    got, ref = torch.load(sharded), torch.load(single)
+    assert got["buckets"] >= 2 and got["in_bucket"]  # 40 MB of parameters: more than one bucket; .grad lives in the buckets
+    assert all(n == got["buckets"] for n in got["launched"])  # every bucket's all-reduce was in flight before backward returned
+    assert_close(got["loss"], ref["loss"], 1e-5, what="global loss")
+    for i, (a, b) in enumerate(zip(got["g_net"], ref["g_net"])):
+        assert float(b.abs().max()) > 0
+        assert_close(a, b, 1e-4, abs_=1e-7 * float(b.abs().max()), what=f"shared parameter {i} (sum over ranks)")
+    lo, hi = got["frames"]
+    assert_close(got["g_depth"], ref["g_depth"][lo : hi + 1], 1e-4, abs_=1e-9, what="explicit depth (halo summed)")
+    assert abs(float(got["g_focal"]) - float(ref["g_focal"])) <= 1e-4 * abs(float(ref["g_focal"])) + 1e-6 * abs(float(ref["loss"]))
+
+
+def _adam_worker(rank, world, port, f, h, w, points, steps, out_path):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import flowmap_amd
+    from flowmap_amd import Batch, Flows, FusedAdam, _lib
+    from flowmap_amd.loss import LossFlow, LossFlowCfg
+    from flowmap_amd.loss.mapping import MappingHuberCfg
+    from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
+    from flowmap_amd.sharding import FrameShard
+    from helpers import build_host_sim, to_flows
+    from oracle import flowmap_oracle as orc
+
+    _lib.set_library_for_testing(build_host_sim())
+    flowmap_amd.set_lazy_surfaces(True)
+    sc = orc.synth_scene(f, h, w, seed=21)
+    flows = to_flows(sc["flows"], "cpu")
+    a, b = shard_pairs(f - 1, world)[rank]
+    lo, hi = shard_frames((a, b))
+    nf = hi - lo + 1
+    model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", 0.9),
+                           ExtrinsicsProcrustesCfg("procrustes", points, False)), num_frames=nf, image_shape=(h, w))
+    model.backbone.depth.data = sc["depth_init"][lo : hi + 1].clone()
+    model.backbone.weights.data = (0.01 * torch.randn((f - 1, h, w), generator=torch.Generator().manual_seed(21)))[a:b].clone()
+    local = Flows(flows.forward[:, a:b].contiguous(), flows.backward[:, a:b].contiguous(),
+                  flows.forward_mask[:, a:b].contiguous(), flows.backward_mask[:, a:b].contiguous())
+    batch = Batch(torch.zeros((1, nf, 3, h, w)))
+    loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
+    shard = FrameShard(rank, world, dist if world > 1 else None)
+    shard.prepare_flow_loss(loss_fn, local)
+    shard.prepare_model(model)
+    if world > 1:
+        optimizer = FusedAdam(model.parameters(), lr=1e-3)
+        optimizer.fuse_depth_update(model.backbone.depth, max_touched_fraction=1.0)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for step in range(steps):
+        optimizer.zero_grad(set_to_none=True)
+        out = model(batch, local, step)
+        loss = loss_fn(batch, local, None, out, step)
+        loss.backward()
+        losses.append(float(shard.sync(loss, [model.intrinsics.focal_length], model.backbone.depth)))
+        optimizer.step()
+    torch.save({"depth": model.backbone.depth.detach().clone(), "weights": model.backbone.weights.detach().clone(),
+                "focal": model.intrinsics.focal_length.detach().clone(), "losses": losses, "frames": (lo, hi), "pairs": (a, b),
+                "in_pass": getattr(optimizer, "counters", {}).get("in_pass_updates", 0)}, f"{out_path}.{rank}")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_in_pass_adam_on_frame_shards_follows_the_unsharded_optimiser(tmp_path):
+    """FusedAdam.fuse_depth_update on a frame shard: interior frames are updated inside the flow pass, the frames shared
+    with a neighbour densely after the halo exchange — over several steps the parameters of every rank follow
+    torch.optim.Adam on the unsharded video (both copies of a shared frame included)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import assert_close
+
+    f, h, w, points, steps, world = 9, 24, 32, 60, 6, 3
+    out, single = str(tmp_path / "shard"), str(tmp_path / "single")
+    mp.spawn(_adam_worker, args=(world, _free_port(), f, h, w, points, steps, out), nprocs=world, join=True)
+    mp.spawn(_adam_worker, args=(1, _free_port(), f, h, w, points, steps, single), nprocs=1, join=True)
+    ref = torch.load(f"{single}.0")
+    for rank in range(world):
+        got = torch.load(f"{out}.{rank}")
+        lo, hi = got["frames"]
+        a, b = got["pairs"]
+        assert got["in_pass"] == steps - 1  # every step after the plan exists
+        for s_, (x, y) in enumerate(zip(got["losses"], ref["losses"])):
+            assert abs(x - y) <= 2e-5 * abs(y), (rank, s_, x, y)
+        assert_close(got["depth"], ref["depth"][lo : hi + 1], 2e-6, abs_=2e-6, what=f"depth parameters of rank {rank}")
+        assert_close(got["weights"], ref["weights"][a:b], 2e-6, abs_=2e-6, what=f"weight logits of rank {rank}")
+        assert abs(float(got["focal"]) - float(ref["focal"])) <= 2e-6
+    assert float((ref["depth"] - torch.load(f"{single}.0")["depth"]).abs().max()) == 0.0
