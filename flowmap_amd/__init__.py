@@ -16,10 +16,11 @@ from .install import install, uninstall  # noqa: F401
 from .model.projection import set_lazy_surfaces  # noqa: F401
 from .graph import GraphedStep  # noqa: F401
 from .host import freeze_gc  # noqa: F401
+from ._ops import release_flow_originals  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 from .types import BackboneOutput, Batch, Flows, ModelOutput, Tracks  # noqa: F401
 
 __all__ = [
-    "loss", "model", "install", "uninstall", "set_lazy_surfaces", "FusedAdam", "GraphedStep", "freeze_gc",
+    "loss", "model", "install", "uninstall", "set_lazy_surfaces", "FusedAdam", "GraphedStep", "freeze_gc", "release_flow_originals",
     "Batch", "BackboneOutput", "Flows", "ModelOutput", "Tracks",
 ]

@@ -252,7 +252,7 @@ use_grad_arena = True
 use_fit_chain = True
 
 # which backward path the facades selected (tests)
-counters = {"procrustes_planned": 0, "procrustes_dense_planned": 0}
+counters = {"procrustes_planned": 0, "procrustes_dense_planned": 0, "flow_packs": 0, "procrustes_plans_built": 0}
 
 
 class LeadingFrames:
@@ -355,6 +355,7 @@ def _procrustes_scatter_plan(indices: Tensor, bwd_flow: Tensor, b: int, f: int, 
             bounds = torch.arange(b * f + 1, dtype=torch.int64, device=dev) * (h * w)
             frame_first = torch.searchsorted(pixels, bounds).to(torch.int32)
             entry[1] = (pixels.contiguous(), first, vectors.contiguous(), weights[entries].contiguous(), frame_first.contiguous())
+            counters["procrustes_plans_built"] += 1
     return entry[1]
 
 
@@ -474,6 +475,13 @@ def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=N
     (loss_flow.py:56,66,70).  Masks are constants of the optimisation, so the result is kept on the
     forward-mask tensor (per backward mask, weight and reducer) and costs nothing after the first step.
     ``reducer`` (frame sharding) maps the local fp64 sum to the global one."""
+    released = mask_fwd.__dict__.get("_fm_released_norms")
+    if released is not None:  # release_flow_originals: the masks are gone, the normalisers computed from them are not
+        hit = released.get((float(weight), id(reducer)))
+        if hit is None:
+            raise RuntimeError("flowmap_amd: the flow masks were released (release_flow_originals) before a loss with this weight / reducer "
+                               "had computed its normaliser from them")
+        return hit
 
     def build():
         vsum = torch.empty((1,), dtype=torch.float64, device=mask_fwd.device)
@@ -485,6 +493,7 @@ def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=N
             total = reducer(vsum)
             veff = torch.where(total == 0, torch.ones_like(total), total)
             norm = torch.cat([float(weight) / veff, veff]).to(torch.float32)
+        mask_fwd.__dict__.setdefault("_fm_norms_seen", {})[(float(weight), id(reducer))] = norm
         return (mask_bwd, reducer, norm)  # the other mask and the reducer are kept alive: their ids are part of the key
 
     key = (mask_fwd._version, id(mask_bwd), mask_bwd._version, mask_bwd.data_ptr(), tuple(mask_fwd.shape), float(weight), id(reducer))
@@ -494,16 +503,23 @@ def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=N
 # The packed copy costs as much HBM as the flows and masks themselves (3.3 GB at C1); set to
 # False to stream the caller's tensors directly (tests exercise both kernels).
 use_packed_inputs = True
+# tests: pack the first time a set of flows is seen (a one-step test then runs the packed kernel instance)
+pack_on_first_sight = False
 
 
-def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mask_bwd: Tensor) -> Optional[Tensor]:
+def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mask_bwd: Tensor, eager: bool = False) -> Optional[Tensor]:
     """Flows + masks in the layout of fm_flow_pack_inputs, or None when it does not apply
-    (width not a multiple of 4, unexpected shapes / dtypes).  Like the valid-sum, these are
-    constants of an optimisation (flow_predictor.py:82-102 runs once per video), so the
-    re-layout runs once per Flows object: kept on the forward-flow tensor and validated against the
-    identity and version of all four tensors."""
+    (width not a multiple of 4, unexpected shapes / dtypes) — or not YET: the re-layout is a full read + write pass over
+    the flows and masks (+3.3 GB resident at C1), worth it only for inputs that come back.  In an overfit loop they are
+    constants (flow_predictor.py:82-102 runs once per video) and the SECOND step that brings the same four tensors packs
+    them; in the reference's pretraining loop every step brings a new ``Flows`` (model_wrapper_pretrain.py:46-71) and
+    nothing is ever packed — the fused kernel streams the caller's tensors (its un-packed instance).  ``eager``: pack at
+    first sight.  Kept on the forward-flow tensor and validated against the identity and version of all four tensors."""
     if not use_packed_inputs:
         return None
+    released = flow_fwd.__dict__.get("_fm_released_packed")
+    if released is not None:
+        return released
     srcs = (flow_fwd, flow_bwd, mask_fwd, mask_bwd)
     if mask_fwd.dim() != 4 or mask_fwd.shape[-1] % 4 != 0 or tuple(mask_bwd.shape) != tuple(mask_fwd.shape):
         return None
@@ -511,6 +527,12 @@ def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mas
         return None
     if any(t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 != 0 for t in srcs):
         return None
+    key = tuple((id(t), t._version, t.data_ptr()) for t in srcs) + (tuple(mask_fwd.shape),)
+    if not (eager or pack_on_first_sight):
+        slot = flow_fwd.__dict__.get("_fm_packed")
+        if (slot is None or slot[0] != key) and flow_fwd.__dict__.get("_fm_packed_seen") != key:
+            flow_fwd.__dict__["_fm_packed_seen"] = key  # first sighting: remember, stream directly
+            return None
 
     def build():
         b, pairs, h, w = mask_fwd.shape
@@ -519,10 +541,36 @@ def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mas
         with _guard(mask_fwd.device):
             call("fm_flow_pack_inputs", ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd), b, pairs + 1, h, w, ptr(packed),
                  stream_for(mask_fwd))
+        counters["flow_packs"] += 1
         return (srcs[1:], packed)  # the three other tensors are kept alive: their ids are part of the key
 
-    key = tuple((id(t), t._version, t.data_ptr()) for t in srcs) + (tuple(mask_fwd.shape),)
     return _derived(flow_fwd, "_fm_packed", key, build)[1]
+
+
+def release_flow_originals(flows) -> int:
+    """After the flows and masks of an overfit loop have been packed (the second step), the fused flow loss reads only the
+    packed copy: the forward flow and the two masks (2.2 of the 3.3 GB at C1; the backward flow stays — the Procrustes fit
+    samples it) can be given back.  Replaces ``flows.forward``, ``flows.forward_mask`` and ``flows.backward_mask`` by
+    storage-free placeholders of the same shape that carry the packed copy and the loss normalisers computed so far.
+    Returns the bytes released.  The placeholders are only good for the fused flow loss: ``flows`` no longer holds the data."""
+    ff, fb, mf, mb = flows.forward, flows.backward, flows.forward_mask, flows.backward_mask
+    slot = ff.__dict__.get("_fm_packed")
+    if slot is None:
+        raise RuntimeError("flowmap_amd: nothing to release — these flows have not been packed yet (the fused flow loss packs them at its second step)")
+    packed = slot[1][1]
+    freed = (ff.numel() + mf.numel() + mb.numel()) * 4
+
+    def placeholder(t: Tensor) -> Tensor:
+        return torch.zeros((1,), dtype=t.dtype, device=t.device).expand(t.shape)
+
+    new_ff, new_mf, new_mb = placeholder(ff), placeholder(mf), placeholder(mb)
+    new_ff.__dict__["_fm_released_packed"] = packed
+    new_mf.__dict__["_fm_released_norms"] = dict(mf.__dict__.get("_fm_norms_seen", {}))
+    for name in ("_fm_flow_acc",):
+        if name in mf.__dict__:
+            new_mf.__dict__[name] = mf.__dict__[name]
+    flows.forward, flows.forward_mask, flows.backward_mask = new_ff, new_mf, new_mb
+    return freed
 
 
 class FlowLossFused:

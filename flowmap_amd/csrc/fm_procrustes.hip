@@ -1114,6 +1114,78 @@ struct FitBwdPlan {
 };
 
 constexpr int kFitBwdThreads = 1024;
+constexpr int kFitBwdGather = 8;  // plan pixels a thread keeps in flight at a time
+
+// A correspondence's gather chain is index -> (flow, weight, later depth) -> four taps of the earlier depth: three dependent
+// round trips to HBM (~2 us each on cold lines).  The chain is split into stages so that BOTH pairs' chains are in flight
+// together and the first two stages are issued before the block waits for the pose-solve backward.
+struct CorrStage1 {  // what the index leads to
+  int idx;
+  float fx, fy, w_raw, z_p;
+};
+struct CorrStage2 {  // the taps and their depths
+  Taps taps;
+  float z[4];
+};
+
+__device__ __forceinline__ CorrStage1 corr_stage1(const CorrSrc& s, int idx) {
+  CorrStage1 a;
+  a.idx = idx;
+  a.fx = s.bwd_flow[2 * (size_t)idx];
+  a.fy = s.bwd_flow[2 * (size_t)idx + 1];
+  a.w_raw = s.weights[idx];
+  a.z_p = s.depth_l[idx];
+  return a;
+}
+
+__device__ __forceinline__ CorrStage2 corr_stage2(const CorrSrc& s, const CorrStage1& a) {
+  CorrStage2 b;
+  const PixelRef px = pixel_ref(a.idx, s.height, s.width);
+  b.taps = bilinear_taps(px.u + a.fx, px.v + a.fy, s.height, s.width);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b.z[k] = b.taps.in[k] ? s.depth_e[tap_row(b.taps, k) * s.width + tap_col(b.taps, k)] : 0.f;
+  return b;
+}
+
+// The Corr that corr_load (fm_math.h) builds, from the staged loads: the same arithmetic in the same order.
+__device__ __forceinline__ Corr corr_assemble(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, const CorrStage1& a, const CorrStage2& b) {
+  Corr c;
+  c.idx = a.idx;
+  c.w = a.w_raw;
+  if (s.weight_sens != 0.f) c.w = fm_sigmoid<false>(s.weight_sens * c.w);
+  c.taps = b.taps;
+  const PixelRef px = pixel_ref(a.idx, s.height, s.width);
+  c.z_p = a.z_p;
+  ray_dir(kinv_l, px.u, px.v, c.ray_p);
+  c.p[0] = c.ray_p[0] * c.z_p;
+  c.p[1] = c.ray_p[1] * c.z_p;
+  c.p[2] = c.ray_p[2] * c.z_p;
+  c.q[0] = c.q[1] = c.q[2] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!c.taps.in[k]) continue;
+    float ray[3];
+    ray_dir(kinv_e, pixel_center(tap_col(c.taps, k), s.width), pixel_center(tap_row(c.taps, k), s.height), ray);
+    c.q[0] += (ray[0] * b.z[k]) * c.taps.w[k];
+    c.q[1] += (ray[1] * b.z[k]) * c.taps.w[k];
+    c.q[2] += (ray[2] * b.z[k]) * c.taps.w[k];
+  }
+  return c;
+}
+
+__device__ __forceinline__ PairGrad pair_grad_from(const double* pg, const double* ax) {
+  PairGrad g;
+  for (int k = 0; k < 9; ++k) g.gM[k] = (float)pg[k];
+  for (int a = 0; a < 3; ++a) {
+    g.gqbar[a] = (float)pg[9 + a];
+    g.gpbar[a] = (float)pg[12 + a];
+    g.pbar[a] = (float)ax[21 + a];
+    g.qbar[a] = (float)ax[24 + a];
+  }
+  g.dbar = (float)pg[15];
+  g.inv_wsum = (float)pg[16];
+  return g;
+}
 
 __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(ProcParams p, FitBwdPlan pl) {
   extern __shared__ float vec_lds[];  // [role 0: dL/dq of pair f | role 1: dL/dp of pair f−1][P][3]
@@ -1126,7 +1198,33 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
   const bool has_l = f > 0;             // ... and the LATER frame of pair (b, f−1)
   const size_t pair_e = (size_t)b * (p.frames - 1) + f, pair_l = pair_e - 1;
   const int t = threadIdx.x;
+  const int P = (int)p.points;
 
+  Mat3 kinv_m, kinv_f, kinv_p;  // K⁻¹ of frames f−1, f, f+1
+  load_mat3(p.kinv + (size_t)bf * 9, kinv_f);
+  load_mat3(p.kinv + (size_t)(has_l ? bf - 1 : bf) * 9, kinv_m);
+  load_mat3(p.kinv + (size_t)(has_e ? bf + 1 : bf) * 9, kinv_p);
+  // role 0: pair f = (earlier f, later f+1); role 1: pair f−1 = (earlier f−1, later f).  (An absent role reads pair f / f−1 of
+  // a neighbouring valid pair index 0 and is masked out below.)
+  const CorrSrc src0 = pair_source<SRC_DEPTH>(p, has_e ? pair_e : pair_l, b, has_e ? f : f - 1);
+  const CorrSrc src1 = pair_source<SRC_DEPTH>(p, has_l ? pair_l : pair_e, b, has_l ? f - 1 : f);
+
+  // ---- the plan slice of this frame: first round of loads (keys, entry ranges), issued before anything waits ----
+  const int lo = pl.frame_first ? pl.frame_first[bf] : 0, hi = pl.frame_first ? pl.frame_first[bf + 1] : 0;
+
+  // ---- stage 1 + 2 of the first batch of correspondences of both pairs ----
+  const bool first_on = t < P;
+  CorrStage1 a0 = {}, a1 = {};
+  CorrStage2 b0 = {}, b1 = {};
+  if (first_on) {
+    const int idx = (int)p.indices[t];
+    if (has_e) a0 = corr_stage1(src0, idx);
+    if (has_l) a1 = corr_stage1(src1, idx);
+    if (has_e) b0 = corr_stage2(src0, a0);
+    if (has_l) b1 = corr_stage2(src1, a1);
+  }
+
+  // ---- pose-solve backward of the two pairs, side by side in two waves (fp64, one thread each) ----
   if (t == 0 || t == kWave) {
     const int role = t == 0 ? 0 : 1;
     const bool on = role == 0 ? has_e : has_l;
@@ -1138,7 +1236,7 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
                          pl.aux + pr * kAuxStride, pg);
       if (pl.g_k) {
         double kd[9], kf[9];
-        for (int k = 0; k < 9; ++k) kd[k] = p.kinv[(size_t)bf * 9 + k];
+        for (int k = 0; k < 9; ++k) kd[k] = kinv_f.m[k];
         inv3d(kd, kf);  // K of this frame
         if (role == 0) pair_kinv_grads(pg, pl.aux + pr * kAuxStride, kf, nullptr, acc, nullptr);
         else pair_kinv_grads(pg, pl.aux + pr * kAuxStride, nullptr, kf, nullptr, acc);
@@ -1147,7 +1245,7 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
     for (int k = 0; k < 9; ++k) kacc_lds[role][k] = acc[k];
   }
   __syncthreads();
-  if (t == 0 && pl.g_k) {  // dK = [g_k] − K⁻ᵀ·dK⁻¹·K⁻ᵀ (kinv_grad_to_k), both roles summed in fp64
+  if (t == 2 * kWave && pl.g_k) {  // dK = [g_k] − K⁻ᵀ·dK⁻¹·K⁻ᵀ (kinv_grad_to_k), both roles summed in fp64; a third wave, off the others' path
     double tot[9], gk[9];
     for (int k = 0; k < 9; ++k) tot[k] = kacc_lds[0][k] + kacc_lds[1][k];
     kinv_grad_to_k(tot, p.kinv + (size_t)bf * 9, gk);
@@ -1158,64 +1256,84 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
   }
 
   // ---- per-correspondence gradients of the two pairs -> LDS (and dL/dweights of pair f) ----
-  const int P = (int)p.points;
-#pragma unroll
-  for (int role = 0; role < 2; ++role) {
-    if (role == 0 ? !has_e : !has_l) continue;  // block-uniform
-    const size_t pair = role == 0 ? pair_e : pair_l;
-    const int i = role == 0 ? f : f - 1;
-    Mat3 kinv_e, kinv_l;
-    load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
-    load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
-    const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
-    const double* pg = pg_lds[role];
-    const double* ax = pl.aux + pair * kAuxStride;
-    PairGrad g;
-    for (int k = 0; k < 9; ++k) g.gM[k] = (float)pg[k];
-    for (int a = 0; a < 3; ++a) {
-      g.gqbar[a] = (float)pg[9 + a];
-      g.gpbar[a] = (float)pg[12 + a];
-      g.pbar[a] = (float)ax[21 + a];
-      g.qbar[a] = (float)ax[24 + a];
+  PairGrad g0 = {}, g1 = {};
+  if (has_e) g0 = pair_grad_from(pg_lds[0], pl.aux + pair_e * kAuxStride);
+  if (has_l) g1 = pair_grad_from(pg_lds[1], pl.aux + pair_l * kAuxStride);
+  for (int j0 = 0; j0 < P; j0 += kFitBwdThreads) {  // (block-uniform trip count)
+    const int j = j0 + t;
+    const bool on = j < P;
+    if (j0 > 0 && on) {  // later batches (P > 1024): the same stages, without the head start
+      const int idx = (int)p.indices[j];
+      if (has_e) a0 = corr_stage1(src0, idx);
+      if (has_l) a1 = corr_stage1(src1, idx);
+      if (has_e) b0 = corr_stage2(src0, a0);
+      if (has_l) b1 = corr_stage2(src1, a1);
     }
-    g.dbar = (float)pg[15];
-    g.inv_wsum = (float)pg[16];
-    float* out = vec_lds + (size_t)role * P * 3;
-    for (int j = t; j < P; j += kFitBwdThreads) {
-      const Corr c = corr_load(src, kinv_e, kinv_l, (int)p.indices[j]);
-      float gq[3], gp[3], gw;
-      corr_backward(c, g, gq, gp, gw);
-      if (role == 0) {
-        if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
-        if (p.grad_weights) p.grad_weights[pair * (size_t)n + c.idx] = gw;   // distinct indices: a plain store per slot
-        out[j * 3 + 0] = gq[0], out[j * 3 + 1] = gq[1], out[j * 3 + 2] = gq[2];
-      } else {
-        out[j * 3 + 0] = gp[0], out[j * 3 + 1] = gp[1], out[j * 3 + 2] = gp[2];
-      }
+    if (!on) continue;
+    float gq[3], gp[3], gw;
+    if (has_e) {
+      const Corr c = corr_assemble(src0, kinv_f, kinv_p, a0, b0);
+      corr_backward(c, g0, gq, gp, gw);
+      if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
+      if (p.grad_weights) p.grad_weights[pair_e * (size_t)n + c.idx] = gw;  // distinct indices: a plain store per slot
+      float* out = vec_lds + (size_t)j * 3;
+      out[0] = gq[0], out[1] = gq[1], out[2] = gq[2];
+    }
+    if (has_l) {
+      const Corr c = corr_assemble(src1, kinv_m, kinv_f, a1, b1);
+      corr_backward(c, g1, gq, gp, gw);
+      float* out = vec_lds + ((size_t)P + j) * 3;
+      out[0] = gp[0], out[1] = gp[1], out[2] = gp[2];
     }
   }
   __syncthreads();
   if (p.grad_depth == nullptr) return;
 
-  // ---- this frame's slice of the planned gather: one plain read-modify-write per touched pixel ----
-  Mat3 ki;
-  load_mat3(p.kinv + (size_t)bf * 9, ki);
-  const int lo = pl.frame_first[bf], hi = pl.frame_first[bf + 1];
+  // ---- this frame's slice of the planned gather: one plain read-modify-write per touched pixel.  A thread keeps
+  // kFitBwdGather pixels in flight: their keys and entry ranges (round 1), their old gradient values and first entries
+  // (round 2) — three dependent round trips per batch instead of four per pixel ----
   const int64_t frame_base = (int64_t)bf * n;
   const int base_e = (int)(pair_e * (size_t)P), base_l = (int)(pair_l * (size_t)P);
-  for (int m = lo + t; m < hi; m += kFitBwdThreads) {
-    const int px = (int)(pl.pixels[m] - frame_base);
-    const int row = px / p.width, col = px - row * p.width;
-    float ray[3];
-    ray_dir(ki, pixel_center(col, p.width), pixel_center(row, p.height), ray);
-    float sum = 0.f;
-    for (int e = pl.first[m]; e < pl.first[m + 1]; ++e) {
-      const int v = pl.vectors[e];
-      const int later = v & 1, j = (v >> 1) - (later ? base_l : base_e);
-      const float* g3 = vec_lds + ((size_t)later * P + j) * 3;
-      sum += pl.tap_weights[e] * (g3[0] * ray[0] + g3[1] * ray[1] + g3[2] * ray[2]);
+  float* gd = p.grad_depth + frame_base;
+  for (int m0 = lo + t; m0 < hi; m0 += kFitBwdThreads * kFitBwdGather) {
+    int px[kFitBwdGather], e0[kFitBwdGather], e1[kFitBwdGather];
+#pragma unroll
+    for (int i = 0; i < kFitBwdGather; ++i) {
+      const int m = m0 + i * kFitBwdThreads;
+      const bool on = m < hi;
+      px[i] = on ? (int)(pl.pixels[m] - frame_base) : -1;
+      e0[i] = on ? pl.first[m] : 0;
+      e1[i] = on ? pl.first[m + 1] : 0;
     }
-    p.grad_depth[frame_base + px] += sum;
+    float old[kFitBwdGather], wt[kFitBwdGather];
+    int vi[kFitBwdGather];
+#pragma unroll
+    for (int i = 0; i < kFitBwdGather; ++i) {
+      const bool on = px[i] >= 0;
+      old[i] = on ? gd[px[i]] : 0.f;
+      vi[i] = on && e0[i] < e1[i] ? pl.vectors[e0[i]] : 0;
+      wt[i] = on && e0[i] < e1[i] ? pl.tap_weights[e0[i]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < kFitBwdGather; ++i) {
+      if (px[i] < 0) continue;
+      const int row = px[i] / p.width, col = px[i] - row * p.width;
+      float ray[3];
+      ray_dir(kinv_f, pixel_center(col, p.width), pixel_center(row, p.height), ray);
+      float sum = 0.f;
+      int v = vi[i];
+      float w = wt[i];
+      for (int e = e0[i]; e < e1[i]; ++e) {
+        if (e > e0[i]) {  // (a pixel several correspondences touch: rare)
+          v = pl.vectors[e];
+          w = pl.tap_weights[e];
+        }
+        const int later = v & 1, j = (v >> 1) - (later ? base_l : base_e);
+        const float* g3 = vec_lds + ((size_t)later * P + j) * 3;
+        sum += w * (g3[0] * ray[0] + g3[1] * ray[1] + g3[2] * ray[2]);
+      }
+      gd[px[i]] = old[i] + sum;
+    }
   }
 }
 

@@ -668,13 +668,16 @@ static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor
       }
     }
   } acc_guard{persistent ? acc : Tensor(), true};
+  const bool pk = packed.defined();  // (the originals may then be placeholders without storage of their own)
+  const float *p_ff = pk ? nullptr : ptr(flow_fwd), *p_fb = pk ? nullptr : ptr(flow_bwd), *p_mf = pk ? nullptr : ptr(mask_fwd),
+              *p_mb = pk ? nullptr : ptr(mask_bwd);
   if (exp_avg.defined()) {  // the depth parameter's Adam update applied by the same pass (fm_flow_loss_fused_adam)
-    FM_CALL(fm_flow_loss_fused_adam, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd),
-            ptr(mask_bwd), ptr(packed), ptr(norm), (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
+    FM_CALL(fm_flow_loss_fused_adam, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), p_ff, p_fb, p_mf,
+            p_mb, ptr(packed), ptr(norm), (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
             ptr(o.g_depth), ptr<double>(acc), (int)items, ptr(exp_avg), ptr(exp_avg_sq), ptr<uint8_t>(touched), (long)adam_step, adam[0], adam[1],
             adam[2], adam[3], scope.stream);
   } else {
-    FM_CALL(fm_flow_loss_fused, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd),
+    FM_CALL(fm_flow_loss_fused, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), p_ff, p_fb, p_mf, p_mb,
             ptr(packed), need ? ptr(norm) : nullptr, (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
             ptr(o.g_depth), ptr<double>(acc), (int)items, scope.stream);
   }
@@ -697,10 +700,16 @@ struct FlowLossFused : public Function<FlowLossFused> {
                         const OptTensor& exp_avg_sq_o, const OptTensor& touched_o, int64_t adam_step, std::vector<double> adam,
                         const OptTensor& adam_flag_o, bool grad_enabled, bool park) {
     check_device({&depth_in, &k_in, &kinv_in, &t_fwd_in, &t_bwd_in, &flow_fwd_in, &flow_bwd_in, &mask_fwd_in, &mask_bwd_in, &norm});
+    TORCH_CHECK(flow_fwd_in.scalar_type() == at::kFloat && flow_bwd_in.scalar_type() == at::kFloat && mask_fwd_in.scalar_type() == at::kFloat &&
+                    mask_bwd_in.scalar_type() == at::kFloat,
+                "flowmap_amd: flows and masks must be float32");
     const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics");
     const Tensor t_fwd = f32c(t_fwd_in, "forward poses"), t_bwd = f32c(t_bwd_in, "backward poses");
-    const Tensor flow_fwd = f32c(flow_fwd_in, "forward flow"), flow_bwd = f32c(flow_bwd_in, "backward flow");
-    const Tensor mask_fwd = f32c(mask_fwd_in, "forward mask"), mask_bwd = f32c(mask_bwd_in, "backward mask");
+    // With a packed copy (fm_flow_pack_inputs) the kernel reads that and nothing else: the four originals are only checked for
+    // their shapes — they may be storage-free placeholders (release_flow_originals) — and reach the C ABI as NULL
+    const bool has_packed = packed_o.has_value() && packed_o->defined();
+    const Tensor flow_fwd = has_packed ? flow_fwd_in : f32c(flow_fwd_in, "forward flow"), flow_bwd = has_packed ? flow_bwd_in : f32c(flow_bwd_in, "backward flow");
+    const Tensor mask_fwd = has_packed ? mask_fwd_in : f32c(mask_fwd_in, "forward mask"), mask_bwd = has_packed ? mask_bwd_in : f32c(mask_bwd_in, "backward mask");
     TORCH_CHECK(depth.dim() == 4, "flowmap_amd: depth must be (batch, frame, height, width)");
     const int64_t b = depth.size(0), f = depth.size(1), h = depth.size(2), w = depth.size(3);
     TORCH_CHECK(flow_fwd.sizes() == at::IntArrayRef({b, f - 1, h, w, 2}) && flow_bwd.sizes() == flow_fwd.sizes(),

@@ -497,7 +497,7 @@ def case_packed_inputs(dev, hw=(18, 28)):
     depth, wlogit, oflows = orc.synth_iid(f, h, w, seed=11)
     focal = 0.85
     ff, fb, mf, mb = (x.to(dev) for x in (oflows.forward, oflows.backward, oflows.forward_mask, oflows.backward_mask))
-    packed = _ops.packed_flow_inputs(ff, fb, mf, mb)
+    packed = _ops.packed_flow_inputs(ff, fb, mf, mb, eager=True)
     if w % 4 != 0:
         assert packed is None  # the reference layout is streamed directly
     else:
@@ -514,17 +514,22 @@ def case_packed_inputs(dev, hw=(18, 28)):
                 want[fr, :quads, 5] = mb[0, fr - 1].reshape(quads, 4).cpu().numpy()
         want = want.reshape(f, chunks, 64, 6, 4).transpose(0, 1, 3, 2, 4)
         assert np.array_equal(packed.cpu().numpy(), want)
-        assert _ops.packed_flow_inputs(ff, fb, mf, mb) is packed  # cached per Flows object
+        assert _ops.packed_flow_inputs(ff, fb, mf, mb, eager=True) is packed  # cached per Flows object
         mf.mul_(1.0)  # an in-place edit bumps the version: the copy is rebuilt
-        assert _ops.packed_flow_inputs(ff, fb, mf, mb) is not packed
+        assert _ops.packed_flow_inputs(ff, fb, mf, mb, eager=True) is not packed
 
     res = {}
     for use in (True, False):
         _ops.use_packed_inputs = use
+        _ops.pack_on_first_sight = True  # (a single step: the loss would otherwise stream the reference layout both times)
+        packs = _ops.counters["flow_packs"]
         try:
             res[use] = run_ours(depth, wlogit, focal, oflows, (h, w), 100, device=dev)
         finally:
             _ops.use_packed_inputs = True
+            _ops.pack_on_first_sight = False
+        # (on the host double `.to("cpu")` hands run_ours the very tensors packed above: the cached copy is then reused)
+        assert _ops.counters["flow_packs"] - packs <= (1 if (use and w % 4 == 0) else 0)
     # identical arithmetic per residual; only the order of the float atomics differs run to run
     for key in ("total", "g_depth", "g_wlogit", "g_focal", "extrinsics"):
         assert_close(res[True][key], res[False][key], 1e-5, abs_=1e-9, what=key)
@@ -813,7 +818,7 @@ def case_flow_fused_leaves(dev, f, h, w, packed, kind="huber", seed=0, tol=TOL):
     norm = _ops.flow_valid_norm(mf, mb, weight)
     pk = None
     if packed:
-        pk = _ops.packed_flow_inputs(ff, fb, mf, mb)
+        pk = _ops.packed_flow_inputs(ff, fb, mf, mb, eager=True)
         assert pk is not None, "the packed layout needs width % 4 == 0"
     loss = _ops.FlowLossFused.apply(d, kk, tf, tb, ff, fb, mf, mb, norm, _ops.MAPPING_KINDS[kind], 0.01, False, 0, pk)
     loss.backward()
@@ -1318,3 +1323,80 @@ def case_views_are_copied_loudly(dev):
     assert any("non-contiguous view" in str(c.message) for c in caught), [str(c.message) for c in caught]
     b = fm.compute_forward_flow(view.contiguous(), ext, k)
     assert torch.equal(a, b)
+
+
+def case_pretraining_mode(dev):
+    """The reference's pretraining loop brings a NEW Flows object with batch size > 1 every step
+    (model_wrapper_pretrain.py:46-71): nothing that is worth its cost only for inputs that come back may run — no re-layout of
+    the flows (fm_flow_pack_inputs), no scatter plan — and every step must still match the oracle.  The same inputs offered a
+    second time ARE packed and planned (the overfit loop), and the packed originals can then be released."""
+    import flowmap_amd
+    from flowmap_amd import Batch, Flows, ModelOutput, _ops
+    from flowmap_amd.loss import LossFlow, LossFlowCfg
+
+    b, f, h, w, p = 2, 4, 16, 24, 60
+    loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
+    idx = torch.linspace(0, h * w - 1, p, dtype=torch.int64)
+    idx_dev = idx.to(dev)
+
+    def inputs(seed):
+        g = torch.Generator().manual_seed(seed)
+        depth = 1.1 + 0.1 * torch.rand((b, f, h, w), generator=g)
+        weights = torch.rand((b, f - 1, h, w), generator=g)
+        fl = orc.OFlows(0.01 * torch.randn((b, f - 1, h, w, 2), generator=g), 0.01 * torch.randn((b, f - 1, h, w, 2), generator=g),
+                        torch.rand((b, f - 1, h, w), generator=g), torch.rand((b, f - 1, h, w), generator=g))
+        return depth, weights, fl
+
+    k = orc.focal_to_k(torch.tensor([0.8, 0.9]), (h, w))[:, None].expand(b, f, 3, 3).contiguous()
+
+    def ours(depth, weights, flows):
+        d, wt, kk = (x.detach().clone().to(dev).requires_grad_(True) for x in (depth, weights, k))
+        xy, _ = fm.sample_image_grid((h, w), dev)
+        surfaces = fm.unproject(xy, d, kk[:, :, None, None])
+        ext = fm.align_surfaces(surfaces, flows.backward, wt, idx_dev)
+        loss = loss_fn(Batch(torch.zeros((b, f, 3, h, w), device=dev)), flows, None, ModelOutput(d, surfaces, kk, ext, wt), 0)
+        loss.backward()
+        return loss.detach(), d.grad, wt.grad
+
+    def truth(depth, weights, fl):
+        d64, w64, k64 = depth.double().requires_grad_(True), weights.double().requires_grad_(True), k.double()
+        fl64 = orc.OFlows(*(x.double() for x in (fl.forward, fl.backward, fl.forward_mask, fl.backward_mask)))
+        o = orc.model_forward(d64, w64, k64, fl64, idx)
+        ref = 1000.0 * orc.flow_loss(o.surfaces, o.extrinsics, k64, fl64, (h, w))
+        ref.backward()
+        return ref.detach(), d64.grad, w64.grad
+
+    fm.set_lazy_surfaces(True)
+    try:
+        packs, plans, planned = _ops.counters["flow_packs"], _ops.counters["procrustes_plans_built"], _ops.counters["procrustes_planned"]
+        for step in range(4):  # a fresh batch every step
+            depth, weights, fl = inputs(100 + step)
+            flows = Flows(fl.forward.to(dev), fl.backward.to(dev), fl.forward_mask.to(dev), fl.backward_mask.to(dev))
+            got, want = ours(depth, weights, flows), truth(depth, weights, fl)
+            for a_, b_, what in zip(got, want, ("loss", "g_depth", "g_weights")):
+                assert_close(a_, b_, 3 * TOL if what == "g_weights" else TOL, what=f"{what}, fresh batch {step}")
+        assert _ops.counters["flow_packs"] == packs, "a Flows object seen once was re-laid-out"
+        assert _ops.counters["procrustes_plans_built"] == plans and _ops.counters["procrustes_planned"] == planned, "a scatter plan was built for inputs seen once"
+
+        # the same Flows object again and again (overfitting): packed and planned at the second step, then released
+        depth, weights, fl = inputs(7)
+        flows = Flows(fl.forward.to(dev), fl.backward.to(dev), fl.forward_mask.to(dev), fl.backward_mask.to(dev))
+        want = truth(depth, weights, fl)
+        history = []
+        for step in range(5):
+            history.append(ours(depth, weights, flows))
+            assert _ops.counters["flow_packs"] - packs == (0 if step == 0 else 1), step
+            if step == 2:
+                freed = flowmap_amd.release_flow_originals(flows)
+                assert freed == (flows.forward.numel() + 2 * flows.forward_mask.numel()) * 4
+                assert flows.forward.untyped_storage().nbytes() <= 16 and flows.forward.shape == (b, f - 1, h, w, 2)
+        assert _ops.counters["procrustes_plans_built"] == plans + 1
+        for step, got in enumerate(history):
+            for a_, b_, what in zip(got, want, ("loss", "g_depth", "g_weights")):
+                assert_close(a_, b_, 3 * TOL if what == "g_weights" else TOL, what=f"{what}, constant flows step {step}")
+        for a_, b_, what in zip(history[-1], history[1], ("loss", "g_depth", "g_weights")):
+            assert_close(a_, b_, 1e-6, abs_=1e-9, what=f"{what} after the originals were released")
+        with pytest.raises(RuntimeError, match="not been packed"):
+            flowmap_amd.release_flow_originals(Flows(*(x.clone().to(dev) for x in (fl.forward, fl.backward, fl.forward_mask, fl.backward_mask))))
+    finally:
+        fm.set_lazy_surfaces(False)

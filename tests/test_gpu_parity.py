@@ -123,7 +123,7 @@ def test_full_size_properties(f, h, w, packed):
         rf, rb = _ops.RelativePoses.apply(ext)
         norm = torch.tensor([1.0, 1.0], device=DEV)  # un-normalised numerator
         parts = [x[:, lo:hi].contiguous() for x in (ff, fb, mf, mb)]
-        pk = _ops.packed_flow_inputs(*parts) if packed else None
+        pk = _ops.packed_flow_inputs(*parts, eager=True) if packed else None
         assert (pk is not None) == packed
         loss = _ops.FlowLossFused.apply(d, k[:, lo : hi + 1].contiguous(), rf, rb, *parts, norm, 0, 0.01, True, 0, pk)
         loss.backward()
@@ -454,3 +454,7 @@ def test_one_launch_fit_agrees_with_the_three_launch_form_under_stress():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(300, dev=str(DEV), verbose=False) < 1e-5
+
+
+def test_pretraining_mode_never_packs_or_plans():
+    cases.case_pretraining_mode(DEV)

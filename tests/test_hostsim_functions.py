@@ -157,3 +157,7 @@ def test_noncontiguous_views_are_copied_loudly():
 
 def test_depth_adam_update_inside_the_flow_pass_with_the_softmin_sweep():
     cases.case_in_pass_adam("cpu", steps=24, softmin=True)
+
+
+def test_pretraining_mode_never_packs_or_plans():
+    cases.case_pretraining_mode("cpu")
