@@ -94,9 +94,12 @@ def parse():
     ap.add_argument("--optimizer", choices=["none", "fused", "in_pass", "torch"], default="none",
                     help="add the Adam step (lr 3e-5, config/overfit.yaml:30) to every iteration: flowmap_amd.FusedAdam or "
                          "torch.optim.Adam; the headline metric is fwd+bwd only (none)")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the step in a hipGraph (flowmap_amd.GraphedStep) and replay it: for the launch-bound regime "
-                         "(small frames, or a rank's share of a strong-scaling run); the sharded step's RCCL collectives are captured too")
+    ap.add_argument("--graph", nargs="?", const="whole", default=None, choices=["whole", "compute", "off"],
+                    help="replay the step as a hipGraph: `whole` (flowmap_amd.GraphedStep: everything incl. the sharded step's RCCL collectives; "
+                         "what a bare --graph means), `compute` (flowmap_amd.GraphedShardedStep: forward + backward in the graph, collectives issued "
+                         "eagerly after the replay), `off`.  Default: off on one GPU (the headline number is measured eagerly, with HIP events around the "
+                         "flow kernel), `compute` for a multi-rank strong-scaling run of the flow loss — a rank's ~15 kernels take ~0.2 ms at 8 GPUs and "
+                         "cannot hide ~0.45 ms of eager enqueueing")
     ap.add_argument("--share", type=int, default=0,
                     help="K > 0: run ONE rank's share of a K-GPU strong-scaling run on this GPU (its pairs + halo frames, collectives on a "
                          "one-rank RCCL communicator): the per-rank step time of a K-GPU run without the wire time")
@@ -327,6 +330,13 @@ def main():
     if args.share > 1 and not 0 <= cut_rank < args.share:
         raise SystemExit("--share-rank must be in [0, K)")
     strong = (cfg["scaling"] == "strong" and world > 1) or args.share > 1
+    if args.graph is None:
+        args.graph = "compute" if (strong and world > 1 and on_gpu and not cfg["tracking"] and args.intrinsics == "regressed"
+                                   and args.optimizer in ("none", "fused")) else "off"
+    if args.graph == "off":
+        args.graph = None
+    if args.graph == "compute" and (not strong or cfg["tracking"] or args.intrinsics != "regressed"):
+        raise SystemExit("--graph compute: a frame-sharded run of the flow loss with regressed intrinsics (the tracking loss and the softmin sweep have collectives inside forward / backward)")
     flowmap_amd.set_lazy_surfaces(True)
     if os.environ.get("FLOWMAP_THREE_LAUNCH_BWD"):  # A/B: the planned Procrustes backward as the three launches of round 2
         from flowmap_amd._lib import torch_ops
@@ -385,7 +395,7 @@ def main():
 
     optimizer = None
     if args.optimizer in ("fused", "in_pass"):
-        optimizer = flowmap_amd.FusedAdam(model.parameters(), lr=3e-5, capturable=args.graph)
+        optimizer = flowmap_amd.FusedAdam(model.parameters(), lr=3e-5, capturable=args.graph == "whole")
         if args.optimizer == "in_pass":  # the depth update applied by the flow-loss pass itself (FusedAdam.fuse_depth_update)
             if args.graph:
                 raise SystemExit("--optimizer in_pass: no --graph (the step number is a host value)")
@@ -394,18 +404,28 @@ def main():
         optimizer = torch.optim.Adam(model.parameters(), lr=3e-5)
     shared = [p for name, p in model.named_parameters() if not name.startswith("backbone.")]  # intrinsics: shared by all frames
 
-    def step():
+    def compute():  # zero_grad + forward + backward of this rank's frames: no collective
         model.zero_grad(set_to_none=True)
         out = model(batch, flows, 0)
         loss = loss_fn(batch, flows, None, out, 0)
+        loss.backward()
+        return loss
+
+    def step():
         tracked = None
         if track_fn is not None and strong:
+            model.zero_grad(set_to_none=True)
+            out = model(batch, flows, 0)
+            loss = loss_fn(batch, flows, None, out, 0)
             tracked = shard.tracking_loss(track_fn, tracks, out, total_pairs)  # global value, this rank's gradients
             (loss + tracked).backward()
-        else:
-            if track_fn is not None:
-                loss = loss + track_fn(batch, flows, tracks, out, 0)
+        elif track_fn is not None:
+            model.zero_grad(set_to_none=True)
+            out = model(batch, flows, 0)
+            loss = loss_fn(batch, flows, None, out, 0) + track_fn(batch, flows, tracks, out, 0)
             loss.backward()
+        else:
+            loss = compute()
         if strong:
             loss = shard.sync(loss, shared, model.backbone.depth, already_global=tracked)
         if optimizer is not None:
@@ -431,7 +451,16 @@ def main():
             torch.cuda.synchronize(device)
             eager_flow_ms = _ops.flow_kernel_times()
             _ops.flow_kernel_timing(False)
-        step = flowmap_amd.GraphedStep(step, warmup=3)  # noqa: F811
+        if args.graph == "compute":
+            sharded = flowmap_amd.GraphedShardedStep(compute, shard, shared, model.backbone.depth, warmup=3)
+
+            def step():  # noqa: F811
+                loss = sharded()
+                if optimizer is not None:
+                    optimizer.step()
+                return loss
+        else:
+            step = flowmap_amd.GraphedStep(step, warmup=3)  # noqa: F811
     for _ in range(args.warmup):
         step()
     flowmap_amd.freeze_gc()  # a full cyclic-GC pass over torch's import-time objects costs ~50 ms (flowmap_amd/host.py)
@@ -487,7 +516,8 @@ def main():
                     + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__}"
                        + (", depth update inside the flow pass)" if args.optimizer == "in_pass" and optimizer.counters["in_pass_updates"] > 0
                           else ", fuse_depth_update requested but the touched set is too large: separate update)" if args.optimizer == "in_pass" else ")"))
-                    + ("; whole step replayed as one hipGraph" if args.graph else "")
+                    + ("; whole step replayed as one hipGraph" if args.graph == "whole" else
+                   "; forward + backward replayed as one hipGraph, collectives issued eagerly after the replay" if args.graph == "compute" else "")
                 + (f"; PROXY: rank {cut_rank}'s share of a {cut_world}-GPU strong-scaling run on one GPU (pairs [{a}, {b}) of {total_pairs}, {f} frames incl. halo), "
                    "every collective on a one-rank RCCL communicator, halo exchange replaced by its local copies/adds; xGMI wire time NOT included" if args.share > 1 else ""))
         result = {

@@ -14,13 +14,13 @@ libflowmap_hip.so through ctypes; there is no CPU or eager fallback.
 from . import flow, loss, model  # noqa: F401
 from .install import install, uninstall  # noqa: F401
 from .model.projection import set_lazy_surfaces  # noqa: F401
-from .graph import GraphedStep  # noqa: F401
+from .graph import GraphedShardedStep, GraphedStep  # noqa: F401
 from .host import freeze_gc  # noqa: F401
 from ._ops import release_flow_originals  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 from .types import BackboneOutput, Batch, Flows, ModelOutput, Tracks  # noqa: F401
 
 __all__ = [
-    "loss", "model", "install", "uninstall", "set_lazy_surfaces", "FusedAdam", "GraphedStep", "freeze_gc", "release_flow_originals",
+    "loss", "model", "install", "uninstall", "set_lazy_surfaces", "FusedAdam", "GraphedStep", "GraphedShardedStep", "freeze_gc", "release_flow_originals",
     "Batch", "BackboneOutput", "Flows", "ModelOutput", "Tracks",
 ]

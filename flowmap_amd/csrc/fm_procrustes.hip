@@ -134,6 +134,63 @@ __device__ __forceinline__ void pose_chain_by_wave0(const float* r, int steps, f
   __syncthreads();
 }
 
+// A correspondence's gather chain is index -> (flow, weight, later depth) -> four taps of the earlier depth: three dependent
+// round trips to HBM (~2 us each on cold lines).  The chain is split into stages so that BOTH pairs' chains are in flight
+// together and the first two stages are issued before the block waits for the pose-solve backward.
+struct CorrStage1 {  // what the index leads to
+  int idx;
+  float fx, fy, w_raw, z_p;
+};
+struct CorrStage2 {  // the taps and their depths
+  Taps taps;
+  float z[4];
+};
+
+__device__ __forceinline__ CorrStage1 corr_stage1(const CorrSrc& s, int idx) {
+  CorrStage1 a;
+  a.idx = idx;
+  a.fx = s.bwd_flow[2 * (size_t)idx];
+  a.fy = s.bwd_flow[2 * (size_t)idx + 1];
+  a.w_raw = s.weights[idx];
+  a.z_p = s.depth_l[idx];
+  return a;
+}
+
+__device__ __forceinline__ CorrStage2 corr_stage2(const CorrSrc& s, const CorrStage1& a) {
+  CorrStage2 b;
+  const PixelRef px = pixel_ref(a.idx, s.height, s.width);
+  b.taps = bilinear_taps(px.u + a.fx, px.v + a.fy, s.height, s.width);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b.z[k] = b.taps.in[k] ? s.depth_e[tap_row(b.taps, k) * s.width + tap_col(b.taps, k)] : 0.f;
+  return b;
+}
+
+// The Corr that corr_load (fm_math.h) builds, from the staged loads: the same arithmetic in the same order.
+__device__ __forceinline__ Corr corr_assemble(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, const CorrStage1& a, const CorrStage2& b) {
+  Corr c;
+  c.idx = a.idx;
+  c.w = a.w_raw;
+  if (s.weight_sens != 0.f) c.w = fm_sigmoid<false>(s.weight_sens * c.w);
+  c.taps = b.taps;
+  const PixelRef px = pixel_ref(a.idx, s.height, s.width);
+  c.z_p = a.z_p;
+  ray_dir(kinv_l, px.u, px.v, c.ray_p);
+  c.p[0] = c.ray_p[0] * c.z_p;
+  c.p[1] = c.ray_p[1] * c.z_p;
+  c.p[2] = c.ray_p[2] * c.z_p;
+  c.q[0] = c.q[1] = c.q[2] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!c.taps.in[k]) continue;
+    float ray[3];
+    ray_dir(kinv_e, pixel_center(tap_col(c.taps, k), s.width), pixel_center(tap_row(c.taps, k), s.height), ray);
+    c.q[0] += (ray[0] * b.z[k]) * c.taps.w[k];
+    c.q[1] += (ray[1] * b.z[k]) * c.taps.w[k];
+    c.q[2] += (ray[2] * b.z[k]) * c.taps.w[k];
+  }
+  return c;
+}
+
 // What fm_procrustes_fit_chain adds to the moments kernel: the LAST block of a pair (a counter per pair) turns the
 // pair's sums into its pose, clears the sums and the counter for the next step (the workspace is persistent and
 // self-cleaning: no memset launch), and the last pair to finish (one more counter) chains the poses into the
@@ -234,12 +291,34 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
   }
   const CorrSrc src = pair_source<SRC>(p, pair, b, i);
   float shift[3];
-  pair_shift<SRC>(p, src, kinv_l, shift);
   float acc[kMomentCount];
 #pragma unroll
   for (int k = 0; k < kMomentCount; ++k) acc[k] = 0.f;
-  for (long j = threadIdx.x; j < p.points; j += blockDim.x)
-    moments_add(corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j), shift, acc);
+  if (SRC == SRC_DEPTH && p.indices != nullptr) {
+    // The reference point's chain (index -> depth) and the thread's first correspondence's chain (index -> flow, weight, depth ->
+    // taps) are issued stage by stage TOGETHER: three dependent round trips to HBM instead of five
+    const long first = threadIdx.x;
+    const bool on = first < p.points;
+    const int idx_mid = (int)p.indices[p.points / 2];
+    const int idx_j = on ? (int)p.indices[first] : idx_mid;
+    const CorrStage1 a = corr_stage1(src, idx_j);
+    float z_mid = src.depth_l[idx_mid];
+    const CorrStage2 bb = corr_stage2(src, a);
+    {  // later_point (fm_math.h) of the middle sample
+      const int row = idx_mid / src.width, col = idx_mid - row * src.width;
+      float ray[3];
+      ray_dir(kinv_l, pixel_center(col, src.width), pixel_center(row, src.height), ray);
+      shift[0] = ray[0] * z_mid; shift[1] = ray[1] * z_mid; shift[2] = ray[2] * z_mid;
+      for (int a3 = 0; a3 < 3; ++a3)
+        if (!(fabsf(shift[a3]) <= 3.0e38f)) shift[a3] = 0.f;
+    }
+    if (on) moments_add(corr_assemble(src, kinv_e, kinv_l, a, bb), shift, acc);
+    for (long j = first + blockDim.x; j < p.points; j += blockDim.x) moments_add(corr_load(src, kinv_e, kinv_l, (int)p.indices[j]), shift, acc);
+  } else {
+    pair_shift<SRC>(p, src, kinv_l, shift);
+    for (long j = threadIdx.x; j < p.points; j += blockDim.x)
+      moments_add(corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j), shift, acc);
+  }
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
 #pragma unroll
   for (int k = 0; k < kMomentCount; ++k) {
@@ -1113,65 +1192,8 @@ struct FitBwdPlan {
   int batch;
 };
 
-constexpr int kFitBwdThreads = 1024;
+constexpr int kFitBwdThreads = 512;
 constexpr int kFitBwdGather = 8;  // plan pixels a thread keeps in flight at a time
-
-// A correspondence's gather chain is index -> (flow, weight, later depth) -> four taps of the earlier depth: three dependent
-// round trips to HBM (~2 us each on cold lines).  The chain is split into stages so that BOTH pairs' chains are in flight
-// together and the first two stages are issued before the block waits for the pose-solve backward.
-struct CorrStage1 {  // what the index leads to
-  int idx;
-  float fx, fy, w_raw, z_p;
-};
-struct CorrStage2 {  // the taps and their depths
-  Taps taps;
-  float z[4];
-};
-
-__device__ __forceinline__ CorrStage1 corr_stage1(const CorrSrc& s, int idx) {
-  CorrStage1 a;
-  a.idx = idx;
-  a.fx = s.bwd_flow[2 * (size_t)idx];
-  a.fy = s.bwd_flow[2 * (size_t)idx + 1];
-  a.w_raw = s.weights[idx];
-  a.z_p = s.depth_l[idx];
-  return a;
-}
-
-__device__ __forceinline__ CorrStage2 corr_stage2(const CorrSrc& s, const CorrStage1& a) {
-  CorrStage2 b;
-  const PixelRef px = pixel_ref(a.idx, s.height, s.width);
-  b.taps = bilinear_taps(px.u + a.fx, px.v + a.fy, s.height, s.width);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) b.z[k] = b.taps.in[k] ? s.depth_e[tap_row(b.taps, k) * s.width + tap_col(b.taps, k)] : 0.f;
-  return b;
-}
-
-// The Corr that corr_load (fm_math.h) builds, from the staged loads: the same arithmetic in the same order.
-__device__ __forceinline__ Corr corr_assemble(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, const CorrStage1& a, const CorrStage2& b) {
-  Corr c;
-  c.idx = a.idx;
-  c.w = a.w_raw;
-  if (s.weight_sens != 0.f) c.w = fm_sigmoid<false>(s.weight_sens * c.w);
-  c.taps = b.taps;
-  const PixelRef px = pixel_ref(a.idx, s.height, s.width);
-  c.z_p = a.z_p;
-  ray_dir(kinv_l, px.u, px.v, c.ray_p);
-  c.p[0] = c.ray_p[0] * c.z_p;
-  c.p[1] = c.ray_p[1] * c.z_p;
-  c.p[2] = c.ray_p[2] * c.z_p;
-  c.q[0] = c.q[1] = c.q[2] = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (!c.taps.in[k]) continue;
-    float ray[3];
-    ray_dir(kinv_e, pixel_center(tap_col(c.taps, k), s.width), pixel_center(tap_row(c.taps, k), s.height), ray);
-    c.q[0] += (ray[0] * b.z[k]) * c.taps.w[k];
-    c.q[1] += (ray[1] * b.z[k]) * c.taps.w[k];
-    c.q[2] += (ray[2] * b.z[k]) * c.taps.w[k];
-  }
-  return c;
-}
 
 __device__ __forceinline__ PairGrad pair_grad_from(const double* pg, const double* ax) {
   PairGrad g;
@@ -1187,6 +1209,10 @@ __device__ __forceinline__ PairGrad pair_grad_from(const double* pg, const doubl
   return g;
 }
 
+// SLOTS: correspondences per thread and pair (P <= SLOTS · kFitBwdThreads): compile-time, so that every slot's staged
+// loads live in registers.  512 threads = 8 waves = 2 per SIMD: the fp64 pose-solve backward of the two solver threads gets
+// the 256-VGPR budget it wants (with 1024 threads — 128 VGPRs — it spilled 112 registers to scratch).
+template <int SLOTS>
 __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(ProcParams p, FitBwdPlan pl) {
   extern __shared__ float vec_lds[];  // [role 0: dL/dq of pair f | role 1: dL/dp of pair f−1][P][3]
   __shared__ double pg_lds[2][kPairGradStride];
@@ -1204,24 +1230,34 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
   load_mat3(p.kinv + (size_t)bf * 9, kinv_f);
   load_mat3(p.kinv + (size_t)(has_l ? bf - 1 : bf) * 9, kinv_m);
   load_mat3(p.kinv + (size_t)(has_e ? bf + 1 : bf) * 9, kinv_p);
-  // role 0: pair f = (earlier f, later f+1); role 1: pair f−1 = (earlier f−1, later f).  (An absent role reads pair f / f−1 of
-  // a neighbouring valid pair index 0 and is masked out below.)
+  // role 0: pair f = (earlier f, later f+1); role 1: pair f−1 = (earlier f−1, later f).  (An absent role gets the other
+  // role's pair — valid addresses — and is masked out below.)
   const CorrSrc src0 = pair_source<SRC_DEPTH>(p, has_e ? pair_e : pair_l, b, has_e ? f : f - 1);
   const CorrSrc src1 = pair_source<SRC_DEPTH>(p, has_l ? pair_l : pair_e, b, has_l ? f - 1 : f);
-
-  // ---- the plan slice of this frame: first round of loads (keys, entry ranges), issued before anything waits ----
   const int lo = pl.frame_first ? pl.frame_first[bf] : 0, hi = pl.frame_first ? pl.frame_first[bf + 1] : 0;
 
-  // ---- stage 1 + 2 of the first batch of correspondences of both pairs ----
-  const bool first_on = t < P;
-  CorrStage1 a0 = {}, a1 = {};
-  CorrStage2 b0 = {}, b1 = {};
-  if (first_on) {
-    const int idx = (int)p.indices[t];
-    if (has_e) a0 = corr_stage1(src0, idx);
-    if (has_l) a1 = corr_stage1(src1, idx);
-    if (has_e) b0 = corr_stage2(src0, a0);
-    if (has_l) b1 = corr_stage2(src1, a1);
+  // ---- stages 1 and 2 of every correspondence this thread owns, both pairs: all in flight before anything waits ----
+  CorrStage1 a0[SLOTS], a1[SLOTS];
+  CorrStage2 b0[SLOTS], b1[SLOTS];
+  int idx[SLOTS];
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl) {
+    const int j = sl * kFitBwdThreads + t;
+    idx[sl] = j < P ? (int)p.indices[j] : -1;
+  }
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl) {
+    a0[sl] = CorrStage1{};
+    a1[sl] = CorrStage1{};
+    if (idx[sl] >= 0 && has_e) a0[sl] = corr_stage1(src0, idx[sl]);
+    if (idx[sl] >= 0 && has_l) a1[sl] = corr_stage1(src1, idx[sl]);
+  }
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl) {
+    b0[sl] = CorrStage2{};
+    b1[sl] = CorrStage2{};
+    if (idx[sl] >= 0 && has_e) b0[sl] = corr_stage2(src0, a0[sl]);
+    if (idx[sl] >= 0 && has_l) b1[sl] = corr_stage2(src1, a1[sl]);
   }
 
   // ---- pose-solve backward of the two pairs, side by side in two waves (fp64, one thread each) ----
@@ -1259,20 +1295,13 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
   PairGrad g0 = {}, g1 = {};
   if (has_e) g0 = pair_grad_from(pg_lds[0], pl.aux + pair_e * kAuxStride);
   if (has_l) g1 = pair_grad_from(pg_lds[1], pl.aux + pair_l * kAuxStride);
-  for (int j0 = 0; j0 < P; j0 += kFitBwdThreads) {  // (block-uniform trip count)
-    const int j = j0 + t;
-    const bool on = j < P;
-    if (j0 > 0 && on) {  // later batches (P > 1024): the same stages, without the head start
-      const int idx = (int)p.indices[j];
-      if (has_e) a0 = corr_stage1(src0, idx);
-      if (has_l) a1 = corr_stage1(src1, idx);
-      if (has_e) b0 = corr_stage2(src0, a0);
-      if (has_l) b1 = corr_stage2(src1, a1);
-    }
-    if (!on) continue;
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl) {
+    if (idx[sl] < 0) continue;
+    const int j = sl * kFitBwdThreads + t;
     float gq[3], gp[3], gw;
     if (has_e) {
-      const Corr c = corr_assemble(src0, kinv_f, kinv_p, a0, b0);
+      const Corr c = corr_assemble(src0, kinv_f, kinv_p, a0[sl], b0[sl]);
       corr_backward(c, g0, gq, gp, gw);
       if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
       if (p.grad_weights) p.grad_weights[pair_e * (size_t)n + c.idx] = gw;  // distinct indices: a plain store per slot
@@ -1280,7 +1309,7 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
       out[0] = gq[0], out[1] = gq[1], out[2] = gq[2];
     }
     if (has_l) {
-      const Corr c = corr_assemble(src1, kinv_m, kinv_f, a1, b1);
+      const Corr c = corr_assemble(src1, kinv_m, kinv_f, a1[sl], b1[sl]);
       corr_backward(c, g1, gq, gp, gw);
       float* out = vec_lds + ((size_t)P + j) * 3;
       out[0] = gp[0], out[1] = gp[1], out[2] = gp[2];
@@ -1744,7 +1773,13 @@ int fm_procrustes_bwd_planned(const float* depth, const float* kinv, const float
   p.batch_repeat = 1;
   FitBwdPlan pl{g_t_bwd, g_t_fwd, t_bwd, aux, plan_pixels, plan_first, plan_vectors, plan_weights, frame_first, g_k, accumulate_k, batch};
   const size_t lds = sizeof(float) * 2 * 3 * (size_t)points;
-  hipLaunchKernelGGL(procrustes_bwd_frame_kernel, dim3((unsigned)(batch * frames)), dim3(kFitBwdThreads), lds, (hipStream_t)stream, p, pl);
+  const dim3 grid((unsigned)(batch * frames)), block(kFitBwdThreads);
+  const int slots = (int)((points + kFitBwdThreads - 1) / kFitBwdThreads);
+  static_assert(FM_FIT_BWD_MAX_POINTS <= 4 * kFitBwdThreads, "slots per thread");
+  if (slots <= 1) hipLaunchKernelGGL(procrustes_bwd_frame_kernel<1>, grid, block, lds, (hipStream_t)stream, p, pl);
+  else if (slots == 2) hipLaunchKernelGGL(procrustes_bwd_frame_kernel<2>, grid, block, lds, (hipStream_t)stream, p, pl);
+  else if (slots == 3) hipLaunchKernelGGL(procrustes_bwd_frame_kernel<3>, grid, block, lds, (hipStream_t)stream, p, pl);
+  else hipLaunchKernelGGL(procrustes_bwd_frame_kernel<4>, grid, block, lds, (hipStream_t)stream, p, pl);
   FM_LAUNCH_STATUS();
 }
 

@@ -66,3 +66,37 @@ class GraphedStep:
 
     def close(self) -> None:
         _ops.graph_capturable = self._previous
+
+
+class GraphedShardedStep:
+    """A frame-sharded step with its COMPUTE replayed as one hipGraph and its collectives issued eagerly after the replay.
+
+    ``compute() -> local loss`` runs zero_grad + forward + backward of this rank's shard and NO collective (the halo
+    exchange's gradient hook is held back while this object exists: ``FrameShard.defer_halo``); ``FrameShard.sync`` then
+    reduces [loss, shared gradients] and exchanges the halo frames as usual.  Per step the host enqueues one graph launch and
+    the three collectives, while the GPU is still busy with the graph: what a rank of an 8-GPU strong-scaling run needs
+    (its ~15 kernels take ~0.2 ms, eagerly enqueueing them ~0.45 ms), without RCCL inside a captured graph — the safe
+    default for multi-rank runs; ``GraphedStep`` over the whole step (collectives captured too) saves the remaining host time.
+
+    The gradient tensors the captured backward writes live in the graph's memory pool and are the same every replay;
+    ``sync`` re-points the shared parameters' ``.grad`` at its reduction buffer, so they are restored before every sync."""
+
+    def __init__(self, compute: Callable[[], object], shard, shared_params, depth_param, warmup: int = 3, device=None) -> None:
+        self.shard, self.shared, self.depth_param = shard, list(shared_params), depth_param
+        shard.defer_halo = True
+        self.inner = GraphedStep(compute, warmup=warmup, device=device)
+        self.loss = self.inner.output
+        self.grads = [p.grad for p in self.shared]
+        self.depth_grad = None if depth_param is None else depth_param.grad
+
+    def __call__(self, already_global=None):
+        self.inner.graph.replay()
+        for p, g in zip(self.shared, self.grads):
+            p.grad = g
+        if self.depth_param is not None:
+            self.depth_param.grad = self.depth_grad
+        return self.shard.sync(self.loss, self.shared, self.depth_param, already_global=already_global)
+
+    def close(self) -> None:
+        self.shard.defer_halo = False
+        self.inner.close()

@@ -83,6 +83,7 @@ class FrameShard:
     def __init__(self, rank: int = 0, world: int = 1, dist=None, group=None, proxy: bool = False):
         self.rank, self.world, self.dist, self.group, self.proxy = rank, world, dist, group, proxy
         self._halo = None  # (requests, recv_prev, recv_next, gradient) of the exchange in flight
+        self.defer_halo = False  # True: the gradient hook does not post the exchange (GraphedShardedStep: sync() posts it after the replay)
         self._halo_buffers = {}  # (shape, device) -> persistent receive (and proxy send) buffers
         self._packed = None  # (key, buffer, views): [loss, gradients of the shared parameters] reduced in place every step
 
@@ -127,7 +128,7 @@ class FrameShard:
             intr.shard = self
         depth = getattr(getattr(model, "backbone", None), "depth", None)
         if depth is not None and depth.requires_grad:
-            depth.register_post_accumulate_grad_hook(lambda param: self.start_halo_exchange(param.grad))
+            depth.register_post_accumulate_grad_hook(lambda param: None if self.defer_halo else self.start_halo_exchange(param.grad))
             halo = ([0] if self.rank > 0 else []) + ([depth.shape[0] - 1] if self.rank < self.world - 1 else [])
             depth.__dict__["_fm_halo_frames"] = tuple(halo)
 
