@@ -50,7 +50,7 @@ SIGNATURES = {
     "fm_adam_step_capturable": [P, P, P, P, L, P, D, D, D, D, D, P],
     "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, I, P, P],
     "fm_procrustes_fit": [P] * 5 + [F, P, L, I, I, I, I, I, P, P, P, P, P],
-    "fm_procrustes_fit_chain": [P] * 5 + [F, P, L, I, I, I, I, P, P, P, P, P, P],
+    "fm_procrustes_fit_chain": [P] * 5 + [F, P, L, I, I, I, I, P, P, P, P, P, P, P],
     "fm_pose_solve": [P, I, P, P, P, P],
     "fm_pose_solve_bwd": [P, P, P, P, I, P, P, L, P],
     "fm_procrustes_scatter": [P] * 5 + [F, P, L, I, I, I, I, I] + [P] * 8 + [P],
@@ -89,7 +89,7 @@ SIGNATURES = {
     "fm_track_scatter_plan": [P, P, P, P, I, I, I, I, P, P, P],
     "fm_depth_gather": [P, P, P, P, P, L, P, P, P, I, I, L, P, P],
     "fm_depth_gather_kgrad": [P, P, P, P, P, L, P, I, I, P, P, I, P, I, P],
-    "fm_procrustes_bwd_planned": [P, P, P, P, F, P, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, P],
+    "fm_procrustes_bwd_planned": [P, P, F, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, P],
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -25,6 +25,21 @@
 
 namespace fm {
 
+// -DFM_PHASE_CLOCKS (tools/build_variants.sh, tools/phase_clocks.py): thread 0 of the first blocks of the one-block-per-pair /
+// one-block-per-frame kernels stamps the shader clock at its phase boundaries.  Not compiled into the product library.
+#ifdef FM_PHASE_CLOCKS
+constexpr int kPhaseSlots = 12, kPhaseBlocks = 256;
+__device__ long long fm_phase_clock_buffer[kPhaseBlocks][kPhaseSlots];
+#define FM_PHASE(slot)                                                                                       \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < kPhaseBlocks) fm_phase_clock_buffer[blockIdx.x][slot] = wall_clock64(); \
+  } while (0)
+#else
+#define FM_PHASE(slot) \
+  do {                 \
+  } while (0)
+#endif
+
 
 struct ProcParams {
   const float* depth;      // (B,F,H,W)            [SRC_DEPTH]
@@ -191,6 +206,18 @@ __device__ __forceinline__ Corr corr_assemble(const CorrSrc& s, const Mat3& kinv
   return c;
 }
 
+// What the forward fit leaves behind per correspondence for the one-launch backward (fm_procrustes_bwd_planned): 32 bytes,
+// q (3), p (3), w, the pixel index — written and later read as two 16-byte vectors, consecutive correspondences by
+// consecutive lanes.  The backward then has no gather chain at all (the forward has just paid for it).
+typedef float corr_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void corr_record(float* corr_out, size_t slot, const Corr& c) {
+  if (corr_out == nullptr) return;
+  corr_v4* o = reinterpret_cast<corr_v4*>(corr_out) + slot * 2;
+  corr_v4 lo4 = {c.q[0], c.q[1], c.q[2], c.p[0]}, hi4 = {c.p[1], c.p[2], c.w, __int_as_float(c.idx)};
+  o[0] = lo4;
+  o[1] = hi4;
+}
+
 // What fm_procrustes_fit_chain adds to the moments kernel: the LAST block of a pair (a counter per pair) turns the
 // pair's sums into its pose, clears the sums and the counter for the next step (the workspace is persistent and
 // self-cleaning: no memset launch), and the last pair to finish (one more counter) chains the poses into the
@@ -202,6 +229,7 @@ struct FitChain {
   double* aux;
   float* ext;     // (B, F, 4, 4)
   int batch;
+  float* corr_out;  // (pairs·P, 8) or null: q (3), p (3), w, index bits of every correspondence, for fm_procrustes_bwd_planned
 };
 
 // grid: (chunks, B*(F-1)): raw moments of every correspondence into stats[0..15] (fp64 atomics).
@@ -312,12 +340,23 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
       for (int a3 = 0; a3 < 3; ++a3)
         if (!(fabsf(shift[a3]) <= 3.0e38f)) shift[a3] = 0.f;
     }
-    if (on) moments_add(corr_assemble(src, kinv_e, kinv_l, a, bb), shift, acc);
-    for (long j = first + blockDim.x; j < p.points; j += blockDim.x) moments_add(corr_load(src, kinv_e, kinv_l, (int)p.indices[j]), shift, acc);
+    if (on) {
+      const Corr c = corr_assemble(src, kinv_e, kinv_l, a, bb);
+      moments_add(c, shift, acc);
+      corr_record(fc.corr_out, pair * (size_t)p.points + (size_t)first, c);
+    }
+    for (long j = first + blockDim.x; j < p.points; j += blockDim.x) {
+      const Corr c = corr_load(src, kinv_e, kinv_l, (int)p.indices[j]);
+      moments_add(c, shift, acc);
+      corr_record(fc.corr_out, pair * (size_t)p.points + (size_t)j, c);
+    }
   } else {
     pair_shift<SRC>(p, src, kinv_l, shift);
-    for (long j = threadIdx.x; j < p.points; j += blockDim.x)
-      moments_add(corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j), shift, acc);
+    for (long j = threadIdx.x; j < p.points; j += blockDim.x) {
+      const Corr c = corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j);
+      moments_add(c, shift, acc);
+      corr_record(fc.corr_out, pair * (size_t)p.points + (size_t)j, c);
+    }
   }
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
 #pragma unroll
@@ -1209,11 +1248,15 @@ __device__ __forceinline__ PairGrad pair_grad_from(const double* pg, const doubl
   return g;
 }
 
-// SLOTS: correspondences per thread and pair (P <= SLOTS · kFitBwdThreads): compile-time, so that every slot's staged
-// loads live in registers.  512 threads = 8 waves = 2 per SIMD: the fp64 pose-solve backward of the two solver threads gets
+// SLOTS: correspondences per thread and pair (P <= SLOTS · kFitBwdThreads): compile-time, so that every slot's record
+// lives in registers.  512 threads = 8 waves = 2 per SIMD: the fp64 pose-solve backward of the two solver threads gets
 // the 256-VGPR budget it wants (with 1024 threads — 128 VGPRs — it spilled 112 registers to scratch).
+// `corr` (pairs·P, 8): the records the forward fit left (corr_record): the backward reads them as coalesced 16-byte vectors;
+// the only scattered accesses left are the read-modify-writes of dL/ddepth and the stores of dL/dweights.  (Measured with
+// phase clocks, tools/phase_clocks.py: re-gathering the correspondences — index -> flow -> taps, ~3 000 cold 64-byte lines per
+// block and dependent round — cost 18 of the block's 52 us at C1, and a cold dependent round costs 5 us even on an idle GPU.)
 template <int SLOTS>
-__global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(ProcParams p, FitBwdPlan pl) {
+__global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(ProcParams p, FitBwdPlan pl, const float* __restrict__ corr) {
   extern __shared__ float vec_lds[];  // [role 0: dL/dq of pair f | role 1: dL/dp of pair f−1][P][3]
   __shared__ double pg_lds[2][kPairGradStride];
   __shared__ double kacc_lds[2][9];
@@ -1225,42 +1268,37 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
   const size_t pair_e = (size_t)b * (p.frames - 1) + f, pair_l = pair_e - 1;
   const int t = threadIdx.x;
   const int P = (int)p.points;
+  FM_PHASE(0);
 
-  Mat3 kinv_m, kinv_f, kinv_p;  // K⁻¹ of frames f−1, f, f+1
+  Mat3 kinv_f;  // K⁻¹ of this frame
   load_mat3(p.kinv + (size_t)bf * 9, kinv_f);
-  load_mat3(p.kinv + (size_t)(has_l ? bf - 1 : bf) * 9, kinv_m);
-  load_mat3(p.kinv + (size_t)(has_e ? bf + 1 : bf) * 9, kinv_p);
-  // role 0: pair f = (earlier f, later f+1); role 1: pair f−1 = (earlier f−1, later f).  (An absent role gets the other
-  // role's pair — valid addresses — and is masked out below.)
-  const CorrSrc src0 = pair_source<SRC_DEPTH>(p, has_e ? pair_e : pair_l, b, has_e ? f : f - 1);
-  const CorrSrc src1 = pair_source<SRC_DEPTH>(p, has_l ? pair_l : pair_e, b, has_l ? f - 1 : f);
   const int lo = pl.frame_first ? pl.frame_first[bf] : 0, hi = pl.frame_first ? pl.frame_first[bf + 1] : 0;
 
-  // ---- stages 1 and 2 of every correspondence this thread owns, both pairs: all in flight before anything waits ----
-  CorrStage1 a0[SLOTS], a1[SLOTS];
-  CorrStage2 b0[SLOTS], b1[SLOTS];
-  int idx[SLOTS];
+  // ---- the records of both pairs (issued before anything waits; consumed after the pose-solve backward) ----
+  corr_v4 r0a[SLOTS], r0b[SLOTS], r1a[SLOTS], r1b[SLOTS];
+  const corr_v4* rec_e = reinterpret_cast<const corr_v4*>(corr) + (has_e ? pair_e : pair_l) * (size_t)P * 2;
+  const corr_v4* rec_l = reinterpret_cast<const corr_v4*>(corr) + (has_l ? pair_l : pair_e) * (size_t)P * 2;
 #pragma unroll
   for (int sl = 0; sl < SLOTS; ++sl) {
     const int j = sl * kFitBwdThreads + t;
-    idx[sl] = j < P ? (int)p.indices[j] : -1;
+    const int jj = j < P ? j : 0;
+    r0a[sl] = rec_e[jj * 2], r0b[sl] = rec_e[jj * 2 + 1];
+    r1a[sl] = rec_l[jj * 2], r1b[sl] = rec_l[jj * 2 + 1];
   }
+  // ... and the first batch of this frame's plan slice (keys, entry ranges): nothing here depends on the gradients
+  int px[kFitBwdGather], e0[kFitBwdGather], e1[kFitBwdGather];
+  const int64_t frame_base = (int64_t)bf * n;
 #pragma unroll
-  for (int sl = 0; sl < SLOTS; ++sl) {
-    a0[sl] = CorrStage1{};
-    a1[sl] = CorrStage1{};
-    if (idx[sl] >= 0 && has_e) a0[sl] = corr_stage1(src0, idx[sl]);
-    if (idx[sl] >= 0 && has_l) a1[sl] = corr_stage1(src1, idx[sl]);
-  }
-#pragma unroll
-  for (int sl = 0; sl < SLOTS; ++sl) {
-    b0[sl] = CorrStage2{};
-    b1[sl] = CorrStage2{};
-    if (idx[sl] >= 0 && has_e) b0[sl] = corr_stage2(src0, a0[sl]);
-    if (idx[sl] >= 0 && has_l) b1[sl] = corr_stage2(src1, a1[sl]);
+  for (int i = 0; i < kFitBwdGather; ++i) {
+    const int m = lo + t + i * kFitBwdThreads;
+    const bool on = m < hi;
+    px[i] = on ? (int)(pl.pixels[m] - frame_base) : -1;
+    e0[i] = on ? pl.first[m] : 0;
+    e1[i] = on ? pl.first[m + 1] : 0;
   }
 
   // ---- pose-solve backward of the two pairs, side by side in two waves (fp64, one thread each) ----
+  FM_PHASE(1);
   if (t == 0 || t == kWave) {
     const int role = t == 0 ? 0 : 1;
     const bool on = role == 0 ? has_e : has_l;
@@ -1270,6 +1308,7 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
       double* pg = pg_lds[role];
       pose_solve_bwd_one(pl.g_t_bwd ? pl.g_t_bwd + pr * 16 : nullptr, pl.g_t_fwd ? pl.g_t_fwd + pr * 16 : nullptr, pl.t_bwd + pr * 16,
                          pl.aux + pr * kAuxStride, pg);
+      FM_PHASE(2);
       if (pl.g_k) {
         double kd[9], kf[9];
         for (int k = 0; k < 9; ++k) kd[k] = kinv_f.m[k];
@@ -1280,7 +1319,9 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
     }
     for (int k = 0; k < 9; ++k) kacc_lds[role][k] = acc[k];
   }
+  FM_PHASE(3);
   __syncthreads();
+  FM_PHASE(4);
   if (t == 2 * kWave && pl.g_k) {  // dK = [g_k] − K⁻ᵀ·dK⁻¹·K⁻ᵀ (kinv_grad_to_k), both roles summed in fp64; a third wave, off the others' path
     double tot[9], gk[9];
     for (int k = 0; k < 9; ++k) tot[k] = kacc_lds[0][k] + kacc_lds[1][k];
@@ -1297,42 +1338,45 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
   if (has_l) g1 = pair_grad_from(pg_lds[1], pl.aux + pair_l * kAuxStride);
 #pragma unroll
   for (int sl = 0; sl < SLOTS; ++sl) {
-    if (idx[sl] < 0) continue;
     const int j = sl * kFitBwdThreads + t;
+    if (j >= P) continue;
     float gq[3], gp[3], gw;
+    Corr c;  // (corr_backward reads p, q, w only)
     if (has_e) {
-      const Corr c = corr_assemble(src0, kinv_f, kinv_p, a0[sl], b0[sl]);
+      c.q[0] = r0a[sl].x, c.q[1] = r0a[sl].y, c.q[2] = r0a[sl].z, c.p[0] = r0a[sl].w, c.p[1] = r0b[sl].x, c.p[2] = r0b[sl].y, c.w = r0b[sl].z;
       corr_backward(c, g0, gq, gp, gw);
       if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
-      if (p.grad_weights) p.grad_weights[pair_e * (size_t)n + c.idx] = gw;  // distinct indices: a plain store per slot
+      if (p.grad_weights) p.grad_weights[pair_e * (size_t)n + __float_as_int(r0b[sl].w)] = gw;  // distinct indices: a plain store per slot
       float* out = vec_lds + (size_t)j * 3;
       out[0] = gq[0], out[1] = gq[1], out[2] = gq[2];
     }
     if (has_l) {
-      const Corr c = corr_assemble(src1, kinv_m, kinv_f, a1[sl], b1[sl]);
+      c.q[0] = r1a[sl].x, c.q[1] = r1a[sl].y, c.q[2] = r1a[sl].z, c.p[0] = r1a[sl].w, c.p[1] = r1b[sl].x, c.p[2] = r1b[sl].y, c.w = r1b[sl].z;
       corr_backward(c, g1, gq, gp, gw);
       float* out = vec_lds + ((size_t)P + j) * 3;
       out[0] = gp[0], out[1] = gp[1], out[2] = gp[2];
     }
   }
+  FM_PHASE(5);
   __syncthreads();
+  FM_PHASE(6);
   if (p.grad_depth == nullptr) return;
 
   // ---- this frame's slice of the planned gather: one plain read-modify-write per touched pixel.  A thread keeps
-  // kFitBwdGather pixels in flight: their keys and entry ranges (round 1), their old gradient values and first entries
-  // (round 2) — three dependent round trips per batch instead of four per pixel ----
-  const int64_t frame_base = (int64_t)bf * n;
+  // kFitBwdGather pixels in flight: their keys and entry ranges (round 1, issued at the top for the first batch), their
+  // old gradient values and first entries (round 2) ----
   const int base_e = (int)(pair_e * (size_t)P), base_l = (int)(pair_l * (size_t)P);
   float* gd = p.grad_depth + frame_base;
   for (int m0 = lo + t; m0 < hi; m0 += kFitBwdThreads * kFitBwdGather) {
-    int px[kFitBwdGather], e0[kFitBwdGather], e1[kFitBwdGather];
+    if (m0 != lo + t) {
 #pragma unroll
-    for (int i = 0; i < kFitBwdGather; ++i) {
-      const int m = m0 + i * kFitBwdThreads;
-      const bool on = m < hi;
-      px[i] = on ? (int)(pl.pixels[m] - frame_base) : -1;
-      e0[i] = on ? pl.first[m] : 0;
-      e1[i] = on ? pl.first[m + 1] : 0;
+      for (int i = 0; i < kFitBwdGather; ++i) {
+        const int m = m0 + i * kFitBwdThreads;
+        const bool on = m < hi;
+        px[i] = on ? (int)(pl.pixels[m] - frame_base) : -1;
+        e0[i] = on ? pl.first[m] : 0;
+        e1[i] = on ? pl.first[m + 1] : 0;
+      }
     }
     float old[kFitBwdGather], wt[kFitBwdGather];
     int vi[kFitBwdGather];
@@ -1363,7 +1407,9 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
       }
       gd[px[i]] = old[i] + sum;
     }
+    if (m0 == lo + t) FM_PHASE(7);
   }
+  FM_PHASE(8);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1678,17 +1724,18 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
 
 int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
                             float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
-                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, void* stream) {
+                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
   FM_CHECK_ARG(bwd_flow && weights && work && t_bwd && aux && points >= 1 && batch >= 1 && frames >= 2);
   FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
+  FM_CHECK_ARG(!corr_out || (points <= 4096 && (reinterpret_cast<uintptr_t>(corr_out) & 15) == 0));
   const int pairs = batch * (frames - 1);
   ProcParams p{};
   p.depth = depth; p.kinv = kinv; p.surfaces = surfaces; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
   p.stats = work; p.frames = frames; p.height = height; p.width = width; p.points = points;
   p.weight_sens = weight_sensitivity;
   p.batch_repeat = 1;
-  FitChain fc{reinterpret_cast<int*>(work + (size_t)pairs * kStatStride), t_bwd, t_fwd, aux, ext, batch};
+  FitChain fc{reinterpret_cast<int*>(work + (size_t)pairs * kStatStride), t_bwd, t_fwd, aux, ext, batch, corr_out};
   if (points <= 4096) {  // one block per pair: the sums stay in the block (procrustes_fit_pair_kernel)
     int* counter = fc.counters + pairs;  // the last of the workspace's ints
     if (surfaces) hipLaunchKernelGGL((procrustes_fit_pair_kernel<SRC_SURF>), dim3(pairs), dim3(1024), 0, (hipStream_t)stream, p, fc, counter);
@@ -1756,17 +1803,16 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
   FM_LAUNCH_STATUS();
 }
 
-int fm_procrustes_bwd_planned(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float weight_sensitivity,
-                              const int64_t* indices, long points, int batch, int frames, int height, int width, const double* aux,
-                              const float* t_bwd, const float* g_t_bwd, const float* g_t_fwd, const int64_t* plan_pixels,
+int fm_procrustes_bwd_planned(const float* corr, const float* kinv, float weight_sensitivity, long points, int batch, int frames, int height, int width,
+                              const double* aux, const float* t_bwd, const float* g_t_bwd, const float* g_t_fwd, const int64_t* plan_pixels,
                               const int32_t* plan_first, const int32_t* plan_vectors, const float* plan_weights, const int32_t* frame_first,
                               float* grad_depth, float* grad_weights, float* g_k, int accumulate_k, void* stream) {
-  FM_CHECK_ARG(depth && kinv && bwd_flow && weights && indices && aux && t_bwd);
+  FM_CHECK_ARG(corr && kinv && aux && t_bwd && (reinterpret_cast<uintptr_t>(corr) & 15) == 0);
   FM_CHECK_ARG(points >= 1 && points <= FM_FIT_BWD_MAX_POINTS && batch >= 1 && frames >= 2 && height >= 1 && width >= 1);
   FM_CHECK_ARG(!grad_depth || (plan_pixels && plan_first && plan_vectors && plan_weights && frame_first));
   FM_CHECK_ARG((long)batch * (frames - 1) * points < (1L << 30));
   ProcParams p{};
-  p.depth = depth; p.kinv = kinv; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
+  p.kinv = kinv;
   p.grad_depth = grad_depth; p.grad_weights = grad_weights;
   p.frames = frames; p.height = height; p.width = width; p.points = points;
   p.weight_sens = weight_sensitivity;
@@ -1776,12 +1822,19 @@ int fm_procrustes_bwd_planned(const float* depth, const float* kinv, const float
   const dim3 grid((unsigned)(batch * frames)), block(kFitBwdThreads);
   const int slots = (int)((points + kFitBwdThreads - 1) / kFitBwdThreads);
   static_assert(FM_FIT_BWD_MAX_POINTS <= 4 * kFitBwdThreads, "slots per thread");
-  if (slots <= 1) hipLaunchKernelGGL(procrustes_bwd_frame_kernel<1>, grid, block, lds, (hipStream_t)stream, p, pl);
-  else if (slots == 2) hipLaunchKernelGGL(procrustes_bwd_frame_kernel<2>, grid, block, lds, (hipStream_t)stream, p, pl);
-  else if (slots == 3) hipLaunchKernelGGL(procrustes_bwd_frame_kernel<3>, grid, block, lds, (hipStream_t)stream, p, pl);
-  else hipLaunchKernelGGL(procrustes_bwd_frame_kernel<4>, grid, block, lds, (hipStream_t)stream, p, pl);
+  if (slots <= 1) hipLaunchKernelGGL(procrustes_bwd_frame_kernel<1>, grid, block, lds, (hipStream_t)stream, p, pl, corr);
+  else if (slots == 2) hipLaunchKernelGGL(procrustes_bwd_frame_kernel<2>, grid, block, lds, (hipStream_t)stream, p, pl, corr);
+  else if (slots == 3) hipLaunchKernelGGL(procrustes_bwd_frame_kernel<3>, grid, block, lds, (hipStream_t)stream, p, pl, corr);
+  else hipLaunchKernelGGL(procrustes_bwd_frame_kernel<4>, grid, block, lds, (hipStream_t)stream, p, pl, corr);
   FM_LAUNCH_STATUS();
 }
+
+#ifdef FM_PHASE_CLOCKS
+int fm_debug_phase_clocks(long long* host_out, int blocks) {  // (blocks, kPhaseSlots) wall_clock64 stamps (100 MHz) of the last launch
+  if (blocks > kPhaseBlocks) blocks = kPhaseBlocks;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fm_phase_clock_buffer), sizeof(long long) * blocks * kPhaseSlots) == hipSuccess ? kPhaseSlots : -1;
+}
+#endif
 
 int fm_procrustes_dense_tiles(int height, int width, int* tiles) {
   FM_CHECK_ARG(tiles && height >= 1 && width >= 1);

@@ -430,7 +430,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     Tensor aux = at::empty({pairs, FM_AUX_STRIDE}, weights.options().dtype(at::kDouble));
     Tensor t_bwd = empty_like_shape({b, f - 1, 4, 4}, weights), t_fwd = empty_like_shape({b, f - 1, 4, 4}, weights);
     // With a persistent workspace (sparse index set, no repeat): moments, finish + solve and the pose chain in ONE launch
-    Tensor work = opt(work_o), ext, stats;
+    Tensor work = opt(work_o), ext, stats, corr;
     const bool chained = work.defined() && indices.defined() && rep == 1;
     {
       DeviceScope scope(dev);
@@ -438,9 +438,13 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
         TORCH_CHECK(work.scalar_type() == at::kDouble && work.is_contiguous() && work.numel() >= pairs * FM_STAT_STRIDE + (pairs + 2) / 2 + 1,
                     "flowmap_amd: the fit workspace is too small");
         ext = empty_like_shape({b, f, 4, 4}, weights);
+        // the planned backward (one launch, fm_procrustes_bwd_planned) reads the correspondences back instead of re-gathering them
+        const bool wants_records = from_depth && grad_enabled && plan_frame_first.has_value() && plan_frame_first->defined() && points <= FM_FIT_BWD_MAX_POINTS &&
+                                   use_one_launch_backward() && (depth.requires_grad() || weights_in.requires_grad() || (k_o.has_value() && k_o->requires_grad()));
+        if (wants_records) corr = at::empty({pairs * points, 8}, weights.options());
         FM_CALL(fm_procrustes_fit_chain, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights),
                 (float)weight_sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(work), ptr(t_bwd), ptr(t_fwd),
-                ptr<double>(aux), ptr(ext), scope.stream);
+                ptr<double>(aux), ptr(ext), ptr(corr), scope.stream);
       } else {
         stats = at::empty({pairs, FM_STAT_STRIDE}, weights.options().dtype(at::kDouble));
         FM_CALL(fm_procrustes_fit, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights), (float)weight_sens,
@@ -449,7 +453,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       }
     }
     ctx->save_for_backward({from_depth ? depth : surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux, opt(plan_pixels), opt(plan_first),
-                            opt(plan_vectors), opt(plan_weights), opt(dense_first), opt(dense_list), ext, opt(plan_frame_first)});
+                            opt(plan_vectors), opt(plan_weights), opt(dense_first), opt(dense_list), ext, opt(plan_frame_first), corr});
     ctx->saved_data["dims"] = std::vector<int64_t>{b, f, h, w, points, rep, from_depth ? 1 : 0};
     ctx->saved_data["weight_sens"] = weight_sens;
     if (sink) ctx->saved_data["sink"] = sink;
@@ -472,7 +476,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     const Tensor &src = saved[0], &kinv = saved[1], &weights = saved[2], &bwd_flow = saved[3], &indices = saved[4], &t_bwd = saved[5],
                  &aux = saved[6];
     const Tensor &plan_pixels = saved[7], &plan_first = saved[8], &plan_vectors = saved[9], &plan_weights = saved[10],
-                 &dense_first = saved[11], &dense_list = saved[12], &ext = saved[13], &plan_frame_first = saved[14];
+                 &dense_first = saved[11], &dense_list = saved[12], &ext = saved[13], &plan_frame_first = saved[14], &corr = saved[15];
     const auto dims = ctx->saved_data["dims"].toIntVector();
     const int64_t b = dims[0], f = dims[1], h = dims[2], w = dims[3], points = dims[4], rep = dims[5];
     const bool from_depth = dims[6] != 0;
@@ -528,13 +532,13 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     const bool k_closed_form = need_k && from_depth && rep == 1;
     // A planned fit of up to FM_FIT_BWD_MAX_POINTS points per pair: pose-solve backward, per-correspondence gradients, the planned
     // gather and dL/dK in ONE launch, one workgroup per frame (fm_procrustes_bwd_planned)
-    const bool one_launch = planned && g_src.defined() && plan_frame_first.defined() && points <= FM_FIT_BWD_MAX_POINTS && use_one_launch_backward();
+    const bool one_launch = planned && g_src.defined() && plan_frame_first.defined() && corr.defined() && points <= FM_FIT_BWD_MAX_POINTS;
     if (one_launch) {
       const bool add_k = need_k && carried_k.defined() && carried_k.sizes() == kinv.sizes() && carried_k.is_contiguous();
       if (need_k) g_k = add_k ? carried_k : at::empty_like(kinv);
       {
         DeviceScope scope(dev);
-        FM_CALL(fm_procrustes_bwd_planned, ptr(src), ptr(kinv), ptr(bwd_flow), ptr(weights), sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f,
+        FM_CALL(fm_procrustes_bwd_planned, ptr(corr), ptr(kinv), sens, (long)points, (int)b, (int)f,
                 (int)h, (int)w, ptr<double>(aux), ptr(t_bwd), ptr(g_t), ptr(g_t_fwd), ptr<int64_t>(plan_pixels), ptr<int32_t>(plan_first),
                 ptr<int32_t>(plan_vectors), ptr(plan_weights), ptr<int32_t>(plan_frame_first), ptr(g_src), ptr(g_w), ptr(g_k), add_k ? 1 : 0,
                 scope.stream);

@@ -144,10 +144,12 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
  * finish chains the poses into ext (B,F,4,4); larger index sets use four workgroups per pair and fp64 atomics, the last of a
  * pair solving.  ext may be NULL (poses only).
  * work: persistent workspace of B·(F-1)·FM_STAT_STRIDE doubles followed by B·(F-1)+1 ints, ZERO on entry and left
- * zero (self-cleaning: zero it once, when it is allocated; one launch at a time per workspace). */
+ * zero (self-cleaning: zero it once, when it is allocated; one launch at a time per workspace).
+ * corr_out (optional, (B·(F-1)·P, 8) floats, 16-byte aligned, P <= 4096): the record of every correspondence —
+ * q (3), p (3), w, the bits of its pixel index — for fm_procrustes_bwd_planned, which then re-gathers nothing. */
 int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
                             float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
-                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, void* stream);
+                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, void* stream);
 
 /* procrustes.py:35-51: R = U·diag(1,1,±1)·Vᵀ by in-register 3×3 SVD, t = q̄ − R·p̄.
  * t_bwd (pairs,4,4) = [R|t] ("inverse relative transformation", later -> earlier
@@ -389,17 +391,18 @@ int fm_depth_gather_kgrad(const float* vectors, const int64_t* pixels, const int
                           float* g_k, int accumulate, void* stream);
 
 /* The WHOLE backward of a planned sparse fit in one launch (fm_pose_solve_bwd_kinv + fm_procrustes_scatter with point_grads +
- * fm_depth_gather_kgrad, projection.py:226-249 / procrustes.py:7-51 backward): one workgroup per frame (b, f) evaluates the
- * correspondences of the two pairs the frame belongs to, keeps their gradient vectors in LDS and adds its slice of the gather
- * plan into grad_depth (plain read-modify-writes, one writer per pixel), STORES grad_weights (B,F-1,H,W) at the sampled
- * pixels of pair f and writes g_k[b, f] = [accumulate_k ? g_k : 0] − K⁻ᵀ·dK⁻¹·K⁻ᵀ with dK⁻¹ in closed form from `aux`.
- * Depth source, batch_repeat 1, distinct `indices`, points <= FM_FIT_BWD_MAX_POINTS.  plan_* as fm_depth_gather takes them for
- * fm_procrustes_scatter_plan; frame_first (B·F + 1) int32: index of the first plan pixel with key >= frame·H·W (the plan is
- * sorted by key).  g_t_bwd / g_t_fwd (B·(F-1),4,4) may be NULL; grad_depth / grad_weights / g_k may be NULL. */
+ * fm_depth_gather_kgrad, projection.py:226-249 / procrustes.py:7-51 backward): one workgroup per frame (b, f) reads the
+ * records (corr: what fm_procrustes_fit_chain left in corr_out) of the two pairs the frame belongs to — coalesced, no gather
+ * chain —, keeps their gradient vectors in LDS and adds its slice of the gather plan into grad_depth (plain
+ * read-modify-writes, one writer per pixel), STORES grad_weights (B,F-1,H,W) at the sampled pixels of pair f and writes
+ * g_k[b, f] = [accumulate_k ? g_k : 0] − K⁻ᵀ·dK⁻¹·K⁻ᵀ with dK⁻¹ in closed form from `aux`.
+ * Depth source, batch_repeat 1, distinct indices, points <= FM_FIT_BWD_MAX_POINTS.  weight_sensitivity as given to the fit.
+ * plan_* as fm_depth_gather takes them for fm_procrustes_scatter_plan; frame_first (B·F + 1) int32: index of the first plan
+ * pixel with key >= frame·H·W (the plan is sorted by key).  g_t_bwd / g_t_fwd (B·(F-1),4,4) may be NULL; grad_depth /
+ * grad_weights / g_k may be NULL. */
 #define FM_FIT_BWD_MAX_POINTS 2048
-int fm_procrustes_bwd_planned(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float weight_sensitivity,
-                              const int64_t* indices, long points, int batch, int frames, int height, int width, const double* aux,
-                              const float* t_bwd, const float* g_t_bwd, const float* g_t_fwd, const int64_t* plan_pixels,
+int fm_procrustes_bwd_planned(const float* corr, const float* kinv, float weight_sensitivity, long points, int batch, int frames, int height, int width,
+                              const double* aux, const float* t_bwd, const float* g_t_bwd, const float* g_t_fwd, const int64_t* plan_pixels,
                               const int32_t* plan_first, const int32_t* plan_vectors, const float* plan_weights, const int32_t* frame_first,
                               float* grad_depth, float* grad_weights, float* g_k, int accumulate_k, void* stream);
 

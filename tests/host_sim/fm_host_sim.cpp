@@ -633,13 +633,32 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
 int fm_pose_chain_fwd(const float* rel, int batch, int steps, float* ext, void*);
 int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
                             float sens, const int64_t* indices, long points, int batch, int frames, int height, int width, double* work,
-                            float* t_bwd, float* t_fwd, double* aux, float* ext, void* stream) {
+                            float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, void* stream) {
   const int pairs = batch * (frames - 1);
   std::vector<double> stats((size_t)pairs * kStatStride);
   (void)work;  // stays zero, as the device leaves it
   if (fm_procrustes_fit(depth, kinv, surfaces, bwd_flow, weights, sens, indices, points, batch, 1, frames, height, width, stats.data(), t_bwd,
                         t_fwd, aux, stream) != 0)
     return 2;
+  if (corr_out) {  // the record of every correspondence, as the device kernel leaves it (corr_record)
+    if (points > 4096) return 1;
+    for (int b = 0; b < batch; ++b)
+      for (int i = 0; i < frames - 1; ++i) {
+        const size_t pair = (size_t)b * (frames - 1) + i;
+        const CorrSrc src = make_src(depth, surfaces, bwd_flow, weights, sens, pair, b, i, frames, height, width, 1);
+        Mat3 kinv_e{}, kinv_l{};
+        if (!surfaces) {
+          load_mat3(kinv + ((size_t)b * frames + i) * 9, kinv_e);
+          load_mat3(kinv + ((size_t)b * frames + i + 1) * 9, kinv_l);
+        }
+        for (long j = 0; j < points; ++j) {
+          const Corr c = corr_load(src, kinv_e, kinv_l, indices ? (int)indices[j] : (int)j);
+          float* o = corr_out + (pair * (size_t)points + (size_t)j) * 8;
+          o[0] = c.q[0], o[1] = c.q[1], o[2] = c.q[2], o[3] = c.p[0], o[4] = c.p[1], o[5] = c.p[2], o[6] = c.w;
+          std::memcpy(o + 7, &c.idx, sizeof(float));
+        }
+      }
+  }
   return fm_pose_chain_fwd(t_bwd, batch, frames - 1, ext, stream);
 }
 
@@ -1357,14 +1376,14 @@ int fm_depth_gather_kgrad(const float* vectors, const int64_t* pixels, const int
   return frames_k > 0 ? fm_intrinsics_inverse_bwd(kinv_acc, kinv, frames_k, g_k, accumulate, stream) : 0;
 }
 
-// The one-launch backward of the planned sparse fit: here the three steps it replaces, run one after the other, plus a check
-// that `frame_first` slices the plan the way the device kernel's per-frame blocks rely on.
-int fm_procrustes_bwd_planned(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float sens,
-                              const int64_t* indices, long points, int batch, int frames, int height, int width, const double* aux,
-                              const float* t_bwd, const float* g_t_bwd, const float* g_t_fwd, const int64_t* plan_pixels,
+// The one-launch backward of the planned sparse fit from the forward's correspondence records: pose-solve backward + closed-form
+// dL/dK⁻¹ (fm_pose_solve_bwd_kinv), corr_backward per record, the planned gather — plus a check that `frame_first` slices the plan
+// the way the device kernel's per-frame blocks rely on.
+int fm_procrustes_bwd_planned(const float* corr, const float* kinv, float sens, long points, int batch, int frames, int height, int width,
+                              const double* aux, const float* t_bwd, const float* g_t_bwd, const float* g_t_fwd, const int64_t* plan_pixels,
                               const int32_t* plan_first, const int32_t* plan_vectors, const float* plan_weights, const int32_t* frame_first,
                               float* grad_depth, float* grad_weights, float* g_k, int accumulate_k, void* stream) {
-  if (!(depth && kinv && bwd_flow && weights && indices && aux && t_bwd) || points < 1 || points > FM_FIT_BWD_MAX_POINTS) return 1;
+  if (!(corr && kinv && aux && t_bwd) || points < 1 || points > FM_FIT_BWD_MAX_POINTS) return 1;
   if (grad_depth && !(plan_pixels && plan_first && plan_vectors && plan_weights && frame_first)) return 1;
   const int pairs = batch * (frames - 1);
   const int64_t n = (int64_t)height * width;
@@ -1387,9 +1406,32 @@ int fm_procrustes_bwd_planned(const float* depth, const float* kinv, const float
   std::vector<double> pair_grad((size_t)pairs * kPairGradStride), kinv_acc((size_t)batch * frames * 9);
   std::vector<float> point_grads((size_t)pairs * points * 6);
   if (fm_pose_solve_bwd_kinv(g_t_bwd, g_t_fwd, t_bwd, aux, kinv, batch, frames, pair_grad.data(), kinv_acc.data(), stream) != 0) return 2;
-  if (fm_procrustes_scatter(depth, kinv, nullptr, bwd_flow, weights, sens, indices, points, batch, 1, frames, height, width, aux, pair_grad.data(),
-                            nullptr, nullptr, grad_weights, nullptr, point_grads.data(), nullptr, stream) != 0)
-    return 2;
+  for (int pr = 0; pr < pairs; ++pr) {
+    const double* pg = pair_grad.data() + (size_t)pr * kPairGradStride;
+    const double* ax = aux + (size_t)pr * kAuxStride;
+    PairGrad g;
+    for (int k = 0; k < 9; ++k) g.gM[k] = (float)pg[k];
+    for (int a = 0; a < 3; ++a) {
+      g.gqbar[a] = (float)pg[9 + a];
+      g.gpbar[a] = (float)pg[12 + a];
+      g.pbar[a] = (float)ax[21 + a];
+      g.qbar[a] = (float)ax[24 + a];
+    }
+    g.dbar = (float)pg[15];
+    g.inv_wsum = (float)pg[16];
+    for (long j = 0; j < points; ++j) {
+      const float* r = corr + ((size_t)pr * points + (size_t)j) * 8;
+      Corr c{};
+      c.q[0] = r[0], c.q[1] = r[1], c.q[2] = r[2], c.p[0] = r[3], c.p[1] = r[4], c.p[2] = r[5], c.w = r[6];
+      std::memcpy(&c.idx, r + 7, sizeof(int));
+      float gq[3], gp[3], gw;
+      corr_backward(c, g, gq, gp, gw);
+      if (sens != 0.f) gw *= sens * c.w * (1.f - c.w);
+      if (grad_weights) grad_weights[(size_t)pr * n + c.idx] = gw;
+      float* o = point_grads.data() + ((size_t)pr * points + (size_t)j) * 6;
+      o[0] = gq[0], o[1] = gq[1], o[2] = gq[2], o[3] = gp[0], o[4] = gp[1], o[5] = gp[2];
+    }
+  }
   if (grad_depth && count > 0 &&
       fm_depth_gather(point_grads.data(), plan_pixels, plan_first, plan_vectors, plan_weights, count, kinv, nullptr, nullptr, height, width, 0, grad_depth,
                       stream) != 0)
