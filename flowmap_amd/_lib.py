@@ -50,7 +50,7 @@ SIGNATURES = {
     "fm_adam_step_capturable": [P, P, P, P, L, P, D, D, D, D, D, P],
     "fm_procrustes_stats": [P] * 5 + [F, P, L, I, I, I, I, I, P, P],
     "fm_procrustes_fit": [P] * 5 + [F, P, L, I, I, I, I, I, P, P, P, P, P],
-    "fm_procrustes_fit_chain": [P] * 5 + [F, P, L, I, I, I, I, P, P, P, P, P, P, P],
+    "fm_procrustes_fit_chain": [P] * 5 + [F, P, L, I, I, I, I, P, P, P, P, P, P, P, P],
     "fm_pose_solve": [P, I, P, P, P, P],
     "fm_pose_solve_bwd": [P, P, P, P, I, P, P, L, P],
     "fm_procrustes_scatter": [P] * 5 + [F, P, L, I, I, I, I, I] + [P] * 8 + [P],

@@ -354,7 +354,13 @@ def _procrustes_scatter_plan(indices: Tensor, bwd_flow: Tensor, b: int, f: int, 
             # where every frame's pixels begin (the plan is sorted by frame·H·W + pixel): fm_procrustes_bwd_planned's blocks, one per frame
             bounds = torch.arange(b * f + 1, dtype=torch.int64, device=dev) * (h * w)
             frame_first = torch.searchsorted(pixels, bounds).to(torch.int32)
-            entry[1] = (pixels.contiguous(), first, vectors.contiguous(), weights[entries].contiguous(), frame_first.contiguous())
+            # the static taps of every correspondence for the forward fit (fm_procrustes_fit_chain's tap_records): slots 0..3 of the
+            # plan as pixel offsets inside the earlier frame (int32 bits, -1 outside) + their bilinear weights
+            per = keys.reshape(b * (f - 1), points, 5)
+            base = (torch.arange(b * (f - 1), dtype=torch.int64, device=dev) // (f - 1) * f + torch.arange(b * (f - 1), dtype=torch.int64, device=dev) % (f - 1)) * (h * w)
+            offsets = torch.where(per[:, :, :4] >= 0, per[:, :, :4] - base[:, None, None], torch.full_like(per[:, :, :4], -1)).to(torch.int32)
+            tap_records = torch.cat([offsets.view(torch.float32), weights.reshape(b * (f - 1), points, 5)[:, :, :4]], dim=2).contiguous()
+            entry[1] = (pixels.contiguous(), first, vectors.contiguous(), weights[entries].contiguous(), frame_first.contiguous(), tap_records)
             counters["procrustes_plans_built"] += 1
     return entry[1]
 
@@ -417,7 +423,7 @@ class ProcrustesFit:
         from_depth = surfaces is None
         rep = int(batch_repeat)
         kinv = sink = wsink = arena = None
-        sparse = (None, None, None, None, None)
+        sparse = (None, None, None, None, None, None)
         dense = (None, None)
         if from_depth:
             if depth is None or k is None:

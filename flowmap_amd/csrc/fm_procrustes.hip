@@ -230,7 +230,8 @@ struct FitChain {
   float* ext;     // (B, F, 4, 4)
   int batch;
   float* corr_out;  // (pairs·P, 8) or null: q (3), p (3), w, index bits of every correspondence, for fm_procrustes_bwd_planned
-};
+  const float* tap_records;  // (pairs·P, 8) or null: STATIC per correspondence (constant flows and indices): the four taps' pixel
+};                           // offsets in the earlier frame (int bits, -1 = outside) and their bilinear weights (fm_procrustes_scatter_plan)
 
 // grid: (chunks, B*(F-1)): raw moments of every correspondence into stats[0..15] (fp64 atomics).
 template <int SRC>
@@ -322,7 +323,54 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
   float acc[kMomentCount];
 #pragma unroll
   for (int k = 0; k < kMomentCount; ++k) acc[k] = 0.f;
-  if (SRC == SRC_DEPTH && p.indices != nullptr) {
+  if (SRC == SRC_DEPTH && p.indices != nullptr && fc.tap_records != nullptr) {
+    // Constant flows and indices (the overfit loop, from its second step on): where a correspondence's four taps lie and what they
+    // weigh never changes, so it comes from a static record — one coalesced read — and every scattered access of the
+    // correspondence (later depth, weight, four tap depths) is issued in ONE dependent round instead of two (index -> flow -> taps)
+    const int idx_mid = (int)p.indices[p.points / 2];
+    const float z_mid = src.depth_l[idx_mid];
+    {  // later_point (fm_math.h) of the middle sample
+      const int row = idx_mid / src.width, col = idx_mid - row * src.width;
+      float ray[3];
+      ray_dir(kinv_l, pixel_center(col, src.width), pixel_center(row, src.height), ray);
+      shift[0] = ray[0] * z_mid; shift[1] = ray[1] * z_mid; shift[2] = ray[2] * z_mid;
+      for (int a3 = 0; a3 < 3; ++a3)
+        if (!(fabsf(shift[a3]) <= 3.0e38f)) shift[a3] = 0.f;
+    }
+    const corr_v4* recs = reinterpret_cast<const corr_v4*>(fc.tap_records) + pair * (size_t)p.points * 2;
+    for (long j = threadIdx.x; j < p.points; j += blockDim.x) {
+      const corr_v4 ro = recs[j * 2], rw = recs[j * 2 + 1];
+      const int idx = (int)p.indices[j];
+      const int off[4] = {__float_as_int(ro.x), __float_as_int(ro.y), __float_as_int(ro.z), __float_as_int(ro.w)};
+      const float tw[4] = {rw.x, rw.y, rw.z, rw.w};
+      Corr c;
+      c.idx = idx;
+      c.w = src.weights[idx];
+      c.z_p = src.depth_l[idx];
+      float zt[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) zt[k] = off[k] >= 0 ? src.depth_e[off[k]] : 0.f;
+      if (src.weight_sens != 0.f) c.w = fm_sigmoid<false>(src.weight_sens * c.w);
+      const PixelRef px = pixel_ref(idx, src.height, src.width);
+      ray_dir(kinv_l, px.u, px.v, c.ray_p);
+      c.p[0] = c.ray_p[0] * c.z_p;
+      c.p[1] = c.ray_p[1] * c.z_p;
+      c.p[2] = c.ray_p[2] * c.z_p;
+      c.q[0] = c.q[1] = c.q[2] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (off[k] < 0) continue;
+        const int tr = off[k] / src.width, tc = off[k] - tr * src.width;
+        float ray[3];
+        ray_dir(kinv_e, pixel_center(tc, src.width), pixel_center(tr, src.height), ray);
+        c.q[0] += (ray[0] * zt[k]) * tw[k];
+        c.q[1] += (ray[1] * zt[k]) * tw[k];
+        c.q[2] += (ray[2] * zt[k]) * tw[k];
+      }
+      moments_add(c, shift, acc);
+      corr_record(fc.corr_out, pair * (size_t)p.points + (size_t)j, c);
+    }
+  } else if (SRC == SRC_DEPTH && p.indices != nullptr) {
     // The reference point's chain (index -> depth) and the thread's first correspondence's chain (index -> flow, weight, depth ->
     // taps) are issued stage by stage TOGETHER: three dependent round trips to HBM instead of five
     const long first = threadIdx.x;
@@ -1232,7 +1280,7 @@ struct FitBwdPlan {
 };
 
 constexpr int kFitBwdThreads = 512;
-constexpr int kFitBwdGather = 8;  // plan pixels a thread keeps in flight at a time
+constexpr int kFitBwdGather = 10;  // plan pixels a thread keeps in flight at a time (10 x 512 covers the ~4 900 pixels a frame's P = 1000 correspondences touch)
 
 __device__ __forceinline__ PairGrad pair_grad_from(const double* pg, const double* ax) {
   PairGrad g;
@@ -1285,16 +1333,28 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
     r0a[sl] = rec_e[jj * 2], r0b[sl] = rec_e[jj * 2 + 1];
     r1a[sl] = rec_l[jj * 2], r1b[sl] = rec_l[jj * 2 + 1];
   }
-  // ... and the first batch of this frame's plan slice (keys, entry ranges): nothing here depends on the gradients
+  // ... and the first batch of this frame's plan slice — keys and entry ranges, then (as soon as those have landed) the old
+  // dL/ddepth values and the entries themselves: nothing of this depends on the gradients, so both dependent rounds of cold
+  // accesses run under the pose-solve backward instead of after it
   int px[kFitBwdGather], e0[kFitBwdGather], e1[kFitBwdGather];
   const int64_t frame_base = (int64_t)bf * n;
+  float* gd = p.grad_depth ? p.grad_depth + frame_base : nullptr;
 #pragma unroll
   for (int i = 0; i < kFitBwdGather; ++i) {
     const int m = lo + t + i * kFitBwdThreads;
-    const bool on = m < hi;
+    const bool on = gd != nullptr && m < hi;
     px[i] = on ? (int)(pl.pixels[m] - frame_base) : -1;
     e0[i] = on ? pl.first[m] : 0;
     e1[i] = on ? pl.first[m + 1] : 0;
+  }
+  float old[kFitBwdGather], wt[kFitBwdGather];
+  int vi[kFitBwdGather];
+#pragma unroll
+  for (int i = 0; i < kFitBwdGather; ++i) {
+    const bool on = px[i] >= 0;
+    old[i] = on ? gd[px[i]] : 0.f;
+    vi[i] = on && e0[i] < e1[i] ? pl.vectors[e0[i]] : 0;
+    wt[i] = on && e0[i] < e1[i] ? pl.tap_weights[e0[i]] : 0.f;
   }
 
   // ---- pose-solve backward of the two pairs, side by side in two waves (fp64, one thread each) ----
@@ -1363,10 +1423,8 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
   if (p.grad_depth == nullptr) return;
 
   // ---- this frame's slice of the planned gather: one plain read-modify-write per touched pixel.  A thread keeps
-  // kFitBwdGather pixels in flight: their keys and entry ranges (round 1, issued at the top for the first batch), their
-  // old gradient values and first entries (round 2) ----
+  // kFitBwdGather pixels in flight; the first batch's loads were issued at the top ----
   const int base_e = (int)(pair_e * (size_t)P), base_l = (int)(pair_l * (size_t)P);
-  float* gd = p.grad_depth + frame_base;
   for (int m0 = lo + t; m0 < hi; m0 += kFitBwdThreads * kFitBwdGather) {
     if (m0 != lo + t) {
 #pragma unroll
@@ -1377,15 +1435,13 @@ __global__ void __launch_bounds__(kFitBwdThreads) procrustes_bwd_frame_kernel(Pr
         e0[i] = on ? pl.first[m] : 0;
         e1[i] = on ? pl.first[m + 1] : 0;
       }
-    }
-    float old[kFitBwdGather], wt[kFitBwdGather];
-    int vi[kFitBwdGather];
 #pragma unroll
-    for (int i = 0; i < kFitBwdGather; ++i) {
-      const bool on = px[i] >= 0;
-      old[i] = on ? gd[px[i]] : 0.f;
-      vi[i] = on && e0[i] < e1[i] ? pl.vectors[e0[i]] : 0;
-      wt[i] = on && e0[i] < e1[i] ? pl.tap_weights[e0[i]] : 0.f;
+      for (int i = 0; i < kFitBwdGather; ++i) {
+        const bool on = px[i] >= 0;
+        old[i] = on ? gd[px[i]] : 0.f;
+        vi[i] = on && e0[i] < e1[i] ? pl.vectors[e0[i]] : 0;
+        wt[i] = on && e0[i] < e1[i] ? pl.tap_weights[e0[i]] : 0.f;
+      }
     }
 #pragma unroll
     for (int i = 0; i < kFitBwdGather; ++i) {
@@ -1724,8 +1780,9 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
 
 int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
                             float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
-                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, void* stream) {
+                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, const float* tap_records, void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
+  FM_CHECK_ARG(!tap_records || (depth && indices && points <= 4096 && (reinterpret_cast<uintptr_t>(tap_records) & 15) == 0));
   FM_CHECK_ARG(bwd_flow && weights && work && t_bwd && aux && points >= 1 && batch >= 1 && frames >= 2);
   FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
   FM_CHECK_ARG(!corr_out || (points <= 4096 && (reinterpret_cast<uintptr_t>(corr_out) & 15) == 0));
@@ -1735,7 +1792,7 @@ int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* 
   p.stats = work; p.frames = frames; p.height = height; p.width = width; p.points = points;
   p.weight_sens = weight_sensitivity;
   p.batch_repeat = 1;
-  FitChain fc{reinterpret_cast<int*>(work + (size_t)pairs * kStatStride), t_bwd, t_fwd, aux, ext, batch, corr_out};
+  FitChain fc{reinterpret_cast<int*>(work + (size_t)pairs * kStatStride), t_bwd, t_fwd, aux, ext, batch, corr_out, tap_records};
   if (points <= 4096) {  // one block per pair: the sums stay in the block (procrustes_fit_pair_kernel)
     int* counter = fc.counters + pairs;  // the last of the workspace's ints
     if (surfaces) hipLaunchKernelGGL((procrustes_fit_pair_kernel<SRC_SURF>), dim3(pairs), dim3(1024), 0, (hipStream_t)stream, p, fc, counter);

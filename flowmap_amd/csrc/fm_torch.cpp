@@ -384,8 +384,8 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                                double weight_sens, int64_t rep, const c10::intrusive_ptr<DepthSink>& sink,
                                const c10::intrusive_ptr<DepthSink>& wsink, const c10::intrusive_ptr<GradArena>& arena,
                                const OptTensor& plan_pixels, const OptTensor& plan_first, const OptTensor& plan_vectors,
-                               const OptTensor& plan_weights, const OptTensor& plan_frame_first, const OptTensor& dense_first,
-                               const OptTensor& dense_list, const OptTensor& work_o, bool grad_enabled) {  // (forward runs with grad mode off: the caller's mode is passed in)
+                               const OptTensor& plan_weights, const OptTensor& plan_frame_first, const OptTensor& plan_tap_records,
+                               const OptTensor& dense_first, const OptTensor& dense_list, const OptTensor& work_o, bool grad_enabled) {  // (forward runs with grad mode off: the caller's mode is passed in)
     ctx->set_materialize_grads(false);  // an unused output (the extrinsics of a flow-only step) must not cost a zeros tensor + the chain's backward
     Tensor depth = opt(depth_o), k = opt(k_o), kinv = opt(kinv_o), surfaces = opt(surfaces_o), indices = opt(indices_o);
     const bool from_depth = !surfaces.defined();
@@ -442,9 +442,11 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
         const bool wants_records = from_depth && grad_enabled && plan_frame_first.has_value() && plan_frame_first->defined() && points <= FM_FIT_BWD_MAX_POINTS &&
                                    use_one_launch_backward() && (depth.requires_grad() || weights_in.requires_grad() || (k_o.has_value() && k_o->requires_grad()));
         if (wants_records) corr = at::empty({pairs * points, 8}, weights.options());
+        const bool taps_ok = from_depth && plan_tap_records.has_value() && plan_tap_records->defined() && plan_tap_records->scalar_type() == at::kFloat &&
+                             plan_tap_records->is_contiguous() && plan_tap_records->numel() == pairs * points * 8 && points <= 4096;
         FM_CALL(fm_procrustes_fit_chain, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights),
                 (float)weight_sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(work), ptr(t_bwd), ptr(t_fwd),
-                ptr<double>(aux), ptr(ext), ptr(corr), scope.stream);
+                ptr<double>(aux), ptr(ext), ptr(corr), taps_ok ? ptr(plan_tap_records) : nullptr, scope.stream);
       } else {
         stats = at::empty({pairs, FM_STAT_STRIDE}, weights.options().dtype(at::kDouble));
         FM_CALL(fm_procrustes_fit, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights), (float)weight_sens,
@@ -591,7 +593,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       wsink->note_final(g_w);
       if (arena_used) wsink->on_leading_add = [arena](const Tensor& into, int64_t count) { arena->note_leading_add(into, count); };
     }
-    variable_list out(21);
+    variable_list out(22);
     if (from_depth) {
       out[0] = g_src;
       out[1] = g_k;
@@ -1148,11 +1150,11 @@ static std::tuple<Tensor, Tensor, Tensor> procrustes_fit_op(const OptTensor& dep
                                                     int64_t batch_repeat, const OptSink& sink, const OptSink& wsink, const OptArena& arena,
                                                     const OptTensor& plan_pixels,
                                                     const OptTensor& plan_first, const OptTensor& plan_vectors, const OptTensor& plan_weights,
-                                                    const OptTensor& plan_frame_first, const OptTensor& dense_first, const OptTensor& dense_list,
-                                                    const OptTensor& work) {
+                                                    const OptTensor& plan_frame_first, const OptTensor& plan_tap_records, const OptTensor& dense_first,
+                                                    const OptTensor& dense_list, const OptTensor& work) {
   auto out = ProcrustesFit::apply(depth, k, kinv, surfaces, weights, bwd_flow, indices, weight_sens, batch_repeat, sink_of(sink), sink_of(wsink),
                                   arena.has_value() ? *arena : c10::intrusive_ptr<GradArena>(), plan_pixels, plan_first, plan_vectors, plan_weights,
-                                  plan_frame_first, dense_first, dense_list, work, at::GradMode::is_enabled());
+                                  plan_frame_first, plan_tap_records, dense_first, dense_list, work, at::GradMode::is_enabled());
   if (sink.has_value() && *sink) (*sink)->fit_node = out[0].grad_fn().get();  // null when no graph is being built
   return {out[0], out[1], out[2]};
 }
@@ -1241,7 +1243,7 @@ TORCH_LIBRARY(flowmap_amd, m) {
       "procrustes_fit(Tensor? depth, Tensor? k, Tensor? kinv, Tensor? surfaces, Tensor weights, Tensor bwd_flow, Tensor? indices, float weight_sens, "
       "int batch_repeat, __torch__.torch.classes.flowmap_amd.DepthSink? sink, __torch__.torch.classes.flowmap_amd.DepthSink? wsink, "
       "__torch__.torch.classes.flowmap_amd.GradArena? arena, "
-      "Tensor? plan_pixels, Tensor? plan_first, Tensor? plan_vectors, Tensor? plan_weights, Tensor? plan_frame_first, Tensor? dense_first, "
+      "Tensor? plan_pixels, Tensor? plan_first, Tensor? plan_vectors, Tensor? plan_weights, Tensor? plan_frame_first, Tensor? plan_tap_records, Tensor? dense_first, "
       "Tensor? dense_list, Tensor? work) "
       "-> (Tensor, Tensor, Tensor)",
       fmt::procrustes_fit_op);

@@ -146,10 +146,16 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
  * work: persistent workspace of B·(F-1)·FM_STAT_STRIDE doubles followed by B·(F-1)+1 ints, ZERO on entry and left
  * zero (self-cleaning: zero it once, when it is allocated; one launch at a time per workspace).
  * corr_out (optional, (B·(F-1)·P, 8) floats, 16-byte aligned, P <= 4096): the record of every correspondence —
- * q (3), p (3), w, the bits of its pixel index — for fm_procrustes_bwd_planned, which then re-gathers nothing. */
+ * q (3), p (3), w, the bits of its pixel index — for fm_procrustes_bwd_planned, which then re-gathers nothing.
+ * tap_records (optional, (B·(F-1)·P, 8), 16-byte aligned; depth source, indices given, P <= 4096): with constant flows and indices the
+ * taps of every correspondence are static — per correspondence the four taps' pixel offsets row·W + col in the earlier frame
+ * (int32 bits, -1 = outside the image) followed by their four bilinear weights, i.e. slots 0..3 of fm_procrustes_scatter_plan's
+ * keys (minus the frame's base) and weights.  The kernel then does not read bwd_flow and issues all scattered reads of a
+ * correspondence in one dependent round. */
 int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
                             float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
-                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, void* stream);
+                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, const float* tap_records,
+                            void* stream);
 
 /* procrustes.py:35-51: R = U·diag(1,1,±1)·Vᵀ by in-register 3×3 SVD, t = q̄ − R·p̄.
  * t_bwd (pairs,4,4) = [R|t] ("inverse relative transformation", later -> earlier

@@ -633,10 +633,28 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
 int fm_pose_chain_fwd(const float* rel, int batch, int steps, float* ext, void*);
 int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
                             float sens, const int64_t* indices, long points, int batch, int frames, int height, int width, double* work,
-                            float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, void* stream) {
+                            float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, const float* tap_records, void* stream) {
   const int pairs = batch * (frames - 1);
   std::vector<double> stats((size_t)pairs * kStatStride);
   (void)work;  // stays zero, as the device leaves it
+  if (tap_records) {  // the static tap records must be what the taps of (indices, flows) are: checked here, then not needed
+    if (!depth || !indices || points > 4096) return 1;
+    const size_t n = (size_t)height * width;
+    for (int pr = 0; pr < pairs; ++pr)
+      for (long j = 0; j < points; ++j) {
+        const int idx = (int)indices[j];
+        const PixelRef px = pixel_ref(idx, height, width);
+        const float* fl = bwd_flow + ((size_t)pr * n + (size_t)idx) * 2;
+        const Taps t = bilinear_taps(px.u + fl[0], px.v + fl[1], height, width);
+        const float* r = tap_records + ((size_t)pr * points + (size_t)j) * 8;
+        for (int k = 0; k < 4; ++k) {
+          int off;
+          std::memcpy(&off, r + k, sizeof(int));
+          const int want = t.in[k] ? tap_row(t, k) * width + tap_col(t, k) : -1;
+          if (off != want || (t.in[k] && r[4 + k] != t.w[k]) || (!t.in[k] && r[4 + k] != 0.f)) return 1;
+        }
+      }
+  }
   if (fm_procrustes_fit(depth, kinv, surfaces, bwd_flow, weights, sens, indices, points, batch, 1, frames, height, width, stats.data(), t_bwd,
                         t_fwd, aux, stream) != 0)
     return 2;

@@ -32,6 +32,11 @@ t_bwd = torch.empty((1, pairs, 4, 4), device=dev)
 t_fwd = torch.empty_like(t_bwd)
 aux = torch.empty((pairs, 40), dtype=torch.float64, device=dev)
 ext = torch.empty((1, f, 4, 4), device=dev)
+from flowmap_amd import _ops  # noqa: E402
+
+_ops._procrustes_scatter_plan(idx, flow, 1, f, h, w)
+tap_records = _ops._procrustes_scatter_plan(idx, flow, 1, f, h, w)[5]
+corr = torch.empty((pairs * p, 8), device=dev)
 lib = _lib.library()
 P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 st = torch.cuda.current_stream().cuda_stream
@@ -69,11 +74,16 @@ def chain_only():
 
 
 def fused():
-    assert lib.fm_procrustes_fit_chain(P(depth), P(kinv), None, P(flow), P(logit), 100.0, P(idx), p, 1, f, h, w, P(work), P(t_bwd), P(t_fwd), P(aux), P(ext), None, st) == 0
+    assert lib.fm_procrustes_fit_chain(P(depth), P(kinv), None, P(flow), P(logit), 100.0, P(idx), p, 1, f, h, w, P(work), P(t_bwd), P(t_fwd), P(aux), P(ext), None, None, st) == 0
 
 
 def fused_no_chain():
-    assert lib.fm_procrustes_fit_chain(P(depth), P(kinv), None, P(flow), P(logit), 100.0, P(idx), p, 1, f, h, w, P(work), P(t_bwd), P(t_fwd), P(aux), None, None, st) == 0
+    assert lib.fm_procrustes_fit_chain(P(depth), P(kinv), None, P(flow), P(logit), 100.0, P(idx), p, 1, f, h, w, P(work), P(t_bwd), P(t_fwd), P(aux), None, None, None, st) == 0
+
+
+def fused_planned():  # the overfit loop from its second step on: static tap records in, correspondence records out
+    assert lib.fm_procrustes_fit_chain(P(depth), P(kinv), None, P(flow), P(logit), 100.0, P(idx), p, 1, f, h, w, P(work), P(t_bwd), P(t_fwd), P(aux), P(ext),
+                                       P(corr), P(tap_records), st) == 0
 
 
 def fused_then_chain():
@@ -84,6 +94,6 @@ def fused_then_chain():
 out = {"workload": f"{f} x {h} x {w}, P = {p}; median of 30, microseconds incl. launch gaps between the launches of one call",
        "moments (memset + 1 launch)": timed(moments), "moments + finish/solve (memset + 2 launches)": timed(fit),
        "pose chain alone (1 launch)": timed(chain_only), "fit then chain (memset + 3 launches)": timed(fit_then_chain),
-       "fit_chain (1 launch)": timed(fused),
+       "fit_chain (1 launch)": timed(fused), "fit_chain with static tap records + correspondence records out (1 launch)": timed(fused_planned),
        "fit_chain without the chain (1 launch)": timed(fused_no_chain), "fit_chain without the chain, then chain (2 launches)": timed(fused_then_chain)}
 print(json.dumps(out))

@@ -44,7 +44,7 @@ def run(iters: int, dev: str = "cuda:0", verbose: bool = True) -> float:
             depth = 1.10 + 0.05 * torch.rand((1, f, h, w), device=dev, generator=g) if it % 50 == 0 else depth * (1 + 1e-4)
             ext.fill_(float("nan"))
             assert lib.fm_procrustes_fit_chain(_ptr(depth), _ptr(kinv), None, _ptr(flow), _ptr(logit), 100.0, _ptr(idx), p, 1, f, h, w,
-                                               _ptr(work), _ptr(tb), _ptr(tf), _ptr(aux), _ptr(ext), None, st) == 0
+                                               _ptr(work), _ptr(tb), _ptr(tf), _ptr(aux), _ptr(ext), None, None, st) == 0
             assert lib.fm_procrustes_fit(_ptr(depth), _ptr(kinv), None, _ptr(flow), _ptr(logit), 100.0, _ptr(idx), p, 1, 1, f, h, w,
                                          _ptr(stats), _ptr(tb2), _ptr(tf2), _ptr(aux2), st) == 0
             assert lib.fm_pose_chain_fwd(_ptr(tb2), 1, pairs, _ptr(ext2), st) == 0
