@@ -34,6 +34,13 @@ SIGNATURES = {
     "fm_flow_valid_norm": [P, P, L, F, P, P, P],
     "fm_scale_if_needed": [P, L, P, L, P, P, P],
     "fm_abi_version": [],
+    "fm_flow_loss_fused_views": [P] * 11 + [I, I, I, I, I, F, F, F, P, P, I, P, P],
+    "fm_flow_valid_norm_views": [P, P, I, I, L, F, P, P, P, P],
+    "fm_flow_pack_inputs_views": [P, P, P, P, I, I, I, I, P, P, P],
+    "fm_procrustes_fit_views": [P] * 5 + [F, P, L, I, I, I, I, P, P, P, P, P, P],
+    "fm_procrustes_fit_chain_views": [P] * 5 + [F, P, L, I, I, I, I, P, P, P, P, P, P, P, P, P],
+    "fm_procrustes_scatter_views": [P] * 5 + [F, P, L, I, I, I, I] + [P] * 7 + [P, P],
+    "fm_procrustes_scatter_plan_views": [P, P, L, I, I, I, I, P, P, P, P],
     "fm_softmin_blend_fwd": [P, P, I, I, I, P, P, P, P],
     "fm_softmin_blend_bwd": [P, P, P, I, I, I, P, P],
     "fm_softmin_score_fwd": [P, P, F, P, P, L, P, P, P, I, I, I, I, P, P],

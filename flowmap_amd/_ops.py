@@ -48,6 +48,43 @@ def _f32c(t: Tensor, what: str) -> Tensor:
     return t.contiguous()
 
 
+class FmLayout(ctypes.Structure):
+    """include/flowmap_hip.h: fm_layout — element strides between the frames / batch entries of an image stack ({0, 0} = dense)."""
+
+    _fields_ = [("frame_stride", ctypes.c_long), ("batch_stride", ctypes.c_long)]
+
+
+def frame_window_layout(t: Tensor) -> Optional[tuple]:
+    """(frame_stride, batch_stride) in elements when ``t`` (batch, frame, ...) can be read in place — every frame dense, i.e. a
+    contiguous tensor or a frame window ``x[:, s:s+f]`` / batch slice of one — else None (the caller copies)."""
+    if t.is_contiguous():
+        return (0, 0)
+    if t.dim() < 3:
+        return None
+    per_frame = 1
+    for d in range(t.dim() - 1, 1, -1):
+        if t.shape[d] != 1 and t.stride(d) != per_frame:
+            return None
+        per_frame *= t.shape[d]
+    if t.shape[1] != 1 and t.stride(1) < per_frame:
+        return None
+    frame_stride = per_frame if t.shape[1] == 1 else t.stride(1)
+    return (frame_stride, frame_stride * t.shape[1] if t.shape[0] == 1 else t.stride(0))
+
+
+def _layout_array(*tensors):
+    """(ctypes array of fm_layout, any of them a real view?) for the `_views` entry points; None when a tensor cannot be read in place."""
+    arr = (FmLayout * len(tensors))()
+    any_view = False
+    for i, t in enumerate(tensors):
+        lay = frame_window_layout(t)
+        if lay is None:
+            return None, False
+        arr[i].frame_stride, arr[i].batch_stride = lay
+        any_view = any_view or lay != (0, 0)
+    return arr, any_view
+
+
 class _guard:
     """Select the tensor's GPU for the launches inside (no-op for the host test double)."""
 
@@ -342,8 +379,13 @@ def _procrustes_scatter_plan(indices: Tensor, bwd_flow: Tensor, b: int, f: int, 
             dev = bwd_flow.device
             keys = torch.empty((b * (f - 1) * points * 5,), dtype=torch.int64, device=dev)
             weights = torch.empty((keys.numel(),), dtype=torch.float32, device=dev)
+            lay, any_view = _layout_array(bwd_flow)
             with _guard(dev):
-                call("fm_procrustes_scatter_plan", ptr(bwd_flow), ptr(indices), points, b, f, h, w, ptr(keys), ptr(weights), stream_for(bwd_flow))
+                if any_view:
+                    call("fm_procrustes_scatter_plan_views", ptr(bwd_flow), ptr(indices), points, b, f, h, w, ptr(keys), ptr(weights),
+                         ctypes.addressof(lay), stream_for(bwd_flow))
+                else:
+                    call("fm_procrustes_scatter_plan", ptr(bwd_flow), ptr(indices), points, b, f, h, w, ptr(keys), ptr(weights), stream_for(bwd_flow))
             used = torch.nonzero(keys >= 0).reshape(-1)
             sorted_keys, order = torch.sort(keys[used], stable=True)
             entries = used[order]
@@ -430,14 +472,14 @@ class ProcrustesFit:
                 raise RuntimeError("flowmap_amd: the Procrustes fit needs depth + intrinsics or surfaces")
             kinv = intrinsics_inverse(k)
             wants_grad = torch.is_grad_enabled() and depth.requires_grad and rep == 1
-            static_flow = bwd_flow.dtype == torch.float32 and bwd_flow.is_contiguous() and depth.dim() == 4 and bwd_flow.dim() == 5
+            static_flow = bwd_flow.dtype == torch.float32 and frame_window_layout(bwd_flow) is not None and depth.dim() == 4 and bwd_flow.dim() == 5
             if rep == 1:
                 sink = depth_sink(depth)
             if wants_grad and static_flow:
                 b, f, h, w = depth.shape
                 if indices is None:
                     note_touched(depth, "procrustes", None)  # every pixel is a correspondence: nothing is left to an in-pass update
-                    if h <= 65535 and w <= 65535:
+                    if h <= 65535 and w <= 65535 and bwd_flow.is_contiguous():
                         dense = _dense_procrustes_plan(bwd_flow, b, f, h, w)
                         counters["procrustes_dense_planned"] += 1
                 elif indices.dtype == torch.int64 and indices.is_contiguous():
@@ -492,9 +534,17 @@ def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=N
     def build():
         vsum = torch.empty((1,), dtype=torch.float64, device=mask_fwd.device)
         norm = torch.empty((2,), dtype=torch.float32, device=mask_fwd.device)
+        lay, any_view = _layout_array(mask_fwd, mask_bwd) if mask_fwd.dim() == 4 else (None, False)
+        mf, mb = (mask_fwd, mask_bwd) if (lay is not None or mask_fwd.dim() != 4) else (mask_fwd.contiguous(), mask_bwd.contiguous())
+        if mask_fwd.dim() != 4:
+            mf, mb = mask_fwd.contiguous(), mask_bwd.contiguous()
         with _guard(mask_fwd.device):
-            call("fm_flow_valid_norm", ptr(mask_fwd), ptr(mask_bwd), mask_fwd.numel(), float(weight), ptr(vsum), ptr(norm),
-                 stream_for(mask_fwd))
+            if any_view:  # frame windows of larger tensors: summed in place
+                b_, pairs_, h_, w_ = mask_fwd.shape
+                call("fm_flow_valid_norm_views", ptr(mf), ptr(mb), b_, pairs_, h_ * w_, float(weight), ptr(vsum), ptr(norm),
+                     ctypes.addressof(lay), stream_for(mask_fwd))
+            else:
+                call("fm_flow_valid_norm", ptr(mf), ptr(mb), mf.numel(), float(weight), ptr(vsum), ptr(norm), stream_for(mask_fwd))
         if reducer is not None:
             total = reducer(vsum)
             veff = torch.where(total == 0, torch.ones_like(total), total)
@@ -531,7 +581,10 @@ def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mas
         return None
     if tuple(flow_fwd.shape) != (*mask_fwd.shape, 2) or tuple(flow_bwd.shape) != (*mask_fwd.shape, 2):
         return None
-    if any(t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 != 0 for t in srcs):
+    if any(t.dtype != torch.float32 or t.data_ptr() % 16 != 0 for t in srcs):
+        return None
+    lay, any_view = _layout_array(*srcs)
+    if lay is None or any(lay[i].frame_stride % 4 or lay[i].batch_stride % 4 for i in range(4)):
         return None
     key = tuple((id(t), t._version, t.data_ptr()) for t in srcs) + (tuple(mask_fwd.shape),)
     if not (eager or pack_on_first_sight):
@@ -545,8 +598,12 @@ def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mas
         chunks = (h * w // 4 + 63) // 64
         packed = torch.empty((b * (pairs + 1), chunks, 6, 64, 4), dtype=torch.float32, device=mask_fwd.device)
         with _guard(mask_fwd.device):
-            call("fm_flow_pack_inputs", ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd), b, pairs + 1, h, w, ptr(packed),
-                 stream_for(mask_fwd))
+            if any_view:
+                call("fm_flow_pack_inputs_views", ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd), b, pairs + 1, h, w, ptr(packed),
+                     ctypes.addressof(lay), stream_for(mask_fwd))
+            else:
+                call("fm_flow_pack_inputs", ptr(flow_fwd), ptr(flow_bwd), ptr(mask_fwd), ptr(mask_bwd), b, pairs + 1, h, w, ptr(packed),
+                     stream_for(mask_fwd))
         counters["flow_packs"] += 1
         return (srcs[1:], packed)  # the three other tensors are kept alive: their ids are part of the key
 

@@ -51,6 +51,9 @@ struct FlowParams {
   float* exp_avg_sq;      // (B,F,H,W)
   const uint8_t* touched; // (B·F·H·W/4): bit e of byte q = pixel 4q+e receives gradient from (or is read by) another operator
   AdamCoef adam;
+  // element strides between frames / batch entries of the caller's image stacks (fm_layout; dense when the caller gave none):
+  // depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd — a frame window x[:, s:s+f] of a larger tensor is read in place
+  long fs[5], bs[5];
 };
 
 // 16-byte streaming accesses.  Every input element is read exactly once and the gradient is
@@ -163,11 +166,11 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   const float scale = GRAD ? p.scale[0] : 0.f;
   const float inv_delta = KIND == kHuber ? 1.0f / p.delta : 0.f;
 
-  const float* depth = p.depth + (size_t)bf * n;
-  const float* ff = p.flow_fwd + pair_f * (size_t)n * 2;
-  const float* mf = p.mask_fwd + pair_f * (size_t)n;
-  const float* fb = p.flow_bwd + pair_b * (size_t)n * 2;
-  const float* mb = p.mask_bwd + pair_b * (size_t)n;
+  const float* depth = p.depth + (size_t)b * p.bs[0] + (size_t)f * p.fs[0];
+  const float* ff = p.flow_fwd + (size_t)b * p.bs[1] + (size_t)f * p.fs[1];  // pair f of this batch entry
+  const float* mf = p.mask_fwd + (size_t)b * p.bs[3] + (size_t)f * p.fs[3];
+  const float* fb = p.flow_bwd + (size_t)b * p.bs[2] + (size_t)(f - 1) * p.fs[2];  // pair f−1 (never dereferenced for f = 0)
+  const float* mb = p.mask_bwd + (size_t)b * p.bs[4] + (size_t)(f - 1) * p.fs[4];
   const size_t chunks = ((size_t)items + kPackLanes - 1) / kPackLanes;
   const float* packed = PACKED ? p.packed + (size_t)bf * chunks * (kPackVecs * kPackLanes * 4) : nullptr;
   float* gd = GRAD && p.grad_depth ? p.grad_depth + (size_t)bf * n : nullptr;
@@ -360,11 +363,17 @@ __global__ void __launch_bounds__(kFinalizeThreads) flow_finalize_kernel(FlowFin
 // caches the result per Flows object; this runs once.
 // out[0] += Σ a + Σ b  (fp64)
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sum2_kernel(const float* a, const float* b, long n, double* out) {
+// a, b: image stacks of `frames_per_batch` frames of n elements per batch entry, frames fs_* and batch entries bs_* elements apart.
+// grid: (chunks, batch · frames_per_batch).
+__global__ void __launch_bounds__(256) sum2_kernel(const float* a, const float* b, long n, int frames_per_batch, long fs_a, long bs_a, long fs_b,
+                                                   long bs_b, double* out) {
+  const int fr = blockIdx.y % frames_per_batch, be = blockIdx.y / frames_per_batch;
+  const float* pa = a + (size_t)be * bs_a + (size_t)fr * fs_a;
+  const float* pb = b ? b + (size_t)be * bs_b + (size_t)fr * fs_b : nullptr;
   double s = 0.0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float t = a[i];
-    if (b) t += b[i];
+    float t = pa[i];
+    if (pb) t += pb[i];
     s += (double)t;
   }
   s = wave_sum(s);
@@ -387,22 +396,25 @@ __global__ void flow_norm_kernel(const double* vsum, float weight, float* norm) 
 //   vec 0,1 = forward flow of pair f   (x0 y0 x1 y1 | x2 y2 x3 y3)     vec 2 = forward mask
 //   vec 3,4 = backward flow of pair f-1                                  vec 5 = backward mask
 // stored [frame][q/64][vec][q%64] as float4; absent pairs and the padding lanes are zero.
+struct PackLayouts {
+  long fs[4], bs[4];  // flow_fwd, flow_bwd, mask_fwd, mask_bwd
+};
+
 __global__ void __launch_bounds__(256) pack_inputs_kernel(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd,
-                                                          const float* mask_bwd, int frames, int n, float* packed) {
+                                                          const float* mask_bwd, int frames, int n, float* packed, PackLayouts lay) {
   const int quads = n / 4;
   const int chunks = (quads + kPackLanes - 1) / kPackLanes;
   const int bf = blockIdx.y, f = bf % frames, b = bf / frames;
-  const size_t pair_f = (size_t)b * (frames - 1) + f;
   const bool has_fwd = f < frames - 1, has_bwd = f > 0;
   const v4f zero = {0.f, 0.f, 0.f, 0.f};
   v4f* out = reinterpret_cast<v4f*>(packed) + (size_t)bf * chunks * (kPackVecs * kPackLanes);
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < chunks * kPackLanes; q += gridDim.x * blockDim.x) {
     const bool live = q < quads;
     v4f* o = out + (size_t)(q / kPackLanes) * (kPackVecs * kPackLanes) + (q % kPackLanes);
-    const v4f* ff = reinterpret_cast<const v4f*>(flow_fwd + pair_f * (size_t)n * 2);
-    const v4f* fb = reinterpret_cast<const v4f*>(flow_bwd + (pair_f - 1) * (size_t)n * 2);
-    const v4f* mf = reinterpret_cast<const v4f*>(mask_fwd + pair_f * (size_t)n);
-    const v4f* mb = reinterpret_cast<const v4f*>(mask_bwd + (pair_f - 1) * (size_t)n);
+    const v4f* ff = reinterpret_cast<const v4f*>(flow_fwd + (size_t)b * lay.bs[0] + (size_t)f * lay.fs[0]);
+    const v4f* fb = reinterpret_cast<const v4f*>(flow_bwd + (size_t)b * lay.bs[1] + (size_t)(f - 1) * lay.fs[1]);
+    const v4f* mf = reinterpret_cast<const v4f*>(mask_fwd + (size_t)b * lay.bs[2] + (size_t)f * lay.fs[2]);
+    const v4f* mb = reinterpret_cast<const v4f*>(mask_bwd + (size_t)b * lay.bs[3] + (size_t)(f - 1) * lay.fs[3]);
     o[0 * kPackLanes] = live && has_fwd ? ff[2 * q] : zero;
     o[1 * kPackLanes] = live && has_fwd ? ff[2 * q + 1] : zero;
     o[2 * kPackLanes] = live && has_fwd ? mf[q] : zero;
@@ -441,8 +453,9 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
                             const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
                             const float* packed, const float* scale, int batch, int frames, int height, int width,
                             int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
-                            int items_per_thread, const FlowAdam* adam, void* stream) {
+                            int items_per_thread, const FlowAdam* adam, const fm_layout* layouts, void* stream) {
   FM_CHECK_ARG(depth && k && kinv && acc);
+  FM_CHECK_ARG(!(layouts && adam));  // the in-pass update rewrites the depth PARAMETER: dense by construction
   FM_CHECK_ARG(packed || (flow_fwd && flow_bwd && mask_fwd && mask_bwd));
   FM_CHECK_ARG(batch >= 1 && frames >= 2 && height >= 1 && width >= 1);
   FM_CHECK_ARG(mapping_kind >= 0 && mapping_kind <= 2);
@@ -452,6 +465,17 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
   const bool grad = scale != nullptr;
   FlowParams p{depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, grad_depth, acc,
                frames, height, width, mapping_kind, delta, aspect_x, aspect_y, items_per_thread > 0 ? items_per_thread : 4};
+  {  // element strides of the five image stacks (dense unless the caller described a view)
+    const long n1 = (long)height * width;
+    const long per_frame[5] = {n1, 2 * n1, 2 * n1, n1, n1};
+    const long frames_of[5] = {frames, frames - 1, frames - 1, frames - 1, frames - 1};
+    for (int i = 0; i < 5; ++i) {
+      const bool given = layouts && (layouts[i].frame_stride != 0 || layouts[i].batch_stride != 0);
+      p.fs[i] = given ? layouts[i].frame_stride : per_frame[i];
+      p.bs[i] = given ? layouts[i].batch_stride : per_frame[i] * frames_of[i];
+      FM_CHECK_ARG(p.fs[i] >= per_frame[i] && (batch == 1 || p.bs[i] >= p.fs[i] * (frames_of[i] - 1) + per_frame[i]));
+    }
+  }
   if (adam) {
     p.depth_rw = const_cast<float*>(depth);
     p.exp_avg = adam->exp_avg;
@@ -463,8 +487,10 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
   // needs a memset launch)
   auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool use_packed = packed != nullptr;
-  FM_CHECK_ARG(!use_packed || (width % 4 == 0 && aligned(packed) && aligned(depth) && (!grad_depth || aligned(grad_depth))));
-  const bool vec4 = use_packed || ((width % 4 == 0) && aligned(depth) && aligned(flow_fwd) && aligned(flow_bwd) && aligned(mask_fwd) &&
+  bool strides16 = true;  // every frame of a view starts on a 16-byte boundary (the 16-byte path's loads)
+  for (int i = 0; i < (use_packed ? 1 : 5); ++i) strides16 = strides16 && p.fs[i] % 4 == 0 && p.bs[i] % 4 == 0;
+  FM_CHECK_ARG(!use_packed || (width % 4 == 0 && aligned(packed) && aligned(depth) && strides16 && (!grad_depth || aligned(grad_depth))));
+  const bool vec4 = use_packed || ((width % 4 == 0) && strides16 && aligned(depth) && aligned(flow_fwd) && aligned(flow_bwd) && aligned(mask_fwd) &&
                                    aligned(mask_bwd) && (!grad_depth || aligned(grad_depth)));
 #ifdef FM_FLOW_FORCE_VEC2
   const int vec = vec4 ? 2 : 1;
@@ -524,7 +550,16 @@ int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, co
                        int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
                        int items_per_thread, void* stream) {
   return flow_loss_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
-                          mapping_kind, delta, aspect_x, aspect_y, grad_depth, acc, items_per_thread, nullptr, stream);
+                          mapping_kind, delta, aspect_x, aspect_y, grad_depth, acc, items_per_thread, nullptr, nullptr, stream);
+}
+
+int fm_flow_loss_fused_views(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                             const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
+                             const float* packed, const float* scale, int batch, int frames, int height, int width,
+                             int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
+                             int items_per_thread, const fm_layout* layouts, void* stream) {
+  return flow_loss_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
+                          mapping_kind, delta, aspect_x, aspect_y, grad_depth, acc, items_per_thread, nullptr, layouts, stream);
 }
 
 int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd, const float* flow_fwd,
@@ -538,7 +573,7 @@ int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, con
   FM_CHECK_ARG(aligned(exp_avg) && aligned(exp_avg_sq));
   const FlowAdam adam{exp_avg, exp_avg_sq, touched, adam_coefficients((double)step, lr, beta1, beta2, eps, 0.0)};
   return flow_loss_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
-                          mapping_kind, delta, aspect_x, aspect_y, grad_depth, acc, items_per_thread, &adam, stream);
+                          mapping_kind, delta, aspect_x, aspect_y, grad_depth, acc, items_per_thread, &adam, nullptr, stream);
 }
 
 int fm_flow_loss_finalize(double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
@@ -550,32 +585,72 @@ int fm_flow_loss_finalize(double* acc, const float* k, const float* kinv, const 
   FM_LAUNCH_STATUS();
 }
 
-int fm_flow_valid_norm(const float* mask_fwd, const float* mask_bwd, long count, float weight, double* vsum, float* norm,
-                       void* stream) {
-  FM_CHECK_ARG(mask_fwd && vsum && norm && count >= 0);
+static int valid_norm_launch(const float* mask_fwd, const float* mask_bwd, int batch, int frames_per_batch, long n, float weight, double* vsum,
+                             float* norm, const fm_layout* layouts, void* stream) {
+  FM_CHECK_ARG(mask_fwd && vsum && norm && batch >= 0 && frames_per_batch >= 0 && n >= 0 && (long)batch * frames_per_batch <= 65535);
   hipStream_t st = (hipStream_t)stream;
+  long fs[2], bs[2];
+  for (int i = 0; i < 2; ++i) {
+    const bool given = layouts && (layouts[i].frame_stride != 0 || layouts[i].batch_stride != 0);
+    fs[i] = given ? layouts[i].frame_stride : n;
+    bs[i] = given ? layouts[i].batch_stride : n * frames_per_batch;
+  }
   if (hipMemsetAsync(vsum, 0, sizeof(double), st) != hipSuccess) return FM_ERR_LAUNCH;
-  if (count > 0) {
-    long blocks = (count + 256 * 16 - 1) / (256 * 16);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sum2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mask_fwd, mask_bwd, count, vsum);
+  if (n > 0 && batch * frames_per_batch > 0) {
+    long blocks = (n + 256 * 16 - 1) / (256 * 16);
+    const long cap = 4096 / ((long)batch * frames_per_batch) + 1;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sum2_kernel, dim3((unsigned)blocks, (unsigned)(batch * frames_per_batch)), dim3(256), 0, st, mask_fwd, mask_bwd, n, frames_per_batch,
+                       fs[0], bs[0], fs[1], bs[1], vsum);
   }
   hipLaunchKernelGGL(flow_norm_kernel, dim3(1), dim3(1), 0, st, vsum, weight, norm);
   FM_LAUNCH_STATUS();
 }
 
-int fm_flow_pack_inputs(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, int batch,
-                        int frames, int height, int width, float* packed, void* stream) {
+int fm_flow_valid_norm(const float* mask_fwd, const float* mask_bwd, long count, float weight, double* vsum, float* norm,
+                       void* stream) {
+  FM_CHECK_ARG(mask_fwd && vsum && norm && count >= 0);
+  // one dense run of `count` elements: cut into at most 1024 equal "frames" so that the launch has a second grid dimension
+  long frames = 1;
+  while (frames < 1024 && count % (frames * 2) == 0 && count / (frames * 2) >= 4096) frames *= 2;
+  return valid_norm_launch(mask_fwd, mask_bwd, 1, (int)frames, count / frames, weight, vsum, norm, nullptr, stream);
+}
+
+int fm_flow_valid_norm_views(const float* mask_fwd, const float* mask_bwd, int batch, int pairs, long pixels, float weight, double* vsum,
+                             float* norm, const fm_layout* layouts, void* stream) {
+  return valid_norm_launch(mask_fwd, mask_bwd, batch, pairs, pixels, weight, vsum, norm, layouts, stream);
+}
+
+static int pack_launch(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, int batch,
+                       int frames, int height, int width, float* packed, const fm_layout* layouts, void* stream) {
   FM_CHECK_ARG(flow_fwd && flow_bwd && mask_fwd && mask_bwd && packed);
   FM_CHECK_ARG(batch >= 1 && frames >= 2 && height >= 1 && width >= 1 && width % 4 == 0 && (long)batch * frames <= 65535);
   auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   FM_CHECK_ARG(aligned(flow_fwd) && aligned(flow_bwd) && aligned(mask_fwd) && aligned(mask_bwd) && aligned(packed));
   const int n = height * width, quads = n / 4;
+  PackLayouts lay;
+  const long per_frame[4] = {2L * n, 2L * n, n, n};
+  for (int i = 0; i < 4; ++i) {
+    const bool given = layouts && (layouts[i].frame_stride != 0 || layouts[i].batch_stride != 0);
+    lay.fs[i] = given ? layouts[i].frame_stride : per_frame[i];
+    lay.bs[i] = given ? layouts[i].batch_stride : per_frame[i] * (frames - 1);
+    FM_CHECK_ARG(lay.fs[i] >= per_frame[i] && lay.fs[i] % 4 == 0 && lay.bs[i] % 4 == 0);
+  }
   int bx = (quads + 255) / 256;
   if (bx > 2048) bx = 2048;
   hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)bx, (unsigned)(batch * frames)), dim3(256), 0, (hipStream_t)stream, flow_fwd,
-                     flow_bwd, mask_fwd, mask_bwd, frames, n, packed);
+                     flow_bwd, mask_fwd, mask_bwd, frames, n, packed, lay);
   FM_LAUNCH_STATUS();
+}
+
+int fm_flow_pack_inputs(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, int batch,
+                        int frames, int height, int width, float* packed, void* stream) {
+  return pack_launch(flow_fwd, flow_bwd, mask_fwd, mask_bwd, batch, frames, height, width, packed, nullptr, stream);
+}
+
+int fm_flow_pack_inputs_views(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, int batch,
+                              int frames, int height, int width, float* packed, const fm_layout* layouts, void* stream) {
+  return pack_launch(flow_fwd, flow_bwd, mask_fwd, mask_bwd, batch, frames, height, width, packed, layouts, stream);
 }
 
 int fm_abi_version(void) { return FM_ABI_VERSION; }

@@ -60,7 +60,11 @@ struct ProcParams {
   long points;
   float weight_sens;       // != 0: `weights` holds logits, w = sigmoid(weight_sens·logit)
   int batch_repeat;        // R >= 1: depth/surfaces/flows/weights (and their gradients) have B/R batch
-};                         //         entries, shared by R consecutive (kinv, pose) batch entries
+                           //         entries, shared by R consecutive (kinv, pose) batch entries
+  // element strides between frames / batch entries of the INPUT image stacks depth, surfaces, bwd_flow, weights (fm_layout;
+  // set by proc_layouts: dense unless the caller described a view).  Gradient buffers and workspaces are always dense.
+  long fs[4], bs[4];
+};
 
 enum { SRC_DEPTH = 0, SRC_SURF = 1 };
 
@@ -72,12 +76,13 @@ __device__ __forceinline__ CorrSrc pair_source(const ProcParams& p, size_t pair,
   const size_t fe = (size_t)bd * p.frames + i, fl = fe + 1;
   pair = (size_t)bd * (p.frames - 1) + i;
   CorrSrc s;
-  s.depth_e = SRC == SRC_DEPTH ? p.depth + fe * n : nullptr;
-  s.depth_l = SRC == SRC_DEPTH ? p.depth + fl * n : nullptr;
-  s.surf_e = SRC == SRC_SURF ? p.surfaces + fe * n * 3 : nullptr;
-  s.surf_l = SRC == SRC_SURF ? p.surfaces + fl * n * 3 : nullptr;
-  s.bwd_flow = p.bwd_flow + pair * n * 2;
-  s.weights = p.weights + pair * n;
+  (void)fe, (void)fl, (void)n;
+  s.depth_e = SRC == SRC_DEPTH ? p.depth + (size_t)bd * p.bs[0] + (size_t)i * p.fs[0] : nullptr;
+  s.depth_l = SRC == SRC_DEPTH ? p.depth + (size_t)bd * p.bs[0] + (size_t)(i + 1) * p.fs[0] : nullptr;
+  s.surf_e = SRC == SRC_SURF ? p.surfaces + (size_t)bd * p.bs[1] + (size_t)i * p.fs[1] : nullptr;
+  s.surf_l = SRC == SRC_SURF ? p.surfaces + (size_t)bd * p.bs[1] + (size_t)(i + 1) * p.fs[1] : nullptr;
+  s.bwd_flow = p.bwd_flow + (size_t)bd * p.bs[2] + (size_t)i * p.fs[2];
+  s.weights = p.weights + (size_t)bd * p.bs[3] + (size_t)i * p.fs[3];
   s.weight_sens = p.weight_sens;
   s.height = p.height;
   s.width = p.width;
@@ -534,7 +539,7 @@ __global__ void __launch_bounds__(256) procrustes_scatter_repeat_kernel(ProcPara
         if (!c.taps.in[k]) continue;
         const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
         const float ut = pixel_center(tc, p.width), vt = pixel_center(tr, p.height);
-        const float z = p.depth[fe * n + tr * p.width + tc];
+        const float z = src.depth_e[tr * p.width + tc];
         float ray[3];
         ray_dir(kinv_e, ut, vt, ray);
         const float wt = c.taps.w[k];
@@ -1051,7 +1056,7 @@ __global__ void __launch_bounds__(256, FM_DENSE_TAPS_BLOCKS) procrustes_dense_bw
 // own pixel in the later frame.  keys[(pair·P + j)·5 + slot] = frame·H·W + pixel (slot 0..3 taps with
 // their bilinear weights, slot 4 the later pixel with weight 1), -1 for a tap outside the image.
 __global__ void __launch_bounds__(256) procrustes_scatter_plan_kernel(const float* bwd_flow, const int64_t* indices, long points, int frames,
-                                                                      int height, int width, int64_t* keys, float* weights) {
+                                                                      int height, int width, int64_t* keys, float* weights, long flow_fs, long flow_bs) {
   const size_t pair = blockIdx.y;
   const int b = (int)(pair / (frames - 1)), i = (int)(pair % (frames - 1));
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1059,7 +1064,7 @@ __global__ void __launch_bounds__(256) procrustes_scatter_plan_kernel(const floa
   const int64_t n = (int64_t)height * width;
   const int idx = indices ? (int)indices[j] : (int)j;
   const PixelRef px = pixel_ref(idx, height, width);
-  const float* fl = bwd_flow + (pair * (size_t)n + (size_t)idx) * 2;
+  const float* fl = bwd_flow + (size_t)b * flow_bs + (size_t)i * flow_fs + (size_t)idx * 2;
   const Taps t = bilinear_taps(px.u + fl[0], px.v + fl[1], height, width);  // as corr_load_with
   const int64_t fe = (int64_t)b * frames + i;
   const size_t o = (pair * (size_t)points + (size_t)j) * 5;
@@ -1711,6 +1716,30 @@ static inline bool dense_tiled(const float* depth, const float* surfaces, const 
          dense_blocks(height, width, pairs) < (1L << 31) - kXcds;
 }
 
+// Fill p.fs / p.bs from the caller's fm_layout[4] = {depth, surfaces, bwd_flow, weights} (NULL or {0,0} entries = dense).
+// `image_batch` = batch entries of the image data (B / batch_repeat).
+static inline bool proc_layouts(ProcParams& p, const fm_layout* layouts, int frames, int height, int width) {
+  const long n = (long)height * width;
+  const long per_frame[4] = {n, 3 * n, 2 * n, n};
+  const long frames_of[4] = {frames, frames, frames - 1, frames - 1};
+  bool any = false;
+  for (int i = 0; i < 4; ++i) {
+    const bool given = layouts && (layouts[i].frame_stride != 0 || layouts[i].batch_stride != 0);
+    any = any || given;
+    p.fs[i] = given ? layouts[i].frame_stride : per_frame[i];
+    p.bs[i] = given ? layouts[i].batch_stride : per_frame[i] * frames_of[i];
+    if (p.fs[i] < per_frame[i]) return false;
+  }
+  (void)any;
+  return true;
+}
+static inline bool proc_is_view(const fm_layout* layouts) {
+  if (!layouts) return false;
+  for (int i = 0; i < 4; ++i)
+    if (layouts[i].frame_stride != 0 || layouts[i].batch_stride != 0) return true;
+  return false;
+}
+
 static inline int choose_iters(long points) {
   // P ~ 1000: the work per pair is a latency chain of gathers, so spread it over as many
   // blocks as possible (4 blocks x 149 pairs instead of 149 blocks: 105 -> ~35 us for the
@@ -1723,18 +1752,20 @@ extern "C" {
 static int procrustes_stats_launch(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                                    const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
                                    int batch_repeat, int frames, int height, int width, double* stats, float* t_bwd, float* t_fwd,
-                                   double* aux, hipStream_t st) {
+                                   double* aux, hipStream_t st, const fm_layout* layouts = nullptr) {
   const int pairs = batch * (frames - 1);
-  if (hipMemsetAsync(stats, 0, sizeof(double) * (size_t)pairs * kStatStride, st) != hipSuccess) return FM_ERR_LAUNCH;
   ProcParams p{};
   p.depth = depth; p.kinv = kinv; p.surfaces = surfaces; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;
   p.stats = stats; p.frames = frames; p.height = height; p.width = width; p.points = points;
   p.weight_sens = weight_sensitivity;
   p.batch_repeat = batch_repeat;
+  FM_CHECK_ARG(proc_layouts(p, layouts, frames, height, width));
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
   const dim3 fgrid((unsigned)((pairs + 63) / 64));
   const bool dense = dense_tiled(depth, surfaces, indices, points, batch_repeat, height, width, pairs);
+  FM_CHECK_ARG(!(dense && proc_is_view(layouts)));  // the tiled dense kernels read dense stacks
+  if (hipMemsetAsync(stats, 0, sizeof(double) * (size_t)pairs * kStatStride, st) != hipSuccess) return FM_ERR_LAUNCH;
   if (dense) {
     const long total = dense_blocks(height, width, pairs);
     hipLaunchKernelGGL(procrustes_moments_dense_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, (unsigned)total);
@@ -1778,9 +1809,20 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
                                  frames, height, width, stats, t_bwd, t_fwd, aux, (hipStream_t)stream);
 }
 
-int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+int fm_procrustes_fit_views(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
                             float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
-                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, const float* tap_records, void* stream) {
+                            double* stats, float* t_bwd, float* t_fwd, double* aux, const fm_layout* layouts, void* stream) {
+  FM_CHECK_ARG((depth && kinv) || surfaces);
+  FM_CHECK_ARG(bwd_flow && weights && stats && t_bwd && aux && points >= 1 && batch >= 1 && frames >= 2);
+  FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
+  return procrustes_stats_launch(depth, kinv, surfaces, bwd_flow, weights, weight_sensitivity, indices, points, batch, 1, frames, height, width,
+                                 stats, t_bwd, t_fwd, aux, (hipStream_t)stream, layouts);
+}
+
+static int fit_chain_launch(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                            float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, const float* tap_records,
+                            const fm_layout* layouts, void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
   FM_CHECK_ARG(!tap_records || (depth && indices && points <= 4096 && (reinterpret_cast<uintptr_t>(tap_records) & 15) == 0));
   FM_CHECK_ARG(bwd_flow && weights && work && t_bwd && aux && points >= 1 && batch >= 1 && frames >= 2);
@@ -1792,6 +1834,7 @@ int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* 
   p.stats = work; p.frames = frames; p.height = height; p.width = width; p.points = points;
   p.weight_sens = weight_sensitivity;
   p.batch_repeat = 1;
+  FM_CHECK_ARG(proc_layouts(p, layouts, frames, height, width));
   FitChain fc{reinterpret_cast<int*>(work + (size_t)pairs * kStatStride), t_bwd, t_fwd, aux, ext, batch, corr_out, tap_records};
   if (points <= 4096) {  // one block per pair: the sums stay in the block (procrustes_fit_pair_kernel)
     int* counter = fc.counters + pairs;  // the last of the workspace's ints
@@ -1804,6 +1847,21 @@ int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* 
   if (surfaces) hipLaunchKernelGGL((procrustes_moments_kernel<SRC_SURF>), grid, dim3(256), 0, (hipStream_t)stream, p, iters, fc);
   else hipLaunchKernelGGL((procrustes_moments_kernel<SRC_DEPTH>), grid, dim3(256), 0, (hipStream_t)stream, p, iters, fc);
   FM_LAUNCH_STATUS();
+}
+
+int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                            float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                            double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, const float* tap_records, void* stream) {
+  return fit_chain_launch(depth, kinv, surfaces, bwd_flow, weights, weight_sensitivity, indices, points, batch, frames, height, width, work, t_bwd,
+                          t_fwd, aux, ext, corr_out, tap_records, nullptr, stream);
+}
+
+int fm_procrustes_fit_chain_views(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                                  float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                                  double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, const float* tap_records,
+                                  const fm_layout* layouts, void* stream) {
+  return fit_chain_launch(depth, kinv, surfaces, bwd_flow, weights, weight_sensitivity, indices, points, batch, frames, height, width, work, t_bwd,
+                          t_fwd, aux, ext, corr_out, tap_records, layouts, stream);
 }
 
 int fm_pose_solve(const double* stats, int pairs, float* t_bwd, float* t_fwd, double* aux, void* stream) {
@@ -1829,11 +1887,11 @@ int fm_pose_solve_bwd_kinv(const float* g_t_bwd, const float* g_t_fwd, const flo
   FM_LAUNCH_STATUS();
 }
 
-int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+static int scatter_launch(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
                           const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
                           int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,
                           float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, float* point_grads,
-                          float* point_weight_grads, void* stream) {
+                          float* point_weight_grads, const fm_layout* layouts, void* stream) {
   FM_CHECK_ARG((depth && kinv) || surfaces);
   FM_CHECK_ARG(bwd_flow && weights && aux && pair_grad && points >= 1);
   FM_CHECK_ARG(batch_repeat >= 1 && batch % batch_repeat == 0);
@@ -1849,6 +1907,8 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
   p.point_weight_grads = point_weight_grads;
   p.weight_sens = weight_sensitivity;
   p.batch_repeat = batch_repeat;
+  FM_CHECK_ARG(proc_layouts(p, layouts, frames, height, width));
+  FM_CHECK_ARG(!(proc_is_view(layouts) && batch_repeat > 1));
   const int iters = choose_iters(points);
   dim3 grid((unsigned)((points + 256L * iters - 1) / (256L * iters)), (unsigned)pairs);
   if (batch_repeat > 1 && !surfaces) {
@@ -1858,6 +1918,23 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
   } else if (surfaces) hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_SURF>), grid, dim3(256), 0, st, p, aux, iters);
   else hipLaunchKernelGGL((procrustes_scatter_kernel<SRC_DEPTH>), grid, dim3(256), 0, st, p, aux, iters);
   FM_LAUNCH_STATUS();
+}
+
+int fm_procrustes_scatter(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                          const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch,
+                          int batch_repeat, int frames, int height, int width, const double* aux, const double* pair_grad,
+                          float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc, float* point_grads,
+                          float* point_weight_grads, void* stream) {
+  return scatter_launch(depth, kinv, surfaces, bwd_flow, weights, weight_sensitivity, indices, points, batch, batch_repeat, frames, height, width, aux,
+                        pair_grad, grad_depth, grad_surfaces, grad_weights, kinv_acc, point_grads, point_weight_grads, nullptr, stream);
+}
+
+int fm_procrustes_scatter_views(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                                const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch, int frames,
+                                int height, int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
+                                float* grad_weights, double* kinv_acc, float* point_grads, const fm_layout* layouts, void* stream) {
+  return scatter_launch(depth, kinv, surfaces, bwd_flow, weights, weight_sensitivity, indices, points, batch, 1, frames, height, width, aux, pair_grad,
+                        grad_depth, grad_surfaces, grad_weights, kinv_acc, point_grads, nullptr, layouts, stream);
 }
 
 int fm_procrustes_bwd_planned(const float* corr, const float* kinv, float weight_sensitivity, long points, int batch, int frames, int height, int width,
@@ -1874,6 +1951,7 @@ int fm_procrustes_bwd_planned(const float* corr, const float* kinv, float weight
   p.frames = frames; p.height = height; p.width = width; p.points = points;
   p.weight_sens = weight_sensitivity;
   p.batch_repeat = 1;
+  proc_layouts(p, nullptr, frames, height, width);
   FitBwdPlan pl{g_t_bwd, g_t_fwd, t_bwd, aux, plan_pixels, plan_first, plan_vectors, plan_weights, frame_first, g_k, accumulate_k, batch};
   const size_t lds = sizeof(float) * 2 * 3 * (size_t)points;
   const dim3 grid((unsigned)(batch * frames)), block(kFitBwdThreads);
@@ -1928,6 +2006,7 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
   p.depth = depth; p.kinv = kinv; p.bwd_flow = bwd_flow; p.weights = weights; p.pair_grad = pair_grad; p.grad_depth = grad_depth;
   p.grad_weights = grad_weights; p.frames = frames; p.height = height; p.width = width;
   p.points = (long)height * width; p.weight_sens = weight_sensitivity; p.batch_repeat = 1;
+  proc_layouts(p, nullptr, frames, height, width);
   const unsigned total = (unsigned)dense_blocks(height, width, pairs);
   hipLaunchKernelGGL(procrustes_dense_consts_kernel, dim3((pairs + 63) / 64), dim3(64), 0, st, p, aux, pairs, consts);
   if (grad_depth || grad_weights)
@@ -1936,13 +2015,27 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
   FM_LAUNCH_STATUS();
 }
 
-int fm_procrustes_scatter_plan(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
-                               int64_t* keys, float* weights, void* stream) {
+static int scatter_plan_launch(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                               int64_t* keys, float* weights, const fm_layout* flow_layout, void* stream) {
   FM_CHECK_ARG(bwd_flow && keys && weights && points >= 1 && batch >= 1 && frames >= 2 && height >= 1 && width >= 1);
   FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
+  const long n2 = 2L * height * width;
+  const bool given = flow_layout && (flow_layout->frame_stride != 0 || flow_layout->batch_stride != 0);
+  const long fs = given ? flow_layout->frame_stride : n2, bs = given ? flow_layout->batch_stride : n2 * (frames - 1);
+  FM_CHECK_ARG(fs >= n2);
   hipLaunchKernelGGL(procrustes_scatter_plan_kernel, dim3((unsigned)((points + 255) / 256), (unsigned)(batch * (frames - 1))), dim3(256), 0,
-                     (hipStream_t)stream, bwd_flow, indices, points, frames, height, width, keys, weights);
+                     (hipStream_t)stream, bwd_flow, indices, points, frames, height, width, keys, weights, fs, bs);
   FM_LAUNCH_STATUS();
+}
+
+int fm_procrustes_scatter_plan(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                               int64_t* keys, float* weights, void* stream) {
+  return scatter_plan_launch(bwd_flow, indices, points, batch, frames, height, width, keys, weights, nullptr, stream);
+}
+
+int fm_procrustes_scatter_plan_views(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                                     int64_t* keys, float* weights, const fm_layout* flow_layout, void* stream) {
+  return scatter_plan_launch(bwd_flow, indices, points, batch, frames, height, width, keys, weights, flow_layout, stream);
 }
 
 int fm_sparse_store(const float* values, const int64_t* indices, long points, int groups, long stride, float* out, void* stream) {

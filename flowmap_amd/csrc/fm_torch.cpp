@@ -46,7 +46,7 @@ using OptTensor = std::optional<Tensor>;
 #define FM_API_LIST(X)                                                                                                                    \
   X(fm_flow_loss_fused) X(fm_flow_loss_fused_adam) X(fm_adam_step_elements) X(fm_flow_loss_finalize) X(fm_scale_if_needed) X(fm_intrinsics_inverse) X(fm_intrinsics_inverse_bwd)              \
   X(fm_focal_intrinsics_fwd) X(fm_focal_intrinsics_bwd) X(fm_pose_chain_fwd) X(fm_pose_chain_bwd) X(fm_relative_pose_fwd)                  \
-  X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_pose_solve_bwd_kinv) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense) X(fm_procrustes_bwd_planned)                \
+  X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_pose_solve_bwd_kinv) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense) X(fm_procrustes_bwd_planned) X(fm_flow_loss_fused_views) X(fm_procrustes_fit_chain_views) X(fm_procrustes_fit_views) X(fm_procrustes_scatter_views)                \
   X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_loss_fused_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
   X(fm_adam_step_capturable) X(fm_softmin_score_fwd) X(fm_softmin_score_bwd) X(fm_softmin_blend_fwd) X(fm_softmin_blend_bwd)         \
   X(fm_random_subset) X(fm_random_subset_stateful) X(fm_abi_version)
@@ -110,6 +110,42 @@ static Tensor f32c(const Tensor& t, const char* what) {
   if (!t.is_contiguous() && t.numel() >= (int64_t(16) << 20))
     TORCH_WARN("flowmap_amd: ", what, " is a non-contiguous view of ", t.numel() * 4 / (1 << 20), " MB and is copied on every call; pass a contiguous tensor");
   return t.contiguous();
+}
+
+// An image stack (batch, frame, ...) read IN PLACE when it is a frame window of a larger tensor — x[:, s:s+f], earlier(x) / later(x),
+// a slice of a pretraining batch: every frame dense, frames and batch entries any (non-negative) number of elements apart.  Anything
+// else (a transposed or channel-sliced view) is copied like f32c does.  `lay` stays {0, 0} for a dense tensor.
+static int64_t& view_copy_counter() {
+  static int64_t n = 0;
+  return n;
+}
+struct ImageStack {
+  Tensor t;
+  fm_layout lay{0, 0};
+  bool is_view() const { return lay.frame_stride != 0 || lay.batch_stride != 0; }
+};
+static ImageStack image_stack(const Tensor& t, const char* what) {
+  TORCH_CHECK(t.scalar_type() == at::kFloat, "flowmap_amd: ", what, " must be float32 (got ", t.scalar_type(), ")");
+  ImageStack out;
+  if (t.is_contiguous()) {
+    out.t = t;
+    return out;
+  }
+  bool frames_dense = t.dim() >= 3;
+  int64_t per_frame = 1;
+  for (int64_t d = t.dim() - 1; d >= 2 && frames_dense; --d) {
+    if (t.size(d) != 1 && t.stride(d) != per_frame) frames_dense = false;
+    per_frame *= t.size(d);
+  }
+  if (frames_dense && (t.size(1) == 1 || t.stride(1) >= per_frame) && (t.size(0) == 1 || t.stride(0) >= 0)) {
+    out.t = t;
+    out.lay.frame_stride = t.size(1) == 1 ? per_frame : t.stride(1);
+    out.lay.batch_stride = t.size(0) == 1 ? out.lay.frame_stride * t.size(1) : t.stride(0);
+    return out;
+  }
+  ++view_copy_counter();
+  out.t = f32c(t, what);
+  return out;
 }
 
 static c10::Device check_device(std::initializer_list<const Tensor*> tensors) {
@@ -396,12 +432,16 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     const Tensor& src_in = from_depth ? depth : surfaces;
     TORCH_CHECK(src_in.defined(), "flowmap_amd: the Procrustes fit needs depth + intrinsics or surfaces");
     const auto dev = check_device({&src_in, &weights_in, &bwd_flow_in, &indices, &k, &kinv});
-    const Tensor weights = f32c(weights_in, "weights"), bwd_flow = f32c(bwd_flow_in, "backward flow");
+    // sparse, un-repeated fits read frame windows in place (fm_procrustes_fit_chain_views / _fit_views / _scatter_views); the tiled dense
+    // kernels and the softmin sweep's repeated batches take dense stacks
+    const bool views_ok = indices_o.has_value() && indices_o->defined() && rep == 1;
+    const Tensor weights = views_ok ? image_stack(weights_in, "weights").t : f32c(weights_in, "weights");
+    const Tensor bwd_flow = views_ok ? image_stack(bwd_flow_in, "backward flow").t : f32c(bwd_flow_in, "backward flow");
     TORCH_CHECK(!bwd_flow_in.requires_grad(), "flowmap_amd: gradients w.r.t. optical flow are not supported (flows are constants)");
     TORCH_CHECK(rep >= 1, "flowmap_amd: batch_repeat must be >= 1");
     int64_t bd, f, h, w, b;
     if (from_depth) {
-      depth = f32c(depth, "depth");
+      depth = views_ok ? image_stack(depth, "depth").t : f32c(depth, "depth");
       TORCH_CHECK(depth.dim() == 4, "flowmap_amd: depth must be (batch, frame, height, width)");
       bd = depth.size(0), f = depth.size(1), h = depth.size(2), w = depth.size(3);
       b = bd * rep;  // pose / intrinsics batch: every image-batch entry serves `rep` candidates
@@ -412,7 +452,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                   "flowmap_amd: intrinsics shape does not match depth (x batch_repeat)");
     } else {
       TORCH_CHECK(rep == 1, "flowmap_amd: batch_repeat needs depth-sourced surfaces");
-      surfaces = f32c(surfaces, "surfaces");
+      surfaces = views_ok ? image_stack(surfaces, "surfaces").t : f32c(surfaces, "surfaces");
       TORCH_CHECK(surfaces.dim() == 5 && surfaces.size(4) == 3, "flowmap_amd: surfaces must be (batch, frame, height, width, 3)");
       bd = surfaces.size(0), f = surfaces.size(1), h = surfaces.size(2), w = surfaces.size(3);
       b = bd;
@@ -432,6 +472,17 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     // With a persistent workspace (sparse index set, no repeat): moments, finish + solve and the pose chain in ONE launch
     Tensor work = opt(work_o), ext, stats, corr;
     const bool chained = work.defined() && indices.defined() && rep == 1;
+    fm_layout lay[4] = {};  // depth, surfaces, bwd_flow, weights
+    bool any_view = false;
+    if (views_ok) {
+      const Tensor* stacks[4] = {&depth, &surfaces, &bwd_flow, &weights};
+      for (int i = 0; i < 4; ++i)
+        if (stacks[i]->defined()) {
+          const ImageStack st = image_stack(*stacks[i], "image stack");  // (in place already: no copy happens here)
+          lay[i] = st.lay;
+          any_view = any_view || st.is_view();
+        }
+    }
     {
       DeviceScope scope(dev);
       if (chained) {
@@ -444,14 +495,24 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
         if (wants_records) corr = at::empty({pairs * points, 8}, weights.options());
         const bool taps_ok = from_depth && plan_tap_records.has_value() && plan_tap_records->defined() && plan_tap_records->scalar_type() == at::kFloat &&
                              plan_tap_records->is_contiguous() && plan_tap_records->numel() == pairs * points * 8 && points <= 4096;
-        FM_CALL(fm_procrustes_fit_chain, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights),
-                (float)weight_sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(work), ptr(t_bwd), ptr(t_fwd),
-                ptr<double>(aux), ptr(ext), ptr(corr), taps_ok ? ptr(plan_tap_records) : nullptr, scope.stream);
+        if (any_view)
+          FM_CALL(fm_procrustes_fit_chain_views, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights),
+                  (float)weight_sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(work), ptr(t_bwd), ptr(t_fwd),
+                  ptr<double>(aux), ptr(ext), ptr(corr), taps_ok ? ptr(plan_tap_records) : nullptr, lay, scope.stream);
+        else
+          FM_CALL(fm_procrustes_fit_chain, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights),
+                  (float)weight_sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(work), ptr(t_bwd), ptr(t_fwd),
+                  ptr<double>(aux), ptr(ext), ptr(corr), taps_ok ? ptr(plan_tap_records) : nullptr, scope.stream);
       } else {
         stats = at::empty({pairs, FM_STAT_STRIDE}, weights.options().dtype(at::kDouble));
-        FM_CALL(fm_procrustes_fit, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights), (float)weight_sens,
-                ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(stats), ptr(t_bwd), ptr(t_fwd),
-                ptr<double>(aux), scope.stream);
+        if (any_view)
+          FM_CALL(fm_procrustes_fit_views, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights), (float)weight_sens,
+                  ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(stats), ptr(t_bwd), ptr(t_fwd), ptr<double>(aux), lay,
+                  scope.stream);
+        else
+          FM_CALL(fm_procrustes_fit, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights), (float)weight_sens,
+                  ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(stats), ptr(t_bwd), ptr(t_fwd),
+                  ptr<double>(aux), scope.stream);
       }
     }
     ctx->save_for_backward({from_depth ? depth : surfaces, kinv, weights, bwd_flow, indices, t_bwd, aux, opt(plan_pixels), opt(plan_first),
@@ -516,18 +577,18 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       sink->active = false;
     }
     if (need_src) {
-      g_src = carried.defined() ? carried : at::zeros_like(src);
+      g_src = carried.defined() ? carried : at::zeros(src.sizes(), src.options());  // (dense, whatever the strides of a window)
       for (auto& scatter : pending) scatter(g_src);
     }
     const bool dense = from_depth && !indices.defined() && rep == 1 && h <= 65535 && w <= 65535 && (!need_src || dense_first.defined());
     const bool planned = from_depth && indices.defined() && rep == 1 && plan_pixels.defined();
     bool arena_used = false;
     if (need_w) {
-      if (dense) g_w = at::empty_like(weights);  // every element stored exactly once
+      if (dense) g_w = at::empty(weights.sizes(), weights.options());  // every element stored exactly once
       else if (planned && arena && g_src.defined()) {  // (the planned pass STORES dL/dweights at its slots)
         g_w = arena->acquire(weights, indices);         // zero except at the slots this very pass overwrites
         arena_used = true;
-      } else g_w = at::zeros_like(weights);
+      } else g_w = at::zeros(weights.sizes(), weights.options());
     }
     // dL/dK⁻¹ is linear in the statistics the forward pass left in aux: written by the pose-solve backward itself, and the per-point
     // passes carry no sums for it (repeated batches — the softmin sweep's candidates — keep the per-point accumulation)
@@ -568,10 +629,22 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                 ptr<double>(aux), ptr<double>(pair_grad), ptr(g_src), ptr(g_w), ptr<int64_t>(dense_first), ptr<uint32_t>(dense_list),
                 ptr<double>(consts), scope.stream);
       } else {
-        FM_CALL(fm_procrustes_scatter, from_depth ? ptr(src) : nullptr, ptr(kinv), from_depth ? nullptr : ptr(src), ptr(bwd_flow), ptr(weights),
-                sens, ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(aux), ptr<double>(pair_grad),
-                from_depth ? ptr(g_src) : nullptr, from_depth ? nullptr : ptr(g_src), ptr(g_w), per_point_k, ptr(point_grads),
-                nullptr, scope.stream);
+        fm_layout lay[4] = {};  // depth, surfaces, bwd_flow, weights: the saved inputs may be frame windows read in place
+        bool any_view = false;
+        if (indices.defined() && rep == 1) {
+          const ImageStack s_src = image_stack(src, "image stack"), s_flow = image_stack(bwd_flow, "image stack"), s_w = image_stack(weights, "image stack");
+          lay[from_depth ? 0 : 1] = s_src.lay, lay[2] = s_flow.lay, lay[3] = s_w.lay;
+          any_view = s_src.is_view() || s_flow.is_view() || s_w.is_view();
+        }
+        if (any_view)
+          FM_CALL(fm_procrustes_scatter_views, from_depth ? ptr(src) : nullptr, ptr(kinv), from_depth ? nullptr : ptr(src), ptr(bwd_flow), ptr(weights),
+                  sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(aux), ptr<double>(pair_grad),
+                  from_depth ? ptr(g_src) : nullptr, from_depth ? nullptr : ptr(g_src), ptr(g_w), per_point_k, ptr(point_grads), lay, scope.stream);
+        else
+          FM_CALL(fm_procrustes_scatter, from_depth ? ptr(src) : nullptr, ptr(kinv), from_depth ? nullptr : ptr(src), ptr(bwd_flow), ptr(weights),
+                  sens, ptr<int64_t>(indices), (long)points, (int)b, (int)rep, (int)f, (int)h, (int)w, ptr<double>(aux), ptr<double>(pair_grad),
+                  from_depth ? ptr(g_src) : nullptr, from_depth ? nullptr : ptr(g_src), ptr(g_w), per_point_k, ptr(point_grads),
+                  nullptr, scope.stream);
       }
       // dL/dK = −K⁻ᵀ·dK⁻¹·K⁻ᵀ, added to the flow loss's own dL/dK when that was parked here (one gradient for autograd,
       // no separate add); with a planned scatter it rides in the gather's launch
@@ -645,7 +718,7 @@ static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor
                           acc_work.numel() == b * f * 2 * FM_FLOW_ACC_STRIDE && acc_work.device() == dev;
   Tensor acc = persistent ? acc_work : at::zeros({b * f * 2 * FM_FLOW_ACC_STRIDE}, depth.options().dtype(at::kDouble));
   o.loss = at::empty({1}, depth.options());
-  if (need && need_depth) o.g_depth = at::empty_like(depth);
+  if (need && need_depth) o.g_depth = at::empty(depth.sizes(), depth.options());  // (dense, whatever the strides of a depth window)
   // the three small gradients share one allocation so one launch rescales them in backward
   o.small = at::empty({2 * t_fwd.numel() + k.numel()}, depth.options());
   o.g_tf = o.small.narrow(0, 0, t_fwd.numel()).view_as(t_fwd);
@@ -675,6 +748,16 @@ static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor
     }
   } acc_guard{persistent ? acc : Tensor(), true};
   const bool pk = packed.defined();  // (the originals may then be placeholders without storage of their own)
+  fm_layout lay[5] = {};
+  bool any_view = false;
+  {
+    const Tensor* stacks[5] = {&depth, &flow_fwd, &flow_bwd, &mask_fwd, &mask_bwd};
+    for (int i = 0; i < (pk ? 1 : 5); ++i) {
+      const ImageStack st = image_stack(*stacks[i], "image stack");  // (already in place or copied by the caller: no copy happens here)
+      lay[i] = st.lay;
+      any_view = any_view || st.is_view();
+    }
+  }
   const float *p_ff = pk ? nullptr : ptr(flow_fwd), *p_fb = pk ? nullptr : ptr(flow_bwd), *p_mf = pk ? nullptr : ptr(mask_fwd),
               *p_mb = pk ? nullptr : ptr(mask_bwd);
   if (exp_avg.defined()) {  // the depth parameter's Adam update applied by the same pass (fm_flow_loss_fused_adam)
@@ -682,6 +765,10 @@ static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor
             p_mb, ptr(packed), ptr(norm), (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
             ptr(o.g_depth), ptr<double>(acc), (int)items, ptr(exp_avg), ptr(exp_avg_sq), ptr<uint8_t>(touched), (long)adam_step, adam[0], adam[1],
             adam[2], adam[3], scope.stream);
+  } else if (any_view) {
+    FM_CALL(fm_flow_loss_fused_views, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), p_ff, p_fb, p_mf, p_mb,
+            ptr(packed), need ? ptr(norm) : nullptr, (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
+            ptr(o.g_depth), ptr<double>(acc), (int)items, lay, scope.stream);
   } else {
     FM_CALL(fm_flow_loss_fused, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), p_ff, p_fb, p_mf, p_mb,
             ptr(packed), need ? ptr(norm) : nullptr, (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
@@ -709,13 +796,14 @@ struct FlowLossFused : public Function<FlowLossFused> {
     TORCH_CHECK(flow_fwd_in.scalar_type() == at::kFloat && flow_bwd_in.scalar_type() == at::kFloat && mask_fwd_in.scalar_type() == at::kFloat &&
                     mask_bwd_in.scalar_type() == at::kFloat,
                 "flowmap_amd: flows and masks must be float32");
-    const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics");
+    const Tensor depth = image_stack(depth_in, "depth").t, k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics");
     const Tensor t_fwd = f32c(t_fwd_in, "forward poses"), t_bwd = f32c(t_bwd_in, "backward poses");
     // With a packed copy (fm_flow_pack_inputs) the kernel reads that and nothing else: the four originals are only checked for
     // their shapes — they may be storage-free placeholders (release_flow_originals) — and reach the C ABI as NULL
     const bool has_packed = packed_o.has_value() && packed_o->defined();
-    const Tensor flow_fwd = has_packed ? flow_fwd_in : f32c(flow_fwd_in, "forward flow"), flow_bwd = has_packed ? flow_bwd_in : f32c(flow_bwd_in, "backward flow");
-    const Tensor mask_fwd = has_packed ? mask_fwd_in : f32c(mask_fwd_in, "forward mask"), mask_bwd = has_packed ? mask_bwd_in : f32c(mask_bwd_in, "backward mask");
+    // (frame windows of larger tensors are read in place: flow_launch hands their strides to fm_flow_loss_fused_views)
+    const Tensor flow_fwd = has_packed ? flow_fwd_in : image_stack(flow_fwd_in, "forward flow").t, flow_bwd = has_packed ? flow_bwd_in : image_stack(flow_bwd_in, "backward flow").t;
+    const Tensor mask_fwd = has_packed ? mask_fwd_in : image_stack(mask_fwd_in, "forward mask").t, mask_bwd = has_packed ? mask_bwd_in : image_stack(mask_bwd_in, "backward mask").t;
     TORCH_CHECK(depth.dim() == 4, "flowmap_amd: depth must be (batch, frame, height, width)");
     const int64_t b = depth.size(0), f = depth.size(1), h = depth.size(2), w = depth.size(3);
     TORCH_CHECK(flow_fwd.sizes() == at::IntArrayRef({b, f - 1, h, w, 2}) && flow_bwd.sizes() == flow_fwd.sizes(),
@@ -738,7 +826,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
     const Tensor exp_avg = opt(exp_avg_o), exp_avg_sq = opt(exp_avg_sq_o), touched = opt(touched_o);
     const bool in_pass_adam = exp_avg.defined();
     if (in_pass_adam) {
-      TORCH_CHECK(need && park && depth_in.requires_grad() && depth.data_ptr() == depth_in.data_ptr() && w % 4 == 0 && adam.size() == 4 && adam_step >= 1,
+      TORCH_CHECK(need && park && depth_in.requires_grad() && depth.data_ptr() == depth_in.data_ptr() && depth.is_contiguous() && w % 4 == 0 && adam.size() == 4 && adam_step >= 1,
                   "flowmap_amd: the in-pass Adam update needs a contiguous float32 depth parameter whose gradient travels through the step's DepthSink");
       TORCH_CHECK(exp_avg.sizes() == depth.sizes() && exp_avg_sq.sizes() == depth.sizes() && exp_avg.is_contiguous() && exp_avg_sq.is_contiguous() &&
                       exp_avg.scalar_type() == at::kFloat && exp_avg_sq.scalar_type() == at::kFloat && touched.defined() &&
@@ -1271,6 +1359,7 @@ TORCH_LIBRARY(flowmap_amd, m) {
         fmt::softmin_intrinsics_op);
   m.def("random_subset(int n, int count, Device device, int seed, Tensor? state) -> Tensor", fmt::random_subset);
   m.def("set_one_launch_backward(bool on) -> ()", fmt::set_one_launch_backward);
+  m.def("view_copies() -> int", []() { return fmt::view_copy_counter(); });
   m.def("flow_timing_enable(bool on) -> ()", fmt::flow_timing_enable);
   m.def("flow_timing_collect(bool tracking) -> float[]", fmt::flow_timing_collect);
 }

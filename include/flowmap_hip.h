@@ -412,6 +412,51 @@ int fm_procrustes_bwd_planned(const float* corr, const float* kinv, float weight
                               const int32_t* plan_first, const int32_t* plan_vectors, const float* plan_weights, const int32_t* frame_first,
                               float* grad_depth, float* grad_weights, float* g_k, int accumulate_k, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Frame windows read in place (SURVEY.md §8b "Ownership"; round 3).
+ * The reference hands its functions views — `earlier(x)` / `later(x)` = x[:, :-1], x[:, 1:] (projection.py:139-140), the
+ * segment windows `surfaces[:, s:s+f]` of the tracking loss (loss_tracking.py:44-52), slices of a pretraining batch.  Such a
+ * window of a (B, F_full, ...) tensor is a pointer to its first frame plus two strides: fm_layout, in ELEMENTS of the tensor —
+ * frame_stride between consecutive frames, batch_stride between batch entries ({0, 0} = dense: frames back to back, batch
+ * entries back to back).  The `_views` entry points below are their dense namesakes with one fm_layout per image-stack
+ * argument (a HOST array; NULL = all dense): the kernels apply the strides when they form each frame's base pointer, so a
+ * window costs no copy.  Everything these functions WRITE (gradients, workspaces) stays dense.  For the 16-byte paths
+ * (W % 4 == 0) the strides must be multiples of 4 elements, else the scalar path runs.
+ *   fm_flow_loss_fused_views       layouts[5] = depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd
+ *   fm_flow_valid_norm_views       layouts[2] = mask_fwd, mask_bwd (each (batch, pairs, pixels))
+ *   fm_flow_pack_inputs_views      layouts[4] = flow_fwd, flow_bwd, mask_fwd, mask_bwd
+ *   fm_procrustes_fit_views / fm_procrustes_fit_chain_views / fm_procrustes_scatter_views (batch_repeat 1, sparse index sets)
+ *                                  layouts[4] = depth, surfaces, bwd_flow, weights
+ *   fm_procrustes_scatter_plan_views   one layout: bwd_flow
+ * --------------------------------------------------------------------------------- */
+typedef struct fm_layout {
+  long frame_stride; /* elements between consecutive frames (0 with batch_stride 0: dense) */
+  long batch_stride; /* elements between batch entries */
+} fm_layout;
+
+int fm_flow_loss_fused_views(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                             const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
+                             const float* packed, const float* scale, int batch, int frames, int height, int width,
+                             int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
+                             int items_per_thread, const fm_layout* layouts, void* stream);
+int fm_flow_valid_norm_views(const float* mask_fwd, const float* mask_bwd, int batch, int pairs, long pixels, float weight, double* vsum,
+                             float* norm, const fm_layout* layouts, void* stream);
+int fm_flow_pack_inputs_views(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, int batch,
+                              int frames, int height, int width, float* packed, const fm_layout* layouts, void* stream);
+int fm_procrustes_fit_views(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                            float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                            double* stats, float* t_bwd, float* t_fwd, double* aux, const fm_layout* layouts, void* stream);
+int fm_procrustes_fit_chain_views(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                                  float weight_sensitivity, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                                  double* work, float* t_bwd, float* t_fwd, double* aux, float* ext, float* corr_out, const float* tap_records,
+                                  const fm_layout* layouts, void* stream);
+int fm_procrustes_scatter_views(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow,
+                                const float* weights, float weight_sensitivity, const int64_t* indices, long points, int batch, int frames,
+                                int height, int width, const double* aux, const double* pair_grad, float* grad_depth, float* grad_surfaces,
+                                float* grad_weights, double* kinv_acc, float* point_grads, const fm_layout* layouts, void* stream);
+int fm_procrustes_scatter_plan_views(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                                     int64_t* keys, float* weights, const fm_layout* flow_layout, void* stream);
+
 /* The tail of IntrinsicsSoftmin.forward (flowmap/model/intrinsics/intrinsics_softmin.py:123-141):
  * soft = softmin((err - min err) * 10) over the N candidates (fp32), K = sum_n soft[n] * candidate_k[n],
  * repeated over `frames`.  err (B,N) fp64 as fm_softmin_score_fwd leaves it; candidate_k (N,3,3);

@@ -1400,3 +1400,72 @@ def case_pretraining_mode(dev):
             flowmap_amd.release_flow_originals(Flows(*(x.clone().to(dev) for x in (fl.forward, fl.backward, fl.forward_mask, fl.backward_mask))))
     finally:
         fm.set_lazy_surfaces(False)
+
+
+def case_frame_windows(dev):
+    """Frame windows of larger tensors — x[:, s:s+f] (loss_tracking.py:44-52), earlier(x) / later(x) (projection.py:139-140), a
+    slice of a pretraining batch — are read IN PLACE through the C ABI's fm_layout strides (fm_*_views): same loss and
+    gradients as contiguous clones of the windows, over several steps (so the packed copy, the scatter plan and the static
+    tap records are built from views too), and not one copy made."""
+    import warnings
+
+    from flowmap_amd import Batch, Flows, ModelOutput, _ops
+    from flowmap_amd._lib import torch_ops
+    from flowmap_amd.loss import LossFlow, LossFlowCfg
+
+    b, frames_full, h, w, p = 2, 8, 16, 24, 60
+    s0, f = 2, 5  # the window: frames 2..6 of 8
+    g = torch.Generator().manual_seed(17)
+    depth_full = (1.1 + 0.1 * torch.rand((b, frames_full, h, w), generator=g)).to(dev)
+    weights_full = torch.rand((b, frames_full - 1, h, w), generator=g).to(dev)
+    flows_full = [t.to(dev) for t in (0.01 * torch.randn((b, frames_full - 1, h, w, 2), generator=g), 0.01 * torch.randn((b, frames_full - 1, h, w, 2), generator=g),
+                                      torch.rand((b, frames_full - 1, h, w), generator=g), torch.rand((b, frames_full - 1, h, w), generator=g))]
+    k = orc.focal_to_k(torch.tensor([0.8, 0.9]), (h, w))[:, None].expand(b, f, 3, 3).contiguous().to(dev)
+    idx = torch.linspace(0, h * w - 1, p, dtype=torch.int64).to(dev)
+    loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
+
+    def run(window: bool, steps=3):
+        d_leaf = depth_full.clone().requires_grad_(True)
+        w_leaf = weights_full.clone().requires_grad_(True)
+        kk = k.clone().requires_grad_(True)
+        if window:
+            flows = Flows(*(t[:, s0 : s0 + f - 1] for t in flows_full))
+        else:
+            flows = Flows(*(t[:, s0 : s0 + f - 1].contiguous() for t in flows_full))
+        out = []
+        for _ in range(steps):
+            for leaf in (d_leaf, w_leaf, kk):
+                leaf.grad = None
+            d = d_leaf[:, s0 : s0 + f] if window else d_leaf[:, s0 : s0 + f].contiguous()
+            wt = w_leaf[:, s0 : s0 + f - 1] if window else w_leaf[:, s0 : s0 + f - 1].contiguous()
+            assert d.is_contiguous() != window
+            xy, _ = fm.sample_image_grid((h, w), dev)
+            surfaces = fm.unproject(xy, d, kk[:, :, None, None])
+            ext = fm.align_surfaces(surfaces, flows.backward, wt, idx)
+            loss = loss_fn(Batch(torch.zeros((b, f, 3, h, w), device=dev)), flows, None, ModelOutput(d, surfaces, kk, ext, wt), 0)
+            loss.backward()
+            out.append((loss.detach().clone(), ext.detach().clone(), d_leaf.grad.clone(), w_leaf.grad.clone(), kk.grad.clone()))
+        return out
+
+    fm.set_lazy_surfaces(True)
+    try:
+        dense = run(False)
+        copies, packs, plans = torch_ops().view_copies(), _ops.counters["flow_packs"], _ops.counters["procrustes_plans_built"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")  # "... is a non-contiguous view ... and is copied on every call" must not appear
+            views = run(True)
+        assert torch_ops().view_copies() == copies, "a frame window was copied"
+        assert _ops.counters["flow_packs"] == packs + 1 and _ops.counters["procrustes_plans_built"] == plans + 1  # packed / planned FROM the views
+        for step, (a, c) in enumerate(zip(views, dense)):
+            for x, y, what in zip(a, c, ("loss", "extrinsics", "g_depth (scattered back into the full tensor)", "g_weights", "g_k")):
+                assert_close(x, y, 2e-5, abs_=1e-7, what=f"{what}, step {step}")
+        # outside the window nothing may have been written
+        g_depth = views[-1][2]
+        assert float(g_depth[:, :s0].abs().max()) == 0 and float(g_depth[:, s0 + f :].abs().max()) == 0
+        # a view that is NOT a frame window (pixels transposed) is still accepted — copied, and counted
+        odd = depth_full[:, s0 : s0 + f].transpose(2, 3).contiguous().transpose(2, 3)
+        xy, _ = fm.sample_image_grid((h, w), dev)
+        fm.align_surfaces(fm.unproject(xy, odd, k[:, :, None, None]), flows_full[1][:, s0 : s0 + f - 1], weights_full[:, s0 : s0 + f - 1], idx)
+        assert torch_ops().view_copies() == copies + 1
+    finally:
+        fm.set_lazy_surfaces(False)

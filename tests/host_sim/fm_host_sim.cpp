@@ -1457,4 +1457,92 @@ int fm_procrustes_bwd_planned(const float* corr, const float* kinv, float sens, 
   return g_k ? fm_intrinsics_inverse_bwd(kinv_acc.data(), kinv, batch * frames, g_k, accumulate_k, stream) : 0;
 }
 
+// ---- frame windows (fm_layout): the double gathers every view into a dense temporary and runs its dense namesake — the
+// semantics of the strides, none of the device kernels' pointer arithmetic ----
+static std::vector<float> sim_densify(const float* p, const fm_layout* lay, int batch, int frames, size_t per_frame) {
+  std::vector<float> out;
+  if (!p) return out;
+  const bool given = lay && (lay->frame_stride != 0 || lay->batch_stride != 0);
+  const size_t fs = given ? (size_t)lay->frame_stride : per_frame, bs = given ? (size_t)lay->batch_stride : per_frame * frames;
+  out.resize((size_t)batch * frames * per_frame);
+  for (int b = 0; b < batch; ++b)
+    for (int f = 0; f < frames; ++f) std::memcpy(out.data() + ((size_t)b * frames + f) * per_frame, p + b * bs + f * fs, per_frame * sizeof(float));
+  return out;
+}
+static const float* sim_or_null(const std::vector<float>& v) { return v.empty() ? nullptr : v.data(); }
+
+int fm_flow_loss_fused_views(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
+                             const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
+                             const float* packed, const float* scale, int batch, int frames, int height, int width, int mapping_kind,
+                             float delta, float ax, float ay, float* grad_depth, double* acc, int items, const fm_layout* layouts, void* stream) {
+  const size_t n = (size_t)height * width;
+  const auto d = sim_densify(depth, layouts ? layouts + 0 : nullptr, batch, frames, n);
+  const auto ff = sim_densify(flow_fwd, layouts ? layouts + 1 : nullptr, batch, frames - 1, 2 * n);
+  const auto fb = sim_densify(flow_bwd, layouts ? layouts + 2 : nullptr, batch, frames - 1, 2 * n);
+  const auto mf = sim_densify(mask_fwd, layouts ? layouts + 3 : nullptr, batch, frames - 1, n);
+  const auto mb = sim_densify(mask_bwd, layouts ? layouts + 4 : nullptr, batch, frames - 1, n);
+  return fm_flow_loss_fused(sim_or_null(d), k, kinv, t_fwd, t_bwd, sim_or_null(ff), sim_or_null(fb), sim_or_null(mf), sim_or_null(mb), packed, scale, batch,
+                            frames, height, width, mapping_kind, delta, ax, ay, grad_depth, acc, items, stream);
+}
+
+int fm_flow_valid_norm_views(const float* mask_fwd, const float* mask_bwd, int batch, int pairs, long pixels, float weight, double* vsum,
+                             float* norm, const fm_layout* layouts, void* stream) {
+  const auto mf = sim_densify(mask_fwd, layouts ? layouts + 0 : nullptr, batch, pairs, (size_t)pixels);
+  const auto mb = sim_densify(mask_bwd, layouts ? layouts + 1 : nullptr, batch, pairs, (size_t)pixels);
+  return fm_flow_valid_norm(sim_or_null(mf), sim_or_null(mb), (long)batch * pairs * pixels, weight, vsum, norm, stream);
+}
+
+int fm_flow_pack_inputs_views(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, int batch,
+                              int frames, int height, int width, float* packed, const fm_layout* layouts, void* stream) {
+  const size_t n = (size_t)height * width;
+  const auto ff = sim_densify(flow_fwd, layouts ? layouts + 0 : nullptr, batch, frames - 1, 2 * n);
+  const auto fb = sim_densify(flow_bwd, layouts ? layouts + 1 : nullptr, batch, frames - 1, 2 * n);
+  const auto mf = sim_densify(mask_fwd, layouts ? layouts + 2 : nullptr, batch, frames - 1, n);
+  const auto mb = sim_densify(mask_bwd, layouts ? layouts + 3 : nullptr, batch, frames - 1, n);
+  return fm_flow_pack_inputs(sim_or_null(ff), sim_or_null(fb), sim_or_null(mf), sim_or_null(mb), batch, frames, height, width, packed, stream);
+}
+
+struct SimProcViews {
+  std::vector<float> depth, surfaces, flow, weights;
+  SimProcViews(const float* d, const float* s, const float* fl, const float* w, const fm_layout* lay, int batch, int frames, int height, int width) {
+    const size_t n = (size_t)height * width;
+    depth = sim_densify(d, lay ? lay + 0 : nullptr, batch, frames, n);
+    surfaces = sim_densify(s, lay ? lay + 1 : nullptr, batch, frames, 3 * n);
+    flow = sim_densify(fl, lay ? lay + 2 : nullptr, batch, frames - 1, 2 * n);
+    weights = sim_densify(w, lay ? lay + 3 : nullptr, batch, frames - 1, n);
+  }
+};
+
+int fm_procrustes_fit_views(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights, float sens,
+                            const int64_t* indices, long points, int batch, int frames, int height, int width, double* stats, float* t_bwd,
+                            float* t_fwd, double* aux, const fm_layout* layouts, void* stream) {
+  const SimProcViews v(depth, surfaces, bwd_flow, weights, layouts, batch, frames, height, width);
+  return fm_procrustes_fit(sim_or_null(v.depth), kinv, sim_or_null(v.surfaces), sim_or_null(v.flow), sim_or_null(v.weights), sens, indices, points, batch, 1,
+                           frames, height, width, stats, t_bwd, t_fwd, aux, stream);
+}
+
+int fm_procrustes_fit_chain_views(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights, float sens,
+                                  const int64_t* indices, long points, int batch, int frames, int height, int width, double* work, float* t_bwd,
+                                  float* t_fwd, double* aux, float* ext, float* corr_out, const float* tap_records, const fm_layout* layouts,
+                                  void* stream) {
+  const SimProcViews v(depth, surfaces, bwd_flow, weights, layouts, batch, frames, height, width);
+  return fm_procrustes_fit_chain(sim_or_null(v.depth), kinv, sim_or_null(v.surfaces), sim_or_null(v.flow), sim_or_null(v.weights), sens, indices, points,
+                                 batch, frames, height, width, work, t_bwd, t_fwd, aux, ext, corr_out, tap_records, stream);
+}
+
+int fm_procrustes_scatter_views(const float* depth, const float* kinv, const float* surfaces, const float* bwd_flow, const float* weights,
+                                float sens, const int64_t* indices, long points, int batch, int frames, int height, int width, const double* aux,
+                                const double* pair_grad, float* grad_depth, float* grad_surfaces, float* grad_weights, double* kinv_acc,
+                                float* point_grads, const fm_layout* layouts, void* stream) {
+  const SimProcViews v(depth, surfaces, bwd_flow, weights, layouts, batch, frames, height, width);
+  return fm_procrustes_scatter(sim_or_null(v.depth), kinv, sim_or_null(v.surfaces), sim_or_null(v.flow), sim_or_null(v.weights), sens, indices, points, batch,
+                               1, frames, height, width, aux, pair_grad, grad_depth, grad_surfaces, grad_weights, kinv_acc, point_grads, nullptr, stream);
+}
+
+int fm_procrustes_scatter_plan_views(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
+                                     int64_t* keys, float* weights, const fm_layout* flow_layout, void* stream) {
+  const auto fl = sim_densify(bwd_flow, flow_layout, batch, frames - 1, 2 * (size_t)height * width);
+  return fm_procrustes_scatter_plan(sim_or_null(fl), indices, points, batch, frames, height, width, keys, weights, stream);
+}
+
 }  // extern "C"

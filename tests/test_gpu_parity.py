@@ -458,3 +458,7 @@ def test_one_launch_fit_agrees_with_the_three_launch_form_under_stress():
 
 def test_pretraining_mode_never_packs_or_plans():
     cases.case_pretraining_mode(DEV)
+
+
+def test_frame_windows_are_read_in_place():
+    cases.case_frame_windows(DEV)

@@ -161,3 +161,7 @@ def test_depth_adam_update_inside_the_flow_pass_with_the_softmin_sweep():
 
 def test_pretraining_mode_never_packs_or_plans():
     cases.case_pretraining_mode("cpu")
+
+
+def test_frame_windows_are_read_in_place():
+    cases.case_frame_windows("cpu")
