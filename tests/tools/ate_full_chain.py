@@ -44,16 +44,20 @@ def scene(args):
 
 def config(args):
     return {k: getattr(args, k) for k in ("frames", "height", "width", "steps", "lr", "points", "noise", "seed", "track_grid", "softmin_points",
-                                          "num_candidates", "after_step", "window")}
+                                          "num_candidates", "after_step", "window", "trace_every", "no_softmin")}
 
 
 def reference_leg(args):
     f, h, w = args.frames, args.height, args.width
     sc, tracks = scene(args)
     gt_pos = sc["extrinsics_gt"][:, :3, 3]
-    d = sc["depth_init"].clone().requires_grad_(True)
+    d = sc["depth_init"].clone()
+    if args.perturb != 0.0:  # the reference path's OWN sensitivity: the same run from initial depths moved by ~1 ulp
+        d = d * (1.0 + args.perturb * torch.randn(d.shape, generator=torch.Generator().manual_seed(12345)))
+    d.requires_grad_(True)
     wl = torch.zeros((f - 1, h, w), requires_grad=True)
-    fo = torch.tensor(0.0, requires_grad=True)  # IntrinsicsRegressed inside IntrinsicsSoftmin starts at 0 (intrinsics_softmin.py:60)
+    # IntrinsicsRegressed inside IntrinsicsSoftmin starts at 0 (intrinsics_softmin.py:60); --no-softmin: a regressed focal length from the start, 10 % off
+    fo = torch.tensor(0.85 * 1.1 if args.no_softmin else 0.0, requires_grad=True)
     opt = torch.optim.Adam([d, wl, fo], lr=args.lr)
     cand = torch.linspace(*CANDIDATES, args.num_candidates)
     idx = orc.procrustes_indices((h, w), args.points)
@@ -62,8 +66,8 @@ def reference_leg(args):
 
     def forward(step):
         depth, weights = d[None], (100.0 * wl).sigmoid()[None]
-        if step >= args.after_step:
-            if step == args.after_step:
+        if args.no_softmin or step >= args.after_step:
+            if step == args.after_step and not args.no_softmin:
                 fo.data = torch.stack(window).mean()
             k = orc.focal_to_k(fo, (h, w)).expand(1, f, 3, 3)
             focal = float(fo.detach())
@@ -91,12 +95,14 @@ def reference_leg(args):
         _, out, _ = forward(args.steps)
     pos = out.extrinsics[0, :, :3, 3]
     result = {
-        "made_by": "python tests/tools/ate_full_chain.py --leg reference " + " ".join(f"--{k.replace('_', '-')} {v}" for k, v in config(args).items()),
+        "made_by": "python tests/tools/ate_full_chain.py --leg reference " + " ".join(f"--{k.replace('_', '-')} {v}" for k, v in config(args).items())
+                   + (f" --perturb {args.perturb}" if args.perturb else ""),
         "config": config(args),
+        "perturb": args.perturb,
         "ate_reference_path_cpu": orc.ate(gt_pos, pos),
         "final_loss_reference_path": losses[-1],
-        "loss_trace": losses[::10],
-        "focal_trace": focal_trace[::10],
+        "loss_trace": losses[:: args.trace_every],
+        "focal_trace": focal_trace[:: args.trace_every],
         "focal_final": float(fo.detach()),
         "positions": pos.tolist(),
         "seconds": time.perf_counter() - t0,
@@ -128,15 +134,18 @@ def ours_leg(args):
     sc, otracks = scene(args)
     gt_pos = sc["extrinsics_gt"][:, :3, 3]
     flowmap_amd.set_lazy_surfaces(True)
-    cfg = ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
-                   IntrinsicsSoftminCfg("softmin", args.softmin_points, *CANDIDATES, args.num_candidates, RegressionCfg(args.after_step, args.window)),
-                   ExtrinsicsProcrustesCfg("procrustes", args.points, False))
+    from flowmap_amd.model.model import IntrinsicsRegressedCfg
+
+    intrinsics = (IntrinsicsRegressedCfg("regressed", 0.85 * 1.1) if args.no_softmin else
+                  IntrinsicsSoftminCfg("softmin", args.softmin_points, *CANDIDATES, args.num_candidates, RegressionCfg(args.after_step, args.window)))
+    cfg = ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), intrinsics, ExtrinsicsProcrustesCfg("procrustes", args.points, False))
     model = Model(cfg, num_frames=f, image_shape=(h, w))
     model.backbone.depth.data = sc["depth_init"].clone()
     model = model.to(dev)
     model.train()
     state = {"step": 0}
-    model.intrinsics._draw_indices = lambda count, device: step_indices(state["step"], count, args.softmin_points).to(device)
+    if not args.no_softmin:
+        model.intrinsics._draw_indices = lambda count, device: step_indices(state["step"], count, args.softmin_points).to(device)
     flows = to_flows(sc["flows"], dev)
     tracks = to_tracks(otracks, dev)
     batch = Batch(torch.zeros((1, f, 3, 1, 1), device=dev).expand(1, f, 3, h, w))
@@ -156,7 +165,7 @@ def ours_leg(args):
         loss = loss_fn(batch, flows, None, out, step) + track_fn(batch, flows, tracks, out, step)
         loss.backward()
         opt.step()
-        if step % 10 == 0:
+        if step % args.trace_every == 0:
             losses.append(float(loss.detach()))
             focal_trace.append(float(out.intrinsics[0, 0, 0, 0].detach()) * w / (h * w) ** 0.5)
     if dev.type == "cuda":
@@ -172,13 +181,17 @@ def ours_leg(args):
     print(json.dumps({
         "scene": f"synthetic consistent scene, {f} frames @ {h}x{w} ({f - 1} chained poses), seed {args.seed}, depth noise {args.noise}",
         "schedule": f"flow (1000) + tracking (100, {len(otracks)} segments x {args.track_grid ** 2} tracks); softmin intrinsics ({args.num_candidates} candidates x "
-                    f"{args.softmin_points} points) for {args.after_step} steps, window {args.window}, then the regressed focal length; Adam lr {args.lr}, {args.steps} steps",
+                    f"{args.softmin_points} points) for {args.after_step} steps, window {args.window}, then the regressed focal length; Adam lr {args.lr}, {args.steps} steps"
+                    if not args.no_softmin else f"flow (1000) + tracking (100, {len(otracks)} segments x {args.track_grid ** 2} tracks); regressed focal length from the start (10 % off); Adam lr {args.lr}, {args.steps} steps",
         "ate_reference_path_cpu": ref["ate_reference_path_cpu"], "ate_flowmap_amd": ate_ours, "ate_abs_diff": abs(ate_ours - ref["ate_reference_path_cpu"]),
         "max_position_diff": float((pos - ref_pos).abs().max()), "position_scale": float(ref_pos.abs().max()),
         "final_loss_reference_path": ref["final_loss_reference_path"], "final_loss_flowmap_amd": final_loss,
-        "focal_final_reference_path": ref["focal_final"], "focal_final_flowmap_amd": float(model.intrinsics.intrinsics_regressed.focal_length.detach()),
+        "focal_final_reference_path": ref["focal_final"], "focal_final_flowmap_amd": float((model.intrinsics if args.no_softmin else model.intrinsics.intrinsics_regressed).focal_length.detach()),
         "loss_trace_max_rel_diff": max(abs(a - b) / abs(b) for a, b in zip(losses, ref["loss_trace"])),
         "focal_trace_max_abs_diff": max(abs(a - b) for a, b in zip(focal_trace, ref["focal_trace"])),
+        "trace_every": args.trace_every,
+        "loss_trace_rel_diffs": [round(abs(a - b) / abs(b), 9) for a, b in zip(losses, ref["loss_trace"])],
+        "focal_trace_abs_diffs": [round(abs(a - b), 9) for a, b in zip(focal_trace, ref["focal_trace"])],
         "seconds_reference_path_cpu": ref["seconds"], "seconds_flowmap_amd": seconds, "device": str(dev),
         "optimizer": "reference path: torch.optim.Adam; flowmap_amd: flowmap_amd.FusedAdam"
                      + (f" with fuse_depth_update ({opt.counters['in_pass_updates']} of {args.steps} depth updates inside the flow pass)" if args.in_pass else ""),
@@ -186,9 +199,29 @@ def ours_leg(args):
     }))
 
 
+def compare_leg(args):
+    """Two runs of the REFERENCE path (the second from initial depths perturbed by --perturb, ~1 ulp): how far apart they end is the
+    bar a second implementation can be held to — the schedule (softmin selector + Adam) amplifies rounding-level differences."""
+    a, b = json.loads(Path(args.reference).read_text()), json.loads(Path(args.other).read_text())
+    pa, pb = torch.tensor(a["positions"]), torch.tensor(b["positions"])
+    n = min(len(a["loss_trace"]), len(b["loss_trace"]))
+    print(json.dumps({
+        "what": "reference path vs reference path from initial depths perturbed by " + str(b.get("perturb")) + " (relative, Gaussian)",
+        "ate_reference_path_cpu": a["ate_reference_path_cpu"], "ate_perturbed_reference_path": b["ate_reference_path_cpu"],
+        "ate_abs_diff": abs(a["ate_reference_path_cpu"] - b["ate_reference_path_cpu"]),
+        "max_position_diff": float((pa - pb).abs().max()), "focal_final": [a["focal_final"], b["focal_final"]],
+        "final_loss": [a["final_loss_reference_path"], b["final_loss_reference_path"]],
+        "loss_trace_max_rel_diff": max(abs(x - y) / abs(x) for x, y in zip(a["loss_trace"][:n], b["loss_trace"][:n])),
+        "focal_trace_max_abs_diff": max(abs(x - y) for x, y in zip(a["focal_trace"][:n], b["focal_trace"][:n])),
+        "made_by": [a["made_by"], b["made_by"]],
+    }))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--leg", choices=["reference", "ours"], required=True)
+    ap.add_argument("--leg", choices=["reference", "ours", "compare"], required=True)
+    ap.add_argument("--perturb", type=float, default=0.0, help="reference leg: relative Gaussian perturbation of the initial depths (sensitivity run)")
+    ap.add_argument("--other", default=None, help="compare leg: the second reference-path record")
     ap.add_argument("--out", default=str(ROOT / "tests" / "golden" / "ate_150x360x640_reference.json"))
     ap.add_argument("--reference", default=str(ROOT / "tests" / "golden" / "ate_150x360x640_reference.json"))
     ap.add_argument("--device", default="cuda:0")
@@ -205,8 +238,10 @@ if __name__ == "__main__":
     ap.add_argument("--num-candidates", type=int, default=60)
     ap.add_argument("--after-step", type=int, default=100)
     ap.add_argument("--window", type=int, default=20)
+    ap.add_argument("--trace-every", type=int, default=10)
+    ap.add_argument("--no-softmin", action="store_true", help="regressed intrinsics from the start (no candidate sweep): the schedule without its chaotic selector")
     ap.add_argument("--in-pass", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
-    (reference_leg if a.leg == "reference" else ours_leg)(a)
+    {"reference": reference_leg, "ours": ours_leg, "compare": compare_leg}[a.leg](a)
