@@ -100,6 +100,10 @@ def parse():
                          "eagerly after the replay), `off`.  Default: off on one GPU (the headline number is measured eagerly, with HIP events around the "
                          "flow kernel), `compute` for a multi-rank strong-scaling run of the flow loss — a rank's ~15 kernels take ~0.2 ms at 8 GPUs and "
                          "cannot hide ~0.45 ms of eager enqueueing")
+    ap.add_argument("--halo", choices=["oneshot", "early"], default="oneshot",
+                    help="strong scaling: how the boundary frames' dL/ddepth reaches the neighbour — `oneshot`: one 3.7 MB (720p) exchange per boundary and "
+                         "direction after backward; `early` (FrameShard.enable_early_halo): the dense part right after the flow pass, under the rest of the "
+                         "step, and a sparse correction (~20 KB) after backward.  Not with --graph compute (a collective cannot sit inside a replay)")
     ap.add_argument("--share", type=int, default=0,
                     help="K > 0: run ONE rank's share of a K-GPU strong-scaling run on this GPU (its pairs + halo frames, collectives on a "
                          "one-rank RCCL communicator): the per-rank step time of a K-GPU run without the wire time")
@@ -335,6 +339,8 @@ def main():
                                    and args.optimizer in ("none", "fused")) else "off"
     if args.graph == "off":
         args.graph = None
+    if args.halo == "early" and args.graph == "compute":
+        raise SystemExit("--halo early needs --graph off|whole: the early exchange starts between the flow pass and backward")
     if args.graph == "compute" and (not strong or cfg["tracking"] or args.intrinsics != "regressed"):
         raise SystemExit("--graph compute: a frame-sharded run of the flow loss with regressed intrinsics (the tracking loss and the softmin sweep have collectives inside forward / backward)")
     flowmap_amd.set_lazy_surfaces(True)
@@ -436,6 +442,10 @@ def main():
     # flows / masks and reduces the valid sums, the second one plans the static scatters (SURVEY §8d:
     # the metric excludes one-time precompute)
     for _ in range(3):
+        step()
+    early_halo = False
+    if args.halo == "early" and strong:
+        early_halo = shard.enable_early_halo(model.backbone.depth)  # (collective over neighbours; the scatter plans exist by now)
         step()
     if dist is not None:  # create the RCCL communicators / P2P channels outside the timed region
         shard.exchange_halo(torch.zeros((2, h, w), device=device))
@@ -543,6 +553,7 @@ def main():
                 "pairs_per_gpu": f - 1,
                 "height": h,
                 "width": w,
+                "halo_exchange": ("early (dense part after the flow pass, sparse correction after backward)" if early_halo else "one shot after backward") if strong else None,
                 "parallelism": (f"frame-pair shards x{world} (1-frame halo, packed all-reduce of loss + shared gradients, halo exchange)" if strong
                                 else f"{world} independent 150-frame shards" if world > 1 else "single GPU"),
                 "loss": float(loss.item()),

@@ -656,10 +656,19 @@ class FlowLossFused:
             offer = optimizer.begin_in_pass(depth, sink, t_fwd, t_bwd)
             if offer is not None:
                 adam, ticket = offer
+        # frame sharding with an early halo exchange (FrameShard.enable_early_halo): the dense dL/ddepth exists at the end of THIS
+        # forward pass — the boundary frames are sent now, under the rest of the step; only a sparse correction follows backward
+        early = _root(depth).__dict__.get("_fm_early_halo") if (sink is not None and ticket is None and torch.is_grad_enabled()) else None
+        if early is not None:
+            sink.request_early_dense(early.unit_flag(depth.device))
         loss = torch_ops().flow_loss(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, int(kind), float(delta),
                                      sink, int(items), acc, *adam)
         if ticket is not None:  # the operator accepted the arguments and launched: only now does the optimiser's state advance
             optimizer.commit_in_pass(ticket)
+        if early is not None:
+            dense = sink.take_early_dense()
+            if dense is not None:
+                early.start_early_halo(dense, _root(depth))
         return loss
 
 
@@ -1001,6 +1010,25 @@ class PackedTracks:
         return self._plans[key]
 
 
+def _local_pixels(self, height: int, width: int, frame0: int):
+    """The scatter plan's touched pixels as flat indices into a depth WINDOW that starts at frame `frame0` (frame sharding) — one
+    tensor object per window, so that consumers comparing identities (FusedAdam.fuse_depth_update, FrameShard.enable_early_halo)
+    see a constant set."""
+    plan = self.scatter_plan(height, width)
+    if plan is None:
+        return None
+    if frame0 == 0:
+        return plan[0]
+    key = (int(height), int(width), int(frame0))
+    cache = self.__dict__.setdefault("_local", {})
+    if key not in cache:
+        cache[key] = plan[0] - int(frame0) * int(height) * int(width)
+    return cache[key]
+
+
+PackedTracks.local_pixels = _local_pixels
+
+
 def pack_tracks(tracks, device, own=None) -> PackedTracks:
     """The packed form of a track list, built once: kept on the first segment's coordinate tensor and
     validated against every segment's identity and version."""
@@ -1026,7 +1054,7 @@ class TrackLossFused:
         needs_depth = torch.is_grad_enabled() and depth.requires_grad
         plan = packed.scatter_plan(depth.shape[2], depth.shape[3]) if needs_depth and depth.dim() == 4 else None  # built at the first step
         if plan is not None:
-            note_touched(depth, "tracking", plan[0] if frame0 == 0 else plan[0] - int(frame0) * depth.shape[2] * depth.shape[3])
+            note_touched(depth, "tracking", packed.local_pixels(depth.shape[2], depth.shape[3], int(frame0)))
         sink = depth_sink(depth) if defer else None
         loss, scale, totals = torch_ops().track_loss(depth, k, kinv, ext, packed.xy, packed.vis, packed.seg, packed.blocks, packed.tiles,
                                                      packed.counts, float(weight), int(kind), float(delta), sink, int(frame0),

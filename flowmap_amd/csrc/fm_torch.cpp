@@ -223,6 +223,11 @@ struct DepthSink : torch::CustomClassHolder {
   const torch::autograd::Node* fit_node = nullptr;        // the fit's autograd node (identity only): a loss parks its gradient
                                                           // only when its poses come from this node, i.e. the node WILL run later
   int64_t leading_in_place = 0, leading_dense = 0, planned_steps = 0;  // which path ran (tests)
+  // frame sharding (FrameShard.enable_early_halo): the flow loss leaves its dense dL/ddepth here right after its FORWARD pass (that is when it
+  // exists), so that the boundary frames' exchange overlaps the rest of the step; `unit_flag` (one int32 on the device) is raised by its
+  // backward when the upstream gradient turns out not to be 1 (the early copy is then stale)
+  bool want_early = false;
+  Tensor early_dense, unit_flag;
   bool in_pass_confirmed = false;  // the backward of a flow loss that applied the in-pass Adam update has run (FusedAdam.step checks)
 
   void arm(const Tensor& depth) {
@@ -847,6 +852,10 @@ struct FlowLossFused : public Function<FlowLossFused> {
     ctx->saved_data["delta"] = delta;
     if (sink && park) ctx->saved_data["sink"] = sink;
     ctx->saved_data["g_depth"] = run.g_depth;
+    if (sink && sink->want_early && run.g_depth.defined() && !in_pass_adam) {
+      sink->early_dense = run.g_depth;  // (the same memory backward hands on: the caller copies the frames it sends)
+      if (sink->unit_flag.defined()) ctx->saved_data["adam_flag"] = sink->unit_flag;
+    }
     ctx->saved_data["small"] = run.small;
     ctx->saved_data["fresh"] = need;
     return run.loss.reshape({});
@@ -1316,7 +1325,18 @@ TORCH_LIBRARY(flowmap_amd, m) {
       .def("leading_dense", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->leading_dense; })
       .def("planned_steps", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->planned_steps; })
       .def("is_active", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->active; })
-      .def("in_pass_confirmed", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->in_pass_confirmed; });
+      .def("in_pass_confirmed", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->in_pass_confirmed; })
+      .def("request_early_dense", [](const c10::intrusive_ptr<fmt::DepthSink>& s, const at::Tensor& unit_flag) {
+        s->want_early = true;
+        s->unit_flag = unit_flag;
+      })
+      .def("take_early_dense", [](const c10::intrusive_ptr<fmt::DepthSink>& s) -> std::optional<at::Tensor> {
+        std::optional<at::Tensor> t;
+        if (s->early_dense.defined()) t = s->early_dense;
+        s->early_dense = at::Tensor();
+        s->want_early = false;
+        return t;
+      });
   m.class_<fmt::GradArena>("GradArena")
       .def(torch::init<>())
       .def("reused", [](const c10::intrusive_ptr<fmt::GradArena>& a) { return a->reused; })

@@ -86,6 +86,9 @@ class FrameShard:
         self.defer_halo = False  # True: the gradient hook does not post the exchange (GraphedShardedStep: sync() posts it after the replay)
         self._halo_buffers = {}  # (shape, device) -> persistent receive (and proxy send) buffers
         self._packed = None  # (key, buffer, views): [loss, gradients of the shared parameters] reduced in place every step
+        self._early = None  # enable_early_halo(): pixel lists, buffers and the requests of the early (dense) part in flight
+        self._unit_flags = {}
+        self._syncs = 0
 
     @property
     def active(self) -> bool:
@@ -199,6 +202,128 @@ class FrameShard:
             buf = self._halo_buffers[key] = torch.zeros_like(like)
         return buf
 
+    # -- early halo exchange ---------------------------------------------------------------
+    # The boundary frame's dL/ddepth is (dense flow-loss part) + (a few thousand pixels the Procrustes fit / the tracks add to).  The
+    # dense part — 3.7 MB per boundary and direction at 720p, ~50 us on an xGMI link — exists when the flow loss's FORWARD pass
+    # ends; the sparse part when backward ends.  With enable_early_halo() the dense part is sent right after the flow pass, so
+    # the link works under finalize + backward, and after backward only the values at the locally touched pixels travel
+    # (~20 KB: latency).  Both neighbours add [dense + sparse] of the other: the same sums as the one-shot exchange.
+    def unit_flag(self, device) -> Tensor:
+        flag = self._unit_flags.get(device)
+        if flag is None:
+            flag = self._unit_flags[device] = torch.zeros((1,), dtype=torch.int32, device=device)
+        return flag
+
+    @staticmethod
+    def _touched_key(depth_param: Tensor):
+        registry = depth_param.__dict__.get("_fm_touched") or {}
+        return tuple((name, id(v), v._version) for name, v in sorted(registry.items()))
+
+    def enable_early_halo(self, depth_param: Tensor) -> bool:
+        """COLLECTIVE over neighbours — call it on every rank at the same point of the loop, once the static set of pixels other
+        operators add gradient to is known (the Procrustes fit's plan exists from the second step on; a tracking loss has run or
+        announced its pixels).  Neighbours exchange the pixel lists of their copies of the shared frames.  -> False (nothing
+        changes) when the set is not known yet.  A later change of the set (a loss switched on) raises in the next step: call
+        this again, on every rank, after that step."""
+        if not self.active:
+            return False
+        registry = depth_param.__dict__.get("_fm_touched") or {}
+        ready = torch.tensor([1 if "procrustes" in registry else 0], dtype=torch.int64, device=depth_param.device)
+        if not self.proxy:
+            self.dist.all_reduce(ready, op=self.dist.ReduceOp.MIN, group=self.group)  # all or nobody
+        if int(ready.item()) == 0:
+            return False
+        frames, h, w = depth_param.shape
+        n = h * w
+        keys = torch.unique(torch.cat([v.reshape(-1) for v in registry.values()]))
+        mine = {"prev": keys[keys < n].contiguous() if self.rank > 0 else None,
+                "next": (keys[keys >= (frames - 1) * n] - (frames - 1) * n).contiguous() if self.rank < self.world - 1 else None}
+        theirs = {"prev": None, "next": None}
+        if self.proxy:
+            theirs = dict(mine)
+        else:
+            dist = self.dist
+            for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)):  # sizes, then lists (set-up only: blocking)
+                if mine[side] is None:
+                    continue
+                size_out = torch.tensor([mine[side].numel()], dtype=torch.int64, device=depth_param.device)
+                size_in = torch.zeros_like(size_out)
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, size_out, peer, self.group), dist.P2POp(dist.irecv, size_in, peer, self.group)]):
+                    req.wait()
+                theirs[side] = torch.empty((int(size_in.item()),), dtype=torch.int64, device=depth_param.device)
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine[side], peer, self.group), dist.P2POp(dist.irecv, theirs[side], peer, self.group)]):
+                    req.wait()
+        dev, dt = depth_param.device, depth_param.dtype
+        frame = lambda: torch.zeros((h, w), dtype=dt, device=dev)  # noqa: E731
+        self._early = {
+            "key": self._touched_key(depth_param), "param": depth_param, "mine": mine, "theirs": theirs, "inflight": None,
+            "send": {s_: frame() for s_ in mine if mine[s_] is not None}, "recv": {s_: frame() for s_ in mine if mine[s_] is not None},
+            "delta_out": {s_: torch.zeros((mine[s_].numel(),), dtype=dt, device=dev) for s_ in mine if mine[s_] is not None},
+            "delta_in": {s_: torch.zeros((theirs[s_].numel(),), dtype=dt, device=dev) for s_ in mine if mine[s_] is not None},
+        }
+        depth_param.__dict__["_fm_early_halo"] = self
+        return True
+
+    def disable_early_halo(self) -> None:
+        if self._early is not None:
+            self._early["param"].__dict__.pop("_fm_early_halo", None)
+            self._early = None
+
+    def _exchange(self, pairs):
+        """[(send buffer, receive buffer, peer)] -> requests (asynchronous); the proxy has no peer: nothing travels."""
+        if self.proxy or not pairs:
+            return []
+        dist = self.dist
+        ops = []
+        for out, into, peer in pairs:
+            ops.append(dist.P2POp(dist.isend, out, peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, into, peer, self.group))
+        return dist.batch_isend_irecv(ops)
+
+    def start_early_halo(self, dense_grad: Tensor, depth_param: Tensor) -> None:
+        """Called by the fused flow loss at the end of its forward pass with its dense dL/ddepth (1, F, H, W): copy the boundary
+        frames (backward will add the sparse parts to the very same memory) and send them."""
+        e = self._early
+        if e is None or e["param"] is not depth_param:
+            return
+        if self._touched_key(depth_param) != e["key"]:
+            raise RuntimeError("flowmap_amd.FrameShard: the set of depth pixels other operators touch has changed since enable_early_halo() "
+                               "(a loss was switched on?): call enable_early_halo() again, on every rank")
+        if e["inflight"] is not None:  # a forward that never reached sync(): complete it first (every rank does)
+            for req in e["inflight"]:
+                req.wait()
+        pairs = []
+        for side, frame, peer in (("prev", 0, self.rank - 1), ("next", -1, self.rank + 1)):
+            if side in e["send"]:
+                e["send"][side].copy_(dense_grad[0, frame])
+                pairs.append((e["send"][side], e["recv"][side], peer))
+        e["inflight"] = self._exchange(pairs)
+
+    def _start_sparse_halo(self, depth_grad: Tensor) -> None:
+        """After backward: what the boundary frames gained since the early copy — non-zero only at the locally touched pixels."""
+        e = self._early
+        pairs = []
+        for side, frame, peer in (("prev", 0, self.rank - 1), ("next", -1, self.rank + 1)):
+            if side in e["send"]:
+                px = e["mine"][side]
+                torch.sub(depth_grad[frame].reshape(-1)[px], e["send"][side].reshape(-1)[px], out=e["delta_out"][side])
+                pairs.append((e["delta_out"][side], e["delta_in"][side], peer))
+        self._halo = (self._exchange(pairs), None, None, depth_grad, depth_grad._version, True)
+
+    def _finish_sparse_halo(self, depth_grad: Tensor) -> None:
+        e = self._early
+        for req in e["inflight"] or []:
+            req.wait()
+        e["inflight"] = None
+        for side, frame in (("prev", 0), ("next", -1)):
+            if side in e["send"]:
+                depth_grad[frame].add_(e["recv"][side])
+                depth_grad[frame].reshape(-1).index_add_(0, e["theirs"][side], e["delta_in"][side])
+        self._syncs += 1
+        if self._syncs % 64 == 0 and int(self.unit_flag(depth_grad.device).item()) != 0:
+            raise RuntimeError("flowmap_amd.FrameShard: with enable_early_halo() the flow loss must reach backward() unscaled (the boundary frames' "
+                               "gradient was sent before backward ran); disable_early_halo() for a scaled loss")
+
     def start_halo_exchange(self, depth_grad: Tensor) -> None:
         """depth_grad (F_local, H, W): the LAST local frame is rank+1's FIRST local frame; post the sends and
         receives of the two boundary frames (asynchronous)."""
@@ -208,6 +333,9 @@ class FrameShard:
             if self._halo[3] is depth_grad and self._halo[4] == depth_grad._version:
                 return  # already posted for this very gradient (the hook ran, sync() asks again)
             self.finish_halo_exchange()  # a backward that never reached sync(): complete it (every rank does) before the next one
+        if self._early is not None and self._early["inflight"] is not None:  # the dense part left after the flow pass: only the sparse rest now
+            self._start_sparse_halo(depth_grad)
+            return
         dist = self.dist
         ops, recv_prev, recv_next = [], None, None
         if self.rank > 0:
@@ -224,17 +352,20 @@ class FrameShard:
             else:
                 ops.append(dist.P2POp(dist.isend, depth_grad[-1].contiguous(), self.rank + 1, self.group))
                 ops.append(dist.P2POp(dist.irecv, recv_next, self.rank + 1, self.group))
-        self._halo = (dist.batch_isend_irecv(ops) if ops else [], recv_prev, recv_next, depth_grad, depth_grad._version)
+        self._halo = (dist.batch_isend_irecv(ops) if ops else [], recv_prev, recv_next, depth_grad, depth_grad._version, False)
 
     def finish_halo_exchange(self) -> None:
         """Wait for the exchange and add the neighbours' parts: both copies of a shared frame end up with
         the sum of the two partial gradients.  (Proxy: the receive buffers hold zeros — same launches, unchanged values.)"""
         if self._halo is None:
             return
-        requests, recv_prev, recv_next, depth_grad, _ = self._halo
+        requests, recv_prev, recv_next, depth_grad, _, sparse = self._halo
         self._halo = None
         for req in requests:
             req.wait()
+        if sparse:
+            self._finish_sparse_halo(depth_grad)
+            return
         if recv_prev is not None:
             depth_grad[0].add_(recv_prev)
         if recv_next is not None:

@@ -406,3 +406,89 @@ def test_in_pass_adam_on_frame_shards_follows_the_unsharded_optimiser(tmp_path):
         assert_close(got["weights"], ref["weights"][a:b], 2e-6, abs_=2e-6, what=f"weight logits of rank {rank}")
         assert abs(float(got["focal"]) - float(ref["focal"])) <= 2e-6
     assert float((ref["depth"] - torch.load(f"{single}.0")["depth"]).abs().max()) == 0.0
+
+
+def _early_worker(rank, world, port, f, h, w, points, with_tracks, out_path):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import flowmap_amd
+    from flowmap_amd import Batch, Flows, _lib
+    from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
+    from flowmap_amd.loss.mapping import MappingHuberCfg
+    from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
+    from flowmap_amd.sharding import FrameShard
+    from helpers import build_host_sim, to_tracks
+    from oracle import flowmap_oracle as orc
+
+    _lib.set_library_for_testing(build_host_sim())
+    flowmap_amd.set_lazy_surfaces(True)
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
+    a, b = shard_pairs(f - 1, world)[rank]
+    lo, hi = shard_frames((a, b))
+    nf = hi - lo + 1
+    model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", 0.85),
+                           ExtrinsicsProcrustesCfg("procrustes", points, False)), num_frames=nf, image_shape=(h, w))
+    model.backbone.depth.data = depth[lo : hi + 1].clone()
+    model.backbone.weights.data = wlogit[a:b].clone()
+    local = Flows(flows.forward[:, a:b].contiguous(), flows.backward[:, a:b].contiguous(),
+                  flows.forward_mask[:, a:b].contiguous(), flows.backward_mask[:, a:b].contiguous())
+    batch = Batch(torch.zeros((1, nf, 3, h, w)))
+    loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
+    tracks = to_tracks(orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5), "cpu") if with_tracks else None
+    track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
+    shard = FrameShard(rank, world, dist)
+    shard.prepare_flow_loss(loss_fn, local)
+    shard.prepare_model(model)
+    assert shard.enable_early_halo(model.backbone.depth) is False  # nothing is planned yet: the one-shot exchange stays
+    history, modes = [], []
+    for step in range(5):
+        model.zero_grad(set_to_none=True)
+        out = model(batch, local, 0)
+        loss = loss_fn(batch, local, None, out, 0)
+        tracked = None
+        if with_tracks:
+            tracked = shard.tracking_loss(track_fn, tracks, out, f - 1)
+            (loss + tracked).backward()
+        else:
+            loss.backward()
+        modes.append(shard._early is not None and shard._halo is not None and shard._halo[5])  # the sparse rest is what is in flight
+        total = shard.sync(loss, [model.intrinsics.focal_length], model.backbone.depth, already_global=tracked)
+        history.append((total.clone(), model.backbone.depth.grad.clone(), model.intrinsics.focal_length.grad.clone()))
+        if step == 1:
+            assert shard.enable_early_halo(model.backbone.depth) is True  # (collective: every rank calls it here)
+    torch.save({"history": history, "modes": modes, "frames": (lo, hi)}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("with_tracks", [False, True], ids=["flow", "flow+tracking"])
+def test_early_halo_exchange_gives_the_same_gradients(tmp_path, with_tracks):
+    """FrameShard.enable_early_halo(): the boundary frames' dense gradient is sent when the flow loss's forward pass ends, the sparse
+    rest (Procrustes / track pixels) after backward — loss and gradients of every step as with the one-shot exchange and as unsharded."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import assert_close
+    from helpers import run_oracle
+    from oracle import flowmap_oracle as orc
+
+    f, h, w, points, world = 8, 12, 16, 40, 3
+    out = str(tmp_path / "early")
+    mp.spawn(_early_worker, args=(world, _free_port(), f, h, w, points, with_tracks, out), nprocs=world, join=True)
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
+    otracks = orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5) if with_tracks else None
+    ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float64)
+    for rank in range(world):
+        got = torch.load(f"{out}.{rank}")
+        assert got["modes"] == [False, False, True, True, True], got["modes"]
+        lo, hi = got["frames"]
+        for step, (total, g_depth, g_focal) in enumerate(got["history"]):
+            assert_close(total, ref["total"], 1e-5, what=f"global loss, step {step}")
+            assert_close(g_depth, ref["g_depth"][lo : hi + 1], 2e-4, what=f"g_depth of rank {rank} (halo summed), step {step}")
+            _focal_close(g_focal, ref)
+        for early_step in (2, 3, 4):  # against the one-shot exchange of step 1: the same sums in another order
+            assert_close(got["history"][early_step][1], got["history"][1][1], 1e-5, abs_=1e-9, what=f"early vs one-shot exchange, rank {rank}")
