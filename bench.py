@@ -103,7 +103,7 @@ def parse():
     ap.add_argument("--halo", choices=["oneshot", "early"], default="oneshot",
                     help="strong scaling: how the boundary frames' dL/ddepth reaches the neighbour — `oneshot`: one 3.7 MB (720p) exchange per boundary and "
                          "direction after backward; `early` (FrameShard.enable_early_halo): the dense part right after the flow pass, under the rest of the "
-                         "step, and a sparse correction (~20 KB) after backward.  Not with --graph compute (a collective cannot sit inside a replay)")
+                         "step, and a sparse correction (~20 KB) after backward (with --graph compute: between the forward and the backward replay)")
     ap.add_argument("--share", type=int, default=0,
                     help="K > 0: run ONE rank's share of a K-GPU strong-scaling run on this GPU (its pairs + halo frames, collectives on a "
                          "one-rank RCCL communicator): the per-rank step time of a K-GPU run without the wire time")
@@ -339,8 +339,6 @@ def main():
                                    and args.optimizer in ("none", "fused")) else "off"
     if args.graph == "off":
         args.graph = None
-    if args.halo == "early" and args.graph == "compute":
-        raise SystemExit("--halo early needs --graph off|whole: the early exchange starts between the flow pass and backward")
     if args.graph == "compute" and (not strong or cfg["tracking"] or args.intrinsics != "regressed"):
         raise SystemExit("--graph compute: a frame-sharded run of the flow loss with regressed intrinsics (the tracking loss and the softmin sweep have collectives inside forward / backward)")
     flowmap_amd.set_lazy_surfaces(True)
@@ -462,7 +460,11 @@ def main():
             eager_flow_ms = _ops.flow_kernel_times()
             _ops.flow_kernel_timing(False)
         if args.graph == "compute":
-            sharded = flowmap_amd.GraphedShardedStep(compute, shard, shared, model.backbone.depth, warmup=3)
+            def forward_only():  # zero_grad + model + flow loss of this rank's frames (backward is captured as a second graph)
+                model.zero_grad(set_to_none=True)
+                return loss_fn(batch, flows, None, model(batch, flows, 0), 0)
+
+            sharded = flowmap_amd.GraphedShardedStep(forward_only, shard, shared, model.backbone.depth, warmup=3)
 
             def step():  # noqa: F811
                 loss = sharded()

@@ -211,17 +211,89 @@ __device__ __forceinline__ Corr corr_assemble(const CorrSrc& s, const Mat3& kinv
   return c;
 }
 
-// What the forward fit leaves behind per correspondence for the one-launch backward (fm_procrustes_bwd_planned): 32 bytes,
-// q (3), p (3), w, the pixel index — written and later read as two 16-byte vectors, consecutive correspondences by
-// consecutive lanes.  The backward then has no gather chain at all (the forward has just paid for it).
+// A correspondence read through its static tap record (fm_procrustes_fit_chain's tap_records): the scattered loads, then the arithmetic of
+// corr_load in the same order.
 typedef float corr_v4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void corr_record(float* corr_out, size_t slot, const Corr& c) {
+struct TapLoad {
+  int idx, o0, o1, o2, o3;
+  float w, z_p, z0, z1, z2, z3, w0, w1, w2, w3;
+};
+__device__ __forceinline__ TapLoad tap_load(const CorrSrc& s, int idx, corr_v4 ro, corr_v4 rw) {
+  TapLoad t;
+  t.idx = idx;
+  t.o0 = __float_as_int(ro.x), t.o1 = __float_as_int(ro.y), t.o2 = __float_as_int(ro.z), t.o3 = __float_as_int(ro.w);
+  t.w0 = rw.x, t.w1 = rw.y, t.w2 = rw.z, t.w3 = rw.w;
+  t.w = s.weights[idx];
+  t.z_p = s.depth_l[idx];
+  t.z0 = t.o0 >= 0 ? s.depth_e[t.o0] : 0.f;
+  t.z1 = t.o1 >= 0 ? s.depth_e[t.o1] : 0.f;
+  t.z2 = t.o2 >= 0 ? s.depth_e[t.o2] : 0.f;
+  t.z3 = t.o3 >= 0 ? s.depth_e[t.o3] : 0.f;
+  return t;
+}
+__device__ __forceinline__ void tap_add(const CorrSrc& s, const Mat3& kinv_e, int off, float z, float w, float& q0, float& q1, float& q2) {
+  if (off < 0) return;
+  const int tr = off / s.width, tc = off - tr * s.width;
+  float ray[3];
+  ray_dir(kinv_e, pixel_center(tc, s.width), pixel_center(tr, s.height), ray);
+  q0 += (ray[0] * z) * w;
+  q1 += (ray[1] * z) * w;
+  q2 += (ray[2] * z) * w;
+}
+// -> q, p, w of the correspondence (scalars on purpose: a Corr assembled field by field went through scratch memory)
+struct CorrCore {
+  float q0, q1, q2, p0, p1, p2, w;
+  int idx;
+};
+__device__ __forceinline__ CorrCore tap_finish(const CorrSrc& s, const Mat3& kinv_e, const Mat3& kinv_l, const TapLoad& t) {
+  CorrCore c;
+  c.idx = t.idx;
+  c.w = t.w;
+  if (s.weight_sens != 0.f) c.w = fm_sigmoid<false>(s.weight_sens * c.w);
+  const PixelRef px = pixel_ref(t.idx, s.height, s.width);
+  float ray_p[3];
+  ray_dir(kinv_l, px.u, px.v, ray_p);
+  c.p0 = ray_p[0] * t.z_p;
+  c.p1 = ray_p[1] * t.z_p;
+  c.p2 = ray_p[2] * t.z_p;
+  c.q0 = c.q1 = c.q2 = 0.f;
+  tap_add(s, kinv_e, t.o0, t.z0, t.w0, c.q0, c.q1, c.q2);
+  tap_add(s, kinv_e, t.o1, t.z1, t.w1, c.q0, c.q1, c.q2);
+  tap_add(s, kinv_e, t.o2, t.z2, t.w2, c.q0, c.q1, c.q2);
+  tap_add(s, kinv_e, t.o3, t.z3, t.w3, c.q0, c.q1, c.q2);
+  return c;
+}
+// moments_add (fm_math.h) on the scalars
+__device__ __forceinline__ void moments_add_core(const CorrCore& c, const float s[3], float (&acc)[kMomentCount]) {
+  const float p0 = c.p0 - s[0], p1 = c.p1 - s[1], p2 = c.p2 - s[2];
+  acc[0] += c.w;
+  acc[1] = fmaf(c.w, p0, acc[1]);
+  acc[2] = fmaf(c.w, p1, acc[2]);
+  acc[3] = fmaf(c.w, p2, acc[3]);
+  const float qv[3] = {c.q0, c.q1, c.q2};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float wq = c.w * (qv[a] - s[a]);
+    acc[4 + a] += wq;
+    acc[7 + a * 3 + 0] = fmaf(wq, p0, acc[7 + a * 3 + 0]);
+    acc[7 + a * 3 + 1] = fmaf(wq, p1, acc[7 + a * 3 + 1]);
+    acc[7 + a * 3 + 2] = fmaf(wq, p2, acc[7 + a * 3 + 2]);
+  }
+}
+__device__ __forceinline__ void corr_record_core(float* corr_out, size_t slot, const CorrCore& c) {
   if (corr_out == nullptr) return;
   corr_v4* o = reinterpret_cast<corr_v4*>(corr_out) + slot * 2;
-  corr_v4 lo4 = {c.q[0], c.q[1], c.q[2], c.p[0]}, hi4 = {c.p[1], c.p[2], c.w, __int_as_float(c.idx)};
+  corr_v4 lo4, hi4;
+  lo4.x = c.q0, lo4.y = c.q1, lo4.z = c.q2, lo4.w = c.p0;
+  hi4.x = c.p1, hi4.y = c.p2, hi4.z = c.w, hi4.w = __int_as_float(c.idx);
   o[0] = lo4;
   o[1] = hi4;
 }
+
+// (corr_record_core above is what the forward fit leaves behind per correspondence for the one-launch backward,
+// fm_procrustes_bwd_planned: 32 bytes — q (3), p (3), w, the pixel index — written and later read as two 16-byte vectors, consecutive
+// correspondences by consecutive lanes.  The backward then has no gather chain at all: the forward has just paid for it.  Records
+// are written on the static-tap path only: a planned backward implies constant flows and indices, hence tap records.)
 
 // What fm_procrustes_fit_chain adds to the moments kernel: the LAST block of a pair (a counter per pair) turns the
 // pair's sums into its pose, clears the sums and the counter for the next step (the workspace is persistent and
@@ -332,7 +404,16 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
     // Constant flows and indices (the overfit loop, from its second step on): where a correspondence's four taps lie and what they
     // weigh never changes, so it comes from a static record — one coalesced read — and every scattered access of the
     // correspondence (later depth, weight, four tap depths) is issued in ONE dependent round instead of two (index -> flow -> taps)
+    // Order of issue: [record, index of this thread's first correspondence, index of the middle sample] -> [its weight, later depth and
+    // four tap depths, the middle sample's depth]: two dependent rounds in all (the reference point's own chain rides along)
+    const corr_v4* recs = reinterpret_cast<const corr_v4*>(fc.tap_records) + pair * (size_t)p.points * 2;
+    const long first = threadIdx.x;
+    const bool on = first < p.points;
+    const long jf = on ? first : 0;
+    const corr_v4 ro0 = recs[jf * 2], rw0 = recs[jf * 2 + 1];
+    const int idx0 = (int)p.indices[jf];
     const int idx_mid = (int)p.indices[p.points / 2];
+    TapLoad t0 = tap_load(src, idx0, ro0, rw0);
     const float z_mid = src.depth_l[idx_mid];
     {  // later_point (fm_math.h) of the middle sample
       const int row = idx_mid / src.width, col = idx_mid - row * src.width;
@@ -342,38 +423,16 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
       for (int a3 = 0; a3 < 3; ++a3)
         if (!(fabsf(shift[a3]) <= 3.0e38f)) shift[a3] = 0.f;
     }
-    const corr_v4* recs = reinterpret_cast<const corr_v4*>(fc.tap_records) + pair * (size_t)p.points * 2;
-    for (long j = threadIdx.x; j < p.points; j += blockDim.x) {
-      const corr_v4 ro = recs[j * 2], rw = recs[j * 2 + 1];
-      const int idx = (int)p.indices[j];
-      const int off[4] = {__float_as_int(ro.x), __float_as_int(ro.y), __float_as_int(ro.z), __float_as_int(ro.w)};
-      const float tw[4] = {rw.x, rw.y, rw.z, rw.w};
-      Corr c;
-      c.idx = idx;
-      c.w = src.weights[idx];
-      c.z_p = src.depth_l[idx];
-      float zt[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) zt[k] = off[k] >= 0 ? src.depth_e[off[k]] : 0.f;
-      if (src.weight_sens != 0.f) c.w = fm_sigmoid<false>(src.weight_sens * c.w);
-      const PixelRef px = pixel_ref(idx, src.height, src.width);
-      ray_dir(kinv_l, px.u, px.v, c.ray_p);
-      c.p[0] = c.ray_p[0] * c.z_p;
-      c.p[1] = c.ray_p[1] * c.z_p;
-      c.p[2] = c.ray_p[2] * c.z_p;
-      c.q[0] = c.q[1] = c.q[2] = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (off[k] < 0) continue;
-        const int tr = off[k] / src.width, tc = off[k] - tr * src.width;
-        float ray[3];
-        ray_dir(kinv_e, pixel_center(tc, src.width), pixel_center(tr, src.height), ray);
-        c.q[0] += (ray[0] * zt[k]) * tw[k];
-        c.q[1] += (ray[1] * zt[k]) * tw[k];
-        c.q[2] += (ray[2] * zt[k]) * tw[k];
-      }
-      moments_add(c, shift, acc);
-      corr_record(fc.corr_out, pair * (size_t)p.points + (size_t)j, c);
+    if (on) {
+      const CorrCore c = tap_finish(src, kinv_e, kinv_l, t0);
+      moments_add_core(c, shift, acc);
+      corr_record_core(fc.corr_out, pair * (size_t)p.points + (size_t)first, c);
+    }
+    for (long j = first + blockDim.x; j < p.points; j += blockDim.x) {
+      const TapLoad t = tap_load(src, (int)p.indices[j], recs[j * 2], recs[j * 2 + 1]);
+      const CorrCore c = tap_finish(src, kinv_e, kinv_l, t);
+      moments_add_core(c, shift, acc);
+      corr_record_core(fc.corr_out, pair * (size_t)p.points + (size_t)j, c);
     }
   } else if (SRC == SRC_DEPTH && p.indices != nullptr) {
     // The reference point's chain (index -> depth) and the thread's first correspondence's chain (index -> flow, weight, depth ->
@@ -393,23 +452,12 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
       for (int a3 = 0; a3 < 3; ++a3)
         if (!(fabsf(shift[a3]) <= 3.0e38f)) shift[a3] = 0.f;
     }
-    if (on) {
-      const Corr c = corr_assemble(src, kinv_e, kinv_l, a, bb);
-      moments_add(c, shift, acc);
-      corr_record(fc.corr_out, pair * (size_t)p.points + (size_t)first, c);
-    }
-    for (long j = first + blockDim.x; j < p.points; j += blockDim.x) {
-      const Corr c = corr_load(src, kinv_e, kinv_l, (int)p.indices[j]);
-      moments_add(c, shift, acc);
-      corr_record(fc.corr_out, pair * (size_t)p.points + (size_t)j, c);
-    }
+    if (on) moments_add(corr_assemble(src, kinv_e, kinv_l, a, bb), shift, acc);
+    for (long j = first + blockDim.x; j < p.points; j += blockDim.x) moments_add(corr_load(src, kinv_e, kinv_l, (int)p.indices[j]), shift, acc);
   } else {
     pair_shift<SRC>(p, src, kinv_l, shift);
-    for (long j = threadIdx.x; j < p.points; j += blockDim.x) {
-      const Corr c = corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j);
-      moments_add(c, shift, acc);
-      corr_record(fc.corr_out, pair * (size_t)p.points + (size_t)j, c);
-    }
+    for (long j = threadIdx.x; j < p.points; j += blockDim.x)
+      moments_add(corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j), shift, acc);
   }
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
 #pragma unroll
@@ -1827,7 +1875,7 @@ static int fit_chain_launch(const float* depth, const float* kinv, const float* 
   FM_CHECK_ARG(!tap_records || (depth && indices && points <= 4096 && (reinterpret_cast<uintptr_t>(tap_records) & 15) == 0));
   FM_CHECK_ARG(bwd_flow && weights && work && t_bwd && aux && points >= 1 && batch >= 1 && frames >= 2);
   FM_CHECK_ARG((long)height * width < (1L << 30) && (long)batch * (frames - 1) <= 65535);
-  FM_CHECK_ARG(!corr_out || (points <= 4096 && (reinterpret_cast<uintptr_t>(corr_out) & 15) == 0));
+  FM_CHECK_ARG(!corr_out || (tap_records && points <= 4096 && (reinterpret_cast<uintptr_t>(corr_out) & 15) == 0));
   const int pairs = batch * (frames - 1);
   ProcParams p{};
   p.depth = depth; p.kinv = kinv; p.surfaces = surfaces; p.bwd_flow = bwd_flow; p.weights = weights; p.indices = indices;

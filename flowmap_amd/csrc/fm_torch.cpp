@@ -497,9 +497,9 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
         // the planned backward (one launch, fm_procrustes_bwd_planned) reads the correspondences back instead of re-gathering them
         const bool wants_records = from_depth && grad_enabled && plan_frame_first.has_value() && plan_frame_first->defined() && points <= FM_FIT_BWD_MAX_POINTS &&
                                    use_one_launch_backward() && (depth.requires_grad() || weights_in.requires_grad() || (k_o.has_value() && k_o->requires_grad()));
-        if (wants_records) corr = at::empty({pairs * points, 8}, weights.options());
         const bool taps_ok = from_depth && plan_tap_records.has_value() && plan_tap_records->defined() && plan_tap_records->scalar_type() == at::kFloat &&
                              plan_tap_records->is_contiguous() && plan_tap_records->numel() == pairs * points * 8 && points <= 4096;
+        if (wants_records && taps_ok) corr = at::empty({pairs * points, 8}, weights.options());
         if (any_view)
           FM_CALL(fm_procrustes_fit_chain_views, from_depth ? ptr(depth) : nullptr, ptr(kinv), ptr(surfaces), ptr(bwd_flow), ptr(weights),
                   (float)weight_sens, ptr<int64_t>(indices), (long)points, (int)b, (int)f, (int)h, (int)w, ptr<double>(work), ptr(t_bwd), ptr(t_fwd),

@@ -69,28 +69,57 @@ class GraphedStep:
 
 
 class GraphedShardedStep:
-    """A frame-sharded step with its COMPUTE replayed as one hipGraph and its collectives issued eagerly after the replay.
+    """A frame-sharded step with its COMPUTE replayed as hipGraphs and its collectives issued eagerly around them.
 
-    ``compute() -> local loss`` runs zero_grad + forward + backward of this rank's shard and NO collective (the halo
-    exchange's gradient hook is held back while this object exists: ``FrameShard.defer_halo``); ``FrameShard.sync`` then
-    reduces [loss, shared gradients] and exchanges the halo frames as usual.  Per step the host enqueues one graph launch and
-    the three collectives, while the GPU is still busy with the graph: what a rank of an 8-GPU strong-scaling run needs
-    (its ~15 kernels take ~0.2 ms, eagerly enqueueing them ~0.45 ms), without RCCL inside a captured graph — the safe
-    default for multi-rank runs; ``GraphedStep`` over the whole step (collectives captured too) saves the remaining host time.
+    ``forward() -> local loss`` runs zero_grad + the model + the flow loss of this rank's shard, ``loss.backward()`` the rest; neither
+    contains a collective (the halo exchange's gradient hook is held back while this object exists: ``FrameShard.defer_halo``).
+    Forward and backward are captured as TWO graphs sharing one memory pool (the pattern of torch.cuda.make_graphed_callables), so
+    that with ``FrameShard.enable_early_halo`` the boundary frames' dense gradient — which exists when the forward graph ends —
+    is sent between the two replays and travels under the backward graph; ``FrameShard.sync`` then reduces [loss, shared
+    gradients] and finishes the halo exchange as usual.  Per step the host enqueues two graph launches and the collectives while
+    the GPU is still busy: what a rank of an 8-GPU strong-scaling run needs (its ~15 kernels take ~0.2 ms, eagerly enqueueing them
+    ~0.45 ms), without RCCL inside a captured graph — the safe default for multi-rank runs; ``GraphedStep`` over the whole step
+    (collectives captured too) saves the remaining host time.
 
-    The gradient tensors the captured backward writes live in the graph's memory pool and are the same every replay;
-    ``sync`` re-points the shared parameters' ``.grad`` at its reduction buffer, so they are restored before every sync."""
+    The gradient tensors the captured backward writes live in the graphs' memory pool and are the same every replay; ``sync``
+    re-points the shared parameters' ``.grad`` at its reduction buffer, so they are restored before every sync."""
 
-    def __init__(self, compute: Callable[[], object], shard, shared_params, depth_param, warmup: int = 3, device=None) -> None:
+    def __init__(self, forward: Callable[[], object], shard, shared_params, depth_param, warmup: int = 3, device=None) -> None:
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.shard, self.shared, self.depth_param = shard, list(shared_params), depth_param
         shard.defer_halo = True
-        self.inner = GraphedStep(compute, warmup=warmup, device=device)
-        self.loss = self.inner.output
+        if shard._early is not None:
+            shard._early["stash_only"] = True
+        self._previous = _ops.graph_capturable
+        _ops.graph_capturable = True
+        _ops.flow_kernel_timing(False)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(max(2, warmup)):
+                forward().backward()
+                shard.take_stashed_early()  # (warm-up: nothing is sent)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        import time
+
+        time.sleep(0.2)  # let the process group's watchdog retire earlier collectives before the capture starts
+        self.forward_graph, self.backward_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.forward_graph, capture_error_mode="thread_local"):
+            self.loss = forward()
+        self.early_dense = shard.take_stashed_early()  # the flow loss's dense dL/ddepth (graph memory: the same tensor every replay), or None
+        with torch.cuda.graph(self.backward_graph, pool=self.forward_graph.pool(), capture_error_mode="thread_local"):
+            self.loss.backward()
         self.grads = [p.grad for p in self.shared]
         self.depth_grad = None if depth_param is None else depth_param.grad
+        if shard._early is not None:
+            shard._early["stash_only"] = False
 
     def __call__(self, already_global=None):
-        self.inner.graph.replay()
+        self.forward_graph.replay()
+        if self.early_dense is not None:
+            self.shard.start_early_halo(self.early_dense, self.depth_param)
+        self.backward_graph.replay()
         for p, g in zip(self.shared, self.grads):
             p.grad = g
         if self.depth_param is not None:
@@ -99,4 +128,4 @@ class GraphedShardedStep:
 
     def close(self) -> None:
         self.shard.defer_halo = False
-        self.inner.close()
+        _ops.graph_capturable = self._previous

@@ -264,6 +264,13 @@ class FrameShard:
         depth_param.__dict__["_fm_early_halo"] = self
         return True
 
+    def take_stashed_early(self):
+        """GraphedShardedStep: the dense gradient the flow loss produced inside a capture / warm-up step (None without early halo)."""
+        if self._early is None:
+            return None
+        dense = self._early.pop("stashed", None)
+        return dense
+
     def disable_early_halo(self) -> None:
         if self._early is not None:
             self._early["param"].__dict__.pop("_fm_early_halo", None)
@@ -285,6 +292,9 @@ class FrameShard:
         frames (backward will add the sparse parts to the very same memory) and send them."""
         e = self._early
         if e is None or e["param"] is not depth_param:
+            return
+        if e.get("stash_only", False):  # GraphedShardedStep's warm-up and captures: nothing is sent; the step sends it between its two replays
+            e["stashed"] = dense_grad
             return
         if self._touched_key(depth_param) != e["key"]:
             raise RuntimeError("flowmap_amd.FrameShard: the set of depth pixels other operators touch has changed since enable_early_halo() "

@@ -145,7 +145,7 @@ int fm_procrustes_fit(const float* depth, const float* kinv, const float* surfac
  * pair solving.  ext may be NULL (poses only).
  * work: persistent workspace of B·(F-1)·FM_STAT_STRIDE doubles followed by B·(F-1)+1 ints, ZERO on entry and left
  * zero (self-cleaning: zero it once, when it is allocated; one launch at a time per workspace).
- * corr_out (optional, (B·(F-1)·P, 8) floats, 16-byte aligned, P <= 4096): the record of every correspondence —
+ * corr_out (optional, needs tap_records; (B·(F-1)·P, 8) floats, 16-byte aligned, P <= 4096): the record of every correspondence —
  * q (3), p (3), w, the bits of its pixel index — for fm_procrustes_bwd_planned, which then re-gathers nothing.
  * tap_records (optional, (B·(F-1)·P, 8), 16-byte aligned; depth source, indices given, P <= 4096): with constant flows and indices the
  * taps of every correspondence are static — per correspondence the four taps' pixel offsets row·W + col in the earlier frame

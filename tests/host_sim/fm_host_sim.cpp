@@ -658,8 +658,8 @@ int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* 
   if (fm_procrustes_fit(depth, kinv, surfaces, bwd_flow, weights, sens, indices, points, batch, 1, frames, height, width, stats.data(), t_bwd,
                         t_fwd, aux, stream) != 0)
     return 2;
-  if (corr_out) {  // the record of every correspondence, as the device kernel leaves it (corr_record)
-    if (points > 4096) return 1;
+  if (corr_out) {  // the record of every correspondence, as the device kernel leaves it (corr_record_core)
+    if (points > 4096 || !tap_records) return 1;
     for (int b = 0; b < batch; ++b)
       for (int i = 0; i < frames - 1; ++i) {
         const size_t pair = (size_t)b * (frames - 1) + i;

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Regenerate every artefact kept under profiles/ for one round (run through gpurun; results land in
 # gpurun_out/profiles_new/, copy them into profiles/ afterwards).   ROUND=r02 bash tools/gpu_refresh_profiles.sh [part...]
-# parts: bench variants stats pmc ate misc      (default: all)
+# parts: bench variants stats pmc ate misc proxy     (default: all)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 REPO=$PWD
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/profiles_new
 mkdir -p "$OUT"
-parts=${*:-bench variants stats pmc ate misc}
+parts=${*:-bench variants stats pmc ate misc proxy}
 stats() {  # stats <name> <bench args...>: rocprofv3 kernel trace of a short bench run -> per-kernel table
   local name=$1; shift
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_$name" -o stats -- python "$REPO/bench.py" --steps 20 --warmup 3 --cpu-frames 0 "$@" > /dev/null 2> "$OUT/prof_$name.err")
@@ -19,7 +19,7 @@ stats() {  # stats <name> <bench args...>: rocprofv3 kernel trace of a short ben
 for part in $parts; do
 case $part in
 bench)
-  python bench.py > "$OUT/${R}_bench_c1.json" 2> "$OUT/bench_c1.err"
+  python bench.py > "$OUT/${R}_bench_c1.json" 2> "$OUT/bench_c1.err"   # (with the CPU baseline on the whole workload: ~70 s of host time)
   python bench.py --config c2 > "$OUT/${R}_bench_c2_tracking.json" 2> "$OUT/bench_c2.err" ;;
 variants)
   { for a in "--config c3" "--config c4" "--inputs iid" "--intrinsics softmin" "--optimizer fused" "--optimizer in_pass" "--optimizer torch" \
@@ -29,14 +29,17 @@ variants)
              "--height 180 --width 240 --intrinsics softmin" "--height 180 --width 240 --tracking --optimizer fused" \
              "--height 180 --width 240 --tracking --optimizer fused --graph"; do
       python bench.py --cpu-frames 0 $a 2>> "$OUT/variants.err"; done; } > "$OUT/${R}_bench_variants.jsonl"
-  FLOWMAP_BENCH_FORCE_DIST=1 python bench.py --cpu-frames 0 --config c2 > "$OUT/${R}_bench_c2_rccl_single_rank_selftest.json" 2>> "$OUT/variants.err" ;;
+  ;;
+proxy)
+  bash tools/scaling_proxy.sh "$OUT/${R}_strong_scaling_proxy.jsonl" > "$OUT/${R}_strong_scaling_proxy_table.txt" 2>&1; cat "$OUT/${R}_strong_scaling_proxy_table.txt" ;;
 stats)
   stats c1_bench
   stats c2_tracking --config c2
   stats dense_procrustes --points 0
   stats c1_adam_in_pass --optimizer in_pass
   stats default_resolution_180x240_tracking_adam --height 180 --width 240 --tracking --optimizer fused
-  stats softmin_sweep --intrinsics softmin ;;
+  stats softmin_sweep --intrinsics softmin
+  stats share8 --share 8 ;;
 pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
     # (i.i.d. inputs and a kernel filter: with the scene synthesis' 126 000 torch launches in the counter pass rocprofv3 crashed)
@@ -72,7 +75,11 @@ PY
 ate)
   python tests/tools/ate_check.py --device cuda --in-pass 2> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_c0_16x256x256.json"
   python tests/tools/ate_check.py --device cuda --height 192 --width 256 --tracking --in-pass 2>> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_16x192x256_flow_tracking.json"
-  python tests/tools/ate_check.py --device cuda --frames 32 --height 360 --width 640 --tracking --in-pass 2>> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_32x360x640_flow_tracking.json" ;;
+  python tests/tools/ate_check.py --device cuda --frames 32 --height 360 --width 640 --tracking --in-pass 2>> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_32x360x640_flow_tracking.json"
+  for v in "" "_nosoftmin"; do
+    [ -f tests/golden/ate_150x360x640${v}_reference.json ] && python tests/tools/ate_full_chain.py --leg ours --reference tests/golden/ate_150x360x640${v}_reference.json 2>> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_150x360x640${v}.json"
+  done
+  [ -f tests/golden/ate_150x360x640_reference_perturbed.json ] && python tests/tools/ate_full_chain.py --leg compare --reference tests/golden/ate_150x360x640_reference.json --other tests/golden/ate_150x360x640_reference_perturbed.json > "$OUT/${R}_ate_150x360x640_reference_sensitivity.json" ;;
 misc)
   python tools/dense_microbench.py > "$OUT/${R}_dense_microbench.txt" 2>&1 ;;
 esac

@@ -34,7 +34,9 @@ corr = torch.empty((pairs * p, 8), device=dev)
 lib = _lib.library()
 P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 st = torch.cuda.current_stream().cuda_stream
-assert lib.fm_procrustes_fit_chain(P(depth), P(kinv), None, P(flow), P(logit), 100.0, P(idx), p, 1, f, h, w, P(work), P(t_bwd), P(t_fwd), P(aux), P(ext), P(corr), None, st) == 0
+_ops._procrustes_scatter_plan(idx, flow, 1, f, h, w)
+_taps0 = _ops._procrustes_scatter_plan(idx, flow, 1, f, h, w)[5]
+assert lib.fm_procrustes_fit_chain(P(depth), P(kinv), None, P(flow), P(logit), 100.0, P(idx), p, 1, f, h, w, P(work), P(t_bwd), P(t_fwd), P(aux), P(ext), P(corr), P(_taps0), st) == 0
 _ops._procrustes_scatter_plan(idx, flow, 1, f, h, w)
 pixels, first, vectors, weights, frame_first, _taps = _ops._procrustes_scatter_plan(idx, flow, 1, f, h, w)
 g_t = torch.randn((1, pairs, 4, 4), device=dev, generator=g)

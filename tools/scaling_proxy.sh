@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 out=${1:-gpurun_out/strong_scaling_proxy.jsonl}; shift
 mkdir -p "$(dirname "$out")"; : > "$out"
 for k in 1 2 4 8; do
-  for mode in "--graph off" "--graph compute" "--graph whole" "--graph off --halo early" "--graph whole --halo early"; do
+  for mode in "--graph off" "--graph compute" "--graph whole" "--graph off --halo early" "--graph compute --halo early" "--graph whole --halo early"; do
     share=""; [ "$k" -gt 1 ] && share="--share $k"
     [ "$k" -eq 1 ] && [ "$mode" != "--graph off" ] && [ "$mode" != "--graph whole" ] && continue   # (one GPU: no collectives, no halo)
     timeout 300 python bench.py --cpu-frames 0 --steps 200 --warmup 20 $share $mode "$@" >> "$out" 2>> "${out%.jsonl}.err" || echo "{\"failed\": \"--share $k $mode\"}" >> "$out"
