@@ -73,9 +73,11 @@ class GraphedShardedStep:
 
     ``forward() -> local loss`` runs zero_grad + the model + the flow loss of this rank's shard, ``loss.backward()`` the rest; neither
     contains a collective (the halo exchange's gradient hook is held back while this object exists: ``FrameShard.defer_halo``).
-    Forward and backward are captured as TWO graphs sharing one memory pool (the pattern of torch.cuda.make_graphed_callables), so
-    that with ``FrameShard.enable_early_halo`` the boundary frames' dense gradient — which exists when the forward graph ends —
-    is sent between the two replays and travels under the backward graph; ``FrameShard.sync`` then reduces [loss, shared
+    They are captured as one graph — or, with ``FrameShard.enable_early_halo``, as TWO graphs sharing one memory pool (the pattern of
+    torch.cuda.make_graphed_callables), so that the boundary frames' dense gradient, which exists when the forward graph ends, is sent
+    between the two replays and travels under the backward graph (measured on the one-GPU proxy: the second replay and the early
+    exchange's local copies / index operations cost ~40 us per step, about what they hide of a ~60 us transfer at 720p — it pays at
+    1080p and beyond); ``FrameShard.sync`` then reduces [loss, shared
     gradients] and finishes the halo exchange as usual.  Per step the host enqueues two graph launches and the collectives while
     the GPU is still busy: what a rank of an 8-GPU strong-scaling run needs (its ~15 kernels take ~0.2 ms, eagerly enqueueing them
     ~0.45 ms), without RCCL inside a captured graph — the safe default for multi-rank runs; ``GraphedStep`` over the whole step
@@ -104,12 +106,19 @@ class GraphedShardedStep:
         import time
 
         time.sleep(0.2)  # let the process group's watchdog retire earlier collectives before the capture starts
-        self.forward_graph, self.backward_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.forward_graph, capture_error_mode="thread_local"):
-            self.loss = forward()
-        self.early_dense = shard.take_stashed_early()  # the flow loss's dense dL/ddepth (graph memory: the same tensor every replay), or None
-        with torch.cuda.graph(self.backward_graph, pool=self.forward_graph.pool(), capture_error_mode="thread_local"):
-            self.loss.backward()
+        self.forward_graph, self.backward_graph = torch.cuda.CUDAGraph(), None
+        if shard._early is None:  # nothing travels between forward and backward: ONE graph (a second replay costs ~15 us of launch latency)
+            with torch.cuda.graph(self.forward_graph, capture_error_mode="thread_local"):
+                self.loss = forward()
+                self.loss.backward()
+            self.early_dense = None
+        else:
+            self.backward_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.forward_graph, capture_error_mode="thread_local"):
+                self.loss = forward()
+            self.early_dense = shard.take_stashed_early()  # the flow loss's dense dL/ddepth (graph memory: the same tensor every replay), or None
+            with torch.cuda.graph(self.backward_graph, pool=self.forward_graph.pool(), capture_error_mode="thread_local"):
+                self.loss.backward()
         self.grads = [p.grad for p in self.shared]
         self.depth_grad = None if depth_param is None else depth_param.grad
         if shard._early is not None:
@@ -119,7 +128,8 @@ class GraphedShardedStep:
         self.forward_graph.replay()
         if self.early_dense is not None:
             self.shard.start_early_halo(self.early_dense, self.depth_param)
-        self.backward_graph.replay()
+        if self.backward_graph is not None:
+            self.backward_graph.replay()
         for p, g in zip(self.shared, self.grads):
             p.grad = g
         if self.depth_param is not None:

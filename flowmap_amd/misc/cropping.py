@@ -73,12 +73,18 @@ def _resident(batch, device=None):
     device = torch.device(device)
     if batch.videos.device == device:
         return batch
+    # Only the VIDEO upload is kept (the other tensor fields — intrinsics, extrinsics, indices — are a few hundred bytes and move per call):
+    # two batches that share a videos tensor but differ elsewhere each get their own small fields, never the other's.
+    # The kept copy pins the full-resolution video in HBM for as long as the host tensor lives; overfit.py drops the host batch
+    # right after the two crops (flowmap/overfit.py:61-66).
     kept = batch.videos.__dict__.get("_fm_resident")
     if kept is not None and kept[0] == (str(device), batch.videos._version):
-        return replace(kept[1], **{k: v for k, v in vars(batch).items() if not isinstance(v, Tensor)})
-    resident = batch.to(device)
-    batch.videos.__dict__["_fm_resident"] = ((str(device), batch.videos._version), resident)
-    return resident
+        videos = kept[1]
+    else:
+        videos = batch.videos.to(device)
+        batch.videos.__dict__["_fm_resident"] = ((str(device), batch.videos._version), videos)
+    moved = {k: (v.to(device) if isinstance(v, Tensor) else v) for k, v in vars(batch).items() if k != "videos"}
+    return replace(batch, videos=videos, **moved)
 
 
 def resize_batch(batch, shape: Tuple[int, int], device=None):
