@@ -34,6 +34,10 @@ SIGNATURES = {
     "fm_flow_valid_norm": [P, P, L, F, P, P, P],
     "fm_scale_if_needed": [P, L, P, L, P, P, P],
     "fm_abi_version": [],
+    "fm_halo_copy": [P, L, I, P, P, P],
+    "fm_halo_delta": [P, L, I, P, P, L, P, P, P, L, P, P],
+    "fm_halo_add": [P, L, I, P, P, P],
+    "fm_halo_scatter": [P, L, I, P, P, L, P, P, L, P],
     "fm_flow_loss_fused_views": [P] * 11 + [I, I, I, I, I, F, F, F, P, P, I, P, P],
     "fm_flow_valid_norm_views": [P, P, I, I, L, F, P, P, P, P],
     "fm_flow_pack_inputs_views": [P, P, P, P, I, I, I, I, P, P, P],

@@ -1,0 +1,136 @@
+// Frame sharding (flowmap_amd/sharding.py): the local work of the halo exchange, as four small launches.
+//
+// Under frame-pair sharding the boundary frame of a shard is shared with the neighbour and both copies need the sum of the two
+// partial dL/ddepth.  With FrameShard.enable_early_halo the dense part travels when the flow loss's forward pass ends and only a
+// sparse correction — the values at the pixels the Procrustes fit / the tracks touched — after backward.  Done with torch's
+// indexing operators that was ~14 launches per step (two copies, four gathers, two subtractions, two adds, two index_adds, ...),
+// 25-40 us on the one-GPU proxy: about what the early exchange hides.  Here: one launch per stage, both boundaries at once.
+//   fm_halo_copy     sent[side]      = grad[frame(side)]                                (what the link reads; backward adds to grad later)
+//   fm_halo_delta    out[side][i]    = grad[frame(side)][px[side][i]] − sent[side][px[side][i]]     (after backward)
+//   fm_halo_add      grad[frame(side)] += dense[side]                                   (the neighbour's dense part)
+//   fm_halo_scatter  grad[frame(side)][px[side][i]] += values[side][i]                  (the neighbour's sparse part; px distinct)
+// side 0 = first local frame (neighbour rank−1), side 1 = last local frame (rank+1); a NULL buffer switches a side off.
+// There is no reference counterpart: the reference has no sharding (flowmap/overfit.py:94-108 replicates the video per rank).
+#include "../../include/flowmap_hip.h"
+#include "fm_device.h"
+
+namespace fm {
+
+typedef float v4f_s __attribute__((ext_vector_type(4)));
+
+// blockIdx.y = side.  16-byte path when the frame size allows.
+__global__ void __launch_bounds__(256) halo_copy_kernel(const float* g0, const float* g1, float* s0, float* s1, long n, int vec) {
+  const float* src = blockIdx.y == 0 ? g0 : g1;
+  float* dst = blockIdx.y == 0 ? s0 : s1;
+  if (dst == nullptr) return;
+  const long stride = (long)gridDim.x * blockDim.x, tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    for (long i = tid; i < n / 4; i += stride) reinterpret_cast<v4f_s*>(dst)[i] = reinterpret_cast<const v4f_s*>(src)[i];
+  } else {
+    for (long i = tid; i < n; i += stride) dst[i] = src[i];
+  }
+}
+
+__global__ void __launch_bounds__(256) halo_add_kernel(float* g0, float* g1, const float* d0, const float* d1, long n, int vec) {
+  float* dst = blockIdx.y == 0 ? g0 : g1;
+  const float* src = blockIdx.y == 0 ? d0 : d1;
+  if (src == nullptr) return;
+  const long stride = (long)gridDim.x * blockDim.x, tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    for (long i = tid; i < n / 4; i += stride) {
+      v4f_s a = reinterpret_cast<v4f_s*>(dst)[i];
+      const v4f_s b = reinterpret_cast<const v4f_s*>(src)[i];
+      a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+      reinterpret_cast<v4f_s*>(dst)[i] = a;
+    }
+  } else {
+    for (long i = tid; i < n; i += stride) dst[i] += src[i];
+  }
+}
+
+__global__ void __launch_bounds__(256) halo_delta_kernel(const float* g0, const float* g1, const float* s0, const float* s1, const int64_t* px0,
+                                                         const int64_t* px1, long n0, long n1, float* o0, float* o1) {
+  const bool first = blockIdx.y == 0;
+  const float* g = first ? g0 : g1;
+  const float* s = first ? s0 : s1;
+  const int64_t* px = first ? px0 : px1;
+  float* o = first ? o0 : o1;
+  const long count = first ? n0 : n1;
+  if (o == nullptr) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) o[i] = g[px[i]] - s[px[i]];
+}
+
+__global__ void __launch_bounds__(256) halo_scatter_kernel(float* g0, float* g1, const int64_t* px0, const int64_t* px1, const float* v0,
+                                                           const float* v1, long n0, long n1) {
+  const bool first = blockIdx.y == 0;
+  float* g = first ? g0 : g1;
+  const int64_t* px = first ? px0 : px1;
+  const float* v = first ? v0 : v1;
+  const long count = first ? n0 : n1;
+  if (v == nullptr) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) g[px[i]] += v[i];
+}
+
+static inline unsigned halo_blocks(long work) {
+  long blocks = (work + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  return (unsigned)blocks;
+}
+static inline bool halo_aligned(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace fm
+
+using namespace fm;
+
+extern "C" {
+
+int fm_halo_copy(const float* grad, long frame_elements, int frames, float* sent_first, float* sent_last, void* stream) {
+  FM_CHECK_ARG(grad && frame_elements >= 1 && frames >= 1);
+  if (!sent_first && !sent_last) return FM_OK;
+  const float* last = grad + (size_t)(frames - 1) * frame_elements;
+  const int vec = frame_elements % 4 == 0 && halo_aligned(grad) && halo_aligned(sent_first) && halo_aligned(sent_last);
+  hipLaunchKernelGGL(halo_copy_kernel, dim3(halo_blocks(frame_elements / (vec ? 4 : 1)), 2), dim3(256), 0, (hipStream_t)stream, grad, last, sent_first,
+                     sent_last, frame_elements, vec);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_halo_add(float* grad, long frame_elements, int frames, const float* dense_first, const float* dense_last, void* stream) {
+  FM_CHECK_ARG(grad && frame_elements >= 1 && frames >= 1);
+  if (!dense_first && !dense_last) return FM_OK;
+  float* last = grad + (size_t)(frames - 1) * frame_elements;
+  FM_CHECK_ARG(frames > 1 || !(dense_first && dense_last));  // (one frame cannot be both boundaries in one launch: two writers)
+  const int vec = frame_elements % 4 == 0 && halo_aligned(grad) && halo_aligned(dense_first) && halo_aligned(dense_last);
+  hipLaunchKernelGGL(halo_add_kernel, dim3(halo_blocks(frame_elements / (vec ? 4 : 1)), 2), dim3(256), 0, (hipStream_t)stream, grad, last, dense_first,
+                     dense_last, frame_elements, vec);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_halo_delta(const float* grad, long frame_elements, int frames, const float* sent_first, const int64_t* pixels_first, long count_first,
+                  float* out_first, const float* sent_last, const int64_t* pixels_last, long count_last, float* out_last, void* stream) {
+  FM_CHECK_ARG(grad && frame_elements >= 1 && frames >= 1 && count_first >= 0 && count_last >= 0);
+  FM_CHECK_ARG(!out_first || (sent_first && (pixels_first || count_first == 0)));
+  FM_CHECK_ARG(!out_last || (sent_last && (pixels_last || count_last == 0)));
+  if ((!out_first || count_first == 0) && (!out_last || count_last == 0)) return FM_OK;
+  const float* last = grad + (size_t)(frames - 1) * frame_elements;
+  const long most = count_first > count_last ? count_first : count_last;
+  hipLaunchKernelGGL(halo_delta_kernel, dim3(halo_blocks(most), 2), dim3(256), 0, (hipStream_t)stream, grad, last, sent_first, sent_last, pixels_first,
+                     pixels_last, out_first ? count_first : 0L, out_last ? count_last : 0L, out_first, out_last);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_halo_scatter(float* grad, long frame_elements, int frames, const int64_t* pixels_first, const float* values_first, long count_first,
+                    const int64_t* pixels_last, const float* values_last, long count_last, void* stream) {
+  FM_CHECK_ARG(grad && frame_elements >= 1 && frames >= 1 && count_first >= 0 && count_last >= 0);
+  FM_CHECK_ARG(!values_first || pixels_first || count_first == 0);
+  FM_CHECK_ARG(!values_last || pixels_last || count_last == 0);
+  FM_CHECK_ARG(frames > 1 || !(values_first && values_last));
+  if ((!values_first || count_first == 0) && (!values_last || count_last == 0)) return FM_OK;
+  float* last = grad + (size_t)(frames - 1) * frame_elements;
+  const long most = count_first > count_last ? count_first : count_last;
+  hipLaunchKernelGGL(halo_scatter_kernel, dim3(halo_blocks(most), 2), dim3(256), 0, (hipStream_t)stream, grad, last, pixels_first, pixels_last,
+                     values_first, values_last, values_first ? count_first : 0L, values_last ? count_last : 0L);
+  FM_LAUNCH_STATUS();
+}
+
+}  // extern "C"

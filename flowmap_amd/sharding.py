@@ -302,22 +302,27 @@ class FrameShard:
         if e["inflight"] is not None:  # a forward that never reached sync(): complete it first (every rank does)
             for req in e["inflight"]:
                 req.wait()
-        pairs = []
-        for side, frame, peer in (("prev", 0, self.rank - 1), ("next", -1, self.rank + 1)):
-            if side in e["send"]:
-                e["send"][side].copy_(dense_grad[0, frame])
-                pairs.append((e["send"][side], e["recv"][side], peer))
+        from ._lib import call, ptr, stream_for
+        from ._ops import _guard
+
+        frames, h, w = dense_grad.shape[1:]
+        with _guard(dense_grad.device):  # both boundary frames in one launch (fm_halo_copy)
+            call("fm_halo_copy", ptr(dense_grad), h * w, frames, ptr(e["send"].get("prev")), ptr(e["send"].get("next")), stream_for(dense_grad))
+        pairs = [(e["send"][side], e["recv"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
         e["inflight"] = self._exchange(pairs)
 
     def _start_sparse_halo(self, depth_grad: Tensor) -> None:
         """After backward: what the boundary frames gained since the early copy — non-zero only at the locally touched pixels."""
+        from ._lib import call, ptr, stream_for
+        from ._ops import _guard
+
         e = self._early
-        pairs = []
-        for side, frame, peer in (("prev", 0, self.rank - 1), ("next", -1, self.rank + 1)):
-            if side in e["send"]:
-                px = e["mine"][side]
-                torch.sub(depth_grad[frame].reshape(-1)[px], e["send"][side].reshape(-1)[px], out=e["delta_out"][side])
-                pairs.append((e["delta_out"][side], e["delta_in"][side], peer))
+        frames, h, w = depth_grad.shape
+        cnt = lambda side: e["mine"][side].numel() if side in e["send"] else 0  # noqa: E731
+        with _guard(depth_grad.device):  # both sides' deltas in one launch (fm_halo_delta)
+            call("fm_halo_delta", ptr(depth_grad), h * w, frames, ptr(e["send"].get("prev")), ptr(e["mine"]["prev"]), cnt("prev"), ptr(e["delta_out"].get("prev")),
+                 ptr(e["send"].get("next")), ptr(e["mine"]["next"]), cnt("next"), ptr(e["delta_out"].get("next")), stream_for(depth_grad))
+        pairs = [(e["delta_out"][side], e["delta_in"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
         self._halo = (self._exchange(pairs), None, None, depth_grad, depth_grad._version, True)
 
     def _finish_sparse_halo(self, depth_grad: Tensor) -> None:
@@ -325,10 +330,15 @@ class FrameShard:
         for req in e["inflight"] or []:
             req.wait()
         e["inflight"] = None
-        for side, frame in (("prev", 0), ("next", -1)):
-            if side in e["send"]:
-                depth_grad[frame].add_(e["recv"][side])
-                depth_grad[frame].reshape(-1).index_add_(0, e["theirs"][side], e["delta_in"][side])
+        from ._lib import call, ptr, stream_for
+        from ._ops import _guard
+
+        frames, h, w = depth_grad.shape
+        cnt = lambda side: e["theirs"][side].numel() if side in e["send"] else 0  # noqa: E731
+        with _guard(depth_grad.device):  # the neighbours' dense parts, then their sparse parts: one launch each for both boundaries
+            call("fm_halo_add", ptr(depth_grad), h * w, frames, ptr(e["recv"].get("prev")), ptr(e["recv"].get("next")), stream_for(depth_grad))
+            call("fm_halo_scatter", ptr(depth_grad), h * w, frames, ptr(e["theirs"]["prev"]), ptr(e["delta_in"].get("prev")), cnt("prev"),
+                 ptr(e["theirs"]["next"]), ptr(e["delta_in"].get("next")), cnt("next"), stream_for(depth_grad))
         self._syncs += 1
         if self._syncs % 64 == 0 and int(self.unit_flag(depth_grad.device).item()) != 0:
             raise RuntimeError("flowmap_amd.FrameShard: with enable_early_halo() the flow loss must reach backward() unscaled (the boundary frames' "
@@ -376,10 +386,19 @@ class FrameShard:
         if sparse:
             self._finish_sparse_halo(depth_grad)
             return
-        if recv_prev is not None:
-            depth_grad[0].add_(recv_prev)
-        if recv_next is not None:
-            depth_grad[-1].add_(recv_next)
+        if recv_prev is not None or recv_next is not None:
+            if depth_grad.dim() == 3 and depth_grad.is_contiguous() and depth_grad.dtype == torch.float32 and (depth_grad.shape[0] > 1 or recv_prev is None or recv_next is None):
+                from ._lib import call, ptr, stream_for
+                from ._ops import _guard
+
+                with _guard(depth_grad.device):  # both boundary frames in one launch
+                    call("fm_halo_add", ptr(depth_grad), depth_grad.shape[1] * depth_grad.shape[2], depth_grad.shape[0], ptr(recv_prev), ptr(recv_next),
+                         stream_for(depth_grad))
+            else:
+                if recv_prev is not None:
+                    depth_grad[0].add_(recv_prev)
+                if recv_next is not None:
+                    depth_grad[-1].add_(recv_next)
 
     def exchange_halo(self, depth_grad: Tensor) -> None:
         self.start_halo_exchange(depth_grad)

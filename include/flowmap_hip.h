@@ -457,6 +457,22 @@ int fm_procrustes_scatter_views(const float* depth, const float* kinv, const flo
 int fm_procrustes_scatter_plan_views(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,
                                      int64_t* keys, float* weights, const fm_layout* flow_layout, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Frame sharding: the local work of the halo exchange (flowmap_amd/sharding.py; no reference counterpart — the reference
+ * replicates the video per rank, flowmap/overfit.py:94-108).  grad (frames, frame_elements): this rank's dL/ddepth; its first frame is
+ * shared with rank−1 ("first"), its last with rank+1 ("last"); a NULL buffer switches that side off.
+ *   fm_halo_copy     sent_* = the boundary frames as they are now (the early exchange sends these while backward still adds to grad)
+ *   fm_halo_delta    out_*[i] = grad[boundary frame][pixels_*[i]] − sent_*[pixels_*[i]]   (what backward added since, at the touched pixels)
+ *   fm_halo_add      boundary frame += dense_*                                            (the neighbour's dense part)
+ *   fm_halo_scatter  boundary frame[pixels_*[i]] += values_*[i]                           (the neighbour's sparse part; pixels distinct)
+ * pixels: int64 offsets inside one frame.  One launch each, both boundaries at once. */
+int fm_halo_copy(const float* grad, long frame_elements, int frames, float* sent_first, float* sent_last, void* stream);
+int fm_halo_delta(const float* grad, long frame_elements, int frames, const float* sent_first, const int64_t* pixels_first, long count_first,
+                  float* out_first, const float* sent_last, const int64_t* pixels_last, long count_last, float* out_last, void* stream);
+int fm_halo_add(float* grad, long frame_elements, int frames, const float* dense_first, const float* dense_last, void* stream);
+int fm_halo_scatter(float* grad, long frame_elements, int frames, const int64_t* pixels_first, const float* values_first, long count_first,
+                    const int64_t* pixels_last, const float* values_last, long count_last, void* stream);
+
 /* The tail of IntrinsicsSoftmin.forward (flowmap/model/intrinsics/intrinsics_softmin.py:123-141):
  * soft = softmin((err - min err) * 10) over the N candidates (fp32), K = sum_n soft[n] * candidate_k[n],
  * repeated over `frames`.  err (B,N) fp64 as fm_softmin_score_fwd leaves it; candidate_k (N,3,3);

@@ -1545,4 +1545,36 @@ int fm_procrustes_scatter_plan_views(const float* bwd_flow, const int64_t* indic
   return fm_procrustes_scatter_plan(sim_or_null(fl), indices, points, batch, frames, height, width, keys, weights, stream);
 }
 
+// ---- frame sharding: the local work of the halo exchange ----
+int fm_halo_copy(const float* grad, long n, int frames, float* sent_first, float* sent_last, void*) {
+  if (!grad || n < 1 || frames < 1) return 1;
+  if (sent_first) std::memcpy(sent_first, grad, sizeof(float) * n);
+  if (sent_last) std::memcpy(sent_last, grad + (size_t)(frames - 1) * n, sizeof(float) * n);
+  return 0;
+}
+int fm_halo_add(float* grad, long n, int frames, const float* dense_first, const float* dense_last, void*) {
+  if (!grad || n < 1 || frames < 1 || (frames == 1 && dense_first && dense_last)) return 1;
+  for (long i = 0; dense_first && i < n; ++i) grad[i] += dense_first[i];
+  for (long i = 0; dense_last && i < n; ++i) grad[(size_t)(frames - 1) * n + i] += dense_last[i];
+  return 0;
+}
+int fm_halo_delta(const float* grad, long n, int frames, const float* sent_first, const int64_t* pixels_first, long count_first, float* out_first,
+                  const float* sent_last, const int64_t* pixels_last, long count_last, float* out_last, void*) {
+  if (!grad || n < 1 || frames < 1 || count_first < 0 || count_last < 0) return 1;
+  if ((out_first && (!sent_first || (!pixels_first && count_first))) || (out_last && (!sent_last || (!pixels_last && count_last)))) return 1;
+  for (long i = 0; out_first && i < count_first; ++i) out_first[i] = grad[pixels_first[i]] - sent_first[pixels_first[i]];
+  const float* last = grad + (size_t)(frames - 1) * n;
+  for (long i = 0; out_last && i < count_last; ++i) out_last[i] = last[pixels_last[i]] - sent_last[pixels_last[i]];
+  return 0;
+}
+int fm_halo_scatter(float* grad, long n, int frames, const int64_t* pixels_first, const float* values_first, long count_first,
+                    const int64_t* pixels_last, const float* values_last, long count_last, void*) {
+  if (!grad || n < 1 || frames < 1 || count_first < 0 || count_last < 0) return 1;
+  if ((values_first && !pixels_first && count_first) || (values_last && !pixels_last && count_last) || (frames == 1 && values_first && values_last)) return 1;
+  for (long i = 0; values_first && i < count_first; ++i) grad[pixels_first[i]] += values_first[i];
+  float* last = grad + (size_t)(frames - 1) * n;
+  for (long i = 0; values_last && i < count_last; ++i) last[pixels_last[i]] += values_last[i];
+  return 0;
+}
+
 }  // extern "C"
