@@ -1469,3 +1469,47 @@ def case_frame_windows(dev):
         assert torch_ops().view_copies() == copies + 1
     finally:
         fm.set_lazy_surfaces(False)
+
+
+def case_halo_kernels(dev):
+    """fm_halo_copy / _delta / _add / _scatter (csrc/fm_shard.hip: the local work of the frame shards' halo exchange) against the
+    torch indexing operators they replace, with both, one and no boundary active, and a frame size the 16-byte path does not take."""
+    from flowmap_amd._lib import call, ptr, stream_for
+
+    for frames, h, w in ((5, 12, 16), (2, 9, 7)):
+        n = h * w
+        g = torch.Generator().manual_seed(frames)
+        grad = torch.randn((frames, h, w), generator=g).to(dev)
+        px = [torch.randperm(n, generator=g)[: n // 3].to(dev), torch.randperm(n, generator=g)[: n // 4].to(dev)]
+        for sides in ((True, True), (True, False), (False, True), (False, False)):
+            first, last = sides
+            sent = [torch.full((h, w), float("nan"), device=dev) if on else None for on in sides]
+            call("fm_halo_copy", ptr(grad), n, frames, ptr(sent[0]), ptr(sent[1]), stream_for(grad))
+            if first:
+                assert torch.equal(sent[0], grad[0])
+            if last:
+                assert torch.equal(sent[1], grad[-1])
+            moved = grad.clone()
+            moved[0].view(-1)[px[0]] += 1.5
+            moved[-1].view(-1)[px[1]] -= 0.25
+            out = [torch.full((px[i].numel(),), float("nan"), device=dev) if sides[i] else None for i in range(2)]
+            call("fm_halo_delta", ptr(moved), n, frames, ptr(sent[0]), ptr(px[0]), px[0].numel(), ptr(out[0]), ptr(sent[1]), ptr(px[1]), px[1].numel(),
+                 ptr(out[1]), stream_for(grad))
+            if first:
+                assert_close(out[0], moved[0].view(-1)[px[0]] - grad[0].view(-1)[px[0]], 1e-6, abs_=1e-7, what="delta, first frame")
+            if last:
+                assert_close(out[1], moved[-1].view(-1)[px[1]] - grad[-1].view(-1)[px[1]], 1e-6, abs_=1e-7, what="delta, last frame")
+            dense = [torch.randn((h, w), generator=g).to(dev) if on else None for on in sides]
+            vals = [torch.randn((px[i].numel(),), generator=g).to(dev) if sides[i] else None for i in range(2)]
+            want = grad.clone()
+            if first:
+                want[0] += dense[0]
+                want[0].view(-1).index_add_(0, px[0], vals[0])
+            if last:
+                want[-1] += dense[1]
+                want[-1].view(-1).index_add_(0, px[1], vals[1])
+            got = grad.clone()
+            call("fm_halo_add", ptr(got), n, frames, ptr(dense[0]), ptr(dense[1]), stream_for(grad))
+            call("fm_halo_scatter", ptr(got), n, frames, ptr(px[0]), ptr(vals[0]), px[0].numel(), ptr(px[1]), ptr(vals[1]), px[1].numel(), stream_for(grad))
+            assert_close(got, want, 1e-6, abs_=1e-6, what=f"add + scatter, sides {sides}")
+            assert torch.equal(got[1:-1], grad[1:-1])  # interior frames untouched

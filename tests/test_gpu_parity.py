@@ -462,3 +462,7 @@ def test_pretraining_mode_never_packs_or_plans():
 
 def test_frame_windows_are_read_in_place():
     cases.case_frame_windows(DEV)
+
+
+def test_halo_exchange_kernels():
+    cases.case_halo_kernels(DEV)
