@@ -100,10 +100,11 @@ def parse():
                          "eagerly after the replay), `off`.  Default: off on one GPU (the headline number is measured eagerly, with HIP events around the "
                          "flow kernel), `compute` for a multi-rank strong-scaling run of the flow loss — a rank's ~15 kernels take ~0.2 ms at 8 GPUs and "
                          "cannot hide ~0.45 ms of eager enqueueing")
-    ap.add_argument("--halo", choices=["oneshot", "early"], default="oneshot",
+    ap.add_argument("--halo", choices=["auto", "oneshot", "early"], default="auto",
                     help="strong scaling: how the boundary frames' dL/ddepth reaches the neighbour — `oneshot`: one 3.7 MB (720p) exchange per boundary and "
                          "direction after backward; `early` (FrameShard.enable_early_halo): the dense part right after the flow pass, under the rest of the "
-                         "step, and a sparse correction (~20 KB) after backward (with --graph compute: between the forward and the backward replay)")
+                         "step, and a sparse correction (~20 KB) after backward (with --graph compute: between the forward and the backward replay).  "
+                         "auto: early for a multi-rank strong-scaling run, oneshot otherwise (the --share proxy states its mode explicitly)")
     ap.add_argument("--share", type=int, default=0,
                     help="K > 0: run ONE rank's share of a K-GPU strong-scaling run on this GPU (its pairs + halo frames, collectives on a "
                          "one-rank RCCL communicator): the per-rank step time of a K-GPU run without the wire time")
@@ -339,6 +340,8 @@ def main():
                                    and args.optimizer in ("none", "fused")) else "off"
     if args.graph == "off":
         args.graph = None
+    if args.halo == "auto":
+        args.halo = "early" if (strong and world > 1) else "oneshot"
     if args.graph == "compute" and (not strong or cfg["tracking"] or args.intrinsics != "regressed"):
         raise SystemExit("--graph compute: a frame-sharded run of the flow loss with regressed intrinsics (the tracking loss and the softmin sweep have collectives inside forward / backward)")
     flowmap_amd.set_lazy_surfaces(True)
