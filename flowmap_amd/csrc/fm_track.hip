@@ -139,6 +139,45 @@ __device__ __forceinline__ void wave_sum7_lane63(float& v0, float& v1, float& v2
 #undef FM_DPP7
 }
 
+// Round 3: a TRANSPOSING reduction for the 14 (padded to 16) per-target sums.  Summing each value across the wave separately costs 6
+// DPP steps per value (84 instructions per target iteration of ~430).  Here every step halves the number of live registers instead:
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange register halves between lane groups, so after one swap + one add a
+// register holds value i in one half of the lanes and value i+8 in the other, each already summed over the pair of lanes it came
+// from.  16 registers -> 8 (lanes l, l+32) -> 4 (rows r, r+1) -> 2 (xor 8: two selects + one DPP add) -> 1 (half-row mirror) ->
+// the quad's two DPP steps: 35 instructions, and lane L ends with the wave total of value L >> 2 (one masked store by every fourth
+// lane instead of 14 stores by lane 63).  The fp32 summation tree differs from the per-value one in the last bits only.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float swap32_sum(float a, float b) {  // lanes < 32: a summed over (l, l+32); lanes >= 32: b likewise
+  // (inline asm: this compiler lowers the SECOND result of __builtin_amdgcn_permlane32_swap / 16_swap to the first — it emitted
+  // v_add v, vdst, vdst — tools/probes/transpose_reduce_probe.hip; the s_nop covers the VALU-write -> lane-swap hazard)
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float swap16_sum(float a, float b) {  // even rows: a summed over (row, row+1); odd rows: b likewise
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float wave_transpose_sum16(const float (&v)[16]) {
+  float r[8], s[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = swap32_sum(v[i], v[i + 8]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[i] = swap16_sum(r[i], r[i + 4]);
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+  // xor 8 inside a row: lanes with bit 3 clear keep s[j], the others s[j+2]; what a lane does not keep goes to its partner
+  const float u0 = (b3 ? s[2] : s[0]) + dpp_move<0x128>(b3 ? s[0] : s[2]);  // row_ror:8
+  const float u1 = (b3 ? s[3] : s[1]) + dpp_move<0x128>(b3 ? s[1] : s[3]);
+  // the two halves of an 8-lane group (mirror inside the half row pairs lane l with 7 - l: the other quad)
+  float w = (b2 ? u1 : u0) + dpp_move<0x141>(b2 ? u0 : u1);  // row_half_mirror
+  w += dpp_move<0xB1>(w);                                    // quad_perm:[1,0,3,2]
+  w += dpp_move<0x4E>(w);                                    // quad_perm:[2,3,0,1]
+  return w;  // lane L: the wave total of v[L >> 2]
+}
+
 // NV (a multiple of 7) per-lane values -> their wave totals in lane 63, in place
 template <int NV>
 __device__ __forceinline__ void wave_sum_lane63_x7(float (&v)[NV]) {
@@ -327,11 +366,21 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
 #pragma unroll
     for (int i = 0; i < kTrackSums; ++i) a[i] = a2[i].x + a2[i].y;
     if (GRAD) {
+#ifdef FM_TRACK_PLAIN_REDUCE
       wave_sum_lane63_x7<kTrackSums>(a);  // the totals are valid in lane 63
       if (threadIdx.x == kWave - 1) {
 #pragma unroll
         for (int i = 0; i < kTrackSums; ++i) mine[(size_t)ft * kTrackSums + i] = a[i];
       }
+#else
+      static_assert(kTrackSums <= 16, "the transposing reduction handles 16 values");
+      float a16[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a16[i] = i < kTrackSums ? a[i] : 0.f;
+      const float total = wave_transpose_sum16(a16);  // lane L: the wave total of sum L >> 2
+      const int lane = threadIdx.x & (kWave - 1);
+      if ((lane & 3) == 0 && (lane >> 2) < kTrackSums) mine[(size_t)ft * kTrackSums + (lane >> 2)] = total;
+#endif
     } else {
       const float lc[2] = {a[12], a[13]};
       wave_store<2>(lc, mine + (size_t)ft * kTrackSums + 12);

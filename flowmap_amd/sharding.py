@@ -340,7 +340,8 @@ class FrameShard:
             call("fm_halo_scatter", ptr(depth_grad), h * w, frames, ptr(e["theirs"]["prev"]), ptr(e["delta_in"].get("prev")), cnt("prev"),
                  ptr(e["theirs"]["next"]), ptr(e["delta_in"].get("next")), cnt("next"), stream_for(depth_grad))
         self._syncs += 1
-        if self._syncs % 64 == 0 and int(self.unit_flag(depth_grad.device).item()) != 0:
+        capturing = depth_grad.is_cuda and torch.cuda.is_current_stream_capturing()  # (a host read cannot sit inside a hipGraph capture)
+        if self._syncs % 64 == 0 and not capturing and int(self.unit_flag(depth_grad.device).item()) != 0:
             raise RuntimeError("flowmap_amd.FrameShard: with enable_early_halo() the flow loss must reach backward() unscaled (the boundary frames' "
                                "gradient was sent before backward ran); disable_early_halo() for a scaled loss")
 
