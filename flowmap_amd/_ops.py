@@ -287,6 +287,10 @@ def touched_elements(depth: Tensor, whole_frames=()):
 use_grad_arena = True
 # Moments, finish + solve and the pose chain as ONE launch (fm_procrustes_fit_chain) instead of a memset and three kernels.
 use_fit_chain = True
+# Dense Procrustes (`num_points: null`) backward: False (default) = one fused pass over the later pixels, tap gradients summed in LDS and
+# flushed with atomics; True = the static tap lists (built once per flow tensor, 4 B per pixel and pair) and the planned pair of kernels
+# without atomics, whose dL/ddepth is bit-reproducible (and 0.9 ms slower per 150 x 720x1280 step).
+use_dense_plan = False
 
 # which backward path the facades selected (tests)
 counters = {"procrustes_planned": 0, "procrustes_dense_planned": 0, "flow_packs": 0, "procrustes_plans_built": 0}
@@ -479,7 +483,7 @@ class ProcrustesFit:
                 b, f, h, w = depth.shape
                 if indices is None:
                     note_touched(depth, "procrustes", None)  # every pixel is a correspondence: nothing is left to an in-pass update
-                    if h <= 65535 and w <= 65535 and bwd_flow.is_contiguous():
+                    if use_dense_plan and h <= 65535 and w <= 65535 and bwd_flow.is_contiguous():
                         dense = _dense_procrustes_plan(bwd_flow, b, f, h, w)
                         counters["procrustes_dense_planned"] += 1
                 elif indices.dtype == torch.int64 and indices.is_contiguous():

@@ -987,7 +987,11 @@ FM_HD void mat4_mul_nt(const double* a, const double* b, double* o) {  // a bᵀ
 //   dL/dK⁻¹_l   = K_lᵀ·Σ (w·s) ⊗ g          dL/dK⁻¹_e = K_eᵀ·Σ (w·t) ⊗ h
 // (corr_backward above, rewritten; ≈60 flops per correspondence instead of ≈250).
 // ---------------------------------------------------------------------------------
-constexpr int kDenseTileH = 32, kDenseTileW = 64;  // tile of one workgroup (and of the static tap lists)
+#ifndef FM_DENSE_TILE_H  // (build-variant experiments: tools/dense_microbench.py)
+#define FM_DENSE_TILE_H 32
+#define FM_DENSE_TILE_W 64
+#endif
+constexpr int kDenseTileH = FM_DENSE_TILE_H, kDenseTileW = FM_DENSE_TILE_W;  // tile of one workgroup (and of the static tap lists)
 
 // (i + 0.5) / n as sample_image_grid divides it (projection.py:109), by reciprocal + one Newton step:
 // the correctly rounded quotient in all but rare double-rounding cases (then 1 ulp off).  Every dense

@@ -655,7 +655,7 @@ constexpr int kTileH = kDenseTileH, kTileW = kDenseTileW;    // 32 x 64 later-fr
 #endif
 constexpr int kWinH = kTileH + FM_DENSE_WIN_ROWS, kWinW = kTileW + FM_DENSE_WIN_COLS;  // +-8 rows, +-16 columns: 18 KB, so the VGPRs and not the LDS set the occupancy (moments 0.88 -> 0.62 ms; +-16 / +-32 was 32 KB)
 constexpr int kRowsPerThread = kTileH / (256 / kTileW);
-static_assert(kTileW == 64 && kWinW % 4 == 0 && kTileH % 4 == 0, "thread mapping: one column, every 4th row");
+static_assert(256 % kTileW == 0 && kWinW % 4 == 0 && kTileH % (256 / kTileW) == 0, "thread mapping: one column, every (256 / kTileW)-th row");
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -697,6 +697,7 @@ struct DenseCtx {
   size_t pair, fe;        // pair index, earlier frame index (batch folded in)
 };
 
+template <int WH = kWinH, int WW = kWinW>
 __device__ __forceinline__ DenseCtx dense_ctx(const ProcParams& p, const DenseBlock& blk, bool window) {
   DenseCtx c;
   const int pairs_per_batch = p.frames - 1;
@@ -723,20 +724,26 @@ __device__ __forceinline__ DenseCtx dense_ctx(const ProcParams& p, const DenseBl
     const float2 fl = reinterpret_cast<const float2*>(c.bwd_flow)[(size_t)cy * p.width + cx];
     const float ox = fminf(fmaxf(rintf(fl.x * c.fw), -1.0e6f), 1.0e6f);
     const float oy = fminf(fmaxf(rintf(fl.y * c.fh), -1.0e6f), 1.0e6f);
-    c.wx0 = (c.tx0 - (kWinW - kTileW) / 2 + (ox == ox ? (int)ox : 0)) & ~3;
-    c.wy0 = c.ty0 - (kWinH - kTileH) / 2 + (oy == oy ? (int)oy : 0);
+    c.wx0 = (c.tx0 - (WW - kTileW) / 2 + (ox == ox ? (int)ox : 0)) & ~3;
+    c.wy0 = c.ty0 - (WH - kTileH) / 2 + (oy == oy ? (int)oy : 0);
   }
   return c;
 }
 
 // Window of the earlier frame's depth plus the pixel-centre coordinates of its columns / rows.
-struct DenseWindow {
-  float z[kWinH * kWinW];
-  float u[kWinW];
-  float v[kWinH];
+template <int WH, int WW>
+struct DenseWindowT {
+  static constexpr int kH = WH, kW = WW;
+  float z[WH * WW];
+  float u[WW];
+  float v[WH];
 };
+typedef DenseWindowT<kWinH, kWinW> DenseWindow;
 
-__device__ __forceinline__ void stage_depth_window(const DenseCtx& c, DenseWindow& win) {
+template <int WH, int WW>
+__device__ __forceinline__ void stage_depth_window(const DenseCtx& c, DenseWindowT<WH, WW>& win) {
+  constexpr int kWinH = WH, kWinW = WW;  // (shadow the defaults: this window's own size)
+  static_assert(WW % 4 == 0 && WW + WH <= 256, "16-byte staging; one thread per coordinate");
   if ((c.width & 3) == 0) {  // 16-byte loads: the window's columns start at a multiple of 4
     for (int i = threadIdx.x; i < kWinH * (kWinW / 4); i += 256) {
       const int r = i / (kWinW / 4), q = i - r * (kWinW / 4);
@@ -774,9 +781,13 @@ __device__ __forceinline__ DenseRaw dense_load(const DenseCtx& c, int idx) {
 struct DensePixel {
   float g[3], h[3], w;
   Taps taps;
+  float u0, u1, v0, v1;  // pixel-centre coordinates of the taps' columns (west, east) and rows (north, south)
+  int cell;              // the north-west tap's cell in the window, -1 when the footprint is not inside it
 };
 
-__device__ __forceinline__ DensePixel dense_pixel(const DenseCtx& c, const DenseWindow& win, const DenseRaw& in, float u, float v) {
+template <int WH, int WW>
+__device__ __forceinline__ DensePixel dense_pixel(const DenseCtx& c, const DenseWindowT<WH, WW>& win, const DenseRaw& in, float u, float v) {
+  constexpr int kWinH = WH, kWinW = WW;
   DensePixel o;
   o.w = c.sens != 0.f ? fm_sigmoid<true>(c.sens * in.wt) : in.wt;
   o.g[0] = in.z * u;
@@ -789,7 +800,9 @@ __device__ __forceinline__ DensePixel dense_pixel(const DenseCtx& c, const Dense
     const float* zw = win.z + wr * kWinW + wc;
     zt[0] = zw[0], zt[1] = zw[1], zt[2] = zw[kWinW], zt[3] = zw[kWinW + 1];
     u0 = win.u[wc], u1 = win.u[wc + 1], v0 = win.v[wr], v1 = win.v[wr + 1];
+    o.cell = wr * kWinW + wc;
   } else {
+    o.cell = -1;
     const int x1 = min(o.taps.x0 + 1, c.width - 1), y1 = min(o.taps.y0 + 1, c.height - 1);  // clamped reads; masked by taps.in
     const float* d0 = c.depth_e + (size_t)o.taps.y0 * c.width;
     const float* d1 = c.depth_e + (size_t)y1 * c.width;
@@ -798,6 +811,47 @@ __device__ __forceinline__ DensePixel dense_pixel(const DenseCtx& c, const Dense
     v0 = center_fast(o.taps.y0, c.fh, c.rcp_h), v1 = center_fast(o.taps.y0 + 1, c.fh, c.rcp_h);
   }
   dense_h(o.taps, zt, u0, u1, v0, v1, o.h);
+  o.u0 = u0, o.u1 = u1, o.v0 = v0, o.v1 = v1;
+  return o;
+}
+
+// Four horizontally adjacent later pixels per thread: 16-byte loads (32 bytes of flow), so a wave's load instruction moves 1 KB
+// (4 rows x 256 B) instead of 256 B — the tiled kernels are bound by the memory pipeline, not by arithmetic (measured: neither
+// halving the occupancy nor adding the tap sums' 70 instructions per pixel moves their duration; quartering the number of
+// memory instructions does).  lane & 15 -> the group of four columns, lane >> 4 and the wave -> the row: 16 rows per pass.
+constexpr int kQuadRows = 256 / (kTileW / 4);          // rows of the tile one pass of the block covers
+constexpr int kQuadPasses = kTileH / kQuadRows;
+static_assert(kTileW % 4 == 0 && kTileH % kQuadRows == 0, "quad mapping");
+struct DenseRaw4 {
+  float fx[4], fy[4], wt[4], z[4];
+};
+// idx = row·width + col0, col0 % 4 == 0.  `vec`: width % 4 == 0 (then all four pixels exist and the addresses are 16-byte aligned
+// on 16-byte aligned stacks); else element-wise with a range test.
+__device__ __forceinline__ DenseRaw4 dense_load4(const DenseCtx& c, int idx, int col0, bool vec) {
+  DenseRaw4 r;
+  if (vec) {
+    const v4f a = *reinterpret_cast<const v4f*>(c.bwd_flow + (size_t)idx * 2), b = *reinterpret_cast<const v4f*>(c.bwd_flow + (size_t)idx * 2 + 4);
+    const v4f w = *reinterpret_cast<const v4f*>(c.weights + idx), z = *reinterpret_cast<const v4f*>(c.depth_l + idx);
+    r.fx[0] = a.x, r.fy[0] = a.y, r.fx[1] = a.z, r.fy[1] = a.w, r.fx[2] = b.x, r.fy[2] = b.y, r.fx[3] = b.z, r.fy[3] = b.w;
+    r.wt[0] = w.x, r.wt[1] = w.y, r.wt[2] = w.z, r.wt[3] = w.w;
+    r.z[0] = z.x, r.z[1] = z.y, r.z[2] = z.z, r.z[3] = z.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool in = col0 + j < c.width;
+      const float2 fl = in ? reinterpret_cast<const float2*>(c.bwd_flow)[idx + j] : make_float2(0.f, 0.f);
+      r.fx[j] = fl.x, r.fy[j] = fl.y;
+      r.wt[j] = in ? c.weights[idx + j] : 0.f;
+      r.z[j] = in ? c.depth_l[idx + j] : 0.f;
+    }
+  }
+  return r;
+}
+__device__ __forceinline__ DenseRaw dense_raw_of(const DenseRaw4& r, int j) {
+  DenseRaw o;
+  o.fl = make_float2(r.fx[j], r.fy[j]);
+  o.wt = r.wt[j];
+  o.z = r.z[j];
   return o;
 }
 
@@ -814,20 +868,28 @@ __global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParam
   float acc[kMomentCount];
 #pragma unroll
   for (int k = 0; k < kMomentCount; ++k) acc[k] = 0.f;
-  const int col = c.tx0 + (threadIdx.x & (kTileW - 1));
-  int row = c.ty0 + threadIdx.x / kTileW;
-  const bool live = col < p.width;
-  const float u = center_fast(col, c.fw, c.rcp_w);
-  DenseRaw next = {};
-  if (live && row < p.height) next = dense_load(c, row * p.width + col);
+  const bool vec = (p.width & 3) == 0;
+  const int col0 = c.tx0 + 4 * (threadIdx.x & (kTileW / 4 - 1));
+  int row = c.ty0 + threadIdx.x / (kTileW / 4);
+  const bool live = col0 < p.width;
+  float u[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) u[j] = center_fast(col0 + j, c.fw, c.rcp_w);
+  DenseRaw4 next = {};
+  if (live && row < p.height) next = dense_load4(c, row * p.width + col0, col0, vec);
   __syncthreads();
-#pragma unroll FM_DENSE_UNROLL_MOMENTS
-  for (int k = 0; k < kRowsPerThread; ++k, row += 256 / kTileW) {
+#pragma unroll
+  for (int k = 0; k < kQuadPasses; ++k, row += kQuadRows) {
     if (!live || row >= p.height) break;
-    const DenseRaw cur = next;
-    if (k + 1 < kRowsPerThread && row + 256 / kTileW < p.height) next = dense_load(c, (row + 256 / kTileW) * p.width + col);
-    const DensePixel px = dense_pixel(c, win, cur, u, center_fast(row, c.fh, c.rcp_h));
-    dense_moments_add(px.g, px.h, px.w, gs, acc);
+    const DenseRaw4 cur = next;
+    if (k + 1 < kQuadPasses && row + kQuadRows < p.height) next = dense_load4(c, (row + kQuadRows) * p.width + col0, col0, vec);
+    const float v = center_fast(row, c.fh, c.rcp_h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (col0 + j >= p.width) break;
+      const DensePixel px = dense_pixel(c, win, dense_raw_of(cur, j), u[j], v);
+      dense_moments_add(px.g, px.h, px.w, gs, acc);
+    }
   }
   block_accumulate<kMomentCount>(acc, red, p.stats + c.pair * kStatStride);
 }
@@ -848,6 +910,7 @@ __global__ void procrustes_finish_solve_dense_kernel(ProcParams p, int pairs, fl
 // Per-pair constants of the dense backward, once per pair (fp64): consts (pairs, kDenseConstStride)
 // = DenseBwd (21 floats' worth), K_e (9), K_l (9).
 constexpr int kDenseConstStride = 40;
+constexpr int kFusedScaleSlot = 39;  // of a pair's row of consts: e with T < 2^e, the fused backward's fixed-point scale (>= 1e9: none usable)
 // (dL/dK⁻¹ of the pair's two frames is linear in the statistics of the forward pass: fm_pose_solve_bwd_kinv has written it.)
 __global__ void __launch_bounds__(64) procrustes_dense_consts_kernel(ProcParams p, const double* aux, int pairs, double* consts) {
   const int pair = blockIdx.x * blockDim.x + threadIdx.x;
@@ -859,6 +922,17 @@ __global__ void __launch_bounds__(64) procrustes_dense_consts_kernel(ProcParams 
                    p.kinv + ((size_t)b * p.frames + i + 1) * 9, c, o + 21, o + 30);
   const float* f = c.bm;
   for (int k = 0; k < 21; ++k) o[k] = (double)f[k];  // bm, a0, b0, gbar, hbar are contiguous
+  // the fused backward's fixed-point scale (see there): the typical tap magnitude of the pair, T < 2^e
+  double t = 0.0;
+  for (int a = 0; a < 3; ++a)
+    t += fabs((double)c.bm[a * 3 + 0] * c.gbar[0]) + fabs((double)c.bm[a * 3 + 1] * c.gbar[1]) + fabs((double)c.bm[a * 3 + 2] * c.gbar[2]) + fabs((double)c.b0[a]);
+  const double wsum = aux[(size_t)pair * kAuxStride + 27];
+  const double wmean = fabs(wsum) / ((double)p.height * p.width);
+  t *= wmean > 1e-30 ? wmean : 1.0;
+  int e = 0;
+  const bool ok = t > 1e-300 && t < 1e300;
+  if (ok) (void)frexp(t, &e);
+  o[kFusedScaleSlot] = (ok && e > -90 && e < 90) ? (double)e : 2.0e9;  // (outside: every tap goes to memory directly)
 }
 
 __device__ __forceinline__ DenseBwd dense_load_consts(const double* consts, size_t pair) {
@@ -911,6 +985,127 @@ __global__ void __launch_bounds__(256, FM_DENSE_LATER_BLOCKS) procrustes_dense_b
     if (c.sens != 0.f) gw *= c.sens * px.w * (1.f - px.w);  // d sigmoid(s·x)/dx
     if (gw_out) gw_out[idx] = gw;
     if (gd_out) gd_out[idx] = gd_cur + px.w * fmaf(sv[0], u, fmaf(sv[1], v, sv[2]));
+  }
+}
+
+// Dense backward, BOTH roles in one pass over the later frame's pixels (the default; the planned pair of kernels above and
+// below is kept for callers that want dL/ddepth bit-reproducible).  One read of (flow, weight, z) and one evaluation of the
+// correspondence serve dL/dweights, the later pixel's own dL/ddepth and the four tap gradients of the earlier frame, which
+// the two-kernel form pays for twice (its tap kernel re-derives β and the taps of 1.05 list entries per pixel).  The tap
+// gradients are summed in an LDS image of the earlier-frame WINDOW the block has staged anyway — 64-bit integer atomics in
+// fixed point — and the image is flushed to dL/ddepth with hardware float atomics (global_atomic_add_f32; neighbouring
+// blocks' windows overlap).  The later pixel's own gradient is an atomic add too: in this launch frame f receives the later
+// role of pair f-1 and the tap role of pair f concurrently.
+//
+// The fixed-point scale is per PAIR and needs no pass over the pixels: the consts kernel derives a typical tap magnitude
+// T = w̄·Σ_a (Σ_d |Bm_ad|·|ḡ_d| + |b0_a|) from the pair's constants (ḡ: the weighted centroid, w̄: the mean weight) and
+// values are scaled so that T ↦ 2^32 (kFusedMagic below).  A correspondence whose |β| exceeds 2^7·T — an outlier depth, a
+// weight far above the mean — does not fit the 2048-contributions-per-cell headroom of the sums and sends its taps to memory
+// directly as float atomics, exactly like a tap outside the window: any input is summed correctly, only the typical ones
+// take the LDS path.
+#ifndef FM_DENSE_FUSED_WIN_ROWS
+#define FM_DENSE_FUSED_WIN_ROWS 8
+#define FM_DENSE_FUSED_WIN_COLS 16
+#endif
+#ifndef FM_DENSE_FUSED_BLOCKS
+#define FM_DENSE_FUSED_BLOCKS 4
+#endif
+#ifndef FM_DENSE_FUSED_UNROLL
+#define FM_DENSE_FUSED_UNROLL 2
+#endif
+#ifndef FM_DENSE_FUSED_SKIP  // timing experiments only (tools/dense_microbench.py): 1 = plain store for the later pixel (racy), 2 = no flush, 4 = no taps
+#define FM_DENSE_FUSED_SKIP 0
+#endif
+#ifndef FM_DENSE_FUSED_PAD   // timing experiments only: extra LDS per block (occupancy)
+#define FM_DENSE_FUSED_PAD 0
+#endif
+// Fixed point without a conversion sequence: for |x| < 2^51 the double x + 1.5·2^52 has the bit pattern M + round(x), M = 0x4338'0000'0000'0000,
+// and M's low 51 bits are zero — so 64-bit INTEGER sums of those patterns carry Σ round(x) in their low 51 bits (two's complement,
+// exact modulo 2^51) whatever the number of terms.  T ↦ 2^32 and a block adds at most 2048 values to a cell, each below 2^39 = 2^7·T:
+// |Σ| < 2^50.  Resolution 2^-32·T per contribution; the sums do not depend on the order of arrival.
+constexpr double kFusedMagic = 6755399441055744.0;  // 1.5·2^52
+constexpr int kFusedUnitBits = 32;
+constexpr float kFusedLimit = 549755813888.f;       // 2^39
+constexpr int kFusedWinH = kTileH + FM_DENSE_FUSED_WIN_ROWS, kFusedWinW = kTileW + FM_DENSE_FUSED_WIN_COLS;  // 40 x 80: 12.8 KB of depth + 25.6 KB of sums
+
+__global__ void __launch_bounds__(256, FM_DENSE_FUSED_BLOCKS) procrustes_dense_bwd_fused_kernel(ProcParams p, const double* consts, unsigned total) {
+  typedef DenseWindowT<kFusedWinH, kFusedWinW> Window;
+  __shared__ Window win;
+  __shared__ unsigned long long iacc[kFusedWinH * kFusedWinW];
+#if FM_DENSE_FUSED_PAD
+  __shared__ int pad[FM_DENSE_FUSED_PAD / 4];
+  if (total == 0xffffffffu) pad[threadIdx.x] = 1;
+#endif
+  const DenseBlock blk = dense_block(p.height, p.width, total);
+  if (!blk.valid) return;
+  const DenseCtx c = dense_ctx<kFusedWinH, kFusedWinW>(p, blk, true);
+  const size_t n = (size_t)p.height * p.width;
+  const DenseBwd cst = dense_load_consts(consts, c.pair);
+  const double scale_e = consts[c.pair * kDenseConstStride + kFusedScaleSlot];
+  const bool usable = scale_e < 1.0e9;
+  const int ex = usable ? (int)scale_e : 0;
+  const float scale = usable ? ldexpf(1.0f, kFusedUnitBits - ex) : __builtin_nanf("");  // T·scale = 2^32 (NaN: every comparison below fails, every tap goes to memory)
+  const double unscale = ldexp(1.0, ex - kFusedUnitBits);
+  stage_depth_window(c, win);
+  for (int i = threadIdx.x; i < kFusedWinH * kFusedWinW; i += 256) iacc[i] = 0ull;
+  const int col = c.tx0 + (threadIdx.x & (kTileW - 1));
+  int row = c.ty0 + threadIdx.x / kTileW;
+  const bool live = col < p.width;
+  const float u = center_fast(col, c.fw, c.rcp_w);
+  float* gw_out = p.grad_weights ? p.grad_weights + c.pair * n : nullptr;
+  float* gd_l = p.grad_depth ? p.grad_depth + (c.fe + 1) * n : nullptr;
+  float* gd_e = p.grad_depth ? p.grad_depth + c.fe * n : nullptr;
+  DenseRaw next = {};
+  if (live && row < p.height) next = dense_load(c, row * p.width + col);
+  __syncthreads();
+#pragma unroll FM_DENSE_FUSED_UNROLL
+  for (int k = 0; k < kRowsPerThread; ++k, row += 256 / kTileW) {
+    if (!live || row >= p.height) break;
+    const int idx = row * p.width + col;
+    const DenseRaw cur = next;
+    if (k + 1 < kRowsPerThread && row + 256 / kTileW < p.height) next = dense_load(c, idx + (256 / kTileW) * p.width);
+    const float v = center_fast(row, c.fh, c.rcp_h);
+    const DensePixel px = dense_pixel(c, win, cur, u, v);
+    float tv[3], gc[3], sv[3], gw;
+    dense_bwd_t(cst, px.g, tv, gc);
+    dense_bwd_s(cst, px.h, tv, gc, sv, gw);
+    if (c.sens != 0.f) gw *= c.sens * px.w * (1.f - px.w);  // d sigmoid(s·x)/dx
+    if (gw_out) gw_out[idx] = gw;
+    if (!gd_l) continue;
+    if (FM_DENSE_FUSED_SKIP & 1) gd_l[idx] += px.w * fmaf(sv[0], u, fmaf(sv[1], v, sv[2]));
+    else atomicAdd(gd_l + idx, px.w * fmaf(sv[0], u, fmaf(sv[1], v, sv[2])));
+    if (FM_DENSE_FUSED_SKIP & 4) continue;
+    // β = w·t = K⁻ᵀ_e·dL/dq; a tap's value is w_k·(β·[u_k, v_k, 1]) with w_k <= 1 and u_k, v_k in (0, 1): below |β0| + |β1| + |β2|
+    const float b0 = px.w * tv[0], b1 = px.w * tv[1], b2 = px.w * tv[2];
+    const float bsum = (fabsf(b0) + fabsf(b1)) + fabsf(b2);
+    if (px.cell >= 0 && bsum * scale < kFusedLimit) {  // (false for a non-finite β and when the pair has no usable scale: scale = NaN)
+      const float sb0 = b0 * scale, sb1 = b1 * scale, sb2 = b2 * scale;
+      unsigned long long* cell = iacc + px.cell;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (!px.taps.in[t]) continue;
+        const float sval = px.taps.w[t] * fmaf(sb0, (t & 1) ? px.u1 : px.u0, fmaf(sb1, (t >> 1) ? px.v1 : px.v0, sb2));
+        // round(sval) as a 64-bit integer in two instructions: the low 51 bits of the double (sval + 1.5·2^52)
+        atomicAdd(cell + (t >> 1) * kFusedWinW + (t & 1), (unsigned long long)__double_as_longlong((double)sval + kFusedMagic));
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (!px.taps.in[t]) continue;
+        const float f0 = fabsf(b0) <= 3.0e38f ? b0 : 0.f, f1 = fabsf(b1) <= 3.0e38f ? b1 : 0.f, f2 = fabsf(b2) <= 3.0e38f ? b2 : 0.f;  // as the planned kernel: a non-finite gradient contributes nothing here
+        const float val = px.taps.w[t] * fmaf(f0, (t & 1) ? px.u1 : px.u0, fmaf(f1, (t >> 1) ? px.v1 : px.v0, f2));
+        if (val != 0.f) atomicAdd(gd_e + (size_t)(px.taps.y0 + (t >> 1)) * p.width + (px.taps.x0 + (t & 1)), val);
+      }
+    }
+  }
+  if (!gd_e || (FM_DENSE_FUSED_SKIP & 2)) return;
+  __syncthreads();
+  // the window's sums -> dL/ddepth of the earlier frame (only cells inside the image ever receive a tap)
+  for (int i = threadIdx.x; i < kFusedWinH * kFusedWinW; i += 256) {
+    const long long v = ((long long)(iacc[i] << 13)) >> 13;  // the low 51 bits, sign-extended
+    if (v == 0) continue;
+    const int r = i / kFusedWinW, q = i - r * kFusedWinW;
+    atomicAdd(gd_e + (size_t)(c.wy0 + r) * p.width + (c.wx0 + q), (float)((double)v * unscale));
   }
 }
 
@@ -2046,7 +2241,7 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
                                 double* consts, void* stream) {
   FM_CHECK_ARG(depth && kinv && bwd_flow && weights && aux && pair_grad && consts && batch >= 1 && frames >= 2);
   FM_CHECK_ARG(height >= 1 && width >= 1 && height <= 65535 && width <= 65535 && (long)height * width < (1L << 30));
-  FM_CHECK_ARG(!grad_depth || (first && list));
+  FM_CHECK_ARG((first == nullptr) == (list == nullptr));  // both: the planned pair of kernels; neither: one fused pass with atomics
   const int pairs = batch * (frames - 1);
   FM_CHECK_ARG(dense_blocks(height, width, pairs) < (1L << 31) - kXcds);
   hipStream_t st = (hipStream_t)stream;
@@ -2057,6 +2252,11 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
   proc_layouts(p, nullptr, frames, height, width);
   const unsigned total = (unsigned)dense_blocks(height, width, pairs);
   hipLaunchKernelGGL(procrustes_dense_consts_kernel, dim3((pairs + 63) / 64), dim3(64), 0, st, p, aux, pairs, consts);
+  if (!first) {
+    if (grad_depth || grad_weights)
+      hipLaunchKernelGGL(procrustes_dense_bwd_fused_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, consts, total);
+    FM_LAUNCH_STATUS();
+  }
   if (grad_depth || grad_weights)
     hipLaunchKernelGGL(procrustes_dense_bwd_later_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, consts, total);
   if (grad_depth) hipLaunchKernelGGL(procrustes_dense_bwd_taps_kernel, dim3(dense_grid(total)), dim3(256), 0, st, p, consts, first, list, total);

@@ -585,7 +585,10 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       g_src = carried.defined() ? carried : at::zeros(src.sizes(), src.options());  // (dense, whatever the strides of a window)
       for (auto& scatter : pending) scatter(g_src);
     }
-    const bool dense = from_depth && !indices.defined() && rep == 1 && h <= 65535 && w <= 65535 && (!need_src || dense_first.defined());
+    // every pixel a correspondence: the tiled dense kernels — one fused pass with atomics, or, when the caller built the static tap lists
+    // (flowmap_amd.set_dense_procrustes_planned), the planned pair of kernels whose dL/ddepth is bit-reproducible
+    const bool dense = from_depth && !indices.defined() && rep == 1 && h <= 65535 && w <= 65535 &&
+                       (!need_src || dense_first.defined() || (src.is_contiguous() && bwd_flow.is_contiguous() && weights.is_contiguous()));
     const bool planned = from_depth && indices.defined() && rep == 1 && plan_pixels.defined();
     bool arena_used = false;
     if (need_w) {
@@ -627,7 +630,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                 kinv_acc.defined() ? (long)kinv_acc.numel() : 0L, scope.stream);
       }
       double* per_point_k = k_closed_form ? nullptr : ptr<double>(kinv_acc);
-      if (dense) {  // every pixel a correspondence: tiled, planned, no atomics
+      if (dense) {  // every pixel a correspondence: tiled (fused pass, or planned without atomics)
         TORCH_CHECK(!need_k || k_closed_form, "flowmap_amd: the dense Procrustes backward derives dL/dK from the forward statistics (no batch repeat)");
         Tensor consts = at::empty({pairs, FM_DENSE_CONST_STRIDE}, weights.options().dtype(at::kDouble));
         FM_CALL(fm_procrustes_scatter_dense, ptr(src), ptr(kinv), ptr(bwd_flow), ptr(weights), sens, (int)b, (int)f, (int)h, (int)w,

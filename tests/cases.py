@@ -865,13 +865,18 @@ def case_dense_procrustes(dev, h, w, flow_sigma, f=4):
     ((rel64 * cot_b.double()).sum() + (torch.linalg.inv(rel64) * cot_f.double()).sum()).backward()
 
     res = {}
-    for name, idx in (("tiled", None), ("generic", torch.arange(h * w, device=dev))):
+    for name, idx, planned in (("tiled", None, False), ("tiled_planned", None, True), ("generic", torch.arange(h * w, device=dev), False)):
         d, kk, lg = (x.clone().to(dev).requires_grad_(True) for x in (depth, k, logits))
-        fl_dev = flow.to(dev)
-        t_bwd, t_fwd = _ops.ProcrustesFit.apply(d, kk, None, lg, fl_dev, idx, 100.0, 1)
+        fl_dev = flow.clone().to(dev)
+        _ops.use_dense_plan = planned
+        try:
+            t_bwd, t_fwd = _ops.ProcrustesFit.apply(d, kk, None, lg, fl_dev, idx, 100.0, 1)
+        finally:
+            _ops.use_dense_plan = False
         ((t_bwd * cot_b.to(dev)).sum() + (t_fwd * cot_f.to(dev)).sum()).backward()
         res[name] = (t_bwd.detach(), d.grad, lg.grad, kk.grad)
-        if idx is None:
+        assert ("_fm_dense_plan" in fl_dev.__dict__) == planned  # the fused pass (the default) builds no lists
+        if planned:
             res["plan"] = fl_dev._fm_dense_plan[1]
     truth = (rel64.detach(), d64.grad, l64.grad, k64.grad)
     # the static tap lists: one entry per (later pixel, earlier-frame tile its taps touch), every tile's list ascending
@@ -882,12 +887,15 @@ def case_dense_procrustes(dev, h, w, flow_sigma, f=4):
         seg = entries[lo:hi]
         assert (seg[1:] > seg[:-1]).all(), "tile list not in ascending pixel order"
         assert ((seg >> 16) < h).all() and ((seg & 0xFFFF) < w).all()
-    for a, b, c, what in zip(res["tiled"], res["generic"], truth, ("t_bwd", "g_depth", "g_logits", "g_k")):
-        assert torch.isfinite(a).all(), what
-        assert_close(a, c, TOL, what=f"{what} vs fp64 oracle")
-        assert_close(a, b, TOL, abs_=1e-7, what=f"{what} vs generic kernels")
-    assert maxerr(res["tiled"][1], truth[1]) <= 10 * TOL, "g_depth: max-abs"
-    assert maxerr(res["tiled"][2], truth[2]) <= 10 * TOL, "g_logits: max-abs"
+    for mode in ("tiled", "tiled_planned"):
+        for a, b, c, what in zip(res[mode], res["generic"], truth, ("t_bwd", "g_depth", "g_logits", "g_k")):
+            assert torch.isfinite(a).all(), (mode, what)
+            assert_close(a, c, TOL, what=f"{mode}: {what} vs fp64 oracle")
+            assert_close(a, b, TOL, abs_=1e-7, what=f"{mode}: {what} vs generic kernels")
+        assert maxerr(res[mode][1], truth[1]) <= 10 * TOL, f"{mode}: g_depth: max-abs"
+        assert maxerr(res[mode][2], truth[2]) <= 10 * TOL, f"{mode}: g_logits: max-abs"
+    assert_close(res["tiled"][1], res["tiled_planned"][1], 1e-6, what="g_depth: fused pass vs planned kernels")
+    assert_close(res["tiled"][2], res["tiled_planned"][2], 1e-6, what="g_logits: fused pass vs planned kernels")
 
 
 def _small_problem(dev, f=5, h=24, w=32, points=60, tracking=True, seed=21, intrinsics=None):

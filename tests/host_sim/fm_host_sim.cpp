@@ -549,7 +549,7 @@ int fm_procrustes_dense_plan(const float* bwd_flow, int batch, int frames, int h
 int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const float* bwd_flow, const float* weights, float sens, int batch,
                                 int frames, int height, int width, const double* aux, const double* pair_grad, float* grad_depth,
                                 float* grad_weights, const int64_t* first, const uint32_t* list, double*, void*) {
-  if (!depth || !kinv || !bwd_flow || !weights || !aux || !pair_grad || (grad_depth && (!first || !list))) return 1;
+  if (!depth || !kinv || !bwd_flow || !weights || !aux || !pair_grad || ((first == nullptr) != (list == nullptr))) return 1;
   int tiles = 0;
   fm_procrustes_dense_tiles(height, width, &tiles);
   const int tiles_x = (width + kDenseTileW - 1) / kDenseTileW;
@@ -596,6 +596,27 @@ int fm_procrustes_scatter_dense(const float* depth, const float* kinv, const flo
       if (num > 1e-6 * den + 1e-30) return 3;  // (1e-3 relative: the per-pixel sums are fp32 products)
     }
     if (!grad_depth) continue;
+    if (!first) {  // the fused pass: every later pixel adds its four taps where they land (the device: LDS window sums + atomics)
+      for (int row = 0; row < height; ++row)
+        for (int col = 0; col < width; ++col) {
+          const size_t idx = (size_t)row * width + col;
+          const float fw = (float)width, fh = (float)height;
+          const float u = center_fast(col, fw, 1.0f / fw), v = center_fast(row, fh, 1.0f / fh);
+          float w = src.weights[idx];
+          if (sens != 0.f) w = fm_sigmoid<false>(sens * w);
+          const float z = src.depth_l[idx];
+          const float g[3] = {z * u, z * v, z};
+          float tv[3], gc[3];
+          dense_bwd_t(c, g, tv, gc);
+          const Taps tp = dense_taps(u + src.bwd_flow[2 * idx], v + src.bwd_flow[2 * idx + 1], height, width);
+          for (int k = 0; k < 4; ++k) {
+            if (!tp.in[k]) continue;
+            const int y = tp.y0 + (k >> 1), x = tp.x0 + (k & 1);
+            grad_depth[fe * n + (size_t)y * width + x] += tp.w[k] * fmaf(w * tv[0], center_fast(x, fw, 1.0f / fw), fmaf(w * tv[1], center_fast(y, fh, 1.0f / fh), w * tv[2]));
+          }
+        }
+      continue;
+    }
     // earlier role: per tile of the earlier frame, the listed later pixels (only taps inside the tile count)
     for (int tile = 0; tile < tiles; ++tile) {
       const int tx0 = (tile % tiles_x) * kDenseTileW, ty0 = (tile / tiles_x) * kDenseTileH;

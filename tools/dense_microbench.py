@@ -24,6 +24,10 @@ logit = 0.01 * torch.randn((1, f - 1, h, w), device=dev, generator=g)
 flows = {"iid": 0.01 * torch.randn((1, f - 1, h, w, 2), device=dev, generator=g)}
 low = 0.01 * torch.randn((f - 1, 2, h // 40, w // 40), device=dev, generator=g)
 flows["smooth"] = torch.nn.functional.interpolate(low, size=(h, w), mode="bicubic", align_corners=False).permute(0, 2, 3, 1)[None].contiguous()
+low = 0.01 * torch.randn((f - 1, 2, 3, 5), device=dev, generator=g)  # a few pixels of variation across a tile: what a real camera motion gives
+flows["gentle"] = torch.nn.functional.interpolate(low, size=(h, w), mode="bicubic", align_corners=False).permute(0, 2, 3, 1)[None].contiguous()
+if len(sys.argv) > 2:
+    flows = {k: v for k, v in flows.items() if k in sys.argv[2].split(",")}
 fx = 0.85 * (h * w) ** 0.5
 k = torch.tensor([[fx / w, 0, 0.5], [0, fx / h, 0.5], [0, 0, 1.0]], device=dev).expand(1, f, 3, 3).contiguous()
 kinv = torch.linalg.inv(k).contiguous()
@@ -87,13 +91,23 @@ for name, path in libs.items():
         fit()
         assert lib.fm_pose_solve_bwd(P(g_t), None, P(t_bwd), P(aux), pairs, P(pair_grad), None, 0, st) == 0
 
+        def fused():
+            assert lib.fm_procrustes_scatter_dense(P(depth), P(kinv), P(flow), P(logit), 100.0, 1, f, h, w, P(aux), P(pair_grad), P(g_depth), P(g_w), None, None, P(consts), st) == 0
+
         def later_only():
             assert lib.fm_procrustes_scatter_dense(P(depth), P(kinv), P(flow), P(logit), 100.0, 1, f, h, w, P(aux), P(pair_grad), None, P(g_w), None, None, P(consts), st) == 0
 
         def both():
             assert lib.fm_procrustes_scatter_dense(P(depth), P(kinv), P(flow), P(logit), 100.0, 1, f, h, w, P(aux), P(pair_grad), P(g_depth), P(g_w), P(first), P(entries), P(consts), st) == 0
 
-        a, b, c = timed(fit), timed(later_only), timed(both)
-        out[f"{name}/{kind}"] = {"fit_ms": round(a, 3), "later_no_depth_ms": round(b, 3), "later_plus_taps_ms": round(c, 3), "entries_per_pixel": round(entries.numel() / (pairs * h * w), 4)}
+        a, b, c, d = timed(fit), timed(later_only), timed(both), timed(fused)
+        g_depth.zero_()
+        both()
+        planned = g_depth.clone()
+        g_depth.zero_()
+        fused()
+        gap = float((g_depth - planned).norm() / planned.norm())
+        out[f"{name}/{kind}"] = {"fit_ms": round(a, 3), "weights_only_ms": round(b, 3), "later_plus_taps_ms": round(c, 3), "fused_ms": round(d, 3),
+                                 "fused_vs_planned": gap, "entries_per_pixel": round(entries.numel() / (pairs * h * w), 4)}
         print(name, kind, out[f"{name}/{kind}"], flush=True)
 print(json.dumps(out))
