@@ -120,6 +120,98 @@ __device__ __forceinline__ void load_quad_packed(QuadIn& q, const float* depth, 
   }
 }
 
+// ---------------------------------------------------------------------------------
+// The two residual terms of a pixel — towards the next frame and towards the previous one — as ONE pass of packed fp32
+// arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fp32 per issue slot).  The kernel is bound by
+// VALU issue, not by HBM (rocprofv3 SQ_INSTS_VALU: 168 instructions per pixel = 0.70 of its 0.78 ms at the 2.0-2.1 GHz the
+// part sustains here); the two terms run the same ~60 operations on different constants, flows and masks, so component x
+// carries the forward term and component y the backward one.  Each component performs exactly the operations of
+// flow_term_fast (fm_math.h) in the same order: the results are bit-identical to the scalar form the host double runs.
+// ---------------------------------------------------------------------------------
+struct DirPair {
+  v2f au, a1, a2, ta, bu, b1, b2, tb, cu, c1, c2, tc;
+};
+__device__ __forceinline__ v2f pk(float x, float y) {
+  v2f r;
+  r.x = x, r.y = y;
+  return r;
+}
+__device__ __forceinline__ v2f pk1(float x) { return pk(x, x); }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// kf / kb: 1 for a direction the frame has, 0 for one it has not (its constants are zeroed, whatever they were computed from)
+__device__ __forceinline__ DirPair make_pair(const DirConst& f, const DirConst& b, float kf, float kb) {
+  DirPair d;
+  auto two = [&](float x, float y) { return pk(kf != 0.f ? x : 0.f, kb != 0.f ? y : 0.f); };
+  d.au = two(f.au, b.au), d.a1 = two(f.a1, b.a1), d.a2 = two(f.a2, b.a2), d.ta = two(f.ta, b.ta);
+  d.bu = two(f.bu, b.bu), d.b1 = two(f.b1, b.b1), d.b2 = two(f.b2, b.b2), d.tb = two(f.tb, b.tb);
+  d.cu = two(f.cu, b.cu), d.c1 = two(f.c1, b.c1), d.c2 = two(f.c2, b.c2), d.tc = two(f.tc, b.tc);
+  return d;
+}
+
+// arow / brow / crow = a1·v + a2 etc. (constant along an image row).  A direction the frame does not have (first / last frame
+// of the video) runs on zero constants, zero flows and a zero mask: every sum it adds is exactly zero.
+template <int KIND, bool GRAD>
+__device__ __forceinline__ void flow_term_pair(const DirPair& d, v2f arow, v2f brow, v2f crow, float z, float u, float zu, float zv, float u_ax,
+                                               float v_ay, v2f flow_x, v2f flow_y, v2f m, float scale, float delta, float inv_delta,
+                                               float ax, float ay, v2f (&acc)[kFlowAcc], float& gz) {
+  const v2f u2 = pk1(u), z2 = pk1(z);
+  const v2f a = pk_fma(d.au, u2, arow);
+  const v2f b = pk_fma(d.bu, u2, brow);
+  const v2f c = pk_fma(d.cu, u2, crow);
+  const v2f xu = pk_fma(z2, a, d.ta);
+  const v2f xv = pk_fma(z2, b, d.tb);
+  const v2f x2 = pk_fma(z2, c, d.tc);
+  const v2f den = x2 + pk1(kProjEps);
+  v2f q = pk(fm_rcp(den.x), fm_rcp(den.y));
+  const bool ok_x = fabsf(q.x) <= 3.0e38f, ok_y = fabsf(q.y) <= 3.0e38f;
+  q = pk(ok_x ? q.x : 0.f, ok_y ? q.y : 0.f);
+  m = pk(ok_x ? m.x : 0.f, ok_y ? m.y : 0.f);
+  const v2f pu = xu * q;
+  const v2f pv = xv * q;
+  const v2f rx = pu - pk_fma(flow_x, pk1(ax), pk1(u_ax));
+  const v2f ry = pv - pk_fma(flow_y, pk1(ay), pk1(v_ay));
+  const v2f ss = pk_fma(rx, rx, ry * ry);
+  v2f rho, coef;  // ρ and dρ/dr = coef·r
+  if (KIND == kL2) {
+    rho = pk1(0.5f) * ss;
+    coef = pk1(1.f);
+  } else {
+    const v2f inv_n = pk(ss.x > 0.f ? fm_rsq(ss.x) : 0.f, ss.y > 0.f ? fm_rsq(ss.y) : 0.f);
+    const v2f n = ss * inv_n;
+    if (KIND == kL1) {
+      rho = n;
+      coef = inv_n;
+    } else {
+      const bool quad_x = n.x < delta, quad_y = n.y < delta;
+      const v2f inner = (pk1(0.5f) * ss) * pk1(inv_delta), outer = n - pk1(0.5f * delta);
+      rho = pk(quad_x ? inner.x : outer.x, quad_y ? inner.y : outer.y);
+      coef = pk(quad_x ? inv_delta : inv_n.x, quad_y ? inv_delta : inv_n.y);
+    }
+  }
+  acc[0] = pk_fma(rho, m, acc[0]);
+  if (GRAD) {
+    const v2f gc = (pk1(scale) * m) * coef;
+    const v2f wu = gc * rx, wv = gc * ry;  // dL/d(kd·p)
+    const v2f o0 = q * wu, o1 = q * wv, o2 = q * pk_fma(wu, pu, wv * pv);
+    const v2f zu2 = pk1(zu), zv2 = pk1(zv);
+    acc[1] += o0;
+    acc[2] += o1;
+    acc[3] += o2;
+    acc[4] = pk_fma(o0, zu2, acc[4]);
+    acc[5] = pk_fma(o0, zv2, acc[5]);
+    acc[6] = pk_fma(o0, z2, acc[6]);
+    acc[7] = pk_fma(o1, zu2, acc[7]);
+    acc[8] = pk_fma(o1, zv2, acc[8]);
+    acc[9] = pk_fma(o1, z2, acc[9]);
+    acc[10] = pk_fma(o2, zu2, acc[10]);
+    acc[11] = pk_fma(o2, zv2, acc[11]);
+    acc[12] = pk_fma(o2, z2, acc[12]);
+    const v2f g = pk_fma(o0, a, pk_fma(o1, b, -o2 * c));  // dL/dz = ω·(a, b, −c) of each direction
+    gz += g.x;
+    gz += g.y;
+  }
+}
+
 #ifndef FM_FLOW_WAVES
 // Waves per SIMD the register allocator must leave room for.  3 (<=168 VGPRs, 133 used, no
 // scratch) beat 4 (128 VGPRs) by 3-5 % and 2 by 4 % in interleaved A/B runs; 5 spills.
@@ -145,24 +237,23 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   for (int c = threadIdx.x; c < p.width; c += blockDim.x) u_tab[c] = pixel_center(c, p.width);
   __syncthreads();
 
-  DirConst df = {}, db = {};
   const size_t pair_f = (size_t)b * (p.frames - 1) + f;  // pair whose earlier frame is f
   const size_t pair_b = pair_f - 1;                       // pair whose later frame is f
+  DirConst df, db;
   {
+    // (both directions unconditionally, on in-range stand-ins where the frame has no such neighbour — conditional initialisation
+    // of the two structs costs a scratch allocation; the stand-in's constants are zeroed in make_pair)
     Mat3 kinv, kd;
     Pose t;
     load_mat3(p.kinv + (size_t)bf * 9, kinv);
-    if (has_fwd) {
-      load_mat3(p.k + (size_t)(bf + 1) * 9, kd);
-      load_pose44(p.t_fwd + pair_f * 16, t);
-      make_dir(t, kinv, kd, p.ax, p.ay, df);
-    }
-    if (has_bwd) {
-      load_mat3(p.k + (size_t)(bf - 1) * 9, kd);
-      load_pose44(p.t_bwd + pair_b * 16, t);
-      make_dir(t, kinv, kd, p.ax, p.ay, db);
-    }
+    load_mat3(p.k + (size_t)(has_fwd ? bf + 1 : bf) * 9, kd);
+    load_pose44(p.t_fwd + (has_fwd ? pair_f : pair_b) * 16, t);
+    make_dir(t, kinv, kd, p.ax, p.ay, df);
+    load_mat3(p.k + (size_t)(has_bwd ? bf - 1 : bf) * 9, kd);
+    load_pose44(p.t_bwd + (has_bwd ? pair_b : pair_f) * 16, t);
+    make_dir(t, kinv, kd, p.ax, p.ay, db);
   }
+  const DirPair dp = make_pair(df, db, has_fwd ? 1.f : 0.f, has_bwd ? 1.f : 0.f);  // (a direction this frame does not have: zeros)
   const float scale = GRAD ? p.scale[0] : 0.f;
   const float inv_delta = KIND == kHuber ? 1.0f / p.delta : 0.f;
 
@@ -175,14 +266,10 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   const float* packed = PACKED ? p.packed + (size_t)bf * chunks * (kPackVecs * kPackLanes * 4) : nullptr;
   float* gd = GRAD && p.grad_depth ? p.grad_depth + (size_t)bf * n : nullptr;
 
-  float acc_f[kFlowAcc], acc_b[kFlowAcc];
+  v2f acc[kFlowAcc];  // x: towards the next frame, y: towards the previous one
 #pragma unroll
-  for (int i = 0; i < kFlowAcc; ++i) acc_f[i] = acc_b[i] = 0.f;
+  for (int i = 0; i < kFlowAcc; ++i) acc[i] = pk1(0.f);
 
-  // The direction tests below are wave-uniform run-time branches ON PURPOSE: they keep each
-  // residual's loads and ~95 ops together.  With compile-time direction flags the
-  // scheduler hoists all seven 16-byte loads and interleaves the eight residuals of a
-  // quad, and the kernel spills (measured: 336 B/lane scratch, +40 % instructions).
   const int base = blockIdx.x * (blockDim.x * p.iters);
 
   // Everything after the loads of one item: coordinates, both residual terms per pixel, store.
@@ -194,19 +281,15 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
     const float v = pixel_center(row, p.height);
     const float v_ay = v * p.ay;
     // a1·v + a2 (and b, c alike) is constant along the image row the quad lies in
-    const float rf0 = fmaf(df.a1, v, df.a2), rf1 = fmaf(df.b1, v, df.b2), rf2 = fmaf(df.c1, v, df.c2);
-    const float rb0 = fmaf(db.a1, v, db.a2), rb1 = fmaf(db.b1, v, db.b2), rb2 = fmaf(db.c1, v, db.c2);
+    const v2f v2 = pk1(v);
+    const v2f arow = pk_fma(dp.a1, v2, dp.a2), brow = pk_fma(dp.b1, v2, dp.b2), crow = pk_fma(dp.c1, v2, dp.c2);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float u = u_tab[col0 + e];
       const float zu = z[e] * u, zv = z[e] * v, u_ax = u * p.ax;
       gz[e] = 0.f;
-      if (has_fwd)
-        flow_term_fast<KIND, GRAD>(df, rf0, rf1, rf2, z[e], u, zu, zv, u_ax, v_ay, fxf[e], fyf[e], mmf[e], scale, p.delta, inv_delta, p.ax,
-                                   p.ay, acc_f, gz[e]);
-      if (has_bwd)
-        flow_term_fast<KIND, GRAD>(db, rb0, rb1, rb2, z[e], u, zu, zv, u_ax, v_ay, fxb[e], fyb[e], mmb[e], scale, p.delta, inv_delta, p.ax,
-                                   p.ay, acc_b, gz[e]);
+      flow_term_pair<KIND, GRAD>(dp, arow, brow, crow, z[e], u, zu, zv, u_ax, v_ay, pk(fxf[e], fxb[e]), pk(fyf[e], fyb[e]), pk(mmf[e], mmb[e]),
+                                 scale, p.delta, inv_delta, p.ax, p.ay, acc, gz[e]);
     }
     if (ADAM) {
       // depth, exp_avg, exp_avg_sq of this quad rewritten in place (model_wrapper_overfit.py:104-105: torch.optim.Adam);
@@ -269,7 +352,7 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
       compute_quad(q, item);
       continue;
     }
-    float z[VEC], fxf[VEC], fyf[VEC], mmf[VEC], fxb[VEC], fyb[VEC], mmb[VEC];
+    float z[VEC], fxf[VEC] = {}, fyf[VEC] = {}, mmf[VEC] = {}, fxb[VEC] = {}, fyb[VEC] = {}, mmb[VEC] = {};  // (an absent direction: zeros)
     if (VEC == 2) {
       const v2f zq = ld2(depth, item);
       z[0] = zq.x; z[VEC - 1] = zq.y;
@@ -300,6 +383,9 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   }
 
   double* dst = p.acc + (size_t)bf * 2 * kFlowAccStride;
+  float acc_f[kFlowAcc], acc_b[kFlowAcc];
+#pragma unroll
+  for (int i = 0; i < kFlowAcc; ++i) acc_f[i] = acc[i].x, acc_b[i] = acc[i].y;
   if (has_fwd) block_accumulate<kFlowAcc>(acc_f, red, dst);
   if (has_bwd) block_accumulate<kFlowAcc>(acc_b, red, dst + kFlowAccStride);
 }

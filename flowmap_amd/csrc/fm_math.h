@@ -359,14 +359,16 @@ FM_HD void make_dir(const Pose& pose, const Mat3& kinv, const Mat3& kd, float ax
     k0[i] = (double)kd.m[i] * ax;
     k1[i] = (double)kd.m[3 + i] * ay;
   }
-  float* a = &d.au;
-  float* b = &d.bu;
-  float* c = &d.cu;
-  for (int j = 0; j < 3; ++j) {
-    a[j] = (float)(k0[0] * m[j] + k0[1] * m[3 + j] + k0[2] * m[6 + j]);
-    b[j] = (float)(k1[0] * m[j] + k1[1] * m[3 + j] + k1[2] * m[6 + j]);
-    c[j] = (float)m[6 + j];
-  }
+  // (field by field: indexing through a pointer into the struct sends it to scratch memory on the device)
+  d.au = (float)(k0[0] * m[0] + k0[1] * m[3] + k0[2] * m[6]);
+  d.a1 = (float)(k0[0] * m[1] + k0[1] * m[4] + k0[2] * m[7]);
+  d.a2 = (float)(k0[0] * m[2] + k0[1] * m[5] + k0[2] * m[8]);
+  d.bu = (float)(k1[0] * m[0] + k1[1] * m[3] + k1[2] * m[6]);
+  d.b1 = (float)(k1[0] * m[1] + k1[1] * m[4] + k1[2] * m[7]);
+  d.b2 = (float)(k1[0] * m[2] + k1[1] * m[5] + k1[2] * m[8]);
+  d.cu = (float)m[6];
+  d.c1 = (float)m[7];
+  d.c2 = (float)m[8];
   d.ta = (float)(k0[0] * pose.t[0] + k0[1] * pose.t[1] + k0[2] * pose.t[2]);
   d.tb = (float)(k1[0] * pose.t[0] + k1[1] * pose.t[1] + k1[2] * pose.t[2]);
   d.tc = pose.t[2];
@@ -425,7 +427,7 @@ FM_HD void flow_term_fast(const DirConst& d, float arow, float brow, float crow,
     acc[10] = fmaf(o2, zu, acc[10]);
     acc[11] = fmaf(o2, zv, acc[11]);
     acc[12] = fmaf(o2, z, acc[12]);
-    gz = fmaf(o0, a, fmaf(o1, b, fmaf(-o2, c, gz)));  // dL/dz = ω·(a, b, −c)
+    gz += fmaf(o0, a, fmaf(o1, b, -o2 * c));  // dL/dz = ω·(a, b, −c)  (the term on its own, then added: what the device's packed pair of directions forms)
   }
 }
 

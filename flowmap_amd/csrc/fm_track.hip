@@ -147,34 +147,7 @@ __device__ __forceinline__ void wave_sum7_lane63(float& v0, float& v1, float& v2
 // v_add v, vdst, vdst; tools/probes/transpose_reduce_probe.hip).  16 registers -> 8 (lanes l, l+32) -> 4 (rows r, r+1) -> 2 (xor 8: two selects + one DPP add) -> 1 (half-row mirror) ->
 // the quad's two DPP steps: 35 instructions, and lane L ends with the wave total of value L >> 2 (one masked store by every fourth
 // lane instead of 14 stores by lane 63).  The fp32 summation tree differs from the per-value one in the last bits only.
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float wave_transpose_sum16(const float (&v)[16]) {
-  // the swaps of a round touch disjoint registers: one asm block per round, one leading s_nop for the VALU-write -> lane-swap hazard
-  float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
-  float b0 = v[8], b1 = v[9], b2 = v[10], b3 = v[11], b4 = v[12], b5 = v[13], b6 = v[14], b7 = v[15];
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %3, %11"
-               "\n\tv_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\tv_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15"
-               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5),
-                 "+v"(b6), "+v"(b7));
-  float r0 = a0 + b0, r1 = a1 + b1, r2 = a2 + b2, r3 = a3 + b3, r4 = a4 + b4, r5 = a5 + b5, r6 = a6 + b6, r7 = a7 + b7;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7"
-               : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
-  const float s[4] = {r0 + r4, r1 + r5, r2 + r6, r3 + r7};
-  const int lane = threadIdx.x & (kWave - 1);
-  const bool bit3 = (lane & 8) != 0, bit2 = (lane & 4) != 0;
-  // xor 8 inside a row: lanes with bit 3 clear keep s[j], the others s[j+2]; what a lane does not keep goes to its partner
-  const float u0 = (bit3 ? s[2] : s[0]) + dpp_move<0x128>(bit3 ? s[0] : s[2]);  // row_ror:8
-  const float u1 = (bit3 ? s[3] : s[1]) + dpp_move<0x128>(bit3 ? s[1] : s[3]);
-  // the two halves of an 8-lane group (mirror inside the half row pairs lane l with 7 - l: the other quad)
-  float w = (bit2 ? u1 : u0) + dpp_move<0x141>(bit2 ? u0 : u1);  // row_half_mirror
-  w += dpp_move<0xB1>(w);                                        // quad_perm:[1,0,3,2]
-  w += dpp_move<0x4E>(w);                                        // quad_perm:[2,3,0,1]
-  return w;  // lane L: the wave total of v[L >> 2]
-}
-
+// (wave_transpose_sum16: fm_device.h)
 // NV (a multiple of 7) per-lane values -> their wave totals in lane 63, in place
 template <int NV>
 __device__ __forceinline__ void wave_sum_lane63_x7(float (&v)[NV]) {
