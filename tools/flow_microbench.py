@@ -55,7 +55,9 @@ pack.argtypes = _lib.SIGNATURES["fm_flow_pack_inputs"]
 packed = torch.empty((f, (h * w // 4 + 63) // 64, 6, 64, 4), device=dev)
 assert pack(ff.data_ptr(), fb.data_ptr(), mf.data_ptr(), mb.data_ptr(), 1, f, h, w, packed.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
 PACKED = [False]
-configs = [(n, True, i, pk) for n in fns for i in (2, 4, 6, 8) for pk in (False, True)] + [("shipped", False, 4, False), ("shipped", False, 4, True)]
+IPT = tuple(int(x) for x in sys.argv[1].split(",")) if len(sys.argv) > 1 else (2, 4, 6, 8)
+PKS = (True,) if len(sys.argv) > 1 else (False, True)
+configs = [(n, True, i, pk) for n in fns for i in IPT for pk in PKS] + [("shipped", False, 4, False), ("shipped", False, 4, True)]
 times = {c: [] for c in configs}
 for rnd in range(6):
     for c in configs:
