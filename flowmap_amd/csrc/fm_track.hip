@@ -35,6 +35,17 @@
 
 namespace fm {
 
+// -DFM_TRACK_CLOCKS (tools/track_clocks.py): lane 0 of the first waves of track_pairs accumulates wall_clock64 (100 MHz) deltas per
+// phase — prologue, per target: scalar constants / residual terms / reduction + store, epilogue — read back by fm_debug_track_clocks.
+#ifdef FM_TRACK_CLOCKS
+constexpr int kTrackClockSlots = 8, kTrackClockWaves = 2048;
+__device__ long long fm_track_clock_buffer[kTrackClockWaves][kTrackClockSlots];
+#define FM_TCLK(var) const long long var = wall_clock64()
+#define FM_TCLK_ADD(slot, a, b) clk[slot] += (b) - (a)
+#else
+#define FM_TCLK(var)
+#define FM_TCLK_ADD(slot, a, b)
+#endif
 constexpr int kTrackTile = FM_TRACK_TILE;  // source frames per thread (registers: 2 x 3 x kTrackTile floats)
 __host__ __device__ constexpr size_t track_partial_stride(int fmax) { return (size_t)fmax * kTrackSums + kTrackTile * 21; }
 
@@ -241,11 +252,23 @@ struct TrackSampling {
 #define FM_TRACK_PG 2
 #endif
 constexpr int kTrackPG = FM_TRACK_PG;
+#ifndef FM_TRACK_AHEAD
+#define FM_TRACK_AHEAD 2
+#endif
+constexpr int kTrackAhead = FM_TRACK_AHEAD;  // target frames whose (visibility, position) loads are in flight
 
 template <int KIND, bool GRAD>
 __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(TrackGeom g, const int32_t* tiles, float* ws, uint8_t* flag,
                                                             const float* ext, const float* tgt, float delta, float ax, float ay, int fmax,
                                                             float* partial, float* gws, TrackSampling smp) {
+#ifdef FM_TRACK_LDS_PAD  // (experiments: fewer resident waves per CU)
+  __shared__ int lds_pad[FM_TRACK_LDS_PAD / 4];
+  if (fmax < 0) lds_pad[threadIdx.x] = 1;
+#endif
+#ifdef FM_TRACK_CLOCKS
+  long long clk[kTrackClockSlots] = {};
+#endif
+  FM_TCLK(c_begin);
   const float inv_delta = KIND == kHuber ? 1.0f / delta : 0.f;
   // this wave's slice of the partial-sum workspace: [fmax][14] target role, then [kTrackTile][21] source role
   float* mine = partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * track_partial_stride(fmax);
@@ -297,32 +320,54 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
     }
   }
 
-  // the target's visibility and position are prefetched one iteration ahead
+  // The target's visibility and position are prefetched kTrackAhead iterations ahead (2; 1, 4 and 8 measure the same: the loop is
+  // bound by VALU issue, 2.1 us per target with two waves on a SIMD — tools/track_clocks.py).
   size_t it[kTrackPG];
-  uint8_t tv_next[kTrackPG];
-  float2 gt_next[kTrackPG];
+  uint8_t tv_q[kTrackAhead][kTrackPG];
+  float2 gt_q[kTrackAhead][kTrackPG];
 #pragma unroll
   for (int q = 0; q < kTrackPG; ++q) {
     it[q] = (size_t)off + pp[q];
-    tv_next[q] = g.vis[it[q]];
-    gt_next[q] = reinterpret_cast<const float2*>(g.xy)[it[q]];
+#pragma unroll
+    for (int d = 0; d < kTrackAhead; ++d) {
+      tv_q[d][q] = 0;
+      gt_q[d][q] = make_float2(0.f, 0.f);
+      if (d < f) {
+        tv_q[d][q] = g.vis[it[q] + (size_t)d * p_count];
+        gt_q[d][q] = reinterpret_cast<const float2*>(g.xy)[it[q] + (size_t)d * p_count];
+      }
+    }
+    it[q] += (size_t)(kTrackAhead - 1) * p_count;  // (the element the loop's next load reads is one frame further)
   }
+  FM_TCLK(c_loop);
+  FM_TCLK_ADD(0, c_begin, c_loop);
   for (int ft = 0; ft < f; ++ft) {
+    FM_TCLK(c0);
     float tv[kTrackPG];
     float2 gt[kTrackPG];
 #pragma unroll
     for (int q = 0; q < kTrackPG; ++q) {
-      tv[q] = active[q] && tv_next[q] != 0 ? 1.f : 0.f;  // target role needs only the track's visibility (projection.py:290)
-      gt[q] = gt_next[q];
-      if (ft + 1 < f) {
-        it[q] += p_count;
-        tv_next[q] = g.vis[it[q]];
-        gt_next[q] = reinterpret_cast<const float2*>(g.xy)[it[q]];
+      tv[q] = active[q] && tv_q[0][q] != 0 ? 1.f : 0.f;  // target role needs only the track's visibility (projection.py:290)
+      gt[q] = gt_q[0][q];
+#pragma unroll
+      for (int d = 0; d + 1 < kTrackAhead; ++d) {
+        tv_q[d][q] = tv_q[d + 1][q];
+        gt_q[d][q] = gt_q[d + 1][q];
+      }
+      it[q] += p_count;
+      if (ft + kTrackAhead < f) {
+        tv_q[kTrackAhead - 1][q] = g.vis[it[q]];
+        gt_q[kTrackAhead - 1][q] = reinterpret_cast<const float2*>(g.xy)[it[q]];
       }
     }
     float tg[kTrackTgt];
 #pragma unroll
     for (int i = 0; i < kTrackTgt; ++i) tg[i] = tgt[(size_t)(start + ft) * kTrackTgt + i];  // wave-uniform: scalar loads
+#ifdef FM_TRACK_CLOCKS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    FM_TCLK(c1);
+    FM_TCLK_ADD(1, c0, c1);
     v2f a2[kTrackSums];
 #pragma unroll
     for (int i = 0; i < kTrackSums; ++i) a2[i] = 0.f;
@@ -335,6 +380,11 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
     float a[kTrackSums];
 #pragma unroll
     for (int i = 0; i < kTrackSums; ++i) a[i] = a2[i].x + a2[i].y;
+#ifdef FM_TRACK_CLOCKS
+    asm volatile("" :: "v"(a[0]), "v"(a[13]));
+#endif
+    FM_TCLK(c2);
+    FM_TCLK_ADD(2, c1, c2);
     if (GRAD) {
 #ifdef FM_TRACK_PLAIN_REDUCE
       wave_sum_lane63_x7<kTrackSums>(a);  // the totals are valid in lane 63
@@ -355,7 +405,10 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
       const float lc[2] = {a[12], a[13]};
       wave_store<2>(lc, mine + (size_t)ft * kTrackSums + 12);
     }
+    FM_TCLK(c3);
+    FM_TCLK_ADD(3, c2, c3);
   }
+  FM_TCLK(c_epi);
 
   if (GRAD) {
 #pragma unroll
@@ -390,6 +443,19 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
       }
     }
   }
+#ifdef FM_TRACK_CLOCKS
+  {
+    const long long c_end = wall_clock64();
+    clk[4] = c_end - c_epi;
+    clk[5] = c_end - c_begin;
+    clk[6] = f;
+    const unsigned wid = blockIdx.x * gridDim.y + blockIdx.y;
+    if (threadIdx.x == 0 && wid < (unsigned)kTrackClockWaves) {
+#pragma unroll
+      for (int i = 0; i < kTrackClockSlots; ++i) fm_track_clock_buffer[wid][i] = clk[i];
+    }
+  }
+#endif
 }
 
 // Per frame: sum the partials of every wave that touched it (fp64, fixed order: bit-reproducible).
@@ -610,6 +676,13 @@ __global__ void __launch_bounds__(64) inv4_kernel(const float* m, int count, flo
 using namespace fm;
 
 extern "C" {
+
+#ifdef FM_TRACK_CLOCKS
+int fm_debug_track_clocks(long long* host_out, int waves) {  // (waves, kTrackClockSlots) accumulated wall_clock64 deltas (100 MHz) of the last track_pairs launch
+  if (waves > kTrackClockWaves) waves = kTrackClockWaves;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fm_track_clock_buffer), sizeof(long long) * waves * kTrackClockSlots) == hipSuccess ? kTrackClockSlots : -1;
+}
+#endif
 
 int fm_extrinsics_inverse(const float* ext, int count, float* inv, void* stream) {
   FM_CHECK_ARG(ext && inv && count >= 1);

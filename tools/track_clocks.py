@@ -1,0 +1,37 @@
+"""Where does the time go INSIDE track_pairs?  Rebuilds the library in place with fm_track.hip compiled -DFM_TRACK_CLOCKS (run this on
+the GPU box through gpurun: nothing is written back), runs the C2 bench in this process and reads the per-wave phase clocks of the
+last launch: prologue (sampling), per target frame: scalar constants / residual terms / reduction + store, epilogue (source role).
+    python tools/track_clocks.py"""
+import ctypes
+import runpy
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import flowmap_amd.build as b  # noqa: E402
+
+b.FILE_FLAGS["fm_track.hip"] = ["-DFM_TRACK_CLOCKS"] + sys.argv[1:]
+b.build_library(force=True, verbose=False)
+from flowmap_amd import _lib  # noqa: E402
+
+sys.argv = ["bench.py", "--config", "c2", "--cpu-frames", "0", "--steps", "5", "--warmup", "2"]
+try:
+    runpy.run_path(str(ROOT / "bench.py"), run_name="__main__")
+except SystemExit:
+    pass
+lib = _lib.library()
+lib.fm_debug_track_clocks.argtypes = [ctypes.c_void_p, ctypes.c_int]
+n = 2048
+out = np.zeros((n, 8), dtype=np.int64)
+assert lib.fm_debug_track_clocks(out.ctypes.data, n) == 8
+out = out[out[:, 5] > 0]
+names = ["prologue", "targets: scalar constants", "targets: terms", "targets: reduce + store", "epilogue", "whole wave"]
+print(f"{len(out)} waves; median / p90 per wave in us (100 MHz clock); targets per wave median {np.median(out[:, 6]):.0f}")
+for i, name in enumerate(names):
+    us = out[:, i] / 100.0
+    print(f"  {name:28s} {np.median(us):8.2f} {np.percentile(us, 90):8.2f}")
+per_target = out[:, 1:4].sum(axis=1) / np.maximum(out[:, 6], 1) / 100.0
+print(f"  per target iteration         {np.median(per_target):8.3f} us")
