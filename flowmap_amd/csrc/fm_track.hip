@@ -95,6 +95,80 @@ __device__ __forceinline__ bool track_sample(const TrackGeom& g, const float* de
   return live;
 }
 
+// track_sample for the N source frames of a tile at once, in three phases — every position first, then every tap depth, then the
+// arithmetic and the stores — so that a lane has N·(1 + 4) loads in flight instead of walking N dependent load -> load chains one
+// after the other (each link a cold round trip of 2.5-5 us: the prologue of track_pairs took 78 of a wave's 178 us that way;
+// tools/track_clocks.py).  want[n] is wave-uniform (the frame exists and is sampled by this rank); idx[n] is in range for every lane
+// (clamped point); `store` masks the lanes beyond the segment's points.  Same arithmetic per item as track_sample (a tap outside
+// the image contributes an exact zero instead of being skipped).
+template <int N>
+__device__ __forceinline__ void track_sample_many(const TrackGeom& g, const float* depth, int depth_frame0, const float* kinv, const float* ext,
+                                                  const int (&frame)[N], const size_t (&idx)[N], const bool (&want)[N], bool store, float* ws,
+                                                  uint8_t* flag, float (&xw)[N][3], bool (&live)[N]) {
+  float2 q[N];
+  uint8_t vis[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    q[n] = make_float2(0.f, 0.f);
+    vis[n] = 0;
+    if (want[n]) {
+      q[n] = reinterpret_cast<const float2*>(g.xy)[idx[n]];
+      vis[n] = g.vis[idx[n]];
+    }
+  }
+  Taps t[N];
+  float z[N][4];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    t[n] = bilinear_taps(q[n].x, q[n].y, g.height, g.width);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[n][k] = 0.f;
+    if (want[n]) {
+      const float* d = depth + (size_t)(frame[n] - depth_frame0) * g.height * g.width;
+      const int x1 = min(t[n].x0 + 1, g.width - 1), y1 = min(t[n].y0 + 1, g.height - 1);  // clamped reads; masked by in[] below
+      z[n][0] = d[t[n].y0 * g.width + t[n].x0];
+      z[n][1] = d[t[n].y0 * g.width + x1];
+      z[n][2] = d[y1 * g.width + t[n].x0];
+      z[n][3] = d[y1 * g.width + x1];
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    live[n] = false;
+    xw[n][0] = xw[n][1] = xw[n][2] = 0.f;
+    if (!want[n]) continue;
+    Mat3 ki;
+    Pose e;
+    load_mat3(kinv + (size_t)frame[n] * 9, ki);
+    load_pose44(ext + (size_t)frame[n] * 16, e);
+    float xyz[3] = {0.f, 0.f, 0.f}, hh[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int tc = tap_col(t[n], k), tr = tap_row(t[n], k);
+      const float ut = pixel_center(tc, g.width), vt = pixel_center(tr, g.height);
+      float ray[3];
+      ray_dir(ki, ut, vt, ray);
+      const float zk = t[n].in[k] ? z[n][k] : 0.f, wk = t[n].in[k] ? t[n].w[k] : 0.f;
+      xyz[0] += (ray[0] * zk) * wk;
+      xyz[1] += (ray[1] * zk) * wk;
+      xyz[2] += (ray[2] * zk) * wk;
+      hh[0] += zk * ut * wk;
+      hh[1] += zk * vt * wk;
+      hh[2] += zk * wk;
+    }
+    apply_pose(e, xyz, xw[n]);
+    const bool inside = q[n].x >= 0.f && q[n].y >= 0.f && q[n].x < 1.f && q[n].y < 1.f;
+    live[n] = store && vis[n] != 0 && inside;
+    if (store) {
+      float* o = ws + idx[n] * kTrackWs;
+      o[0] = xyz[0]; o[1] = xyz[1]; o[2] = xyz[2];
+      o[3] = xw[n][0]; o[4] = xw[n][1]; o[5] = xw[n][2];
+      o[6] = hh[0];  o[7] = hh[1];  o[8] = hh[2];
+      flag[idx[n]] = live[n] ? 1 : 0;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const float* depth, int depth_frame0, const float* kinv,
                                                            const float* ext, float* ws, uint8_t* flag) {
   const int sg = g.blocks[blockIdx.x * 2], fl = g.blocks[blockIdx.x * 2 + 1];
@@ -288,29 +362,41 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
   v2f live[kTrackPG][kTrackTile / 2];  // 1 when the source role is visible (projection.py:290-294), else 0
 #pragma unroll
   for (int q = 0; q < kTrackPG; ++q) {
+    float lvs[kTrackTile], xs[kTrackTile][3];
+    if (smp.depth != nullptr) {  // sample this point's source frames of the tile (all loads of the tile in flight together)
+      int frame[kTrackTile];
+      size_t idx[kTrackTile];
+      bool want[kTrackTile], lv[kTrackTile];
 #pragma unroll
-    for (int t = 0; t < kTrackTile; ++t) {
-      float lv = 0.f, x0 = 0.f, x1 = 0.f, x2 = 0.f;
-      const int fs = fs0 + t;
-      if (active[q] && fs < f) {
-        const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
-        if (smp.depth != nullptr) {
-          const int frame = start + fs;
-          if (frame >= smp.own_first && frame < smp.own_end) {
-            float xs[3];
-            if (track_sample(g, smp.depth, smp.depth_frame0, smp.kinv, ext, frame, is, ws, flag, xs)) {
-              lv = 1.f;
-              x0 = xs[0]; x1 = xs[1]; x2 = xs[2];
-            }
-          } else {
-            flag[is] = 0;  // another rank's source
+      for (int t = 0; t < kTrackTile; ++t) {
+        const int fs = fs0 + t;
+        frame[t] = start + fs;
+        idx[t] = (size_t)off + (size_t)min(fs, f - 1) * p_count + pp[q];
+        want[t] = fs < f && frame[t] >= smp.own_first && frame[t] < smp.own_end;
+        if (fs < f && !want[t] && active[q]) flag[idx[t]] = 0;  // another rank's source
+      }
+      track_sample_many<kTrackTile>(g, smp.depth, smp.depth_frame0, smp.kinv, ext, frame, idx, want, active[q], ws, flag, xs, lv);
+#pragma unroll
+      for (int t = 0; t < kTrackTile; ++t) lvs[t] = lv[t] ? 1.f : 0.f;
+    } else {
+#pragma unroll
+      for (int t = 0; t < kTrackTile; ++t) {
+        const int fs = fs0 + t;
+        lvs[t] = 0.f;
+        xs[t][0] = xs[t][1] = xs[t][2] = 0.f;
+        if (active[q] && fs < f) {
+          const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
+          if (flag[is] != 0) {
+            lvs[t] = 1.f;
+            const float* w9 = ws + is * kTrackWs;
+            xs[t][0] = w9[3]; xs[t][1] = w9[4]; xs[t][2] = w9[5];
           }
-        } else if (flag[is] != 0) {
-          lv = 1.f;
-          const float* w9 = ws + is * kTrackWs;
-          x0 = w9[3]; x1 = w9[4]; x2 = w9[5];
         }
       }
+    }
+#pragma unroll
+    for (int t = 0; t < kTrackTile; ++t) {
+      const float lv = lvs[t], x0 = lv != 0.f ? xs[t][0] : 0.f, x1 = lv != 0.f ? xs[t][1] : 0.f, x2 = lv != 0.f ? xs[t][2] : 0.f;
       if (t & 1) {
         live[q][t / 2].y = lv; xw[q][t / 2][0].y = x0; xw[q][t / 2][1].y = x1; xw[q][t / 2][2].y = x2;
       } else {
