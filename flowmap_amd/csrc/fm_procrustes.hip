@@ -856,7 +856,10 @@ __device__ __forceinline__ DenseRaw dense_raw_of(const DenseRaw4& r, int j) {
 }
 
 // grid: 1-D, >= tiles·pairs blocks (dense_block).  Raw pixel-space moments of the tile's pixels.
-__global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParams p, unsigned total) {
+#ifndef FM_DENSE_MOMENTS_BLOCKS
+#define FM_DENSE_MOMENTS_BLOCKS 1
+#endif
+__global__ void __launch_bounds__(256, FM_DENSE_MOMENTS_BLOCKS) procrustes_moments_dense_kernel(ProcParams p, unsigned total) {
   __shared__ double red[4 * kMomentCount];
   __shared__ DenseWindow win;
   const DenseBlock blk = dense_block(p.height, p.width, total);
@@ -891,6 +894,8 @@ __global__ void __launch_bounds__(256) procrustes_moments_dense_kernel(ProcParam
       dense_moments_add(px.g, px.h, px.w, gs, acc);
     }
   }
+  // (Two pixels per pass in packed fp32 — v_pk_fma_f32 on pairs of the quad — issued 14 % fewer instructions and ran 7 % SLOWER: a
+  // packed instruction occupies the SIMD about twice as long as a plain one on this part, tools/probes/pk_rate_probe.hip.)
   block_accumulate<kMomentCount>(acc, red, p.stats + c.pair * kStatStride);
 }
 
