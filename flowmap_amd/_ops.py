@@ -287,10 +287,30 @@ def touched_elements(depth: Tensor, whole_frames=()):
 use_grad_arena = True
 # Moments, finish + solve and the pose chain as ONE launch (fm_procrustes_fit_chain) instead of a memset and three kernels.
 use_fit_chain = True
-# Dense Procrustes (`num_points: null`) backward: False (default) = one fused pass over the later pixels, tap gradients summed in LDS and
-# flushed with atomics; True = the static tap lists (built once per flow tensor, 4 B per pixel and pair) and the planned pair of kernels
-# without atomics, whose dL/ddepth is bit-reproducible (and 0.9 ms slower per 150 x 720x1280 step).
-use_dense_plan = False
+# Dense Procrustes (`num_points: null`) backward.  False = one fused pass over the later pixels, tap gradients summed in an LDS image of the
+# earlier-frame window and flushed with atomics (1.2 ms at 150 x 720x1280 when the flow varies by a few pixels inside a 32x64 tile — camera
+# motion —, but every tap that leaves the window is a scattered atomic: 2.2 ms on rough flows, 8 ms on i.i.d. ones); True = the static tap
+# lists (built once per flow tensor, 4 B per pixel and pair) and the planned pair of kernels without atomics (2.0-2.2 ms on ANY flow,
+# dL/ddepth bit-reproducible); None (default) = decided once per flow tensor by how much the flow varies inside the tiles.
+use_dense_plan = None
+# (auto) the planned kernels are chosen when more than this fraction of the tiles has flows leaving the fused pass's window
+dense_plan_rough_tiles = 0.25
+
+
+def _dense_flow_is_rough(bwd_flow: Tensor, h: int, w: int) -> bool:
+    """Would the fused dense backward's window (the 32x64 tile displaced by the flow at its centre, +-4 rows / +-8 columns) lose the taps of
+    this flow?  Per tile the spread (max - min) of the flow in pixels; a tile is rough when it exceeds 6 rows or 12 columns.  Evaluated once
+    per flow tensor with four pooling passes (a few ms at C1 size, one host sync) and kept on the tensor."""
+
+    def build():
+        fl = bwd_flow.reshape(-1, h, w, 2).permute(0, 3, 1, 2)  # (pairs, 2, H, W)
+        hi = torch.nn.functional.max_pool2d(fl, (32, 64), ceil_mode=True)
+        lo = -torch.nn.functional.max_pool2d(-fl, (32, 64), ceil_mode=True)
+        spread = hi - lo
+        rough = (spread[:, 0] * w > 12.0) | (spread[:, 1] * h > 6.0) | ~torch.isfinite(spread).all(dim=1)
+        return bool(rough.float().mean().item() > dense_plan_rough_tiles)
+
+    return _derived(bwd_flow, "_fm_dense_rough", (bwd_flow._version, h, w), build)
 
 # which backward path the facades selected (tests)
 counters = {"procrustes_planned": 0, "procrustes_dense_planned": 0, "flow_packs": 0, "procrustes_plans_built": 0}
@@ -483,7 +503,8 @@ class ProcrustesFit:
                 b, f, h, w = depth.shape
                 if indices is None:
                     note_touched(depth, "procrustes", None)  # every pixel is a correspondence: nothing is left to an in-pass update
-                    if use_dense_plan and h <= 65535 and w <= 65535 and bwd_flow.is_contiguous():
+                    planned = _dense_flow_is_rough(bwd_flow, h, w) if use_dense_plan is None else bool(use_dense_plan)
+                    if planned and h <= 65535 and w <= 65535 and bwd_flow.is_contiguous():
                         dense = _dense_procrustes_plan(bwd_flow, b, f, h, w)
                         counters["procrustes_dense_planned"] += 1
                 elif indices.dtype == torch.int64 and indices.is_contiguous():

@@ -872,12 +872,18 @@ def case_dense_procrustes(dev, h, w, flow_sigma, f=4):
         try:
             t_bwd, t_fwd = _ops.ProcrustesFit.apply(d, kk, None, lg, fl_dev, idx, 100.0, 1)
         finally:
-            _ops.use_dense_plan = False
+            _ops.use_dense_plan = None
         ((t_bwd * cot_b.to(dev)).sum() + (t_fwd * cot_f.to(dev)).sum()).backward()
         res[name] = (t_bwd.detach(), d.grad, lg.grad, kk.grad)
         assert ("_fm_dense_plan" in fl_dev.__dict__) == planned  # the fused pass (the default) builds no lists
         if planned:
             res["plan"] = fl_dev._fm_dense_plan[1]
+    # left to itself the facade picks by the flow: i.i.d. flows of a few pixels leave the fused pass's window (planned kernels), a
+    # flow that is constant inside the tiles does not (no lists)
+    for fl_auto, want_plan in (((0.5 * torch.randn(flow.shape, generator=g)).to(dev), True), (torch.full_like(flow, 0.01).to(dev), False)):
+        d, kk, lg = (x.clone().to(dev).requires_grad_(True) for x in (depth, k, logits))
+        t_bwd, t_fwd = _ops.ProcrustesFit.apply(d, kk, None, lg, fl_auto, None, 100.0, 1)
+        assert ("_fm_dense_plan" in fl_auto.__dict__) == want_plan, (flow_sigma, want_plan)
     truth = (rel64.detach(), d64.grad, l64.grad, k64.grad)
     # the static tap lists: one entry per (later pixel, earlier-frame tile its taps touch), every tile's list ascending
     first, entries = res["plan"]
