@@ -269,6 +269,11 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   v2f acc[kFlowAcc];  // x: towards the next frame, y: towards the previous one
 #pragma unroll
   for (int i = 0; i < kFlowAcc; ++i) acc[i] = pk1(0.f);
+#ifdef FM_FLOW_SCALAR_TERMS
+  float sacc_f[kFlowAcc], sacc_b[kFlowAcc];
+#pragma unroll
+  for (int i = 0; i < kFlowAcc; ++i) sacc_f[i] = sacc_b[i] = 0.f;
+#endif
 
   const int base = blockIdx.x * (blockDim.x * p.iters);
 
@@ -281,6 +286,20 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
     const float v = pixel_center(row, p.height);
     const float v_ay = v * p.ay;
     // a1·v + a2 (and b, c alike) is constant along the image row the quad lies in
+#ifdef FM_FLOW_SCALAR_TERMS  // (A/B: the two directions one after the other in plain fp32, behind wave-uniform run-time tests)
+    const float rf0 = fmaf(df.a1, v, df.a2), rf1 = fmaf(df.b1, v, df.b2), rf2 = fmaf(df.c1, v, df.c2);
+    const float rb0 = fmaf(db.a1, v, db.a2), rb1 = fmaf(db.b1, v, db.b2), rb2 = fmaf(db.c1, v, db.c2);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float u = u_tab[col0 + e];
+      const float zu = z[e] * u, zv = z[e] * v, u_ax = u * p.ax;
+      gz[e] = 0.f;
+      if (has_fwd)
+        flow_term_fast<KIND, GRAD>(df, rf0, rf1, rf2, z[e], u, zu, zv, u_ax, v_ay, fxf[e], fyf[e], mmf[e], scale, p.delta, inv_delta, p.ax, p.ay, sacc_f, gz[e]);
+      if (has_bwd)
+        flow_term_fast<KIND, GRAD>(db, rb0, rb1, rb2, z[e], u, zu, zv, u_ax, v_ay, fxb[e], fyb[e], mmb[e], scale, p.delta, inv_delta, p.ax, p.ay, sacc_b, gz[e]);
+    }
+#else
     const v2f v2 = pk1(v);
     const v2f arow = pk_fma(dp.a1, v2, dp.a2), brow = pk_fma(dp.b1, v2, dp.b2), crow = pk_fma(dp.c1, v2, dp.c2);
 #pragma unroll
@@ -291,6 +310,7 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
       flow_term_pair<KIND, GRAD>(dp, arow, brow, crow, z[e], u, zu, zv, u_ax, v_ay, pk(fxf[e], fxb[e]), pk(fyf[e], fyb[e]), pk(mmf[e], mmb[e]),
                                  scale, p.delta, inv_delta, p.ax, p.ay, acc, gz[e]);
     }
+#endif
     if (ADAM) {
       // depth, exp_avg, exp_avg_sq of this quad rewritten in place (model_wrapper_overfit.py:104-105: torch.optim.Adam);
       // pixels another operator still reads from / adds gradient to keep their values and get dL/ddepth stored instead
@@ -386,6 +406,10 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   float acc_f[kFlowAcc], acc_b[kFlowAcc];
 #pragma unroll
   for (int i = 0; i < kFlowAcc; ++i) acc_f[i] = acc[i].x, acc_b[i] = acc[i].y;
+#ifdef FM_FLOW_SCALAR_TERMS
+#pragma unroll
+  for (int i = 0; i < kFlowAcc; ++i) acc_f[i] = sacc_f[i], acc_b[i] = sacc_b[i];
+#endif
   if (has_fwd) block_accumulate<kFlowAcc>(acc_f, red, dst);
   if (has_bwd) block_accumulate<kFlowAcc>(acc_b, red, dst + kFlowAccStride);
 }
