@@ -1016,7 +1016,7 @@ __global__ void __launch_bounds__(256, FM_DENSE_LATER_BLOCKS) procrustes_dense_b
 #define FM_DENSE_FUSED_BLOCKS 4
 #endif
 #ifndef FM_DENSE_FUSED_UNROLL
-#define FM_DENSE_FUSED_UNROLL 2
+#define FM_DENSE_FUSED_UNROLL 4
 #endif
 #ifndef FM_DENSE_FUSED_SKIP  // timing experiments only (tools/dense_microbench.py): 1 = plain store for the later pixel (racy), 2 = no flush, 4 = no taps
 #define FM_DENSE_FUSED_SKIP 0
