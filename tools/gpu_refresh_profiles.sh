@@ -76,7 +76,7 @@ ate)
   python tests/tools/ate_check.py --device cuda --in-pass 2> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_c0_16x256x256.json"
   python tests/tools/ate_check.py --device cuda --height 192 --width 256 --tracking --in-pass 2>> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_16x192x256_flow_tracking.json"
   python tests/tools/ate_check.py --device cuda --frames 32 --height 360 --width 640 --tracking --in-pass 2>> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_32x360x640_flow_tracking.json"
-  for v in "" "_nosoftmin"; do
+  for v in "" "_nosoftmin" "_nosoftmin_lr3e-4"; do
     [ -f tests/golden/ate_150x360x640${v}_reference.json ] && python tests/tools/ate_full_chain.py --leg ours --reference tests/golden/ate_150x360x640${v}_reference.json 2>> "$OUT/ate.err" | tail -1 > "$OUT/${R}_ate_150x360x640${v}.json"
   done
   [ -f tests/golden/ate_150x360x640_reference_perturbed.json ] && python tests/tools/ate_full_chain.py --leg compare --reference tests/golden/ate_150x360x640_reference.json --other tests/golden/ate_150x360x640_reference_perturbed.json > "$OUT/${R}_ate_150x360x640_reference_sensitivity.json" ;;
