@@ -191,7 +191,7 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
 
 /* Dense Procrustes backward (`num_points: null`, config/experiment/ablation_explicit_depth.yaml:11-12:
  * every pixel of every pair is a correspondence; replaces grid_sampler_2d_backward + index_put of
- * projection.py:226-249 over all H·W pixels) WITHOUT atomics on the big tensors.  The pattern is static
+ * projection.py:226-249 over all H·W pixels).  Planned form, WITHOUT atomics on the big tensors: the pattern is static
  * (the flows are constants of the optimisation), so it is planned once per flow tensor:
  *   fm_procrustes_dense_tiles(H, W, &tiles)                      tiles of the earlier frame per pair (host only)
  *   pass 1: fm_procrustes_dense_plan(bwd_flow, B, F, H, W, counts, NULL, NULL)   counts (B·(F-1)·tiles) int32,
@@ -205,7 +205,14 @@ int fm_procrustes_scatter(const float* depth, const float* kinv, const float* su
  * need not be zeroed, must not hold another gradient); grad_depth (B,F,H,W) is ADDED to with plain
  * read-modify-writes (each pixel has one writer per launch).  dL/dK⁻¹ is not formed here: it is linear in the
  * statistics of the forward pass and comes from fm_pose_solve_bwd_kinv.
- * grad_depth / grad_weights may be NULL; first / list are needed for grad_depth.
+ * grad_depth / grad_weights may be NULL.
+ * first / list: both given = the planned pair of kernels described above (no atomics; dL/ddepth bit-reproducible; 2.0-2.2 ms per
+ * 150 x 720x1280 step on ANY flow).  Both NULL (round 3) = ONE fused pass over the later pixels that needs no plan: the tap gradients
+ * are summed in an LDS image of the earlier-frame window the block stages for its depth samples (64-bit integer sums in a per-pair
+ * fixed point) and leave with float atomics, the later pixel's own gradient is an atomic add too — 1.2 ms when the flow varies by a
+ * few pixels inside a 32x64 tile (camera motion), but every tap that leaves the window (+-4 rows / +-8 columns around the tile
+ * displaced by the flow at its centre) is a scattered atomic: slower than the planned kernels on rough flows.  Same gradients to
+ * 1e-7 (norm-wise).  flowmap_amd's host layer picks per flow tensor (_ops._dense_flow_is_rough).
  * consts: workspace of B·(F-1)·FM_DENSE_CONST_STRIDE doubles (per-pair constants, written by the call). */
 #define FM_DENSE_CONST_STRIDE 40
 int fm_procrustes_dense_tiles(int height, int width, int* tiles);
