@@ -19,7 +19,7 @@
 //   [1..3]   σ = Σ ω                      ω = (q·w_u, q·w_v, q·(w·kd p)),  q = 1/(Z'+eps)
 //   [4..12]  Ω = Σ ω ⊗ (z·[u,v,1])
 // from which flow_finalize_frame derives dL/dR, dL/dt, dL/dK⁻¹_src and dL/dK_dst.
-// DPP wave reduction -> LDS (fp64) -> one fp64 atomic per value per block.
+// Transposing wave reduction (fm_device.h) -> LDS (fp64) -> one fp64 atomic per value per block.
 #include "../../include/flowmap_hip.h"
 #include "fm_device.h"
 #include "fm_pose.h"
@@ -122,11 +122,12 @@ __device__ __forceinline__ void load_quad_packed(QuadIn& q, const float* depth, 
 
 // ---------------------------------------------------------------------------------
 // The two residual terms of a pixel — towards the next frame and towards the previous one — as ONE pass of packed fp32
-// arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fp32 per issue slot).  The kernel is bound by
-// VALU issue, not by HBM (rocprofv3 SQ_INSTS_VALU: 168 instructions per pixel = 0.70 of its 0.78 ms at the 2.0-2.1 GHz the
-// part sustains here); the two terms run the same ~60 operations on different constants, flows and masks, so component x
-// carries the forward term and component y the backward one.  Each component performs exactly the operations of
-// flow_term_fast (fm_math.h) in the same order: the results are bit-identical to the scalar form the host double runs.
+// arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  The two terms run the same ~60 operations on different constants,
+// flows and masks, so component x carries the forward term and component y the backward one; no run-time direction tests, 32 fewer
+// instructions per pixel.  Each component performs exactly the operations of flow_term_fast (fm_math.h) in the same order: the
+// results are bit-identical to the scalar form the host double runs.  (What it does NOT buy on this part is issue time: a packed
+// instruction occupies the SIMD about twice as long as a plain one — tools/probes/pk_rate_probe.hip — and the kernel waits for HBM
+// in either form; -DFM_FLOW_SCALAR_TERMS keeps the scalar form for A/B runs, tools/ab_flow.sh.  DESIGN.md §3.1.)
 // ---------------------------------------------------------------------------------
 struct DirPair {
   v2f au, a1, a2, ta, bu, b1, b2, tb, cu, c1, c2, tc;
@@ -213,8 +214,9 @@ __device__ __forceinline__ void flow_term_pair(const DirPair& d, v2f arow, v2f b
 }
 
 #ifndef FM_FLOW_WAVES
-// Waves per SIMD the register allocator must leave room for.  3 (<=168 VGPRs, 133 used, no
-// scratch) beat 4 (128 VGPRs) by 3-5 % and 2 by 4 % in interleaved A/B runs; 5 spills.
+// Waves per SIMD the register allocator must leave room for.  3 (<=168 VGPRs; the packed pair of terms uses 150, the scalar
+// form 106, no scratch).  Round 2's scalar kernel: 3 beat 4 by 3-5 % and 2 by 4 %; round 3 (tools/flow_microbench.py, tools/ab_flow.sh):
+// 2, 3 and (scalar form) 4 within the run-to-run spread — the kernel waits for HBM either way.
 #define FM_FLOW_WAVES 3
 #endif
 
