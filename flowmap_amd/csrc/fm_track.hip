@@ -160,10 +160,12 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
     const bool inside = q[n].x >= 0.f && q[n].y >= 0.f && q[n].x < 1.f && q[n].y < 1.f;
     live[n] = store && vis[n] != 0 && inside;
     if (store) {
+#ifndef FM_TRACK_SKIP_WS  // (timing experiments: what the nine strided stores cost)
       float* o = ws + idx[n] * kTrackWs;
       o[0] = xyz[0]; o[1] = xyz[1]; o[2] = xyz[2];
       o[3] = xw[n][0]; o[4] = xw[n][1]; o[5] = xw[n][2];
       o[6] = hh[0];  o[7] = hh[1];  o[8] = hh[2];
+#endif
       flag[idx[n]] = live[n] ? 1 : 0;
     }
   }
