@@ -467,13 +467,29 @@ def main():
                 model.zero_grad(set_to_none=True)
                 return loss_fn(batch, flows, None, model(batch, flows, 0), 0)
 
-            sharded = flowmap_amd.GraphedShardedStep(forward_only, shard, shared, model.backbone.depth, warmup=3)
+            # (the capture holds no collective — those stay eager around the graphs — so a rank whose capture fails can still meet the others
+            # in the agreement below; if ANY rank could not capture, every rank runs the eager step: slower, but a number instead of a hang)
+            sharded, failure = None, None
+            try:
+                sharded = flowmap_amd.GraphedShardedStep(forward_only, shard, shared, model.backbone.depth, warmup=3)
+            except Exception as exc:  # noqa: BLE001
+                failure = exc
+            ok = torch.tensor([0.0 if sharded is None else 1.0], device=device)
+            if dist is not None:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                print(f"[bench] rank {rank}: hipGraph capture of the sharded step failed ({failure!r}); every rank falls back to the eager step", file=sys.stderr)
+                args.graph = None
+                eager_step = step
 
-            def step():  # noqa: F811
-                loss = sharded()
-                if optimizer is not None:
-                    optimizer.step()
-                return loss
+                def step():  # noqa: F811
+                    return eager_step()
+            else:
+                def step():  # noqa: F811
+                    loss = sharded()
+                    if optimizer is not None:
+                        optimizer.step()
+                    return loss
         else:
             step = flowmap_amd.GraphedStep(step, warmup=3)  # noqa: F811
     for _ in range(args.warmup):
