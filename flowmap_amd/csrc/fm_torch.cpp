@@ -337,6 +337,7 @@ struct FocalIntrinsics : public Function<FocalIntrinsics> {
     ctx->saved_data["geometry"] = std::vector<int64_t>{focal.numel(), repeat, h, w};
     ctx->saved_data["shape"] = focal.sizes().vec();
     ctx->mark_non_differentiable({kinv});
+    ctx->set_materialize_grads(false);  // (else the engine builds a zeros tensor for K⁻¹'s absent gradient in every backward: one fill launch per step)
     return {k, kinv};
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
