@@ -997,6 +997,7 @@ FM_CALL(fm_track_loss_fused_fwd, ptr(depth), (int)frame0, (int)own_first, (int)o
     ctx->saved_data["dims"] = std::vector<int64_t>{f, h, w, frame0};
     if (sink && park) ctx->saved_data["sink"] = sink;
     ctx->mark_non_differentiable({scale, totals});
+    ctx->set_materialize_grads(false);  // (no zeros tensors for the two non-differentiable outputs in every backward: two fill launches per step)
     return {loss.reshape({}), scale, totals};
   }
 
