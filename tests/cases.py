@@ -933,6 +933,42 @@ def _small_problem(dev, f=5, h=24, w=32, points=60, tracking=True, seed=21, intr
     return model, batch, flows, loss_of
 
 
+def case_step_torch_ops(dev):
+    """What a step launches BESIDE the library's own kernels: autograd's ones_like for loss.backward(), the sum of the two losses and the
+    two sums autograd forms where two consumers meet (dL/d extrinsics, dL/dK) — and nothing else.  In particular no zeros tensors
+    materialised for the non-differentiable outputs of the custom functions (K^-1 of FocalIntrinsics, scale / totals of the tracking
+    loss): each was a fill launch per step until round 3."""
+    import flowmap_amd
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    quiet = ("view", "unsqueeze", "squeeze", "detach", "empty", "select.int", "slice", "expand", "reshape", "alias", "permute", "as_strided",
+             "t.default", "transpose", "_local_scalar_dense", "lift_fresh", "unbind", "split", "flowmap_amd", "profiler", "_to_copy", "clone")
+    for tracking, allowed in ((False, {"aten.ones_like.default": 1}), (True, {"aten.ones_like.default": 1, "aten.add.Tensor": 3})):
+        try:
+            model, batch, flows, loss_of = _small_problem(dev, tracking=tracking)
+
+            def step():
+                model.zero_grad(set_to_none=True)
+                loss_of(model(batch, flows, 0)).backward()
+
+            for _ in range(3):  # plans, packed inputs, arenas exist from the third step on
+                step()
+            seen = {}
+
+            class Trace(TorchDispatchMode):
+                def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                    name = str(func)
+                    if not any(q in name for q in quiet):
+                        seen[name] = seen.get(name, 0) + 1
+                    return func(*args, **(kwargs or {}))
+
+            with Trace():
+                step()
+            assert seen == allowed, (tracking, seen)
+        finally:
+            flowmap_amd.set_lazy_surfaces(False)
+
+
 def _grads(model):
     return [p.grad.detach().clone() for p in (model.backbone.depth, model.backbone.weights, model.intrinsics.focal_length)]
 

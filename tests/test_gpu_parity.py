@@ -466,3 +466,7 @@ def test_frame_windows_are_read_in_place():
 
 def test_halo_exchange_kernels():
     cases.case_halo_kernels(DEV)
+
+
+def test_a_step_launches_no_stray_torch_kernels():
+    cases.case_step_torch_ops(DEV)
