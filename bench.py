@@ -84,7 +84,7 @@ def parse():
                     help="frames of the CPU-baseline leg, taken from the front of the SAME inputs the GPU leg runs on (0 = skip; default: the whole "
                          "video when the host has >= 96 GB of free memory — one iteration of 150 x 720p takes the oracle ~40 GB and ~30 s — "
                          "else a 32-frame sample, labelled as such)")
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=3, help="timed iterations of the CPU-baseline leg after its warm-up (BASELINE.md §3: 1 warm-up + 3)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads for the CPU baseline (16 measured fastest on the 256-thread EPYC 9575F host: "
                     "8 -> 0.42, 16 -> 0.25, 32 -> 0.35, 64 -> 0.45, 256 -> 5.2 s/iter at 4 frames @720p)")
@@ -110,6 +110,15 @@ def parse():
                          "one-rank RCCL communicator): the per-rank step time of a K-GPU run without the wire time")
     ap.add_argument("--share-rank", type=int, default=-1, help="which rank's share (default: an interior rank with the largest share)")
     ap.add_argument("--count-launches", action="store_true", help="count the kernel launches of one step with torch.profiler (after the timed region)")
+    ap.add_argument("--whole", action="store_true",
+                    help="config c4 WHOLE on one GPU: all 1200 frames @ 1080x1920 (79.6 GB of inputs + a 59.7 GB packed copy of the 288 GB) instead of "
+                         "one GPU's 150-frame shard; implies --release-originals")
+    ap.add_argument("--release-originals", action="store_true",
+                    help="flowmap_amd.release_flow_originals(flows) once the flows are packed: the forward flow and both masks (half of the inputs) are "
+                         "given back; the CPU-baseline sample is copied to the host first")
+    ap.add_argument("--torch-baseline", type=int, default=0, metavar="STEPS",
+                    help="after the timed region: the reference's op sequence on stock PyTorch-ROCm on this GPU (tests/tools/torch_gpu_reference_ops.py "
+                         "in a process of its own, 1 warm-up + STEPS steps on i.i.d. inputs of the workload's size) as `rocm_torch_baseline`")
     return ap.parse_args()
 
 
@@ -261,6 +270,36 @@ def cpu_baseline(depth, wlogit, flows, focal, frames, h, w, points, iters, threa
     return (time.perf_counter() - t0) / iters, cores, first, loss
 
 
+def torch_baseline(frames, h, w, points, steps, timeout=600):
+    """SURVEY.md §8d's third column: the reference's op sequence executed by stock PyTorch-ROCm on this GPU, in a process of its own
+    (its ~40 GB of autograd temporaries and a possible device fault stay out of this one) — a measured ratio, not a target."""
+    import subprocess
+
+    cmd = [sys.executable, str(ROOT / "tests" / "tools" / "torch_gpu_reference_ops.py"), "--frames", str(frames), "--height", str(h), "--width", str(w),
+           "--points", str(points), "--iters", str(steps)]
+    try:
+        run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        if run.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"failed": True, "returncode": run.returncode, "stderr_tail": run.stderr[-600:]}
+    except subprocess.TimeoutExpired:
+        return {"failed": True, "timeout_s": timeout}
+
+
+def _cpu_frames(args, f_video, h, w):
+    """Frames of the CPU-baseline leg: the whole video when it is no bigger than 1.25 x the headline workload and the host has the memory
+    (one iteration of 150 x 720p takes the oracle ~40 GB and ~25 s), else a 32-frame sample from the front of the same inputs."""
+    if args.cpu_frames >= 0:
+        return min(args.cpu_frames, f_video)
+    try:
+        avail_gb = int(next(line for line in open("/proc/meminfo") if line.startswith("MemAvailable")).split()[1]) / 2**20
+    except Exception:  # noqa: BLE001
+        avail_gb = 0.0
+    small = f_video * h * w <= 1.25 * 150 * 720 * 1280
+    return f_video if (avail_gb >= 96 and small) else min(32, f_video)
+
+
 def count_launches(step, device):
     """Kernel launches of one step, counted by torch.profiler's device activity (None when the profiler is unavailable)."""
     try:
@@ -327,6 +366,12 @@ def main():
         if getattr(args, key) is not None:
             cfg[key] = getattr(args, key)
     cfg["tracking"] = cfg["tracking"] or args.tracking
+    if args.whole:
+        if args.config != "c4" or world > 1 or args.share:
+            raise SystemExit("--whole: config c4 on one GPU")
+        cfg["frames"] = 1200 if args.frames is None else args.frames
+        cfg["ref"] = "BASELINE.json configs[4] WHOLE on one GPU (1200 frames; the config shards them over 8)"
+        args.release_originals = True
     f_video, h, w = cfg["frames"], cfg["height"], cfg["width"]
     # the (rank, world) the VIDEO is cut for: the process group's, or — `--share K` — rank R of K on this one GPU
     cut_world, cut_rank = (args.share, args.share_rank) if args.share > 1 else (world, rank)
@@ -443,6 +488,18 @@ def main():
     # flows / masks and reduces the valid sums, the second one plans the static scatters (SURVEY §8d:
     # the metric excludes one-time precompute)
     for _ in range(3):
+        step()
+    cpu_sample = None
+    if args.release_originals:
+        if strong:
+            raise SystemExit("--release-originals: single-GPU runs")
+        n_cpu = _cpu_frames(args, f_video, h, w)
+        if world == 1 and n_cpu >= 2 and args.points > 0:  # the CPU leg's inputs, before the originals go
+            cpu_sample = Flows(*(x[:, : n_cpu - 1].cpu() for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)))
+        released = flowmap_amd.release_flow_originals(flows)
+        if on_gpu:
+            torch.cuda.empty_cache()
+        print(f"[bench] released {released / 1e9:.1f} GB of flow originals (the fused flow loss reads the packed copy)", file=sys.stderr)
         step()
     early_halo = False
     if args.halo == "early" and strong:
@@ -598,6 +655,9 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": kernel_ms,
                 "launches_timed": len(flow_ms),
+                # every launch of the timed region in order (is a short run still on a clock ramp?  VERDICT r3 item 1b)
+                "kernel_ms_per_launch": [round(x, 4) for x in flow_ms] if len(flow_ms) <= 200 else None,
+                "kernel_ms_first5_last5": [sum(flow_ms[:5]) / 5, sum(flow_ms[-5:]) / 5] if len(flow_ms) >= 10 else None,
             },
         }
         if track_ms:
@@ -624,18 +684,12 @@ def main():
         if args.share > 1:
             result["proxy"] = {"share_of": cut_world, "rank": cut_rank, "pairs": [a, b], "frames_resident": f, "video_pairs": total_pairs,
                                "per_rank_ms_per_step": ms_per_step, "wire_time_included": False}
-        cpu_frames = args.cpu_frames
-        if cpu_frames < 0:
-            try:
-                avail_gb = int(next(line for line in open("/proc/meminfo") if line.startswith("MemAvailable")).split()[1]) / 2**20
-            except Exception:  # noqa: BLE001
-                avail_gb = 0.0
-            cpu_frames = f_video if avail_gb >= 96 else min(32, f_video)
+        cpu_frames = _cpu_frames(args, f_video, h, w)
         if world == 1 and args.share <= 1 and cpu_frames >= 2 and args.points > 0:
             cpu_frames = min(cpu_frames, f)
             focal0 = 0.85 if cfg["inputs"] == "iid" else 0.8
-            dt, cores, first, cpu_loss = cpu_baseline(model.backbone.depth.data, model.backbone.weights.data, flows, focal0, cpu_frames, h, w, args.points,
-                                                      args.cpu_iters, args.cpu_threads)
+            dt, cores, first, cpu_loss = cpu_baseline(model.backbone.depth.data, model.backbone.weights.data, cpu_sample if cpu_sample is not None else flows,
+                                                      focal0, cpu_frames, h, w, args.points, args.cpu_iters, args.cpu_threads)
             whole = cpu_frames == f_video
             scaled = dt if whole else dt * (f_video - 1) / (cpu_frames - 1)  # per-pair cost is constant (optimistic for the CPU)
             result["cpu_baseline"] = {
@@ -655,6 +709,8 @@ def main():
                 "loss": cpu_loss,
                 "loss_rel_diff_vs_gpu": (abs(cpu_loss - float(loss.item())) / abs(cpu_loss)) if (whole and optimizer is None) else None,
             }
+        if args.torch_baseline > 0 and on_gpu and world == 1:
+            result["rocm_torch_baseline"] = torch_baseline(f_video, h, w, args.points, args.torch_baseline)
         print(json.dumps(result), file=result_stream, flush=True)
     if dist is not None:
         dist.barrier()

@@ -63,3 +63,24 @@ def test_share_proxy_runs_one_ranks_share_with_every_collective(extra):
     assert "PROXY" in line["config"]["workload"] and "cpu_baseline" not in line
     edge = _run(1, ["--config", "c1", "--share", "3", "--share-rank", "2", *extra])
     assert edge["proxy"]["pairs"] == [6, 8] and edge["config"]["frames_per_gpu"] == 3
+
+
+def test_whole_c4_path_releases_the_originals_and_keeps_a_cpu_sample():
+    """bench.py --config c4 --whole (all of configs[4] on one GPU, here shrunk): the flows are packed, the originals released — the CPU leg's
+    sample copied first — and the line says so; the loss equals the run that keeps the originals."""
+    small = ["--frames", "9", "--height", "24", "--width", "32", "--points", "60", "--steps", "2", "--warmup", "1", "--cpu-frames", "4", "--cpu-iters", "1"]
+    launcher = str(ROOT / "tests" / "tools" / "bench_dryrun.py")
+    lines = []
+    for extra in (["--whole"], []):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env["OMP_NUM_THREADS"] = "2"
+        done = subprocess.run([sys.executable, launcher, "--gpus", "1", "--config", "c4", *small, *extra], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert done.returncode == 0, done.stderr[-3000:]
+        if extra:
+            assert "released" in done.stderr
+        lines.append(json.loads([ln for ln in done.stdout.splitlines() if ln.startswith("{")][0]))
+    whole, kept = lines
+    assert "WHOLE" in whole["config"]["workload"] and whole["config"]["video_frames"] == 9
+    assert whole["cpu_baseline"]["frames"] == 4 and whole["cpu_baseline"]["whole_workload"] is False
+    assert abs(whole["config"]["loss"] - kept["config"]["loss"]) <= 1e-6 * abs(kept["config"]["loss"])
+    assert abs(whole["cpu_baseline"]["loss"] - kept["cpu_baseline"]["loss"]) <= 1e-6 * abs(kept["cpu_baseline"]["loss"])

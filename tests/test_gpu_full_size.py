@@ -185,3 +185,138 @@ def test_c4_shard_flow_loss_150x1080x1920_iid_vs_oracle():
     what the reference's own arithmetic delivers on these inputs.  Both gaps are recorded."""
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     c4_shard_case(150, 1080, 1920, P, DEV, _oracle_dtype(), "C4 shard (150 x 1080x1920, i.i.d., flow)")
+
+
+# ---- BASELINE.json configs[4] WHOLE on one GPU (VERDICT r3, item 1a): 1200 frames @ 1080x1920, 2.5e9 pixels ----
+
+
+def _device_relerr(a, b, chunk=1 << 28):
+    """conftest.relerr for tensors of 10 GB: ||a - b|| / ||b|| accumulated in fp64 ON the device, a chunk at a time."""
+    a, b = a.reshape(-1), b.reshape(-1)
+    num = den = 0.0
+    for i in range(0, a.numel(), chunk):
+        x, y = a[i : i + chunk].double(), b[i : i + chunk].double()
+        num += float(((x - y) ** 2).sum())
+        den += float((y**2).sum())
+    return (num / den) ** 0.5 if den > 1e-60 else num**0.5
+
+
+def _gpu_step(depth, wlogit, flows, hw, points, focal=0.85):
+    """One step of the product path (Model + LossFlow, as helpers.run_ours drives it) on tensors that ALREADY live on the GPU and
+    are used in place (frame windows of the whole video included): loss (python float), V = Σmask (python float, fp64 sum) and the
+    gradients, left on the GPU."""
+    import flowmap_amd
+    from flowmap_amd import Batch
+    from flowmap_amd.loss import LossFlow, LossFlowCfg
+    from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
+
+    f = depth.shape[0]
+    flowmap_amd.set_lazy_surfaces(True)
+    try:
+        cfg = ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", float(focal)),
+                       ExtrinsicsProcrustesCfg("procrustes", points, False))
+        with torch.device("meta"):
+            model = Model(cfg, num_frames=2, image_shape=(2, 2))  # (no 10 GB host allocation for parameters that are replaced below)
+        model = model.to_empty(device=depth.device)
+        model.intrinsics.focal_length.data = torch.tensor(float(focal), device=depth.device)
+        model.backbone.depth = torch.nn.Parameter(depth)
+        model.backbone.weights = torch.nn.Parameter(wlogit)
+        model.extrinsics = type(model.extrinsics)(cfg.extrinsics, f)
+        batch = Batch(torch.zeros((1, f, 3, 1, 1), device=depth.device).expand(1, f, 3, *hw))
+        loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
+        out = model(batch, flows, 0)
+        loss = loss_fn(batch, flows, None, out, 0)
+        loss.backward()
+        valid = float(flows.forward_mask.sum(dtype=torch.float64) + flows.backward_mask.sum(dtype=torch.float64))
+        return {"loss": float(loss.detach().double()), "valid": valid, "extrinsics": out.extrinsics.detach(),
+                "g_depth": model.backbone.depth.grad, "g_wlogit": model.backbone.weights.grad,
+                "g_focal": float(model.intrinsics.focal_length.grad.double())}
+    finally:
+        flowmap_amd.set_lazy_surfaces(False)
+
+
+def test_c4_whole_1200x1080x1920_on_one_gpu():
+    """BASELINE.json configs[4] WHOLE on one MI355X: 1200 frames @ 1080x1920 of i.i.d. inputs = 2.49e9 pixels, 79.6 GB of inputs + a
+    59.7 GB packed copy + 10 GB gradients of the 288 GB.  Element offsets pass 2^31 at frame 1036 (2^32 bytes at frame 518, 2^32 elements
+    of the packed buffer at frame 350), grid.y = 1200, the pose chain has 1199 links.  Too big for the oracle whole, so:
+      * run-to-run agreement of the whole video (packed kernel);
+      * additivity over the eight 150-frame shards configs[4] assigns to eight GPUs (each the size test_c4_shard_... holds against the
+        fp64 oracle): Σ loss_s·V_s = loss·V, interior frames' dL/ddepth equal, halo frames' sum, Σ dL/dfocal_s·V_s = dL/dfocal·V;
+      * a four-frame window BEYOND element 2^31 (frames 1100..1103) against the fp64 oracle: dL/ddepth and dL/dweights of its interior
+        frames / pair depend on nothing outside the window (the relative pose of a pair is a function of its two frames)."""
+    from flowmap_amd import Flows, _ops
+    from flowmap_amd.sharding import shard_frames, shard_pairs
+    from helpers import run_oracle
+
+    if torch.cuda.get_device_properties(0).total_memory < 250 * 2**30:
+        pytest.skip("needs a 288 GB GPU")
+    f, h, w, p = 1200, 1080, 1920, 1000
+    g = torch.Generator(device=DEV).manual_seed(4)
+    depth = 1.10 + 0.05 * torch.rand((f, h, w), device=DEV, generator=g)
+    wlogit = 0.01 * torch.randn((f - 1, h, w), device=DEV, generator=g)
+    flows = Flows(0.01 * torch.randn((1, f - 1, h, w, 2), device=DEV, generator=g), 0.01 * torch.randn((1, f - 1, h, w, 2), device=DEV, generator=g),
+                  torch.rand((1, f - 1, h, w), device=DEV, generator=g), torch.rand((1, f - 1, h, w), device=DEV, generator=g))
+    assert depth.numel() > 2**31 and flows.forward.numel() > 2**32
+
+    _ops.pack_on_first_sight = True
+    try:
+        whole = _gpu_step(depth, wlogit, flows, (h, w), p)
+        assert flows.forward.__dict__.get("_fm_packed") is not None, "the whole-video step did not run the packed kernel"
+        assert flows.forward.__dict__["_fm_packed"][1][1].numel() > 2**32
+        again = _gpu_step(depth, wlogit, flows, (h, w), p)
+        assert whole["loss"] == whole["loss"] and bool(torch.isfinite(whole["g_depth"]).all())
+        record = {"case": "C4 whole (1200 x 1080x1920, i.i.d., flow, one GPU)", "loss": whole["loss"], "valid": whole["valid"],
+                  "run_to_run_loss": abs(again["loss"] - whole["loss"]) / abs(whole["loss"]),
+                  "run_to_run_g_depth": _device_relerr(again["g_depth"], whole["g_depth"]), "run_to_run_g_wlogit": _device_relerr(again["g_wlogit"], whole["g_wlogit"])}
+        assert record["run_to_run_loss"] <= 1e-6 and record["run_to_run_g_depth"] <= 1e-5 and record["run_to_run_g_wlogit"] <= 1e-5, record
+        del again
+        torch.cuda.empty_cache()
+
+        # -- the eight shards of configs[4] --
+        num, focal_sum, worst = 0.0, 0.0, {"interior": 0.0, "halo": 0.0, "wlogit": 0.0}
+        halo_carry = None
+        for a, b in shard_pairs(f - 1, 8):
+            lo, hi = shard_frames((a, b))
+            part = Flows(*(x[:, a:b] for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)))
+            sh = _gpu_step(depth[lo : hi + 1], wlogit[a:b], part, (h, w), p)
+            scale = sh["valid"] / whole["valid"]  # the shard normalises by its own Σmask
+            num += sh["loss"] * scale
+            focal_sum += sh["g_focal"] * scale
+            gd = sh["g_depth"] * scale
+            worst["interior"] = max(worst["interior"], _device_relerr(gd[1:-1], whole["g_depth"][lo + 1 : hi]))
+            worst["wlogit"] = max(worst["wlogit"], _device_relerr(sh["g_wlogit"] * scale, whole["g_wlogit"][a:b]))
+            first = gd[0] if halo_carry is None else gd[0] + halo_carry
+            worst["halo"] = max(worst["halo"], _device_relerr(first, whole["g_depth"][lo]))
+            halo_carry = gd[-1].clone()
+            del sh, gd, part
+            torch.cuda.empty_cache()
+        worst["halo"] = max(worst["halo"], _device_relerr(halo_carry, whole["g_depth"][f - 1]))
+        record.update({"shard_additivity_loss": abs(num - whole["loss"]) / abs(whole["loss"]),
+                       "shard_additivity_g_focal_abs": abs(focal_sum - whole["g_focal"]), "g_focal": whole["g_focal"],
+                       "shard_g_depth_interior": worst["interior"], "shard_g_depth_halo": worst["halo"], "shard_g_wlogit": worst["wlogit"]})
+
+        # -- a window beyond element 2^31 against the oracle --
+        lo, hi = 1100, 1103
+        assert lo * h * w > 2**31
+        win = orc.OFlows(*(x[:, lo:hi].cpu() for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)))
+        d_win, w_win = depth[lo : hi + 1].cpu(), wlogit[lo:hi].cpu()
+        truth = run_oracle(d_win, w_win, 0.85, win, (h, w), p, dtype=torch.float64)
+        ref32 = run_oracle(d_win, w_win, 0.85, win, (h, w), p, dtype=torch.float32)
+        v_win = float(win.forward_mask.sum(dtype=torch.float64) + win.backward_mask.sum(dtype=torch.float64))
+        scale = whole["valid"] / v_win  # the whole video normalises by ITS Σmask
+        ours_d = (whole["g_depth"][lo + 1 : hi] * scale).cpu()
+        ours_w = (whole["g_wlogit"][lo + 1 : hi - 1] * scale).cpu()  # the pair between the two interior frames
+        touched = step_masks((h, w), p, win)["procrustes"][1:-1]
+        for key, ours, tr, r32 in (("g_depth", ours_d, truth["g_depth"][1:-1], ref32["g_depth"][1:-1]),
+                                    ("g_depth[procrustes]", ours_d[touched], truth["g_depth"][1:-1][touched], ref32["g_depth"][1:-1][touched]),
+                                    ("g_wlogit", ours_w, truth["g_wlogit"][1:-1], ref32["g_wlogit"][1:-1])):
+            record["window_" + key] = relerr(ours, tr)
+            record["window_" + key + "_fp32_reference_gap"] = relerr(r32, tr)
+        emit(record)
+        assert record["shard_additivity_loss"] <= 1e-5, record
+        assert record["shard_g_depth_interior"] <= 1e-4 and record["shard_g_depth_halo"] <= 1e-4 and record["shard_g_wlogit"] <= 1e-4, record
+        for key in ("g_depth", "g_depth[procrustes]", "g_wlogit"):
+            assert record["window_" + key] <= max(1e-4, 2.0 * record["window_" + key + "_fp32_reference_gap"]), (key, record)
+    finally:
+        _ops.pack_on_first_sight = False

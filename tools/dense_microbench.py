@@ -72,6 +72,7 @@ def timed(fn, reps=5):
 P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 st = torch.cuda.current_stream().cuda_stream
 out = {}
+shipped_stats = {}  # the fit's fp64 moments per flow kind from the shipped library: every variant must reproduce them
 for name, path in libs.items():
     lib = bind(path)
     for kind, flow in flows.items():
@@ -89,6 +90,9 @@ for name, path in libs.items():
             assert lib.fm_procrustes_fit(P(depth), P(kinv), None, P(flow), P(logit), 100.0, None, h * w, 1, 1, f, h, w, P(stats), P(t_bwd), P(t_fwd), P(aux), st) == 0
 
         fit()
+        if name == "shipped":
+            shipped_stats[kind] = stats.clone()
+        stats_gap = float(((stats - shipped_stats[kind]).abs().amax(0) / shipped_stats[kind].abs().amax(0).clamp_min(1e-300)).max()) if kind in shipped_stats else None
         assert lib.fm_pose_solve_bwd(P(g_t), None, P(t_bwd), P(aux), pairs, P(pair_grad), None, 0, st) == 0
 
         def fused():
@@ -108,6 +112,6 @@ for name, path in libs.items():
         fused()
         gap = float((g_depth - planned).norm() / planned.norm())
         out[f"{name}/{kind}"] = {"fit_ms": round(a, 3), "weights_only_ms": round(b, 3), "later_plus_taps_ms": round(c, 3), "fused_ms": round(d, 3),
-                                 "fused_vs_planned": gap, "entries_per_pixel": round(entries.numel() / (pairs * h * w), 4)}
+                                 "fused_vs_planned": gap, "moments_vs_shipped": stats_gap, "entries_per_pixel": round(entries.numel() / (pairs * h * w), 4)}
         print(name, kind, out[f"{name}/{kind}"], flush=True)
 print(json.dumps(out))
