@@ -110,6 +110,10 @@ def parse():
                          "one-rank RCCL communicator): the per-rank step time of a K-GPU run without the wire time")
     ap.add_argument("--share-rank", type=int, default=-1, help="which rank's share (default: an interior rank with the largest share)")
     ap.add_argument("--count-launches", action="store_true", help="count the kernel launches of one step with torch.profiler (after the timed region)")
+    ap.add_argument("--sustained-steps", type=int, default=100,
+                    help="N = 1: after the timed K steps, N more steps timed separately and reported as `sustained` (informational; `value` stays the K steps "
+                         "after W warm-up steps).  The first ~30 launches after an idle period run on a power-management transient (profiles/r04_driver_command_ramp.txt): "
+                         "a 20-step run measures that transient, a 2000-step overfit run the sustained state.  0 = skip")
     ap.add_argument("--whole", action="store_true",
                     help="config c4 WHOLE on one GPU: all 1200 frames @ 1080x1920 (79.6 GB of inputs + a 59.7 GB packed copy of the 288 GB) instead of "
                          "one GPU's 150-frame shard; implies --release-originals")
@@ -571,6 +575,19 @@ def main():
 
     flow_ms = _ops.flow_kernel_times() if not args.graph else eager_flow_ms
     track_ms = _ops.flow_kernel_times(tracking=True)
+    sustained = None
+    if world == 1 and on_gpu and not args.graph and args.sustained_steps > 0:  # the same step, straight on: the state a long run is in
+        t1 = time.perf_counter()
+        for _ in range(args.sustained_steps):
+            step()
+        sync_device()
+        dt = time.perf_counter() - t1
+        more = _ops.flow_kernel_times()
+        _ops.flow_kernel_times(tracking=True)
+        sustained = {"steps": args.sustained_steps, "after_steps": args.steps, "ms_per_step": dt / args.sustained_steps * 1e3, "value": args.sustained_steps / dt,
+                     "kernel_ms": sum(more) / max(len(more), 1),
+                     "note": "informational: the steps that follow the timed region without a pause — `value` above is the contract's K steps after W warm-up steps, "
+                             "which at K = 20, W = 5 lie on the power-management transient of a GPU that was idle (kernel_ms_per_launch shows it)"}
     _ops.flow_kernel_timing(False)
     kernel_ms = sum(flow_ms) / max(len(flow_ms), 1)
     traffic, traffic_src = None, None
@@ -660,6 +677,10 @@ def main():
                 "kernel_ms_first5_last5": [sum(flow_ms[:5]) / 5, sum(flow_ms[-5:]) / 5] if len(flow_ms) >= 10 else None,
             },
         }
+        if sustained is not None:
+            n_bytes = algo_bytes
+            sustained["roofline_frac"] = (n_bytes / (sustained["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if sustained["kernel_ms"] > 0 else None
+            result["sustained"] = sustained
         if track_ms:
             residuals = sum(int(t.xy.shape[1]) ** 2 * int(t.xy.shape[2]) for t in tracks)
             if strong:  # this rank evaluates the sources it owns: its share of the residuals

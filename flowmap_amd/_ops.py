@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes
 import warnings
+import weakref
 from typing import Optional
 
 import torch
@@ -36,6 +37,27 @@ AUX_STRIDE = 40
 PAIR_GRAD_STRIDE = 20
 DENSE_CONST_STRIDE = 40  # FM_DENSE_CONST_STRIDE
 TRACK_TILE = 6  # FM_TRACK_TILE (include/flowmap_hip.h; tests/test_abi.py checks they agree)
+
+
+# Device flags (one int32 each) that a backward raises when a loss reached it SCALED although something had already used its unscaled
+# gradient (FusedAdam.fuse_depth_update, FrameShard.enable_early_halo).  Their owners read them every so often; a step replayed as a
+# hipGraph runs no Python, so GraphedStep reads every live flag outside its replays.  Weak: a flag dies with its owner.
+_unit_flags = weakref.WeakSet()
+
+
+def register_unit_flag(flag: Tensor) -> Tensor:
+    _unit_flags.add(flag)
+    return flag
+
+
+def check_unit_flags(what: str) -> None:
+    """Raise (and clear) if any registered flag is up.  Synchronises: callers space their calls out."""
+    for flag in list(_unit_flags):
+        if int(flag.item()) != 0:
+            flag.zero_()
+            raise RuntimeError(f"flowmap_amd: {what}: a loss reached backward() with an upstream gradient other than 1 although its unscaled gradient had "
+                               "already been used (FusedAdam.fuse_depth_update applied it inside the flow pass / FrameShard.enable_early_halo sent it before "
+                               "backward): the affected steps are wrong.  Switch those options off for a scaled or averaged loss.")
 
 
 def _f32c(t: Tensor, what: str) -> Tensor:

@@ -58,10 +58,18 @@ class GraphedStep:
                 self.output = fn()
         finally:
             pass
+        self.replays = 0
+        self.verify_unit_upstream_every = 64  # replays between (synchronising) reads of the "scaled loss" device flags; 0 = never
 
     def __call__(self):
         """Replay the captured step; returns the tensors ``fn`` returned (refreshed in place)."""
         self.graph.replay()
+        self.replays += 1
+        # the Python that reads the "loss was scaled" flags (FusedAdam.step, FrameShard.sync) is not run by a replay: read them here,
+        # after the first replay (a loop that scales its loss does so from the start) and every 64th
+        every = self.verify_unit_upstream_every
+        if every and (self.replays == 1 or self.replays % every == 0):
+            _ops.check_unit_flags("a step replayed as a hipGraph (GraphedStep)")
         return self.output
 
     def close(self) -> None:

@@ -164,7 +164,7 @@ class FusedAdam(torch.optim.Optimizer):
         beta1, beta2 = group["betas"]
         flag = self._scaled_flags.get(param.device)
         if flag is None:  # raised by the loss's backward when its upstream gradient is not 1 (the in-pass update used the unscaled one)
-            flag = self._scaled_flags[param.device] = torch.zeros((1,), dtype=torch.int32, device=param.device)
+            flag = self._scaled_flags[param.device] = _ops.register_unit_flag(torch.zeros((1,), dtype=torch.int32, device=param.device))
         args = (state["exp_avg"].view(depth.shape), state["exp_avg_sq"].view(depth.shape), mask, step,
                 [float(group["lr"]), float(beta1), float(beta2), float(group["eps"])], flag)
         return args, (param, step, elements, halo, sink)
@@ -198,11 +198,13 @@ class FusedAdam(torch.optim.Optimizer):
                         torch_ops().adam_step(p[frame], grad[frame], state["exp_avg"][frame], state["exp_avg_sq"][frame], step, None, *hyper)
                     torch_ops().adam_step_elements(p, grad, state["exp_avg"], state["exp_avg_sq"], elements, step, *hyper)
                     every = self.verify_unit_upstream_every
-                    if every and step % every == 0 and int(self._scaled_flags[p.device].item()) != 0:
+                    first = self.counters["in_pass_updates"] == 1  # a loop that scales its loss does so from its first step: one read there catches it at once
+                    if every and (first or step % every == 0) and int(self._scaled_flags[p.device].item()) != 0:
+                        self._scaled_flags[p.device].zero_()  # reported: a later, correct loop starts clean
                         raise RuntimeError("flowmap_amd.FusedAdam: with fuse_depth_update the loss must reach backward() unscaled — the depth "
                                            "update inside the flow pass used the gradient of the loss itself, but backward() delivered an upstream "
                                            "gradient other than 1 (a scaled or averaged loss, a GradScaler): parameters and optimiser state of "
-                                           f"the last {every} steps are not those of torch.optim.Adam.  Switch fuse_depth_update off for this loop.")
+                                           f"the last {1 if first else every} step(s) are not those of torch.optim.Adam.  Switch fuse_depth_update off for this loop.")
                     continue
                 if p.grad is None:
                     continue

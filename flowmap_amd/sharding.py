@@ -83,6 +83,7 @@ class FrameShard:
     def __init__(self, rank: int = 0, world: int = 1, dist=None, group=None, proxy: bool = False):
         self.rank, self.world, self.dist, self.group, self.proxy = rank, world, dist, group, proxy
         self._halo = None  # (requests, recv_prev, recv_next, gradient) of the exchange in flight
+        self._halo_by_hook = False  # that exchange was posted by the gradient hook (sync() then only completes it)
         self.defer_halo = False  # True: the gradient hook does not post the exchange (GraphedShardedStep: sync() posts it after the replay)
         self._halo_buffers = {}  # (shape, device) -> persistent receive (and proxy send) buffers
         self._packed = None  # (key, buffer, views): [loss, gradients of the shared parameters] reduced in place every step
@@ -171,8 +172,11 @@ class FrameShard:
         ``shared_params``: a parameter, a list of parameters, or None.  No-op for world == 1.
 
         Afterwards every shared parameter's ``.grad`` IS a view of the reduced buffer (no copy back); the buffer is
-        rewritten by the next call.  A shared module with millions of parameters should use ``SharedGradientBuckets``
-        instead (bucketed, overlapped with backward)."""
+        rewritten by the next call — a reference to a gradient kept across steps sees the next step's values (clone it), and so
+        does gradient accumulation across ``sync()`` calls without ``zero_grad``: the slot then holds [reduced previous + local
+        new] and the sum over ranks counts the previous part `world` times (accumulate locally and call ``sync()`` once instead).
+        ``zero_grad(set_to_none=False)`` is fine: the zeroed view is accumulated into in place and reduced where it is.
+        A shared module with millions of parameters should use ``SharedGradientBuckets`` instead (bucketed, overlapped with backward)."""
         extra = 0.0 if already_global is None else already_global.detach()
         if not self.active:
             return loss.detach() if already_global is None else loss.detach() + extra
@@ -183,11 +187,21 @@ class FrameShard:
             shared_params = [shared_params]
         with_grad = [p for p in shared_params if p.grad is not None]
         if depth_param is not None and depth_param.grad is not None:
-            self.start_halo_exchange(depth_param.grad)  # (no hook registered: start it now; a no-op when the hook has posted it)
+            self.start_halo_exchange(depth_param.grad, from_sync=True)  # (no hook registered: start it now; a no-op when the hook has posted it)
         packed, views = self._packed_buffer(loss, with_grad)
         with torch.no_grad():
-            pieces = [loss.detach().reshape(1).to(torch.float32)] + [p.grad.reshape(-1).to(torch.float32) for p in with_grad]
-            torch.cat(pieces, out=packed)  # one launch, into the persistent buffer
+            # a gradient that is STILL the view of its slot (zero_grad(set_to_none=False) zeroed it in place and backward accumulated into
+            # it) is already where the reduction reads it: torch.cat(..., out=packed) would be handed overlapping input and output
+            aliased = [p.grad.data_ptr() == view.data_ptr() and p.grad.shape == view.shape and p.grad.is_contiguous() and p.grad.dtype == torch.float32
+                       for p, view in zip(with_grad, views)]
+            if not any(aliased):
+                pieces = [loss.detach().reshape(1).to(torch.float32)] + [p.grad.reshape(-1).to(torch.float32) for p in with_grad]
+                torch.cat(pieces, out=packed)  # one launch, into the persistent buffer
+            else:
+                packed[:1].copy_(loss.detach().reshape(1))
+                fresh = [(view, p.grad) for p, view, same in zip(with_grad, views, aliased) if not same]
+                if fresh:
+                    torch._foreach_copy_([v for v, _ in fresh], [g.to(torch.float32) for _, g in fresh])
         work = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.finish_halo_exchange()
         work.wait()  # (RCCL: a stream dependency, not a host wait; gloo: blocks)
@@ -211,7 +225,9 @@ class FrameShard:
     def unit_flag(self, device) -> Tensor:
         flag = self._unit_flags.get(device)
         if flag is None:
-            flag = self._unit_flags[device] = torch.zeros((1,), dtype=torch.int32, device=device)
+            from ._ops import register_unit_flag
+
+            flag = self._unit_flags[device] = register_unit_flag(torch.zeros((1,), dtype=torch.int32, device=device))
         return flag
 
     @staticmethod
@@ -341,19 +357,31 @@ class FrameShard:
                  ptr(e["theirs"]["next"]), ptr(e["delta_in"].get("next")), cnt("next"), stream_for(depth_grad))
         self._syncs += 1
         capturing = depth_grad.is_cuda and torch.cuda.is_current_stream_capturing()  # (a host read cannot sit inside a hipGraph capture)
-        if self._syncs % 64 == 0 and not capturing and int(self.unit_flag(depth_grad.device).item()) != 0:
+        # (read at the first exchange — a loop that scales its loss does so from its first step — and every 64th after it; a step replayed as a
+        # hipGraph never reaches this Python: GraphedStep / GraphedShardedStep read the flag outside the replay, flowmap_amd/graph.py)
+        if (self._syncs == 1 or self._syncs % 64 == 0) and not capturing and int(self.unit_flag(depth_grad.device).item()) != 0:
+            self.unit_flag(depth_grad.device).zero_()  # reported: a later, correct loop starts clean
             raise RuntimeError("flowmap_amd.FrameShard: with enable_early_halo() the flow loss must reach backward() unscaled (the boundary frames' "
                                "gradient was sent before backward ran); disable_early_halo() for a scaled loss")
 
-    def start_halo_exchange(self, depth_grad: Tensor) -> None:
+    def start_halo_exchange(self, depth_grad: Tensor, from_sync: bool = False) -> None:
         """depth_grad (F_local, H, W): the LAST local frame is rank+1's FIRST local frame; post the sends and
-        receives of the two boundary frames (asynchronous)."""
+        receives of the two boundary frames (asynchronous).  ``from_sync``: the call sync() makes after backward — a no-op when
+        the gradient hook of the same backward has already posted the exchange (an explicit per-exchange flag, not an inference
+        from the gradient's version counter)."""
         if not self.active:
             return
         if self._halo is not None:
-            if self._halo[3] is depth_grad and self._halo[4] == depth_grad._version:
-                return  # already posted for this very gradient (the hook ran, sync() asks again)
+            if from_sync and self._halo_by_hook and self._halo[3] is depth_grad:
+                # the gradient hook of THIS backward posted it; sync() only asks again.  An in-place edit of the gradient in between
+                # (clip_grad_norm_, a scaling, a second backward without sync) would make the posted frame stale and the neighbour's part
+                # be added to something else: refuse instead of exchanging twice
+                if self._halo[4] != depth_grad._version:
+                    raise RuntimeError("flowmap_amd.FrameShard: dL/ddepth was modified in place between backward and sync() while its halo exchange "
+                                       "was in flight; modify gradients after sync(), or set shard.defer_halo = True so that sync() posts the exchange")
+                return
             self.finish_halo_exchange()  # a backward that never reached sync(): complete it (every rank does) before the next one
+        self._halo_by_hook = not from_sync
         if self._early is not None and self._early["inflight"] is not None:  # the dense part left after the flow pass: only the sparse rest now
             self._start_sparse_halo(depth_grad)
             return

@@ -24,6 +24,10 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--points", type=int, default=1000)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="frames per call: the video evaluated as consecutive windows of this many frames (sharing their boundary frame), one "
+                         "forward + backward each.  Round 4: the whole-video call aborts with a GPU memory-access fault from 32 frames @ 720p on "
+                         "(profiles/r04_stock_pytorch_rocm_fault_32_and_150_frames.txt; 16 frames run), so the 150-frame figure is the sum of its 16-frame windows")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     f, h, w = args.frames, args.height, args.width
@@ -37,9 +41,18 @@ def main():
     def step():
         for p in (depth, wlogit, focal):
             p.grad = None
-        total, _, _ = orc.explicit_depth_step(depth, wlogit, focal, flows, (h, w), num_points=args.points)
-        total.backward()
-        return total
+        if args.chunk <= 1 or args.chunk >= f:
+            total, _, _ = orc.explicit_depth_step(depth, wlogit, focal, flows, (h, w), num_points=args.points)
+            total.backward()
+            return total
+        value = 0.0
+        for lo in range(0, f - 1, args.chunk - 1):  # windows [lo, lo + chunk) share their boundary frame: every pair once
+            hi = min(lo + args.chunk, f)
+            part = orc.OFlows(*(x[:, lo : hi - 1] for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)))
+            total, _, _ = orc.explicit_depth_step(depth[lo:hi], wlogit[lo : hi - 1], focal, part, (h, w), num_points=args.points)
+            total.backward()
+            value = value + total.detach()
+        return value
 
     step()
     torch.cuda.synchronize()
@@ -50,7 +63,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.iters
     print(json.dumps({"what": "reference op sequence (oracle) on stock PyTorch-ROCm, same GPU, fwd+bwd", "frames": f, "height": h, "width": w,
-                      "procrustes_points": args.points, "ms_per_step": dt * 1e3, "iters_per_sec": 1.0 / dt,
+                      "procrustes_points": args.points, "frames_per_call": args.chunk if 1 < args.chunk < f else f, "ms_per_step": dt * 1e3, "iters_per_sec": 1.0 / dt,
                       "peak_memory_gb": torch.cuda.max_memory_allocated() / 1e9, "loss": float(loss.detach())}))
 
 
