@@ -91,6 +91,9 @@ def frame_window_layout(t: Tensor) -> Optional[tuple]:
     if t.shape[1] != 1 and t.stride(1) < per_frame:
         return None
     frame_stride = per_frame if t.shape[1] == 1 else t.stride(1)
+    # batch entries must not overlap (the launchers refuse it): a batch-expanded stack (stride 0 over the batch) is copied by the caller
+    if t.shape[0] != 1 and t.stride(0) < frame_stride * (t.shape[1] - 1) + per_frame:
+        return None
     return (frame_stride, frame_stride * t.shape[1] if t.shape[0] == 1 else t.stride(0))
 
 

@@ -137,11 +137,16 @@ static ImageStack image_stack(const Tensor& t, const char* what) {
     if (t.size(d) != 1 && t.stride(d) != per_frame) frames_dense = false;
     per_frame *= t.size(d);
   }
-  if (frames_dense && (t.size(1) == 1 || t.stride(1) >= per_frame) && (t.size(0) == 1 || t.stride(0) >= 0)) {
-    out.t = t;
-    out.lay.frame_stride = t.size(1) == 1 ? per_frame : t.stride(1);
-    out.lay.batch_stride = t.size(0) == 1 ? out.lay.frame_stride * t.size(1) : t.stride(0);
-    return out;
+  if (frames_dense && (t.size(1) == 1 || t.stride(1) >= per_frame)) {
+    const int64_t frame_stride = t.size(1) == 1 ? per_frame : t.stride(1);
+    // batch entries must not overlap — the launchers (flow_loss_launch, pack_launch) refuse a batch stride below the extent of one entry, so
+    // a batch-EXPANDED stack (stride 0 over the batch) is copied here instead of failing there with "invalid argument"
+    if (t.size(0) == 1 || t.stride(0) >= frame_stride * (t.size(1) - 1) + per_frame) {
+      out.t = t;
+      out.lay.frame_stride = frame_stride;
+      out.lay.batch_stride = t.size(0) == 1 ? frame_stride * t.size(1) : t.stride(0);
+      return out;
+    }
   }
   ++view_copy_counter();
   out.t = f32c(t, what);

@@ -1517,6 +1517,22 @@ def case_frame_windows(dev):
         xy, _ = fm.sample_image_grid((h, w), dev)
         fm.align_surfaces(fm.unproject(xy, odd, k[:, :, None, None]), flows_full[1][:, s0 : s0 + f - 1], weights_full[:, s0 : s0 + f - 1], idx)
         assert torch_ops().view_copies() == copies + 1
+        # batch-EXPANDED stacks (stride 0 over the batch: one video's flows / masks shown to every batch entry) overlap between batch
+        # entries, which the launchers refuse: the binding copies them instead of passing them on as "views" 
+        assert _ops.frame_window_layout(flows_full[2][:1].expand(b, -1, -1, -1)) is None
+        one = Flows(*(t[:1, s0 : s0 + f - 1].expand(b, *t.shape[1:][:0], f - 1, *t.shape[2:]) for t in flows_full))
+        same = Flows(*(t.contiguous() for t in (one.forward, one.backward, one.forward_mask, one.backward_mask)))
+        results = []
+        for fl in (one, same):
+            d = depth_full[:, s0 : s0 + f].clone().requires_grad_(True)
+            surfaces = fm.unproject(xy, d, k[:, :, None, None])
+            wt = weights_full[:, s0 : s0 + f - 1].contiguous()
+            ext = fm.align_surfaces(surfaces, fl.backward, wt, idx)
+            loss = loss_fn(Batch(torch.zeros((b, f, 3, h, w), device=dev)), fl, None, ModelOutput(d, surfaces, k, ext, wt), 0)
+            loss.backward()
+            results.append((loss.detach(), d.grad))
+        assert_close(results[0][0], results[1][0], 1e-6, what="loss, batch-expanded flows")
+        assert_close(results[0][1], results[1][1], 1e-6, abs_=1e-9, what="g_depth, batch-expanded flows")
     finally:
         fm.set_lazy_surfaces(False)
 

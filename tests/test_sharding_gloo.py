@@ -492,3 +492,86 @@ def test_early_halo_exchange_gives_the_same_gradients(tmp_path, with_tracks):
             _focal_close(g_focal, ref)
         for early_step in (2, 3, 4):  # against the one-shot exchange of step 1: the same sums in another order
             assert_close(got["history"][early_step][1], got["history"][1][1], 1e-5, abs_=1e-9, what=f"early vs one-shot exchange, rank {rank}")
+
+
+def _kept_grad_worker(rank, world, port, f, h, w, points, out_path):
+    """Steps that KEEP their gradient tensors (optimizer.zero_grad(set_to_none=False)): after the first sync() every shared parameter's .grad
+    is the view of its slot in the persistent reduction buffer, zeroed in place and accumulated into by the next backward."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import flowmap_amd
+    from flowmap_amd import Batch, Flows, _lib
+    from flowmap_amd.loss import LossFlow, LossFlowCfg
+    from flowmap_amd.loss.mapping import MappingHuberCfg
+    from flowmap_amd.model.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap_amd.model.model import BackboneExplicitDepthCfg, IntrinsicsRegressedCfg, Model, ModelCfg
+    from flowmap_amd.sharding import FrameShard
+    from helpers import build_host_sim
+    from oracle import flowmap_oracle as orc
+
+    _lib.set_library_for_testing(build_host_sim())
+    flowmap_amd.set_lazy_surfaces(True)
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
+    a, b = shard_pairs(f - 1, world)[rank]
+    lo, hi = shard_frames((a, b))
+    nf = hi - lo + 1
+    model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", 0.85),
+                           ExtrinsicsProcrustesCfg("procrustes", points, False)), num_frames=nf, image_shape=(h, w))
+    model.backbone.depth.data = depth[lo : hi + 1].clone()
+    model.backbone.weights.data = wlogit[a:b].clone()
+    local = Flows(*(x[:, a:b].contiguous() for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)))
+    batch = Batch(torch.zeros((1, nf, 3, h, w)))
+    loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
+    shard = FrameShard(rank, world, dist)
+    shard.prepare_flow_loss(loss_fn, local)
+    shard.prepare_model(model)
+    history, aliased = [], []
+    focal = model.intrinsics.focal_length
+    for step in range(4):
+        model.zero_grad(set_to_none=False)
+        loss = loss_fn(batch, local, None, model(batch, local, 0), 0)
+        loss.backward()
+        aliased.append(shard._packed is not None and focal.grad is not None and focal.grad.data_ptr() == shard._packed[2][0].data_ptr())
+        total = shard.sync(loss, [focal], model.backbone.depth)
+        history.append((total.clone(), model.backbone.depth.grad.clone(), focal.grad.clone()))
+    # an in-place edit of dL/ddepth between backward (whose hook posted the halo exchange) and sync(): refused, not exchanged twice
+    model.zero_grad(set_to_none=False)
+    loss = loss_fn(batch, local, None, model(batch, local, 0), 0)
+    loss.backward()
+    model.backbone.depth.grad.mul_(1.0)
+    refused = False
+    try:
+        shard.sync(loss, [focal], model.backbone.depth)
+    except RuntimeError as exc:
+        refused = "modified in place" in str(exc)
+    shard.finish_halo_exchange()  # (complete what was posted: every rank does)
+    torch.save({"history": history, "aliased": aliased, "refused": refused, "frames": (lo, hi)}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sync_with_gradients_kept_across_steps(tmp_path):
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import assert_close
+    from helpers import run_oracle
+    from oracle import flowmap_oracle as orc
+
+    f, h, w, points, world = 7, 12, 16, 40, 2
+    out = str(tmp_path / "kept")
+    mp.spawn(_kept_grad_worker, args=(world, _free_port(), f, h, w, points, out), nprocs=world, join=True)
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
+    ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, dtype=torch.float64)
+    for rank in range(world):
+        got = torch.load(f"{out}.{rank}")
+        assert got["aliased"] == [False, True, True, True], got["aliased"]  # from the second step on the gradient IS its slot of the buffer
+        assert got["refused"]
+        lo, hi = got["frames"]
+        for step, (total, g_depth, g_focal) in enumerate(got["history"]):
+            assert_close(total, ref["total"], 1e-5, what=f"global loss, step {step}")
+            assert_close(g_depth, ref["g_depth"][lo : hi + 1], 1e-4, what=f"g_depth of rank {rank}, step {step}")
+            _focal_close(g_focal, ref)
