@@ -81,24 +81,35 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
     ref_loss = importlib.import_module("flowmap.loss")
     ref_mapping = importlib.import_module("flowmap.loss.mapping")
     ref_extr = importlib.import_module("flowmap.model.extrinsics")
+    # Every name is bound to a DISPATCHER: tensors on the GPU go to this package's kernels, tensors on the host to the reference's own
+    # function, which is right here (flowmap_amd/_reference.py; SURVEY.md §8b: "CPU tensors -> the reference-equivalent torch path",
+    # BASELINE.json configs[0]).  The classes in the registries dispatch inside their forward() the same way.
+    from . import _reference
+
+    _reference.twins.clear()
     public = [n for n in dir(our_projection) if not n.startswith("_") and hasattr(ref_projection, n) and callable(getattr(our_projection, n))]
+    originals = {name: getattr(ref_projection, name) for name in public}
+    originals["align_rigid"] = ref_procrustes.align_rigid
+    bound = {name: _reference.dispatching(name, getattr(our_projection, name), originals[name]) for name in public}
+    bound["align_rigid"] = _reference.dispatching("align_rigid", our_procrustes.align_rigid, originals["align_rigid"])
+    # IntrinsicsSoftmin reshapes / indexes the surfaces with einops right away (intrinsics_softmin.py:104-109): the materialising variant
+    bound_unproject_dense = _reference.dispatching("unproject", our_projection.unproject_dense, originals["unproject"])
     for name in public:
-        _set(ref_projection, name, getattr(our_projection, name))
-    _set(ref_procrustes, "align_rigid", our_procrustes.align_rigid)
+        _set(ref_projection, name, bound[name])
+    _set(ref_procrustes, "align_rigid", bound["align_rigid"])
 
     for mod_name, names in _IMPORT_SITES.items():
         mod = sites.get(mod_name)
         if mod is None:
             continue
         for name in names:
-            src = our_procrustes if name == "align_rigid" else our_projection
-            value = getattr(src, name)
-            if name == "unproject" and mod_name.endswith("intrinsics_softmin"):
-                # IntrinsicsSoftmin reshapes / indexes the surfaces with einops right away
-                # (intrinsics_softmin.py:104-109): hand it the materialising variant.
-                value = our_projection.unproject_dense
+            value = bound_unproject_dense if (name == "unproject" and mod_name.endswith("intrinsics_softmin")) else bound[name]
             _set(mod, name, value)
 
+    _reference.twins.update({"LossFlow": ref_loss.LOSSES["flow"], "LossTracking": ref_loss.LOSSES["tracking"],
+                             "ExtrinsicsProcrustes": ref_extr.EXTRINSICS["procrustes"]})
+    for kind, cls in ref_mapping.MAPPINGS.items():
+        _reference.twins["Mapping:" + kind] = cls
     _set(ref_loss, "LOSSES", {**ref_loss.LOSSES, "flow": our_loss.LossFlow, "tracking": our_loss.LossTracking})
     _set(ref_mapping, "MAPPINGS", {**ref_mapping.MAPPINGS, **our_mapping.MAPPINGS})
     _set(ref_extr, "EXTRINSICS", {**ref_extr.EXTRINSICS, "procrustes": ExtrinsicsProcrustes})
@@ -106,12 +117,14 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
         from .model.intrinsics_softmin import IntrinsicsSoftmin
 
         ref_intr = importlib.import_module("flowmap.model.intrinsics")
+        _reference.twins["IntrinsicsSoftmin"] = ref_intr.INTRINSICS["softmin"]
         _set(ref_intr, "INTRINSICS", {**ref_intr.INTRINSICS, "softmin": IntrinsicsSoftmin})
 
     if fused_regressed:
         from .model.model import IntrinsicsRegressed
 
         ref_intr = importlib.import_module("flowmap.model.intrinsics")
+        _reference.twins["IntrinsicsRegressed"] = ref_intr.INTRINSICS["regressed"]
         _set(ref_intr, "INTRINSICS", {**ref_intr.INTRINSICS, "regressed": IntrinsicsRegressed})
 
     if flow_postprocess:
@@ -119,13 +132,19 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
 
         ref_fp = importlib.import_module("flowmap.flow.flow_predictor")
 
+        ref_bidirectional = ref_fp.FlowPredictor.compute_bidirectional_flow
+
         def compute_bidirectional_flow(self, batch, flow_shape):
+            if _reference.on_host(batch):  # host tensors: the reference's own method
+                return ref_bidirectional(self, batch, flow_shape)
             videos = batch.videos
             forward, forward_mask = _ops.flow_postprocess(videos, self.forward(videos), flow_shape, reverse=False)
             backward, backward_mask = _ops.flow_postprocess(videos, self.forward(videos.flip(dims=(1,))), flow_shape, reverse=True)
             return ref_fp.Flows(forward, backward, forward_mask, backward_mask)
 
-        _set(ref_fp.FlowPredictor, "compute_consistency_mask", staticmethod(_ops.consistency_mask))
+        ref_consistency = ref_fp.FlowPredictor.__dict__["compute_consistency_mask"]
+        ref_consistency = ref_consistency.__func__ if isinstance(ref_consistency, staticmethod) else ref_consistency
+        _set(ref_fp.FlowPredictor, "compute_consistency_mask", staticmethod(_reference.dispatching("compute_consistency_mask", _ops.consistency_mask, ref_consistency)))
         _set(ref_fp.FlowPredictor, "compute_bidirectional_flow", compute_bidirectional_flow)
 
     if fused_adam:
@@ -136,7 +155,11 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
         if ref_wrapper is not None:
             from .optim import FusedAdam
 
+            ref_configure = ref_wrapper.ModelWrapperOverfit.configure_optimizers
+
             def configure_optimizers(self):
+                if not _lib_is_double() and any(p.device.type == "cpu" for p in self.parameters()):
+                    return ref_configure(self)  # host parameters: torch.optim.Adam, as the reference builds it (model_wrapper_overfit.py:104-105)
                 return FusedAdam(self.parameters(), lr=self.cfg.lr)
 
             _set(ref_wrapper.ModelWrapperOverfit, "configure_optimizers", configure_optimizers)
@@ -151,11 +174,25 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
                 crop_sites.append(importlib.import_module(mod_name))
             except Exception:  # hydra / lightning are not installed
                 pass
+        import torch
+
+        def without_gpu(ours, ref):  # (the fused resize + crop takes a HOST batch and uploads it: what decides is whether there is a GPU at all)
+            import functools
+
+            @functools.wraps(ours)
+            def call(*args, **kwargs):
+                if not torch.cuda.is_available() and not _lib_is_double():
+                    return ref(*args, **kwargs)
+                return ours(*args, **kwargs)
+
+            return call
+
         for name in _CROPPING_NAMES:
-            _set(ref_cropping, name, getattr(our_cropping, name))
+            value = without_gpu(getattr(our_cropping, name), getattr(ref_cropping, name))
+            _set(ref_cropping, name, value)
             for mod in crop_sites:
                 if hasattr(mod, name):
-                    _set(mod, name, getattr(our_cropping, name))
+                    _set(mod, name, value)
 
     if lazy_surfaces:
         # flowmap/overfit.py:15-19 imports the package under jaxtyping's import hook, which type-checks
@@ -166,6 +203,12 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
         _set(ref_model, "ModelOutput", _plain_constructor_subclass(ref_model.ModelOutput))
 
     our_projection.set_lazy_surfaces(lazy_surfaces)
+
+
+def _lib_is_double() -> bool:
+    from . import _lib
+
+    return _lib.using_test_double()
 
 
 def _plain_constructor_subclass(base):
@@ -185,6 +228,9 @@ def _plain_constructor_subclass(base):
 def uninstall() -> None:
     from .model import projection as our_projection
 
+    from . import _reference
+
+    _reference.twins.clear()
     while _saved:
         obj, name, old = _saved.pop()
         if old is _MISSING:

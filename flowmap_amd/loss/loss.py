@@ -8,6 +8,8 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
+from .. import _reference
+
 
 def or_one(valid_sum: Tensor) -> Tensor:
     """``valid_sum or 1`` (loss_flow.py:70, loss_tracking.py:61) without the device->host
@@ -34,7 +36,16 @@ class Loss(nn.Module):
         super().__init__()
         self.cfg = cfg
 
+    # the reference class this one replaces in flowmap.loss.LOSSES (its name in flowmap_amd._reference.twins); None: no host path
+    reference_name: Optional[str] = None
+
     def forward(self, batch, flows, tracks: Optional[list], model_output, global_step: int) -> Tensor:
+        ref_cls = _reference.host_twin(self.reference_name, batch) if self.reference_name else None
+        if ref_cls is not None:  # host tensors after install(): the reference's own loss (flowmap_amd/_reference.py)
+            twin = self.__dict__.get("_fm_host_twin")
+            if twin is None or type(twin) is not ref_cls:
+                twin = self.__dict__["_fm_host_twin"] = ref_cls(self.cfg)
+            return twin.forward(batch, flows, tracks, model_output, global_step)
         if global_step >= self.cfg.enable_after:
             return self.compute_weighted_loss(batch, flows, tracks, model_output, global_step, self.cfg.weight)
         # loss.py:39-41: a constant 0 until the loss is switched on

@@ -30,6 +30,8 @@ class LossFlow(Loss[LossFlowCfg]):
     kernel with its own backward.
     """
 
+    reference_name = "LossFlow"
+
     # tuning knob of the fused kernel (items per thread); None -> library default
     items_per_thread: Optional[int] = None
     # park the dense depth gradient on the Procrustes node instead of returning it twice

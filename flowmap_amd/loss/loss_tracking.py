@@ -31,6 +31,8 @@ class LossTracking(Loss[LossTrackingCfg]):
     composition of compute_track_flow -> mapping -> masked sums.
     """
 
+    reference_name = "LossTracking"
+
     # let ProcrustesFit.backward apply our sparse depth scatter to its final buffer
     defer_depth_scatter: bool = True
 

