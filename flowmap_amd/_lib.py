@@ -30,6 +30,7 @@ SIGNATURES = {
     "fm_flow_loss_fused": [P] * 11 + [I, I, I, I, I, F, F, F, P, P, I, P],
     "fm_flow_loss_fused_adam": [P] * 11 + [I, I, I, I, I, F, F, F, P, P, I, P, P, P, L, D, D, D, D, P],
     "fm_flow_pack_inputs": [P, P, P, P, I, I, I, I, P, P],
+    "fm_flow_loss_fused_taps": [P] * 11 + [I, I, I, I, I, F, F, F, P, P, I, P, P, P, P, L, D, D, D, D, P],
     "fm_flow_loss_finalize": [P] * 6 + [I, I, F, F] + [P] * 4 + [P],
     "fm_flow_valid_norm": [P, P, L, F, P, P, P],
     "fm_scale_if_needed": [P, L, P, L, P, P, P],
@@ -95,6 +96,8 @@ SIGNATURES = {
     "fm_track_points": [P, I] + [P] * 4 + [I] + [P] * 4 + [I, I, I, I, P, P, P, P],
     "fm_track_loss_fwd": [P] * 6 + [I, I, I, P, P, I, I, I, I, F, F, F, F] + [P] * 7 + [P],
     "fm_track_loss_fused_fwd": [P, I, I, I, P, P, P, P, I, P, P, P, P, I, I, I, I, I, I, F, F, F, F] + [P] * 10 + [P],
+    "fm_track_loss_fused_fwd_taps": [P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, I, F, F, F, F] + [P] * 10 + [P] * 6 + [L, P, P],
+    "fm_tap_grad_apply": [P, P, L, P, P, P, P, P],
     "fm_track_loss_bwd": [P] * 7 + [I, P, P, P],
     "fm_track_scatter": [P] * 6 + [I, I, P, P, P, I, I, I, P, P],
     "fm_track_scatter_plan": [P, P, P, P, I, I, I, I, P, P, P],

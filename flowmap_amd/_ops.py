@@ -338,7 +338,8 @@ def _dense_flow_is_rough(bwd_flow: Tensor, h: int, w: int) -> bool:
     return _derived(bwd_flow, "_fm_dense_rough", (bwd_flow._version, h, w), build)
 
 # which backward path the facades selected (tests)
-counters = {"procrustes_planned": 0, "procrustes_dense_planned": 0, "flow_packs": 0, "procrustes_plans_built": 0}
+counters = {"procrustes_planned": 0, "procrustes_dense_planned": 0, "flow_packs": 0, "procrustes_plans_built": 0, "track_tap_samples": 0,
+            "flow_tap_passes": 0, "flow_tap_absorbs": 0}
 
 
 class LeadingFrames:
@@ -711,8 +712,30 @@ class FlowLossFused:
         early = _root(depth).__dict__.get("_fm_early_halo") if (sink is not None and ticket is None and torch.is_grad_enabled()) else None
         if early is not None:
             sink.request_early_dense(early.unit_flag(depth.device))
+        # the tap exchange with the tracking loss (its static taps were registered with the parameter by TrackLossFused): this pass leaves the
+        # depth at every tap in the plan's compact image and absorbs the tracking gradient a look-ahead evaluation left in the sink
+        tap_plan = tap_plan_of(depth) if (sink is not None and torch.is_grad_enabled() and depth.requires_grad) else None
+        if tap_plan is not None and packed is None and not all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (flow_fwd, flow_bwd, mask_fwd, mask_bwd)):
+            tap_plan = None  # (frame windows / unaligned flows: the pass that reads them in place has no tap variant)
+        # (verified only while the version counter still vouches for the image: after a regular update the image was simply out of date, and
+        # whoever sampled it did so before that update)
+        verify = tap_plan is not None and tap_plan.sampled_now and ticket is None and tap_plan.image_valid_for(_root(depth))
+        taps = (None, None, None, None) if tap_plan is None else (tap_plan.mask, tap_plan.chunk_base, tap_plan.image, tap_plan.stale_flag if verify else None)
+        offered = tap_plan is not None and sink.offers_taps()
         loss = torch_ops().flow_loss(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, int(kind), float(delta),
-                                     sink, int(items), acc, *adam)
+                                     sink, int(items), acc, *adam, *taps)
+        if tap_plan is not None:
+            counters["flow_tap_passes"] += 1
+            counters["flow_tap_absorbs"] += int(offered and sink.tap_absorbed())
+            if ticket is None and loss.requires_grad:
+                tap_plan.tag(_root(depth))  # depth as this pass read it: good until the parameter moves
+            else:
+                tap_plan.invalidate()  # (an in-pass Adam update: the pixels other operators keep are updated after this pass)
+            tap_plan.sampled_now = False
+            if verify:
+                capturing = depth.is_cuda and torch.cuda.is_current_stream_capturing()
+                if (tap_plan.samples == 1 or tap_plan.samples % 64 == 0) and not capturing:
+                    tap_plan.check_stale()
         if ticket is not None:  # the operator accepted the arguments and launched: only now does the optimiser's state advance
             optimizer.commit_in_pass(ticket)
         if early is not None:
@@ -1033,6 +1056,8 @@ class PackedTracks:
         self.counts = [self.nblocks, self.ntiles, self.pmax, self.fmax, self.total, int(self.partial), self.last_frame,
                        0 if own is None else int(own[0]), -1 if own is None else int(own[1])]  # ..., source frames owned here [first, end)
         self._plans: dict = {}
+        self._tap_slots: dict = {}
+        self._tap_plans: dict = {}
 
     def scatter_plan(self, height: int, width: int):
         """Where the tracking gradient lands in dL/ddepth, planned once per image shape (tracks are
@@ -1056,8 +1081,113 @@ class PackedTracks:
                     first = torch.zeros((pixels.numel() + 1,), dtype=torch.int32, device=dev)
                     first[1:] = torch.cumsum(counts, 0).to(torch.int32)
                     plan = (pixels.contiguous(), first, (entries // 4).to(torch.int32).contiguous(), weights[entries].contiguous())
+                    # where each tap of each track point sits in `pixels` (its rank), -1 for a tap that contributes nothing: the tap
+                    # exchange's view of the same plan (fm_track_loss_fused_fwd_taps)
+                    slots = torch.full((self.total * 4,), -1, dtype=torch.int32, device=dev)
+                    slots[used] = torch.searchsorted(plan[0], keys[used]).to(torch.int32)
+                    self._tap_slots[key] = slots.contiguous()
             self._plans[key] = plan
         return self._plans[key]
+
+    def tap_plan(self, frames: int, height: int, width: int):
+        """The static tap set of this track list as the fused flow pass wants it (include/flowmap_hip.h: fm_flow_taps), built once per
+        video shape: a TapPlan with the sorted tap pixels, the per-quad bit mask over a (1, frames, height, width) depth tensor, the rank of
+        the first tap of every 64-quad chunk of a frame, and the (total, 4) slot of every tap of every track point.  None when the layout
+        does not apply (width or pixel count not a multiple of 4, nothing scattered, a segment past the last frame)."""
+        key = (int(frames), int(height), int(width))
+        if key not in self._tap_plans:
+            plan = self.scatter_plan(height, width) if self.nblocks > 0 and not self.partial else None
+            n = int(height) * int(width)
+            built = None
+            if plan is not None and width % 4 == 0 and self.last_frame <= frames and plan[0].numel() < 2**31:
+                pixels = plan[0]
+                dev = pixels.device
+                quads, chunks = n // 4, (n // 4 + 63) // 64
+                mask = torch.zeros((frames * quads,), dtype=torch.uint8, device=dev)
+                quad, bit = torch.div(pixels, 4, rounding_mode="floor"), pixels % 4
+                for e in range(4):
+                    mask[quad[bit == e]] |= 1 << e
+                # rank of the first tap at or after quad 64·c of frame f: taps with key < f·n + 256·c
+                starts = (torch.arange(frames, dtype=torch.int64, device=dev)[:, None] * n
+                          + torch.arange(chunks, dtype=torch.int64, device=dev)[None, :] * 256).reshape(-1)
+                chunk_base = torch.searchsorted(pixels, starts).to(torch.int32).contiguous()
+                built = TapPlan(self, key, plan, mask, chunk_base, self._tap_slots[(int(height), int(width))])
+            self._tap_plans[key] = built
+        return self._tap_plans[key]
+
+
+class TapPlan:
+    """The tracking loss's static tap set on one depth tensor shape, and the compact tap image that travels between the fused flow pass
+    and the tracking loss (csrc/fm_flow.hip: TAPS; csrc/fm_track.hip: track_sample_many).  ``image`` (M floats) holds the depth value
+    at every tap as the last flow pass left it; it may be sampled from only while the depth parameter has not moved since
+    (``image_valid_for``: same storage, same version counter)."""
+
+    def __init__(self, packed, key, plan, mask, chunk_base, slots):
+        self.packed, self.key, self.plan = packed, key, plan
+        self.pixels, self.mask, self.chunk_base, self.slots = plan[0], mask, chunk_base, slots
+        self.image = torch.zeros((plan[0].numel(),), dtype=torch.float32, device=plan[0].device)
+        self._tag = None  # what the image was left for: (the parameter object, its storage — held, so its address is not reused —, data_ptr, version)
+        # raised by the flow pass when a tap depth it reads differs from the image value the tracking loss of the same step sampled: the
+        # parameter was edited behind its version counter (`param.data.clamp_()` ...).  Read at the first sampled step and every 64th.
+        self.stale_flag = torch.zeros((1,), dtype=torch.int32, device=plan[0].device)
+        self.sampled_now = False  # the tracking loss of the current step sampled from the image: the coming flow pass verifies it
+        self.samples = 0
+
+    def tag(self, root: Tensor) -> None:
+        self._tag = (weakref.ref(root), root.untyped_storage(), root.data_ptr(), root._version)
+
+    def invalidate(self) -> None:
+        self._tag = None
+
+    def image_valid_for(self, root: Tensor) -> bool:
+        tag = self._tag
+        if tag is None or tag[0]() is not root or tag[1]._cdata != root.untyped_storage()._cdata or tag[2:] != (root.data_ptr(), root._version):
+            return False
+        # a step replayed as a hipGraph runs no Python: whether depth moved between replays could not be checked
+        return not (root.is_cuda and torch.cuda.is_current_stream_capturing())
+
+    def note_sampled(self) -> None:
+        self.sampled_now = True
+        self.samples += 1
+
+    def check_stale(self) -> None:
+        """(synchronises) Raise if a flow pass found the image stale although the version counter said otherwise."""
+        if int(self.stale_flag.item()) != 0:
+            self.stale_flag.zero_()
+            self.invalidate()
+            raise RuntimeError(
+                "flowmap_amd: the depth parameter was modified without its version counter moving (an edit through `.data`, a raw pointer): the "
+                "tracking loss sampled tap depths the last flow pass had left behind, and they were stale — the tracking loss and its gradients "
+                "of the affected steps are wrong.  Edit parameters in place under torch.no_grad() (as optimisers do), or set "
+                "flowmap_amd._ops.use_tap_image = False.")
+
+
+# sample the tracking loss's tap depths from the image the flow pass leaves (while the parameter's version counter has not moved)
+use_tap_image = True
+
+# the tap exchange between the fused flow loss and the fused tracking loss (DESIGN.md §3.4); False: both run as in round 3
+use_tap_exchange = True
+
+
+def _whole_parameter(depth: Tensor) -> Optional[Tensor]:
+    """The leaf parameter ``depth`` (1, F, H, W) is a whole, dense view of — or None."""
+    root = _root(depth)
+    if depth.dim() != 4 or depth.shape[0] != 1 or not depth.is_contiguous() or depth.dtype != torch.float32:
+        return None
+    if depth.data_ptr() != root.data_ptr() or depth.numel() != root.numel() or not root.is_contiguous():
+        return None
+    return root
+
+
+def tap_plan_of(depth: Tensor) -> Optional[TapPlan]:
+    """The TapPlan a tracking loss registered for the parameter behind ``depth`` (matching its shape), if any."""
+    if not use_tap_exchange:
+        return None
+    root = _whole_parameter(depth)
+    plan = root.__dict__.get("_fm_tap_plan") if root is not None else None
+    if plan is None or plan.key != tuple(int(d) for d in depth.shape[1:]) or plan.mask.device != depth.device or depth.data_ptr() % 16 != 0:
+        return None
+    return plan
 
 
 def _local_pixels(self, height: int, width: int, frame0: int):
@@ -1098,7 +1228,9 @@ class TrackLossFused:
     the gradients this rank's share of it (autograd / FrameShard.sync sum them)."""
 
     @staticmethod
-    def apply(depth, k, ext, packed: PackedTracks, weight, kind, delta, defer, frame0=0, reducer=None, fit_from=None):
+    def apply(depth, k, ext, packed: PackedTracks, weight, kind, delta, defer, frame0=0, reducer=None, fit_from=None, offer_taps=False):
+        """``offer_taps``: the caller guarantees that the fused flow loss of this step runs on the same depth tensor right after this call
+        (LossFlow's look-ahead): dL/ddepth is compacted at the static taps and left in the step's DepthSink for that pass to absorb."""
         check_device(depth, k, ext, packed.xy)
         kinv = intrinsics_inverse(k)
         needs_depth = torch.is_grad_enabled() and depth.requires_grad
@@ -1106,9 +1238,25 @@ class TrackLossFused:
         if plan is not None:
             note_touched(depth, "tracking", packed.local_pixels(depth.shape[2], depth.shape[3], int(frame0)))
         sink = depth_sink(depth) if defer else None
+        # the tap exchange: whole video local, gradients on — register the static tap set with the parameter (the flow pass then leaves the tap
+        # depths in its compact image) and sample from that image while the parameter has not moved since
+        taps = (None, None)
+        root = _whole_parameter(depth) if (use_tap_exchange and plan is not None and reducer is None and int(frame0) == 0 and defer) else None
+        if root is not None and root.is_leaf and ext.shape[1] == depth.shape[1]:
+            tap_plan = packed.tap_plan(depth.shape[1], depth.shape[2], depth.shape[3])
+            if tap_plan is not None:
+                root.__dict__["_fm_tap_plan"] = tap_plan
+                if use_tap_image and tap_plan.image_valid_for(root):
+                    taps = (tap_plan.slots, tap_plan.image)
+                    tap_plan.note_sampled()
+                    counters["track_tap_samples"] += 1
+                else:
+                    tap_plan.sampled_now = False
+        else:
+            offer_taps = False
         loss, scale, totals = torch_ops().track_loss(depth, k, kinv, ext, packed.xy, packed.vis, packed.seg, packed.blocks, packed.tiles,
                                                      packed.counts, float(weight), int(kind), float(delta), sink, int(frame0),
-                                                     *(plan if plan is not None else (None, None, None, None)), fit_from)
+                                                     *(plan if plan is not None else (None, None, None, None)), fit_from, *taps, bool(offer_taps))
         if reducer is not None:
             # the operator's gradients follow the `scale` tensor they find at backward time: overwrite it with the
             # global normaliser and report the global value through the local node

@@ -51,6 +51,16 @@ struct FlowParams {
   float* exp_avg_sq;      // (B,F,H,W)
   const uint8_t* touched; // (B·F·H·W/4): bit e of byte q = pixel 4q+e receives gradient from (or is read by) another operator
   AdamCoef adam;
+  // fm_flow_loss_fused_taps: the STATIC tap set of the tracking loss (fm_flow_taps, include/flowmap_hip.h) — per quad a byte of tap
+  // bits, per 64-quad chunk of a frame the rank of its first tap among all taps in (frame, pixel) order.  At a tap the pass adds
+  // tap_scale[0]·tap_grad[rank] into dL/ddepth (the tracking loss's gradient, computed before this pass and compacted) and stores the
+  // depth it leaves behind in tap_depth[rank] for the tracking loss's next evaluation: neither operator touches a cold line of the images
+  const uint8_t* tap_mask;
+  const int32_t* tap_chunk_base;
+  const float* tap_grad;
+  const float* tap_scale;
+  float* tap_depth;
+  int* tap_stale;  // raised when a tap depth differs from the value tap_depth held on entry (the image the tracking loss sampled from)
   // element strides between frames / batch entries of the caller's image stacks (fm_layout; dense when the caller gave none):
   // depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd — a frame window x[:, s:s+f] of a larger tensor is read in place
   long fs[5], bs[5];
@@ -220,9 +230,10 @@ __device__ __forceinline__ void flow_term_pair(const DirPair& d, v2f arow, v2f b
 #define FM_FLOW_WAVES 3
 #endif
 
-template <int VEC, int KIND, bool GRAD, bool PACKED, bool ADAM = false>
+template <int VEC, int KIND, bool GRAD, bool PACKED, bool ADAM = false, bool TAPS = false>
 __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowParams p) {
   static_assert(!ADAM || (VEC == 4 && GRAD), "the in-pass Adam update runs on the 16-byte gradient path");
+  static_assert(!TAPS || (VEC == 4 && GRAD), "the tap exchange runs on the 16-byte gradient path");
   extern __shared__ double lds[];  // reduction scratch (fp64), then the [width] u-table
   double* red = lds;
   float* u_tab = reinterpret_cast<float*>(lds + (256 / 64) * kFlowAcc);
@@ -258,6 +269,7 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   const DirPair dp = make_pair(df, db, has_fwd ? 1.f : 0.f, has_bwd ? 1.f : 0.f);  // (a direction this frame does not have: zeros)
   const float scale = GRAD ? p.scale[0] : 0.f;
   const float inv_delta = KIND == kHuber ? 1.0f / p.delta : 0.f;
+  const float tap_scale = (TAPS && p.tap_grad) ? p.tap_scale[0] : 0.f;
 
   const float* depth = p.depth + (size_t)b * p.bs[0] + (size_t)f * p.fs[0];
   const float* ff = p.flow_fwd + (size_t)b * p.bs[1] + (size_t)f * p.fs[1];  // pair f of this batch entry
@@ -313,6 +325,30 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
                                  scale, p.delta, inv_delta, p.ax, p.ay, acc, gz[e]);
     }
 #endif
+    // The tracking loss's taps among this quad's pixels: a wave holds the 64 consecutive quads of one chunk, so the rank of a
+    // lane's first tap = the chunk's base + the taps of the lanes below it (four ballots, one per pixel of the quad).
+    unsigned tap_bits = 0;
+    int tap_slot = 0;
+    if (TAPS) {
+      tap_bits = p.tap_mask[(size_t)bf * items + item];
+      if (__ballot(tap_bits != 0)) {  // (wave-uniform)
+        unsigned below = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const unsigned long long be = __ballot((tap_bits >> e) & 1u);
+          below += __builtin_amdgcn_mbcnt_hi((unsigned)(be >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)be, 0u));
+        }
+        if (tap_bits != 0) {
+          tap_slot = p.tap_chunk_base[(size_t)bf * chunks + (item >> 6)] + (int)below;
+          if (p.tap_grad) {
+            int s = tap_slot;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+              if ((tap_bits >> e) & 1u) gz[e] += tap_scale * p.tap_grad[s++];
+          }
+        }
+      }
+    }
     if (ADAM) {
       // depth, exp_avg, exp_avg_sq of this quad rewritten in place (model_wrapper_overfit.py:104-105: torch.optim.Adam);
       // pixels another operator still reads from / adds gradient to keep their values and get dL/ddepth stored instead
@@ -333,7 +369,22 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
       FM_STORE(z4, reinterpret_cast<v4f*>(p.depth_rw) + q);
       FM_STORE(m4, reinterpret_cast<v4f*>(p.exp_avg) + q);
       FM_STORE(v4, reinterpret_cast<v4f*>(p.exp_avg_sq) + q);
+      if (TAPS && tap_bits != 0 && p.tap_depth) {  // the depth this pass leaves behind (a pixel another operator keeps is refreshed by its own update)
+        int s = tap_slot;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if ((tap_bits >> e) & 1u) p.tap_depth[s++] = z4[e];
+      }
     } else if (GRAD && gd) {
+      if (TAPS && tap_bits != 0 && p.tap_depth) {
+        int s = tap_slot;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if ((tap_bits >> e) & 1u) {
+            if (p.tap_stale && __float_as_uint(p.tap_depth[s]) != __float_as_uint(z[e])) *p.tap_stale = 1;
+            p.tap_depth[s++] = z[e];
+          }
+      }
       if (VEC == 4) {
         v4f o;
         o.x = gz[0]; o.y = gz[1]; o.z = gz[2]; o.w = gz[3];
@@ -565,9 +616,10 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
                             const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
                             const float* packed, const float* scale, int batch, int frames, int height, int width,
                             int mapping_kind, float delta, float aspect_x, float aspect_y, float* grad_depth, double* acc,
-                            int items_per_thread, const FlowAdam* adam, const fm_layout* layouts, void* stream) {
+                            int items_per_thread, const FlowAdam* adam, const fm_layout* layouts, void* stream, const fm_flow_taps* taps = nullptr) {
   FM_CHECK_ARG(depth && k && kinv && acc);
   FM_CHECK_ARG(!(layouts && adam));  // the in-pass update rewrites the depth PARAMETER: dense by construction
+  FM_CHECK_ARG(!taps || (!layouts && taps->mask && taps->chunk_base && scale && grad_depth && width % 4 == 0 && (taps->grad == nullptr || taps->scale != nullptr)));
   FM_CHECK_ARG(packed || (flow_fwd && flow_bwd && mask_fwd && mask_bwd));
   FM_CHECK_ARG(batch >= 1 && frames >= 2 && height >= 1 && width >= 1);
   FM_CHECK_ARG(mapping_kind >= 0 && mapping_kind <= 2);
@@ -594,6 +646,14 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
     p.exp_avg_sq = adam->exp_avg_sq;
     p.touched = adam->touched;
     p.adam = adam->coef;
+  }
+  if (taps) {
+    p.tap_mask = taps->mask;
+    p.tap_chunk_base = taps->chunk_base;
+    p.tap_grad = taps->grad;
+    p.tap_scale = taps->scale;
+    p.tap_depth = taps->depth;
+    p.tap_stale = taps->stale;
   }
   // (`acc` is zero on entry: fm_flow_loss_finalize clears what it has read, so a workspace kept across steps never
   // needs a memset launch)
@@ -628,7 +688,12 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
   const size_t lds = sizeof(float) * (size_t)width + sizeof(double) * (threads / 64) * kFlowAcc;
 #define FM_FLOW_LAUNCH(V, K, P)                                                                              \
   do {                                                                                                       \
-    if (adam) {                                                                                              \
+    if (taps) {                                                                                              \
+      if constexpr (V == 4) {                                                                                \
+        if (adam) hipLaunchKernelGGL((flow_fused_kernel<4, K, true, P, true, true>), grid, dim3(threads), lds, st, p);  \
+        else hipLaunchKernelGGL((flow_fused_kernel<4, K, true, P, false, true>), grid, dim3(threads), lds, st, p);      \
+      }                                                                                                      \
+    } else if (adam) {                                                                                       \
       if constexpr (V == 4) hipLaunchKernelGGL((flow_fused_kernel<4, K, true, P, true>), grid, dim3(threads), lds, st, p); \
     } else if (grad) hipLaunchKernelGGL((flow_fused_kernel<V, K, true, P>), grid, dim3(threads), lds, st, p);  \
     else hipLaunchKernelGGL((flow_fused_kernel<V, K, false, P>), grid, dim3(threads), lds, st, p);          \
@@ -645,6 +710,7 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
     else FM_FLOW_KIND(V, false);       \
   } while (0)
   FM_CHECK_ARG(!adam || (vec == 4 && grad && grad_depth));
+  FM_CHECK_ARG(!taps || vec == 4);
   if (vec == 4) FM_FLOW_VEC(4);
 #ifdef FM_FLOW_FORCE_VEC2
   else if (vec == 2) FM_FLOW_KIND(2, false);
@@ -686,6 +752,26 @@ int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, con
   const FlowAdam adam{exp_avg, exp_avg_sq, touched, adam_coefficients((double)step, lr, beta1, beta2, eps, 0.0)};
   return flow_loss_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
                           mapping_kind, delta, aspect_x, aspect_y, grad_depth, acc, items_per_thread, &adam, nullptr, stream);
+}
+
+int fm_flow_loss_fused_taps(float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd, const float* flow_fwd,
+                            const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, const float* packed, const float* scale,
+                            int batch, int frames, int height, int width, int mapping_kind, float delta, float aspect_x, float aspect_y,
+                            float* grad_depth, double* acc, int items_per_thread, const fm_flow_taps* taps, float* exp_avg, float* exp_avg_sq,
+                            const uint8_t* touched, long step, double lr, double beta1, double beta2, double eps, void* stream) {
+  FM_CHECK_ARG(taps != nullptr);
+  if (exp_avg == nullptr) {
+    FM_CHECK_ARG(exp_avg_sq == nullptr && touched == nullptr);
+    return flow_loss_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
+                            mapping_kind, delta, aspect_x, aspect_y, grad_depth, acc, items_per_thread, nullptr, nullptr, stream, taps);
+  }
+  FM_CHECK_ARG(exp_avg_sq && touched && scale && grad_depth && step >= 1 && width % 4 == 0);
+  FM_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0);
+  auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  FM_CHECK_ARG(aligned(exp_avg) && aligned(exp_avg_sq));
+  const FlowAdam adam{exp_avg, exp_avg_sq, touched, adam_coefficients((double)step, lr, beta1, beta2, eps, 0.0)};
+  return flow_loss_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
+                          mapping_kind, delta, aspect_x, aspect_y, grad_depth, acc, items_per_thread, &adam, nullptr, stream, taps);
 }
 
 int fm_flow_loss_finalize(double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,

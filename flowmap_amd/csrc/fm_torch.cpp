@@ -49,7 +49,7 @@ using OptTensor = std::optional<Tensor>;
   X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_pose_solve_bwd_kinv) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense) X(fm_procrustes_bwd_planned) X(fm_flow_loss_fused_views) X(fm_procrustes_fit_chain_views) X(fm_procrustes_fit_views) X(fm_procrustes_scatter_views)                \
   X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_loss_fused_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
   X(fm_adam_step_capturable) X(fm_softmin_score_fwd) X(fm_softmin_score_bwd) X(fm_softmin_blend_fwd) X(fm_softmin_blend_bwd)         \
-  X(fm_random_subset) X(fm_random_subset_stateful) X(fm_abi_version)
+  X(fm_random_subset) X(fm_random_subset_stateful) X(fm_abi_version) X(fm_flow_loss_fused_taps) X(fm_track_loss_fused_fwd_taps) X(fm_tap_grad_apply)
 
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
@@ -234,6 +234,22 @@ struct DepthSink : torch::CustomClassHolder {
   bool want_early = false;
   Tensor early_dense, unit_flag;
   bool in_pass_confirmed = false;  // the backward of a flow loss that applied the in-pass Adam update has run (FusedAdam.step checks)
+  // The tap exchange (include/flowmap_hip.h: fm_flow_taps).  A tracking loss evaluated BEFORE the flow pass offers its unscaled dL/ddepth
+  // at its static taps (tap_grad, M floats) with its normaliser (tap_scale); the flow pass adds scale·tap_grad into the dense gradient it
+  // writes (tap_absorbed) — assuming both losses reach backward() with the same upstream gradient.  Whether that held is settled where
+  // everything is known: in the fit's backward, which runs after both (settle_taps), with one conditional launch when it did not.
+  Tensor tap_grad, tap_scale, tap_pixels;
+  bool tap_absorbed = false;
+  Tensor tap_flow_upstream, tap_track_upstream;  // defined once the respective node's backward has run in this pass
+  bool tap_confirmed = false;                    // the tracking node whose gradient was absorbed has run its backward (FusedAdam.step checks)
+  int64_t taps_settled_free = 0, taps_settled_launch = 0;  // (tests)
+  void offer_taps(const Tensor& grad, const Tensor& scale, const Tensor& pixels) {
+    tap_grad = grad, tap_scale = scale, tap_pixels = pixels;
+    tap_absorbed = false;
+    tap_flow_upstream = Tensor(), tap_track_upstream = Tensor();
+  }
+  bool offers_taps() const { return tap_grad.defined() && !tap_absorbed; }
+  void settle_taps(Tensor& buffer);
 
   void arm(const Tensor& depth) {
     active = true;
@@ -291,6 +307,25 @@ struct GradArena : torch::CustomClassHolder {
            (int64_t)grad._version() == version && grad.is_contiguous();
   }
 };
+
+// What the flow pass absorbed for the tracking loss was right if both losses reached backward() with the same upstream gradient — the
+// same tensor object when they are summed into one root (AddBackward hands its gradient to both unchanged): nothing to do.  Otherwise
+// buffer += scale·(plus − minus)·tap_grad at the taps, one launch whose blocks leave at once when the factor turns out to be zero.
+void DepthSink::settle_taps(Tensor& buffer) {
+  if (!tap_absorbed || !tap_grad.defined()) return;
+  const Tensor plus = tap_track_upstream, minus = tap_flow_upstream;
+  tap_flow_upstream = Tensor(), tap_track_upstream = Tensor();  // (a second backward through a retained graph starts clean)
+  if (!plus.defined() && !minus.defined()) return;
+  if (plus.defined() && minus.defined() && plus.data_ptr() == minus.data_ptr()) {
+    ++taps_settled_free;
+    return;
+  }
+  ++taps_settled_launch;
+  TORCH_CHECK(buffer.defined() && buffer.is_contiguous(), "flowmap_amd: the tap exchange needs a dense dL/ddepth buffer");
+  DeviceScope scope(buffer.device());
+  FM_CALL(fm_tap_grad_apply, ptr(tap_grad), ptr<int64_t>(tap_pixels), (long)tap_pixels.numel(), ptr(tap_scale), ptr(plus), ptr(minus), ptr(buffer),
+          scope.stream);
+}
 
 // tests and A/B timing: the planned sparse fit's backward as one launch (default) or as the three launches it replaces
 static bool& one_launch_backward_flag() {
@@ -590,6 +625,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
     if (need_src) {
       g_src = carried.defined() ? carried : at::zeros(src.sizes(), src.options());  // (dense, whatever the strides of a window)
       for (auto& scatter : pending) scatter(g_src);
+      if (sink) sink->settle_taps(g_src);
     }
     // every pixel a correspondence: the tiled dense kernels — one fused pass with atomics, or, when the caller built the static tap lists
     // (flowmap_amd.set_dense_procrustes_planned), the planned pair of kernels whose dL/ddepth is bit-reproducible
@@ -718,12 +754,17 @@ static FlowTimings& flow_timings() {
 struct FlowLaunch {
   Tensor loss, g_depth, small, g_tf, g_tb, g_k;
 };
+// the tap exchange of one launch (fm_flow_taps): the static mask / rank table, what a tracking loss offered, where the tap depths go
+struct FlowTapArgs {
+  Tensor mask, chunk_base, grad, scale, depth_out, stale;
+  bool on() const { return mask.defined(); }
+};
 
 static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& t_fwd, const Tensor& t_bwd,
                               const Tensor& flow_fwd, const Tensor& flow_bwd, const Tensor& mask_fwd, const Tensor& mask_bwd, const Tensor& norm,
                               const Tensor& packed, int64_t kind, double delta, int64_t items, bool need, bool need_depth, const Tensor& acc_work,
                               const Tensor& exp_avg = Tensor(), const Tensor& exp_avg_sq = Tensor(), const Tensor& touched = Tensor(),
-                              int64_t adam_step = 0, const std::vector<double>& adam = {}) {
+                              int64_t adam_step = 0, const std::vector<double>& adam = {}, const FlowTapArgs& taps = FlowTapArgs()) {
   const int64_t b = depth.size(0), f = depth.size(1), h = depth.size(2), w = depth.size(3);
   const auto dev = depth.device();
   FlowLaunch o;
@@ -774,7 +815,16 @@ static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor
   }
   const float *p_ff = pk ? nullptr : ptr(flow_fwd), *p_fb = pk ? nullptr : ptr(flow_bwd), *p_mf = pk ? nullptr : ptr(mask_fwd),
               *p_mb = pk ? nullptr : ptr(mask_bwd);
-  if (exp_avg.defined()) {  // the depth parameter's Adam update applied by the same pass (fm_flow_loss_fused_adam)
+  if (taps.on()) {  // the tap exchange with the tracking loss, with or without the in-pass Adam update (fm_flow_loss_fused_taps)
+    TORCH_CHECK(!any_view, "flowmap_amd: the tap exchange reads dense image stacks (the caller hands frame windows to the plain pass)");
+    const fm_flow_taps t{ptr<uint8_t>(taps.mask), ptr<int32_t>(taps.chunk_base), ptr(taps.grad), ptr(taps.scale), ptr(taps.depth_out),
+                         exp_avg.defined() ? nullptr : ptr<int32_t>(taps.stale)};
+    const bool ad = exp_avg.defined();
+    FM_CALL(fm_flow_loss_fused_taps, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), p_ff, p_fb, p_mf, p_mb, ptr(packed), ptr(norm), (int)b,
+            (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale, ptr(o.g_depth), ptr<double>(acc), (int)items, &t,
+            ptr(exp_avg), ptr(exp_avg_sq), ptr<uint8_t>(touched), (long)adam_step, ad ? adam[0] : 0.0, ad ? adam[1] : 0.0, ad ? adam[2] : 0.0,
+            ad ? adam[3] : 0.0, scope.stream);
+  } else if (exp_avg.defined()) {  // the depth parameter's Adam update applied by the same pass (fm_flow_loss_fused_adam)
     FM_CALL(fm_flow_loss_fused_adam, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), p_ff, p_fb, p_mf,
             p_mb, ptr(packed), ptr(norm), (int)b, (int)f, (int)h, (int)w, (int)kind, (float)delta, (float)w / scale, (float)h / scale,
             ptr(o.g_depth), ptr<double>(acc), (int)items, ptr(exp_avg), ptr(exp_avg_sq), ptr<uint8_t>(touched), (long)adam_step, adam[0], adam[1],
@@ -805,7 +855,8 @@ struct FlowLossFused : public Function<FlowLossFused> {
                         const Tensor& mask_bwd_in, const Tensor& norm, const OptTensor& packed_o, int64_t kind, double delta,
                         const c10::intrusive_ptr<DepthSink>& sink, int64_t items, const OptTensor& acc_work, const OptTensor& exp_avg_o,
                         const OptTensor& exp_avg_sq_o, const OptTensor& touched_o, int64_t adam_step, std::vector<double> adam,
-                        const OptTensor& adam_flag_o, bool grad_enabled, bool park) {
+                        const OptTensor& adam_flag_o, const OptTensor& tap_mask_o, const OptTensor& tap_chunk_base_o, const OptTensor& tap_depth_o,
+                        const OptTensor& tap_stale_o, bool grad_enabled, bool park) {
     check_device({&depth_in, &k_in, &kinv_in, &t_fwd_in, &t_bwd_in, &flow_fwd_in, &flow_bwd_in, &mask_fwd_in, &mask_bwd_in, &norm});
     TORCH_CHECK(flow_fwd_in.scalar_type() == at::kFloat && flow_bwd_in.scalar_type() == at::kFloat && mask_fwd_in.scalar_type() == at::kFloat &&
                     mask_bwd_in.scalar_type() == at::kFloat,
@@ -847,8 +898,36 @@ struct FlowLossFused : public Function<FlowLossFused> {
                       touched.scalar_type() == at::kByte && touched.is_contiguous() && touched.numel() * 4 == depth.numel(),
                   "flowmap_amd: Adam state / touched-pixel mask do not match the depth tensor");
     }
+    // The tap exchange: the static tap set of the tracking loss (mask + rank table from the caller), its offered gradient (from the sink, when
+    // a tracking loss of this step ran before this pass and the dense gradient is parked with the fit, whose backward settles the account)
+    // and the compact image the tap depths are left in
+    FlowTapArgs taps;
+    if (tap_mask_o.has_value() && tap_mask_o->defined() && need && depth_in.requires_grad() && depth.is_contiguous() && w % 4 == 0 &&
+        depth.data_ptr() == depth_in.data_ptr()) {
+      taps.mask = *tap_mask_o;
+      taps.chunk_base = opt(tap_chunk_base_o);
+      taps.depth_out = opt(tap_depth_o);
+      taps.stale = opt(tap_stale_o);
+      TORCH_CHECK(!taps.stale.defined() || (taps.stale.scalar_type() == at::kInt && taps.stale.numel() == 1 && taps.stale.device() == depth.device()),
+                  "flowmap_amd: the stale-image flag is one int32 on the depth tensor's device");
+      const int64_t quads = b * f * h * w / 4, chunks = b * f * ((h * w / 4 + 63) / 64);
+      TORCH_CHECK(taps.mask.scalar_type() == at::kByte && taps.mask.is_contiguous() && taps.mask.numel() == quads && taps.chunk_base.defined() &&
+                      taps.chunk_base.scalar_type() == at::kInt && taps.chunk_base.is_contiguous() && taps.chunk_base.numel() == chunks &&
+                      taps.mask.device() == depth.device() && taps.chunk_base.device() == depth.device(),
+                  "flowmap_amd: the tap mask / rank table do not match the depth tensor");
+      TORCH_CHECK(!taps.depth_out.defined() || (taps.depth_out.scalar_type() == at::kFloat && taps.depth_out.is_contiguous() &&
+                                                taps.depth_out.device() == depth.device()),
+                  "flowmap_amd: the compact tap image is a contiguous float32 tensor on the depth tensor's device");
+      if (sink && park && sink->accepts(depth) && sink->offers_taps() &&
+          (!taps.depth_out.defined() || taps.depth_out.numel() == sink->tap_grad.numel())) {
+        taps.grad = sink->tap_grad;
+        taps.scale = sink->tap_scale;
+      }
+    }
     FlowLaunch run = flow_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, items, need,
-                                 depth_in.requires_grad(), opt(acc_work), exp_avg, exp_avg_sq, touched, adam_step, adam);
+                                 depth_in.requires_grad(), opt(acc_work), exp_avg, exp_avg_sq, touched, adam_step, adam, taps);
+    if (taps.grad.defined()) sink->tap_absorbed = true;
+    ctx->saved_data["tap_absorbed"] = taps.grad.defined();
     ctx->saved_data["in_pass_adam"] = in_pass_adam;
     if (in_pass_adam && adam_flag_o.has_value() && adam_flag_o->defined()) {
       TORCH_CHECK(adam_flag_o->scalar_type() == at::kInt && adam_flag_o->numel() == 1 && adam_flag_o->device() == depth.device(),
@@ -871,11 +950,12 @@ struct FlowLossFused : public Function<FlowLossFused> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    variable_list out(24);
+    variable_list out(28);
     if (!grads[0].defined()) return out;
     const auto saved = ctx->get_saved_variables();
     const Tensor &depth = saved[0], &k = saved[1], &t_fwd = saved[3];
     Tensor g_depth, small;
+    const bool delivers_taps = ctx->saved_data["fresh"].toBool() && ctx->saved_data["tap_absorbed"].toBool();
     if (ctx->saved_data["fresh"].toBool()) {
       if (ctx->saved_data["g_depth"].isTensor()) g_depth = ctx->saved_data["g_depth"].toTensor();
       small = ctx->saved_data["small"].toTensor();
@@ -902,6 +982,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
     }
     auto sink = ctx->saved_data.count("sink") ? ctx->saved_data["sink"].toCustomClass<DepthSink>() : c10::intrusive_ptr<DepthSink>();
     if (sink && ctx->saved_data["in_pass_adam"].toBool()) sink->in_pass_confirmed = true;
+    if (sink && delivers_taps) sink->tap_flow_upstream = g;  // the absorbed tap gradient travels with this buffer, multiplied by g
     if (sink && g_depth.defined() && sink->accepts(depth) && !sink->carried.defined()) {
       sink->carried = g_depth;  // returned (summed with the sparse parts) by the Procrustes fit's node, which runs later
       g_depth = Tensor();
@@ -937,8 +1018,8 @@ struct TrackLossFused : public Function<TrackLossFused> {
                                const Tensor& xy, const Tensor& vis, const Tensor& seg, const Tensor& blocks, const Tensor& tiles,
                                std::vector<int64_t> counts, double weight, int64_t kind, double delta,
                                const c10::intrusive_ptr<DepthSink>& sink, int64_t frame0, const OptTensor& plan_pixels,
-                               const OptTensor& plan_first, const OptTensor& plan_entries, const OptTensor& plan_weights, bool grad_enabled,
-                               bool park) {
+                               const OptTensor& plan_first, const OptTensor& plan_entries, const OptTensor& plan_weights, const OptTensor& tap_slot_o,
+                               const OptTensor& tap_depth_o, bool offer_taps, bool grad_enabled, bool park) {
     const auto dev = check_device({&depth_in, &k_in, &kinv_in, &ext_in, &xy});
     const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics"),
                  ext = f32c(ext_in, "extrinsics");
@@ -963,6 +1044,20 @@ struct TrackLossFused : public Function<TrackLossFused> {
     Tensor acc2 = need ? at::empty({f * 24}, fopt.dtype(at::kDouble)) : Tensor();
     Tensor tgt = at::empty({f, 12}, fopt);
     Tensor part = at::empty({std::max<int64_t>(ntiles, 1) * ((pmax + 63) / 64) * (fmax * 14 + FM_TRACK_TILE * 21)}, fopt);
+    // The tap exchange (fm_flow_taps): sample from the compact tap image the last flow pass left (tap_slot + tap_depth, when the caller
+    // vouches that depth has not moved since), and / or compact this loss's dL/ddepth at the taps for the flow pass that follows (offer_taps).
+    // Whole video local (no frame sharding), gradients on, the fit's node downstream.
+    const bool whole = frame0 == 0 && f_local == f && !partial && counts[7] == 0 && (counts[8] < 0 || counts[8] >= f);
+    const Tensor tap_slot = (whole && tap_slot_o.has_value() && tap_depth_o.has_value() && tap_slot_o->defined() && tap_depth_o->defined()) ? *tap_slot_o : Tensor();
+    const Tensor tap_depth = tap_slot.defined() ? *tap_depth_o : Tensor();
+    if (tap_slot.defined())
+      TORCH_CHECK(tap_slot.scalar_type() == at::kInt && tap_slot.is_contiguous() && tap_slot.numel() == total * 4 && tap_depth.scalar_type() == at::kFloat &&
+                      tap_depth.is_contiguous() && tap_slot.device() == depth.device() && tap_depth.device() == depth.device(),
+                  "flowmap_amd: tap slots (total, 4) int32 and a float32 compact tap image on the depth tensor's device");
+    const bool offer = offer_taps && whole && need && depth_in.requires_grad() && ntiles > 0 && sink && park && sink->accepts(depth) &&
+                       plan_pixels.has_value() && plan_pixels->defined() && plan_pixels->numel() > 0;
+    Tensor tap_grad = offer ? at::empty({plan_pixels->numel()}, fopt) : Tensor();
+    const bool use_taps = tap_slot.defined() || tap_grad.defined();
     const float sc = std::sqrt((float)(h * w));
     {
       DeviceScope scope(dev);
@@ -975,10 +1070,19 @@ struct TrackLossFused : public Function<TrackLossFused> {
           e1 = tm.create();
           tm.record(e0, scope.stream);
         }
-FM_CALL(fm_track_loss_fused_fwd, ptr(depth), (int)frame0, (int)own_first, (int)own_end, ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), (int)f,
-                ptr(xy), ptr<uint8_t>(vis), ptr<int32_t>(seg), ptr<int32_t>(tiles), (int)ntiles, (int)pmax, (int)fmax, (int)h, (int)w, (int)kind,
-                (float)delta, (float)w / sc, (float)h / sc, (float)weight, ptr(ws), ptr<uint8_t>(flag), ptr(tgt), ptr(part), ptr<double>(acc),
-                ptr(loss), ptr(scale), ptr<double>(totals), ptr(gws), ptr<double>(acc2), scope.stream);
+        if (use_taps) {
+          FM_CALL(fm_track_loss_fused_fwd_taps, ptr(depth), ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), (int)f, ptr(xy), ptr<uint8_t>(vis),
+                  ptr<int32_t>(seg), ptr<int32_t>(tiles), (int)ntiles, (int)pmax, (int)fmax, (int)h, (int)w, (int)kind, (float)delta, (float)w / sc,
+                  (float)h / sc, (float)weight, ptr(ws), ptr<uint8_t>(flag), ptr(tgt), ptr(part), ptr<double>(acc), ptr(loss), ptr(scale),
+                  ptr<double>(totals), ptr(gws), ptr<double>(acc2), ptr<int32_t>(tap_slot), ptr(tap_depth), ptr<int64_t>(opt(plan_pixels)),
+                  ptr<int32_t>(opt(plan_first)), ptr<int32_t>(opt(plan_entries)), ptr(opt(plan_weights)),
+                  tap_grad.defined() ? (long)tap_grad.numel() : 0L, ptr(tap_grad), scope.stream);
+        } else {
+          FM_CALL(fm_track_loss_fused_fwd, ptr(depth), (int)frame0, (int)own_first, (int)own_end, ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), (int)f,
+                  ptr(xy), ptr<uint8_t>(vis), ptr<int32_t>(seg), ptr<int32_t>(tiles), (int)ntiles, (int)pmax, (int)fmax, (int)h, (int)w, (int)kind,
+                  (float)delta, (float)w / sc, (float)h / sc, (float)weight, ptr(ws), ptr<uint8_t>(flag), ptr(tgt), ptr(part), ptr<double>(acc),
+                  ptr(loss), ptr(scale), ptr<double>(totals), ptr(gws), ptr<double>(acc2), scope.stream);
+        }
         if (e0) {
           tm.record(e1, scope.stream);
           std::lock_guard<std::mutex> lock(timing_mutex());
@@ -997,6 +1101,8 @@ FM_CALL(fm_track_loss_fused_fwd, ptr(depth), (int)frame0, (int)own_first, (int)o
     // (`scale` is deliberately NOT a version-checked saved tensor: a sharded caller overwrites it with the global normaliser)
     ctx->save_for_backward({k, kinv, ext_inv, acc, opt(plan_pixels), opt(plan_first), opt(plan_entries), opt(plan_weights), depth});
     ctx->saved_data["scale"] = scale;
+    ctx->saved_data["tap_grad"] = tap_grad;
+    if (tap_grad.defined()) sink->offer_taps(tap_grad, scale, *plan_pixels);
     ctx->saved_data["gws"] = gws;
     ctx->saved_data["acc2"] = acc2;
     ctx->saved_data["dims"] = std::vector<int64_t>{f, h, w, frame0};
@@ -1007,7 +1113,7 @@ FM_CALL(fm_track_loss_fused_fwd, ptr(depth), (int)frame0, (int)own_first, (int)o
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    variable_list out(21);
+    variable_list out(24);
     if (!grads[0].defined()) return out;
     const auto saved = ctx->get_saved_variables();
     const Tensor &k = saved[0], &kinv = saved[1], &ext_inv = saved[2], &acc = saved[3];
@@ -1035,7 +1141,14 @@ FM_CALL(fm_track_loss_fused_fwd, ptr(depth), (int)frame0, (int)own_first, (int)o
     };
     if (ctx->needs_input_grad(0)) {
       auto sink = ctx->saved_data.count("sink") ? ctx->saved_data["sink"].toCustomClass<DepthSink>() : c10::intrusive_ptr<DepthSink>();
-      if (sink && sink->accepts(depth)) {
+      const Tensor tap_grad = ctx->saved_data["tap_grad"].isTensor() ? ctx->saved_data["tap_grad"].toTensor() : Tensor();
+      if (sink && sink->accepts(depth) && tap_grad.defined() && sink->tap_absorbed && sink->tap_grad.defined() &&
+          sink->tap_grad.data_ptr() == tap_grad.data_ptr()) {
+        // the flow pass of this step added scale·tap_grad into the dense gradient it wrote: nothing is scattered — the fit's node compares
+        // the two upstream gradients (DepthSink::settle_taps)
+        sink->tap_track_upstream = g;
+        sink->tap_confirmed = true;
+      } else if (sink && sink->accepts(depth)) {
         sink->pending.push_back(scatter);  // lands in the buffer the Procrustes fit's node returns
       } else {
         Tensor g_depth = at::zeros_like(depth);
@@ -1269,25 +1382,27 @@ static Tensor flow_loss_op(const Tensor& depth, const Tensor& k, const Tensor& k
                            const Tensor& flow_bwd, const Tensor& mask_fwd, const Tensor& mask_bwd, const Tensor& norm, const OptTensor& packed,
                            int64_t kind, double delta, const OptSink& sink, int64_t items, const OptTensor& acc_work, const OptTensor& exp_avg,
                            const OptTensor& exp_avg_sq, const OptTensor& touched, int64_t adam_step, std::vector<double> adam,
-                           const OptTensor& adam_flag) {
+                           const OptTensor& adam_flag, const OptTensor& tap_mask, const OptTensor& tap_chunk_base, const OptTensor& tap_depth,
+                           const OptTensor& tap_stale) {
   auto s = sink_of(sink);
   // park dL/ddepth in the sink only when both pose tensors come from the fit that armed it: that node then runs after this one
   const bool park = s && s->fit_node != nullptr && reaches(t_fwd.grad_fn(), s->fit_node, 3) && reaches(t_bwd.grad_fn(), s->fit_node, 3);
   return FlowLossFused::apply(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, s, items, acc_work,
-                              exp_avg, exp_avg_sq, touched, adam_step, adam, adam_flag, at::GradMode::is_enabled(), park);
+                              exp_avg, exp_avg_sq, touched, adam_step, adam, adam_flag, tap_mask, tap_chunk_base, tap_depth, tap_stale,
+                              at::GradMode::is_enabled(), park);
 }
 static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& ext, const Tensor& xy,
                                                         const Tensor& vis, const Tensor& seg, const Tensor& blocks, const Tensor& tiles,
                                                         std::vector<int64_t> counts, double weight, int64_t kind, double delta,
                                                         const OptSink& sink, int64_t frame0, const OptTensor& plan_pixels,
                                                         const OptTensor& plan_first, const OptTensor& plan_entries, const OptTensor& plan_weights,
-                                                        const OptTensor& anchor) {
+                                                        const OptTensor& anchor, const OptTensor& tap_slot, const OptTensor& tap_depth, bool offer_taps) {
   auto s = sink_of(sink);
   // `anchor`: the tensor whose history leads to the fit (the local extrinsics under frame sharding, where `ext` is the gathered chain)
   const Tensor& from = (anchor.has_value() && anchor->defined()) ? *anchor : ext;
   const bool park = s && s->fit_node != nullptr && reaches(from.grad_fn(), s->fit_node, 3);
   auto out = TrackLossFused::apply(depth, k, kinv, ext, xy, vis, seg, blocks, tiles, counts, weight, kind, delta, s, frame0, plan_pixels, plan_first,
-                                   plan_entries, plan_weights, at::GradMode::is_enabled(), park);
+                                   plan_entries, plan_weights, tap_slot, tap_depth, offer_taps, at::GradMode::is_enabled(), park);
   return {out[0], out[1], out[2]};
 }
 // would a flow loss fed these poses hand its dL/ddepth to the sink's fit (i.e. is the in-pass Adam update possible)?
@@ -1336,6 +1451,10 @@ TORCH_LIBRARY(flowmap_amd, m) {
       .def("planned_steps", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->planned_steps; })
       .def("is_active", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->active; })
       .def("in_pass_confirmed", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->in_pass_confirmed; })
+      .def("tap_absorbed", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->tap_absorbed; })
+      .def("tap_confirmed", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->tap_confirmed; })
+      .def("offers_taps", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return s->offers_taps(); })
+      .def("taps_settled", [](const c10::intrusive_ptr<fmt::DepthSink>& s) { return std::vector<int64_t>{s->taps_settled_free, s->taps_settled_launch}; })
       .def("request_early_dense", [](const c10::intrusive_ptr<fmt::DepthSink>& s, const at::Tensor& unit_flag) {
         s->want_early = true;
         s->unit_flag = unit_flag;
@@ -1368,12 +1487,14 @@ TORCH_LIBRARY(flowmap_amd, m) {
   m.def(
       "flow_loss(Tensor depth, Tensor k, Tensor kinv, Tensor t_fwd, Tensor t_bwd, Tensor flow_fwd, Tensor flow_bwd, Tensor mask_fwd, Tensor mask_bwd, "
       "Tensor norm, Tensor? packed, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int items, Tensor? acc_work, "
-      "Tensor? exp_avg, Tensor? exp_avg_sq, Tensor? touched, int adam_step, float[] adam, Tensor? adam_flag) -> Tensor",
+      "Tensor? exp_avg, Tensor? exp_avg_sq, Tensor? touched, int adam_step, float[] adam, Tensor? adam_flag, Tensor? tap_mask=None, "
+      "Tensor? tap_chunk_base=None, Tensor? tap_depth=None, Tensor? tap_stale=None) -> Tensor",
       fmt::flow_loss_op);
   m.def(
       "track_loss(Tensor depth, Tensor k, Tensor kinv, Tensor ext, Tensor xy, Tensor vis, Tensor seg, Tensor blocks, Tensor tiles, int[] counts, "
       "float weight, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int frame0, Tensor? plan_pixels, Tensor? plan_first, "
-      "Tensor? plan_entries, Tensor? plan_weights, Tensor? anchor) -> (Tensor, Tensor, Tensor)",
+      "Tensor? plan_entries, Tensor? plan_weights, Tensor? anchor, Tensor? tap_slot=None, Tensor? tap_depth=None, bool offer_taps=False) "
+      "-> (Tensor, Tensor, Tensor)",
       fmt::track_loss_op);
   m.def("leading_frames(Tensor x, int count, __torch__.torch.classes.flowmap_amd.DepthSink? sink) -> Tensor", fmt::leading_frames_op);
   m.def("adam_step(Tensor(a!) p, Tensor grad, Tensor(b!) m, Tensor(c!) v, int step, Tensor? step_tensor, float lr, float beta1, float beta2, float eps, "

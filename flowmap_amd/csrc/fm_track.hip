@@ -101,10 +101,14 @@ __device__ __forceinline__ bool track_sample(const TrackGeom& g, const float* de
 // tools/track_clocks.py).  want[n] is wave-uniform (the frame exists and is sampled by this rank); idx[n] is in range for every lane
 // (clamped point); `store` masks the lanes beyond the segment's points.  Same arithmetic per item as track_sample (a tap outside
 // the image contributes an exact zero instead of being skipped).
+// tap_slot / tap_depth (fm_track_loss_fused_fwd_taps): the four tap depths of point idx come from the compact tap image the flow pass
+// leaves behind — tap_depth[tap_slot[4·idx + k]]; slot -1: a tap that contributes nothing; slot <= -2: read the depth image after all
+// (a pixel another operator updates after the flow pass) — instead of four cold lines of the depth images.
 template <int N>
 __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const float* depth, int depth_frame0, const float* kinv, const float* ext,
                                                   const int (&frame)[N], const size_t (&idx)[N], const bool (&want)[N], bool store, float* ws,
-                                                  uint8_t* flag, float (&xw)[N][3], bool (&live)[N]) {
+                                                  uint8_t* flag, float (&xw)[N][3], bool (&live)[N], const int32_t* tap_slot = nullptr,
+                                                  const float* tap_depth = nullptr) {
   float2 q[N];
   uint8_t vis[N];
 #pragma unroll
@@ -126,10 +130,16 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
     if (want[n]) {
       const float* d = depth + (size_t)(frame[n] - depth_frame0) * g.height * g.width;
       const int x1 = min(t[n].x0 + 1, g.width - 1), y1 = min(t[n].y0 + 1, g.height - 1);  // clamped reads; masked by in[] below
-      z[n][0] = d[t[n].y0 * g.width + t[n].x0];
-      z[n][1] = d[t[n].y0 * g.width + x1];
-      z[n][2] = d[y1 * g.width + t[n].x0];
-      z[n][3] = d[y1 * g.width + x1];
+      const int a[4] = {t[n].y0 * g.width + t[n].x0, t[n].y0 * g.width + x1, y1 * g.width + t[n].x0, y1 * g.width + x1};
+      if (tap_slot != nullptr) {
+        const int4 s4 = reinterpret_cast<const int4*>(tap_slot)[idx[n]];
+        const int sl[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[n][k] = sl[k] >= 0 ? tap_depth[sl[k]] : (sl[k] < -1 ? d[a[k]] : 0.f);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[n][k] = d[a[k]];
+      }
     }
   }
 #pragma unroll
@@ -320,6 +330,8 @@ struct TrackSampling {
   const float* depth;  // null: ws / flag were filled by fm_track_points
   const float* kinv;
   int depth_frame0, own_first, own_end;  // frames [own_first, own_end) are sources on this rank (frame sharding)
+  const int32_t* tap_slot;  // (total, 4) or null: where the compact tap image holds each tap's depth (track_sample_many)
+  const float* tap_depth;
 };
 
 // Points per lane (FM_TRACK_PG): with two, a wave covers 128 points and the per-target reduction of the 14 sums (a quarter
@@ -377,7 +389,8 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
         want[t] = fs < f && frame[t] >= smp.own_first && frame[t] < smp.own_end;
         if (fs < f && !want[t] && active[q]) flag[idx[t]] = 0;  // another rank's source
       }
-      track_sample_many<kTrackTile>(g, smp.depth, smp.depth_frame0, smp.kinv, ext, frame, idx, want, active[q], ws, flag, xs, lv);
+      track_sample_many<kTrackTile>(g, smp.depth, smp.depth_frame0, smp.kinv, ext, frame, idx, want, active[q], ws, flag, xs, lv, smp.tap_slot,
+                                    smp.tap_depth);
 #pragma unroll
       for (int t = 0; t < kTrackTile; ++t) lvs[t] = lv[t] ? 1.f : 0.f;
     } else {
@@ -703,6 +716,44 @@ __global__ void __launch_bounds__(256) depth_gather_kernel(const float* vectors,
   grad_depth[(size_t)(frame - frame0) * n + px] += sum;
 }
 
+// The planned gather again, but INTO THE COMPACT TAP IMAGE instead of the depth gradient: tap_grad[m] = Σ_e weights[e]·<vectors[entries[e]],
+// K⁻¹(frame)·[u, v, 1]> for the m-th touched pixel — unscaled; the fused flow pass (fm_flow_loss_fused_taps) adds scale·tap_grad at the
+// pixel when it writes dL/ddepth, so the tracking loss never read-modify-writes a cold line of the gradient image.
+__global__ void __launch_bounds__(256) tap_grad_kernel(const float* vectors, const int64_t* pixels, const int32_t* first, const int32_t* entries,
+                                                       const float* weights, long count, const float* kinv, int height, int width,
+                                                       float* tap_grad) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= count) return;
+  const int64_t n = (int64_t)height * width;
+  const int64_t key = pixels[m];
+  const int64_t frame = key / n;
+  const int px = (int)(key - frame * n);
+  const int row = px / width, col = px - row * width;
+  Mat3 ki;
+  load_mat3(kinv + (size_t)frame * 9, ki);
+  float ray[3];
+  ray_dir(ki, pixel_center(col, width), pixel_center(row, height), ray);
+  float sum = 0.f;
+  for (int e = first[m]; e < first[m + 1]; ++e) {
+    const float* v = vectors + (size_t)entries[e] * 3;
+    sum += weights[e] * (v[0] * ray[0] + v[1] * ray[1] + v[2] * ray[2]);
+  }
+  tap_grad[m] = sum;
+}
+
+// grad_depth[pixels[m]] += scale[0]·(plus − minus)·tap_grad[m], nothing at all when the factor is zero (every block leaves after
+// three scalar loads).  The corrections of the tap exchange: the flow pass added scale·tap_grad assuming the tracking loss would reach
+// backward() with the same upstream gradient as the flow loss; `plus` = the tracking loss's upstream gradient (null: its backward never
+// ran), `minus` = what the flow pass's share was multiplied by (null: it was never delivered).
+__global__ void __launch_bounds__(256) tap_grad_apply_kernel(const float* tap_grad, const int64_t* pixels, long count, const float* scale,
+                                                             const float* plus, const float* minus, float* grad_depth) {
+  const float factor = scale[0] * ((plus ? plus[0] : 0.f) - (minus ? minus[0] : 0.f));
+  if (factor == 0.f) return;
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= count) return;
+  grad_depth[pixels[m]] += factor * tap_grad[m];
+}
+
 // The planned gather (scale = upstream = 1, frame0 = 0) with the map of the K⁻¹ gradient back to K in the same launch:
 // the blocks past the gather's do dK = [g_k] − K⁻ᵀ·dK⁻¹·K⁻ᵀ for 64 frames each.
 __global__ void __launch_bounds__(256) depth_gather_kgrad_kernel(const float* vectors, const int64_t* pixels, const int32_t* first,
@@ -826,7 +877,7 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
   FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr));
   return track_loss_launch(const_cast<float*>(ws), const_cast<uint8_t*>(flag), xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames,
                            height, width, mapping_kind, delta, aspect_x, aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                           TrackSampling{nullptr, nullptr, 0, 0, 0}, (hipStream_t)stream);
+                           TrackSampling{nullptr, nullptr, 0, 0, 0, nullptr, nullptr}, (hipStream_t)stream);
 }
 
 int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first, int own_end, const float* kinv, const float* ext,
@@ -841,7 +892,38 @@ int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first,
   hipLaunchKernelGGL(track_targets_kernel, dim3((frames + 63) / 64), dim3(64), 0, st, ext_inv, k, frames, tgt);
   return track_loss_launch(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, mapping_kind, delta, aspect_x,
                            aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                           TrackSampling{depth, kinv, depth_frame0, own_first, own_end}, st);
+                           TrackSampling{depth, kinv, depth_frame0, own_first, own_end, nullptr, nullptr}, st);
+}
+
+int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
+                                 const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* tiles, int ntiles, int pmax, int fmax,
+                                 int height, int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* ws,
+                                 uint8_t* flag, float* tgt, float* partial, double* acc, float* loss, float* scale, double* totals, float* gws,
+                                 double* acc2, const int32_t* tap_slot, const float* tap_depth, const int64_t* plan_pixels,
+                                 const int32_t* plan_first, const int32_t* plan_entries, const float* plan_weights, long plan_count,
+                                 float* tap_grad, void* stream) {
+  FM_CHECK_ARG(depth && kinv && ext && ext_inv && k && xy && vis && seg && tiles && ws && flag && tgt && partial && acc && loss && scale);
+  FM_CHECK_ARG(ntiles >= 1 && pmax >= 1 && fmax >= 1 && frames >= 1 && mapping_kind >= 0 && mapping_kind <= 2);
+  FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr) && (tap_slot == nullptr) == (tap_depth == nullptr));
+  FM_CHECK_ARG(tap_grad == nullptr || (gws && plan_pixels && plan_first && plan_entries && plan_weights && plan_count >= 0));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(track_targets_kernel, dim3((frames + 63) / 64), dim3(64), 0, st, ext_inv, k, frames, tgt);
+  const int status = track_loss_launch(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, mapping_kind, delta,
+                                       aspect_x, aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
+                                       TrackSampling{depth, kinv, 0, 0, frames, tap_slot, tap_depth}, st);
+  if (status != FM_OK || tap_grad == nullptr || plan_count == 0) return status;
+  hipLaunchKernelGGL(tap_grad_kernel, dim3((unsigned)((plan_count + 255) / 256)), dim3(256), 0, st, gws, plan_pixels, plan_first, plan_entries,
+                     plan_weights, plan_count, kinv, height, width, tap_grad);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_tap_grad_apply(const float* tap_grad, const int64_t* pixels, long count, const float* scale, const float* upstream_plus,
+                      const float* upstream_minus, float* grad_depth, void* stream) {
+  FM_CHECK_ARG(count >= 0 && (count == 0 || (tap_grad && pixels && grad_depth)) && scale);
+  if (count == 0) return FM_OK;
+  hipLaunchKernelGGL(tap_grad_apply_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tap_grad, pixels, count, scale,
+                     upstream_plus, upstream_minus, grad_depth);
+  FM_LAUNCH_STATUS();
 }
 
 int fm_track_loss_bwd(const double* acc, const double* acc2, const float* scale, const float* upstream, const float* ext_inv,

@@ -5,6 +5,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Literal, Optional
 
+import torch
 from torch import Tensor
 
 from .. import _ops
@@ -51,8 +52,28 @@ class LossFlow(Loss[LossFlowCfg]):
         s = model_output.surfaces
         return isinstance(s, LazySurfaces) and s.depths is model_output.depths
 
-    def _fused(self, flows, model_output, weight: float) -> Tensor:
+    # The tap exchange: when, in the previous step, a fused tracking loss followed this loss on the same depth parameter,
+    # evaluate it AHEAD of the flow pass — same arguments, same value, returned when that loss is called — so that the pass can absorb its
+    # depth gradient at the static taps instead of the tracking loss read-modify-writing cold lines of dL/ddepth afterwards.
+    look_ahead: bool = True
+
+    def _look_ahead(self, tracks, model_output, global_step: int) -> None:
+        depths = model_output.surfaces.depths
+        note = _ops._root(depths).__dict__.get("_fm_tracking_follows_flow")
+        if note is None or not (torch.is_grad_enabled() and depths.requires_grad) or not _ops.use_tap_exchange:
+            return
+        follower, weight = note[0](), note[1]
+        if follower is None or global_step < follower.cfg.enable_after or not follower._fusable(model_output, tracks):
+            return
+        if _ops.tap_plan_of(depths) is None or (id(follower), weight) in depths.__dict__.get("_fm_tracking_ahead", {}):
+            return
+        follower._fused(tracks, model_output, weight, look_ahead=True)
+
+    def _fused(self, flows, model_output, weight: float, tracks=None, global_step: int = 0) -> Tensor:
         s: LazySurfaces = model_output.surfaces
+        if tracks is not None and self.look_ahead and self.carry_depth_grad:
+            self._look_ahead(tracks, model_output, global_step)
+        s.depths.__dict__["_fm_flow_ran"] = True
         direct = getattr(model_output.extrinsics, "_fm_relative_poses", None) if self.use_fitted_poses else None
         if direct is not None and direct[0].shape[:2] == (s.depths.shape[0], s.depths.shape[1] - 1):
             rel_fwd, rel_bwd = direct  # straight from the Procrustes fit (align_surfaces)
@@ -68,13 +89,13 @@ class LossFlow(Loss[LossFlowCfg]):
 
     def compute_weighted_loss(self, batch, flows, tracks, model_output, global_step: int, weight: float) -> Tensor:
         if self._fusable(model_output):
-            return self._fused(flows, model_output, weight)
+            return self._fused(flows, model_output, weight, tracks, global_step)
         return weight * self.compute_unweighted_loss(batch, flows, tracks, model_output, global_step)
 
     # -- general --------------------------------------------------------------------------
     def compute_unweighted_loss(self, batch, flows, tracks: Optional[list], model_output, global_step: int) -> Tensor:
         if self._fusable(model_output):
-            return self._fused(flows, model_output, 1.0)
+            return self._fused(flows, model_output, 1.0, tracks, global_step)
 
         _, _, _, h, w = batch.videos.shape
         device = batch.videos.device

@@ -2,6 +2,7 @@
 
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass
 from typing import Literal, Optional
 
@@ -48,13 +49,27 @@ class LossTracking(Loss[LossTrackingCfg]):
             and len(tracks) > 0
         )
 
-    def _fused(self, tracks, model_output, weight: float) -> Tensor:
+    def _fused(self, tracks, model_output, weight: float, look_ahead: bool = False) -> Tensor:
+        """``look_ahead``: called by the flow loss of the same step just before its own pass (LossFlow._look_ahead) — the loss is evaluated
+        now, its depth gradient left at the static taps for that pass to absorb, and the value kept on the step's depth tensor until this
+        loss is asked for it with the same track list."""
         s: LazySurfaces = model_output.surfaces
+        kept = s.depths.__dict__.get("_fm_tracking_ahead")
+        if not look_ahead and kept is not None:
+            hit = kept.pop((id(self), float(weight)), None)
+            if hit is not None and hit[0] is tracks:
+                return hit[1]
         packed = _ops.pack_tracks(tracks, s.depths.device)
-        return _ops.TrackLossFused.apply(
+        loss = _ops.TrackLossFused.apply(
             s.depths, model_output.intrinsics, model_output.extrinsics, packed, weight, _ops.MAPPING_KINDS[self.mapping.kind],
-            self.mapping.delta, self.defer_depth_scatter,
+            self.mapping.delta, self.defer_depth_scatter, offer_taps=look_ahead,
         )
+        if look_ahead:
+            s.depths.__dict__.setdefault("_fm_tracking_ahead", {})[(id(self), float(weight))] = (tracks, loss)
+        elif s.depths.__dict__.get("_fm_flow_ran") and self.defer_depth_scatter:
+            # this loss followed a fused flow loss on the same depth tensor: from the next step on that flow loss evaluates it ahead of its pass
+            _ops._root(s.depths).__dict__["_fm_tracking_follows_flow"] = (weakref.ref(self), float(weight))
+        return loss
 
     def forward(self, batch, flows, tracks, model_output, global_step: int) -> Tensor:
         if global_step < self.cfg.enable_after and tracks is not None and self._fusable(model_output, tracks):

@@ -36,8 +36,9 @@ extern "C" {
 #define FM_FLOW_ACC_STRIDE 20  /* doubles per (frame, direction) in `acc` */
 /* Version of this interface: bumped whenever an entry point changes its arguments or its contract (round 3: the workspaces of
  * fm_flow_loss_fused / fm_procrustes_fit_chain are self-cleaning — zero on entry, left zero — instead of being cleared by the
- * call; fm_scale_if_needed reports a non-unit scalar).  A binding checks fm_abi_version() == FM_ABI_VERSION when it loads the library. */
-#define FM_ABI_VERSION 3
+ * call; fm_scale_if_needed reports a non-unit scalar; round 4, version 4: the tap exchange entry
+ * points fm_flow_loss_fused_taps / fm_track_loss_fused_fwd_taps / fm_tap_grad_apply).  A binding checks fm_abi_version() == FM_ABI_VERSION when it loads the library. */
+#define FM_ABI_VERSION 4
 int fm_abi_version(void);
 
 #define FM_STAT_STRIDE 16      /* doubles per pair in `stats` */
@@ -84,6 +85,36 @@ int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, con
                             int batch, int frames, int height, int width, int mapping_kind, float delta, float aspect_x, float aspect_y,
                             float* grad_depth, double* acc, int items_per_thread, float* exp_avg, float* exp_avg_sq, const uint8_t* touched,
                             long step, double lr, double beta1, double beta2, double eps, void* stream);
+
+/* The tap exchange between the fused flow loss and the fused tracking loss (round 4).  Track positions are constants of an
+ * optimisation (flowmap/tracking/__init__.py:49-70 computes them once per video), so the set of depth pixels the tracking loss
+ * bilinearly samples (projection.py:266-272) — its "taps" — is STATIC: M distinct pixels, ranked in (frame, row, column) order
+ * (fm_track_scatter_plan's sorted `pixels`).  fm_flow_taps describes that set to the pass that streams every depth pixel anyway:
+ *   mask       (B·F·H·W/4) bytes: bit e of byte q = pixel 4q+e is a tap;
+ *   chunk_base (B·F·ceil(H·W/256)) int32: rank of the first tap at or after quad 64c of frame bf (chunks of 64 quads per frame);
+ *   grad       (M) or NULL: the tracking loss's UNSCALED dL/ddepth at the taps (fm_track_loss_fused_fwd_taps' tap_grad) — the pass
+ *              adds scale[0]·grad[rank] into the dL/ddepth it writes (and into the gradient its in-pass Adam update uses);
+ *   scale      device scalar: the tracking loss's weight / max(count, 1) (its `scale` output), assumed to reach backward() unscaled
+ *              (fm_tap_grad_apply corrects the dense gradient otherwise);
+ *   depth      (M) out or NULL: the depth value the pass leaves at each tap (after an in-pass Adam update: the updated one) — the
+ *              tracking loss's next evaluation samples from these M floats instead of 4 cold lines per track point;
+ *   stale      one int32 on the device or NULL (without the Adam update only): set to 1 when a tap's depth differs from the value `depth`
+ *              held on entry, i.e. when the tracking loss of this step sampled an image that no longer matched the depth tensor.
+ * fm_flow_loss_fused_taps = fm_flow_loss_fused (exp_avg NULL) or fm_flow_loss_fused_adam (exp_avg etc. given) with that exchange;
+ * dense depth, W % 4 == 0, gradients on. */
+typedef struct fm_flow_taps {
+  const uint8_t* mask;
+  const int32_t* chunk_base;
+  const float* grad;
+  const float* scale;
+  float* depth;
+  int32_t* stale;
+} fm_flow_taps;
+int fm_flow_loss_fused_taps(float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd, const float* flow_fwd,
+                            const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, const float* packed, const float* scale,
+                            int batch, int frames, int height, int width, int mapping_kind, float delta, float aspect_x, float aspect_y,
+                            float* grad_depth, double* acc, int items_per_thread, const fm_flow_taps* taps, float* exp_avg, float* exp_avg_sq,
+                            const uint8_t* touched, long step, double lr, double beta1, double beta2, double eps, void* stream);
 
 /* Flows and masks are constants of an optimisation (computed once by
  * FlowPredictor.compute_bidirectional_flow, flowmap/flow/flow_predictor.py:82-102).  Copies them
@@ -367,6 +398,26 @@ int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first,
                             const int32_t* tiles, int ntiles, int pmax, int fmax, int height, int width, int mapping_kind, float delta,
                             float aspect_x, float aspect_y, float weight, float* ws, uint8_t* flag, float* tgt, float* partial, double* acc,
                             float* loss, float* scale, double* totals, float* gws, double* acc2, void* stream);
+
+/* fm_track_loss_fused_fwd (whole video local) on the static tap set (fm_flow_taps above; loss_tracking.py:28-61 /
+ * projection.py:266-272 unchanged in value):
+ *   tap_slot (total,4) int32 + tap_depth (M), both or neither: tap k of track point i reads tap_depth[tap_slot[4i+k]] — the compact
+ *     image fm_flow_loss_fused_taps left behind — instead of the depth image (slot -1: the tap contributes nothing; slot <= -2: read
+ *     `depth` after all);
+ *   tap_grad (M) out or NULL, with the plan of fm_track_scatter_plan sorted as fm_depth_gather takes it (plan_count = M): the UNSCALED
+ *     dL/ddepth of the tracking loss at each tap, for the `grad` member of fm_flow_taps (needs gws). */
+int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
+                                 const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* tiles, int ntiles, int pmax, int fmax,
+                                 int height, int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* ws,
+                                 uint8_t* flag, float* tgt, float* partial, double* acc, float* loss, float* scale, double* totals, float* gws,
+                                 double* acc2, const int32_t* tap_slot, const float* tap_depth, const int64_t* plan_pixels,
+                                 const int32_t* plan_first, const int32_t* plan_entries, const float* plan_weights, long plan_count,
+                                 float* tap_grad, void* stream);
+/* grad_depth[pixels[m]] += scale[0]·(plus − minus)·tap_grad[m] for the M taps (plus / minus: device scalars, NULL = 0); no memory is
+ * touched when the factor is 0.  The correction of the tap exchange when the tracking loss's upstream gradient (plus) differs from
+ * the factor the flow pass's copy of it was delivered with (minus), and the plain scatter (minus NULL) when nothing was delivered. */
+int fm_tap_grad_apply(const float* tap_grad, const int64_t* pixels, long count, const float* scale, const float* upstream_plus,
+                      const float* upstream_minus, float* grad_depth, void* stream);
 
 /* g_ext (F,4,4), g_k (F,3,3) from acc / acc2, multiplied by scale[0]·upstream[0]
  * (upstream NULL = 1). */

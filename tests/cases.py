@@ -933,6 +933,103 @@ def _small_problem(dev, f=5, h=24, w=32, points=60, tracking=True, seed=21, intr
     return model, batch, flows, loss_of
 
 
+def case_tap_exchange(dev):
+    """The tap exchange between the fused flow loss and the fused tracking loss (fm_flow_loss_fused_taps / fm_track_loss_fused_fwd_taps /
+    fm_tap_grad_apply): from the second step on the tracking loss is evaluated ahead of the flow pass, which absorbs its depth gradient at
+    the static taps and leaves the tap depths in a compact image the next evaluation samples from.  Values and every gradient equal the
+    plain order's (the exchange switched off) however the two losses reach backward(): summed (no correction launched), scaled
+    differently, one of them alone, in two backward calls; and after the depth parameter moved the stale image is not used."""
+    import flowmap_amd
+    from flowmap_amd import _ops
+    from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
+    from helpers import to_tracks
+
+    f, h, w = 6, 24, 32
+    sc = orc.synth_scene(f, h, w, seed=33)
+    otracks = orc.synth_tracks(f, h, w, scene=sc, seed=33, interval=2, radius=2, grid=6)
+
+    def roots(lf, lt, how):
+        return {"sum": [lf + lt], "scaled": [2.0 * lf + 0.5 * lt], "flow_only": [lf], "track_only": [lt], "two_calls": [lf, lt]}[how]
+
+    def run(exchange: bool, how: str, steps: int = 3, move_at=None, track_kind="huber"):
+        _ops.use_tap_exchange = exchange
+        model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False, seed=33)
+        tracks = to_tracks(otracks, dev)
+        flow_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
+        track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", mapping_cfg(track_kind)))
+        results, sinks = [], []
+        for step in range(steps):
+            if move_at is not None and step == move_at:
+                with torch.no_grad():
+                    model.backbone.depth.mul_(1.01)  # the parameter moves (an optimiser the library does not know): the image is stale
+            model.zero_grad(set_to_none=True)
+            out = model(batch, flows, step)
+            lf = flow_fn(batch, flows, tracks, out, step)
+            lt = track_fn(batch, flows, tracks, out, step)
+            calls = roots(lf, lt, how)
+            for i, root in enumerate(calls):
+                root.backward(retain_graph=i + 1 < len(calls))
+            sinks.append(_ops.depth_sink(out.depths))
+            results.append([x.detach().clone() for x in (lf, lt, out.extrinsics, model.backbone.depth.grad, model.backbone.weights.grad,
+                                                         model.intrinsics.focal_length.grad)])
+        return results, sinks
+
+    names = ("loss_flow", "loss_tracking", "extrinsics", "g_depth", "g_wlogit", "g_focal")
+    try:
+        for how in ("sum", "scaled", "flow_only", "track_only", "two_calls"):
+            before = dict(_ops.counters)
+            plain, _ = run(False, how)
+            assert _ops.counters["flow_tap_passes"] == before["flow_tap_passes"]
+            got, sinks = run(True, how)
+            assert _ops.counters["flow_tap_absorbs"] - before["flow_tap_absorbs"] == 2, (how, _ops.counters)  # steps 1 and 2
+            assert _ops.counters["track_tap_samples"] - before["track_tap_samples"] == 1, (how, _ops.counters)  # step 2 (the image exists after step 1)
+            free, launched = (sum(s.taps_settled()[i] for s in sinks) for i in (0, 1))
+            assert (free, launched) == {"sum": (2, 0), "scaled": (0, 2), "flow_only": (0, 2), "track_only": (0, 2), "two_calls": (0, 2)}[how], (how, free, launched)
+            for step, (a, b) in enumerate(zip(got, plain)):
+                for x, y, what in zip(a, b, names):
+                    # same arithmetic per element; the absorbed gradient joins the flow pass's sum in another order (fp32 rounding of one add)
+                    err = float((x - y).abs().max())
+                    assert err <= 2e-6 * max(float(y.abs().max()), 1e-30), (how, step, what, err, float(y.abs().max()))
+            # the tracking part is really there (the comparison is not vacuous): dL/ddepth differs from the flow-only gradient at the taps
+            assert float((got[2][3] - run(False, "flow_only", steps=1)[0][0][3]).abs().max()) > 0 or how == "flow_only"
+        # a parameter that moved between the steps: the compact image is not sampled from (and the results still agree)
+        before = dict(_ops.counters)
+        plain, _ = run(False, "sum", steps=4, move_at=2)
+        got, _ = run(True, "sum", steps=4, move_at=2)
+        assert _ops.counters["track_tap_samples"] - before["track_tap_samples"] == 1, _ops.counters  # step 3 only (step 2 saw a moved parameter)
+        for step, (a, b) in enumerate(zip(got, plain)):
+            for x, y, what in zip(a, b, names):
+                err = float((x - y).abs().max())
+                assert err <= 2e-6 * max(float(y.abs().max()), 1e-30), ("moved", step, what, err)
+        # an edit behind the version counter (`param.data...`): the flow pass finds the image the tracking loss sampled stale — loudly
+        _ops.use_tap_exchange = True
+        model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False, seed=33)
+        tracks = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=34, interval=2, radius=2, grid=6), dev)
+        flow_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
+        track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", mapping_cfg("huber")))
+        raised = False
+        for step in range(3):
+            if step == 2:
+                model.backbone.depth.data.mul_(1.01)
+            model.zero_grad(set_to_none=True)
+            out = model(batch, flows, step)
+            try:
+                total = flow_fn(batch, flows, tracks, out, step) + track_fn(batch, flows, tracks, out, step)
+            except RuntimeError as exc:
+                raised = "version counter" in str(exc)
+                break
+            total.backward()
+        assert raised
+        # another robust kernel on the tracking side (the exchange does not depend on it)
+        plain, _ = run(False, "sum", track_kind="l1")
+        got, _ = run(True, "sum", track_kind="l1")
+        for x, y, what in zip(got[-1], plain[-1], names):
+            assert float((x - y).abs().max()) <= 2e-6 * max(float(y.abs().max()), 1e-30), ("l1", what)
+    finally:
+        _ops.use_tap_exchange = True
+        flowmap_amd.set_lazy_surfaces(False)
+
+
 def case_step_torch_ops(dev):
     """What a step launches BESIDE the library's own kernels: autograd's ones_like for loss.backward(), the sum of the two losses and the
     two sums autograd forms where two consumers meet (dL/d extrinsics, dL/dK) — and nothing else.  In particular no zeros tensors

@@ -136,6 +136,51 @@ int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, con
   return 0;
 }
 
+// The tap exchange, serially: the full gradient first, then every pixel in (frame, pixel) order — its rank among the taps is a running
+// count, checked against chunk_base at every 64-quad chunk (the table the device kernel relies on).
+int fm_flow_loss_fused_taps(float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd, const float* flow_fwd,
+                            const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, const float* packed, const float* scale,
+                            int batch, int frames, int height, int width, int mapping_kind, float delta, float ax, float ay,
+                            float* grad_depth, double* acc, int items, const fm_flow_taps* taps, float* exp_avg, float* exp_avg_sq,
+                            const uint8_t* touched, long step, double lr, double beta1, double beta2, double eps, void* stream) {
+  if (!taps || !taps->mask || !taps->chunk_base || !scale || !grad_depth || width % 4 != 0 || (taps->grad && !taps->scale)) return 1;
+  if (exp_avg && (!exp_avg_sq || !touched || step < 1)) return 1;
+  if (!exp_avg && (exp_avg_sq || touched)) return 1;
+  const size_t n = (size_t)height * width, total = (size_t)batch * frames * n;
+  std::vector<float> g(total);
+  if (fm_flow_loss_fused(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
+                         mapping_kind, delta, ax, ay, g.data(), acc, items, stream) != 0)
+    return 2;
+  const AdamCoef c = exp_avg ? adam_coefficients((double)step, lr, beta1, beta2, eps, 0.0) : AdamCoef{};
+  const size_t quads = n / 4, chunks = (quads + 63) / 64;
+  const float ts = taps->grad ? taps->scale[0] : 0.f;
+  int rank = 0;
+  for (size_t bf = 0; bf < (size_t)batch * frames; ++bf)
+    for (size_t q = 0; q < quads; ++q) {
+      if (q % 64 == 0 && taps->chunk_base[bf * chunks + q / 64] != rank) return 2;  // the rank table does not match the mask
+      const unsigned bits = taps->mask[bf * quads + q];
+      for (int e = 0; e < 4; ++e) {
+        const size_t i = (bf * quads + q) * 4 + e;
+        const bool tap = (bits >> e) & 1u;
+        if (tap && taps->grad) g[i] += ts * taps->grad[rank];
+        if (exp_avg) {
+          if ((touched[i / 4] >> (i % 4)) & 1u) grad_depth[i] = g[i];
+          else adam_update(c, depth[i], g[i], exp_avg[i], exp_avg_sq[i]);
+        } else {
+          grad_depth[i] = g[i];
+        }
+        if (tap) {
+          if (taps->depth) {
+            if (taps->stale && !exp_avg && std::memcmp(&taps->depth[rank], &depth[i], sizeof(float)) != 0) *taps->stale = 1;
+            taps->depth[rank] = depth[i];
+          }
+          ++rank;
+        }
+      }
+    }
+  return 0;
+}
+
 int fm_flow_loss_finalize(double* acc, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
                           const float* norm, int batch, int frames, float ax, float ay, float* loss, float* g_t_fwd, float* g_t_bwd,
                           float* g_k, void*) {
@@ -1197,9 +1242,21 @@ int fm_extrinsics_inverse(const float* ext, int count, float* inv, void*) {
   return 0;
 }
 
+static int sim_track_points(const float* depth, int depth_frame0, const float* kinv, const float* ext, const float* ext_inv, const float* k,
+                            int frames, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks,
+                            int height, int width, float* ws, uint8_t* flag, float* tgt, const int32_t* tap_slot, const float* tap_depth);
+
 int fm_track_points(const float* depth, int depth_frame0, const float* kinv, const float* ext, const float* ext_inv, const float* k,
                     int frames, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int,
                     int height, int width, float* ws, uint8_t* flag, float* tgt, void*) {
+  return sim_track_points(depth, depth_frame0, kinv, ext, ext_inv, k, frames, xy, vis, seg, blocks, nblocks, height, width, ws, flag, tgt, nullptr,
+                          nullptr);
+}
+
+// tap_slot / tap_depth: the tap depths come from the compact tap image (slot >= 0), are zero (slot -1) or are read from `depth` (slot <= -2)
+static int sim_track_points(const float* depth, int depth_frame0, const float* kinv, const float* ext, const float* ext_inv, const float* k,
+                            int frames, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks,
+                            int height, int width, float* ws, uint8_t* flag, float* tgt, const int32_t* tap_slot, const float* tap_depth) {
   for (int fr = 0; fr < frames; ++fr) track_target(ext_inv + (size_t)fr * 16, k + (size_t)fr * 9, tgt + (size_t)fr * kTrackTgt);
   for (int blk = 0; blk < nblocks; ++blk) {
     const int sg = blocks[blk * 2], fl = blocks[blk * 2 + 1];
@@ -1221,7 +1278,11 @@ int fm_track_points(const float* depth, int depth_frame0, const float* kinv, con
         const float ut = pixel_center(tc, width), vt = pixel_center(tr, height);
         float ray[3];
         ray_dir(ki, ut, vt, ray);
-        const float z = d[tr * width + tc];
+        float z = d[tr * width + tc];
+        if (tap_slot) {
+          const int sl = tap_slot[idx * 4 + k];
+          z = sl >= 0 ? tap_depth[sl] : (sl < -1 ? z : 0.f);
+        }
         for (int a = 0; a < 3; ++a) xyz[a] += (ray[a] * z) * t.w[k];
         hh[0] += z * ut * t.w[k];
         hh[1] += z * vt * t.w[k];
@@ -1327,6 +1388,56 @@ int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first,
     return 2;
   return fm_track_loss_fwd(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, kind, delta, ax, ay, weight,
                            partial, acc, loss, scale, totals, gws, acc2, stream);
+}
+
+int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
+                                 const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* tiles, int ntiles, int pmax, int fmax,
+                                 int height, int width, int kind, float delta, float ax, float ay, float weight, float* ws, uint8_t* flag,
+                                 float* tgt, float* partial, double* acc, float* loss, float* scale, double* totals, float* gws, double* acc2,
+                                 const int32_t* tap_slot, const float* tap_depth, const int64_t* plan_pixels, const int32_t* plan_first,
+                                 const int32_t* plan_entries, const float* plan_weights, long plan_count, float* tap_grad, void* stream) {
+  if ((tap_slot == nullptr) != (tap_depth == nullptr)) return 1;
+  if (tap_grad && !(gws && plan_pixels && plan_first && plan_entries && plan_weights && plan_count >= 0)) return 1;
+  std::vector<int32_t> blocks;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int sg = tiles[tile * 2], fs0 = tiles[tile * 2 + 1], f = seg[sg * 4 + 1];
+    for (int fs = fs0; fs < fs0 + FM_TRACK_TILE && fs < f; ++fs) {
+      blocks.push_back(sg);
+      blocks.push_back(fs);
+    }
+  }
+  if (sim_track_points(depth, 0, kinv, ext, ext_inv, k, frames, xy, vis, seg, blocks.data(), (int)(blocks.size() / 2), height, width, ws, flag, tgt,
+                       tap_slot, tap_depth) != 0)
+    return 2;
+  if (fm_track_loss_fwd(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, kind, delta, ax, ay, weight, partial, acc,
+                        loss, scale, totals, gws, acc2, stream) != 0)
+    return 2;
+  if (!tap_grad) return 0;
+  const int64_t n = (int64_t)height * width;
+  for (long m = 0; m < plan_count; ++m) {
+    const int64_t frame = plan_pixels[m] / n;
+    const int px = (int)(plan_pixels[m] - frame * n);
+    Mat3 ki;
+    load_mat3(kinv + (size_t)frame * 9, ki);
+    float ray[3];
+    ray_dir(ki, pixel_center(px % width, width), pixel_center(px / width, height), ray);
+    float sum = 0.f;
+    for (int e = plan_first[m]; e < plan_first[m + 1]; ++e) {
+      const float* v = gws + (size_t)plan_entries[e] * 3;
+      sum += plan_weights[e] * (v[0] * ray[0] + v[1] * ray[1] + v[2] * ray[2]);
+    }
+    tap_grad[m] = sum;
+  }
+  return 0;
+}
+
+int fm_tap_grad_apply(const float* tap_grad, const int64_t* pixels, long count, const float* scale, const float* upstream_plus,
+                      const float* upstream_minus, float* grad_depth, void*) {
+  if (count < 0 || !scale || (count > 0 && !(tap_grad && pixels && grad_depth))) return 1;
+  const float factor = scale[0] * ((upstream_plus ? upstream_plus[0] : 0.f) - (upstream_minus ? upstream_minus[0] : 0.f));
+  if (factor == 0.f) return 0;
+  for (long m = 0; m < count; ++m) grad_depth[pixels[m]] += factor * tap_grad[m];
+  return 0;
 }
 
 int fm_track_loss_bwd(const double* acc, const double* acc2, const float* scale, const float* upstream, const float* ext_inv,

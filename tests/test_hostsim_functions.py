@@ -147,6 +147,10 @@ def test_depth_adam_update_inside_the_flow_pass_follows_torch_adam():
     cases.case_in_pass_adam("cpu")
 
 
+def test_tap_exchange():
+    cases.case_tap_exchange("cpu")
+
+
 def test_in_pass_adam_update_refuses_what_it_cannot_do():
     cases.case_in_pass_adam_refusals("cpu")
 
