@@ -120,6 +120,9 @@ def parse():
     ap.add_argument("--release-originals", action="store_true",
                     help="flowmap_amd.release_flow_originals(flows) once the flows are packed: the forward flow and both masks (half of the inputs) are "
                          "given back; the CPU-baseline sample is copied to the host first")
+    ap.add_argument("--no-tap-exchange", action="store_true",
+                    help="flow + tracking: run the two losses as in round 3 (the tracking loss after the flow pass, sampling the depth images and "
+                         "read-modify-writing dL/ddepth at its taps) instead of the tap exchange (flowmap_amd/_ops.py: TapPlan)")
     ap.add_argument("--torch-baseline", type=int, default=0, metavar="STEPS",
                     help="after the timed region: the reference's op sequence on stock PyTorch-ROCm on this GPU (tests/tools/torch_gpu_reference_ops.py "
                          "in a process of its own, 1 warm-up + STEPS steps on i.i.d. inputs of the workload's size) as `rocm_torch_baseline`")
@@ -394,6 +397,8 @@ def main():
     if args.graph == "compute" and (not strong or cfg["tracking"] or args.intrinsics != "regressed"):
         raise SystemExit("--graph compute: a frame-sharded run of the flow loss with regressed intrinsics (the tracking loss and the softmin sweep have collectives inside forward / backward)")
     flowmap_amd.set_lazy_surfaces(True)
+    if args.no_tap_exchange:
+        _ops.use_tap_exchange = False
     if os.environ.get("FLOWMAP_THREE_LAUNCH_BWD"):  # A/B: the planned Procrustes backward as the three launches of round 2
         from flowmap_amd._lib import torch_ops
 
@@ -478,7 +483,9 @@ def main():
         elif track_fn is not None:
             model.zero_grad(set_to_none=True)
             out = model(batch, flows, 0)
-            loss = loss_fn(batch, flows, None, out, 0) + track_fn(batch, flows, tracks, out, 0)
+            # (every loss is handed the tracks, as ModelWrapperOverfit.training_step does, model_wrapper_overfit.py:57-62: from the second step on
+            # the flow loss evaluates the tracking loss ahead of its pass — the tap exchange, flowmap_amd/_ops.py: TapPlan)
+            loss = loss_fn(batch, flows, tracks, out, 0) + track_fn(batch, flows, tracks, out, 0)
             loss.backward()
         else:
             loss = compute()
@@ -690,7 +697,9 @@ def main():
             t_ms = sum(track_ms) / len(track_ms)
             gflops = residuals * TRACK_FLOPS_PER_RESIDUAL / (t_ms * 1e-3) / 1e9
             result["roofline_tracking"] = {
-                "kernel": "fm::track_pairs_kernel<huber, GRAD> (+ track_reduce, finalize: one fm_track_loss_fwd call)",
+                "kernel": "fm::track_pairs_kernel<huber, GRAD> (+ track_reduce, finalize" + (", tap_grad: one fm_track_loss_fused_fwd_taps call)" if _ops.counters["flow_tap_absorbs"] else ": one fm_track_loss_fused_fwd call)"),
+                "tap_exchange": {"flow_passes_with_taps": _ops.counters["flow_tap_passes"], "absorbed": _ops.counters["flow_tap_absorbs"],
+                                 "sampled_from_tap_image": _ops.counters["track_tap_samples"]},
                 "bound": "valu",
                 "achieved": gflops,
                 "peak": FP32_PEAK_GFLOPS,

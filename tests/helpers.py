@@ -47,9 +47,11 @@ def to_tracks(ot, device):
 
 
 def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="huber", device="cpu", lazy=True,
-             flow_weight=1000.0, track_weight=100.0, loss_scale=1.0):
+             flow_weight=1000.0, track_weight=100.0, loss_scale=1.0, steps=1):
     """One step through flowmap_amd exactly as ModelWrapperOverfit.training_step would
-    drive it.  Returns dict of loss values and parameter gradients (on CPU)."""
+    drive it.  Returns dict of loss values and parameter gradients (on CPU).  ``steps`` > 1: the same step repeated on the
+    same parameters (no optimiser), the LAST one reported — from its second step on a flow + tracking loop runs the tap
+    exchange, from its third the tracking loss samples the compact tap image (flowmap_amd/_ops.py: TapPlan)."""
     f = depth.shape[0]
     flowmap_amd.set_lazy_surfaces(lazy)
     try:
@@ -68,10 +70,12 @@ def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="h
         losses = [LossFlow(LossFlowCfg(0, flow_weight, "flow", mapping_cfg(kind)))]
         if tracks is not None:
             losses.append(LossTracking(LossTrackingCfg(0, track_weight, "tracking", mapping_cfg(kind))))
-        out = model(batch, flows, 0)
-        parts = [fn(batch, flows, tracks, out, 0) for fn in losses]
-        total = sum(parts) * loss_scale if loss_scale != 1.0 else sum(parts)
-        total.backward()
+        for _ in range(steps):
+            model.zero_grad(set_to_none=True)
+            out = model(batch, flows, 0)
+            parts = [fn(batch, flows, tracks, out, 0) for fn in losses]
+            total = sum(parts) * loss_scale if loss_scale != 1.0 else sum(parts)
+            total.backward()
         return {
             "total": total.detach().cpu(),
             "loss_flow": parts[0].detach().cpu(),

@@ -427,6 +427,11 @@ def test_flow_fused_leaves(f, h, w, packed, kind):
 
 
 @pytest.mark.gpu
+def test_tap_exchange():
+    cases.case_tap_exchange(DEV)
+
+
+@pytest.mark.gpu
 def test_depth_adam_update_inside_the_flow_pass_follows_torch_adam():
     cases.case_in_pass_adam(DEV, steps=200, lr=3e-4)  # 10x the reference's learning rate (config/overfit.yaml:30)
 

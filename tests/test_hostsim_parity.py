@@ -91,6 +91,7 @@ def test_full_size_module_logic_at_toy_size():
     built = full.build_reference(12, 40, 56, 300, "cpu", torch.float64, interval=3, radius=4, grid=9)
     full.compare_flow_only(built, (40, 56), 300, "cpu")
     full.compare_flow_and_tracking(built, (40, 56), 300, "cpu")
+    full.compare_flow_and_tracking(built, (40, 56), 300, "cpu", steps=3, label="C2-tap-exchange")  # (the third step: tap exchange + tap image)
 
 
 def test_full_size_cases_run_small_on_the_host_double():
