@@ -87,6 +87,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v4f ld4(const float* base, int i) { return FM_LOAD(reinterpret_cast<const v4f*>(base) + i); }
 __device__ __forceinline__ v2f ld2(const float* base, int i) { return FM_LOAD(reinterpret_cast<const v2f*>(base) + i); }
 
+// One quad's share of the tap exchange (fm_flow_taps): which of its pixels are taps, the rank of the first one, the tracking gradient offered
+// at each and the value the compact image held for it.
+struct TapState {
+  unsigned bits;
+  int slot;
+  float grad[4], old[4];
+};
+
 // One quad's raw inputs, kept as the 16-byte vectors they were loaded as.
 struct QuadIn {
   v4f z, fa, fc, fm, ba, bc, bm;
@@ -247,6 +255,16 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   const int items = n / VEC;
   const int items_per_row = p.width / VEC;
 
+  // (the tap exchange's first mask byte / chunk base: requested before anything else, used after the constants below are set up)
+  unsigned tap_bits_next = 0;
+  int tap_base_next = 0;
+  if constexpr (TAPS) {
+    const int first = blockIdx.x * (blockDim.x * p.iters) + (int)threadIdx.x;
+    if (first < items) {
+      tap_bits_next = p.tap_mask[(size_t)bf * items + first];
+      tap_base_next = p.tap_chunk_base[(size_t)bf * (((size_t)items + kPackLanes - 1) / kPackLanes) + (first >> 6)];
+    }
+  }
   for (int c = threadIdx.x; c < p.width; c += blockDim.x) u_tab[c] = pixel_center(c, p.width);
   __syncthreads();
 
@@ -293,7 +311,7 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
 
   // Everything after the loads of one item: coordinates, both residual terms per pixel, store.
   auto compute = [&](const float (&z)[VEC], const float (&fxf)[VEC], const float (&fyf)[VEC], const float (&mmf)[VEC],
-                     const float (&fxb)[VEC], const float (&fyb)[VEC], const float (&mmb)[VEC], int item) {
+                     const float (&fxb)[VEC], const float (&fyb)[VEC], const float (&mmb)[VEC], int item, const TapState& ts) {
     float gz[VEC];
     const int row = item / items_per_row;
     const int col0 = (item - row * items_per_row) * VEC;
@@ -325,29 +343,16 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
                                  scale, p.delta, inv_delta, p.ax, p.ay, acc, gz[e]);
     }
 #endif
-    // The tracking loss's taps among this quad's pixels: a wave holds the 64 consecutive quads of one chunk, so the rank of a
-    // lane's first tap = the chunk's base + the taps of the lanes below it (four ballots, one per pixel of the quad).
-    unsigned tap_bits = 0;
-    int tap_slot = 0;
+    // the tracking loss's gradient at this quad's taps (loaded by prepare_taps before the terms above were evaluated)
+    const unsigned tap_bits = TAPS ? ts.bits : 0u;
+    const int tap_slot = ts.slot;
     if (TAPS) {
-      tap_bits = p.tap_mask[(size_t)bf * items + item];
-      if (__ballot(tap_bits != 0)) {  // (wave-uniform)
-        unsigned below = 0;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          const unsigned long long be = __ballot((tap_bits >> e) & 1u);
-          below += __builtin_amdgcn_mbcnt_hi((unsigned)(be >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)be, 0u));
-        }
-        if (tap_bits != 0) {
-          tap_slot = p.tap_chunk_base[(size_t)bf * chunks + (item >> 6)] + (int)below;
-          if (p.tap_grad) {
-            int s = tap_slot;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e)
-              if ((tap_bits >> e) & 1u) gz[e] += tap_scale * p.tap_grad[s++];
-          }
-        }
-      }
+      for (int e = 0; e < VEC; ++e) gz[e] = fmaf(tap_scale, ((tap_bits >> e) & 1u) ? ts.grad[e] : 0.f, gz[e]);
+      // the next item's mask byte and chunk base were requested before this item's loads: they have arrived — take them HERE, ahead of the
+      // stores below (the memory counter is one in-order queue of loads and stores: taking them at the top of the next iteration would wait
+      // for these stores to be acknowledged)
+      asm volatile("" : "+v"(tap_bits_next), "+v"(tap_base_next));
     }
     if (ADAM) {
       // depth, exp_avg, exp_avg_sq of this quad rewritten in place (model_wrapper_overfit.py:104-105: torch.optim.Adam);
@@ -381,7 +386,7 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
           if ((tap_bits >> e) & 1u) {
-            if (p.tap_stale && __float_as_uint(p.tap_depth[s]) != __float_as_uint(z[e])) *p.tap_stale = 1;
+            if (p.tap_stale && __float_as_uint(ts.old[e]) != __float_as_uint(z[e])) *p.tap_stale = 1;
             p.tap_depth[s++] = z[e];
           }
       }
@@ -399,7 +404,7 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
     }
   };
 
-  auto compute_quad = [&](const QuadIn& q, int item) {
+  auto compute_quad = [&](const QuadIn& q, int item, const TapState& ts) {
     float z[VEC], fxf[VEC], fyf[VEC], mmf[VEC], fxb[VEC], fyb[VEC], mmb[VEC];
     if (VEC == 4) {
       z[0] = q.z.x; z[1 % VEC] = q.z.y; z[2 % VEC] = q.z.z; z[3 % VEC] = q.z.w;
@@ -410,19 +415,66 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
       fxb[0] = q.ba.x; fyb[0] = q.ba.y; fxb[1 % VEC] = q.ba.z; fyb[1 % VEC] = q.ba.w;
       fxb[2 % VEC] = q.bc.x; fyb[2 % VEC] = q.bc.y; fxb[3 % VEC] = q.bc.z; fyb[3 % VEC] = q.bc.w;
     }
-    compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item);
+    compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item, ts);
   };
 
+  // The tracking loss's taps among a quad's pixels.  A wave holds the 64 consecutive quads of one chunk, so the rank of a lane's first tap =
+  // the chunk's base + the taps of the lanes below it (four ballots, one per pixel of the quad).  No round trip of the exchange is left
+  // exposed: the mask byte and the chunk's base of the NEXT item are requested one iteration ahead (the first item's at the top of the
+  // kernel, under the constants' set-up); the offered gradient and the image's old value are requested — four plus four loads leaving
+  // together, raw, the tap / no-tap selection applied where they are used — BEFORE the quad's seven 16-byte loads and consumed after its
+  // terms.  (The first version loaded everything where it used it, one dependent round trip after the other: 1.26 instead of 0.78 ms at C2.)
+  auto prepare_taps = [&](TapState& ts, unsigned bits, int chunk_base) {
+    ts.bits = bits;
+    if (!__ballot(bits != 0)) return;  // (wave-uniform)
+    unsigned below = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned long long be = __ballot((bits >> e) & 1u);
+      below += __builtin_amdgcn_mbcnt_hi((unsigned)(be >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)be, 0u));
+    }
+    ts.slot = chunk_base + (int)below;
+    if (bits != 0) {
+      // the slot of pixel e if it is a tap, else the lane's first slot (a valid address: the load's value is discarded)
+      int at[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) at[e] = ((bits >> e) & 1u) ? ts.slot + __builtin_popcount(bits & ((1u << e) - 1u)) : ts.slot;
+      if (p.tap_grad) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ts.grad[e] = p.tap_grad[at[e]];
+      }
+      if (!ADAM && p.tap_stale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ts.old[e] = p.tap_depth[at[e]];
+      }
+    }
+  };
+  auto request_taps = [&](int item) {
+    if (item < items) {
+      tap_bits_next = p.tap_mask[(size_t)bf * items + item];
+      tap_base_next = p.tap_chunk_base[(size_t)bf * chunks + (item >> 6)];
+    }
+  };
+  // (the first item's mask byte / chunk base, requested at the top of the kernel: taken here, outside the loop — a load pending at the loop's
+  // header would put the wait inside it, where it also waits for the previous iteration's stores)
+  if constexpr (TAPS) asm volatile("" : "+v"(tap_bits_next), "+v"(tap_base_next));
   // (A depth-2 software pipeline of the loads — two QuadIn register sets, loop unrolled by
   // two, 168 VGPRs — measured 0.856 vs 0.845 ms: no gain, removed.)
   for (int it = 0; it < p.iters; ++it) {
     const int item = base + it * blockDim.x + threadIdx.x;
     if (item >= items) break;
     if (VEC == 4) {
+      TapState ts = {};
+      if constexpr (TAPS) {
+        const unsigned bits_now = tap_bits_next;
+        const int base_now = tap_base_next;
+        if (it + 1 < p.iters) request_taps(item + (int)blockDim.x);
+        prepare_taps(ts, bits_now, base_now);
+      }
       QuadIn q = {};
       if constexpr (PACKED) load_quad_packed(q, depth, packed, item, has_fwd, has_bwd);
       else load_quad(q, depth, ff, mf, fb, mb, item, has_fwd, has_bwd);
-      compute_quad(q, item);
+      compute_quad(q, item, ts);
       continue;
     }
     float z[VEC], fxf[VEC] = {}, fyf[VEC] = {}, mmf[VEC] = {}, fxb[VEC] = {}, fyb[VEC] = {}, mmb[VEC] = {};  // (an absent direction: zeros)
@@ -452,7 +504,7 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
         fxb[0] = a.x; fyb[0] = a.y; mmb[0] = mb[item];
       }
     }
-    compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item);
+    compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item, TapState{});
   }
 
   double* dst = p.acc + (size_t)bf * 2 * kFlowAccStride;

@@ -47,7 +47,7 @@ from flowmap.tracking.track_predictor import Tracks  # noqa: E402
 
 from oracle import flowmap_oracle as orc  # noqa: E402  (input generators only)
 
-OUT = HERE.parent / "tests" / "golden"
+OUT = Path(os.environ.get("FLOWMAP_GOLDEN_OUT", HERE.parent / "tests" / "golden"))
 OUT.mkdir(parents=True, exist_ok=True)
 torch.set_num_threads(8)
 
@@ -298,6 +298,12 @@ def gold_functions():
         (res * cot).sum().backward()
         cases.update({f"{name}_p": p, f"{name}_q": q, f"{name}_w": wt, f"{name}_cot": cot, f"{name}_T": res,
                       f"{name}_g_p": p.grad, f"{name}_g_q": q.grad, f"{name}_g_w": wt.grad})
+        # the SAME reference function in fp64 (round 4): what its own fp32 gradients above are worth — the tests hold a gradient to
+        # max(1e-4, 2 x the reference's fp32-vs-fp64 gap) of this truth
+        with fp64_reference():
+            p64, q64, w64 = (x.detach().double().requires_grad_(True) for x in (p, q, wt))
+            (align_rigid(p64, q64, w64) * cot.double()).sum().backward()
+        cases.update({f"{name}_f64_g_p": p64.grad, f"{name}_f64_g_q": q64.grad, f"{name}_f64_g_w": w64.grad})
     save("fn_align_rigid", **cases)
 
     # --- align_surfaces: b=2, subsampled + repeated indices, flows pushing samples off-image
@@ -314,8 +320,12 @@ def gold_functions():
     ext = rp.align_surfaces(surfaces, bflow, wts, idx)
     cot = torch.randn(ext.shape, generator=g)
     (ext * cot).sum().backward()
+    with fp64_reference():
+        z64, k64, w64 = (x.detach().double().requires_grad_(True) for x in (z, k3, wts))
+        e64 = rp.align_surfaces(rp.unproject(rp.sample_image_grid((h, w))[0], z64, k64[:, :, None, None]), bflow.double(), w64, idx)
+        (e64 * cot.double()).sum().backward()
     save("fn_align_surfaces", z=z, k=k3, bwd_flow=bflow, weights=wts, indices=idx, cot=cot,
-         extrinsics=ext, g_z=z.grad, g_k=k3.grad, g_weights=wts.grad)
+         extrinsics=ext, g_z=z.grad, g_k=k3.grad, g_weights=wts.grad, f64_g_z=z64.grad, f64_g_k=k64.grad, f64_g_weights=w64.grad)
 
     # --- compute_track_flow ---------------------------------------------------------------
     b, f, h, w, p = 1, 5, 9, 11, 14
@@ -457,8 +467,22 @@ def gold_softmin():
         torch.randperm = real_randperm
     cot = torch.arange(9.0).reshape(3, 3) / 9
     (k[0, 0] * cot).sum().backward()
+    # the same module in fp64 (round 4): the truth its own fp32 gradients are measured against
+    d64, w64 = d.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    flows64 = Flows(fl.forward.double(), fl.backward.double(), fl.forward_mask.double(), fl.backward_mask.double())
+    grid32 = ism.sample_image_grid
+    torch.randperm = lambda *a, **k: perm.clone()
+    ism.sample_image_grid = lambda *a, **k: (lambda xy_ij: (xy_ij[0].double(), xy_ij[1]))(grid32(*a, **k))
+    try:
+        with fp64_reference():
+            k64 = ism.IntrinsicsSoftmin(cfg).double().forward(batch, flows64, BackboneOutput(d64, w64), 0)
+    finally:
+        torch.randperm = real_randperm
+        ism.sample_image_grid = grid32
+    assert k64.dtype == torch.float64
+    (k64[0, 0] * cot.double()).sum().backward()
     save("fn_softmin", depth=depth, weights=wt, bwd=fl.backward, indices=perm[:96], candidates=module.focal_length_candidates,
-         cot=cot, intrinsics=k[0, 0], g_depth=d.grad, g_weights=wt.grad)
+         cot=cot, intrinsics=k[0, 0], g_depth=d.grad, g_weights=wt.grad, f64_intrinsics=k64[0, 0], f64_g_depth=d64.grad, f64_g_weights=w64.grad)
 
 
 if __name__ == "__main__":

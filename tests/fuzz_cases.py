@@ -6,8 +6,7 @@ import random
 
 import torch
 
-from conftest import assert_close
-from helpers import run_oracle, run_ours
+from helpers import compare_step, run_oracle, run_ours
 from oracle import flowmap_oracle as orc
 
 
@@ -39,9 +38,7 @@ def run_case(cfg, device):
         p = min(p, h * w)
     ours = run_ours(sc["depth_init"], wl, 0.8, flows, (h, w), p, tracks, kind, device=device, lazy=lazy)
     ref = run_oracle(sc["depth_init"], wl, 0.8, flows, (h, w), p, tracks, kind, dtype=torch.float64)
-    tag = f"cfg{cfg}"
-    assert_close(ours["total"], ref["total"], 1e-4, what=f"total {tag}")
-    assert_close(ours["extrinsics"], ref["extrinsics"], 1e-4, what=f"extrinsics {tag}")
-    assert_close(ours["g_depth"], ref["g_depth"], 2e-4, what=f"g_depth {tag}")
-    assert_close(ours["g_wlogit"], ref["g_wlogit"], 5e-4, abs_=1e-7, what=f"g_wlogit {tag}")
-    assert_close(ours["g_focal"], ref["g_focal"], 2e-3, abs_=1e-4 * abs(float(ref["total"])), what=f"g_focal {tag}")
+    # every value and gradient at 1e-4 of the fp64 oracle, or twice the gap the reference path's own fp32 evaluation (the fp32 oracle) has on
+    # the same inputs (helpers.compare_step; round 4: these gates were 2e-4 / 5e-4 / 2e-3 without a measured gap beside them)
+    ref32 = run_oracle(sc["depth_init"], wl, 0.8, flows, (h, w), p, tracks, kind, dtype=torch.float32)
+    compare_step(ours, ref, ref32)

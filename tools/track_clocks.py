@@ -17,7 +17,10 @@ b.FILE_FLAGS["fm_track.hip"] = ["-DFM_TRACK_CLOCKS"] + sys.argv[1:]
 b.build_library(force=True, verbose=False)
 from flowmap_amd import _lib  # noqa: E402
 
-sys.argv = ["bench.py", "--config", "c2", "--cpu-frames", "0", "--steps", "5", "--warmup", "2"]
+import os  # noqa: E402
+
+sys.argv = ["bench.py", "--config", "c2", "--cpu-frames", "0", "--steps", "5", "--warmup", "2", "--sustained-steps", "0"] + (
+    ["--no-tap-exchange"] if os.environ.get("FLOWMAP_NO_TAP_EXCHANGE") else [])
 try:
     runpy.run_path(str(ROOT / "bench.py"), run_name="__main__")
 except SystemExit:
