@@ -720,7 +720,7 @@ class FlowLossFused:
         # (verified only while the version counter still vouches for the image: after a regular update the image was simply out of date, and
         # whoever sampled it did so before that update)
         verify = tap_plan is not None and tap_plan.sampled_now and ticket is None and tap_plan.image_valid_for(_root(depth))
-        taps = (None, None, None, None) if tap_plan is None else (tap_plan.mask, tap_plan.chunk_base, tap_plan.image, tap_plan.stale_flag if verify else None)
+        taps = (None, None, None, None) if tap_plan is None else (tap_plan.chunk_base, tap_plan.pixel_in_frame, tap_plan.image, tap_plan.stale_flag if verify else None)
         offered = tap_plan is not None and sink.offers_taps()
         loss = torch_ops().flow_loss(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, int(kind), float(delta),
                                      sink, int(items), acc, *adam, *taps)
@@ -1083,16 +1083,20 @@ class PackedTracks:
                     plan = (pixels.contiguous(), first, (entries // 4).to(torch.int32).contiguous(), weights[entries].contiguous())
                     # where each tap of each track point sits in `pixels` (its rank), -1 for a tap that contributes nothing: the tap
                     # exchange's view of the same plan (fm_track_loss_fused_fwd_taps)
+                    # (bit 30: the pixel has more than one entry, i.e. several track points share it — fm_track_loss_fused_fwd_taps)
+                    assert plan[0].numel() < 1 << 30
                     slots = torch.full((self.total * 4,), -1, dtype=torch.int32, device=dev)
-                    slots[used] = torch.searchsorted(plan[0], keys[used]).to(torch.int32)
-                    self._tap_slots[key] = slots.contiguous()
+                    ranks = torch.searchsorted(plan[0], keys[used])
+                    shared = counts > 1
+                    slots[used] = (ranks + shared[ranks].to(torch.int64) * (1 << 30)).to(torch.int32)
+                    self._tap_slots[key] = (slots.contiguous(), torch.nonzero(shared).reshape(-1).to(torch.int32).contiguous())
             self._plans[key] = plan
         return self._plans[key]
 
     def tap_plan(self, frames: int, height: int, width: int):
         """The static tap set of this track list as the fused flow pass wants it (include/flowmap_hip.h: fm_flow_taps), built once per
-        video shape: a TapPlan with the sorted tap pixels, the per-quad bit mask over a (1, frames, height, width) depth tensor, the rank of
-        the first tap of every 64-quad chunk of a frame, and the (total, 4) slot of every tap of every track point.  None when the layout
+        video shape: a TapPlan with the sorted tap pixels, the rank of the first tap of every 64-quad chunk of a frame of a (1, frames,
+        height, width) depth tensor, each tap's pixel index inside its frame, and the (total, 4) slot of every tap of every track point.  None when the layout
         does not apply (width or pixel count not a multiple of 4, nothing scattered, a segment past the last frame)."""
         key = (int(frames), int(height), int(width))
         if key not in self._tap_plans:
@@ -1103,15 +1107,12 @@ class PackedTracks:
                 pixels = plan[0]
                 dev = pixels.device
                 quads, chunks = n // 4, (n // 4 + 63) // 64
-                mask = torch.zeros((frames * quads,), dtype=torch.uint8, device=dev)
-                quad, bit = torch.div(pixels, 4, rounding_mode="floor"), pixels % 4
-                for e in range(4):
-                    mask[quad[bit == e]] |= 1 << e
-                # rank of the first tap at or after quad 64·c of frame f: taps with key < f·n + 256·c
+                # rank of the first tap at or after quad 64·c of frame f: taps with key < f·n + 256·c; one more entry at the end: M
                 starts = (torch.arange(frames, dtype=torch.int64, device=dev)[:, None] * n
                           + torch.arange(chunks, dtype=torch.int64, device=dev)[None, :] * 256).reshape(-1)
-                chunk_base = torch.searchsorted(pixels, starts).to(torch.int32).contiguous()
-                built = TapPlan(self, key, plan, mask, chunk_base, self._tap_slots[(int(height), int(width))])
+                chunk_base = torch.cat([torch.searchsorted(pixels, starts), torch.tensor([pixels.numel()], dtype=torch.int64, device=dev)]).to(torch.int32).contiguous()
+                pixel_in_frame = (pixels % n).to(torch.int32).contiguous()
+                built = TapPlan(self, key, plan, chunk_base, pixel_in_frame, *self._tap_slots[(int(height), int(width))])
             self._tap_plans[key] = built
         return self._tap_plans[key]
 
@@ -1122,10 +1123,11 @@ class TapPlan:
     at every tap as the last flow pass left it; it may be sampled from only while the depth parameter has not moved since
     (``image_valid_for``: same storage, same version counter)."""
 
-    def __init__(self, packed, key, plan, mask, chunk_base, slots):
+    def __init__(self, packed, key, plan, chunk_base, pixel_in_frame, slots, shared_ranks):
         self.packed, self.key, self.plan = packed, key, plan
-        self.pixels, self.mask, self.chunk_base, self.slots = plan[0], mask, chunk_base, slots
-        self.image = torch.zeros((plan[0].numel(),), dtype=torch.float32, device=plan[0].device)
+        self.pixels, self.chunk_base, self.pixel_in_frame, self.slots, self.shared_ranks = plan[0], chunk_base, pixel_in_frame, slots, shared_ranks
+        # (one value of padding: the tracking loss reads the two taps of an image row with one 8-byte load)
+        self.image = torch.zeros((plan[0].numel() + 1,), dtype=torch.float32, device=plan[0].device)[: plan[0].numel()]
         self._tag = None  # what the image was left for: (the parameter object, its storage — held, so its address is not reused —, data_ptr, version)
         # raised by the flow pass when a tap depth it reads differs from the image value the tracking loss of the same step sampled: the
         # parameter was edited behind its version counter (`param.data.clamp_()` ...).  Read at the first sampled step and every 64th.
@@ -1185,7 +1187,7 @@ def tap_plan_of(depth: Tensor) -> Optional[TapPlan]:
         return None
     root = _whole_parameter(depth)
     plan = root.__dict__.get("_fm_tap_plan") if root is not None else None
-    if plan is None or plan.key != tuple(int(d) for d in depth.shape[1:]) or plan.mask.device != depth.device or depth.data_ptr() % 16 != 0:
+    if plan is None or plan.key != tuple(int(d) for d in depth.shape[1:]) or plan.chunk_base.device != depth.device or depth.data_ptr() % 16 != 0:
         return None
     return plan
 
@@ -1240,14 +1242,15 @@ class TrackLossFused:
         sink = depth_sink(depth) if defer else None
         # the tap exchange: whole video local, gradients on — register the static tap set with the parameter (the flow pass then leaves the tap
         # depths in its compact image) and sample from that image while the parameter has not moved since
-        taps = (None, None)
+        taps = (None, None, None)
         root = _whole_parameter(depth) if (use_tap_exchange and plan is not None and reducer is None and int(frame0) == 0 and defer) else None
         if root is not None and root.is_leaf and ext.shape[1] == depth.shape[1]:
             tap_plan = packed.tap_plan(depth.shape[1], depth.shape[2], depth.shape[3])
             if tap_plan is not None:
                 root.__dict__["_fm_tap_plan"] = tap_plan
+                taps = (tap_plan.slots, None, tap_plan.shared_ranks)
                 if use_tap_image and tap_plan.image_valid_for(root):
-                    taps = (tap_plan.slots, tap_plan.image)
+                    taps = (tap_plan.slots, tap_plan.image, tap_plan.shared_ranks)
                     tap_plan.note_sampled()
                     counters["track_tap_samples"] += 1
                 else:

@@ -51,12 +51,14 @@ struct FlowParams {
   float* exp_avg_sq;      // (B,F,H,W)
   const uint8_t* touched; // (B·F·H·W/4): bit e of byte q = pixel 4q+e receives gradient from (or is read by) another operator
   AdamCoef adam;
-  // fm_flow_loss_fused_taps: the STATIC tap set of the tracking loss (fm_flow_taps, include/flowmap_hip.h) — per quad a byte of tap
-  // bits, per 64-quad chunk of a frame the rank of its first tap among all taps in (frame, pixel) order.  At a tap the pass adds
-  // tap_scale[0]·tap_grad[rank] into dL/ddepth (the tracking loss's gradient, computed before this pass and compacted) and stores the
-  // depth it leaves behind in tap_depth[rank] for the tracking loss's next evaluation: neither operator touches a cold line of the images
-  const uint8_t* tap_mask;
+  // fm_flow_loss_fused_taps: the STATIC tap set of the tracking loss (fm_flow_taps, include/flowmap_hip.h), M pixels ranked in (frame,
+  // pixel) order — tap_chunk_base: the rank of the first tap at or after quad 64·c of frame bf (one more entry at the end: M);
+  // tap_pixel: each tap's pixel index inside its frame.  A workgroup owns a run of consecutive quads of one frame, hence a run of
+  // consecutive taps: it stages tap_scale[0]·tap_grad of its taps in an LDS image of its pixels before its main loop (added into
+  // dL/ddepth with one LDS read per quad), collects the depth it leaves behind in a second LDS image and writes its taps' values to
+  // tap_depth afterwards — coalesced on the tap side, branch-free in the loop, no cold line of the images touched by the tracking loss.
   const int32_t* tap_chunk_base;
+  const int32_t* tap_pixel;
   const float* tap_grad;
   const float* tap_scale;
   float* tap_depth;
@@ -86,14 +88,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #endif
 __device__ __forceinline__ v4f ld4(const float* base, int i) { return FM_LOAD(reinterpret_cast<const v4f*>(base) + i); }
 __device__ __forceinline__ v2f ld2(const float* base, int i) { return FM_LOAD(reinterpret_cast<const v2f*>(base) + i); }
-
-// One quad's share of the tap exchange (fm_flow_taps): which of its pixels are taps, the rank of the first one, the tracking gradient offered
-// at each and the value the compact image held for it.
-struct TapState {
-  unsigned bits;
-  int slot;
-  float grad[4], old[4];
-};
 
 // One quad's raw inputs, kept as the 16-byte vectors they were loaded as.
 struct QuadIn {
@@ -242,9 +236,11 @@ template <int VEC, int KIND, bool GRAD, bool PACKED, bool ADAM = false, bool TAP
 __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowParams p) {
   static_assert(!ADAM || (VEC == 4 && GRAD), "the in-pass Adam update runs on the 16-byte gradient path");
   static_assert(!TAPS || (VEC == 4 && GRAD), "the tap exchange runs on the 16-byte gradient path");
-  extern __shared__ double lds[];  // reduction scratch (fp64), then the [width] u-table
+  extern __shared__ double lds[];  // reduction scratch (fp64), then the [width] u-table, then (TAPS) the two tap images of the block's pixels
   double* red = lds;
   float* u_tab = reinterpret_cast<float*>(lds + (256 / 64) * kFlowAcc);
+  v4f* tap_g4 = reinterpret_cast<v4f*>(u_tab + ((p.width + 3) & ~3));  // [256·iters] quads: scale·(tracking gradient) at the block's pixels, 0 off the taps
+  v4f* tap_z4 = tap_g4 + 256 * p.iters;                                 // [256·iters] quads: the depth this pass leaves at the block's pixels
 
   const int bf = blockIdx.y;  // batch*frames + frame
   const int f = bf % p.frames;
@@ -255,18 +251,29 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   const int items = n / VEC;
   const int items_per_row = p.width / VEC;
 
-  // (the tap exchange's first mask byte / chunk base: requested before anything else, used after the constants below are set up)
-  unsigned tap_bits_next = 0;
-  int tap_base_next = 0;
+  for (int c = threadIdx.x; c < p.width; c += blockDim.x) u_tab[c] = pixel_center(c, p.width);
+  int tap_first = 0, tap_end = 0;  // the block's run of taps
+  const int block_quad0 = blockIdx.x * (blockDim.x * p.iters);
   if constexpr (TAPS) {
-    const int first = blockIdx.x * (blockDim.x * p.iters) + (int)threadIdx.x;
-    if (first < items) {
-      tap_bits_next = p.tap_mask[(size_t)bf * items + first];
-      tap_base_next = p.tap_chunk_base[(size_t)bf * (((size_t)items + kPackLanes - 1) / kPackLanes) + (first >> 6)];
+    const size_t chunk_count = ((size_t)items + kPackLanes - 1) / kPackLanes;
+    const size_t c0 = (size_t)bf * chunk_count + (size_t)(block_quad0 >> 6);
+    const size_t c1 = (size_t)bf * chunk_count + min((size_t)(block_quad0 >> 6) + (size_t)(blockDim.x * p.iters >> 6), chunk_count);
+    tap_first = p.tap_chunk_base[c0];
+    tap_end = p.tap_chunk_base[c1];
+    if (p.tap_grad) {
+      const v4f zero = {0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < p.iters; ++it) tap_g4[it * blockDim.x + threadIdx.x] = zero;
     }
   }
-  for (int c = threadIdx.x; c < p.width; c += blockDim.x) u_tab[c] = pixel_center(c, p.width);
   __syncthreads();
+  if constexpr (TAPS) {
+    if (p.tap_grad) {
+      const float ts = p.tap_scale[0];
+      float* tap_g = reinterpret_cast<float*>(tap_g4);
+      for (int t = tap_first + (int)threadIdx.x; t < tap_end; t += blockDim.x) tap_g[p.tap_pixel[t] - 4 * block_quad0] = ts * p.tap_grad[t];
+      __syncthreads();
+    }
+  }
 
   const size_t pair_f = (size_t)b * (p.frames - 1) + f;  // pair whose earlier frame is f
   const size_t pair_b = pair_f - 1;                       // pair whose later frame is f
@@ -287,7 +294,6 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
   const DirPair dp = make_pair(df, db, has_fwd ? 1.f : 0.f, has_bwd ? 1.f : 0.f);  // (a direction this frame does not have: zeros)
   const float scale = GRAD ? p.scale[0] : 0.f;
   const float inv_delta = KIND == kHuber ? 1.0f / p.delta : 0.f;
-  const float tap_scale = (TAPS && p.tap_grad) ? p.tap_scale[0] : 0.f;
 
   const float* depth = p.depth + (size_t)b * p.bs[0] + (size_t)f * p.fs[0];
   const float* ff = p.flow_fwd + (size_t)b * p.bs[1] + (size_t)f * p.fs[1];  // pair f of this batch entry
@@ -311,7 +317,7 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
 
   // Everything after the loads of one item: coordinates, both residual terms per pixel, store.
   auto compute = [&](const float (&z)[VEC], const float (&fxf)[VEC], const float (&fyf)[VEC], const float (&mmf)[VEC],
-                     const float (&fxb)[VEC], const float (&fyb)[VEC], const float (&mmb)[VEC], int item, const TapState& ts) {
+                     const float (&fxb)[VEC], const float (&fyb)[VEC], const float (&mmb)[VEC], int item) {
     float gz[VEC];
     const int row = item / items_per_row;
     const int col0 = (item - row * items_per_row) * VEC;
@@ -343,16 +349,13 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
                                  scale, p.delta, inv_delta, p.ax, p.ay, acc, gz[e]);
     }
 #endif
-    // the tracking loss's gradient at this quad's taps (loaded by prepare_taps before the terms above were evaluated)
-    const unsigned tap_bits = TAPS ? ts.bits : 0u;
-    const int tap_slot = ts.slot;
+    const int local_quad = item - block_quad0;
     if (TAPS) {
+      if (p.tap_grad) {  // (wave-uniform) the tracking loss's share of dL/ddepth at this quad's pixels: zero off the taps
+        const v4f tg = tap_g4[local_quad];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) gz[e] = fmaf(tap_scale, ((tap_bits >> e) & 1u) ? ts.grad[e] : 0.f, gz[e]);
-      // the next item's mask byte and chunk base were requested before this item's loads: they have arrived — take them HERE, ahead of the
-      // stores below (the memory counter is one in-order queue of loads and stores: taking them at the top of the next iteration would wait
-      // for these stores to be acknowledged)
-      asm volatile("" : "+v"(tap_bits_next), "+v"(tap_base_next));
+        for (int e = 0; e < VEC; ++e) gz[e] += tg[e];
+      }
     }
     if (ADAM) {
       // depth, exp_avg, exp_avg_sq of this quad rewritten in place (model_wrapper_overfit.py:104-105: torch.optim.Adam);
@@ -374,21 +377,12 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
       FM_STORE(z4, reinterpret_cast<v4f*>(p.depth_rw) + q);
       FM_STORE(m4, reinterpret_cast<v4f*>(p.exp_avg) + q);
       FM_STORE(v4, reinterpret_cast<v4f*>(p.exp_avg_sq) + q);
-      if (TAPS && tap_bits != 0 && p.tap_depth) {  // the depth this pass leaves behind (a pixel another operator keeps is refreshed by its own update)
-        int s = tap_slot;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          if ((tap_bits >> e) & 1u) p.tap_depth[s++] = z4[e];
-      }
+      if (TAPS) tap_z4[local_quad] = z4;  // (a pixel another operator keeps is refreshed by its own update: the caller knows which)
     } else if (GRAD && gd) {
-      if (TAPS && tap_bits != 0 && p.tap_depth) {
-        int s = tap_slot;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          if ((tap_bits >> e) & 1u) {
-            if (p.tap_stale && __float_as_uint(ts.old[e]) != __float_as_uint(z[e])) *p.tap_stale = 1;
-            p.tap_depth[s++] = z[e];
-          }
+      if (TAPS) {
+        v4f zq;
+        zq.x = z[0]; zq.y = z[1 % VEC]; zq.z = z[2 % VEC]; zq.w = z[3 % VEC];
+        tap_z4[local_quad] = zq;
       }
       if (VEC == 4) {
         v4f o;
@@ -404,7 +398,7 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
     }
   };
 
-  auto compute_quad = [&](const QuadIn& q, int item, const TapState& ts) {
+  auto compute_quad = [&](const QuadIn& q, int item) {
     float z[VEC], fxf[VEC], fyf[VEC], mmf[VEC], fxb[VEC], fyb[VEC], mmb[VEC];
     if (VEC == 4) {
       z[0] = q.z.x; z[1 % VEC] = q.z.y; z[2 % VEC] = q.z.z; z[3 % VEC] = q.z.w;
@@ -415,66 +409,19 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
       fxb[0] = q.ba.x; fyb[0] = q.ba.y; fxb[1 % VEC] = q.ba.z; fyb[1 % VEC] = q.ba.w;
       fxb[2 % VEC] = q.bc.x; fyb[2 % VEC] = q.bc.y; fxb[3 % VEC] = q.bc.z; fyb[3 % VEC] = q.bc.w;
     }
-    compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item, ts);
+    compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item);
   };
 
-  // The tracking loss's taps among a quad's pixels.  A wave holds the 64 consecutive quads of one chunk, so the rank of a lane's first tap =
-  // the chunk's base + the taps of the lanes below it (four ballots, one per pixel of the quad).  No round trip of the exchange is left
-  // exposed: the mask byte and the chunk's base of the NEXT item are requested one iteration ahead (the first item's at the top of the
-  // kernel, under the constants' set-up); the offered gradient and the image's old value are requested — four plus four loads leaving
-  // together, raw, the tap / no-tap selection applied where they are used — BEFORE the quad's seven 16-byte loads and consumed after its
-  // terms.  (The first version loaded everything where it used it, one dependent round trip after the other: 1.26 instead of 0.78 ms at C2.)
-  auto prepare_taps = [&](TapState& ts, unsigned bits, int chunk_base) {
-    ts.bits = bits;
-    if (!__ballot(bits != 0)) return;  // (wave-uniform)
-    unsigned below = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned long long be = __ballot((bits >> e) & 1u);
-      below += __builtin_amdgcn_mbcnt_hi((unsigned)(be >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)be, 0u));
-    }
-    ts.slot = chunk_base + (int)below;
-    if (bits != 0) {
-      // the slot of pixel e if it is a tap, else the lane's first slot (a valid address: the load's value is discarded)
-      int at[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) at[e] = ((bits >> e) & 1u) ? ts.slot + __builtin_popcount(bits & ((1u << e) - 1u)) : ts.slot;
-      if (p.tap_grad) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ts.grad[e] = p.tap_grad[at[e]];
-      }
-      if (!ADAM && p.tap_stale) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ts.old[e] = p.tap_depth[at[e]];
-      }
-    }
-  };
-  auto request_taps = [&](int item) {
-    if (item < items) {
-      tap_bits_next = p.tap_mask[(size_t)bf * items + item];
-      tap_base_next = p.tap_chunk_base[(size_t)bf * chunks + (item >> 6)];
-    }
-  };
-  // (the first item's mask byte / chunk base, requested at the top of the kernel: taken here, outside the loop — a load pending at the loop's
-  // header would put the wait inside it, where it also waits for the previous iteration's stores)
-  if constexpr (TAPS) asm volatile("" : "+v"(tap_bits_next), "+v"(tap_base_next));
   // (A depth-2 software pipeline of the loads — two QuadIn register sets, loop unrolled by
   // two, 168 VGPRs — measured 0.856 vs 0.845 ms: no gain, removed.)
   for (int it = 0; it < p.iters; ++it) {
     const int item = base + it * blockDim.x + threadIdx.x;
     if (item >= items) break;
     if (VEC == 4) {
-      TapState ts = {};
-      if constexpr (TAPS) {
-        const unsigned bits_now = tap_bits_next;
-        const int base_now = tap_base_next;
-        if (it + 1 < p.iters) request_taps(item + (int)blockDim.x);
-        prepare_taps(ts, bits_now, base_now);
-      }
       QuadIn q = {};
       if constexpr (PACKED) load_quad_packed(q, depth, packed, item, has_fwd, has_bwd);
       else load_quad(q, depth, ff, mf, fb, mb, item, has_fwd, has_bwd);
-      compute_quad(q, item, ts);
+      compute_quad(q, item);
       continue;
     }
     float z[VEC], fxf[VEC] = {}, fyf[VEC] = {}, mmf[VEC] = {}, fxb[VEC] = {}, fyb[VEC] = {}, mmb[VEC] = {};  // (an absent direction: zeros)
@@ -504,9 +451,20 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
         fxb[0] = a.x; fyb[0] = a.y; mmb[0] = mb[item];
       }
     }
-    compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item, TapState{});
+    compute(z, fxf, fyf, mmf, fxb, fyb, mmb, item);
   }
 
+  if constexpr (TAPS) {
+    if (p.tap_depth) {  // the block's taps: the depth this pass leaves at each, from the LDS image (coalesced on the tap side)
+      __syncthreads();
+      const float* tap_z = reinterpret_cast<const float*>(tap_z4);
+      for (int t = tap_first + (int)threadIdx.x; t < tap_end; t += blockDim.x) {
+        const float znew = tap_z[p.tap_pixel[t] - 4 * block_quad0];
+        if (!ADAM && p.tap_stale && __float_as_uint(p.tap_depth[t]) != __float_as_uint(znew)) *p.tap_stale = 1;
+        p.tap_depth[t] = znew;
+      }
+    }
+  }
   double* dst = p.acc + (size_t)bf * 2 * kFlowAccStride;
   float acc_f[kFlowAcc], acc_b[kFlowAcc];
 #pragma unroll
@@ -671,7 +629,7 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
                             int items_per_thread, const FlowAdam* adam, const fm_layout* layouts, void* stream, const fm_flow_taps* taps = nullptr) {
   FM_CHECK_ARG(depth && k && kinv && acc);
   FM_CHECK_ARG(!(layouts && adam));  // the in-pass update rewrites the depth PARAMETER: dense by construction
-  FM_CHECK_ARG(!taps || (!layouts && taps->mask && taps->chunk_base && scale && grad_depth && width % 4 == 0 && (taps->grad == nullptr || taps->scale != nullptr)));
+  FM_CHECK_ARG(!taps || (!layouts && taps->chunk_base && taps->pixel && scale && grad_depth && width % 4 == 0 && (taps->grad == nullptr || taps->scale != nullptr)));
   FM_CHECK_ARG(packed || (flow_fwd && flow_bwd && mask_fwd && mask_bwd));
   FM_CHECK_ARG(batch >= 1 && frames >= 2 && height >= 1 && width >= 1);
   FM_CHECK_ARG(mapping_kind >= 0 && mapping_kind <= 2);
@@ -700,8 +658,8 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
     p.adam = adam->coef;
   }
   if (taps) {
-    p.tap_mask = taps->mask;
     p.tap_chunk_base = taps->chunk_base;
+    p.tap_pixel = taps->pixel;
     p.tap_grad = taps->grad;
     p.tap_scale = taps->scale;
     p.tap_depth = taps->depth;
@@ -737,7 +695,8 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
   }
   const long per_block = (long)threads * p.iters;
   dim3 grid((unsigned)((items + per_block - 1) / per_block), (unsigned)(batch * frames));
-  const size_t lds = sizeof(float) * (size_t)width + sizeof(double) * (threads / 64) * kFlowAcc;
+  size_t lds = sizeof(float) * (size_t)width + sizeof(double) * (threads / 64) * kFlowAcc;
+  if (taps) lds = sizeof(float) * (size_t)((width + 3) & ~3) + sizeof(double) * (threads / 64) * kFlowAcc + 2 * sizeof(float) * 4 * (size_t)threads * p.iters;
 #define FM_FLOW_LAUNCH(V, K, P)                                                                              \
   do {                                                                                                       \
     if (taps) {                                                                                              \

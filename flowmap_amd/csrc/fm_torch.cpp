@@ -756,8 +756,8 @@ struct FlowLaunch {
 };
 // the tap exchange of one launch (fm_flow_taps): the static mask / rank table, what a tracking loss offered, where the tap depths go
 struct FlowTapArgs {
-  Tensor mask, chunk_base, grad, scale, depth_out, stale;
-  bool on() const { return mask.defined(); }
+  Tensor chunk_base, pixel, grad, scale, depth_out, stale;
+  bool on() const { return chunk_base.defined(); }
 };
 
 static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& t_fwd, const Tensor& t_bwd,
@@ -817,7 +817,7 @@ static FlowLaunch flow_launch(const Tensor& depth, const Tensor& k, const Tensor
               *p_mb = pk ? nullptr : ptr(mask_bwd);
   if (taps.on()) {  // the tap exchange with the tracking loss, with or without the in-pass Adam update (fm_flow_loss_fused_taps)
     TORCH_CHECK(!any_view, "flowmap_amd: the tap exchange reads dense image stacks (the caller hands frame windows to the plain pass)");
-    const fm_flow_taps t{ptr<uint8_t>(taps.mask), ptr<int32_t>(taps.chunk_base), ptr(taps.grad), ptr(taps.scale), ptr(taps.depth_out),
+    const fm_flow_taps t{ptr<int32_t>(taps.chunk_base), ptr<int32_t>(taps.pixel), ptr(taps.grad), ptr(taps.scale), ptr(taps.depth_out),
                          exp_avg.defined() ? nullptr : ptr<int32_t>(taps.stale)};
     const bool ad = exp_avg.defined();
     FM_CALL(fm_flow_loss_fused_taps, ptr(depth), ptr(k), ptr(kinv), ptr(t_fwd), ptr(t_bwd), p_ff, p_fb, p_mf, p_mb, ptr(packed), ptr(norm), (int)b,
@@ -855,7 +855,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
                         const Tensor& mask_bwd_in, const Tensor& norm, const OptTensor& packed_o, int64_t kind, double delta,
                         const c10::intrusive_ptr<DepthSink>& sink, int64_t items, const OptTensor& acc_work, const OptTensor& exp_avg_o,
                         const OptTensor& exp_avg_sq_o, const OptTensor& touched_o, int64_t adam_step, std::vector<double> adam,
-                        const OptTensor& adam_flag_o, const OptTensor& tap_mask_o, const OptTensor& tap_chunk_base_o, const OptTensor& tap_depth_o,
+                        const OptTensor& adam_flag_o, const OptTensor& tap_chunk_base_o, const OptTensor& tap_pixel_o, const OptTensor& tap_depth_o,
                         const OptTensor& tap_stale_o, bool grad_enabled, bool park) {
     check_device({&depth_in, &k_in, &kinv_in, &t_fwd_in, &t_bwd_in, &flow_fwd_in, &flow_bwd_in, &mask_fwd_in, &mask_bwd_in, &norm});
     TORCH_CHECK(flow_fwd_in.scalar_type() == at::kFloat && flow_bwd_in.scalar_type() == at::kFloat && mask_fwd_in.scalar_type() == at::kFloat &&
@@ -902,24 +902,24 @@ struct FlowLossFused : public Function<FlowLossFused> {
     // a tracking loss of this step ran before this pass and the dense gradient is parked with the fit, whose backward settles the account)
     // and the compact image the tap depths are left in
     FlowTapArgs taps;
-    if (tap_mask_o.has_value() && tap_mask_o->defined() && need && depth_in.requires_grad() && depth.is_contiguous() && w % 4 == 0 &&
+    if (tap_chunk_base_o.has_value() && tap_chunk_base_o->defined() && need && depth_in.requires_grad() && depth.is_contiguous() && w % 4 == 0 &&
         depth.data_ptr() == depth_in.data_ptr()) {
-      taps.mask = *tap_mask_o;
-      taps.chunk_base = opt(tap_chunk_base_o);
+      taps.chunk_base = *tap_chunk_base_o;
+      taps.pixel = opt(tap_pixel_o);
       taps.depth_out = opt(tap_depth_o);
       taps.stale = opt(tap_stale_o);
       TORCH_CHECK(!taps.stale.defined() || (taps.stale.scalar_type() == at::kInt && taps.stale.numel() == 1 && taps.stale.device() == depth.device()),
                   "flowmap_amd: the stale-image flag is one int32 on the depth tensor's device");
-      const int64_t quads = b * f * h * w / 4, chunks = b * f * ((h * w / 4 + 63) / 64);
-      TORCH_CHECK(taps.mask.scalar_type() == at::kByte && taps.mask.is_contiguous() && taps.mask.numel() == quads && taps.chunk_base.defined() &&
-                      taps.chunk_base.scalar_type() == at::kInt && taps.chunk_base.is_contiguous() && taps.chunk_base.numel() == chunks &&
-                      taps.mask.device() == depth.device() && taps.chunk_base.device() == depth.device(),
-                  "flowmap_amd: the tap mask / rank table do not match the depth tensor");
+      const int64_t chunks = b * f * ((h * w / 4 + 63) / 64);
+      TORCH_CHECK(taps.chunk_base.scalar_type() == at::kInt && taps.chunk_base.is_contiguous() && taps.chunk_base.numel() == chunks + 1 &&
+                      taps.pixel.defined() && taps.pixel.scalar_type() == at::kInt && taps.pixel.is_contiguous() &&
+                      taps.chunk_base.device() == depth.device() && taps.pixel.device() == depth.device(),
+                  "flowmap_amd: the tap rank table / pixel list do not match the depth tensor");
       TORCH_CHECK(!taps.depth_out.defined() || (taps.depth_out.scalar_type() == at::kFloat && taps.depth_out.is_contiguous() &&
-                                                taps.depth_out.device() == depth.device()),
-                  "flowmap_amd: the compact tap image is a contiguous float32 tensor on the depth tensor's device");
+                                                taps.depth_out.device() == depth.device() && taps.depth_out.numel() == taps.pixel.numel()),
+                  "flowmap_amd: the compact tap image is a contiguous float32 tensor of one value per tap on the depth tensor's device");
       if (sink && park && sink->accepts(depth) && sink->offers_taps() &&
-          (!taps.depth_out.defined() || taps.depth_out.numel() == sink->tap_grad.numel())) {
+          taps.pixel.numel() == sink->tap_grad.numel()) {
         taps.grad = sink->tap_grad;
         taps.scale = sink->tap_scale;
       }
@@ -1019,7 +1019,7 @@ struct TrackLossFused : public Function<TrackLossFused> {
                                std::vector<int64_t> counts, double weight, int64_t kind, double delta,
                                const c10::intrusive_ptr<DepthSink>& sink, int64_t frame0, const OptTensor& plan_pixels,
                                const OptTensor& plan_first, const OptTensor& plan_entries, const OptTensor& plan_weights, const OptTensor& tap_slot_o,
-                               const OptTensor& tap_depth_o, bool offer_taps, bool grad_enabled, bool park) {
+                               const OptTensor& tap_depth_o, const OptTensor& tap_shared_o, bool offer_taps, bool grad_enabled, bool park) {
     const auto dev = check_device({&depth_in, &k_in, &kinv_in, &ext_in, &xy});
     const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics"),
                  ext = f32c(ext_in, "extrinsics");
@@ -1048,16 +1048,18 @@ struct TrackLossFused : public Function<TrackLossFused> {
     // vouches that depth has not moved since), and / or compact this loss's dL/ddepth at the taps for the flow pass that follows (offer_taps).
     // Whole video local (no frame sharding), gradients on, the fit's node downstream.
     const bool whole = frame0 == 0 && f_local == f && !partial && counts[7] == 0 && (counts[8] < 0 || counts[8] >= f);
-    const Tensor tap_slot = (whole && tap_slot_o.has_value() && tap_depth_o.has_value() && tap_slot_o->defined() && tap_depth_o->defined()) ? *tap_slot_o : Tensor();
-    const Tensor tap_depth = tap_slot.defined() ? *tap_depth_o : Tensor();
+    const Tensor tap_slot = (whole && tap_slot_o.has_value() && tap_slot_o->defined()) ? *tap_slot_o : Tensor();
+    const Tensor tap_depth = (tap_slot.defined() && tap_depth_o.has_value() && tap_depth_o->defined()) ? *tap_depth_o : Tensor();
+    const Tensor tap_shared = (tap_slot.defined() && tap_shared_o.has_value() && tap_shared_o->defined()) ? *tap_shared_o : Tensor();
     if (tap_slot.defined())
-      TORCH_CHECK(tap_slot.scalar_type() == at::kInt && tap_slot.is_contiguous() && tap_slot.numel() == total * 4 && tap_depth.scalar_type() == at::kFloat &&
-                      tap_depth.is_contiguous() && tap_slot.device() == depth.device() && tap_depth.device() == depth.device(),
-                  "flowmap_amd: tap slots (total, 4) int32 and a float32 compact tap image on the depth tensor's device");
+      TORCH_CHECK(tap_slot.scalar_type() == at::kInt && tap_slot.is_contiguous() && tap_slot.numel() == total * 4 && tap_slot.device() == depth.device() &&
+                      (!tap_depth.defined() || (tap_depth.scalar_type() == at::kFloat && tap_depth.is_contiguous() && tap_depth.device() == depth.device())) &&
+                      (!tap_shared.defined() || (tap_shared.scalar_type() == at::kInt && tap_shared.is_contiguous() && tap_shared.device() == depth.device())),
+                  "flowmap_amd: tap slots (total, 4) int32, a float32 compact tap image and an int32 list of shared taps on the depth tensor's device");
     const bool offer = offer_taps && whole && need && depth_in.requires_grad() && ntiles > 0 && sink && park && sink->accepts(depth) &&
                        plan_pixels.has_value() && plan_pixels->defined() && plan_pixels->numel() > 0;
     Tensor tap_grad = offer ? at::empty({plan_pixels->numel()}, fopt) : Tensor();
-    const bool use_taps = tap_slot.defined() || tap_grad.defined();
+    const bool use_taps = tap_depth.defined() || tap_grad.defined();
     const float sc = std::sqrt((float)(h * w));
     {
       DeviceScope scope(dev);
@@ -1076,7 +1078,9 @@ struct TrackLossFused : public Function<TrackLossFused> {
                   (float)h / sc, (float)weight, ptr(ws), ptr<uint8_t>(flag), ptr(tgt), ptr(part), ptr<double>(acc), ptr(loss), ptr(scale),
                   ptr<double>(totals), ptr(gws), ptr<double>(acc2), ptr<int32_t>(tap_slot), ptr(tap_depth), ptr<int64_t>(opt(plan_pixels)),
                   ptr<int32_t>(opt(plan_first)), ptr<int32_t>(opt(plan_entries)), ptr(opt(plan_weights)),
-                  tap_grad.defined() ? (long)tap_grad.numel() : 0L, ptr(tap_grad), scope.stream);
+                  tap_grad.defined() ? (long)tap_grad.numel() : 0L, tap_grad.defined() ? ptr<int32_t>(tap_shared) : nullptr,
+                  (tap_grad.defined() && tap_shared.defined()) ? (long)tap_shared.numel() : 0L,
+                  ptr(tap_grad), scope.stream);
         } else {
           FM_CALL(fm_track_loss_fused_fwd, ptr(depth), (int)frame0, (int)own_first, (int)own_end, ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), (int)f,
                   ptr(xy), ptr<uint8_t>(vis), ptr<int32_t>(seg), ptr<int32_t>(tiles), (int)ntiles, (int)pmax, (int)fmax, (int)h, (int)w, (int)kind,
@@ -1113,7 +1117,7 @@ struct TrackLossFused : public Function<TrackLossFused> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    variable_list out(24);
+    variable_list out(25);
     if (!grads[0].defined()) return out;
     const auto saved = ctx->get_saved_variables();
     const Tensor &k = saved[0], &kinv = saved[1], &ext_inv = saved[2], &acc = saved[3];
@@ -1382,13 +1386,13 @@ static Tensor flow_loss_op(const Tensor& depth, const Tensor& k, const Tensor& k
                            const Tensor& flow_bwd, const Tensor& mask_fwd, const Tensor& mask_bwd, const Tensor& norm, const OptTensor& packed,
                            int64_t kind, double delta, const OptSink& sink, int64_t items, const OptTensor& acc_work, const OptTensor& exp_avg,
                            const OptTensor& exp_avg_sq, const OptTensor& touched, int64_t adam_step, std::vector<double> adam,
-                           const OptTensor& adam_flag, const OptTensor& tap_mask, const OptTensor& tap_chunk_base, const OptTensor& tap_depth,
+                           const OptTensor& adam_flag, const OptTensor& tap_chunk_base, const OptTensor& tap_pixel, const OptTensor& tap_depth,
                            const OptTensor& tap_stale) {
   auto s = sink_of(sink);
   // park dL/ddepth in the sink only when both pose tensors come from the fit that armed it: that node then runs after this one
   const bool park = s && s->fit_node != nullptr && reaches(t_fwd.grad_fn(), s->fit_node, 3) && reaches(t_bwd.grad_fn(), s->fit_node, 3);
   return FlowLossFused::apply(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, s, items, acc_work,
-                              exp_avg, exp_avg_sq, touched, adam_step, adam, adam_flag, tap_mask, tap_chunk_base, tap_depth, tap_stale,
+                              exp_avg, exp_avg_sq, touched, adam_step, adam, adam_flag, tap_chunk_base, tap_pixel, tap_depth, tap_stale,
                               at::GradMode::is_enabled(), park);
 }
 static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& ext, const Tensor& xy,
@@ -1396,13 +1400,14 @@ static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, con
                                                         std::vector<int64_t> counts, double weight, int64_t kind, double delta,
                                                         const OptSink& sink, int64_t frame0, const OptTensor& plan_pixels,
                                                         const OptTensor& plan_first, const OptTensor& plan_entries, const OptTensor& plan_weights,
-                                                        const OptTensor& anchor, const OptTensor& tap_slot, const OptTensor& tap_depth, bool offer_taps) {
+                                                        const OptTensor& anchor, const OptTensor& tap_slot, const OptTensor& tap_depth, const OptTensor& tap_shared,
+                                                        bool offer_taps) {
   auto s = sink_of(sink);
   // `anchor`: the tensor whose history leads to the fit (the local extrinsics under frame sharding, where `ext` is the gathered chain)
   const Tensor& from = (anchor.has_value() && anchor->defined()) ? *anchor : ext;
   const bool park = s && s->fit_node != nullptr && reaches(from.grad_fn(), s->fit_node, 3);
   auto out = TrackLossFused::apply(depth, k, kinv, ext, xy, vis, seg, blocks, tiles, counts, weight, kind, delta, s, frame0, plan_pixels, plan_first,
-                                   plan_entries, plan_weights, tap_slot, tap_depth, offer_taps, at::GradMode::is_enabled(), park);
+                                   plan_entries, plan_weights, tap_slot, tap_depth, tap_shared, offer_taps, at::GradMode::is_enabled(), park);
   return {out[0], out[1], out[2]};
 }
 // would a flow loss fed these poses hand its dL/ddepth to the sink's fit (i.e. is the in-pass Adam update possible)?
@@ -1487,13 +1492,14 @@ TORCH_LIBRARY(flowmap_amd, m) {
   m.def(
       "flow_loss(Tensor depth, Tensor k, Tensor kinv, Tensor t_fwd, Tensor t_bwd, Tensor flow_fwd, Tensor flow_bwd, Tensor mask_fwd, Tensor mask_bwd, "
       "Tensor norm, Tensor? packed, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int items, Tensor? acc_work, "
-      "Tensor? exp_avg, Tensor? exp_avg_sq, Tensor? touched, int adam_step, float[] adam, Tensor? adam_flag, Tensor? tap_mask=None, "
-      "Tensor? tap_chunk_base=None, Tensor? tap_depth=None, Tensor? tap_stale=None) -> Tensor",
+      "Tensor? exp_avg, Tensor? exp_avg_sq, Tensor? touched, int adam_step, float[] adam, Tensor? adam_flag, Tensor? tap_chunk_base=None, "
+      "Tensor? tap_pixel=None, Tensor? tap_depth=None, Tensor? tap_stale=None) -> Tensor",
       fmt::flow_loss_op);
   m.def(
       "track_loss(Tensor depth, Tensor k, Tensor kinv, Tensor ext, Tensor xy, Tensor vis, Tensor seg, Tensor blocks, Tensor tiles, int[] counts, "
       "float weight, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int frame0, Tensor? plan_pixels, Tensor? plan_first, "
-      "Tensor? plan_entries, Tensor? plan_weights, Tensor? anchor, Tensor? tap_slot=None, Tensor? tap_depth=None, bool offer_taps=False) "
+      "Tensor? plan_entries, Tensor? plan_weights, Tensor? anchor, Tensor? tap_slot=None, Tensor? tap_depth=None, Tensor? tap_shared=None, "
+      "bool offer_taps=False) "
       "-> (Tensor, Tensor, Tensor)",
       fmt::track_loss_op);
   m.def("leading_frames(Tensor x, int count, __torch__.torch.classes.flowmap_amd.DepthSink? sink) -> Tensor", fmt::leading_frames_op);

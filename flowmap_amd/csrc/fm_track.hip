@@ -57,10 +57,16 @@ struct TrackGeom {
   int height, width;
 };
 
+// The work-space record of a track point (fm_pose.h: kTrackWs floats) is stored per (segment, frame) block as kTrackWs PLANES of p_count
+// values — component c of point p of the block starting at point index `block` sits at (block·kTrackWs + c·p_count + p) — so that a wave's
+// stores and loads of one component are contiguous (as records of 36 bytes every store instruction touched 18 lines).
+__device__ __forceinline__ float* ws_plane(float* ws, size_t block, int p_count, int p) { return ws + block * kTrackWs + p; }
+__device__ __forceinline__ const float* ws_plane(const float* ws, size_t block, int p_count, int p) { return ws + block * kTrackWs + p; }
+
 // ---------------------------------------------------------------- track_points ------
 // One track point of one frame: ws[idx] = [xyz | X_w | h], flag[idx]; returns the flag, X_w in xw.
 __device__ __forceinline__ bool track_sample(const TrackGeom& g, const float* depth, int depth_frame0, const float* kinv, const float* ext,
-                                             int frame, size_t idx, float* ws, uint8_t* flag, float xw[3]) {
+                                             int frame, size_t idx, int p_count, int p, float* ws, uint8_t* flag, float xw[3]) {
   const float2 q = reinterpret_cast<const float2*>(g.xy)[idx];
   Mat3 ki;
   Pose e;
@@ -85,10 +91,11 @@ __device__ __forceinline__ bool track_sample(const TrackGeom& g, const float* de
     hh[2] += z * t.w[k];
   }
   apply_pose(e, xyz, xw);
-  float* o = ws + idx * kTrackWs;
-  o[0] = xyz[0]; o[1] = xyz[1]; o[2] = xyz[2];
-  o[3] = xw[0];  o[4] = xw[1];  o[5] = xw[2];
-  o[6] = hh[0];  o[7] = hh[1];  o[8] = hh[2];
+  float* o = ws_plane(ws, idx - p, p_count, p);
+  const size_t pc = (size_t)p_count;
+  o[0] = xyz[0]; o[pc] = xyz[1]; o[2 * pc] = xyz[2];
+  o[3 * pc] = xw[0];  o[4 * pc] = xw[1];  o[5 * pc] = xw[2];
+  o[6 * pc] = hh[0];  o[7 * pc] = hh[1];  o[8 * pc] = hh[2];
   const bool inside = q.x >= 0.f && q.y >= 0.f && q.x < 1.f && q.y < 1.f;
   const bool live = g.vis[idx] != 0 && inside;
   flag[idx] = live ? 1 : 0;
@@ -102,13 +109,15 @@ __device__ __forceinline__ bool track_sample(const TrackGeom& g, const float* de
 // (clamped point); `store` masks the lanes beyond the segment's points.  Same arithmetic per item as track_sample (a tap outside
 // the image contributes an exact zero instead of being skipped).
 // tap_slot / tap_depth (fm_track_loss_fused_fwd_taps): the four tap depths of point idx come from the compact tap image the flow pass
-// leaves behind — tap_depth[tap_slot[4·idx + k]]; slot -1: a tap that contributes nothing; slot <= -2: read the depth image after all
-// (a pixel another operator updates after the flow pass) — instead of four cold lines of the depth images.
+// leaves behind — tap_depth[rank], rank = the low 30 bits of tap_slot[4·idx + k] (bit 30: the pixel is shared with another track point);
+// slot -1: a tap that contributes nothing; slot <= -2: read the depth image after all (a pixel another operator updates after the flow
+// pass) — instead of four cold lines of the depth images.
+constexpr int kTapRank = 0x3fffffff, kTapShared = 0x40000000;
 template <int N>
 __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const float* depth, int depth_frame0, const float* kinv, const float* ext,
-                                                  const int (&frame)[N], const size_t (&idx)[N], const bool (&want)[N], bool store, float* ws,
-                                                  uint8_t* flag, float (&xw)[N][3], bool (&live)[N], const int32_t* tap_slot = nullptr,
-                                                  const float* tap_depth = nullptr) {
+                                                  const int (&frame)[N], const size_t (&idx)[N], const bool (&want)[N], bool store, int p_count,
+                                                  int p, float* ws, uint8_t* flag, float (&xw)[N][3], bool (&live)[N],
+                                                  const int32_t* tap_slot = nullptr, const float* tap_depth = nullptr) {
   float2 q[N];
   uint8_t vis[N];
 #pragma unroll
@@ -131,11 +140,26 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
       const float* d = depth + (size_t)(frame[n] - depth_frame0) * g.height * g.width;
       const int x1 = min(t[n].x0 + 1, g.width - 1), y1 = min(t[n].y0 + 1, g.height - 1);  // clamped reads; masked by in[] below
       const int a[4] = {t[n].y0 * g.width + t[n].x0, t[n].y0 * g.width + x1, y1 * g.width + t[n].x0, y1 * g.width + x1};
-      if (tap_slot != nullptr) {
+      if (tap_depth != nullptr) {
         const int4 s4 = reinterpret_cast<const int4*>(tap_slot)[idx[n]];
         const int sl[4] = {s4.x, s4.y, s4.z, s4.w};
+        // the two taps of an image row are neighbouring pixels, hence neighbouring ranks: one 8-byte load per row (the image is padded by one value)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) z[n][k] = sl[k] >= 0 ? tap_depth[sl[k]] : (sl[k] < -1 ? d[a[k]] : 0.f);
+        for (int r = 0; r < 2; ++r) {
+          const int sa = sl[2 * r], sb = sl[2 * r + 1];
+          if (sa < -1 || sb < -1) {  // (a pixel another operator updates after the flow pass: read the depth image)
+            z[n][2 * r] = sa >= 0 ? tap_depth[sa & kTapRank] : (sa < -1 ? d[a[2 * r]] : 0.f);
+            z[n][2 * r + 1] = sb >= 0 ? tap_depth[sb & kTapRank] : (sb < -1 ? d[a[2 * r + 1]] : 0.f);
+          } else if (sa >= 0) {
+            float2 v;
+            __builtin_memcpy(&v, tap_depth + (sa & kTapRank), sizeof(float2));
+            z[n][2 * r] = v.x;
+            z[n][2 * r + 1] = sb >= 0 ? v.y : 0.f;
+          } else {
+            z[n][2 * r] = 0.f;
+            z[n][2 * r + 1] = sb >= 0 ? tap_depth[sb & kTapRank] : 0.f;
+          }
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) z[n][k] = d[a[k]];
@@ -171,10 +195,11 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
     live[n] = store && vis[n] != 0 && inside;
     if (store) {
 #ifndef FM_TRACK_SKIP_WS  // (timing experiments: what the nine strided stores cost)
-      float* o = ws + idx[n] * kTrackWs;
-      o[0] = xyz[0]; o[1] = xyz[1]; o[2] = xyz[2];
-      o[3] = xw[n][0]; o[4] = xw[n][1]; o[5] = xw[n][2];
-      o[6] = hh[0];  o[7] = hh[1];  o[8] = hh[2];
+      float* o = ws_plane(ws, idx[n] - p, p_count, p);
+      const size_t pc = (size_t)p_count;
+      o[0] = xyz[0]; o[pc] = xyz[1]; o[2 * pc] = xyz[2];
+      o[3 * pc] = xw[n][0]; o[4 * pc] = xw[n][1]; o[5 * pc] = xw[n][2];
+      o[6 * pc] = hh[0];  o[7 * pc] = hh[1];  o[8 * pc] = hh[2];
 #endif
       flag[idx[n]] = live[n] ? 1 : 0;
     }
@@ -188,7 +213,7 @@ __global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const fl
   const int p = blockIdx.y * blockDim.x + threadIdx.x;
   if (p >= p_count) return;
   float xw[3];
-  track_sample(g, depth, depth_frame0, kinv, ext, start + fl, (size_t)off + (size_t)fl * p_count + p, ws, flag, xw);
+  track_sample(g, depth, depth_frame0, kinv, ext, start + fl, (size_t)off + (size_t)fl * p_count + p, p_count, p, ws, flag, xw);
 }
 
 // Per frame: the target-role constants (au, av, c) of track_target (fm_pose.h).
@@ -331,7 +356,9 @@ struct TrackSampling {
   const float* kinv;
   int depth_frame0, own_first, own_end;  // frames [own_first, own_end) are sources on this rank (frame sharding)
   const int32_t* tap_slot;  // (total, 4) or null: where the compact tap image holds each tap's depth (track_sample_many)
-  const float* tap_depth;
+  const float* tap_depth;   // the image, or null: sample the depth images
+  float* tap_grad;          // (M) or null: the epilogue stores the unscaled dL/ddepth of every tap that belongs to ONE track point straight
+                            // into the compact gradient (the taps several points share are summed by tap_grad_kernel afterwards)
 };
 
 // Points per lane (FM_TRACK_PG): with two, a wave covers 128 points and the per-target reduction of the 14 sums (a quarter
@@ -389,8 +416,8 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
         want[t] = fs < f && frame[t] >= smp.own_first && frame[t] < smp.own_end;
         if (fs < f && !want[t] && active[q]) flag[idx[t]] = 0;  // another rank's source
       }
-      track_sample_many<kTrackTile>(g, smp.depth, smp.depth_frame0, smp.kinv, ext, frame, idx, want, active[q], ws, flag, xs, lv, smp.tap_slot,
-                                    smp.tap_depth);
+      track_sample_many<kTrackTile>(g, smp.depth, smp.depth_frame0, smp.kinv, ext, frame, idx, want, active[q], p_count, pp[q], ws, flag, xs, lv,
+                                    smp.tap_slot, smp.tap_depth);
 #pragma unroll
       for (int t = 0; t < kTrackTile; ++t) lvs[t] = lv[t] ? 1.f : 0.f;
     } else {
@@ -403,8 +430,8 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
           const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
           if (flag[is] != 0) {
             lvs[t] = 1.f;
-            const float* w9 = ws + is * kTrackWs;
-            xs[t][0] = w9[3]; xs[t][1] = w9[4]; xs[t][2] = w9[5];
+            const float* w9 = ws_plane(ws, is - p[q], p_count, p[q]);
+            xs[t][0] = w9[3 * (size_t)p_count]; xs[t][1] = w9[4 * (size_t)p_count]; xs[t][2] = w9[5 * (size_t)p_count];
           }
         }
       }
@@ -528,13 +555,31 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
           float gxyz[3];
           const float gx[3] = {(t & 1) ? gxw[q][t / 2][0].y : gxw[q][t / 2][0].x, (t & 1) ? gxw[q][t / 2][1].y : gxw[q][t / 2][1].x,
                                (t & 1) ? gxw[q][t / 2][2].y : gxw[q][t / 2][2].x};
-          float b1[21];
-          track_source_term(e, ws + is * kTrackWs, gx, b1, gxyz);
+          float b1[21], w9[kTrackWs];
+          const float* wp = ws_plane(ws, is - p[q], p_count, p[q]);
+#pragma unroll
+          for (int c = 0; c < kTrackWs; ++c) w9[c] = (c < 3 || c >= 6) ? wp[c * (size_t)p_count] : 0.f;  // (xyz and h: what the source role reads)
+          track_source_term(e, w9, gx, b1, gxyz);
 #pragma unroll
           for (int i = 0; i < 21; ++i) b[i] += b1[i];
           gws[is * 3 + 0] = gxyz[0];
           gws[is * 3 + 1] = gxyz[1];
           gws[is * 3 + 2] = gxyz[2];
+          if (smp.tap_grad != nullptr) {  // dL/ddepth at this point's own taps: w_k · <dL/dxyz, K⁻¹·[u_k, v_k, 1]> (as tap_grad_kernel sums it)
+            const float2 qq = reinterpret_cast<const float2*>(g.xy)[is];
+            const Taps tp = bilinear_taps(qq.x, qq.y, g.height, g.width);
+            const int4 s4 = reinterpret_cast<const int4*>(smp.tap_slot)[is];
+            const int sl[4] = {s4.x, s4.y, s4.z, s4.w};
+            Mat3 ki;
+            load_mat3(smp.kinv + (size_t)(start + fs) * 9, ki);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (sl[k] < 0 || (sl[k] & kTapShared)) continue;
+              float ray[3];
+              ray_dir(ki, pixel_center(tap_col(tp, k), g.width), pixel_center(tap_row(tp, k), g.height), ray);
+              smp.tap_grad[sl[k]] = tp.w[k] * (gxyz[0] * ray[0] + gxyz[1] * ray[1] + gxyz[2] * ray[2]);
+            }
+          }
         }
       }
       wave_sum_lane63_x7<21>(b);
@@ -720,10 +765,11 @@ __global__ void __launch_bounds__(256) depth_gather_kernel(const float* vectors,
 // K⁻¹(frame)·[u, v, 1]> for the m-th touched pixel — unscaled; the fused flow pass (fm_flow_loss_fused_taps) adds scale·tap_grad at the
 // pixel when it writes dL/ddepth, so the tracking loss never read-modify-writes a cold line of the gradient image.
 __global__ void __launch_bounds__(256) tap_grad_kernel(const float* vectors, const int64_t* pixels, const int32_t* first, const int32_t* entries,
-                                                       const float* weights, long count, const float* kinv, int height, int width,
-                                                       float* tap_grad) {
-  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                       const float* weights, long count, const int32_t* ranks, const float* kinv, int height,
+                                                       int width, float* tap_grad) {
+  long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= count) return;
+  if (ranks) m = ranks[m];  // (only the taps that several track points share: the others were stored by track_pairs' epilogue)
   const int64_t n = (int64_t)height * width;
   const int64_t key = pixels[m];
   const int64_t frame = key / n;
@@ -877,7 +923,7 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
   FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr));
   return track_loss_launch(const_cast<float*>(ws), const_cast<uint8_t*>(flag), xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames,
                            height, width, mapping_kind, delta, aspect_x, aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                           TrackSampling{nullptr, nullptr, 0, 0, 0, nullptr, nullptr}, (hipStream_t)stream);
+                           TrackSampling{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr}, (hipStream_t)stream);
 }
 
 int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first, int own_end, const float* kinv, const float* ext,
@@ -892,7 +938,7 @@ int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first,
   hipLaunchKernelGGL(track_targets_kernel, dim3((frames + 63) / 64), dim3(64), 0, st, ext_inv, k, frames, tgt);
   return track_loss_launch(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, mapping_kind, delta, aspect_x,
                            aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                           TrackSampling{depth, kinv, depth_frame0, own_first, own_end, nullptr, nullptr}, st);
+                           TrackSampling{depth, kinv, depth_frame0, own_first, own_end, nullptr, nullptr, nullptr}, st);
 }
 
 int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
@@ -901,19 +947,24 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
                                  uint8_t* flag, float* tgt, float* partial, double* acc, float* loss, float* scale, double* totals, float* gws,
                                  double* acc2, const int32_t* tap_slot, const float* tap_depth, const int64_t* plan_pixels,
                                  const int32_t* plan_first, const int32_t* plan_entries, const float* plan_weights, long plan_count,
-                                 float* tap_grad, void* stream) {
+                                 const int32_t* shared_ranks, long shared_count, float* tap_grad, void* stream) {
   FM_CHECK_ARG(depth && kinv && ext && ext_inv && k && xy && vis && seg && tiles && ws && flag && tgt && partial && acc && loss && scale);
   FM_CHECK_ARG(ntiles >= 1 && pmax >= 1 && fmax >= 1 && frames >= 1 && mapping_kind >= 0 && mapping_kind <= 2);
-  FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr) && (tap_slot == nullptr) == (tap_depth == nullptr));
+  FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr) && (tap_depth == nullptr || tap_slot != nullptr));
   FM_CHECK_ARG(tap_grad == nullptr || (gws && plan_pixels && plan_first && plan_entries && plan_weights && plan_count >= 0));
+  FM_CHECK_ARG(shared_ranks == nullptr || (tap_slot != nullptr && shared_count >= 0 && shared_count <= plan_count));
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(track_targets_kernel, dim3((frames + 63) / 64), dim3(64), 0, st, ext_inv, k, frames, tgt);
+  // with the list of shared taps the epilogue of track_pairs stores every other tap's gradient itself
+  float* direct = (tap_grad != nullptr && shared_ranks != nullptr) ? tap_grad : nullptr;
   const int status = track_loss_launch(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, mapping_kind, delta,
                                        aspect_x, aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                                       TrackSampling{depth, kinv, 0, 0, frames, tap_slot, tap_depth}, st);
-  if (status != FM_OK || tap_grad == nullptr || plan_count == 0) return status;
-  hipLaunchKernelGGL(tap_grad_kernel, dim3((unsigned)((plan_count + 255) / 256)), dim3(256), 0, st, gws, plan_pixels, plan_first, plan_entries,
-                     plan_weights, plan_count, kinv, height, width, tap_grad);
+                                       TrackSampling{depth, kinv, 0, 0, frames, tap_slot, tap_depth, direct}, st);
+  if (status != FM_OK || tap_grad == nullptr) return status;
+  const long count = direct ? shared_count : plan_count;
+  if (count == 0) return status;
+  hipLaunchKernelGGL(tap_grad_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, gws, plan_pixels, plan_first, plan_entries,
+                     plan_weights, count, direct ? shared_ranks : nullptr, kinv, height, width, tap_grad);
   FM_LAUNCH_STATUS();
 }
 

@@ -90,8 +90,9 @@ int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, con
  * optimisation (flowmap/tracking/__init__.py:49-70 computes them once per video), so the set of depth pixels the tracking loss
  * bilinearly samples (projection.py:266-272) — its "taps" — is STATIC: M distinct pixels, ranked in (frame, row, column) order
  * (fm_track_scatter_plan's sorted `pixels`).  fm_flow_taps describes that set to the pass that streams every depth pixel anyway:
- *   mask       (B·F·H·W/4) bytes: bit e of byte q = pixel 4q+e is a tap;
- *   chunk_base (B·F·ceil(H·W/256)) int32: rank of the first tap at or after quad 64c of frame bf (chunks of 64 quads per frame);
+ *   chunk_base (B·F·ceil(H·W/256) + 1) int32: rank of the first tap at or after quad 64c of frame bf (chunks of 64 quads per frame; the
+ *              last entry is M) — a workgroup of the pass owns a run of consecutive quads of a frame, hence the taps [base(first), base(end));
+ *   pixel      (M) int32: each tap's pixel index inside its frame (row·W + col);
  *   grad       (M) or NULL: the tracking loss's UNSCALED dL/ddepth at the taps (fm_track_loss_fused_fwd_taps' tap_grad) — the pass
  *              adds scale[0]·grad[rank] into the dL/ddepth it writes (and into the gradient its in-pass Adam update uses);
  *   scale      device scalar: the tracking loss's weight / max(count, 1) (its `scale` output), assumed to reach backward() unscaled
@@ -103,8 +104,8 @@ int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, con
  * fm_flow_loss_fused_taps = fm_flow_loss_fused (exp_avg NULL) or fm_flow_loss_fused_adam (exp_avg etc. given) with that exchange;
  * dense depth, W % 4 == 0, gradients on. */
 typedef struct fm_flow_taps {
-  const uint8_t* mask;
   const int32_t* chunk_base;
+  const int32_t* pixel;
   const float* grad;
   const float* scale;
   float* depth;
@@ -357,7 +358,7 @@ int fm_align_rigid_bwd(const float* p, const float* q, const float* w, int group
  */
 int fm_extrinsics_inverse(const float* ext, int count, float* inv, void* stream); /* general 4x4 inverse, projection.py:288 */
 
-/* Per (frame-in-segment, point): ws (total,9) = [xyz camera-space point sampled from the
+/* Per (frame-in-segment, point): ws (total·9 floats: an opaque work space between these calls) = [xyz camera-space point sampled from the
  * source frame's surface (projection.py:266-274) | X_w = E·xyz | h = Σ_taps w·z·[u,v,1]];
  * flag (total) = visibility ∧ source-in-frame (projection.py:290-294).  Per frame: tgt
  * (frames,12) = rows 0,1 of K·inv(E)[:3,:] and row 2 of inv(E) (the target-role projection
@@ -401,18 +402,21 @@ int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first,
 
 /* fm_track_loss_fused_fwd (whole video local) on the static tap set (fm_flow_taps above; loss_tracking.py:28-61 /
  * projection.py:266-272 unchanged in value):
- *   tap_slot (total,4) int32 + tap_depth (M), both or neither: tap k of track point i reads tap_depth[tap_slot[4i+k]] — the compact
- *     image fm_flow_loss_fused_taps left behind — instead of the depth image (slot -1: the tap contributes nothing; slot <= -2: read
- *     `depth` after all);
+ *   tap_slot (total,4) int32: tap k of track point i is the tap of rank (tap_slot[4i+k] & 0x3fffffff); bit 30: another track point shares
+ *     the pixel; -1: the tap contributes nothing; <= -2: the pixel is updated by another operator after the flow pass;
+ *   tap_depth (M + 1 readable) or NULL: with it, the tap depths are read from the compact image fm_flow_loss_fused_taps left behind —
+ *     tap_depth[rank] — instead of the depth image (slots <= -2 read `depth` after all);
  *   tap_grad (M) out or NULL, with the plan of fm_track_scatter_plan sorted as fm_depth_gather takes it (plan_count = M): the UNSCALED
- *     dL/ddepth of the tracking loss at each tap, for the `grad` member of fm_flow_taps (needs gws). */
+ *     dL/ddepth of the tracking loss at each tap, for the `grad` member of fm_flow_taps (needs gws).  shared_ranks (shared_count) int32 or
+ *     NULL: the ranks of the taps with more than one plan entry — with the list (and tap_slot) the pair kernel stores the gradient of
+ *     every other tap itself and only these are summed from the plan; without it all M are. */
 int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
                                  const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* tiles, int ntiles, int pmax, int fmax,
                                  int height, int width, int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* ws,
                                  uint8_t* flag, float* tgt, float* partial, double* acc, float* loss, float* scale, double* totals, float* gws,
                                  double* acc2, const int32_t* tap_slot, const float* tap_depth, const int64_t* plan_pixels,
                                  const int32_t* plan_first, const int32_t* plan_entries, const float* plan_weights, long plan_count,
-                                 float* tap_grad, void* stream);
+                                 const int32_t* shared_ranks, long shared_count, float* tap_grad, void* stream);
 /* grad_depth[pixels[m]] += scale[0]·(plus − minus)·tap_grad[m] for the M taps (plus / minus: device scalars, NULL = 0); no memory is
  * touched when the factor is 0.  The correction of the tap exchange when the tracking loss's upstream gradient (plus) differs from
  * the factor the flow pass's copy of it was delivered with (minus), and the plain scatter (minus NULL) when nothing was delivered. */

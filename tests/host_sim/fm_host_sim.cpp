@@ -136,14 +136,14 @@ int fm_flow_loss_fused_adam(float* depth, const float* k, const float* kinv, con
   return 0;
 }
 
-// The tap exchange, serially: the full gradient first, then every pixel in (frame, pixel) order — its rank among the taps is a running
-// count, checked against chunk_base at every 64-quad chunk (the table the device kernel relies on).
+// The tap exchange, serially: the full gradient first, then every tap in rank order — frame by frame through chunk_base, whose entries are
+// checked against the pixel list (the table the device kernel relies on to find a workgroup's run of taps).
 int fm_flow_loss_fused_taps(float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd, const float* flow_fwd,
                             const float* flow_bwd, const float* mask_fwd, const float* mask_bwd, const float* packed, const float* scale,
                             int batch, int frames, int height, int width, int mapping_kind, float delta, float ax, float ay,
                             float* grad_depth, double* acc, int items, const fm_flow_taps* taps, float* exp_avg, float* exp_avg_sq,
                             const uint8_t* touched, long step, double lr, double beta1, double beta2, double eps, void* stream) {
-  if (!taps || !taps->mask || !taps->chunk_base || !scale || !grad_depth || width % 4 != 0 || (taps->grad && !taps->scale)) return 1;
+  if (!taps || !taps->chunk_base || !taps->pixel || !scale || !grad_depth || width % 4 != 0 || (taps->grad && !taps->scale)) return 1;
   if (exp_avg && (!exp_avg_sq || !touched || step < 1)) return 1;
   if (!exp_avg && (exp_avg_sq || touched)) return 1;
   const size_t n = (size_t)height * width, total = (size_t)batch * frames * n;
@@ -151,32 +151,31 @@ int fm_flow_loss_fused_taps(float* depth, const float* k, const float* kinv, con
   if (fm_flow_loss_fused(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, packed, scale, batch, frames, height, width,
                          mapping_kind, delta, ax, ay, g.data(), acc, items, stream) != 0)
     return 2;
-  const AdamCoef c = exp_avg ? adam_coefficients((double)step, lr, beta1, beta2, eps, 0.0) : AdamCoef{};
   const size_t quads = n / 4, chunks = (quads + 63) / 64;
   const float ts = taps->grad ? taps->scale[0] : 0.f;
-  int rank = 0;
-  for (size_t bf = 0; bf < (size_t)batch * frames; ++bf)
-    for (size_t q = 0; q < quads; ++q) {
-      if (q % 64 == 0 && taps->chunk_base[bf * chunks + q / 64] != rank) return 2;  // the rank table does not match the mask
-      const unsigned bits = taps->mask[bf * quads + q];
-      for (int e = 0; e < 4; ++e) {
-        const size_t i = (bf * quads + q) * 4 + e;
-        const bool tap = (bits >> e) & 1u;
-        if (tap && taps->grad) g[i] += ts * taps->grad[rank];
-        if (exp_avg) {
-          if ((touched[i / 4] >> (i % 4)) & 1u) grad_depth[i] = g[i];
-          else adam_update(c, depth[i], g[i], exp_avg[i], exp_avg_sq[i]);
-        } else {
-          grad_depth[i] = g[i];
-        }
-        if (tap) {
-          if (taps->depth) {
-            if (taps->stale && !exp_avg && std::memcmp(&taps->depth[rank], &depth[i], sizeof(float)) != 0) *taps->stale = 1;
-            taps->depth[rank] = depth[i];
-          }
-          ++rank;
-        }
+  std::vector<size_t> tap_at;  // flat pixel index of every tap, in rank order
+  for (size_t bf = 0; bf < (size_t)batch * frames; ++bf) {
+    for (size_t c = 0; c < chunks; ++c)
+      for (int t = taps->chunk_base[bf * chunks + c]; t < taps->chunk_base[bf * chunks + c + 1]; ++t) {
+        if ((size_t)t != tap_at.size() || taps->pixel[t] < 0 || (size_t)taps->pixel[t] / 256 != c) return 2;  // the rank table does not match the pixel list
+        tap_at.push_back(bf * n + (size_t)taps->pixel[t]);
       }
+  }
+  if (taps->grad)
+    for (size_t t = 0; t < tap_at.size(); ++t) g[tap_at[t]] += ts * taps->grad[t];
+  const AdamCoef c = exp_avg ? adam_coefficients((double)step, lr, beta1, beta2, eps, 0.0) : AdamCoef{};
+  for (size_t i = 0; i < total; ++i) {
+    if (exp_avg) {
+      if ((touched[i / 4] >> (i % 4)) & 1u) grad_depth[i] = g[i];
+      else adam_update(c, depth[i], g[i], exp_avg[i], exp_avg_sq[i]);
+    } else {
+      grad_depth[i] = g[i];
+    }
+  }
+  if (taps->depth)
+    for (size_t t = 0; t < tap_at.size(); ++t) {
+      if (taps->stale && !exp_avg && std::memcmp(&taps->depth[t], &depth[tap_at[t]], sizeof(float)) != 0) *taps->stale = 1;
+      taps->depth[t] = depth[tap_at[t]];
     }
   return 0;
 }
@@ -1281,7 +1280,7 @@ static int sim_track_points(const float* depth, int depth_frame0, const float* k
         float z = d[tr * width + tc];
         if (tap_slot) {
           const int sl = tap_slot[idx * 4 + k];
-          z = sl >= 0 ? tap_depth[sl] : (sl < -1 ? z : 0.f);
+          z = sl >= 0 ? tap_depth[sl & 0x3fffffff] : (sl < -1 ? z : 0.f);
         }
         for (int a = 0; a < 3; ++a) xyz[a] += (ray[a] * z) * t.w[k];
         hh[0] += z * ut * t.w[k];
@@ -1395,8 +1394,20 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
                                  int height, int width, int kind, float delta, float ax, float ay, float weight, float* ws, uint8_t* flag,
                                  float* tgt, float* partial, double* acc, float* loss, float* scale, double* totals, float* gws, double* acc2,
                                  const int32_t* tap_slot, const float* tap_depth, const int64_t* plan_pixels, const int32_t* plan_first,
-                                 const int32_t* plan_entries, const float* plan_weights, long plan_count, float* tap_grad, void* stream) {
-  if ((tap_slot == nullptr) != (tap_depth == nullptr)) return 1;
+                                 const int32_t* plan_entries, const float* plan_weights, long plan_count, const int32_t* shared_ranks,
+                                 long shared_count, float* tap_grad, void* stream) {
+  if (tap_depth != nullptr && tap_slot == nullptr) return 1;
+  if (shared_ranks != nullptr && (tap_slot == nullptr || shared_count < 0 || shared_count > plan_count)) return 1;
+  if (shared_ranks != nullptr && tap_grad != nullptr) {  // the list must name exactly the taps with more than one plan entry, and the slots say so too
+    long seen = 0;
+    for (long m = 0; m < plan_count; ++m)
+      if (plan_first[m + 1] - plan_first[m] > 1) {
+        if (seen >= shared_count || shared_ranks[seen] != (int32_t)m) return 2;
+        ++seen;
+      }
+    if (seen != shared_count) return 2;
+  }
+  if (tap_depth == nullptr) tap_slot = nullptr;  // (sampling from the depth images)
   if (tap_grad && !(gws && plan_pixels && plan_first && plan_entries && plan_weights && plan_count >= 0)) return 1;
   std::vector<int32_t> blocks;
   for (int tile = 0; tile < ntiles; ++tile) {

@@ -191,6 +191,14 @@ def test_softmin_intrinsics():
     assert_close(k[0], g["intrinsics"], TOL, what="intrinsics")
     assert_close_or_reference_gap(d.grad[0], g["f64_g_depth"][0], g["g_depth"][0], TOL, what="g_depth")
     assert_close_or_reference_gap(w.grad, g["f64_g_weights"], g["g_weights"], TOL, what="g_weights")
+    # the oracle in fp64 IS the reference module in fp64 (the truth tests/test_install_reference.py measures the softmin sweep against)
+    d64 = t(g["depth"])[None].double().requires_grad_(True)
+    w64 = t(g["weights"]).double().requires_grad_(True)
+    k64 = orc.softmin_intrinsics(d64, w64, t(g["bwd"]).double(), t(g["candidates"]).double(), t(g["indices"]), (h, wd))
+    (k64[0] * t(g["cot"]).double()).sum().backward()
+    assert_close(k64[0], g["f64_intrinsics"], 1e-9, what="fp64 intrinsics")
+    assert_close(d64.grad[0], g["f64_g_depth"][0], 1e-7, what="fp64 g_depth")
+    assert_close(w64.grad, g["f64_g_weights"], 1e-7, what="fp64 g_weights")
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])

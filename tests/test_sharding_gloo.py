@@ -39,6 +39,14 @@ def _focal_close(got, ref):
     assert err <= bound, f"g_focal: {float(got):.6e} vs {float(ref['g_focal']):.6e} (bound {bound:.2e})"
 
 
+def _shard_close(got, truth, ref32, what):
+    """A shard's slice of a gradient against the fp64 oracle's: 1e-4, or twice the gap the reference path's own fp32 evaluation (the fp32
+    oracle) has on the same slice — measured here (these are i.i.d. inputs: conftest.assert_close_or_reference_gap)."""
+    from conftest import assert_close_or_reference_gap
+
+    assert_close_or_reference_gap(got, truth, ref32, 1e-4, what=what)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -130,6 +138,7 @@ def test_two_rank_shards_match_unsharded_oracle(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), f, h, w, points, out), nprocs=world, join=True)
     depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
     ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, dtype=torch.float64)
+    ref32 = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, dtype=torch.float32)
     res = [torch.load(f"{out}.{r}") for r in range(world)]
     for r in res:
         assert_close(r["loss"], ref["total"], 1e-5, what="global loss")
@@ -137,7 +146,7 @@ def test_two_rank_shards_match_unsharded_oracle(tmp_path):
         lo, hi = r["frames"]
         a, b = r["pairs"]
         assert_close(r["g_depth"], ref["g_depth"][lo : hi + 1], 1e-4, what="g_depth shard (halo summed)")
-        assert_close(r["g_w"], ref["g_wlogit"][a:b], 3e-4, what="g_wlogit shard")
+        _shard_close(r["g_w"], ref["g_wlogit"][a:b], ref32["g_wlogit"][a:b], "g_wlogit shard")
 
 
 @pytest.mark.timeout(300)
@@ -157,6 +166,7 @@ def test_sharded_tracking_matches_unsharded_oracle(tmp_path, world):
     depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
     otracks = orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5)
     ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float64)
+    ref32 = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float32)
     assert float(ref["loss_tracking"]) > 0
     res = [torch.load(f"{out}.{r}") for r in range(world)]
     for r in res:
@@ -165,8 +175,8 @@ def test_sharded_tracking_matches_unsharded_oracle(tmp_path, world):
         _focal_close(r["g_focal"], ref)
         lo, hi = r["frames"]
         a, b = r["pairs"]
-        assert_close(r["g_depth"], ref["g_depth"][lo : hi + 1], 2e-4, what="g_depth shard (halo summed)")
-        assert_close(r["g_w"], ref["g_wlogit"][a:b], 5e-4, what="g_wlogit shard")
+        _shard_close(r["g_depth"], ref["g_depth"][lo : hi + 1], ref32["g_depth"][lo : hi + 1], "g_depth shard (halo summed)")
+        _shard_close(r["g_w"], ref["g_wlogit"][a:b], ref32["g_wlogit"][a:b], "g_wlogit shard")
 
 
 @pytest.mark.timeout(300)
@@ -482,13 +492,14 @@ def test_early_halo_exchange_gives_the_same_gradients(tmp_path, with_tracks):
     depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
     otracks = orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5) if with_tracks else None
     ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float64)
+    ref32 = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float32)
     for rank in range(world):
         got = torch.load(f"{out}.{rank}")
         assert got["modes"] == [False, False, True, True, True], got["modes"]
         lo, hi = got["frames"]
         for step, (total, g_depth, g_focal) in enumerate(got["history"]):
             assert_close(total, ref["total"], 1e-5, what=f"global loss, step {step}")
-            assert_close(g_depth, ref["g_depth"][lo : hi + 1], 2e-4, what=f"g_depth of rank {rank} (halo summed), step {step}")
+            _shard_close(g_depth, ref["g_depth"][lo : hi + 1], ref32["g_depth"][lo : hi + 1], f"g_depth of rank {rank} (halo summed), step {step}")
             _focal_close(g_focal, ref)
         for early_step in (2, 3, 4):  # against the one-shot exchange of step 1: the same sums in another order
             assert_close(got["history"][early_step][1], got["history"][1][1], 1e-5, abs_=1e-9, what=f"early vs one-shot exchange, rank {rank}")

@@ -2,9 +2,9 @@
 # round 4, third GPU call: the tap exchange with its loads requested ahead (flow pass), where a wave of track_pairs spends its time with
 # and without the compact tap image (phase clocks), kernel tables of a C2 step.
 cd "${GRAFT_REPO_ROOT:-.}"; REPO=$PWD
-out=gpurun_out/r04c; mkdir -p $out
+out=gpurun_out/r04d; mkdir -p $out
 export TMPDIR=/tmp
-( time timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -rf -k "tap or in_pass or adam or flow_fused" ) > $out/pytest_parity.log 2>&1; tail -4 $out/pytest_parity.log
+( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -rf ) > $out/pytest_parity.log 2>&1; tail -4 $out/pytest_parity.log
 b() { name=$1; shift; timeout 400 python3 bench.py --steps 100 --warmup 20 --cpu-frames 0 --sustained-steps 0 "$@" > $out/bench_$name.json 2> $out/bench_$name.err; python3 - "$out/bench_$name.json" "$name" <<'PY'
 import json, sys
 try:
