@@ -266,14 +266,6 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
     }
   }
   __syncthreads();
-  if constexpr (TAPS) {
-    if (p.tap_grad) {
-      const float ts = p.tap_scale[0];
-      float* tap_g = reinterpret_cast<float*>(tap_g4);
-      for (int t = tap_first + (int)threadIdx.x; t < tap_end; t += blockDim.x) tap_g[p.tap_pixel[t] - 4 * block_quad0] = ts * p.tap_grad[t];
-      __syncthreads();
-    }
-  }
 
   const size_t pair_f = (size_t)b * (p.frames - 1) + f;  // pair whose earlier frame is f
   const size_t pair_b = pair_f - 1;                       // pair whose later frame is f
@@ -414,12 +406,40 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
 
   // (A depth-2 software pipeline of the loads — two QuadIn register sets, loop unrolled by
   // two, 168 VGPRs — measured 0.856 vs 0.845 ms: no gain, removed.)
+  // The tap exchange's set-up costs a workgroup two dependent round trips (its taps' pixels and gradients, then the LDS image): they are
+  // requested BEHIND the first quad's own seven loads, so that they travel together, and the image is filled while those loads are still
+  // in flight (filled before them, as the first version did, the set-up delayed every workgroup's first load: +70 us on the 0.8 ms pass).
+  QuadIn q_first = {};
+  int my_tap = -1;  // this thread's tap of the workgroup's run (the taps past 256 per workgroup, if any, are walked in loops)
+  int my_tap_pixel = 0;
+  if constexpr (TAPS) {
+    float my_tap_grad = 0.f;
+    if (tap_first + (int)threadIdx.x < tap_end) {  // (requested first: the quad's loads below are waited for one by one — the memory counter is in order)
+      my_tap = tap_first + (int)threadIdx.x;
+      my_tap_pixel = p.tap_pixel[my_tap];
+      if (p.tap_grad) my_tap_grad = p.tap_grad[my_tap];
+    }
+    const int item0 = base + (int)threadIdx.x;
+    if (item0 < items) {
+      if constexpr (PACKED) load_quad_packed(q_first, depth, packed, item0, has_fwd, has_bwd);
+      else load_quad(q_first, depth, ff, mf, fb, mb, item0, has_fwd, has_bwd);
+    }
+    my_tap_pixel -= 4 * block_quad0;
+    if (p.tap_grad) {
+      const float ts = p.tap_scale[0];
+      float* tap_g = reinterpret_cast<float*>(tap_g4);
+      if (my_tap >= 0) tap_g[my_tap_pixel] = ts * my_tap_grad;
+      for (int t = tap_first + (int)blockDim.x + (int)threadIdx.x; t < tap_end; t += blockDim.x) tap_g[p.tap_pixel[t] - 4 * block_quad0] = ts * p.tap_grad[t];
+      __syncthreads();
+    }
+  }
   for (int it = 0; it < p.iters; ++it) {
     const int item = base + it * blockDim.x + threadIdx.x;
     if (item >= items) break;
     if (VEC == 4) {
       QuadIn q = {};
-      if constexpr (PACKED) load_quad_packed(q, depth, packed, item, has_fwd, has_bwd);
+      if (TAPS && it == 0) q = q_first;
+      else if constexpr (PACKED) load_quad_packed(q, depth, packed, item, has_fwd, has_bwd);
       else load_quad(q, depth, ff, mf, fb, mb, item, has_fwd, has_bwd);
       compute_quad(q, item);
       continue;
@@ -458,7 +478,12 @@ __global__ void __launch_bounds__(256, FM_FLOW_WAVES) flow_fused_kernel(FlowPara
     if (p.tap_depth) {  // the block's taps: the depth this pass leaves at each, from the LDS image (coalesced on the tap side)
       __syncthreads();
       const float* tap_z = reinterpret_cast<const float*>(tap_z4);
-      for (int t = tap_first + (int)threadIdx.x; t < tap_end; t += blockDim.x) {
+      if (my_tap >= 0) {
+        const float znew = tap_z[my_tap_pixel];
+        if (!ADAM && p.tap_stale && __float_as_uint(p.tap_depth[my_tap]) != __float_as_uint(znew)) *p.tap_stale = 1;
+        p.tap_depth[my_tap] = znew;
+      }
+      for (int t = tap_first + (int)blockDim.x + (int)threadIdx.x; t < tap_end; t += blockDim.x) {
         const float znew = tap_z[p.tap_pixel[t] - 4 * block_quad0];
         if (!ADAM && p.tap_stale && __float_as_uint(p.tap_depth[t]) != __float_as_uint(znew)) *p.tap_stale = 1;
         p.tap_depth[t] = znew;

@@ -140,6 +140,12 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
       const float* d = depth + (size_t)(frame[n] - depth_frame0) * g.height * g.width;
       const int x1 = min(t[n].x0 + 1, g.width - 1), y1 = min(t[n].y0 + 1, g.height - 1);  // clamped reads; masked by in[] below
       const int a[4] = {t[n].y0 * g.width + t[n].x0, t[n].y0 * g.width + x1, y1 * g.width + t[n].x0, y1 * g.width + x1};
+#ifdef FM_TRACK_SKIP_SAMPLE  // (timing experiments: what the tap gathers cost)
+      if (true) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[n][k] = 1.5f;
+      } else
+#endif
       if (tap_depth != nullptr) {
         const int4 s4 = reinterpret_cast<const int4*>(tap_slot)[idx[n]];
         const int sl[4] = {s4.x, s4.y, s4.z, s4.w};
@@ -572,12 +578,24 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
             const int sl[4] = {s4.x, s4.y, s4.z, s4.w};
             Mat3 ki;
             load_mat3(smp.kinv + (size_t)(start + fs) * 9, ki);
+            float val[4];
+            bool own[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              if (sl[k] < 0 || (sl[k] & kTapShared)) continue;
               float ray[3];
               ray_dir(ki, pixel_center(tap_col(tp, k), g.width), pixel_center(tap_row(tp, k), g.height), ray);
-              smp.tap_grad[sl[k]] = tp.w[k] * (gxyz[0] * ray[0] + gxyz[1] * ray[1] + gxyz[2] * ray[2]);
+              val[k] = tp.w[k] * (gxyz[0] * ray[0] + gxyz[1] * ray[1] + gxyz[2] * ray[2]);
+              own[k] = sl[k] >= 0 && !(sl[k] & kTapShared);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {  // the two taps of an image row have neighbouring ranks: one 8-byte store
+              if (own[2 * r] && own[2 * r + 1]) {
+                const float2 v = make_float2(val[2 * r], val[2 * r + 1]);
+                __builtin_memcpy(smp.tap_grad + sl[2 * r], &v, sizeof(float2));
+              } else {
+                if (own[2 * r]) smp.tap_grad[sl[2 * r]] = val[2 * r];
+                if (own[2 * r + 1]) smp.tap_grad[sl[2 * r + 1]] = val[2 * r + 1];
+              }
             }
           }
         }
