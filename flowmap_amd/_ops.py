@@ -719,7 +719,9 @@ class FlowLossFused:
             tap_plan = None  # (frame windows / unaligned flows: the pass that reads them in place has no tap variant)
         # (verified only while the version counter still vouches for the image: after a regular update the image was simply out of date, and
         # whoever sampled it did so before that update)
-        verify = tap_plan is not None and tap_plan.sampled_now and ticket is None and tap_plan.image_valid_for(_root(depth))
+        # ... and at the first sampled step and every 64th only: the check costs the pass one more load per tap
+        verify = (tap_plan is not None and tap_plan.sampled_now and ticket is None and (tap_plan.samples == 1 or tap_plan.samples % 64 == 0)
+                  and tap_plan.image_valid_for(_root(depth)))
         taps = (None, None, None, None) if tap_plan is None else (tap_plan.chunk_base, tap_plan.pixel_in_frame, tap_plan.image, tap_plan.stale_flag if verify else None)
         offered = tap_plan is not None and sink.offers_taps()
         loss = torch_ops().flow_loss(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, int(kind), float(delta),
@@ -734,7 +736,7 @@ class FlowLossFused:
             tap_plan.sampled_now = False
             if verify:
                 capturing = depth.is_cuda and torch.cuda.is_current_stream_capturing()
-                if (tap_plan.samples == 1 or tap_plan.samples % 64 == 0) and not capturing:
+                if not capturing:
                     tap_plan.check_stale()
         if ticket is not None:  # the operator accepted the arguments and launched: only now does the optimiser's state advance
             optimizer.commit_in_pass(ticket)

@@ -46,6 +46,7 @@ __device__ long long fm_track_clock_buffer[kTrackClockWaves][kTrackClockSlots];
 #define FM_TCLK(var)
 #define FM_TCLK_ADD(slot, a, b)
 #endif
+constexpr unsigned kXcds = 8;  // accelerator complex dies of an MI355X, each with its own L2 (MI355X_MICROARCH.md)
 constexpr int kTrackTile = FM_TRACK_TILE;  // source frames per thread (registers: 2 x 3 x kTrackTile floats)
 __host__ __device__ constexpr size_t track_partial_stride(int fmax) { return (size_t)fmax * kTrackSums + kTrackTile * 21; }
 
@@ -381,7 +382,7 @@ constexpr int kTrackAhead = FM_TRACK_AHEAD;  // target frames whose (visibility,
 template <int KIND, bool GRAD>
 __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(TrackGeom g, const int32_t* tiles, float* ws, uint8_t* flag,
                                                             const float* ext, const float* tgt, float delta, float ax, float ay, int fmax,
-                                                            float* partial, float* gws, TrackSampling smp) {
+                                                            float* partial, float* gws, TrackSampling smp, int ntiles, int pgroups) {
 #ifdef FM_TRACK_LDS_PAD  // (experiments: fewer resident waves per CU)
   __shared__ int lds_pad[FM_TRACK_LDS_PAD / 4];
   if (fmax < 0) lds_pad[threadIdx.x] = 1;
@@ -391,15 +392,22 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
 #endif
   FM_TCLK(c_begin);
   const float inv_delta = KIND == kHuber ? 1.0f / delta : 0.f;
+  // Workgroups go to the eight XCDs round-robin in launch order, and every XCD has its own L2: consecutive launch indices are dealt to
+  // the SAME XCD's share of the (tile, point group) list — tile-major, tiles in frame order — so that an XCD's waves sample neighbouring
+  // frames (their taps: a few hundred KB of the compact tap image / of the depth images per frame) instead of all of them.
+  const unsigned work_items = gridDim.x, per_xcd = (work_items + kXcds - 1) / kXcds;
+  const unsigned work = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+  if (work >= (unsigned)(ntiles * pgroups)) return;
+  const unsigned tile_index = work / (unsigned)pgroups, group_index = work % (unsigned)pgroups;
   // this wave's slice of the partial-sum workspace: [fmax][14] target role, then [kTrackTile][21] source role
-  float* mine = partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * track_partial_stride(fmax);
-  const int sg = tiles[blockIdx.x * 2], fs0 = tiles[blockIdx.x * 2 + 1];
+  float* mine = partial + (size_t)work * track_partial_stride(fmax);
+  const int sg = tiles[tile_index * 2], fs0 = tiles[tile_index * 2 + 1];
   const int start = g.seg[sg * 4], f = g.seg[sg * 4 + 1], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
   int p[kTrackPG], pp[kTrackPG];
   bool active[kTrackPG];
 #pragma unroll
   for (int q = 0; q < kTrackPG; ++q) {
-    p[q] = (blockIdx.y * kTrackPG + q) * blockDim.x + threadIdx.x;
+    p[q] = (group_index * kTrackPG + q) * blockDim.x + threadIdx.x;
     active[q] = p[q] < p_count;
     pp[q] = active[q] ? p[q] : p_count - 1;  // clamped: loads stay in bounds, results are masked
   }
@@ -613,7 +621,7 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
     clk[4] = c_end - c_epi;
     clk[5] = c_end - c_begin;
     clk[6] = f;
-    const unsigned wid = blockIdx.x * gridDim.y + blockIdx.y;
+    const unsigned wid = work;
     if (threadIdx.x == 0 && wid < (unsigned)kTrackClockWaves) {
 #pragma unroll
       for (int i = 0; i < kTrackClockSlots; ++i) fm_track_clock_buffer[wid][i] = clk[i];
@@ -912,15 +920,16 @@ static int track_loss_launch(float* ws, uint8_t* flag, const float* xy, const ui
                              float* loss, float* scale, double* totals, float* gws, double* acc2, TrackSampling smp, hipStream_t st) {
   TrackGeom g{xy, vis, seg, nullptr, height, width};
   const int pgroups = (pmax + kWave * kTrackPG - 1) / (kWave * kTrackPG);  // (the caller sized `partial` for groups of kWave points: enough)
-  const dim3 grid(ntiles, pgroups);
+  const unsigned items = (unsigned)ntiles * (unsigned)pgroups;
+  const dim3 grid(((items + kXcds - 1) / kXcds) * kXcds);  // (a multiple of the XCD count: the kernel deals launch indices to XCD shares)
 #define FM_TRACK_LAUNCH(K)                                                                                                          \
   do {                                                                                                                               \
     if (gws)                                                                                                                         \
       hipLaunchKernelGGL((track_pairs_kernel<K, true>), grid, dim3(kWave), 0, st, g, tiles, ws, flag, ext, tgt, delta,              \
-                         aspect_x, aspect_y, fmax, partial, gws, smp);                                                               \
+                         aspect_x, aspect_y, fmax, partial, gws, smp, ntiles, pgroups);                                              \
     else                                                                                                                             \
       hipLaunchKernelGGL((track_pairs_kernel<K, false>), grid, dim3(kWave), 0, st, g, tiles, ws, flag, ext, tgt, delta,             \
-                         aspect_x, aspect_y, fmax, partial, gws, smp);                                                               \
+                         aspect_x, aspect_y, fmax, partial, gws, smp, ntiles, pgroups);                                              \
   } while (0)
   if (mapping_kind == kHuber) FM_TRACK_LAUNCH(kHuber);
   else if (mapping_kind == kL1) FM_TRACK_LAUNCH(kL1);

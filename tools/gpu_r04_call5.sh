@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, fifth GPU call: the tap exchange's third form (set-up behind the first quad's loads, paired stores), where the prologue of track_pairs goes
 cd "${GRAFT_REPO_ROOT:-.}"; REPO=$PWD
-out=gpurun_out/r04e; mkdir -p $out
+out=gpurun_out/r04f; mkdir -p $out
 export TMPDIR=/tmp
 ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -rf -k "tap or track or in_pass or adam" ) > $out/pytest_parity.log 2>&1; tail -4 $out/pytest_parity.log
 b() { name=$1; shift; timeout 400 python3 bench.py --steps 100 --warmup 20 --cpu-frames 0 --sustained-steps 0 "$@" > $out/bench_$name.json 2> $out/bench_$name.err; python3 - "$out/bench_$name.json" "$name" <<'PY'
@@ -17,8 +17,8 @@ PY
 }
 b c2_exchange --config c2
 b c2_round3 --config c2 --no-tap-exchange
-b c2_exchange_b --config c2
-b c2_round3_b --config c2 --no-tap-exchange
+b small_exchange --config c2 --height 180 --width 240
+b small_round3 --config c2 --height 180 --width 240 --no-tap-exchange
 for v in exchange round3; do
   extra=""; [ $v = round3 ] && extra="--no-tap-exchange"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $REPO/$out/prof_c2_$v -o c2 -- python3 $REPO/bench.py --config c2 --steps 20 --warmup 5 --cpu-frames 0 --sustained-steps 0 $extra) > $out/prof_c2_$v.log 2>&1
@@ -26,6 +26,6 @@ for v in exchange round3; do
 done
 clk() { name=$1; shift; timeout 600 python3 tools/track_clocks.py "$@" > $out/track_clocks_$name.txt 2> $out/track_clocks_$name.err; grep -A8 "waves; median" $out/track_clocks_$name.err; }
 clk exchange
-clk exchange_skip_ws -DFM_TRACK_SKIP_WS
+
 clk exchange_skip_sample -DFM_TRACK_SKIP_SAMPLE
-clk exchange_skip_both -DFM_TRACK_SKIP_SAMPLE -DFM_TRACK_SKIP_WS
+
