@@ -1168,6 +1168,10 @@ class TapPlan:
 
 # sample the tracking loss's tap depths from the image the flow pass leaves (while the parameter's version counter has not moved)
 use_tap_image = True
+# The exchange pays where the depth images are far larger than the last-level cache (256 MB of Infinity Cache on an MI355X): at 150 x 720p
+# (553 MB) the tracking loss's taps are cold lines and the exchange takes 0.08 ms off a 1.25 ms step; at the reference's default 180 x 240
+# (26 MB, cache-resident) there is nothing cold to avoid and its bookkeeping costs 0.05 ms.  Depth tensors below this size run as in round 3.
+tap_exchange_min_bytes = 128 << 20
 
 # the tap exchange between the fused flow loss and the fused tracking loss; False: both run as in round 3
 use_tap_exchange = True
@@ -1185,7 +1189,7 @@ def _whole_parameter(depth: Tensor) -> Optional[Tensor]:
 
 def tap_plan_of(depth: Tensor) -> Optional[TapPlan]:
     """The TapPlan a tracking loss registered for the parameter behind ``depth`` (matching its shape), if any."""
-    if not use_tap_exchange:
+    if not use_tap_exchange or depth.numel() * 4 < tap_exchange_min_bytes:
         return None
     root = _whole_parameter(depth)
     plan = root.__dict__.get("_fm_tap_plan") if root is not None else None
@@ -1245,7 +1249,8 @@ class TrackLossFused:
         # the tap exchange: whole video local, gradients on — register the static tap set with the parameter (the flow pass then leaves the tap
         # depths in its compact image) and sample from that image while the parameter has not moved since
         taps = (None, None, None)
-        root = _whole_parameter(depth) if (use_tap_exchange and plan is not None and reducer is None and int(frame0) == 0 and defer) else None
+        root = _whole_parameter(depth) if (use_tap_exchange and plan is not None and reducer is None and int(frame0) == 0 and defer
+                                           and depth.numel() * 4 >= tap_exchange_min_bytes) else None
         if root is not None and root.is_leaf and ext.shape[1] == depth.shape[1]:
             tap_plan = packed.tap_plan(depth.shape[1], depth.shape[2], depth.shape[3])
             if tap_plan is not None:

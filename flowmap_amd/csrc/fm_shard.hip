@@ -13,8 +13,52 @@
 // There is no reference counterpart: the reference has no sharding (flowmap/overfit.py:94-108 replicates the video per rank).
 #include "../../include/flowmap_hip.h"
 #include "fm_device.h"
+#include "fm_pose.h"
 
 namespace fm {
+
+// The ghost term (FrameShard.enable_ghost_halo): instead of RECEIVING the neighbour's dense dL/ddepth of the shared frame (3.7 MB per
+// boundary and direction at 720p), a rank EVALUATES it.  The neighbour's dense part is one flow-loss direction of one pair — the
+// backward term of pair L−1 (neighbour rank−1) or the forward term of pair L (neighbour rank+1), with frame L as its source: a function
+// of depth[L] (held here), the constant flow and mask of that pair (handed over once, at set-up), K, and the pair's 4x4 pose, which
+// the neighbour's Procrustes fit produces each step: 64 bytes travel.  Same per-pixel arithmetic as the fused flow pass (flow_term_fast,
+// fm_math.h); only dL/ddepth is kept — the loss value and the pose / intrinsics sums of the term belong to the neighbour, who
+// evaluates it too.  blockIdx.y = side (0: first local frame, backward term; 1: last local frame, forward term).
+struct GhostSide {
+  const float* depth;  // (H,W) the shared frame's depth
+  const float* pose;   // (4,4) source camera -> destination camera
+  const float* flow;   // (H,W,2) the ghost pair's flow for this direction
+  const float* mask;   // (H,W)
+  float* grad;         // (H,W) dL/ddepth of the shared frame: the term's part is ADDED
+};
+template <int KIND>
+__global__ void __launch_bounds__(256) flow_ghost_kernel(GhostSide s0, GhostSide s1, const float* kinv, const float* k_dst, const float* norm,
+                                                         const float* upstream, int height, int width, float delta, float ax, float ay) {
+  const GhostSide s = blockIdx.y == 0 ? s0 : s1;
+  if (s.grad == nullptr) return;
+  Mat3 ki, kd;
+  Pose t;
+  load_mat3(kinv, ki);
+  load_mat3(k_dst, kd);
+  load_pose44(s.pose, t);
+  DirConst d;
+  make_dir(t, ki, kd, ax, ay, d);
+  const float scale = norm[0] * (upstream ? upstream[0] : 1.f);
+  const float inv_delta = KIND == kHuber ? 1.0f / delta : 0.f;
+  const long n = (long)height * width;
+  for (long px = (long)blockIdx.x * blockDim.x + threadIdx.x; px < n; px += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(px / width), col = (int)(px - (long)row * width);
+    const float u = pixel_center(col, width), v = pixel_center(row, height);
+    const float z = s.depth[px];
+    float acc[kFlowAcc], gz = 0.f;
+#pragma unroll
+    for (int i = 0; i < kFlowAcc; ++i) acc[i] = 0.f;
+    const float2 fl = reinterpret_cast<const float2*>(s.flow)[px];
+    flow_term_fast<KIND, true>(d, fmaf(d.a1, v, d.a2), fmaf(d.b1, v, d.b2), fmaf(d.c1, v, d.c2), z, u, z * u, z * v, u * ax, v * ay, fl.x, fl.y,
+                               s.mask[px], scale, delta, inv_delta, ax, ay, acc, gz);
+    s.grad[px] += gz;
+  }
+}
 
 typedef float v4f_s __attribute__((ext_vector_type(4)));
 
@@ -84,6 +128,29 @@ static inline bool halo_aligned(const void* p) { return p == nullptr || (reinter
 using namespace fm;
 
 extern "C" {
+
+int fm_flow_ghost_terms(const float* depth_first, const float* pose_first, const float* flow_first, const float* mask_first, float* grad_first,
+                        const float* depth_last, const float* pose_last, const float* flow_last, const float* mask_last, float* grad_last,
+                        const float* kinv, const float* k_dst, const float* norm, const float* upstream, int height, int width,
+                        int mapping_kind, float delta, float aspect_x, float aspect_y, void* stream) {
+  FM_CHECK_ARG(kinv && k_dst && norm && height >= 1 && width >= 1 && mapping_kind >= 0 && mapping_kind <= 2);
+  FM_CHECK_ARG(grad_first == nullptr || (depth_first && pose_first && flow_first && mask_first));
+  FM_CHECK_ARG(grad_last == nullptr || (depth_last && pose_last && flow_last && mask_last));
+  if (grad_first == nullptr && grad_last == nullptr) return FM_OK;
+  const GhostSide s0{depth_first, pose_first, flow_first, mask_first, grad_first}, s1{depth_last, pose_last, flow_last, mask_last, grad_last};
+  const long n = (long)height * width;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const dim3 grid((unsigned)blocks, 2);
+  hipStream_t st = (hipStream_t)stream;
+  if (mapping_kind == kHuber)
+    hipLaunchKernelGGL(flow_ghost_kernel<kHuber>, grid, dim3(256), 0, st, s0, s1, kinv, k_dst, norm, upstream, height, width, delta, aspect_x, aspect_y);
+  else if (mapping_kind == kL1)
+    hipLaunchKernelGGL(flow_ghost_kernel<kL1>, grid, dim3(256), 0, st, s0, s1, kinv, k_dst, norm, upstream, height, width, delta, aspect_x, aspect_y);
+  else
+    hipLaunchKernelGGL(flow_ghost_kernel<kL2>, grid, dim3(256), 0, st, s0, s1, kinv, k_dst, norm, upstream, height, width, delta, aspect_x, aspect_y);
+  FM_LAUNCH_STATUS();
+}
 
 int fm_halo_copy(const float* grad, long frame_elements, int frames, float* sent_first, float* sent_last, void* stream) {
   FM_CHECK_ARG(grad && frame_elements >= 1 && frames >= 1);

@@ -979,6 +979,8 @@ def case_tap_exchange(dev):
         return results, sinks
 
     names = ("loss_flow", "loss_tracking", "extrinsics", "g_depth", "g_wlogit", "g_focal")
+    min_bytes = _ops.tap_exchange_min_bytes
+    _ops.tap_exchange_min_bytes = 0  # (by default the exchange engages for depth tensors beyond the last-level cache only)
     try:
         for how in ("sum", "scaled", "flow_only", "track_only", "two_calls"):
             before = dict(_ops.counters)
@@ -1031,6 +1033,7 @@ def case_tap_exchange(dev):
             assert float((x - y).abs().max()) <= 2e-6 * max(float(y.abs().max()), 1e-30), ("l1", what)
     finally:
         _ops.use_tap_exchange = True
+        _ops.tap_exchange_min_bytes = min_bytes
         flowmap_amd.set_lazy_surfaces(False)
 
 

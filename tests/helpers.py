@@ -52,8 +52,11 @@ def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="h
     drive it.  Returns dict of loss values and parameter gradients (on CPU).  ``steps`` > 1: the same step repeated on the
     same parameters (no optimiser), the LAST one reported — from its second step on a flow + tracking loop runs the tap
     exchange, from its third the tracking loss samples the compact tap image (flowmap_amd/_ops.py: TapPlan)."""
+    from flowmap_amd import _ops
+
     f = depth.shape[0]
     flowmap_amd.set_lazy_surfaces(lazy)
+    min_bytes = _ops.tap_exchange_min_bytes
     try:
         cfg = ModelCfg(
             BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
@@ -70,6 +73,8 @@ def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="h
         losses = [LossFlow(LossFlowCfg(0, flow_weight, "flow", mapping_cfg(kind)))]
         if tracks is not None:
             losses.append(LossTracking(LossTrackingCfg(0, track_weight, "tracking", mapping_cfg(kind))))
+        if steps > 1:
+            _ops.tap_exchange_min_bytes = 0  # (a repeated step is asked for to exercise the tap exchange, whatever the size)
         for _ in range(steps):
             model.zero_grad(set_to_none=True)
             out = model(batch, flows, 0)
@@ -87,6 +92,7 @@ def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="h
         }
     finally:
         flowmap_amd.set_lazy_surfaces(False)
+        _ops.tap_exchange_min_bytes = min_bytes
 
 
 def run_oracle(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="huber", dtype=torch.float32,
