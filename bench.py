@@ -100,11 +100,13 @@ def parse():
                          "eagerly after the replay), `off`.  Default: off on one GPU (the headline number is measured eagerly, with HIP events around the "
                          "flow kernel), `compute` for a multi-rank strong-scaling run of the flow loss — a rank's ~15 kernels take ~0.2 ms at 8 GPUs and "
                          "cannot hide ~0.45 ms of eager enqueueing")
-    ap.add_argument("--halo", choices=["auto", "oneshot", "early"], default="auto",
+    ap.add_argument("--halo", choices=["auto", "oneshot", "early", "ghost"], default="auto",
                     help="strong scaling: how the boundary frames' dL/ddepth reaches the neighbour — `oneshot`: one 3.7 MB (720p) exchange per boundary and "
                          "direction after backward; `early` (FrameShard.enable_early_halo): the dense part right after the flow pass, under the rest of the "
                          "step, and a sparse correction (~20 KB) after backward (with --graph compute: between the forward and the backward replay).  "
-                         "auto: early for a multi-rank strong-scaling run, oneshot otherwise (the --share proxy states its mode explicitly)")
+                         "`ghost` (FrameShard.enable_ghost_halo): no frame travels at all — each rank is handed the neighbouring pair's constant flow once, receives its 64-byte pose "
+                         "per step and evaluates the neighbour's dense part itself (fm_flow_ghost_terms), the same sparse correction after backward.  "
+                         "auto: ghost for a multi-rank strong-scaling run, oneshot otherwise (the --share proxy states its mode explicitly)")
     ap.add_argument("--share", type=int, default=0,
                     help="K > 0: run ONE rank's share of a K-GPU strong-scaling run on this GPU (its pairs + halo frames, collectives on a "
                          "one-rank RCCL communicator): the per-rank step time of a K-GPU run without the wire time")
@@ -393,7 +395,7 @@ def main():
     if args.graph == "off":
         args.graph = None
     if args.halo == "auto":
-        args.halo = "early" if (strong and world > 1) else "oneshot"
+        args.halo = "ghost" if (strong and world > 1) else "oneshot"
     if args.graph == "compute" and (not strong or cfg["tracking"] or args.intrinsics != "regressed"):
         raise SystemExit("--graph compute: a frame-sharded run of the flow loss with regressed intrinsics (the tracking loss and the softmin sweep have collectives inside forward / backward)")
     flowmap_amd.set_lazy_surfaces(True)
@@ -419,6 +421,10 @@ def main():
     if strong:
         a, b = shard_pairs(total_pairs, cut_world)[cut_rank]
         lo, hi = shard_frames((a, b))
+        # the ghost halo's constants: the flow and mask of the pair before this shard's first frame (backward direction) and of the pair after
+        # its last frame (forward direction) — the two terms the neighbours would otherwise send the gradient of
+        ghost_prev = (flows.backward[0, a - 1].clone(), flows.backward_mask[0, a - 1].clone()) if (args.halo == "ghost" and a > 0) else None
+        ghost_next = (flows.forward[0, b].clone(), flows.forward_mask[0, b].clone()) if (args.halo == "ghost" and b < total_pairs) else None
         depth, wlogit = depth[lo : hi + 1].clone(), wlogit[a:b].clone()
         flows = Flows(*(x[:, a:b].contiguous() for x in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)))
         del scene
@@ -515,6 +521,10 @@ def main():
     early_halo = False
     if args.halo == "early" and strong:
         early_halo = shard.enable_early_halo(model.backbone.depth)  # (collective over neighbours; the scatter plans exist by now)
+        step()
+    if args.halo == "ghost" and strong:
+        early_halo = shard.enable_ghost_halo(model.backbone.depth, ghost_prev, ghost_next)
+        shard.set_proxy_ghost_flows(flows)  # (the --share proxy: the shard's own boundary pairs stand in for the neighbours')
         step()
     if dist is not None:  # create the RCCL communicators / P2P channels outside the timed region
         shard.exchange_halo(torch.zeros((2, h, w), device=device))
@@ -655,7 +665,8 @@ def main():
                 "pairs_per_gpu": f - 1,
                 "height": h,
                 "width": w,
-                "halo_exchange": ("early (dense part after the flow pass, sparse correction after backward)" if early_halo else "one shot after backward") if strong else None,
+                "halo_exchange": (("ghost (the neighbour's dense part evaluated from its 64-byte pose, sparse correction after backward)" if args.halo == "ghost" else
+                                   "early (dense part after the flow pass, sparse correction after backward)") if early_halo else "one shot after backward") if strong else None,
                 "parallelism": (f"frame-pair shards x{world} (1-frame halo, packed all-reduce of loss + shared gradients, halo exchange)" if strong
                                 else f"{world} independent 150-frame shards" if world > 1 else "single GPU"),
                 "loss": float(loss.item()),

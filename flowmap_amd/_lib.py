@@ -36,6 +36,7 @@ SIGNATURES = {
     "fm_scale_if_needed": [P, L, P, L, P, P, P],
     "fm_abi_version": [],
     "fm_halo_copy": [P, L, I, P, P, P],
+    "fm_flow_ghost_terms": [P] * 14 + [I, I, I, F, F, F, P],
     "fm_halo_delta": [P, L, I, P, P, L, P, P, P, L, P, P],
     "fm_halo_add": [P, L, I, P, P, P],
     "fm_halo_scatter": [P, L, I, P, P, L, P, P, L, P],

@@ -709,7 +709,9 @@ class FlowLossFused:
                 adam, ticket = offer
         # frame sharding with an early halo exchange (FrameShard.enable_early_halo): the dense dL/ddepth exists at the end of THIS
         # forward pass — the boundary frames are sent now, under the rest of the step; only a sparse correction follows backward
-        early = _root(depth).__dict__.get("_fm_early_halo") if (sink is not None and ticket is None and torch.is_grad_enabled()) else None
+        early = _root(depth).__dict__.get("_fm_early_halo") if (sink is not None and torch.is_grad_enabled()) else None
+        if early is not None and ticket is not None and not early.ghost_halo_enabled():
+            early = None  # (the early DENSE exchange is not combined with the in-pass Adam update; the ghost halo is: it reads the boundary frames only)
         if early is not None:
             sink.request_early_dense(early.unit_flag(depth.device))
         # the tap exchange with the tracking loss (its static taps were registered with the parameter by TrackLossFused): this pass leaves the
@@ -743,7 +745,7 @@ class FlowLossFused:
         if early is not None:
             dense = sink.take_early_dense()
             if dense is not None:
-                early.start_early_halo(dense, _root(depth))
+                early.start_early_halo(dense, _root(depth), (t_fwd, t_bwd, k, kinv, norm, int(kind), float(delta)))
         return loss
 
 

@@ -940,9 +940,11 @@ struct FlowLossFused : public Function<FlowLossFused> {
     ctx->saved_data["delta"] = delta;
     if (sink && park) ctx->saved_data["sink"] = sink;
     ctx->saved_data["g_depth"] = run.g_depth;
-    if (sink && sink->want_early && run.g_depth.defined() && !in_pass_adam) {
-      sink->early_dense = run.g_depth;  // (the same memory backward hands on: the caller copies the frames it sends)
-      if (sink->unit_flag.defined()) ctx->saved_data["adam_flag"] = sink->unit_flag;
+    if (sink && sink->want_early && run.g_depth.defined()) {
+      // (the same memory backward hands on: the caller copies the frames it sends.  With the in-pass Adam update only the pixels the pass
+      // keeps are written — the frames shared with a neighbour are kept whole, and they are all the caller reads)
+      sink->early_dense = run.g_depth;
+      if (sink->unit_flag.defined() && !in_pass_adam) ctx->saved_data["adam_flag"] = sink->unit_flag;  // (in-pass: the optimiser's own flag watches the same condition)
     }
     ctx->saved_data["small"] = run.small;
     ctx->saved_data["fresh"] = need;

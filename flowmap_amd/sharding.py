@@ -90,6 +90,7 @@ class FrameShard:
         self._early = None  # enable_early_halo(): pixel lists, buffers and the requests of the early (dense) part in flight
         self._unit_flags = {}
         self._syncs = 0
+        self.ghost_evaluations = 0  # steps whose shared frames' dense parts were evaluated here (enable_ghost_halo) instead of received
 
     @property
     def active(self) -> bool:
@@ -280,6 +281,17 @@ class FrameShard:
         depth_param.__dict__["_fm_early_halo"] = self
         return True
 
+    def ghost_halo_enabled(self) -> bool:
+        return self._early is not None and self._early.get("ghost") is not None
+
+    def set_proxy_ghost_flows(self, flows) -> None:
+        """One-GPU proxy of the ghost halo: the shard's own first / last pair stand in for the neighbouring pairs (same sizes, same work)."""
+        e = self._early
+        if e is None or e.get("ghost") is None:
+            return
+        e["ghost"]["proxy_flows"] = {"prev": (flows.backward[0, 0].contiguous(), flows.backward_mask[0, 0].contiguous()),
+                                     "next": (flows.forward[0, -1].contiguous(), flows.forward_mask[0, -1].contiguous())}
+
     def take_stashed_early(self):
         """GraphedShardedStep: the dense gradient the flow loss produced inside a capture / warm-up step (None without early halo)."""
         if self._early is None:
@@ -292,6 +304,34 @@ class FrameShard:
             self._early["param"].__dict__.pop("_fm_early_halo", None)
             self._early = None
 
+    # -- ghost halo -------------------------------------------------------------------------
+    # The dense part of a shared frame's dL/ddepth that the NEIGHBOUR computes is one direction of the flow loss of one pair with the
+    # shared frame as its source: a function of that frame's depth (held on both ranks), the pair's constant flow and mask, K, and the
+    # pair's pose.  With enable_ghost_halo() a rank is handed those constants once and receives the 64-byte pose each step — sent as soon
+    # as the neighbour's fit has produced it, long before it is needed — and EVALUATES the term (fm_flow_ghost_terms, ~6 us for two
+    # 720p frames) instead of receiving 3.7 MB per boundary and direction; the sparse rest (Procrustes / track pixels) travels after
+    # backward exactly as with the early exchange.  Intrinsics must be shared by all frames (regressed / softmin), as they are here.
+    def enable_ghost_halo(self, depth_param: Tensor, flows_prev=None, flows_next=None) -> bool:
+        """COLLECTIVE over neighbours, like ``enable_early_halo`` (which it builds on: same pixel lists, same sparse round).
+        ``flows_prev`` = (backward flow (H, W, 2), backward mask (H, W)) of the pair BEFORE this rank's first frame — rank−1's last pair —,
+        ``flows_next`` = (forward flow, forward mask) of the pair AFTER its last frame — rank+1's first pair; None on the video's ends (and in
+        the one-GPU proxy, where the rank's own boundary pairs stand in).  -> False when the static pixel set is not known yet."""
+        if not self.enable_early_halo(depth_param):
+            return False
+        e = self._early
+        for side, given in (("prev", flows_prev), ("next", flows_next)):
+            if side in e["send"] and given is None and not self.proxy:
+                raise ValueError(f"flowmap_amd.FrameShard.enable_ghost_halo: this rank shares its {'first' if side == 'prev' else 'last'} frame with a "
+                                 f"neighbour: flows_{side} (the neighbouring pair's flow and mask) is needed")
+        dev = depth_param.device
+        pose = lambda: torch.eye(4, dtype=torch.float32, device=dev)  # noqa: E731
+        e["ghost"] = {
+            "flows": {"prev": None if flows_prev is None else tuple(t.to(dev, torch.float32).contiguous() for t in flows_prev),
+                      "next": None if flows_next is None else tuple(t.to(dev, torch.float32).contiguous() for t in flows_next)},
+            "pose_out": {s_: pose() for s_ in e["send"]}, "pose_in": {s_: pose() for s_ in e["send"]}, "context": None,
+        }
+        return True
+
     def _exchange(self, pairs):
         """[(send buffer, receive buffer, peer)] -> requests (asynchronous); the proxy has no peer: nothing travels."""
         if self.proxy or not pairs:
@@ -303,12 +343,17 @@ class FrameShard:
             ops.append(dist.P2POp(dist.irecv, into, peer, self.group))
         return dist.batch_isend_irecv(ops)
 
-    def start_early_halo(self, dense_grad: Tensor, depth_param: Tensor) -> None:
+    def start_early_halo(self, dense_grad: Tensor, depth_param: Tensor, context=None) -> None:
         """Called by the fused flow loss at the end of its forward pass with its dense dL/ddepth (1, F, H, W): copy the boundary
-        frames (backward will add the sparse parts to the very same memory) and send them."""
+        frames (backward will add the sparse parts to the very same memory) and send them — or, with the ghost halo, send the boundary
+        pairs' poses instead.  ``context``: what the ghost terms are evaluated from later — (t_fwd, t_bwd, k, kinv, norm, kind, delta) of
+        the flow loss that calls."""
         e = self._early
         if e is None or e["param"] is not depth_param:
             return
+        ghost = e.get("ghost")
+        if ghost is not None and context is not None:
+            ghost["context"] = context
         if e.get("stash_only", False):  # GraphedShardedStep's warm-up and captures: nothing is sent; the step sends it between its two replays
             e["stashed"] = dense_grad
             return
@@ -324,7 +369,25 @@ class FrameShard:
         frames, h, w = dense_grad.shape[1:]
         with _guard(dense_grad.device):  # both boundary frames in one launch (fm_halo_copy)
             call("fm_halo_copy", ptr(dense_grad), h * w, frames, ptr(e["send"].get("prev")), ptr(e["send"].get("next")), stream_for(dense_grad))
-        pairs = [(e["send"][side], e["recv"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
+        if ghost is not None:
+            # the neighbour evaluates my side of the shared frame itself: it needs the pose of MY boundary pair — towards rank−1 my first
+            # pair's camera a -> a+1 (its forward term of that pair), towards rank+1 my last pair's camera b -> b−1 (its backward term)
+            if ghost["context"] is None:
+                raise RuntimeError("flowmap_amd.FrameShard: the ghost halo needs the flow loss's poses (a fused LossFlow on this shard's depth parameter)")
+            t_fwd, t_bwd = ghost["context"][0], ghost["context"][1]
+            with torch.no_grad():
+                if "prev" in e["send"]:
+                    ghost["pose_out"]["prev"].copy_(t_fwd.detach()[0, 0])
+                if "next" in e["send"]:
+                    ghost["pose_out"]["next"].copy_(t_bwd.detach()[0, -1])
+                if self.proxy:  # no peer: the rank's own boundary poses stand in for the neighbours'
+                    if "prev" in e["send"]:
+                        ghost["pose_in"]["prev"].copy_(t_bwd.detach()[0, 0])
+                    if "next" in e["send"]:
+                        ghost["pose_in"]["next"].copy_(t_fwd.detach()[0, -1])
+            pairs = [(ghost["pose_out"][side], ghost["pose_in"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
+        else:
+            pairs = [(e["send"][side], e["recv"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
         e["inflight"] = self._exchange(pairs)
 
     def _start_sparse_halo(self, depth_grad: Tensor) -> None:
@@ -351,8 +414,28 @@ class FrameShard:
 
         frames, h, w = depth_grad.shape
         cnt = lambda side: e["theirs"][side].numel() if side in e["send"] else 0  # noqa: E731
+        ghost = e.get("ghost")
         with _guard(depth_grad.device):  # the neighbours' dense parts, then their sparse parts: one launch each for both boundaries
-            call("fm_halo_add", ptr(depth_grad), h * w, frames, ptr(e["recv"].get("prev")), ptr(e["recv"].get("next")), stream_for(depth_grad))
+            if ghost is not None:
+                t_fwd, t_bwd, k, kinv, norm, kind, delta = ghost["context"]
+                depth = e["param"].detach()
+                flows = dict(ghost["flows"])
+                if self.proxy:  # (stand-ins: the rank's own boundary pairs)
+                    pf = ghost.get("proxy_flows")
+                    if pf is None:
+                        raise RuntimeError("flowmap_amd.FrameShard (proxy): set_proxy_ghost_flows() has not been called")
+                    flows = pf
+                first, last = flows.get("prev") if "prev" in e["send"] else None, flows.get("next") if "next" in e["send"] else None
+                scale = (h * w) ** 0.5
+                self.ghost_evaluations += 1
+                call("fm_flow_ghost_terms",
+                     ptr(depth[0]) if first else None, ptr(ghost["pose_in"].get("prev")) if first else None, ptr(first[0]) if first else None,
+                     ptr(first[1]) if first else None, ptr(depth_grad[0]) if first else None,
+                     ptr(depth[-1]) if last else None, ptr(ghost["pose_in"].get("next")) if last else None, ptr(last[0]) if last else None,
+                     ptr(last[1]) if last else None, ptr(depth_grad[-1]) if last else None,
+                     ptr(kinv.detach()[0, 0]), ptr(k.detach()[0, 0]), ptr(norm), None, h, w, int(kind), float(delta), w / scale, h / scale, stream_for(depth_grad))
+            else:
+                call("fm_halo_add", ptr(depth_grad), h * w, frames, ptr(e["recv"].get("prev")), ptr(e["recv"].get("next")), stream_for(depth_grad))
             call("fm_halo_scatter", ptr(depth_grad), h * w, frames, ptr(e["theirs"]["prev"]), ptr(e["delta_in"].get("prev")), cnt("prev"),
                  ptr(e["theirs"]["next"]), ptr(e["delta_in"].get("next")), cnt("next"), stream_for(depth_grad))
         self._syncs += 1

@@ -529,6 +529,18 @@ int fm_procrustes_scatter_plan_views(const float* bwd_flow, const int64_t* indic
  *   fm_halo_scatter  boundary frame[pixels_*[i]] += values_*[i]                           (the neighbour's sparse part; pixels distinct)
  * pixels: int64 offsets inside one frame.  One launch each, both boundaries at once. */
 int fm_halo_copy(const float* grad, long frame_elements, int frames, float* sent_first, float* sent_last, void* stream);
+/* The ghost halo (round 4; FrameShard.enable_ghost_halo): the neighbour's DENSE part of a shared frame's dL/ddepth is not received but
+ * evaluated — it is one direction of the flow loss of one pair with the shared frame as its source (the backward term of the pair
+ * before a rank's first frame, the forward term of the pair after its last; loss_flow.py:46-68, projection.py:143-184 for one frame):
+ *   grad_* (H,W) += norm[0]·upstream[0]·d/ddepth [ ρ(project(pose_*·unproject(depth_*)) − grid, flow_*)·mask_* ]
+ * with pose_* (4,4) the source camera -> destination camera transform the neighbour's Procrustes fit produced this step (the only
+ * per-step message: 64 bytes), flow_* (H,W,2) / mask_* (H,W) that pair's constant flow and mask in this direction (handed over once),
+ * kinv (3,3) of the shared frame and k_dst (3,3) of the destination camera (intrinsics shared by all frames).  Same arithmetic per
+ * pixel as fm_flow_loss_fused.  A NULL grad_* switches the side off; upstream NULL = 1. */
+int fm_flow_ghost_terms(const float* depth_first, const float* pose_first, const float* flow_first, const float* mask_first, float* grad_first,
+                        const float* depth_last, const float* pose_last, const float* flow_last, const float* mask_last, float* grad_last,
+                        const float* kinv, const float* k_dst, const float* norm, const float* upstream, int height, int width,
+                        int mapping_kind, float delta, float aspect_x, float aspect_y, void* stream);
 int fm_halo_delta(const float* grad, long frame_elements, int frames, const float* sent_first, const int64_t* pixels_first, long count_first,
                   float* out_first, const float* sent_last, const int64_t* pixels_last, long count_last, float* out_last, void* stream);
 int fm_halo_add(float* grad, long frame_elements, int frames, const float* dense_first, const float* dense_last, void* stream);

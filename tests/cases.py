@@ -839,6 +839,45 @@ def case_flow_fused_leaves(dev, f, h, w, packed, kind="huber", seed=0, tol=TOL):
     assert float(tf.grad[0, :, 3].abs().max()) == 0.0 and float(tb.grad[0, :, 3].abs().max()) == 0.0  # [..., :3] drops the last row
 
 
+def case_ghost_terms(dev, kind="huber"):
+    """fm_flow_ghost_terms (the ghost halo of frame sharding): the dL/ddepth of ONE direction of ONE pair's flow-loss term, added into a
+    frame's gradient — the fused flow loss of the whole video restricted to a shard [1 .. F-2] plus the two ghost terms (the backward term
+    of pair 0 at frame 1, the forward term of pair F-2 at frame F-2) gives the whole video's dL/ddepth of the shard's boundary frames."""
+    from flowmap_amd import _ops
+    from flowmap_amd._lib import call, ptr, stream_for
+
+    f, h, w = 5, 12, 16
+    gen = torch.Generator().manual_seed(5)
+    depth = (1.0 + 0.3 * torch.rand((1, f, h, w), generator=gen)).to(dev)
+    k = orc.focal_to_k(torch.tensor(0.85), (h, w)).repeat(1, f, 1, 1).to(dev)  # (shared by all frames, as the ghost halo requires)
+    t_fwd, t_bwd = _random_rigid(f - 1, gen)[None].float().to(dev), _random_rigid(f - 1, gen)[None].float().to(dev)
+    ff, fb = (0.01 * torch.randn((1, f - 1, h, w, 2), generator=gen)).to(dev), (0.01 * torch.randn((1, f - 1, h, w, 2), generator=gen)).to(dev)
+    mf, mb = torch.rand((1, f - 1, h, w), generator=gen).to(dev), torch.rand((1, f - 1, h, w), generator=gen).to(dev)
+    weight = 1000.0
+    norm = _ops.flow_valid_norm(mf, mb, weight)  # the GLOBAL normaliser, as a shard uses it
+
+    def grad_of(lo, hi):  # the fused flow loss over frames lo..hi (pairs lo..hi-1), normalised globally
+        d = depth[:, lo : hi + 1].clone().requires_grad_(True)
+        loss = _ops.FlowLossFused.apply(d, k[:, lo : hi + 1].contiguous(), t_fwd[:, lo:hi].contiguous(), t_bwd[:, lo:hi].contiguous(),
+                                        ff[:, lo:hi].contiguous(), fb[:, lo:hi].contiguous(), mf[:, lo:hi].contiguous(), mb[:, lo:hi].contiguous(),
+                                        norm, _ops.MAPPING_KINDS[kind], 0.01, False, 0, None)
+        loss.backward()
+        return d.grad[0]
+
+    whole = grad_of(0, f - 1)
+    shard = grad_of(1, f - 2).clone()  # frames 1 .. F-2: its boundary frames lack one term each
+    assert float((shard[0] - whole[1]).abs().max()) > 1e-3 * float(whole[1].abs().max())
+    kinv = _ops.intrinsics_inverse(k)
+    scale = (h * w) ** 0.5
+    with _ops._guard(depth.device):
+        call("fm_flow_ghost_terms", ptr(depth[0, 1]), ptr(t_bwd[0, 0]), ptr(fb[0, 0]), ptr(mb[0, 0]), ptr(shard[0]),
+             ptr(depth[0, f - 2]), ptr(t_fwd[0, f - 2]), ptr(ff[0, f - 2]), ptr(mf[0, f - 2]), ptr(shard[-1]),
+             ptr(kinv[0, 0]), ptr(k[0, 0]), ptr(norm), None, h, w, _ops.MAPPING_KINDS[kind], 0.01, w / scale, h / scale, stream_for(depth))
+    for name, mine, ref in (("first", shard[0], whole[1]), ("last", shard[-1], whole[f - 2]), ("interior", shard[1], whole[2])):
+        err = float((mine - ref).abs().max())
+        assert err <= 2e-6 * float(ref.abs().max()), (name, err)  # (the same per-pixel arithmetic; the two terms are summed in another order)
+
+
 def case_dense_procrustes(dev, h, w, flow_sigma, f=4):
     """`num_points: null` (every pixel a correspondence, ablation_explicit_depth.yaml:11-12): the tiled,
     planned, atomic-free dense kernels (pixel-space sums, fm_procrustes_scatter_dense) against the fp64

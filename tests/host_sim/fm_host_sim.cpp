@@ -1695,6 +1695,41 @@ int fm_halo_copy(const float* grad, long n, int frames, float* sent_first, float
   if (sent_last) std::memcpy(sent_last, grad + (size_t)(frames - 1) * n, sizeof(float) * n);
   return 0;
 }
+// The ghost terms: a two-frame flow loss per side, evaluated by this file's own fused loss with the other direction masked out — the
+// shared frame as source, a stand-in (never read where the mask is zero ... its term is multiplied by a zero mask) as the other frame.
+int fm_flow_ghost_terms(const float* depth_first, const float* pose_first, const float* flow_first, const float* mask_first, float* grad_first,
+                        const float* depth_last, const float* pose_last, const float* flow_last, const float* mask_last, float* grad_last,
+                        const float* kinv, const float* k_dst, const float* norm, const float* upstream, int height, int width, int kind,
+                        float delta, float ax, float ay, void* stream) {
+  if (!kinv || !k_dst || !norm || height < 1 || width < 1 || kind < 0 || kind > 2) return 1;
+  const size_t n = (size_t)height * width;
+  const float scale = norm[0] * (upstream ? upstream[0] : 1.f);
+  for (int side = 0; side < 2; ++side) {
+    const float* depth = side == 0 ? depth_first : depth_last;
+    const float* pose = side == 0 ? pose_first : pose_last;
+    const float* flow = side == 0 ? flow_first : flow_last;
+    const float* mask = side == 0 ? mask_first : mask_last;
+    float* grad = side == 0 ? grad_first : grad_last;
+    if (!grad) continue;
+    if (!depth || !pose || !flow || !mask) return 1;
+    // frames [shared, other] with the ghost term as the FORWARD direction of their pair (frame 0 -> camera 1): K of frame 0 = the shared
+    // frame's, of frame 1 = the destination's; the backward direction (source frame 1) has a zero mask
+    std::vector<float> d2(2 * n, 1.f), k2(18), ki2(18), tf(16), tb(16, 0.f), fb(2 * n, 0.f), mb(n, 0.f), g2(2 * n, 0.f);
+    std::memcpy(d2.data(), depth, sizeof(float) * n);
+    std::memcpy(ki2.data(), kinv, sizeof(float) * 9);
+    std::memcpy(ki2.data() + 9, kinv, sizeof(float) * 9);
+    std::memcpy(k2.data() + 9, k_dst, sizeof(float) * 9);
+    std::memcpy(k2.data(), k_dst, sizeof(float) * 9);
+    std::memcpy(tf.data(), pose, sizeof(float) * 16);
+    for (int i = 0; i < 4; ++i) tb[i * 5] = 1.f;
+    std::vector<double> acc(2 * 2 * kFlowAccStride, 0.0);
+    if (fm_flow_loss_fused(d2.data(), k2.data(), ki2.data(), tf.data(), tb.data(), flow, fb.data(), mask, mb.data(), nullptr, &scale, 1, 2, height,
+                           width, kind, delta, ax, ay, g2.data(), acc.data(), 0, stream) != 0)
+      return 2;
+    for (size_t i = 0; i < n; ++i) grad[i] += g2[i];
+  }
+  return 0;
+}
 int fm_halo_add(float* grad, long n, int frames, const float* dense_first, const float* dense_last, void*) {
   if (!grad || n < 1 || frames < 1 || (frames == 1 && dense_first && dense_last)) return 1;
   for (long i = 0; dense_first && i < n; ++i) grad[i] += dense_first[i];

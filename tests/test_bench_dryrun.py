@@ -47,6 +47,19 @@ def test_strong_scaling_reports_the_whole_video(extra):
         assert abs(line["config"]["loss"] - single["config"]["loss"]) <= 2e-5 * abs(single["config"]["loss"]), (world, line["config"]["loss"], single["config"]["loss"])
 
 
+@pytest.mark.parametrize("halo", ["oneshot", "early", "ghost"])
+def test_every_halo_mode_reports_the_same_loss(halo):
+    """bench.py --halo oneshot | early | ghost over three ranks (ghost — the default of a multi-rank strong-scaling run — hands every rank
+    the neighbouring pairs' flows when the video is cut): the mode is named in the line, the loss is the whole video's."""
+    single = _run(1, ["--config", "c1"])
+    line = _run(3, ["--config", "c1", "--halo", halo, "--steps", "3"])
+    assert str(line["config"]["halo_exchange"]).startswith({"oneshot": "one shot", "early": "early", "ghost": "ghost"}[halo])
+    assert abs(line["config"]["loss"] - single["config"]["loss"]) <= 2e-5 * abs(single["config"]["loss"])
+    if halo == "ghost":
+        proxy = _run(1, ["--config", "c1", "--share", "3", "--halo", "ghost"])
+        assert str(proxy["config"]["halo_exchange"]).startswith("ghost") and proxy["proxy"]["share_of"] == 3
+
+
 def test_weak_scaling_runs_one_video_per_rank():
     line = _run(2, ["--config", "c1", "--scaling", "weak"])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["frames_per_gpu"] == 9

@@ -427,6 +427,12 @@ def test_flow_fused_leaves(f, h, w, packed, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["huber", "l1", "l2"])
+def test_ghost_terms(kind):
+    cases.case_ghost_terms(DEV, kind)
+
+
+@pytest.mark.gpu
 def test_tap_exchange():
     cases.case_tap_exchange(DEV)
 

@@ -147,6 +147,11 @@ def test_depth_adam_update_inside_the_flow_pass_follows_torch_adam():
     cases.case_in_pass_adam("cpu")
 
 
+@pytest.mark.parametrize("kind", ["huber", "l1", "l2"])
+def test_ghost_terms(kind):
+    cases.case_ghost_terms("cpu", kind)
+
+
 def test_tap_exchange():
     cases.case_tap_exchange("cpu")
 

@@ -335,7 +335,7 @@ def test_shared_module_gradients_are_bucketed_and_match_the_unsharded_step(tmp_p
     assert abs(float(got["g_focal"]) - float(ref["g_focal"])) <= 1e-4 * abs(float(ref["g_focal"])) + 1e-6 * abs(float(ref["loss"]))
 
 
-def _adam_worker(rank, world, port, f, h, w, points, steps, out_path):
+def _adam_worker(rank, world, port, f, h, w, points, steps, out_path, ghost=False):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -384,16 +384,21 @@ def _adam_worker(rank, world, port, f, h, w, points, steps, out_path):
         loss.backward()
         losses.append(float(shard.sync(loss, [model.intrinsics.focal_length], model.backbone.depth)))
         optimizer.step()
+        if ghost and world > 1 and step == 1:  # (the Procrustes plan exists: the static pixel lists can be exchanged)
+            prev = (flows.backward[0, a - 1], flows.backward_mask[0, a - 1]) if rank > 0 else None
+            nxt = (flows.forward[0, b], flows.forward_mask[0, b]) if rank < world - 1 else None
+            assert shard.enable_ghost_halo(model.backbone.depth, prev, nxt) is True
     torch.save({"depth": model.backbone.depth.detach().clone(), "weights": model.backbone.weights.detach().clone(),
                 "focal": model.intrinsics.focal_length.detach().clone(), "losses": losses, "frames": (lo, hi), "pairs": (a, b),
-                "in_pass": getattr(optimizer, "counters", {}).get("in_pass_updates", 0)}, f"{out_path}.{rank}")
+                "in_pass": getattr(optimizer, "counters", {}).get("in_pass_updates", 0), "ghost": shard.ghost_evaluations}, f"{out_path}.{rank}")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_in_pass_adam_on_frame_shards_follows_the_unsharded_optimiser(tmp_path):
+@pytest.mark.parametrize("ghost", [False, True], ids=["one-shot halo", "ghost halo"])
+def test_in_pass_adam_on_frame_shards_follows_the_unsharded_optimiser(tmp_path, ghost):
     """FusedAdam.fuse_depth_update on a frame shard: interior frames are updated inside the flow pass, the frames shared
     with a neighbour densely after the halo exchange — over several steps the parameters of every rank follow
     torch.optim.Adam on the unsharded video (both copies of a shared frame included)."""
@@ -402,7 +407,7 @@ def test_in_pass_adam_on_frame_shards_follows_the_unsharded_optimiser(tmp_path):
 
     f, h, w, points, steps, world = 9, 24, 32, 60, 6, 3
     out, single = str(tmp_path / "shard"), str(tmp_path / "single")
-    mp.spawn(_adam_worker, args=(world, _free_port(), f, h, w, points, steps, out), nprocs=world, join=True)
+    mp.spawn(_adam_worker, args=(world, _free_port(), f, h, w, points, steps, out, ghost), nprocs=world, join=True)
     mp.spawn(_adam_worker, args=(1, _free_port(), f, h, w, points, steps, single), nprocs=1, join=True)
     ref = torch.load(f"{single}.0")
     for rank in range(world):
@@ -410,6 +415,7 @@ def test_in_pass_adam_on_frame_shards_follows_the_unsharded_optimiser(tmp_path):
         lo, hi = got["frames"]
         a, b = got["pairs"]
         assert got["in_pass"] == steps - 1  # every step after the plan exists
+        assert got["ghost"] == (steps - 2 if ghost else 0)  # (switched on after the second step)
         for s_, (x, y) in enumerate(zip(got["losses"], ref["losses"])):
             assert abs(x - y) <= 2e-5 * abs(y), (rank, s_, x, y)
         assert_close(got["depth"], ref["depth"][lo : hi + 1], 2e-6, abs_=2e-6, what=f"depth parameters of rank {rank}")
@@ -418,7 +424,7 @@ def test_in_pass_adam_on_frame_shards_follows_the_unsharded_optimiser(tmp_path):
     assert float((ref["depth"] - torch.load(f"{single}.0")["depth"]).abs().max()) == 0.0
 
 
-def _early_worker(rank, world, port, f, h, w, points, with_tracks, out_path):
+def _early_worker(rank, world, port, f, h, w, points, with_tracks, out_path, ghost=False):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -469,11 +475,47 @@ def _early_worker(rank, world, port, f, h, w, points, with_tracks, out_path):
         modes.append(shard._early is not None and shard._halo is not None and shard._halo[5])  # the sparse rest is what is in flight
         total = shard.sync(loss, [model.intrinsics.focal_length], model.backbone.depth, already_global=tracked)
         history.append((total.clone(), model.backbone.depth.grad.clone(), model.intrinsics.focal_length.grad.clone()))
-        if step == 1:
+        if step == 1 and not ghost:
             assert shard.enable_early_halo(model.backbone.depth) is True  # (collective: every rank calls it here)
+        if step == 1 and ghost:  # the ghost halo: the neighbouring pairs' constant flows, handed over once
+            prev = (flows.backward[0, a - 1], flows.backward_mask[0, a - 1]) if rank > 0 else None
+            nxt = (flows.forward[0, b], flows.forward_mask[0, b]) if rank < world - 1 else None
+            assert shard.enable_ghost_halo(model.backbone.depth, prev, nxt) is True
+    assert shard.ghost_evaluations == (3 if ghost else 0)
     torch.save({"history": history, "modes": modes, "frames": (lo, hi)}, f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("with_tracks", [False, True], ids=["flow", "flow+tracking"])
+def test_ghost_halo_gives_the_same_gradients(tmp_path, with_tracks, world):
+    """FrameShard.enable_ghost_halo(): the neighbour's dense part of a shared frame's gradient is EVALUATED from the 64-byte pose it sends
+    (fm_flow_ghost_terms) instead of received as a frame; the sparse rest travels after backward — loss and gradients of every step as
+    with the one-shot exchange and as the unsharded oracle."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import assert_close
+    from helpers import run_oracle
+    from oracle import flowmap_oracle as orc
+
+    f, h, w, points = 9, 12, 16, 40
+    out = str(tmp_path / "ghost")
+    mp.spawn(_early_worker, args=(world, _free_port(), f, h, w, points, with_tracks, out, True), nprocs=world, join=True)
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
+    otracks = orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5) if with_tracks else None
+    ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float64)
+    ref32 = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float32)
+    for rank in range(world):
+        got = torch.load(f"{out}.{rank}")
+        assert got["modes"] == [False, False, True, True, True], got["modes"]
+        lo, hi = got["frames"]
+        for step, (total, g_depth, g_focal) in enumerate(got["history"]):
+            assert_close(total, ref["total"], 1e-5, what=f"global loss, step {step}")
+            _shard_close(g_depth, ref["g_depth"][lo : hi + 1], ref32["g_depth"][lo : hi + 1], f"g_depth of rank {rank} (ghost halo), step {step}")
+            _focal_close(g_focal, ref)
+        for ghost_step in (2, 3, 4):  # against the one-shot exchange of step 1: the same terms, the dense one evaluated here instead of there
+            assert_close(got["history"][ghost_step][1], got["history"][1][1], 1e-5, abs_=1e-9, what=f"ghost vs one-shot exchange, rank {rank}")
 
 
 @pytest.mark.timeout(300)
