@@ -273,13 +273,15 @@ def announce_track_pixels(depth: Tensor, tracks) -> None:
     note_touched(depth, "tracking", plan[0])
 
 
-def touched_elements(depth: Tensor, whole_frames=()):
+def touched_elements(depth: Tensor, whole_frames=(), exclude=()):
     """(sorted unique flat indices, per-quad bit mask uint8 (numel/4)) of everything recorded by note_touched, built
     once per combination of recorded sets; None when nothing was recorded or a 4-element quad layout does not apply.
     ``whole_frames`` (frame sharding: the halo frames, indices along dim 1 of a (1, F, H, W) depth): every element of these
     frames is marked in the mask but left OUT of the index list — the caller updates them with a dense pass per frame."""
     root = _root(depth)
     registry = root.__dict__.get("_fm_touched")
+    if registry and exclude:  # (``exclude``: consumers whose gradient the flow pass itself absorbs — the tracking loss under the tap exchange)
+        registry = {name: v for name, v in registry.items() if name not in exclude}
     if not registry or depth.numel() % 4 != 0:
         return None
     whole_frames = tuple(sorted(int(f) for f in whole_frames))
@@ -305,7 +307,7 @@ def touched_elements(depth: Tensor, whole_frames=()):
         return list(registry.values()), keys.contiguous(), mask
 
     key = tuple((name, id(v), v._version) for name, v in sorted(registry.items())) + (depth.numel(), whole_frames)
-    return _derived(root, "_fm_touched_union", key, build)[1:]
+    return _derived(root, "_fm_touched_union" + ("_without_" + "_".join(exclude) if exclude else ""), key, build)[1:]
 
 
 # Persistent dL/dweights storage (GradArena) for sparse fits with a constant index set; False = fresh zeros every step
@@ -703,8 +705,15 @@ class FlowLossFused:
         acc = _derived(mask_fwd, "_fm_flow_acc", (size, str(depth.device)), lambda: torch.zeros((size,), dtype=torch.float64, device=depth.device))
         adam, ticket = (None, None, None, 0, [], None), None
         optimizer = _root(depth).__dict__.get("_fm_fused_adam")
+        # the tap exchange with the tracking loss (its static taps were registered with the parameter by TrackLossFused): this pass leaves the
+        # depth at every tap in the plan's compact image and absorbs the tracking gradient a look-ahead evaluation left in the sink
+        tap_plan = tap_plan_of(depth) if (sink is not None and torch.is_grad_enabled() and depth.requires_grad) else None
+        if tap_plan is not None and packed is None and not all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (flow_fwd, flow_bwd, mask_fwd, mask_bwd)):
+            tap_plan = None  # (frame windows / unaligned flows: the pass that reads them in place has no tap variant)
+        absorbing = tap_plan is not None and sink.offers_taps()
         if optimizer is not None and sink is not None and torch.is_grad_enabled():
-            offer = optimizer.begin_in_pass(depth, sink, t_fwd, t_bwd)
+            # (a tracking gradient this pass absorbs completes dL/ddepth at the taps: they need not wait for the element-list update)
+            offer = optimizer.begin_in_pass(depth, sink, t_fwd, t_bwd, exclude=("tracking",) if absorbing else ())
             if offer is not None:
                 adam, ticket = offer
         # frame sharding with an early halo exchange (FrameShard.enable_early_halo): the dense dL/ddepth exists at the end of THIS
@@ -714,27 +723,29 @@ class FlowLossFused:
             early = None  # (the early DENSE exchange is not combined with the in-pass Adam update; the ghost halo is: it reads the boundary frames only)
         if early is not None:
             sink.request_early_dense(early.unit_flag(depth.device))
-        # the tap exchange with the tracking loss (its static taps were registered with the parameter by TrackLossFused): this pass leaves the
-        # depth at every tap in the plan's compact image and absorbs the tracking gradient a look-ahead evaluation left in the sink
-        tap_plan = tap_plan_of(depth) if (sink is not None and torch.is_grad_enabled() and depth.requires_grad) else None
-        if tap_plan is not None and packed is None and not all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (flow_fwd, flow_bwd, mask_fwd, mask_bwd)):
-            tap_plan = None  # (frame windows / unaligned flows: the pass that reads them in place has no tap variant)
         # (verified only while the version counter still vouches for the image: after a regular update the image was simply out of date, and
         # whoever sampled it did so before that update)
         # ... and at the first sampled step and every 64th only: the check costs the pass one more load per tap
         verify = (tap_plan is not None and tap_plan.sampled_now and ticket is None and (tap_plan.samples == 1 or tap_plan.samples % 64 == 0)
                   and tap_plan.image_valid_for(_root(depth)))
         taps = (None, None, None, None) if tap_plan is None else (tap_plan.chunk_base, tap_plan.pixel_in_frame, tap_plan.image, tap_plan.stale_flag if verify else None)
-        offered = tap_plan is not None and sink.offers_taps()
+        offered = absorbing
         loss = torch_ops().flow_loss(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, int(kind), float(delta),
-                                     sink, int(items), acc, *adam, *taps)
+                                     sink, int(items), acc, *adam, *taps, bool(absorbing and ticket is not None))
         if tap_plan is not None:
             counters["flow_tap_passes"] += 1
             counters["flow_tap_absorbs"] += int(offered and sink.tap_absorbed())
             if ticket is None and loss.requires_grad:
+                tap_plan.image_slots = tap_plan.slots
                 tap_plan.tag(_root(depth))  # depth as this pass read it: good until the parameter moves
+            elif ticket is not None:
+                # an in-pass Adam update: the image holds the updated depth except at the pixels other operators keep (the ticket's element
+                # list), which step() updates afterwards — it becomes valid, read around those, when step() has finished (FusedAdam.step)
+                tap_plan.invalidate()
+                tap_plan.image_slots = tap_plan.slots_reading_around(ticket[2])
+                tap_plan.pending_in_pass = True
             else:
-                tap_plan.invalidate()  # (an in-pass Adam update: the pixels other operators keep are updated after this pass)
+                tap_plan.invalidate()
             tap_plan.sampled_now = False
             if verify:
                 capturing = depth.is_cuda and torch.cuda.is_current_stream_capturing()
@@ -1138,9 +1149,29 @@ class TapPlan:
         self.stale_flag = torch.zeros((1,), dtype=torch.int32, device=plan[0].device)
         self.sampled_now = False  # the tracking loss of the current step sampled from the image: the coming flow pass verifies it
         self.samples = 0
+        self.image_slots = slots  # the slot table to sample the CURRENT image with (an in-pass Adam update leaves one with holes: slots_reading_around)
+        self.pending_in_pass = False  # the image was left by an in-pass Adam update whose step() has not finished: FusedAdam.step tags it
 
     def tag(self, root: Tensor) -> None:
         self._tag = (weakref.ref(root), root.untyped_storage(), root.data_ptr(), root._version)
+        self.pending_in_pass = False
+
+    def slots_reading_around(self, kept: Optional[Tensor]) -> Tensor:
+        """The slot table for sampling from an image an IN-PASS Adam update left: the taps at the pixels that update keeps for the
+        element-list update (``kept``: sorted flat indices — the Procrustes samples and taps) are flagged to be read from the depth image
+        (bit 29); the image holds their pre-update value.  Built once per kept set."""
+        if kept is None or kept.numel() == 0:
+            return self.slots
+        key = (id(kept), kept._version)
+        hit = self.__dict__.get("_around")
+        if hit is None or hit[0] != key:
+            dense_rank = torch.isin(self.pixels, kept)  # per tap (rank): is its pixel kept?
+            slots = self.slots.clone()
+            valid = slots >= 0
+            ranks = (slots[valid] & 0x1FFFFFFF).to(torch.int64)
+            slots[valid] = slots[valid] | (dense_rank[ranks].to(torch.int32) << 29)
+            hit = self.__dict__["_around"] = (key, kept, slots.contiguous())
+        return hit[2]
 
     def invalidate(self) -> None:
         self._tag = None
@@ -1259,7 +1290,7 @@ class TrackLossFused:
                 root.__dict__["_fm_tap_plan"] = tap_plan
                 taps = (tap_plan.slots, None, tap_plan.shared_ranks)
                 if use_tap_image and tap_plan.image_valid_for(root):
-                    taps = (tap_plan.slots, tap_plan.image, tap_plan.shared_ranks)
+                    taps = (tap_plan.image_slots, tap_plan.image, tap_plan.shared_ranks)
                     tap_plan.note_sampled()
                     counters["track_tap_samples"] += 1
                 else:

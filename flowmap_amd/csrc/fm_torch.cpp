@@ -856,7 +856,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
                         const c10::intrusive_ptr<DepthSink>& sink, int64_t items, const OptTensor& acc_work, const OptTensor& exp_avg_o,
                         const OptTensor& exp_avg_sq_o, const OptTensor& touched_o, int64_t adam_step, std::vector<double> adam,
                         const OptTensor& adam_flag_o, const OptTensor& tap_chunk_base_o, const OptTensor& tap_pixel_o, const OptTensor& tap_depth_o,
-                        const OptTensor& tap_stale_o, bool grad_enabled, bool park) {
+                        const OptTensor& tap_stale_o, bool tap_require, bool grad_enabled, bool park) {
     check_device({&depth_in, &k_in, &kinv_in, &t_fwd_in, &t_bwd_in, &flow_fwd_in, &flow_bwd_in, &mask_fwd_in, &mask_bwd_in, &norm});
     TORCH_CHECK(flow_fwd_in.scalar_type() == at::kFloat && flow_bwd_in.scalar_type() == at::kFloat && mask_fwd_in.scalar_type() == at::kFloat &&
                     mask_bwd_in.scalar_type() == at::kFloat,
@@ -926,6 +926,9 @@ struct FlowLossFused : public Function<FlowLossFused> {
     }
     FlowLaunch run = flow_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, items, need,
                                  depth_in.requires_grad(), opt(acc_work), exp_avg, exp_avg_sq, touched, adam_step, adam, taps);
+    // (the caller left the tracking loss's taps to this pass's in-pass Adam update: it must really have absorbed their gradient)
+    TORCH_CHECK(!tap_require || taps.grad.defined(), "flowmap_amd: the flow pass was to absorb the tracking loss's gradient at its taps (tap exchange + in-pass "
+                "Adam) but the step's DepthSink offers none that fits");
     if (taps.grad.defined()) sink->tap_absorbed = true;
     ctx->saved_data["tap_absorbed"] = taps.grad.defined();
     ctx->saved_data["in_pass_adam"] = in_pass_adam;
@@ -952,7 +955,7 @@ struct FlowLossFused : public Function<FlowLossFused> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    variable_list out(28);
+    variable_list out(29);
     if (!grads[0].defined()) return out;
     const auto saved = ctx->get_saved_variables();
     const Tensor &depth = saved[0], &k = saved[1], &t_fwd = saved[3];
@@ -1389,12 +1392,12 @@ static Tensor flow_loss_op(const Tensor& depth, const Tensor& k, const Tensor& k
                            int64_t kind, double delta, const OptSink& sink, int64_t items, const OptTensor& acc_work, const OptTensor& exp_avg,
                            const OptTensor& exp_avg_sq, const OptTensor& touched, int64_t adam_step, std::vector<double> adam,
                            const OptTensor& adam_flag, const OptTensor& tap_chunk_base, const OptTensor& tap_pixel, const OptTensor& tap_depth,
-                           const OptTensor& tap_stale) {
+                           const OptTensor& tap_stale, bool tap_require) {
   auto s = sink_of(sink);
   // park dL/ddepth in the sink only when both pose tensors come from the fit that armed it: that node then runs after this one
   const bool park = s && s->fit_node != nullptr && reaches(t_fwd.grad_fn(), s->fit_node, 3) && reaches(t_bwd.grad_fn(), s->fit_node, 3);
   return FlowLossFused::apply(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, s, items, acc_work,
-                              exp_avg, exp_avg_sq, touched, adam_step, adam, adam_flag, tap_chunk_base, tap_pixel, tap_depth, tap_stale,
+                              exp_avg, exp_avg_sq, touched, adam_step, adam, adam_flag, tap_chunk_base, tap_pixel, tap_depth, tap_stale, tap_require,
                               at::GradMode::is_enabled(), park);
 }
 static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, const Tensor& k, const Tensor& kinv, const Tensor& ext, const Tensor& xy,
@@ -1495,7 +1498,7 @@ TORCH_LIBRARY(flowmap_amd, m) {
       "flow_loss(Tensor depth, Tensor k, Tensor kinv, Tensor t_fwd, Tensor t_bwd, Tensor flow_fwd, Tensor flow_bwd, Tensor mask_fwd, Tensor mask_bwd, "
       "Tensor norm, Tensor? packed, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int items, Tensor? acc_work, "
       "Tensor? exp_avg, Tensor? exp_avg_sq, Tensor? touched, int adam_step, float[] adam, Tensor? adam_flag, Tensor? tap_chunk_base=None, "
-      "Tensor? tap_pixel=None, Tensor? tap_depth=None, Tensor? tap_stale=None) -> Tensor",
+      "Tensor? tap_pixel=None, Tensor? tap_depth=None, Tensor? tap_stale=None, bool tap_require=False) -> Tensor",
       fmt::flow_loss_op);
   m.def(
       "track_loss(Tensor depth, Tensor k, Tensor kinv, Tensor ext, Tensor xy, Tensor vis, Tensor seg, Tensor blocks, Tensor tiles, int[] counts, "

@@ -110,10 +110,10 @@ __device__ __forceinline__ bool track_sample(const TrackGeom& g, const float* de
 // (clamped point); `store` masks the lanes beyond the segment's points.  Same arithmetic per item as track_sample (a tap outside
 // the image contributes an exact zero instead of being skipped).
 // tap_slot / tap_depth (fm_track_loss_fused_fwd_taps): the four tap depths of point idx come from the compact tap image the flow pass
-// leaves behind — tap_depth[rank], rank = the low 30 bits of tap_slot[4·idx + k] (bit 30: the pixel is shared with another track point);
-// slot -1: a tap that contributes nothing; slot <= -2: read the depth image after all (a pixel another operator updates after the flow
-// pass) — instead of four cold lines of the depth images.
-constexpr int kTapRank = 0x3fffffff, kTapShared = 0x40000000;
+// leaves behind — tap_depth[rank], rank = the low 29 bits of tap_slot[4·idx + k]; bit 30: the pixel is shared with another track point;
+// bit 29: read the depth image after all (a pixel another operator updates after the flow pass); slot -1: a tap that contributes
+// nothing — instead of four cold lines of the depth images.
+constexpr int kTapRank = 0x1fffffff, kTapDense = 0x20000000, kTapShared = 0x40000000;
 template <int N>
 __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const float* depth, int depth_frame0, const float* kinv, const float* ext,
                                                   const int (&frame)[N], const size_t (&idx)[N], const bool (&want)[N], bool store, int p_count,
@@ -154,9 +154,9 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const int sa = sl[2 * r], sb = sl[2 * r + 1];
-          if (sa < -1 || sb < -1) {  // (a pixel another operator updates after the flow pass: read the depth image)
-            z[n][2 * r] = sa >= 0 ? tap_depth[sa & kTapRank] : (sa < -1 ? d[a[2 * r]] : 0.f);
-            z[n][2 * r + 1] = sb >= 0 ? tap_depth[sb & kTapRank] : (sb < -1 ? d[a[2 * r + 1]] : 0.f);
+          if ((sa >= 0 && (sa & kTapDense)) || (sb >= 0 && (sb & kTapDense))) {  // (a pixel another operator updates after the flow pass: read the depth image)
+            z[n][2 * r] = sa < 0 ? 0.f : (sa & kTapDense) ? d[a[2 * r]] : tap_depth[sa & kTapRank];
+            z[n][2 * r + 1] = sb < 0 ? 0.f : (sb & kTapDense) ? d[a[2 * r + 1]] : tap_depth[sb & kTapRank];
           } else if (sa >= 0) {
             float2 v;
             __builtin_memcpy(&v, tap_depth + (sa & kTapRank), sizeof(float2));
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
             const float2 qq = reinterpret_cast<const float2*>(g.xy)[is];
             const Taps tp = bilinear_taps(qq.x, qq.y, g.height, g.width);
             const int4 s4 = reinterpret_cast<const int4*>(smp.tap_slot)[is];
-            const int sl[4] = {s4.x, s4.y, s4.z, s4.w};
+            int sl[4] = {s4.x, s4.y, s4.z, s4.w};
             Mat3 ki;
             load_mat3(smp.kinv + (size_t)(start + fs) * 9, ki);
             float val[4];
@@ -594,6 +594,7 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
               ray_dir(ki, pixel_center(tap_col(tp, k), g.width), pixel_center(tap_row(tp, k), g.height), ray);
               val[k] = tp.w[k] * (gxyz[0] * ray[0] + gxyz[1] * ray[1] + gxyz[2] * ray[2]);
               own[k] = sl[k] >= 0 && !(sl[k] & kTapShared);
+              sl[k] &= kTapRank;
             }
 #pragma unroll
             for (int r = 0; r < 2; ++r) {  // the two taps of an image row have neighbouring ranks: one 8-byte store

@@ -118,7 +118,7 @@ class FusedAdam(torch.optim.Optimizer):
     def in_pass_pending(self, param: torch.Tensor) -> bool:
         return param in self._in_pass
 
-    def begin_in_pass(self, depth: torch.Tensor, sink, t_fwd: torch.Tensor, t_bwd: torch.Tensor):
+    def begin_in_pass(self, depth: torch.Tensor, sink, t_fwd: torch.Tensor, t_bwd: torch.Tensor, exclude=()):
         """Called by the fused flow loss.  -> None when the update of the parameter behind ``depth`` cannot run inside its
         pass (the step then runs as usual), else ``(operator arguments, ticket)`` with the operator arguments
         (exp_avg, exp_avg_sq, touched mask, step number, [lr, beta1, beta2, eps]).  NOTHING is committed here: the caller hands
@@ -147,7 +147,7 @@ class FusedAdam(torch.optim.Optimizer):
         if "procrustes" not in registry:
             return None  # the fit's backward is not planned (yet): the pixels it reads are not known
         halo = tuple(param.__dict__.get("_fm_halo_frames", ()))  # frame sharding: frames whose gradient is complete only after the exchange
-        union = _ops.touched_elements(depth, halo)
+        union = _ops.touched_elements(depth, halo, exclude)  # (``exclude``: consumers whose gradient the pass itself absorbs — the tap exchange)
         if union is None:
             return None
         elements, mask = union
@@ -196,7 +196,14 @@ class FusedAdam(torch.optim.Optimizer):
                     hyper = (float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), 0.0)
                     for frame in halo:  # frame sharding: the frames shared with a neighbour, dense, from the exchanged (summed) gradient
                         torch_ops().adam_step(p[frame], grad[frame], state["exp_avg"][frame], state["exp_avg_sq"][frame], step, None, *hyper)
+                    if sink.tap_absorbed() and not sink.tap_confirmed():
+                        raise RuntimeError("flowmap_amd.FusedAdam: the flow pass applied the depth update with the tracking loss's gradient absorbed at its taps "
+                                           "(the tap exchange), but that tracking loss never reached backward(): the update of those pixels used a gradient "
+                                           "that was not part of the loss.  Evaluate the losses the same way every step, or set flowmap_amd._ops.use_tap_exchange = False.")
                     torch_ops().adam_step_elements(p, grad, state["exp_avg"], state["exp_avg_sq"], elements, step, *hyper)
+                    tap_plan = p.__dict__.get("_fm_tap_plan")
+                    if tap_plan is not None and tap_plan.pending_in_pass:
+                        tap_plan.tag(p)  # the compact tap image the pass left is the parameter's as of now (read around the elements just updated)
                     every = self.verify_unit_upstream_every
                     first = self.counters["in_pass_updates"] == 1  # a loop that scales its loss does so from its first step: one read there catches it at once
                     if every and (first or step % every == 0) and int(self._scaled_flags[p.device].item()) != 0:

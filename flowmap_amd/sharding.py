@@ -328,7 +328,7 @@ class FrameShard:
         e["ghost"] = {
             "flows": {"prev": None if flows_prev is None else tuple(t.to(dev, torch.float32).contiguous() for t in flows_prev),
                       "next": None if flows_next is None else tuple(t.to(dev, torch.float32).contiguous() for t in flows_next)},
-            "pose_out": {s_: pose() for s_ in e["send"]}, "pose_in": {s_: pose() for s_ in e["send"]}, "context": None,
+            "pose_in": {s_: pose() for s_ in e["send"]}, "context": None,
         }
         return True
 
@@ -374,18 +374,11 @@ class FrameShard:
             # pair's camera a -> a+1 (its forward term of that pair), towards rank+1 my last pair's camera b -> b−1 (its backward term)
             if ghost["context"] is None:
                 raise RuntimeError("flowmap_amd.FrameShard: the ghost halo needs the flow loss's poses (a fused LossFlow on this shard's depth parameter)")
-            t_fwd, t_bwd = ghost["context"][0], ghost["context"][1]
-            with torch.no_grad():
-                if "prev" in e["send"]:
-                    ghost["pose_out"]["prev"].copy_(t_fwd.detach()[0, 0])
-                if "next" in e["send"]:
-                    ghost["pose_out"]["next"].copy_(t_bwd.detach()[0, -1])
-                if self.proxy:  # no peer: the rank's own boundary poses stand in for the neighbours'
-                    if "prev" in e["send"]:
-                        ghost["pose_in"]["prev"].copy_(t_bwd.detach()[0, 0])
-                    if "next" in e["send"]:
-                        ghost["pose_in"]["next"].copy_(t_fwd.detach()[0, -1])
-            pairs = [(ghost["pose_out"][side], ghost["pose_in"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
+            t_fwd, t_bwd = ghost["context"][0].detach(), ghost["context"][1].detach()
+            out = {"prev": t_fwd[0, 0], "next": t_bwd[0, -1]}  # (contiguous 4x4 views of the fit's outputs: sent where they lie)
+            if self.proxy:  # no peer: the rank's own boundary poses stand in for the neighbours'
+                ghost["pose_in"] = {"prev": t_bwd[0, 0], "next": t_fwd[0, -1]}
+            pairs = [(out[side], ghost["pose_in"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
         else:
             pairs = [(e["send"][side], e["recv"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
         e["inflight"] = self._exchange(pairs)

@@ -402,10 +402,10 @@ int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first,
 
 /* fm_track_loss_fused_fwd (whole video local) on the static tap set (fm_flow_taps above; loss_tracking.py:28-61 /
  * projection.py:266-272 unchanged in value):
- *   tap_slot (total,4) int32: tap k of track point i is the tap of rank (tap_slot[4i+k] & 0x3fffffff); bit 30: another track point shares
- *     the pixel; -1: the tap contributes nothing; <= -2: the pixel is updated by another operator after the flow pass;
+ *   tap_slot (total,4) int32: tap k of track point i is the tap of rank (tap_slot[4i+k] & 0x1fffffff); bit 30: another track point shares
+ *     the pixel; bit 29: the pixel is updated by another operator after the flow pass; -1: the tap contributes nothing;
  *   tap_depth (M + 1 readable) or NULL: with it, the tap depths are read from the compact image fm_flow_loss_fused_taps left behind —
- *     tap_depth[rank] — instead of the depth image (slots <= -2 read `depth` after all);
+ *     tap_depth[rank] — instead of the depth image (slots with bit 29 read `depth` after all);
  *   tap_grad (M) out or NULL, with the plan of fm_track_scatter_plan sorted as fm_depth_gather takes it (plan_count = M): the UNSCALED
  *     dL/ddepth of the tracking loss at each tap, for the `grad` member of fm_flow_taps (needs gws).  shared_ranks (shared_count) int32 or
  *     NULL: the ranks of the taps with more than one plan entry — with the list (and tap_slot) the pair kernel stores the gradient of

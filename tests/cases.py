@@ -1251,7 +1251,7 @@ def case_threads_and_hooks(dev):
         flowmap_amd.set_lazy_surfaces(False)
 
 
-def case_in_pass_adam(dev, steps=40, track_after=6, lr=1e-3, softmin=False):
+def case_in_pass_adam(dev, steps=40, track_after=6, lr=1e-3, softmin=False, exchange=False):
     """FusedAdam.fuse_depth_update: the depth update applied inside the fused flow pass (fm_flow_loss_fused_adam) + the
     element-list update of the touched pixels (fm_adam_step_elements) walk the same trajectory as torch.optim.Adam on the
     same losses (model_wrapper_overfit.py:104-105) — flow loss from step 0, tracking loss switched on later
@@ -1265,6 +1265,10 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=1e-3, softmin=False):
 
     f, h, w = 5, 24, 32
     trajectories, engaged = {}, 0
+    # ``exchange``: with the tap exchange forced on at this size — once the tracking loss runs, the flow pass absorbs its gradient, updates its
+    # taps in the pass like any other pixel, and the next evaluation samples the image the update left (around the Procrustes pixels)
+    min_bytes, counted = _ops.tap_exchange_min_bytes, dict(_ops.counters)
+    _ops.tap_exchange_min_bytes = 0 if exchange else 1 << 60
     # softmin: the reference's default intrinsics (config/model/intrinsics/softmin.yaml) — the sweep reads random pixels of
     # frames 0 / 1, new every step, then hands over to a regressed focal length; both phases and the hand-over are crossed
     intrinsics = IntrinsicsSoftminCfg("softmin", 200, 0.5, 2.0, 8, RegressionCfg(steps // 2, 5)) if softmin else None
@@ -1298,6 +1302,13 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=1e-3, softmin=False):
     finally:
         flowmap_amd.set_lazy_surfaces(False)
         _ops.use_grad_arena = True
+        _ops.tap_exchange_min_bytes = min_bytes
+    if exchange:
+        tracked_steps = steps - track_after
+        # per mode: the first tracked step runs in the plain order, every later one ahead of the flow pass; with the in-pass update the image
+        # is sampled from the step after the first absorbing one on, with the separate updates never (the parameter moves after the pass)
+        assert _ops.counters["flow_tap_absorbs"] - counted["flow_tap_absorbs"] == 4 * (tracked_steps - 1), _ops.counters
+        assert _ops.counters["track_tap_samples"] - counted["track_tap_samples"] >= tracked_steps - 3, _ops.counters
     assert engaged >= steps - 3, engaged  # the plan exists from the third step on
     assert trajectories["fused_dense"][1].counters["sparse_updates"] == 0
     for mode in ("fused", "in_pass"):  # the weight logits: element-list update from the first planned step on

@@ -1280,7 +1280,7 @@ static int sim_track_points(const float* depth, int depth_frame0, const float* k
         float z = d[tr * width + tc];
         if (tap_slot) {
           const int sl = tap_slot[idx * 4 + k];
-          z = sl >= 0 ? tap_depth[sl & 0x3fffffff] : (sl < -1 ? z : 0.f);
+          z = sl < 0 ? 0.f : ((sl & 0x20000000) ? z : tap_depth[sl & 0x1fffffff]);
         }
         for (int a = 0; a < 3; ++a) xyz[a] += (ray[a] * z) * t.w[k];
         hh[0] += z * ut * t.w[k];

@@ -433,6 +433,11 @@ def test_ghost_terms(kind):
 
 
 @pytest.mark.gpu
+def test_depth_adam_update_inside_the_flow_pass_with_the_tap_exchange():
+    cases.case_in_pass_adam(DEV, steps=60, lr=3e-4, exchange=True)
+
+
+@pytest.mark.gpu
 def test_tap_exchange():
     cases.case_tap_exchange(DEV)
 

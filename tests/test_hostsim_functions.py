@@ -152,6 +152,10 @@ def test_ghost_terms(kind):
     cases.case_ghost_terms("cpu", kind)
 
 
+def test_depth_adam_update_inside_the_flow_pass_with_the_tap_exchange():
+    cases.case_in_pass_adam("cpu", steps=24, exchange=True)
+
+
 def test_tap_exchange():
     cases.case_tap_exchange("cpu")
 
