@@ -871,6 +871,11 @@ struct FlowLossFused : public Function<FlowLossFused> {
     const Tensor mask_fwd = has_packed ? mask_fwd_in : image_stack(mask_fwd_in, "forward mask").t, mask_bwd = has_packed ? mask_bwd_in : image_stack(mask_bwd_in, "backward mask").t;
     TORCH_CHECK(depth.dim() == 4, "flowmap_amd: depth must be (batch, frame, height, width)");
     const int64_t b = depth.size(0), f = depth.size(1), h = depth.size(2), w = depth.size(3);
+    // the C ABI's hard limits (include/flowmap_hip.h: fm_flow_loss_fused), named here instead of surfacing as "invalid argument"
+    TORCH_CHECK(b * f <= 65535, "flowmap_amd: the fused flow loss handles at most 65 535 source frames per call (batch x frames = ", b * f,
+                "): split the batch");
+    TORCH_CHECK(h * w < (int64_t(1) << 30), "flowmap_amd: the fused flow loss indexes pixels inside a frame with 32 bits: height x width = ", h * w,
+                " must stay below 2^30 (frames x height x width is not limited)");
     TORCH_CHECK(flow_fwd.sizes() == at::IntArrayRef({b, f - 1, h, w, 2}) && flow_bwd.sizes() == flow_fwd.sizes(),
                 "flowmap_amd: flow shape does not match depth");
     TORCH_CHECK(mask_fwd.sizes() == at::IntArrayRef({b, f - 1, h, w}) && mask_bwd.sizes() == mask_fwd.sizes(),

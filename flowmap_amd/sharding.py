@@ -325,7 +325,13 @@ class FrameShard:
                                  f"neighbour: flows_{side} (the neighbouring pair's flow and mask) is needed")
         dev = depth_param.device
         pose = lambda: torch.eye(4, dtype=torch.float32, device=dev)  # noqa: E731
+        # what the ghost terms are evaluated from, copied out of the step's own tensors by ONE launch per step (start_early_halo) into storage
+        # that outlives the step — a step replayed as hipGraphs keeps its intermediates in the graphs' private pool, and nothing here
+        # holds on to those: [my first pair's forward pose | my last pair's backward pose | (proxy stand-ins: first backward, last forward) | K | K⁻¹]
+        pack = torch.zeros((4 * 16 + 2 * 9,), dtype=torch.float32, device=dev)
         e["ghost"] = {
+            "pack": pack, "pose_out": {"prev": pack[0:16].view(4, 4), "next": pack[16:32].view(4, 4)},
+            "proxy_in": {"prev": pack[32:48].view(4, 4), "next": pack[48:64].view(4, 4)}, "k": pack[64:73].view(3, 3), "kinv": pack[73:82].view(3, 3),
             "flows": {"prev": None if flows_prev is None else tuple(t.to(dev, torch.float32).contiguous() for t in flows_prev),
                       "next": None if flows_next is None else tuple(t.to(dev, torch.float32).contiguous() for t in flows_next)},
             "pose_in": {s_: pose() for s_ in e["send"]}, "context": None,
@@ -353,7 +359,11 @@ class FrameShard:
             return
         ghost = e.get("ghost")
         if ghost is not None and context is not None:
-            ghost["context"] = context
+            t_fwd, t_bwd, k, kinv, norm, kind, delta = context
+            with torch.no_grad():  # (one launch; inside a capture it becomes a node of the forward graph)
+                torch.cat([t_fwd.detach()[0, 0].reshape(-1), t_bwd.detach()[0, -1].reshape(-1), t_bwd.detach()[0, 0].reshape(-1),
+                           t_fwd.detach()[0, -1].reshape(-1), k.detach()[0, 0].reshape(-1), kinv.detach()[0, 0].reshape(-1)], out=ghost["pack"])
+            ghost["context"] = (norm, kind, delta)
         if e.get("stash_only", False):  # GraphedShardedStep's warm-up and captures: nothing is sent; the step sends it between its two replays
             e["stashed"] = dense_grad
             return
@@ -374,11 +384,9 @@ class FrameShard:
             # pair's camera a -> a+1 (its forward term of that pair), towards rank+1 my last pair's camera b -> b−1 (its backward term)
             if ghost["context"] is None:
                 raise RuntimeError("flowmap_amd.FrameShard: the ghost halo needs the flow loss's poses (a fused LossFlow on this shard's depth parameter)")
-            t_fwd, t_bwd = ghost["context"][0].detach(), ghost["context"][1].detach()
-            out = {"prev": t_fwd[0, 0], "next": t_bwd[0, -1]}  # (contiguous 4x4 views of the fit's outputs: sent where they lie)
             if self.proxy:  # no peer: the rank's own boundary poses stand in for the neighbours'
-                ghost["pose_in"] = {"prev": t_bwd[0, 0], "next": t_fwd[0, -1]}
-            pairs = [(out[side], ghost["pose_in"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
+                ghost["pose_in"] = ghost["proxy_in"]
+            pairs = [(ghost["pose_out"][side], ghost["pose_in"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
         else:
             pairs = [(e["send"][side], e["recv"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
         e["inflight"] = self._exchange(pairs)
@@ -410,7 +418,7 @@ class FrameShard:
         ghost = e.get("ghost")
         with _guard(depth_grad.device):  # the neighbours' dense parts, then their sparse parts: one launch each for both boundaries
             if ghost is not None:
-                t_fwd, t_bwd, k, kinv, norm, kind, delta = ghost["context"]
+                norm, kind, delta = ghost["context"]
                 depth = e["param"].detach()
                 flows = dict(ghost["flows"])
                 if self.proxy:  # (stand-ins: the rank's own boundary pairs)
@@ -426,7 +434,7 @@ class FrameShard:
                      ptr(first[1]) if first else None, ptr(depth_grad[0]) if first else None,
                      ptr(depth[-1]) if last else None, ptr(ghost["pose_in"].get("next")) if last else None, ptr(last[0]) if last else None,
                      ptr(last[1]) if last else None, ptr(depth_grad[-1]) if last else None,
-                     ptr(kinv.detach()[0, 0]), ptr(k.detach()[0, 0]), ptr(norm), None, h, w, int(kind), float(delta), w / scale, h / scale, stream_for(depth_grad))
+                     ptr(ghost["kinv"]), ptr(ghost["k"]), ptr(norm), None, h, w, int(kind), float(delta), w / scale, h / scale, stream_for(depth_grad))
             else:
                 call("fm_halo_add", ptr(depth_grad), h * w, frames, ptr(e["recv"].get("prev")), ptr(e["recv"].get("next")), stream_for(depth_grad))
             call("fm_halo_scatter", ptr(depth_grad), h * w, frames, ptr(e["theirs"]["prev"]), ptr(e["delta_in"].get("prev")), cnt("prev"),

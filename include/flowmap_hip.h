@@ -64,6 +64,13 @@ int fm_abi_version(void);
  *   packed: NULL, or flows + masks re-laid-out by fm_flow_pack_inputs — then flow_* / mask_*
  *          are not read (may be NULL).  Same bytes, one stream instead of six (needs W % 4 == 0).
  *   items_per_thread: tuning knob (<=0 -> default).
+ * Hard limits (return 1, "invalid argument", when exceeded — the host layer names the limit in its message): batch·frames <= 65 535
+ * (one grid row per source frame), H·W < 2^30 (32-bit pixel indices inside a frame; base pointers are 64-bit, so frames·H·W is
+ * unlimited: configs[4] whole, 2.5e9 elements, runs), W % 4 == 0 and 16-byte aligned buffers for the 16-byte path (else the scalar
+ * path runs).  Determinism: dL/ddepth is written once per element (bit-reproducible); the 13 per-(frame, direction) sums meet in
+ * `acc` through fp64 ATOMICS across workgroups, so the loss and the pose / intrinsics gradients derived from them can differ in their
+ * last bits from run to run (tests: 1e-6 relative); the tracking loss's sums (fm_track_loss_*) are reduced in a fixed order and are
+ * bit-reproducible.
  */
 int fm_flow_loss_fused(const float* depth, const float* k, const float* kinv, const float* t_fwd, const float* t_bwd,
                        const float* flow_fwd, const float* flow_bwd, const float* mask_fwd, const float* mask_bwd,
