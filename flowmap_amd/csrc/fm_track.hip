@@ -622,6 +622,8 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
     clk[4] = c_end - c_epi;
     clk[5] = c_end - c_begin;
     clk[6] = f;
+    // where the wave ran: HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID, so that the host can count resident waves per SIMD
+    clk[7] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     const unsigned wid = work;
     if (threadIdx.x == 0 && wid < (unsigned)kTrackClockWaves) {
 #pragma unroll

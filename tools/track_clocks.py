@@ -36,5 +36,14 @@ print(f"{len(out)} waves; median / p90 per wave in us (100 MHz clock); targets p
 for i, name in enumerate(names):
     us = out[:, i] / 100.0
     print(f"  {name:28s} {np.median(us):8.2f} {np.percentile(us, 90):8.2f}")
+hw, xcc = out[:, 7] & 0xFFFFFFFF, (out[:, 7] >> 32) & 0xF
+simd = (xcc << 16) | (((hw >> 13) & 7) << 12) | (((hw >> 12) & 1) << 11) | (((hw >> 8) & 15) << 4) | ((hw >> 4) & 3)  # (XCC, SE, SH, CU, SIMD)
+per_simd = np.unique(simd, return_counts=True)[1]
+per_cu = np.unique(simd >> 4, return_counts=True)[1]
+print(f"  waves per SIMD that ran any: {dict(zip(*np.unique(per_simd, return_counts=True)))} over {len(per_simd)} SIMDs; waves per CU: {dict(zip(*np.unique(per_cu, return_counts=True)))} over {len(per_cu)} CUs")
+terms = out[:, 2] / 100.0
+for n in sorted(set(per_simd)):
+    sel = np.isin(simd, np.unique(simd)[per_simd == n])
+    print(f"    SIMDs with {n} waves: terms median {np.median(terms[sel]):.1f} us, whole wave median {np.median(out[sel, 5]) / 100.0:.1f} us")
 per_target = out[:, 1:4].sum(axis=1) / np.maximum(out[:, 6], 1) / 100.0
 print(f"  per target iteration         {np.median(per_target):8.3f} us")
