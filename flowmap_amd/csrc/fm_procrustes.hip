@@ -1106,6 +1106,9 @@ __global__ void __launch_bounds__(256, FM_DENSE_LATER_BLOCKS) procrustes_dense_b
 #ifndef FM_DENSE_FUSED_UNROLL
 #define FM_DENSE_FUSED_UNROLL 4
 #endif
+#ifndef FM_DENSE_FUSED_QUAD  // 1: four adjacent later pixels per thread (16-byte loads / stores); 0: round 3's one pixel per thread (A/B: tools/dense_microbench.py)
+#define FM_DENSE_FUSED_QUAD 1
+#endif
 #ifndef FM_DENSE_FUSED_SKIP  // timing experiments only (tools/dense_microbench.py): 1 = plain store for the later pixel (racy), 2 = no flush, 4 = no taps
 #define FM_DENSE_FUSED_SKIP 0
 #endif
@@ -1141,33 +1144,21 @@ __global__ void __launch_bounds__(256, FM_DENSE_FUSED_BLOCKS) procrustes_dense_b
   const double unscale = ldexp(1.0, ex - kFusedUnitBits);
   stage_depth_window(c, win);
   for (int i = threadIdx.x; i < kFusedWinH * kFusedWinW; i += 256) iacc[i] = 0ull;
-  const int col = c.tx0 + (threadIdx.x & (kTileW - 1));
-  int row = c.ty0 + threadIdx.x / kTileW;
-  const bool live = col < p.width;
-  const float u = center_fast(col, c.fw, c.rcp_w);
   float* gw_out = p.grad_weights ? p.grad_weights + c.pair * n : nullptr;
   float* gd_l = p.grad_depth ? p.grad_depth + (c.fe + 1) * n : nullptr;
   float* gd_e = p.grad_depth ? p.grad_depth + c.fe * n : nullptr;
-  DenseRaw next = {};
-  if (live && row < p.height) next = dense_load(c, row * p.width + col);
-  __syncthreads();
-#pragma unroll FM_DENSE_FUSED_UNROLL
-  for (int k = 0; k < kRowsPerThread; ++k, row += 256 / kTileW) {
-    if (!live || row >= p.height) break;
-    const int idx = row * p.width + col;
-    const DenseRaw cur = next;
-    if (k + 1 < kRowsPerThread && row + 256 / kTileW < p.height) next = dense_load(c, idx + (256 / kTileW) * p.width);
-    const float v = center_fast(row, c.fh, c.rcp_h);
+  // One later pixel's share of the backward: dL/dweights (returned), its own dL/ddepth (one float atomic: frame f receives the later
+  // role of pair f-1 and the tap role of pair f in the same launch) and its four tap gradients (LDS image, or memory when they do not fit).
+  auto one_pixel = [&](const DenseRaw& cur, float u, float v, int idx) -> float {
     const DensePixel px = dense_pixel(c, win, cur, u, v);
     float tv[3], gc[3], sv[3], gw;
     dense_bwd_t(cst, px.g, tv, gc);
     dense_bwd_s(cst, px.h, tv, gc, sv, gw);
     if (c.sens != 0.f) gw *= c.sens * px.w * (1.f - px.w);  // d sigmoid(s·x)/dx
-    if (gw_out) gw_out[idx] = gw;
-    if (!gd_l) continue;
+    if (!gd_l) return gw;
     if (FM_DENSE_FUSED_SKIP & 1) gd_l[idx] += px.w * fmaf(sv[0], u, fmaf(sv[1], v, sv[2]));
     else atomicAdd(gd_l + idx, px.w * fmaf(sv[0], u, fmaf(sv[1], v, sv[2])));
-    if (FM_DENSE_FUSED_SKIP & 4) continue;
+    if (FM_DENSE_FUSED_SKIP & 4) return gw;
     // β = w·t = K⁻ᵀ_e·dL/dq; a tap's value is w_k·(β·[u_k, v_k, 1]) with w_k <= 1 and u_k, v_k in (0, 1): below |β0| + |β1| + |β2|
     const float b0 = px.w * tv[0], b1 = px.w * tv[1], b2 = px.w * tv[2];
     const float bsum = (fabsf(b0) + fabsf(b1)) + fabsf(b2);
@@ -1190,7 +1181,59 @@ __global__ void __launch_bounds__(256, FM_DENSE_FUSED_BLOCKS) procrustes_dense_b
         if (val != 0.f) atomicAdd(gd_e + (size_t)(px.taps.y0 + (t >> 1)) * p.width + (px.taps.x0 + (t & 1)), val);
       }
     }
+    return gw;
+  };
+#if FM_DENSE_FUSED_QUAD
+  // Four horizontally adjacent later pixels per thread, as in the moments kernel: 16-byte loads of flow / weights / depth and one 16-byte
+  // store of dL/dweights — a quarter of the global load / store instructions (these tiled kernels are bound by the memory pipeline).
+  const bool vec = (p.width & 3) == 0;
+  const int col0 = c.tx0 + 4 * (threadIdx.x & (kTileW / 4 - 1));
+  int row = c.ty0 + threadIdx.x / (kTileW / 4);
+  const bool live = col0 < p.width;
+  float u4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) u4[j] = center_fast(col0 + j, c.fw, c.rcp_w);
+  DenseRaw4 next4 = {};
+  if (live && row < p.height) next4 = dense_load4(c, row * p.width + col0, col0, vec);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kQuadPasses; ++k, row += kQuadRows) {
+    if (!live || row >= p.height) break;
+    const int idx = row * p.width + col0;
+    const DenseRaw4 cur4 = next4;
+    if (k + 1 < kQuadPasses && row + kQuadRows < p.height) next4 = dense_load4(c, (row + kQuadRows) * p.width + col0, col0, vec);
+    const float v = center_fast(row, c.fh, c.rcp_h);
+    float gw4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (col0 + j >= p.width) break;
+      gw4[j] = one_pixel(dense_raw_of(cur4, j), u4[j], v, idx + j);
+    }
+    if (gw_out) {
+      if (vec) *reinterpret_cast<v4f*>(gw_out + idx) = v4f{gw4[0], gw4[1], gw4[2], gw4[3]};
+      else
+        for (int j = 0; j < 4 && col0 + j < p.width; ++j) gw_out[idx + j] = gw4[j];
+    }
   }
+#else
+  const int col = c.tx0 + (threadIdx.x & (kTileW - 1));
+  int row = c.ty0 + threadIdx.x / kTileW;
+  const bool live = col < p.width;
+  const float u = center_fast(col, c.fw, c.rcp_w);
+  DenseRaw next = {};
+  if (live && row < p.height) next = dense_load(c, row * p.width + col);
+  __syncthreads();
+#pragma unroll FM_DENSE_FUSED_UNROLL
+  for (int k = 0; k < kRowsPerThread; ++k, row += 256 / kTileW) {
+    if (!live || row >= p.height) break;
+    const int idx = row * p.width + col;
+    const DenseRaw cur = next;
+    if (k + 1 < kRowsPerThread && row + 256 / kTileW < p.height) next = dense_load(c, idx + (256 / kTileW) * p.width);
+    const float v = center_fast(row, c.fh, c.rcp_h);
+    const float gw = one_pixel(cur, u, v, idx);
+    if (gw_out) gw_out[idx] = gw;
+  }
+#endif
   if (!gd_e || (FM_DENSE_FUSED_SKIP & 2)) return;
   __syncthreads();
   // the window's sums -> dL/ddepth of the earlier frame (only cells inside the image ever receive a tap)
