@@ -1106,7 +1106,7 @@ __global__ void __launch_bounds__(256, FM_DENSE_LATER_BLOCKS) procrustes_dense_b
 #ifndef FM_DENSE_FUSED_UNROLL
 #define FM_DENSE_FUSED_UNROLL 4
 #endif
-#ifndef FM_DENSE_FUSED_QUAD  // 0 (default): one later pixel per thread; 1: four adjacent pixels per thread, 16-byte loads / stores — measured (profiles/r04_dense_microbench_quad.txt): 2.26 instead of 1.17 ms, the four taps of a lane's neighbouring pixels land 32 bytes apart in the LDS image (8-way bank conflicts of its 64-bit atomics)
+#ifndef FM_DENSE_FUSED_QUAD  // 0 (default): one later pixel per thread; 1: four adjacent pixels per thread, 16-byte loads / stores — measured (profiles/r04_dense_microbench_quad.txt): 2.26 instead of 1.17 ms (not investigated further; a lane's four pixels put their taps 32 bytes apart in the LDS image, which the 64-bit atomics of a wave then hit with bank conflicts)
 #define FM_DENSE_FUSED_QUAD 0
 #endif
 #ifndef FM_DENSE_FUSED_SKIP  // timing experiments only (tools/dense_microbench.py): 1 = plain store for the later pixel (racy), 2 = no flush, 4 = no taps
