@@ -1143,7 +1143,7 @@ class TapPlan:
         self.pixels, self.chunk_base, self.pixel_in_frame, self.slots, self.shared_ranks = plan[0], chunk_base, pixel_in_frame, slots, shared_ranks
         # (one value of padding: the tracking loss reads the two taps of an image row with one 8-byte load)
         self.image = torch.zeros((plan[0].numel() + 1,), dtype=torch.float32, device=plan[0].device)[: plan[0].numel()]
-        self._tag = None  # what the image was left for: (the parameter object, its storage — held, so its address is not reused —, data_ptr, version)
+        self._tag = None  # what the image was left for: (the parameter object — weakly —, its storage object's identity, data_ptr, version)
         # raised by the flow pass when a tap depth it reads differs from the image value the tracking loss of the same step sampled: the
         # parameter was edited behind its version counter (`param.data.clamp_()` ...).  Read at the first sampled step and every 64th.
         self.stale_flag = torch.zeros((1,), dtype=torch.int32, device=plan[0].device)
@@ -1153,7 +1153,8 @@ class TapPlan:
         self.pending_in_pass = False  # the image was left by an in-pass Adam update whose step() has not finished: FusedAdam.step tags it
 
     def tag(self, root: Tensor) -> None:
-        self._tag = (weakref.ref(root), root.untyped_storage(), root.data_ptr(), root._version)
+        # (nothing here keeps the parameter or its storage alive: a plan outlives models — it hangs on the track tensors)
+        self._tag = (weakref.ref(root), root.untyped_storage()._cdata, root.data_ptr(), root._version)
         self.pending_in_pass = False
 
     def slots_reading_around(self, kept: Optional[Tensor]) -> Tensor:
@@ -1178,7 +1179,7 @@ class TapPlan:
 
     def image_valid_for(self, root: Tensor) -> bool:
         tag = self._tag
-        if tag is None or tag[0]() is not root or tag[1]._cdata != root.untyped_storage()._cdata or tag[2:] != (root.data_ptr(), root._version):
+        if tag is None or tag[0]() is not root or tag[1] != root.untyped_storage()._cdata or tag[2:] != (root.data_ptr(), root._version):
             return False
         # a step replayed as a hipGraph runs no Python: whether depth moved between replays could not be checked
         return not (root.is_cuda and torch.cuda.is_current_stream_capturing())
