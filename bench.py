@@ -501,6 +501,14 @@ def main():
             optimizer.step()
         return loss
 
+    # Host housekeeping FIRST: a full cyclic-GC pass over torch's import-time objects costs ~50 ms (flowmap_amd/host.py: freeze_gc).  Until round 4 it
+    # ran between the warm-up steps and the timed region and left the GPU idle for that long: the timed region then started from an idle part's
+    # power state, not from the state the warm-up steps exist to reach — the flow kernel climbs from 0.78 to 0.95 ms over its first launches after an
+    # idle period and needs ~17 launches to settle (profiles/r04_driver_command_ramp.txt, r04_driver_command_gc_placement.txt).  Now nothing but
+    # the contract's barrier + synchronize separates precompute, warm-up and the timed steps.  (A/B: FLOWMAP_BENCH_GC=early|late = before / after warm-up.)
+    gc_when = os.environ.get("FLOWMAP_BENCH_GC", "first")
+    if gc_when == "first":
+        flowmap_amd.freeze_gc()
     # one-time precompute, outside warm-up and timing whatever W is: the first step packs the constant
     # flows / masks and reduces the valid sums, the second one plans the static scatters (SURVEY §8d:
     # the metric excludes one-time precompute)
@@ -570,9 +578,12 @@ def main():
                     return loss
         else:
             step = flowmap_amd.GraphedStep(step, warmup=3)  # noqa: F811
+    if gc_when == "early":
+        flowmap_amd.freeze_gc()
     for _ in range(args.warmup):
         step()
-    flowmap_amd.freeze_gc()  # a full cyclic-GC pass over torch's import-time objects costs ~50 ms (flowmap_amd/host.py)
+    if gc_when == "late":
+        flowmap_amd.freeze_gc()
     if not args.graph and on_gpu:
         _ops.flow_kernel_timing(True)  # HIP events on the launch stream around the fused flow kernel / track_pairs
     if dist is not None:
