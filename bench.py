@@ -352,7 +352,10 @@ def main():
             os.environ.setdefault(key, value)
         if on_gpu:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            import datetime
+
+            # (a collective that never completes — this path has not run with a peer yet — fails after five minutes instead of RCCL's default ten)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=5))
         else:
             dist.init_process_group("gloo")
     else:
