@@ -622,11 +622,17 @@ def main():
     _ops.flow_kernel_timing(False)
     kernel_ms = sum(flow_ms) / max(len(flow_ms), 1)
     traffic, traffic_src = None, None
-    for name in ("r03_flow_kernel_traffic.json", "r02_flow_kernel_traffic.json", "r01_flow_kernel_traffic.json"):  # HBM bytes per launch from the PMC passes (same workload only)
+    taps_on = _ops.counters["flow_tap_passes"] > 0
+    for name in ("r04_flow_kernel_traffic.json", "r03_flow_kernel_traffic.json", "r02_flow_kernel_traffic.json", "r01_flow_kernel_traffic.json"):  # HBM bytes per launch from the PMC passes (same workload only)
         try:
             rec = json.loads((ROOT / "profiles" / name).read_text())
             if {k: rec["workload"][k] for k in ("frames", "height", "width")} == {"frames": f, "height": h, "width": w}:
-                entry = rec["flow_fused_kernel_adam"] if (args.optimizer == "in_pass" and optimizer.counters["in_pass_updates"] > 0) else rec
+                in_pass_on = args.optimizer == "in_pass" and optimizer.counters["in_pass_updates"] > 0
+                key = {(False, False): "", (False, True): "flow_fused_kernel_taps", (True, False): "flow_fused_kernel_adam",
+                       (True, True): "flow_fused_kernel_adam_taps"}[(in_pass_on, taps_on)]  # (the kernel instance that ran)
+                if key and key not in rec:
+                    continue
+                entry = rec[key] if key else rec
                 traffic, traffic_src = entry["hbm_bytes_per_launch"], f"profiles/{name}"
                 break
         except Exception:
