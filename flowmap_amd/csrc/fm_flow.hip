@@ -712,7 +712,10 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
     // quads: 3 -> 675 full blocks 1.68 ms, 4 -> 506.25 blocks 1.73 ms, 6 -> 337.5 blocks 1.82 ms), so
     // take the first of 4, 3, 5 that tiles the frame exactly.
     p.iters = 4;
-    for (int cand : {4, 3, 5})
+    // (with the tap exchange a workgroup pays a fixed set-up — its taps' LDS images, two barriers —: five quads per thread first.  C2,
+    // 230 400 quads per frame: 0.78 ms against 0.80 with four, 0.83 with three, 0.95 with six; gpurun_out r04r / r04s)
+    const int order_plain[3] = {4, 3, 5}, order_taps[3] = {5, 4, 3};
+    for (int cand : (taps ? order_taps : order_plain))
       if (items % ((long)threads * cand) == 0) {
         p.iters = cand;
         break;
@@ -720,6 +723,7 @@ static int flow_loss_launch(const float* depth, const float* k, const float* kin
   }
   const long per_block = (long)threads * p.iters;
   dim3 grid((unsigned)((items + per_block - 1) / per_block), (unsigned)(batch * frames));
+  FM_CHECK_ARG(!taps || p.iters <= 6);  // (the two LDS images of a workgroup's pixels: 2 x 4 KB per quad per thread)
   size_t lds = sizeof(float) * (size_t)width + sizeof(double) * (threads / 64) * kFlowAcc;
   if (taps) lds = sizeof(float) * (size_t)((width + 3) & ~3) + sizeof(double) * (threads / 64) * kFlowAcc + 2 * sizeof(float) * 4 * (size_t)threads * p.iters;
 #define FM_FLOW_LAUNCH(V, K, P)                                                                              \
