@@ -510,6 +510,10 @@ def main():
     # idle period and needs ~17 launches to settle (profiles/r04_driver_command_ramp.txt, r04_driver_command_gc_placement.txt).  Now nothing but
     # the contract's barrier + synchronize separates precompute, warm-up and the timed steps.  (A/B: FLOWMAP_BENCH_GC=early|late = before / after warm-up.)
     gc_when = os.environ.get("FLOWMAP_BENCH_GC", "first")
+    if os.environ.get("FLOWMAP_PLAIN_LOSS"):  # A/B: the losses as plain tensors (autograd's ones_like fill + the flow loss's seed check: two more launches)
+        from flowmap_amd import _ops as _fm_ops
+
+        _fm_ops.use_unit_seed = False
     if gc_when == "first":
         flowmap_amd.freeze_gc()
     # one-time precompute, outside warm-up and timing whatever W is: the first step packs the constant

@@ -757,7 +757,7 @@ class FlowLossFused:
             dense = sink.take_early_dense()
             if dense is not None:
                 early.start_early_halo(dense, _root(depth), (t_fwd, t_bwd, k, kinv, norm, int(kind), float(delta)))
-        return loss
+        return as_root_loss(loss)
 
 
 def softmin_intrinsics(depth, weights, bwd_flow, indices, candidate_k, rel, weight_sens, frames):
@@ -1210,6 +1210,62 @@ tap_exchange_min_bytes = 128 << 20
 # the tap exchange between the fused flow loss and the fused tracking loss; False: both run as in round 3
 use_tap_exchange = True
 
+# The fused losses come back as RootLoss tensors (below); False: plain tensors, and a step pays autograd's ones_like fill and the flow
+# loss's is-the-seed-one launch again (two of the eight launches of a flow-only step)
+use_unit_seed = True
+_unit_seeds: dict = {}
+
+
+class RootLoss(Tensor):
+    """A scalar loss that seeds its own ``backward()``.  ``loss.backward()`` normally makes autograd fill a fresh ``ones_like(loss)`` (a
+    launch) and hand it down, and a fused loss then has to find out on the device that its upstream gradient is 1 before it releases the
+    gradients it already holds (``fm_scale_if_needed``: another launch, which does nothing).  Here ``backward()`` without an explicit
+    gradient passes a ones tensor that was made once per device and registered with the operators (``register_unit_seed``): a node that
+    receives exactly that tensor — same memory, never written — knows its upstream gradient on the host.  Everything else is a plain
+    tensor: sums and products of such losses are again RootLoss (``torch.Tensor``'s default ``__torch_function__``), a product with a
+    weight reaches the fused node as an ordinary gradient and is handled as before, ``torch.autograd.grad`` / an explicit ``gradient=`` /
+    ``create_graph=True`` take autograd's usual path."""
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        if gradient is None and not create_graph and use_unit_seed and self.dim() == 0 and self.dtype == torch.float32:
+            gradient = unit_seed(self.device)
+        return torch.autograd.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        out = super().__torch_function__(func, types, args, kwargs)
+        # only a scalar that still carries a graph stays a RootLoss: detach(), .cpu() of a detached value, stacked logs ... are plain tensors
+        if type(out) is RootLoss and not (out.requires_grad and out.dim() == 0):
+            return out.as_subclass(Tensor)
+        return out
+
+    def __reduce_ex__(self, protocol):  # saved / deep-copied as the plain tensor it is (torch.load(weights_only=True) knows no RootLoss)
+        return self.as_subclass(Tensor).__reduce_ex__(protocol)
+
+    def __format__(self, format_spec):  # (torch.Tensor.__format__ formats the VALUE of a 0-d tensor only when type(self) is Tensor)
+        if self.dim() == 0 and not self.is_meta:
+            return self.item().__format__(format_spec)
+        return object.__format__(self, format_spec)
+
+
+def unit_seed(device) -> Tensor:
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    seed = _unit_seeds.get(device)
+    if seed is None or seed._version != 0:
+        seed = torch.ones((), dtype=torch.float32, device=device)
+        torch_ops().register_unit_seed(seed)
+        _unit_seeds[device] = seed
+    return seed
+
+
+def as_root_loss(loss: Tensor) -> Tensor:
+    if not use_unit_seed or not loss.requires_grad or loss.dim() != 0 or type(loss) is not Tensor:
+        return loss
+    unit_seed(loss.device)  # made outside any later graph capture
+    return loss.as_subclass(RootLoss)
+
 
 def _whole_parameter(depth: Tensor) -> Optional[Tensor]:
     """The leaf parameter ``depth`` (1, F, H, W) is a whole, dense view of — or None."""
@@ -1309,4 +1365,4 @@ class TrackLossFused:
             scale.copy_(torch.stack([float(weight) / den, total[1]]).to(torch.float32))
             value = (float(weight) * total[0] / den).to(torch.float32)
             loss = loss + (value - loss).detach()
-        return loss
+        return as_root_loss(loss)

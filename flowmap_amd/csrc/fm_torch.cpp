@@ -335,6 +335,32 @@ static bool& one_launch_backward_flag() {
 static bool use_one_launch_backward() { return one_launch_backward_flag(); }
 static void set_one_launch_backward(bool on) { one_launch_backward_flag() = on; }
 
+// The root of a step's backward: `loss.backward()` makes autograd fill a fresh ones_like(loss) and hands it down as the seed — one launch — and
+// the flow loss then has to find out ON THE DEVICE that the seed is 1 (fm_scale_if_needed: a second launch that does nothing).  The losses
+// of this package are returned as `RootLoss` tensors (flowmap_amd/_ops.py) whose backward() seeds with a ones tensor made once and registered
+// here: a seed that IS that tensor (same memory, never written: version counter 0) is known to be 1 on the host and nothing is launched.
+static std::vector<Tensor>& unit_seeds() {
+  static std::vector<Tensor> seeds;
+  return seeds;
+}
+static void register_unit_seed(const Tensor& seed) {
+  TORCH_CHECK(seed.defined() && seed.numel() == 1 && seed.scalar_type() == at::kFloat && seed._version() == 0 && !seed.requires_grad(),
+              "flowmap_amd: a unit seed is one float32 that nobody has written since it was made");
+  for (const Tensor& known : unit_seeds())
+    if (known.data_ptr() == seed.data_ptr()) return;
+  unit_seeds().push_back(seed);
+}
+static bool is_unit_seed(const Tensor& g) {
+  if (!g.defined() || g.numel() != 1) return false;
+  for (const Tensor& known : unit_seeds())
+    if (known.data_ptr() == g.data_ptr() && known._version() == 0 && g.scalar_type() == at::kFloat) return true;
+  return false;
+}
+static int64_t& unit_seed_uses() {
+  static int64_t count = 0;
+  return count;
+}
+
 // does the autograd graph above `from` contain `target` within `depth` hops?  (poses -> [chain ->] fit)
 static bool reaches(const std::shared_ptr<torch::autograd::Node>& from, const torch::autograd::Node* target, int depth) {
   if (!from || target == nullptr) return false;
@@ -982,8 +1008,11 @@ struct FlowLossFused : public Function<FlowLossFused> {
       small = run.small;
     }
     TORCH_CHECK(small.defined(), "flowmap_amd: the flow loss was evaluated without gradients (no input required grad)");
+    const bool unit = is_unit_seed(grads[0]);  // the step's own root seed (RootLoss.backward): 1 by construction, nothing to rescale
     const Tensor g = grads[0].reshape({1}).to(at::kFloat).contiguous();
-    {
+    if (unit) {
+      ++unit_seed_uses();
+    } else {
       DeviceScope scope(g.device());
       // (with the in-pass Adam update the gradient has ALREADY been used, unscaled: a scalar other than 1 raises the caller's flag)
       Tensor flag = ctx->saved_data.count("adam_flag") ? ctx->saved_data["adam_flag"].toTensor() : Tensor();
@@ -1526,6 +1555,8 @@ TORCH_LIBRARY(flowmap_amd, m) {
         fmt::softmin_intrinsics_op);
   m.def("random_subset(int n, int count, Device device, int seed, Tensor? state) -> Tensor", fmt::random_subset);
   m.def("set_one_launch_backward(bool on) -> ()", fmt::set_one_launch_backward);
+  m.def("register_unit_seed(Tensor seed) -> ()", fmt::register_unit_seed);
+  m.def("unit_seed_uses() -> int", []() { return fmt::unit_seed_uses(); });
   m.def("view_copies() -> int", []() { return fmt::view_copy_counter(); });
   m.def("flow_timing_enable(bool on) -> ()", fmt::flow_timing_enable);
   m.def("flow_timing_collect(bool tracking) -> float[]", fmt::flow_timing_collect);

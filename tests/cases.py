@@ -1077,8 +1077,9 @@ def case_tap_exchange(dev):
 
 
 def case_step_torch_ops(dev):
-    """What a step launches BESIDE the library's own kernels: autograd's ones_like for loss.backward(), the sum of the two losses and the
-    two sums autograd forms where two consumers meet (dL/d extrinsics, dL/dK) — and nothing else.  In particular no zeros tensors
+    """What a step launches BESIDE the library's own kernels: the sum of the two losses and the two sums autograd forms where two consumers
+    meet (dL/d extrinsics, dL/dK) — and nothing else: not even autograd's ones_like for loss.backward() (the losses are RootLoss tensors,
+    which seed their backward with the registered ones tensor; with `_ops.use_unit_seed = False` the fill is back).  In particular no zeros tensors
     materialised for the non-differentiable outputs of the custom functions (K^-1 of FocalIntrinsics, scale / totals of the tracking
     loss): each was a fill launch per step until round 3."""
     import flowmap_amd
@@ -1086,17 +1087,24 @@ def case_step_torch_ops(dev):
 
     quiet = ("view", "unsqueeze", "squeeze", "detach", "empty", "select.int", "slice", "expand", "reshape", "alias", "permute", "as_strided",
              "t.default", "transpose", "_local_scalar_dense", "lift_fresh", "unbind", "split", "flowmap_amd", "profiler", "_to_copy", "clone")
-    for tracking, allowed in ((False, {"aten.ones_like.default": 1}), (True, {"aten.ones_like.default": 1, "aten.add.Tensor": 3})):
+    for tracking, allowed in ((False, {}), (True, {"aten.add.Tensor": 3}), (None, {"aten.ones_like.default": 1})):
+        from flowmap_amd import _ops
+        from flowmap_amd._lib import torch_ops
+
         try:
-            model, batch, flows, loss_of = _small_problem(dev, tracking=tracking)
+            _ops.use_unit_seed = tracking is not None  # (None: the plain-tensor path, flow only)
+            model, batch, flows, loss_of = _small_problem(dev, tracking=bool(tracking))
 
             def step():
                 model.zero_grad(set_to_none=True)
-                loss_of(model(batch, flows, 0)).backward()
+                loss = loss_of(model(batch, flows, 0))
+                assert (type(loss) is _ops.RootLoss) == (tracking is not None)
+                loss.backward()
 
             for _ in range(3):  # plans, packed inputs, arenas exist from the third step on
                 step()
             seen = {}
+            known_unit = torch_ops().unit_seed_uses()
 
             class Trace(TorchDispatchMode):
                 def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -1108,12 +1116,91 @@ def case_step_torch_ops(dev):
             with Trace():
                 step()
             assert seen == allowed, (tracking, seen)
+            assert torch_ops().unit_seed_uses() - known_unit == int(tracking is not None)  # the flow loss's node knew its seed on the host
         finally:
+            _ops.use_unit_seed = True
             flowmap_amd.set_lazy_surfaces(False)
 
 
 def _grads(model):
     return [p.grad.detach().clone() for p in (model.backbone.depth, model.backbone.weights, model.intrinsics.focal_length)]
+
+
+def case_root_loss(dev):
+    """RootLoss (flowmap_amd/_ops.py): the fused losses seed their own backward() with the registered ones tensor.  Same gradients as the
+    plain-tensor path however the loss reaches backward — directly, summed, scaled by a weight (an ordinary upstream gradient again),
+    with an explicit gradient, through torch.autograd.grad, twice through a retained graph; a seed somebody wrote into is not trusted any
+    more; and the value behaves like a plain tensor where users touch it (format strings, detach, torch.save / torch.load, deepcopy)."""
+    import copy
+    import io
+
+    import flowmap_amd
+    from flowmap_amd import _ops
+    from flowmap_amd._lib import torch_ops
+
+    try:
+        model, batch, flows, loss_of = _small_problem(dev, tracking=True)
+
+        def grads_of(run):
+            model.zero_grad(set_to_none=True)
+            run(loss_of(model(batch, flows, 0)))
+            return _grads(model)
+
+        for _ in range(3):
+            grads_of(lambda loss: loss.backward())
+        _ops.use_unit_seed = False
+        plain = grads_of(lambda loss: loss.backward())
+        plain3 = grads_of(lambda loss: (3.0 * loss).backward())
+        _ops.use_unit_seed = True
+
+        def same(got, want, what):
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), what
+
+        uses = torch_ops().unit_seed_uses()
+        same(grads_of(lambda loss: loss.backward()), plain, "seeded backward")
+        assert torch_ops().unit_seed_uses() == uses + 1
+        same(grads_of(lambda loss: (3.0 * loss).backward()), plain3, "a weighted loss: an ordinary upstream gradient")
+        same(grads_of(lambda loss: loss.backward(gradient=torch.full_like(loss, 3.0))), plain3, "explicit gradient")
+        assert torch_ops().unit_seed_uses() == uses + 1
+
+        def by_grad(loss):
+            params = (model.backbone.depth, model.backbone.weights, model.intrinsics.focal_length)
+            for p, g in zip(params, torch.autograd.grad(loss, params)):
+                p.grad = g
+
+        same(grads_of(by_grad), plain, "torch.autograd.grad")
+
+        def twice(loss):
+            loss.backward(retain_graph=True)
+            loss.backward()
+
+        for a, b in zip(grads_of(twice), plain):
+            assert_close(a, 2 * b, 1e-5, "two backward calls through a retained graph")
+
+        # somebody scaled the seed in place: the registered tensor's version counter moved, so it is an ordinary gradient from then on
+        # (read on the device), and the next backward() makes a fresh one
+        seed = _ops.unit_seed(torch.device(dev))
+        seed.mul_(3.0)
+        same(grads_of(lambda loss: loss.backward(gradient=seed)), plain3, "an edited seed is read, not trusted")
+        assert _ops.unit_seed(torch.device(dev)) is not seed and float(_ops.unit_seed(torch.device(dev))) == 1.0
+        same(grads_of(lambda loss: loss.backward()), plain, "a fresh seed after the edit")
+
+        loss = loss_of(model(batch, flows, 0))
+        assert type(loss) is _ops.RootLoss and type(loss.detach()) is torch.Tensor and type(loss * 2) is _ops.RootLoss
+        assert type(torch.stack([loss, loss])) is torch.Tensor
+        assert f"{loss:.4f}" == f"{loss.item():.4f}" and f"{loss.detach():.3e}" == f"{loss.item():.3e}"
+        buf = io.BytesIO()
+        torch.save({"loss": loss.detach(), "live": loss}, buf)
+        buf.seek(0)
+        back = torch.load(buf, weights_only=True)
+        assert type(back["live"]) is torch.Tensor and torch.equal(back["loss"].cpu(), loss.detach().cpu())
+        assert type(copy.deepcopy(loss.detach())) is torch.Tensor
+        with torch.no_grad():
+            assert type(loss_of(model(batch, flows, 0))) is torch.Tensor  # nothing to seed without a graph
+    finally:
+        _ops.use_unit_seed = True
+        flowmap_amd.set_lazy_surfaces(False)
 
 
 def case_grad_arena(dev):

@@ -1,0 +1,13 @@
+"""Stand-in: the batch container the hot path reads ``videos`` from."""
+from dataclasses import dataclass
+from typing import Optional
+
+from torch import Tensor
+
+
+@dataclass
+class Batch:
+    videos: Tensor  # (batch, frame, 3, height, width)
+    indices: Optional[Tensor] = None
+    scenes: Optional[list] = None
+    datasets: Optional[list] = None

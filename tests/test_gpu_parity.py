@@ -486,3 +486,7 @@ def test_halo_exchange_kernels():
 
 def test_a_step_launches_no_stray_torch_kernels():
     cases.case_step_torch_ops(DEV)
+
+
+def test_losses_seed_their_own_backward():
+    cases.case_root_loss(DEV)
