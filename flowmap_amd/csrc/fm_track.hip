@@ -621,7 +621,7 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
     const long long c_end = wall_clock64();
     clk[4] = c_end - c_epi;
     clk[5] = c_end - c_begin;
-    clk[6] = f;
+    clk[6] = (long long)f | ((c_begin & 0xffffffffffLL) << 8);  // (targets, and when the wave began: the host lines the waves up in time)
     // where the wave ran: HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID, so that the host can count resident waves per SIMD
     clk[7] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     const unsigned wid = work;
