@@ -340,8 +340,8 @@ static void set_one_launch_backward(bool on) { one_launch_backward_flag() = on; 
 // of this package are returned as `RootLoss` tensors (flowmap_amd/_ops.py) whose backward() seeds with a ones tensor made once and registered
 // here: a seed that IS that tensor (same memory, never written: version counter 0) is known to be 1 on the host and nothing is launched.
 static std::vector<Tensor>& unit_seeds() {
-  static std::vector<Tensor> seeds;
-  return seeds;
+  static auto* seeds = new std::vector<Tensor>();  // (never destroyed: device tensors must not be freed during static destruction, after the allocator)
+  return *seeds;
 }
 static void register_unit_seed(const Tensor& seed) {
   TORCH_CHECK(seed.defined() && seed.numel() == 1 && seed.scalar_type() == at::kFloat && seed._version() == 0 && !seed.requires_grad(),
