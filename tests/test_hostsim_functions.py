@@ -190,3 +190,30 @@ def test_a_step_launches_no_stray_torch_kernels():
 
 def test_losses_seed_their_own_backward():
     cases.case_root_loss("cpu")
+
+
+def test_dense_backward_selector_by_flow_roughness():
+    """Which dense Procrustes backward a flow tensor gets (flowmap_amd/_ops.py: _dense_flow_is_rough): the fused one-pass kernel keeps a
+    40 x 80 window of the earlier frame per 32 x 64 tile, displaced by the flow at the tile's centre — on i.i.d. flows (BASELINE configs[4]:
+    N(0, 0.01^2) of the image size, i.e. +-13 / +-19 pixels at 720p / 1080p) nearly every tap leaves it and goes to memory one atomic at a
+    time: 7.9 ms against 2.2 for the planned pair of kernels at C1 (profiles/r03_dense_microbench.txt), so those flows MUST take the plan;
+    a consistent scene's flow (smooth inside a tile) must not pay for the lists."""
+    import torch
+
+    from flowmap_amd import _ops
+    from oracle import flowmap_oracle as orc
+
+    g = torch.Generator().manual_seed(4)
+    for h, w in ((720, 1280), (1080, 1920)):
+        iid = 0.01 * torch.randn((1, 2, h, w, 2), generator=g)
+        assert _ops._dense_flow_is_rough(iid, h, w), (h, w)
+    h, w = 360, 640
+    scene = orc.synth_scene(3, h, w, seed=2)["flows"].backward
+    assert not _ops._dense_flow_is_rough(scene.contiguous(), h, w)
+    # tiles with a NaN in the flow (no usable window centre) count as rough; a handful of rough tiles below the threshold does not flip the choice
+    broken = scene.clone()
+    broken[0, 0] = float("nan")  # (one of the two pairs: half of the tiles)
+    assert _ops._dense_flow_is_rough(broken, h, w)
+    few = scene.clone()
+    few[0, 0, :32, :64] += 0.2 * torch.randn((32, 64, 2), generator=g)
+    assert not _ops._dense_flow_is_rough(few, h, w)  # (one of 240 tiles: far below dense_plan_rough_tiles = 0.25)
