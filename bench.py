@@ -636,7 +636,7 @@ def main():
                        (True, True): "flow_fused_kernel_adam_taps"}[(in_pass_on, taps_on)]  # (the kernel instance that ran)
                 if key and key not in rec:
                     continue
-                entry = rec[key] if key else rec
+                entry = rec[key] if key else rec.get("driver_command_round4", rec)  # (the plain instance: re-measured in round 4 on the driver's own command)
                 traffic, traffic_src = entry["hbm_bytes_per_launch"], f"profiles/{name}"
                 break
         except Exception:
