@@ -38,6 +38,8 @@ SIGNATURES = {
     "fm_halo_copy": [P, L, I, P, P, P],
     "fm_flow_ghost_terms": [P] * 14 + [I, I, I, F, F, F, P],
     "fm_halo_delta": [P, L, I, P, P, L, P, P, P, L, P, P],
+    "fm_halo_ghost_begin": [P, L, I, P, L, P, P, L, P, P, P, I, P, P, P, P],
+    "fm_halo_delta_sparse": [P, L, I, P, P, L, P, P, P, L, P, P],
     "fm_halo_add": [P, L, I, P, P, P],
     "fm_halo_scatter": [P, L, I, P, P, L, P, P, L, P],
     "fm_flow_loss_fused_views": [P] * 11 + [I, I, I, I, I, F, F, F, P, P, I, P, P],

@@ -387,6 +387,7 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
   __shared__ double pair_stats[kStatStride];
   __shared__ double chain_buf[2][16][64];
   __shared__ int last_of_all;
+  FM_PHASE(0);  // (tools/phase_clocks_fit.py: entry)
   const size_t pair = blockIdx.x;
   const int b = (int)(pair / (p.frames - 1));
   const int i = (int)(pair % (p.frames - 1));
@@ -459,6 +460,10 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
     for (long j = threadIdx.x; j < p.points; j += blockDim.x)
       moments_add(corr_load(src, kinv_e, kinv_l, p.indices ? (int)p.indices[j] : (int)j), shift, acc);
   }
+#ifdef FM_PHASE_CLOCKS
+  asm volatile("" :: "v"(acc[0]), "v"(acc[kMomentCount - 1]));  // thread 0's gathers have returned and its moments are formed
+#endif
+  FM_PHASE(1);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
 #pragma unroll
   for (int k = 0; k < kMomentCount; ++k) {
@@ -474,11 +479,13 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
     pair_stats[threadIdx.x] = tot;
   }
   __syncthreads();
+  FM_PHASE(2);  // every wave's sums are in LDS and added
   if (threadIdx.x == 0) {
     double local[kStatStride];
     for (int k = 0; k < kStatStride; ++k) local[k] = pair_stats[k];
     moments_finish(local, shift);
     pose_solve_one(local, fc.t_bwd + pair * 16, fc.t_fwd ? fc.t_fwd + pair * 16 : nullptr, fc.aux + pair * kAuxStride);
+    FM_PHASE(3);  // finished moments, solved, pose stored
     if (fc.ext != nullptr) {
       __threadfence();  // the pose is visible before the counter says so
       last_of_all = atomicAdd(counter, 1) == (int)gridDim.x - 1;
@@ -486,10 +493,12 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
     }
   }
   __syncthreads();
+  FM_PHASE(4);  // fence + counter
   if (!last_of_all) return;
   __threadfence();  // see every pair's pose
   for (int bb = 0; bb < fc.batch; ++bb)
     pose_chain_by_wave0(fc.t_bwd + (size_t)bb * (p.frames - 1) * 16, p.frames - 1, fc.ext + (size_t)bb * p.frames * 16, chain_buf);
+  FM_PHASE(5);  // (the last block only: the poses are chained)
 }
 
 // One thread per pair: raw moments -> (Σw, Σw·p, Σw·q, M) in place.

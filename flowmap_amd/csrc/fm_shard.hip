@@ -104,6 +104,48 @@ __global__ void __launch_bounds__(256) halo_delta_kernel(const float* g0, const 
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) o[i] = g[px[i]] - s[px[i]];
 }
 
+// The ghost halo's forward end in one launch.  blockIdx.y = side: base[i] = the boundary frame's gradient at the side's touched pixels (all
+// that fm_halo_delta_sparse will ask for: a gather of a few thousand values instead of fm_halo_copy's two whole frames); block (0, 0)
+// also copies what the ghost terms are evaluated from / what is sent — the boundary pairs' poses, K and K^-1 of the first frame — into `pack`:
+//   [t_fwd[0] | t_bwd[pairs-1] | t_bwd[0] | t_fwd[pairs-1] | K | K^-1]  (4 x 16 + 2 x 9 floats)
+constexpr int kGhostPack = 4 * 16 + 2 * 9;
+__global__ void __launch_bounds__(256) halo_ghost_begin_kernel(const float* g0, const float* g1, const int64_t* px0, const int64_t* px1, long n0, long n1,
+                                                               float* b0, float* b1, const float* t_fwd, const float* t_bwd, int pairs, const float* k,
+                                                               const float* kinv, float* pack) {
+  const bool first = blockIdx.y == 0;
+  if (first && blockIdx.x == 0 && pack != nullptr && threadIdx.x < kGhostPack) {
+    const int t = threadIdx.x;
+    const size_t last = (size_t)(pairs - 1) * 16;
+    float v;
+    if (t < 16) v = t_fwd[t];
+    else if (t < 32) v = t_bwd[last + (t - 16)];
+    else if (t < 48) v = t_bwd[t - 32];
+    else if (t < 64) v = t_fwd[last + (t - 48)];
+    else if (t < 73) v = k[t - 64];
+    else v = kinv[t - 73];
+    pack[t] = v;
+  }
+  const float* g = first ? g0 : g1;
+  const int64_t* px = first ? px0 : px1;
+  float* b = first ? b0 : b1;
+  const long count = first ? n0 : n1;
+  if (b == nullptr) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) b[i] = g[px[i]];
+}
+
+// fm_halo_delta against that compact baseline: out[i] = grad[boundary frame][px[i]] - base[i]
+__global__ void __launch_bounds__(256) halo_delta_sparse_kernel(const float* g0, const float* g1, const float* b0, const float* b1, const int64_t* px0,
+                                                                const int64_t* px1, long n0, long n1, float* o0, float* o1) {
+  const bool first = blockIdx.y == 0;
+  const float* g = first ? g0 : g1;
+  const float* b = first ? b0 : b1;
+  const int64_t* px = first ? px0 : px1;
+  float* o = first ? o0 : o1;
+  const long count = first ? n0 : n1;
+  if (o == nullptr) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) o[i] = g[px[i]] - b[i];
+}
+
 __global__ void __launch_bounds__(256) halo_scatter_kernel(float* g0, float* g1, const int64_t* px0, const int64_t* px1, const float* v0,
                                                            const float* v1, long n0, long n1) {
   const bool first = blockIdx.y == 0;
@@ -183,6 +225,35 @@ int fm_halo_delta(const float* grad, long frame_elements, int frames, const floa
   const long most = count_first > count_last ? count_first : count_last;
   hipLaunchKernelGGL(halo_delta_kernel, dim3(halo_blocks(most), 2), dim3(256), 0, (hipStream_t)stream, grad, last, sent_first, sent_last, pixels_first,
                      pixels_last, out_first ? count_first : 0L, out_last ? count_last : 0L, out_first, out_last);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_halo_ghost_begin(const float* grad, long frame_elements, int frames, const int64_t* pixels_first, long count_first, float* base_first,
+                        const int64_t* pixels_last, long count_last, float* base_last, const float* t_fwd, const float* t_bwd, int pairs,
+                        const float* k, const float* kinv, float* pack, void* stream) {
+  FM_CHECK_ARG(grad && frame_elements >= 1 && frames >= 1 && count_first >= 0 && count_last >= 0);
+  FM_CHECK_ARG(!base_first || pixels_first || count_first == 0);
+  FM_CHECK_ARG(!base_last || pixels_last || count_last == 0);
+  FM_CHECK_ARG(!pack || (t_fwd && t_bwd && k && kinv && pairs >= 1));
+  const float* last = grad + (size_t)(frames - 1) * frame_elements;
+  const long n0 = base_first ? count_first : 0L, n1 = base_last ? count_last : 0L;
+  if (!pack && n0 == 0 && n1 == 0) return FM_OK;
+  const long most = n0 > n1 ? n0 : n1;
+  hipLaunchKernelGGL(halo_ghost_begin_kernel, dim3(halo_blocks(most), 2), dim3(256), 0, (hipStream_t)stream, grad, last, pixels_first, pixels_last, n0, n1,
+                     base_first, base_last, t_fwd, t_bwd, pairs, k, kinv, pack);
+  FM_LAUNCH_STATUS();
+}
+
+int fm_halo_delta_sparse(const float* grad, long frame_elements, int frames, const float* base_first, const int64_t* pixels_first, long count_first,
+                         float* out_first, const float* base_last, const int64_t* pixels_last, long count_last, float* out_last, void* stream) {
+  FM_CHECK_ARG(grad && frame_elements >= 1 && frames >= 1 && count_first >= 0 && count_last >= 0);
+  FM_CHECK_ARG(!out_first || count_first == 0 || (base_first && pixels_first));
+  FM_CHECK_ARG(!out_last || count_last == 0 || (base_last && pixels_last));
+  if ((!out_first || count_first == 0) && (!out_last || count_last == 0)) return FM_OK;
+  const float* last = grad + (size_t)(frames - 1) * frame_elements;
+  const long most = count_first > count_last ? count_first : count_last;
+  hipLaunchKernelGGL(halo_delta_sparse_kernel, dim3(halo_blocks(most), 2), dim3(256), 0, (hipStream_t)stream, grad, last, base_first, base_last,
+                     pixels_first, pixels_last, out_first ? count_first : 0L, out_last ? count_last : 0L, out_first, out_last);
   FM_LAUNCH_STATUS();
 }
 

@@ -334,8 +334,13 @@ class FrameShard:
             "proxy_in": {"prev": pack[32:48].view(4, 4), "next": pack[48:64].view(4, 4)}, "k": pack[64:73].view(3, 3), "kinv": pack[73:82].view(3, 3),
             "flows": {"prev": None if flows_prev is None else tuple(t.to(dev, torch.float32).contiguous() for t in flows_prev),
                       "next": None if flows_next is None else tuple(t.to(dev, torch.float32).contiguous() for t in flows_next)},
-            "pose_in": {s_: pose() for s_ in e["send"]}, "context": None,
+            "pose_in": {s_: pose() for s_ in e["send"]}, "context": None, "begun": False,
+            # the dense gradient at the shared frames' touched pixels as the flow loss left it: what the sparse round subtracts (fm_halo_ghost_begin)
+            "base": {s_: torch.zeros((e["mine"][s_].numel(),), dtype=torch.float32, device=dev) for s_ in e["send"]},
         }
+        # (the whole-frame copies of the early exchange are not needed: nothing dense travels)
+        e["send"] = {s_: None for s_ in e["send"]}
+        e["recv"] = {s_: None for s_ in e["recv"]}
         return True
 
     def _exchange(self, pairs):
@@ -359,11 +364,24 @@ class FrameShard:
             return
         ghost = e.get("ghost")
         if ghost is not None and context is not None:
+            # ONE launch (fm_halo_ghost_begin; inside a capture it becomes a node of the forward graph): the boundary pairs' poses, K and K⁻¹
+            # into the persistent pack, and the dense gradient's values at the touched pixels of the shared frames — the baseline of the
+            # sparse round — instead of copies of the two frames
+            from ._lib import call, ptr, stream_for
+            from ._ops import _guard
+
             t_fwd, t_bwd, k, kinv, norm, kind, delta = context
-            with torch.no_grad():  # (one launch; inside a capture it becomes a node of the forward graph)
-                torch.cat([t_fwd.detach()[0, 0].reshape(-1), t_bwd.detach()[0, -1].reshape(-1), t_bwd.detach()[0, 0].reshape(-1),
-                           t_fwd.detach()[0, -1].reshape(-1), k.detach()[0, 0].reshape(-1), kinv.detach()[0, 0].reshape(-1)], out=ghost["pack"])
+            ok = all(t.dtype == torch.float32 and t.is_contiguous() for t in (t_fwd, t_bwd, k, kinv, dense_grad)) and t_fwd.shape[0] == 1
+            if not ok:
+                raise RuntimeError("flowmap_amd.FrameShard (ghost halo): the flow loss's poses / intrinsics / dense gradient must be contiguous float32, batch 1")
+            frames, h, w = dense_grad.shape[1:]
+            count = lambda side: e["mine"][side].numel() if side in e["send"] else 0  # noqa: E731
+            with _guard(dense_grad.device):
+                call("fm_halo_ghost_begin", ptr(dense_grad), h * w, frames, ptr(e["mine"]["prev"]), count("prev"), ptr(ghost["base"].get("prev")),
+                     ptr(e["mine"]["next"]), count("next"), ptr(ghost["base"].get("next")), ptr(t_fwd.detach()), ptr(t_bwd.detach()), t_fwd.shape[1],
+                     ptr(k.detach()), ptr(kinv.detach()), ptr(ghost["pack"]), stream_for(dense_grad))
             ghost["context"] = (norm, kind, delta)
+            ghost["begun"] = True
         if e.get("stash_only", False):  # GraphedShardedStep's warm-up and captures: nothing is sent; the step sends it between its two replays
             e["stashed"] = dense_grad
             return
@@ -377,8 +395,11 @@ class FrameShard:
         from ._ops import _guard
 
         frames, h, w = dense_grad.shape[1:]
-        with _guard(dense_grad.device):  # both boundary frames in one launch (fm_halo_copy)
-            call("fm_halo_copy", ptr(dense_grad), h * w, frames, ptr(e["send"].get("prev")), ptr(e["send"].get("next")), stream_for(dense_grad))
+        if ghost is None:
+            with _guard(dense_grad.device):  # both boundary frames in one launch (fm_halo_copy)
+                call("fm_halo_copy", ptr(dense_grad), h * w, frames, ptr(e["send"].get("prev")), ptr(e["send"].get("next")), stream_for(dense_grad))
+        elif not ghost.get("begun", False):  # (the baseline and the poses come from the flow loss's own call, above — in a graphed step: inside its capture)
+            raise RuntimeError("flowmap_amd.FrameShard: the ghost halo needs the flow loss's poses (a fused LossFlow on this shard's depth parameter)")
         if ghost is not None:
             # the neighbour evaluates my side of the shared frame itself: it needs the pose of MY boundary pair — towards rank−1 my first
             # pair's camera a -> a+1 (its forward term of that pair), towards rank+1 my last pair's camera b -> b−1 (its backward term)
@@ -399,9 +420,15 @@ class FrameShard:
         e = self._early
         frames, h, w = depth_grad.shape
         cnt = lambda side: e["mine"][side].numel() if side in e["send"] else 0  # noqa: E731
-        with _guard(depth_grad.device):  # both sides' deltas in one launch (fm_halo_delta)
-            call("fm_halo_delta", ptr(depth_grad), h * w, frames, ptr(e["send"].get("prev")), ptr(e["mine"]["prev"]), cnt("prev"), ptr(e["delta_out"].get("prev")),
-                 ptr(e["send"].get("next")), ptr(e["mine"]["next"]), cnt("next"), ptr(e["delta_out"].get("next")), stream_for(depth_grad))
+        ghost = e.get("ghost")
+        with _guard(depth_grad.device):  # both sides' deltas in one launch (fm_halo_delta; against the compact baseline with the ghost halo)
+            if ghost is not None:
+                call("fm_halo_delta_sparse", ptr(depth_grad), h * w, frames, ptr(ghost["base"].get("prev")), ptr(e["mine"]["prev"]), cnt("prev"),
+                     ptr(e["delta_out"].get("prev")), ptr(ghost["base"].get("next")), ptr(e["mine"]["next"]), cnt("next"), ptr(e["delta_out"].get("next")),
+                     stream_for(depth_grad))
+            else:
+                call("fm_halo_delta", ptr(depth_grad), h * w, frames, ptr(e["send"].get("prev")), ptr(e["mine"]["prev"]), cnt("prev"), ptr(e["delta_out"].get("prev")),
+                     ptr(e["send"].get("next")), ptr(e["mine"]["next"]), cnt("next"), ptr(e["delta_out"].get("next")), stream_for(depth_grad))
         pairs = [(e["delta_out"][side], e["delta_in"][side], peer) for side, peer in (("prev", self.rank - 1), ("next", self.rank + 1)) if side in e["send"]]
         self._halo = (self._exchange(pairs), None, None, depth_grad, depth_grad._version, True)
 

@@ -550,6 +550,20 @@ int fm_flow_ghost_terms(const float* depth_first, const float* pose_first, const
                         int mapping_kind, float delta, float aspect_x, float aspect_y, void* stream);
 int fm_halo_delta(const float* grad, long frame_elements, int frames, const float* sent_first, const int64_t* pixels_first, long count_first,
                   float* out_first, const float* sent_last, const int64_t* pixels_last, long count_last, float* out_last, void* stream);
+/* The ghost halo's forward end and its sparse round against a COMPACT baseline (round 4): with the ghost halo no frame travels, so the
+ * boundary frames need not be copied whole (fm_halo_copy) only to be subtracted at a few thousand pixels later.
+ *   fm_halo_ghost_begin   base_*[i] = grad[boundary frame][pixels_*[i]], and — the same launch — pack (82 floats) =
+ *                         [t_fwd[0] | t_bwd[pairs−1] | t_bwd[0] | t_fwd[pairs−1] | k (3,3) | kinv (3,3)]: the boundary pairs' poses (4,4 each; what
+ *                         FrameShard sends to its neighbours / the one-GPU proxy evaluates its own ghost terms from), K and K⁻¹ of the first
+ *                         frame, copied into storage that outlives the step (a step replayed as hipGraphs keeps its own tensors in the
+ *                         graphs' pool).  t_fwd / t_bwd: (pairs,4,4).  pack NULL: the baseline only.
+ *   fm_halo_delta_sparse  out_*[i] = grad[boundary frame][pixels_*[i]] − base_*[i]
+ * pixels as in fm_halo_delta; a NULL base_* / out_* switches the side off. */
+int fm_halo_ghost_begin(const float* grad, long frame_elements, int frames, const int64_t* pixels_first, long count_first, float* base_first,
+                        const int64_t* pixels_last, long count_last, float* base_last, const float* t_fwd, const float* t_bwd, int pairs,
+                        const float* k, const float* kinv, float* pack, void* stream);
+int fm_halo_delta_sparse(const float* grad, long frame_elements, int frames, const float* base_first, const int64_t* pixels_first, long count_first,
+                         float* out_first, const float* base_last, const int64_t* pixels_last, long count_last, float* out_last, void* stream);
 int fm_halo_add(float* grad, long frame_elements, int frames, const float* dense_first, const float* dense_last, void* stream);
 int fm_halo_scatter(float* grad, long frame_elements, int frames, const int64_t* pixels_first, const float* values_first, long count_first,
                     const int64_t* pixels_last, const float* values_last, long count_last, void* stream);

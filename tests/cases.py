@@ -1779,7 +1779,7 @@ def case_frame_windows(dev):
 
 
 def case_halo_kernels(dev):
-    """fm_halo_copy / _delta / _add / _scatter (csrc/fm_shard.hip: the local work of the frame shards' halo exchange) against the
+    """fm_halo_copy / _delta / _add / _scatter / _ghost_begin / _delta_sparse (csrc/fm_shard.hip: the local work of the frame shards' halo exchange) against the
     torch indexing operators they replace, with both, one and no boundary active, and a frame size the 16-byte path does not take."""
     from flowmap_amd._lib import call, ptr, stream_for
 
@@ -1806,6 +1806,28 @@ def case_halo_kernels(dev):
                 assert_close(out[0], moved[0].view(-1)[px[0]] - grad[0].view(-1)[px[0]], 1e-6, abs_=1e-7, what="delta, first frame")
             if last:
                 assert_close(out[1], moved[-1].view(-1)[px[1]] - grad[-1].view(-1)[px[1]], 1e-6, abs_=1e-7, what="delta, last frame")
+            # the ghost halo's forms of the same two steps: a compact baseline (the touched pixels only) gathered by the launch that also packs
+            # the boundary pairs' poses, K and K^-1 (fm_halo_ghost_begin), and the delta against it (fm_halo_delta_sparse)
+            pairs = 3
+            t_fwd, t_bwd = torch.randn((pairs, 4, 4), generator=g).to(dev), torch.randn((pairs, 4, 4), generator=g).to(dev)
+            k3, kinv3 = torch.randn((3, 3), generator=g).to(dev), torch.randn((3, 3), generator=g).to(dev)
+            for with_pack in (True, False):
+                base = [torch.full((px[i].numel(),), float("nan"), device=dev) if sides[i] else None for i in range(2)]
+                pack = torch.full((82,), float("nan"), device=dev) if with_pack else None
+                call("fm_halo_ghost_begin", ptr(grad), n, frames, ptr(px[0]), px[0].numel(), ptr(base[0]), ptr(px[1]), px[1].numel(), ptr(base[1]),
+                     ptr(t_fwd), ptr(t_bwd), pairs, ptr(k3), ptr(kinv3), ptr(pack), stream_for(grad))
+                if with_pack:
+                    want_pack = torch.cat([t_fwd[0].reshape(-1), t_bwd[-1].reshape(-1), t_bwd[0].reshape(-1), t_fwd[-1].reshape(-1), k3.reshape(-1), kinv3.reshape(-1)])
+                    assert torch.equal(pack, want_pack)
+                for i, frame in ((0, 0), (1, -1)):
+                    if sides[i]:
+                        assert torch.equal(base[i], grad[frame].reshape(-1)[px[i]])
+                out2 = [torch.full((px[i].numel(),), float("nan"), device=dev) if sides[i] else None for i in range(2)]
+                call("fm_halo_delta_sparse", ptr(moved), n, frames, ptr(base[0]), ptr(px[0]), px[0].numel(), ptr(out2[0]), ptr(base[1]), ptr(px[1]), px[1].numel(),
+                     ptr(out2[1]), stream_for(grad))
+                for i in range(2):
+                    if sides[i]:
+                        assert torch.equal(out2[i], out[i]), "the delta against the compact baseline = the delta against the copied frame"
             dense = [torch.randn((h, w), generator=g).to(dev) if on else None for on in sides]
             vals = [torch.randn((px[i].numel(),), generator=g).to(dev) if sides[i] else None for i in range(2)]
             want = grad.clone()

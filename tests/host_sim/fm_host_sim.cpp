@@ -1745,6 +1745,35 @@ int fm_halo_delta(const float* grad, long n, int frames, const float* sent_first
   for (long i = 0; out_last && i < count_last; ++i) out_last[i] = last[pixels_last[i]] - sent_last[pixels_last[i]];
   return 0;
 }
+int fm_halo_ghost_begin(const float* grad, long n, int frames, const int64_t* pixels_first, long count_first, float* base_first,
+                        const int64_t* pixels_last, long count_last, float* base_last, const float* t_fwd, const float* t_bwd, int pairs, const float* k,
+                        const float* kinv, float* pack, void*) {
+  if (!grad || n < 1 || frames < 1 || count_first < 0 || count_last < 0) return 1;
+  if ((base_first && !pixels_first && count_first) || (base_last && !pixels_last && count_last)) return 1;
+  if (pack && (!t_fwd || !t_bwd || !k || !kinv || pairs < 1)) return 1;
+  if (pack) {
+    const size_t last = (size_t)(pairs - 1) * 16;
+    std::memcpy(pack, t_fwd, sizeof(float) * 16);
+    std::memcpy(pack + 16, t_bwd + last, sizeof(float) * 16);
+    std::memcpy(pack + 32, t_bwd, sizeof(float) * 16);
+    std::memcpy(pack + 48, t_fwd + last, sizeof(float) * 16);
+    std::memcpy(pack + 64, k, sizeof(float) * 9);
+    std::memcpy(pack + 73, kinv, sizeof(float) * 9);
+  }
+  for (long i = 0; base_first && i < count_first; ++i) base_first[i] = grad[pixels_first[i]];
+  const float* last_frame = grad + (size_t)(frames - 1) * n;
+  for (long i = 0; base_last && i < count_last; ++i) base_last[i] = last_frame[pixels_last[i]];
+  return 0;
+}
+int fm_halo_delta_sparse(const float* grad, long n, int frames, const float* base_first, const int64_t* pixels_first, long count_first, float* out_first,
+                         const float* base_last, const int64_t* pixels_last, long count_last, float* out_last, void*) {
+  if (!grad || n < 1 || frames < 1 || count_first < 0 || count_last < 0) return 1;
+  if ((out_first && count_first && (!base_first || !pixels_first)) || (out_last && count_last && (!base_last || !pixels_last))) return 1;
+  for (long i = 0; out_first && i < count_first; ++i) out_first[i] = grad[pixels_first[i]] - base_first[i];
+  const float* last = grad + (size_t)(frames - 1) * n;
+  for (long i = 0; out_last && i < count_last; ++i) out_last[i] = last[pixels_last[i]] - base_last[i];
+  return 0;
+}
 int fm_halo_scatter(float* grad, long n, int frames, const int64_t* pixels_first, const float* values_first, long count_first,
                     const int64_t* pixels_last, const float* values_last, long count_last, void*) {
   if (!grad || n < 1 || frames < 1 || count_first < 0 || count_last < 0) return 1;

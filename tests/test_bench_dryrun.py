@@ -29,6 +29,8 @@ def _run(world: int, extra):
                "--master-port", str(_free_port()), launcher, "--gpus", str(world), *ARGS, *extra]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "2"
+    if world == 1:  # (--share K makes a one-rank process group on bench.py's default port: its own port, so that these tests can run side by side)
+        env["MASTER_PORT"] = str(_free_port())
     done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0, done.stderr[-3000:]
     lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
