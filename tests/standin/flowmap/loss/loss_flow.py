@@ -2,7 +2,7 @@
 from dataclasses import dataclass
 
 from ..model.projection import compute_backward_flow, compute_forward_flow, sample_image_grid
-from .loss import Loss, LossCfgCommon
+from . import Loss, LossCfgCommon
 from .mapping import get_mapping
 
 

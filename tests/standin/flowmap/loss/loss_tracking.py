@@ -2,7 +2,7 @@
 from dataclasses import dataclass
 
 from ..model.projection import compute_track_flow
-from .loss import Loss, LossCfgCommon
+from . import Loss, LossCfgCommon
 from .mapping import get_mapping
 
 
