@@ -25,7 +25,9 @@ def configs(seed: int, count: int):
     return out
 
 
-def run_case(cfg, device):
+def run_case(cfg, device, steps=1):
+    """``steps`` > 1: the step repeated on unchanged parameters and the LAST one compared — a flow + tracking case then runs the tap exchange
+    (forced whatever the size, helpers.run_ours) from its second step and samples the compact tap image from its third."""
     i, f, h, w, p, kind, with_tracks, lazy = cfg
     sc = orc.synth_scene(f, h, w, seed=100 + i, depth_noise=0.03)
     g = torch.Generator().manual_seed(i)
@@ -36,7 +38,7 @@ def run_case(cfg, device):
     tracks = orc.synth_tracks(f, h, w, scene=sc, seed=i, interval=2, radius=2, grid=5) if with_tracks else None
     if p is not None:
         p = min(p, h * w)
-    ours = run_ours(sc["depth_init"], wl, 0.8, flows, (h, w), p, tracks, kind, device=device, lazy=lazy)
+    ours = run_ours(sc["depth_init"], wl, 0.8, flows, (h, w), p, tracks, kind, device=device, lazy=lazy, steps=steps)
     ref = run_oracle(sc["depth_init"], wl, 0.8, flows, (h, w), p, tracks, kind, dtype=torch.float64)
     # every value and gradient at 1e-4 of the fp64 oracle, or twice the gap the reference path's own fp32 evaluation (the fp32 oracle) has on
     # the same inputs (helpers.compare_step; round 4: these gates were 2e-4 / 5e-4 / 2e-3 without a measured gap beside them)
