@@ -286,6 +286,8 @@ def torch_baseline(frames, h, w, points, steps, timeout=600):
 
     cmd = [sys.executable, str(ROOT / "tests" / "tools" / "torch_gpu_reference_ops.py"), "--frames", str(frames), "--height", str(h), "--width", str(w),
            "--points", str(points), "--iters", str(steps)]
+    if frames * h * w > 24 * 720 * 1280:  # the whole-video call faults from 32 frames @ 720p on (profiles/r04_stock_pytorch_rocm_fault_*): 16-frame windows
+        cmd += ["--chunk", str(max(2, (16 * 720 * 1280) // (h * w)))]
     try:
         run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
         lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
@@ -793,6 +795,15 @@ def main():
             }
         if args.torch_baseline > 0 and on_gpu and world == 1:
             result["rocm_torch_baseline"] = torch_baseline(f_video, h, w, args.points, args.torch_baseline)
+        elif (f_video, h, w, args.points) == (150, 720, 1280, 1000) and tracks is None and optimizer is None:
+            # (measured once, not by this run — like `ate`: the reference's op sequence on stock PyTorch-ROCm takes 20 s per step)
+            record = ROOT / "profiles" / "r04_stock_pytorch_rocm_150_frames_in_16_frame_windows.json"
+            try:
+                rec = json.loads(record.read_text())
+                result["rocm_torch_baseline"] = {"record": f"profiles/{record.name}", "ms_per_step": rec["ms_per_step"], "iters_per_sec": rec["iters_per_sec"],
+                                                 "frames_per_call": rec["frames_per_call"], "note": "measured once (--torch-baseline N measures it in this run); " + rec["note"]}
+            except Exception:  # noqa: BLE001
+                pass
         print(json.dumps(result), file=result_stream, flush=True)
     if dist is not None:
         dist.barrier()
