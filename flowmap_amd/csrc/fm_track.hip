@@ -132,6 +132,30 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
   }
   Taps t[N];
   float z[N][4];
+  // The compact tap image, branch-free (the usual case): every slot row first, then — one wave-uniform test later — one 8-byte load per
+  // image row of every sample, all in flight together.  Lane-divergent branches around the loads (a row with no first tap, a pixel
+  // flagged "read the depth image") made the compiler wait for each sample's loads where its branches joined: a dozen dependent
+  // round trips in the prologue instead of two.
+  int4 s4[N];
+  bool image_only = tap_depth != nullptr;
+#ifdef FM_TRACK_SKIP_SAMPLE
+  image_only = false;
+#endif
+  if (image_only) {
+    bool dense = false;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      s4[n] = make_int4(-1, -1, -1, -1);
+      if (want[n]) s4[n] = reinterpret_cast<const int4*>(tap_slot)[idx[n]];
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const int sl[4] = {s4[n].x, s4[n].y, s4[n].z, s4[n].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dense |= sl[k] >= 0 && (sl[k] & kTapDense) != 0;
+    }
+    image_only = __ballot(dense) == 0;  // (pixels an in-pass Adam update leaves to other operators are read from the depth image: the general form below)
+  }
 #pragma unroll
   for (int n = 0; n < N; ++n) {
     t[n] = bilinear_taps(q[n].x, q[n].y, g.height, g.width);
@@ -147,9 +171,20 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
         for (int k = 0; k < 4; ++k) z[n][k] = 1.5f;
       } else
 #endif
-      if (tap_depth != nullptr) {
-        const int4 s4 = reinterpret_cast<const int4*>(tap_slot)[idx[n]];
-        const int sl[4] = {s4.x, s4.y, s4.z, s4.w};
+      if (image_only) {
+        const int sl[4] = {s4[n].x, s4[n].y, s4[n].z, s4[n].w};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {  // (the two taps of an image row are neighbouring ranks when both exist; the image is padded by one value)
+          const int sa = sl[2 * r], sb = sl[2 * r + 1];
+          const int base = sa >= 0 ? (sa & kTapRank) : (sb >= 0 ? (sb & kTapRank) : 0);
+          float2 v;
+          __builtin_memcpy(&v, tap_depth + base, sizeof(float2));
+          z[n][2 * r] = sa >= 0 ? v.x : 0.f;
+          z[n][2 * r + 1] = sb >= 0 ? (sa >= 0 ? v.y : v.x) : 0.f;
+        }
+      } else if (tap_depth != nullptr) {
+        const int4 s4g = reinterpret_cast<const int4*>(tap_slot)[idx[n]];
+        const int sl[4] = {s4g.x, s4g.y, s4g.z, s4g.w};
         // the two taps of an image row are neighbouring pixels, hence neighbouring ranks: one 8-byte load per row (the image is padded by one value)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
