@@ -1221,23 +1221,45 @@ class RootLoss(Tensor):
     launch) and hand it down, and a fused loss then has to find out on the device that its upstream gradient is 1 before it releases the
     gradients it already holds (``fm_scale_if_needed``: another launch, which does nothing).  Here ``backward()`` without an explicit
     gradient passes a ones tensor that was made once per device and registered with the operators (``register_unit_seed``): a node that
-    receives exactly that tensor — same memory, never written — knows its upstream gradient on the host.  Everything else is a plain
-    tensor: sums and products of such losses are again RootLoss (``torch.Tensor``'s default ``__torch_function__``), a product with a
-    weight reaches the fused node as an ordinary gradient and is handled as before, ``torch.autograd.grad`` / an explicit ``gradient=`` /
-    ``create_graph=True`` take autograd's usual path."""
+    receives exactly that tensor — same memory, never written — knows its upstream gradient on the host.
+
+    Like ``nn.Parameter`` the class switches ``__torch_function__`` off: operators and attribute reads on a RootLoss cost what they cost on
+    a plain tensor (with the default ``__torch_function__`` every ``.dim()`` / ``.dtype`` / ``+`` went through Python: 0.1 ms per step where
+    the host is the bottleneck) and RETURN plain tensors — ``detach()``, ``torch.stack`` of logged values, whatever a caller computes from
+    the loss.  Only the arithmetic a training step does with its losses keeps the class, through the operators defined here: sums
+    (``sum(losses)``, ``a + b``), differences, a weight or a divisor (which reach the fused node as an ordinary gradient and are handled
+    as before).  ``torch.autograd.grad`` / an explicit ``gradient=`` / ``create_graph=True`` take autograd's usual path."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         if gradient is None and not create_graph and use_unit_seed and self.dim() == 0 and self.dtype == torch.float32:
             gradient = unit_seed(self.device)
         return torch.autograd.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
 
-    @classmethod
-    def __torch_function__(cls, func, types, args=(), kwargs=None):
-        out = super().__torch_function__(func, types, args, kwargs)
-        # only a scalar that still carries a graph stays a RootLoss: detach(), .cpu() of a detached value, stacked logs ... are plain tensors
-        if type(out) is RootLoss and not (out.requires_grad and out.dim() == 0):
-            return out.as_subclass(Tensor)
-        return out
+    def __add__(self, other):
+        return as_root_loss(Tensor.__add__(self, other))
+
+    def __radd__(self, other):  # (sum(losses) starts from 0 + loss)
+        return as_root_loss(Tensor.__radd__(self, other))
+
+    def __sub__(self, other):
+        return as_root_loss(Tensor.__sub__(self, other))
+
+    def __rsub__(self, other):
+        return as_root_loss(Tensor.__rsub__(self, other))
+
+    def __mul__(self, other):
+        return as_root_loss(Tensor.__mul__(self, other))
+
+    def __rmul__(self, other):
+        return as_root_loss(Tensor.__rmul__(self, other))
+
+    def __truediv__(self, other):
+        return as_root_loss(Tensor.__truediv__(self, other))
+
+    def __neg__(self):
+        return as_root_loss(Tensor.__neg__(self))
 
     def __reduce_ex__(self, protocol):  # saved / deep-copied as the plain tensor it is (torch.load(weights_only=True) knows no RootLoss)
         return self.as_subclass(Tensor).__reduce_ex__(protocol)
@@ -1249,6 +1271,9 @@ class RootLoss(Tensor):
 
 
 def unit_seed(device) -> Tensor:
+    seed = _unit_seeds.get(device)
+    if seed is not None and seed._version == 0:
+        return seed
     device = torch.device(device)
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
@@ -1260,11 +1285,18 @@ def unit_seed(device) -> Tensor:
     return seed
 
 
-def as_root_loss(loss: Tensor) -> Tensor:
-    if not use_unit_seed or not loss.requires_grad or loss.dim() != 0 or type(loss) is not Tensor:
+def as_root_loss(loss):
+    if type(loss) is not Tensor or not use_unit_seed or not loss.requires_grad or loss.dim() != 0:
+        return loss  # (also NotImplemented from a reflected operator)
+    if loss.device not in _unit_seeds:
+        unit_seed(loss.device)  # made outside any later graph capture
+    # the SAME tensor object, re-typed (both classes are plain Python subclasses of torch._C.TensorBase with one layout): `as_subclass` would
+    # make an alias — a second tensor and an AliasBackward node for the engine to walk in every backward
+    try:
+        loss.__class__ = RootLoss
         return loss
-    unit_seed(loss.device)  # made outside any later graph capture
-    return loss.as_subclass(RootLoss)
+    except TypeError:
+        return loss.as_subclass(RootLoss)
 
 
 def _whole_parameter(depth: Tensor) -> Optional[Tensor]:
