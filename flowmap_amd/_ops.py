@@ -1342,9 +1342,21 @@ PackedTracks.local_pixels = _local_pixels
 def pack_tracks(tracks, device, own=None) -> PackedTracks:
     """The packed form of a track list, built once: kept on the first segment's coordinate tensor and
     validated against every segment's identity and version."""
+    # (the same list object step after step: compare what could have changed — the segments' tensors, their version counters, their start
+    # frames — against the last call's snapshot without building the full key: 6 us instead of 20 per step where the host is the bottleneck)
+    first = tracks[0].xy
+    last = first.__dict__.get("_fm_packed_tracks_last")
+    if last is not None and last[0] is tracks and last[1] == (device, own) and len(tracks) == len(last[2]):
+        for t, (xy, xy_version, vis, vis_version, start) in zip(tracks, last[2]):
+            if t.xy is not xy or xy._version != xy_version or t.visibility is not vis or vis._version != vis_version or t.start_frame != start:
+                break
+        else:
+            return last[3]
     key = tuple((id(t.xy), t.xy._version, id(t.visibility), t.visibility._version, int(t.start_frame), tuple(t.xy.shape)) for t in tracks)
     key += (str(device), own)
-    return _derived(tracks[0].xy, "_fm_packed_tracks", key, lambda: (list(tracks), PackedTracks(tracks, device, own)))[1]
+    packed = _derived(first, "_fm_packed_tracks", key, lambda: (list(tracks), PackedTracks(tracks, device, own)))[1]
+    first.__dict__["_fm_packed_tracks_last"] = (tracks, (device, own), [(t.xy, t.xy._version, t.visibility, t.visibility._version, t.start_frame) for t in tracks], packed)
+    return packed
 
 
 class TrackLossFused:

@@ -217,3 +217,33 @@ def test_dense_backward_selector_by_flow_roughness():
     few = scene.clone()
     few[0, 0, :32, :64] += 0.2 * torch.randn((32, 64, 2), generator=g)
     assert not _ops._dense_flow_is_rough(few, h, w)  # (one of 240 tiles: far below dense_plan_rough_tiles = 0.25)
+
+
+def test_packed_tracks_follow_their_tensors():
+    """pack_tracks keeps the packed form of a track list on its first coordinate tensor and, from the second call on, only compares what
+    could have changed: the same list gives the same object; an in-place edit of a segment's positions or visibility, a replaced
+    segment, another start frame or another device / ownership gives a new one."""
+    import torch
+
+    from flowmap_amd import _ops
+    from helpers import to_tracks
+    from oracle import flowmap_oracle as orc
+
+    sc = orc.synth_scene(6, 16, 24, seed=3)
+    tracks = to_tracks(orc.synth_tracks(6, 16, 24, scene=sc, seed=3, interval=2, radius=2, grid=4), "cpu")
+    first = _ops.pack_tracks(tracks, torch.device("cpu"))
+    assert _ops.pack_tracks(tracks, torch.device("cpu")) is first and _ops.pack_tracks(tracks, torch.device("cpu")) is first
+    tracks[1].xy.mul_(1.0)  # (version counter moves)
+    second = _ops.pack_tracks(tracks, torch.device("cpu"))
+    assert second is not first and _ops.pack_tracks(tracks, torch.device("cpu")) is second
+    tracks[-1].visibility.logical_and_(tracks[-1].visibility)
+    third = _ops.pack_tracks(tracks, torch.device("cpu"))
+    assert third is not second
+    tracks[0] = type(tracks[0])(tracks[0].xy.clone(), tracks[0].visibility, tracks[0].start_frame)
+    fourth = _ops.pack_tracks(tracks, torch.device("cpu"))
+    assert fourth is not third and _ops.pack_tracks(tracks, torch.device("cpu")) is fourth
+    owned = _ops.pack_tracks(tracks, torch.device("cpu"), own=(0, 3))
+    assert owned is not fourth and _ops.pack_tracks(tracks, torch.device("cpu"), own=(0, 3)) is owned
+    fifth = _ops.pack_tracks(tracks, torch.device("cpu"))  # (one form is kept per track list: back to the whole video builds it again)
+    assert fifth is not owned and _ops.pack_tracks(tracks, torch.device("cpu")) is fifth
+    assert _ops.pack_tracks(list(tracks), torch.device("cpu")) is fifth  # (another list of the same segments: the full key finds it)
