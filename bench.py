@@ -512,6 +512,10 @@ def main():
     # idle period and needs ~17 launches to settle (profiles/r04_driver_command_ramp.txt, r04_driver_command_gc_placement.txt).  Now nothing but
     # the contract's barrier + synchronize separates precompute, warm-up and the timed steps.  (A/B: FLOWMAP_BENCH_GC=early|late = before / after warm-up.)
     gc_when = os.environ.get("FLOWMAP_BENCH_GC", "first")
+    if os.environ.get("FLOWMAP_TAP_EXCHANGE_MIN_BYTES"):  # A/B: the depth size from which the tap exchange engages (default 128 MB, flowmap_amd/_ops.py)
+        from flowmap_amd import _ops as _fm_ops
+
+        _fm_ops.tap_exchange_min_bytes = int(os.environ["FLOWMAP_TAP_EXCHANGE_MIN_BYTES"])
     if os.environ.get("FLOWMAP_PLAIN_LOSS"):  # A/B: the losses as plain tensors (autograd's ones_like fill + the flow loss's seed check: two more launches)
         from flowmap_amd import _ops as _fm_ops
 
