@@ -125,6 +125,11 @@ def parse():
     ap.add_argument("--no-tap-exchange", action="store_true",
                     help="flow + tracking: run the two losses as in round 3 (the tracking loss after the flow pass, sampling the depth images and "
                          "read-modify-writing dL/ddepth at its taps) instead of the tap exchange (flowmap_amd/_ops.py: TapPlan)")
+    ap.add_argument("--model", choices=["installed", "direct"], default="installed",
+                    help="how the step's modules are built.  `installed` (default): flowmap_amd.install() patches a reference-LAYOUT `flowmap` package "
+                         "(the real dcharatan/flowmap when it is importable, else tests/standin — the GPU box has no /root/reference) and the step is that "
+                         "package's own Model(get_backbone, get_intrinsics, get_extrinsics) + get_losses, i.e. what an unmodified overfit.py runs "
+                         "(model_wrapper_overfit.py:51-62).  `direct`: flowmap_amd.model.model.Model and the loss classes constructed by hand")
     ap.add_argument("--torch-baseline", type=int, default=0, metavar="STEPS",
                     help="after the timed region: the reference's op sequence on stock PyTorch-ROCm on this GPU (tests/tools/torch_gpu_reference_ops.py "
                          "in a process of its own, 1 warm-up + STEPS steps on i.i.d. inputs of the workload's size) as `rocm_torch_baseline`")
@@ -298,6 +303,48 @@ def torch_baseline(frames, h, w, points, steps, timeout=600):
         return {"failed": True, "timeout_s": timeout}
 
 
+def reference_layout_package():
+    """The `flowmap` package flowmap_amd.install() patches: whatever `import flowmap` finds (the real dcharatan/flowmap on the caller's path),
+    else the stand-in of the reference's module LAYOUT under tests/standin (registries, factories, import-site bindings; the GPU box has no
+    reference).  Returns (kind, where)."""
+    try:
+        import flowmap
+    except ImportError:
+        sys.path.insert(0, str(ROOT / "tests" / "standin"))
+        import flowmap
+    where = str(Path(flowmap.__file__).resolve().parent)
+    return ("stand-in of the reference's layout (tests/standin/flowmap)" if where.startswith(str(ROOT)) else "dcharatan/flowmap"), where
+
+
+def installed_modules(model_cfg_parts, num_frames, image_shape, with_tracking):
+    """After flowmap_amd.install(): the reference-layout package's OWN Model and loss factory (model/model.py:41-55, loss/__init__.py:16-17) —
+    every part resolved through the registries install() rebound (BACKBONES, INTRINSICS, EXTRINSICS, LOSSES, MAPPINGS)."""
+    from flowmap.loss import get_losses
+    from flowmap.loss.loss_flow import LossFlowCfg
+    from flowmap.loss.loss_tracking import LossTrackingCfg
+    from flowmap.loss.mapping import MappingHuberCfg
+    from flowmap.model.backbone import BackboneExplicitDepthCfg
+    from flowmap.model.extrinsics.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap.model.intrinsics import IntrinsicsRegressedCfg, IntrinsicsSoftminCfg
+    from flowmap.model.model import Model, ModelCfg
+
+    backbone, intrinsics, extrinsics = model_cfg_parts
+    if intrinsics[0] == "softmin":
+        try:
+            from flowmap.model.intrinsics.intrinsics_softmin import RegressionCfg
+        except ImportError:
+            from flowmap.model.intrinsics import RegressionCfg
+        intrinsics_cfg = IntrinsicsSoftminCfg(*intrinsics[:-1], RegressionCfg(*intrinsics[-1]))
+    else:
+        intrinsics_cfg = IntrinsicsRegressedCfg(*intrinsics)
+    model = Model(ModelCfg(BackboneExplicitDepthCfg(*backbone), intrinsics_cfg, ExtrinsicsProcrustesCfg(*extrinsics), True),
+                  num_frames=num_frames, image_shape=image_shape)
+    cfgs = [LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01))]
+    if with_tracking:
+        cfgs.append(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
+    return model, get_losses(cfgs)
+
+
 def _cpu_frames(args, f_video, h, w):
     """Frames of the CPU-baseline leg: the whole video when it is no bigger than 1.25 x the headline workload and the host has the memory
     (one iteration of 150 x 720p takes the oracle ~40 GB and ~25 s), else a 32-frame sample from the front of the same inputs."""
@@ -437,29 +484,54 @@ def main():
             torch.cuda.empty_cache()
     f = depth.shape[0]  # frames resident on this rank
 
-    if args.intrinsics == "softmin":
-        from flowmap_amd.model.intrinsics_softmin import IntrinsicsSoftminCfg, RegressionCfg
+    focal0 = 0.85 if cfg["inputs"] == "iid" else 0.8
+    parts = (("explicit_depth", 1.0, 100.0),
+             ("softmin", 8192, 0.5, 2.0, 60, (1000, 100)) if args.intrinsics == "softmin" else ("regressed", focal0),
+             ("procrustes", args.points if args.points > 0 else None, False))
 
-        intrinsics_cfg = IntrinsicsSoftminCfg("softmin", 8192, 0.5, 2.0, 60, RegressionCfg(1000, 100))
+    def direct_modules():  # this package's mirror of model/model.py and the loss classes, constructed by hand
+        if parts[1][0] == "softmin":
+            from flowmap_amd.model.intrinsics_softmin import IntrinsicsSoftminCfg, RegressionCfg
+
+            intrinsics_cfg = IntrinsicsSoftminCfg(*parts[1][:-1], RegressionCfg(*parts[1][-1]))
+        else:
+            intrinsics_cfg = IntrinsicsRegressedCfg(*parts[1])
+        made = Model(ModelCfg(BackboneExplicitDepthCfg(*parts[0]), intrinsics_cfg, ExtrinsicsProcrustesCfg(*parts[2])), num_frames=f, image_shape=(h, w))
+        fns = [LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))]
+        if tracks is not None:
+            from flowmap_amd.loss import LossTracking, LossTrackingCfg
+
+            fns.append(LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01))))
+        return made, fns
+
+    package = None
+    if args.model == "installed":
+        # THE DROP-IN PATH (north_star: "so overfit.py drops it in unchanged"): install() rebinds the registries and import sites of
+        # a reference-layout `flowmap` package, and the step below is that package's Model + get_losses, not classes picked by hand.
+        package = reference_layout_package()
+        flowmap_amd.install()
+        from flowmap.dataset.types import Batch as PackageBatch
+        from flowmap.flow.flow_predictor import Flows as PackageFlows
+        from flowmap.tracking.track_predictor import Tracks as PackageTracks
+        import dataclasses as _dc
+
+        model, loss_fns = installed_modules(parts, f, (h, w), tracks is not None)
+        assert type(model.backbone).__module__.startswith("flowmap_amd") and type(loss_fns[0]).__module__.startswith("flowmap_amd"), "install() did not rebind the registries"
+        flows = PackageFlows(flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)
+        if tracks is not None:
+            tracks = [PackageTracks(t.xy, t.visibility, t.start_frame) for t in tracks]
+        videos = torch.zeros((1, f, 3, 1, 1), device=device).expand(1, f, 3, h, w)
+        batch = PackageBatch(videos, *([None] * (len(_dc.fields(PackageBatch)) - 1)))
     else:
-        intrinsics_cfg = IntrinsicsRegressedCfg("regressed", 0.85 if cfg["inputs"] == "iid" else 0.8)
-    model_cfg = ModelCfg(
-        BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
-        intrinsics_cfg,
-        ExtrinsicsProcrustesCfg("procrustes", args.points if args.points > 0 else None, False),
-    )
-    model = Model(model_cfg, num_frames=f, image_shape=(h, w)).to(device)
+        model, loss_fns = direct_modules()
+        batch = Batch(torch.zeros((1, f, 3, 1, 1), device=device).expand(1, f, 3, h, w))
+    model = model.to(device)
     model.backbone.depth.data = depth
     model.backbone.weights.data = wlogit
-    batch = Batch(torch.zeros((1, f, 3, 1, 1), device=device).expand(1, f, 3, h, w))
-    loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
+    loss_fn = loss_fns[0]
+    track_fn = loss_fns[1] if tracks is not None else None
     if args.items_per_thread:
         loss_fn.items_per_thread = args.items_per_thread
-    track_fn = None
-    if tracks is not None:
-        from flowmap_amd.loss import LossTracking, LossTrackingCfg
-
-        track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
     shard = FrameShard(cut_rank, cut_world, dist, proxy=args.share > 1)
     if strong:
         shard.prepare_flow_loss(loss_fn, flows)  # global valid-sum (one-time all-reduce)
@@ -476,35 +548,40 @@ def main():
         optimizer = torch.optim.Adam(model.parameters(), lr=3e-5)
     shared = [p for name, p in model.named_parameters() if not name.startswith("backbone.")]  # intrinsics: shared by all frames
 
-    def compute():  # zero_grad + forward + backward of this rank's frames: no collective
-        model.zero_grad(set_to_none=True)
-        out = model(batch, flows, 0)
-        loss = loss_fn(batch, flows, None, out, 0)
-        loss.backward()
-        return loss
-
-    def step():
-        tracked = None
-        if track_fn is not None and strong:
+    def make_step(model, loss_fn, track_fn, batch, flows, tracks):
+        def compute():  # zero_grad + forward + backward of this rank's frames: no collective
             model.zero_grad(set_to_none=True)
             out = model(batch, flows, 0)
             loss = loss_fn(batch, flows, None, out, 0)
-            tracked = shard.tracking_loss(track_fn, tracks, out, total_pairs)  # global value, this rank's gradients
-            (loss + tracked).backward()
-        elif track_fn is not None:
-            model.zero_grad(set_to_none=True)
-            out = model(batch, flows, 0)
-            # (every loss is handed the tracks, as ModelWrapperOverfit.training_step does, model_wrapper_overfit.py:57-62: from the second step on
-            # the flow loss evaluates the tracking loss ahead of its pass — the tap exchange, flowmap_amd/_ops.py: TapPlan)
-            loss = loss_fn(batch, flows, tracks, out, 0) + track_fn(batch, flows, tracks, out, 0)
             loss.backward()
-        else:
-            loss = compute()
-        if strong:
-            loss = shard.sync(loss, shared, model.backbone.depth, already_global=tracked)
-        if optimizer is not None:
-            optimizer.step()
-        return loss
+            return loss
+
+        def step():
+            tracked = None
+            if track_fn is not None and strong:
+                model.zero_grad(set_to_none=True)
+                out = model(batch, flows, 0)
+                loss = loss_fn(batch, flows, None, out, 0)
+                tracked = shard.tracking_loss(track_fn, tracks, out, total_pairs)  # global value, this rank's gradients
+                (loss + tracked).backward()
+            elif track_fn is not None:
+                model.zero_grad(set_to_none=True)
+                out = model(batch, flows, 0)
+                # (every loss is handed the tracks, as ModelWrapperOverfit.training_step does, model_wrapper_overfit.py:57-62: from the second step on
+                # the flow loss evaluates the tracking loss ahead of its pass — the tap exchange, flowmap_amd/_ops.py: TapPlan)
+                loss = loss_fn(batch, flows, tracks, out, 0) + track_fn(batch, flows, tracks, out, 0)
+                loss.backward()
+            else:
+                loss = compute()
+            if strong:
+                loss = shard.sync(loss, shared, model.backbone.depth, already_global=tracked)
+            if optimizer is not None:
+                optimizer.step()
+            return loss
+
+        return step
+
+    step = make_step(model, loss_fn, track_fn, batch, flows, tracks)
 
     # Host housekeeping FIRST: a full cyclic-GC pass over torch's import-time objects costs ~50 ms (flowmap_amd/host.py: freeze_gc).  Until round 4 it
     # ran between the warm-up steps and the timed region and left the GPU idle for that long: the timed region then started from an idle part's
@@ -630,6 +707,28 @@ def main():
                      "note": "informational: the steps that follow the timed region without a pause — `value` above is the contract's K steps after W warm-up steps, "
                              "which at K = 20, W = 5 lie on the power-management transient of a GPU that was idle (kernel_ms_per_launch shows it)"}
     _ops.flow_kernel_timing(False)
+    direct = None
+    if package is not None and world == 1 and args.share <= 1 and not args.graph and optimizer is None and not args.release_originals:
+        # the same step with this package's own Model and loss classes constructed by hand (what rounds 1-4 timed), on the same parameters and inputs,
+        # straight after the steps above: the drop-in path must cost what the hand-built one costs
+        direct_model, direct_fns = direct_modules()
+        direct_model = direct_model.to(device)
+        direct_model.backbone.depth.data = model.backbone.depth.data
+        direct_model.backbone.weights.data = model.backbone.weights.data
+        direct_step = make_step(direct_model, direct_fns[0], direct_fns[1] if tracks is not None else None,
+                                Batch(batch.videos), Flows(flows.forward, flows.backward, flows.forward_mask, flows.backward_mask), tracks)
+        n_direct = args.sustained_steps if (on_gpu and args.sustained_steps > 0) else args.steps
+        for _ in range(3 + args.warmup):
+            direct_loss = direct_step()
+        sync_device()
+        t1 = time.perf_counter()
+        for _ in range(n_direct):
+            direct_loss = direct_step()
+        sync_device()
+        direct = {"what": "flowmap_amd.model.model.Model + flowmap_amd.loss classes constructed by hand (--model direct), same parameters and inputs, "
+                          f"{n_direct} steps straight after the steps above (compare with `sustained`, which the installed path ran just before)",
+                  "steps": n_direct, "ms_per_step": (time.perf_counter() - t1) / n_direct * 1e3, "loss": float(direct_loss.item())}
+        del direct_model, direct_step
     kernel_ms = sum(flow_ms) / max(len(flow_ms), 1)
     traffic, traffic_src = None, None
     taps_on = _ops.counters["flow_tap_passes"] > 0
@@ -664,7 +763,9 @@ def main():
         step_gbs = algo_bytes / (ms_per_step * 1e-3) / 1e9
         workload = (f"{cfg['ref']}: {f_video} frames @ {h}x{w}, {cfg['inputs']} inputs, flow loss (huber 0.01, weight 1000)"
                     + (f" + tracking loss (weight 100): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else "")
-                    + f", explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points if args.points > 0 else 'all pixels'}; fwd+bwd, "
+                    + f", explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points if args.points > 0 else 'all pixels'}; "
+                    + (f"modules built by the {package[0]} package after flowmap_amd.install(); " if package is not None else "modules constructed by hand (--model direct); ")
+                    + "fwd+bwd, "
                     + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__}"
                        + (", depth update inside the flow pass)" if args.optimizer == "in_pass" and optimizer.counters["in_pass_updates"] > 0
                           else ", fuse_depth_update requested but the touched set is too large: separate update)" if args.optimizer == "in_pass" else ")"))
@@ -742,6 +843,21 @@ def main():
             }
         except Exception:  # noqa: BLE001
             pass
+        if package is not None:
+            result["via_install"] = {
+                "package": package[0], "package_path": package[1],
+                "what": "flowmap_amd.install() on that package, then ITS Model (get_backbone / get_intrinsics / get_extrinsics) and get_losses: `value`, `ms_per_step`, "
+                        "`roofline` and `sustained` of this line are measured on this path",
+                "modules": {"backbone": f"{type(model.backbone).__module__}.{type(model.backbone).__name__}",
+                            "intrinsics": f"{type(model.intrinsics).__module__}.{type(model.intrinsics).__name__}",
+                            "extrinsics": f"{type(model.extrinsics).__module__}.{type(model.extrinsics).__name__}",
+                            "model": f"{type(model).__module__}.{type(model).__name__}",
+                            "losses": [f"{type(fn).__module__}.{type(fn).__name__}" for fn in loss_fns]},
+                "ms_per_step": ms_per_step, "launches_per_step": launches,
+                "sustained_ms_per_step": sustained["ms_per_step"] if sustained is not None else None,
+                "direct": direct,
+                "installed_over_direct": (sustained["ms_per_step"] / direct["ms_per_step"]) if (sustained is not None and direct is not None) else None,
+            }
         if sustained is not None:
             n_bytes = algo_bytes
             sustained["roofline_frac"] = (n_bytes / (sustained["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if sustained["kernel_ms"] > 0 else None

@@ -7,8 +7,13 @@ reprojection / flow-consistency inner loop behind the reference's Python call su
     flowmap_amd.install()          rebinds an importable reference ``flowmap`` package
                                    to these implementations
 
-All arithmetic runs in hand-written HIP kernels (flowmap_amd/csrc) loaded from
-libflowmap_hip.so through ctypes; there is no CPU or eager fallback.
+All arithmetic of this package runs in hand-written HIP kernels (flowmap_amd/csrc) loaded
+from libflowmap_hip.so; the package holds no CPU or eager implementation of it, and a missing
+library or a host tensor reaching a kernel raises.  One hand-over exists and is not this
+package's arithmetic: after ``install()`` a call whose tensors live on the HOST is passed to
+the reference's own function or class that ``install()`` replaced (flowmap_amd/_reference.py;
+SURVEY.md §8b "CPU tensors -> the reference-equivalent torch path", BASELINE.json configs[0]).
+GPU tensors never reach it, and without ``install()`` there is nothing to hand over to.
 """
 
 from . import flow, loss, model  # noqa: F401

@@ -1,10 +1,13 @@
 """ctypes binding of libflowmap_hip.so (the C ABI declared in include/flowmap_hip.h).
 
 The library is built in-tree by ``__graft_entry__.build()`` / ``flowmap_amd.build``.
-There is NO fallback: if the shared object is missing or a call reports a non-zero
-status, a RuntimeError is raised.  ``set_library_for_testing`` exists so the CPU test
-suite can inject tests/host_sim's serial build of the same math; the product never
-selects it on its own.
+There is NO fallback inside this package: if the shared object is missing or a call reports
+a non-zero status, a RuntimeError is raised, and a host tensor reaching a kernel is refused
+(``check_device``).  (After ``flowmap_amd.install()`` the entry points the reference reaches
+hand HOST-tensor calls back to the reference's own functions before they get here —
+flowmap_amd/_reference.py; that is the host application's code, not a second implementation.)
+``set_library_for_testing`` exists so the CPU test suite can inject tests/host_sim's serial
+build of the same math; the product never selects it on its own.
 """
 
 from __future__ import annotations

@@ -45,7 +45,7 @@ _CROPPING_SITES = ("flowmap.overfit", "flowmap.model.model_wrapper_pretrain")
 
 
 def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postprocess: bool = True, fused_adam: bool = True,
-            cropping: bool = True, fused_regressed: bool = True) -> None:
+            cropping: bool = True, fused_regressed: bool = True, lazy_backbone: bool = True) -> None:
     """Patch the reference in place.  ``lazy_surfaces=True`` additionally lets
     ``Model.forward``'s ``unproject`` hand a LazySurfaces to the fused consumers;
     ``fused_softmin=True`` registers the fused candidate sweep as INTRINSICS["softmin"]
@@ -58,7 +58,11 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
     ``resize_batch`` / ``crop_and_resize_batch_for_model`` / ``_for_flow`` (flowmap/misc/cropping.py)
     to the one-pass resize+crop, which uploads a host batch once and prepares both videos in HBM;
     ``fused_regressed=True`` registers INTRINSICS["regressed"] = ``flowmap_amd``'s IntrinsicsRegressed
-    (same cfg and parameter name; K and K⁻¹ for all frames from one launch, one-launch backward)."""
+    (same cfg and parameter name; K and K⁻¹ for all frames from one launch, one-launch backward);
+    ``lazy_backbone=True`` registers BACKBONES["explicit_depth"] (flowmap/model/backbone/__init__.py:5-8) = ``flowmap_amd``'s
+    BackboneExplicitDepth (same cfg, same parameter names ``depth`` / ``weights``: state_dict-compatible), whose forward hands the weight
+    logits on unevaluated when ``lazy_surfaces`` is on (flowmap_amd/model/backbone.py) — the step an unmodified ``overfit.py`` then runs is
+    the step ``bench.py`` times."""
     from . import loss as our_loss
     from .loss import mapping as our_mapping
     from .model import procrustes as our_procrustes
@@ -126,6 +130,29 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
         ref_intr = importlib.import_module("flowmap.model.intrinsics")
         _reference.twins["IntrinsicsRegressed"] = ref_intr.INTRINSICS["regressed"]
         _set(ref_intr, "INTRINSICS", {**ref_intr.INTRINSICS, "regressed": IntrinsicsRegressed})
+
+    if lazy_backbone:
+        from .model import backbone as our_backbone
+
+        ref_backbone = importlib.import_module("flowmap.model.backbone")
+        _reference.twins["BackboneExplicitDepth"] = ref_backbone.BACKBONES["explicit_depth"]
+        _set(ref_backbone, "BACKBONES", {**ref_backbone.BACKBONES, "explicit_depth": our_backbone.BackboneExplicitDepth})
+        try:  # backbone/backbone.py:13-17 (the package's __init__ does not re-export it)
+            ref_output = importlib.import_module("flowmap.model.backbone.backbone").BackboneOutput
+        except Exception:
+            ref_output = ref_backbone.BackboneOutput
+        our_backbone.set_output_type(_plain_constructor_subclass(ref_output))
+
+    # The reference's factories are annotated with its abstract bases (`get_backbone(...) -> Backbone`, backbone/__init__.py:13-18; likewise
+    # get_extrinsics / get_intrinsics / get_losses / get_mapping), which beartype checks under the import hook of overfit.py:15-19: the classes
+    # registered above are declared virtual subclasses of those bases (ABCMeta.register; all four bases are ABCs).
+    for mod_name, base_name, ours in _virtual_bases(our_loss, our_mapping, ExtrinsicsProcrustes, fused_softmin, fused_regressed, lazy_backbone):
+        try:
+            base = getattr(importlib.import_module(mod_name), base_name)
+            for cls in ours:
+                base.register(cls)
+        except Exception:  # a stand-in package without that base class, or a base that is not an ABC: nothing to declare
+            pass
 
     if flow_postprocess:
         from . import _ops
@@ -205,6 +232,29 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
     our_projection.set_lazy_surfaces(lazy_surfaces)
 
 
+def _virtual_bases(our_loss, our_mapping, extrinsics_cls, fused_softmin, fused_regressed, lazy_backbone):
+    """(module, abstract base, this package's classes registered under it)."""
+    out = [("flowmap.loss.loss", "Loss", (our_loss.LossFlow, our_loss.LossTracking)),
+           ("flowmap.loss.mapping.mapping", "Mapping", tuple(our_mapping.MAPPINGS.values())),
+           ("flowmap.model.extrinsics.extrinsics", "Extrinsics", (extrinsics_cls,))]
+    intrinsics = []
+    if fused_softmin:
+        from .model.intrinsics_softmin import IntrinsicsSoftmin
+
+        intrinsics.append(IntrinsicsSoftmin)
+    if fused_regressed:
+        from .model.model import IntrinsicsRegressed
+
+        intrinsics.append(IntrinsicsRegressed)
+    if intrinsics:
+        out.append(("flowmap.model.intrinsics.intrinsics", "Intrinsics", tuple(intrinsics)))
+    if lazy_backbone:
+        from .model.backbone import BackboneExplicitDepth
+
+        out.append(("flowmap.model.backbone.backbone", "Backbone", (BackboneExplicitDepth,)))
+    return out
+
+
 def _lib_is_double() -> bool:
     from . import _lib
 
@@ -238,3 +288,6 @@ def uninstall() -> None:
         else:
             setattr(obj, name, old)
     our_projection.set_lazy_surfaces(False)
+    from .model import backbone as our_backbone
+
+    our_backbone.set_output_type(None)

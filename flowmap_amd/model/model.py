@@ -16,9 +16,10 @@ import torch
 from torch import Tensor, nn
 
 from .. import _ops, _reference
-from ..types import BackboneOutput, ModelOutput
+from ..types import ModelOutput
+from .backbone import BackboneExplicitDepth, BackboneExplicitDepthCfg  # noqa: F401  (flowmap/model/backbone/backbone_explicit_depth.py)
 from .extrinsics_procrustes import ExtrinsicsProcrustes, ExtrinsicsProcrustesCfg
-from .projection import LazyWeights, lazy_surfaces_enabled, sample_image_grid, unproject
+from .projection import sample_image_grid, unproject
 
 
 _K_CONSTANTS: dict = {}
@@ -45,34 +46,6 @@ def focal_lengths_to_intrinsics(focal_lengths: Tensor, image_shape: Tuple[int, i
     offset, divisor = _k_constants(image_shape, focal_lengths.device)
     scaled = focal_lengths * (h * w) ** 0.5
     return torch.addcdiv(offset, scaled[..., None, None], divisor)
-
-
-@dataclass
-class BackboneExplicitDepthCfg:
-    """flowmap/model/backbone/backbone_explicit_depth.py:12-16"""
-
-    name: Literal["explicit_depth"]
-    initial_depth: float
-    weight_sensitivity: float
-
-
-class BackboneExplicitDepth(nn.Module):
-    """flowmap/model/backbone/backbone_explicit_depth.py:19-41: depth and correspondence-
-    weight logits as free parameters."""
-
-    def __init__(self, cfg: BackboneExplicitDepthCfg, num_frames: int, image_shape: Tuple[int, int]) -> None:
-        super().__init__()
-        self.cfg = cfg
-        self.depth = nn.Parameter(torch.full((num_frames, *image_shape), cfg.initial_depth, dtype=torch.float32))
-        self.weights = nn.Parameter(torch.full((num_frames - 1, *image_shape), 0, dtype=torch.float32))
-
-    def forward(self, batch, flows) -> BackboneOutput:
-        b = batch.videos.shape[0]
-        assert b == 1
-        if lazy_surfaces_enabled():
-            # same values, not stored: align_surfaces applies the sigmoid at the points it gathers
-            return BackboneOutput(self.depth[None], LazyWeights(self.weights[None], self.cfg.weight_sensitivity))
-        return BackboneOutput(self.depth[None], (self.cfg.weight_sensitivity * self.weights).sigmoid()[None])
 
 
 @dataclass

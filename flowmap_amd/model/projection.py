@@ -193,7 +193,21 @@ class LazyWeights:
             self._dense = (self.sensitivity * self.logits).sigmoid()
         return self._dense
 
+    @property
+    def ndim(self):
+        return self.logits.ndim
+
+    def dim(self):
+        return self.logits.dim()
+
+    def size(self, i=None):
+        return self.logits.shape if i is None else self.logits.shape[i]
+
     def __getitem__(self, item):
+        # frame slices keep laziness: weights[:, :1]  (intrinsics_softmin.py:100,120 read the first pair only)
+        if (isinstance(item, tuple) and len(item) == 2 and isinstance(item[0], slice) and item[0] == slice(None)
+                and isinstance(item[1], slice)):
+            return LazyWeights(self.logits[item], self.sensitivity)
         return self.materialize()[item]
 
     def __getattr__(self, name):
@@ -204,6 +218,9 @@ class LazyWeights:
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
+        if func in (torch.ones_like, torch.zeros_like, torch.empty_like) and args and isinstance(args[0], LazyWeights):
+            # model/model.py:67-68 (`use_correspondence_weights: false`) asks for the shape only: no sigmoid over (f-1, h, w) for that
+            return func(args[0].logits.detach(), *args[1:], **kwargs)
         conv = lambda a: a.materialize() if isinstance(a, (LazyWeights, LazySurfaces)) else a  # noqa: E731
         return func(*tuple(conv(a) for a in args), **{k: conv(v) for k, v in kwargs.items()})
 

@@ -98,3 +98,30 @@ def assert_close_or_reference_gap(a, truth, ref32, rel=1e-4, slack=2.0, what="")
     bound = max(rel, slack * gap)
     assert e <= bound, f"{what}: rel err {e:.3e} > max({rel:.1e}, {slack} x fp32-reference gap {gap:.3e})"
     return e, gap
+
+
+# ---- the stand-in package of the reference's module layout (tests/standin/flowmap): what flowmap_amd.install() patches where the reference is not mounted ----
+
+STANDIN = str(ROOT / "tests" / "standin")
+
+
+def forget_flowmap_modules():  # every module of whatever package called `flowmap` an earlier test imported (the real reference in the build container)
+    for name in [n for n in sys.modules if n == "flowmap" or n.startswith("flowmap.")]:
+        del sys.modules[name]
+
+
+@pytest.fixture()
+def standin():
+    import flowmap_amd
+
+    flowmap_amd.uninstall()
+    forget_flowmap_modules()
+    sys.path[:0] = [str(ROOT), STANDIN]
+    import flowmap
+
+    assert str(Path(flowmap.__file__).resolve()).startswith(STANDIN)
+    yield
+    flowmap_amd.uninstall()
+    forget_flowmap_modules()
+    sys.path.remove(STANDIN)
+    sys.path.remove(str(ROOT))

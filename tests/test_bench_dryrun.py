@@ -42,6 +42,13 @@ def _run(world: int, extra):
 def test_strong_scaling_reports_the_whole_video(extra):
     single = _run(1, extra)
     assert single["n_gpus"] == 1 and single["config"]["frames_per_gpu"] == 9
+    # the default line is measured on the drop-in path: the stand-in package's Model / get_losses after install(); the hand-built modules agree
+    via = single["via_install"]
+    assert via["package"].startswith("stand-in") and via["modules"]["backbone"] == "flowmap_amd.model.backbone.BackboneExplicitDepth"
+    assert via["modules"]["model"] == "flowmap.model.model.Model" and via["ms_per_step"] == single["ms_per_step"]
+    if "softmin" not in extra:  # (the sweep draws fresh random pixels every step: two runs do not end on the same loss)
+        assert abs(via["direct"]["loss"] - single["config"]["loss"]) <= 1e-6 * abs(single["config"]["loss"])
+    assert "via_install" not in _run(1, [*extra, "--model", "direct"])
     for world in (2, 3):
         line = _run(world, extra)
         assert line["n_gpus"] == world and line["scaling"] == "strong" and line["steps"] == 2

@@ -128,6 +128,49 @@ def test_c2_tap_exchange_150x720x1280_vs_oracle(full_size):
     assert _ops.counters["flow_tap_absorbs"] - before["flow_tap_absorbs"] == 2 and _ops.counters["track_tap_samples"] - before["track_tap_samples"] == 1
 
 
+def test_c1_installed_standin_150x720x1280_vs_oracle(full_size, standin):
+    """configs[1] at its own size THROUGH install(): the stand-in package's Model — every part from the registries install()
+    rebound, the lazy-weight backbone included — and its get_losses, on cuda:0, against the same oracle step as test_c1_..."""
+    import flowmap.loss as pkg_loss
+    from flowmap.dataset.types import Batch
+    from flowmap.flow.flow_predictor import Flows
+    from flowmap.loss.loss_flow import LossFlowCfg
+    from flowmap.loss.mapping import MappingHuberCfg
+    from flowmap.model.backbone import BackboneExplicitDepthCfg
+    from flowmap.model.extrinsics.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap.model.intrinsics import IntrinsicsRegressedCfg
+    from flowmap.model.model import Model, ModelCfg
+
+    import flowmap_amd
+    from flowmap_amd.model.projection import LazySurfaces, LazyWeights
+
+    sc, wl, _, ref = full_size
+    flowmap_amd.install()
+    try:
+        model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", FOCAL),
+                               ExtrinsicsProcrustesCfg("procrustes", P, False), True), num_frames=F, image_shape=(H, W))
+        assert type(model.backbone).__module__ == "flowmap_amd.model.backbone"
+        model.backbone.depth.data = sc["depth_init"].clone()
+        model.backbone.weights.data = wl.clone()
+        model = model.to(DEV)
+        batch = Batch(torch.zeros((1, F, 3, 1, 1), device=DEV).expand(1, F, 3, H, W))
+        fl = sc["flows"]
+        flows = Flows(fl.forward.to(DEV), fl.backward.to(DEV), fl.forward_mask.to(DEV), fl.backward_mask.to(DEV))
+        losses = pkg_loss.get_losses([LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01))])
+        for _ in range(2):  # (the second step runs the packed kernel: what bench.py times)
+            model.zero_grad(set_to_none=True)
+            out = model(batch, flows, 0)
+            loss = losses[0](batch, flows, None, out, 0)
+            loss.backward()
+        assert isinstance(out.surfaces, LazySurfaces) and isinstance(out.backward_correspondence_weights, LazyWeights)
+        ours = {"loss_flow": loss.detach().cpu(), "extrinsics": out.extrinsics.detach().cpu(), "g_depth": model.backbone.depth.grad.cpu(),
+                "g_wlogit": model.backbone.weights.grad.cpu(), "g_focal": model.intrinsics.focal_length.grad.cpu()}
+    finally:
+        flowmap_amd.uninstall()
+    assert_close(ours["loss_flow"], ref["loss_flow"], 1e-4, what="loss_flow")
+    check(ours, ref, ref["flow"], step_masks((H, W), P, sc["flows"]), "C1-installed-standin")
+
+
 # ---- BASELINE.json configs[3], configs[4] at their own frame size (VERDICT r2: row J1) ----
 
 

@@ -79,8 +79,17 @@ def test_unmodified_reference_model_runs_on_our_kernels(patched_reference, name,
         cfgs.append(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
         tracks = [Tracks(t(g[f"trk{i}_xy"]), t(g[f"trk{i}_vis"]), int(g[f"trk{i}_start"])) for i in range(int(g["n_segments"]))]
     losses = ref_loss.get_losses(cfgs)  # the reference's factory -> our Loss classes
+    # get_backbone (model/backbone/__init__.py:13-18) built this package's backbone: same parameter names, and a virtual subclass of the
+    # reference's abstract base (what `-> Backbone` is checked against under the import hook)
+    from flowmap.model.backbone.backbone import Backbone, BackboneOutput
+    from flowmap_amd.model.projection import LazyWeights
+
+    assert type(model.backbone).__module__ == "flowmap_amd.model.backbone" and isinstance(model.backbone, Backbone)
+    assert [n for n, _ in model.backbone.named_parameters()] == ["depth", "weights"]
     out = model(batch, flows, 0)
     assert isinstance(out.surfaces, LazySurfaces)  # Model.forward's unproject went lazy
+    assert isinstance(out.backward_correspondence_weights, LazyWeights)  # ... and no sigmoid ran over the (f-1, h, w) logits
+    assert isinstance(model.backbone.forward(batch, flows), BackboneOutput)
     total = sum(fn(batch, flows, tracks, out, 0) for fn in losses)
     total.backward()
     assert_close(total, g["total"], 1e-4, what="total")
@@ -91,6 +100,32 @@ def test_unmodified_reference_model_runs_on_our_kernels(patched_reference, name,
     assert_close_or_reference_gap(model.backbone.depth.grad, g["f64_g_depth"], g["g_depth"], 1e-4, what="g_depth")
     assert_close_or_reference_gap(model.backbone.weights.grad, g["f64_g_wlogit"], g["g_wlogit"], 1e-4, what="g_wlogit")
     assert_close_or_reference_gap(model.intrinsics.focal_length.grad, g["f64_g_focal"], g["g_focal"], 1e-4, what="g_focal")
+
+
+def test_rebound_backbone_is_state_dict_compatible_with_the_reference(patched_reference):
+    """BACKBONES["explicit_depth"] after install() (backbone/__init__.py:5-8 -> flowmap_amd/model/backbone.py): a checkpoint of the reference's
+    module loads into it and the other way round (same parameter names and shapes); uninstall() puts the reference's class back."""
+    import flowmap.model.backbone as ref_backbone
+    from flowmap.model.backbone.backbone_explicit_depth import BackboneExplicitDepthCfg
+
+    import flowmap_amd
+    from flowmap_amd import _reference
+
+    cfg = BackboneExplicitDepthCfg("explicit_depth", 1.5, 100.0)
+    ours = ref_backbone.get_backbone(cfg, 4, (6, 8))
+    assert type(ours).__module__ == "flowmap_amd.model.backbone"
+    assert float(ours.depth[0, 0, 0]) == 1.5 and ours.num_frames == 4 and ours.image_shape == (6, 8)
+    theirs = _reference.twins["BackboneExplicitDepth"](cfg, 4, (6, 8))
+    with torch.no_grad():
+        theirs.depth.mul_(2.0)
+        theirs.weights.add_(0.25)
+    ours.load_state_dict(theirs.state_dict())
+    assert torch.equal(ours.depth, theirs.depth) and torch.equal(ours.weights, theirs.weights)
+    theirs.load_state_dict(ours.state_dict())
+    assert set(ours.state_dict()) == set(theirs.state_dict()) == {"depth", "weights"}
+    flowmap_amd.uninstall()
+    assert ref_backbone.BACKBONES["explicit_depth"].__module__ == "flowmap.model.backbone.backbone_explicit_depth"
+    flowmap_amd.install()  # (the fixture's teardown uninstalls)
 
 
 def test_reference_softmin_intrinsics_under_install():

@@ -11,29 +11,6 @@ import pytest
 import torch
 
 ROOT = Path(__file__).resolve().parent.parent
-STANDIN = str(ROOT / "tests" / "standin")
-
-
-def _forget_standin():  # every module of the package called `flowmap`
-    for name in [n for n in sys.modules if n == "flowmap" or n.startswith("flowmap.")]:
-        del sys.modules[name]
-
-
-@pytest.fixture()
-def standin():
-    import flowmap_amd
-
-    flowmap_amd.uninstall()
-    _forget_standin()  # (whatever package of that name an earlier test imported — the real reference in the build container)
-    sys.path[:0] = [str(ROOT), STANDIN]
-    import flowmap
-
-    assert str(Path(flowmap.__file__).resolve()).startswith(STANDIN)
-    yield
-    flowmap_amd.uninstall()
-    _forget_standin()
-    sys.path.remove(STANDIN)
-    sys.path.remove(str(ROOT))
 
 
 def _problem(name, with_tracks, dev):
@@ -101,7 +78,7 @@ def _installed_step(name, with_tracks, dev):
 
     import flowmap_amd
     from flowmap_amd import _ops
-    from flowmap_amd.model.projection import LazySurfaces
+    from flowmap_amd.model.projection import LazySurfaces, LazyWeights
 
     original_unproject = ref_model.unproject
     flowmap_amd.install()
@@ -112,8 +89,10 @@ def _installed_step(name, with_tracks, dev):
         before = dict(_ops.counters)
         g, model, batch, flows, tracks, losses = _problem(name, with_tracks, dev)
         assert type(losses[0]) is flowmap_amd.loss.LossFlow and type(model.extrinsics).__module__.startswith("flowmap_amd")
+        assert type(model.backbone).__module__ == "flowmap_amd.model.backbone"  # get_backbone -> BACKBONES["explicit_depth"], rebound
         out = _step_and_compare(g, model, batch, flows, tracks, losses)
         assert isinstance(out.surfaces, LazySurfaces)  # the stand-in Model's unproject went lazy: the fused kernels consumed depth directly
+        assert isinstance(out.backward_correspondence_weights, LazyWeights)  # no sigmoid over the (f-1, h, w) logits: applied at the gathered pixels
         # a second and third step: the flow loss packs its constant inputs once the same flows come back — which only the fused path does
         for _ in range(2):
             model.zero_grad(set_to_none=True)
@@ -123,6 +102,9 @@ def _installed_step(name, with_tracks, dev):
     finally:
         flowmap_amd.uninstall()
     assert ref_loss.LOSSES["flow"].__module__.startswith("flowmap.") and ref_model.unproject is original_unproject
+    import flowmap.model.backbone as ref_backbone
+
+    assert ref_backbone.BACKBONES["explicit_depth"].__module__.startswith("flowmap.")
 
 
 @pytest.mark.parametrize("name,with_tracks", CASES)
@@ -145,3 +127,85 @@ def test_install_on_the_standin_runs_the_hip_library(standin, name, with_tracks)
 
     assert not _lib.using_test_double()
     _installed_step(name, with_tracks, "cuda:0")
+
+
+def _no_stray_torch_kernels(dev):
+    """cases.case_step_torch_ops on the INSTALLED path: the stand-in's Model (get_backbone / get_intrinsics / get_extrinsics) and get_losses after
+    install().  Beside the library's kernels a flow-only step launches nothing — in particular no sigmoid over the weight logits (the rebound
+    backbone hands them on as LazyWeights) and no ones_like fill for backward(); flow + tracking adds the sum of the two losses and the two sums
+    autograd forms where two consumers meet."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    import flowmap_amd
+    from flowmap_amd import _ops
+
+    quiet = ("view", "unsqueeze", "squeeze", "detach", "empty", "select.int", "slice", "expand", "reshape", "alias", "permute", "as_strided",
+             "t.default", "transpose", "_local_scalar_dense", "lift_fresh", "unbind", "split", "flowmap_amd", "profiler", "_to_copy", "clone")
+    flowmap_amd.install()
+    try:
+        for name, with_tracks, allowed in (("step_iid_flow", False, {}), ("step_scene_flow_tracking", True, {"aten.add.Tensor": 3})):
+            g, model, batch, flows, tracks, losses = _problem(name, with_tracks, dev)
+
+            def step():
+                model.zero_grad(set_to_none=True)
+                out = model(batch, flows, 0)
+                total = losses[0](batch, flows, tracks, out, 0)
+                for fn in losses[1:]:
+                    total = total + fn(batch, flows, tracks, out, 0)
+                assert type(total) is _ops.RootLoss
+                total.backward()
+
+            for _ in range(3):  # plans, packed inputs, arenas exist from the third step on
+                step()
+            seen = {}
+
+            class Trace(TorchDispatchMode):
+                def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                    op = str(func)
+                    if not any(q in op for q in quiet):
+                        seen[op] = seen.get(op, 0) + 1
+                    return func(*args, **(kwargs or {}))
+
+            with Trace():
+                step()
+            assert seen == allowed, (name, seen)
+    finally:
+        flowmap_amd.uninstall()
+
+
+def test_an_installed_step_launches_no_stray_torch_kernels_host_double(standin):
+    from flowmap_amd import _lib
+    from helpers import build_host_sim
+
+    _lib.set_library_for_testing(build_host_sim())
+    try:
+        _no_stray_torch_kernels("cpu")
+    finally:
+        _lib.set_library_for_testing(None)
+
+
+@pytest.mark.gpu
+def test_an_installed_step_launches_no_stray_torch_kernels(standin):
+    _no_stray_torch_kernels("cuda:0")
+
+
+@pytest.mark.parametrize("name,with_tracks", CASES)
+def test_host_tensors_after_install_go_back_to_the_packages_own_code(standin, name, with_tracks):
+    """The ONE hand-over of the product path (flowmap_amd/_reference.py; SURVEY.md §8b, BASELINE.json configs[0]): with the real C ABI library
+    selected (no test double), install() leaves host-tensor calls to the functions and classes it replaced — here the stand-in's own — so the
+    step reproduces the goldens on the CPU, the rebound backbone included; without install() the same host tensors are refused
+    (test_abi.py::test_no_cpu_fallback)."""
+    import flowmap_amd
+    from flowmap_amd import _lib, _reference
+
+    _lib.set_library_for_testing(None)
+    flowmap_amd.install()
+    try:
+        before = _reference.counters["host_calls"]
+        g, model, batch, flows, tracks, losses = _problem(name, with_tracks, "cpu")
+        assert type(model.backbone).__module__ == "flowmap_amd.model.backbone"
+        out = _step_and_compare(g, model, batch, flows, tracks, losses)
+        assert torch.is_tensor(out.surfaces) and torch.is_tensor(out.backward_correspondence_weights)  # the package's own unproject / sigmoid
+        assert _reference.counters["host_calls"] > before
+    finally:
+        flowmap_amd.uninstall()
