@@ -280,8 +280,10 @@ def touched_elements(depth: Tensor, whole_frames=(), exclude=()):
     frames is marked in the mask but left OUT of the index list — the caller updates them with a dense pass per frame."""
     root = _root(depth)
     registry = root.__dict__.get("_fm_touched")
-    if registry and exclude:  # (``exclude``: consumers whose gradient the flow pass itself absorbs — the tracking loss under the tap exchange)
-        registry = {name: v for name, v in registry.items() if name not in exclude}
+    if registry and exclude:
+        # ``exclude``: the pixel sets (tensor objects) of consumers whose gradient the flow pass itself absorbs — the ONE tracking loss whose
+        # tap gradient the step's DepthSink offers.  By identity, not by consumer name: a second tracking loss on the same depth keeps its pixels.
+        registry = {name: v for name, v in registry.items() if not any(v is x for x in exclude)}
     if not registry or depth.numel() % 4 != 0:
         return None
     whole_frames = tuple(sorted(int(f) for f in whole_frames))
@@ -307,7 +309,7 @@ def touched_elements(depth: Tensor, whole_frames=(), exclude=()):
         return list(registry.values()), keys.contiguous(), mask
 
     key = tuple((name, id(v), v._version) for name, v in sorted(registry.items())) + (depth.numel(), whole_frames)
-    return _derived(root, "_fm_touched_union" + ("_without_" + "_".join(exclude) if exclude else ""), key, build)[1:]
+    return _derived(root, "_fm_touched_union" + ("_without_" + "_".join(str(id(x)) for x in exclude) if exclude else ""), key, build)[1:]
 
 
 # Persistent dL/dweights storage (GradArena) for sparse fits with a constant index set; False = fresh zeros every step
@@ -710,10 +712,12 @@ class FlowLossFused:
         tap_plan = tap_plan_of(depth) if (sink is not None and torch.is_grad_enabled() and depth.requires_grad) else None
         if tap_plan is not None and packed is None and not all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (flow_fwd, flow_bwd, mask_fwd, mask_bwd)):
             tap_plan = None  # (frame windows / unaligned flows: the pass that reads them in place has no tap variant)
+        if tap_plan is not None and int(items) > 6:
+            tap_plan = None  # (the tap variant of the pass stages at most 6 quads per thread: fm_flow_loss_fused_taps)
         absorbing = tap_plan is not None and sink.offers_taps()
         if optimizer is not None and sink is not None and torch.is_grad_enabled():
             # (a tracking gradient this pass absorbs completes dL/ddepth at the taps: they need not wait for the element-list update)
-            offer = optimizer.begin_in_pass(depth, sink, t_fwd, t_bwd, exclude=("tracking",) if absorbing else ())
+            offer = optimizer.begin_in_pass(depth, sink, t_fwd, t_bwd, exclude=(tap_plan.pixels,) if absorbing else ())
             if offer is not None:
                 adam, ticket = offer
         # frame sharding with an early halo exchange (FrameShard.enable_early_halo): the dense dL/ddepth exists at the end of THIS
@@ -1099,7 +1103,8 @@ class PackedTracks:
                     # where each tap of each track point sits in `pixels` (its rank), -1 for a tap that contributes nothing: the tap
                     # exchange's view of the same plan (fm_track_loss_fused_fwd_taps)
                     # (bit 30: the pixel has more than one entry, i.e. several track points share it — fm_track_loss_fused_fwd_taps)
-                    assert plan[0].numel() < 1 << 30
+                    # (the slot encoding keeps 29 rank bits: bit 29 = read the depth image, TapPlan.slots_reading_around)
+                    assert plan[0].numel() < 1 << 29
                     slots = torch.full((self.total * 4,), -1, dtype=torch.int32, device=dev)
                     ranks = torch.searchsorted(plan[0], keys[used])
                     shared = counts > 1
@@ -1118,7 +1123,7 @@ class PackedTracks:
             plan = self.scatter_plan(height, width) if self.nblocks > 0 and not self.partial else None
             n = int(height) * int(width)
             built = None
-            if plan is not None and width % 4 == 0 and self.last_frame <= frames and plan[0].numel() < 2**31:
+            if plan is not None and width % 4 == 0 and self.last_frame <= frames and plan[0].numel() < 2**29:
                 pixels = plan[0]
                 dev = pixels.device
                 quads, chunks = n // 4, (n // 4 + 63) // 64
@@ -1378,17 +1383,32 @@ class TrackLossFused:
         needs_depth = torch.is_grad_enabled() and depth.requires_grad
         plan = packed.scatter_plan(depth.shape[2], depth.shape[3]) if needs_depth and depth.dim() == 4 else None  # built at the first step
         if plan is not None:
-            note_touched(depth, "tracking", packed.local_pixels(depth.shape[2], depth.shape[3], int(frame0)))
+            pixels = packed.local_pixels(depth.shape[2], depth.shape[3], int(frame0))
+            known = _root(depth).__dict__.get("_fm_touched", {}).get("tracking")
+            # (a second tracking loss with its own track set on the same depth registers beside the first, not over it)
+            note_touched(depth, "tracking" if (known is None or known is pixels) else f"tracking@{id(packed)}", pixels)
         sink = depth_sink(depth) if defer else None
         # the tap exchange: whole video local, gradients on — register the static tap set with the parameter (the flow pass then leaves the tap
         # depths in its compact image) and sample from that image while the parameter has not moved since
         taps = (None, None, None)
         root = _whole_parameter(depth) if (use_tap_exchange and plan is not None and reducer is None and int(frame0) == 0 and defer
                                            and depth.numel() * 4 >= tap_exchange_min_bytes) else None
+        if root is not None and root.__dict__.get("_fm_tap_exchange_off"):
+            root = None
         if root is not None and root.is_leaf and ext.shape[1] == depth.shape[1]:
             tap_plan = packed.tap_plan(depth.shape[1], depth.shape[2], depth.shape[3])
+            registered = root.__dict__.get("_fm_tap_plan")
+            owner = root.__dict__.get("_fm_tap_owner_step")
+            if tap_plan is not None and registered is not None and registered is not tap_plan and owner is not None and owner() is depth:
+                # TWO tracking losses with their own track sets on one depth tensor in one step: the exchange is built around ONE static tap set
+                # per parameter (one compact image, one absorbed gradient) — it is switched off for this parameter for good; both run as in round 3
+                root.__dict__["_fm_tap_exchange_off"] = True
+                root.__dict__.pop("_fm_tap_plan", None)
+                root.__dict__.pop("_fm_tracking_follows_flow", None)
+                tap_plan, offer_taps = None, False
             if tap_plan is not None:
                 root.__dict__["_fm_tap_plan"] = tap_plan
+                root.__dict__["_fm_tap_owner_step"] = weakref.ref(depth)  # (the step's depth tensor: a second registration within the same step is a second loss)
                 taps = (tap_plan.slots, None, tap_plan.shared_ranks)
                 if use_tap_image and tap_plan.image_valid_for(root):
                     taps = (tap_plan.image_slots, tap_plan.image, tap_plan.shared_ranks)

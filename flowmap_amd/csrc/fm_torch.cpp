@@ -242,10 +242,15 @@ struct DepthSink : torch::CustomClassHolder {
   bool tap_absorbed = false;
   Tensor tap_flow_upstream, tap_track_upstream;  // defined once the respective node's backward has run in this pass
   bool tap_confirmed = false;                    // the tracking node whose gradient was absorbed has run its backward (FusedAdam.step checks)
+  // The absorbing pass also applied the in-pass Adam update at the taps (they left the element list): the update used scale·tap_grad at
+  // factor 1 and cannot be corrected afterwards.  This is the optimiser's scaled-loss flag; settle_taps raises it ON THE DEVICE when the
+  // two upstream gradients turn out to differ (`flow + 3·tracking`), and FusedAdam.step reports it like a scaled loss.
+  Tensor tap_adam_flag;
   int64_t taps_settled_free = 0, taps_settled_launch = 0;  // (tests)
   void offer_taps(const Tensor& grad, const Tensor& scale, const Tensor& pixels) {
     tap_grad = grad, tap_scale = scale, tap_pixels = pixels;
     tap_absorbed = false;
+    tap_adam_flag = Tensor();
     tap_flow_upstream = Tensor(), tap_track_upstream = Tensor();
   }
   bool offers_taps() const { return tap_grad.defined() && !tap_absorbed; }
@@ -324,7 +329,7 @@ void DepthSink::settle_taps(Tensor& buffer) {
   TORCH_CHECK(buffer.defined() && buffer.is_contiguous(), "flowmap_amd: the tap exchange needs a dense dL/ddepth buffer");
   DeviceScope scope(buffer.device());
   FM_CALL(fm_tap_grad_apply, ptr(tap_grad), ptr<int64_t>(tap_pixels), (long)tap_pixels.numel(), ptr(tap_scale), ptr(plus), ptr(minus), ptr(buffer),
-          scope.stream);
+          ptr<int>(tap_adam_flag), scope.stream);
 }
 
 // tests and A/B timing: the planned sparse fit's backward as one launch (default) or as the three launches it replaces
@@ -955,12 +960,16 @@ struct FlowLossFused : public Function<FlowLossFused> {
         taps.scale = sink->tap_scale;
       }
     }
-    FlowLaunch run = flow_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, items, need,
-                                 depth_in.requires_grad(), opt(acc_work), exp_avg, exp_avg_sq, touched, adam_step, adam, taps);
-    // (the caller left the tracking loss's taps to this pass's in-pass Adam update: it must really have absorbed their gradient)
+    // (the caller left the tracking loss's taps to this pass's in-pass Adam update: it must really absorb their gradient — checked BEFORE the
+    // launch, which rewrites the parameter and the optimiser state in place)
     TORCH_CHECK(!tap_require || taps.grad.defined(), "flowmap_amd: the flow pass was to absorb the tracking loss's gradient at its taps (tap exchange + in-pass "
                 "Adam) but the step's DepthSink offers none that fits");
-    if (taps.grad.defined()) sink->tap_absorbed = true;
+    FlowLaunch run = flow_launch(depth, k, kinv, t_fwd, t_bwd, flow_fwd, flow_bwd, mask_fwd, mask_bwd, norm, packed, kind, delta, items, need,
+                                 depth_in.requires_grad(), opt(acc_work), exp_avg, exp_avg_sq, touched, adam_step, adam, taps);
+    if (taps.grad.defined()) {
+      sink->tap_absorbed = true;
+      sink->tap_adam_flag = (in_pass_adam && adam_flag_o.has_value() && adam_flag_o->defined()) ? *adam_flag_o : Tensor();
+    }
     ctx->saved_data["tap_absorbed"] = taps.grad.defined();
     ctx->saved_data["in_pass_adam"] = in_pass_adam;
     if (in_pass_adam && adam_flag_o.has_value() && adam_flag_o->defined()) {

@@ -856,10 +856,11 @@ __global__ void __launch_bounds__(256) tap_grad_kernel(const float* vectors, con
 // backward() with the same upstream gradient as the flow loss; `plus` = the tracking loss's upstream gradient (null: its backward never
 // ran), `minus` = what the flow pass's share was multiplied by (null: it was never delivered).
 __global__ void __launch_bounds__(256) tap_grad_apply_kernel(const float* tap_grad, const int64_t* pixels, long count, const float* scale,
-                                                             const float* plus, const float* minus, float* grad_depth) {
+                                                             const float* plus, const float* minus, float* grad_depth, int* mismatch) {
   const float factor = scale[0] * ((plus ? plus[0] : 0.f) - (minus ? minus[0] : 0.f));
   if (factor == 0.f) return;
   const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m == 0 && mismatch) *mismatch = 1;  // (an in-pass Adam update already used the absorbed gradient at factor 1: FusedAdam.step reports it)
   if (m >= count) return;
   grad_depth[pixels[m]] += factor * tap_grad[m];
 }
@@ -1034,11 +1035,11 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
 }
 
 int fm_tap_grad_apply(const float* tap_grad, const int64_t* pixels, long count, const float* scale, const float* upstream_plus,
-                      const float* upstream_minus, float* grad_depth, void* stream) {
+                      const float* upstream_minus, float* grad_depth, int* mismatch_flag, void* stream) {
   FM_CHECK_ARG(count >= 0 && (count == 0 || (tap_grad && pixels && grad_depth)) && scale);
   if (count == 0) return FM_OK;
   hipLaunchKernelGGL(tap_grad_apply_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tap_grad, pixels, count, scale,
-                     upstream_plus, upstream_minus, grad_depth);
+                     upstream_plus, upstream_minus, grad_depth, mismatch_flag);
   FM_LAUNCH_STATUS();
 }
 

@@ -80,8 +80,11 @@ class FrameShard:
     so every collective executes as a one-rank RCCL operation, and the halo exchange — which has no peer — is stood in for by
     the local work it causes (a copy of the two boundary frames out, an accumulate of two received frames in)."""
 
-    def __init__(self, rank: int = 0, world: int = 1, dist=None, group=None, proxy: bool = False):
+    def __init__(self, rank: int = 0, world: int = 1, dist=None, group=None, proxy: bool = False, force_collectives: bool = False):
         self.rank, self.world, self.dist, self.group, self.proxy = rank, world, dist, group, proxy
+        # a one-rank job normally issues no collective at all; True: it issues every one of them on its one-member group (the driver's GPU
+        # boxes have one GPU: tests/test_gpu_rccl.py runs each collective call site of the sharded step on a real RCCL communicator this way)
+        self.force_collectives = force_collectives
         self._halo = None  # (requests, recv_prev, recv_next, gradient) of the exchange in flight
         self._halo_by_hook = False  # that exchange was posted by the gradient hook (sync() then only completes it)
         self.defer_halo = False  # True: the gradient hook does not post the exchange (GraphedShardedStep: sync() posts it after the replay)
@@ -94,7 +97,7 @@ class FrameShard:
 
     @property
     def active(self) -> bool:
-        return self.world > 1 and self.dist is not None
+        return (self.world > 1 or self.force_collectives) and self.dist is not None
 
     @staticmethod
     def owned_sources(total_pairs: int, world: int, rank: int) -> Tuple[int, int]:

@@ -37,8 +37,9 @@ extern "C" {
 /* Version of this interface: bumped whenever an entry point changes its arguments or its contract (round 3: the workspaces of
  * fm_flow_loss_fused / fm_procrustes_fit_chain are self-cleaning — zero on entry, left zero — instead of being cleared by the
  * call; fm_scale_if_needed reports a non-unit scalar; round 4, version 4: the tap exchange entry
- * points fm_flow_loss_fused_taps / fm_track_loss_fused_fwd_taps / fm_tap_grad_apply).  A binding checks fm_abi_version() == FM_ABI_VERSION when it loads the library. */
-#define FM_ABI_VERSION 4
+ * points fm_flow_loss_fused_taps / fm_track_loss_fused_fwd_taps / fm_tap_grad_apply; round 5, version 5: fm_tap_grad_apply reports a
+ * non-zero correction through a device flag).  A binding checks fm_abi_version() == FM_ABI_VERSION when it loads the library. */
+#define FM_ABI_VERSION 5
 int fm_abi_version(void);
 
 #define FM_STAT_STRIDE 16      /* doubles per pair in `stats` */
@@ -426,9 +427,11 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
                                  const int32_t* shared_ranks, long shared_count, float* tap_grad, void* stream);
 /* grad_depth[pixels[m]] += scale[0]·(plus − minus)·tap_grad[m] for the M taps (plus / minus: device scalars, NULL = 0); no memory is
  * touched when the factor is 0.  The correction of the tap exchange when the tracking loss's upstream gradient (plus) differs from
- * the factor the flow pass's copy of it was delivered with (minus), and the plain scatter (minus NULL) when nothing was delivered. */
+ * the factor the flow pass's copy of it was delivered with (minus), and the plain scatter (minus NULL) when nothing was delivered.
+ * mismatch_flag (one int32 on the device, or NULL): set to 1 when the factor is not 0 — the caller passes it when something has ALREADY
+ * consumed the absorbed gradient at factor 1 and cannot be corrected (the in-pass Adam update of the absorbing flow pass). */
 int fm_tap_grad_apply(const float* tap_grad, const int64_t* pixels, long count, const float* scale, const float* upstream_plus,
-                      const float* upstream_minus, float* grad_depth, void* stream);
+                      const float* upstream_minus, float* grad_depth, int* mismatch_flag, void* stream);
 
 /* g_ext (F,4,4), g_k (F,3,3) from acc / acc2, multiplied by scale[0]·upstream[0]
  * (upstream NULL = 1). */

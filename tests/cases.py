@@ -1446,6 +1446,64 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=1e-3, softmin=False, exch
     assert float((ref[-1][0] - ref[0][0]).abs().max()) > 5e-3
 
 
+def case_in_pass_adam_exchange_unequal_upstreams(dev):
+    """the tap exchange + FusedAdam.fuse_depth_update with the two losses reaching backward() under DIFFERENT upstream
+    gradients (`flow + 3·tracking`).  The absorbing flow pass has then applied the depth update at the taps with the tracking gradient at
+    factor 1 — not correctable afterwards — so the fit's node raises the optimiser's scaled-loss flag on the device (fm_tap_grad_apply's
+    mismatch flag) and step() reports it; the plain sum of the same two losses runs clean; and a SECOND tracking loss on the same depth
+    (its own track set) keeps its pixels in the element list: the trajectory of torch.optim.Adam."""
+    import flowmap_amd
+    from flowmap_amd import FusedAdam, _ops
+    from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
+    from helpers import to_tracks
+
+    f, h, w = 5, 24, 32
+    min_bytes = _ops.tap_exchange_min_bytes
+    _ops.tap_exchange_min_bytes = 0
+    try:
+        sc = orc.synth_scene(f, h, w, seed=21)
+        tracks = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=21, interval=2, radius=2, grid=5), dev)
+        other = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=5, interval=3, radius=1, grid=4), dev)
+
+        def loop(factor, steps, mode, second=False):
+            model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False)
+            flow_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
+            track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", mapping_cfg("huber")))
+            second_fn = LossTracking(LossTrackingCfg(0, 50.0, "tracking", mapping_cfg("huber"))) if second else None
+            optimizer = torch.optim.Adam(model.parameters(), lr=1e-3) if mode == "torch" else FusedAdam(model.parameters(), lr=1e-3)
+            if mode == "in_pass":
+                optimizer.fuse_depth_update(model.backbone.depth, max_touched_fraction=1.0)
+                optimizer.verify_unit_upstream_every = 1
+            absorbed = _ops.counters["flow_tap_absorbs"]
+            for step in range(steps):
+                optimizer.zero_grad(set_to_none=True)
+                out = model(batch, flows, step)
+                total = flow_fn(batch, flows, tracks, out, step)
+                tracked = track_fn(batch, flows, tracks, out, step)
+                total = total + (tracked if factor == 1.0 else factor * tracked)
+                if second_fn is not None:
+                    total = total + second_fn(batch, flows, other, out, step)
+                total.backward()
+                optimizer.step()
+            return model.backbone.depth.detach().clone(), optimizer, _ops.counters["flow_tap_absorbs"] - absorbed
+
+        # equal upstreams: clean, and the pass did absorb
+        _, optimizer, absorbed = loop(1.0, 6, "in_pass")
+        assert absorbed >= 3 and optimizer.counters["in_pass_updates"] >= 4
+        # unequal upstreams: loud, not silently wrong
+        with pytest.raises(RuntimeError, match="unscaled"):
+            loop(3.0, 6, "in_pass")
+        # two tracking losses with their own track sets on one depth: the exchange (one tap set, one absorbed gradient per parameter) switches
+        # itself off for that parameter, both losses' pixels stay in the element list, the in-pass update still runs
+        d_ref, _, _ = loop(1.0, 8, "torch", second=True)
+        d_ours, optimizer, absorbed = loop(1.0, 8, "in_pass", second=True)
+        assert absorbed == 0 and optimizer.counters["in_pass_updates"] >= 5
+        assert float((d_ours - d_ref).abs().max()) <= 4e-6 * float(d_ref.abs().max()), float((d_ours - d_ref).abs().max())
+    finally:
+        flowmap_amd.set_lazy_surfaces(False)
+        _ops.tap_exchange_min_bytes = min_bytes
+
+
 def case_in_pass_adam_refusals(dev):
     """Where the in-pass update cannot run it does not: weight decay, a dense fit (every pixel is a correspondence), a
     consumer of depth that shows up after the update has been applied (loud), a second backward."""

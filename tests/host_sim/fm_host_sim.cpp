@@ -1443,10 +1443,11 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
 }
 
 int fm_tap_grad_apply(const float* tap_grad, const int64_t* pixels, long count, const float* scale, const float* upstream_plus,
-                      const float* upstream_minus, float* grad_depth, void*) {
+                      const float* upstream_minus, float* grad_depth, int* mismatch_flag, void*) {
   if (count < 0 || !scale || (count > 0 && !(tap_grad && pixels && grad_depth))) return 1;
   const float factor = scale[0] * ((upstream_plus ? upstream_plus[0] : 0.f) - (upstream_minus ? upstream_minus[0] : 0.f));
   if (factor == 0.f) return 0;
+  if (mismatch_flag && count > 0) *mismatch_flag = 1;
   for (long m = 0; m < count; ++m) grad_depth[pixels[m]] += factor * tap_grad[m];
   return 0;
 }
