@@ -60,14 +60,15 @@ def pmc_table(path):
 
 
 if __name__ == "__main__":
-    dirs = sys.argv[1:]
+    dirs = [a for a in sys.argv[1:] if a != "--pmc-only"]
+    pmc_only = "--pmc-only" in sys.argv  # every directory is a PMC pass (no --stats pass first)
     for i, d in enumerate(dirs):
         path = db_in(d)
         print(f"## {d}: {path}")
         if not path:
             continue
         try:
-            if i == 0:
+            if i == 0 and not pmc_only:
                 kernel_table(path)
             else:
                 pmc_table(path)
