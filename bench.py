@@ -125,6 +125,12 @@ def parse():
     ap.add_argument("--no-tap-exchange", action="store_true",
                     help="flow + tracking: run the two losses as in round 3 (the tracking loss after the flow pass, sampling the depth images and "
                          "read-modify-writing dL/ddepth at its taps) instead of the tap exchange (flowmap_amd/_ops.py: TapPlan)")
+    ap.add_argument("--ate", choices=["auto", "on", "off"], default="auto",
+                    help="the metric's second half, `final ATE vs ref`, MEASURED BY THIS RUN: after the timed region, the optimisation the imported reference "
+                         "ran once on the build container's CPU (oracle/make_ate_reference.py -> tests/golden/ate_*_imported_reference.json: 150 frames, flow + "
+                         "tracking, softmin -> regressed intrinsics, Adam) is run here by flowmap_amd from the same initial parameters on the same seeded scene, and "
+                         "both ATEs go into the line's `ate` block.  auto: at N = 1 on the headline config when a fixture is present (seconds on the GPU)")
+    ap.add_argument("--ate-fixture", default=None, help="the reference leg's record (default: the 720p one under tests/golden/, else the 360p one)")
     ap.add_argument("--model", choices=["installed", "direct"], default="installed",
                     help="how the step's modules are built.  `installed` (default): flowmap_amd.install() patches a reference-LAYOUT `flowmap` package "
                          "(the real dcharatan/flowmap when it is importable, else tests/standin — the GPU box has no /root/reference) and the step is that "
@@ -343,6 +349,55 @@ def installed_modules(model_cfg_parts, num_frames, image_shape, with_tracking):
     if with_tracking:
         cfgs.append(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
     return model, get_losses(cfgs)
+
+
+def ate_leg(device, fixture):
+    """`final ATE vs ref`, by this run: flowmap_amd optimises the fixture's scene from the fixture's initial parameters on `device` and its camera
+    positions are scored with the reference's ATE (misc/ate.py:7-25) next to the imported reference's own result.  A CHECKER leg like
+    `cpu_baseline`: the scene generator and the ATE restatement come from tests/tools + oracle/ and nothing here is timed as the product."""
+    import types
+
+    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    import ate_full_chain as chain
+
+    ref = json.loads(Path(fixture).read_text())
+    base = dict(reference=str(fixture), device=str(device), in_pass=False, **ref["config"])
+    t0 = time.perf_counter()
+    first = chain.ours_leg(types.SimpleNamespace(**base), quiet=True, scene_device=str(device))
+    built = first.pop("_built")
+    scene_and_run_s = time.perf_counter() - t0
+    # the schedule's own sensitivity, seen through this implementation: the same run from initial depths moved by 1e-7 (relative, Gaussian)
+    again = chain.ours_leg(types.SimpleNamespace(**base), quiet=True, perturb=1e-7, built=built)
+    again.pop("_built")
+    rel = abs(first["ate_flowmap_amd"] - first["ate_reference_path_cpu"]) / first["ate_reference_path_cpu"]
+    out = {
+        "measured_by_this_run": True,
+        "fixture": str(Path(fixture).relative_to(ROOT)) if str(fixture).startswith(str(ROOT)) else str(fixture),
+        "reference": ref.get("reference_kind", "the reference path as restated by oracle/flowmap_oracle.py (tests/tools/ate_full_chain.py --leg reference)")
+                     + ", on the build container's CPU: " + ref.get("made_by", ""),
+        "scene": first["scene"], "schedule": first["schedule"],
+        "ate_reference": first["ate_reference_path_cpu"], "ate_flowmap_amd": first["ate_flowmap_amd"], "ate_abs_diff": first["ate_abs_diff"], "ate_rel_diff": rel,
+        "final_loss_reference": first["final_loss_reference_path"], "final_loss_flowmap_amd": first["final_loss_flowmap_amd"],
+        "focal_final_reference": first["focal_final_reference_path"], "focal_final_flowmap_amd": first["focal_final_flowmap_amd"],
+        "loss_trace_max_rel_diff": first["loss_trace_max_rel_diff"], "max_position_diff": first["max_position_diff"], "position_scale": first["position_scale"],
+        "seconds_reference_cpu": first["seconds_reference_path_cpu"], "seconds_flowmap_amd": first["seconds_flowmap_amd"],
+        "seconds_scene_synthesis_and_run": scene_and_run_s,
+        "self_sensitivity": {"what": "flowmap_amd against itself from initial depths perturbed by 1e-7 (relative): what rounding-level differences become under this schedule",
+                             "ate_perturbed": again["ate_flowmap_amd"],
+                             "ate_rel_diff": abs(again["ate_flowmap_amd"] - first["ate_flowmap_amd"]) / first["ate_flowmap_amd"]},
+    }
+    sens = ref.get("self_sensitivity")  # (written into the fixture by oracle/make_ate_reference.py --perturb: the reference against itself)
+    if sens:
+        out["self_sensitivity"]["reference_ate_rel_diff"] = sens.get("ate_rel_diff")
+        out["self_sensitivity"]["reference_made_by"] = sens.get("made_by")
+    return out
+
+
+def default_ate_fixture():
+    for name in ("ate_150x720x1280_imported_reference.json", "ate_150x360x640_imported_reference.json"):
+        if (ROOT / "tests" / "golden" / name).exists():
+            return ROOT / "tests" / "golden" / name
+    return None
 
 
 def _cpu_frames(args, f_video, h, w):
@@ -734,7 +789,7 @@ def main():
     kernel_ms = sum(flow_ms) / max(len(flow_ms), 1)
     traffic, traffic_src = None, None
     taps_on = _ops.counters["flow_tap_passes"] > 0
-    for name in ("r04_flow_kernel_traffic.json", "r03_flow_kernel_traffic.json", "r02_flow_kernel_traffic.json", "r01_flow_kernel_traffic.json"):  # HBM bytes per launch from the PMC passes (same workload only)
+    for name in ("r05_flow_kernel_traffic.json", "r04_flow_kernel_traffic.json", "r03_flow_kernel_traffic.json", "r02_flow_kernel_traffic.json", "r01_flow_kernel_traffic.json"):  # HBM bytes per launch from the PMC passes (same workload only)
         try:
             rec = json.loads((ROOT / "profiles" / name).read_text())
             if {k: rec["workload"][k] for k in ("frames", "height", "width")} == {"frames": f, "height": h, "width": w}:
@@ -743,7 +798,7 @@ def main():
                        (True, True): "flow_fused_kernel_adam_taps"}[(in_pass_on, taps_on)]  # (the kernel instance that ran)
                 if key and key not in rec:
                     continue
-                entry = rec[key] if key else rec.get("driver_command_round4", rec)  # (the plain instance: re-measured in round 4 on the driver's own command)
+                entry = rec[key] if key else rec.get("driver_command_round4", rec)  # (r05: the plain instance is the record's top level)  # (the plain instance: re-measured in round 4 on the driver's own command)
                 traffic, traffic_src = entry["hbm_bytes_per_launch"], f"profiles/{name}"
                 break
         except Exception:
@@ -828,21 +883,21 @@ def main():
                 "kernel_ms_first5_last5": [sum(flow_ms[:5]) / 5, sum(flow_ms[-5:]) / 5] if len(flow_ms) >= 10 else None,
             },
         }
-        # the metric's second half ("final ATE vs ref"): not a quantity of a timing run on random-init inputs — the committed record of the
-        # same optimisation run twice from one initialisation, by the imported reference (CPU, oracle/make_ate_reference.py) and by this
-        # package (GPU, tests/tools/ate_full_chain.py --leg ours), is quoted here the way `traffic_measured_in` quotes the PMC passes
+        # the metric's second half ("final ATE vs ref"), measured by THIS run (ate_leg above); records of earlier runs are quoted under
+        # `quoted_records`, never beside the measured values
+        fixture = Path(args.ate_fixture) if args.ate_fixture else default_ate_fixture()
+        want_ate = args.ate == "on" or (args.ate == "auto" and world == 1 and args.share <= 1 and on_gpu and args.config == "c1" and not args.whole
+                                        and (f_video, h, w) == (150, 720, 1280))
+        if want_ate and fixture is not None and fixture.exists():
+            try:
+                result["ate"] = ate_leg(device, fixture)
+            except Exception as exc:  # noqa: BLE001  (the timing line must not be lost to the comparison leg)
+                result["ate"] = {"measured_by_this_run": False, "failed": repr(exc)[:400]}
+        quoted = {}
         try:
             rec = json.loads((ROOT / "profiles" / "r04_ate_150x360x640_vs_imported_reference.json").read_text())
-            result["ate"] = {
-                "record": "profiles/r04_ate_150x360x640_vs_imported_reference.json (reference leg: tests/golden/ate_150x360x640_imported_reference.json)",
-                "scene": rec.get("scene"), "schedule": rec.get("schedule"),
-                "reference": "the imported reference itself (flowmap.model.model.Model + flowmap.loss.get_losses + torch.optim.Adam + flowmap.misc.ate.compute_ate), CPU",
-                "ate_reference": rec["ate_reference_path_cpu"], "ate_flowmap_amd": rec["ate_flowmap_amd"], "ate_abs_diff": rec["ate_abs_diff"],
-                "final_loss_reference": rec["final_loss_reference_path"], "final_loss_flowmap_amd": rec["final_loss_flowmap_amd"],
-                "seconds_reference_cpu": rec["seconds_reference_path_cpu"], "seconds_flowmap_amd": rec["seconds_flowmap_amd"],
-                "note": "150 frames @ 360x640, 200 Adam steps at lr 1e-3 (not 720p / 2000 steps at 3e-5: the reference leg takes 44 min on the build "
-                        "container's CPU as it is); measured once, not by this run",
-            }
+            quoted["ate_150x360x640_round4"] = {"record": "profiles/r04_ate_150x360x640_vs_imported_reference.json", "ate_reference": rec["ate_reference_path_cpu"],
+                                                "ate_flowmap_amd": rec["ate_flowmap_amd"], "note": "200 Adam steps at lr 1e-3, measured in round 4, not by this run"}
         except Exception:  # noqa: BLE001
             pass
         if package is not None:
@@ -922,10 +977,12 @@ def main():
             record = ROOT / "profiles" / "r04_stock_pytorch_rocm_150_frames_in_16_frame_windows.json"
             try:
                 rec = json.loads(record.read_text())
-                result["rocm_torch_baseline"] = {"record": f"profiles/{record.name}", "ms_per_step": rec["ms_per_step"], "iters_per_sec": rec["iters_per_sec"],
+                quoted["rocm_torch_baseline"] = {"record": f"profiles/{record.name}", "ms_per_step": rec["ms_per_step"], "iters_per_sec": rec["iters_per_sec"],
                                                  "frames_per_call": rec["frames_per_call"], "note": "measured once (--torch-baseline N measures it in this run); " + rec["note"]}
             except Exception:  # noqa: BLE001
                 pass
+        if quoted:
+            result["quoted_records"] = {"what": "numbers of EARLIER runs kept under profiles/, quoted for context: nothing under this key was measured by this run", **quoted}
         print(json.dumps(result), file=result_stream, flush=True)
     if dist is not None:
         dist.barrier()

@@ -35,9 +35,12 @@ def step_indices(step: int, n: int, count: int) -> torch.Tensor:
     return torch.randperm(n, generator=torch.Generator().manual_seed(1000 + step))[: min(count, n)]
 
 
-def scene(args):
+def scene(args, device="cpu"):
+    """``device``: where the scene is GENERATED (fp64 there, fp32 results on the host either way: oracle.synth_scene) — minutes on host cores
+    at 150 x 720p, seconds on the GPU; the two differ by the rounding of the device's fp64 elementary functions, i.e. in about one fp32 value of
+    10^9 by one ulp."""
     f, h, w = args.frames, args.height, args.width
-    sc = orc.synth_scene(f, h, w, seed=args.seed, focal=0.85, depth_noise=args.noise)
+    sc = orc.synth_scene(f, h, w, seed=args.seed, focal=0.85, depth_noise=args.noise, device=device)
     tracks = orc.synth_tracks(f, h, w, scene=sc, seed=args.seed, interval=5, radius=min(20, f), grid=args.track_grid)
     return sc, tracks
 
@@ -112,7 +115,9 @@ def reference_leg(args):
     print(json.dumps({k: v for k, v in result.items() if k != "positions"}))
 
 
-def ours_leg(args):
+def ours_leg(args, quiet=False, scene_device="cpu", perturb=0.0, built=None):
+    """-> the comparison record (also printed unless ``quiet``).  ``perturb``: relative Gaussian perturbation of the initial depths (the
+    schedule's sensitivity seen through this implementation); ``built``: a (scene, tracks) pair from an earlier call, reused."""
     import flowmap_amd
     from flowmap_amd import Batch, _lib
     from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
@@ -131,7 +136,7 @@ def ours_leg(args):
         from helpers import build_host_sim
 
         _lib.set_library_for_testing(build_host_sim())
-    sc, otracks = scene(args)
+    sc, otracks = built if built is not None else scene(args, scene_device)
     gt_pos = sc["extrinsics_gt"][:, :3, 3]
     flowmap_amd.set_lazy_surfaces(True)
     from flowmap_amd.model.model import IntrinsicsRegressedCfg
@@ -140,7 +145,10 @@ def ours_leg(args):
                   IntrinsicsSoftminCfg("softmin", args.softmin_points, *CANDIDATES, args.num_candidates, RegressionCfg(args.after_step, args.window)))
     cfg = ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), intrinsics, ExtrinsicsProcrustesCfg("procrustes", args.points, False))
     model = Model(cfg, num_frames=f, image_shape=(h, w))
-    model.backbone.depth.data = sc["depth_init"].clone()
+    d0 = sc["depth_init"].clone()
+    if perturb != 0.0:
+        d0 = d0 * (1.0 + perturb * torch.randn(d0.shape, generator=torch.Generator().manual_seed(12345)))
+    model.backbone.depth.data = d0
     model = model.to(dev)
     model.train()
     state = {"step": 0}
@@ -178,7 +186,7 @@ def ours_leg(args):
     pos = out.extrinsics[0, :, :3, 3].cpu()
     ate_ours = orc.ate(gt_pos, pos)
     ref_pos = torch.tensor(ref["positions"])
-    print(json.dumps({
+    record = {
         "scene": f"synthetic consistent scene, {f} frames @ {h}x{w} ({f - 1} chained poses), seed {args.seed}, depth noise {args.noise}",
         "schedule": f"flow (1000) + tracking (100, {len(otracks)} segments x {args.track_grid ** 2} tracks); softmin intrinsics ({args.num_candidates} candidates x "
                     f"{args.softmin_points} points) for {args.after_step} steps, window {args.window}, then the regressed focal length; Adam lr {args.lr}, {args.steps} steps"
@@ -196,7 +204,12 @@ def ours_leg(args):
         "optimizer": "reference path: torch.optim.Adam; flowmap_amd: flowmap_amd.FusedAdam"
                      + (f" with fuse_depth_update ({opt.counters['in_pass_updates']} of {args.steps} depth updates inside the flow pass)" if args.in_pass else ""),
         "reference_made_by": ref["made_by"],
-    }))
+        "perturb": perturb, "positions_flowmap_amd": pos.tolist(),
+    }
+    if not quiet:
+        print(json.dumps({k: v for k, v in record.items() if k != "positions_flowmap_amd"}))
+    record["_built"] = (sc, otracks)
+    return record
 
 
 def compare_leg(args):
