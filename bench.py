@@ -136,6 +136,9 @@ def parse():
                          "(the real dcharatan/flowmap when it is importable, else tests/standin — the GPU box has no /root/reference) and the step is that "
                          "package's own Model(get_backbone, get_intrinsics, get_extrinsics) + get_losses, i.e. what an unmodified overfit.py runs "
                          "(model_wrapper_overfit.py:51-62).  `direct`: flowmap_amd.model.model.Model and the loss classes constructed by hand")
+    ap.add_argument("--no-track-presample", action="store_true",
+                    help="flow + tracking: the tracking loss samples in the prologue of its pair kernel (rounds 2-4) instead of beside the Procrustes fit on a "
+                         "second stream (flowmap_amd/_ops.py: track_presample)")
     ap.add_argument("--torch-baseline", type=int, default=0, metavar="STEPS",
                     help="after the timed region: the reference's op sequence on stock PyTorch-ROCm on this GPU (tests/tools/torch_gpu_reference_ops.py "
                          "in a process of its own, 1 warm-up + STEPS steps on i.i.d. inputs of the workload's size) as `rocm_torch_baseline`")
@@ -510,6 +513,8 @@ def main():
     flowmap_amd.set_lazy_surfaces(True)
     if args.no_tap_exchange:
         _ops.use_tap_exchange = False
+    if args.no_track_presample:
+        _ops.use_track_presample = False
     if os.environ.get("FLOWMAP_THREE_LAUNCH_BWD"):  # A/B: the planned Procrustes backward as the three launches of round 2
         from flowmap_amd._lib import torch_ops
 
@@ -931,6 +936,7 @@ def main():
                 "kernel": "fm::track_pairs_kernel<huber, GRAD> (+ track_reduce, finalize" + (", tap_grad: one fm_track_loss_fused_fwd_taps call)" if _ops.counters["flow_tap_absorbs"] else ": one fm_track_loss_fused_fwd call)"),
                 "tap_exchange": {"flow_passes_with_taps": _ops.counters["flow_tap_passes"], "absorbed": _ops.counters["flow_tap_absorbs"],
                                  "sampled_from_tap_image": _ops.counters["track_tap_samples"]},
+                "sampled_beside_the_fit": {"presample_launches": _ops.counters["track_presamples"], "losses_that_used_them": _ops.counters["track_presampled_losses"]},
                 "bound": "valu",
                 "achieved": gflops,
                 "peak": FP32_PEAK_GFLOPS,

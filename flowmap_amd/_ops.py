@@ -29,110 +29,8 @@ from torch import Tensor
 
 from ._lib import call, check_device, ptr, stream_for, torch_ops
 
-MAPPING_KINDS = {"huber": 0, "l1": 1, "l2": 2}
-
-FLOW_ACC_STRIDE = 20
-STAT_STRIDE = 16
-AUX_STRIDE = 40
-PAIR_GRAD_STRIDE = 20
-DENSE_CONST_STRIDE = 40  # FM_DENSE_CONST_STRIDE
-TRACK_TILE = 6  # FM_TRACK_TILE (include/flowmap_hip.h; tests/test_abi.py checks they agree)
-
-
-# Device flags (one int32 each) that a backward raises when a loss reached it SCALED although something had already used its unscaled
-# gradient (FusedAdam.fuse_depth_update, FrameShard.enable_early_halo).  Their owners read them every so often; a step replayed as a
-# hipGraph runs no Python, so GraphedStep reads every live flag outside its replays.  Weak: a flag dies with its owner.
-_unit_flags = weakref.WeakSet()
-
-
-def register_unit_flag(flag: Tensor) -> Tensor:
-    _unit_flags.add(flag)
-    return flag
-
-
-def check_unit_flags(what: str) -> None:
-    """Raise (and clear) if any registered flag is up.  Synchronises: callers space their calls out."""
-    for flag in list(_unit_flags):
-        if int(flag.item()) != 0:
-            flag.zero_()
-            raise RuntimeError(f"flowmap_amd: {what}: a loss reached backward() with an upstream gradient other than 1 although its unscaled gradient had "
-                               "already been used (FusedAdam.fuse_depth_update applied it inside the flow pass / FrameShard.enable_early_halo sent it before "
-                               "backward): the affected steps are wrong.  Switch those options off for a scaled or averaged loss.")
-
-
-def _f32c(t: Tensor, what: str) -> Tensor:
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"flowmap_amd: {what} must be float32 (got {t.dtype})")
-    if t.is_contiguous():
-        return t
-    if t.numel() >= 1 << 24:  # a copy the size of a pass over the step's tensors: say so (SURVEY.md §8b "Ownership")
-        warnings.warn(f"flowmap_amd: {what} is a non-contiguous view of {t.numel() * 4 >> 20} MB and is copied on every call; pass a contiguous tensor")
-    return t.contiguous()
-
-
-class FmLayout(ctypes.Structure):
-    """include/flowmap_hip.h: fm_layout — element strides between the frames / batch entries of an image stack ({0, 0} = dense)."""
-
-    _fields_ = [("frame_stride", ctypes.c_long), ("batch_stride", ctypes.c_long)]
-
-
-def frame_window_layout(t: Tensor) -> Optional[tuple]:
-    """(frame_stride, batch_stride) in elements when ``t`` (batch, frame, ...) can be read in place — every frame dense, i.e. a
-    contiguous tensor or a frame window ``x[:, s:s+f]`` / batch slice of one — else None (the caller copies)."""
-    if t.is_contiguous():
-        return (0, 0)
-    if t.dim() < 3:
-        return None
-    per_frame = 1
-    for d in range(t.dim() - 1, 1, -1):
-        if t.shape[d] != 1 and t.stride(d) != per_frame:
-            return None
-        per_frame *= t.shape[d]
-    if t.shape[1] != 1 and t.stride(1) < per_frame:
-        return None
-    frame_stride = per_frame if t.shape[1] == 1 else t.stride(1)
-    # batch entries must not overlap (the launchers refuse it): a batch-expanded stack (stride 0 over the batch) is copied by the caller
-    if t.shape[0] != 1 and t.stride(0) < frame_stride * (t.shape[1] - 1) + per_frame:
-        return None
-    return (frame_stride, frame_stride * t.shape[1] if t.shape[0] == 1 else t.stride(0))
-
-
-def _layout_array(*tensors):
-    """(ctypes array of fm_layout, any of them a real view?) for the `_views` entry points; None when a tensor cannot be read in place."""
-    arr = (FmLayout * len(tensors))()
-    any_view = False
-    for i, t in enumerate(tensors):
-        lay = frame_window_layout(t)
-        if lay is None:
-            return None, False
-        arr[i].frame_stride, arr[i].batch_stride = lay
-        any_view = any_view or lay != (0, 0)
-    return arr, any_view
-
-
-class _guard:
-    """Select the tensor's GPU for the launches inside (no-op for the host test double)."""
-
-    def __init__(self, dev: torch.device):
-        self.ctx = torch.cuda.device(dev) if dev.type == "cuda" else None
-
-    def __enter__(self):
-        if self.ctx is not None:
-            self.ctx.__enter__()
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-
-
-def _derived(owner: Tensor, name: str, key, build):
-    """``build()`` once per (owner tensor object, key): the value is kept on the tensor itself."""
-    slot = owner.__dict__.get(name)
-    if slot is not None and slot[0] == key:
-        return slot[1]
-    value = build()
-    owner.__dict__[name] = (key, value)
-    return value
+from ._base import (AUX_STRIDE, DENSE_CONST_STRIDE, FLOW_ACC_STRIDE, MAPPING_KINDS, PAIR_GRAD_STRIDE, STAT_STRIDE, TRACK_TILE, FmLayout,  # noqa: F401
+                    _derived, _f32c, _guard, _layout_array, _unit_flags, check_unit_flags, frame_window_layout, register_unit_flag)
 
 
 # --------------------------------------------------------------------------------------
@@ -342,7 +240,7 @@ def _dense_flow_is_rough(bwd_flow: Tensor, h: int, w: int) -> bool:
     return _derived(bwd_flow, "_fm_dense_rough", (bwd_flow._version, h, w), build)
 
 # which backward path the facades selected (tests)
-counters = {"procrustes_planned": 0, "procrustes_dense_planned": 0, "flow_packs": 0, "procrustes_plans_built": 0, "track_tap_samples": 0,
+counters = {"track_presamples": 0, "track_presampled_losses": 0, "procrustes_planned": 0, "procrustes_dense_planned": 0, "flow_packs": 0, "procrustes_plans_built": 0, "track_tap_samples": 0,
             "flow_tap_passes": 0, "flow_tap_absorbs": 0}
 
 
@@ -487,6 +385,62 @@ def _dense_procrustes_plan(bwd_flow: Tensor, b: int, f: int, h: int, w: int):
     return _derived(bwd_flow, "_fm_dense_plan", (bwd_flow._version, b, f, h, w), build)
 
 
+# The tracking loss's sampling splits into a camera-space half — bilinear taps of depth, K⁻¹: xyz and h per (segment, frame, point) — and the
+# pose that takes xyz to the world.  Only the second half needs the step's poses.  When a fused tracking loss ran on this depth parameter in
+# the previous step (it leaves a request on the parameter), the first half is launched HERE, on a second stream, right before the Procrustes
+# fit is enqueued: the fit is a latency-bound launch of one block per pair (~150 of 256 CUs, 38 us at C2) and the sampling a latency-bound
+# gather (37-64 us as the prologue of track_pairs, with every wave of that kernel waiting at once) — side by side they cost the longer of the
+# two.  The tracking loss of the step then finds xyz / h / flags ready (`_fm_presampled` on the step's depth tensor) and its pair kernel
+# starts with coalesced loads (fm_track_loss_fused_fwd_taps, presampled = 1).  Same arithmetic, same results bit for bit.
+use_track_presample = True
+track_presample_min_bytes = 64 << 20  # (below this the depth images are cache-resident and the step is host-bound: the bookkeeping would cost more)
+_side_streams: dict = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device)
+    return _side_streams[key]
+
+
+def track_presample(depth: Tensor, kinv: Tensor) -> None:
+    root = _whole_parameter(depth)
+    request = root.__dict__.get("_fm_track_presample") if root is not None else None
+    if request is None or not use_track_presample or depth.numel() * 4 < track_presample_min_bytes:
+        return
+    if depth.is_cuda and torch.cuda.is_current_stream_capturing():
+        return  # (a captured step must join every stream it forks: whether the tracking loss will come is not known here)
+    packed = request()
+    if packed is None or packed.partial or packed.nblocks == 0 or depth.shape[0] != 1 or packed.last_frame > depth.shape[1] or not depth.is_contiguous() \
+            or depth.dtype != torch.float32 or packed.xy.device != depth.device:
+        return
+    f, h, w = depth.shape[1:]
+    taps = (None, None)
+    if use_tap_exchange and use_tap_image and depth.numel() * 4 >= tap_exchange_min_bytes:
+        plan = root.__dict__.get("_fm_tap_plan")
+        if plan is not None and plan.packed is packed and plan.key == (int(f), int(h), int(w)) and plan.image_valid_for(root):
+            taps = (plan.image_slots, plan.image)
+    # (allocated on the CALLER's stream: the blocks are handed back to that stream's pool, after the tracking loss — which waits for the
+    # event below — has read them)
+    ws = torch.empty((packed.total, 9), dtype=torch.float32, device=depth.device)
+    flag = torch.empty((packed.total,), dtype=torch.uint8, device=depth.device)
+    args = (ptr(depth), ptr(kinv), ptr(packed.xy), ptr(packed.vis), ptr(packed.seg), ptr(packed.blocks), packed.nblocks, packed.pmax, int(h), int(w),
+            ptr(taps[0]), ptr(taps[1]), ptr(ws), ptr(flag))
+    done = None
+    if depth.is_cuda:
+        side, main = _side_stream(depth.device), torch.cuda.current_stream(depth.device)
+        side.wait_stream(main)  # depth, K⁻¹ (and the tap image) are final on the caller's stream
+        with torch.cuda.stream(side):
+            call("fm_track_presample", *args, side.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(side)
+    else:  # the host double: executed in place
+        call("fm_track_presample", *args, None)
+    depth.__dict__["_fm_presampled"] = (packed, ws, flag, done, kinv, taps[1] is not None)
+    counters["track_presamples"] += 1
+
+
 class ProcrustesFit:
     """align_surfaces up to (not including) the pose chain (projection.py:213-249) with
     align_rigid (procrustes.py:7-51) inside (csrc/fm_torch.cpp: ProcrustesFit).  Source of xyz is either
@@ -552,6 +506,8 @@ class ProcrustesFit:
             pairs = bwd_flow.shape[0] * bwd_flow.shape[1]
             work = _derived(bwd_flow, "_fm_fit_work", (pairs, str(bwd_flow.device)),
                             lambda: torch.zeros((pairs * STAT_STRIDE + (pairs + 2) // 2 + 1,), dtype=torch.float64, device=bwd_flow.device))
+        if from_depth and rep == 1 and sink is not None and depth.dim() == 4:
+            track_presample(depth, kinv)  # (the tracking loss's camera-space sampling, beside the fit: see track_presample)
         t_bwd, t_fwd, ext = torch_ops().procrustes_fit(depth, k, kinv, surfaces, weights, bwd_flow, indices, float(weight_sens), rep, sink, wsink,
                                                        arena, *sparse, *dense, work)
         return t_bwd, t_fwd, (ext if ext.numel() > 0 else None)
@@ -798,411 +754,11 @@ def random_subset(n: int, count: int, device, seed: Optional[int] = None) -> Ten
     return torch_ops().random_subset(int(n), int(count), device, int(seed), None)
 
 
-# --------------------------------------------------------------------------------------
-# Flow post-processing (no gradients: flows and masks are constants of the optimisation)
-# --------------------------------------------------------------------------------------
-
-
-def _check_video_flow(videos: Tensor, flow: Tensor):
-    check_device(videos, flow)
-    if videos.dim() != 5 or videos.shape[2] != 3:
-        raise RuntimeError("flowmap_amd: videos must be (batch, frame, 3, height, width)")
-    b, f, _, h, w = videos.shape
-    if f < 2 or tuple(flow.shape) != (b, f - 1, h, w, 2):
-        raise RuntimeError("flowmap_amd: flow must be (batch, frame-1, height, width, 2) at the video's resolution")
-    return b, f, h, w
-
-
-def consistency_mask(videos: Tensor, flow: Tensor) -> Tensor:
-    """FlowPredictor.compute_consistency_mask (flowmap/flow/flow_predictor.py:59-80)."""
-    b, f, h, w = _check_video_flow(videos, flow)
-    with torch.no_grad():
-        videos, flow = _f32c(videos, "videos"), _f32c(flow, "flow")
-        mask = torch.empty((b, f - 1, h, w), dtype=torch.float32, device=videos.device)
-        with _guard(videos.device):
-            call("fm_consistency_mask", ptr(videos), ptr(flow), b, f, h, w, ptr(mask), stream_for(videos))
-    return mask
-
-
-def flow_postprocess(videos: Tensor, raw_flow: Tensor, shape, reverse: bool):
-    """Consistency mask + rescale_flow + rescale_mask (+ the flips back when ``reverse``) of
-    compute_bidirectional_flow (flow_predictor.py:82-102).  -> (flow (b,f-1,*shape,2), mask)."""
-    b, f, h, w = _check_video_flow(videos, raw_flow)
-    oh, ow = int(shape[0]), int(shape[1])
-    with torch.no_grad():
-        videos, raw_flow = _f32c(videos, "videos"), _f32c(raw_flow, "flow")
-        out_flow = torch.empty((b, f - 1, oh, ow, 2), dtype=torch.float32, device=videos.device)
-        out_mask = torch.empty((b, f - 1, oh, ow), dtype=torch.float32, device=videos.device)
-        with _guard(videos.device):
-            call("fm_flow_postprocess", ptr(videos), ptr(raw_flow), b, f, h, w, oh, ow, 1 if reverse else 0, ptr(out_flow),
-                 ptr(out_mask), stream_for(videos))
-    return out_flow, out_mask
-
-
-def resize_crop(images: Tensor, resized_shape, crop_shape) -> Tensor:
-    """``center_crop_images(F.interpolate(images, resized_shape, bilinear), crop_shape)``
-    (flowmap/misc/cropping.py:19-51) for (..., H, W) images in one launch; no gradients (it is
-    data preparation)."""
-    check_device(images)
-    *lead, h, w = images.shape
-    rh, rw = int(resized_shape[0]), int(resized_shape[1])
-    oh, ow = int(crop_shape[0]), int(crop_shape[1])
-    if oh > rh or ow > rw or min(oh, ow, rh, rw) < 1:
-        raise RuntimeError("flowmap_amd: the crop must fit inside the resized image")
-    planes = 1
-    for d in lead:
-        planes *= int(d)
-    with torch.no_grad():
-        images = _f32c(images, "images")
-        out = torch.empty((*lead, oh, ow), dtype=torch.float32, device=images.device)
-        done = 0
-        with _guard(images.device):
-            while done < planes:  # the launch takes at most 65535 planes
-                chunk = min(planes - done, 65535)
-                call("fm_resize_crop", images.data_ptr() + done * h * w * 4, chunk, h, w, rh, rw, (rh - oh) // 2, (rw - ow) // 2, oh, ow,
-                     out.data_ptr() + done * oh * ow * 4, stream_for(images))
-                done += chunk
-    return out
-
-
-# --------------------------------------------------------------------------------------
-# Function-level building blocks on explicit point sets
-# --------------------------------------------------------------------------------------
-
-
-class Unproject(torch.autograd.Function):
-    """unproject (flowmap/model/projection.py:76-90) for G groups of N points:
-    xy (N,2) shared or (G,N,2); z (G,N); k (G,3,3) -> (G,N,3)."""
-
-    @staticmethod
-    def forward(ctx, xy, z, k):
-        dev = check_device(xy, z, k)
-        xy, z, k = _f32c(xy, "coordinates"), _f32c(z, "z"), _f32c(k, "intrinsics")
-        if xy.requires_grad:
-            raise RuntimeError("flowmap_amd: gradients w.r.t. image coordinates are not supported")
-        g, n = z.shape
-        shared = xy.dim() == 2
-        kinv = intrinsics_inverse(k)
-        out = torch.empty((g, n, 3), dtype=torch.float32, device=dev)
-        with _guard(dev):
-            call("fm_unproject_fwd", ptr(xy), 0 if shared else n * 2, ptr(z), ptr(kinv), g, n, ptr(out), stream_for(z))
-        ctx.save_for_backward(xy, z, kinv)
-        ctx.shared = shared
-        return out
-
-    @staticmethod
-    def backward(ctx, g_out):
-        xy, z, kinv = ctx.saved_tensors
-        g, n = z.shape
-        g_out = _f32c(g_out, "grad")
-        g_z = torch.empty_like(z) if ctx.needs_input_grad[1] else None
-        need_k = ctx.needs_input_grad[2]
-        acc = torch.empty((g, 9), dtype=torch.float64, device=z.device) if need_k else None
-        g_k = None
-        with _guard(z.device):
-            st = stream_for(z)
-            call("fm_unproject_bwd", ptr(xy), 0 if ctx.shared else n * 2, ptr(z), ptr(kinv), ptr(g_out), g, n, ptr(g_z), ptr(acc), st)
-            if need_k:
-                g_k = torch.empty_like(kinv)
-                call("fm_intrinsics_inverse_bwd", ptr(acc), ptr(kinv), g, ptr(g_k), 0, st)
-        return None, g_z, g_k
-
-
-class Reproject(torch.autograd.Function):
-    """reproject_points (flowmap/model/projection.py:116-134): xyz (G,N,3), T (G,4,4),
-    K (G,3,3) -> xy (G,N,2)."""
-
-    @staticmethod
-    def forward(ctx, xyz, t, k):
-        dev = check_device(xyz, t, k)
-        xyz, t, k = _f32c(xyz, "points"), _f32c(t, "transformations"), _f32c(k, "intrinsics")
-        g, n, _ = xyz.shape
-        out = torch.empty((g, n, 2), dtype=torch.float32, device=dev)
-        with _guard(dev):
-            call("fm_reproject_fwd", ptr(xyz), ptr(t), ptr(k), g, n, ptr(out), stream_for(xyz))
-        ctx.save_for_backward(xyz, t, k)
-        return out
-
-    @staticmethod
-    def backward(ctx, g_xy):
-        xyz, t, k = ctx.saved_tensors
-        g, n, _ = xyz.shape
-        g_xy = _f32c(g_xy, "grad")
-        g_xyz = torch.empty_like(xyz) if ctx.needs_input_grad[0] else None
-        g_t = torch.empty_like(t)
-        g_k = torch.empty_like(k)
-        acc = torch.empty((g, 18), dtype=torch.float64, device=xyz.device)
-        with _guard(xyz.device):
-            call("fm_reproject_bwd", ptr(xyz), ptr(t), ptr(k), ptr(g_xy), g, n, ptr(g_xyz), ptr(g_t), ptr(g_k), ptr(acc),
-                 stream_for(xyz))
-        return g_xyz, g_t if ctx.needs_input_grad[1] else None, g_k if ctx.needs_input_grad[2] else None
-
-
-class BilinearSample(torch.autograd.Function):
-    """F.grid_sample(bilinear, border, align_corners=False) of a channels-last image
-    (G,H,W,C) at normalised coordinates (G,P,2) in (0,1) -> (G,P,C)
-    (flowmap/model/projection.py:235-241,266-272)."""
-
-    @staticmethod
-    def forward(ctx, img, xy):
-        dev = check_device(img, xy)
-        img, xy = _f32c(img, "image"), _f32c(xy, "coordinates")
-        if xy.requires_grad:
-            raise RuntimeError("flowmap_amd: gradients w.r.t. sampling coordinates are not supported")
-        g, h, w, c = img.shape
-        p = xy.shape[1]
-        out = torch.empty((g, p, c), dtype=torch.float32, device=dev)
-        with _guard(dev):
-            call("fm_bilinear_sample_fwd", ptr(img), ptr(xy), g, h, w, c, p, ptr(out), stream_for(img))
-        ctx.save_for_backward(xy)
-        ctx.dims = (g, h, w, c, p)
-        return out
-
-    @staticmethod
-    def backward(ctx, g_out):
-        (xy,) = ctx.saved_tensors
-        g, h, w, c, p = ctx.dims
-        g_out = _f32c(g_out, "grad")
-        g_img = torch.zeros((g, h, w, c), dtype=torch.float32, device=xy.device)
-        with _guard(xy.device):
-            call("fm_bilinear_sample_bwd", ptr(g_out), ptr(xy), g, h, w, c, p, ptr(g_img), stream_for(xy))
-        return g_img, None
-
-
-class RobustMapping(torch.autograd.Function):
-    """Mapping.forward (flowmap/loss/mapping/mapping.py:35-43) on (n,2) pairs."""
-
-    @staticmethod
-    def forward(ctx, a, b, kind, delta, ax, ay):
-        dev = check_device(a, b)
-        a, b = _f32c(a, "a"), _f32c(b, "b")
-        n = a.shape[0]
-        out = torch.empty((n,), dtype=torch.float32, device=dev)
-        with _guard(dev):
-            call("fm_mapping_fwd", ptr(a), ptr(b), n, kind, float(delta), float(ax), float(ay), ptr(out), stream_for(a))
-        ctx.save_for_backward(a, b)
-        ctx.cfg = (kind, float(delta), float(ax), float(ay))
-        return out
-
-    @staticmethod
-    def backward(ctx, g_out):
-        a, b = ctx.saved_tensors
-        kind, delta, ax, ay = ctx.cfg
-        g_out = _f32c(g_out, "grad")
-        g_a = torch.empty_like(a) if ctx.needs_input_grad[0] else None
-        g_b = torch.empty_like(b) if ctx.needs_input_grad[1] else None
-        with _guard(a.device):
-            call("fm_mapping_bwd", ptr(a), ptr(b), ptr(g_out), a.shape[0], kind, delta, ax, ay, ptr(g_a), ptr(g_b), stream_for(a))
-        return g_a, g_b, None, None, None, None
-
-
-class AlignRigid(torch.autograd.Function):
-    """align_rigid (flowmap/model/procrustes.py:7-51): p, q (G,P,3), w (G,P) -> (G,4,4)."""
-
-    @staticmethod
-    def forward(ctx, p, q, w):
-        dev = check_device(p, q, w)
-        p, q, w = _f32c(p, "p"), _f32c(q, "q"), _f32c(w, "weights")
-        g, n, _ = p.shape
-        stats = torch.empty((g, STAT_STRIDE), dtype=torch.float64, device=dev)
-        t = torch.empty((g, 4, 4), dtype=torch.float32, device=dev)
-        aux = torch.empty((g, AUX_STRIDE), dtype=torch.float64, device=dev)
-        with _guard(dev):
-            st = stream_for(p)
-            call("fm_align_rigid_stats", ptr(p), ptr(q), ptr(w), g, n, ptr(stats), st)
-            call("fm_pose_solve", ptr(stats), g, ptr(t), None, ptr(aux), st)
-        ctx.save_for_backward(p, q, w, t, aux)
-        return t
-
-    @staticmethod
-    def backward(ctx, g_t):
-        p, q, w, t, aux = ctx.saved_tensors
-        g, n, _ = p.shape
-        g_t = _f32c(g_t, "grad")
-        pair_grad = torch.empty((g, PAIR_GRAD_STRIDE), dtype=torch.float64, device=p.device)
-        g_p = torch.empty_like(p) if ctx.needs_input_grad[0] else None
-        g_q = torch.empty_like(q) if ctx.needs_input_grad[1] else None
-        g_w = torch.empty_like(w) if ctx.needs_input_grad[2] else None
-        with _guard(p.device):
-            st = stream_for(p)
-            call("fm_pose_solve_bwd", ptr(g_t), None, ptr(t), ptr(aux), g, ptr(pair_grad), None, 0, st)
-            call("fm_align_rigid_bwd", ptr(p), ptr(q), ptr(w), g, n, ptr(aux), ptr(pair_grad), ptr(g_p), ptr(g_q), ptr(g_w), st)
-        return g_p, g_q, g_w
-
-
-# --------------------------------------------------------------------------------------
-# Fused tracking loss
-# --------------------------------------------------------------------------------------
-
-
-class PackedTracks:
-    """All track segments (flowmap/tracking/track_predictor.py:13-20) packed into the flat
-    arrays fm_track_* expects.  Tracks are constants of the optimisation: packed once.
-    ``own = (first, end)``: frame sharding — only frames first <= frame < end act as SOURCES on
-    this rank (the targets of a segment can lie on any rank; they need poses, not depth)."""
-
-    def __init__(self, tracks, device, own=None):
-        xy, vis, seg, blocks, tiles = [], [], [], [], []
-        offset = 0
-        owned = (lambda frame: True) if own is None else (lambda frame: own[0] <= frame < own[1])
-        for s_idx, t in enumerate(tracks):
-            b, f, p, _ = t.xy.shape
-            if b != 1:
-                raise RuntimeError("flowmap_amd: the fused tracking loss supports batch size 1 (as the reference asserts)")
-            start = int(t.start_frame)
-            xy.append(t.xy[0].reshape(f * p, 2).to(device=device, dtype=torch.float32))
-            vis.append(t.visibility[0].reshape(f * p).to(device=device, dtype=torch.uint8))
-            seg.append([start, f, p, offset])
-            blocks.extend([s_idx, fr] for fr in range(f) if owned(start + fr))
-            tiles.extend([s_idx, fr] for fr in range(0, f, TRACK_TILE) if any(owned(start + q) for q in range(fr, min(fr + TRACK_TILE, f))))
-            offset += f * p
-        self.total = offset
-        self.partial = own is not None  # some (segment, frame) entries are not sources here: flags start at 0
-        self.xy = torch.cat(xy).contiguous()
-        self.vis = torch.cat(vis).contiguous()
-        self.seg = torch.tensor(seg, dtype=torch.int32).to(device)
-        # frame-major launch order for the per-(segment, frame) kernels (track_points, track_scatter):
-        # the ~8 segments that cover a frame gather from / scatter into the SAME depth image back to
-        # back, so their 4-tap accesses share DRAM pages and L2 lines instead of sweeping 41 images
-        blocks.sort(key=lambda sf: (seg[sf[0]][0] + sf[1], sf[0]))
-        self.blocks = torch.tensor(blocks, dtype=torch.int32).reshape(-1, 2).to(device)
-        self.nblocks = len(blocks)
-        self.tiles = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 2).to(device)  # (segment, first source frame) per register tile
-        self.ntiles = len(tiles)
-        self.pmax = max(s_[2] for s_ in seg)
-        self.fmax = max(s_[1] for s_ in seg)
-        self.last_frame = max(s_[0] + s_[1] for s_ in seg)
-        self.counts = [self.nblocks, self.ntiles, self.pmax, self.fmax, self.total, int(self.partial), self.last_frame,
-                       0 if own is None else int(own[0]), -1 if own is None else int(own[1])]  # ..., source frames owned here [first, end)
-        self._plans: dict = {}
-        self._tap_slots: dict = {}
-        self._tap_plans: dict = {}
-
-    def scatter_plan(self, height: int, width: int):
-        """Where the tracking gradient lands in dL/ddepth, planned once per image shape (tracks are
-        constants): (pixels int64 ascending, first int32, source point of each entry int32, weights)
-        for fm_depth_gather.  Built with one launch + a sort; None when nothing is scattered."""
-        key = (int(height), int(width))
-        if key not in self._plans:
-            plan = None
-            if self.nblocks > 0:
-                dev = self.xy.device
-                keys = torch.full((self.total * 4,), -1, dtype=torch.int64, device=dev)
-                weights = torch.empty((self.total * 4,), dtype=torch.float32, device=dev)
-                with _guard(dev):
-                    call("fm_track_scatter_plan", ptr(self.xy), ptr(self.vis), ptr(self.seg), ptr(self.blocks), self.nblocks, self.pmax,
-                         key[0], key[1], ptr(keys), ptr(weights), stream_for(self.xy))
-                used = torch.nonzero(keys >= 0).reshape(-1)
-                if used.numel() > 0:
-                    sorted_keys, order = torch.sort(keys[used], stable=True)
-                    entries = used[order]
-                    pixels, counts = torch.unique_consecutive(sorted_keys, return_counts=True)
-                    first = torch.zeros((pixels.numel() + 1,), dtype=torch.int32, device=dev)
-                    first[1:] = torch.cumsum(counts, 0).to(torch.int32)
-                    plan = (pixels.contiguous(), first, (entries // 4).to(torch.int32).contiguous(), weights[entries].contiguous())
-                    # where each tap of each track point sits in `pixels` (its rank), -1 for a tap that contributes nothing: the tap
-                    # exchange's view of the same plan (fm_track_loss_fused_fwd_taps)
-                    # (bit 30: the pixel has more than one entry, i.e. several track points share it — fm_track_loss_fused_fwd_taps)
-                    # (the slot encoding keeps 29 rank bits: bit 29 = read the depth image, TapPlan.slots_reading_around)
-                    assert plan[0].numel() < 1 << 29
-                    slots = torch.full((self.total * 4,), -1, dtype=torch.int32, device=dev)
-                    ranks = torch.searchsorted(plan[0], keys[used])
-                    shared = counts > 1
-                    slots[used] = (ranks + shared[ranks].to(torch.int64) * (1 << 30)).to(torch.int32)
-                    self._tap_slots[key] = (slots.contiguous(), torch.nonzero(shared).reshape(-1).to(torch.int32).contiguous())
-            self._plans[key] = plan
-        return self._plans[key]
-
-    def tap_plan(self, frames: int, height: int, width: int):
-        """The static tap set of this track list as the fused flow pass wants it (include/flowmap_hip.h: fm_flow_taps), built once per
-        video shape: a TapPlan with the sorted tap pixels, the rank of the first tap of every 64-quad chunk of a frame of a (1, frames,
-        height, width) depth tensor, each tap's pixel index inside its frame, and the (total, 4) slot of every tap of every track point.  None when the layout
-        does not apply (width or pixel count not a multiple of 4, nothing scattered, a segment past the last frame)."""
-        key = (int(frames), int(height), int(width))
-        if key not in self._tap_plans:
-            plan = self.scatter_plan(height, width) if self.nblocks > 0 and not self.partial else None
-            n = int(height) * int(width)
-            built = None
-            if plan is not None and width % 4 == 0 and self.last_frame <= frames and plan[0].numel() < 2**29:
-                pixels = plan[0]
-                dev = pixels.device
-                quads, chunks = n // 4, (n // 4 + 63) // 64
-                # rank of the first tap at or after quad 64·c of frame f: taps with key < f·n + 256·c; one more entry at the end: M
-                starts = (torch.arange(frames, dtype=torch.int64, device=dev)[:, None] * n
-                          + torch.arange(chunks, dtype=torch.int64, device=dev)[None, :] * 256).reshape(-1)
-                chunk_base = torch.cat([torch.searchsorted(pixels, starts), torch.tensor([pixels.numel()], dtype=torch.int64, device=dev)]).to(torch.int32).contiguous()
-                pixel_in_frame = (pixels % n).to(torch.int32).contiguous()
-                built = TapPlan(self, key, plan, chunk_base, pixel_in_frame, *self._tap_slots[(int(height), int(width))])
-            self._tap_plans[key] = built
-        return self._tap_plans[key]
-
-
-class TapPlan:
-    """The tracking loss's static tap set on one depth tensor shape, and the compact tap image that travels between the fused flow pass
-    and the tracking loss (csrc/fm_flow.hip: TAPS; csrc/fm_track.hip: track_sample_many).  ``image`` (M floats) holds the depth value
-    at every tap as the last flow pass left it; it may be sampled from only while the depth parameter has not moved since
-    (``image_valid_for``: same storage, same version counter)."""
-
-    def __init__(self, packed, key, plan, chunk_base, pixel_in_frame, slots, shared_ranks):
-        self.packed, self.key, self.plan = packed, key, plan
-        self.pixels, self.chunk_base, self.pixel_in_frame, self.slots, self.shared_ranks = plan[0], chunk_base, pixel_in_frame, slots, shared_ranks
-        # (one value of padding: the tracking loss reads the two taps of an image row with one 8-byte load)
-        self.image = torch.zeros((plan[0].numel() + 1,), dtype=torch.float32, device=plan[0].device)[: plan[0].numel()]
-        self._tag = None  # what the image was left for: (the parameter object — weakly —, its storage object's identity, data_ptr, version)
-        # raised by the flow pass when a tap depth it reads differs from the image value the tracking loss of the same step sampled: the
-        # parameter was edited behind its version counter (`param.data.clamp_()` ...).  Read at the first sampled step and every 64th.
-        self.stale_flag = torch.zeros((1,), dtype=torch.int32, device=plan[0].device)
-        self.sampled_now = False  # the tracking loss of the current step sampled from the image: the coming flow pass verifies it
-        self.samples = 0
-        self.image_slots = slots  # the slot table to sample the CURRENT image with (an in-pass Adam update leaves one with holes: slots_reading_around)
-        self.pending_in_pass = False  # the image was left by an in-pass Adam update whose step() has not finished: FusedAdam.step tags it
-
-    def tag(self, root: Tensor) -> None:
-        # (nothing here keeps the parameter or its storage alive: a plan outlives models — it hangs on the track tensors)
-        self._tag = (weakref.ref(root), root.untyped_storage()._cdata, root.data_ptr(), root._version)
-        self.pending_in_pass = False
-
-    def slots_reading_around(self, kept: Optional[Tensor]) -> Tensor:
-        """The slot table for sampling from an image an IN-PASS Adam update left: the taps at the pixels that update keeps for the
-        element-list update (``kept``: sorted flat indices — the Procrustes samples and taps) are flagged to be read from the depth image
-        (bit 29); the image holds their pre-update value.  Built once per kept set."""
-        if kept is None or kept.numel() == 0:
-            return self.slots
-        key = (id(kept), kept._version)
-        hit = self.__dict__.get("_around")
-        if hit is None or hit[0] != key:
-            dense_rank = torch.isin(self.pixels, kept)  # per tap (rank): is its pixel kept?
-            slots = self.slots.clone()
-            valid = slots >= 0
-            ranks = (slots[valid] & 0x1FFFFFFF).to(torch.int64)
-            slots[valid] = slots[valid] | (dense_rank[ranks].to(torch.int32) << 29)
-            hit = self.__dict__["_around"] = (key, kept, slots.contiguous())
-        return hit[2]
-
-    def invalidate(self) -> None:
-        self._tag = None
-
-    def image_valid_for(self, root: Tensor) -> bool:
-        tag = self._tag
-        if tag is None or tag[0]() is not root or tag[1] != root.untyped_storage()._cdata or tag[2:] != (root.data_ptr(), root._version):
-            return False
-        # a step replayed as a hipGraph runs no Python: whether depth moved between replays could not be checked
-        return not (root.is_cuda and torch.cuda.is_current_stream_capturing())
-
-    def note_sampled(self) -> None:
-        self.sampled_now = True
-        self.samples += 1
-
-    def check_stale(self) -> None:
-        """(synchronises) Raise if a flow pass found the image stale although the version counter said otherwise."""
-        if int(self.stale_flag.item()) != 0:
-            self.stale_flag.zero_()
-            self.invalidate()
-            raise RuntimeError(
-                "flowmap_amd: the depth parameter was modified without its version counter moving (an edit through `.data`, a raw pointer): the "
-                "tracking loss sampled tap depths the last flow pass had left behind, and they were stale — the tracking loss and its gradients "
-                "of the affected steps are wrong.  Edit parameters in place under torch.no_grad() (as optimisers do), or set "
-                "flowmap_amd._ops.use_tap_image = False.")
+# The one-off data preparation (flow / mask post-processing, resize + crop), the function-level operators on explicit point sets and the
+# tracking loss's static data live in modules of their own; their names stay reachable here.
+from ._functions import AlignRigid, BilinearSample, Reproject, RobustMapping, Unproject  # noqa: E402,F401
+from ._preprocess import consistency_mask, flow_postprocess, resize_crop  # noqa: E402,F401
+from ._tracks import PackedTracks, TapPlan  # noqa: E402,F401
 
 
 # sample the tracking loss's tap depths from the image the flow pass leaves (while the parameter's version counter has not moved)
@@ -1418,9 +974,22 @@ class TrackLossFused:
                     tap_plan.sampled_now = False
         else:
             offer_taps = False
+        # the camera-space half of the sampling may already be there (track_presample, launched beside this step's Procrustes fit)
+        pre = (None, None)
+        ready = depth.__dict__.pop("_fm_presampled", None)
+        if ready is not None and ready[0] is packed and ready[4].data_ptr() == kinv.data_ptr() and reducer is None and int(frame0) == 0 and ext.shape[1] == depth.shape[1]:
+            if ready[3] is not None:
+                torch.cuda.current_stream(depth.device).wait_event(ready[3])
+            pre = (ready[1], ready[2])
+            counters["track_presampled_losses"] += 1
+        if (use_track_presample and reducer is None and int(frame0) == 0 and defer and not packed.partial and needs_depth and depth.dim() == 4
+                and ext.shape[1] == depth.shape[1]):
+            whole = _whole_parameter(depth)
+            if whole is not None and whole.is_leaf:
+                whole.__dict__["_fm_track_presample"] = weakref.ref(packed)  # from the next step on: sampled beside the fit
         loss, scale, totals = torch_ops().track_loss(depth, k, kinv, ext, packed.xy, packed.vis, packed.seg, packed.blocks, packed.tiles,
                                                      packed.counts, float(weight), int(kind), float(delta), sink, int(frame0),
-                                                     *(plan if plan is not None else (None, None, None, None)), fit_from, *taps, bool(offer_taps))
+                                                     *(plan if plan is not None else (None, None, None, None)), fit_from, *taps, bool(offer_taps), *pre)
         if reducer is not None:
             # the operator's gradients follow the `scale` tensor they find at backward time: overwrite it with the
             # global normaliser and report the global value through the local node

@@ -48,12 +48,22 @@ def _first_tensor(obj, depth: int = 0) -> Optional[torch.Tensor]:
     return None
 
 
+_Tensor = torch.Tensor
+
+
 def on_host(*objs) -> bool:
-    """Do the tensors of this call live on the host while the C ABI is the HIP library?"""
-    if _lib.using_test_double():
+    """Do the tensors of this call live on the host while the C ABI is the HIP library?  (Called several times per optimisation step by
+    every rebound name: the common cases — a tensor, a Batch, a LazySurfaces as the first argument — are decided without recursion.)"""
+    if _lib._lib_is_test_double:
         return False
     for obj in objs:
-        t = _first_tensor(obj)
+        if isinstance(obj, _Tensor):
+            return obj.device.type == "cpu"
+        t = getattr(obj, "depths", None)  # LazySurfaces, BackboneOutput, ModelOutput
+        if not isinstance(t, _Tensor):
+            t = getattr(obj, "videos", None)  # Batch
+        if not isinstance(t, _Tensor):
+            t = _first_tensor(obj)
         if t is not None:
             return t.device.type == "cpu"
     return False
@@ -61,6 +71,8 @@ def on_host(*objs) -> bool:
 
 def host_twin(name: str, *objs):
     """The reference's original for ``name`` when this call must go to it, else None."""
+    if not twins:  # nothing installed: stand-alone use of this package
+        return None
     ref = twins.get(name)
     if ref is None or not on_host(*objs):
         return None
@@ -76,7 +88,7 @@ def dispatching(name: str, ours, ref):
 
     @functools.wraps(ours)
     def call(*args, **kwargs):
-        if on_host(*args, *kwargs.values()):
+        if (on_host(*args, *kwargs.values()) if kwargs else on_host(*args)):
             counters["host_calls"] += 1
             return ref(*args, **kwargs)
         return ours(*args, **kwargs)

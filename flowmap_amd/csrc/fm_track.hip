@@ -114,7 +114,9 @@ __device__ __forceinline__ bool track_sample(const TrackGeom& g, const float* de
 // bit 29: read the depth image after all (a pixel another operator updates after the flow pass); slot -1: a tap that contributes
 // nothing — instead of four cold lines of the depth images.
 constexpr int kTapRank = 0x1fffffff, kTapDense = 0x20000000, kTapShared = 0x40000000;
-template <int N>
+// POSE = false (track_presample_kernel): the camera-space half only — xyz and h into planes 0-2 / 6-8, the flag; no pose is read, planes 3-5
+// (X_w) are left to the pair kernel, which applies the pose when it exists (TrackSampling::presampled); xw returns xyz.
+template <int N, bool POSE = true>
 __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const float* depth, int depth_frame0, const float* kinv, const float* ext,
                                                   const int (&frame)[N], const size_t (&idx)[N], const bool (&want)[N], bool store, int p_count,
                                                   int p, float* ws, uint8_t* flag, float (&xw)[N][3], bool (&live)[N],
@@ -214,9 +216,7 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
     xw[n][0] = xw[n][1] = xw[n][2] = 0.f;
     if (!want[n]) continue;
     Mat3 ki;
-    Pose e;
     load_mat3(kinv + (size_t)frame[n] * 9, ki);
-    load_pose44(ext + (size_t)frame[n] * 16, e);
     float xyz[3] = {0.f, 0.f, 0.f}, hh[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -232,7 +232,13 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
       hh[1] += zk * vt * wk;
       hh[2] += zk * wk;
     }
-    apply_pose(e, xyz, xw[n]);
+    if (POSE) {
+      Pose e;
+      load_pose44(ext + (size_t)frame[n] * 16, e);
+      apply_pose(e, xyz, xw[n]);
+    } else {
+      xw[n][0] = xyz[0]; xw[n][1] = xyz[1]; xw[n][2] = xyz[2];
+    }
     const bool inside = q[n].x >= 0.f && q[n].y >= 0.f && q[n].x < 1.f && q[n].y < 1.f;
     live[n] = store && vis[n] != 0 && inside;
     if (store) {
@@ -240,7 +246,9 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
       float* o = ws_plane(ws, idx[n] - p, p_count, p);
       const size_t pc = (size_t)p_count;
       o[0] = xyz[0]; o[pc] = xyz[1]; o[2 * pc] = xyz[2];
-      o[3 * pc] = xw[n][0]; o[4 * pc] = xw[n][1]; o[5 * pc] = xw[n][2];
+      if (POSE) {
+        o[3 * pc] = xw[n][0]; o[4 * pc] = xw[n][1]; o[5 * pc] = xw[n][2];
+      }
       o[6 * pc] = hh[0];  o[7 * pc] = hh[1];  o[8 * pc] = hh[2];
 #endif
       flag[idx[n]] = live[n] ? 1 : 0;
@@ -259,6 +267,26 @@ __global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const fl
 }
 
 // Per frame: the target-role constants (au, av, c) of track_target (fm_pose.h).
+// The camera-space half of the sampling on its own (fm_track_presample): needs depth (or the compact tap image) and K⁻¹ only — not the poses —
+// so it can run BESIDE the Procrustes fit that produces them (a second stream: the fit keeps ~150 of the 256 CUs busy with latency-bound
+// gathers), instead of in the prologue of every wave of track_pairs, where all waves wait for their gathers at the same time with the VALU
+// idle chip-wide (37 us of a 200 us kernel at C2, profiles/r04_track_pairs_phase_clocks.txt).  Same arithmetic per item as track_sample_many.
+// grid: (blocks of (segment, local frame), ceil(pmax / 256)).
+__global__ void __launch_bounds__(256) track_presample_kernel(TrackGeom g, const float* depth, const float* kinv, const int32_t* tap_slot,
+                                                              const float* tap_depth, float* ws, uint8_t* flag) {
+  const int sg = g.blocks[blockIdx.x * 2], fl = g.blocks[blockIdx.x * 2 + 1];
+  const int start = g.seg[sg * 4], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
+  const int p = blockIdx.y * blockDim.x + threadIdx.x;
+  if (blockIdx.y * blockDim.x >= (unsigned)p_count) return;  // (block-uniform)
+  const int pp = min(p, p_count - 1);
+  const int frame[1] = {start + fl};
+  const size_t idx[1] = {(size_t)off + (size_t)fl * p_count + pp};
+  const bool want[1] = {true};
+  float xw[1][3];
+  bool live[1];
+  track_sample_many<1, false>(g, depth, 0, kinv, nullptr, frame, idx, want, p < p_count, p_count, pp, ws, flag, xw, live, tap_slot, tap_depth);
+}
+
 __global__ void __launch_bounds__(64) track_targets_kernel(const float* ext_inv, const float* k, int frames, float* tgt) {
   const int fr = blockIdx.x * blockDim.x + threadIdx.x;
   if (fr < frames) track_target(ext_inv + (size_t)fr * 16, k + (size_t)fr * 9, tgt + (size_t)fr * kTrackTgt);
@@ -401,6 +429,8 @@ struct TrackSampling {
   const float* tap_depth;   // the image, or null: sample the depth images
   float* tap_grad;          // (M) or null: the epilogue stores the unscaled dL/ddepth of every tap that belongs to ONE track point straight
                             // into the compact gradient (the taps several points share are summed by tap_grad_kernel afterwards)
+  int presampled;           // 1 (with depth null): fm_track_presample has filled xyz / h (planes 0-2, 6-8) and the flags: the prologue reads xyz
+                            // — coalesced — applies the source frame's pose and stores X_w (planes 3-5)
 };
 
 // Points per lane (FM_TRACK_PG): with two, a wave covers 128 points and the per-target reduction of the 14 sums (a quarter
@@ -469,6 +499,39 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
                                     smp.tap_slot, smp.tap_depth);
 #pragma unroll
       for (int t = 0; t < kTrackTile; ++t) lvs[t] = lv[t] ? 1.f : 0.f;
+    } else if (smp.presampled != 0) {
+      // every load of the tile first (the stores of X_w below go to the same workspace: the compiler would not move a load across them)
+      float cx[kTrackTile][3];
+      uint8_t fl8[kTrackTile];
+#pragma unroll
+      for (int t = 0; t < kTrackTile; ++t) {
+        const int fs = min(fs0 + t, f - 1);
+        const size_t is = (size_t)off + (size_t)fs * p_count + pp[q];
+        const float* w9 = ws_plane(ws, is - pp[q], p_count, pp[q]);
+        fl8[t] = flag[is];
+        cx[t][0] = w9[0]; cx[t][1] = w9[(size_t)p_count]; cx[t][2] = w9[2 * (size_t)p_count];
+      }
+#pragma unroll
+      for (int t = 0; t < kTrackTile; ++t) {
+        const int fs = fs0 + t;
+        lvs[t] = 0.f;
+        xs[t][0] = xs[t][1] = xs[t][2] = 0.f;
+        if (fs < f) {  // (wave-uniform)
+          Pose e;
+          load_pose44(ext + (size_t)(start + fs) * 16, e);
+          float xwv[3];
+          apply_pose(e, cx[t], xwv);
+          if (active[q]) {
+            const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
+            float* o = ws_plane(ws, is - p[q], p_count, p[q]);
+            o[3 * (size_t)p_count] = xwv[0]; o[4 * (size_t)p_count] = xwv[1]; o[5 * (size_t)p_count] = xwv[2];
+            if (fl8[t] != 0) {
+              lvs[t] = 1.f;
+              xs[t][0] = xwv[0]; xs[t][1] = xwv[1]; xs[t][2] = xwv[2];
+            }
+          }
+        }
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < kTrackTile; ++t) {
@@ -953,6 +1016,17 @@ int fm_track_points(const float* depth, int depth_frame0, const float* kinv, con
   FM_LAUNCH_STATUS();
 }
 
+int fm_track_presample(const float* depth, const float* kinv, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks,
+                       int nblocks, int pmax, int height, int width, const int32_t* tap_slot, const float* tap_depth, float* ws, uint8_t* flag,
+                       void* stream) {
+  FM_CHECK_ARG(depth && kinv && xy && vis && seg && blocks && ws && flag && nblocks >= 1 && pmax >= 1 && height >= 1 && width >= 1);
+  FM_CHECK_ARG(tap_depth == nullptr || tap_slot != nullptr);
+  TrackGeom g{xy, vis, seg, blocks, height, width};
+  hipLaunchKernelGGL(track_presample_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, depth, kinv,
+                     tap_depth ? tap_slot : nullptr, tap_depth, ws, flag);
+  FM_LAUNCH_STATUS();
+}
+
 static int track_loss_launch(float* ws, uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* tiles,
                              int ntiles, int pmax, int fmax, const float* ext, const float* tgt, int frames, int height, int width,
                              int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* partial, double* acc,
@@ -989,7 +1063,7 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
   FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr));
   return track_loss_launch(const_cast<float*>(ws), const_cast<uint8_t*>(flag), xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames,
                            height, width, mapping_kind, delta, aspect_x, aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                           TrackSampling{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr}, (hipStream_t)stream);
+                           TrackSampling{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0}, (hipStream_t)stream);
 }
 
 int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first, int own_end, const float* kinv, const float* ext,
@@ -1004,7 +1078,7 @@ int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first,
   hipLaunchKernelGGL(track_targets_kernel, dim3((frames + 63) / 64), dim3(64), 0, st, ext_inv, k, frames, tgt);
   return track_loss_launch(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, mapping_kind, delta, aspect_x,
                            aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                           TrackSampling{depth, kinv, depth_frame0, own_first, own_end, nullptr, nullptr, nullptr}, st);
+                           TrackSampling{depth, kinv, depth_frame0, own_first, own_end, nullptr, nullptr, nullptr, 0}, st);
 }
 
 int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
@@ -1013,8 +1087,9 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
                                  uint8_t* flag, float* tgt, float* partial, double* acc, float* loss, float* scale, double* totals, float* gws,
                                  double* acc2, const int32_t* tap_slot, const float* tap_depth, const int64_t* plan_pixels,
                                  const int32_t* plan_first, const int32_t* plan_entries, const float* plan_weights, long plan_count,
-                                 const int32_t* shared_ranks, long shared_count, float* tap_grad, void* stream) {
+                                 const int32_t* shared_ranks, long shared_count, float* tap_grad, int presampled, void* stream) {
   FM_CHECK_ARG(depth && kinv && ext && ext_inv && k && xy && vis && seg && tiles && ws && flag && tgt && partial && acc && loss && scale);
+  FM_CHECK_ARG(presampled == 0 || presampled == 1);
   FM_CHECK_ARG(ntiles >= 1 && pmax >= 1 && fmax >= 1 && frames >= 1 && mapping_kind >= 0 && mapping_kind <= 2);
   FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr) && (tap_depth == nullptr || tap_slot != nullptr));
   FM_CHECK_ARG(tap_grad == nullptr || (gws && plan_pixels && plan_first && plan_entries && plan_weights && plan_count >= 0));
@@ -1025,7 +1100,7 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
   float* direct = (tap_grad != nullptr && shared_ranks != nullptr) ? tap_grad : nullptr;
   const int status = track_loss_launch(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, mapping_kind, delta,
                                        aspect_x, aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                                       TrackSampling{depth, kinv, 0, 0, frames, tap_slot, tap_depth, direct}, st);
+                                       TrackSampling{presampled ? nullptr : depth, kinv, 0, 0, frames, tap_slot, tap_depth, direct, presampled}, st);
   if (status != FM_OK || tap_grad == nullptr) return status;
   const long count = direct ? shared_count : plan_count;
   if (count == 0) return status;

@@ -67,7 +67,25 @@ def main():
     ap.add_argument("--trace-every", type=int, default=10)
     ap.add_argument("--no-softmin", action="store_true")
     ap.add_argument("--threads", type=int, default=6)
+    ap.add_argument("--perturb", type=float, default=0.0,
+                    help="relative Gaussian perturbation of the initial depths (1e-7 ~ one fp32 ulp): the reference's OWN sensitivity under this schedule — "
+                         "the bar a second implementation is held to.  Run it with --out <other file>, then --merge-sensitivity")
+    ap.add_argument("--merge-sensitivity", default=None, metavar="PERTURBED_RECORD",
+                    help="no optimisation: read --out (the unperturbed record) and PERTURBED_RECORD, write `self_sensitivity` into --out")
     args = ap.parse_args()
+    if args.merge_sensitivity:
+        a, b = json.loads(Path(args.out).read_text()), json.loads(Path(args.merge_sensitivity).read_text())
+        pa, pb = torch.tensor(a["positions"]), torch.tensor(b["positions"])
+        a["self_sensitivity"] = {
+            "what": "the imported reference against itself from initial depths perturbed by " + str(b.get("perturb")) + " (relative, Gaussian)",
+            "ate": a["ate_reference_path_cpu"], "ate_perturbed": b["ate_reference_path_cpu"],
+            "ate_rel_diff": abs(a["ate_reference_path_cpu"] - b["ate_reference_path_cpu"]) / a["ate_reference_path_cpu"],
+            "max_position_diff": float((pa - pb).abs().max()), "final_loss": [a["final_loss_reference_path"], b["final_loss_reference_path"]],
+            "focal_final": [a["focal_final"], b["focal_final"]], "made_by": b["made_by"],
+        }
+        Path(args.out).write_text(json.dumps(a))
+        print(json.dumps(a["self_sensitivity"]))
+        return
     torch.set_num_threads(args.threads)
     f, h, w = args.frames, args.height, args.width
     sc, otracks = chain.scene(args)
@@ -77,7 +95,10 @@ def main():
                   IntrinsicsSoftminCfg("softmin", args.softmin_points, *chain.CANDIDATES, args.num_candidates, RegressionCfg(args.after_step, args.window)))
     cfg = ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), intrinsics, ExtrinsicsProcrustesCfg("procrustes", args.points, False), True)
     model = Model(cfg, num_frames=f, image_shape=(h, w))
-    model.backbone.depth.data = sc["depth_init"].clone()
+    d0 = sc["depth_init"].clone()
+    if args.perturb != 0.0:
+        d0 = d0 * (1.0 + args.perturb * torch.randn(d0.shape, generator=torch.Generator().manual_seed(12345)))
+    model.backbone.depth.data = d0
     model.train()
     batch = Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["scene"], ["synthetic"])
     flows = Flows(sc["flows"].forward, sc["flows"].backward, sc["flows"].forward_mask, sc["flows"].backward_mask)
@@ -120,10 +141,10 @@ def main():
                                             "num_candidates", "after_step", "window", "trace_every", "no_softmin")}
     result = {
         "made_by": "PYTHONDONTWRITEBYTECODE=1 python oracle/make_ate_reference.py " + " ".join(f"--{k.replace('_', '-')} {v}" for k, v in config.items() if k != "no_softmin")
-                   + (" --no-softmin" if args.no_softmin else ""),
+                   + (" --no-softmin" if args.no_softmin else "") + (f" --perturb {args.perturb}" if args.perturb else ""),
         "reference_kind": "the imported reference (dcharatan/flowmap at /root/reference): flowmap.model.model.Model + flowmap.loss.get_losses + torch.optim.Adam + flowmap.misc.ate.compute_ate",
         "config": config,
-        "perturb": 0.0,
+        "perturb": args.perturb,
         "ate_reference_path_cpu": float(ate),
         "final_loss_reference_path": final_loss,
         "loss_trace": loss_trace,
