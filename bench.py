@@ -136,9 +136,9 @@ def parse():
                          "(the real dcharatan/flowmap when it is importable, else tests/standin — the GPU box has no /root/reference) and the step is that "
                          "package's own Model(get_backbone, get_intrinsics, get_extrinsics) + get_losses, i.e. what an unmodified overfit.py runs "
                          "(model_wrapper_overfit.py:51-62).  `direct`: flowmap_amd.model.model.Model and the loss classes constructed by hand")
-    ap.add_argument("--no-track-presample", action="store_true",
-                    help="flow + tracking: the tracking loss samples in the prologue of its pair kernel (rounds 2-4) instead of beside the Procrustes fit on a "
-                         "second stream (flowmap_amd/_ops.py: track_presample)")
+    ap.add_argument("--track-presample", action="store_true",
+                    help="flow + tracking (A/B; measured and not adopted, flowmap_amd/_ops.py: track_presample): the camera-space half of the tracking loss's "
+                         "sampling runs beside the Procrustes fit on a second stream instead of in the prologue of the pair kernel")
     ap.add_argument("--torch-baseline", type=int, default=0, metavar="STEPS",
                     help="after the timed region: the reference's op sequence on stock PyTorch-ROCm on this GPU (tests/tools/torch_gpu_reference_ops.py "
                          "in a process of its own, 1 warm-up + STEPS steps on i.i.d. inputs of the workload's size) as `rocm_torch_baseline`")
@@ -513,8 +513,8 @@ def main():
     flowmap_amd.set_lazy_surfaces(True)
     if args.no_tap_exchange:
         _ops.use_tap_exchange = False
-    if args.no_track_presample:
-        _ops.use_track_presample = False
+    if args.track_presample:
+        _ops.use_track_presample = True
     if os.environ.get("FLOWMAP_THREE_LAUNCH_BWD"):  # A/B: the planned Procrustes backward as the three launches of round 2
         from flowmap_amd._lib import torch_ops
 
@@ -892,7 +892,8 @@ def main():
         # `quoted_records`, never beside the measured values
         fixture = Path(args.ate_fixture) if args.ate_fixture else default_ate_fixture()
         want_ate = args.ate == "on" or (args.ate == "auto" and world == 1 and args.share <= 1 and on_gpu and args.config == "c1" and not args.whole
-                                        and (f_video, h, w) == (150, 720, 1280))
+                                        and (f_video, h, w) == (150, 720, 1280) and tracks is None and optimizer is None and not args.graph
+                                        and not under_rocprof)
         if want_ate and fixture is not None and fixture.exists():
             try:
                 result["ate"] = ate_leg(device, fixture)

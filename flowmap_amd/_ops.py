@@ -392,7 +392,13 @@ def _dense_procrustes_plan(bwd_flow: Tensor, b: int, f: int, h: int, w: int):
 # gather (37-64 us as the prologue of track_pairs, with every wave of that kernel waiting at once) — side by side they cost the longer of the
 # two.  The tracking loss of the step then finds xyz / h / flags ready (`_fm_presampled` on the step's depth tensor) and its pair kernel
 # starts with coalesced loads (fm_track_loss_fused_fwd_taps, presampled = 1).  Same arithmetic, same results bit for bit.
-use_track_presample = True
+#
+# MEASURED, NOT ADOPTED (round 5, profiles/r05_track_presample_ab.json): at C2 the pair kernel drops from 0.205 to 0.187 ms (its prologue's
+# gathers become three coalesced loads and a pose), but the step does not move (1.130 against 1.125 ms; two runs each): the 24 us sampling
+# kernel does overlap the fit, which slows by 2.5 us beside it, and the fork / join of the second stream (two cross-stream event waits) costs
+# what the kernel gained.  With an optimiser that moves depth every step the tap image is stale, the sampling gathers 5.6 M cold taps
+# (~0.1 ms, longer than the fit it hides under) and the step is SLOWER (1.93 against 1.82 ms).  Off by default; the tests switch it on.
+use_track_presample = False
 track_presample_min_bytes = 64 << 20  # (below this the depth images are cache-resident and the step is host-bound: the bookkeeping would cost more)
 _side_streams: dict = {}
 

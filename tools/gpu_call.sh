@@ -20,7 +20,7 @@ for w in $what; do
       python bench.py --cpu-frames 0 $args > $out/bench_$name.json 2> $out/bench_$name.err; cat $out/bench_$name.json; tail -3 $out/bench_$name.err ;;
     prof-*)  # prof-<name>:<bench args with + for spaces>, e.g. prof-dense:--points+0   -> rocprofv3 kernel stats
       name=${w#prof-}; args=${name#*:}; name=${name%%:*}; args=${args//+/ }
-      (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $REPO/$out/prof_$name -o stats -- python $REPO/bench.py --steps ${PROF_STEPS:-20} --warmup ${PROF_WARMUP:-5} --cpu-frames 0 --sustained-steps 0 $args > /dev/null 2> $REPO/$out/prof_$name.err)
+      (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $REPO/$out/prof_$name -o stats -- python $REPO/bench.py --steps ${PROF_STEPS:-20} --warmup ${PROF_WARMUP:-5} --cpu-frames 0 --sustained-steps 0 --ate off $args > /dev/null 2> $REPO/$out/prof_$name.err)
       python tools/export_profile.py $out/prof_$name > $out/${name}_rocprofv3_summary.csv 2>> $out/prof_$name.err; rm -rf $out/prof_$name
       head -14 $out/${name}_rocprofv3_summary.csv ;;
     sq-*)  # sq-<name>:<bench args>   -> VALU / SALU / LDS instructions per wave, cycles, VALU share of the issue slots per fm:: kernel (a PMC pass of its own)
@@ -29,7 +29,7 @@ for w in $what; do
     pmc-*)  # pmc-<name>:<bench args>  -> HBM bytes per launch of every fm:: kernel: FETCH_SIZE and WRITE_SIZE in separate passes (the guide's recipe)
       name=${w#pmc-}; args=${name#*:}; name=${name%%:*}; args=${args//+/ }
       for c in FETCH_SIZE WRITE_SIZE; do
-        (cd /tmp && rm -rf /tmp/pmc_$c && timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o pmc -- python $REPO/bench.py --steps 5 --warmup 2 --cpu-frames 0 --sustained-steps 0 $args > /dev/null 2> $REPO/$out/pmc_${name}_$c.err)
+        (cd /tmp && rm -rf /tmp/pmc_$c && timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o pmc -- python $REPO/bench.py --steps 5 --warmup 2 --cpu-frames 0 --sustained-steps 0 --ate off $args > /dev/null 2> $REPO/$out/pmc_${name}_$c.err)
       done
       python tools/export_profile.py --pmc-only /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $out/${name}_pmc.txt 2>> $out/pmc_${name}_FETCH_SIZE.err; head -30 $out/${name}_pmc.txt ;;
     hostprof-*)  # hostprof-<name>:<args of tools/host_profile_default.py>

@@ -7,7 +7,7 @@ REPO=$PWD
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/prof_sq
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES -d /tmp/prof_sq -o sq -- python "$REPO/bench.py" --steps 3 --warmup 1 --cpu-frames 0 ${BENCH_ARGS:-} > /tmp/prof_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES -d /tmp/prof_sq -o sq -- python "$REPO/bench.py" --steps 3 --warmup 1 --cpu-frames 0 --ate off --sustained-steps 0 ${BENCH_ARGS:-} > /tmp/prof_sq.log 2>&1
 cd "$REPO"
 python - <<'PY'
 import glob, sqlite3
