@@ -31,6 +31,11 @@ adds it causes (flowmap_amd.sharding.FrameShard(proxy=True)) — i.e. everything
 bytes spend on xGMI.  `--graph` replays the step (collectives included) as one hipGraph.  tools/scaling_proxy.sh runs
 K = 1, 2, 4, 8 eager and graphed -> profiles/r03_strong_scaling_proxy.jsonl; DESIGN.md §5 turns it into a projection.
 
+The default step (`--model installed`) is built by a reference-LAYOUT `flowmap` package after flowmap_amd.install(): the real package when it
+is importable, else tests/standin/flowmap (the GPU box has no reference).  The stand-in is the HOST APPLICATION's stand-in, not the product: after
+install() every arithmetic name it resolves is this library's; its own arithmetic (the oracle's, for the CPU tests) is imported lazily and refuses
+GPU tensors, and the line reports `via_install.oracle_imported_by_the_timed_path` (false) and the kernels of a step (all `fm::`).
+
 Prints ONE JSON line (rank 0) with `roofline` for the fused flow kernel (HIP events on its launch stream
 inside the timed region), `roofline_tracking` when the tracking loss runs (track_pairs: VALU-bound, GFLOP/s)
 and, at N = 1, `cpu_baseline` (the oracle — a PyTorch-CPU port of the reference path — timed on a bounded
@@ -55,6 +60,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP32_PEAK_GFLOPS = 157300.0  # same guide: fp32 vector peak with packed FMA
+TRACK_VALU_PER_RESIDUAL = 67.2  # measured: SQ_INSTS_VALU x 64 lanes / residuals at C2 (profiles/r05_c2_sq_counters.csv)
 TRACK_FLOPS_PER_RESIDUAL = 90.0  # track_pair_term (csrc/fm_pose.h): ~60 VALU instructions, FMAs counted twice
 
 CONFIGS = {
@@ -791,6 +797,9 @@ def main():
                           f"{n_direct} steps straight after the steps above (compare with `sustained`, which the installed path ran just before)",
                   "steps": n_direct, "ms_per_step": (time.perf_counter() - t1) / n_direct * 1e3, "loss": float(direct_loss.item())}
         del direct_model, direct_step
+    # What ran so far — precompute, warm-up, the timed steps, the sustained steps, the hand-built twin — is the product path.  The oracle is a
+    # checker: the legs below (`ate`, `cpu_baseline`) import it; nothing above may have (the stand-in package reaches it lazily and refuses GPU tensors).
+    oracle_loaded_by_product_path = any(name == "oracle" or name.startswith("oracle.") for name in sys.modules)
     kernel_ms = sum(flow_ms) / max(len(flow_ms), 1)
     traffic, traffic_src = None, None
     taps_on = _ops.counters["flow_tap_passes"] > 0
@@ -917,6 +926,11 @@ def main():
                             "model": f"{type(model).__module__}.{type(model).__name__}",
                             "losses": [f"{type(fn).__module__}.{type(fn).__name__}" for fn in loss_fns]},
                 "ms_per_step": ms_per_step, "launches_per_step": launches,
+                # every kernel of a step is this library's (a torch kernel here would mean some name fell through to eager arithmetic), and the
+                # oracle had not been imported when the timed steps ended
+                "kernels_not_from_libflowmap_hip": [k for k in launch_names if "fm::" not in k and not k.startswith(("softmin_", "random_"))
+                                                    and "#" not in k],
+                "oracle_imported_by_the_timed_path": oracle_loaded_by_product_path,
                 "sustained_ms_per_step": sustained["ms_per_step"] if sustained is not None else None,
                 "direct": direct,
                 "installed_over_direct": (sustained["ms_per_step"] / direct["ms_per_step"]) if (sustained is not None and direct is not None) else None,
@@ -946,6 +960,12 @@ def main():
                 "traffic": None,
                 "residuals_per_launch": residuals,
                 "flops_per_residual": TRACK_FLOPS_PER_RESIDUAL,
+                # the kernel's own currency: VALU issue slots.  SQ_INSTS_VALU of track_pairs = 28 970 per wave x 1 984 waves at C2
+                # (profiles/r05_c2_sq_counters.csv) = 67.2 instructions per residual and lane; a wave64 instruction occupies its SIMD for 4 cycles
+                # (packed fp32 ones for ~8: the floor below is optimistic), 1024 SIMDs, ~2.1 GHz sustained under load
+                "issue_roofline": {"valu_instructions_per_residual": TRACK_VALU_PER_RESIDUAL, "measured_in": "profiles/r05_c2_sq_counters.csv",
+                                   "issue_bound_ms": residuals * TRACK_VALU_PER_RESIDUAL / 64 * 4 / (1024 * 2.1e9) * 1e3,
+                                   "frac": (residuals * TRACK_VALU_PER_RESIDUAL / 64 * 4 / (1024 * 2.1e9) * 1e3) / t_ms if t_ms > 0 else None},
                 "kernel_ms": t_ms,
                 "launches_timed": len(track_ms),
             }

@@ -154,6 +154,47 @@ __device__ __forceinline__ void pose_chain_by_wave0(const float* r, int steps, f
   __syncthreads();
 }
 
+// The same chain by ONE wave in registers (round 5): the caller lets only threads 0..63 in.  The Hillis-Steele rounds exchange the 16 doubles
+// with wave shuffles instead of going through LDS between block-wide barriers — in the one-block-per-pair fit the barriers of a 1024-thread
+// block, eight of them, were most of the chain's 8-10 us (profiles/r04_fit_phase_clocks_*.txt: 7.6 us for 19 poses, 10 for 149).  Same
+// products in the same order as pose_chain_by_wave0: chunk products, inclusive scan over the 64 chunks, re-walk — bit-identical results.
+__device__ __forceinline__ void pose_chain_one_wave(const float* r, int steps, float* e) {
+  const int t = threadIdx.x;  // the lane
+  const int chunk = (steps + 63) / 64;
+  const int lo = t * chunk, hi = min(steps, lo + chunk);
+  double prod[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int s = lo; s < hi; ++s) {
+    double m[16], nxt[16];
+    for (int k = 0; k < 16; ++k) m[k] = r[(size_t)s * 16 + k];
+    mat4_mul(prod, m, nxt);
+    for (int k = 0; k < 16; ++k) prod[k] = nxt[k];
+  }
+  for (int off = 1; off < 64; off <<= 1) {
+    double left[16], out[16];
+    for (int k = 0; k < 16; ++k) left[k] = __shfl_up(prod[k], off, 64);
+    mat4_mul(left, prod, out);
+    if (t >= off)
+      for (int k = 0; k < 16; ++k) prod[k] = out[k];
+  }
+  double run[16];
+  for (int k = 0; k < 16; ++k) run[k] = __shfl_up(prod[k], 1, 64);  // the product of every chunk before this lane's
+  if (t == 0) {
+    for (int k = 0; k < 16; ++k) {
+      run[k] = (k % 5 == 0) ? 1.0 : 0.0;
+      e[k] = (float)run[k];  // E_0 = I
+    }
+  }
+  for (int s = lo; s < hi; ++s) {
+    double m[16], nxt[16];
+    for (int k = 0; k < 16; ++k) m[k] = r[(size_t)s * 16 + k];
+    mat4_mul(run, m, nxt);
+    for (int k = 0; k < 16; ++k) {
+      run[k] = nxt[k];
+      e[(size_t)(s + 1) * 16 + k] = (float)nxt[k];
+    }
+  }
+}
+
 // A correspondence's gather chain is index -> (flow, weight, later depth) -> four taps of the earlier depth: three dependent
 // round trips to HBM (~2 us each on cold lines).  The chain is split into stages so that BOTH pairs' chains are in flight
 // together and the first two stages are issued before the block waits for the pose-solve backward.
@@ -385,7 +426,6 @@ template <int SRC>
 __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p, FitChain fc, int* counter) {
   __shared__ double red[16 * kMomentCount];
   __shared__ double pair_stats[kStatStride];
-  __shared__ double chain_buf[2][16][64];
   __shared__ int last_of_all;
   FM_PHASE(0);  // (tools/phase_clocks_fit.py: entry)
   const size_t pair = blockIdx.x;
@@ -494,10 +534,10 @@ __global__ void __launch_bounds__(1024) procrustes_fit_pair_kernel(ProcParams p,
   }
   __syncthreads();
   FM_PHASE(4);  // fence + counter
-  if (!last_of_all) return;
+  if (!last_of_all || threadIdx.x >= kWave) return;  // (one wave of the last block chains the poses: pose_chain_one_wave)
   __threadfence();  // see every pair's pose
   for (int bb = 0; bb < fc.batch; ++bb)
-    pose_chain_by_wave0(fc.t_bwd + (size_t)bb * (p.frames - 1) * 16, p.frames - 1, fc.ext + (size_t)bb * p.frames * 16, chain_buf);
+    pose_chain_one_wave(fc.t_bwd + (size_t)bb * (p.frames - 1) * 16, p.frames - 1, fc.ext + (size_t)bb * p.frames * 16);
   FM_PHASE(5);  // (the last block only: the poses are chained)
 }
 

@@ -3,7 +3,7 @@ from dataclasses import dataclass
 
 from torch import Tensor, nn
 
-from oracle import flowmap_oracle as orc
+from flowmap import orc  # (the oracle behind a lazy, host-only proxy: flowmap/__init__.py)
 
 
 @dataclass

@@ -1,7 +1,7 @@
 """Stand-in: the robust-mapping registry."""
 from dataclasses import dataclass
 
-from oracle import flowmap_oracle as orc
+from flowmap import orc  # (the oracle behind a lazy, host-only proxy: flowmap/__init__.py)
 
 
 @dataclass

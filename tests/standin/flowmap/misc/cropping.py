@@ -1,7 +1,7 @@
 """Stand-in: the three resize / crop entry points install() rebinds (host arithmetic: the oracle's)."""
 import dataclasses
 
-from oracle import flowmap_oracle as orc
+from flowmap import orc  # (the oracle behind a lazy, host-only proxy: flowmap/__init__.py)
 
 
 def resize_batch(batch, shape):

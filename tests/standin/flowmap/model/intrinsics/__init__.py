@@ -5,7 +5,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from oracle import flowmap_oracle as orc
+from flowmap import orc  # (the oracle behind a lazy, host-only proxy: flowmap/__init__.py)
 
 
 @dataclass

@@ -1,5 +1,5 @@
 """Stand-in: the weighted rigid fit (host arithmetic: the oracle's)."""
-from oracle import flowmap_oracle as orc
+from flowmap import orc  # (the oracle behind a lazy, host-only proxy: flowmap/__init__.py)
 
 
 def align_rigid(points, targets, weights):

@@ -1,7 +1,7 @@
 """Stand-in: the geometry functions other modules bind by name at import (host arithmetic: the oracle's)."""
 import torch
 
-from oracle import flowmap_oracle as orc
+from flowmap import orc  # (the oracle behind a lazy, host-only proxy: flowmap/__init__.py)
 
 from .procrustes import align_rigid
 
@@ -26,11 +26,11 @@ def unproject(coordinates, z, intrinsics):
     return orc.lift(coordinates, z, intrinsics)
 
 
-def project_camera_space(points, intrinsics, epsilon=orc.EPS_PROJECT, infinity=orc.INF_PROJECT):
+def project_camera_space(points, intrinsics, epsilon=1e-5, infinity=1e8):
     return orc.pinhole(points, intrinsics, epsilon, infinity)
 
 
-def project(points, extrinsics, intrinsics, epsilon=orc.EPS_PROJECT):
+def project(points, extrinsics, intrinsics, epsilon=1e-5):
     return orc.world_to_image(points, extrinsics, intrinsics, epsilon)
 
 
