@@ -403,7 +403,7 @@ def ate_leg(device, fixture):
 
 
 def default_ate_fixture():
-    for name in ("ate_150x720x1280_imported_reference.json", "ate_150x360x640_imported_reference.json"):
+    for name in ("ate_150x720x1280_200_steps_imported_reference.json", "ate_150x720x1280_imported_reference.json", "ate_150x360x640_imported_reference.json"):
         if (ROOT / "tests" / "golden" / name).exists():
             return ROOT / "tests" / "golden" / name
     return None
