@@ -7,6 +7,7 @@ out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 REPO=$PWD
 export FLOWMAP_PARITY_RECORD=$PWD/$out/full_size_parity.jsonl
+export FLOWMAP_FOCAL_LOG=$PWD/$out/focal_gate_ratios.txt   # tests/helpers.focal_close: err / (2^-24 x sum of |terms|) of every dL/dfocal comparison
 for w in $what; do
   case $w in
     info) { free -g; nproc; lscpu | grep -i "model name"; rocm-smi --showmeminfo vram 2>/dev/null | head -8; } > $out/info.txt 2>&1 ;;
