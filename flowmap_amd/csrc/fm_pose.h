@@ -3,6 +3,7 @@
 // thread in fp64; kernels are thin wrappers (fm_procrustes.hip, fm_flow.hip) and
 // tests/host_sim calls the very same functions on the CPU.
 #pragma once
+#include <cstring>
 
 #include "fm_math.h"
 
@@ -374,46 +375,67 @@ FM_HD void track_target(const float* ext_inv44, const float* k33, float* tgt) {
   }
 }
 
-// One (source fs, target ft, point) residual: adds into the target-role sums a[kTrackSums]
-// (S in [0..11], Σρ in [12], count in [13]) and the source point's dL/dX_w.  Branch-free:
-// hardware rcp / rsq, mapping kind a template parameter, invisibility (projection.py:290-296:
-// the target must land inside [0,1)²) a 0/1 factor.  A point exactly on the camera plane
-// (Z'+eps == 0) projects to ±1e8 in the reference and is invisible there too.
+// The bit pattern of a float as an unsigned integer: for non-negative, non-NaN x and positive b, x < b <=> bits(x) < bits(b); a negative x (sign
+// bit) and a NaN compare above every positive b.  One unsigned compare stands for `x >= 0 && x < b`.
+FM_HD unsigned track_float_bits(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __float_as_uint(x);
+#else
+  unsigned u;
+  std::memcpy(&u, &x, sizeof(u));
+  return u;
+#endif
+}
+
+// Round 5 — the residual in SCALED image coordinates.  The mapping measures (u − u_gt)·ax, (v − v_gt)·ay (fix_aspect_ratio, mapping.py:9-24):
+// with the target's projection rows pre-multiplied, au' = ax·au, av' = ay·av (track_scale_target), and the track position pre-multiplied
+// per (target, point), the pair term works on u' = ax·u, v' = ay·v directly — r = (u' − u_gt', v' − v_gt'), dL/du' = coef·m·r_x — and sheds the
+// four multiplications by ax / ay of every residual; the in-frame test u ∈ [0, 1) becomes u' ∈ [0, ax), ONE unsigned compare of bit patterns
+// per coordinate (u' is formed by an fma with +0, so it is never −0); the Huber map is two `min`s instead of two compares and three selects:
+//   c = min(1/n, 1/δ) (1/n = rsq(n²) = +inf at n = 0),  t = n²·c (= n²/δ below the knee, n above),  ρ = t − ½·min(t, δ),  dρ/dr = c·r
+// — the same values as the two-branch form (½·n²/δ | n − ½δ; 1/δ | 1/n), bit for bit away from the knee.  The sums come out as S0/ax, S1/ay:
+// the caller multiplies them back (track_pair_term below; the pair kernel when it stores a target's sums).
+// Per residual in the pair kernel's loop: 49.3 -> 42 VALU instructions (profiles/r05_track_pairs_inner_loop_isa.txt).
+FM_HD void track_scale_target(const float (&tg)[kTrackTgt], float ax, float ay, float (&ts)[kTrackTgt]) {
+  for (int j = 0; j < 4; ++j) {
+    ts[j] = tg[j] * ax;
+    ts[4 + j] = tg[4 + j] * ay;
+    ts[8 + j] = tg[8 + j];
+  }
+}
+
 template <int KIND, bool GRAD>
-FM_HD void track_pair_term(const float (&tg)[kTrackTgt], const float xw[3], float gt_x, float gt_y, float m, float delta,
-                           float inv_delta, float ax, float ay, float (&a)[kTrackSums], float gxw[3]) {
-  const float xu = fmaf(tg[0], xw[0], fmaf(tg[1], xw[1], fmaf(tg[2], xw[2], tg[3])));
-  const float xv = fmaf(tg[4], xw[0], fmaf(tg[5], xw[1], fmaf(tg[6], xw[2], tg[7])));
-  const float x2 = fmaf(tg[8], xw[0], fmaf(tg[9], xw[1], fmaf(tg[10], xw[2], tg[11])));
+FM_HD void track_pair_term_scaled(const float (&ts)[kTrackTgt], const float xw[3], float gt_xs, float gt_ys, float m, float delta,
+                                  float inv_delta, float ax, float ay, float (&a)[kTrackSums], float gxw[3]) {
+  const float xu = fmaf(ts[0], xw[0], fmaf(ts[1], xw[1], fmaf(ts[2], xw[2], ts[3])));
+  const float xv = fmaf(ts[4], xw[0], fmaf(ts[5], xw[1], fmaf(ts[6], xw[2], ts[7])));
+  const float x2 = fmaf(ts[8], xw[0], fmaf(ts[9], xw[1], fmaf(ts[10], xw[2], ts[11])));
   float q = fm_rcp(x2 + kProjEps);
   const bool ok = fabsf(q) <= 3.0e38f;
   q = ok ? q : 0.f;
-  const float u = xu * q, v = xv * q;
-  const bool inside = ok && u >= 0.f && v >= 0.f && u < 1.f && v < 1.f;
+  const float u = fmaf(xu, q, 0.f), v = fmaf(xv, q, 0.f);  // ax·u, ay·v; (−0) + (+0) = +0
+  const bool inside = ok && track_float_bits(u) < track_float_bits(ax) && track_float_bits(v) < track_float_bits(ay);
   m = inside ? m : 0.f;
-  const float rx = (u - gt_x) * ax, ry = (v - gt_y) * ay;  // exact 0 for equal inputs (cf. aspect_diff)
+  const float rx = u - gt_xs, ry = v - gt_ys;
   const float ss = fmaf(rx, rx, ry * ry);
   float rho, coef;  // ρ and dρ/dr = coef·r
   if (KIND == kL2) {
     rho = 0.5f * ss;
     coef = 1.f;
-  } else {
+  } else if (KIND == kL1) {
     const float inv_n = ss > 0.f ? fm_rsq(ss) : 0.f;
-    const float n = ss * inv_n;
-    if (KIND == kL1) {
-      rho = n;
-      coef = inv_n;
-    } else {
-      const bool quad = n < delta;
-      rho = quad ? 0.5f * ss * inv_delta : n - 0.5f * delta;
-      coef = quad ? inv_delta : inv_n;
-    }
+    rho = ss * inv_n;
+    coef = inv_n;
+  } else {
+    coef = fminf(fm_rsq(ss), inv_delta);
+    const float t = ss * coef;
+    rho = fmaf(-0.5f, fminf(t, delta), t);
   }
   a[12] = fmaf(rho, m, a[12]);
   a[13] += m;
   if (!GRAD) return;
   const float gc = m * coef;
-  const float wu = gc * rx * ax, wv = gc * ry * ay;  // dL/du, dL/dv (unscaled)
+  const float wu = gc * rx, wv = gc * ry;  // dL/du', dL/dv' (unscaled by the loss normaliser)
   const float o0 = q * wu, o1 = q * wv, o2 = q * fmaf(wu, u, wv * v);
   a[0] = fmaf(o0, xw[0], a[0]);
   a[1] = fmaf(o0, xw[1], a[1]);
@@ -427,9 +449,31 @@ FM_HD void track_pair_term(const float (&tg)[kTrackTgt], const float xw[3], floa
   a[9] = fmaf(o2, xw[1], a[9]);
   a[10] = fmaf(o2, xw[2], a[10]);
   a[11] += o2;
-  gxw[0] = fmaf(o0, tg[0], fmaf(o1, tg[4], fmaf(-o2, tg[8], gxw[0])));  // dL/dX_w = ω·(au, av, −c)
-  gxw[1] = fmaf(o0, tg[1], fmaf(o1, tg[5], fmaf(-o2, tg[9], gxw[1])));
-  gxw[2] = fmaf(o0, tg[2], fmaf(o1, tg[6], fmaf(-o2, tg[10], gxw[2])));
+  gxw[0] = fmaf(o0, ts[0], fmaf(o1, ts[4], fmaf(-o2, ts[8], gxw[0])));  // dL/dX_w = ω'·(au', av', −c)
+  gxw[1] = fmaf(o0, ts[1], fmaf(o1, ts[5], fmaf(-o2, ts[9], gxw[1])));
+  gxw[2] = fmaf(o0, ts[2], fmaf(o1, ts[6], fmaf(-o2, ts[10], gxw[2])));
+}
+
+// One (source fs, target ft, point) residual: adds into the target-role sums a[kTrackSums]
+// (S in [0..11], Σρ in [12], count in [13]) and the source point's dL/dX_w.  Branch-free:
+// hardware rcp / rsq, mapping kind a template parameter, invisibility (projection.py:290-296:
+// the target must land inside [0,1)²) a 0/1 factor.  A point exactly on the camera plane
+// (Z'+eps == 0) projects to ±1e8 in the reference and is invisible there too.
+// (The un-scaled interface the host double calls: scales the target and the track position, runs the term above, scales the sums back.)
+template <int KIND, bool GRAD>
+FM_HD void track_pair_term(const float (&tg)[kTrackTgt], const float xw[3], float gt_x, float gt_y, float m, float delta,
+                           float inv_delta, float ax, float ay, float (&a)[kTrackSums], float gxw[3]) {
+  float ts[kTrackTgt], loc[kTrackSums];
+  track_scale_target(tg, ax, ay, ts);
+  for (int i = 0; i < kTrackSums; ++i) loc[i] = 0.f;
+  track_pair_term_scaled<KIND, GRAD>(ts, xw, gt_x * ax, gt_y * ay, m, delta, inv_delta, ax, ay, loc, gxw);
+  for (int j = 0; j < 4; ++j) {
+    a[j] += loc[j] * ax;
+    a[4 + j] += loc[4 + j] * ay;
+    a[8 + j] += loc[8 + j];
+  }
+  a[12] += loc[12];
+  a[13] += loc[13];
 }
 
 // Source-role step of one point once its dL/dX_w is complete: b[21] = this point's terms of

@@ -355,48 +355,52 @@ __device__ __forceinline__ void wave_sum_lane63_x7(float (&v)[NV]) {
 // function (which the host double runs).  `a` holds a partial sum per half, added together after the tile.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// (round 5) in SCALED image coordinates — track_pair_term_scaled (fm_pose.h): `ts` are the target's rows pre-multiplied by the aspect factors
+// (track_scale_target), gt_xs / gt_ys the track position pre-multiplied; the sums S0 / S1 come out divided by ax / ay (the kernel multiplies them
+// back where it stores a target's totals).
 template <int KIND, bool GRAD>
-__device__ __forceinline__ void track_pair_term2(const float (&tg)[kTrackTgt], const v2f (&xw)[3], float gt_x, float gt_y, v2f m, float delta,
+__device__ __forceinline__ void track_pair_term2(const float (&ts)[kTrackTgt], const v2f (&xw)[3], float gt_xs, float gt_ys, v2f m, float delta,
                                                  float inv_delta, float ax, float ay, v2f (&a)[kTrackSums], v2f (&gxw)[3]) {
-  const v2f xu = tg[0] * xw[0] + (tg[1] * xw[1] + (tg[2] * xw[2] + tg[3]));
-  const v2f xv = tg[4] * xw[0] + (tg[5] * xw[1] + (tg[6] * xw[2] + tg[7]));
-  const v2f x2 = tg[8] * xw[0] + (tg[9] * xw[1] + (tg[10] * xw[2] + tg[11]));
+  const v2f xu = ts[0] * xw[0] + (ts[1] * xw[1] + (ts[2] * xw[2] + ts[3]));
+  const v2f xv = ts[4] * xw[0] + (ts[5] * xw[1] + (ts[6] * xw[2] + ts[7]));
+  const v2f x2 = ts[8] * xw[0] + (ts[9] * xw[1] + (ts[10] * xw[2] + ts[11]));
   v2f q;
   q.x = fm_rcp(x2.x + kProjEps);
   q.y = fm_rcp(x2.y + kProjEps);
   const bool ok0 = fabsf(q.x) <= 3.0e38f, ok1 = fabsf(q.y) <= 3.0e38f;
   q.x = ok0 ? q.x : 0.f;
   q.y = ok1 ? q.y : 0.f;
-  const v2f u = xu * q, v = xv * q;
-  m.x = (ok0 && u.x >= 0.f && v.x >= 0.f && u.x < 1.f && v.x < 1.f) ? m.x : 0.f;
-  m.y = (ok1 && u.y >= 0.f && v.y >= 0.f && u.y < 1.f && v.y < 1.f) ? m.y : 0.f;
-  const v2f rx = (u - gt_x) * ax, ry = (v - gt_y) * ay;  // exact 0 for equal inputs (cf. aspect_diff)
+  const v2f zero = {0.f, 0.f};
+  const v2f u = __builtin_elementwise_fma(xu, q, zero), v = __builtin_elementwise_fma(xv, q, zero);  // ax·u, ay·v; never −0
+  const unsigned bx = __float_as_uint(ax), by = __float_as_uint(ay);
+  m.x = (ok0 && __float_as_uint(u.x) < bx && __float_as_uint(v.x) < by) ? m.x : 0.f;
+  m.y = (ok1 && __float_as_uint(u.y) < bx && __float_as_uint(v.y) < by) ? m.y : 0.f;
+  const v2f rx = u - gt_xs, ry = v - gt_ys;
   const v2f ss = rx * rx + ry * ry;
   v2f rho, coef;  // ρ and dρ/dr = coef·r
   if (KIND == kL2) {
     rho = 0.5f * ss;
     coef = 1.f;
-  } else {
+  } else if (KIND == kL1) {
     v2f inv_n;
     inv_n.x = ss.x > 0.f ? fm_rsq(ss.x) : 0.f;
     inv_n.y = ss.y > 0.f ? fm_rsq(ss.y) : 0.f;
-    const v2f n = ss * inv_n;
-    if (KIND == kL1) {
-      rho = n;
-      coef = inv_n;
-    } else {
-      const v2f quad_rho = (0.5f * inv_delta) * ss, lin_rho = n - 0.5f * delta;
-      rho.x = n.x < delta ? quad_rho.x : lin_rho.x;
-      rho.y = n.y < delta ? quad_rho.y : lin_rho.y;
-      coef.x = n.x < delta ? inv_delta : inv_n.x;
-      coef.y = n.y < delta ? inv_delta : inv_n.y;
-    }
+    rho = ss * inv_n;
+    coef = inv_n;
+  } else {
+    coef.x = fminf(fm_rsq(ss.x), inv_delta);
+    coef.y = fminf(fm_rsq(ss.y), inv_delta);
+    const v2f t = ss * coef;
+    v2f knee;
+    knee.x = fminf(t.x, delta);
+    knee.y = fminf(t.y, delta);
+    rho = -0.5f * knee + t;
   }
   a[12] = rho * m + a[12];
   a[13] += m;
   if (!GRAD) return;
   const v2f gc = m * coef;
-  const v2f wu = gc * rx * ax, wv = gc * ry * ay;  // dL/du, dL/dv (unscaled)
+  const v2f wu = gc * rx, wv = gc * ry;  // dL/du', dL/dv' (unscaled by the loss normaliser)
   const v2f o0 = q * wu, o1 = q * wv, o2 = q * (wu * u + wv * v);
   a[0] = o0 * xw[0] + a[0];
   a[1] = o0 * xw[1] + a[1];
@@ -410,9 +414,9 @@ __device__ __forceinline__ void track_pair_term2(const float (&tg)[kTrackTgt], c
   a[9] = o2 * xw[1] + a[9];
   a[10] = o2 * xw[2] + a[10];
   a[11] += o2;
-  gxw[0] = o0 * tg[0] + (o1 * tg[4] + (gxw[0] - o2 * tg[8]));  // dL/dX_w = ω·(au, av, −c)
-  gxw[1] = o0 * tg[1] + (o1 * tg[5] + (gxw[1] - o2 * tg[9]));
-  gxw[2] = o0 * tg[2] + (o1 * tg[6] + (gxw[2] - o2 * tg[10]));
+  gxw[0] = o0 * ts[0] + (o1 * ts[4] + (gxw[0] - o2 * ts[8]));  // dL/dX_w = ω'·(au', av', −c)
+  gxw[1] = o0 * ts[1] + (o1 * ts[5] + (gxw[1] - o2 * ts[9]));
+  gxw[2] = o0 * ts[2] + (o1 * ts[6] + (gxw[2] - o2 * ts[10]));
 }
 
 static_assert(kTrackTile % 2 == 0, "the source frames of a tile are processed in pairs");
@@ -588,7 +592,7 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
 #pragma unroll
     for (int q = 0; q < kTrackPG; ++q) {
       tv[q] = active[q] && tv_q[0][q] != 0 ? 1.f : 0.f;  // target role needs only the track's visibility (projection.py:290)
-      gt[q] = gt_q[0][q];
+      gt[q] = make_float2(gt_q[0][q].x * ax, gt_q[0][q].y * ay);  // (scaled image coordinates: track_pair_term_scaled, fm_pose.h)
 #pragma unroll
       for (int d = 0; d + 1 < kTrackAhead; ++d) {
         tv_q[d][q] = tv_q[d + 1][q];
@@ -602,7 +606,8 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
     }
     float tg[kTrackTgt];
 #pragma unroll
-    for (int i = 0; i < kTrackTgt; ++i) tg[i] = tgt[(size_t)(start + ft) * kTrackTgt + i];  // wave-uniform: scalar loads
+    for (int i = 0; i < kTrackTgt; ++i)  // wave-uniform: scalar loads; the projection rows pre-multiplied by the aspect factors (track_scale_target)
+      tg[i] = tgt[(size_t)(start + ft) * kTrackTgt + i] * (i < 4 ? ax : (i < 8 ? ay : 1.f));
 #ifdef FM_TRACK_CLOCKS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -630,7 +635,7 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
       wave_sum_lane63_x7<kTrackSums>(a);  // the totals are valid in lane 63
       if (threadIdx.x == kWave - 1) {
 #pragma unroll
-        for (int i = 0; i < kTrackSums; ++i) mine[(size_t)ft * kTrackSums + i] = a[i];
+        for (int i = 0; i < kTrackSums; ++i) mine[(size_t)ft * kTrackSums + i] = a[i] * (i < 4 ? ax : (i < 8 ? ay : 1.f));
       }
 #else
       static_assert(kTrackSums <= 16, "the transposing reduction handles 16 values");
@@ -639,7 +644,8 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
       for (int i = 0; i < 16; ++i) a16[i] = i < kTrackSums ? a[i] : 0.f;
       const float total = wave_transpose_sum16(a16);  // lane L: the wave total of sum L >> 2
       const int lane = threadIdx.x & (kWave - 1);
-      if ((lane & 3) == 0 && (lane >> 2) < kTrackSums) mine[(size_t)ft * kTrackSums + (lane >> 2)] = total;
+      const int which = lane >> 2;  // (S0 and S1 were accumulated divided by ax / ay: back to the un-scaled sums track_frame_grads reads)
+      if ((lane & 3) == 0 && which < kTrackSums) mine[(size_t)ft * kTrackSums + which] = total * (which < 4 ? ax : (which < 8 ? ay : 1.f));
 #endif
     } else {
       const float lc[2] = {a[12], a[13]};
