@@ -142,6 +142,10 @@ def parse():
                          "(the real dcharatan/flowmap when it is importable, else tests/standin — the GPU box has no /root/reference) and the step is that "
                          "package's own Model(get_backbone, get_intrinsics, get_extrinsics) + get_losses, i.e. what an unmodified overfit.py runs "
                          "(model_wrapper_overfit.py:51-62).  `direct`: flowmap_amd.model.model.Model and the loss classes constructed by hand")
+    ap.add_argument("--training-step", choices=["off", "eager", "graph"], default="off",
+                    help="drive the step through the reference-layout package's ModelWrapperOverfit.training_step (model_wrapper_overfit.py:51-73) in a "
+                         "trainer's order — training_step, zero_grad, backward, optimiser, global_step + 1: `eager` = the package's own method after "
+                         "install(); `graph` = install(graph=True): forward + losses and backward replayed as two hipGraphs (flowmap_amd/training.py)")
     ap.add_argument("--track-presample", action="store_true",
                     help="flow + tracking (A/B; measured and not adopted, flowmap_amd/_ops.py: track_presample): the camera-space half of the tracking loss's "
                          "sampling runs beside the Procrustes fit on a second stream instead of in the prologue of the pair kernel")
@@ -577,7 +581,7 @@ def main():
         # THE DROP-IN PATH (north_star: "so overfit.py drops it in unchanged"): install() rebinds the registries and import sites of
         # a reference-layout `flowmap` package, and the step below is that package's Model + get_losses, not classes picked by hand.
         package = reference_layout_package()
-        flowmap_amd.install()
+        flowmap_amd.install(graph=args.training_step == "graph")
         from flowmap.dataset.types import Batch as PackageBatch
         from flowmap.flow.flow_predictor import Flows as PackageFlows
         from flowmap.tracking.track_predictor import Tracks as PackageTracks
@@ -615,6 +619,16 @@ def main():
     elif args.optimizer == "torch":
         optimizer = torch.optim.Adam(model.parameters(), lr=3e-5)
     shared = [p for name, p in model.named_parameters() if not name.startswith("backbone.")]  # intrinsics: shared by all frames
+    wrapper = None
+    if args.training_step != "off":
+        if package is None or strong or world > 1 or args.graph:
+            raise SystemExit("--training-step: the installed path (--model installed) on one GPU, without --graph / --share")
+        try:
+            from flowmap.model.model_wrapper_overfit import ModelWrapperOverfit, ModelWrapperOverfitCfg
+        except ImportError as exc:
+            raise SystemExit(f"--training-step: {package[0]} has no importable model_wrapper_overfit here ({exc})")
+        wrapper = ModelWrapperOverfit(ModelWrapperOverfitCfg(3e-5, 32), model, batch, flows, tracks, loss_fns, [])
+        wrapper.train()
 
     def make_step(model, loss_fn, track_fn, batch, flows, tracks):
         def compute():  # zero_grad + forward + backward of this rank's frames: no collective
@@ -623,6 +637,18 @@ def main():
             loss = loss_fn(batch, flows, None, out, 0)
             loss.backward()
             return loss
+
+        def trainer_step():  # what a trainer's loop does around training_step (Lightning's automatic optimisation: closure = step -> zero_grad -> backward)
+            loss = wrapper.training_step(None)
+            (optimizer if optimizer is not None else model).zero_grad(set_to_none=True)
+            loss.backward()
+            if optimizer is not None:
+                optimizer.step()
+            wrapper.global_step += 1
+            return loss
+
+        if wrapper is not None and wrapper.model is model:
+            return trainer_step
 
         def step():
             tracked = None
@@ -836,6 +862,7 @@ def main():
                     + (f" + tracking loss (weight 100): {len(tracks)} segments x {tracks[0].xy.shape[2]} tracks" if tracks else "")
                     + f", explicit-depth backbone, {args.intrinsics} intrinsics, Procrustes P={args.points if args.points > 0 else 'all pixels'}; "
                     + (f"modules built by the {package[0]} package after flowmap_amd.install(); " if package is not None else "modules constructed by hand (--model direct); ")
+                    + ("stepped through that package's ModelWrapperOverfit.training_step" + (" replayed as hipGraphs (install(graph=True))" if args.training_step == "graph" else "") + "; " if wrapper is not None else "")
                     + "fwd+bwd, "
                     + ("no optimiser" if optimizer is None else f"+ Adam step ({type(optimizer).__module__}.{type(optimizer).__name__}"
                        + (", depth update inside the flow pass)" if args.optimizer == "in_pass" and optimizer.counters["in_pass_updates"] > 0
@@ -932,6 +959,11 @@ def main():
                                                     and "#" not in k],
                 "oracle_imported_by_the_timed_path": oracle_loaded_by_product_path,
                 "sustained_ms_per_step": sustained["ms_per_step"] if sustained is not None else None,
+                "training_step": None if wrapper is None else {
+                    "mode": args.training_step,
+                    "what": "the step is the package's ModelWrapperOverfit.training_step in a trainer's order (training_step, zero_grad, backward, optimiser, global_step + 1)"
+                            + ("; install(graph=True): forward + losses and backward replayed as two hipGraphs" if args.training_step == "graph" else ""),
+                    **({k: getattr(wrapper.__dict__.get("_fm_graphed_training"), k, None) for k in ("captures", "replays", "disabled")} if args.training_step == "graph" else {})},
                 "direct": direct,
                 "installed_over_direct": (sustained["ms_per_step"] / direct["ms_per_step"]) if (sustained is not None and direct is not None) else None,
             }

@@ -45,7 +45,7 @@ _CROPPING_SITES = ("flowmap.overfit", "flowmap.model.model_wrapper_pretrain")
 
 
 def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postprocess: bool = True, fused_adam: bool = True,
-            cropping: bool = True, fused_regressed: bool = True, lazy_backbone: bool = True) -> None:
+            cropping: bool = True, fused_regressed: bool = True, lazy_backbone: bool = True, graph: bool | None = None) -> None:
     """Patch the reference in place.  ``lazy_surfaces=True`` additionally lets
     ``Model.forward``'s ``unproject`` hand a LazySurfaces to the fused consumers;
     ``fused_softmin=True`` registers the fused candidate sweep as INTRINSICS["softmin"]
@@ -62,7 +62,10 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
     ``lazy_backbone=True`` registers BACKBONES["explicit_depth"] (flowmap/model/backbone/__init__.py:5-8) = ``flowmap_amd``'s
     BackboneExplicitDepth (same cfg, same parameter names ``depth`` / ``weights``: state_dict-compatible), whose forward hands the weight
     logits on unevaluated when ``lazy_surfaces`` is on (flowmap_amd/model/backbone.py) — the step an unmodified ``overfit.py`` then runs is
-    the step ``bench.py`` times."""
+    the step ``bench.py`` times; ``graph=True`` (default: the environment's ``FLOWMAP_AMD_GRAPH=1``, else off) rebinds
+    ``ModelWrapperOverfit.training_step`` (model_wrapper_overfit.py:51-73) to a step that replays the model's forward + the losses and the
+    loss's ``backward()`` as two hipGraphs while the optimisation's host-side control flow stands still, and runs the reference's own method
+    otherwise (flowmap_amd/training.py: what the reference's default ≈ 180×240 resolution needs, where the eager step is host-bound)."""
     from . import loss as our_loss
     from .loss import mapping as our_mapping
     from .model import procrustes as our_procrustes
@@ -190,6 +193,24 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
                 return FusedAdam(self.parameters(), lr=self.cfg.lr)
 
             _set(ref_wrapper.ModelWrapperOverfit, "configure_optimizers", configure_optimizers)
+
+    if graph is None:
+        import os
+
+        graph = os.environ.get("FLOWMAP_AMD_GRAPH", "0").lower() not in ("", "0", "false", "off")
+    if graph:
+        try:
+            ref_wrapper = importlib.import_module("flowmap.model.model_wrapper_overfit")
+        except Exception:  # lightning / hydra are not installed here; nothing to rebind
+            ref_wrapper = None
+        if ref_wrapper is not None:
+            from . import _ops
+            from .training import make_training_step
+
+            eager_step = ref_wrapper.ModelWrapperOverfit.__dict__.get("training_step", ref_wrapper.ModelWrapperOverfit.training_step)
+            _set(ref_wrapper.ModelWrapperOverfit, "training_step", make_training_step(eager_step))
+            # whether the compact tap image is current is a per-step decision of the host (parameter version counters): a replay cannot make it
+            _set(_ops, "use_tap_image", False)
 
     if cropping:
         from .misc import cropping as our_cropping

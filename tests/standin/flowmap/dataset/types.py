@@ -11,3 +11,5 @@ class Batch:
     indices: Optional[Tensor] = None
     scenes: Optional[list] = None
     datasets: Optional[list] = None
+    extrinsics: Optional[Tensor] = None  # (batch, frame, 4, 4) ground truth where a dataset has it
+    intrinsics: Optional[Tensor] = None  # (batch, frame, 3, 3)

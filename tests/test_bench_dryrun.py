@@ -106,3 +106,17 @@ def test_whole_c4_path_releases_the_originals_and_keeps_a_cpu_sample():
     assert whole["cpu_baseline"]["frames"] == 4 and whole["cpu_baseline"]["whole_workload"] is False
     assert abs(whole["config"]["loss"] - kept["config"]["loss"]) <= 1e-6 * abs(kept["config"]["loss"])
     assert abs(whole["cpu_baseline"]["loss"] - kept["cpu_baseline"]["loss"]) <= 1e-6 * abs(kept["cpu_baseline"]["loss"])
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_training_step_mode_drives_the_packages_wrapper(mode):
+    """bench.py --training-step eager | graph: the step is the reference-layout package's ModelWrapperOverfit.training_step in a trainer's
+    order; on the host double install(graph=True) captures nothing and the line says so.  Same loss as the default installed step."""
+    plain = _run(1, ["--config", "c2"])
+    line = _run(1, ["--config", "c2", "--training-step", mode])
+    info = line["via_install"]["training_step"]
+    assert info["mode"] == mode and "training_step" in line["config"]["workload"]
+    if mode == "graph":
+        assert info["captures"] == 0 and info["replays"] == 0 and info["disabled"] is None
+    assert abs(line["config"]["loss"] - plain["config"]["loss"]) <= 1e-6 * abs(plain["config"]["loss"])
+    assert plain["via_install"]["training_step"] is None
