@@ -65,7 +65,8 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
     the step ``bench.py`` times; ``graph=True`` (default: the environment's ``FLOWMAP_AMD_GRAPH=1``, else off) rebinds
     ``ModelWrapperOverfit.training_step`` (model_wrapper_overfit.py:51-73) to a step that replays the model's forward + the losses and the
     loss's ``backward()`` as two hipGraphs while the optimisation's host-side control flow stands still, and runs the reference's own method
-    otherwise (flowmap_amd/training.py: what the reference's default ≈ 180×240 resolution needs, where the eager step is host-bound)."""
+    otherwise (flowmap_amd/training.py: what the reference's default ≈ 180×240 resolution needs, where the eager step is host-bound; videos
+    whose depth maps exceed 128 MB are HBM-bound and keep the eager step)."""
     from . import loss as our_loss
     from .loss import mapping as our_mapping
     from .model import procrustes as our_procrustes
@@ -204,13 +205,10 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
         except Exception:  # lightning / hydra are not installed here; nothing to rebind
             ref_wrapper = None
         if ref_wrapper is not None:
-            from . import _ops
             from .training import make_training_step
 
             eager_step = ref_wrapper.ModelWrapperOverfit.__dict__.get("training_step", ref_wrapper.ModelWrapperOverfit.training_step)
             _set(ref_wrapper.ModelWrapperOverfit, "training_step", make_training_step(eager_step))
-            # whether the compact tap image is current is a per-step decision of the host (parameter version counters): a replay cannot make it
-            _set(_ops, "use_tap_image", False)
 
     if cropping:
         from .misc import cropping as our_cropping

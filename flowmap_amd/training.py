@@ -17,7 +17,8 @@ optimisation — and every call checks it:
 * every loss is switched on (``global_step >= cfg.enable_after``, loss/loss.py:39-41) and the intrinsics module is past its hand-over
   (intrinsics_softmin.py:74-82: the softmin sweep records focal lengths on the host until ``regression.after_step``);
 * tensors on the GPU, the HIP library loaded, gradients enabled, module in training mode, the same batch / flows / tracks objects, the same
-  set of parameters requiring gradients, no in-pass Adam update (``FusedAdam.fuse_depth_update``: its step number is a host value).
+  set of parameters requiring gradients, no in-pass Adam update (``FusedAdam.fuse_depth_update``: its step number is a host value), depth
+  maps below 128 MB (see the end of this note).
 
 When the phase changes (a loss switches on, the intrinsics hand over, ``eval()``), the graphs are dropped, the reference's own
 ``training_step`` runs — ``warmup`` times in the new phase, so that every cache the kernels' host side keeps is filled — and the new phase is
@@ -26,8 +27,9 @@ captured.  A capture that fails leaves the wrapper on the eager path for good, w
 The gradients the captured backward writes live in the graphs' pool and are the same tensors every step: ``backward()`` re-points
 ``param.grad`` at them (a trainer that sets gradients to ``None`` or zeroes them in place between steps — every trainer — sees exactly
 what the eager step gives; gradient ACCUMULATION over several ``training_step`` calls is not supported and a loss divided by anything but 1
-raises).  The tracking loss samples the depth images, not the compact tap image, while this is installed (``_ops.use_tap_image``): whether
-the image is current is decided on the host per step.
+raises).  Videos whose depth maps exceed the last-level cache (128 MB: where the tap exchange between the flow and tracking losses engages,
+DESIGN.md §3.4) keep the eager step: there the kernels are HBM-bound, the host's enqueue time hides behind them, and whether the compact tap
+image is current is a per-step decision of the host.
 """
 
 from __future__ import annotations
@@ -126,6 +128,7 @@ class GraphedTraining:
         self.awaiting_backward = False
         self.verify_unit_upstream_every = 64
         self._capturable_before = None
+        self._aliases = None
 
     # ---------------------------------------------------------------- the phase
     def on_device(self, wrapper) -> bool:
@@ -149,6 +152,11 @@ class GraphedTraining:
         elif not isinstance(intrinsics, regressed_cls):
             return None
         if any(step < fn.cfg.enable_after for fn in losses):
+            return None
+        # From the size at which the tap exchange engages (depth beyond the last-level cache: 128 MB, _ops.tap_exchange_min_bytes) the step is
+        # bound by HBM, the host's enqueue time hides behind the kernels, and whether the compact tap image is current is a per-step decision
+        # of the host that a replay could not make: the eager step stays.
+        if backbone.depth.numel() * backbone.depth.element_size() >= _ops.tap_exchange_min_bytes:
             return None
         params = list(wrapper.parameters())
         if any("_fm_fused_adam" in p.__dict__ for p in params):  # FusedAdam.fuse_depth_update: the update's step number is a host value
@@ -198,10 +206,10 @@ class GraphedTraining:
             wrapper.log("train/intrinsics/fx_error", self.errors[0])
             wrapper.log("train/intrinsics/fy_error", self.errors[1])
 
-    def forward(self, wrapper):
+    def forward(self, wrapper, model_call=None):
         """The body of training_step without its logging calls (model_wrapper_overfit.py:51-73)."""
         step = wrapper.global_step
-        model_output = wrapper.model(wrapper.batch, wrapper.flows, step)
+        model_output = wrapper.model(wrapper.batch, wrapper.flows, step) if model_call is None else model_call(wrapper.batch, wrapper.flows, step)
         total, values = 0, []
         for loss_fn in wrapper.losses:
             loss = loss_fn.forward(wrapper.batch, wrapper.flows, wrapper.tracks, model_output, step)
@@ -214,26 +222,53 @@ class GraphedTraining:
             errors = ((truth[..., 0, 0].mean() - k[..., 0, 0].mean()).abs(), (truth[..., 1, 1].mean() - k[..., 1, 1].mean()).abs())
         return total, values, errors
 
+    @staticmethod
+    def alias_parameters(named):
+        """name -> a new leaf over the parameter's storage that carries what this package keeps on the parameter object."""
+        aliases = {}
+        for name, p in named:
+            alias = p.detach().requires_grad_(True)
+            alias.__dict__.update(p.__dict__)
+            aliases[name] = alias
+        return aliases
+
+    def forward_on_aliases(self, wrapper, aliases):
+        return self.forward(wrapper, lambda *args: torch.func.functional_call(wrapper.model, aliases, args, strict=False))
+
     def capture(self, wrapper) -> None:
         device = wrapper.batch.videos.device
-        self.params = [p for p in wrapper.parameters() if p.requires_grad]
+        named = [(name, p) for name, p in wrapper.model.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
+        if {id(p) for p in self.params} != {id(p) for p in wrapper.parameters() if p.requires_grad}:
+            raise RuntimeError("parameters outside wrapper.model require gradients")
         for p in self.params:
-            p.grad = None  # (the trainer clears them before backward() anyway; the captured backward must CREATE them, in the graphs' pool)
+            # The trainer clears the previous step's gradients between training_step and backward(); the backward captured HERE must see them
+            # cleared too: a live gradient over the GradArena's storage makes the fit's backward take fresh zeros (csrc/fm_torch.cpp: GradArena) —
+            # captured, that is 4 bytes per weight logit filled on every replay.
+            p.grad = None
         self._capturable_before = _ops.graph_capturable
         _ops.graph_capturable = True
         _ops.flow_kernel_timing(False)  # event records do not belong in a graph
         torch.cuda.synchronize(device)
         self.forward_graph, backward_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # The captured autograd graph must not end in the parameters' own AccumulateGrad nodes: those were made by the eager steps on the
+        # trainer's stream and live as long as ANYTHING still holds a tensor of one of those steps (a logger, the trainer, a reference cycle
+        # the frozen collector never visits); the engine orders every gradient that reaches such a node — torch.autograd.grad included —
+        # against the node's stream, i.e. it would tie the capturing stream to the trainer's (torch warns, HIP faults).  So the step is
+        # captured on ALIASES of the parameters — new leaves over the same storage, made under the capturing stream, carrying the
+        # parameter's derived constants (plans, arenas: everything this package keeps on a tensor lives in its __dict__) — through
+        # torch.func.functional_call, and differentiated with respect to them.
         with torch.cuda.graph(self.forward_graph, capture_error_mode="thread_local"):
-            total, self.values, self.errors = self.forward(wrapper)
+            aliases = self.alias_parameters(named)
+            total, self.values, self.errors = self.forward_on_aliases(wrapper, aliases)
         if not isinstance(total, Tensor) or not total.requires_grad:
             raise RuntimeError("the step's total loss does not require gradients")
+        seed = _ops.unit_seed(total.device) if (_ops.use_unit_seed and total.dim() == 0 and total.dtype == torch.float32) else None
         with torch.cuda.graph(backward_graph, pool=self.forward_graph.pool(), capture_error_mode="thread_local"):
-            total.backward()
+            grads = torch.autograd.grad([total], [aliases[name] for name, _ in named], None if seed is None else [seed], allow_unused=True)
         self.backward_graph = backward_graph
-        self.grads = [p.grad for p in self.params]
-        for p in self.params:
-            p.grad = None
+        self.grads = list(grads)
+        self._aliases = aliases  # (kept: the graphs read the parameters' storage through them)
         # the SAME tensor object re-typed (as _ops.as_root_loss does): logging, detach(), clone() see a plain scalar
         total = total.detach()  # (its autograd history was consumed by the captured backward)
         total.requires_grad_(True)
@@ -267,7 +302,7 @@ class GraphedTraining:
             _ops.graph_capturable = self._capturable_before
         # (the loss of the dropped graphs keeps pointing here: a late backward() on it is refused in replay_backward)
         self.forward_graph = self.backward_graph = None
-        self.total, self.values, self.errors, self.grads, self.params = None, [], None, [], []
+        self.total, self.values, self.errors, self.grads, self.params, self._aliases = None, [], None, [], [], None
         self.awaiting_backward = False
 
 

@@ -27,7 +27,7 @@ class ModelWrapperOverfit(nn.Module):
         self.logged = {}
 
     def log(self, name, value):
-        self.logged[name] = value
+        self.logged[name] = value.detach() if torch.is_tensor(value) else value  # (a trainer's logger keeps values, not their autograd history)
 
     def training_step(self, dummy):
         output = self.model(self.batch, self.flows, self.global_step)

@@ -36,10 +36,10 @@ def test_install_graph_rebinds_training_step_and_uninstall_restores_it(standin):
     try:
         assert ref_wrapper.ModelWrapperOverfit.training_step is not original
         assert ref_wrapper.ModelWrapperOverfit.training_step.__wrapped__ is original
-        assert _ops.use_tap_image is False
+        assert _ops.use_tap_image is True  # (untouched: graphs exist only below the size at which the tap exchange engages)
     finally:
         flowmap_amd.uninstall()
-    assert ref_wrapper.ModelWrapperOverfit.training_step is original and _ops.use_tap_image is True
+    assert ref_wrapper.ModelWrapperOverfit.training_step is original
 
 
 def test_on_the_host_double_the_installed_graph_step_is_the_packages_own(standin):
@@ -203,6 +203,15 @@ def test_the_state_machine_around_the_graphs(standin):
         del wrapper.model.backbone.depth.__dict__["_fm_fused_adam"]
         wrapper.losses[1].cfg.enable_after = wrapper.global_step + 1
         assert state.signature(wrapper) is None
+        wrapper.losses[1].cfg.enable_after = 0
+        from flowmap_amd import _ops
+
+        previous, _ops.tap_exchange_min_bytes = _ops.tap_exchange_min_bytes, wrapper.model.backbone.depth.numel() * 4
+        try:  # depth maps from the size at which the tap exchange engages: HBM-bound, the eager step stays
+            assert state.signature(wrapper) is None
+        finally:
+            _ops.tap_exchange_min_bytes = previous
+        assert state.signature(wrapper) is not None
         assert isinstance(training.make_training_step(eager).__wrapped__, type(eager))
     finally:
         flowmap_amd.uninstall()
@@ -273,3 +282,40 @@ def test_a_replayed_training_step_enqueues_two_graph_launches(standin):
         assert wrapper.model.backbone.depth.grad is not None and torch.isfinite(wrapper.model.backbone.depth.grad).all()
     finally:
         flowmap_amd.uninstall()
+
+
+def test_the_step_on_parameter_aliases_is_the_step(standin):
+    """What the capture differentiates: the model called through torch.func.functional_call on ALIASES of its parameters (new leaves over the
+    same storage that carry the parameter's derived constants).  On the host double: same loss, same gradients as the eager installed step,
+    the weights' gradient in the parameter's own arena, the plans of the eager steps reused (no new scatter plan is built)."""
+    import flowmap.model.model_wrapper_overfit as ref_wrapper
+
+    import flowmap_amd
+    from flowmap_amd import _lib, _ops, training
+    from helpers import build_host_sim
+
+    _lib.set_library_for_testing(build_host_sim())
+    try:
+        flowmap_amd.install()
+        wrapper = _wrapper("step_scene_flow_tracking", True, "cpu")
+        wrapper.fit_steps(None, 2)  # the eager steps of a phase: packed inputs, scatter / tap plans
+        wrapper.zero_grad(set_to_none=True)
+        loss = wrapper.training_step(None)
+        loss.backward()
+        expected = {name: p.grad.clone() for name, p in wrapper.model.named_parameters()}
+        wrapper.zero_grad(set_to_none=True)
+        before = dict(_ops.counters)
+        state = training.GraphedTraining(ref_wrapper.ModelWrapperOverfit.training_step)
+        named = list(wrapper.model.named_parameters())
+        aliases = state.alias_parameters(named)
+        total, values, _ = state.forward_on_aliases(wrapper, aliases)
+        grads = torch.autograd.grad([total], [aliases[name] for name, _ in named], [_ops.unit_seed(total.device)], allow_unused=True)
+        assert float(total.detach()) == pytest.approx(float(loss.detach()), rel=1e-6) and len(values) == 2
+        for (name, p), g in zip(named, grads):
+            assert p.grad is None and g is not None, name
+            assert torch.allclose(g, expected[name], rtol=1e-5, atol=1e-12), name
+        moved = {k for k, v in _ops.counters.items() if v != before.get(k, 0)}
+        assert not {k for k in moved if "plan" in k and "hit" not in k}, moved
+    finally:
+        flowmap_amd.uninstall()
+        _lib.set_library_for_testing(None)
