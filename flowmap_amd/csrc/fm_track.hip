@@ -419,6 +419,62 @@ __device__ __forceinline__ void track_pair_term2(const float (&ts)[kTrackTgt], c
   gxw[2] = o0 * ts[2] + (o1 * ts[6] + (gxw[2] - o2 * ts[10]));
 }
 
+// Build variant FM_TRACK_MFMA (round 5): the two dense 3x4 products of a residual — the pose transform X_c = T'·[X_w; 1] and the
+// gradient's way back dL/dX_w += T'ᵀ·ω' — on the matrix pipe.  v_mfma_f32_4x4x1_16B_f32 accumulates sixteen independent 4x4 outer
+// products D_b[i][j] += A(lane 4b+i)·B(lane 4b+j), lane 4b+j holding column j of its quad's block in four registers.  With the B
+// operand a per-lane quantity of the lane's OWN residual (component k of X_w; ω'_r) and the A operand a per-target constant laid out
+// across the quad (lane 4b+i: T'[i][k]; lane 4b+k: ±T'[r][k]), the lane's column IS its own product: four instructions give (x_u, x_v,
+// x_2, ·), three more add this target's term to (dL/dX_w0, dL/dX_w1, dL/dX_w2, ·) — no cross-lane movement of operands, the same fmaf chains
+// in the same order as track_pair_term_scaled (the matrix pipe's fp32 product-accumulate is an fmaf).  What stays on the VALU is packed over
+// the (u, v) pair of ONE residual instead of over two source frames.  The VALU multiply-adds these replace are 18 of the 49 a residual costs.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+template <int KIND, bool GRAD>
+__device__ __forceinline__ void track_pair_term_mfma(const v4f_t xc, const float (&xw)[3], const v2f gt_s, float m, float delta, float inv_delta,
+                                                     unsigned bx, unsigned by, v2f (&a01)[4], float (&a2)[4], float& a_rho, float& a_cnt,
+                                                     const float (&ab)[3], v4f_t& gacc) {
+  float q = fm_rcp(xc.z + kProjEps);
+  const bool ok = fabsf(q) <= 3.0e38f;
+  q = ok ? q : 0.f;
+  const v2f zero = {0.f, 0.f}, qq = {q, q};
+  const v2f uv = __builtin_elementwise_fma(v2f{xc.x, xc.y}, qq, zero);  // ax·u, ay·v; never −0
+  m = (ok && __float_as_uint(uv.x) < bx && __float_as_uint(uv.y) < by) ? m : 0.f;
+  const v2f r = uv - gt_s;
+  const float ss = r.x * r.x + r.y * r.y;
+  float rho, coef;  // ρ and dρ/dr = coef·r
+  if (KIND == kL2) {
+    rho = 0.5f * ss;
+    coef = 1.f;
+  } else if (KIND == kL1) {
+    const float inv_n = ss > 0.f ? fm_rsq(ss) : 0.f;
+    rho = ss * inv_n;
+    coef = inv_n;
+  } else {
+    coef = fminf(fm_rsq(ss), inv_delta);
+    const float t = ss * coef;
+    rho = -0.5f * fminf(t, delta) + t;
+  }
+  a_rho = rho * m + a_rho;
+  a_cnt += m;
+  if (!GRAD) return;
+  const float gc = m * coef;
+  const v2f w = v2f{gc, gc} * r;   // dL/du', dL/dv' (unscaled by the loss normaliser)
+  const v2f o01 = qq * w;
+  const float o2 = q * (w.x * uv.x + w.y * uv.y);
+  a01[0] = o01 * v2f{xw[0], xw[0]} + a01[0];  // (S0 | S1) rows, component by component
+  a01[1] = o01 * v2f{xw[1], xw[1]} + a01[1];
+  a01[2] = o01 * v2f{xw[2], xw[2]} + a01[2];
+  a01[3] += o01;
+  a2[0] = o2 * xw[0] + a2[0];
+  a2[1] = o2 * xw[1] + a2[1];
+  a2[2] = o2 * xw[2] + a2[2];
+  a2[3] += o2;
+  // dL/dX_w[k] = o0·ts[k] + (o1·ts[4 + k] + (dL/dX_w[k] − o2·ts[8 + k])): innermost first (ab[2] carries the minus sign)
+  gacc = __builtin_amdgcn_mfma_f32_4x4x1f32(ab[2], o2, gacc, 0, 0, 0);
+  gacc = __builtin_amdgcn_mfma_f32_4x4x1f32(ab[1], o01.y, gacc, 0, 0, 0);
+  gacc = __builtin_amdgcn_mfma_f32_4x4x1f32(ab[0], o01.x, gacc, 0, 0, 0);
+}
+
 static_assert(kTrackTile % 2 == 0, "the source frames of a tile are processed in pairs");
 
 // Sampling inside the pair kernel (fm_track_loss_fused_fwd): the wave samples the points of its own tile's source
@@ -443,6 +499,9 @@ struct TrackSampling {
 #define FM_TRACK_PG 2
 #endif
 constexpr int kTrackPG = FM_TRACK_PG;
+#ifndef FM_TRACK_MFMA  // 1: the pose transform and dL/dX_w on the matrix pipe (track_pair_term_mfma)
+#define FM_TRACK_MFMA 0
+#endif
 #ifndef FM_TRACK_AHEAD
 #define FM_TRACK_AHEAD 2
 #endif
@@ -482,8 +541,13 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
   }
 
   // source frames fs0 + 2j (.x) and fs0 + 2j + 1 (.y) share packed registers
+#if FM_TRACK_MFMA
+  float xw1[kTrackPG][kTrackTile][3], live1[kTrackPG][kTrackTile];  // per source frame (the matrix pipe takes one residual's operands per lane)
+  v4f_t gacc[kTrackPG][kTrackTile];                                  // (dL/dX_w0, dL/dX_w1, dL/dX_w2, ·): the MFMAs' accumulators
+#else
   v2f xw[kTrackPG][kTrackTile / 2][3], gxw[kTrackPG][kTrackTile / 2][3];
   v2f live[kTrackPG][kTrackTile / 2];  // 1 when the source role is visible (projection.py:290-294), else 0
+#endif
 #pragma unroll
   for (int q = 0; q < kTrackPG; ++q) {
     float lvs[kTrackTile], xs[kTrackTile][3];
@@ -555,12 +619,18 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
 #pragma unroll
     for (int t = 0; t < kTrackTile; ++t) {
       const float lv = lvs[t], x0 = lv != 0.f ? xs[t][0] : 0.f, x1 = lv != 0.f ? xs[t][1] : 0.f, x2 = lv != 0.f ? xs[t][2] : 0.f;
+#if FM_TRACK_MFMA
+      live1[q][t] = lv; xw1[q][t][0] = x0; xw1[q][t][1] = x1; xw1[q][t][2] = x2;
+      gacc[q][t] = v4f_t{0.f, 0.f, 0.f, 0.f};
+      continue;
+#else
       if (t & 1) {
         live[q][t / 2].y = lv; xw[q][t / 2][0].y = x0; xw[q][t / 2][1].y = x1; xw[q][t / 2][2].y = x2;
       } else {
         live[q][t / 2].x = lv; xw[q][t / 2][0].x = x0; xw[q][t / 2][1].x = x1; xw[q][t / 2][2].x = x2;
       }
       gxw[q][t / 2][0] = gxw[q][t / 2][1] = gxw[q][t / 2][2] = 0.f;
+#endif
     }
   }
 
@@ -604,15 +674,58 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
         gt_q[kTrackAhead - 1][q] = reinterpret_cast<const float2*>(g.xy)[it[q]];
       }
     }
+#if FM_TRACK_MFMA
+    // the target's scaled rows laid out across the quad: af[k] = T'[lane & 3][k] (row 3: zeros), ab[r] = ±T'[r][lane & 3]
+    const int quad_lane = threadIdx.x & 3;
+    const float* trow = tgt + (size_t)(start + ft) * kTrackTgt;
+    const float row_scale = quad_lane == 0 ? ax : (quad_lane == 1 ? ay : (quad_lane == 2 ? 1.f : 0.f));
+    const v4f_t trow4 = *reinterpret_cast<const v4f_t*>(trow + 4 * min(quad_lane, 2));
+    const float af[4] = {trow4.x * row_scale, trow4.y * row_scale, trow4.z * row_scale, trow4.w * row_scale};
+    const float ab[3] = {trow[quad_lane] * ax, trow[4 + quad_lane] * ay, -trow[8 + quad_lane]};
+#else
     float tg[kTrackTgt];
 #pragma unroll
     for (int i = 0; i < kTrackTgt; ++i)  // wave-uniform: scalar loads; the projection rows pre-multiplied by the aspect factors (track_scale_target)
       tg[i] = tgt[(size_t)(start + ft) * kTrackTgt + i] * (i < 4 ? ax : (i < 8 ? ay : 1.f));
+#endif
 #ifdef FM_TRACK_CLOCKS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     FM_TCLK(c1);
     FM_TCLK_ADD(1, c0, c1);
+    float a[kTrackSums];
+#if FM_TRACK_MFMA
+    {
+      // X_c of the iteration's twelve residuals: four MFMAs each, the chains interleaved (translation first: the scalar function's order)
+      v4f_t xc[kTrackPG][kTrackTile];
+      const float one = 1.0f;
+#pragma unroll
+      for (int q = 0; q < kTrackPG; ++q)
+#pragma unroll
+        for (int t = 0; t < kTrackTile; ++t) xc[q][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[3], one, v4f_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int k = 2; k >= 0; --k)
+#pragma unroll
+        for (int q = 0; q < kTrackPG; ++q)
+#pragma unroll
+          for (int t = 0; t < kTrackTile; ++t) xc[q][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[k], xw1[q][t][k], xc[q][t], 0, 0, 0);
+      v2f a01[4];
+      float a2s[4], a_rho = 0.f, a_cnt = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a01[i] = 0.f, a2s[i] = 0.f;
+      const unsigned bx = __float_as_uint(ax), by = __float_as_uint(ay);
+#pragma unroll
+      for (int q = 0; q < kTrackPG; ++q) {
+        const v2f gt_s = {gt[q].x, gt[q].y};
+#pragma unroll
+        for (int t = 0; t < kTrackTile; ++t)
+          track_pair_term_mfma<KIND, GRAD>(xc[q][t], xw1[q][t], gt_s, tv[q] * live1[q][t], delta, inv_delta, bx, by, a01, a2s, a_rho, a_cnt, ab, gacc[q][t]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = a01[i].x, a[4 + i] = a01[i].y, a[8 + i] = a2s[i];
+      a[12] = a_rho, a[13] = a_cnt;
+    }
+#else
     v2f a2[kTrackSums];
 #pragma unroll
     for (int i = 0; i < kTrackSums; ++i) a2[i] = 0.f;
@@ -622,9 +735,9 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
       for (int j = 0; j < kTrackTile / 2; ++j)
         track_pair_term2<KIND, GRAD>(tg, xw[q][j], gt[q].x, gt[q].y, tv[q] * live[q][j], delta, inv_delta, ax, ay, a2, gxw[q][j]);
     }
-    float a[kTrackSums];
 #pragma unroll
     for (int i = 0; i < kTrackSums; ++i) a[i] = a2[i].x + a2[i].y;
+#endif
 #ifdef FM_TRACK_CLOCKS
     asm volatile("" :: "v"(a[0]), "v"(a[13]));
 #endif
@@ -668,11 +781,18 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
       load_pose44(ext + (size_t)(start + fs) * 16, e);
 #pragma unroll
       for (int q = 0; q < kTrackPG; ++q) {
+#if FM_TRACK_MFMA
+        if (live1[q][t] != 0.f) {
+          const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
+          float gxyz[3];
+          const float gx[3] = {gacc[q][t].x, gacc[q][t].y, gacc[q][t].z};
+#else
         if (((t & 1) ? live[q][t / 2].y : live[q][t / 2].x) != 0.f) {
           const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
           float gxyz[3];
           const float gx[3] = {(t & 1) ? gxw[q][t / 2][0].y : gxw[q][t / 2][0].x, (t & 1) ? gxw[q][t / 2][1].y : gxw[q][t / 2][1].x,
                                (t & 1) ? gxw[q][t / 2][2].y : gxw[q][t / 2][2].x};
+#endif
           float b1[21], w9[kTrackWs];
           const float* wp = ws_plane(ws, is - p[q], p_count, p[q]);
 #pragma unroll
