@@ -34,6 +34,7 @@ image is current is a per-step decision of the host.
 
 from __future__ import annotations
 
+import os
 import warnings
 from typing import Callable, List, Optional
 
@@ -129,6 +130,12 @@ class GraphedTraining:
         self.verify_unit_upstream_every = 64
         self._capturable_before = None
         self._aliases = None
+        self._side_streams = None
+        # The losses after the first on streams of their own inside the capture (FLOWMAP_AMD_GRAPH_STREAMS=1).  Measured at 180x240, flow + tracking:
+        # 0.348-0.349 ms against 0.355-0.356 on one stream (profiles/r05_training_step_graph_streams_ab.txt) — track_pairs holds two 256-register
+        # waves on nearly every SIMD, so the flow pass's blocks find room only at its edges.  2 % does not pay for a second stream's allocator
+        # discipline: off by default.
+        self.concurrent_losses = os.environ.get("FLOWMAP_AMD_GRAPH_STREAMS", "0").lower() not in ("0", "false", "off", "")
 
     # ---------------------------------------------------------------- the phase
     def on_device(self, wrapper) -> bool:
@@ -206,14 +213,30 @@ class GraphedTraining:
             wrapper.log("train/intrinsics/fx_error", self.errors[0])
             wrapper.log("train/intrinsics/fy_error", self.errors[1])
 
-    def forward(self, wrapper, model_call=None):
-        """The body of training_step without its logging calls (model_wrapper_overfit.py:51-73)."""
+    def forward(self, wrapper, model_call=None, side_streams=None):
+        """The body of training_step without its logging calls (model_wrapper_overfit.py:51-73).  ``side_streams`` (inside a capture): every loss
+        after the first is evaluated on a stream of its own, forked where the model's forward ends and joined before the losses are summed —
+        the fused losses are independent passes over the same model output (the flow pass is bound by memory, the tracking kernel by VALU issue),
+        and as branches of one hipGraph they overlap at no cost to the host; autograd runs each loss's backward on the stream of its forward."""
         step = wrapper.global_step
         model_output = wrapper.model(wrapper.batch, wrapper.flows, step) if model_call is None else model_call(wrapper.batch, wrapper.flows, step)
-        total, values = 0, []
-        for loss_fn in wrapper.losses:
-            loss = loss_fn.forward(wrapper.batch, wrapper.flows, wrapper.tracks, model_output, step)
-            values.append(loss)
+        main = torch.cuda.current_stream() if side_streams else None
+        used = []
+        if side_streams:
+            used = list(side_streams[: max(0, len(wrapper.losses) - 1)])
+            for side in used:  # fork BEFORE the first loss is enqueued: the branches start where the model's forward ends
+                side.wait_stream(main)
+        values = []
+        for index, loss_fn in enumerate(wrapper.losses):
+            if used and index > 0:
+                with torch.cuda.stream(used[index - 1]):
+                    values.append(loss_fn.forward(wrapper.batch, wrapper.flows, wrapper.tracks, model_output, step))
+            else:
+                values.append(loss_fn.forward(wrapper.batch, wrapper.flows, wrapper.tracks, model_output, step))
+        for side in used:
+            main.wait_stream(side)
+        total = 0
+        for loss in values:
             total = total + loss
         errors = None
         truth = getattr(wrapper.batch, "intrinsics", None)
@@ -232,8 +255,8 @@ class GraphedTraining:
             aliases[name] = alias
         return aliases
 
-    def forward_on_aliases(self, wrapper, aliases):
-        return self.forward(wrapper, lambda *args: torch.func.functional_call(wrapper.model, aliases, args, strict=False))
+    def forward_on_aliases(self, wrapper, aliases, side_streams=None):
+        return self.forward(wrapper, lambda *args: torch.func.functional_call(wrapper.model, aliases, args, strict=False), side_streams)
 
     def capture(self, wrapper) -> None:
         device = wrapper.batch.videos.device
@@ -251,6 +274,8 @@ class GraphedTraining:
         _ops.flow_kernel_timing(False)  # event records do not belong in a graph
         torch.cuda.synchronize(device)
         self.forward_graph, backward_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        side_streams = [torch.cuda.Stream(device) for _ in range(len(wrapper.losses) - 1)] if (self.concurrent_losses and len(wrapper.losses) > 1) else None
+        self._side_streams = side_streams  # (kept: the backward graph's branches were captured on them)
         # The captured autograd graph must not end in the parameters' own AccumulateGrad nodes: those were made by the eager steps on the
         # trainer's stream and live as long as ANYTHING still holds a tensor of one of those steps (a logger, the trainer, a reference cycle
         # the frozen collector never visits); the engine orders every gradient that reaches such a node — torch.autograd.grad included —
@@ -260,7 +285,7 @@ class GraphedTraining:
         # torch.func.functional_call, and differentiated with respect to them.
         with torch.cuda.graph(self.forward_graph, capture_error_mode="thread_local"):
             aliases = self.alias_parameters(named)
-            total, self.values, self.errors = self.forward_on_aliases(wrapper, aliases)
+            total, self.values, self.errors = self.forward_on_aliases(wrapper, aliases, side_streams)
         if not isinstance(total, Tensor) or not total.requires_grad:
             raise RuntimeError("the step's total loss does not require gradients")
         seed = _ops.unit_seed(total.device) if (_ops.use_unit_seed and total.dim() == 0 and total.dtype == torch.float32) else None

@@ -12,10 +12,16 @@ import torch
 from test_install_standin import _problem
 
 
-def _wrapper(name, with_tracks, dev, enable_tracking_after=0, lr=1e-3):
+def _wrapper(name, with_tracks, dev, enable_tracking_after=0, lr=1e-3, softmin=None):
     from flowmap.model.model_wrapper_overfit import ModelWrapperOverfit, ModelWrapperOverfitCfg
 
     g, model, batch, flows, tracks, losses = _problem(name, with_tracks, dev)
+    if softmin is not None:  # the reference's default intrinsics (config/overfit.yaml): the softmin sweep, handing over to a regressed focal length
+        from flowmap.model.intrinsics import IntrinsicsSoftminCfg, RegressionCfg, get_intrinsics
+
+        after_step, window = softmin
+        torch.manual_seed(5)
+        model.intrinsics = get_intrinsics(IntrinsicsSoftminCfg("softmin", 200, 0.5, 2.0, 20, RegressionCfg(after_step, window))).to(dev)
     if with_tracks:
         losses[1].cfg.enable_after = enable_tracking_after
     wrapper = ModelWrapperOverfit(ModelWrapperOverfitCfg(lr, 32), model, batch, flows, tracks, losses, [])
@@ -319,3 +325,33 @@ def test_the_step_on_parameter_aliases_is_the_step(standin):
     finally:
         flowmap_amd.uninstall()
         _lib.set_library_for_testing(None)
+
+
+def _run_softmin_trainer(graph, dev, steps=10):
+    import flowmap_amd
+
+    flowmap_amd.install(graph=graph)
+    try:
+        torch.manual_seed(11)
+        wrapper = _wrapper("step_scene_flow_tracking", True, dev, softmin=(3, 2))
+        optimizer = wrapper.configure_optimizers()
+        history = [float(wrapper.fit_steps(optimizer, 1).detach()) for _ in range(steps)]
+        return history, [p.detach().clone() for p in wrapper.parameters()], wrapper.__dict__.get("_fm_graphed_training")
+    finally:
+        flowmap_amd.uninstall()
+
+
+@pytest.mark.gpu
+def test_the_replay_starts_after_the_softmin_hand_over(standin):
+    """The reference's default intrinsics: the softmin sweep (steps 0-2, random pixels, the focal lengths of the window recorded on the host), the
+    hand-over to the regressed focal length at step 3 — all of that runs as the package's own step; steps 4-5 are the new phase's eager steps,
+    step 6 is captured, 6-9 replayed.  Same trajectory as the eager installed run."""
+    from conftest import assert_close
+
+    eager_history, eager_params, _ = _run_softmin_trainer(False, "cuda:0")
+    history, params, state = _run_softmin_trainer(True, "cuda:0")
+    assert state is not None and state.disabled is None, getattr(state, "disabled", None)
+    assert state.captures == 1 and state.replays == 4
+    assert_close(torch.tensor(history), torch.tensor(eager_history), 1e-5, what="loss history")
+    for ours, theirs in zip(params, eager_params):
+        assert_close(ours, theirs, 1e-5, what="parameters")
