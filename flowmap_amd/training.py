@@ -128,7 +128,6 @@ class GraphedTraining:
         self.replays = self.captures = 0
         self.awaiting_backward = False
         self.verify_unit_upstream_every = 64
-        self._capturable_before = None
         self._aliases = None
         self._side_streams = None
         # The losses after the first on streams of their own inside the capture (FLOWMAP_AMD_GRAPH_STREAMS=1).  Measured at 180x240, flow + tracking:
@@ -269,10 +268,18 @@ class GraphedTraining:
             # cleared too: a live gradient over the GradArena's storage makes the fit's backward take fresh zeros (csrc/fm_torch.cpp: GradArena) —
             # captured, that is 4 bytes per weight logit filled on every replay.
             p.grad = None
-        self._capturable_before = _ops.graph_capturable
-        _ops.graph_capturable = True
         _ops.flow_kernel_timing(False)  # event records do not belong in a graph
         torch.cuda.synchronize(device)
+        # (while a capture runs, anything that draws random numbers must keep its state on the device: _ops.graph_capturable.  No eligible
+        # phase draws any — the softmin sweep is the package's own step — and the switch is global, so it is on for the capture only: left
+        # on, every later eager sweep of the process would draw from the device-side state instead of torch's generator)
+        capturable_before, _ops.graph_capturable = _ops.graph_capturable, True
+        try:
+            self._capture(wrapper, device, named)
+        finally:
+            _ops.graph_capturable = capturable_before
+
+    def _capture(self, wrapper, device, named) -> None:
         self.forward_graph, backward_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         side_streams = [torch.cuda.Stream(device) for _ in range(len(wrapper.losses) - 1)] if (self.concurrent_losses and len(wrapper.losses) > 1) else None
         self._side_streams = side_streams  # (kept: the backward graph's branches were captured on them)
@@ -323,8 +330,6 @@ class GraphedTraining:
             _ops.check_unit_flags("a training_step replayed as hipGraphs (flowmap_amd.install(graph=True))")
 
     def drop(self) -> None:
-        if self.forward_graph is not None and self._capturable_before is not None:
-            _ops.graph_capturable = self._capturable_before
         # (the loss of the dropped graphs keeps pointing here: a late backward() on it is refused in replay_backward)
         self.forward_graph = self.backward_graph = None
         self.total, self.values, self.errors, self.grads, self.params, self._aliases = None, [], None, [], [], None

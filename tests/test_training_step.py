@@ -260,6 +260,9 @@ def test_the_replayed_training_step_follows_the_eager_installed_one(standin):
         assert abs(logged[key] - eager_logged[key]) <= 1e-5 * abs(eager_logged[key]), key
     for ours, theirs in zip(params, eager_params):
         assert_close(ours, theirs, 1e-5, what="parameters")
+    from flowmap_amd import _ops
+
+    assert _ops.graph_capturable is False  # on for the capture only: a process-wide switch must not outlive it (later eager sweeps draw from torch's generator)
 
 
 @pytest.mark.gpu
