@@ -4,10 +4,12 @@
 optionally, the optimiser — into one hipGraph (``torch.cuda.CUDAGraph``) and replays it; every
 kernel of this package launches on torch's current stream and allocates through torch, so it is
 captured like any torch op.  What it buys is HOST time: a replay costs the CPU a few microseconds
-instead of the 0.5-0.9 ms it takes to enqueue the ~50-70 launches of a step (8 ranks on one host,
-or a slow host).  It does NOT shorten the step on this stack: at the reference's default resolution
-(150 frames of 180x240, flow + tracking + Adam) the step is bound by the dependent chain of short
-kernels on the GPU — 0.856 ms eager, 0.872 ms replayed — and at 720p by HBM.
+instead of the 0.45-0.6 ms it takes to enqueue the launches of a step.  Where the host is the
+bottleneck that is the step time — the reference's default resolution (150 frames of 180x240, flow +
+tracking: 0.35 ms of kernels, 0.45-0.58 ms eager, 0.354 ms replayed; round 5), a rank
+of an 8-GPU strong-scaling run, a slow host; at 720p the kernels are HBM-bound and the host's time hides
+behind them.  ``flowmap_amd.install(graph=True)`` (flowmap_amd/training.py) gives the same replay to a
+trainer that owns the loop: it wraps ``ModelWrapperOverfit.training_step``.
 
 A frame-sharded step (flowmap_amd.sharding.FrameShard) is captured with its collectives: RCCL work is stream-ordered,
 ``FrameShard.sync`` keeps its buffers across steps and never waits on the host, so the all-reduce, the halo exchange and the
