@@ -60,7 +60,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP32_PEAK_GFLOPS = 157300.0  # same guide: fp32 vector peak with packed FMA
-TRACK_VALU_PER_RESIDUAL = 67.2  # measured: SQ_INSTS_VALU x 64 lanes / residuals at C2 (profiles/r05_c2_sq_counters.csv)
+TRACK_VALU_PER_RESIDUAL = 60.3  # measured: SQ_INSTS_VALU (26 019 per wave x 1 984 waves) x 64 lanes / residuals at C2 (profiles/r05_c2_sq_counters_scaled_residual.csv; 67.2 before the scaled-residual loop)
 TRACK_FLOPS_PER_RESIDUAL = 90.0  # track_pair_term (csrc/fm_pose.h): ~60 VALU instructions, FMAs counted twice
 
 CONFIGS = {
@@ -992,10 +992,10 @@ def main():
                 "traffic": None,
                 "residuals_per_launch": residuals,
                 "flops_per_residual": TRACK_FLOPS_PER_RESIDUAL,
-                # the kernel's own currency: VALU issue slots.  SQ_INSTS_VALU of track_pairs = 28 970 per wave x 1 984 waves at C2
-                # (profiles/r05_c2_sq_counters.csv) = 67.2 instructions per residual and lane; a wave64 instruction occupies its SIMD for 4 cycles
+                # the kernel's own currency: VALU issue slots.  SQ_INSTS_VALU of track_pairs = 26 019 per wave x 1 984 waves at C2
+                # (profiles/r05_c2_sq_counters_scaled_residual.csv) = 60.3 instructions per residual and lane; a wave64 instruction occupies its SIMD for 4 cycles
                 # (packed fp32 ones for ~8: the floor below is optimistic), 1024 SIMDs, ~2.1 GHz sustained under load
-                "issue_roofline": {"valu_instructions_per_residual": TRACK_VALU_PER_RESIDUAL, "measured_in": "profiles/r05_c2_sq_counters.csv",
+                "issue_roofline": {"valu_instructions_per_residual": TRACK_VALU_PER_RESIDUAL, "measured_in": "profiles/r05_c2_sq_counters_scaled_residual.csv",
                                    "issue_bound_ms": residuals * TRACK_VALU_PER_RESIDUAL / 64 * 4 / (1024 * 2.1e9) * 1e3,
                                    "frac": (residuals * TRACK_VALU_PER_RESIDUAL / 64 * 4 / (1024 * 2.1e9) * 1e3) / t_ms if t_ms > 0 else None},
                 "kernel_ms": t_ms,
