@@ -146,6 +146,10 @@ def parse():
                     help="drive the step through the reference-layout package's ModelWrapperOverfit.training_step (model_wrapper_overfit.py:51-73) in a "
                          "trainer's order — training_step, zero_grad, backward, optimiser, global_step + 1: `eager` = the package's own method after "
                          "install(); `graph` = install(graph=True): forward + losses and backward replayed as two hipGraphs (flowmap_amd/training.py)")
+    ap.add_argument("--default-resolution", choices=["auto", "on", "off"], default="auto",
+                    help="the reference's default operating point (config/overfit.yaml:33-38: 150 frames of ~180x240, flow + tracking) beside the headline: "
+                         "two child runs of this file — the package's ModelWrapperOverfit.training_step eager and under install(graph=True) — reported "
+                         "under `default_resolution` (auto: with the default headline run on one GPU, like the ATE leg)")
     ap.add_argument("--track-presample", action="store_true",
                     help="flow + tracking (A/B; measured and not adopted, flowmap_amd/_ops.py: track_presample): the camera-space half of the tracking loss's "
                          "sampling runs beside the Procrustes fit on a second stream instead of in the prologue of the pair kernel")
@@ -403,6 +407,36 @@ def ate_leg(device, fixture):
     if sens:
         out["self_sensitivity"]["reference_ate_rel_diff"] = sens.get("ate_rel_diff")
         out["self_sensitivity"]["reference_made_by"] = sens.get("made_by")
+    return out
+
+
+def default_resolution_leg(timeout=240):
+    """config/overfit.yaml:33-38 — the resolution an unmodified `overfit.py` runs at — measured by THIS run in two child processes of this file:
+    150 frames of 180x240, flow + tracking, stepped through the reference-layout package's ModelWrapperOverfit.training_step in a trainer's order
+    of calls, eager after install() and replayed as hipGraphs after install(graph=True) (flowmap_amd/training.py).  Informational; a failure here
+    leaves the headline line alone."""
+    import subprocess
+
+    out = {"what": "150 frames @ 180x240 (config/overfit.yaml:33-38), flow + tracking, fwd+bwd through the package's ModelWrapperOverfit.training_step in a "
+                   "trainer's order of calls; measured by child runs of this file (bench.py --height 180 --width 240 --tracking --training-step eager|graph)"}
+    for mode in ("eager", "graph"):
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--height", "180", "--width", "240", "--tracking", "--training-step", mode, "--steps", "100",
+               "--warmup", "20", "--cpu-frames", "0", "--ate", "off", "--sustained-steps", "0", "--default-resolution", "off"]
+        env = dict(os.environ, FLOWMAP_BENCH_NO_PROFILER="1")
+        try:
+            done = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=str(ROOT))
+            line = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+            if done.returncode != 0 or not line:
+                out[mode] = {"failed": (done.stderr or "")[-300:]}
+                continue
+            rec = json.loads(line[-1])
+            step = (rec.get("via_install") or {}).get("training_step") or {}
+            out[mode] = {"ms_per_step": rec["ms_per_step"], "iters_per_sec": rec["value"], "steps": rec["steps"], "loss": rec["config"]["loss"],
+                         **({k: step.get(k) for k in ("captures", "replays", "disabled")} if mode == "graph" else {})}
+        except Exception as exc:  # noqa: BLE001
+            out[mode] = {"failed": repr(exc)[:300]}
+    if all("ms_per_step" in out.get(m, {}) for m in ("eager", "graph")):
+        out["graph_over_eager"] = out["eager"]["ms_per_step"] / out["graph"]["ms_per_step"]
     return out
 
 
@@ -935,6 +969,8 @@ def main():
                 result["ate"] = ate_leg(device, fixture)
             except Exception as exc:  # noqa: BLE001  (the timing line must not be lost to the comparison leg)
                 result["ate"] = {"measured_by_this_run": False, "failed": repr(exc)[:400]}
+        if args.default_resolution == "on" or (args.default_resolution == "auto" and want_ate and wrapper is None):
+            result["default_resolution"] = default_resolution_leg()
         quoted = {}
         try:
             rec = json.loads((ROOT / "profiles" / "r04_ate_150x360x640_vs_imported_reference.json").read_text())
