@@ -17,8 +17,8 @@ optimisation — and every call checks it:
 * every loss is switched on (``global_step >= cfg.enable_after``, loss/loss.py:39-41) and the intrinsics module is past its hand-over
   (intrinsics_softmin.py:74-82: the softmin sweep records focal lengths on the host until ``regression.after_step``);
 * tensors on the GPU, the HIP library loaded, gradients enabled, module in training mode, the same batch / flows / tracks objects, the same
-  set of parameters requiring gradients, no in-pass Adam update (``FusedAdam.fuse_depth_update``: its step number is a host value), depth
-  maps below 128 MB (see the end of this note).
+  set of parameters requiring gradients, no in-pass Adam update (``FusedAdam.fuse_depth_update``: its step number is a host value), no hooks
+  on the parameters' gradients and no data-parallel process group (a replay runs no hook), depth maps below 128 MB (see the end of this note).
 
 When the phase changes (a loss switches on, the intrinsics hand over, ``eval()``), the graphs are dropped, the reference's own
 ``training_step`` runs — ``warmup`` times in the new phase, so that every cache the kernels' host side keeps is filled — and the new phase is
@@ -39,6 +39,7 @@ import warnings
 from typing import Callable, List, Optional
 
 import torch
+import torch.distributed
 from torch import Tensor
 
 from . import _lib, _ops
@@ -141,6 +142,8 @@ class GraphedTraining:
         """GPU tensors on the HIP library, gradients on, training mode: where a hipGraph can exist at all."""
         if _lib.using_test_double() or not torch.is_grad_enabled() or not wrapper.training:
             return False
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            return False  # (a data-parallel wrapper reduces gradients from hooks on the parameters' AccumulateGrad nodes: a replay runs none)
         return wrapper.batch.videos.device.type == "cuda"
 
     def signature(self, wrapper):
@@ -166,6 +169,10 @@ class GraphedTraining:
             return None
         params = list(wrapper.parameters())
         if any("_fm_fused_adam" in p.__dict__ for p in params):  # FusedAdam.fuse_depth_update: the update's step number is a host value
+            return None
+        # hooks on a parameter's gradient (a frame shard's halo exchange, a data-parallel reducer, a user's register_hook) run in autograd's
+        # backward; the captured backward is differentiated with respect to aliases of the parameters and replayed: it would run none of them
+        if any(getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) for p in params):
             return None
         flows, tracks = wrapper.flows, wrapper.tracks
         return (id(wrapper.batch), id(flows), id(tracks), flows.backward.data_ptr(), None if tracks is None else len(tracks),

@@ -210,6 +210,10 @@ def test_the_state_machine_around_the_graphs(standin):
         wrapper.losses[1].cfg.enable_after = wrapper.global_step + 1
         assert state.signature(wrapper) is None
         wrapper.losses[1].cfg.enable_after = 0
+        handle = wrapper.model.backbone.depth.register_hook(lambda g: g)  # a hook on a parameter's gradient: a replay would not run it
+        assert state.signature(wrapper) is None
+        handle.remove()
+        assert state.signature(wrapper) is not None
         from flowmap_amd import _ops
 
         previous, _ops.tap_exchange_min_bytes = _ops.tap_exchange_min_bytes, wrapper.model.backbone.depth.numel() * 4
