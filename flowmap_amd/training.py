@@ -176,7 +176,8 @@ class GraphedTraining:
             return None
         flows, tracks = wrapper.flows, wrapper.tracks
         return (id(wrapper.batch), id(flows), id(tracks), flows.backward.data_ptr(), None if tracks is None else len(tracks),
-                tuple(id(fn) for fn in losses), tuple((id(p), p.requires_grad, p.data_ptr()) for p in params), str(wrapper.batch.videos.device))
+                tuple((id(fn), float(fn.cfg.weight)) for fn in losses), tuple((id(p), p.requires_grad, p.data_ptr()) for p in params),
+                str(wrapper.batch.videos.device))
 
     def phase(self, wrapper):
         return self.signature(wrapper) if self.on_device(wrapper) else None
