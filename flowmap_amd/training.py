@@ -175,7 +175,12 @@ class GraphedTraining:
         if any(getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) for p in params):
             return None
         flows, tracks = wrapper.flows, wrapper.tracks
-        return (id(wrapper.batch), id(flows), id(tracks), flows.backward.data_ptr(), None if tracks is None else len(tracks),
+        # the constants of the optimisation as the eager path's caches key them: object, storage and version counter (an edit in place would
+        # make the eager step re-derive its packed copies and plans; a replay could not)
+        constants = tuple((t.data_ptr(), t._version) for t in (flows.forward, flows.backward, flows.forward_mask, flows.backward_mask))
+        if tracks is not None:
+            constants += tuple((t.xy.data_ptr(), t.xy._version, t.visibility.data_ptr(), t.visibility._version, int(t.start_frame)) for t in tracks)
+        return (id(wrapper.batch), id(flows), id(tracks), constants,
                 tuple((id(fn), float(fn.cfg.weight)) for fn in losses), tuple((id(p), p.requires_grad, p.data_ptr()) for p in params),
                 str(wrapper.batch.videos.device))
 
