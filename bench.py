@@ -673,7 +673,7 @@ def main():
             return loss
 
         def trainer_step():  # what a trainer's loop does around training_step (Lightning's automatic optimisation: closure = step -> zero_grad -> backward)
-            loss = wrapper.training_step(None)
+            loss = wrapper.training_step(None) / 1  # (Lightning: closure_loss = training_step_output / accumulate_grad_batches)
             (optimizer if optimizer is not None else model).zero_grad(set_to_none=True)
             loss.backward()
             if optimizer is not None:

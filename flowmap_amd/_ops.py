@@ -823,6 +823,10 @@ class RootLoss(Tensor):
         return as_root_loss(Tensor.__rmul__(self, other))
 
     def __truediv__(self, other):
+        # (a trainer normalises the loss by its accumulation factor — Lightning: `closure_loss / accumulate_grad_batches`, 1 by default — and calls
+        # backward() on the quotient: dividing by the number 1 is the loss itself, and the fused nodes keep their host-known seed)
+        if type(other) in (int, float) and other == 1:
+            return self
         return as_root_loss(Tensor.__truediv__(self, other))
 
     def __neg__(self):

@@ -1161,6 +1161,13 @@ def case_root_loss(dev):
         same(grads_of(lambda loss: loss.backward()), plain, "seeded backward")
         assert torch_ops().unit_seed_uses() == uses + 1
         same(grads_of(lambda loss: (3.0 * loss).backward()), plain3, "a weighted loss: an ordinary upstream gradient")
+        # a trainer's normalisation by its accumulation factor (Lightning: closure_loss / accumulate_grad_batches): the number 1 is the loss itself
+        before = torch_ops().unit_seed_uses()
+        same(grads_of(lambda loss: (loss / 1).backward()), plain, "loss / 1")
+        assert torch_ops().unit_seed_uses() == before + 1
+        probe = loss_of(model(batch, flows, 0))
+        assert (probe / 1) is probe and (probe / 1.0) is probe and (probe / 2) is not probe and (probe / torch.ones((), device=probe.device)) is not probe
+        del probe
         same(grads_of(lambda loss: loss.backward(gradient=torch.full_like(loss, 3.0))), plain3, "explicit gradient")
         assert torch_ops().unit_seed_uses() == uses + 1
 

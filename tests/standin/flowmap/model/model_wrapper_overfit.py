@@ -51,6 +51,8 @@ class ModelWrapperOverfit(nn.Module):
         loss = None
         for _ in range(steps):
             loss = self.training_step(None)
+            loss = loss / 1  # (a trainer divides the step's loss by its gradient-accumulation factor — 1 here — and differentiates the quotient)
+            self.kept = loss.detach().clone()  # (and keeps a detached copy for its progress bar)
             if optimizer is not None:
                 optimizer.zero_grad(set_to_none=True)
             else:
