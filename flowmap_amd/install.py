@@ -202,7 +202,11 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
     if graph:
         try:
             ref_wrapper = importlib.import_module("flowmap.model.model_wrapper_overfit")
-        except Exception:  # lightning / hydra are not installed here; nothing to rebind
+        except Exception as exc:  # lightning / hydra are not installed here; nothing to rebind — said aloud: the caller asked for it
+            import warnings
+
+            warnings.warn(f"flowmap_amd.install(graph=True): flowmap.model.model_wrapper_overfit is not importable ({type(exc).__name__}: {exc}); "
+                          "training_step stays as it is")
             ref_wrapper = None
         if ref_wrapper is not None:
             from .training import make_training_step
