@@ -638,3 +638,103 @@ def test_host_softmin_and_functions_after_install(patched_reference_real_library
     # a rebound function with host tensors: the reference's own
     xy, _ = ref_projection.sample_image_grid((4, 6), "cpu")
     assert xy.shape == (4, 6, 2) and ref_projection.unproject._fm_reference is not ref_projection.unproject
+
+
+def _real_overfit_wrapper(name="step_scene_flow_tracking", enable_tracking_after=0, with_truth=False):
+    """The reference's OWN ModelWrapperOverfit (model_wrapper_overfit.py:25-43) around its own Model and get_losses — under oracle/refstubs'
+    import-only LightningModule (a torch module with `log` and `global_step`: this image has no lightning)."""
+    from conftest import load_golden, t
+
+    import flowmap.loss as ref_loss
+    from flowmap.dataset.types import Batch
+    from flowmap.flow.flow_predictor import Flows
+    from flowmap.loss.loss_flow import LossFlowCfg
+    from flowmap.loss.loss_tracking import LossTrackingCfg
+    from flowmap.loss.mapping.mapping_huber import MappingHuberCfg
+    from flowmap.model.backbone.backbone_explicit_depth import BackboneExplicitDepthCfg
+    from flowmap.model.extrinsics.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+    from flowmap.model.intrinsics.intrinsics_regressed import IntrinsicsRegressedCfg
+    from flowmap.model.model import Model, ModelCfg
+    from flowmap.model.model_wrapper_overfit import ModelWrapperOverfit, ModelWrapperOverfitCfg
+    from flowmap.tracking.track_predictor import Tracks
+
+    g = load_golden(name)
+    depth, wlogit = t(g["depth"]), t(g["wlogit"])
+    f, h, w = depth.shape
+    npts = int(g["num_points"])
+    model = Model(ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsRegressedCfg("regressed", float(g["focal"])),
+                           ExtrinsicsProcrustesCfg("procrustes", None if npts < 0 else npts, False), True), num_frames=f, image_shape=(h, w))
+    model.backbone.depth.data = depth.clone()
+    model.backbone.weights.data = wlogit.clone()
+    truth = None
+    if with_truth:  # a dataset with ground-truth intrinsics: training_step also logs the focal-length errors (model_wrapper_overfit.py:65-73)
+        truth = torch.eye(3)[None, None].repeat(1, f, 1, 1)
+        truth[..., 0, 0], truth[..., 1, 1], truth[..., 0, 2], truth[..., 1, 2] = 0.9, 1.2, 0.5, 0.5
+    batch = Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["s"], ["d"], None, truth)
+    flows = Flows(t(g["fwd"]), t(g["bwd"]), t(g["fwd_mask"]), t(g["bwd_mask"]))
+    tracks = [Tracks(t(g[f"trk{i}_xy"]), t(g[f"trk{i}_vis"]), int(g[f"trk{i}_start"])) for i in range(int(g["n_segments"]))]
+    losses = ref_loss.get_losses([LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)),
+                                  LossTrackingCfg(enable_tracking_after, 100.0, "tracking", MappingHuberCfg("huber", 0.01))])
+    wrapper = ModelWrapperOverfit(ModelWrapperOverfitCfg(1e-3, 32), model, batch, flows, tracks, losses, [])
+    wrapper.train()
+    return g, wrapper
+
+
+def test_install_graph_on_the_references_own_overfit_wrapper(patched_reference):
+    """install(graph=True) on the REAL flowmap.model.model_wrapper_overfit: training_step is rebound around the reference's own method (whose source
+    file is the reference's), configure_optimizers builds FusedAdam, and a trainer's order of calls — training_step, loss / 1, zero_grad, backward,
+    step — runs the reference's method on this package's kernels (host double: nothing is captured here), logging under the reference's names."""
+    import flowmap.model.model_wrapper_overfit as ref_wrapper
+    from conftest import assert_close
+
+    import flowmap_amd
+
+    original = ref_wrapper.ModelWrapperOverfit.training_step
+    assert str(REF) in original.__code__.co_filename
+    flowmap_amd.install(graph=True)
+    rebound = ref_wrapper.ModelWrapperOverfit.training_step
+    assert rebound is not original and rebound.__wrapped__ is original
+    g, wrapper = _real_overfit_wrapper(enable_tracking_after=1)
+    optimizer = wrapper.configure_optimizers()
+    assert type(optimizer).__module__ == "flowmap_amd.optim"
+    history = []
+    for _ in range(4):
+        loss = wrapper.training_step(None) / 1
+        history.append(float(loss.detach()))
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        optimizer.step()
+        wrapper.global_step += 1
+    state = wrapper.__dict__["_fm_graphed_training"]
+    assert state.captures == 0 and state.disabled is None  # (the host double: no hipGraph can exist; the reference's method ran every time)
+    assert set(wrapper.logged) == {"train/loss/flow", "train/loss/tracking"}
+    assert history[2] < history[1]  # (step 0 has no tracking term yet: enable_after = 1)
+    assert abs(float(wrapper.logged["train/loss/flow"]) + float(wrapper.logged["train/loss/tracking"]) - history[-1]) <= 1e-6 * abs(history[-1])
+    flowmap_amd.uninstall()
+    assert ref_wrapper.ModelWrapperOverfit.training_step is original
+    flowmap_amd.install()  # (the fixture's teardown uninstalls)
+    _, fresh = _real_overfit_wrapper()
+    assert_close(fresh.training_step(None), g["total"], 1e-4, what="the reference's training_step on our kernels vs the unpatched reference's total")
+
+
+def test_the_captured_body_is_the_references_training_step(patched_reference):
+    """What install(graph=True) captures is a restatement of training_step's body (flowmap_amd/training.py: GraphedTraining.forward + .log):
+    against the reference's OWN method on the same wrapper — same total, same logged names and values, with and without ground-truth
+    intrinsics in the batch (the focal-length errors, model_wrapper_overfit.py:65-73)."""
+    import flowmap.model.model_wrapper_overfit as ref_wrapper
+
+    from flowmap_amd import training
+
+    real = ref_wrapper.ModelWrapperOverfit.training_step
+    for with_truth in (False, True):
+        _, wrapper = _real_overfit_wrapper(with_truth=with_truth)
+        theirs = real(wrapper, None)
+        logged_by_the_reference = {k: float(v) for k, v in wrapper.logged.items()}
+        wrapper.logged.clear()
+        state = training.GraphedTraining(real)
+        state.total, state.values, state.errors = state.forward(wrapper)
+        state.log(wrapper)
+        assert float(state.total.detach()) == float(theirs.detach())
+        assert {k: float(v) for k, v in wrapper.logged.items()} == logged_by_the_reference
+        assert set(logged_by_the_reference) == {"train/loss/flow", "train/loss/tracking"} | ({"train/intrinsics/fx_error", "train/intrinsics/fy_error"} if with_truth else set())
+        assert state.signature(wrapper) is not None  # the reference's wrapper around rebound parts has a phase: on the GPU it would be captured
