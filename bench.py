@@ -410,7 +410,7 @@ def ate_leg(device, fixture):
     return out
 
 
-def default_resolution_leg(timeout=240):
+def default_resolution_leg(timeout=90):  # (a child takes ~10 s; a stuck one must not cost the headline line its place in the driver's time limit)
     """config/overfit.yaml:33-38 — the resolution an unmodified `overfit.py` runs at — measured by THIS run in two child processes of this file:
     150 frames of 180x240, flow + tracking, stepped through the reference-layout package's ModelWrapperOverfit.training_step in a trainer's order
     of calls, eager after install() and replayed as hipGraphs after install(graph=True) (flowmap_amd/training.py).  Informational; a failure here
