@@ -362,3 +362,18 @@ def test_the_replay_starts_after_the_softmin_hand_over(standin):
     assert_close(torch.tensor(history), torch.tensor(eager_history), 1e-5, what="loss history")
     for ours, theirs in zip(params, eager_params):
         assert_close(ours, theirs, 1e-5, what="parameters")
+
+
+@pytest.mark.gpu
+def test_the_losses_as_branches_of_the_captured_graph(standin, monkeypatch):
+    """FLOWMAP_AMD_GRAPH_STREAMS=1 (off by default: 2 % at 180x240): the tracking loss captured on a stream of its own beside the flow loss, its
+    backward on that stream — the same trajectory as the eager installed run."""
+    from conftest import assert_close
+
+    eager_history, _, eager_params, _ = _run_trainer(False, "cuda:0", steps_a=7, steps_b=0)
+    monkeypatch.setenv("FLOWMAP_AMD_GRAPH_STREAMS", "1")
+    history, _, params, state = _run_trainer(True, "cuda:0", steps_a=7, steps_b=0)
+    assert state.concurrent_losses and state.disabled is None and state.captures == 1 and state.replays == 3, state.disabled
+    assert_close(torch.tensor(history), torch.tensor(eager_history), 1e-5, what="loss history")
+    for ours, theirs in zip(params, eager_params):
+        assert_close(ours, theirs, 1e-5, what="parameters")
