@@ -781,6 +781,10 @@ use_tap_exchange = True
 # loss's is-the-seed-one launch again (two of the eight launches of a flow-only step)
 use_unit_seed = True
 _unit_seeds: dict = {}
+# RootLoss.backward() runs autograd's nodes on the calling thread (no hand-over to the device's worker thread); FLOWMAP_AMD_BACKWARD_THREAD=engine: autograd's default
+import os as _os  # noqa: E402
+
+backward_on_calling_thread = _os.environ.get("FLOWMAP_AMD_BACKWARD_THREAD", "caller").lower() != "engine"
 
 
 class RootLoss(Tensor):
@@ -802,6 +806,12 @@ class RootLoss(Tensor):
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         if gradient is None and not create_graph and use_unit_seed and self.dim() == 0 and self.dtype == torch.float32:
             gradient = unit_seed(self.device)
+        if backward_on_calling_thread and not create_graph:
+            # autograd hands the nodes of GPU tensors to a worker thread per device and waits for it: two thread wake-ups around a backward
+            # pass whose nodes only ENQUEUE a handful of kernels — where the host is the bottleneck (the reference's default resolution)
+            # they are a measurable part of the step.  The nodes of a fused loss run just as well on the calling thread.
+            with torch.autograd.set_multithreading_enabled(False):
+                return torch.autograd.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
         return torch.autograd.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
 
     def __add__(self, other):
