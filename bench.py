@@ -485,10 +485,48 @@ def _reserve_stdout():
     return real
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` — one process per GPU over RCCL, rank 0 prints the ONE JSON
+    line — like the reference, which goes multi-GPU without a launcher (overfit.py:94-108: Lightning spawns when device_count() > 1).  The
+    process image is replaced (exec): exit code, signals and stdout are the launcher's.  FLOWMAP_BENCH_LAUNCHER names the script the ranks
+    run instead of this file (tests/test_bench_dryrun.py: the launcher that injects the host test double for the gloo dry run)."""
+    on_gpu = os.environ.get("FLOWMAP_BENCH_DEVICE", "cuda") == "cuda"
+    if on_gpu:
+        visible = torch.cuda.device_count()
+        if visible < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} GPU(s) visible to this process; refusing to report an {args.gpus}-GPU number from fewer ranks")
+    script = os.environ.get("FLOWMAP_BENCH_LAUNCHER") or str(Path(__file__).resolve())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script, *sys.argv[1:]]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (the host driver supports dmabuf IPC only: RCCL across processes needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")  # (torch.distributed.run would set 1 and warn; the ranks' host work is launch glue)
+    print(f"[bench] --gpus {args.gpus}: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.share:
+            raise SystemExit("--share K runs one rank's share on ONE process: --gpus 1")
+        launch_ranks(args)  # (does not return)
     result_stream = _reserve_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # the line's n_gpus is the process group's size; a launcher that started a different number of ranks than --gpus asks for would put a
+        # number for the wrong N into a scaling record
+        raise SystemExit(f"bench.py --gpus {args.gpus} under WORLD_SIZE={world}: the launcher's rank count and --gpus disagree")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # tests/test_bench_dryrun.py runs this file's multi-rank glue over gloo with CPU tensors and the host test double
@@ -509,6 +547,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=5))
         else:
             dist.init_process_group("gloo")
+        if not args.share and dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: the process group has {dist.get_world_size()} rank(s)")
     else:
         dist = None
     device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
@@ -911,6 +951,11 @@ def main():
             "unit": "iters/sec (one iter = fwd+bwd over the whole video"
                     + (", sharded by frame pairs over the GPUs)" if strong else "; weak scaling: one video per GPU, aggregate over GPUs)" if world > 1 else ")"),
             "n_gpus": world,
+            # the ranks that actually met in the process group (RCCL on the GPU; gloo in the CPU dry run), and the frames each of them holds
+            "rccl_ranks": dist.get_world_size() if (dist is not None and not args.share) else 1,
+            "collective_backend": (dist.get_backend() if dist is not None else None),
+            "frame_split": ([list(shard_frames(pr)) for pr in shard_pairs(total_pairs, cut_world)] if strong
+                            else [[0, f_video - 1]] * world),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,

@@ -27,6 +27,8 @@ counters = {"host_calls": 0}
 def _first_tensor(obj, depth: int = 0) -> Optional[torch.Tensor]:
     if torch.is_tensor(obj):
         return obj
+    if getattr(type(obj), "_fm_lazy", False):  # LazyWeights: any other attribute read would evaluate the (f-1, h, w) sigmoid it stands for
+        return obj.logits
     depths = getattr(obj, "depths", None)  # LazySurfaces, BackboneOutput, ModelOutput
     if torch.is_tensor(depths):
         return depths
@@ -59,6 +61,8 @@ def on_host(*objs) -> bool:
     for obj in objs:
         if isinstance(obj, _Tensor):
             return obj.device.type == "cpu"
+        if getattr(type(obj), "_fm_lazy", False):  # LazyWeights (see _first_tensor)
+            return obj.logits.device.type == "cpu"
         t = getattr(obj, "depths", None)  # LazySurfaces, BackboneOutput, ModelOutput
         if not isinstance(t, _Tensor):
             t = getattr(obj, "videos", None)  # Batch

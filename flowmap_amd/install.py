@@ -145,7 +145,7 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
             ref_output = importlib.import_module("flowmap.model.backbone.backbone").BackboneOutput
         except Exception:
             ref_output = ref_backbone.BackboneOutput
-        our_backbone.set_output_type(_plain_constructor_subclass(ref_output))
+        our_backbone.set_output_type(_plain_constructor_subclass(ref_output), lazy_slices=fused_softmin)
 
     # The reference's factories are annotated with its abstract bases (`get_backbone(...) -> Backbone`, backbone/__init__.py:13-18; likewise
     # get_extrinsics / get_intrinsics / get_losses / get_mapping), which beartype checks under the import hook of overfit.py:15-19: the classes

@@ -26,11 +26,15 @@ from .projection import LazyWeights, lazy_surfaces_enabled
 # constructor, flowmap_amd/install.py: under jaxtyping's import hook the reference's dataclass checks its fields and would reject a
 # LazyWeights, while every `backbone_output: BackboneOutput` annotation of the reference accepts the subclass).
 _output_type = BackboneOutput
+# Do frame slices of the weights stay lazy (LazyWeights.lazy_slices)?  Off under install(fused_softmin=False): the reference's own
+# IntrinsicsSoftmin then reads `backbone_output.weights[:, :1]` with einops (intrinsics_softmin.py:100,120) and must get a tensor.
+_lazy_slices = True
 
 
-def set_output_type(cls=None) -> None:
-    global _output_type
+def set_output_type(cls=None, lazy_slices: bool = True) -> None:
+    global _output_type, _lazy_slices
     _output_type = BackboneOutput if cls is None else cls
+    _lazy_slices = bool(lazy_slices)
 
 
 @dataclass
@@ -61,5 +65,5 @@ class BackboneExplicitDepth(nn.Module):
             return ref_cls.forward(self, batch, flows)
         if lazy_surfaces_enabled():
             # same values, not stored: align_surfaces applies the sigmoid at the points it gathers
-            return _output_type(self.depth[None], LazyWeights(self.weights[None], self.cfg.weight_sensitivity))
+            return _output_type(self.depth[None], LazyWeights(self.weights[None], self.cfg.weight_sensitivity, _lazy_slices))
         return _output_type(self.depth[None], (self.cfg.weight_sensitivity * self.weights).sigmoid()[None])

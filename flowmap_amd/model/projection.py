@@ -171,9 +171,14 @@ class LazyWeights:
     ``align_surfaces`` applies the sigmoid inside its gather and writes the logit gradient
     directly.  Any other use materialises the real (b, f-1, h, w) tensor."""
 
-    def __init__(self, logits: Tensor, sensitivity: float):
+    _fm_lazy = True  # (flowmap_amd/_reference.py asks a lazy value for its device without touching its attributes)
+
+    def __init__(self, logits: Tensor, sensitivity: float, lazy_slices: bool = True):
         self.logits = logits  # (b, f-1, h, w)
         self.sensitivity = float(sensitivity)
+        # frame slices stay lazy only for consumers that understand a LazyWeights (this package's IntrinsicsSoftmin / align_surfaces); the
+        # reference's own IntrinsicsSoftmin hands `weights[:, :1]` to einops (intrinsics_softmin.py:120), which needs a real tensor
+        self.lazy_slices = bool(lazy_slices)
         self._dense: Optional[Tensor] = None
 
     @property
@@ -207,7 +212,10 @@ class LazyWeights:
         # frame slices keep laziness: weights[:, :1]  (intrinsics_softmin.py:100,120 read the first pair only)
         if (isinstance(item, tuple) and len(item) == 2 and isinstance(item[0], slice) and item[0] == slice(None)
                 and isinstance(item[1], slice)):
-            return LazyWeights(self.logits[item], self.sensitivity)
+            if self.lazy_slices:
+                return LazyWeights(self.logits[item], self.sensitivity)
+            if self._dense is None:  # the sigmoid of the frames asked for, not of the whole (b, f-1, h, w) tensor
+                return (self.sensitivity * self.logits[item]).sigmoid()
         return self.materialize()[item]
 
     def __getattr__(self, name):

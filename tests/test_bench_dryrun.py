@@ -120,3 +120,41 @@ def test_training_step_mode_drives_the_packages_wrapper(mode):
         assert info["captures"] == 0 and info["replays"] == 0 and info["disabled"] is None
     assert abs(line["config"]["loss"] - plain["config"]["loss"]) <= 1e-6 * abs(plain["config"]["loss"])
     assert plain["via_install"]["training_step"] is None
+
+
+def _literal(argv, expect_ok=True, extra_env=None):
+    """`python bench.py <argv>` — the driver's command shape, no launcher around it.  The dry run's two environment variables say which device the
+    ranks compute on (cpu: gloo) and which script they run (the launcher that injects the host test double before bench.py's main())."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="2", FLOWMAP_BENCH_DEVICE="cpu", FLOWMAP_BENCH_LAUNCHER=str(ROOT / "tests" / "tools" / "bench_dryrun.py"), **(extra_env or {}))
+    done = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    if not expect_ok:
+        return done
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, done.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+SMALL = ["--frames", "9", "--height", "24", "--width", "32", "--points", "60", "--cpu-frames", "0"]
+
+
+def test_the_literal_command_launches_n_ranks():
+    """`python bench.py --gpus 2 --steps 2 --warmup 1` (no torch.distributed.run in front) is a TWO-rank run: bench.py becomes
+    the launcher (overfit.py:94-108 goes multi-GPU without one too), the ranks meet in a process group of that size, the line says so and
+    names the frames each rank holds; the loss is the whole video's."""
+    single = _run(1, ["--config", "c1"])
+    line = _literal(["--gpus", "2", "--steps", "2", "--warmup", "1", *SMALL])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo" and line["steps"] == 2 and line["warmup"] == 1
+    assert line["frame_split"] == [[0, 4], [4, 8]] and line["config"]["frames_per_gpu"] == 5 and line["scaling"] == "strong"
+    assert abs(line["config"]["loss"] - single["config"]["loss"]) <= 2e-5 * abs(single["config"]["loss"])
+    assert single["rccl_ranks"] == 1 and single["frame_split"] == [[0, 8]]
+    four = _literal(["--gpus", "4", "--steps", "2", "--warmup", "1", *SMALL])
+    assert four["n_gpus"] == 4 and four["rccl_ranks"] == 4 and four["frame_split"] == [[0, 2], [2, 4], [4, 6], [6, 8]]
+    assert abs(four["config"]["loss"] - single["config"]["loss"]) <= 2e-5 * abs(single["config"]["loss"])
+
+
+def test_a_rank_count_that_disagrees_with_gpus_is_refused():
+    """A launcher that started another number of ranks than --gpus names must not produce a line (it would enter a scaling record under the wrong N)."""
+    done = _literal(["--gpus", "2", "--steps", "1", "--warmup", "0", *SMALL], expect_ok=False, extra_env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert done.returncode != 0 and "disagree" in done.stderr and not [ln for ln in done.stdout.splitlines() if ln.startswith("{")]

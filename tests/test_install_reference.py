@@ -225,6 +225,76 @@ def test_reference_softmin_intrinsics_under_install():
             sys.path.remove(p)
 
 
+def test_reference_softmin_model_under_install_without_the_fused_sweep():
+    """install(fused_softmin=False) keeps the REFERENCE's IntrinsicsSoftmin while the backbone is the rebound lazy one: the module reads
+    `backbone_output.weights[:, :1]` with einops (intrinsics_softmin.py:100,120), so frame slices of the lazy weights must come back as tensors
+    there.  The reference's own Model (explicit depth -> softmin -> Procrustes) + flow loss, unpatched vs installed that way: same pixels drawn
+    (same seed, same torch.randperm), same loss and gradients."""
+    sys.dont_write_bytecode = True
+    added = [str(ROOT / "oracle" / "refstubs"), str(REF)]
+    sys.path[:0] = added
+    try:
+        from conftest import assert_close
+        from flowmap.dataset.types import Batch
+        from flowmap.flow.flow_predictor import Flows
+        from flowmap.loss import get_losses
+        from flowmap.loss.loss_flow import LossFlowCfg
+        from flowmap.loss.mapping.mapping_huber import MappingHuberCfg
+        from flowmap.model.backbone.backbone_explicit_depth import BackboneExplicitDepthCfg
+        from flowmap.model.extrinsics.extrinsics_procrustes import ExtrinsicsProcrustesCfg
+        from flowmap.model.intrinsics.intrinsics_softmin import IntrinsicsSoftminCfg, RegressionCfg
+        from flowmap.model.model import Model, ModelCfg
+
+        import flowmap_amd
+        from flowmap_amd import _lib
+        from flowmap_amd.model.projection import LazyWeights
+        from helpers import build_host_sim
+        from oracle import flowmap_oracle as orc
+
+        f, h, w = 4, 16, 20
+        scene = orc.synth_scene(f, h, w, seed=3)
+        depth, fl = scene["depth_init"], scene["flows"]
+        wlogit = 0.01 * torch.randn((f - 1, h, w), generator=torch.Generator().manual_seed(3))
+        flows = Flows(fl.forward, fl.backward, fl.forward_mask, fl.backward_mask)
+        batch = Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["s"], ["d"])
+        cfg = ModelCfg(BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0), IntrinsicsSoftminCfg("softmin", 64, 0.5, 2.0, 12, RegressionCfg(5, 2)),
+                       ExtrinsicsProcrustesCfg("procrustes", 50, False), True)
+
+        def run():
+            model = Model(cfg, num_frames=f, image_shape=(h, w))
+            model.backbone.depth.data = depth.clone()
+            model.backbone.weights.data = wlogit.clone()
+            (loss_fn,) = get_losses([LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01))])
+            torch.manual_seed(0)  # IntrinsicsSoftmin draws torch.randperm
+            out = model(batch, flows, 0)
+            loss = loss_fn(batch, flows, None, out, 0)
+            loss.backward()
+            return type(model.backbone), type(model.intrinsics), out, loss.detach(), model.backbone.depth.grad, model.backbone.weights.grad
+
+        _, ref_intr_cls, out_ref, loss_ref, gd_ref, gw_ref = run()
+        _lib.set_library_for_testing(build_host_sim())
+        flowmap_amd.install(fused_softmin=False)
+        try:
+            backbone_cls, intr_cls, out, loss, gd, gw = run()
+            # the lazy backbone is in, the reference's sweep stayed, and a frame slice of its weights is a tensor (all of them: still lazy)
+            assert backbone_cls.__module__.startswith("flowmap_amd") and intr_cls is ref_intr_cls
+            sliced = LazyWeights(wlogit[None], 100.0, lazy_slices=False)[:, :1]
+            assert torch.is_tensor(sliced) and sliced.shape == (1, 1, h, w)
+            assert_close(sliced, (100 * wlogit[None, :1]).sigmoid(), 1e-7, what="the slice's values")
+        finally:
+            flowmap_amd.uninstall()
+            _lib.set_library_for_testing(None)
+        assert isinstance(LazyWeights(wlogit[None], 100.0)[:, :1], LazyWeights)  # the default (this package's own sweep reads the logits)
+        assert_close(out.intrinsics, out_ref.intrinsics, 1e-5, what="softmin intrinsics")
+        assert_close(out.extrinsics, out_ref.extrinsics, 1e-4, what="extrinsics")
+        assert_close(loss, loss_ref, 1e-4, what="flow loss")
+        assert_close(gd, gd_ref, 2e-4, what="g_depth")
+        assert_close(gw, gw_ref, 2e-4, abs_=1e-9, what="g_weight_logits")
+    finally:
+        for p in added:
+            sys.path.remove(p)
+
+
 def test_reference_flow_predictor_under_install(patched_reference):
     """A predictor subclassing the REFERENCE's FlowPredictor inherits the fused
     post-processing after install(), returns the reference's Flows type, and reproduces what
