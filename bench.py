@@ -32,7 +32,7 @@ bytes spend on xGMI.  `--graph` replays the step (collectives included) as one h
 K = 1, 2, 4, 8 eager and graphed -> profiles/r03_strong_scaling_proxy.jsonl; DESIGN.md §5 turns it into a projection.
 
 The default step (`--model installed`) is built by a reference-LAYOUT `flowmap` package after flowmap_amd.install(): the real package when it
-is importable, else tests/standin/flowmap (the GPU box has no reference).  The stand-in is the HOST APPLICATION's stand-in, not the product: after
+is importable, else bench_support/standin/flowmap (the GPU box has no reference).  The stand-in is the HOST APPLICATION's stand-in, not the product: after
 install() every arithmetic name it resolves is this library's; its own arithmetic (the oracle's, for the CPU tests) is imported lazily and refuses
 GPU tensors, and the line reports `via_install.oracle_imported_by_the_timed_path` (false) and the kernels of a step (all `fm::`).
 
@@ -54,9 +54,9 @@ from pathlib import Path
 
 import torch
 
+sys.dont_write_bytecode = True  # (`import flowmap` may find the real, read-only reference on the caller's path: never write bytecode next to it)
 ROOT = Path(__file__).resolve().parent
-sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))  # (the test tree is NOT on the path of the timed step: only the checker legs below — `ate`, `cpu_baseline` — add it / import oracle/)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP32_PEAK_GFLOPS = 157300.0  # same guide: fp32 vector peak with packed FMA
@@ -139,7 +139,7 @@ def parse():
     ap.add_argument("--ate-fixture", default=None, help="the reference leg's record (default: the 720p one under tests/golden/, else the 360p one)")
     ap.add_argument("--model", choices=["installed", "direct"], default="installed",
                     help="how the step's modules are built.  `installed` (default): flowmap_amd.install() patches a reference-LAYOUT `flowmap` package "
-                         "(the real dcharatan/flowmap when it is importable, else tests/standin — the GPU box has no /root/reference) and the step is that "
+                         "(the real dcharatan/flowmap when it is importable, else bench_support/standin — the GPU box has no /root/reference) and the step is that "
                          "package's own Model(get_backbone, get_intrinsics, get_extrinsics) + get_losses, i.e. what an unmodified overfit.py runs "
                          "(model_wrapper_overfit.py:51-62).  `direct`: flowmap_amd.model.model.Model and the loss classes constructed by hand")
     ap.add_argument("--training-step", choices=["off", "eager", "graph"], default="off",
@@ -328,15 +328,15 @@ def torch_baseline(frames, h, w, points, steps, timeout=600):
 
 def reference_layout_package():
     """The `flowmap` package flowmap_amd.install() patches: whatever `import flowmap` finds (the real dcharatan/flowmap on the caller's path),
-    else the stand-in of the reference's module LAYOUT under tests/standin (registries, factories, import-site bindings; the GPU box has no
+    else the stand-in of the reference's module LAYOUT under bench_support/standin (registries, factories, import-site bindings; the GPU box has no
     reference).  Returns (kind, where)."""
     try:
         import flowmap
     except ImportError:
-        sys.path.insert(0, str(ROOT / "tests" / "standin"))
+        sys.path.insert(0, str(ROOT / "bench_support" / "standin"))
         import flowmap
     where = str(Path(flowmap.__file__).resolve().parent)
-    return ("stand-in of the reference's layout (tests/standin/flowmap)" if where.startswith(str(ROOT)) else "dcharatan/flowmap"), where
+    return ("stand-in of the reference's layout (bench_support/standin/flowmap)" if where.startswith(str(ROOT)) else "dcharatan/flowmap"), where
 
 
 def installed_modules(model_cfg_parts, num_frames, image_shape, with_tracking):
@@ -374,7 +374,7 @@ def ate_leg(device, fixture):
     `cpu_baseline`: the scene generator and the ATE restatement come from tests/tools + oracle/ and nothing here is timed as the product."""
     import types
 
-    sys.path.insert(0, str(ROOT / "tests" / "tools"))
+    sys.path[:0] = [str(ROOT / "tests" / "tools"), str(ROOT / "tests")]
     import ate_full_chain as chain
 
     ref = json.loads(Path(fixture).read_text())
@@ -1093,8 +1093,21 @@ def main():
                                                       focal0, cpu_frames, h, w, args.points, args.cpu_iters, args.cpu_threads)
             whole = cpu_frames == f_video
             scaled = dt if whole else dt * (f_video - 1) / (cpu_frames - 1)  # per-pair cost is constant (optimistic for the CPU)
+            # What the port costs next to the code it stands for: oracle/make_cpu_calibration.py timed the IMPORTED reference (its own Model +
+            # LossFlow) and the port interleaved on the same inputs in the build container (the GPU box has no reference to time)
+            calibration = None
+            try:
+                cal = json.loads((ROOT / "tests" / "golden" / "cpu_calibration.json").read_text())
+                calibration = {"port_over_reference": cal["port_over_reference"], "measured_at": cal["port_over_reference_measured_at"],
+                               "threads": cal["threads"], "host": cal["host"], "record": "tests/golden/cpu_calibration.json (" + cal["made_by"] + ")",
+                               "by_size": {"x".join(str(r[k]) for k in ("frames", "height", "width")): round(r["port_over_reference"], 3) for r in cal["sizes"]}}
+            except Exception:  # noqa: BLE001
+                pass
             result["cpu_baseline"] = {
                 "value": 1.0 / scaled,
+                # the same measurement restated for the reference's own code: seconds x (reference / port) from the calibration record
+                "reference_equivalent_value": (calibration["port_over_reference"] / scaled) if calibration else None,
+                "port_over_reference": calibration,
                 "unit": "iters/sec",
                 "cores": cores,
                 "kind": "port",

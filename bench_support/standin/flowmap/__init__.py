@@ -1,4 +1,4 @@
-"""Stand-in for the reference package's module layout (tests/standin/README.md).  Test infrastructure.
+"""Stand-in for the reference package's module layout (bench_support/standin/README.md).  Test infrastructure.
 
 Its own arithmetic — what its functions do while nothing is installed — is the oracle's (oracle/flowmap_oracle.py), reached through the proxy
 below: the oracle is imported only when that arithmetic first RUNS, and it refuses device tensors.  So a process that installs flowmap_amd
@@ -19,7 +19,7 @@ class _HostOnlyOracle:
         def host_only(*args, **kwargs):
             for value in (*args, *kwargs.values()):
                 if torch.is_tensor(value) and value.is_cuda:
-                    raise RuntimeError(f"tests/standin: the stand-in's own arithmetic ({name}: the oracle's, host-only test infrastructure) was reached "
+                    raise RuntimeError(f"bench_support/standin: the stand-in's own arithmetic ({name}: the oracle's, host-only test infrastructure) was reached "
                                        "with a GPU tensor — flowmap_amd.install() did not rebind the caller")
             return attr(*args, **kwargs)
 

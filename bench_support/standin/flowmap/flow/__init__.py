@@ -1,0 +1,1 @@
+"""(stand-in package: bench_support/standin/README.md)"""

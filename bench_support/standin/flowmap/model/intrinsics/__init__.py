@@ -49,7 +49,7 @@ class IntrinsicsSoftmin(nn.Module):
         self.cfg = cfg
 
     def forward(self, batch, flows, backbone_output, global_step):
-        raise NotImplementedError("tests/standin: no host softmin sweep")
+        raise NotImplementedError("bench_support/standin: no host softmin sweep")
 
 
 INTRINSICS = {"regressed": IntrinsicsRegressed, "softmin": IntrinsicsSoftmin}

@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--window", type=int, default=20)
     ap.add_argument("--trace-every", type=int, default=10)
     ap.add_argument("--no-softmin", action="store_true")
+    ap.add_argument("--tracking-after", type=int, default=0,
+                    help="LossTrackingCfg.enable_after (config/loss/tracking.yaml:4-6: 50): the tracking loss is a constant 0 before that step (loss.py:39-46)")
     ap.add_argument("--threads", type=int, default=6)
     ap.add_argument("--perturb", type=float, default=0.0,
                     help="relative Gaussian perturbation of the initial depths (1e-7 ~ one fp32 ulp): the reference's OWN sensitivity under this schedule — "
@@ -103,7 +105,7 @@ def main():
     batch = Batch(torch.zeros((1, f, 3, h, w)), torch.arange(f)[None], ["scene"], ["synthetic"])
     flows = Flows(sc["flows"].forward, sc["flows"].backward, sc["flows"].forward_mask, sc["flows"].backward_mask)
     tracks = [Tracks(t.xy, t.visibility, t.start_frame) for t in otracks]
-    losses = get_losses([LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)), LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01))])
+    losses = get_losses([LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)), LossTrackingCfg(args.tracking_after, 100.0, "tracking", MappingHuberCfg("huber", 0.01))])
     opt = torch.optim.Adam(model.parameters(), lr=args.lr)
 
     real_randperm = torch.randperm
@@ -138,7 +140,7 @@ def main():
     ate, _, _ = compute_ate(gt_pos, pos)
     regressed = model.intrinsics if args.no_softmin else model.intrinsics.intrinsics_regressed
     config = {k: getattr(args, k) for k in ("frames", "height", "width", "steps", "lr", "points", "noise", "seed", "track_grid", "softmin_points",
-                                            "num_candidates", "after_step", "window", "trace_every", "no_softmin")}
+                                            "num_candidates", "after_step", "window", "trace_every", "no_softmin", "tracking_after")}
     result = {
         "made_by": "PYTHONDONTWRITEBYTECODE=1 python oracle/make_ate_reference.py " + " ".join(f"--{k.replace('_', '-')} {v}" for k, v in config.items() if k != "no_softmin")
                    + (" --no-softmin" if args.no_softmin else "") + (f" --perturb {args.perturb}" if args.perturb else ""),

@@ -6,6 +6,10 @@ import numpy as np
 import pytest
 import torch
 
+# Several tests import the read-only reference (/root/reference) when it is mounted: no bytecode is ever written next to its sources
+# (67 .pyc files had appeared there), whichever test imports it first.
+sys.dont_write_bytecode = True
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
@@ -100,9 +104,9 @@ def assert_close_or_reference_gap(a, truth, ref32, rel=1e-4, slack=2.0, what="")
     return e, gap
 
 
-# ---- the stand-in package of the reference's module layout (tests/standin/flowmap): what flowmap_amd.install() patches where the reference is not mounted ----
+# ---- the stand-in package of the reference's module layout (bench_support/standin/flowmap): what flowmap_amd.install() patches where the reference is not mounted ----
 
-STANDIN = str(ROOT / "tests" / "standin")
+STANDIN = str(ROOT / "bench_support" / "standin")
 
 
 def forget_flowmap_modules():  # every module of whatever package called `flowmap` an earlier test imported (the real reference in the build container)

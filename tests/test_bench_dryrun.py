@@ -104,6 +104,10 @@ def test_whole_c4_path_releases_the_originals_and_keeps_a_cpu_sample():
     whole, kept = lines
     assert "WHOLE" in whole["config"]["workload"] and whole["config"]["video_frames"] == 9
     assert whole["cpu_baseline"]["frames"] == 4 and whole["cpu_baseline"]["whole_workload"] is False
+    # the port's time restated for the reference's own code (tests/golden/cpu_calibration.json: imported reference vs port, interleaved)
+    cal = whole["cpu_baseline"]["port_over_reference"]
+    assert 0.5 < cal["port_over_reference"] < 1.5 and cal["measured_at"] == [150, 720, 1280]
+    assert abs(whole["cpu_baseline"]["reference_equivalent_value"] - whole["cpu_baseline"]["value"] * cal["port_over_reference"]) < 1e-9
     assert abs(whole["config"]["loss"] - kept["config"]["loss"]) <= 1e-6 * abs(kept["config"]["loss"])
     assert abs(whole["cpu_baseline"]["loss"] - kept["cpu_baseline"]["loss"]) <= 1e-6 * abs(kept["cpu_baseline"]["loss"])
 

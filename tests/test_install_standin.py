@@ -1,4 +1,4 @@
-"""flowmap_amd.install() on the stand-in package (tests/standin: the reference's module LAYOUT with the oracle's arithmetic), where the
+"""flowmap_amd.install() on the stand-in package (bench_support/standin: the reference's module LAYOUT with the oracle's arithmetic), where the
 reference itself cannot be: on the GPU box.  The rebinding (registries + import-site names) and the HIP library run in ONE process
 here: the stand-in's Model and loss factory on cuda:0 after install(), against the golden numbers the real reference produced
 (tests/golden/step_*.npz).  The CPU suite runs the same on the host double, and first checks that the stand-in, left alone, reproduces

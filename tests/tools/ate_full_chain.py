@@ -47,7 +47,7 @@ def scene(args, device="cpu"):
 
 def config(args):
     return {k: getattr(args, k) for k in ("frames", "height", "width", "steps", "lr", "points", "noise", "seed", "track_grid", "softmin_points",
-                                          "num_candidates", "after_step", "window", "trace_every", "no_softmin")}
+                                          "num_candidates", "after_step", "window", "trace_every", "no_softmin")} | {"tracking_after": getattr(args, "tracking_after", 0)}
 
 
 def reference_leg(args):
@@ -81,8 +81,9 @@ def reference_leg(args):
             if step >= args.after_step - args.window:
                 window.append(torch.tensor(focal))
         out = orc.model_forward(depth, weights, k, sc["flows"], idx)
-        loss = 1000.0 * orc.flow_loss(out.surfaces, out.extrinsics, k, sc["flows"], (h, w)) + 100.0 * orc.tracking_loss(
-            out.surfaces, out.extrinsics, k, tracks, (h, w))
+        loss = 1000.0 * orc.flow_loss(out.surfaces, out.extrinsics, k, sc["flows"], (h, w))
+        if step >= getattr(args, "tracking_after", 0):  # loss.py:39-46: a constant 0 before LossCfgCommon.enable_after
+            loss = loss + 100.0 * orc.tracking_loss(out.surfaces, out.extrinsics, k, tracks, (h, w))
         return loss, out, focal
 
     for step in range(args.steps):
@@ -128,6 +129,7 @@ def ours_leg(args, quiet=False, scene_device="cpu", perturb=0.0, built=None):
     from helpers import to_flows, to_tracks
 
     ref = json.loads(Path(args.reference).read_text())
+    args.tracking_after = 0  # (records made before round 6 carry no such key: the tracking loss from step 0)
     for key, value in ref["config"].items():  # the reference leg's configuration IS the configuration
         setattr(args, key, value)
     f, h, w = args.frames, args.height, args.width
@@ -158,7 +160,7 @@ def ours_leg(args, quiet=False, scene_device="cpu", perturb=0.0, built=None):
     tracks = to_tracks(otracks, dev)
     batch = Batch(torch.zeros((1, f, 3, 1, 1), device=dev).expand(1, f, 3, h, w))
     loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
-    track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
+    track_fn = LossTracking(LossTrackingCfg(args.tracking_after, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
     opt = flowmap_amd.FusedAdam(model.parameters(), lr=args.lr)
     if args.in_pass:
         opt.fuse_depth_update(model.backbone.depth, max_touched_fraction=1.0)
@@ -188,7 +190,7 @@ def ours_leg(args, quiet=False, scene_device="cpu", perturb=0.0, built=None):
     ref_pos = torch.tensor(ref["positions"])
     record = {
         "scene": f"synthetic consistent scene, {f} frames @ {h}x{w} ({f - 1} chained poses), seed {args.seed}, depth noise {args.noise}",
-        "schedule": f"flow (1000) + tracking (100, {len(otracks)} segments x {args.track_grid ** 2} tracks); softmin intrinsics ({args.num_candidates} candidates x "
+        "schedule": f"flow (1000) + tracking (100, {len(otracks)} segments x {args.track_grid ** 2} tracks" + (f", from step {args.tracking_after}" if args.tracking_after else "") + f"); softmin intrinsics ({args.num_candidates} candidates x "
                     f"{args.softmin_points} points) for {args.after_step} steps, window {args.window}, then the regressed focal length; Adam lr {args.lr}, {args.steps} steps"
                     if not args.no_softmin else f"flow (1000) + tracking (100, {len(otracks)} segments x {args.track_grid ** 2} tracks); regressed focal length from the start (10 % off); Adam lr {args.lr}, {args.steps} steps",
         "ate_reference_path_cpu": ref["ate_reference_path_cpu"], "ate_flowmap_amd": ate_ours, "ate_abs_diff": abs(ate_ours - ref["ate_reference_path_cpu"]),
@@ -254,6 +256,7 @@ if __name__ == "__main__":
     ap.add_argument("--trace-every", type=int, default=10)
     ap.add_argument("--no-softmin", action="store_true", help="regressed intrinsics from the start (no candidate sweep): the schedule without its chaotic selector")
     ap.add_argument("--in-pass", action="store_true")
+    ap.add_argument("--tracking-after", type=int, default=0, help="LossTrackingCfg.enable_after (config/loss/tracking.yaml:4-6: 50)")
     ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
