@@ -150,9 +150,6 @@ def parse():
                     help="the reference's default operating point (config/overfit.yaml:33-38: 150 frames of ~180x240, flow + tracking) beside the headline: "
                          "two child runs of this file — the package's ModelWrapperOverfit.training_step eager and under install(graph=True) — reported "
                          "under `default_resolution` (auto: with the default headline run on one GPU, like the ATE leg)")
-    ap.add_argument("--track-presample", action="store_true",
-                    help="flow + tracking (A/B; measured and not adopted, flowmap_amd/_ops.py: track_presample): the camera-space half of the tracking loss's "
-                         "sampling runs beside the Procrustes fit on a second stream instead of in the prologue of the pair kernel")
     ap.add_argument("--torch-baseline", type=int, default=0, metavar="STEPS",
                     help="after the timed region: the reference's op sequence on stock PyTorch-ROCm on this GPU (tests/tools/torch_gpu_reference_ops.py "
                          "in a process of its own, 1 warm-up + STEPS steps on i.i.d. inputs of the workload's size) as `rocm_torch_baseline`")
@@ -597,8 +594,6 @@ def main():
     flowmap_amd.set_lazy_surfaces(True)
     if args.no_tap_exchange:
         _ops.use_tap_exchange = False
-    if args.track_presample:
-        _ops.use_track_presample = True
     if os.environ.get("FLOWMAP_THREE_LAUNCH_BWD"):  # A/B: the planned Procrustes backward as the three launches of round 2
         from flowmap_amd._lib import torch_ops
 
@@ -1064,7 +1059,6 @@ def main():
                 "kernel": "fm::track_pairs_kernel<huber, GRAD> (+ track_reduce, finalize" + (", tap_grad: one fm_track_loss_fused_fwd_taps call)" if _ops.counters["flow_tap_absorbs"] else ": one fm_track_loss_fused_fwd call)"),
                 "tap_exchange": {"flow_passes_with_taps": _ops.counters["flow_tap_passes"], "absorbed": _ops.counters["flow_tap_absorbs"],
                                  "sampled_from_tap_image": _ops.counters["track_tap_samples"]},
-                "sampled_beside_the_fit": {"presample_launches": _ops.counters["track_presamples"], "losses_that_used_them": _ops.counters["track_presampled_losses"]},
                 "bound": "valu",
                 "achieved": gflops,
                 "peak": FP32_PEAK_GFLOPS,

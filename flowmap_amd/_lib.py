@@ -102,8 +102,7 @@ SIGNATURES = {
     "fm_track_points": [P, I] + [P] * 4 + [I] + [P] * 4 + [I, I, I, I, P, P, P, P],
     "fm_track_loss_fwd": [P] * 6 + [I, I, I, P, P, I, I, I, I, F, F, F, F] + [P] * 7 + [P],
     "fm_track_loss_fused_fwd": [P, I, I, I, P, P, P, P, I, P, P, P, P, I, I, I, I, I, I, F, F, F, F] + [P] * 10 + [P],
-    "fm_track_loss_fused_fwd_taps": [P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, I, F, F, F, F] + [P] * 10 + [P] * 6 + [L, P, L, P, I, P],
-    "fm_track_presample": [P, P, P, P, P, P, I, I, I, I, P, P, P, P, P],
+    "fm_track_loss_fused_fwd_taps": [P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, I, F, F, F, F] + [P] * 10 + [P] * 6 + [L, P, L, P, P],
     "fm_tap_grad_apply": [P, P, L, P, P, P, P, P, P],
     "fm_track_loss_bwd": [P] * 7 + [I, P, P, P],
     "fm_track_scatter": [P] * 6 + [I, I, P, P, P, I, I, I, P, P],

@@ -240,7 +240,7 @@ def _dense_flow_is_rough(bwd_flow: Tensor, h: int, w: int) -> bool:
     return _derived(bwd_flow, "_fm_dense_rough", (bwd_flow._version, h, w), build)
 
 # which backward path the facades selected (tests)
-counters = {"track_presamples": 0, "track_presampled_losses": 0, "procrustes_planned": 0, "procrustes_dense_planned": 0, "flow_packs": 0, "procrustes_plans_built": 0, "track_tap_samples": 0,
+counters = {"procrustes_planned": 0, "procrustes_dense_planned": 0, "flow_packs": 0, "procrustes_plans_built": 0, "track_tap_samples": 0,
             "flow_tap_passes": 0, "flow_tap_absorbs": 0}
 
 
@@ -385,68 +385,6 @@ def _dense_procrustes_plan(bwd_flow: Tensor, b: int, f: int, h: int, w: int):
     return _derived(bwd_flow, "_fm_dense_plan", (bwd_flow._version, b, f, h, w), build)
 
 
-# The tracking loss's sampling splits into a camera-space half — bilinear taps of depth, K⁻¹: xyz and h per (segment, frame, point) — and the
-# pose that takes xyz to the world.  Only the second half needs the step's poses.  When a fused tracking loss ran on this depth parameter in
-# the previous step (it leaves a request on the parameter), the first half is launched HERE, on a second stream, right before the Procrustes
-# fit is enqueued: the fit is a latency-bound launch of one block per pair (~150 of 256 CUs, 38 us at C2) and the sampling a latency-bound
-# gather (37-64 us as the prologue of track_pairs, with every wave of that kernel waiting at once) — side by side they cost the longer of the
-# two.  The tracking loss of the step then finds xyz / h / flags ready (`_fm_presampled` on the step's depth tensor) and its pair kernel
-# starts with coalesced loads (fm_track_loss_fused_fwd_taps, presampled = 1).  Same arithmetic, same results bit for bit.
-#
-# MEASURED, NOT ADOPTED (round 5, profiles/r05_track_presample_ab.json): at C2 the pair kernel drops from 0.205 to 0.187 ms (its prologue's
-# gathers become three coalesced loads and a pose), but the step does not move (1.130 against 1.125 ms; two runs each): the 24 us sampling
-# kernel does overlap the fit, which slows by 2.5 us beside it, and the fork / join of the second stream (two cross-stream event waits) costs
-# what the kernel gained.  With an optimiser that moves depth every step the tap image is stale, the sampling gathers 5.6 M cold taps
-# (~0.1 ms, longer than the fit it hides under) and the step is SLOWER (1.93 against 1.82 ms).  Off by default; the tests switch it on.
-use_track_presample = False
-track_presample_min_bytes = 64 << 20  # (below this the depth images are cache-resident and the step is host-bound: the bookkeeping would cost more)
-_side_streams: dict = {}
-
-
-def _side_stream(device):
-    key = (device.type, device.index)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device)
-    return _side_streams[key]
-
-
-def track_presample(depth: Tensor, kinv: Tensor) -> None:
-    root = _whole_parameter(depth)
-    request = root.__dict__.get("_fm_track_presample") if root is not None else None
-    if request is None or not use_track_presample or depth.numel() * 4 < track_presample_min_bytes:
-        return
-    if depth.is_cuda and torch.cuda.is_current_stream_capturing():
-        return  # (a captured step must join every stream it forks: whether the tracking loss will come is not known here)
-    packed = request()
-    if packed is None or packed.partial or packed.nblocks == 0 or depth.shape[0] != 1 or packed.last_frame > depth.shape[1] or not depth.is_contiguous() \
-            or depth.dtype != torch.float32 or packed.xy.device != depth.device:
-        return
-    f, h, w = depth.shape[1:]
-    taps = (None, None)
-    if use_tap_exchange and use_tap_image and depth.numel() * 4 >= tap_exchange_min_bytes:
-        plan = root.__dict__.get("_fm_tap_plan")
-        if plan is not None and plan.packed is packed and plan.key == (int(f), int(h), int(w)) and plan.image_valid_for(root):
-            taps = (plan.image_slots, plan.image)
-    # (allocated on the CALLER's stream: the blocks are handed back to that stream's pool, after the tracking loss — which waits for the
-    # event below — has read them)
-    ws = torch.empty((packed.total, 9), dtype=torch.float32, device=depth.device)
-    flag = torch.empty((packed.total,), dtype=torch.uint8, device=depth.device)
-    args = (ptr(depth), ptr(kinv), ptr(packed.xy), ptr(packed.vis), ptr(packed.seg), ptr(packed.blocks), packed.nblocks, packed.pmax, int(h), int(w),
-            ptr(taps[0]), ptr(taps[1]), ptr(ws), ptr(flag))
-    done = None
-    if depth.is_cuda:
-        side, main = _side_stream(depth.device), torch.cuda.current_stream(depth.device)
-        side.wait_stream(main)  # depth, K⁻¹ (and the tap image) are final on the caller's stream
-        with torch.cuda.stream(side):
-            call("fm_track_presample", *args, side.cuda_stream)
-        done = torch.cuda.Event()
-        done.record(side)
-    else:  # the host double: executed in place
-        call("fm_track_presample", *args, None)
-    depth.__dict__["_fm_presampled"] = (packed, ws, flag, done, kinv, taps[1] is not None)
-    counters["track_presamples"] += 1
-
-
 class ProcrustesFit:
     """align_surfaces up to (not including) the pose chain (projection.py:213-249) with
     align_rigid (procrustes.py:7-51) inside (csrc/fm_torch.cpp: ProcrustesFit).  Source of xyz is either
@@ -512,8 +450,6 @@ class ProcrustesFit:
             pairs = bwd_flow.shape[0] * bwd_flow.shape[1]
             work = _derived(bwd_flow, "_fm_fit_work", (pairs, str(bwd_flow.device)),
                             lambda: torch.zeros((pairs * STAT_STRIDE + (pairs + 2) // 2 + 1,), dtype=torch.float64, device=bwd_flow.device))
-        if from_depth and rep == 1 and sink is not None and depth.dim() == 4:
-            track_presample(depth, kinv)  # (the tracking loss's camera-space sampling, beside the fit: see track_presample)
         t_bwd, t_fwd, ext = torch_ops().procrustes_fit(depth, k, kinv, surfaces, weights, bwd_flow, indices, float(weight_sens), rep, sink, wsink,
                                                        arena, *sparse, *dense, work)
         return t_bwd, t_fwd, (ext if ext.numel() > 0 else None)
@@ -994,22 +930,9 @@ class TrackLossFused:
                     tap_plan.sampled_now = False
         else:
             offer_taps = False
-        # the camera-space half of the sampling may already be there (track_presample, launched beside this step's Procrustes fit)
-        pre = (None, None)
-        ready = depth.__dict__.pop("_fm_presampled", None)
-        if ready is not None and ready[0] is packed and ready[4].data_ptr() == kinv.data_ptr() and reducer is None and int(frame0) == 0 and ext.shape[1] == depth.shape[1]:
-            if ready[3] is not None:
-                torch.cuda.current_stream(depth.device).wait_event(ready[3])
-            pre = (ready[1], ready[2])
-            counters["track_presampled_losses"] += 1
-        if (use_track_presample and reducer is None and int(frame0) == 0 and defer and not packed.partial and needs_depth and depth.dim() == 4
-                and ext.shape[1] == depth.shape[1]):
-            whole = _whole_parameter(depth)
-            if whole is not None and whole.is_leaf:
-                whole.__dict__["_fm_track_presample"] = weakref.ref(packed)  # from the next step on: sampled beside the fit
         loss, scale, totals = torch_ops().track_loss(depth, k, kinv, ext, packed.xy, packed.vis, packed.seg, packed.blocks, packed.tiles,
                                                      packed.counts, float(weight), int(kind), float(delta), sink, int(frame0),
-                                                     *(plan if plan is not None else (None, None, None, None)), fit_from, *taps, bool(offer_taps), *pre)
+                                                     *(plan if plan is not None else (None, None, None, None)), fit_from, *taps, bool(offer_taps))
         if reducer is not None:
             # the operator's gradients follow the `scale` tensor they find at backward time: overwrite it with the
             # global normaliser and report the global value through the local node

@@ -908,9 +908,8 @@ __device__ __forceinline__ DenseRaw dense_raw_of(const DenseRaw4& r, int j) {
 #ifndef FM_DENSE_MOMENTS_BLOCKS
 #define FM_DENSE_MOMENTS_BLOCKS 1
 #endif
-#ifndef FM_DENSE_MOMENTS_MFMA
-#define FM_DENSE_MOMENTS_MFMA 0
-#endif
+// (The two matrix-pipe formulations of these sums — v_mfma_f32_4x4x1 per pixel, and per 16-pixel group through LDS — were measured in round 4
+// and rejected, 0.903 / 0.664 ms against 0.608: docs/history/patches/r04_dense_procrustes_mfma_and_quad.patch, profiles/r04_dense_microbench_mfma.txt.)
 __global__ void __launch_bounds__(256, FM_DENSE_MOMENTS_BLOCKS) procrustes_moments_dense_kernel(ProcParams p, unsigned total) {
   __shared__ double red[4 * kMomentCount];
   __shared__ DenseWindow win;
@@ -923,32 +922,6 @@ __global__ void __launch_bounds__(256, FM_DENSE_MOMENTS_BLOCKS) procrustes_momen
   float acc[kMomentCount];
 #pragma unroll
   for (int k = 0; k < kMomentCount; ++k) acc[k] = 0.f;
-#if FM_DENSE_MOMENTS_MFMA
-  // Build variant (north_star: "MFMA only for the small covariance GEMMs where it actually pays"; measured in tools/dense_microbench.py,
-  // decision in DESIGN.md §3.2).  The 16 moments of a pixel are the outer product [w, w·h'] ⊗ [1, g'] (dense_moments_add), and
-  // v_mfma_f32_4x4x1_16B_f32 accumulates 16 independent 4x4 outer products D_b[i][j] += A(lane 4b+i)·B(lane 4b+j), one per quad of lanes.
-  // With one pixel per lane and component r / c of its two vectors in a register each, instruction (r, c) leaves the pixel's own
-  // product on the DIAGONAL of its quad's block — lane l, accumulator element l & 3 — with no cross-lane movement of the operands; the
-  // twelve off-diagonal products of a block mix different pixels and are ignored.  Sixteen MFMAs (matrix pipe) replace the sixteen
-  // VALU multiply-adds of dense_moments_add; each is bit-for-bit the same fmaf chain (the guide's f32-MFMA numerics).
-  //   == 1: operands stay where they are, sixteen MFMAs per pixel, a quarter of each one's products used (above);
-  //   == 2: the two 4-vectors of a lane's pixel are written to a wave-private LDS buffer (one 16-byte store each) and read back
-  //         TRANSPOSED — lane 4b+i reads component i of the pixel of lane 4b+s, s = 0..3 — so that each of FOUR MFMAs per pixel step
-  //         accumulates the complete 4x4 outer products of sixteen pixels: the exchange costs LDS instructions, not VALU ones.
-#if FM_DENSE_MOMENTS_MFMA == 1
-  v4f accm[kMomentCount];
-#pragma unroll
-  for (int k = 0; k < kMomentCount; ++k) accm[k] = v4f{0.f, 0.f, 0.f, 0.f};
-#else
-  // one float4 per lane and vector, a float4 of padding after every 16 lanes: the transposed 4-byte reads of a step then hit 64 banks
-  __shared__ v4f xch[4][2][kWave + 4];
-  v4f accv = {0.f, 0.f, 0.f, 0.f};
-  const int xlane = threadIdx.x & (kWave - 1), xwave = threadIdx.x >> 6;
-  const int xw = xlane + (xlane >> 4);
-  const float* xa = reinterpret_cast<const float*>(&xch[xwave][0][0]) + ((xlane & ~3) + (xlane >> 4)) * 4 + (xlane & 3);
-  const float* xb = reinterpret_cast<const float*>(&xch[xwave][1][0]) + ((xlane & ~3) + (xlane >> 4)) * 4 + (xlane & 3);
-#endif
-#endif
   const bool vec = (p.width & 3) == 0;
   const int col0 = c.tx0 + 4 * (threadIdx.x & (kTileW / 4 - 1));
   int row = c.ty0 + threadIdx.x / (kTileW / 4);
@@ -961,45 +934,6 @@ __global__ void __launch_bounds__(256, FM_DENSE_MOMENTS_BLOCKS) procrustes_momen
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kQuadPasses; ++k, row += kQuadRows) {
-#if FM_DENSE_MOMENTS_MFMA
-    // (an MFMA executes for the whole wave: lanes outside the image contribute w = 0 instead of leaving the loop)
-    const bool row_live = live && row < p.height;
-    const DenseRaw4 cur = next;
-    if (k + 1 < kQuadPasses && live && row + kQuadRows < p.height) next = dense_load4(c, (row + kQuadRows) * p.width + col0, col0, vec);
-    const float v = center_fast(row, c.fh, c.rcp_h);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // (a pixel outside the image: its raw inputs are zeros or, in a 16-byte load's tail, never loaded — dense_load4 —, its
-      // coordinates finite, its taps clamped to the border: every product is finite and w = 0 removes it from all sixteen sums)
-      const bool on = row_live && col0 + j < p.width;
-      const DensePixel px = dense_pixel(c, win, dense_raw_of(cur, j), u[j], v);
-      const float w = on ? px.w : 0.f;
-      const float a[4] = {w, w * (px.h[0] - gs[0]), w * (px.h[1] - gs[1]), w * (px.h[2] - gs[2])};
-      const float b[4] = {1.f, px.g[0] - gs[0], px.g[1] - gs[1], px.g[2] - gs[2]};
-#if FM_DENSE_MOMENTS_MFMA == 1
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int slot = r == 0 ? q : (q == 0 ? 3 + r : 7 + 3 * (r - 1) + (q - 1));
-          accm[slot] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], b[q], accm[slot], 0, 0, 0);
-        }
-#else
-      xch[xwave][0][xw] = v4f{a[0], a[1], a[2], a[3]};
-      xch[xwave][1][xw] = v4f{b[0], b[1], b[2], b[3]};
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (a wave's LDS operations complete in order: this orders the compiler)
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      float ra[4], rb[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) ra[t] = xa[4 * t], rb[t] = xb[4 * t];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) accv = __builtin_amdgcn_mfma_f32_4x4x1f32(ra[t], rb[t], accv, 0, 0, 0);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#endif
-    }
-#else
     if (!live || row >= p.height) break;
     const DenseRaw4 cur = next;
     if (k + 1 < kQuadPasses && row + kQuadRows < p.height) next = dense_load4(c, (row + kQuadRows) * p.width + col0, col0, vec);
@@ -1010,27 +944,7 @@ __global__ void __launch_bounds__(256, FM_DENSE_MOMENTS_BLOCKS) procrustes_momen
       const DensePixel px = dense_pixel(c, win, dense_raw_of(cur, j), u[j], v);
       dense_moments_add(px.g, px.h, px.w, gs, acc);
     }
-#endif
   }
-#if FM_DENSE_MOMENTS_MFMA
-  {
-    const int d = threadIdx.x & 3;
-#if FM_DENSE_MOMENTS_MFMA == 1
-#pragma unroll
-    for (int k = 0; k < kMomentCount; ++k) acc[k] = d == 0 ? accm[k].x : d == 1 ? accm[k].y : d == 2 ? accm[k].z : accm[k].w;
-#else
-    // lane 4b+j holds D_b[i][j] in element i: its column of the quad's sixteen sums; block_accumulate adds the quads (and the zeros)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int slot = r == 0 ? q : (q == 0 ? 3 + r : 7 + 3 * (r - 1) + (q - 1));
-        const float val = r == 0 ? accv.x : r == 1 ? accv.y : r == 2 ? accv.z : accv.w;
-        acc[slot] = d == q ? val : 0.f;
-      }
-#endif
-  }
-#endif
   // (Two pixels per pass in packed fp32 — v_pk_fma_f32 on pairs of the quad — issued 14 % fewer instructions and ran 7 % SLOWER: a
   // packed instruction occupies the SIMD about twice as long as a plain one on this part, tools/probes/pk_rate_probe.hip.)
   block_accumulate<kMomentCount>(acc, red, p.stats + c.pair * kStatStride);
@@ -1155,9 +1069,8 @@ __global__ void __launch_bounds__(256, FM_DENSE_LATER_BLOCKS) procrustes_dense_b
 #ifndef FM_DENSE_FUSED_UNROLL
 #define FM_DENSE_FUSED_UNROLL 4
 #endif
-#ifndef FM_DENSE_FUSED_QUAD  // 0 (default): one later pixel per thread; 1: four adjacent pixels per thread, 16-byte loads / stores — measured (profiles/r04_dense_microbench_quad.txt): 2.26 instead of 1.17 ms (not investigated further; a lane's four pixels put their taps 32 bytes apart in the LDS image, which the 64-bit atomics of a wave then hit with bank conflicts)
-#define FM_DENSE_FUSED_QUAD 0
-#endif
+// (Four adjacent later pixels per thread with 16-byte accesses — what helps the moments kernel — made this pass slower, 2.26 against 1.17 ms:
+// docs/history/patches/r04_dense_procrustes_mfma_and_quad.patch, profiles/r04_dense_microbench_quad.txt.)
 #ifndef FM_DENSE_FUSED_SKIP  // timing experiments only (tools/dense_microbench.py): 1 = plain store for the later pixel (racy), 2 = no flush, 4 = no taps
 #define FM_DENSE_FUSED_SKIP 0
 #endif
@@ -1232,39 +1145,6 @@ __global__ void __launch_bounds__(256, FM_DENSE_FUSED_BLOCKS) procrustes_dense_b
     }
     return gw;
   };
-#if FM_DENSE_FUSED_QUAD
-  // Four horizontally adjacent later pixels per thread, as in the moments kernel: 16-byte loads of flow / weights / depth and one 16-byte
-  // store of dL/dweights — a quarter of the global load / store instructions (these tiled kernels are bound by the memory pipeline).
-  const bool vec = (p.width & 3) == 0;
-  const int col0 = c.tx0 + 4 * (threadIdx.x & (kTileW / 4 - 1));
-  int row = c.ty0 + threadIdx.x / (kTileW / 4);
-  const bool live = col0 < p.width;
-  float u4[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) u4[j] = center_fast(col0 + j, c.fw, c.rcp_w);
-  DenseRaw4 next4 = {};
-  if (live && row < p.height) next4 = dense_load4(c, row * p.width + col0, col0, vec);
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < kQuadPasses; ++k, row += kQuadRows) {
-    if (!live || row >= p.height) break;
-    const int idx = row * p.width + col0;
-    const DenseRaw4 cur4 = next4;
-    if (k + 1 < kQuadPasses && row + kQuadRows < p.height) next4 = dense_load4(c, (row + kQuadRows) * p.width + col0, col0, vec);
-    const float v = center_fast(row, c.fh, c.rcp_h);
-    float gw4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (col0 + j >= p.width) break;
-      gw4[j] = one_pixel(dense_raw_of(cur4, j), u4[j], v, idx + j);
-    }
-    if (gw_out) {
-      if (vec) *reinterpret_cast<v4f*>(gw_out + idx) = v4f{gw4[0], gw4[1], gw4[2], gw4[3]};
-      else
-        for (int j = 0; j < 4 && col0 + j < p.width; ++j) gw_out[idx + j] = gw4[j];
-    }
-  }
-#else
   const int col = c.tx0 + (threadIdx.x & (kTileW - 1));
   int row = c.ty0 + threadIdx.x / kTileW;
   const bool live = col < p.width;
@@ -1282,7 +1162,6 @@ __global__ void __launch_bounds__(256, FM_DENSE_FUSED_BLOCKS) procrustes_dense_b
     const float gw = one_pixel(cur, u, v, idx);
     if (gw_out) gw_out[idx] = gw;
   }
-#endif
   if (!gd_e || (FM_DENSE_FUSED_SKIP & 2)) return;
   __syncthreads();
   // the window's sums -> dL/ddepth of the earlier frame (only cells inside the image ever receive a tap)

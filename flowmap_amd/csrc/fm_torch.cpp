@@ -49,7 +49,7 @@ using OptTensor = std::optional<Tensor>;
   X(fm_relative_pose_bwd) X(fm_procrustes_fit) X(fm_procrustes_fit_chain) X(fm_depth_gather_kgrad) X(fm_pose_solve_bwd) X(fm_pose_solve_bwd_kinv) X(fm_procrustes_scatter) X(fm_procrustes_scatter_dense) X(fm_procrustes_bwd_planned) X(fm_flow_loss_fused_views) X(fm_procrustes_fit_chain_views) X(fm_procrustes_fit_views) X(fm_procrustes_scatter_views)                \
   X(fm_depth_gather) X(fm_extrinsics_inverse) X(fm_track_loss_fused_fwd) X(fm_track_loss_bwd) X(fm_adam_step)                 \
   X(fm_adam_step_capturable) X(fm_softmin_score_fwd) X(fm_softmin_score_bwd) X(fm_softmin_blend_fwd) X(fm_softmin_blend_bwd)         \
-  X(fm_random_subset) X(fm_random_subset_stateful) X(fm_abi_version) X(fm_flow_loss_fused_taps) X(fm_track_loss_fused_fwd_taps) X(fm_tap_grad_apply) X(fm_track_presample)
+  X(fm_random_subset) X(fm_random_subset_stateful) X(fm_abi_version) X(fm_flow_loss_fused_taps) X(fm_track_loss_fused_fwd_taps) X(fm_tap_grad_apply)
 
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
@@ -1067,8 +1067,7 @@ struct TrackLossFused : public Function<TrackLossFused> {
                                std::vector<int64_t> counts, double weight, int64_t kind, double delta,
                                const c10::intrusive_ptr<DepthSink>& sink, int64_t frame0, const OptTensor& plan_pixels,
                                const OptTensor& plan_first, const OptTensor& plan_entries, const OptTensor& plan_weights, const OptTensor& tap_slot_o,
-                               const OptTensor& tap_depth_o, const OptTensor& tap_shared_o, bool offer_taps, const OptTensor& pre_ws_o,
-                               const OptTensor& pre_flag_o, bool grad_enabled, bool park) {
+                               const OptTensor& tap_depth_o, const OptTensor& tap_shared_o, bool offer_taps, bool grad_enabled, bool park) {
     const auto dev = check_device({&depth_in, &k_in, &kinv_in, &ext_in, &xy});
     const Tensor depth = f32c(depth_in, "depth"), k = f32c(k_in, "intrinsics"), kinv = f32c(kinv_in, "inverse intrinsics"),
                  ext = f32c(ext_in, "extrinsics");
@@ -1083,16 +1082,8 @@ struct TrackLossFused : public Function<TrackLossFused> {
     const int64_t own_first = std::max<int64_t>(counts[7], frame0), own_end = std::min<int64_t>(counts[8] < 0 ? f : counts[8], frame0 + f_local);
     const auto fopt = depth.options();
     Tensor ext_inv = at::empty_like(ext);
-    // fm_track_presample (launched by the caller beside this step's Procrustes fit) may have filled xyz / h / the flags already: its buffers
-    // are used in place and the pair kernel only applies the poses (whole video, nothing sharded)
-    const bool presampled = pre_ws_o.has_value() && pre_ws_o->defined() && pre_flag_o.has_value() && pre_flag_o->defined();
-    if (presampled)
-      TORCH_CHECK(frame0 == 0 && f_local == f && !partial && pre_ws_o->scalar_type() == at::kFloat && pre_ws_o->is_contiguous() && pre_ws_o->numel() == total * 9 &&
-                      pre_flag_o->scalar_type() == at::kByte && pre_flag_o->is_contiguous() && pre_flag_o->numel() == total &&
-                      pre_ws_o->device() == depth.device() && pre_flag_o->device() == depth.device(),
-                  "flowmap_amd: presampled track points must cover the whole packed track set on the depth tensor's device (whole video, not sharded)");
-    Tensor ws = presampled ? *pre_ws_o : at::empty({total, 9}, fopt);
-    Tensor flag = presampled ? *pre_flag_o : (partial ? at::zeros({total}, fopt.dtype(at::kByte)) : at::empty({total}, fopt.dtype(at::kByte)));
+    Tensor ws = at::empty({total, 9}, fopt);
+    Tensor flag = partial ? at::zeros({total}, fopt.dtype(at::kByte)) : at::empty({total}, fopt.dtype(at::kByte));
     Tensor acc = at::empty({f * 20}, fopt.dtype(at::kDouble));
     Tensor loss = at::empty({1}, fopt), scale = at::empty({2}, fopt), totals = at::empty({2}, fopt.dtype(at::kDouble));
     const bool need = (depth_in.requires_grad() || k_in.requires_grad() || ext_in.requires_grad()) && grad_enabled;
@@ -1116,7 +1107,7 @@ struct TrackLossFused : public Function<TrackLossFused> {
     const bool offer = offer_taps && whole && need && depth_in.requires_grad() && ntiles > 0 && sink && park && sink->accepts(depth) &&
                        plan_pixels.has_value() && plan_pixels->defined() && plan_pixels->numel() > 0;
     Tensor tap_grad = offer ? at::empty({plan_pixels->numel()}, fopt) : Tensor();
-    const bool use_taps = tap_depth.defined() || tap_grad.defined() || presampled;
+    const bool use_taps = tap_depth.defined() || tap_grad.defined();
     const float sc = std::sqrt((float)(h * w));
     {
       DeviceScope scope(dev);
@@ -1137,7 +1128,7 @@ struct TrackLossFused : public Function<TrackLossFused> {
                   ptr<int32_t>(opt(plan_first)), ptr<int32_t>(opt(plan_entries)), ptr(opt(plan_weights)),
                   tap_grad.defined() ? (long)tap_grad.numel() : 0L, tap_grad.defined() ? ptr<int32_t>(tap_shared) : nullptr,
                   (tap_grad.defined() && tap_shared.defined()) ? (long)tap_shared.numel() : 0L,
-                  ptr(tap_grad), presampled ? 1 : 0, scope.stream);
+                  ptr(tap_grad), scope.stream);
         } else {
           FM_CALL(fm_track_loss_fused_fwd, ptr(depth), (int)frame0, (int)own_first, (int)own_end, ptr(kinv), ptr(ext), ptr(ext_inv), ptr(k), (int)f,
                   ptr(xy), ptr<uint8_t>(vis), ptr<int32_t>(seg), ptr<int32_t>(tiles), (int)ntiles, (int)pmax, (int)fmax, (int)h, (int)w, (int)kind,
@@ -1174,7 +1165,7 @@ struct TrackLossFused : public Function<TrackLossFused> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    variable_list out(27);
+    variable_list out(25);
     if (!grads[0].defined()) return out;
     const auto saved = ctx->get_saved_variables();
     const Tensor &k = saved[0], &kinv = saved[1], &ext_inv = saved[2], &acc = saved[3];
@@ -1458,13 +1449,13 @@ static std::tuple<Tensor, Tensor, Tensor> track_loss_op(const Tensor& depth, con
                                                         const OptSink& sink, int64_t frame0, const OptTensor& plan_pixels,
                                                         const OptTensor& plan_first, const OptTensor& plan_entries, const OptTensor& plan_weights,
                                                         const OptTensor& anchor, const OptTensor& tap_slot, const OptTensor& tap_depth, const OptTensor& tap_shared,
-                                                        bool offer_taps, const OptTensor& pre_ws, const OptTensor& pre_flag) {
+                                                        bool offer_taps) {
   auto s = sink_of(sink);
   // `anchor`: the tensor whose history leads to the fit (the local extrinsics under frame sharding, where `ext` is the gathered chain)
   const Tensor& from = (anchor.has_value() && anchor->defined()) ? *anchor : ext;
   const bool park = s && s->fit_node != nullptr && reaches(from.grad_fn(), s->fit_node, 3);
   auto out = TrackLossFused::apply(depth, k, kinv, ext, xy, vis, seg, blocks, tiles, counts, weight, kind, delta, s, frame0, plan_pixels, plan_first,
-                                   plan_entries, plan_weights, tap_slot, tap_depth, tap_shared, offer_taps, pre_ws, pre_flag, at::GradMode::is_enabled(), park);
+                                   plan_entries, plan_weights, tap_slot, tap_depth, tap_shared, offer_taps, at::GradMode::is_enabled(), park);
   return {out[0], out[1], out[2]};
 }
 // would a flow loss fed these poses hand its dL/ddepth to the sink's fit (i.e. is the in-pass Adam update possible)?
@@ -1556,7 +1547,7 @@ TORCH_LIBRARY(flowmap_amd, m) {
       "track_loss(Tensor depth, Tensor k, Tensor kinv, Tensor ext, Tensor xy, Tensor vis, Tensor seg, Tensor blocks, Tensor tiles, int[] counts, "
       "float weight, int kind, float delta, __torch__.torch.classes.flowmap_amd.DepthSink? sink, int frame0, Tensor? plan_pixels, Tensor? plan_first, "
       "Tensor? plan_entries, Tensor? plan_weights, Tensor? anchor, Tensor? tap_slot=None, Tensor? tap_depth=None, Tensor? tap_shared=None, "
-      "bool offer_taps=False, Tensor? pre_ws=None, Tensor? pre_flag=None) "
+      "bool offer_taps=False) "
       "-> (Tensor, Tensor, Tensor)",
       fmt::track_loss_op);
   m.def("leading_frames(Tensor x, int count, __torch__.torch.classes.flowmap_amd.DepthSink? sink) -> Tensor", fmt::leading_frames_op);

@@ -114,9 +114,7 @@ __device__ __forceinline__ bool track_sample(const TrackGeom& g, const float* de
 // bit 29: read the depth image after all (a pixel another operator updates after the flow pass); slot -1: a tap that contributes
 // nothing — instead of four cold lines of the depth images.
 constexpr int kTapRank = 0x1fffffff, kTapDense = 0x20000000, kTapShared = 0x40000000;
-// POSE = false (track_presample_kernel): the camera-space half only — xyz and h into planes 0-2 / 6-8, the flag; no pose is read, planes 3-5
-// (X_w) are left to the pair kernel, which applies the pose when it exists (TrackSampling::presampled); xw returns xyz.
-template <int N, bool POSE = true>
+template <int N>
 __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const float* depth, int depth_frame0, const float* kinv, const float* ext,
                                                   const int (&frame)[N], const size_t (&idx)[N], const bool (&want)[N], bool store, int p_count,
                                                   int p, float* ws, uint8_t* flag, float (&xw)[N][3], bool (&live)[N],
@@ -232,13 +230,9 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
       hh[1] += zk * vt * wk;
       hh[2] += zk * wk;
     }
-    if (POSE) {
-      Pose e;
-      load_pose44(ext + (size_t)frame[n] * 16, e);
-      apply_pose(e, xyz, xw[n]);
-    } else {
-      xw[n][0] = xyz[0]; xw[n][1] = xyz[1]; xw[n][2] = xyz[2];
-    }
+    Pose e;
+    load_pose44(ext + (size_t)frame[n] * 16, e);
+    apply_pose(e, xyz, xw[n]);
     const bool inside = q[n].x >= 0.f && q[n].y >= 0.f && q[n].x < 1.f && q[n].y < 1.f;
     live[n] = store && vis[n] != 0 && inside;
     if (store) {
@@ -246,9 +240,7 @@ __device__ __forceinline__ void track_sample_many(const TrackGeom& g, const floa
       float* o = ws_plane(ws, idx[n] - p, p_count, p);
       const size_t pc = (size_t)p_count;
       o[0] = xyz[0]; o[pc] = xyz[1]; o[2 * pc] = xyz[2];
-      if (POSE) {
-        o[3 * pc] = xw[n][0]; o[4 * pc] = xw[n][1]; o[5 * pc] = xw[n][2];
-      }
+      o[3 * pc] = xw[n][0]; o[4 * pc] = xw[n][1]; o[5 * pc] = xw[n][2];
       o[6 * pc] = hh[0];  o[7 * pc] = hh[1];  o[8 * pc] = hh[2];
 #endif
       flag[idx[n]] = live[n] ? 1 : 0;
@@ -267,26 +259,6 @@ __global__ void __launch_bounds__(256) track_points_kernel(TrackGeom g, const fl
 }
 
 // Per frame: the target-role constants (au, av, c) of track_target (fm_pose.h).
-// The camera-space half of the sampling on its own (fm_track_presample): needs depth (or the compact tap image) and K⁻¹ only — not the poses —
-// so it can run BESIDE the Procrustes fit that produces them (a second stream: the fit keeps ~150 of the 256 CUs busy with latency-bound
-// gathers), instead of in the prologue of every wave of track_pairs, where all waves wait for their gathers at the same time with the VALU
-// idle chip-wide (37 us of a 200 us kernel at C2, profiles/r04_track_pairs_phase_clocks.txt).  Same arithmetic per item as track_sample_many.
-// grid: (blocks of (segment, local frame), ceil(pmax / 256)).
-__global__ void __launch_bounds__(256) track_presample_kernel(TrackGeom g, const float* depth, const float* kinv, const int32_t* tap_slot,
-                                                              const float* tap_depth, float* ws, uint8_t* flag) {
-  const int sg = g.blocks[blockIdx.x * 2], fl = g.blocks[blockIdx.x * 2 + 1];
-  const int start = g.seg[sg * 4], p_count = g.seg[sg * 4 + 2], off = g.seg[sg * 4 + 3];
-  const int p = blockIdx.y * blockDim.x + threadIdx.x;
-  if (blockIdx.y * blockDim.x >= (unsigned)p_count) return;  // (block-uniform)
-  const int pp = min(p, p_count - 1);
-  const int frame[1] = {start + fl};
-  const size_t idx[1] = {(size_t)off + (size_t)fl * p_count + pp};
-  const bool want[1] = {true};
-  float xw[1][3];
-  bool live[1];
-  track_sample_many<1, false>(g, depth, 0, kinv, nullptr, frame, idx, want, p < p_count, p_count, pp, ws, flag, xw, live, tap_slot, tap_depth);
-}
-
 __global__ void __launch_bounds__(64) track_targets_kernel(const float* ext_inv, const float* k, int frames, float* tgt) {
   const int fr = blockIdx.x * blockDim.x + threadIdx.x;
   if (fr < frames) track_target(ext_inv + (size_t)fr * 16, k + (size_t)fr * 9, tgt + (size_t)fr * kTrackTgt);
@@ -419,61 +391,8 @@ __device__ __forceinline__ void track_pair_term2(const float (&ts)[kTrackTgt], c
   gxw[2] = o0 * ts[2] + (o1 * ts[6] + (gxw[2] - o2 * ts[10]));
 }
 
-// Build variant FM_TRACK_MFMA (round 5): the two dense 3x4 products of a residual — the pose transform X_c = T'·[X_w; 1] and the
-// gradient's way back dL/dX_w += T'ᵀ·ω' — on the matrix pipe.  v_mfma_f32_4x4x1_16B_f32 accumulates sixteen independent 4x4 outer
-// products D_b[i][j] += A(lane 4b+i)·B(lane 4b+j), lane 4b+j holding column j of its quad's block in four registers.  With the B
-// operand a per-lane quantity of the lane's OWN residual (component k of X_w; ω'_r) and the A operand a per-target constant laid out
-// across the quad (lane 4b+i: T'[i][k]; lane 4b+k: ±T'[r][k]), the lane's column IS its own product: four instructions give (x_u, x_v,
-// x_2, ·), three more add this target's term to (dL/dX_w0, dL/dX_w1, dL/dX_w2, ·) — no cross-lane movement of operands, the same fmaf chains
-// in the same order as track_pair_term_scaled (the matrix pipe's fp32 product-accumulate is an fmaf).  What stays on the VALU is packed over
-// the (u, v) pair of ONE residual instead of over two source frames.  The VALU multiply-adds these replace are 18 of the 49 a residual costs.
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-
-template <int KIND, bool GRAD>
-__device__ __forceinline__ void track_pair_term_mfma(const v4f_t xc, const float (&xw)[3], const v2f gt_s, float m, float delta, float inv_delta,
-                                                     unsigned bx, unsigned by, v2f (&a01)[4], float (&a2)[4], float& a_rho, float& a_cnt,
-                                                     const float (&ab)[3], v4f_t& gacc) {
-  float q = fm_rcp(xc.z + kProjEps);
-  const bool ok = fabsf(q) <= 3.0e38f;
-  q = ok ? q : 0.f;
-  const v2f zero = {0.f, 0.f}, qq = {q, q};
-  const v2f uv = __builtin_elementwise_fma(v2f{xc.x, xc.y}, qq, zero);  // ax·u, ay·v; never −0
-  m = (ok && __float_as_uint(uv.x) < bx && __float_as_uint(uv.y) < by) ? m : 0.f;
-  const v2f r = uv - gt_s;
-  const float ss = r.x * r.x + r.y * r.y;
-  float rho, coef;  // ρ and dρ/dr = coef·r
-  if (KIND == kL2) {
-    rho = 0.5f * ss;
-    coef = 1.f;
-  } else if (KIND == kL1) {
-    const float inv_n = ss > 0.f ? fm_rsq(ss) : 0.f;
-    rho = ss * inv_n;
-    coef = inv_n;
-  } else {
-    coef = fminf(fm_rsq(ss), inv_delta);
-    const float t = ss * coef;
-    rho = -0.5f * fminf(t, delta) + t;
-  }
-  a_rho = rho * m + a_rho;
-  a_cnt += m;
-  if (!GRAD) return;
-  const float gc = m * coef;
-  const v2f w = v2f{gc, gc} * r;   // dL/du', dL/dv' (unscaled by the loss normaliser)
-  const v2f o01 = qq * w;
-  const float o2 = q * (w.x * uv.x + w.y * uv.y);
-  a01[0] = o01 * v2f{xw[0], xw[0]} + a01[0];  // (S0 | S1) rows, component by component
-  a01[1] = o01 * v2f{xw[1], xw[1]} + a01[1];
-  a01[2] = o01 * v2f{xw[2], xw[2]} + a01[2];
-  a01[3] += o01;
-  a2[0] = o2 * xw[0] + a2[0];
-  a2[1] = o2 * xw[1] + a2[1];
-  a2[2] = o2 * xw[2] + a2[2];
-  a2[3] += o2;
-  // dL/dX_w[k] = o0·ts[k] + (o1·ts[4 + k] + (dL/dX_w[k] − o2·ts[8 + k])): innermost first (ab[2] carries the minus sign)
-  gacc = __builtin_amdgcn_mfma_f32_4x4x1f32(ab[2], o2, gacc, 0, 0, 0);
-  gacc = __builtin_amdgcn_mfma_f32_4x4x1f32(ab[1], o01.y, gacc, 0, 0, 0);
-  gacc = __builtin_amdgcn_mfma_f32_4x4x1f32(ab[0], o01.x, gacc, 0, 0, 0);
-}
+// (Round 5's matrix-pipe variant of the pair term — v_mfma_f32_4x4x1 for the pose transform and dL/dX_w: parity-green, 23 us slower —
+// is kept as a patch, docs/history/patches/r05_track_pairs_mfma.patch; profiles/r05_track_pairs_mfma_ab.txt.)
 
 static_assert(kTrackTile % 2 == 0, "the source frames of a tile are processed in pairs");
 
@@ -489,8 +408,6 @@ struct TrackSampling {
   const float* tap_depth;   // the image, or null: sample the depth images
   float* tap_grad;          // (M) or null: the epilogue stores the unscaled dL/ddepth of every tap that belongs to ONE track point straight
                             // into the compact gradient (the taps several points share are summed by tap_grad_kernel afterwards)
-  int presampled;           // 1 (with depth null): fm_track_presample has filled xyz / h (planes 0-2, 6-8) and the flags: the prologue reads xyz
-                            // — coalesced — applies the source frame's pose and stores X_w (planes 3-5)
 };
 
 // Points per lane (FM_TRACK_PG): with two, a wave covers 128 points and the per-target reduction of the 14 sums (a quarter
@@ -499,9 +416,6 @@ struct TrackSampling {
 #define FM_TRACK_PG 2
 #endif
 constexpr int kTrackPG = FM_TRACK_PG;
-#ifndef FM_TRACK_MFMA  // 1: the pose transform and dL/dX_w on the matrix pipe (track_pair_term_mfma)
-#define FM_TRACK_MFMA 0
-#endif
 #ifndef FM_TRACK_AHEAD
 #define FM_TRACK_AHEAD 2
 #endif
@@ -541,13 +455,8 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
   }
 
   // source frames fs0 + 2j (.x) and fs0 + 2j + 1 (.y) share packed registers
-#if FM_TRACK_MFMA
-  float xw1[kTrackPG][kTrackTile][3], live1[kTrackPG][kTrackTile];  // per source frame (the matrix pipe takes one residual's operands per lane)
-  v4f_t gacc[kTrackPG][kTrackTile];                                  // (dL/dX_w0, dL/dX_w1, dL/dX_w2, ·): the MFMAs' accumulators
-#else
   v2f xw[kTrackPG][kTrackTile / 2][3], gxw[kTrackPG][kTrackTile / 2][3];
   v2f live[kTrackPG][kTrackTile / 2];  // 1 when the source role is visible (projection.py:290-294), else 0
-#endif
 #pragma unroll
   for (int q = 0; q < kTrackPG; ++q) {
     float lvs[kTrackTile], xs[kTrackTile][3];
@@ -567,39 +476,6 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
                                     smp.tap_slot, smp.tap_depth);
 #pragma unroll
       for (int t = 0; t < kTrackTile; ++t) lvs[t] = lv[t] ? 1.f : 0.f;
-    } else if (smp.presampled != 0) {
-      // every load of the tile first (the stores of X_w below go to the same workspace: the compiler would not move a load across them)
-      float cx[kTrackTile][3];
-      uint8_t fl8[kTrackTile];
-#pragma unroll
-      for (int t = 0; t < kTrackTile; ++t) {
-        const int fs = min(fs0 + t, f - 1);
-        const size_t is = (size_t)off + (size_t)fs * p_count + pp[q];
-        const float* w9 = ws_plane(ws, is - pp[q], p_count, pp[q]);
-        fl8[t] = flag[is];
-        cx[t][0] = w9[0]; cx[t][1] = w9[(size_t)p_count]; cx[t][2] = w9[2 * (size_t)p_count];
-      }
-#pragma unroll
-      for (int t = 0; t < kTrackTile; ++t) {
-        const int fs = fs0 + t;
-        lvs[t] = 0.f;
-        xs[t][0] = xs[t][1] = xs[t][2] = 0.f;
-        if (fs < f) {  // (wave-uniform)
-          Pose e;
-          load_pose44(ext + (size_t)(start + fs) * 16, e);
-          float xwv[3];
-          apply_pose(e, cx[t], xwv);
-          if (active[q]) {
-            const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
-            float* o = ws_plane(ws, is - p[q], p_count, p[q]);
-            o[3 * (size_t)p_count] = xwv[0]; o[4 * (size_t)p_count] = xwv[1]; o[5 * (size_t)p_count] = xwv[2];
-            if (fl8[t] != 0) {
-              lvs[t] = 1.f;
-              xs[t][0] = xwv[0]; xs[t][1] = xwv[1]; xs[t][2] = xwv[2];
-            }
-          }
-        }
-      }
     } else {
 #pragma unroll
       for (int t = 0; t < kTrackTile; ++t) {
@@ -619,18 +495,12 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
 #pragma unroll
     for (int t = 0; t < kTrackTile; ++t) {
       const float lv = lvs[t], x0 = lv != 0.f ? xs[t][0] : 0.f, x1 = lv != 0.f ? xs[t][1] : 0.f, x2 = lv != 0.f ? xs[t][2] : 0.f;
-#if FM_TRACK_MFMA
-      live1[q][t] = lv; xw1[q][t][0] = x0; xw1[q][t][1] = x1; xw1[q][t][2] = x2;
-      gacc[q][t] = v4f_t{0.f, 0.f, 0.f, 0.f};
-      continue;
-#else
       if (t & 1) {
         live[q][t / 2].y = lv; xw[q][t / 2][0].y = x0; xw[q][t / 2][1].y = x1; xw[q][t / 2][2].y = x2;
       } else {
         live[q][t / 2].x = lv; xw[q][t / 2][0].x = x0; xw[q][t / 2][1].x = x1; xw[q][t / 2][2].x = x2;
       }
       gxw[q][t / 2][0] = gxw[q][t / 2][1] = gxw[q][t / 2][2] = 0.f;
-#endif
     }
   }
 
@@ -674,58 +544,16 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
         gt_q[kTrackAhead - 1][q] = reinterpret_cast<const float2*>(g.xy)[it[q]];
       }
     }
-#if FM_TRACK_MFMA
-    // the target's scaled rows laid out across the quad: af[k] = T'[lane & 3][k] (row 3: zeros), ab[r] = ±T'[r][lane & 3]
-    const int quad_lane = threadIdx.x & 3;
-    const float* trow = tgt + (size_t)(start + ft) * kTrackTgt;
-    const float row_scale = quad_lane == 0 ? ax : (quad_lane == 1 ? ay : (quad_lane == 2 ? 1.f : 0.f));
-    const v4f_t trow4 = *reinterpret_cast<const v4f_t*>(trow + 4 * min(quad_lane, 2));
-    const float af[4] = {trow4.x * row_scale, trow4.y * row_scale, trow4.z * row_scale, trow4.w * row_scale};
-    const float ab[3] = {trow[quad_lane] * ax, trow[4 + quad_lane] * ay, -trow[8 + quad_lane]};
-#else
     float tg[kTrackTgt];
 #pragma unroll
     for (int i = 0; i < kTrackTgt; ++i)  // wave-uniform: scalar loads; the projection rows pre-multiplied by the aspect factors (track_scale_target)
       tg[i] = tgt[(size_t)(start + ft) * kTrackTgt + i] * (i < 4 ? ax : (i < 8 ? ay : 1.f));
-#endif
 #ifdef FM_TRACK_CLOCKS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     FM_TCLK(c1);
     FM_TCLK_ADD(1, c0, c1);
     float a[kTrackSums];
-#if FM_TRACK_MFMA
-    {
-      // X_c of the iteration's twelve residuals: four MFMAs each, the chains interleaved (translation first: the scalar function's order)
-      v4f_t xc[kTrackPG][kTrackTile];
-      const float one = 1.0f;
-#pragma unroll
-      for (int q = 0; q < kTrackPG; ++q)
-#pragma unroll
-        for (int t = 0; t < kTrackTile; ++t) xc[q][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[3], one, v4f_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-      for (int k = 2; k >= 0; --k)
-#pragma unroll
-        for (int q = 0; q < kTrackPG; ++q)
-#pragma unroll
-          for (int t = 0; t < kTrackTile; ++t) xc[q][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[k], xw1[q][t][k], xc[q][t], 0, 0, 0);
-      v2f a01[4];
-      float a2s[4], a_rho = 0.f, a_cnt = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a01[i] = 0.f, a2s[i] = 0.f;
-      const unsigned bx = __float_as_uint(ax), by = __float_as_uint(ay);
-#pragma unroll
-      for (int q = 0; q < kTrackPG; ++q) {
-        const v2f gt_s = {gt[q].x, gt[q].y};
-#pragma unroll
-        for (int t = 0; t < kTrackTile; ++t)
-          track_pair_term_mfma<KIND, GRAD>(xc[q][t], xw1[q][t], gt_s, tv[q] * live1[q][t], delta, inv_delta, bx, by, a01, a2s, a_rho, a_cnt, ab, gacc[q][t]);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = a01[i].x, a[4 + i] = a01[i].y, a[8 + i] = a2s[i];
-      a[12] = a_rho, a[13] = a_cnt;
-    }
-#else
     v2f a2[kTrackSums];
 #pragma unroll
     for (int i = 0; i < kTrackSums; ++i) a2[i] = 0.f;
@@ -737,7 +565,6 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
     }
 #pragma unroll
     for (int i = 0; i < kTrackSums; ++i) a[i] = a2[i].x + a2[i].y;
-#endif
 #ifdef FM_TRACK_CLOCKS
     asm volatile("" :: "v"(a[0]), "v"(a[13]));
 #endif
@@ -781,18 +608,11 @@ __global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(
       load_pose44(ext + (size_t)(start + fs) * 16, e);
 #pragma unroll
       for (int q = 0; q < kTrackPG; ++q) {
-#if FM_TRACK_MFMA
-        if (live1[q][t] != 0.f) {
-          const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
-          float gxyz[3];
-          const float gx[3] = {gacc[q][t].x, gacc[q][t].y, gacc[q][t].z};
-#else
         if (((t & 1) ? live[q][t / 2].y : live[q][t / 2].x) != 0.f) {
           const size_t is = (size_t)off + (size_t)fs * p_count + p[q];
           float gxyz[3];
           const float gx[3] = {(t & 1) ? gxw[q][t / 2][0].y : gxw[q][t / 2][0].x, (t & 1) ? gxw[q][t / 2][1].y : gxw[q][t / 2][1].x,
                                (t & 1) ? gxw[q][t / 2][2].y : gxw[q][t / 2][2].x};
-#endif
           float b1[21], w9[kTrackWs];
           const float* wp = ws_plane(ws, is - p[q], p_count, p[q]);
 #pragma unroll
@@ -1142,17 +962,6 @@ int fm_track_points(const float* depth, int depth_frame0, const float* kinv, con
   FM_LAUNCH_STATUS();
 }
 
-int fm_track_presample(const float* depth, const float* kinv, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks,
-                       int nblocks, int pmax, int height, int width, const int32_t* tap_slot, const float* tap_depth, float* ws, uint8_t* flag,
-                       void* stream) {
-  FM_CHECK_ARG(depth && kinv && xy && vis && seg && blocks && ws && flag && nblocks >= 1 && pmax >= 1 && height >= 1 && width >= 1);
-  FM_CHECK_ARG(tap_depth == nullptr || tap_slot != nullptr);
-  TrackGeom g{xy, vis, seg, blocks, height, width};
-  hipLaunchKernelGGL(track_presample_kernel, dim3(nblocks, (pmax + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, depth, kinv,
-                     tap_depth ? tap_slot : nullptr, tap_depth, ws, flag);
-  FM_LAUNCH_STATUS();
-}
-
 static int track_loss_launch(float* ws, uint8_t* flag, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* tiles,
                              int ntiles, int pmax, int fmax, const float* ext, const float* tgt, int frames, int height, int width,
                              int mapping_kind, float delta, float aspect_x, float aspect_y, float weight, float* partial, double* acc,
@@ -1189,7 +998,7 @@ int fm_track_loss_fwd(const float* ws, const uint8_t* flag, const float* xy, con
   FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr));
   return track_loss_launch(const_cast<float*>(ws), const_cast<uint8_t*>(flag), xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames,
                            height, width, mapping_kind, delta, aspect_x, aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                           TrackSampling{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0}, (hipStream_t)stream);
+                           TrackSampling{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr}, (hipStream_t)stream);
 }
 
 int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first, int own_end, const float* kinv, const float* ext,
@@ -1204,7 +1013,7 @@ int fm_track_loss_fused_fwd(const float* depth, int depth_frame0, int own_first,
   hipLaunchKernelGGL(track_targets_kernel, dim3((frames + 63) / 64), dim3(64), 0, st, ext_inv, k, frames, tgt);
   return track_loss_launch(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, mapping_kind, delta, aspect_x,
                            aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                           TrackSampling{depth, kinv, depth_frame0, own_first, own_end, nullptr, nullptr, nullptr, 0}, st);
+                           TrackSampling{depth, kinv, depth_frame0, own_first, own_end, nullptr, nullptr, nullptr}, st);
 }
 
 int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const float* ext, const float* ext_inv, const float* k, int frames,
@@ -1213,9 +1022,8 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
                                  uint8_t* flag, float* tgt, float* partial, double* acc, float* loss, float* scale, double* totals, float* gws,
                                  double* acc2, const int32_t* tap_slot, const float* tap_depth, const int64_t* plan_pixels,
                                  const int32_t* plan_first, const int32_t* plan_entries, const float* plan_weights, long plan_count,
-                                 const int32_t* shared_ranks, long shared_count, float* tap_grad, int presampled, void* stream) {
+                                 const int32_t* shared_ranks, long shared_count, float* tap_grad, void* stream) {
   FM_CHECK_ARG(depth && kinv && ext && ext_inv && k && xy && vis && seg && tiles && ws && flag && tgt && partial && acc && loss && scale);
-  FM_CHECK_ARG(presampled == 0 || presampled == 1);
   FM_CHECK_ARG(ntiles >= 1 && pmax >= 1 && fmax >= 1 && frames >= 1 && mapping_kind >= 0 && mapping_kind <= 2);
   FM_CHECK_ARG((gws == nullptr) == (acc2 == nullptr) && (tap_depth == nullptr || tap_slot != nullptr));
   FM_CHECK_ARG(tap_grad == nullptr || (gws && plan_pixels && plan_first && plan_entries && plan_weights && plan_count >= 0));
@@ -1226,7 +1034,7 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
   float* direct = (tap_grad != nullptr && shared_ranks != nullptr) ? tap_grad : nullptr;
   const int status = track_loss_launch(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, mapping_kind, delta,
                                        aspect_x, aspect_y, weight, partial, acc, loss, scale, totals, gws, acc2,
-                                       TrackSampling{presampled ? nullptr : depth, kinv, 0, 0, frames, tap_slot, tap_depth, direct, presampled}, st);
+                                       TrackSampling{depth, kinv, 0, 0, frames, tap_slot, tap_depth, direct}, st);
   if (status != FM_OK || tap_grad == nullptr) return status;
   const long count = direct ? shared_count : plan_count;
   if (count == 0) return status;

@@ -38,8 +38,9 @@ extern "C" {
  * fm_flow_loss_fused / fm_procrustes_fit_chain are self-cleaning — zero on entry, left zero — instead of being cleared by the
  * call; fm_scale_if_needed reports a non-unit scalar; round 4, version 4: the tap exchange entry
  * points fm_flow_loss_fused_taps / fm_track_loss_fused_fwd_taps / fm_tap_grad_apply; round 5, version 5: fm_tap_grad_apply reports a
- * non-zero correction through a device flag; fm_track_presample and the `presampled` argument of fm_track_loss_fused_fwd_taps).  A binding checks fm_abi_version() == FM_ABI_VERSION when it loads the library. */
-#define FM_ABI_VERSION 5
+ * non-zero correction through a device flag; fm_track_presample and the `presampled` argument of fm_track_loss_fused_fwd_taps; round 6,
+ * version 6: that entry point and that argument are gone again — measured, not adopted: docs/history/patches/r05_track_presample.patch).  A binding checks fm_abi_version() == FM_ABI_VERSION when it loads the library. */
+#define FM_ABI_VERSION 6
 int fm_abi_version(void);
 
 #define FM_STAT_STRIDE 16      /* doubles per pair in `stats` */
@@ -424,18 +425,7 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
                                  uint8_t* flag, float* tgt, float* partial, double* acc, float* loss, float* scale, double* totals, float* gws,
                                  double* acc2, const int32_t* tap_slot, const float* tap_depth, const int64_t* plan_pixels,
                                  const int32_t* plan_first, const int32_t* plan_entries, const float* plan_weights, long plan_count,
-                                 const int32_t* shared_ranks, long shared_count, float* tap_grad, int presampled, void* stream);
-/* Round 5 — the camera-space half of the tracking loss's sampling as a launch of its own (projection.py:266-272: bilinearly sample the
- * surfaces at the track positions; here xyz = Σ_k w_k·z_k·K⁻¹[u_k, v_k, 1] and h = Σ_k w_k·z_k·[u_k, v_k, 1] per (segment, frame, point),
- * into planes 0-2 / 6-8 of `ws`, and the visibility flag).  It needs depth (or the compact tap image: tap_slot + tap_depth as above) and K⁻¹
- * but NOT the poses, so a caller launches it on a second stream beside fm_procrustes_fit_chain — which produces the poses and leaves
- * a hundred CUs idle — and then calls fm_track_loss_fused_fwd_taps with presampled = 1 and the same ws / flag: the pair kernel reads xyz
- * coalesced and applies the pose instead of every wave waiting for its cold gathers in its prologue.  Whole video (depth_frame0 = 0, every
- * source frame owned).  blocks (nblocks, 2): the (segment, local frame) entries of the packed tracks (as fm_track_points takes them).
- * presampled = 0: fm_track_loss_fused_fwd_taps samples in its prologue as before. */
-int fm_track_presample(const float* depth, const float* kinv, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks,
-                       int nblocks, int pmax, int height, int width, const int32_t* tap_slot, const float* tap_depth, float* ws, uint8_t* flag,
-                       void* stream);
+                                 const int32_t* shared_ranks, long shared_count, float* tap_grad, void* stream);
 /* grad_depth[pixels[m]] += scale[0]·(plus − minus)·tap_grad[m] for the M taps (plus / minus: device scalars, NULL = 0); no memory is
  * touched when the factor is 0.  The correction of the tap exchange when the tracking loss's upstream gradient (plus) differs from
  * the factor the flow pass's copy of it was delivered with (minus), and the plain scatter (minus NULL) when nothing was delivered.

@@ -1453,65 +1453,6 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=1e-3, softmin=False, exch
     assert float((ref[-1][0] - ref[0][0]).abs().max()) > 5e-3
 
 
-def case_track_presample(dev):
-    """The tracking loss's camera-space sampling launched beside the Procrustes fit (fm_track_presample on a second stream, then
-    fm_track_loss_fused_fwd_taps with presampled = 1: _ops.track_presample): from the second step on, with the tap exchange on and off (sampling
-    the compact tap image / the depth images), the loss and every gradient are those of the step that samples in the pair kernel's prologue —
-    bit for bit on the host double, to the atomics' order on the GPU — and a track list that changes between steps falls back cleanly."""
-    import flowmap_amd
-    from flowmap_amd import _ops
-    from flowmap_amd.loss import LossFlow, LossFlowCfg, LossTracking, LossTrackingCfg
-    from helpers import to_tracks
-
-    f, h, w = 6, 24, 32
-    saved = (_ops.tap_exchange_min_bytes, _ops.track_presample_min_bytes, _ops.use_track_presample, _ops.use_tap_exchange)
-    try:
-        sc = orc.synth_scene(f, h, w, seed=33)
-        otracks = orc.synth_tracks(f, h, w, scene=sc, seed=33, interval=2, radius=2, grid=5)
-        other = orc.synth_tracks(f, h, w, scene=sc, seed=7, interval=3, radius=1, grid=4)
-
-        def loop(presample, exchange, steps=4, swap_at=None):
-            _ops.tap_exchange_min_bytes, _ops.track_presample_min_bytes = 0, 0
-            _ops.use_track_presample, _ops.use_tap_exchange = presample, exchange
-            model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False, seed=33)
-            tracks, second = to_tracks(otracks, dev), to_tracks(other, dev)
-            flow_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
-            track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", mapping_cfg("huber")))
-            before = dict(_ops.counters)
-            out_steps = []
-            for step in range(steps):
-                use = second if (swap_at is not None and step >= swap_at) else tracks
-                model.zero_grad(set_to_none=True)
-                out = model(batch, flows, step)
-                total = flow_fn(batch, flows, use, out, step) + track_fn(batch, flows, use, out, step)
-                total.backward()
-                out_steps.append([x.detach().clone() for x in (total, out.extrinsics, model.backbone.depth.grad, model.backbone.weights.grad,
-                                                               model.intrinsics.focal_length.grad)])
-            return out_steps, {k: _ops.counters[k] - before.get(k, 0) for k in ("track_presamples", "track_presampled_losses", "track_tap_samples")}
-
-        for exchange in (False, True):
-            plain, n0 = loop(False, exchange)
-            pre, n1 = loop(True, exchange)
-            assert n0["track_presamples"] == 0 and n1["track_presamples"] == 3 and n1["track_presampled_losses"] == 3, (n0, n1)
-            assert n1["track_tap_samples"] == n0["track_tap_samples"]  # (the image is sampled when it is valid, presampled or not)
-            for step, (a, b) in enumerate(zip(pre, plain)):
-                for x, y, what in zip(a, b, ("loss", "extrinsics", "g_depth", "g_weights", "g_focal")):
-                    if str(dev) == "cpu":
-                        assert torch.equal(x, y), (exchange, step, what, float((x - y).abs().max()))
-                    else:
-                        assert_close(x, y, 2e-6, abs_=1e-9, what=f"{what} (step {step}, exchange {exchange})")
-        # another track list from step 2 on: the request of step 1 names the old packed set — its samples are not used for the new list
-        plain, _ = loop(False, True, steps=5, swap_at=2)
-        pre, n = loop(True, True, steps=5, swap_at=2)
-        assert n["track_presampled_losses"] >= 2 and n["track_presamples"] >= n["track_presampled_losses"]
-        for step, (a, b) in enumerate(zip(pre, plain)):
-            for x, y, what in zip(a, b, ("loss", "extrinsics", "g_depth", "g_weights", "g_focal")):
-                assert_close(x, y, 2e-6 if str(dev) != "cpu" else 0.0, abs_=1e-9 if str(dev) != "cpu" else 0.0, what=f"{what} (step {step}, tracks swapped)")
-    finally:
-        _ops.tap_exchange_min_bytes, _ops.track_presample_min_bytes, _ops.use_track_presample, _ops.use_tap_exchange = saved
-        flowmap_amd.set_lazy_surfaces(False)
-
-
 def case_in_pass_adam_exchange_unequal_upstreams(dev):
     """the tap exchange + FusedAdam.fuse_depth_update with the two losses reaching backward() under DIFFERENT upstream
     gradients (`flow + 3·tracking`).  The absorbing flow pass has then applied the depth update at the taps with the tracking gradient at

@@ -57,7 +57,7 @@ def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="h
 
     f = depth.shape[0]
     flowmap_amd.set_lazy_surfaces(lazy)
-    min_bytes, presample_min = _ops.tap_exchange_min_bytes, _ops.track_presample_min_bytes
+    min_bytes = _ops.tap_exchange_min_bytes
     try:
         cfg = ModelCfg(
             BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
@@ -76,7 +76,6 @@ def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="h
             losses.append(LossTracking(LossTrackingCfg(0, track_weight, "tracking", mapping_cfg(kind))))
         if steps > 1:
             _ops.tap_exchange_min_bytes = 0  # (a repeated step is asked for to exercise the tap exchange, whatever the size)
-            _ops.track_presample_min_bytes = 0  # ... and the tracking loss's sampling beside the fit (from the second step on)
         for _ in range(steps):
             model.zero_grad(set_to_none=True)
             out = model(batch, flows, 0)
@@ -95,7 +94,6 @@ def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="h
     finally:
         flowmap_amd.set_lazy_surfaces(False)
         _ops.tap_exchange_min_bytes = min_bytes
-        _ops.track_presample_min_bytes = presample_min
 
 
 def run_oracle(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="huber", dtype=torch.float32,

@@ -1241,12 +1241,9 @@ int fm_extrinsics_inverse(const float* ext, int count, float* inv, void*) {
   return 0;
 }
 
-// mode 0: sample and apply the pose (the whole record); 1: the camera-space half only (fm_track_presample: xyz, h, flag — no pose, no targets);
-// 2: the pose applied to an xyz that mode 1 left (fm_track_loss_fused_fwd_taps with presampled = 1)
 static int sim_track_points(const float* depth, int depth_frame0, const float* kinv, const float* ext, const float* ext_inv, const float* k,
                             int frames, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks,
-                            int height, int width, float* ws, uint8_t* flag, float* tgt, const int32_t* tap_slot, const float* tap_depth,
-                            int mode = 0);
+                            int height, int width, float* ws, uint8_t* flag, float* tgt, const int32_t* tap_slot, const float* tap_depth);
 
 int fm_track_points(const float* depth, int depth_frame0, const float* kinv, const float* ext, const float* ext_inv, const float* k,
                     int frames, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks, int,
@@ -1258,10 +1255,8 @@ int fm_track_points(const float* depth, int depth_frame0, const float* kinv, con
 // tap_slot / tap_depth: the tap depths come from the compact tap image (slot >= 0), are zero (slot -1) or are read from `depth` (slot <= -2)
 static int sim_track_points(const float* depth, int depth_frame0, const float* kinv, const float* ext, const float* ext_inv, const float* k,
                             int frames, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks, int nblocks,
-                            int height, int width, float* ws, uint8_t* flag, float* tgt, const int32_t* tap_slot, const float* tap_depth,
-                            int mode) {
-  if (mode != 1)
-    for (int fr = 0; fr < frames; ++fr) track_target(ext_inv + (size_t)fr * 16, k + (size_t)fr * 9, tgt + (size_t)fr * kTrackTgt);
+                            int height, int width, float* ws, uint8_t* flag, float* tgt, const int32_t* tap_slot, const float* tap_depth) {
+  for (int fr = 0; fr < frames; ++fr) track_target(ext_inv + (size_t)fr * 16, k + (size_t)fr * 9, tgt + (size_t)fr * kTrackTgt);
   for (int blk = 0; blk < nblocks; ++blk) {
     const int sg = blocks[blk * 2], fl = blocks[blk * 2 + 1];
     const int start = seg[sg * 4], pc = seg[sg * 4 + 2], off = seg[sg * 4 + 3];
@@ -1269,16 +1264,10 @@ static int sim_track_points(const float* depth, int depth_frame0, const float* k
     Mat3 ki;
     Pose e;
     load_mat3(kinv + (size_t)frame * 9, ki);
-    if (mode != 1) load_pose44(ext + (size_t)frame * 16, e);
+    load_pose44(ext + (size_t)frame * 16, e);
     const float* d = depth + (size_t)(frame - depth_frame0) * height * width;
     for (int p = 0; p < pc; ++p) {
       const size_t idx = (size_t)off + (size_t)fl * pc + p;
-      if (mode == 2) {  // xyz, h and the flag are there: X_w = pose · xyz
-        float xw[3];
-        apply_pose(e, ws + idx * kTrackWs, xw);
-        for (int a = 0; a < 3; ++a) ws[idx * kTrackWs + 3 + a] = xw[a];
-        continue;
-      }
       const float qx = xy[idx * 2], qy = xy[idx * 2 + 1];
       const Taps t = bilinear_taps(qx, qy, height, width);
       float xyz[3] = {0, 0, 0}, hh[3] = {0, 0, 0};
@@ -1298,8 +1287,8 @@ static int sim_track_points(const float* depth, int depth_frame0, const float* k
         hh[1] += z * vt * t.w[k];
         hh[2] += z * t.w[k];
       }
-      float xw[3] = {0.f, 0.f, 0.f};
-      if (mode != 1) apply_pose(e, xyz, xw);
+      float xw[3];
+      apply_pose(e, xyz, xw);
       for (int a = 0; a < 3; ++a) {
         ws[idx * kTrackWs + a] = xyz[a];
         ws[idx * kTrackWs + 3 + a] = xw[a];
@@ -1406,9 +1395,8 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
                                  float* tgt, float* partial, double* acc, float* loss, float* scale, double* totals, float* gws, double* acc2,
                                  const int32_t* tap_slot, const float* tap_depth, const int64_t* plan_pixels, const int32_t* plan_first,
                                  const int32_t* plan_entries, const float* plan_weights, long plan_count, const int32_t* shared_ranks,
-                                 long shared_count, float* tap_grad, int presampled, void* stream) {
+                                 long shared_count, float* tap_grad, void* stream) {
   if (tap_depth != nullptr && tap_slot == nullptr) return 1;
-  if (presampled != 0 && presampled != 1) return 1;
   if (shared_ranks != nullptr && (tap_slot == nullptr || shared_count < 0 || shared_count > plan_count)) return 1;
   if (shared_ranks != nullptr && tap_grad != nullptr) {  // the list must name exactly the taps with more than one plan entry, and the slots say so too
     long seen = 0;
@@ -1430,7 +1418,7 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
     }
   }
   if (sim_track_points(depth, 0, kinv, ext, ext_inv, k, frames, xy, vis, seg, blocks.data(), (int)(blocks.size() / 2), height, width, ws, flag, tgt,
-                       tap_slot, tap_depth, presampled ? 2 : 0) != 0)
+                       tap_slot, tap_depth) != 0)
     return 2;
   if (fm_track_loss_fwd(ws, flag, xy, vis, seg, tiles, ntiles, pmax, fmax, ext, tgt, frames, height, width, kind, delta, ax, ay, weight, partial, acc,
                         loss, scale, totals, gws, acc2, stream) != 0)
@@ -1452,14 +1440,6 @@ int fm_track_loss_fused_fwd_taps(const float* depth, const float* kinv, const fl
     tap_grad[m] = sum;
   }
   return 0;
-}
-
-int fm_track_presample(const float* depth, const float* kinv, const float* xy, const uint8_t* vis, const int32_t* seg, const int32_t* blocks,
-                       int nblocks, int pmax, int height, int width, const int32_t* tap_slot, const float* tap_depth, float* ws, uint8_t* flag, void*) {
-  if (!(depth && kinv && xy && vis && seg && blocks && ws && flag) || nblocks < 1 || pmax < 1 || height < 1 || width < 1) return 1;
-  if (tap_depth != nullptr && tap_slot == nullptr) return 1;
-  return sim_track_points(depth, 0, kinv, nullptr, nullptr, nullptr, 0, xy, vis, seg, blocks, nblocks, height, width, ws, flag, nullptr,
-                          tap_depth ? tap_slot : nullptr, tap_depth, 1);
 }
 
 int fm_tap_grad_apply(const float* tap_grad, const int64_t* pixels, long count, const float* scale, const float* upstream_plus,

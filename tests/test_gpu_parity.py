@@ -448,11 +448,6 @@ def test_depth_adam_update_inside_the_flow_pass_follows_torch_adam():
 
 
 @pytest.mark.gpu
-def test_tracking_sampling_beside_the_fit_changes_nothing():
-    cases.case_track_presample(DEV)
-
-
-@pytest.mark.gpu
 def test_in_pass_adam_with_the_tap_exchange_is_loud_about_unequal_upstreams():
     cases.case_in_pass_adam_exchange_unequal_upstreams(DEV)
 

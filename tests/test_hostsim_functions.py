@@ -160,10 +160,6 @@ def test_tap_exchange():
     cases.case_tap_exchange("cpu")
 
 
-def test_tracking_sampling_beside_the_fit_changes_nothing():
-    cases.case_track_presample("cpu")
-
-
 def test_in_pass_adam_with_the_tap_exchange_is_loud_about_unequal_upstreams():
     cases.case_in_pass_adam_exchange_unequal_upstreams("cpu")
 

@@ -17,12 +17,7 @@ ap.add_argument("--count", type=int, default=150)
 ap.add_argument("--seed", type=int, default=11)
 ap.add_argument("--steps", type=int, default=1)
 ap.add_argument("--tracks", action="store_true")
-ap.add_argument("--presample", action="store_true", help="with --steps > 1 --tracks: the tracking loss's sampling beside the fit (flowmap_amd._ops.use_track_presample, off by default)")
 args = ap.parse_args()
-if args.presample:
-    from flowmap_amd import _ops as _fm_ops
-
-    _fm_ops.use_track_presample = True
 if args.device == "cpu":
     from flowmap_amd import _lib
     from helpers import build_host_sim
@@ -49,8 +44,7 @@ for cfg in cases:
             engaged += int(_ops.counters["flow_tap_absorbs"] > before)
     except AssertionError as exc:
         failed.append((cfg, str(exc)[:200]))
-print(f"{len(cases) - len(failed)} / {len(cases)} cases passed" + (f"; the flow pass absorbed the tracking loss's tap gradients in {engaged} of them" if args.steps > 1 else "")
-      + (f"; {_fm_ops.counters['track_presampled_losses']} tracking losses used points sampled beside the fit" if args.presample else ""))
+print(f"{len(cases) - len(failed)} / {len(cases)} cases passed" + (f"; the flow pass absorbed the tracking loss's tap gradients in {engaged} of them" if args.steps > 1 else ""))
 for cfg, msg in failed:
     print("FAILED", cfg, msg)
 sys.exit(1 if failed else 0)
