@@ -593,7 +593,7 @@ def main():
         raise SystemExit("--graph compute: a frame-sharded run of the flow loss with regressed intrinsics (the tracking loss and the softmin sweep have collectives inside forward / backward)")
     flowmap_amd.set_lazy_surfaces(True)
     if args.no_tap_exchange:
-        _ops.use_tap_exchange = False
+        _ops.options.tap_exchange = False
     if os.environ.get("FLOWMAP_THREE_LAUNCH_BWD"):  # A/B: the planned Procrustes backward as the three launches of round 2
         from flowmap_amd._lib import torch_ops
 
@@ -755,11 +755,11 @@ def main():
     if os.environ.get("FLOWMAP_TAP_EXCHANGE_MIN_BYTES"):  # A/B: the depth size from which the tap exchange engages (default 128 MB, flowmap_amd/_ops.py)
         from flowmap_amd import _ops as _fm_ops
 
-        _fm_ops.tap_exchange_min_bytes = int(os.environ["FLOWMAP_TAP_EXCHANGE_MIN_BYTES"])
+        _fm_ops.options.tap_exchange_min_bytes = int(os.environ["FLOWMAP_TAP_EXCHANGE_MIN_BYTES"])
     if os.environ.get("FLOWMAP_PLAIN_LOSS"):  # A/B: the losses as plain tensors (autograd's ones_like fill + the flow loss's seed check: two more launches)
         from flowmap_amd import _ops as _fm_ops
 
-        _fm_ops.use_unit_seed = False
+        _fm_ops.options.unit_seed = False
     if gc_when == "first":
         flowmap_amd.freeze_gc()
     # one-time precompute, outside warm-up and timing whatever W is: the first step packs the constant

@@ -16,7 +16,7 @@ SURVEY.md §8b "CPU tensors -> the reference-equivalent torch path", BASELINE.js
 GPU tensors never reach it, and without ``install()`` there is nothing to hand over to.
 """
 
-from . import flow, loss, model  # noqa: F401
+from . import config, flow, loss, model  # noqa: F401
 from .install import install, uninstall  # noqa: F401
 from .model.projection import set_lazy_surfaces  # noqa: F401
 from .graph import GraphedShardedStep, GraphedStep  # noqa: F401
@@ -26,6 +26,6 @@ from .optim import FusedAdam  # noqa: F401
 from .types import BackboneOutput, Batch, Flows, ModelOutput, Tracks  # noqa: F401
 
 __all__ = [
-    "loss", "model", "install", "uninstall", "set_lazy_surfaces", "FusedAdam", "GraphedStep", "GraphedShardedStep", "freeze_gc", "release_flow_originals",
+    "config", "loss", "model", "install", "uninstall", "set_lazy_surfaces", "FusedAdam", "GraphedStep", "GraphedShardedStep", "freeze_gc", "release_flow_originals",
     "Batch", "BackboneOutput", "Flows", "ModelOutput", "Tracks",
 ]

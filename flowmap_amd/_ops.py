@@ -28,6 +28,7 @@ import torch
 from torch import Tensor
 
 from ._lib import call, check_device, ptr, stream_for, torch_ops
+from .config import options
 
 from ._base import (AUX_STRIDE, DENSE_CONST_STRIDE, FLOW_ACC_STRIDE, MAPPING_KINDS, PAIR_GRAD_STRIDE, STAT_STRIDE, TRACK_TILE, FmLayout,  # noqa: F401
                     _derived, _f32c, _guard, _layout_array, _unit_flags, check_unit_flags, frame_window_layout, register_unit_flag)
@@ -210,18 +211,7 @@ def touched_elements(depth: Tensor, whole_frames=(), exclude=()):
     return _derived(root, "_fm_touched_union" + ("_without_" + "_".join(str(id(x)) for x in exclude) if exclude else ""), key, build)[1:]
 
 
-# Persistent dL/dweights storage (GradArena) for sparse fits with a constant index set; False = fresh zeros every step
-use_grad_arena = True
-# Moments, finish + solve and the pose chain as ONE launch (fm_procrustes_fit_chain) instead of a memset and three kernels.
-use_fit_chain = True
-# Dense Procrustes (`num_points: null`) backward.  False = one fused pass over the later pixels, tap gradients summed in an LDS image of the
-# earlier-frame window and flushed with atomics (1.2 ms at 150 x 720x1280 when the flow varies by a few pixels inside a 32x64 tile — camera
-# motion —, but every tap that leaves the window is a scattered atomic: 2.2 ms on rough flows, 8 ms on i.i.d. ones); True = the static tap
-# lists (built once per flow tensor, 4 B per pixel and pair) and the planned pair of kernels without atomics (2.0-2.2 ms on ANY flow,
-# dL/ddepth bit-reproducible); None (default) = decided once per flow tensor by how much the flow varies inside the tiles.
-use_dense_plan = None
-# (auto) the planned kernels are chosen when more than this fraction of the tiles has flows leaving the fused pass's window
-dense_plan_rough_tiles = 0.25
+# (the switches that used to be module variables here — grad arena, one-launch fit, dense-plan choice — are flowmap_amd.config.options)
 
 
 def _dense_flow_is_rough(bwd_flow: Tensor, h: int, w: int) -> bool:
@@ -235,7 +225,7 @@ def _dense_flow_is_rough(bwd_flow: Tensor, h: int, w: int) -> bool:
         lo = -torch.nn.functional.max_pool2d(-fl, (32, 64), ceil_mode=True)
         spread = hi - lo
         rough = (spread[:, 0] * w > 12.0) | (spread[:, 1] * h > 6.0) | ~torch.isfinite(spread).all(dim=1)
-        return bool(rough.float().mean().item() > dense_plan_rough_tiles)
+        return bool(rough.float().mean().item() > options.dense_plan_rough_tiles)
 
     return _derived(bwd_flow, "_fm_dense_rough", (bwd_flow._version, h, w), build)
 
@@ -431,7 +421,7 @@ class ProcrustesFit:
                 b, f, h, w = depth.shape
                 if indices is None:
                     note_touched(depth, "procrustes", None)  # every pixel is a correspondence: nothing is left to an in-pass update
-                    planned = _dense_flow_is_rough(bwd_flow, h, w) if use_dense_plan is None else bool(use_dense_plan)
+                    planned = _dense_flow_is_rough(bwd_flow, h, w) if options.dense_plan is None else bool(options.dense_plan)
                     if planned and h <= 65535 and w <= 65535 and bwd_flow.is_contiguous():
                         dense = _dense_procrustes_plan(bwd_flow, b, f, h, w)
                         counters["procrustes_dense_planned"] += 1
@@ -441,12 +431,12 @@ class ProcrustesFit:
                     if plan is not None:
                         sparse = plan
                         counters["procrustes_planned"] += 1
-                        if use_grad_arena and torch.is_tensor(weights) and weights.requires_grad:
+                        if options.grad_arena and torch.is_tensor(weights) and weights.requires_grad:
                             arena = grad_arena(weights)
                             _note_sparse_grad(weights, arena, indices, h * w)
             wsink = weights.__dict__.get("_fm_sink")  # exists when the softmin sweep took LeadingFrames of the weights
         work = None
-        if chain and use_fit_chain and rep == 1 and indices is not None and bwd_flow.dim() == 5:
+        if chain and options.fit_chain and rep == 1 and indices is not None and bwd_flow.dim() == 5:
             pairs = bwd_flow.shape[0] * bwd_flow.shape[1]
             work = _derived(bwd_flow, "_fm_fit_work", (pairs, str(bwd_flow.device)),
                             lambda: torch.zeros((pairs * STAT_STRIDE + (pairs + 2) // 2 + 1,), dtype=torch.float64, device=bwd_flow.device))
@@ -509,11 +499,6 @@ def flow_valid_norm(mask_fwd: Tensor, mask_bwd: Tensor, weight: float, reducer=N
     return _derived(mask_fwd, "_fm_norm", key, build)[2]
 
 
-# The packed copy costs as much HBM as the flows and masks themselves (3.3 GB at C1); set to
-# False to stream the caller's tensors directly (tests exercise both kernels).
-use_packed_inputs = True
-# tests: pack the first time a set of flows is seen (a one-step test then runs the packed kernel instance)
-pack_on_first_sight = False
 
 
 def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mask_bwd: Tensor, eager: bool = False) -> Optional[Tensor]:
@@ -524,7 +509,7 @@ def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mas
     them; in the reference's pretraining loop every step brings a new ``Flows`` (model_wrapper_pretrain.py:46-71) and
     nothing is ever packed — the fused kernel streams the caller's tensors (its un-packed instance).  ``eager``: pack at
     first sight.  Kept on the forward-flow tensor and validated against the identity and version of all four tensors."""
-    if not use_packed_inputs:
+    if not options.packed_inputs:
         return None
     released = flow_fwd.__dict__.get("_fm_released_packed")
     if released is not None:
@@ -540,7 +525,7 @@ def packed_flow_inputs(flow_fwd: Tensor, flow_bwd: Tensor, mask_fwd: Tensor, mas
     if lay is None or any(lay[i].frame_stride % 4 or lay[i].batch_stride % 4 for i in range(4)):
         return None
     key = tuple((id(t), t._version, t.data_ptr()) for t in srcs) + (tuple(mask_fwd.shape),)
-    if not (eager or pack_on_first_sight):
+    if not (eager or options.pack_on_first_sight):
         slot = flow_fwd.__dict__.get("_fm_packed")
         if (slot is None or slot[0] != key) and flow_fwd.__dict__.get("_fm_packed_seen") != key:
             flow_fwd.__dict__["_fm_packed_seen"] = key  # first sighting: remember, stream directly
@@ -703,24 +688,8 @@ from ._preprocess import consistency_mask, flow_postprocess, resize_crop  # noqa
 from ._tracks import PackedTracks, TapPlan  # noqa: E402,F401
 
 
-# sample the tracking loss's tap depths from the image the flow pass leaves (while the parameter's version counter has not moved)
-use_tap_image = True
-# The exchange pays where the depth images are far larger than the last-level cache (256 MB of Infinity Cache on an MI355X): at 150 x 720p
-# (553 MB) the tracking loss's taps are cold lines and the exchange takes 0.08 ms off a 1.25 ms step; at the reference's default 180 x 240
-# (26 MB, cache-resident) there is nothing cold to avoid and its bookkeeping costs 0.05 ms.  Depth tensors below this size run as in round 3.
-tap_exchange_min_bytes = 128 << 20
-
-# the tap exchange between the fused flow loss and the fused tracking loss; False: both run as in round 3
-use_tap_exchange = True
-
-# The fused losses come back as RootLoss tensors (below); False: plain tensors, and a step pays autograd's ones_like fill and the flow
-# loss's is-the-seed-one launch again (two of the eight launches of a flow-only step)
-use_unit_seed = True
+# (tap image / tap exchange / unit seed / calling-thread backward: flowmap_amd.config.options)
 _unit_seeds: dict = {}
-# RootLoss.backward() runs autograd's nodes on the calling thread (no hand-over to the device's worker thread); FLOWMAP_AMD_BACKWARD_THREAD=engine: autograd's default
-import os as _os  # noqa: E402
-
-backward_on_calling_thread = _os.environ.get("FLOWMAP_AMD_BACKWARD_THREAD", "caller").lower() != "engine"
 
 
 class RootLoss(Tensor):
@@ -740,9 +709,9 @@ class RootLoss(Tensor):
     __torch_function__ = torch._C._disabled_torch_function_impl
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
-        if gradient is None and not create_graph and use_unit_seed and self.dim() == 0 and self.dtype == torch.float32:
+        if gradient is None and not create_graph and options.unit_seed and self.dim() == 0 and self.dtype == torch.float32:
             gradient = unit_seed(self.device)
-        if backward_on_calling_thread and not create_graph:
+        if options.backward_on_calling_thread and not create_graph:
             # autograd hands the nodes of GPU tensors to a worker thread per device and waits for it: two thread wake-ups around a backward
             # pass whose nodes only ENQUEUE a handful of kernels — where the host is the bottleneck (the reference's default resolution)
             # they are a measurable part of the step.  The nodes of a fused loss run just as well on the calling thread.
@@ -803,7 +772,7 @@ def unit_seed(device) -> Tensor:
 
 
 def as_root_loss(loss):
-    if type(loss) is not Tensor or not use_unit_seed or not loss.requires_grad or loss.dim() != 0:
+    if type(loss) is not Tensor or not options.unit_seed or not loss.requires_grad or loss.dim() != 0:
         return loss  # (also NotImplemented from a reflected operator)
     if loss.device not in _unit_seeds:
         unit_seed(loss.device)  # made outside any later graph capture
@@ -828,7 +797,7 @@ def _whole_parameter(depth: Tensor) -> Optional[Tensor]:
 
 def tap_plan_of(depth: Tensor) -> Optional[TapPlan]:
     """The TapPlan a tracking loss registered for the parameter behind ``depth`` (matching its shape), if any."""
-    if not use_tap_exchange or depth.numel() * 4 < tap_exchange_min_bytes:
+    if not options.tap_exchange or depth.numel() * 4 < options.tap_exchange_min_bytes:
         return None
     root = _whole_parameter(depth)
     plan = root.__dict__.get("_fm_tap_plan") if root is not None else None
@@ -903,8 +872,8 @@ class TrackLossFused:
         # the tap exchange: whole video local, gradients on — register the static tap set with the parameter (the flow pass then leaves the tap
         # depths in its compact image) and sample from that image while the parameter has not moved since
         taps = (None, None, None)
-        root = _whole_parameter(depth) if (use_tap_exchange and plan is not None and reducer is None and int(frame0) == 0 and defer
-                                           and depth.numel() * 4 >= tap_exchange_min_bytes) else None
+        root = _whole_parameter(depth) if (options.tap_exchange and plan is not None and reducer is None and int(frame0) == 0 and defer
+                                           and depth.numel() * 4 >= options.tap_exchange_min_bytes) else None
         if root is not None and root.__dict__.get("_fm_tap_exchange_off"):
             root = None
         if root is not None and root.is_leaf and ext.shape[1] == depth.shape[1]:
@@ -922,7 +891,7 @@ class TrackLossFused:
                 root.__dict__["_fm_tap_plan"] = tap_plan
                 root.__dict__["_fm_tap_owner_step"] = weakref.ref(depth)  # (the step's depth tensor: a second registration within the same step is a second loss)
                 taps = (tap_plan.slots, None, tap_plan.shared_ranks)
-                if use_tap_image and tap_plan.image_valid_for(root):
+                if options.tap_image and tap_plan.image_valid_for(root):
                     taps = (tap_plan.image_slots, tap_plan.image, tap_plan.shared_ranks)
                     tap_plan.note_sampled()
                     counters["track_tap_samples"] += 1

@@ -187,4 +187,4 @@ class TapPlan:
                 "flowmap_amd: the depth parameter was modified without its version counter moving (an edit through `.data`, a raw pointer): the "
                 "tracking loss sampled tap depths the last flow pass had left behind, and they were stale — the tracking loss and its gradients "
                 "of the affected steps are wrong.  Edit parameters in place under torch.no_grad() (as optimisers do), or set "
-                "flowmap_amd._ops.use_tap_image = False.")
+                "flowmap_amd._ops.options.tap_image = False.")

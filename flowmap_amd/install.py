@@ -45,7 +45,8 @@ _CROPPING_SITES = ("flowmap.overfit", "flowmap.model.model_wrapper_pretrain")
 
 
 def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postprocess: bool = True, fused_adam: bool = True,
-            cropping: bool = True, fused_regressed: bool = True, lazy_backbone: bool = True, graph: bool | None = None) -> None:
+            cropping: bool = True, fused_regressed: bool = True, lazy_backbone: bool = True, graph: bool | None = None,
+            options: dict | None = None) -> None:
     """Patch the reference in place.  ``lazy_surfaces=True`` additionally lets
     ``Model.forward``'s ``unproject`` hand a LazySurfaces to the fused consumers;
     ``fused_softmin=True`` registers the fused candidate sweep as INTRINSICS["softmin"]
@@ -66,7 +67,13 @@ def install(lazy_surfaces: bool = True, fused_softmin: bool = True, flow_postpro
     ``ModelWrapperOverfit.training_step`` (model_wrapper_overfit.py:51-73) to a step that replays the model's forward + the losses and the
     loss's ``backward()`` as two hipGraphs while the optimisation's host-side control flow stands still, and runs the reference's own method
     otherwise (flowmap_amd/training.py: what the reference's default ≈ 180×240 resolution needs, where the eager step is host-bound; videos
-    whose depth maps exceed 128 MB are HBM-bound and keep the eager step)."""
+    whose depth maps exceed 128 MB are HBM-bound and keep the eager step); ``options``: run-time switches of the package
+    (``flowmap_amd.config.Options`` field names: ``tap_exchange``, ``tap_exchange_min_bytes``, ``unit_seed``, ``packed_inputs``, …) set for the
+    rest of the process — the one place, with ``flowmap_amd.config``, where such switches live."""
+    if options:
+        from . import config
+
+        config.configure(**dict(options))
     from . import loss as our_loss
     from .loss import mapping as our_mapping
     from .model import procrustes as our_procrustes

@@ -60,7 +60,7 @@ class LossFlow(Loss[LossFlowCfg]):
     def _look_ahead(self, tracks, model_output, global_step: int) -> None:
         depths = model_output.surfaces.depths
         note = _ops._root(depths).__dict__.get("_fm_tracking_follows_flow")
-        if note is None or not (torch.is_grad_enabled() and depths.requires_grad) or not _ops.use_tap_exchange:
+        if note is None or not (torch.is_grad_enabled() and depths.requires_grad) or not _ops.options.tap_exchange:
             return
         follower, weight = note[0](), note[1]
         if follower is None or global_step < follower.cfg.enable_after or not follower._fusable(model_output, tracks):

@@ -199,7 +199,7 @@ class FusedAdam(torch.optim.Optimizer):
                     if sink.tap_absorbed() and not sink.tap_confirmed():
                         raise RuntimeError("flowmap_amd.FusedAdam: the flow pass applied the depth update with the tracking loss's gradient absorbed at its taps "
                                            "(the tap exchange), but that tracking loss never reached backward(): the update of those pixels used a gradient "
-                                           "that was not part of the loss.  Evaluate the losses the same way every step, or set flowmap_amd._ops.use_tap_exchange = False.")
+                                           "that was not part of the loss.  Evaluate the losses the same way every step, or set flowmap_amd._ops.options.tap_exchange = False.")
                     torch_ops().adam_step_elements(p, grad, state["exp_avg"], state["exp_avg_sq"], elements, step, *hyper)
                     tap_plan = p.__dict__.get("_fm_tap_plan")
                     if tap_plan is not None and tap_plan.pending_in_pass:

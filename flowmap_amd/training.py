@@ -162,10 +162,10 @@ class GraphedTraining:
             return None
         if any(step < fn.cfg.enable_after for fn in losses):
             return None
-        # From the size at which the tap exchange engages (depth beyond the last-level cache: 128 MB, _ops.tap_exchange_min_bytes) the step is
+        # From the size at which the tap exchange engages (depth beyond the last-level cache: 128 MB, _ops.options.tap_exchange_min_bytes) the step is
         # bound by HBM, the host's enqueue time hides behind the kernels, and whether the compact tap image is current is a per-step decision
         # of the host that a replay could not make: the eager step stays.
-        if backbone.depth.numel() * backbone.depth.element_size() >= _ops.tap_exchange_min_bytes:
+        if backbone.depth.numel() * backbone.depth.element_size() >= _ops.options.tap_exchange_min_bytes:
             return None
         params = list(wrapper.parameters())
         if any("_fm_fused_adam" in p.__dict__ for p in params):  # FusedAdam.fuse_depth_update: the update's step number is a host value
@@ -308,7 +308,7 @@ class GraphedTraining:
             total, self.values, self.errors = self.forward_on_aliases(wrapper, aliases, side_streams)
         if not isinstance(total, Tensor) or not total.requires_grad:
             raise RuntimeError("the step's total loss does not require gradients")
-        seed = _ops.unit_seed(total.device) if (_ops.use_unit_seed and total.dim() == 0 and total.dtype == torch.float32) else None
+        seed = _ops.unit_seed(total.device) if (_ops.options.unit_seed and total.dim() == 0 and total.dtype == torch.float32) else None
         with torch.cuda.graph(backward_graph, pool=self.forward_graph.pool(), capture_error_mode="thread_local"):
             grads = torch.autograd.grad([total], [aliases[name] for name, _ in named], None if seed is None else [seed], allow_unused=True)
         self.backward_graph = backward_graph

@@ -524,14 +524,14 @@ def case_packed_inputs(dev, hw=(18, 28)):
 
     res = {}
     for use in (True, False):
-        _ops.use_packed_inputs = use
-        _ops.pack_on_first_sight = True  # (a single step: the loss would otherwise stream the reference layout both times)
+        _ops.options.packed_inputs = use
+        _ops.options.pack_on_first_sight = True  # (a single step: the loss would otherwise stream the reference layout both times)
         packs = _ops.counters["flow_packs"]
         try:
             res[use] = run_ours(depth, wlogit, focal, oflows, (h, w), 100, device=dev)
         finally:
-            _ops.use_packed_inputs = True
-            _ops.pack_on_first_sight = False
+            _ops.options.packed_inputs = True
+            _ops.options.pack_on_first_sight = False
         # (on the host double `.to("cpu")` hands run_ours the very tensors packed above: the cached copy is then reused)
         assert _ops.counters["flow_packs"] - packs <= (1 if (use and w % 4 == 0) else 0)
     # identical arithmetic per residual; only the order of the float atomics differs run to run
@@ -911,11 +911,11 @@ def case_dense_procrustes(dev, h, w, flow_sigma, f=4):
     for name, idx, planned in (("tiled", None, False), ("tiled_planned", None, True), ("generic", torch.arange(h * w, device=dev), False)):
         d, kk, lg = (x.clone().to(dev).requires_grad_(True) for x in (depth, k, logits))
         fl_dev = flow.clone().to(dev)
-        _ops.use_dense_plan = planned
+        _ops.options.dense_plan = planned
         try:
             t_bwd, t_fwd = _ops.ProcrustesFit.apply(d, kk, None, lg, fl_dev, idx, 100.0, 1)
         finally:
-            _ops.use_dense_plan = None
+            _ops.options.dense_plan = None
         ((t_bwd * cot_b.to(dev)).sum() + (t_fwd * cot_f.to(dev)).sum()).backward()
         res[name] = (t_bwd.detach(), d.grad, lg.grad, kk.grad)
         assert ("_fm_dense_plan" in fl_dev.__dict__) == planned  # the fused pass (the default) builds no lists
@@ -995,7 +995,7 @@ def case_tap_exchange(dev):
         return {"sum": [lf + lt], "scaled": [2.0 * lf + 0.5 * lt], "flow_only": [lf], "track_only": [lt], "two_calls": [lf, lt]}[how]
 
     def run(exchange: bool, how: str, steps: int = 3, move_at=None, track_kind="huber"):
-        _ops.use_tap_exchange = exchange
+        _ops.options.tap_exchange = exchange
         model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False, seed=33)
         tracks = to_tracks(otracks, dev)
         flow_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
@@ -1018,8 +1018,8 @@ def case_tap_exchange(dev):
         return results, sinks
 
     names = ("loss_flow", "loss_tracking", "extrinsics", "g_depth", "g_wlogit", "g_focal")
-    min_bytes = _ops.tap_exchange_min_bytes
-    _ops.tap_exchange_min_bytes = 0  # (by default the exchange engages for depth tensors beyond the last-level cache only)
+    min_bytes = _ops.options.tap_exchange_min_bytes
+    _ops.options.tap_exchange_min_bytes = 0  # (by default the exchange engages for depth tensors beyond the last-level cache only)
     try:
         for how in ("sum", "scaled", "flow_only", "track_only", "two_calls"):
             before = dict(_ops.counters)
@@ -1047,7 +1047,7 @@ def case_tap_exchange(dev):
                 err = float((x - y).abs().max())
                 assert err <= 2e-6 * max(float(y.abs().max()), 1e-30), ("moved", step, what, err)
         # an edit behind the version counter (`param.data...`): the flow pass finds the image the tracking loss sampled stale — loudly
-        _ops.use_tap_exchange = True
+        _ops.options.tap_exchange = True
         model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False, seed=33)
         tracks = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=34, interval=2, radius=2, grid=6), dev)
         flow_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", mapping_cfg("huber")))
@@ -1071,15 +1071,15 @@ def case_tap_exchange(dev):
         for x, y, what in zip(got[-1], plain[-1], names):
             assert float((x - y).abs().max()) <= 2e-6 * max(float(y.abs().max()), 1e-30), ("l1", what)
     finally:
-        _ops.use_tap_exchange = True
-        _ops.tap_exchange_min_bytes = min_bytes
+        _ops.options.tap_exchange = True
+        _ops.options.tap_exchange_min_bytes = min_bytes
         flowmap_amd.set_lazy_surfaces(False)
 
 
 def case_step_torch_ops(dev):
     """What a step launches BESIDE the library's own kernels: the sum of the two losses and the two sums autograd forms where two consumers
     meet (dL/d extrinsics, dL/dK) — and nothing else: not even autograd's ones_like for loss.backward() (the losses are RootLoss tensors,
-    which seed their backward with the registered ones tensor; with `_ops.use_unit_seed = False` the fill is back).  In particular no zeros tensors
+    which seed their backward with the registered ones tensor; with `_ops.options.unit_seed = False` the fill is back).  In particular no zeros tensors
     materialised for the non-differentiable outputs of the custom functions (K^-1 of FocalIntrinsics, scale / totals of the tracking
     loss): each was a fill launch per step until round 3."""
     import flowmap_amd
@@ -1092,7 +1092,7 @@ def case_step_torch_ops(dev):
         from flowmap_amd._lib import torch_ops
 
         try:
-            _ops.use_unit_seed = tracking is not None  # (None: the plain-tensor path, flow only)
+            _ops.options.unit_seed = tracking is not None  # (None: the plain-tensor path, flow only)
             model, batch, flows, loss_of = _small_problem(dev, tracking=bool(tracking))
 
             def step():
@@ -1118,7 +1118,7 @@ def case_step_torch_ops(dev):
             assert seen == allowed, (tracking, seen)
             assert torch_ops().unit_seed_uses() - known_unit == int(tracking is not None)  # the flow loss's node knew its seed on the host
         finally:
-            _ops.use_unit_seed = True
+            _ops.options.unit_seed = True
             flowmap_amd.set_lazy_surfaces(False)
 
 
@@ -1148,10 +1148,10 @@ def case_root_loss(dev):
 
         for _ in range(3):
             grads_of(lambda loss: loss.backward())
-        _ops.use_unit_seed = False
+        _ops.options.unit_seed = False
         plain = grads_of(lambda loss: loss.backward())
         plain3 = grads_of(lambda loss: (3.0 * loss).backward())
-        _ops.use_unit_seed = True
+        _ops.options.unit_seed = True
 
         def same(got, want, what):
             for a, b in zip(got, want):
@@ -1206,7 +1206,7 @@ def case_root_loss(dev):
         with torch.no_grad():
             assert type(loss_of(model(batch, flows, 0))) is torch.Tensor  # nothing to seed without a graph
     finally:
-        _ops.use_unit_seed = True
+        _ops.options.unit_seed = True
         flowmap_amd.set_lazy_surfaces(False)
 
 
@@ -1220,7 +1220,7 @@ def case_grad_arena(dev):
     try:
         history = {}
         for arena in (False, True):
-            _ops.use_grad_arena = arena
+            _ops.options.grad_arena = arena
             model, batch, flows, loss_of = _small_problem(dev, tracking=False)
             steps = []
             for _ in range(5):  # step 1: atomics into zeros; step 2 builds the plan; from then on the arena
@@ -1256,7 +1256,7 @@ def case_grad_arena(dev):
         assert arena.refilled() == refills + 1
         assert_close(model.backbone.weights.grad, once[1], 2e-5, abs_=1e-7, what="g_weights after an in-place edit")
     finally:
-        _ops.use_grad_arena = True
+        _ops.options.grad_arena = True
         flowmap_amd.set_lazy_surfaces(False)
 
 
@@ -1361,15 +1361,15 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=1e-3, softmin=False, exch
     trajectories, engaged = {}, 0
     # ``exchange``: with the tap exchange forced on at this size — once the tracking loss runs, the flow pass absorbs its gradient, updates its
     # taps in the pass like any other pixel, and the next evaluation samples the image the update left (around the Procrustes pixels)
-    min_bytes, counted = _ops.tap_exchange_min_bytes, dict(_ops.counters)
-    _ops.tap_exchange_min_bytes = 0 if exchange else 1 << 60
+    min_bytes, counted = _ops.options.tap_exchange_min_bytes, dict(_ops.counters)
+    _ops.options.tap_exchange_min_bytes = 0 if exchange else 1 << 60
     # softmin: the reference's default intrinsics (config/model/intrinsics/softmin.yaml) — the sweep reads random pixels of
     # frames 0 / 1, new every step, then hands over to a regressed focal length; both phases and the hand-over are crossed
     intrinsics = IntrinsicsSoftminCfg("softmin", 200, 0.5, 2.0, 8, RegressionCfg(steps // 2, 5)) if softmin else None
     try:
         for mode in ("torch", "fused", "in_pass", "fused_dense"):
             torch.manual_seed(7)  # the sweep draws its pixels from torch's CPU generator
-            _ops.use_grad_arena = mode != "fused_dense"  # fused_dense: fresh zeros for dL/dweights, dense update of the logits
+            _ops.options.grad_arena = mode != "fused_dense"  # fused_dense: fresh zeros for dL/dweights, dense update of the logits
             model, batch, flows, _ = _small_problem(dev, f=f, h=h, w=w, tracking=False, intrinsics=intrinsics)
             sc = orc.synth_scene(f, h, w, seed=21)
             tracks = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=21, interval=2, radius=2, grid=5), dev)
@@ -1395,8 +1395,8 @@ def case_in_pass_adam(dev, steps=40, track_after=6, lr=1e-3, softmin=False, exch
             trajectories[mode] = (history, optimizer, model)
     finally:
         flowmap_amd.set_lazy_surfaces(False)
-        _ops.use_grad_arena = True
-        _ops.tap_exchange_min_bytes = min_bytes
+        _ops.options.grad_arena = True
+        _ops.options.tap_exchange_min_bytes = min_bytes
     if exchange:
         tracked_steps = steps - track_after
         # per mode: the first tracked step runs in the plain order, every later one ahead of the flow pass; with the in-pass update the image
@@ -1465,8 +1465,8 @@ def case_in_pass_adam_exchange_unequal_upstreams(dev):
     from helpers import to_tracks
 
     f, h, w = 5, 24, 32
-    min_bytes = _ops.tap_exchange_min_bytes
-    _ops.tap_exchange_min_bytes = 0
+    min_bytes = _ops.options.tap_exchange_min_bytes
+    _ops.options.tap_exchange_min_bytes = 0
     try:
         sc = orc.synth_scene(f, h, w, seed=21)
         tracks = to_tracks(orc.synth_tracks(f, h, w, scene=sc, seed=21, interval=2, radius=2, grid=5), dev)
@@ -1508,7 +1508,7 @@ def case_in_pass_adam_exchange_unequal_upstreams(dev):
         assert float((d_ours - d_ref).abs().max()) <= 4e-6 * float(d_ref.abs().max()), float((d_ours - d_ref).abs().max())
     finally:
         flowmap_amd.set_lazy_surfaces(False)
-        _ops.tap_exchange_min_bytes = min_bytes
+        _ops.options.tap_exchange_min_bytes = min_bytes
 
 
 def case_in_pass_adam_refusals(dev):

@@ -57,7 +57,7 @@ def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="h
 
     f = depth.shape[0]
     flowmap_amd.set_lazy_surfaces(lazy)
-    min_bytes = _ops.tap_exchange_min_bytes
+    min_bytes = _ops.options.tap_exchange_min_bytes
     try:
         cfg = ModelCfg(
             BackboneExplicitDepthCfg("explicit_depth", 1.0, 100.0),
@@ -75,7 +75,7 @@ def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="h
         if tracks is not None:
             losses.append(LossTracking(LossTrackingCfg(0, track_weight, "tracking", mapping_cfg(kind))))
         if steps > 1:
-            _ops.tap_exchange_min_bytes = 0  # (a repeated step is asked for to exercise the tap exchange, whatever the size)
+            _ops.options.tap_exchange_min_bytes = 0  # (a repeated step is asked for to exercise the tap exchange, whatever the size)
         for _ in range(steps):
             model.zero_grad(set_to_none=True)
             out = model(batch, flows, 0)
@@ -93,7 +93,7 @@ def run_ours(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="h
         }
     finally:
         flowmap_amd.set_lazy_surfaces(False)
-        _ops.tap_exchange_min_bytes = min_bytes
+        _ops.options.tap_exchange_min_bytes = min_bytes
 
 
 def run_oracle(depth, wlogit, focal, oflows, hw, num_points, otracks=None, kind="huber", dtype=torch.float32,

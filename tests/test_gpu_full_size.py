@@ -312,7 +312,7 @@ def test_c4_whole_1200x1080x1920_on_one_gpu():
                   torch.rand((1, f - 1, h, w), device=DEV, generator=g), torch.rand((1, f - 1, h, w), device=DEV, generator=g))
     assert depth.numel() > 2**31 and flows.forward.numel() > 2**32
 
-    _ops.pack_on_first_sight = True
+    _ops.options.pack_on_first_sight = True
     try:
         whole = _gpu_step(depth, wlogit, flows, (h, w), p)
         assert flows.forward.__dict__.get("_fm_packed") is not None, "the whole-video step did not run the packed kernel"
@@ -372,4 +372,4 @@ def test_c4_whole_1200x1080x1920_on_one_gpu():
         for key in ("g_depth", "g_depth[procrustes]", "g_wlogit"):
             assert record["window_" + key] <= max(1e-4, 2.0 * record["window_" + key + "_fp32_reference_gap"]), (key, record)
     finally:
-        _ops.pack_on_first_sight = False
+        _ops.options.pack_on_first_sight = False

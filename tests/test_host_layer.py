@@ -243,3 +243,25 @@ def test_errors_of_the_preparation_and_intrinsics_entry_points_are_loud():
     k_soft, soft = _ops.softmin_intrinsics(depth, w, bwd, idx, cand, rel, 0.0, 3)
     assert k_soft.shape == (1, 3, 3, 3) and soft.shape == (1, 4) and abs(float(soft.sum()) - 1) < 1e-6
     assert Batch(videos).intrinsics is None
+
+
+def test_options_live_in_one_object():
+    """flowmap_amd.config (round 6): the run-time switches are fields of ONE object — set through install(options=...) / configure(), scoped with
+    override(); `_ops` reads that very object at call time; an unknown name raises instead of silently doing nothing."""
+    import flowmap_amd
+    from flowmap_amd import _ops, config
+
+    assert _ops.options is config.options and config.options.tap_exchange is True and config.options.tap_exchange_min_bytes == 128 << 20
+    with config.override(tap_exchange=False, tap_exchange_min_bytes=0) as inside:
+        assert inside is config.options and not _ops.options.tap_exchange and _ops.options.tap_exchange_min_bytes == 0
+        with pytest.raises(AttributeError):
+            config.configure(tap_exchnge=True)
+    assert config.options.tap_exchange and config.options.tap_exchange_min_bytes == 128 << 20  # restored
+    with pytest.raises(AttributeError):
+        with config.override(no_such_option=1):
+            pass
+    assert not hasattr(_ops, "use_tap_exchange") and not hasattr(_ops, "use_unit_seed")  # (the module-level variables of rounds 1-5 are gone)
+    assert config.defaults() == config.Options()
+    import inspect
+
+    assert "options" in inspect.signature(flowmap_amd.install).parameters

@@ -42,7 +42,7 @@ def test_install_graph_rebinds_training_step_and_uninstall_restores_it(standin):
     try:
         assert ref_wrapper.ModelWrapperOverfit.training_step is not original
         assert ref_wrapper.ModelWrapperOverfit.training_step.__wrapped__ is original
-        assert _ops.use_tap_image is True  # (untouched: graphs exist only below the size at which the tap exchange engages)
+        assert _ops.options.tap_image is True  # (untouched: graphs exist only below the size at which the tap exchange engages)
     finally:
         flowmap_amd.uninstall()
     assert ref_wrapper.ModelWrapperOverfit.training_step is original
@@ -216,11 +216,11 @@ def test_the_state_machine_around_the_graphs(standin):
         assert state.signature(wrapper) is not None
         from flowmap_amd import _ops
 
-        previous, _ops.tap_exchange_min_bytes = _ops.tap_exchange_min_bytes, wrapper.model.backbone.depth.numel() * 4
+        previous, _ops.options.tap_exchange_min_bytes = _ops.options.tap_exchange_min_bytes, wrapper.model.backbone.depth.numel() * 4
         try:  # depth maps from the size at which the tap exchange engages: HBM-bound, the eager step stays
             assert state.signature(wrapper) is None
         finally:
-            _ops.tap_exchange_min_bytes = previous
+            _ops.options.tap_exchange_min_bytes = previous
         assert state.signature(wrapper) is not None
         assert isinstance(training.make_training_step(eager).__wrapped__, type(eager))
     finally:
