@@ -444,6 +444,14 @@ def default_ate_fixture():
     return None
 
 
+def c0_ate_fixture():
+    """BASELINE.json configs[0] (16 frames @ 256x256) on the reference's REAL schedule (config/overfit.yaml:24-31: 2000 Adam steps at lr 3e-5;
+    config/model/intrinsics/softmin.yaml:13-14: hand-over after step 1000, window 100; config/loss/tracking.yaml:4-6: tracking from step 50;
+    config/tracking/cotracker.yaml:3: 35 x 35 tracks), run once by the imported reference (oracle/make_ate_reference.py, 17 min on 4 host threads)."""
+    path = ROOT / "tests" / "golden" / "ate_c0_16x256x256_full_schedule_imported_reference.json"
+    return path if path.exists() else None
+
+
 def _cpu_frames(args, f_video, h, w):
     """Frames of the CPU-baseline leg: the whole video when it is no bigger than 1.25 x the headline workload and the host has the memory
     (one iteration of 150 x 720p takes the oracle ~40 GB and ~25 s), else a 32-frame sample from the front of the same inputs."""
@@ -1009,6 +1017,13 @@ def main():
                 result["ate"] = ate_leg(device, fixture)
             except Exception as exc:  # noqa: BLE001  (the timing line must not be lost to the comparison leg)
                 result["ate"] = {"measured_by_this_run": False, "failed": repr(exc)[:400]}
+        if want_ate and c0_ate_fixture() is not None:
+            # ... and the one place where the softmin window, the `enable_after` gate and all 2000 Adam steps of the reference's schedule meet the
+            # reference end to end: configs[0] on config/overfit.yaml's own schedule
+            try:
+                result["ate_c0_full_schedule"] = ate_leg(device, c0_ate_fixture())
+            except Exception as exc:  # noqa: BLE001
+                result["ate_c0_full_schedule"] = {"measured_by_this_run": False, "failed": repr(exc)[:400]}
         if args.default_resolution == "on" or (args.default_resolution == "auto" and want_ate and wrapper is None):
             result["default_resolution"] = default_resolution_leg()
         quoted = {}

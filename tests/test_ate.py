@@ -42,7 +42,8 @@ def test_bench_ate_leg_on_the_host_double(tmp_path):
     fixture = tmp_path / "ate_small_reference.json"
     subprocess.run([sys.executable, str(ROOT / "tests" / "tools" / "ate_full_chain.py"), "--leg", "reference", "--frames", "6", "--height", "24", "--width", "32",
                     "--steps", "6", "--points", "60", "--track-grid", "4", "--softmin-points", "64", "--num-candidates", "8", "--after-step", "3", "--window", "2",
-                    "--trace-every", "2", "--threads", "2", "--out", str(fixture)], check=True, capture_output=True, text=True)
+                    "--trace-every", "2", "--threads", "2", "--tracking-after", "2",  # (LossTrackingCfg.enable_after, config/loss/tracking.yaml:4-6: a constant 0 before)
+                    "--out", str(fixture)], check=True, capture_output=True, text=True)
     import bench
     from flowmap_amd import _lib
     from helpers import build_host_sim
@@ -56,6 +57,7 @@ def test_bench_ate_leg_on_the_host_double(tmp_path):
 
         flowmap_amd.set_lazy_surfaces(False)
     assert block["measured_by_this_run"] and block["ate_rel_diff"] < 1e-4 and block["loss_trace_max_rel_diff"] < 1e-4
+    assert "from step 2" in block["schedule"]
     assert block["self_sensitivity"]["ate_rel_diff"] < 1e-4
 
 
@@ -89,3 +91,36 @@ def test_final_ate_on_the_metrics_configuration_vs_the_imported_reference():
     bar = max(0.01, 2.0 * sens["ate_rel_diff"], 2.0 * (sens.get("reference_ate_rel_diff") or 0.0))
     assert block["ate_rel_diff"] <= bar, (block["ate_rel_diff"], bar)
     assert abs(block["final_loss_flowmap_amd"] - block["final_loss_reference"]) <= 0.02 * abs(block["final_loss_reference"])
+
+
+@pytest.mark.gpu
+def test_final_ate_on_the_references_real_schedule_at_configs0():
+    """BASELINE configs[0] (16 frames @ 256x256) on the reference's REAL schedule — 2000 Adam steps at lr 3e-5
+    (config/overfit.yaml:24-31), softmin intrinsics handing over to the regressed focal length after step 1000 with a 100-step window
+    (config/model/intrinsics/softmin.yaml:13-14), the tracking loss enabled from step 50 (config/loss/tracking.yaml:4-6) on 35 x 35 tracks per segment
+    (config/tracking/cotracker.yaml:3) — the reference leg run by the imported reference itself (17 min on the build container's CPU,
+    tests/golden/ate_c0_16x256x256_full_schedule_imported_reference.json, with its own twin from depths perturbed by 1e-7), ours here from the same
+    initial parameters.  The only place the softmin window, the enable_after gate and the full 2000 steps meet the reference end to end."""
+    import torch
+
+    sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+    import bench
+
+    fixture = bench.c0_ate_fixture()
+    if fixture is None:
+        pytest.skip("the configs[0] full-schedule record has not been generated (oracle/make_ate_reference.py --frames 16 --height 256 --width 256 --steps 2000 ...)")
+    import flowmap_amd
+
+    try:
+        block = bench.ate_leg(torch.device("cuda", 0), fixture)
+    finally:
+        flowmap_amd.set_lazy_surfaces(False)
+    print(json.dumps(block))
+    assert "16 frames @ 256x256" in block["scene"] and "2000 steps" in block["schedule"] and "from step 50" in block["schedule"]
+    sens = block["self_sensitivity"]
+    # held to the schedule's own sensitivity (the larger of the reference's and ours, times two), never looser than 0.5 %
+    bar = min(0.005, max(1e-3, 2.0 * sens["ate_rel_diff"], 2.0 * (sens.get("reference_ate_rel_diff") or 0.0)))
+    assert block["ate_rel_diff"] <= bar, (block["ate_rel_diff"], bar)
+    assert abs(block["final_loss_flowmap_amd"] - block["final_loss_reference"]) <= 2e-3 * abs(block["final_loss_reference"])
+    assert abs(block["focal_final_flowmap_amd"] - block["focal_final_reference"]) <= 1e-3 * abs(block["focal_final_reference"])
+    assert block["loss_trace_max_rel_diff"] <= 5e-3
