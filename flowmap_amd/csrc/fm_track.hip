@@ -419,10 +419,13 @@ constexpr int kTrackPG = FM_TRACK_PG;
 #ifndef FM_TRACK_AHEAD
 #define FM_TRACK_AHEAD 2
 #endif
+#ifndef FM_TRACK_WAVES  // resident waves per SIMD the register budget is set for (A/B: tools/ab_lib_variants.sh; profiles/r06_track_pairs_closure.txt)
+#define FM_TRACK_WAVES (FM_TRACK_PG == 1 ? 4 : 2)
+#endif
 constexpr int kTrackAhead = FM_TRACK_AHEAD;  // target frames whose (visibility, position) loads are in flight
 
 template <int KIND, bool GRAD>
-__global__ void __launch_bounds__(64, kTrackPG == 1 ? 4 : 2) track_pairs_kernel(TrackGeom g, const int32_t* tiles, float* ws, uint8_t* flag,
+__global__ void __launch_bounds__(64, FM_TRACK_WAVES) track_pairs_kernel(TrackGeom g, const int32_t* tiles, float* ws, uint8_t* flag,
                                                             const float* ext, const float* tgt, float delta, float ax, float ay, int fmax,
                                                             float* partial, float* gws, TrackSampling smp, int ntiles, int pgroups) {
 #ifdef FM_TRACK_LDS_PAD  // (experiments: fewer resident waves per CU)
