@@ -1071,7 +1071,8 @@ __global__ void __launch_bounds__(256, FM_DENSE_LATER_BLOCKS) procrustes_dense_b
 #endif
 // (Four adjacent later pixels per thread with 16-byte accesses — what helps the moments kernel — made this pass slower, 2.26 against 1.17 ms:
 // docs/history/patches/r04_dense_procrustes_mfma_and_quad.patch, profiles/r04_dense_microbench_quad.txt.)
-#ifndef FM_DENSE_FUSED_SKIP  // timing experiments only (tools/dense_microbench.py): 1 = plain store for the later pixel (racy), 2 = no flush, 4 = no taps
+#ifndef FM_DENSE_FUSED_SKIP  // timing experiments only (tools/dense_microbench.py): 1 = plain store for the later pixel (racy), 2 = no flush, 4 = no taps,
+                            // 8 = the window flushed with plain read-modify-writes (racy in ONE launch: what a four-colour tile order would be allowed to do)
 #define FM_DENSE_FUSED_SKIP 0
 #endif
 #ifndef FM_DENSE_FUSED_PAD   // timing experiments only: extra LDS per block (occupancy)
@@ -1169,7 +1170,9 @@ __global__ void __launch_bounds__(256, FM_DENSE_FUSED_BLOCKS) procrustes_dense_b
     const long long v = ((long long)(iacc[i] << 13)) >> 13;  // the low 51 bits, sign-extended
     if (v == 0) continue;
     const int r = i / kFusedWinW, q = i - r * kFusedWinW;
-    atomicAdd(gd_e + (size_t)(c.wy0 + r) * p.width + (c.wx0 + q), (float)((double)v * unscale));
+    float* cell = gd_e + (size_t)(c.wy0 + r) * p.width + (c.wx0 + q);
+    if (FM_DENSE_FUSED_SKIP & 8) *cell += (float)((double)v * unscale);
+    else atomicAdd(cell, (float)((double)v * unscale));
   }
 }
 
