@@ -15,7 +15,7 @@ sys.path.insert(0, str(ROOT))
 from flowmap_amd import _lib  # noqa: E402
 
 dev = "cuda:0"
-f, h, w = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (150, 720, 1280)
+f, h, w = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 and sys.argv[1].isdigit() else (150, 720, 1280)
 p = 1000
 g = torch.Generator(device=dev).manual_seed(0)
 depth = 1.10 + 0.05 * torch.rand((1, f, h, w), device=dev, generator=g)
@@ -25,6 +25,11 @@ fx = 0.85 * (h * w) ** 0.5
 k = torch.tensor([[fx / w, 0, 0.5], [0, fx / h, 0.5], [0, 0, 1.0]], device=dev).expand(1, f, 3, 3).contiguous()
 kinv = torch.linalg.inv(k).contiguous()
 idx = torch.linspace(0, h * w - 1, p, dtype=torch.int64).to(dev)
+if "--contiguous" in sys.argv:
+    # round 6: what the fit would cost if its operands were COALESCED (the bound on a compact image of the fit's taps): the P points are
+    # P consecutive pixels of a row and the flow is zero, so a wave's gathers of weights / later depth / tap depths fall into the lines its neighbours read
+    idx = torch.arange(p, dtype=torch.int64, device=dev) + (h // 2) * w
+    flow.zero_()
 pairs = f - 1
 stats = torch.empty((pairs, 16), dtype=torch.float64, device=dev)
 work = torch.zeros((pairs * 16 + (pairs + 2) // 2 + 1,), dtype=torch.float64, device=dev)
@@ -91,7 +96,8 @@ def fused_then_chain():
     assert lib.fm_pose_chain_fwd(P(t_bwd), 1, pairs, P(ext), st) == 0
 
 
-out = {"workload": f"{f} x {h} x {w}, P = {p}; median of 30, microseconds incl. launch gaps between the launches of one call",
+out = {"indices": "P consecutive pixels, zero flow (coalesced operands)" if "--contiguous" in sys.argv else "linspace over the image (the reference's selection: every operand a cold line)",
+       "workload": f"{f} x {h} x {w}, P = {p}; median of 30, microseconds incl. launch gaps between the launches of one call",
        "moments (memset + 1 launch)": timed(moments), "moments + finish/solve (memset + 2 launches)": timed(fit),
        "pose chain alone (1 launch)": timed(chain_only), "fit then chain (memset + 3 launches)": timed(fit_then_chain),
        "fit_chain (1 launch)": timed(fused), "fit_chain with static tap records + correspondence records out (1 launch)": timed(fused_planned),
