@@ -400,10 +400,11 @@ class ProcrustesFit:
         return t_bwd, t_fwd
 
     @staticmethod
-    def apply_chained(depth, k, surfaces, weights, bwd_flow, indices, weight_sens=0.0, batch_repeat=1, chain=True):
+    def apply_chained(depth, k, surfaces, weights, bwd_flow, indices, weight_sens=0.0, batch_repeat=1, chain=True, want_extrinsics=True):
         """-> (t_bwd, t_fwd, extrinsics or None).  ``chain``: let the fit's own launch chain the poses into the
         extrinsics (get_extrinsics, projection.py:187-210) when it can — a sparse index set, no repeat; the
-        persistent, self-cleaning workspace this needs is kept on the flow tensor."""
+        persistent, self-cleaning workspace this needs is kept on the flow tensor.  ``want_extrinsics = False``: the one-launch fit
+        without the chain — the caller holds the relative poses and chains them if and when something asks (LazyExtrinsics)."""
         from_depth = surfaces is None
         rep = int(batch_repeat)
         kinv = sink = wsink = arena = None
@@ -441,7 +442,7 @@ class ProcrustesFit:
             work = _derived(bwd_flow, "_fm_fit_work", (pairs, str(bwd_flow.device)),
                             lambda: torch.zeros((pairs * STAT_STRIDE + (pairs + 2) // 2 + 1,), dtype=torch.float64, device=bwd_flow.device))
         t_bwd, t_fwd, ext = torch_ops().procrustes_fit(depth, k, kinv, surfaces, weights, bwd_flow, indices, float(weight_sens), rep, sink, wsink,
-                                                       arena, *sparse, *dense, work)
+                                                       arena, *sparse, *dense, work, bool(want_extrinsics))
         return t_bwd, t_fwd, (ext if ext.numel() > 0 else None)
 
 

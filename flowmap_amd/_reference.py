@@ -27,8 +27,9 @@ counters = {"host_calls": 0}
 def _first_tensor(obj, depth: int = 0) -> Optional[torch.Tensor]:
     if torch.is_tensor(obj):
         return obj
-    if getattr(type(obj), "_fm_lazy", False):  # LazyWeights: any other attribute read would evaluate the (f-1, h, w) sigmoid it stands for
-        return obj.logits
+    lazy = getattr(type(obj), "_fm_lazy", None)  # LazyWeights / LazyExtrinsics: any other attribute read would EVALUATE what they stand for
+    if lazy:
+        return obj.__dict__[lazy]
     depths = getattr(obj, "depths", None)  # LazySurfaces, BackboneOutput, ModelOutput
     if torch.is_tensor(depths):
         return depths
@@ -61,8 +62,9 @@ def on_host(*objs) -> bool:
     for obj in objs:
         if isinstance(obj, _Tensor):
             return obj.device.type == "cpu"
-        if getattr(type(obj), "_fm_lazy", False):  # LazyWeights (see _first_tensor)
-            return obj.logits.device.type == "cpu"
+        lazy = getattr(type(obj), "_fm_lazy", None)  # LazyWeights / LazyExtrinsics (see _first_tensor)
+        if lazy:
+            return obj.__dict__[lazy].device.type == "cpu"
         t = getattr(obj, "depths", None)  # LazySurfaces, BackboneOutput, ModelOutput
         if not isinstance(t, _Tensor):
             t = getattr(obj, "videos", None)  # Batch

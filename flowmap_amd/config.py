@@ -48,6 +48,10 @@ class Options:
     # The fused losses come back as RootLoss tensors (flowmap_amd/_ops.py); False: plain tensors, and a step pays autograd's ones_like fill and
     # the flow loss's is-the-seed-one launch again (two of the eight launches of a flow-only step)
     unit_seed: bool = True
+    # ExtrinsicsProcrustes hands the camera-to-world chain on UNEVALUATED (LazyExtrinsics) while gradients are being recorded and nothing has asked
+    # for it yet: the fused flow loss reads the fit's relative poses, and the chain is the last block's ~7 us at 149 poses with the rest of the GPU
+    # idle.  Needs lazy surfaces (install()'s default); False = the fit's launch always chains the poses (rounds 1-5)
+    lazy_extrinsics: bool = True
     # RootLoss.backward() runs autograd's nodes on the calling thread (no hand-over to the device's worker thread);
     # FLOWMAP_AMD_BACKWARD_THREAD=engine (or False here): autograd's default
     backward_on_calling_thread: bool = dataclasses.field(

@@ -498,7 +498,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
                                const c10::intrusive_ptr<DepthSink>& wsink, const c10::intrusive_ptr<GradArena>& arena,
                                const OptTensor& plan_pixels, const OptTensor& plan_first, const OptTensor& plan_vectors,
                                const OptTensor& plan_weights, const OptTensor& plan_frame_first, const OptTensor& plan_tap_records,
-                               const OptTensor& dense_first, const OptTensor& dense_list, const OptTensor& work_o, bool grad_enabled) {  // (forward runs with grad mode off: the caller's mode is passed in)
+                               const OptTensor& dense_first, const OptTensor& dense_list, const OptTensor& work_o, bool want_ext, bool grad_enabled) {  // (forward runs with grad mode off: the caller's mode is passed in)
     ctx->set_materialize_grads(false);  // an unused output (the extrinsics of a flow-only step) must not cost a zeros tensor + the chain's backward
     Tensor depth = opt(depth_o), k = opt(k_o), kinv = opt(kinv_o), surfaces = opt(surfaces_o), indices = opt(indices_o);
     const bool from_depth = !surfaces.defined();
@@ -565,7 +565,9 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       if (chained) {
         TORCH_CHECK(work.scalar_type() == at::kDouble && work.is_contiguous() && work.numel() >= pairs * FM_STAT_STRIDE + (pairs + 2) / 2 + 1,
                     "flowmap_amd: the fit workspace is too small");
-        ext = empty_like_shape({b, f, 4, 4}, weights);
+        // want_ext = false (lazy extrinsics, round 6): the caller chains the poses only if something asks for them — the flow loss takes the
+        // relative poses, and the chain is the last block's ~7 us at 149 poses with the rest of the GPU idle (profiles/r06_fit_microbench.jsonl)
+        if (want_ext) ext = empty_like_shape({b, f, 4, 4}, weights);
         // the planned backward (one launch, fm_procrustes_bwd_planned) reads the correspondences back instead of re-gathering them
         const bool wants_records = from_depth && grad_enabled && plan_frame_first.has_value() && plan_frame_first->defined() && points <= FM_FIT_BWD_MAX_POINTS &&
                                    use_one_launch_backward() && (depth.requires_grad() || weights_in.requires_grad() || (k_o.has_value() && k_o->requires_grad()));
@@ -607,7 +609,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       sink->arm(depth);
       sink->k_ptr = (k_o.has_value() && k_o->requires_grad()) ? k.data_ptr() : nullptr;
     }
-    if (!chained) ext = at::empty({0}, weights.options());  // placeholder output: the caller chains the poses itself
+    if (!chained || !ext.defined()) ext = at::empty({0}, weights.options());  // placeholder output: the caller chains the poses itself
     return {t_bwd, t_fwd, ext};
   }
 
@@ -747,7 +749,7 @@ struct ProcrustesFit : public Function<ProcrustesFit> {
       wsink->note_final(g_w);
       if (arena_used) wsink->on_leading_add = [arena](const Tensor& into, int64_t count) { arena->note_leading_add(into, count); };
     }
-    variable_list out(22);
+    variable_list out(23);
     if (from_depth) {
       out[0] = g_src;
       out[1] = g_k;
@@ -1423,10 +1425,10 @@ static std::tuple<Tensor, Tensor, Tensor> procrustes_fit_op(const OptTensor& dep
                                                     const OptTensor& plan_pixels,
                                                     const OptTensor& plan_first, const OptTensor& plan_vectors, const OptTensor& plan_weights,
                                                     const OptTensor& plan_frame_first, const OptTensor& plan_tap_records, const OptTensor& dense_first,
-                                                    const OptTensor& dense_list, const OptTensor& work) {
+                                                    const OptTensor& dense_list, const OptTensor& work, bool want_ext) {
   auto out = ProcrustesFit::apply(depth, k, kinv, surfaces, weights, bwd_flow, indices, weight_sens, batch_repeat, sink_of(sink), sink_of(wsink),
                                   arena.has_value() ? *arena : c10::intrusive_ptr<GradArena>(), plan_pixels, plan_first, plan_vectors, plan_weights,
-                                  plan_frame_first, plan_tap_records, dense_first, dense_list, work, at::GradMode::is_enabled());
+                                  plan_frame_first, plan_tap_records, dense_first, dense_list, work, want_ext, at::GradMode::is_enabled());
   if (sink.has_value() && *sink) (*sink)->fit_node = out[0].grad_fn().get();  // null when no graph is being built
   return {out[0], out[1], out[2]};
 }
@@ -1534,7 +1536,7 @@ TORCH_LIBRARY(flowmap_amd, m) {
       "int batch_repeat, __torch__.torch.classes.flowmap_amd.DepthSink? sink, __torch__.torch.classes.flowmap_amd.DepthSink? wsink, "
       "__torch__.torch.classes.flowmap_amd.GradArena? arena, "
       "Tensor? plan_pixels, Tensor? plan_first, Tensor? plan_vectors, Tensor? plan_weights, Tensor? plan_frame_first, Tensor? plan_tap_records, Tensor? dense_first, "
-      "Tensor? dense_list, Tensor? work) "
+      "Tensor? dense_list, Tensor? work, bool want_ext=True) "
       "-> (Tensor, Tensor, Tensor)",
       fmt::procrustes_fit_op);
   m.def(

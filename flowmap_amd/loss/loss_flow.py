@@ -9,7 +9,7 @@ import torch
 from torch import Tensor
 
 from .. import _ops
-from ..model.projection import LazySurfaces, compute_backward_flow, compute_forward_flow, sample_image_grid
+from ..model.projection import LazySurfaces, _dense_extrinsics, compute_backward_flow, compute_forward_flow, sample_image_grid
 from .loss import Loss, LossCfgCommon, or_one
 from .mapping import MappingCfg, get_mapping
 
@@ -78,7 +78,7 @@ class LossFlow(Loss[LossFlowCfg]):
         if direct is not None and direct[0].shape[:2] == (s.depths.shape[0], s.depths.shape[1] - 1):
             rel_fwd, rel_bwd = direct  # straight from the Procrustes fit (align_surfaces)
         else:
-            rel_fwd, rel_bwd = _ops.RelativePoses.apply(model_output.extrinsics)
+            rel_fwd, rel_bwd = _ops.RelativePoses.apply(_dense_extrinsics(model_output.extrinsics))
         norm = _ops.flow_valid_norm(flows.forward_mask, flows.backward_mask, weight, self.valid_sum_reducer)
         packed = _ops.packed_flow_inputs(flows.forward, flows.backward, flows.forward_mask, flows.backward_mask)  # cached
         return _ops.FlowLossFused.apply(

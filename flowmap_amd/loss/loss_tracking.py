@@ -11,7 +11,7 @@ from torch import Tensor
 import torch
 
 from .. import _ops
-from ..model.projection import LazySurfaces, compute_track_flow
+from ..model.projection import LazySurfaces, _dense_extrinsics, compute_track_flow
 from .loss import Loss, LossCfgCommon, or_one
 from .mapping import MappingCfg, get_mapping
 
@@ -61,7 +61,7 @@ class LossTracking(Loss[LossTrackingCfg]):
                 return hit[1]
         packed = _ops.pack_tracks(tracks, s.depths.device)
         loss = _ops.TrackLossFused.apply(
-            s.depths, model_output.intrinsics, model_output.extrinsics, packed, weight, _ops.MAPPING_KINDS[self.mapping.kind],
+            s.depths, model_output.intrinsics, _dense_extrinsics(model_output.extrinsics), packed, weight, _ops.MAPPING_KINDS[self.mapping.kind],
             self.mapping.delta, self.defer_depth_scatter, offer_taps=look_ahead,
         )
         if look_ahead:

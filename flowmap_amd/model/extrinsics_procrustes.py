@@ -10,7 +10,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import _reference
-from .projection import align_surfaces
+from .projection import _align_surfaces
 
 
 @dataclass
@@ -61,4 +61,6 @@ class ExtrinsicsProcrustes(nn.Module):
         _, _, h, w, _ = surfaces.shape
         indices = procrustes_indices(h, w, self.cfg.num_points, self.cfg.randomize_points, surfaces.device)
         # Align the depth maps using a Procrustes fit.
-        return align_surfaces(surfaces, flows.backward, backbone_output.weights, indices)
+        # (the chain may come back unevaluated — LazyExtrinsics — while gradients are recorded and nothing has read it so far: a flow-only
+        # training step reads the fit's relative poses, not the chain)
+        return _align_surfaces(surfaces, flows.backward, backbone_output.weights, indices, lazy_ok=True)

@@ -171,7 +171,7 @@ class LazyWeights:
     ``align_surfaces`` applies the sigmoid inside its gather and writes the logit gradient
     directly.  Any other use materialises the real (b, f-1, h, w) tensor."""
 
-    _fm_lazy = True  # (flowmap_amd/_reference.py asks a lazy value for its device without touching its attributes)
+    _fm_lazy = "logits"  # (flowmap_amd/_reference.py asks a lazy value for its device through this attribute, without evaluating it)
 
     def __init__(self, logits: Tensor, sensitivity: float, lazy_slices: bool = True):
         self.logits = logits  # (b, f-1, h, w)
@@ -234,6 +234,95 @@ class LazyWeights:
 
     def __repr__(self):
         return f"LazyWeights(shape={tuple(self.shape)}, sensitivity={self.sensitivity})"
+
+
+class LazyExtrinsics:
+    """The camera-to-world chain of ``get_extrinsics`` (flowmap/model/projection.py:187-210) over the fit's relative poses, NOT evaluated yet.
+
+    ``align_surfaces`` returns one while gradients are being recorded (a training step) and nothing has asked for the chain in an earlier
+    step: the fused flow loss reads the relative poses (``_fm_relative_poses``), so a flow-only step never chains them — in the fit's launch
+    that is the LAST block's one wave working for ~7 us at 149 poses while the rest of the GPU waits (``profiles/r06_fit_microbench.jsonl``).
+    Anything else — an attribute, an index, a torch function, this package's tracking loss — evaluates the chain (one launch,
+    ``fm_pose_chain_fwd``, differentiable through the fit's poses) and notes on the constant flow tensor that the chain is wanted: from the
+    next step on the fit's own launch produces it again, as in rounds 1-5.  Under ``torch.no_grad()`` (validation, ``Model.export``: the
+    reference's ``ModelExports`` checks its fields) and inside a hipGraph capture ``align_surfaces`` returns the tensor as before."""
+
+    _fm_lazy = "_rel"  # (flowmap_amd/_reference.py asks a lazy value for its device through this attribute, without evaluating it)
+
+    def __init__(self, rel: Tensor, rel_inv: Tensor, flow_tensor: Optional[Tensor] = None):
+        self._rel = rel  # (b, f-1, 4, 4): later camera -> earlier camera, the factors of the chain
+        self._fm_relative_poses = (rel_inv, rel)
+        self._flow_tensor = flow_tensor
+        self._dense: Optional[Tensor] = None
+
+    @property
+    def shape(self):
+        b, pairs = self._rel.shape[:2]
+        return torch.Size((b, pairs + 1, 4, 4))
+
+    @property
+    def device(self):
+        return self._rel.device
+
+    @property
+    def dtype(self):
+        return self._rel.dtype
+
+    @property
+    def ndim(self):
+        return 4
+
+    def dim(self):
+        return 4
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def materialize(self) -> Tensor:
+        if self._dense is None:
+            self._dense = _ops.PoseChain.apply(self._rel)
+            self._dense._fm_relative_poses = self._fm_relative_poses
+            if self._flow_tensor is not None:  # something reads the chain in this optimisation: the fit's launch chains it from the next step on
+                self._flow_tensor.__dict__["_fm_extrinsics_wanted"] = True
+        return self._dense
+
+    def __getitem__(self, item):
+        return self.materialize()[item]
+
+    def __len__(self):
+        return int(self._rel.shape[0])
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    # torch.as_tensor / numpy.asarray of the value (the array protocols: a detached view of the evaluated chain)
+    def __dlpack__(self, *args, **kwargs):
+        return self.materialize().detach().__dlpack__(*args, **kwargs)
+
+    def __dlpack_device__(self):
+        return self._rel.__dlpack_device__()
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.materialize().detach().cpu().numpy()
+        return out if dtype is None else out.astype(dtype)
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        conv = lambda a: a.materialize() if isinstance(a, (LazyExtrinsics, LazyWeights, LazySurfaces)) else a  # noqa: E731
+        return func(*tuple(conv(a) for a in args), **{k: conv(v) for k, v in kwargs.items()})
+
+    def __repr__(self):
+        return f"LazyExtrinsics(shape={tuple(self.shape)}, device={self.device}, evaluated={self._dense is not None})"
+
+
+def _dense_extrinsics(extrinsics):
+    return extrinsics.materialize() if isinstance(extrinsics, LazyExtrinsics) else extrinsics
 
 
 # --------------------------------------------------------------------------------------
@@ -348,12 +437,12 @@ def transform_rigid(homogeneous_coordinates: Tensor, transformation: Tensor) -> 
 
 def transform_cam2world(homogeneous_coordinates: Tensor, extrinsics: Tensor) -> Tensor:
     """flowmap/model/projection.py:33-38"""
-    return transform_rigid(homogeneous_coordinates, extrinsics)
+    return transform_rigid(homogeneous_coordinates, _dense_extrinsics(extrinsics))
 
 
 def transform_world2cam(homogeneous_coordinates: Tensor, extrinsics: Tensor) -> Tensor:
     """flowmap/model/projection.py:41-46"""
-    return transform_rigid(homogeneous_coordinates, torch.linalg.inv_ex(extrinsics, check_errors=False)[0])
+    return transform_rigid(homogeneous_coordinates, torch.linalg.inv_ex(_dense_extrinsics(extrinsics), check_errors=False)[0])
 
 
 _EYE_CACHE: dict = {}
@@ -386,7 +475,7 @@ def project(points: Tensor, extrinsics: Tensor, intrinsics: Tensor, epsilon: flo
     """flowmap/model/projection.py:61-73: world -> image, plus the in-front test."""
     if epsilon != 1e-5:
         raise NotImplementedError("flowmap_amd.project supports epsilon=1e-5")
-    inv = torch.linalg.inv_ex(extrinsics, check_errors=False)[0]
+    inv = torch.linalg.inv_ex(_dense_extrinsics(extrinsics), check_errors=False)[0]
     cam_z = (inv[..., 2, :3] * points).sum(-1) + inv[..., 2, 3]
     return reproject_points(points, inv, intrinsics), cam_z >= 0
 
@@ -397,7 +486,7 @@ def project(points: Tensor, extrinsics: Tensor, intrinsics: Tensor, epsilon: flo
 
 
 def _flow_positions(surfaces, extrinsics: Tensor, intrinsics: Tensor, forward: bool) -> Tensor:
-    surfaces = _dense(surfaces)
+    surfaces, extrinsics = _dense(surfaces), _dense_extrinsics(extrinsics)
     check_device(surfaces, extrinsics, intrinsics)
     rel_f, rel_b = _ops.RelativePoses.apply(extrinsics)
     b, f = surfaces.shape[:2]
@@ -439,6 +528,12 @@ def get_extrinsics(inverse_relative_transformations: Tensor) -> Tensor:
 def align_surfaces(surfaces, backward_flows: Tensor, backward_weights: Tensor, indices: Tensor) -> Tensor:
     """flowmap/model/projection.py:213-252: per-pair weighted Procrustes on flow-induced
     correspondences, chained into camera-to-world extrinsics (b,f,4,4)."""
+    return _align_surfaces(surfaces, backward_flows, backward_weights, indices, lazy_ok=False)
+
+
+def _align_surfaces(surfaces, backward_flows: Tensor, backward_weights: Tensor, indices: Tensor, lazy_ok: bool):
+    """``lazy_ok`` (ExtrinsicsProcrustes.forward, i.e. Model.forward -> ModelOutput.extrinsics): the chain may come back as a LazyExtrinsics;
+    the function-level API above always returns the tensor."""
     idx = indices
     if isinstance(surfaces, LazySurfaces):
         h, w = surfaces.depths.shape[2:]
@@ -453,7 +548,15 @@ def align_surfaces(surfaces, backward_flows: Tensor, backward_weights: Tensor, i
         else:
             backward_weights = backward_weights.materialize()
     if isinstance(surfaces, LazySurfaces):
-        rel, rel_inv, extrinsics = _ops.ProcrustesFit.apply_chained(surfaces.depths, surfaces.intrinsics, None, backward_weights, backward_flows, idx, sens)
+        # the chain only when something reads it (LazyExtrinsics): a training step (gradients recorded) on lazy surfaces, outside a graph capture,
+        # in an optimisation where nothing has asked for the extrinsics so far
+        lazy = (lazy_ok and _ops.options.lazy_extrinsics and torch.is_grad_enabled() and idx is not None and torch.is_tensor(backward_flows)
+                and not backward_flows.__dict__.get("_fm_extrinsics_wanted", False)
+                and not (backward_flows.is_cuda and torch.cuda.is_current_stream_capturing()))
+        rel, rel_inv, extrinsics = _ops.ProcrustesFit.apply_chained(surfaces.depths, surfaces.intrinsics, None, backward_weights, backward_flows, idx, sens,
+                                                                    want_extrinsics=not lazy)
+        if lazy and extrinsics is None:
+            return LazyExtrinsics(rel, rel_inv, backward_flows)
     else:
         rel, rel_inv, extrinsics = _ops.ProcrustesFit.apply_chained(None, None, surfaces, backward_weights, backward_flows, idx, sens)
     if extrinsics is None:  # (dense fits chain the poses in a launch of their own)
@@ -474,7 +577,7 @@ def compute_track_flow(surfaces, extrinsics: Tensor, intrinsics: Tensor, tracks)
     """flowmap/model/projection.py:255-298: reproject every track point from every source
     frame into every target frame.  Returns (xy_target (b,fs,ft,p,2), visibility
     (b,fs,ft,p) bool)."""
-    surfaces = _dense(surfaces)
+    surfaces, extrinsics = _dense(surfaces), _dense_extrinsics(extrinsics)
     check_device(surfaces, extrinsics, intrinsics, tracks.xy)
     b, f, h, w, _ = surfaces.shape
     p = tracks.xy.shape[2]

@@ -688,7 +688,7 @@ def _tracking_loss(shard: "FrameShard", loss_fn, tracks, model_output, total_pai
     pair is all-reduced, and the pose gradients travel back through the gather's backward.
     Returns the GLOBAL weighted loss; its gradients are this rank's share."""
     from . import _ops
-    from .model.projection import LazySurfaces
+    from .model.projection import LazySurfaces, _dense_extrinsics
 
     if global_step < loss_fn.cfg.enable_after:
         return torch.zeros((), dtype=torch.float32, device=model_output.depths.device)
@@ -696,7 +696,8 @@ def _tracking_loss(shard: "FrameShard", loss_fn, tracks, model_output, total_pai
     ranges, owns = _frame_layout(total_pairs, shard.world)
     lo, _ = ranges[shard.rank]
     frames = total_pairs + 1
-    ext = _global_extrinsics(shard, model_output.extrinsics, total_pairs)
+    local_ext = _dense_extrinsics(model_output.extrinsics)  # (a LazyExtrinsics of a flow-only step so far: the tracking loss reads the chain)
+    ext = _global_extrinsics(shard, local_ext, total_pairs)
     k = model_output.intrinsics
     if k.shape[1] != frames:  # intrinsics are shared by all frames (regressed / softmin): extend to the whole video
         k = k[:, :1].expand(1, frames, 3, 3).contiguous()
@@ -707,7 +708,7 @@ def _tracking_loss(shard: "FrameShard", loss_fn, tracks, model_output, total_pai
         return totals
 
     return _ops.TrackLossFused.apply(depths, k, ext, packed, loss_fn.cfg.weight, _ops.MAPPING_KINDS[loss_fn.mapping.kind],
-                                     loss_fn.mapping.delta, loss_fn.defer_depth_scatter, lo, reducer, model_output.extrinsics)
+                                     loss_fn.mapping.delta, loss_fn.defer_depth_scatter, lo, reducer, local_ext)
 
 
 FrameShard.global_extrinsics = lambda self, local_ext, total_pairs: _global_extrinsics(self, local_ext, total_pairs)

@@ -1126,6 +1126,64 @@ def _grads(model):
     return [p.grad.detach().clone() for p in (model.backbone.depth, model.backbone.weights, model.intrinsics.focal_length)]
 
 
+def case_lazy_extrinsics(dev):
+    """LazyExtrinsics (round 6; flowmap_amd/model/projection.py): while gradients are recorded and nothing has asked for the camera-to-world chain,
+    align_surfaces returns it unevaluated — a flow-only step never chains the poses (the fit's launch runs without its last-block chain, the fused
+    flow loss reads the relative poses).  Whatever then reads it gets exactly the tensor the fit's own launch would have produced, with the
+    same gradients; the first read notes on the flow tensor that the chain is wanted and later steps produce it in the fit's launch again;
+    torch.no_grad() and options.lazy_extrinsics = False keep the tensor."""
+    import flowmap_amd
+    from flowmap_amd import _ops, config
+    from flowmap_amd.model.projection import LazyExtrinsics
+
+    try:
+        model, batch, flows, loss_of = _small_problem(dev, tracking=False)
+        flows.backward.__dict__.pop("_fm_extrinsics_wanted", None)
+        with config.override(lazy_extrinsics=False):  # rounds 1-5: the chain in the fit's launch
+            for _ in range(3):  # (the third step: the static plans exist from the second one on — the path every later step takes)
+                model.zero_grad(set_to_none=True)
+                eager = model(batch, flows, 0)
+                assert torch.is_tensor(eager.extrinsics)
+                loss_of(eager).backward()
+            want, want_ext = _grads(model), eager.extrinsics.detach().clone()
+            model.zero_grad(set_to_none=True)
+            eager = model(batch, flows, 0)
+            (loss_of(eager) + eager.extrinsics[0, :, :3, 3].square().sum()).backward()  # something that differentiates through the chain
+            want_chain = _grads(model)
+        for _ in range(2):  # flow-only steps: the chain is never evaluated, values and gradients are those of the eager step bit for bit
+            model.zero_grad(set_to_none=True)
+            out = model(batch, flows, 0)
+            assert isinstance(out.extrinsics, LazyExtrinsics) and tuple(out.extrinsics.shape) == tuple(want_ext.shape) and out.extrinsics.device == want_ext.device
+            loss_of(out).backward()
+            assert out.extrinsics._dense is None and "_fm_extrinsics_wanted" not in flows.backward.__dict__
+            for a, b in zip(_grads(model), want):
+                assert torch.equal(a, b)
+        # a reader: the chain is evaluated (one launch), equal to the fit's own, differentiable through the fit's poses
+        model.zero_grad(set_to_none=True)
+        out = model(batch, flows, 0)
+        (loss_of(out) + out.extrinsics[0, :, :3, 3].square().sum()).backward()
+        assert torch.equal(out.extrinsics.materialize().detach(), want_ext) and torch.equal(torch.linalg.inv(out.extrinsics).detach(), torch.linalg.inv(want_ext))
+        for a, b in zip(_grads(model), want_chain):
+            assert torch.equal(a, b)
+        assert flows.backward.__dict__.get("_fm_extrinsics_wanted") is True
+        assert torch.is_tensor(model(batch, flows, 0).extrinsics)  # ... and from now on the fit's launch chains the poses again
+        flows.backward.__dict__.pop("_fm_extrinsics_wanted")
+        with torch.no_grad():  # validation / Model.export (the reference's ModelExports checks its fields): a tensor
+            assert torch.is_tensor(model(batch, flows, 0).extrinsics)
+        # the tracking loss reads the chain: lazy on the first step only
+        model, batch, flows, loss_of = _small_problem(dev, tracking=True)
+        flows.backward.__dict__.pop("_fm_extrinsics_wanted", None)
+        seen = []
+        for _ in range(3):
+            model.zero_grad(set_to_none=True)
+            out = model(batch, flows, 0)
+            seen.append(isinstance(out.extrinsics, LazyExtrinsics))
+            loss_of(out).backward()
+        assert seen == [True, False, False]
+    finally:
+        flowmap_amd.set_lazy_surfaces(False)
+
+
 def case_root_loss(dev):
     """RootLoss (flowmap_amd/_ops.py): the fused losses seed their own backward() with the registered ones tensor.  Same gradients as the
     plain-tensor path however the loss reaches backward — directly, summed, scaled by a weight (an ordinary upstream gradient again),

@@ -742,7 +742,7 @@ int fm_procrustes_fit_chain(const float* depth, const float* kinv, const float* 
         }
       }
   }
-  return fm_pose_chain_fwd(t_bwd, batch, frames - 1, ext, stream);
+  return ext ? fm_pose_chain_fwd(t_bwd, batch, frames - 1, ext, stream) : 0;  // (ext may be NULL: poses only)
 }
 
 int fm_procrustes_scatter_plan(const float* bwd_flow, const int64_t* indices, long points, int batch, int frames, int height, int width,

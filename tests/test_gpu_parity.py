@@ -443,6 +443,11 @@ def test_tap_exchange():
 
 
 @pytest.mark.gpu
+def test_lazy_extrinsics():
+    cases.case_lazy_extrinsics(DEV)
+
+
+@pytest.mark.gpu
 def test_depth_adam_update_inside_the_flow_pass_follows_torch_adam():
     cases.case_in_pass_adam(DEV, steps=200, lr=3e-4)  # 10x the reference's learning rate (config/overfit.yaml:30)
 

@@ -251,3 +251,7 @@ def test_packed_tracks_follow_their_tensors():
     fifth = _ops.pack_tracks(tracks, torch.device("cpu"))  # (one form is kept per track list: back to the whole video builds it again)
     assert fifth is not owned and _ops.pack_tracks(tracks, torch.device("cpu")) is fifth
     assert _ops.pack_tracks(list(tracks), torch.device("cpu")) is fifth  # (another list of the same segments: the full key finds it)
+
+
+def test_lazy_extrinsics():
+    cases.case_lazy_extrinsics("cpu")

@@ -269,6 +269,8 @@ def test_reference_softmin_model_under_install_without_the_fused_sweep():
             out = model(batch, flows, 0)
             loss = loss_fn(batch, flows, None, out, 0)
             loss.backward()
+            # (out.extrinsics: under install() a LazyExtrinsics of this flow-only step — evaluated here, while the host double is still in place)
+            out.extrinsics = torch.as_tensor(out.extrinsics).detach().clone()
             return type(model.backbone), type(model.intrinsics), out, loss.detach(), model.backbone.depth.grad, model.backbone.weights.grad
 
         _, ref_intr_cls, out_ref, loss_ref, gd_ref, gw_ref = run()
