@@ -245,7 +245,7 @@ class LazyExtrinsics:
     Anything else — an attribute, an index, a torch function, this package's tracking loss — evaluates the chain (one launch,
     ``fm_pose_chain_fwd``, differentiable through the fit's poses) and notes on the constant flow tensor that the chain is wanted: from the
     next step on the fit's own launch produces it again, as in rounds 1-5.  Under ``torch.no_grad()`` (validation, ``Model.export``: the
-    reference's ``ModelExports`` checks its fields) and inside a hipGraph capture ``align_surfaces`` returns the tensor as before."""
+    reference's ``ModelExports`` checks its fields) the module returns the tensor as before; so does the function-level ``align_surfaces``."""
 
     _fm_lazy = "_rel"  # (flowmap_amd/_reference.py asks a lazy value for its device through this attribute, without evaluating it)
 
@@ -548,11 +548,11 @@ def _align_surfaces(surfaces, backward_flows: Tensor, backward_weights: Tensor, 
         else:
             backward_weights = backward_weights.materialize()
     if isinstance(surfaces, LazySurfaces):
-        # the chain only when something reads it (LazyExtrinsics): a training step (gradients recorded) on lazy surfaces, outside a graph capture,
-        # in an optimisation where nothing has asked for the extrinsics so far
+        # the chain only when something reads it (LazyExtrinsics): a training step (gradients recorded) on lazy surfaces, in an optimisation
+        # where nothing has asked for the extrinsics so far.  (Inside a hipGraph capture too: a reader inside the captured region becomes part of
+        # the graph, and the captured steps of this package — GraphedStep, GraphedShardedStep, training.py — hand no ModelOutput out of it.)
         lazy = (lazy_ok and _ops.options.lazy_extrinsics and torch.is_grad_enabled() and idx is not None and torch.is_tensor(backward_flows)
-                and not backward_flows.__dict__.get("_fm_extrinsics_wanted", False)
-                and not (backward_flows.is_cuda and torch.cuda.is_current_stream_capturing()))
+                and not backward_flows.__dict__.get("_fm_extrinsics_wanted", False))
         rel, rel_inv, extrinsics = _ops.ProcrustesFit.apply_chained(surfaces.depths, surfaces.intrinsics, None, backward_weights, backward_flows, idx, sens,
                                                                     want_extrinsics=not lazy)
         if lazy and extrinsics is None:
