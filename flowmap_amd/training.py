@@ -321,6 +321,8 @@ class GraphedTraining:
         total.__dict__["_fm_graphed_training"] = self
         self.total = total
         self.values = [v.detach() for v in self.values]
+        if self.errors is not None:  # (un-detached, they kept the captured forward's autograd graph and its saved tensors alive)
+            self.errors = tuple(e.detach() for e in self.errors)
         self.captures += 1
 
     def replay_backward(self, loss) -> None:
