@@ -150,6 +150,13 @@ def parse():
                     help="the reference's default operating point (config/overfit.yaml:33-38: 150 frames of ~180x240, flow + tracking) beside the headline: "
                          "two child runs of this file — the package's ModelWrapperOverfit.training_step eager and under install(graph=True) — reported "
                          "under `default_resolution` (auto: with the default headline run on one GPU, like the ATE leg)")
+    ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto",
+                    help="the process group's backend: auto = nccl (RCCL over xGMI) on GPUs, gloo on the CPU dry run.  `gloo` on GPUs is the FUNCTIONAL multi-rank "
+                         "test of this file on a box with fewer GPUs than ranks (with --one-gpu): the same kernels, the same point-to-point halo exchange and "
+                         "collectives between real peers, staged through the host by gloo — timing is meaningless there")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="every rank computes on cuda:0 (needs --backend gloo: RCCL refuses two ranks on one device).  tests/test_gpu_multirank.py: the sharded "
+                         "step between 2-3 real ranks on the one GPU a gpurun box has")
     ap.add_argument("--torch-baseline", type=int, default=0, metavar="STEPS",
                     help="after the timed region: the reference's op sequence on stock PyTorch-ROCm on this GPU (tests/tools/torch_gpu_reference_ops.py "
                          "in a process of its own, 1 warm-up + STEPS steps on i.i.d. inputs of the workload's size) as `rocm_torch_baseline`")
@@ -505,7 +512,7 @@ def launch_ranks(args):
     process image is replaced (exec): exit code, signals and stdout are the launcher's.  FLOWMAP_BENCH_LAUNCHER names the script the ranks
     run instead of this file (tests/test_bench_dryrun.py: the launcher that injects the host test double for the gloo dry run)."""
     on_gpu = os.environ.get("FLOWMAP_BENCH_DEVICE", "cuda") == "cuda"
-    if on_gpu:
+    if on_gpu and not args.one_gpu:
         visible = torch.cuda.device_count()
         if visible < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} GPU(s) visible to this process; refusing to report an {args.gpus}-GPU number from fewer ranks")
@@ -539,19 +546,24 @@ def main():
     on_gpu = os.environ.get("FLOWMAP_BENCH_DEVICE", "cuda") == "cuda"
     if args.share and world > 1:
         raise SystemExit("--share K runs one rank's share on ONE process")
+    backend = ("nccl" if on_gpu else "gloo") if args.backend == "auto" else args.backend
+    if args.one_gpu:
+        if backend != "gloo" or not on_gpu:
+            raise SystemExit("--one-gpu: GPU ranks over --backend gloo (RCCL refuses two ranks on one device)")
+        local_rank = 0
     if world > 1 or args.share > 1:  # --share: a one-rank process group, so that every collective of the sharded step executes
         import torch.distributed as dist
 
         for key, value in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(key, value)
-        if on_gpu:
-            torch.cuda.set_device(local_rank)
-            import datetime
+        import datetime
 
+        if on_gpu and backend == "nccl":
+            torch.cuda.set_device(local_rank)
             # (a collective that never completes — this path has not run with a peer yet — fails after five minutes instead of RCCL's default ten)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=5))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=5))
         if not args.share and dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: the process group has {dist.get_world_size()} rank(s)")
     else:
@@ -978,6 +990,7 @@ def main():
                 "width": w,
                 "halo_exchange": (("ghost (the neighbour's dense part evaluated from its 64-byte pose, sparse correction after backward)" if args.halo == "ghost" else
                                    "early (dense part after the flow pass, sparse correction after backward)") if early_halo else "one shot after backward") if strong else None,
+                "ranks_share_one_gpu": bool(args.one_gpu),
                 "parallelism": (f"frame-pair shards x{world} (1-frame halo, packed all-reduce of loss + shared gradients, halo exchange)" if strong
                                 else f"{world} independent 150-frame shards" if world > 1 else "single GPU"),
                 "loss": float(loss.item()),

@@ -1,0 +1,67 @@
+"""The frame-sharded step between REAL peers on a GPU (round 6).  A gpurun box has one MI355X and RCCL refuses two ranks on one device, so the ranks
+share cuda:0 and meet over gloo (which takes GPU tensors: tools/probes/gloo_gpu_probe.py): `python bench.py --gpus N --backend gloo --one-gpu` —
+the literal N-rank command of the driver with two flags that say where the ranks compute and how they talk.  What runs is everything a rank of an
+8-GPU run does except RCCL itself: this package's HIP kernels on every rank, the point-to-point halo exchange (one-shot, early and ghost forms),
+the packed all-reduce, the tracking loss's pose all-gather, forward + backward replayed as hipGraphs with the collectives between and after the
+replays (GraphedShardedStep: the default of a multi-rank run, never executed with a peer before this test).  Every world size must report the
+loss of the whole video.  Timing is meaningless here (two processes time-slice one GPU, gloo stages through the host)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+SMALL = ["--frames", "9", "--height", "48", "--width", "64", "--points", "120", "--cpu-frames", "0", "--steps", "3", "--warmup", "1", "--sustained-steps", "0",
+         "--ate", "off", "--default-resolution", "off"]
+
+
+def _bench(argv):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="2", FLOWMAP_BENCH_NO_PROFILER="1")
+    done = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, done.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module")
+def whole_video():
+    return {cfg: _bench(["--config", cfg, *SMALL]) for cfg in ("c1", "c2")}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,halo,graph", [(2, "oneshot", "off"), (2, "early", "off"), (2, "early", "compute"), (3, "ghost", "off"), (3, "ghost", "compute"),
+                                              (3, "early", "compute")])
+def test_flow_loss_between_real_ranks_on_the_gpu(whole_video, world, halo, graph):
+    single = whole_video["c1"]
+    line = _bench(["--gpus", str(world), "--backend", "gloo", "--one-gpu", "--config", "c1", "--halo", halo, "--graph", graph, *SMALL])
+    assert line["n_gpus"] == world and line["rccl_ranks"] == world and line["collective_backend"] == "gloo" and line["config"]["ranks_share_one_gpu"] is True
+    assert len(line["frame_split"]) == world and line["config"]["frames_per_gpu"] < 9 and line["scaling"] == "strong"
+    assert str(line["config"]["halo_exchange"]).startswith({"oneshot": "one shot", "early": "early", "ghost": "ghost"}[halo])
+    if graph == "compute":
+        assert "replayed as one hipGraph" in line["config"]["workload"]  # (the capture succeeded on every rank: no fall-back to the eager step)
+    assert abs(line["config"]["loss"] - single["config"]["loss"]) <= 2e-5 * abs(single["config"]["loss"]), (line["config"]["loss"], single["config"]["loss"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_flow_and_tracking_between_real_ranks_on_the_gpu(whole_video, world):
+    """... with the tracking loss: windows straddle the shard borders — the local pose chains are all-gathered, [sum, count] and the pose gradients all-reduced."""
+    single = whole_video["c2"]
+    line = _bench(["--gpus", str(world), "--backend", "gloo", "--one-gpu", "--config", "c2", *SMALL])
+    assert line["n_gpus"] == world and line["rccl_ranks"] == world and "tracking loss" in line["config"]["workload"]
+    assert abs(line["config"]["loss"] - single["config"]["loss"]) <= 2e-5 * abs(single["config"]["loss"]), (line["config"]["loss"], single["config"]["loss"])
+
+
+@pytest.mark.gpu
+def test_adam_steps_between_real_ranks_on_the_gpu(whole_video):
+    """... with the optimiser in the loop (FusedAdam): the shared frames' gradient is complete only after the halo exchange, the focal length's only after the
+    all-reduce; the same number of steps (one-shot halo: no extra set-up step) ends on the loss the unsharded run ends on."""
+    single = _bench(["--config", "c1", "--optimizer", "fused", *SMALL])
+    line = _bench(["--gpus", "2", "--backend", "gloo", "--one-gpu", "--config", "c1", "--optimizer", "fused", "--halo", "oneshot", "--graph", "off", *SMALL])
+    assert line["n_gpus"] == 2 and "Adam step" in line["config"]["workload"]
+    assert abs(line["config"]["loss"] - single["config"]["loss"]) <= 5e-5 * abs(single["config"]["loss"]), (line["config"]["loss"], single["config"]["loss"])

@@ -1,0 +1,28 @@
+#!/bin/bash
+# The driver's N-rank command at the metric's size on a ONE-GPU box: the ranks share cuda:0 and meet over gloo (RCCL refuses two ranks on one device;
+# gloo takes GPU tensors — tools/probes/gloo_gpu_probe.py).  FUNCTIONAL record: every rank runs this package's kernels on its shard of the 150-frame video, the halo
+# travels point to point, forward + backward replay as hipGraphs; the loss must be the whole video's.  Timing is meaningless (N processes time-slice one GPU).
+#   gpurun -- 'bash tools/gpu_multirank_one_gpu.sh'
+cd "${GRAFT_REPO_ROOT:-.}"
+out=gpurun_out/r06_multirank; mkdir -p $out
+export FLOWMAP_BENCH_NO_PROFILER=1
+common="--steps 5 --warmup 2 --cpu-frames 0 --ate off --default-resolution off --sustained-steps 0"
+run() {  # name, args
+  timeout 900 python bench.py $2 $common > $out/$1.json 2> $out/$1.err
+  python - "$1" "$out/$1.json" <<'PY'
+import json, sys
+name, path = sys.argv[1:3]
+try:
+    d = json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
+    print(name, "n_gpus", d["n_gpus"], "ranks", d["rccl_ranks"], d["collective_backend"], "frames/rank", d["config"]["frames_per_gpu"], "halo", str(d["config"]["halo_exchange"])[:8],
+          "graphs" if "hipGraph" in d["config"]["workload"] else "eager", "loss", repr(d["config"]["loss"]), flush=True)
+except Exception as exc:
+    print(name, "FAILED", repr(exc)[:200], flush=True)
+PY
+}
+run n1 "--config c1"
+for n in 2 4 8; do run n${n}_early_graphs "--gpus $n --backend gloo --one-gpu --config c1"; done
+run n8_ghost_graphs "--gpus 8 --backend gloo --one-gpu --config c1 --halo ghost"
+run n4_oneshot_eager "--gpus 4 --backend gloo --one-gpu --config c1 --halo oneshot --graph off"
+run n1_c2 "--config c2"
+run n4_c2 "--gpus 4 --backend gloo --one-gpu --config c2"
