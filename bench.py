@@ -112,7 +112,7 @@ def parse():
                          "step, and a sparse correction (~20 KB) after backward (with --graph compute: between the forward and the backward replay).  "
                          "`ghost` (FrameShard.enable_ghost_halo): no frame travels at all — each rank is handed the neighbouring pair's constant flow once, receives its 64-byte pose "
                          "per step and evaluates the neighbour's dense part itself (fm_flow_ghost_terms), the same sparse correction after backward.  "
-                         "auto: early for a multi-rank strong-scaling run, oneshot otherwise (the --share proxy states its mode explicitly)")
+                         "auto: ghost for a multi-rank strong-scaling run, oneshot otherwise (the --share proxy states its mode explicitly)")
     ap.add_argument("--share", type=int, default=0,
                     help="K > 0: run ONE rank's share of a K-GPU strong-scaling run on this GPU (its pairs + halo frames, collectives on a "
                          "one-rank RCCL communicator): the per-rank step time of a K-GPU run without the wire time")
@@ -606,9 +606,10 @@ def main():
     if args.graph == "off":
         args.graph = None
     if args.halo == "auto":
-        # (`early`, not `ghost`: neither has run with a peer on RCCL yet — ADVICE r4 — and the early form exchanges whole frames with the plain
-        # send / receive the one-shot form uses; the ghost form is one flag away once a multi-GPU run has validated it)
-        args.halo = "early" if (strong and world > 1) else "oneshot"
+        # (round 6: `ghost` — every form has now run between real ranks on a GPU, over gloo: tests/test_gpu_multirank.py and, at the metric's size with 8
+        # ranks, profiles/r06_multirank_gloo_one_gpu.txt; none has run over RCCL.  The ghost form sends 64 bytes per boundary and step where the early form
+        # sends a 3.7 MB frame: the one that DESIGN.md §5 projects to meet the 8-GPU target.  `--halo early` / `oneshot` remain)
+        args.halo = "ghost" if (strong and world > 1) else "oneshot"
     if args.graph == "compute" and (not strong or cfg["tracking"] or args.intrinsics != "regressed"):
         raise SystemExit("--graph compute: a frame-sharded run of the flow loss with regressed intrinsics (the tracking loss and the softmin sweep have collectives inside forward / backward)")
     flowmap_amd.set_lazy_surfaces(True)

@@ -21,8 +21,9 @@ except Exception as exc:
 PY
 }
 run n1 "--config c1"
-for n in 2 4 8; do run n${n}_early_graphs "--gpus $n --backend gloo --one-gpu --config c1"; done
-run n8_ghost_graphs "--gpus 8 --backend gloo --one-gpu --config c1 --halo ghost"
+for n in 2 4 8; do run n${n}_default "--gpus $n --backend gloo --one-gpu --config c1"; done   # the driver's command shape: ghost halo, compute graphs
+run n8_early_graphs "--gpus 8 --backend gloo --one-gpu --config c1 --halo early"
 run n4_oneshot_eager "--gpus 4 --backend gloo --one-gpu --config c1 --halo oneshot --graph off"
 run n1_c2 "--config c2"
-run n4_c2 "--gpus 4 --backend gloo --one-gpu --config c2"
+run n4_c2_default "--gpus 4 --backend gloo --one-gpu --config c2"
+run n8_c2_early "--gpus 8 --backend gloo --one-gpu --config c2 --halo early"
