@@ -21,7 +21,11 @@ SMALL = ["--frames", "9", "--height", "48", "--width", "64", "--points", "120", 
 def _bench(argv):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(OMP_NUM_THREADS="2", FLOWMAP_BENCH_NO_PROFILER="1")
-    done = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    for attempt in range(2):
+        done = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        # (the launcher picks a free rendezvous port and torch.distributed.run binds it a moment later: another process can take it in between — retried once)
+        if done.returncode == 0 or "ddress already in use" not in done.stderr:
+            break
     assert done.returncode == 0, done.stderr[-3000:]
     lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
     assert len(lines) == 1, done.stdout  # ONE JSON line, from rank 0
