@@ -27,3 +27,6 @@ run n4_oneshot_eager "--gpus 4 --backend gloo --one-gpu --config c1 --halo onesh
 run n1_c2 "--config c2"
 run n4_c2_default "--gpus 4 --backend gloo --one-gpu --config c2"
 run n8_c2_early "--gpus 8 --backend gloo --one-gpu --config c2 --halo early"
+# BASELINE configs[3]: 65 frames @ 1080x1920 frame-sharded over 4 ranks (pairs 0-15 | 16-31 | 32-47 | 48-63)
+run n1_c3 "--config c3"
+run n4_c3_default "--gpus 4 --backend gloo --one-gpu --config c3"
