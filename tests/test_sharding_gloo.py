@@ -51,7 +51,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, f, h, w, points, out_path, with_tracks=False, softmin=False):
+def _worker(rank, world, port, f, h, w, points, out_path, with_tracks=False, softmin=False, device="cpu"):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -68,7 +68,11 @@ def _worker(rank, world, port, f, h, w, points, out_path, with_tracks=False, sof
     from helpers import build_host_sim
     from oracle import flowmap_oracle as orc
 
-    _lib.set_library_for_testing(build_host_sim())
+    dev = torch.device(device)
+    if dev.type == "cpu":
+        _lib.set_library_for_testing(build_host_sim())
+    # (device = "cuda:0": the ranks share the one GPU of a gpurun box and meet over gloo, which moves GPU tensors — the HIP library on every rank,
+    # real peers: tests at the bottom of this file, -m gpu)
     flowmap_amd.set_lazy_surfaces(True)
     depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
     a, b = shard_pairs(f - 1, world)[rank]
@@ -90,9 +94,10 @@ def _worker(rank, world, port, f, h, w, points, out_path, with_tracks=False, sof
         model.intrinsics._draw_indices = lambda count, device: fixed.to(device)
     model.backbone.depth.data = depth[lo : hi + 1].clone()
     model.backbone.weights.data = wlogit[a:b].clone()
-    local = Flows(flows.forward[:, a:b].contiguous(), flows.backward[:, a:b].contiguous(),
-                  flows.forward_mask[:, a:b].contiguous(), flows.backward_mask[:, a:b].contiguous())
-    batch = Batch(torch.zeros((1, nf, 3, h, w)))
+    model = model.to(dev)
+    local = Flows(flows.forward[:, a:b].contiguous().to(dev), flows.backward[:, a:b].contiguous().to(dev),
+                  flows.forward_mask[:, a:b].contiguous().to(dev), flows.backward_mask[:, a:b].contiguous().to(dev))
+    batch = Batch(torch.zeros((1, nf, 3, h, w), device=dev))
     loss_fn = LossFlow(LossFlowCfg(0, 1000.0, "flow", MappingHuberCfg("huber", 0.01)))
     shard = FrameShard(rank, world, dist)
     shard.prepare_flow_loss(loss_fn, local)
@@ -103,7 +108,7 @@ def _worker(rank, world, port, f, h, w, points, out_path, with_tracks=False, sof
     if with_tracks:
         from helpers import to_tracks
 
-        tracks = to_tracks(orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5), "cpu")  # GLOBAL frame indices
+        tracks = to_tracks(orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5), dev)  # GLOBAL frame indices
         track_fn = LossTracking(LossTrackingCfg(0, 100.0, "tracking", MappingHuberCfg("huber", 0.01)))
         # global value on every rank; its autograd gradients are this rank's share of the term
         track_total = shard.tracking_loss(track_fn, tracks, out, f - 1)
@@ -112,11 +117,11 @@ def _worker(rank, world, port, f, h, w, points, out_path, with_tracks=False, sof
         loss.backward()
     shared = [p for name, p in model.named_parameters() if not name.startswith("backbone.")]  # a LIST of shared parameters
     total = shard.sync(loss, shared, model.backbone.depth, already_global=track_total)
-    g_focal = None if softmin else model.intrinsics.focal_length.grad.clone()
+    g_focal = None if softmin else model.intrinsics.focal_length.grad.cpu().clone()
     torch.save(
-        {"loss": total.clone(), "track": None if track_total is None else track_total.detach().clone(), "g_focal": g_focal, "k": out.intrinsics.detach().clone(),
-         "g_depth": model.backbone.depth.grad.clone(),
-         "g_w": model.backbone.weights.grad.clone(), "frames": (lo, hi), "pairs": (a, b)},
+        {"loss": total.cpu().clone(), "track": None if track_total is None else track_total.detach().cpu().clone(), "g_focal": g_focal,
+         "k": out.intrinsics.detach().cpu().clone(), "g_depth": model.backbone.depth.grad.cpu().clone(),
+         "g_w": model.backbone.weights.grad.cpu().clone(), "frames": (lo, hi), "pairs": (a, b)},
         f"{out_path}.{rank}",
     )
     dist.barrier()
@@ -627,3 +632,39 @@ def test_sync_with_gradients_kept_across_steps(tmp_path):
             assert_close(total, ref["total"], 1e-5, what=f"global loss, step {step}")
             assert_close(g_depth, ref["g_depth"][lo : hi + 1], 1e-4, what=f"g_depth of rank {rank}, step {step}")
             _focal_close(g_focal, ref, ref32)
+
+
+# ---- round 6: the same checks with the HIP library on every rank — the ranks share the one GPU of a gpurun box and meet over gloo ----
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,with_tracks", [(2, False), (3, False), (2, True), (3, True), (4, True)])
+def test_real_ranks_on_the_gpu_match_the_unsharded_oracle(tmp_path, world, with_tracks):
+    """FrameShard between REAL ranks running this package's kernels (cuda:0 shared by the ranks; gloo moves GPU tensors, point to point
+    included): loss, dL/dfocal, every rank's slice of dL/ddepth INCLUDING the halo frames summed across the border, dL/dweights — against the
+    unsharded fp64 oracle, gates as on the host double.  RCCL refuses two ranks on one device: its transport is what this leaves untested."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from conftest import assert_close
+    from helpers import run_oracle
+    from oracle import flowmap_oracle as orc
+
+    f, h, w, points = 9, 24, 32, 60
+    out = str(tmp_path / "shard")
+    mp.spawn(_worker, args=(world, _free_port(), f, h, w, points, out, with_tracks, False, "cuda:0"), nprocs=world, join=True)
+    depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
+    otracks = orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5) if with_tracks else None
+    ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float64)
+    ref32 = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float32)
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    assert sorted(r["frames"] for r in res) == [shard_frames(pr) for pr in shard_pairs(f - 1, world)]
+    for r in res:
+        if with_tracks:
+            assert float(ref["loss_tracking"]) > 0
+            assert_close(r["track"], ref["loss_tracking"], 1e-5, what="global tracking loss")
+        assert_close(r["loss"], ref["total"], 1e-5, what="global loss")
+        _focal_close(r["g_focal"], ref, ref32)
+        lo, hi = r["frames"]
+        a, b = r["pairs"]
+        _shard_close(r["g_depth"], ref["g_depth"][lo : hi + 1], ref32["g_depth"][lo : hi + 1], "g_depth shard (halo summed)")
+        _shard_close(r["g_w"], ref["g_wlogit"][a:b], ref32["g_wlogit"][a:b], "g_wlogit shard")
