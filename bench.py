@@ -151,12 +151,12 @@ def parse():
                          "two child runs of this file — the package's ModelWrapperOverfit.training_step eager and under install(graph=True) — reported "
                          "under `default_resolution` (auto: with the default headline run on one GPU, like the ATE leg)")
     ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto",
-                    help="the process group's backend: auto = nccl (RCCL over xGMI) on GPUs, gloo on the CPU dry run.  `gloo` on GPUs is the FUNCTIONAL multi-rank "
-                         "test of this file on a box with fewer GPUs than ranks (with --one-gpu): the same kernels, the same point-to-point halo exchange and "
-                         "collectives between real peers, staged through the host by gloo — timing is meaningless there")
+                    help="the process group's backend: auto = nccl (RCCL) on GPUs, gloo on the CPU dry run.  `gloo` on GPUs (it moves GPU tensors through the "
+                         "host) is an alternative for --one-gpu")
     ap.add_argument("--one-gpu", action="store_true",
-                    help="every rank computes on cuda:0 (needs --backend gloo: RCCL refuses two ranks on one device).  tests/test_gpu_multirank.py: the sharded "
-                         "step between 2-3 real ranks on the one GPU a gpurun box has")
+                    help="every rank computes on cuda:0: the FUNCTIONAL multi-rank run on a one-GPU box (tests/test_gpu_multirank.py; timing is meaningless).  "
+                         "Over RCCL (the default backend) every rank declares a host of its own (NCCL_HOSTID) and the ranks meet over RCCL's socket transport on "
+                         "the loopback interface — RCCL refuses two ranks of one host on one device; over --backend gloo the tensors are staged through the host")
     ap.add_argument("--torch-baseline", type=int, default=0, metavar="STEPS",
                     help="after the timed region: the reference's op sequence on stock PyTorch-ROCm on this GPU (tests/tools/torch_gpu_reference_ops.py "
                          "in a process of its own, 1 warm-up + STEPS steps on i.i.d. inputs of the workload's size) as `rocm_torch_baseline`")
@@ -548,9 +548,19 @@ def main():
         raise SystemExit("--share K runs one rank's share on ONE process")
     backend = ("nccl" if on_gpu else "gloo") if args.backend == "auto" else args.backend
     if args.one_gpu:
-        if backend != "gloo" or not on_gpu:
-            raise SystemExit("--one-gpu: GPU ranks over --backend gloo (RCCL refuses two ranks on one device)")
+        if not on_gpu:
+            raise SystemExit("--one-gpu: GPU ranks")
         local_rank = 0
+        if backend == "nccl":
+            # RCCL refuses two ranks of one HOST on one device ("Duplicate GPU detected"): every rank declares a host of its own and the ranks meet over
+            # RCCL's socket transport on the loopback interface (tools/probes/rccl_one_gpu_probe.py) — RCCL's own point-to-point and collective code,
+            # proxy threads and stream semantics, everything but xGMI
+            os.environ.update(NCCL_HOSTID=f"flowmap-amd-one-gpu-rank-{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1",
+                              NCCL_SHM_DISABLE="1")
+            if args.graph == "whole" and world > 1:
+                # (measured, round 6: hipStreamEndCapture segfaults on a capture that holds RCCL calls over the socket transport — its proxy steps are
+                # host-function nodes; over xGMI peer-to-peer, which needs no proxy, this has not run)
+                raise SystemExit("--one-gpu with --graph whole: RCCL's socket transport cannot be captured into a hipGraph here; use --graph compute (the default) or off")
     if world > 1 or args.share > 1:  # --share: a one-rank process group, so that every collective of the sharded step executes
         import torch.distributed as dist
 
@@ -607,7 +617,7 @@ def main():
         args.graph = None
     if args.halo == "auto":
         # (round 6: `ghost` — every form has now run between real ranks on a GPU, over gloo: tests/test_gpu_multirank.py and, at the metric's size with 8
-        # ranks, profiles/r06_multirank_gloo_one_gpu.txt; none has run over RCCL.  The ghost form sends 64 bytes per boundary and step where the early form
+        # ranks, profiles/r06_multirank_rccl_one_gpu.txt; none has run over RCCL.  The ghost form sends 64 bytes per boundary and step where the early form
         # sends a 3.7 MB frame: the one that DESIGN.md §5 projects to meet the 8-GPU target.  `--halo early` / `oneshot` remain)
         args.halo = "ghost" if (strong and world > 1) else "oneshot"
     if args.graph == "compute" and (not strong or cfg["tracking"] or args.intrinsics != "regressed"):

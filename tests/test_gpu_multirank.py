@@ -1,10 +1,10 @@
-"""The frame-sharded step between REAL peers on a GPU (round 6).  A gpurun box has one MI355X and RCCL refuses two ranks on one device, so the ranks
-share cuda:0 and meet over gloo (which takes GPU tensors: tools/probes/gloo_gpu_probe.py): `python bench.py --gpus N --backend gloo --one-gpu` —
-the literal N-rank command of the driver with two flags that say where the ranks compute and how they talk.  What runs is everything a rank of an
-8-GPU run does except RCCL itself: this package's HIP kernels on every rank, the point-to-point halo exchange (one-shot, early and ghost forms),
-the packed all-reduce, the tracking loss's pose all-gather, forward + backward replayed as hipGraphs with the collectives between and after the
-replays (GraphedShardedStep: the default of a multi-rank run, never executed with a peer before this test).  Every world size must report the
-loss of the whole video.  Timing is meaningless here (two processes time-slice one GPU, gloo stages through the host)."""
+"""The frame-sharded step between REAL peers on a GPU, over RCCL (round 6).  A gpurun box has one MI355X, and RCCL refuses two ranks of one HOST on one
+device — so with `--one-gpu` every rank declares a host of its own (NCCL_HOSTID) and the ranks, all computing on cuda:0, meet over RCCL's socket transport
+on the loopback interface (tools/probes/rccl_one_gpu_probe.py): `python bench.py --gpus N --one-gpu` is the literal N-rank command of the driver plus ONE
+flag.  What runs is everything a rank of an 8-GPU run does except xGMI: this package's HIP kernels on every rank, RCCL's point-to-point halo exchange
+(one-shot, early and ghost forms) and collectives with RCCL's stream semantics, the tracking loss's pose all-gather, forward + backward replayed as hipGraphs
+with the collectives between and after the replays (GraphedShardedStep: the default of a multi-rank run).  The same over gloo (it moves GPU tensors through the host) as a second transport.  Every world size must report the loss of
+the whole video.  Timing is meaningless here (N processes time-slice one GPU)."""
 import json
 import os
 import subprocess
@@ -38,34 +38,40 @@ def whole_video():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
 @pytest.mark.parametrize("world,halo,graph", [(2, "oneshot", "off"), (2, "early", "off"), (2, "early", "compute"), (3, "ghost", "off"), (3, "ghost", "compute"),
                                               (3, "early", "compute")])
-def test_flow_loss_between_real_ranks_on_the_gpu(whole_video, world, halo, graph):
+def test_flow_loss_between_real_ranks_on_the_gpu(whole_video, world, halo, graph, backend):
+    # (`--graph whole` — the RCCL calls captured INSIDE the step's hipGraph, flowmap_amd.GraphedStep — is not in this list: over RCCL's socket transport, the only
+    # one two ranks on one GPU can use, hipStreamEndCapture segfaults (the transport's proxy steps are host-function nodes), and gloo cannot be captured at all;
+    # it runs on a one-rank communicator in test_gpu_rccl.py and needs real xGMI peers for more.  The default of a multi-rank run is `compute`.)
     single = whole_video["c1"]
-    line = _bench(["--gpus", str(world), "--backend", "gloo", "--one-gpu", "--config", "c1", "--halo", halo, "--graph", graph, *SMALL])
-    assert line["n_gpus"] == world and line["rccl_ranks"] == world and line["collective_backend"] == "gloo" and line["config"]["ranks_share_one_gpu"] is True
+    line = _bench(["--gpus", str(world), "--backend", backend, "--one-gpu", "--config", "c1", "--halo", halo, "--graph", graph, *SMALL])
+    assert line["n_gpus"] == world and line["rccl_ranks"] == world and line["collective_backend"] == backend and line["config"]["ranks_share_one_gpu"] is True
     assert len(line["frame_split"]) == world and line["config"]["frames_per_gpu"] < 9 and line["scaling"] == "strong"
     assert str(line["config"]["halo_exchange"]).startswith({"oneshot": "one shot", "early": "early", "ghost": "ghost"}[halo])
-    if graph == "compute":
+    if graph != "off":
         assert "replayed as one hipGraph" in line["config"]["workload"]  # (the capture succeeded on every rank: no fall-back to the eager step)
     assert abs(line["config"]["loss"] - single["config"]["loss"]) <= 2e-5 * abs(single["config"]["loss"]), (line["config"]["loss"], single["config"]["loss"])
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_flow_and_tracking_between_real_ranks_on_the_gpu(whole_video, world):
+def test_flow_and_tracking_between_real_ranks_on_the_gpu(whole_video, world, backend):
     """... with the tracking loss: windows straddle the shard borders — the local pose chains are all-gathered, [sum, count] and the pose gradients all-reduced."""
     single = whole_video["c2"]
-    line = _bench(["--gpus", str(world), "--backend", "gloo", "--one-gpu", "--config", "c2", *SMALL])
+    line = _bench(["--gpus", str(world), "--backend", backend, "--one-gpu", "--config", "c2", *SMALL])
     assert line["n_gpus"] == world and line["rccl_ranks"] == world and "tracking loss" in line["config"]["workload"]
     assert abs(line["config"]["loss"] - single["config"]["loss"]) <= 2e-5 * abs(single["config"]["loss"]), (line["config"]["loss"], single["config"]["loss"])
 
 
 @pytest.mark.gpu
-def test_adam_steps_between_real_ranks_on_the_gpu(whole_video):
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_adam_steps_between_real_ranks_on_the_gpu(whole_video, backend):
     """... with the optimiser in the loop (FusedAdam): the shared frames' gradient is complete only after the halo exchange, the focal length's only after the
     all-reduce; the same number of steps (one-shot halo: no extra set-up step) ends on the loss the unsharded run ends on."""
     single = _bench(["--config", "c1", "--optimizer", "fused", *SMALL])
-    line = _bench(["--gpus", "2", "--backend", "gloo", "--one-gpu", "--config", "c1", "--optimizer", "fused", "--halo", "oneshot", "--graph", "off", *SMALL])
+    line = _bench(["--gpus", "2", "--backend", backend, "--one-gpu", "--config", "c1", "--optimizer", "fused", "--halo", "oneshot", "--graph", "off", *SMALL])
     assert line["n_gpus"] == 2 and "Adam step" in line["config"]["workload"]
     assert abs(line["config"]["loss"] - single["config"]["loss"]) <= 5e-5 * abs(single["config"]["loss"]), (line["config"]["loss"], single["config"]["loss"])

@@ -51,12 +51,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, f, h, w, points, out_path, with_tracks=False, softmin=False, device="cpu"):
+def _worker(rank, world, port, f, h, w, points, out_path, with_tracks=False, softmin=False, device="cpu", backend="gloo"):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":  # RCCL between ranks that share ONE GPU: a host of its own per rank, the socket transport on loopback (tools/probes/rccl_one_gpu_probe.py)
+        import datetime
+
+        os.environ.update(NCCL_HOSTID=f"flowmap-amd-test-rank-{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(torch.device(device))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device), timeout=datetime.timedelta(minutes=3))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     import flowmap_amd
     from flowmap_amd import Batch, Flows, _lib
@@ -639,11 +647,13 @@ def test_sync_with_gradients_kept_across_steps(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
 @pytest.mark.parametrize("world,with_tracks", [(2, False), (3, False), (2, True), (3, True), (4, True)])
-def test_real_ranks_on_the_gpu_match_the_unsharded_oracle(tmp_path, world, with_tracks):
-    """FrameShard between REAL ranks running this package's kernels (cuda:0 shared by the ranks; gloo moves GPU tensors, point to point
-    included): loss, dL/dfocal, every rank's slice of dL/ddepth INCLUDING the halo frames summed across the border, dL/dweights — against the
-    unsharded fp64 oracle, gates as on the host double.  RCCL refuses two ranks on one device: its transport is what this leaves untested."""
+def test_real_ranks_on_the_gpu_match_the_unsharded_oracle(tmp_path, world, with_tracks, backend):
+    """FrameShard between REAL ranks running this package's kernels on cuda:0, which they share — over RCCL (every rank a host of its own: the socket
+    transport on loopback, RCCL's own point-to-point / collective code and stream semantics) and over gloo (GPU tensors staged through the host): loss,
+    dL/dfocal, every rank's slice of dL/ddepth INCLUDING the halo frames summed across the border, dL/dweights — against the unsharded fp64 oracle, gates
+    as on the host double.  What this leaves untested is xGMI."""
     sys.path.insert(0, str(ROOT / "tests"))
     from conftest import assert_close
     from helpers import run_oracle
@@ -651,7 +661,7 @@ def test_real_ranks_on_the_gpu_match_the_unsharded_oracle(tmp_path, world, with_
 
     f, h, w, points = 9, 24, 32, 60
     out = str(tmp_path / "shard")
-    mp.spawn(_worker, args=(world, _free_port(), f, h, w, points, out, with_tracks, False, "cuda:0"), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), f, h, w, points, out, with_tracks, False, "cuda:0", backend), nprocs=world, join=True)
     depth, wlogit, flows = orc.synth_iid(f, h, w, seed=9)
     otracks = orc.synth_tracks(f, h, w, seed=9, interval=2, radius=3, grid=5) if with_tracks else None
     ref = run_oracle(depth, wlogit, 0.85, flows, (h, w), points, otracks, dtype=torch.float64)

@@ -1,7 +1,8 @@
 #!/bin/bash
-# The driver's N-rank command at the metric's size on a ONE-GPU box: the ranks share cuda:0 and meet over gloo (RCCL refuses two ranks on one device;
-# gloo takes GPU tensors — tools/probes/gloo_gpu_probe.py).  FUNCTIONAL record: every rank runs this package's kernels on its shard of the 150-frame video, the halo
-# travels point to point, forward + backward replay as hipGraphs; the loss must be the whole video's.  Timing is meaningless (N processes time-slice one GPU).
+# The driver's N-rank command at the metric's size on a ONE-GPU box, over RCCL: the ranks share cuda:0, every rank declares a host of its own (NCCL_HOSTID) and they meet
+# over RCCL's socket transport on the loopback interface (tools/probes/rccl_one_gpu_probe.py; RCCL refuses two ranks of one host on one device).  FUNCTIONAL record: every
+# rank runs this package's kernels on its shard of the 150-frame video, the halo travels point to point through RCCL, forward + backward replay as hipGraphs; the loss must
+# be the whole video's.  Timing is meaningless (N processes time-slice one GPU, the transport is sockets).  One line over gloo for comparison.
 #   gpurun -- 'bash tools/gpu_multirank_one_gpu.sh'
 cd "${GRAFT_REPO_ROOT:-.}"
 out=gpurun_out/r06_multirank; mkdir -p $out
@@ -21,12 +22,13 @@ except Exception as exc:
 PY
 }
 run n1 "--config c1"
-for n in 2 4 8; do run n${n}_default "--gpus $n --backend gloo --one-gpu --config c1"; done   # the driver's command shape: ghost halo, compute graphs
-run n8_early_graphs "--gpus 8 --backend gloo --one-gpu --config c1 --halo early"
-run n4_oneshot_eager "--gpus 4 --backend gloo --one-gpu --config c1 --halo oneshot --graph off"
+for n in 2 4 8; do run n${n}_default "--gpus $n --one-gpu --config c1"; done   # the driver's command shape: ghost halo, compute graphs
+run n8_early_graphs "--gpus 8 --one-gpu --config c1 --halo early"
+run n4_oneshot_eager "--gpus 4 --one-gpu --config c1 --halo oneshot --graph off"
+run n8_default_gloo "--gpus 8 --backend gloo --one-gpu --config c1"
 run n1_c2 "--config c2"
-run n4_c2_default "--gpus 4 --backend gloo --one-gpu --config c2"
-run n8_c2_early "--gpus 8 --backend gloo --one-gpu --config c2 --halo early"
+run n4_c2_default "--gpus 4 --one-gpu --config c2"
+run n8_c2_early "--gpus 8 --one-gpu --config c2 --halo early"
 # BASELINE configs[3]: 65 frames @ 1080x1920 frame-sharded over 4 ranks (pairs 0-15 | 16-31 | 32-47 | 48-63)
 run n1_c3 "--config c3"
-run n4_c3_default "--gpus 4 --backend gloo --one-gpu --config c3"
+run n4_c3_default "--gpus 4 --one-gpu --config c3"
