@@ -1,7 +1,7 @@
 """Frame-pair sharding over RCCL on the GPUs of one node: flow + tracking losses with the video split over
 ``torch.cuda.device_count()`` ranks (one process per GPU, backend "nccl" = RCCL over xGMI) against the unsharded
-fp64 oracle — the multi-GPU twin of tests/test_sharding_gloo.py.  Skips itself on a box with fewer than two GPUs
-(the 1-GPU gpurun boxes); the first multi-GPU lease validates the RCCL path.  The very same worker also runs over gloo on
+fp64 oracle — the multi-GPU twin of tests/test_sharding_gloo.py.  On a box with fewer than two GPUs (the 1-GPU gpurun boxes)
+three RCCL ranks share the one device (round 6: a host id per rank, RCCL's socket transport); the first multi-GPU lease adds xGMI.  The very same worker also runs over gloo on
 the host test double (CPU, two ranks) so that the test's own logic is exercised before that day."""
 
 import os
@@ -16,15 +16,20 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _worker(rank, world, port, f, h, w, points, out_path, on_gpu=True, one_rank_extras=False):
+def _worker(rank, world, port, f, h, w, points, out_path, on_gpu=True, one_rank_extras=False, one_gpu=False):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
     if on_gpu:
-        torch.cuda.set_device(rank)
-        dev = torch.device("cuda", rank)
+        index = 0 if one_gpu else rank
+        if one_gpu and world > 1:
+            # RCCL refuses two ranks of one HOST on one device: every rank declares a host of its own and the ranks meet over RCCL's socket transport on
+            # loopback (tools/probes/rccl_one_gpu_probe.py) — RCCL's own point-to-point / collective code and stream semantics, everything but xGMI
+            os.environ.update(NCCL_HOSTID=f"flowmap-amd-test-rank-{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1")
+        torch.cuda.set_device(index)
+        dev = torch.device("cuda", index)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:  # the same code over gloo on the host test double
         from flowmap_amd import _lib
@@ -140,7 +145,7 @@ def _one_rank_extras(dist, dev, sc, wl, f, h, w, points, on_gpu):
     return out
 
 
-def _run_and_compare(tmp_path, world, on_gpu):
+def _run_and_compare(tmp_path, world, on_gpu, one_gpu=False):
     sys.path.insert(0, str(ROOT / "tests"))
     from conftest import assert_close
     from helpers import run_oracle
@@ -151,7 +156,7 @@ def _run_and_compare(tmp_path, world, on_gpu):
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
     out = str(tmp_path / "rccl")
-    mp.spawn(_worker, args=(world, port, f, h, w, points, out, on_gpu, world == 1), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, f, h, w, points, out, on_gpu, world == 1, one_gpu), nprocs=world, join=True)
     sc = orc.synth_scene(f, h, w, seed=5)
     wl = 0.01 * torch.randn((f - 1, h, w), generator=torch.Generator().manual_seed(5))
     tracks = orc.synth_tracks(f, h, w, scene=sc, seed=5, interval=3, radius=5, grid=8)
@@ -183,7 +188,9 @@ def _run_and_compare(tmp_path, world, on_gpu):
 def test_rccl_sharded_step_matches_unsharded_oracle(tmp_path):
     world = torch.cuda.device_count()
     if world < 2:
-        pytest.skip(f"needs >= 2 GPUs for an RCCL run (this box has {world})")
+        # round 6: a one-GPU box no longer skips — three RCCL ranks share the device (a host id each, the socket transport)
+        _run_and_compare(tmp_path, 3, on_gpu=True, one_gpu=True)
+        return
     _run_and_compare(tmp_path, min(world, 8), on_gpu=True)
 
 
