@@ -647,8 +647,8 @@ def test_sync_with_gradients_kept_across_steps(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("backend", ["nccl", "gloo"])
-@pytest.mark.parametrize("world,with_tracks", [(2, False), (3, False), (2, True), (3, True), (4, True)])
+@pytest.mark.parametrize("backend,world,with_tracks", [("nccl", 2, False), ("nccl", 3, False), ("nccl", 2, True), ("nccl", 3, True), ("nccl", 4, True), ("gloo", 2, False),
+                                                       ("gloo", 3, True)])
 def test_real_ranks_on_the_gpu_match_the_unsharded_oracle(tmp_path, world, with_tracks, backend):
     """FrameShard between REAL ranks running this package's kernels on cuda:0, which they share — over RCCL (every rank a host of its own: the socket
     transport on loopback, RCCL's own point-to-point / collective code and stream semantics) and over gloo (GPU tensors staged through the host): loss,
