@@ -3,8 +3,11 @@
 
     python bench.py                                   # N = 1: config c1, 20 warm-up + 100 timed steps
     python bench.py --config c2|c3|c4 [--scaling strong|weak] [--inputs scene|iid]
+    python bench.py --gpus N --steps K --warmup W      # N > 1: launches its own N ranks (one per GPU, RCCL), equivalent to
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --one-gpu [--backend gloo]   # FUNCTIONAL N-rank run on a one-GPU box: the ranks share cuda:0 and meet over RCCL's socket
+                                                           # transport (a host id per rank) or gloo; tests/test_gpu_multirank.py; timing meaningless
 
 One "step" = what ModelWrapperOverfit.training_step + backward do per optimisation iteration
 (model_wrapper_overfit.py:51-62): explicit-depth backbone -> intrinsics -> unproject ->
