@@ -23,6 +23,7 @@ def _worker(rank, world, port, f, h, w, points, out_path, on_gpu=True, one_rank_
     import torch.distributed as dist
 
     if on_gpu:
+        torch.set_num_threads(4)  # (the scene is synthesised on the host by every rank: on a 256-thread box the ranks' default thread pools fight each other — 100 s instead of 10)
         index = 0 if one_gpu else rank
         if one_gpu and world > 1:
             # RCCL refuses two ranks of one HOST on one device: every rank declares a host of its own and the ranks meet over RCCL's socket transport on
