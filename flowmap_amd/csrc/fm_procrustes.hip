@@ -593,14 +593,31 @@ __global__ void __launch_bounds__(256) procrustes_scatter_repeat_kernel(ProcPara
   const int idx = active ? (p.indices ? (int)p.indices[j] : (int)j) : 0;
 
   float s_gw = 0.f, s_later = 0.f, s_tap[4] = {0.f, 0.f, 0.f, 0.f};
-  Taps taps = {};
-  for (int r = gid * kRepeatGroup; r < rep && r < (gid + 1) * kRepeatGroup; ++r) {
+  // Round 6: what a correspondence READS — its flow, weight, later depth, the four taps and their depths — is the same for every candidate (the
+  // candidates differ in K⁻¹ and the pose only): the dependent gather chain index -> flow -> taps runs ONCE per thread instead of once per
+  // candidate, and the candidates' arithmetic runs as one unrolled stretch without a barrier in it (their per-pair constants — 23 doubles and
+  // two 3x3 matrices each, block-uniform — are then loaded ahead of use); the block reductions of the per-candidate intrinsics sums follow.
+  // 50.4 -> 41.8 us per launch at 60 candidates x 8192 points (profiles/r06_c1_softmin_rocprofv3_summary.csv).  Same arithmetic per candidate.
+  const CorrSrc src0 = pair_source<SRC_DEPTH>(p, (size_t)(bd * rep) * (p.frames - 1) + i, bd * rep, i);
+  CorrStage1 st1 = {};
+  CorrStage2 st2 = {};
+  if (active) {
+    st1 = corr_stage1(src0, idx);
+    st2 = corr_stage2(src0, st1);
+  }
+  const Taps taps = st2.taps;
+  float accs[kRepeatGroup][18];  // per candidate of the group: [0..8] dKinv later frame, [9..17] dKinv earlier frame
+#pragma unroll
+  for (int t = 0; t < kRepeatGroup; ++t) {
+    const int r = gid * kRepeatGroup + t;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) accs[t][k] = 0.f;
+    if (r >= rep) continue;  // (block-uniform)
     const int b = bd * rep + r;
     const size_t pair = (size_t)b * (p.frames - 1) + i;  // (kinv, pose) pair
     Mat3 kinv_e, kinv_l;
     load_mat3(p.kinv + ((size_t)b * p.frames + i) * 9, kinv_e);
     load_mat3(p.kinv + ((size_t)b * p.frames + i + 1) * 9, kinv_l);
-    const CorrSrc src = pair_source<SRC_DEPTH>(p, pair, b, i);
     const double* pg = p.pair_grad + pair * kPairGradStride;
     const double* ax = aux + pair * kAuxStride;
     PairGrad g;
@@ -613,49 +630,50 @@ __global__ void __launch_bounds__(256) procrustes_scatter_repeat_kernel(ProcPara
     }
     g.dbar = (float)pg[15];
     g.inv_wsum = (float)pg[16];
-    float acc[18];  // [0..8] dKinv later frame, [9..17] dKinv earlier frame
+    if (!active) continue;
+    float* acc = accs[t];
+    const Corr c = corr_assemble(src0, kinv_e, kinv_l, st1, st2);
+    float gq[3], gp[3], gw;
+    corr_backward(c, g, gq, gp, gw);
+    if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
+    s_gw += gw;
+    s_later += gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2];
+    const int row = idx / p.width, col = idx - row * p.width;
+    const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
+    const float zh[3] = {c.z_p * u, c.z_p * v, c.z_p};
 #pragma unroll
-    for (int k = 0; k < 18; ++k) acc[k] = 0.f;
-    if (active) {
-      const Corr c = corr_load(src, kinv_e, kinv_l, idx);
-      taps = c.taps;
-      float gq[3], gp[3], gw;
-      corr_backward(c, g, gq, gp, gw);
-      if (p.weight_sens != 0.f) gw *= p.weight_sens * c.w * (1.f - c.w);  // d sigmoid(s·x)/dx
-      s_gw += gw;
-      s_later += gp[0] * c.ray_p[0] + gp[1] * c.ray_p[1] + gp[2] * c.ray_p[2];
-      const int row = idx / p.width, col = idx - row * p.width;
-      const float u = pixel_center(col, p.width), v = pixel_center(row, p.height);
-      const float zh[3] = {c.z_p * u, c.z_p * v, c.z_p};
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) acc[a * 3 + d] += gp[a] * zh[d];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!c.taps.in[k]) continue;
+      const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
+      const float ut = pixel_center(tc, p.width), vt = pixel_center(tr, p.height);
+      const float z = st2.z[k];
+      float ray[3];
+      ray_dir(kinv_e, ut, vt, ray);
+      const float wt = c.taps.w[k];
+      s_tap[k] += wt * (gq[0] * ray[0] + gq[1] * ray[1] + gq[2] * ray[2]);
+      const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int d = 0; d < 3; ++d) acc[a * 3 + d] += gp[a] * zh[d];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (!c.taps.in[k]) continue;
-        const int tc = tap_col(c.taps, k), tr = tap_row(c.taps, k);
-        const float ut = pixel_center(tc, p.width), vt = pixel_center(tr, p.height);
-        const float z = src.depth_e[tr * p.width + tc];
-        float ray[3];
-        ray_dir(kinv_e, ut, vt, ray);
-        const float wt = c.taps.w[k];
-        s_tap[k] += wt * (gq[0] * ray[0] + gq[1] * ray[1] + gq[2] * ray[2]);
-        const float zt[3] = {z * ut * wt, z * vt * wt, z * wt};
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int d = 0; d < 3; ++d) acc[9 + a * 3 + d] += gq[a] * zt[d];
-      }
+        for (int d = 0; d < 3; ++d) acc[9 + a * 3 + d] += gq[a] * zt[d];
     }
-    if (p.kinv_acc) {
+  }
+  if (p.kinv_acc) {
+#pragma unroll
+    for (int t = 0; t < kRepeatGroup; ++t) {
+      const int r = gid * kRepeatGroup + t;
+      if (r >= rep) break;  // (block-uniform)
       float ordered[18];
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        ordered[k] = acc[9 + k];
-        ordered[9 + k] = acc[k];
+        ordered[k] = accs[t][9 + k];
+        ordered[9 + k] = accs[t][k];
       }
-      block_accumulate<18>(ordered, red, p.kinv_acc + ((size_t)b * p.frames + i) * 9);
+      block_accumulate<18>(ordered, red, p.kinv_acc + ((size_t)(bd * rep + r) * p.frames + i) * 9);
     }
   }
   if (!active) return;
