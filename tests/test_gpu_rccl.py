@@ -202,8 +202,8 @@ def test_every_collective_call_site_runs_on_a_one_rank_rccl_communicator(tmp_pat
     suite.  The same worker with world = 1 and the collectives forced on (FrameShard(force_collectives=True)): the set-up all-reduce of
     Σmask, the packed all-reduce of [loss, shared gradients], the tracking loss's pose all-gather + [Σρ, count] all-reduce + pose-gradient
     all-reduce — each on a real RCCL communicator — against the unsharded fp64 oracle; then an interior rank's share of three on the same
-    communicator with the one-shot, early and ghost halo forms and the ghost form replayed as hipGraphs.  What still needs a second GPU is
-    the point-to-point exchange itself (the share has no peer) — that is the test above."""
+    communicator with the one-shot, early and ghost halo forms and the ghost form replayed as hipGraphs.  The point-to-point exchange itself
+    (the share has no peer) is the test above and tests/test_gpu_multirank.py: real RCCL ranks, sharing the one GPU since round 6."""
     _run_and_compare(tmp_path, 1, on_gpu=True)
 
 
