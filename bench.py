@@ -932,7 +932,7 @@ def main():
     kernel_ms = sum(flow_ms) / max(len(flow_ms), 1)
     traffic, traffic_src = None, None
     taps_on = _ops.counters["flow_tap_passes"] > 0
-    for name in ("r05_flow_kernel_traffic.json", "r04_flow_kernel_traffic.json", "r03_flow_kernel_traffic.json", "r02_flow_kernel_traffic.json", "r01_flow_kernel_traffic.json"):  # HBM bytes per launch from the PMC passes (same workload only)
+    for name in ("r06_flow_kernel_traffic.json", "r05_flow_kernel_traffic.json", "r04_flow_kernel_traffic.json", "r03_flow_kernel_traffic.json", "r02_flow_kernel_traffic.json", "r01_flow_kernel_traffic.json"):  # HBM bytes per launch from the PMC passes (same workload only)
         try:
             rec = json.loads((ROOT / "profiles" / name).read_text())
             if {k: rec["workload"][k] for k in ("frames", "height", "width")} == {"frames": f, "height": h, "width": w}:
