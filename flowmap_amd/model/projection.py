@@ -306,6 +306,13 @@ class LazyExtrinsics:
         out = self.materialize().detach().cpu().numpy()
         return out if dtype is None else out.astype(dtype)
 
+    # torch.save / pickle / copy.deepcopy: the VALUE travels — the evaluated chain as a plain, detached tensor
+    def __reduce_ex__(self, protocol):
+        return self.materialize().detach().__reduce_ex__(protocol)
+
+    def __deepcopy__(self, memo):
+        return self.materialize().detach().clone()
+
     def __getattr__(self, name):
         if name.startswith("_"):
             raise AttributeError(name)

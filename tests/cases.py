@@ -1163,6 +1163,21 @@ def case_lazy_extrinsics(dev):
         out = model(batch, flows, 0)
         (loss_of(out) + out.extrinsics[0, :, :3, 3].square().sum()).backward()
         assert torch.equal(out.extrinsics.materialize().detach(), want_ext) and torch.equal(torch.linalg.inv(out.extrinsics).detach(), torch.linalg.inv(want_ext))
+        # the value behaves like the tensor where users touch it: torch.as_tensor, numpy, .to() / .cpu(), torch.save / load, deepcopy, iteration
+        import copy
+        import io
+
+        import numpy as np
+
+        assert torch.equal(torch.as_tensor(out.extrinsics), want_ext) and np.array_equal(np.asarray(out.extrinsics), want_ext.cpu().numpy())
+        assert torch.equal(out.extrinsics.cpu(), want_ext.cpu()) and torch.equal(out.extrinsics.to(want_ext.device).detach(), want_ext) and len(out.extrinsics) == 1
+        buffer = io.BytesIO()
+        torch.save(out.extrinsics, buffer)
+        buffer.seek(0)
+        loaded = torch.load(buffer, weights_only=False)
+        assert type(loaded) is torch.Tensor and torch.equal(loaded.to(want_ext.device), want_ext)
+        copied = copy.deepcopy(out.extrinsics)
+        assert type(copied) is torch.Tensor and torch.equal(copied, want_ext) and torch.equal(next(iter(out.extrinsics)).detach(), want_ext[0])
         for a, b in zip(_grads(model), want_chain):
             assert torch.equal(a, b)
         assert flows.backward.__dict__.get("_fm_extrinsics_wanted") is True
